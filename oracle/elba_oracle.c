@@ -1,0 +1,534 @@
+/*
+ * oracle/elba_oracle.c — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A plain-C restatement of ELBA's overlap-detection hot path,
+ * used as the checker by tests/, by __graft_entry__.smoke() and as the `cpu_baseline` leg of
+ * bench.py.  The product (elba_amd/csrc, libelba_amd.so) never includes, links or calls this.
+ *
+ * All file:line citations are into /root/reference (PASSIONLab/ELBA @ v2).
+ *
+ * PARITY PINNING (what this oracle has been checked against; see tests/test_oracle_*.py):
+ *   a1  2-bit encode ............ PINNED: reference DnaSeq::compress compiled from source (oracle/_ref) + committed vectors
+ *   a2  pack / roll / twin / rep  PINNED: reference Kmer<1> compiled from source (oracle/_ref) + committed vectors
+ *   a3  murmur3 x64_128 seed 313  PINNED: reference HashFuncs.cpp compiled from source (oracle/_ref) + committed vectors
+ *   a4  owner ................... restated from src/KmerOps.cpp:352-359 (KmerOps.cpp needs CombBLAS: unbuildable here)
+ *   a7/a8 reliable k-mers ....... PINNED two ways: (i) a replay of KmerOps.cpp's two-pass control flow on the reference's own
+ *                                 Bloom + Kmer code (oracle/ref_shim.cpp: ref_replay_count); (ii) the counts the survey measured
+ *                                 from the reference's KmerOps.cpp on its bundled reads.fa (I, N, Z, dups)
+ *   a12 SharedSeeds semiring .... restated from include/SharedSeeds.hpp:36-58 (header needs CombBLAS types: unbuildable here);
+ *                                 fold shapes checked against SURVEY.md App. B ("left fold p1..p4 -> {(1,1),(4,4),4}")
+ *   a13 B = A*A^T + prune ....... pattern, numshared, P, Y_raw, Y, diagonal, strict-upper, max numshared PINNED by SURVEY.md
+ *                                 App. B's figures for reads.fa at (17,2,8) and (31,15,35).
+ *                                 SEED VALUES: **parity unpinned** — the fold order lives in CombBLAS (un-vendored, un-pinned,
+ *                                 absent; github.com/PASSIONLab/CombBLAS, plain clone per usage.txt:5-6).  The canonical rule of
+ *                                 SURVEY.md §8c-2 is implemented: k-mer ids = rank of the packed canonical k-mer value; seeds[0] =
+ *                                 product with minimal (kid,posQ,posT), seeds[1] = maximal — i.e. what an ascending-k left fold
+ *                                 of Semiring::add produces.
+ *
+ * Scope of this restatement: k <= 32 (NLONGS == 1, include/Kmer.hpp:95-97), LOWER >= 2.
+ */
+#define _GNU_SOURCE
+#include <stdint.h>
+#include <stddef.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * a1. 2-bit encoding.  include/DnaSeq.hpp:136-154 (codetab), src/DnaSeq.cpp:7-29 (compress).
+ * ---------------------------------------------------------------------------------------------- */
+static uint8_t orc_charcode(unsigned char c)
+{
+    switch (c) {
+    case 'A': case 'a': case 'N': case 'n': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return 4;            /* "X": the reference ORs the overflowing code in (UB by its own comment) */
+    }
+}
+
+size_t orc_bytes_needed(size_t len) { return (len + 3) / 4; }   /* include/DnaSeq.hpp:131 */
+
+/* Writes (len+3)/4 bytes; first base in bits 7-6; unused low bits of the last byte are zero. */
+size_t orc_encode_read(const char *s, size_t len, uint8_t *mem)
+{
+    size_t nbytes = orc_bytes_needed(len);
+    int remain = (int)(4 * nbytes - len);
+    for (size_t b = 0; b < nbytes; ++b) {
+        uint8_t byte = 0;
+        int left = (b != nbytes - 1) ? 4 : 4 - remain;
+        for (int i = 0; i < left; ++i) {
+            uint8_t code = orc_charcode((unsigned char)s[4 * b + i]);
+            uint8_t shift = (uint8_t)(code << (6 - 2 * i));      /* truncated to 8 bits like the reference's uint8_t */
+            byte |= shift;
+        }
+        mem[b] = byte;
+    }
+    return nbytes;
+}
+
+static inline int orc_base_at(const uint8_t *mem, size_t i)     /* src/DnaSeq.cpp:48-54 */
+{
+    return (mem[i / 4] >> (6 - 2 * (i % 4))) & 3;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a2. Packed k-mers, k <= 32.  src/Kmer.cpp:67-87 (set_kmer), :149-165 (GetExtension),
+ *     :167-198 (GetTwin), :200-205 (GetRep), :118-131 (operator<).
+ *     Base i sits at bits 2*(31-i); the low 64-2k bits are zero.
+ * ---------------------------------------------------------------------------------------------- */
+uint64_t orc_kmer_from_ascii(const char *s, int k)
+{
+    uint64_t w = 0;
+    for (int i = 0; i < k; ++i) w |= (uint64_t)orc_charcode((unsigned char)s[i]) << (2 * (31 - i));
+    return w;
+}
+
+uint64_t orc_kmer_extend(uint64_t w, int code, int k)           /* roll one base in */
+{
+    return (w << 2) | ((uint64_t)code << (2 * (32 - (k % 32))));
+}
+
+uint64_t orc_kmer_twin(uint64_t w, int k)
+{
+    /* reverse the 32 two-bit groups and complement them (what the 256-entry tetramer table + byte reversal do) */
+    uint64_t x = ~w;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);
+    /* x now holds the reverse complement of all 32 groups; the k real bases are the LOW 2k bits' mirror:
+       the (32-k) padding groups (zero -> complemented to 3 -> reversed) occupy the TOP; shift them out. */
+    int shift = (k % 32) ? 2 * (32 - (k % 32)) : 0;
+    return x << shift;
+}
+
+uint64_t orc_kmer_rep(uint64_t w, int k)
+{
+    uint64_t t = orc_kmer_twin(w, k);
+    return t < w ? t : w;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a3. MurmurHash3 x64_128, seed 313, first word.  src/HashFuncs.cpp:40-117, :231-236; src/Kmer.cpp:207-213.
+ *     Key = the 8 bytes of the packed k-mer as stored (little-endian u64).
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static inline uint64_t fmix64(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33; return k;
+}
+
+void orc_murmur3_x64_128(const void *key, uint32_t len, uint32_t seed, uint64_t out[2])
+{
+    const uint8_t *data = (const uint8_t *)key;
+    const uint32_t nblocks = len / 16;
+    uint64_t h1 = seed, h2 = seed;
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    for (uint32_t i = 0; i < nblocks; ++i) {
+        uint64_t k1, k2;
+        memcpy(&k1, data + 16 * i, 8); memcpy(&k2, data + 16 * i + 8, 8);
+        k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    const uint8_t *tail = data + 16 * nblocks;
+    uint64_t k1 = 0, k2 = 0;
+    uint32_t rem = len & 15;
+    for (uint32_t b = rem; b > 8; --b) k2 ^= (uint64_t)tail[b - 1] << (8 * (b - 9));
+    if (rem > 8) { k2 *= c2; k2 = rotl64(k2, 33); k2 *= c1; h2 ^= k2; }
+    for (uint32_t b = (rem > 8 ? 8 : rem); b > 0; --b) k1 ^= (uint64_t)tail[b - 1] << (8 * (b - 1));
+    if (rem > 0) { k1 *= c1; k1 = rotl64(k1, 31); k1 *= c2; h1 ^= k1; }
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    h1 += h2; h2 += h1;
+    out[0] = h1; out[1] = h2;
+}
+
+uint64_t orc_kmer_hash(uint64_t w)
+{
+    uint64_t o[2];
+    orc_murmur3_x64_128(&w, 8, 313, o);
+    return o[0];
+}
+
+/* a4. src/KmerOps.cpp:352-359. */
+int orc_kmer_owner(uint64_t hash, int nprocs)
+{
+    double range = (double)hash * (double)nprocs;
+    size_t owner = (size_t)(range / (double)UINT64_MAX);
+    return (int)owner;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * a12. SharedSeeds + Semiring.  include/SharedSeeds.hpp:8-58.  Explicit field order (never the
+ *      std::tuple memory layout).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { uint32_t q0, t0, q1, t1; int32_t numshared; } orc_seed_t;
+
+orc_seed_t orc_sr_multiply(uint32_t a, uint32_t b)               /* :48-52 */
+{
+    orc_seed_t r = { a, b, 0, 0, 1 };
+    return r;
+}
+orc_seed_t orc_sr_add(orc_seed_t l, orc_seed_t r)                /* :41-46 */
+{
+    orc_seed_t o = { l.q0, l.t0, r.q0, r.t0, l.numshared + r.numshared };
+    return o;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * The oracle context: reads -> reliable k-mers -> A (CSC + CSR) -> B.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int k, lower, upper;
+    int64_t M;                 /* reads (rows of A, rows/cols of B) */
+    int64_t first_read_id;
+    /* k-mer stage */
+    int64_t I;                 /* k-mer instances */
+    int64_t N;                 /* reliable k-mers */
+    int64_t Z;                 /* nnz(A) */
+    int64_t ndistinct;         /* distinct canonical k-mers */
+    uint64_t *kmers;           /* [N] packed canonical k-mer values, ascending == k-mer id order */
+    int64_t *colptr;           /* [N+1] */
+    uint32_t *csc_read;        /* [Z] local read index, within column sorted by (read,pos) */
+    uint32_t *csc_pos;         /* [Z] */
+    int64_t *rowptr;           /* [M+1] */
+    uint32_t *csr_kid;         /* [Z] within row sorted by (kid,pos) */
+    uint32_t *csr_pos;         /* [Z] */
+    int64_t *hist;             /* [upper+2] histogram of column counts (src/main.cpp:449-485) */
+    /* B */
+    int64_t P, Yraw, Y, ndiag, nupper, maxshared;
+    int64_t *b_rowptr;         /* [M+1] */
+    uint32_t *b_col;           /* [Y] ascending within row */
+    orc_seed_t *b_val;         /* [Y] */
+} orc_ctx;
+
+orc_ctx *orc_create(int k, int lower, int upper)
+{
+    if (k < 3 || k > 32 || !(k & 1) || lower < 1 || lower > upper || upper > 65535) return NULL;  /* include/compiletime.h:10,21 */
+    orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
+    c->k = k; c->lower = lower; c->upper = upper;
+    return c;
+}
+
+static void orc_free_A(orc_ctx *c)
+{
+    free(c->kmers); free(c->colptr); free(c->csc_read); free(c->csc_pos);
+    free(c->rowptr); free(c->csr_kid); free(c->csr_pos); free(c->hist);
+    c->kmers = NULL; c->colptr = NULL; c->csc_read = c->csc_pos = NULL; c->rowptr = NULL; c->csr_kid = c->csr_pos = NULL; c->hist = NULL;
+}
+static void orc_free_B(orc_ctx *c)
+{
+    free(c->b_rowptr); free(c->b_col); free(c->b_val);
+    c->b_rowptr = NULL; c->b_col = NULL; c->b_val = NULL;
+}
+void orc_destroy(orc_ctx *c) { if (!c) return; orc_free_A(c); orc_free_B(c); free(c); }
+
+/* Enumerate the canonical k-mers of one packed read (a2; include/KmerOps.hpp:105-137 ForeachKmer:
+ * reads shorter than k contribute nothing; position = forward start index). Returns count. */
+int64_t orc_read_kmers(const uint8_t *mem, uint32_t len, int k, uint64_t *out)
+{
+    if ((int64_t)len < k) return 0;
+    uint64_t w = 0;
+    for (int i = 0; i < k; ++i) w |= (uint64_t)orc_base_at(mem, (size_t)i) << (2 * (31 - i));
+    int64_t n = (int64_t)len - k + 1;
+    out[0] = orc_kmer_rep(w, k);
+    for (int64_t i = 1; i < n; ++i) {
+        w = orc_kmer_extend(w, orc_base_at(mem, (size_t)(i + k - 1)), k);
+        out[i] = orc_kmer_rep(w, k);
+    }
+    return n;
+}
+
+typedef struct { uint64_t kmer; uint32_t read, pos; } orc_inst_t;
+
+/* stable LSD radix sort of instances by the right-aligned 2k-bit k-mer value (11-bit digits) */
+static void orc_sort_instances(orc_inst_t *a, orc_inst_t *tmp, int64_t n, int k)
+{
+    const int shift0 = 64 - 2 * k;
+    const int bits = 2 * k;
+    for (int lo = 0; lo < bits; lo += 11) {
+        int64_t cnt[2049];
+        memset(cnt, 0, sizeof(cnt));
+        for (int64_t i = 0; i < n; ++i) cnt[(((a[i].kmer >> shift0) >> lo) & 2047) + 1]++;
+        for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
+        for (int64_t i = 0; i < n; ++i) tmp[cnt[((a[i].kmer >> shift0) >> lo) & 2047]++] = a[i];
+        orc_inst_t *t = a; a = tmp; tmp = t;
+    }
+    /* result is in `a`; the caller passes buffers so that an odd number of passes lands in its tmp — handled by caller */
+}
+static int orc_sort_passes(int k) { return (2 * k + 10) / 11; }
+
+/*
+ * a7 + a8 + a9 + a10 in one call: exact counting of canonical k-mers over all reads, keep those with
+ * LOWER <= count <= UPPER (SURVEY.md App. A.4 — the net effect of src/KmerOps.cpp:158-187,283-318,335-340 for
+ * LOWER >= 2), k-mer ids by ascending packed value, every instance of a reliable k-mer becomes an entry
+ * (read, kid, pos) — duplicates within a read are KEPT (src/KmerOps.cpp:400 SumDuplicates=false).
+ * Builds CSC (the reference's AT, src/main.cpp:272-273) and CSR (the reference's A).
+ */
+int orc_count_and_build(orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off, const uint32_t *lens, int64_t nreads)
+{
+    orc_free_A(c); orc_free_B(c);
+    const int k = c->k;
+    c->M = nreads;
+    int64_t I = 0;
+    for (int64_t r = 0; r < nreads; ++r) if ((int64_t)lens[r] >= k) I += (int64_t)lens[r] - k + 1;
+    c->I = I;
+    orc_inst_t *a = (orc_inst_t *)malloc((size_t)(I > 0 ? I : 1) * sizeof(orc_inst_t));
+    orc_inst_t *b = (orc_inst_t *)malloc((size_t)(I > 0 ? I : 1) * sizeof(orc_inst_t));
+    uint32_t maxlen = 0;
+    for (int64_t r = 0; r < nreads; ++r) if (lens[r] > maxlen) maxlen = lens[r];
+    uint64_t *scratch = (uint64_t *)malloc((size_t)(maxlen + 1) * sizeof(uint64_t));
+    if (!a || !b || !scratch) { free(a); free(b); free(scratch); return -1; }
+    int64_t z = 0;
+    for (int64_t r = 0; r < nreads; ++r) {
+        int64_t n = orc_read_kmers(buf + byte_off[r], lens[r], k, scratch);
+        for (int64_t p = 0; p < n; ++p) { a[z].kmer = scratch[p]; a[z].read = (uint32_t)r; a[z].pos = (uint32_t)p; ++z; }
+    }
+    free(scratch);
+    orc_sort_instances(a, b, I, k);
+    orc_inst_t *s = (orc_sort_passes(k) & 1) ? b : a;      /* sorted by (kmer, read, pos): the sort is stable */
+
+    /* run-length pass 1: count N, Z */
+    int64_t N = 0, Z = 0, nd = 0;
+    c->hist = (int64_t *)calloc((size_t)c->upper + 2, sizeof(int64_t));
+    for (int64_t i = 0; i < I; ) {
+        int64_t j = i + 1;
+        while (j < I && s[j].kmer == s[i].kmer) ++j;
+        int64_t cnt = j - i;
+        ++nd;
+        if (cnt >= c->lower && cnt <= c->upper) { ++N; Z += cnt; c->hist[cnt]++; }
+        i = j;
+    }
+    c->N = N; c->Z = Z; c->ndistinct = nd;
+    c->kmers = (uint64_t *)malloc((size_t)(N + 1) * sizeof(uint64_t));
+    c->colptr = (int64_t *)malloc((size_t)(N + 1) * sizeof(int64_t));
+    c->csc_read = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->csc_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->rowptr = (int64_t *)calloc((size_t)(nreads + 2), sizeof(int64_t));
+    c->csr_kid = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->csr_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    int64_t kid = 0, e = 0;
+    for (int64_t i = 0; i < I; ) {
+        int64_t j = i + 1;
+        while (j < I && s[j].kmer == s[i].kmer) ++j;
+        int64_t cnt = j - i;
+        if (cnt >= c->lower && cnt <= c->upper) {
+            c->kmers[kid] = s[i].kmer;
+            c->colptr[kid] = e;
+            for (int64_t t = i; t < j; ++t) { c->csc_read[e] = s[t].read; c->csc_pos[e] = s[t].pos; c->rowptr[s[t].read + 1]++; ++e; }
+            ++kid;
+        }
+        i = j;
+    }
+    c->colptr[N] = e;
+    free(a); free(b);
+    /* CSR by a stable counting transpose of the CSC stream: rows come out sorted by (kid, pos). */
+    for (int64_t r = 0; r < nreads; ++r) c->rowptr[r + 1] += c->rowptr[r];
+    int64_t *cur = (int64_t *)malloc((size_t)(nreads + 1) * sizeof(int64_t));
+    memcpy(cur, c->rowptr, (size_t)(nreads + 1) * sizeof(int64_t));
+    for (int64_t kk = 0; kk < N; ++kk)
+        for (int64_t t = c->colptr[kk]; t < c->colptr[kk + 1]; ++t) {
+            int64_t d = cur[c->csc_read[t]]++;
+            c->csr_kid[d] = (uint32_t)kk; c->csr_pos[d] = c->csc_pos[t];
+        }
+    free(cur);
+    return 0;
+}
+
+/*
+ * Alternative entry for a13 alone: take A as triples (row, col, val) — what create_seed_matrix's caller holds
+ * (src/KmerOps.cpp:380-400 emits exactly such triples) — and build CSC/CSR with the canonical entry order:
+ * within a column by (row,val), within a row by (col,val).  Duplicates kept.
+ */
+static int orc_cmp_csc(const void *x, const void *y)
+{
+    const int64_t *a = (const int64_t *)x, *b = (const int64_t *)y;   /* (col,row,val) */
+    for (int i = 0; i < 3; ++i) { if (a[i] < b[i]) return -1; if (a[i] > b[i]) return 1; }
+    return 0;
+}
+int orc_set_triples(orc_ctx *c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals)
+{
+    orc_free_A(c); orc_free_B(c);
+    c->M = M; c->N = N; c->Z = Z; c->I = 0; c->ndistinct = 0;
+    int64_t *t = (int64_t *)malloc((size_t)(Z + 1) * 3 * sizeof(int64_t));
+    for (int64_t i = 0; i < Z; ++i) {
+        if (rows[i] < 0 || rows[i] >= M || cols[i] < 0 || cols[i] >= N) { free(t); return -2; }
+        t[3 * i] = cols[i]; t[3 * i + 1] = rows[i]; t[3 * i + 2] = vals[i];
+    }
+    qsort(t, (size_t)Z, 3 * sizeof(int64_t), orc_cmp_csc);
+    c->kmers = NULL;
+    c->colptr = (int64_t *)calloc((size_t)(N + 2), sizeof(int64_t));
+    c->csc_read = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->csc_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->rowptr = (int64_t *)calloc((size_t)(M + 2), sizeof(int64_t));
+    c->csr_kid = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->csr_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    for (int64_t i = 0; i < Z; ++i) {
+        c->colptr[t[3 * i] + 1]++; c->rowptr[t[3 * i + 1] + 1]++;
+        c->csc_read[i] = (uint32_t)t[3 * i + 1]; c->csc_pos[i] = (uint32_t)t[3 * i + 2];
+    }
+    for (int64_t i = 0; i < N; ++i) c->colptr[i + 1] += c->colptr[i];
+    for (int64_t i = 0; i < M; ++i) c->rowptr[i + 1] += c->rowptr[i];
+    int64_t *cur = (int64_t *)malloc((size_t)(M + 1) * sizeof(int64_t));
+    memcpy(cur, c->rowptr, (size_t)(M + 1) * sizeof(int64_t));
+    for (int64_t i = 0; i < Z; ++i) { int64_t d = cur[t[3 * i + 1]]++; c->csr_kid[d] = (uint32_t)t[3 * i]; c->csr_pos[d] = (uint32_t)t[3 * i + 2]; }
+    free(cur); free(t);
+    return 0;
+}
+
+/*
+ * a13: B = A*A^T over SharedSeeds::Semiring, then Prune(numshared <= 1)  (src/SharedSeeds.cpp:4-10).
+ * Row-by-row Gustavson with a dense accumulator; for row i the products are visited in ascending
+ * (kid, posQ, posT) order and combined by a LEFT fold of Semiring::add (include/SharedSeeds.hpp:41-46), so
+ * seeds[0] = first product, seeds[1] = last product, numshared = #products: the canonical rule of SURVEY §8c-2.
+ * Both triangles and the diagonal are computed (CombBLAS computes all of B).  Columns ascending within a row.
+ * nthreads > 1 splits rows over OpenMP threads (each with its own accumulator); results are identical.
+ */
+static int orc_cmp_u32(const void *x, const void *y)
+{
+    uint32_t a = *(const uint32_t *)x, b = *(const uint32_t *)y;
+    return a < b ? -1 : a > b;
+}
+
+int orc_spgemm(orc_ctx *c, int nthreads)
+{
+    orc_free_B(c);
+    const int64_t M = c->M;
+    if (nthreads < 1) nthreads = 1;
+    int64_t *rowcnt = (int64_t *)calloc((size_t)(M + 2), sizeof(int64_t));
+    uint32_t **rcol = (uint32_t **)calloc((size_t)(M + 1), sizeof(uint32_t *));
+    orc_seed_t **rval = (orc_seed_t **)calloc((size_t)(M + 1), sizeof(orc_seed_t *));
+    int64_t P = 0, Yraw = 0, ndiag = 0, nupper = 0, maxshared = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads) reduction(+:P,Yraw,ndiag,nupper) reduction(max:maxshared)
+#endif
+    {
+        orc_seed_t *acc = (orc_seed_t *)calloc((size_t)(M + 1), sizeof(orc_seed_t));
+        uint32_t *touched = (uint32_t *)malloc((size_t)(M + 1) * sizeof(uint32_t));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 16)
+#endif
+        for (int64_t i = 0; i < M; ++i) {
+            int64_t nt = 0;
+            for (int64_t e = c->rowptr[i]; e < c->rowptr[i + 1]; ++e) {
+                uint32_t kid = c->csr_kid[e], q = c->csr_pos[e];
+                for (int64_t f = c->colptr[kid]; f < c->colptr[kid + 1]; ++f) {
+                    uint32_t j = c->csc_read[f];
+                    orc_seed_t prod = orc_sr_multiply(q, c->csc_pos[f]);
+                    if (acc[j].numshared == 0) { acc[j] = prod; touched[nt++] = j; }
+                    else acc[j] = orc_sr_add(acc[j], prod);
+                    ++P;
+                }
+            }
+            Yraw += nt;
+            int64_t keep = 0;
+            for (int64_t t = 0; t < nt; ++t) if (acc[touched[t]].numshared > 1) touched[keep++] = touched[t]; else acc[touched[t]].numshared = 0;
+            qsort(touched, (size_t)keep, sizeof(uint32_t), orc_cmp_u32);
+            rowcnt[i + 1] = keep;
+            rcol[i] = (uint32_t *)malloc((size_t)(keep + 1) * sizeof(uint32_t));
+            rval[i] = (orc_seed_t *)malloc((size_t)(keep + 1) * sizeof(orc_seed_t));
+            for (int64_t t = 0; t < keep; ++t) {
+                uint32_t j = touched[t];
+                rcol[i][t] = j; rval[i][t] = acc[j];
+                if ((int64_t)j == i) ++ndiag;
+                if ((int64_t)j > i) ++nupper;
+                if (acc[j].numshared > maxshared) maxshared = acc[j].numshared;
+                acc[j].numshared = 0;
+            }
+        }
+        free(acc); free(touched);
+    }
+    for (int64_t i = 0; i < M; ++i) rowcnt[i + 1] += rowcnt[i];
+    int64_t Y = rowcnt[M];
+    c->b_rowptr = rowcnt;
+    c->b_col = (uint32_t *)malloc((size_t)(Y + 1) * sizeof(uint32_t));
+    c->b_val = (orc_seed_t *)malloc((size_t)(Y + 1) * sizeof(orc_seed_t));
+    for (int64_t i = 0; i < M; ++i) {
+        int64_t n = rowcnt[i + 1] - rowcnt[i];
+        memcpy(c->b_col + rowcnt[i], rcol[i], (size_t)n * sizeof(uint32_t));
+        memcpy(c->b_val + rowcnt[i], rval[i], (size_t)n * sizeof(orc_seed_t));
+        free(rcol[i]); free(rval[i]);
+    }
+    free(rcol); free(rval);
+    c->P = P; c->Yraw = Yraw; c->Y = Y; c->ndiag = ndiag; c->nupper = nupper; c->maxshared = maxshared;
+    return 0;
+}
+
+/*
+ * a14: the consumer's view.  Fill a CombBLAS-shaped DCSC (jc, cp, ir, numx) of the block
+ * [row_lo,row_hi) x [col_lo,col_hi) of B with LOCAL indices, column-major, rows ascending within a column —
+ * the arrays src/PairwiseAlignment.cpp:28-32 walks.  Caller frees with orc_free_ptr.
+ */
+int orc_export_dcsc(const orc_ctx *c, int64_t row_lo, int64_t row_hi, int64_t col_lo, int64_t col_hi,
+                    int64_t *nnz, int64_t *nzc, int64_t **jc, int64_t **cp, int64_t **ir, orc_seed_t **numx)
+{
+    const int64_t ncols = col_hi - col_lo;
+    int64_t *cnt = (int64_t *)calloc((size_t)(ncols + 2), sizeof(int64_t));
+    int64_t total = 0;
+    for (int64_t i = row_lo; i < row_hi; ++i)
+        for (int64_t e = c->b_rowptr[i]; e < c->b_rowptr[i + 1]; ++e) {
+            int64_t j = c->b_col[e];
+            if (j >= col_lo && j < col_hi) { cnt[j - col_lo + 1]++; ++total; }
+        }
+    int64_t nz = 0;
+    for (int64_t j = 0; j < ncols; ++j) if (cnt[j + 1]) ++nz;
+    *jc = (int64_t *)malloc((size_t)(nz + 1) * sizeof(int64_t));
+    *cp = (int64_t *)malloc((size_t)(nz + 2) * sizeof(int64_t));
+    *ir = (int64_t *)malloc((size_t)(total + 1) * sizeof(int64_t));
+    *numx = (orc_seed_t *)malloc((size_t)(total + 1) * sizeof(orc_seed_t));
+    int64_t *start = (int64_t *)malloc((size_t)(ncols + 1) * sizeof(int64_t));
+    int64_t run = 0, ci = 0;
+    for (int64_t j = 0; j < ncols; ++j) {
+        start[j] = run;
+        if (cnt[j + 1]) { (*jc)[ci] = j; (*cp)[ci] = run; ++ci; }
+        run += cnt[j + 1];
+    }
+    (*cp)[nz] = run;
+    for (int64_t i = row_lo; i < row_hi; ++i)
+        for (int64_t e = c->b_rowptr[i]; e < c->b_rowptr[i + 1]; ++e) {
+            int64_t j = c->b_col[e];
+            if (j >= col_lo && j < col_hi) { int64_t d = start[j - col_lo]++; (*ir)[d] = i - row_lo; (*numx)[d] = c->b_val[e]; }
+        }
+    free(start); free(cnt);
+    *nnz = total; *nzc = nz;
+    return 0;
+}
+void orc_free_ptr(void *p) { free(p); }
+
+/*
+ * test.py:57-65 property: a stored seed pair names the same k-mer in both reads, forward or reverse-complement.
+ * Returns 1 if valid.
+ */
+int orc_seed_is_valid(const uint8_t *qmem, uint32_t qlen, const uint8_t *tmem, uint32_t tlen, uint32_t q, uint32_t t, int k)
+{
+    if ((int64_t)q + k > (int64_t)qlen || (int64_t)t + k > (int64_t)tlen) return 0;
+    uint64_t a = 0, b = 0;
+    for (int i = 0; i < k; ++i) { a |= (uint64_t)orc_base_at(qmem, q + (size_t)i) << (2 * (31 - i)); b |= (uint64_t)orc_base_at(tmem, t + (size_t)i) << (2 * (31 - i)); }
+    return a == b || a == orc_kmer_twin(b, k);
+}
+
+/* getters (ctypes-friendly) */
+int64_t orc_get_i64(const orc_ctx *c, int what)
+{
+    switch (what) {
+    case 0: return c->M; case 1: return c->I; case 2: return c->N; case 3: return c->Z; case 4: return c->ndistinct;
+    case 5: return c->P; case 6: return c->Yraw; case 7: return c->Y; case 8: return c->ndiag; case 9: return c->nupper; case 10: return c->maxshared;
+    default: return -1;
+    }
+}
+const void *orc_get_ptr(const orc_ctx *c, int what)
+{
+    switch (what) {
+    case 0: return c->kmers; case 1: return c->colptr; case 2: return c->csc_read; case 3: return c->csc_pos;
+    case 4: return c->rowptr; case 5: return c->csr_kid; case 6: return c->csr_pos; case 7: return c->hist;
+    case 8: return c->b_rowptr; case 9: return c->b_col; case 10: return c->b_val;
+    default: return NULL;
+    }
+}

@@ -1,0 +1,190 @@
+"""ctypes bindings for the CPU oracle (oracle/elba_oracle.c) and the reference-primitive shim (oracle/_ref).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+The product package (elba_amd/) must never import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_ORACLE_SO = os.path.join(HERE, "_build", "libelba_oracle.so")
+
+
+class Seed(C.Structure):
+    _fields_ = [("q0", C.c_uint32), ("t0", C.c_uint32), ("q1", C.c_uint32), ("t1", C.c_uint32), ("numshared", C.c_int32)]
+
+
+SEED_DTYPE = np.dtype([("q0", "<u4"), ("t0", "<u4"), ("q1", "<u4"), ("t1", "<u4"), ("numshared", "<i4")])
+
+
+def build(force=False):
+    if force or not os.path.exists(_ORACLE_SO) or os.path.getmtime(_ORACLE_SO) < os.path.getmtime(os.path.join(HERE, "elba_oracle.c")):
+        subprocess.check_call(["make", "-C", HERE, "oracle"], stdout=subprocess.DEVNULL)
+    return _ORACLE_SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_ORACLE_SO)
+        L.orc_encode_read.restype = C.c_size_t
+        L.orc_encode_read.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+        L.orc_kmer_from_ascii.restype = C.c_uint64
+        L.orc_kmer_from_ascii.argtypes = [C.c_char_p, C.c_int]
+        L.orc_kmer_twin.restype = C.c_uint64
+        L.orc_kmer_twin.argtypes = [C.c_uint64, C.c_int]
+        L.orc_kmer_rep.restype = C.c_uint64
+        L.orc_kmer_rep.argtypes = [C.c_uint64, C.c_int]
+        L.orc_kmer_extend.restype = C.c_uint64
+        L.orc_kmer_extend.argtypes = [C.c_uint64, C.c_int, C.c_int]
+        L.orc_kmer_hash.restype = C.c_uint64
+        L.orc_kmer_hash.argtypes = [C.c_uint64]
+        L.orc_murmur3_x64_128.restype = None
+        L.orc_murmur3_x64_128.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.orc_kmer_owner.restype = C.c_int
+        L.orc_kmer_owner.argtypes = [C.c_uint64, C.c_int]
+        L.orc_read_kmers.restype = C.c_int64
+        L.orc_read_kmers.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_sr_multiply.restype = Seed
+        L.orc_sr_multiply.argtypes = [C.c_uint32, C.c_uint32]
+        L.orc_sr_add.restype = Seed
+        L.orc_sr_add.argtypes = [Seed, Seed]
+        L.orc_create.restype = C.c_void_p
+        L.orc_create.argtypes = [C.c_int, C.c_int, C.c_int]
+        L.orc_destroy.restype = None
+        L.orc_destroy.argtypes = [C.c_void_p]
+        L.orc_count_and_build.restype = C.c_int
+        L.orc_count_and_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_set_triples.restype = C.c_int
+        L.orc_set_triples.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_spgemm.restype = C.c_int
+        L.orc_spgemm.argtypes = [C.c_void_p, C.c_int]
+        L.orc_export_dcsc.restype = C.c_int
+        L.orc_export_dcsc.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64] + [C.c_void_p] * 6
+        L.orc_free_ptr.restype = None
+        L.orc_free_ptr.argtypes = [C.c_void_p]
+        L.orc_seed_is_valid.restype = C.c_int
+        L.orc_seed_is_valid.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_get_i64.restype = C.c_int64
+        L.orc_get_i64.argtypes = [C.c_void_p, C.c_int]
+        L.orc_get_ptr.restype = C.c_void_p
+        L.orc_get_ptr.argtypes = [C.c_void_p, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _arr(ptr, n, dtype):
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    dt = np.dtype(dtype)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+
+def pack_reads(seqs):
+    """ASCII reads -> (buf u8, byte_off u64, lens u32) in DnaBuffer layout (src/DnaBuffer.cpp:22-29) via the oracle encoder."""
+    L = lib()
+    lens = np.array([len(s) for s in seqs], dtype=np.uint32)
+    nb = (lens.astype(np.int64) + 3) // 4
+    off = np.zeros(len(seqs), dtype=np.uint64)
+    if len(seqs):
+        off[1:] = np.cumsum(nb)[:-1]
+    buf = np.zeros(int(nb.sum()) + 8, dtype=np.uint8)
+    for i, s in enumerate(seqs):
+        b = s if isinstance(s, bytes) else s.encode()
+        L.orc_encode_read(b, len(b), buf.ctypes.data + int(off[i]))
+    return buf, off, lens
+
+
+class Oracle:
+    """Reads -> reliable k-mers -> A -> B with the CPU restatement."""
+
+    STAT = dict(M=0, I=1, N=2, Z=3, ndistinct=4, P=5, Yraw=6, Y=7, ndiag=8, nupper=9, maxshared=10)
+
+    def __init__(self, k, lower, upper):
+        self.L = lib()
+        self.h = self.L.orc_create(k, lower, upper)
+        if not self.h:
+            raise ValueError("invalid (k, lower, upper)")
+        self.k, self.lower, self.upper = k, lower, upper
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.orc_destroy(self.h)
+            self.h = None
+
+    def stat(self, name):
+        return int(self.L.orc_get_i64(self.h, self.STAT[name]))
+
+    def count_and_build(self, buf, off, lens):
+        buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        off = np.ascontiguousarray(off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        rc = self.L.orc_count_and_build(self.h, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens))
+        if rc:
+            raise RuntimeError("orc_count_and_build failed: %d" % rc)
+
+    def set_triples(self, M, N, rows, cols, vals):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        vals = np.ascontiguousarray(vals, dtype=np.uint32)
+        rc = self.L.orc_set_triples(self.h, M, N, len(rows), rows.ctypes.data, cols.ctypes.data, vals.ctypes.data)
+        if rc:
+            raise RuntimeError("orc_set_triples failed: %d" % rc)
+
+    def spgemm(self, nthreads=1):
+        rc = self.L.orc_spgemm(self.h, nthreads)
+        if rc:
+            raise RuntimeError("orc_spgemm failed: %d" % rc)
+
+    def A(self):
+        M, N, Z = self.stat("M"), self.stat("N"), self.stat("Z")
+        g = lambda w, n, dt: _arr(self.L.orc_get_ptr(self.h, w), n, dt)
+        return dict(M=M, N=N, Z=Z,
+                    kmers=g(0, N, np.uint64), colptr=g(1, N + 1, np.int64), csc_read=g(2, Z, np.uint32), csc_pos=g(3, Z, np.uint32),
+                    rowptr=g(4, M + 1, np.int64), csr_kid=g(5, Z, np.uint32), csr_pos=g(6, Z, np.uint32),
+                    hist=g(7, self.upper + 2, np.int64))
+
+    def B(self):
+        M, Y = self.stat("M"), self.stat("Y")
+        g = lambda w, n, dt: _arr(self.L.orc_get_ptr(self.h, w), n, dt)
+        return dict(M=M, Y=Y, rowptr=g(8, M + 1, np.int64), col=g(9, Y, np.uint32), val=g(10, Y, SEED_DTYPE))
+
+    def export_dcsc(self, row_lo, row_hi, col_lo, col_hi):
+        nnz, nzc = C.c_int64(), C.c_int64()
+        jc, cp, ir, numx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self.L.orc_export_dcsc(self.h, row_lo, row_hi, col_lo, col_hi, C.byref(nnz), C.byref(nzc), C.byref(jc), C.byref(cp), C.byref(ir), C.byref(numx))
+        out = dict(nnz=nnz.value, nzc=nzc.value, jc=_arr(jc.value, nzc.value, np.int64), cp=_arr(cp.value, nzc.value + 1, np.int64),
+                   ir=_arr(ir.value, nnz.value, np.int64), numx=_arr(numx.value, nnz.value, SEED_DTYPE))
+        for p in (jc, cp, ir, numx):
+            self.L.orc_free_ptr(p)
+        return out
+
+
+def ref_lib(k):
+    """The reference's own primitives compiled from /root/reference (oracle/_ref); None when not built."""
+    p = os.path.join(HERE, "_ref", "libelbaref_k%d.so" % k)
+    if not os.path.exists(p):
+        return None
+    R = C.CDLL(p)
+    R.ref_encode.restype = C.c_size_t
+    R.ref_encode.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p]
+    R.ref_kmers.restype = C.c_int64
+    R.ref_kmers.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int]
+    R.ref_kmer_from_ascii.restype = None
+    R.ref_kmer_from_ascii.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    R.ref_kmer_hash.restype = C.c_uint64
+    R.ref_kmer_hash.argtypes = [C.c_void_p]
+    R.ref_murmur3_128.restype = None
+    R.ref_murmur3_128.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    R.ref_bloom_second_sightings.restype = C.c_int64
+    R.ref_bloom_second_sightings.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    R.ref_replay_count.restype = C.c_int64
+    R.ref_replay_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    return R

@@ -1,0 +1,241 @@
+"""CPU tests: the oracle (oracle/elba_oracle.c) against the committed golden vectors, which were produced by the
+REFERENCE's own compiled code (tests/golden/make_golden.py) or measured from it by the survey."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import util
+from oracle import pyoracle as po
+
+G = util.GOLDEN
+
+
+def _rows(name):
+    return [l.split() for l in open(os.path.join(G, name)) if l[0] != "#" and l.strip()]
+
+
+@pytest.mark.parametrize("k", [17, 31])
+def test_kmer_pack_twin_rep_hash(k):
+    L = po.lib()
+    for s, fwd, twin, rep, h, hf in _rows("kmer_vectors_k%d.txt" % k):
+        w = L.orc_kmer_from_ascii(s.encode(), k)
+        assert w == int(fwd, 16), s
+        assert L.orc_kmer_twin(w, k) == int(twin, 16), s
+        assert L.orc_kmer_rep(w, k) == int(rep, 16), s
+        assert L.orc_kmer_hash(int(rep, 16)) == int(h, 16), s
+        assert L.orc_kmer_hash(w) == int(hf, 16), s
+        # twin is an involution; rep is the smaller of the two
+        assert L.orc_kmer_twin(L.orc_kmer_twin(w, k), k) == w
+
+
+def test_encode_vectors():
+    L = po.lib()
+    for s, hx in _rows("encode_vectors.txt"):
+        mem = np.zeros((len(s) + 3) // 4, dtype=np.uint8)
+        nb = L.orc_encode_read(s.encode(), len(s), mem.ctypes.data)
+        assert nb == len(mem) and mem.tobytes().hex() == hx, s
+
+
+def test_murmur_vectors():
+    L = po.lib()
+    for key, h1, h2 in _rows("murmur_vectors.txt"):
+        b = b"" if key == "-" else bytes.fromhex(key)
+        out = (C.c_uint64 * 2)()
+        L.orc_murmur3_x64_128(b, len(b), 313, out)
+        assert (out[0], out[1]) == (int(h1, 16), int(h2, 16)), key
+
+
+@pytest.mark.parametrize("k", [17, 31])
+def test_rolling_canonical_kmers(k):
+    L = po.lib()
+    for s, ks in _rows("read_kmers_k%d.txt" % k):
+        buf, off, lens = po.pack_reads([s.encode()])
+        out = np.zeros(max(1, len(s)), dtype=np.uint64)
+        n = L.orc_read_kmers(buf.ctypes.data, len(s), k, out.ctypes.data)
+        exp = [] if ks == "-" else [int(x, 16) for x in ks.split(",")]
+        assert n == len(exp) and out[:n].tolist() == exp
+
+
+def test_owner_formula():
+    # src/KmerOps.cpp:352-359; KmerOps.cpp itself is unbuildable here (needs CombBLAS): formula-level check only
+    L = po.lib()
+    for p in (1, 2, 4, 8, 16):
+        assert L.orc_kmer_owner(0, p) == 0
+        assert L.orc_kmer_owner((1 << 63), p) == p // 2
+        assert L.orc_kmer_owner((1 << 64) - (1 << 20), p) in (p - 1, p)  # double rounding at the very top, as in the reference
+    rng = np.random.default_rng(5)
+    for h in rng.integers(0, 1 << 63, 200, dtype=np.uint64).tolist():
+        for p in (3, 8):
+            o = L.orc_kmer_owner(h, p)
+            assert o == int(float(h) * p / float((1 << 64) - 1))
+
+
+def test_semiring_fold_shapes():
+    # include/SharedSeeds.hpp:41-52; SURVEY.md App. B: left fold p1..p4 -> {(1,1),(4,4),4}; balanced tree -> {(1,1),(3,3),4}
+    L = po.lib()
+    p = [L.orc_sr_multiply(i, i) for i in range(1, 5)]
+    acc = p[0]
+    for x in p[1:]:
+        acc = L.orc_sr_add(acc, x)
+    assert (acc.q0, acc.t0, acc.q1, acc.t1, acc.numshared) == (1, 1, 4, 4, 4)
+    tree = L.orc_sr_add(L.orc_sr_add(p[0], p[1]), L.orc_sr_add(p[2], p[3]))
+    assert (tree.q0, tree.t0, tree.q1, tree.t1, tree.numshared) == (1, 1, 3, 3, 4)
+    one = L.orc_sr_multiply(7, 9)
+    assert (one.q0, one.t0, one.q1, one.t1, one.numshared) == (7, 9, 0, 0, 1)
+
+
+def _check_set(name, meta):
+    k, lo, up = meta["k"], meta["lower"], meta["upper"]
+    seqs = util.read_fasta(os.path.join(G, name + ".fa"))
+    buf, off, lens = po.pack_reads(seqs)
+    o = po.Oracle(k, lo, up)
+    o.count_and_build(buf, off, lens)
+    o.spgemm(1)
+    for key in ("M", "I", "N", "Z", "P", "Yraw", "Y"):
+        assert o.stat(key) == meta[key], (name, key)
+    A = o.A()
+    km, rd, ps = util.triples_from_A(A)
+    gk, gr, gp = util.read_triples(os.path.join(G, "%s_k%d_L%d_U%d.triples" % (name, k, lo, up)))
+    assert (km == gk).all() and (rd == gr).all() and (ps == gp).all()
+    gB = util.read_B(os.path.join(G, "%s_k%d_L%d_U%d.B" % (name, k, lo, up)))
+    assert (util.b_triplets(o.B()) == gB).all()
+    return o, buf, off, lens
+
+
+def test_small_err_set():
+    m = util.golden_meta()["small_err"][0]
+    _check_set("small_err", m)
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_small_clean_set(idx):
+    m = util.golden_meta()["small_clean"][idx]
+    _check_set("small_clean", m)
+
+
+def _seed_checks(o, buf, off, lens, k):
+    """Canonical rule + test.py:57-65 validity + CSR/CSC consistency, straight from A."""
+    L = po.lib()
+    A, B = o.A(), o.B()
+    rows = np.repeat(np.arange(B["M"]), np.diff(B["rowptr"]))
+    # brute-force canonical seeds for a sample of entries
+    rng = np.random.default_rng(1)
+    idx = rng.choice(len(rows), size=min(300, len(rows)), replace=False) if len(rows) else []
+    for e in idx:
+        i, j, v = int(rows[e]), int(B["col"][e]), B["val"][e]
+        prods = []
+        for a in range(A["rowptr"][i], A["rowptr"][i + 1]):
+            kid, q = int(A["csr_kid"][a]), int(A["csr_pos"][a])
+            for f in range(A["colptr"][kid], A["colptr"][kid + 1]):
+                if int(A["csc_read"][f]) == j:
+                    prods.append((kid, q, int(A["csc_pos"][f])))
+        assert len(prods) == v["numshared"] >= 2
+        assert (v["q0"], v["t0"]) == min(prods)[1:] and (v["q1"], v["t1"]) == max(prods)[1:]
+        for (q, t) in ((v["q0"], v["t0"]), (v["q1"], v["t1"])):
+            assert L.orc_seed_is_valid(buf.ctypes.data + int(off[i]), int(lens[i]), buf.ctypes.data + int(off[j]), int(lens[j]), int(q), int(t), k)
+
+
+def test_seed_rule_and_validity_small():
+    m = util.golden_meta()["small_err"][0]
+    o, buf, off, lens = _check_set("small_err", m)
+    _seed_checks(o, buf, off, lens, m["k"])
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_reference_sample_appB(idx):
+    """The reference's bundled reads.fa; expected figures measured by the survey from the reference's own KmerOps.cpp."""
+    m = util.golden_meta()["reads_ref_appB"][idx]
+    seqs = util.read_fasta(os.path.join(G, "reads_ref.fa.gz"))
+    buf, off, lens = po.pack_reads(seqs)
+    o = po.Oracle(m["k"], m["lower"], m["upper"])
+    o.count_and_build(buf, off, lens)
+    o.spgemm(2)
+    for key in ("M", "I", "N", "Z", "P", "Yraw", "Y", "nupper", "maxshared"):
+        assert o.stat(key) == m[key], key
+    assert o.stat("Y") == o.stat("ndiag") + 2 * o.stat("nupper")  # symmetric pattern
+    A = o.A()
+    rows = np.repeat(np.arange(A["M"], dtype=np.int64), np.diff(A["rowptr"]))
+    key = rows * A["N"] + A["csr_kid"]
+    assert len(key) - len(np.unique(key)) == m["dups"]
+    if idx == 0:
+        _seed_checks(o, buf, off, lens, m["k"])
+
+
+def test_threads_do_not_change_result():
+    m = util.golden_meta()["small_err"][0]
+    seqs = util.read_fasta(os.path.join(G, "small_err.fa"))
+    buf, off, lens = po.pack_reads(seqs)
+    o = po.Oracle(m["k"], m["lower"], m["upper"])
+    o.count_and_build(buf, off, lens)
+    o.spgemm(1); B1 = o.B()
+    o.spgemm(4); B4 = o.B()
+    assert (B1["rowptr"] == B4["rowptr"]).all() and (B1["col"] == B4["col"]).all() and (B1["val"] == B4["val"]).all()
+
+
+def test_dcsc_export_matches_consumer_walk():
+    """src/PairwiseAlignment.cpp:28-56: walking (jc,cp,ir,numx) must visit exactly B's entries; strict upper = candidates."""
+    m = util.golden_meta()["small_err"][0]
+    seqs = util.read_fasta(os.path.join(G, "small_err.fa"))
+    buf, off, lens = po.pack_reads(seqs)
+    o = po.Oracle(m["k"], m["lower"], m["upper"])
+    o.count_and_build(buf, off, lens); o.spgemm(1)
+    B = o.B(); M = B["M"]
+    d = o.export_dcsc(0, M, 0, M)
+    assert d["nnz"] == B["Y"]
+    seen = {}
+    for ci in range(d["nzc"]):
+        for e in range(d["cp"][ci], d["cp"][ci + 1]):
+            seen[(int(d["ir"][e]), int(d["jc"][ci]))] = d["numx"][e]
+        assert (np.diff(d["ir"][d["cp"][ci]:d["cp"][ci + 1]]) > 0).all()
+    rows = np.repeat(np.arange(M), np.diff(B["rowptr"]))
+    assert len(seen) == B["Y"]
+    for e in range(B["Y"]):
+        assert seen[(int(rows[e]), int(B["col"][e]))] == B["val"][e]
+    assert sum(1 for (r, c) in seen if r < c) == o.stat("nupper")
+    # a grid-cell block (2x2 grid, cell (0,1)) carries local indices
+    h = M // 2
+    blk = o.export_dcsc(0, h, h, M)
+    for ci in range(blk["nzc"]):
+        for e in range(blk["cp"][ci], blk["cp"][ci + 1]):
+            assert seen[(int(blk["ir"][e]), int(blk["jc"][ci]) + h)] == blk["numx"][e]
+
+
+def test_triples_entry_reproduces_B():
+    """create_seed_matrix's own input form: A handed over as (row, col, val) triples (src/KmerOps.cpp:380-400)."""
+    m = util.golden_meta()["small_err"][0]
+    seqs = util.read_fasta(os.path.join(G, "small_err.fa"))
+    buf, off, lens = po.pack_reads(seqs)
+    o = po.Oracle(m["k"], m["lower"], m["upper"])
+    o.count_and_build(buf, off, lens); o.spgemm(1)
+    A, B = o.A(), o.B()
+    rows = np.repeat(np.arange(A["M"], dtype=np.int64), np.diff(A["rowptr"]))
+    perm = np.random.default_rng(3).permutation(A["Z"])
+    o2 = po.Oracle(m["k"], m["lower"], m["upper"])
+    o2.set_triples(A["M"], A["N"], rows[perm], A["csr_kid"].astype(np.int64)[perm], A["csr_pos"][perm])
+    o2.spgemm(1)
+    B2 = o2.B()
+    assert (B["rowptr"] == B2["rowptr"]).all() and (B["col"] == B2["col"]).all() and (B["val"] == B2["val"]).all()
+
+
+@pytest.mark.skipif(po.ref_lib(17) is None, reason="oracle/_ref not built (reference tree absent)")
+def test_live_against_reference_primitives():
+    """Random cross-check against the reference's compiled Kmer/DnaSeq/HashFuncs (only where oracle/_ref exists)."""
+    L = po.lib()
+    rng = np.random.default_rng(99)
+    for k in (17, 31):
+        R = po.ref_lib(k)
+        for _ in range(20):
+            ln = int(rng.integers(k, 400))
+            s = bytes(rng.choice(list(b"ACGTNacgtn"), ln).tolist())
+            m1 = np.zeros((ln + 3) // 4 + 8, dtype=np.uint8); m2 = m1.copy()
+            R.ref_encode(s, ln, m1.ctypes.data); L.orc_encode_read(s, ln, m2.ctypes.data)
+            assert (m1 == m2).all()
+            o1 = np.zeros(ln, dtype=np.uint64); o2 = o1.copy()
+            n1 = R.ref_kmers(m1.ctypes.data, ln, o1.ctypes.data, 1)
+            n2 = L.orc_read_kmers(m2.ctypes.data, ln, k, o2.ctypes.data)
+            assert n1 == n2 and (o1 == o2).all()
+            for w in o1[:5].tolist():
+                x = C.c_uint64(w)
+                assert R.ref_kmer_hash(C.byref(x)) == L.orc_kmer_hash(w)
