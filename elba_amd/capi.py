@@ -1,0 +1,260 @@
+"""ctypes binding of include/elba_amd.h and include/elba_synth.h (no torch types cross this boundary)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libelba_amd.so")
+
+
+class ElbaError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__("elba status %d: %s" % (status, text))
+        self.status = status
+
+
+class Seed(C.Structure):
+    _fields_ = [("q0", C.c_uint32), ("t0", C.c_uint32), ("q1", C.c_uint32), ("t1", C.c_uint32), ("numshared", C.c_int32)]
+
+
+SEED_DTYPE = np.dtype([("q0", "<u4"), ("t0", "<u4"), ("q1", "<u4"), ("t1", "<u4"), ("numshared", "<i4")])
+
+
+class Cfg(C.Structure):
+    _fields_ = [("k", C.c_int32), ("lower", C.c_int32), ("upper", C.c_int32), ("device", C.c_int32),
+                ("workspace_hint_bytes", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32)]
+
+
+class KmerStats(C.Structure):
+    _fields_ = [("nreads", C.c_int64), ("instances", C.c_int64), ("distinct", C.c_int64), ("reliable", C.c_int64), ("entries", C.c_int64),
+                ("ms_total", C.c_float), ("ms_count", C.c_float), ("ms_lookup", C.c_float), ("ms_sort", C.c_float)]
+
+
+class MatrixStats(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("max_row_nnz", C.c_int64), ("ms_total", C.c_float)]
+
+
+class OverlapStats(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("products", C.c_int64), ("nnz_before_prune", C.c_int64), ("nnz", C.c_int64), ("nnz_diag", C.c_int64),
+                ("nnz_upper", C.c_int64), ("max_numshared", C.c_int64), ("rows_lds", C.c_int64), ("rows_global", C.c_int64),
+                ("algorithmic_bytes", C.c_int64), ("passes", C.c_int32), ("reserved", C.c_int32),
+                ("ms_total", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float), ("ms_finalize", C.c_float)]
+
+
+class Dcsc(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("nzc", C.c_int64),
+                ("jc", C.c_void_p), ("cp", C.c_void_p), ("ir", C.c_void_p), ("numx", C.c_void_p)]
+
+
+class Csr(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("rowptr", C.c_void_p), ("col", C.c_void_p), ("val", C.c_void_p)]
+
+
+class KmerMatrix(C.Structure):
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("kmers", C.c_void_p), ("colptr", C.c_void_p),
+                ("csc_row", C.c_void_p), ("csc_val", C.c_void_p), ("rowptr", C.c_void_p), ("csr_col", C.c_void_p), ("csr_val", C.c_void_p)]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("M", C.c_int64), ("N", C.c_int64), ("Z", C.c_int64), ("Y", C.c_int64),
+                ("a_rowptr", C.c_void_p), ("a_csr", C.c_void_p), ("a_colptr", C.c_void_p), ("a_csc", C.c_void_p),
+                ("b_rowptr", C.c_void_p), ("b_col", C.c_void_p), ("b_val", C.c_void_p), ("stream", C.c_void_p)]
+
+
+class SynthCfg(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("genome_length", C.c_int64), ("depth", C.c_double), ("avg_len", C.c_double), ("sd_len", C.c_double),
+                ("min_len", C.c_int64), ("error_rate", C.c_double), ("repeat_families", C.c_int32), ("repeat_fraction", C.c_double),
+                ("repeat_len", C.c_int64), ("first_read", C.c_int64), ("num_reads", C.c_int64)]
+
+
+class SynthReads(C.Structure):
+    _fields_ = [("nreads", C.c_int64), ("total_reads", C.c_int64), ("packed_bytes", C.c_int64), ("total_bases", C.c_int64),
+                ("packed", C.c_void_p), ("byte_off", C.c_void_p), ("len", C.c_void_p), ("genome_pos", C.c_void_p), ("strand", C.c_void_p)]
+
+
+EXPORTED_SYMBOLS = [
+    "elba_abi_version", "elba_strerror", "elba_last_error", "elba_ctx_create", "elba_ctx_destroy", "elba_set_reads", "elba_set_reads_device",
+    "elba_count_kmers", "elba_create_kmer_matrix", "elba_set_kmer_matrix", "elba_create_seed_matrix", "elba_export_dcsc", "elba_free_dcsc",
+    "elba_export_csr", "elba_free_csr", "elba_export_kmer_matrix", "elba_free_kmer_matrix", "elba_kmer_histogram", "elba_get_device_view",
+    "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
+]
+
+_lib = None
+
+
+def load_library():
+    """Loads libelba_amd.so or raises: the product path never falls back to anything else."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not os.path.exists(p):
+        raise ElbaError(-1, "libelba_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C elba_amd/csrc`" % p)
+    L = C.CDLL(p)
+    vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+    L.elba_abi_version.restype = i32
+    L.elba_strerror.restype = C.c_char_p; L.elba_strerror.argtypes = [i32]
+    L.elba_last_error.restype = C.c_char_p; L.elba_last_error.argtypes = [vp]
+    L.elba_ctx_create.restype = i32; L.elba_ctx_create.argtypes = [C.POINTER(vp), C.POINTER(Cfg)]
+    L.elba_ctx_destroy.restype = None; L.elba_ctx_destroy.argtypes = [vp]
+    L.elba_set_reads.restype = i32; L.elba_set_reads.argtypes = [vp, vp, vp, vp, i64, i64]
+    L.elba_set_reads_device.restype = i32; L.elba_set_reads_device.argtypes = [vp, vp, i64, vp, vp, i64, i64]
+    L.elba_count_kmers.restype = i32; L.elba_count_kmers.argtypes = [vp, C.POINTER(KmerStats)]
+    L.elba_create_kmer_matrix.restype = i32; L.elba_create_kmer_matrix.argtypes = [vp, C.POINTER(MatrixStats)]
+    L.elba_set_kmer_matrix.restype = i32; L.elba_set_kmer_matrix.argtypes = [vp, i64, i64, i64, vp, vp, vp, C.POINTER(MatrixStats)]
+    L.elba_create_seed_matrix.restype = i32; L.elba_create_seed_matrix.argtypes = [vp, C.POINTER(OverlapStats)]
+    L.elba_export_dcsc.restype = i32; L.elba_export_dcsc.argtypes = [vp, i64, i64, i64, i64, C.POINTER(Dcsc)]
+    L.elba_free_dcsc.restype = None; L.elba_free_dcsc.argtypes = [C.POINTER(Dcsc)]
+    L.elba_export_csr.restype = i32; L.elba_export_csr.argtypes = [vp, i64, i64, C.POINTER(Csr)]
+    L.elba_free_csr.restype = None; L.elba_free_csr.argtypes = [C.POINTER(Csr)]
+    L.elba_export_kmer_matrix.restype = i32; L.elba_export_kmer_matrix.argtypes = [vp, C.POINTER(KmerMatrix)]
+    L.elba_free_kmer_matrix.restype = None; L.elba_free_kmer_matrix.argtypes = [C.POINTER(KmerMatrix)]
+    L.elba_kmer_histogram.restype = i32; L.elba_kmer_histogram.argtypes = [vp, vp, i64]
+    L.elba_get_device_view.restype = i32; L.elba_get_device_view.argtypes = [vp, C.POINTER(DeviceView)]
+    L.elba_synth_num_reads.restype = i64; L.elba_synth_num_reads.argtypes = [C.POINTER(SynthCfg)]
+    L.elba_synth_generate.restype = i32; L.elba_synth_generate.argtypes = [C.POINTER(SynthCfg), C.POINTER(SynthReads)]
+    L.elba_synth_free.restype = None; L.elba_synth_free.argtypes = [C.POINTER(SynthReads)]
+    _lib = L
+    return L
+
+
+def _copy(ptr, n, dtype):
+    dt = np.dtype(dtype)
+    if n == 0 or not ptr:
+        return np.zeros(0, dtype=dt)
+    buf = (C.c_char * (n * dt.itemsize)).from_address(ptr)
+    return np.frombuffer(buf, dtype=dt, count=n).copy()
+
+
+def _stats(s):
+    return {f[0]: getattr(s, f[0]) for f in s._fields_}
+
+
+def synth_reads(seed, genome_length, depth, avg_len, sd_len, error_rate=0.0, min_len=100, repeat_families=0, repeat_fraction=0.0,
+                repeat_len=0, first_read=0, num_reads=-1):
+    """Generates (packed u8, byte_off u64, len u32, info) with the native generator (host code; no GPU needed)."""
+    L = load_library()
+    cfg = SynthCfg(seed, genome_length, depth, avg_len, sd_len, min_len, error_rate, repeat_families, repeat_fraction, repeat_len, first_read, num_reads)
+    out = SynthReads()
+    rc = L.elba_synth_generate(C.byref(cfg), C.byref(out))
+    if rc:
+        raise ElbaError(rc, "elba_synth_generate failed")
+    try:
+        packed = _copy(out.packed, out.packed_bytes + 16, np.uint8)
+        off = _copy(out.byte_off, out.nreads, np.uint64)
+        ln = _copy(out.len, out.nreads, np.uint32)
+        info = dict(nreads=out.nreads, total_reads=out.total_reads, total_bases=out.total_bases,
+                    genome_pos=_copy(out.genome_pos, out.nreads, np.int64), strand=_copy(out.strand, out.nreads, np.uint8))
+    finally:
+        L.elba_synth_free(C.byref(out))
+    return packed, off, ln, info
+
+
+class Engine:
+    """One context on one GPU.  Method names follow the reference's free functions (include/KmerOps.hpp:24-31,
+    include/SharedSeeds.hpp:98-99); each is a single C-ABI call."""
+
+    def __init__(self, k, lower, upper, device=0, workspace_hint_bytes=0):
+        self.L = load_library()
+        self.h = C.c_void_p()
+        cfg = Cfg(k, lower, upper, device, workspace_hint_bytes, 0, 0)
+        rc = self.L.elba_ctx_create(C.byref(self.h), C.byref(cfg))
+        if rc:
+            self.h = C.c_void_p()
+            raise ElbaError(rc, self.L.elba_strerror(rc).decode())
+        self.k, self.lower, self.upper, self.device = k, lower, upper, device
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.elba_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise ElbaError(rc, "%s: %s" % (self.L.elba_strerror(rc).decode(), self.L.elba_last_error(self.h).decode()))
+
+    # --- inputs ---
+    def set_reads(self, packed, byte_off, lens, first_global_id=0):
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        byte_off = np.ascontiguousarray(byte_off, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        self._check(self.L.elba_set_reads(self.h, packed.ctypes.data, byte_off.ctypes.data, lens.ctypes.data, len(lens), first_global_id))
+
+    def set_reads_device(self, d_packed, packed_bytes, d_byte_off, d_len, nreads, first_global_id=0):
+        self._check(self.L.elba_set_reads_device(self.h, d_packed, packed_bytes, d_byte_off, d_len, nreads, first_global_id))
+
+    def set_kmer_matrix(self, nrows, ncols, rows, cols, vals):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        cols = np.ascontiguousarray(cols, dtype=np.int64)
+        vals = np.ascontiguousarray(vals, dtype=np.uint32)
+        st = MatrixStats()
+        self._check(self.L.elba_set_kmer_matrix(self.h, nrows, ncols, len(rows), rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, C.byref(st)))
+        return _stats(st)
+
+    # --- stages ---
+    def count_kmers(self):
+        """get_kmer_count_map_keys + get_kmer_count_map_values."""
+        st = KmerStats()
+        self._check(self.L.elba_count_kmers(self.h, C.byref(st)))
+        return _stats(st)
+
+    def create_kmer_matrix(self):
+        st = MatrixStats()
+        self._check(self.L.elba_create_kmer_matrix(self.h, C.byref(st)))
+        return _stats(st)
+
+    def create_seed_matrix(self):
+        st = OverlapStats()
+        self._check(self.L.elba_create_seed_matrix(self.h, C.byref(st)))
+        return _stats(st)
+
+    # --- outputs ---
+    def export_csr(self, row_lo=0, row_hi=None):
+        if row_hi is None:
+            row_hi = self.device_view()["M"]
+        o = Csr()
+        self._check(self.L.elba_export_csr(self.h, row_lo, row_hi, C.byref(o)))
+        try:
+            return dict(M=o.nrows, Y=o.nnz, rowptr=_copy(o.rowptr, o.nrows + 1, np.int64), col=_copy(o.col, o.nnz, np.int64), val=_copy(o.val, o.nnz, SEED_DTYPE))
+        finally:
+            self.L.elba_free_csr(C.byref(o))
+
+    def export_dcsc(self, row_lo, row_hi, col_lo, col_hi):
+        o = Dcsc()
+        self._check(self.L.elba_export_dcsc(self.h, row_lo, row_hi, col_lo, col_hi, C.byref(o)))
+        try:
+            return dict(nnz=o.nnz, nzc=o.nzc, jc=_copy(o.jc, o.nzc, np.int64), cp=_copy(o.cp, o.nzc + 1, np.int64),
+                        ir=_copy(o.ir, o.nnz, np.int64), numx=_copy(o.numx, o.nnz, SEED_DTYPE))
+        finally:
+            self.L.elba_free_dcsc(C.byref(o))
+
+    def export_kmer_matrix(self):
+        o = KmerMatrix()
+        self._check(self.L.elba_export_kmer_matrix(self.h, C.byref(o)))
+        try:
+            return dict(M=o.nrows, N=o.ncols, Z=o.nnz, kmers=_copy(o.kmers, o.ncols, np.uint64) if o.kmers else None,
+                        colptr=_copy(o.colptr, o.ncols + 1, np.int64), csc_read=_copy(o.csc_row, o.nnz, np.int64), csc_pos=_copy(o.csc_val, o.nnz, np.uint32),
+                        rowptr=_copy(o.rowptr, o.nrows + 1, np.int64), csr_kid=_copy(o.csr_col, o.nnz, np.int64), csr_pos=_copy(o.csr_val, o.nnz, np.uint32))
+        finally:
+            self.L.elba_free_kmer_matrix(C.byref(o))
+
+    def kmer_histogram(self, n=None):
+        n = n or self.upper + 2
+        h = np.zeros(n, dtype=np.int64)
+        self._check(self.L.elba_kmer_histogram(self.h, h.ctypes.data, n))
+        return h
+
+    def device_view(self):
+        v = DeviceView()
+        self._check(self.L.elba_get_device_view(self.h, C.byref(v)))
+        return _stats(v)

@@ -1,0 +1,335 @@
+// capi.hip — the extern "C" surface declared in include/elba_amd.h.  Every entry point converts elba::Error into a status
+// code + elba_last_error text; nothing here computes on the CPU except index bookkeeping of exported copies.
+#include "common.hpp"
+#include <new>
+
+using namespace elba;
+
+struct elba_ctx {
+    Ctx c;
+};
+
+namespace {
+
+template <class F>
+int guarded(elba_ctx *ctx, F &&f)
+{
+    if (!ctx) return ELBA_ERR_INVALID_ARG;
+    try {
+        ELBA_HIP(hipSetDevice(ctx->c.device));
+        f(ctx->c);
+        return ELBA_OK;
+    } catch (const Error &e) {
+        ctx->c.last_error = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        ctx->c.last_error = "host allocation failed";
+        return ELBA_ERR_OUT_OF_MEMORY;
+    } catch (...) {
+        ctx->c.last_error = "unknown exception";
+        return ELBA_ERR_INTERNAL;
+    }
+}
+
+template <class T>
+T *host_alloc(size_t n)
+{
+    T *p = static_cast<T *>(malloc((n ? n : 1) * sizeof(T)));
+    if (!p) throw std::bad_alloc();
+    return p;
+}
+
+template <class T>
+std::vector<T> download(Ctx &c, const void *d, size_t n)
+{
+    std::vector<T> h(n);
+    if (n) ELBA_HIP(hipMemcpyAsync(h.data(), d, n * sizeof(T), hipMemcpyDeviceToHost, c.stream));
+    ELBA_HIP(hipStreamSynchronize(c.stream));
+    return h;
+}
+
+}  // namespace
+
+extern "C" {
+
+int elba_abi_version(void) { return ELBA_ABI_VERSION; }
+
+const char *elba_strerror(int status)
+{
+    switch (status) {
+    case ELBA_OK: return "ok";
+    case ELBA_ERR_INVALID_ARG: return "invalid argument";
+    case ELBA_ERR_NO_DEVICE: return "no HIP device available (this library has no CPU fallback)";
+    case ELBA_ERR_HIP: return "HIP runtime error";
+    case ELBA_ERR_OUT_OF_MEMORY: return "out of memory";
+    case ELBA_ERR_STATE: return "stage called out of order";
+    case ELBA_ERR_UNSUPPORTED: return "unsupported configuration";
+    case ELBA_ERR_INTERNAL: return "internal error";
+    default: return "unknown status";
+    }
+}
+
+const char *elba_last_error(const elba_ctx *ctx) { return ctx ? ctx->c.last_error.c_str() : "null context"; }
+
+int elba_ctx_create(elba_ctx **out, const elba_cfg *cfg)
+{
+    if (!out || !cfg) return ELBA_ERR_INVALID_ARG;
+    *out = nullptr;
+    // include/compiletime.h:10,21: k odd, 2 < k < 96, 0 < L <= U <= 65535.  Here: one 64-bit word per k-mer (k <= 31).
+    if (cfg->k < 3 || !(cfg->k & 1) || cfg->k >= 96) return ELBA_ERR_INVALID_ARG;
+    if (cfg->lower < 1 || cfg->lower > cfg->upper || cfg->upper > 65535) return ELBA_ERR_INVALID_ARG;
+    if (cfg->k > 31) return ELBA_ERR_UNSUPPORTED;
+    if (cfg->lower < 2) return ELBA_ERR_UNSUPPORTED;   // LOWER == 1 is nondeterministic in the reference
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ELBA_ERR_NO_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return ELBA_ERR_INVALID_ARG;
+    elba_ctx *ctx = new (std::nothrow) elba_ctx();
+    if (!ctx) return ELBA_ERR_OUT_OF_MEMORY;
+    ctx->c.cfg = *cfg;
+    ctx->c.device = cfg->device;
+    int rc = guarded(ctx, [&](Ctx &c) {
+        ELBA_HIP(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+        hipDeviceProp_t prop;
+        ELBA_HIP(hipGetDeviceProperties(&prop, c.device));
+        c.num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    });
+    if (rc != ELBA_OK) { delete ctx; return rc; }
+    *out = ctx;
+    return ELBA_OK;
+}
+
+void elba_ctx_destroy(elba_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->c.device);
+    if (ctx->c.stream) { (void)hipStreamSynchronize(ctx->c.stream); (void)hipStreamDestroy(ctx->c.stream); }
+    delete ctx;
+}
+
+static void check_reads_host(const uint64_t *byte_off, const uint32_t *len, int64_t nreads, int64_t *packed_bytes)
+{
+    int64_t end = 0;
+    for (int64_t r = 0; r < nreads; ++r) {
+        int64_t e = (int64_t)byte_off[r] + ((int64_t)len[r] + 3) / 4;
+        if (e > end) end = e;
+    }
+    *packed_bytes = end;
+}
+
+int elba_set_reads(elba_ctx *ctx, const uint8_t *packed, const uint64_t *byte_off, const uint32_t *len, int64_t nreads, int64_t first_global_id)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(nreads >= 0 && (nreads == 0 || (packed && byte_off && len)), ELBA_ERR_INVALID_ARG, "set_reads: null array");
+        ELBA_REQUIRE(nreads < 0xFFFFFFFFll, ELBA_ERR_UNSUPPORTED, "set_reads: more than 2^32-1 reads on one GPU");
+        int64_t pb = 0;
+        check_reads_host(byte_off, len, nreads, &pb);
+        c.own_packed.reserve((size_t)pb + 16);       // +16: the enumerate kernel reads whole 8-byte windows
+        c.own_byte_off.reserve((size_t)(nreads + 1) * 8);
+        c.own_len.reserve((size_t)(nreads + 1) * 4);
+        ELBA_HIP(hipMemsetAsync(c.own_packed.p, 0, (size_t)pb + 16, c.stream));
+        if (pb) ELBA_HIP(hipMemcpyAsync(c.own_packed.p, packed, (size_t)pb, hipMemcpyHostToDevice, c.stream));
+        if (nreads) {
+            ELBA_HIP(hipMemcpyAsync(c.own_byte_off.p, byte_off, (size_t)nreads * 8, hipMemcpyHostToDevice, c.stream));
+            ELBA_HIP(hipMemcpyAsync(c.own_len.p, len, (size_t)nreads * 4, hipMemcpyHostToDevice, c.stream));
+        }
+        ELBA_HIP(hipStreamSynchronize(c.stream));
+        c.d_packed = c.own_packed.as<uint8_t>(); c.d_byte_off = c.own_byte_off.as<uint64_t>(); c.d_len = c.own_len.as<uint32_t>();
+        c.h_len.assign(len, len + nreads);
+        c.h_byte_off.assign(byte_off, byte_off + nreads);
+        c.nreads = nreads; c.first_global_id = first_global_id; c.packed_bytes = pb;
+        c.have_reads = true; c.have_counts = false;
+    });
+}
+
+int elba_set_reads_device(elba_ctx *ctx, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads, int64_t first_global_id)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(nreads >= 0 && packed_bytes >= 0 && (nreads == 0 || (d_packed && d_byte_off && d_len)), ELBA_ERR_INVALID_ARG, "set_reads_device: null array");
+        ELBA_REQUIRE(nreads < 0xFFFFFFFFll, ELBA_ERR_UNSUPPORTED, "set_reads_device: more than 2^32-1 reads on one GPU");
+        // the packed buffer is copied once device-to-device so that the 16 guard bytes behind it exist; offsets/lengths are borrowed
+        c.own_packed.reserve((size_t)packed_bytes + 16);
+        ELBA_HIP(hipMemsetAsync(c.own_packed.p, 0, (size_t)packed_bytes + 16, c.stream));
+        if (packed_bytes) ELBA_HIP(hipMemcpyAsync(c.own_packed.p, d_packed, (size_t)packed_bytes, hipMemcpyDeviceToDevice, c.stream));
+        c.d_packed = c.own_packed.as<uint8_t>();
+        c.d_byte_off = static_cast<const uint64_t *>(d_byte_off);
+        c.d_len = static_cast<const uint32_t *>(d_len);
+        c.h_len = download<uint32_t>(c, d_len, (size_t)nreads);
+        c.h_byte_off = download<uint64_t>(c, d_byte_off, (size_t)nreads);
+        for (int64_t r = 0; r < nreads; ++r)
+            ELBA_REQUIRE((int64_t)c.h_byte_off[r] + ((int64_t)c.h_len[r] + 3) / 4 <= packed_bytes, ELBA_ERR_INVALID_ARG, "set_reads_device: read exceeds the packed buffer");
+        c.nreads = nreads; c.first_global_id = first_global_id; c.packed_bytes = packed_bytes;
+        c.have_reads = true; c.have_counts = false;
+    });
+}
+
+int elba_count_kmers(elba_ctx *ctx, elba_kmer_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        stage_count_kmers(c);
+        if (stats) *stats = c.kstats;
+    });
+}
+
+int elba_create_kmer_matrix(elba_ctx *ctx, elba_matrix_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        EventTimer t;
+        t.start(c.stream);
+        stage_create_kmer_matrix(c);
+        t.stop(c.stream);
+        if (stats) { stats->nrows = c.M; stats->ncols = c.N; stats->nnz = c.Z; stats->max_row_nnz = c.max_row_nnz; stats->ms_total = t.ms(); }
+    });
+}
+
+int elba_set_kmer_matrix(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t *rows, const int64_t *cols, const uint32_t *vals, elba_matrix_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        EventTimer t;
+        t.start(c.stream);
+        stage_set_kmer_matrix(c, nrows, ncols, nnz, rows, cols, vals);
+        t.stop(c.stream);
+        if (stats) { stats->nrows = c.M; stats->ncols = c.N; stats->nnz = c.Z; stats->max_row_nnz = c.max_row_nnz; stats->ms_total = t.ms(); }
+    });
+}
+
+int elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        stage_create_seed_matrix(c);
+        if (stats) *stats = c.ostats;
+    });
+}
+
+int elba_export_csr(elba_ctx *ctx, int64_t row_lo, int64_t row_hi, elba_csr_t *out)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(out, ELBA_ERR_INVALID_ARG, "export_csr: null output");
+        memset(out, 0, sizeof(*out));
+        ELBA_REQUIRE(c.have_B, ELBA_ERR_STATE, "export_csr: no seed matrix");
+        ELBA_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= c.M, ELBA_ERR_INVALID_ARG, "export_csr: bad row range");
+        auto rp = download<int64_t>(c, c.b_rowptr.as<int64_t>() + row_lo, (size_t)(row_hi - row_lo + 1));
+        const int64_t e0 = rp.front(), e1 = rp.back(), n = e1 - e0;
+        auto col = download<uint32_t>(c, c.b_col.as<uint32_t>() + e0, (size_t)n);
+        out->nrows = row_hi - row_lo; out->ncols = c.M; out->nnz = n;
+        out->rowptr = host_alloc<int64_t>((size_t)(row_hi - row_lo + 1));
+        out->col = host_alloc<int64_t>((size_t)n);
+        out->val = host_alloc<elba_seed_t>((size_t)n);
+        for (size_t i = 0; i < rp.size(); ++i) out->rowptr[i] = rp[i] - e0;
+        for (int64_t i = 0; i < n; ++i) out->col[i] = col[(size_t)i];
+        if (n) ELBA_HIP(hipMemcpyAsync(out->val, c.b_val.as<elba_seed_t>() + e0, (size_t)n * sizeof(elba_seed_t), hipMemcpyDeviceToHost, c.stream));
+        ELBA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+void elba_free_csr(elba_csr_t *c)
+{
+    if (!c) return;
+    free(c->rowptr); free(c->col); free(c->val);
+    memset(c, 0, sizeof(*c));
+}
+
+int elba_export_dcsc(elba_ctx *ctx, int64_t row_lo, int64_t row_hi, int64_t col_lo, int64_t col_hi, elba_dcsc_t *out)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(out, ELBA_ERR_INVALID_ARG, "export_dcsc: null output");
+        memset(out, 0, sizeof(*out));
+        ELBA_REQUIRE(c.have_B, ELBA_ERR_STATE, "export_dcsc: no seed matrix");
+        ELBA_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= c.M && col_lo >= 0 && col_lo <= col_hi && col_hi <= c.M, ELBA_ERR_INVALID_ARG, "export_dcsc: bad block");
+        // rows [row_lo,row_hi) of the device CSR -> host; column-major regrouping is index bookkeeping on the exported copy
+        auto rp = download<int64_t>(c, c.b_rowptr.as<int64_t>() + row_lo, (size_t)(row_hi - row_lo + 1));
+        const int64_t e0 = rp.front(), n = rp.back() - e0;
+        auto col = download<uint32_t>(c, c.b_col.as<uint32_t>() + e0, (size_t)n);
+        auto val = download<elba_seed_t>(c, c.b_val.as<elba_seed_t>() + e0, (size_t)n);
+        const int64_t ncols = col_hi - col_lo;
+        std::vector<int64_t> cnt((size_t)ncols + 1, 0);
+        int64_t total = 0;
+        for (int64_t e = 0; e < n; ++e) { int64_t j = col[(size_t)e]; if (j >= col_lo && j < col_hi) { cnt[(size_t)(j - col_lo)]++; ++total; } }
+        int64_t nzc = 0;
+        for (int64_t j = 0; j < ncols; ++j) if (cnt[(size_t)j]) ++nzc;
+        out->nrows = row_hi - row_lo; out->ncols = ncols; out->nnz = total; out->nzc = nzc;
+        out->jc = host_alloc<int64_t>((size_t)nzc);
+        out->cp = host_alloc<int64_t>((size_t)nzc + 1);
+        out->ir = host_alloc<int64_t>((size_t)total);
+        out->numx = host_alloc<elba_seed_t>((size_t)total);
+        std::vector<int64_t> start((size_t)ncols + 1, 0);
+        int64_t run = 0, ci = 0;
+        for (int64_t j = 0; j < ncols; ++j) {
+            start[(size_t)j] = run;
+            if (cnt[(size_t)j]) { out->jc[ci] = j; out->cp[ci] = run; ++ci; }
+            run += cnt[(size_t)j];
+        }
+        out->cp[nzc] = run;
+        for (int64_t r = 0; r < row_hi - row_lo; ++r)
+            for (int64_t e = rp[(size_t)r] - e0; e < rp[(size_t)r + 1] - e0; ++e) {
+                int64_t j = col[(size_t)e];
+                if (j >= col_lo && j < col_hi) { int64_t d = start[(size_t)(j - col_lo)]++; out->ir[d] = r; out->numx[d] = val[(size_t)e]; }
+            }
+    });
+}
+
+void elba_free_dcsc(elba_dcsc_t *d)
+{
+    if (!d) return;
+    free(d->jc); free(d->cp); free(d->ir); free(d->numx);
+    memset(d, 0, sizeof(*d));
+}
+
+int elba_export_kmer_matrix(elba_ctx *ctx, elba_kmer_matrix_t *out)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(out, ELBA_ERR_INVALID_ARG, "export_kmer_matrix: null output");
+        memset(out, 0, sizeof(*out));
+        ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "export_kmer_matrix: no k-mer matrix");
+        const size_t M = (size_t)c.M, N = (size_t)c.N, Z = (size_t)c.Z;
+        auto rp = download<uint32_t>(c, c.a_rowptr.p, M + 1);
+        auto cp = download<uint32_t>(c, c.a_colptr.p, N + 1);
+        auto csr = download<uint64_t>(c, c.a_csr.p, Z);
+        auto csc = download<uint64_t>(c, c.a_csc.p, Z);
+        out->nrows = c.M; out->ncols = c.N; out->nnz = c.Z;
+        out->colptr = host_alloc<int64_t>(N + 1); out->rowptr = host_alloc<int64_t>(M + 1);
+        out->csc_row = host_alloc<int64_t>(Z); out->csc_val = host_alloc<uint32_t>(Z);
+        out->csr_col = host_alloc<int64_t>(Z); out->csr_val = host_alloc<uint32_t>(Z);
+        for (size_t i = 0; i <= N; ++i) out->colptr[i] = cp[i];
+        for (size_t i = 0; i <= M; ++i) out->rowptr[i] = rp[i];
+        for (size_t z = 0; z < Z; ++z) {
+            out->csc_row[z] = (int64_t)(csc[z] >> 32) + c.first_global_id_rows(); out->csc_val[z] = (uint32_t)csc[z];
+            out->csr_col[z] = (int64_t)(csr[z] >> 32); out->csr_val[z] = (uint32_t)csr[z];
+        }
+        if (c.A_has_kmers) {
+            out->kmers = host_alloc<uint64_t>(N);
+            if (N) ELBA_HIP(hipMemcpyAsync(out->kmers, c.rel_kmers.p, N * 8, hipMemcpyDeviceToHost, c.stream));
+            ELBA_HIP(hipStreamSynchronize(c.stream));
+        }
+    });
+}
+
+void elba_free_kmer_matrix(elba_kmer_matrix_t *m)
+{
+    if (!m) return;
+    free(m->kmers); free(m->colptr); free(m->csc_row); free(m->csc_val); free(m->rowptr); free(m->csr_col); free(m->csr_val);
+    memset(m, 0, sizeof(*m));
+}
+
+int elba_kmer_histogram(elba_ctx *ctx, int64_t *hist, int64_t len)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(hist && len > 0, ELBA_ERR_INVALID_ARG, "kmer_histogram: null output");
+        ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "kmer_histogram: no k-mer matrix");
+        auto cp = download<uint32_t>(c, c.a_colptr.p, (size_t)c.N + 1);
+        for (int64_t i = 0; i < len; ++i) hist[i] = 0;
+        for (int64_t k = 0; k < c.N; ++k) { int64_t n = (int64_t)cp[(size_t)k + 1] - cp[(size_t)k]; if (n < len) hist[n]++; }
+    });
+}
+
+int elba_get_device_view(elba_ctx *ctx, elba_device_view *v)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(v, ELBA_ERR_INVALID_ARG, "get_device_view: null output");
+        memset(v, 0, sizeof(*v));
+        v->stream = (void *)c.stream;
+        if (c.have_A) { v->M = c.M; v->N = c.N; v->Z = c.Z; v->a_rowptr = c.a_rowptr.p; v->a_csr = c.a_csr.p; v->a_colptr = c.a_colptr.p; v->a_csc = c.a_csc.p; }
+        if (c.have_B) { v->Y = c.Y; v->b_rowptr = c.b_rowptr.p; v->b_col = c.b_col.p; v->b_val = c.b_val.p; }
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// Internal declarations shared by the HIP translation units of libelba_amd.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/elba_amd.h"
+
+namespace elba {
+
+struct Error {
+    int code;
+    std::string msg;
+};
+
+#define ELBA_HIP(expr)                                                                                   \
+    do {                                                                                                 \
+        hipError_t e__ = (expr);                                                                         \
+        if (e__ != hipSuccess) {                                                                         \
+            throw ::elba::Error{e__ == hipErrorOutOfMemory ? ELBA_ERR_OUT_OF_MEMORY : ELBA_ERR_HIP,      \
+                                std::string(#expr) + ": " + hipGetErrorString(e__) + " (" + __FILE__ +  \
+                                    ":" + std::to_string(__LINE__) + ")"};                               \
+        }                                                                                                \
+    } while (0)
+
+#define ELBA_REQUIRE(cond, code, text)                       \
+    do {                                                     \
+        if (!(cond)) throw ::elba::Error{(code), (text)};    \
+    } while (0)
+
+// Growable device buffer (never shrinks; capacity is reused across calls so the steady state allocates nothing).
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    ~DevBuf() { release(); }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    void reserve(size_t bytes)
+    {
+        if (bytes <= cap) return;
+        release();
+        size_t want = bytes + (bytes >> 3) + 256;   // slack so that small growth does not reallocate
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { want = bytes; e = hipMalloc(&p, want); }
+        if (e != hipSuccess) { p = nullptr; throw Error{ELBA_ERR_OUT_OF_MEMORY, "hipMalloc of " + std::to_string(bytes) + " bytes failed"}; }
+        cap = want;
+    }
+    template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+struct EventTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    void init() { if (!a) { ELBA_HIP(hipEventCreate(&a)); ELBA_HIP(hipEventCreate(&b)); } }
+    void start(hipStream_t s) { init(); ELBA_HIP(hipEventRecord(a, s)); }
+    void stop(hipStream_t s) { ELBA_HIP(hipEventRecord(b, s)); }
+    float ms() { float t = 0; ELBA_HIP(hipEventSynchronize(b)); ELBA_HIP(hipEventElapsedTime(&t, a, b)); return t; }
+    ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+};
+
+// ---- primitives (prims.hip) -------------------------------------------------------------------------------------
+// Exclusive prefix sums; in and out may alias.  tmp is grown as needed.
+void exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, int64_t n, DevBuf &tmp);
+void exclusive_scan_u32_to_i64(hipStream_t s, const uint32_t *in, int64_t *out, int64_t n, DevBuf &tmp);
+// Stable LSD radix sort of (key u64, value u64) pairs on key bits [bit_lo, bit_hi).  Ping-pongs between the two
+// buffer pairs; returns 0 if the result is in (k0,v0), 1 if in (k1,v1).
+int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
+void fill_u32(hipStream_t s, uint32_t *p, uint32_t v, int64_t n);
+void fill_u64(hipStream_t s, uint64_t *p, uint64_t v, int64_t n);
+// ptr[k] = first index z with keys[z] >= k, for k in [0, nkeys]; keys ascending (sorted group ids -> CSR/CSC pointers)
+void group_offsets_u32(hipStream_t s, const uint64_t *sorted_keys, int key_shift, int64_t n, uint32_t *ptr, int64_t nkeys);
+uint64_t reduce_max_u64(hipStream_t s, const uint64_t *p, int64_t n, DevBuf &tmp);   // synchronises
+
+// ---- context ----------------------------------------------------------------------------------------------------
+struct Ctx {
+    elba_cfg cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    int num_cus = 256;
+
+    // reads (DnaBuffer layout)
+    int64_t nreads = 0, first_global_id = 0, packed_bytes = 0;
+    const uint8_t *d_packed = nullptr;     // either owned (own_*) or borrowed from the caller
+    const uint64_t *d_byte_off = nullptr;
+    const uint32_t *d_len = nullptr;
+    DevBuf own_packed, own_byte_off, own_len;
+    bool have_reads = false;
+    std::vector<uint32_t> h_len;           // host copy of lengths (instance offsets are a host-side prefix sum)
+    std::vector<uint64_t> h_byte_off;
+
+    // k-mer stage results (device)
+    bool have_counts = false;
+    int64_t I = 0, ndistinct = 0;
+    DevBuf inst_off;      // u64[M+1] instance offset of each read
+    DevBuf tab_keys;      // u64[cap]  open-addressed k-mer table
+    DevBuf tab_vals;      // u32[cap]  count, later k-mer id (or 0xFFFFFFFF = not reliable)
+    int64_t tab_cap = 0;
+    DevBuf rel_kmers;     // u64[N] reliable k-mers ascending (right-aligned value order == packed order)
+    DevBuf rel_counts;    // u32[N]
+    elba_kmer_stats kstats{};
+
+    // A (device)
+    bool have_A = false;
+    bool A_has_kmers = false;
+    int64_t M = 0, N = 0, Z = 0, max_row_nnz = 0, max_col_nnz = 0;
+    DevBuf a_rowptr, a_csr, a_colptr, a_csc;   // u32[M+1], u64[Z], u32[N+1], u64[Z]
+    // rows of an A built from reads are local read indices; exported triples carry global ids (src/KmerOps.cpp:215-219)
+    int64_t first_global_id_rows() const { return A_has_kmers ? first_global_id : 0; }
+
+    // B (device)
+    bool have_B = false;
+    int64_t Y = 0;
+    DevBuf b_rowptr, b_col, b_val;             // i64[M+1], u32[Y], elba_seed_t[Y]
+    elba_overlap_stats ostats{};
+
+    // workspaces
+    DevBuf ws_scan, ws_sort, ws_a, ws_b, ws_c, ws_d, ws_e, ws_f;
+    DevBuf ov_rowub, ov_rowcnt, ov_rowoff, ov_lists, ov_counters, ov_tmp_col, ov_tmp_val, ov_gtable, ov_sortkeys;
+    int64_t ov_tmp_cap = 0;
+
+    EventTimer t_total, t_a, t_b, t_c;
+};
+
+// ---- stages -----------------------------------------------------------------------------------------------------
+void stage_count_kmers(Ctx &c);                                   // kmer.hip
+void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
+void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip
+void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
+
+}  // namespace elba

@@ -1,0 +1,304 @@
+// kmer.hip — k-mer front end on the GPU: packed 2-bit reads -> reliable canonical k-mers -> A (CSC + CSR).
+//
+// Replaces get_kmer_count_map_keys / get_kmer_count_map_values / create_kmer_matrix (src/KmerOps.cpp:18-401) and the
+// explicit transpose (src/main.cpp:272-273).  The reference's Bloom filter + HyperLogLog + two all-to-all passes have
+// one net effect when LOWER >= 2: a canonical k-mer is kept iff its total instance count c obeys
+// LOWER <= c <= UPPER, and every instance of a kept k-mer becomes one entry (read, pos).  That is computed here exactly:
+//
+//   pass 1  k_kmer_count     every k-mer instance -> canonical packed value (rolling-free: each lane rebuilds its window from two
+//                            aligned 8-byte loads of the 2-bit stream, reverse complement by bit tricks) -> open-addressed
+//                            HBM table (u64 key CAS + u32 count add)
+//           k_table_select   table sweep, wave-ballot compaction of the keys with LOWER <= count <= UPPER
+//           radix sort       reliable keys by value: k-mer id = rank (canonical order)
+//   pass 2  k_kmer_lookup    second enumeration (the reference also enumerates twice, src/KmerOps.cpp:219), table lookup,
+//                            scatter of (read,pos) into the k-mer's column; columns (<= UPPER entries) are then sorted in
+//                            registers so the result does not depend on arrival order
+//           CSR              stable radix sort of the CSC stream by read (matrix.hip)
+//
+// Packed k-mer layout (src/Kmer.cpp:67-87): base i at bits 2*(31-i), low 64-2k bits zero; canonical = min(kmer, twin)
+// (src/Kmer.cpp:200-205); position = forward start index (include/KmerOps.hpp:91-103).
+#include "common.hpp"
+#include "matrix.hpp"
+
+namespace elba {
+
+namespace {
+
+constexpr uint64_t KEMPTY = ~0ull;
+constexpr uint32_t NOT_RELIABLE = 0xFFFFFFFFu;
+constexpr int EN_ITEMS = 8;                    // instances per lane
+constexpr int EN_THREADS = 256;
+constexpr int EN_PER_WAVE = 64 * EN_ITEMS;
+constexpr int EN_PER_BLOCK = EN_THREADS * EN_ITEMS;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL; k ^= k >> 33;
+    return k;
+}
+
+__device__ __forceinline__ uint64_t twin64(uint64_t w, int k)
+{
+    uint64_t x = ~w;
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);
+    return x << (2 * (32 - k));
+}
+
+struct EnumParams {
+    const uint8_t *packed; const uint64_t *byte_off; const uint32_t *len; const uint64_t *inst_off;
+    uint32_t nreads; uint64_t I; int k;
+};
+
+// canonical k-mer of read `r` at position `p` (two aligned 8-byte loads; the buffer carries 16 guard bytes)
+__device__ __forceinline__ uint64_t canonical_at(const EnumParams &e, uint32_t r, uint32_t p)
+{
+    const uint64_t b = e.byte_off[r] + (p >> 2);
+    const uint64_t a = b & ~7ull;
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(e.packed + a);
+    const uint64_t hi = __builtin_bswap64(w[0]), lo = __builtin_bswap64(w[1]);
+    const uint32_t sh = (uint32_t)(b - a) * 8 + 2 * (p & 3);              // 0..62
+    const uint64_t win = sh ? ((hi << sh) | (lo >> (64 - sh))) : hi;
+    const uint64_t fwd = win & (~0ull << (64 - 2 * e.k));
+    const uint64_t tw = twin64(fwd, e.k);
+    return tw < fwd ? tw : fwd;
+}
+
+// Calls f(instance index g, read r, pos p, canonical k-mer) for the EN_ITEMS instances of this lane; instances of a wave are
+// consecutive, so the read is found by ONE binary search per wave plus a short forward walk.
+template <class F>
+__device__ __forceinline__ void for_each_instance(const EnumParams &e, F &&f)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * EN_THREADS + threadIdx.x) >> 6;
+    const uint64_t g0 = wave * EN_PER_WAVE;
+    if (g0 >= e.I) return;
+    uint32_t lo = 0, hi = e.nreads;                 // last r with inst_off[r] <= g0
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (e.inst_off[mid] <= g0) lo = mid; else hi = mid;
+    }
+    uint32_t r = lo;
+#pragma unroll
+    for (int it = 0; it < EN_ITEMS; ++it) {
+        const uint64_t g = g0 + (uint64_t)it * 64 + lane;
+        if (g >= e.I) break;
+        while (g >= e.inst_off[r + 1]) ++r;         // reads shorter than k have empty ranges and are skipped here
+        const uint32_t p = (uint32_t)(g - e.inst_off[r]);
+        f(g, r, p, canonical_at(e, r, p));
+    }
+}
+
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_count(EnumParams e, unsigned long long *keys, uint32_t *vals, uint64_t capmask)
+{
+    for_each_instance(e, [&](uint64_t, uint32_t, uint32_t, uint64_t km) {
+        uint64_t slot = mix64(km) & capmask;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)KEMPTY, (unsigned long long)km);
+            if (old == KEMPTY || old == km) break;
+            slot = (slot + 1) & capmask;
+        }
+        atomicAdd(&vals[slot], 1u);
+    });
+}
+
+struct SelCounters { unsigned long long distinct, reliable, entries; };
+
+__global__ __launch_bounds__(256) void k_table_select(const uint64_t *keys, uint32_t *vals, uint64_t cap, uint32_t lower, uint32_t upper,
+                                                      uint64_t *out_keys, uint64_t *out_slots, SelCounters *ctr)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt = (1ull << lane) - 1;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long nd = 0, nz = 0;
+    for (uint64_t s0 = (uint64_t)blockIdx.x * blockDim.x; s0 < cap; s0 += stride) {     // block-uniform trip count
+        const uint64_t s = s0 + threadIdx.x;
+        bool keep = false;
+        uint64_t km = 0;
+        if (s < cap) {
+            km = keys[s];
+            if (km != KEMPTY) {
+                ++nd;
+                const uint32_t c = vals[s];
+                keep = c >= lower && c <= upper;
+                if (keep) nz += c; else vals[s] = NOT_RELIABLE;
+            }
+        }
+        const uint64_t bal = __ballot(keep);
+        if (bal) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&ctr->reliable, (unsigned long long)__popcll(bal));
+            base = __shfl(base, 0, 64);
+            if (keep) { const uint64_t at = base + __popcll(bal & lt); out_keys[at] = km; out_slots[at] = s; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_xor(nd, d, 64); nz += __shfl_xor(nz, d, 64); }
+    if (lane == 0) { if (nd) atomicAdd(&ctr->distinct, nd); if (nz) atomicAdd(&ctr->entries, nz); }
+}
+
+__global__ void k_assign_ids(const uint64_t *sorted_slots, uint32_t *vals, uint32_t *counts, uint64_t N)
+{
+    const uint64_t kid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (kid >= N) return;
+    const uint64_t slot = sorted_slots[kid];
+    counts[kid] = vals[slot];
+    vals[slot] = (uint32_t)kid;
+}
+
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_lookup(EnumParams e, const uint64_t *keys, const uint32_t *vals, uint64_t capmask,
+                                                            const uint32_t *colptr, uint32_t *fill, uint64_t *csc)
+{
+    for_each_instance(e, [&](uint64_t, uint32_t r, uint32_t p, uint64_t km) {
+        uint64_t slot = mix64(km) & capmask;
+        while (keys[slot] != km) slot = (slot + 1) & capmask;     // every instance was inserted in pass 1
+        const uint32_t kid = vals[slot];
+        if (kid != NOT_RELIABLE) {
+            const uint32_t at = atomicAdd(&fill[kid], 1u);
+            csc[colptr[kid] + at] = ((uint64_t)r << 32) | p;
+        }
+    });
+}
+
+// one lane per column: sort its (<= UPPER) entries ascending as u64 == by (read, pos); also emits the column id of every entry
+__global__ void k_sort_columns(const uint32_t *colptr, uint64_t *csc, uint64_t *kid_keys, uint64_t N)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t c0 = colptr[k], c1 = colptr[k + 1];
+    for (uint32_t a = c0 + 1; a < c1; ++a) {
+        const uint64_t v = csc[a];
+        uint32_t b = a;
+        while (b > c0 && csc[b - 1] > v) { csc[b] = csc[b - 1]; --b; }
+        csc[b] = v;
+    }
+    for (uint32_t a = c0; a < c1; ++a) kid_keys[a] = k;
+}
+
+int next_pow2_bits(uint64_t v)
+{
+    int b = 0;
+    while ((1ull << b) < v) ++b;
+    return b;
+}
+
+EnumParams make_enum(Ctx &c)
+{
+    EnumParams e{};
+    e.packed = c.d_packed; e.byte_off = c.d_byte_off; e.len = c.d_len; e.inst_off = c.inst_off.as<uint64_t>();
+    e.nreads = (uint32_t)c.nreads; e.I = (uint64_t)c.I; e.k = c.cfg.k;
+    return e;
+}
+
+}  // namespace
+
+void stage_count_kmers(Ctx &c)
+{
+    ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "count_kmers: no reads (call elba_set_reads)");
+    hipStream_t s = c.stream;
+    const int k = c.cfg.k;
+    const int64_t M = c.nreads;
+    c.have_counts = false; c.have_A = false; c.have_B = false;
+    elba_kmer_stats st{};
+    st.nreads = M;
+
+    // instance offsets: a host prefix sum over the read lengths (include/KmerOps.hpp:118-119: reads shorter than k contribute nothing)
+    std::vector<uint64_t> off((size_t)M + 1);
+    uint64_t I = 0;
+    for (int64_t r = 0; r < M; ++r) { off[(size_t)r] = I; if ((int64_t)c.h_len[(size_t)r] >= k) I += (uint64_t)c.h_len[(size_t)r] - k + 1; }
+    off[(size_t)M] = I;
+    ELBA_REQUIRE(I < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: more than 2^32 k-mer instances on one GPU");
+    c.I = (int64_t)I;
+    c.inst_off.reserve((size_t)(M + 1) * 8);
+    ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s));
+
+    // table: load factor <= 1/2 (distinct <= I)
+    int cbits = next_pow2_bits(2 * I + 2);
+    if (cbits < 10) cbits = 10;
+    size_t free_b = 0, total_b = 0;
+    ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
+    while (cbits > 10 && ((size_t)12 << cbits) > free_b / 2 + c.tab_keys.cap + c.tab_vals.cap && (1ull << (cbits - 1)) > I + I / 4) --cbits;
+    const uint64_t cap = 1ull << cbits;
+    c.tab_cap = (int64_t)cap;
+    c.tab_keys.reserve((size_t)cap * 8);
+    c.tab_vals.reserve((size_t)cap * 4);
+
+    c.t_total.start(s);
+    c.t_a.start(s);
+    ELBA_HIP(hipMemsetAsync(c.tab_keys.p, 0xFF, (size_t)cap * 8, s));
+    ELBA_HIP(hipMemsetAsync(c.tab_vals.p, 0, (size_t)cap * 4, s));
+    EnumParams e = make_enum(c);
+    const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+    if (I > 0)
+        hipLaunchKernelGGL(k_kmer_count, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.tab_keys.as<unsigned long long>(), c.tab_vals.as<uint32_t>(), cap - 1);
+    c.t_a.stop(s);
+
+    // select reliable keys
+    c.t_b.start(s);
+    c.ws_scan.reserve(256);
+    SelCounters *dctr = c.ws_scan.as<SelCounters>();
+    ELBA_HIP(hipMemsetAsync(dctr, 0, sizeof(SelCounters), s));
+    // worst case every distinct k-mer is reliable: N <= I / lower
+    const uint64_t maxN = I / (uint64_t)c.cfg.lower + 1;
+    c.ws_a.reserve(maxN * 8); c.ws_b.reserve(maxN * 8); c.ws_c.reserve(maxN * 8); c.ws_d.reserve(maxN * 8);
+    {
+        int nb = c.num_cus * 8;
+        hipLaunchKernelGGL(k_table_select, dim3(nb), dim3(256), 0, s, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap,
+                           (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), dctr);
+    }
+    SelCounters hc{};
+    ELBA_HIP(hipMemcpyAsync(&hc, dctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    const uint64_t N = hc.reliable, Z = hc.entries;
+    ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
+    // k-mer ids = rank of the packed value
+    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)N, 64 - 2 * k, 64, c.ws_sort);
+    const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>();
+    const uint64_t *sslots = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
+    c.rel_kmers.reserve((size_t)(N + 1) * 8);
+    c.rel_counts.reserve((size_t)(N + 2) * 4);
+    if (N > 0) {
+        ELBA_HIP(hipMemcpyAsync(c.rel_kmers.p, skeys, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_assign_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, sslots, c.tab_vals.as<uint32_t>(), c.rel_counts.as<uint32_t>(), N);
+    }
+    c.t_b.stop(s);
+    c.t_total.stop(s);
+    ELBA_HIP(hipStreamSynchronize(s));
+    st.instances = (int64_t)I; st.distinct = (int64_t)hc.distinct; st.reliable = (int64_t)N; st.entries = (int64_t)Z;
+    st.ms_total = c.t_total.ms(); st.ms_count = c.t_a.ms(); st.ms_sort = c.t_b.ms(); st.ms_lookup = 0;
+    c.ndistinct = (int64_t)hc.distinct;
+    c.N = (int64_t)N; c.Z = (int64_t)Z;
+    c.kstats = st;
+    c.have_counts = true;
+}
+
+void stage_create_kmer_matrix(Ctx &c)
+{
+    ELBA_REQUIRE(c.have_counts, ELBA_ERR_STATE, "create_kmer_matrix: no k-mer counts (call elba_count_kmers)");
+    hipStream_t s = c.stream;
+    const int64_t M = c.nreads, N = c.N, Z = c.Z;
+    c.have_A = false; c.have_B = false;
+    c.t_c.start(s);
+    c.a_colptr.reserve((size_t)(N + 2) * 4);
+    c.a_csc.reserve((size_t)(Z + 1) * 8);
+    // colptr = exclusive scan of the per-k-mer counts
+    ELBA_HIP(hipMemsetAsync(c.rel_counts.as<uint32_t>() + N, 0, 4, s));
+    exclusive_scan_u32(s, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), N + 1, c.ws_scan);
+    c.ws_e.reserve((size_t)(N + 1) * 4);
+    c.ws_f.reserve((size_t)(Z + 1) * 8);
+    ELBA_HIP(hipMemsetAsync(c.ws_e.p, 0, (size_t)(N + 1) * 4, s));
+    EnumParams e = make_enum(c);
+    const uint64_t nblocks = ((uint64_t)c.I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+    if (c.I > 0)
+        hipLaunchKernelGGL(k_kmer_lookup, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(),
+                           (uint64_t)c.tab_cap - 1, c.a_colptr.as<uint32_t>(), c.ws_e.as<uint32_t>(), c.a_csc.as<uint64_t>());
+    if (N > 0)
+        hipLaunchKernelGGL(k_sort_columns, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.ws_f.as<uint64_t>(), (uint64_t)N);
+    c.t_c.stop(s);
+    c.A_has_kmers = true;
+    finish_matrix_from_sorted_csc(c, M, N, Z, c.ws_f.as<uint64_t>(), 0, c.a_csc.as<uint64_t>());
+    c.kstats.ms_lookup = c.t_c.ms();
+}
+
+}  // namespace elba

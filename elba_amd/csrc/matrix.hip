@@ -1,0 +1,144 @@
+// matrix.hip — device construction of A in both orientations.
+//   CSC(A)  = the reference's AT (src/main.cpp:272-273): column k-mer, entries (read, pos) ordered by (read, pos)
+//   CSR(A)  = the reference's A  (src/KmerOps.cpp:361-401): row read, entries (kid, pos) ordered by (kid, pos)
+// Entries are single u64 words (hi = read or kid, lo = pos) so that one 8-byte load fetches an entry and a row /
+// column segment sorted as u64 is in canonical order.  Duplicate (read,kid) entries are kept (SumDuplicates=false,
+// src/KmerOps.cpp:400).
+#include "common.hpp"
+#include "matrix.hpp"
+
+namespace elba {
+
+namespace {
+
+__global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, const uint64_t *csc, int64_t Z, uint64_t *row_keys, uint64_t *csr_vals)
+{
+    int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    uint64_t kid = kid_keys[z] >> kid_shift;
+    uint64_t e = csc[z];
+    row_keys[z] = e >> 32;                                   // read
+    csr_vals[z] = (kid << 32) | (e & 0xFFFFFFFFull);         // kid | pos
+}
+
+__global__ void k_colrow_to_csc(const uint64_t *colrow, const uint64_t *pos, int64_t Z, uint64_t *csc)
+{
+    int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    csc[z] = ((colrow[z] & 0xFFFFFFFFull) << 32) | (pos[z] & 0xFFFFFFFFull);
+}
+
+__global__ void k_max_seg_len(const uint32_t *ptr, int64_t nseg, unsigned long long *out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long m = 0;
+    for (; i < nseg; i += stride) {
+        unsigned long long l = ptr[i + 1] - ptr[i];
+        m = l > m ? l : m;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        unsigned long long o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+int bits_for(uint64_t maxval)
+{
+    int b = 1;
+    while (b < 64 && (maxval >> b)) ++b;
+    return b;
+}
+
+}  // namespace
+
+int64_t max_segment_len(Ctx &c, const uint32_t *ptr, int64_t nseg)
+{
+    if (nseg <= 0) return 0;
+    c.ws_scan.reserve(64);
+    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, c.stream));
+    int64_t nb = (nseg + 255) / 256;
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(k_max_seg_len, dim3((unsigned)nb), dim3(256), 0, c.stream, ptr, nseg, c.ws_scan.as<unsigned long long>());
+    uint64_t h = 0;
+    ELBA_HIP(hipMemcpyAsync(&h, c.ws_scan.p, 8, hipMemcpyDeviceToHost, c.stream));
+    ELBA_HIP(hipStreamSynchronize(c.stream));
+    return (int64_t)h;
+}
+
+// Input: Z entries sorted by (kid, read, pos): kid_keys[z] >> kid_shift = kid, csc[z] = read<<32|pos (device, in c.a_csc or elsewhere).
+// Produces c.a_colptr, c.a_csc (copy if csc is not already c.a_csc), c.a_rowptr, c.a_csr, max_row_nnz, max_col_nnz.
+void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, const uint64_t *kid_keys, int kid_shift, const uint64_t *csc)
+{
+    hipStream_t s = c.stream;
+    c.M = M; c.N = N; c.Z = Z;
+    c.a_colptr.reserve((size_t)(N + 1) * 4);
+    c.a_rowptr.reserve((size_t)(M + 1) * 4);
+    c.a_csc.reserve((size_t)(Z + 1) * 8);
+    c.a_csr.reserve((size_t)(Z + 1) * 8);
+    group_offsets_u32(s, kid_keys, kid_shift, Z, c.a_colptr.as<uint32_t>(), N);
+    if (csc != c.a_csc.as<uint64_t>() && Z > 0)
+        ELBA_HIP(hipMemcpyAsync(c.a_csc.p, csc, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+    // stable sort by read: rows come out ordered by (kid, pos)
+    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_b.reserve((size_t)(Z + 1) * 8);
+    c.ws_c.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
+    uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
+    if (Z > 0) {
+        int64_t nb = (Z + 255) / 256;
+        hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nb), dim3(256), 0, s, kid_keys, kid_shift, c.a_csc.as<uint64_t>(), Z, k0, v0);
+    }
+    int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, bits_for((uint64_t)(M > 0 ? M - 1 : 0)), c.ws_sort);
+    const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;
+    group_offsets_u32(s, rk, 0, Z, c.a_rowptr.as<uint32_t>(), M);
+    if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+    c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
+    c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
+    c.have_A = true;
+    c.have_B = false;
+}
+
+void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals)
+{
+    ELBA_REQUIRE(M >= 0 && N >= 0 && Z >= 0, ELBA_ERR_INVALID_ARG, "negative matrix dimension");
+    ELBA_REQUIRE(M < 0xFFFFFFFFll && N < 0xFFFFFFFFll && Z < 0xFFFFFFFFll, ELBA_ERR_UNSUPPORTED, "matrix dimension beyond 32-bit device indices");
+    ELBA_REQUIRE(Z == 0 || (rows && cols && vals), ELBA_ERR_INVALID_ARG, "null triple array");
+    hipStream_t s = c.stream;
+    std::vector<uint64_t> hk((size_t)Z + 1), hv((size_t)Z + 1);
+    uint32_t maxpos = 0;
+    for (int64_t z = 0; z < Z; ++z) {
+        ELBA_REQUIRE(rows[z] >= 0 && rows[z] < M && cols[z] >= 0 && cols[z] < N, ELBA_ERR_INVALID_ARG, "triple index out of range");
+        hk[(size_t)z] = vals[z];
+        hv[(size_t)z] = ((uint64_t)cols[z] << 32) | (uint64_t)rows[z];
+        if (vals[z] > maxpos) maxpos = vals[z];
+    }
+    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_b.reserve((size_t)(Z + 1) * 8);
+    c.ws_c.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
+    c.ws_e.reserve((size_t)(Z + 1) * 8); c.ws_f.reserve((size_t)(Z + 1) * 8);
+    uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
+    if (Z > 0) {
+        ELBA_HIP(hipMemcpyAsync(k0, hk.data(), (size_t)Z * 8, hipMemcpyHostToDevice, s));
+        ELBA_HIP(hipMemcpyAsync(v0, hv.data(), (size_t)Z * 8, hipMemcpyHostToDevice, s));
+    }
+    // (1) by pos, (2) by row, (3) by col — LSD, stable: final order (col, row, pos)
+    int w = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, bits_for(maxpos), c.ws_sort);
+    // swap roles: key := (col<<32|row), value := pos
+    uint64_t *ck = w ? v1 : v0, *cv = w ? k1 : k0, *ok = w ? v0 : v1, *ov = w ? k0 : k1;
+    int w2 = radix_sort_pairs(s, ck, cv, ok, ov, Z, 0, bits_for((uint64_t)(M > 0 ? M - 1 : 0)), c.ws_sort);
+    if (w2) { uint64_t *t; t = ck; ck = ok; ok = t; t = cv; cv = ov; ov = t; }
+    int w3 = radix_sort_pairs(s, ck, cv, ok, ov, Z, 32, 32 + bits_for((uint64_t)(N > 0 ? N - 1 : 0)), c.ws_sort);
+    if (w3) { uint64_t *t; t = ck; ck = ok; ok = t; t = cv; cv = ov; ov = t; }
+    // ck = (col<<32|row) sorted, cv = pos.  Move the keys out of the ws_a..d pool (finish_* reuses it).
+    uint64_t *keys = c.ws_e.as<uint64_t>();
+    uint64_t *csc = c.ws_f.as<uint64_t>();
+    if (Z > 0) {
+        ELBA_HIP(hipMemcpyAsync(keys, ck, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+        int64_t nb = (Z + 255) / 256;
+        hipLaunchKernelGGL(k_colrow_to_csc, dim3((unsigned)nb), dim3(256), 0, s, ck, cv, Z, csc);
+    }
+    c.A_has_kmers = false;
+    finish_matrix_from_sorted_csc(c, M, N, Z, keys, 32, csc);
+}
+
+}  // namespace elba

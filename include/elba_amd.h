@@ -1,0 +1,189 @@
+/*
+ * elba_amd.h — C ABI of the MI355X-native overlap-detection engine (libelba_amd.so).
+ *
+ * This is the drop-in boundary for ELBA's hot path.  Each entry point names the
+ * reference interface it replaces; all file:line citations are into PASSIONLab/ELBA @ v2.
+ *
+ *   reference (C++/MPI/CombBLAS, one call chain in src/main.cpp:191-285)      this ABI
+ *   -----------------------------------------------------------------------   --------------------------------
+ *   DnaBuffer (include/DnaBuffer.hpp:13-38), index.getmydna() main.cpp:126      elba_set_reads / elba_set_reads_device
+ *   get_kmer_count_map_keys   (include/KmerOps.hpp:27-28, main.cpp:192)   \
+ *   get_kmer_count_map_values (include/KmerOps.hpp:30,    main.cpp:225)   /    elba_count_kmers
+ *   create_kmer_matrix        (include/KmerOps.hpp:24-25, main.cpp:259)   \
+ *   AT = *A; AT->Transpose()  (src/main.cpp:272-273)                      /    elba_create_kmer_matrix
+ *   (A handed over by a caller that already owns it: the SpParMat triples
+ *    of src/KmerOps.cpp:380-400)                                               elba_set_kmer_matrix
+ *   create_seed_matrix        (include/SharedSeeds.hpp:98-99, main.cpp:281)    elba_create_seed_matrix
+ *   Bmat.seqptr()->GetDCSC()  (src/PairwiseAlignment.cpp:16-19)                elba_export_dcsc
+ *   SharedSeeds               (include/SharedSeeds.hpp:8-96)                   elba_seed_t
+ *
+ * Conventions: plain pointers and sizes only; every function returns an int status (ELBA_OK == 0);
+ * host arrays handed in are borrowed for the duration of the call; arrays handed out are owned by
+ * the library and released with the matching elba_free_* call.  One context per process and GPU,
+ * calls on a context are serialised by the caller (the reference is single-threaded per rank on this
+ * path).  The library fails loudly (ELBA_ERR_NO_DEVICE) when no HIP device is present:
+ * there is no CPU fallback.
+ *
+ * Canonical result order: k-mer ids are the ranks of the packed canonical k-mer
+ * values (ascending); entries of a column of A are ordered by (read, pos), of a row by (k-mer id, pos);
+ * B(i,j).seeds[0] / seeds[1] are the products with minimal / maximal (k-mer id, posQ, posT) — what an
+ * ascending-k left fold of SharedSeeds::Semiring::add (include/SharedSeeds.hpp:41-46) yields.
+ */
+#ifndef ELBA_AMD_H_
+#define ELBA_AMD_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ELBA_ABI_VERSION 1
+
+enum {
+    ELBA_OK = 0,
+    ELBA_ERR_INVALID_ARG   = 1,  /* bad pointer / size / (k, lower, upper) outside include/compiletime.h:10,21 */
+    ELBA_ERR_NO_DEVICE     = 2,  /* no HIP device: the product path has no CPU fallback */
+    ELBA_ERR_HIP           = 3,  /* a HIP runtime call failed (elba_last_error has the text) */
+    ELBA_ERR_OUT_OF_MEMORY = 4,
+    ELBA_ERR_STATE         = 5,  /* stage called before its inputs exist */
+    ELBA_ERR_UNSUPPORTED   = 6,  /* k > 31 (NLONGS > 1), index ranges beyond 32 bit */
+    ELBA_ERR_INTERNAL      = 7
+};
+
+typedef struct elba_ctx elba_ctx;
+
+/* SharedSeeds with an explicit field order (the reference's std::tuple pair is laid out reversed in
+ * memory, SURVEY.md a11 — never memcpy into it, use std::get<>). */
+typedef struct { uint32_t q0, t0, q1, t1; int32_t numshared; } elba_seed_t;
+
+typedef struct {
+    int32_t k;          /* KMER_SIZE: odd, 3..31 here (reference: compile-time, Makefile:1) */
+    int32_t lower;      /* LOWER_KMER_FREQ >= 2 (SURVEY.md App. A.4 precondition)            */
+    int32_t upper;      /* UPPER_KMER_FREQ <= 65535                                          */
+    int32_t device;     /* HIP device ordinal                                                */
+    int64_t workspace_hint_bytes; /* 0 = decide from the input; otherwise pre-size the overlap workspace */
+    int32_t flags;      /* reserved, 0 */
+    int32_t reserved;
+} elba_cfg;
+
+typedef struct {
+    int64_t nreads;        /* M                                                       */
+    int64_t instances;     /* I  = sum_reads max(0, len-k+1)                          */
+    int64_t distinct;      /* distinct canonical k-mers seen                          */
+    int64_t reliable;      /* N  = k-mers with lower <= count <= upper                */
+    int64_t entries;       /* Z  = nnz(A)                                             */
+    float   ms_total;      /* device time of the stage (HIP events on the library's stream) */
+    float   ms_count;      /* enumerate + hash-count kernel                           */
+    float   ms_lookup;     /* second enumeration + lookup + compaction                */
+    float   ms_sort;       /* sorts (k-mer ids)                                       */
+} elba_kmer_stats;
+
+typedef struct {
+    int64_t nrows, ncols, nnz;   /* M, N, Z */
+    int64_t max_row_nnz;
+    float   ms_total;
+} elba_matrix_stats;
+
+typedef struct {
+    int64_t nrows;          /* M */
+    int64_t products;       /* P = sum_k c_k^2 (semiring multiplies)                      */
+    int64_t nnz_before_prune; /* Y_raw = nnz of the raw product                            */
+    int64_t nnz;            /* Y = nnz(B) after Prune(numshared <= 1) — the metric's unit */
+    int64_t nnz_diag;       /* diagonal entries kept                                      */
+    int64_t nnz_upper;      /* strict upper triangle = #alignment candidates on one rank  */
+    int64_t max_numshared;
+    int64_t rows_lds;       /* rows accumulated in LDS tables                             */
+    int64_t rows_global;    /* rows spilled to the HBM table path                         */
+    int64_t algorithmic_bytes; /* 16Z + 8(2M+N+3) + 24Y                    */
+    int32_t passes;         /* 1, or 2 when the output workspace had to grow              */
+    int32_t reserved;
+    float   ms_total;       /* whole timed region: resident A -> resident pruned CSR B    */
+    float   ms_symbolic;    /* row upper bounds + binning                                 */
+    float   ms_numeric;     /* hash-accumulate kernels (the dominant kernels)             */
+    float   ms_finalize;    /* row-pointer scan + per-row column sort + copy              */
+} elba_overlap_stats;
+
+/* CombBLAS-shaped DCSC of a block of B with LOCAL indices: exactly the arrays walked by
+ * src/PairwiseAlignment.cpp:28-32 (jc[nzc], cp[nzc+1], ir[nnz], numx[nnz]). */
+typedef struct {
+    int64_t nrows, ncols, nnz, nzc;
+    int64_t *jc, *cp, *ir;
+    elba_seed_t *numx;
+} elba_dcsc_t;
+
+/* B (or a row range of it) as CSR, columns ascending within a row. */
+typedef struct {
+    int64_t nrows, ncols, nnz;
+    int64_t *rowptr;       /* [nrows+1] */
+    int64_t *col;          /* [nnz]     */
+    elba_seed_t *val;      /* [nnz]     */
+} elba_csr_t;
+
+/* A in both orientations, for parity checks and for callers that want CombBLAS triples back. */
+typedef struct {
+    int64_t nrows, ncols, nnz;
+    uint64_t *kmers;       /* [ncols] packed canonical k-mer of each column (NULL if A came from elba_set_kmer_matrix) */
+    int64_t *colptr;       /* [ncols+1] */
+    int64_t *csc_row;      /* [nnz] read id, within a column ordered by (read, pos) */
+    uint32_t *csc_val;     /* [nnz] position */
+    int64_t *rowptr;       /* [nrows+1] */
+    int64_t *csr_col;      /* [nnz] k-mer id, within a row ordered by (kid, pos) */
+    uint32_t *csr_val;     /* [nnz] position */
+} elba_kmer_matrix_t;
+
+/* Device-resident views (HIP pointers, valid until the next stage call / destroy): for consumers that stay on the GPU
+ * (next rows f1/f2 of SURVEY.md §8f) and for the benchmark harness. */
+typedef struct {
+    int64_t M, N, Z, Y;
+    const void *a_rowptr;  /* u32[M+1] */
+    const void *a_csr;     /* u64[Z]: kid<<32 | pos */
+    const void *a_colptr;  /* u32[N+1] */
+    const void *a_csc;     /* u64[Z]: read<<32 | pos */
+    const void *b_rowptr;  /* i64[M+1] */
+    const void *b_col;     /* u32[Y] */
+    const void *b_val;     /* elba_seed_t[Y] */
+    void *stream;          /* hipStream_t the library launches on */
+} elba_device_view;
+
+int  elba_abi_version(void);
+const char *elba_strerror(int status);
+const char *elba_last_error(const elba_ctx *ctx);           /* detail text of the last failure on this context */
+
+int  elba_ctx_create(elba_ctx **out, const elba_cfg *cfg);
+void elba_ctx_destroy(elba_ctx *ctx);
+
+/* DnaBuffer layout (src/DnaSeq.cpp:7-29, src/DnaBuffer.cpp:22-29): read r occupies bytes
+ * [byte_off[r], byte_off[r] + (len[r]+3)/4) of `packed`, 4 bases per byte, first base in bits 7-6.
+ * first_global_id: global id of local read 0 (the reference's MPI_Exscan offset, src/KmerOps.cpp:215). */
+int  elba_set_reads(elba_ctx *ctx, const uint8_t *packed, const uint64_t *byte_off, const uint32_t *len,
+                    int64_t nreads, int64_t first_global_id);
+/* Same, with all three arrays already resident in HBM on cfg.device (no copy; caller keeps them alive). */
+int  elba_set_reads_device(elba_ctx *ctx, const void *d_packed, int64_t packed_bytes, const void *d_byte_off,
+                           const void *d_len, int64_t nreads, int64_t first_global_id);
+
+int  elba_count_kmers(elba_ctx *ctx, elba_kmer_stats *stats);
+int  elba_create_kmer_matrix(elba_ctx *ctx, elba_matrix_stats *stats);
+
+/* A as COO triples in any order (duplicates kept: SumDuplicates=false, src/KmerOps.cpp:400). */
+int  elba_set_kmer_matrix(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz,
+                          const int64_t *rows, const int64_t *cols, const uint32_t *vals, elba_matrix_stats *stats);
+
+int  elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats);
+
+int  elba_export_dcsc(elba_ctx *ctx, int64_t row_lo, int64_t row_hi, int64_t col_lo, int64_t col_hi, elba_dcsc_t *out);
+void elba_free_dcsc(elba_dcsc_t *d);
+int  elba_export_csr(elba_ctx *ctx, int64_t row_lo, int64_t row_hi, elba_csr_t *out);
+void elba_free_csr(elba_csr_t *c);
+int  elba_export_kmer_matrix(elba_ctx *ctx, elba_kmer_matrix_t *out);
+void elba_free_kmer_matrix(elba_kmer_matrix_t *m);
+/* histogram of column counts: hist[c] = #reliable k-mers occurring c times, c in [0, upper] (src/main.cpp:449-485) */
+int  elba_kmer_histogram(elba_ctx *ctx, int64_t *hist, int64_t len);
+
+int  elba_get_device_view(elba_ctx *ctx, elba_device_view *view);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ELBA_AMD_H_ */

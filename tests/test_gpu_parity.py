@@ -1,0 +1,203 @@
+"""-m gpu: the HIP path, called through the C ABI, against the CPU oracle and the committed golden fixtures.
+Bit-exact everywhere (integer / index work)."""
+import os
+
+import numpy as np
+import pytest
+
+import elba_amd
+import gpu_util as gu
+import synth
+import util
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+G = util.GOLDEN
+
+
+def _golden_set(name, meta):
+    seqs = util.read_fasta(os.path.join(G, name + ".fa"))
+    return po.pack_reads(seqs)
+
+
+@pytest.mark.parametrize("name,idx", [("small_err", 0), ("small_clean", 0), ("small_clean", 1)])
+def test_seed_matrix_from_triples_matches_golden_and_oracle(name, idx):
+    """create_seed_matrix alone: A handed over as shuffled COO triples (the reference boundary of include/SharedSeeds.hpp:98-99)."""
+    m = util.golden_meta()[name][idx]
+    k, lo, up = m["k"], m["lower"], m["upper"]
+    gk, gr, gp = util.read_triples(os.path.join(G, "%s_k%d_L%d_U%d.triples" % (name, k, lo, up)))
+    uk, kid = np.unique(gk, return_inverse=True)
+    perm = np.random.default_rng(0).permutation(len(gk))
+    e = elba_amd.Engine(k, lo, up)
+    ms = e.set_kmer_matrix(m["M"], len(uk), gr[perm], kid[perm], gp[perm])
+    assert (ms["nrows"], ms["ncols"], ms["nnz"]) == (m["M"], m["N"], m["Z"])
+    st = e.create_seed_matrix()
+    assert (st["products"], st["nnz_before_prune"], st["nnz"]) == (m["P"], m["Yraw"], m["Y"])
+    gB = e.export_csr()
+    golden = util.read_B(os.path.join(G, "%s_k%d_L%d_U%d.B" % (name, k, lo, up)))
+    assert (util.b_triplets(dict(M=gB["M"], rowptr=gB["rowptr"], col=gB["col"], val=gB["val"])) == golden).all()
+    o = po.Oracle(k, lo, up)
+    o.set_triples(m["M"], len(uk), gr, kid, gp)
+    o.spgemm(2)
+    gu.assert_B_equal(gB, o.B())
+    gu.assert_stats_equal(st, o)
+    e.close()
+
+
+@pytest.mark.parametrize("name,idx", [("small_err", 0), ("small_clean", 0), ("small_clean", 1)])
+def test_full_pipeline_matches_golden_triples(name, idx):
+    """reads -> count -> A: the (kmer, read, pos) triples must equal the ones the reference's KmerOps replay produced."""
+    m = util.golden_meta()[name][idx]
+    k, lo, up = m["k"], m["lower"], m["upper"]
+    packed, off, lens = _golden_set(name, m)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up)
+    assert (ks["instances"], ks["reliable"], ks["entries"]) == (m["I"], m["N"], m["Z"])
+    gA = e.export_kmer_matrix()
+    km, rd, ps = util.triples_from_A(dict(colptr=gA["colptr"], kmers=gA["kmers"], csc_read=gA["csc_read"], csc_pos=gA["csc_pos"]))
+    gk, gr, gp = util.read_triples(os.path.join(G, "%s_k%d_L%d_U%d.triples" % (name, k, lo, up)))
+    assert (km == gk).all() and (rd == gr).all() and (ps == gp).all()
+    o = gu.oracle_run(packed, off, lens, k, lo, up)
+    gu.assert_A_equal(gA, o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    assert (e.kmer_histogram() == o.A()["hist"]).all()
+    e.close()
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_reference_sample_reads(idx):
+    """The reference's bundled reads.fa; figures measured by the survey from the reference's own code."""
+    m = util.golden_meta()["reads_ref_appB"][idx]
+    seqs = util.read_fasta(os.path.join(G, "reads_ref.fa.gz"))
+    packed, off, lens = po.pack_reads(seqs)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, m["k"], m["lower"], m["upper"])
+    assert (ks["nreads"], ks["instances"], ks["reliable"], ks["entries"]) == (m["M"], m["I"], m["N"], m["Z"])
+    assert (st["products"], st["nnz_before_prune"], st["nnz"], st["nnz_upper"], st["max_numshared"]) == (m["P"], m["Yraw"], m["Y"], m["nupper"], m["maxshared"])
+    o = gu.oracle_run(packed, off, lens, m["k"], m["lower"], m["upper"])
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+
+
+def test_medium_noisy_reads_full_pipeline():
+    packed, off, lens, info = elba_amd.synth_reads(21, 400000, 20, 4000, 800, error_rate=0.12)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 8)
+    assert ks["distinct"] == o.stat("ndistinct")
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    assert st["algorithmic_bytes"] == 16 * o.stat("Z") + 8 * (2 * o.stat("M") + o.stat("N") + 3) + 24 * o.stat("Y")
+    e.close()
+
+
+def _concat(sets):
+    packed, off, lens, base = [], [], [], 0
+    for (p, o, l, _) in sets:
+        nb = int(o[-1]) + (int(l[-1]) + 3) // 4 if len(l) else 0
+        packed.append(p[:nb]); off.append(o + np.uint64(base)); lens.append(l); base += nb
+    return np.concatenate(packed + [np.zeros(16, np.uint8)]), np.concatenate(off), np.concatenate(lens)
+
+
+def test_every_table_tier_including_hbm_spill():
+    """A noisy set with very uneven read lengths (row bounds from ~10^2 to ~10^3.5: every LDS tier) plus an error-free, extremely
+    deep set whose per-row partner bound exceeds the largest LDS table (HBM spill path)."""
+    noisy = elba_amd.synth_reads(5, 150000, 14, 2500, 1800, error_rate=0.10, min_len=60)
+    deep = elba_amd.synth_reads(15, 2000, 250, 100, 10, error_rate=0.0, min_len=60)
+    packed, off, lens = _concat([noisy, deep])
+    assert len(lens) > 4300
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 600)
+    assert st["rows_global"] > 1000 and st["rows_lds"] > 500
+    o = gu.oracle_run(packed, off, lens, 17, 2, 600, threads=8)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.close()
+
+
+def test_wide_rows_use_block_and_global_sorts():
+    """Rows with > 64 and > 4096 surviving partners exercise the LDS-bitonic and HBM-bitonic finalize paths."""
+    packed, off, lens, info = elba_amd.synth_reads(6, 200, 2200, 100, 0, error_rate=0.0, min_len=100)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 21, 2, 20000)
+    o = gu.oracle_run(packed, off, lens, 21, 2, 20000, threads=8)
+    assert np.diff(o.B()["rowptr"]).max() > 4096
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.close()
+
+
+def test_staging_overflow_triggers_second_pass_with_identical_result():
+    packed, off, lens, info = elba_amd.synth_reads(8, 60000, 15, 2500, 400, error_rate=0.05)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 12, workspace_hint_bytes=24 * 100)
+    assert st["passes"] == 2
+    o = gu.oracle_run(packed, off, lens, 17, 2, 12)
+    gu.assert_B_equal(e.export_csr(), o.B())
+    st2 = e.create_seed_matrix()          # workspace is now large enough
+    assert st2["passes"] == 1
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+
+
+def test_dcsc_export_is_what_pairwise_alignment_walks():
+    """src/PairwiseAlignment.cpp:28-56 walk over (jc, cp, ir, numx), whole matrix and a 2x2-grid cell, against the oracle's export."""
+    m = util.golden_meta()["small_err"][0]
+    packed, off, lens = _golden_set("small_err", m)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, m["k"], m["lower"], m["upper"])
+    o = gu.oracle_run(packed, off, lens, m["k"], m["lower"], m["upper"])
+    M = m["M"]
+    for (r0, r1, c0, c1) in [(0, M, 0, M), (0, M // 2, M // 2, M), (M // 2, M, 0, M // 2), (3, 3, 0, M)]:
+        g, w = e.export_dcsc(r0, r1, c0, c1), o.export_dcsc(r0, r1, c0, c1)
+        assert g["nnz"] == w["nnz"] and g["nzc"] == w["nzc"]
+        for key in ("jc", "cp", "ir", "numx"):
+            assert (g[key] == w[key]).all(), key
+    full = e.export_dcsc(0, M, 0, M)
+    cand = sum(1 for ci in range(full["nzc"]) for x in range(full["cp"][ci], full["cp"][ci + 1]) if full["ir"][x] < full["jc"][ci])
+    assert cand == st["nnz_upper"]
+    e.close()
+
+
+def test_edge_cases_empty_short_and_N_reads():
+    # no reads at all
+    e = elba_amd.Engine(17, 2, 8)
+    e.set_reads(np.zeros(16, np.uint8), np.zeros(0, np.uint64), np.zeros(0, np.uint32))
+    ks = e.count_kmers(); ms = e.create_kmer_matrix(); st = e.create_seed_matrix()
+    assert (ks["instances"], ks["reliable"], ms["nnz"], st["nnz"]) == (0, 0, 0, 0)
+    assert e.export_csr()["Y"] == 0
+    # reads shorter than k, exactly k, all-N (N -> A), lower-case, duplicated reads, a homopolymer (one k-mer many times > UPPER)
+    rng = np.random.default_rng(4)
+    base = bytes(rng.choice(list(b"ACGT"), 300).tolist())
+    seqs = [b"ACGT", base[:17], base[:17], b"N" * 40, b"n" * 40, base.lower(), base, synth.revcomp(base), b"A" * 16, b"", base[100:260], b"T" * 60]
+    packed, off, lens = po.pack_reads(seqs)
+    for (k, lo, up) in [(17, 2, 8), (17, 2, 200), (5, 2, 50)]:
+        e2, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up)
+        o = gu.oracle_run(packed, off, lens, k, lo, up)
+        gu.assert_A_equal(e2.export_kmer_matrix(), o.A())
+        gu.assert_B_equal(e2.export_csr(), o.B())
+        gu.assert_stats_equal(st, o)
+        e2.close()
+    e.close()
+
+
+def test_stage_order_and_bad_input_errors():
+    e = elba_amd.Engine(17, 2, 8)
+    with pytest.raises(elba_amd.ElbaError) as ei:
+        e.count_kmers()
+    assert ei.value.status == 5
+    with pytest.raises(elba_amd.ElbaError) as ei:
+        e.create_seed_matrix()
+    assert ei.value.status == 5
+    with pytest.raises(elba_amd.ElbaError) as ei:
+        e.set_kmer_matrix(4, 4, [0, 5], [0, 1], [1, 2])
+    assert ei.value.status == 1
+    e.close()
+
+
+def test_repeated_calls_are_deterministic():
+    packed, off, lens, info = elba_amd.synth_reads(9, 80000, 12, 3000, 500, error_rate=0.1)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
+    a = e.export_csr()
+    for _ in range(3):
+        e.create_seed_matrix()
+        b = e.export_csr()
+        assert (a["rowptr"] == b["rowptr"]).all() and (a["col"] == b["col"]).all() and (a["val"] == b["val"]).all()
+    e.close()
