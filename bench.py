@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py — overlap-matrix build throughput (candidate-overlap nnz/s of B = A·Aᵀ, SharedSeeds semiring) on MI355X.
+
+Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches one process per
+GPU with torch.distributed.run.  One JSON line on rank 0.
+
+A "step" is one pass of the hot path's headline region over the synthetic input: device-resident A (CSR + CSC) -> device-resident
+pruned CSR B (reference timer "creating seed matrix (spgemm)", src/main.cpp:280-282), all of it: symbolic bounds, LDS-hash numeric
+kernels, row-pointer scan, per-row sort/copy, and the host synchronisations the C ABI performs.  For N > 1 the step also includes the
+RCCL all-to-all that exchanges the k-mer column panels (the distributed analogue of the SUMMA broadcasts inside the same timer).
+Inputs are resident in HBM when the timed region starts.  The k-mer stage that builds A on the GPU is run (and reported) before the
+timed region.
+
+Workload at N = 1: BASELINE.json configs[1] restated per SURVEY.md §8d-2 ("ecsample30x-like": 16 890 reads, 4.64 Mb genome, 30x,
+len N(8240, 2000) >= 1000, 15 % sub/ins/del error, k=17, L=2, U=8, seed 1).  At N > 1 the same per-GPU read count is kept and the
+genome grows with N (weak scaling): reads are sharded by contiguous row blocks, k-mer columns by hash owner.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (reads per GPU, genome bases per GPU, depth, avg_len, sd_len, min_len, error, k, L, U, seed)
+    "ecsample30x-like": dict(genome=4_640_000, depth=30.0, avg_len=8240.0, sd_len=2000.0, min_len=1000, error=0.15, k=17, lower=2, upper=8, seed=1),
+    "plumbing-135": dict(genome=100_000, depth=13.5, avg_len=10000.0, sd_len=1000.0, min_len=1000, error=0.0, k=17, lower=2, upper=8, seed=313),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="ecsample30x-like", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import elba_amd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    w = WORKLOADS[args.workload]
+    k, lo, up = w["k"], w["lower"], w["upper"]
+
+    def barrier_sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        from elba_amd.capi import Engine
+        t0 = time.time()
+        packed, off, lens, info = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"])
+        t_gen = time.time() - t0
+        eng = Engine(k, lo, up, device=local_rank)
+        # inputs resident in HBM before anything is timed
+        d_packed = torch.from_numpy(packed).cuda(); d_off = torch.from_numpy(off.view(np.int64)).cuda(); d_len = torch.from_numpy(lens.view(np.int32)).cuda()
+        eng.set_reads_device(d_packed.data_ptr(), int(packed.size) - 16, d_off.data_ptr(), d_len.data_ptr(), len(lens))
+        torch.cuda.synchronize()
+        t0 = time.time(); ks = eng.count_kmers(); ms = eng.create_kmer_matrix(); torch.cuda.synchronize(); t_kmer_wall = time.time() - t0
+        runner = eng
+        step = eng.create_seed_matrix
+        extra_cfg = {}
+    else:
+        from elba_amd.distributed import DistributedOverlap
+        runner = DistributedOverlap(k, lo, up, device=local_rank, rank=rank, world=world, dist=dist)
+        t0 = time.time()
+        info = runner.generate_and_set_reads(w, weak=True)
+        t_gen = time.time() - t0
+        t0 = time.time(); ks, ms = runner.build_kmer_matrix(); torch.cuda.synchronize(); t_kmer_wall = time.time() - t0
+        step = runner.create_seed_matrix
+        extra_cfg = {"partition": "1D read rows x hash-owned k-mer columns", "exchange": "RCCL all_to_all_single (column panels)"}
+
+    for _ in range(args.warmup):
+        st = step()
+    barrier_sync()
+    t0 = time.perf_counter()
+    acc = dict(ms_total=0.0, ms_numeric=0.0, ms_symbolic=0.0, ms_finalize=0.0)
+    for _ in range(args.steps):
+        st = step()
+        for key in acc:
+            acc[key] += st[key]
+    barrier_sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        tot = torch.tensor([st["nnz"], st["products"], st["algorithmic_bytes"], ks["instances"], ms["nnz"]], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        Y, P, abytes, I_tot, Z_tot = [int(x) for x in tot.tolist()]
+    else:
+        Y, P, abytes, I_tot, Z_tot = st["nnz"], st["products"], st["algorithmic_bytes"], ks["instances"], ms["nnz"]
+    steps = max(1, args.steps)
+    ms_step = dt / steps * 1e3
+    for key in acc:
+        acc[key] /= steps
+
+    # roofline of the dominant kernel (k_spgemm_rows, all table tiers: they jointly process every row once per step).
+    # achieved = algorithmic bytes of this rank's rows / HIP-event duration of those launches on the library's stream.
+    peak_gbs = 8000.0
+    my_bytes = st["algorithmic_bytes"]
+    achieved = my_bytes / (acc["ms_numeric"] * 1e-3) / 1e9 if acc["ms_numeric"] > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
+                traffic = tj.get("hbm_bytes_per_step_dominant_kernel")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_spgemm_rows (LDS-hash numeric, all tiers)", "achieved": round(achieved, 3), "peak": peak_gbs, "unit": "GB/s",
+                "frac": round(achieved / peak_gbs, 6), "traffic": traffic,
+                "algorithmic_bytes_per_step": my_bytes, "bytes_per_nnz": round(my_bytes / max(1, st["nnz"]), 2),
+                "kernel_ms": round(acc["ms_numeric"], 4), "region_ms_device": round(acc["ms_total"], 4),
+                "frac_whole_region": round(my_bytes / (acc["ms_total"] * 1e-3) / 1e9 / peak_gbs, 6) if acc["ms_total"] > 0 else 0.0,
+                "expanded_stream_bytes": 8 * st["products"] + 8 * ms["nnz"] + 24 * st["nnz"]}
+
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import pyoracle as po   # checker + CPU baseline only
+        A = runner.export_kmer_matrix()
+        o = po.Oracle(k, lo, up)
+        rows = np.repeat(np.arange(A["M"], dtype=np.int64), np.diff(A["rowptr"]))
+        o.set_triples(A["M"], A["N"], rows, A["csr_kid"], A["csr_pos"])
+        t0 = time.perf_counter(); o.spgemm(1); t1 = time.perf_counter() - t0
+        ncores = os.cpu_count() or 1
+        t0 = time.perf_counter(); o.spgemm(ncores); tn = time.perf_counter() - t0
+        cpu = {"value": round(o.stat("Y") / t1, 1), "unit": "overlap nnz/s", "cores": 1, "kind": "port",
+               "sample": "the full workload's SpGEMM region (same A, P=%d products) once, oracle/elba_oracle.c orc_spgemm, gcc -O3" % o.stat("P"),
+               "seconds": round(t1, 4), "all_cores": {"value": round(o.stat("Y") / tn, 1), "cores": ncores, "seconds": round(tn, 4)}}
+        B = runner.export_csr(); oB = o.B()
+        parity = bool(B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"]).all() and (B["val"] == oB["val"]).all())
+
+    if rank == 0:
+        out = {
+            "metric": "overlap nnz/sec (A·Aᵀ SpGEMM, SharedSeeds semiring, after Prune(numshared<=1))",
+            "value": round(Y / (dt / steps), 1), "unit": "overlap nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": dict({"workload": args.workload, "reads": int(info["total_reads"]) if "total_reads" in info else None, "k": k, "lower": lo, "upper": up,
+                            "genome": w["genome"] * world, "depth": w["depth"], "error": w["error"], "kmer_instances": I_tot, "nnz_A": Z_tot,
+                            "products": P, "overlap_nnz": Y, "algorithmic_bytes": abytes}, **extra_cfg),
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+            "parity_vs_oracle": parity,
+            "kmer_stage": {"device_ms": round(ks["ms_total"] + ms["ms_total"], 3), "wall_ms": round(t_kmer_wall * 1e3, 3),
+                           "instances_per_s": round(ks["instances"] / max(1e-9, t_kmer_wall), 1), "count_ms": round(ks["ms_count"], 3), "select_sort_ms": round(ks["ms_sort"], 3)},
+            "phases_ms": {key: round(v, 4) for key, v in acc.items()},
+            "gen_s": round(t_gen, 2),
+        }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
