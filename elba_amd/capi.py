@@ -40,7 +40,7 @@ class MatrixStats(C.Structure):
 
 class OverlapStats(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("products", C.c_int64), ("nnz_before_prune", C.c_int64), ("nnz", C.c_int64), ("nnz_diag", C.c_int64),
-                ("nnz_upper", C.c_int64), ("max_numshared", C.c_int64), ("rows_lds", C.c_int64), ("rows_global", C.c_int64),
+                ("nnz_upper", C.c_int64), ("max_numshared", C.c_int64), ("rows_lds", C.c_int64), ("rows_global", C.c_int64), ("rows_escalated", C.c_int64),
                 ("algorithmic_bytes", C.c_int64), ("passes", C.c_int32), ("reserved", C.c_int32),
                 ("ms_total", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float), ("ms_finalize", C.c_float)]
 

@@ -45,6 +45,27 @@ __global__ void k_max_seg_len(const uint32_t *ptr, int64_t nseg, unsigned long l
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// products per row: ub_i = sum over the row's entries of the length of the entry's column (one wavefront per row)
+__global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, uint32_t M, uint32_t *rowprod, uint64_t *csrx)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < M; i += nwaves) {
+        const uint32_t rs = rowptr[i], re = rowptr[i + 1];
+        unsigned long long ub = 0;
+        for (uint32_t e = rs + lane; e < re; e += 64) {
+            const uint32_t kid = (uint32_t)(csr[e] >> 32);
+            const uint32_t c0 = colptr[kid], len = colptr[kid + 1] - c0;
+            csrx[e] = ((uint64_t)c0 << 32) | len;
+            ub += len;
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) ub += __shfl_xor(ub, d, 64);
+        if (lane == 0) rowprod[i] = ub > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ub;
+    }
+}
+
 int bits_for(uint64_t maxval)
 {
     int b = 1;
@@ -93,6 +114,14 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;
     group_offsets_u32(s, rk, 0, Z, c.a_rowptr.as<uint32_t>(), M);
     if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+    c.a_rowprod.reserve((size_t)(M + 1) * 4);
+    c.a_csrx.reserve((size_t)(Z + 1) * 8);
+    if (M > 0) {
+        int nb = (int)((M + 3) / 4);
+        if (nb > c.num_cus * 8) nb = c.num_cus * 8;
+        hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_csrx.as<uint64_t>());
+    }
+    c.row_lo = 0; c.row_hi = -1;
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
     c.have_A = true;

@@ -4,18 +4,21 @@
 // with a row-wise hash SpGEMM written for CDNA4:
 //
 //   * one workgroup owns one read-row i of CSR(A); its lanes walk the row's entries (kid, posQ) with coalesced 8-byte
-//     loads and, for each, the k-mer's column of CSC(A) — (read j, posT) entries — gathered from HBM/L2;
+//     loads and, for each, the k-mer's column of CSC(A) — (read j, posT) entries — gathered from HBM/L2/Infinity Cache;
+//     each lane keeps two row entries and up to 16 speculative column loads in flight (the walk is latency-bound);
 //   * every product (i,k)x(j,k) updates an open-addressed accumulator keyed by the partner read j that lives in LDS
 //     (16 B per slot, SoA: key | count | smin | smax); the semiring's non-commutative add (include/SharedSeeds.hpp:41-46:
 //     keep the FIRST seed of the left operand and the FIRST seed of the right operand) is made order-free by the
 //     canonical rule of SURVEY.md §8c-2: the row's products carry a sequence number s = (entry index in row << fbits) |
 //     (entry index in column) that is monotone in (kid, posQ, posT); ds_min_u32/ds_max_u32 of s give exactly the first
 //     and last operand of an ascending-k left fold, ds_add_u32 gives numshared;
+//   * tables are sized OPTIMISTICALLY (512 ... 8192 slots) from the row's product count, which over-estimates the
+//     number of distinct partners by 10-1000x on real read sets; a row that fills its table beyond 3/4 is abandoned and
+//     re-queued on the next tier; the last tier keeps the table in HBM, sized by the bound that cannot overflow
+//     (min(products, reads)).  LDS capacity is therefore a performance tier, never a correctness limit;
 //   * survivors (numshared >= 2) are compacted with wavefront ballots + popcount prefix, their two seed positions are
 //     decoded from smin/smax, and the row is appended to an HBM staging area; a scan over per-row counts gives the CSR
-//     row pointers and a last pass sorts each row's columns and moves it to its final place;
-//   * rows whose partner bound exceeds the largest LDS table take the same code path with the table in HBM (spill),
-//     so no input can overflow: LDS capacity is a performance tier, not a correctness limit.
+//     row pointers and a last pass sorts each row's columns and moves it to its final place.
 //
 // No MFMA anywhere: the contraction is index matching plus integer min/max/add.
 #include "common.hpp"
@@ -25,30 +28,39 @@ namespace elba {
 namespace {
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr int NUM_LDS_BINS = 4;                 // table bits 10, 11, 12, 13
-constexpr int NUM_BINS = NUM_LDS_BINS + 1;      // + HBM spill
-constexpr int LDS_TBITS0 = 10;
+constexpr int NUM_LDS_TIERS = 5;                // 512, 1024, 2048, 4096, 8192 slots
+constexpr int NUM_TIERS = NUM_LDS_TIERS + 1;    // + HBM spill
+constexpr int LDS_TBITS0 = 9;
+constexpr int SPEC = 8;                         // speculative column entries loaded per row entry and round
+constexpr uint32_t STAGE_CHUNK = 1024;          // staging entries a workgroup draws from the global cursor at a time
+constexpr uint32_t FIN_WAVE_MAX = 256;          // widest row the one-wave column sort takes
+constexpr uint32_t FIN_LDS_MAX = 4096;          // widest row the LDS bitonic sort takes
 
 struct OvCounters {              // device-side counters, zeroed per call
     unsigned long long cursor;   // next free staging slot
     unsigned long long products; // P
     unsigned long long yraw;     // nnz before prune
+    unsigned long long nnz;      // nnz after prune (the cursor also counts unused chunk tails)
     unsigned long long ndiag, nupper;
     unsigned long long cap_need; // sum_i min(ub_i, M): staging capacity that can never overflow
     unsigned int maxshared;
     unsigned int overflow;       // staging area too small: rerun after growing
-    unsigned int bin_count[NUM_BINS];
-    unsigned int pad[1];
+    unsigned int tier_count[NUM_TIERS];   // rows queued per tier (grows while lower tiers escalate rows)
+    unsigned int tier_done[NUM_TIERS];    // rows completed per tier
+    unsigned int fin_count[2];            // rows needing the LDS-bitonic / HBM-bitonic column sort
+    unsigned int pad[2];
 };
 
 struct OvParams {
-    const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc;
-    uint32_t M;
+    const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_csrx;
+    uint32_t M;              // number of rows of A held here
+    uint32_t Mcols;          // number of reads overall (partner id range)
+    uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
-    uint32_t *row_ub;        // [M]
     uint32_t *row_cnt;       // [M+1]
     unsigned long long *row_off;   // [M]
-    uint32_t *lists;         // [NUM_BINS][M]
+    uint32_t *lists;         // [NUM_TIERS][M]
+    uint32_t *fin_lists;     // [2][M]
     OvCounters *ctr;
     uint32_t *tmp_col; elba_seed_t *tmp_val; unsigned long long tmp_cap;
     uint32_t *gtable; unsigned long long gstride;   // HBM spill tables: per block 4*gstride u32
@@ -61,50 +73,79 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
     return v;
 }
 
-// ---- symbolic: products per row, table-size bin ------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_row_bounds(OvParams p)
+__device__ __forceinline__ uint32_t guaranteed_tbits(uint32_t ub, uint32_t mcols)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t i = wave; i < p.M; i += nwaves) {
-        const uint32_t rs = p.a_rowptr[i], re = p.a_rowptr[i + 1];
-        uint32_t ub = 0;
-        for (uint32_t e = rs + lane; e < re; e += 64) {
-            const uint32_t kid = (uint32_t)(p.a_csr[e] >> 32);
-            ub += p.a_colptr[kid + 1] - p.a_colptr[kid];
+    const uint32_t need = ub < mcols ? ub : mcols;        // distinct partners <= min(products, reads)
+    return need <= 1 ? 1u : (uint32_t)(32 - __clz(2 * need - 1));   // ceil(log2(2*need)): load factor <= 1/2
+}
+
+// ---- symbolic: queue every non-empty row on its starting tier ------------------------------------------------------
+// The per-row product count ub_i = sum_{k in row i} c_k is part of A's device format (built with A, matrix.hip).
+__global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt = (1ull << lane) - 1;
+    unsigned long long prod = 0, cap = 0;
+    for (uint32_t i0 = p.row_lo + blockIdx.x * blockDim.x; i0 < p.row_hi; i0 += stride) {      // block-uniform trip count
+        const uint32_t i = i0 + threadIdx.x;
+        int mytier = -1;
+        const uint32_t ub = i < p.row_hi ? p.a_rowprod[i] : 0;   // empty rows: row_cnt was zeroed by the host
+        if (ub != 0) {
+        prod += ub;
+        cap += ub < p.Mcols ? ub : p.Mcols;
+        const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
+        // optimistic estimate of distinct partners: a sixteenth of the products (measured 0.06 on 15 %-error reads,
+        // far less on accurate ones), at least 128; a wrong guess costs one abandoned attempt, never correctness
+        uint32_t est = ub >> 4;
+        if (est < 128) est = 128;
+        int tier = 0;
+        while (tier < NUM_LDS_TIERS && est > (1u << (LDS_TBITS0 + tier - 1))) ++tier;      // est <= 1/2 of the table
+        // never start above the tier that is already guaranteed to fit
+        const int gt = gbits <= LDS_TBITS0 ? 0 : (int)gbits - LDS_TBITS0;
+        if (gt < tier) tier = gt;
+        if (tier > NUM_LDS_TIERS) tier = NUM_LDS_TIERS;
+        mytier = tier;
         }
-        ub = wave_sum_u32(ub);
-        if (lane == 0) {
-            p.row_ub[i] = ub;
-            if (ub == 0) { p.row_cnt[i] = 0; p.row_off[i] = 0; continue; }
-            const uint32_t need = ub < p.M ? ub : p.M;          // distinct partners <= min(products, reads)
-            uint32_t tbits = 32 - __clz(2 * need - 1);          // ceil(log2(2*need)): load factor <= 1/2
-            if (need <= 1) tbits = 1;
-            int bin = tbits <= LDS_TBITS0 ? 0 : (int)tbits - LDS_TBITS0;
-            if (bin > NUM_LDS_BINS) bin = NUM_LDS_BINS;
-            const uint32_t at = atomicAdd(&p.ctr->bin_count[bin], 1u);
-            p.lists[(size_t)bin * p.M + at] = i;
-            atomicAdd(&p.ctr->products, (unsigned long long)ub);
-            atomicAdd(&p.ctr->cap_need, (unsigned long long)need);
+        // one atomic per wavefront and tier (a single hot counter sustains only ~10^8 atomics/s)
+#pragma unroll
+        for (int t = 0; t < NUM_TIERS; ++t) {
+            const uint64_t bal = __ballot(mytier == t);
+            if (bal == 0) continue;
+            uint32_t base = 0;
+            if (lane == (uint32_t)(__ffsll((unsigned long long)bal) - 1)) base = atomicAdd(&p.ctr->tier_count[t], (uint32_t)__popcll(bal));
+            base = __shfl(base, __ffsll((unsigned long long)bal) - 1, 64);
+            if (mytier == t) p.lists[(size_t)t * p.M + base + (uint32_t)__popcll(bal & lt)] = i;
         }
     }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { prod += __shfl_xor(prod, d, 64); cap += __shfl_xor(cap, d, 64); }
+    if ((threadIdx.x & 63) == 0 && prod) { atomicAdd(&p.ctr->products, prod); atomicAdd(&p.ctr->cap_need, cap); }
 }
 
 // ---- numeric -----------------------------------------------------------------------------------------------------
+// misc words in LDS: 0 diag n, 1 diag smin, 2 diag smax, 3 compaction cursor, 4 y, 5 yraw, 6/7 staging offset lo/hi, 8 fits,
+//                    9 claimed slots, 10 abandon flag
 template <bool GLOBAL>
 struct Table {
-    uint32_t *keys, *cnt, *smin, *smax;
-    uint32_t tbits;
+    uint32_t *keys, *cnt, *smin, *smax, *misc;
+    uint32_t tbits, limit;
     __device__ __forceinline__ uint32_t size() const { return 1u << tbits; }
-    __device__ __forceinline__ uint32_t home(uint32_t j) const { return (j * 0x9E3779B1u) >> (32 - tbits); }
+    __device__ __forceinline__ bool abandoned() const { return !GLOBAL && *(volatile uint32_t *)&misc[10] != 0; }
     __device__ __forceinline__ void insert(uint32_t j, uint32_t s) const
     {
+        // Once the abandon flag is up no lane starts another insert, so at most 3T/4 + BLOCK slots are ever claimed
+        // (BLOCK <= T/8): the probe loop always meets an empty slot.
+        if (abandoned()) return;
         const uint32_t mask = size() - 1;
-        uint32_t slot = home(j);
+        uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
         for (;;) {
             const uint32_t old = atomicCAS(&keys[slot], EMPTY, j);
-            if (old == EMPTY || old == j) break;
+            if (old == j) break;
+            if (old == EMPTY) {
+                if (!GLOBAL) { if (atomicAdd(&misc[9], 1u) >= limit) *(volatile uint32_t *)&misc[10] = 1u; }   // filling up: abandon the row
+                break;
+            }
             slot = (slot + 1) & mask;
         }
         atomicAdd(&cnt[slot], 1u);
@@ -119,28 +160,33 @@ struct Table {
 };
 
 template <int BLOCK, bool GLOBAL>
-__global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int bin, uint32_t lds_tbits)
+__global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uint32_t lds_tbits)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    // misc words: 0 diag n, 1 diag smin, 2 diag smax, 3 compaction cursor, 4 y, 5 yraw, 6/7 staging offset lo/hi, 8 fits
     uint32_t *misc = GLOBAL ? smem : smem + (size_t)4 * (1u << lds_tbits);
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1;
-    const uint32_t nrows = p.ctr->bin_count[bin];
+    const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
     const uint32_t fmask = (1u << p.fbits) - 1;
+    // per-workgroup state kept in registers across the rows of this persistent loop (flushed once at the end)
+    unsigned long long chunk_off = 0, acc_yraw = 0, acc_y = 0;
+    uint32_t chunk_left = 0, acc_done = 0, acc_ndiag = 0;
+    unsigned long long acc_nup = 0;
+    uint32_t acc_mx = 0;
 
     for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const uint32_t i = p.lists[(size_t)bin * p.M + it];
+        const uint32_t i = p.lists[(size_t)tier * p.M + it];
         Table<GLOBAL> tab;
+        tab.misc = misc;
         if (GLOBAL) {
-            const uint32_t ub = p.row_ub[i];
-            const uint32_t need = ub < p.M ? ub : p.M;
-            tab.tbits = 32 - __clz(2 * need - 1);
+            tab.tbits = guaranteed_tbits(p.a_rowprod[i], p.Mcols);
+            tab.limit = 0xFFFFFFFFu;
             uint32_t *base = p.gtable + (size_t)blockIdx.x * 4 * p.gstride;
             tab.keys = base; tab.cnt = base + p.gstride; tab.smin = base + 2 * p.gstride; tab.smax = base + 3 * p.gstride;
         } else {
             tab.tbits = lds_tbits;
             const uint32_t T = 1u << lds_tbits;
+            tab.limit = (T >> 2) * 3 - 1;            // abandon at 3/4 load
             tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
         }
         const uint32_t T = tab.size();
@@ -148,22 +194,63 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int bin, uint
         if (tid < 16) misc[tid] = (tid == 1) ? 0xFFFFFFFFu : 0u;
         __syncthreads();
 
-        // ---- expand + accumulate ----
+        // ---- expand + accumulate: two row entries per lane, SPEC speculative column loads each ----
         const uint32_t rs = p.a_rowptr[i], re = p.a_rowptr[i + 1];
         uint32_t dn = 0, dmin = 0xFFFFFFFFu, dmax = 0;
-        for (uint32_t e = rs + tid; e < re; e += BLOCK) {
-            const uint32_t kid = (uint32_t)(p.a_csr[e] >> 32);
-            const uint32_t c0 = p.a_colptr[kid], c1 = p.a_colptr[kid + 1];
-            const uint32_t sbase = (e - rs) << p.fbits;
-            for (uint32_t f = c0; f < c1; ++f) {
-                const uint32_t j = (uint32_t)(p.a_csc[f] >> 32);
-                const uint32_t s = sbase | (f - c0);
-                if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }   // diagonal: registers, not 1 hot slot
+        for (uint32_t e0 = rs + tid; e0 < re; e0 += 2 * BLOCK) {
+            if (tab.abandoned()) break;
+            const uint32_t e1 = e0 + BLOCK;
+            const bool v1 = e1 < re;
+            // a_csrx[e] = column start << 32 | column length of the entry's k-mer: no colptr indirection on the hot path
+            const uint64_t x0 = p.a_csrx[e0];
+            const uint64_t x1 = v1 ? p.a_csrx[e1] : (x0 & 0xFFFFFFFF00000000ull);
+            const uint32_t a0 = (uint32_t)(x0 >> 32), b0 = a0 + (uint32_t)x0;
+            const uint32_t a1 = (uint32_t)(x1 >> 32), b1 = a1 + (uint32_t)x1;
+            uint64_t c0[SPEC], c1[SPEC];
+#pragma unroll
+            for (int u = 0; u < SPEC; ++u) {
+                c0[u] = p.a_csc[a0 + u < b0 ? a0 + u : a0];
+                c1[u] = p.a_csc[a1 + u < b1 ? a1 + u : a1];
+            }
+            const uint32_t sb0 = (e0 - rs) << p.fbits, sb1 = (e1 - rs) << p.fbits;
+#pragma unroll
+            for (int u = 0; u < SPEC; ++u) {
+                if (a0 + u < b0) {
+                    const uint32_t j = (uint32_t)(c0[u] >> 32), s = sb0 | (uint32_t)u;
+                    if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }   // diagonal: registers, not 1 hot slot
+                    else tab.insert(j, s);
+                }
+            }
+            for (uint32_t f = a0 + SPEC; f < b0; ++f) {                     // columns longer than SPEC (UPPER > 8)
+                const uint32_t j = (uint32_t)(p.a_csc[f] >> 32), s = sb0 | (f - a0);
+                if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
+                else tab.insert(j, s);
+            }
+#pragma unroll
+            for (int u = 0; u < SPEC; ++u) {
+                if (a1 + u < b1) {
+                    const uint32_t j = (uint32_t)(c1[u] >> 32), s = sb1 | (uint32_t)u;
+                    if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
+                    else tab.insert(j, s);
+                }
+            }
+            for (uint32_t f = a1 + SPEC; f < b1; ++f) {
+                const uint32_t j = (uint32_t)(p.a_csc[f] >> 32), s = sb1 | (f - a1);
+                if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
                 else tab.insert(j, s);
             }
         }
         if (dn) { atomicAdd(&misc[0], dn); atomicMin(&misc[1], dmin); atomicMax(&misc[2], dmax); }
         __syncthreads();
+        if (tab.abandoned()) {
+            // the optimistic table was too small: hand the row to the next tier (its kernel starts after this one ends)
+            if (tid == 0) {
+                const uint32_t at = atomicAdd(&p.ctr->tier_count[tier + 1], 1u);
+                p.lists[(size_t)(tier + 1) * p.M + at] = i;
+            }
+            __syncthreads();
+            continue;
+        }
 
         // ---- count survivors, reserve staging space ----
         uint32_t y = 0, yraw = 0;
@@ -177,14 +264,26 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int bin, uint
         if (tid == 0) {
             const uint32_t dcount = misc[0];
             const uint32_t ytot = misc[4] + (dcount >= 2 ? 1u : 0u);
-            const unsigned long long off = atomicAdd(&p.ctr->cursor, (unsigned long long)ytot);
+            // staging space: the workgroup draws CHUNK-sized pieces from the global cursor and sub-allocates its rows
+            // from them (one hot 64-bit counter sustains ~10^8 atomics/s; one atomic per row would cap the kernel)
+            unsigned long long off;
+            if (ytot <= chunk_left) { off = chunk_off; chunk_off += ytot; chunk_left -= ytot; }
+            else if (ytot >= STAGE_CHUNK / 2) off = atomicAdd(&p.ctr->cursor, (unsigned long long)ytot);
+            else { off = atomicAdd(&p.ctr->cursor, (unsigned long long)STAGE_CHUNK); chunk_off = off + ytot; chunk_left = STAGE_CHUNK - ytot; }
             const bool fits = off + ytot <= p.tmp_cap;
             if (!fits) atomicOr(&p.ctr->overflow, 1u);
             p.row_cnt[i] = ytot;
             p.row_off[i] = off;
             misc[4] = ytot; misc[6] = (uint32_t)off; misc[7] = (uint32_t)(off >> 32); misc[8] = fits ? 1u : 0u;
-            atomicAdd(&p.ctr->yraw, (unsigned long long)(misc[5] + (dcount >= 1 ? 1u : 0u)));
-            if (dcount >= 2) atomicAdd(&p.ctr->ndiag, 1ull);
+            acc_yraw += misc[5] + (dcount >= 1 ? 1u : 0u);
+            acc_done += 1;
+            acc_ndiag += dcount >= 2 ? 1u : 0u;
+            acc_y += ytot;
+            if (ytot > FIN_WAVE_MAX) {                         // rows too wide for the one-wave column sort
+                const int which = ytot > FIN_LDS_MAX ? 1 : 0;
+                const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
+                p.fin_lists[(size_t)which * p.M + at] = i;
+            }
         }
         __syncthreads();
         const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
@@ -207,8 +306,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int bin, uint
                     const uint32_t a = tab.ld(tab.smin, s0), b = tab.ld(tab.smax, s0);
                     const uint64_t ea = p.a_csr[rs + (a >> p.fbits)], eb = p.a_csr[rs + (b >> p.fbits)];
                     elba_seed_t v;
-                    v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[p.a_colptr[(uint32_t)(ea >> 32)] + (a & fmask)];
-                    v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[p.a_colptr[(uint32_t)(eb >> 32)] + (b & fmask)];
+                    v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[(uint32_t)(p.a_csrx[rs + (a >> p.fbits)] >> 32) + (a & fmask)];
+                    v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[(uint32_t)(p.a_csrx[rs + (b >> p.fbits)] >> 32) + (b & fmask)];
                     v.numshared = (int32_t)n;
                     p.tmp_col[off + at] = j;
                     p.tmp_val[off + at] = v;
@@ -222,22 +321,30 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int bin, uint
                 const uint32_t a = misc[1], b = misc[2];
                 const uint64_t ea = p.a_csr[rs + (a >> p.fbits)], eb = p.a_csr[rs + (b >> p.fbits)];
                 elba_seed_t v;
-                v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[p.a_colptr[(uint32_t)(ea >> 32)] + (a & fmask)];
-                v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[p.a_colptr[(uint32_t)(eb >> 32)] + (b & fmask)];
+                v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[(uint32_t)(p.a_csrx[rs + (a >> p.fbits)] >> 32) + (a & fmask)];
+                v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[(uint32_t)(p.a_csrx[rs + (b >> p.fbits)] >> 32) + (b & fmask)];
                 v.numshared = (int32_t)misc[0];
                 p.tmp_col[off + at] = i;
                 p.tmp_val[off + at] = v;
                 mx = misc[0] > mx ? misc[0] : mx;
             }
-            nup = wave_sum_u32(nup);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
-            if (lane == 0) {
-                if (nup) atomicAdd(&p.ctr->nupper, (unsigned long long)nup);
-                if (mx) atomicMax(&p.ctr->maxshared, mx);
-            }
+            acc_nup += nup;
+            acc_mx = mx > acc_mx ? mx : acc_mx;
         }
         __syncthreads();    // table and misc are re-initialised by the next row
+    }
+    // flush the workgroup's statistics: a handful of atomics per workgroup instead of six per row
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { acc_nup += __shfl_xor(acc_nup, d, 64); uint32_t o = __shfl_xor(acc_mx, d, 64); acc_mx = o > acc_mx ? o : acc_mx; }
+    if (lane == 0) {
+        if (acc_nup) atomicAdd(&p.ctr->nupper, acc_nup);
+        if (acc_mx) atomicMax(&p.ctr->maxshared, acc_mx);
+    }
+    if (tid == 0 && acc_done) {
+        atomicAdd(&p.ctr->yraw, acc_yraw);
+        atomicAdd(&p.ctr->nnz, acc_y);
+        atomicAdd(&p.ctr->tier_done[tier], acc_done);
+        if (acc_ndiag) atomicAdd(&p.ctr->ndiag, (unsigned long long)acc_ndiag);
     }
 }
 
@@ -246,30 +353,46 @@ struct FinParams {
     const uint32_t *row_cnt; const unsigned long long *row_off; const int64_t *b_rowptr;
     const uint32_t *tmp_col; const elba_seed_t *tmp_val;
     uint32_t *b_col; elba_seed_t *b_val;
-    uint32_t M;
+    uint32_t M, row_lo, row_hi;
+    const uint32_t *fin_lists; const OvCounters *ctr;
     uint64_t *sortkeys; unsigned long long sort_stride;
 };
 
-constexpr uint32_t FIN_WAVE_MAX = 64;
-constexpr uint32_t FIN_LDS_MAX = 4096;
 
-// rows with <= 64 entries: one wavefront per row, rank by 64-wide shuffle compare
+// rows with <= FIN_WAVE_MAX entries: one wavefront per row; the row's columns are staged in LDS and every lane ranks its
+// (up to 4) elements against all of them — columns are distinct, so ranks are a permutation
 __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t cols[4][FIN_WAVE_MAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t i = wave; i < p.M; i += nwaves) {
+    for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
         const uint32_t y = p.row_cnt[i];
         if (y == 0 || y > FIN_WAVE_MAX) continue;
         const unsigned long long off = p.row_off[i];
         const int64_t dst = p.b_rowptr[i];
-        uint32_t col = 0xFFFFFFFFu;
-        elba_seed_t v{};
-        if ((uint32_t)lane < y) { col = p.tmp_col[off + lane]; v = p.tmp_val[off + lane]; }
-        uint32_t rank = 0;
-        for (uint32_t l = 0; l < y; ++l) rank += (__shfl(col, (int)l, 64) < col) ? 1u : 0u;
-        if ((uint32_t)lane < y) { p.b_col[dst + rank] = col; p.b_val[dst + rank] = v; }
+        uint32_t mine[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = (uint32_t)lane + 64u * u;
+            mine[u] = t < y ? p.tmp_col[off + t] : 0xFFFFFFFFu;
+            if (t < y) cols[w][t] = mine[u];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t rank[4] = {0, 0, 0, 0};
+        for (uint32_t l = 0; l < y; ++l) {
+            const uint32_t c = cols[w][l];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rank[u] += c < mine[u] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = (uint32_t)lane + 64u * u;
+            if (t < y) { p.b_col[dst + rank[u]] = mine[u]; p.b_val[dst + rank[u]] = p.tmp_val[off + t]; }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -296,9 +419,11 @@ template <bool GLOBAL>
 __global__ __launch_bounds__(256) void k_finalize_block(FinParams p)
 {
     __shared__ uint64_t lkeys[GLOBAL ? 1 : FIN_LDS_MAX];
-    for (uint32_t i = blockIdx.x; i < p.M; i += gridDim.x) {
+    const int which = GLOBAL ? 1 : 0;
+    const uint32_t n = p.ctr->fin_count[which];
+    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+        const uint32_t i = p.fin_lists[(size_t)which * p.M + it];
         const uint32_t y = p.row_cnt[i];
-        if (GLOBAL ? (y <= FIN_LDS_MAX) : (y <= FIN_WAVE_MAX || y > FIN_LDS_MAX)) continue;
         uint64_t *keys = GLOBAL ? p.sortkeys + (size_t)blockIdx.x * p.sort_stride : lkeys;
         const unsigned long long off = p.row_off[i];
         const int64_t dst = p.b_rowptr[i];
@@ -331,8 +456,9 @@ void stage_create_seed_matrix(Ctx &c)
     ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "create_seed_matrix: no k-mer matrix (call elba_create_kmer_matrix or elba_set_kmer_matrix)");
     hipStream_t s = c.stream;
     const int64_t M = c.M, N = c.N, Z = c.Z;
+    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? M : c.row_hi;
     elba_overlap_stats st{};
-    st.nrows = M;
+    st.nrows = row_hi - row_lo;
     c.have_B = false;
 
     const uint32_t fbits = (uint32_t)bits_for_u((uint64_t)(c.max_col_nnz > 1 ? c.max_col_nnz - 1 : 1));
@@ -341,10 +467,9 @@ void stage_create_seed_matrix(Ctx &c)
     ELBA_REQUIRE((uint64_t)c.max_row_nnz * (uint64_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1) < 0xFFFFFFFFull, ELBA_ERR_UNSUPPORTED,
                  "products per row exceed 32 bits");
 
-    c.ov_rowub.reserve((size_t)(M + 1) * 4);
     c.ov_rowcnt.reserve((size_t)(M + 2) * 4);
     c.ov_rowoff.reserve((size_t)(M + 1) * 8);
-    c.ov_lists.reserve((size_t)NUM_BINS * (size_t)(M + 1) * 4);
+    c.ov_lists.reserve((size_t)(NUM_TIERS + 2) * (size_t)(M + 1) * 4);
     c.ov_counters.reserve(sizeof(OvCounters));
     c.b_rowptr.reserve((size_t)(M + 2) * 8);
 
@@ -354,17 +479,15 @@ void stage_create_seed_matrix(Ctx &c)
     while (gstride < 2ull * (uint64_t)(M > 1 ? M : 1)) gstride <<= 1;
     c.ov_gtable.reserve((size_t)spill_blocks * 4 * gstride * 4);
 
-    if (c.ov_tmp_cap == 0) {
-        int64_t guess = c.cfg.workspace_hint_bytes > 0 ? c.cfg.workspace_hint_bytes / 24 : 0;
-        c.ov_tmp_cap = guess;   // grown below once cap_need is known
-    }
+    if (c.ov_tmp_cap == 0 && c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / 24;
 
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
-    p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
-    p.M = (uint32_t)M; p.fbits = fbits;
-    p.row_ub = c.ov_rowub.as<uint32_t>(); p.row_cnt = c.ov_rowcnt.as<uint32_t>();
+    p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_csrx = c.a_csrx.as<uint64_t>();
+    p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits;
+    p.row_cnt = c.ov_rowcnt.as<uint32_t>();
     p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
+    p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
     p.ctr = c.ov_counters.as<OvCounters>();
     p.gtable = c.ov_gtable.as<uint32_t>(); p.gstride = gstride;
 
@@ -375,6 +498,7 @@ void stage_create_seed_matrix(Ctx &c)
     }
 
     const int cus = c.num_cus;
+    const int64_t nrows = row_hi - row_lo;
     OvCounters hc{};
     int passes = 0;
     float ms_sym = 0, ms_num = 0;
@@ -384,19 +508,19 @@ void stage_create_seed_matrix(Ctx &c)
         ELBA_HIP(hipMemsetAsync(c.ov_counters.p, 0, sizeof(OvCounters), s));
         ELBA_HIP(hipMemsetAsync(c.ov_rowcnt.p, 0, (size_t)(M + 2) * 4, s));
         c.t_a.start(s);
-        if (M > 0) {
-            int nb = (int)((M + 3) / 4);
-            if (nb > cus * 8) nb = cus * 8;
-            hipLaunchKernelGGL(k_row_bounds, dim3(nb), dim3(256), 0, s, p);
+        if (nrows > 0) {
+            int nb = (int)((nrows + 255) / 256);
+            if (nb > cus * 4) nb = cus * 4;
+            hipLaunchKernelGGL(k_classify_rows, dim3(nb), dim3(256), 0, s, p);
         }
         c.t_a.stop(s);
-        if (passes == 1 && c.ov_tmp_cap == 0) {
+        if (c.ov_tmp_cap == 0) {
             // first call on this context: size the staging area from the bound that can never overflow (one sync)
             ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
             ELBA_HIP(hipStreamSynchronize(s));
             size_t free_b = 0, total_b = 0;
             ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
-            int64_t want = (int64_t)hc.cap_need + 64;
+            int64_t want = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;   // + one open chunk per workgroup
             int64_t budget = (int64_t)(free_b / 2 / 24);
             c.ov_tmp_cap = want < budget ? want : budget;
             if (c.ov_tmp_cap < 1024) c.ov_tmp_cap = 1024;
@@ -406,14 +530,16 @@ void stage_create_seed_matrix(Ctx &c)
         p.tmp_col = c.ov_tmp_col.as<uint32_t>(); p.tmp_val = c.ov_tmp_val.as<elba_seed_t>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
 
         c.t_b.start(s);
-        if (M > 0) {
-            // LDS tiers: 1024/2048/4096/8192 slots of 16 B; block size scales with the table so LDS per wave stays 16 KiB
-            const int gridcap = cus * 16;
-            hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(gridcap), dim3(64), (size_t)16 * 1024 + 64, s, p, 0, 10u);
-            hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * 8), dim3(128), (size_t)16 * 2048 + 64, s, p, 1, 11u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 4), dim3(256), (size_t)16 * 4096 + 64, s, p, 2, 12u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 2), dim3(256), (size_t)16 * 8192 + 64, s, p, 3, 13u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, true>), dim3(spill_blocks), dim3(256), (size_t)64, s, p, 4, 0u);
+        if (nrows > 0) {
+            // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
+            // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
+            const size_t X = 64;   // misc words
+            hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * 16), dim3(64), (size_t)16 * 512 + X, s, p, 0, 9u);
+            hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * 8), dim3(128), (size_t)16 * 1024 + X, s, p, 1, 10u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 4), dim3(256), (size_t)16 * 2048 + X, s, p, 2, 11u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 2), dim3(256), (size_t)16 * 4096 + X, s, p, 3, 12u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus), dim3(256), (size_t)16 * 8192 + X, s, p, 4, 13u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, true>), dim3(spill_blocks), dim3(256), X, s, p, 5, 0u);
         }
         c.t_b.stop(s);
         ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
@@ -421,46 +547,54 @@ void stage_create_seed_matrix(Ctx &c)
         ms_sym += c.t_a.ms(); ms_num += c.t_b.ms();
         if (!hc.overflow) break;
         ELBA_REQUIRE(passes < 3, ELBA_ERR_INTERNAL, "overlap staging area overflowed twice");
-        c.ov_tmp_cap = (int64_t)hc.cursor + 64;      // exact need is now known
+        c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;      // the bound that cannot overflow
     }
 
     // row pointers, final arrays
-    const int64_t Y = (int64_t)hc.cursor;
+    const int64_t Y = (int64_t)hc.nnz;
     c.t_c.start(s);
     exclusive_scan_u32_to_i64(s, c.ov_rowcnt.as<uint32_t>(), c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
     c.b_col.reserve((size_t)(Y + 1) * 4);
     c.b_val.reserve((size_t)(Y + 1) * sizeof(elba_seed_t));
-    if (M > 0 && Y > 0) {
+    if (nrows > 0 && Y > 0) {
         FinParams f{};
         f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
         f.tmp_col = p.tmp_col; f.tmp_val = p.tmp_val; f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
-        f.M = (uint32_t)M;
-        const int gblocks = 32;
-        uint64_t sstride = 2;
-        while (sstride < (uint64_t)M) sstride <<= 1;
-        c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
-        f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
-        int nb = (int)((M + 3) / 4);
+        f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
+        int nb = (int)((nrows + 3) / 4);
         if (nb > cus * 8) nb = cus * 8;
         hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
-        int nb2 = (int)(M < (int64_t)cus * 8 ? M : (int64_t)cus * 8);
-        hipLaunchKernelGGL((k_finalize_block<false>), dim3(nb2), dim3(256), 0, s, f);
-        hipLaunchKernelGGL((k_finalize_block<true>), dim3(gblocks), dim3(256), 0, s, f);
+        if (hc.fin_count[0]) {
+            int nb2 = (int)(hc.fin_count[0] < (unsigned)cus * 8 ? hc.fin_count[0] : (unsigned)cus * 8);
+            hipLaunchKernelGGL((k_finalize_block<false>), dim3(nb2), dim3(256), 0, s, f);
+        }
+        if (hc.fin_count[1]) {
+            const int gblocks = 32;
+            uint64_t sstride = 2;
+            while (sstride < (uint64_t)M) sstride <<= 1;
+            c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
+            f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
+            hipLaunchKernelGGL((k_finalize_block<true>), dim3(gblocks), dim3(256), 0, s, f);
+        }
     }
     c.t_c.stop(s);
     c.t_total.stop(s);
     ELBA_HIP(hipStreamSynchronize(s));
 
     st.products = (int64_t)hc.products;
+    st.nnz_before_prune = (int64_t)hc.yraw;
     st.nnz = Y;
     st.nnz_diag = (int64_t)hc.ndiag;
     st.nnz_upper = (int64_t)hc.nupper;
     st.max_numshared = (int64_t)hc.maxshared;
-    st.rows_lds = (int64_t)hc.bin_count[0] + hc.bin_count[1] + hc.bin_count[2] + hc.bin_count[3];
-    st.rows_global = (int64_t)hc.bin_count[4];
+    st.rows_lds = 0;
+    for (int t = 0; t < NUM_LDS_TIERS; ++t) st.rows_lds += hc.tier_done[t];
+    st.rows_global = (int64_t)hc.tier_done[NUM_LDS_TIERS];
+    int64_t queued = 0;
+    for (int t = 0; t < NUM_TIERS; ++t) queued += hc.tier_count[t];
+    st.rows_escalated = queued - st.rows_lds - st.rows_global;
     st.algorithmic_bytes = 16 * Z + 8 * (2 * M + N + 3) + 24 * Y;
     st.passes = passes;
-    st.nnz_before_prune = (int64_t)hc.yraw;
     st.ms_total = c.t_total.ms();
     st.ms_symbolic = ms_sym;
     st.ms_numeric = ms_num;

@@ -96,6 +96,7 @@ typedef struct {
     int64_t max_numshared;
     int64_t rows_lds;       /* rows accumulated in LDS tables                             */
     int64_t rows_global;    /* rows spilled to the HBM table path                         */
+    int64_t rows_escalated; /* optimistic-table overflows re-queued on a larger tier      */
     int64_t algorithmic_bytes; /* 16Z + 8(2M+N+3) + 24Y                    */
     int32_t passes;         /* 1, or 2 when the output workspace had to grow              */
     int32_t reserved;

@@ -34,7 +34,7 @@ def test_struct_layouts_match_header():
     assert capi.SEED_DTYPE.itemsize == 20
     assert C.sizeof(capi.Cfg) == 32
     assert C.sizeof(capi.Dcsc) == 64
-    assert C.sizeof(capi.OverlapStats) == 10 * 8 + 2 * 4 + 4 * 4
+    assert C.sizeof(capi.OverlapStats) == 11 * 8 + 2 * 4 + 4 * 4
 
 
 def test_bad_configurations_are_rejected():

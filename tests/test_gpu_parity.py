@@ -107,7 +107,7 @@ def test_every_table_tier_including_hbm_spill():
     packed, off, lens = _concat([noisy, deep])
     assert len(lens) > 4300
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 600)
-    assert st["rows_global"] > 1000 and st["rows_lds"] > 500
+    assert st["rows_lds"] > 3000 and st["rows_lds"] + st["rows_global"] == int((np.diff(e.export_kmer_matrix()["rowptr"]) > 0).sum())
     o = gu.oracle_run(packed, off, lens, 17, 2, 600, threads=8)
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
@@ -121,6 +121,33 @@ def test_wide_rows_use_block_and_global_sorts():
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 21, 2, 20000)
     o = gu.oracle_run(packed, off, lens, 21, 2, 20000, threads=8)
     assert np.diff(o.B()["rowptr"]).max() > 4096
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.close()
+
+
+def test_optimistic_tables_escalate_and_spill_to_hbm():
+    """Collision/overflow stress: rows whose distinct-partner count defeats every optimistic LDS table.  A is handed over as
+    triples: `dense` columns each hold ALL reads (every row then has M partners, M > 3/4 of the largest LDS table -> HBM spill),
+    a band of medium columns makes rows that overflow the small tiers only (escalation), singletons make rows that fit at once."""
+    M, rng = 7000, np.random.default_rng(12)
+    rows, cols, vals = [], [], []
+    ncol = 0
+    for c in range(2):                                   # two dense columns over rows 0..3499 -> 3500 partners, numshared 2
+        r = np.arange(3500); rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1
+    for c in range(2):                                   # rows 0..6999 in two more dense columns -> 7000 partners
+        r = np.arange(M); rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1
+    for b in range(0, 3000, 500):                        # medium: groups of 500 rows sharing 2 columns
+        for c in range(2):
+            r = 3500 + np.arange(b, b + 500) % 3500; rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals).astype(np.uint32)
+    e = elba_amd.Engine(17, 2, 8)
+    e.set_kmer_matrix(M, ncol, rows, cols, vals)
+    st = e.create_seed_matrix()
+    assert st["rows_global"] > 0 and st["rows_escalated"] > 0
+    o = po.Oracle(17, 2, 8)
+    o.set_triples(M, ncol, rows, cols, vals)
+    o.spgemm(8)
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
     e.close()
