@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="ecsample30x-like", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dbg", type=int, default=0, help="diagnostic kernel ablations (results are wrong; never for reporting)")
     args = ap.parse_args()
 
     import torch
@@ -72,7 +73,7 @@ def main():
         t0 = time.time()
         packed, off, lens, info = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"])
         t_gen = time.time() - t0
-        eng = Engine(k, lo, up, device=local_rank)
+        eng = Engine(k, lo, up, device=local_rank, flags=args.dbg)
         # inputs resident in HBM before anything is timed
         d_packed = torch.from_numpy(packed).cuda(); d_off = torch.from_numpy(off.view(np.int64)).cuda(); d_len = torch.from_numpy(lens.view(np.int32)).cuda()
         eng.set_reads_device(d_packed.data_ptr(), int(packed.size) - 16, d_off.data_ptr(), d_len.data_ptr(), len(lens))

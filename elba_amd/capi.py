@@ -158,10 +158,10 @@ class Engine:
     """One context on one GPU.  Method names follow the reference's free functions (include/KmerOps.hpp:24-31,
     include/SharedSeeds.hpp:98-99); each is a single C-ABI call."""
 
-    def __init__(self, k, lower, upper, device=0, workspace_hint_bytes=0):
+    def __init__(self, k, lower, upper, device=0, workspace_hint_bytes=0, flags=0):
         self.L = load_library()
         self.h = C.c_void_p()
-        cfg = Cfg(k, lower, upper, device, workspace_hint_bytes, 0, 0)
+        cfg = Cfg(k, lower, upper, device, workspace_hint_bytes, flags, 0)
         rc = self.L.elba_ctx_create(C.byref(self.h), C.byref(cfg))
         if rc:
             self.h = C.c_void_p()

@@ -28,10 +28,9 @@ namespace elba {
 namespace {
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr int NUM_LDS_TIERS = 5;                // 512, 1024, 2048, 4096, 8192 slots
+constexpr int NUM_LDS_TIERS = 4;                // 512, 1024, 2048, 4096 slots (20 B per slot incl. the survivor list)
 constexpr int NUM_TIERS = NUM_LDS_TIERS + 1;    // + HBM spill
 constexpr int LDS_TBITS0 = 9;
-constexpr int SPEC = 8;                         // speculative column entries loaded per row entry and round
 constexpr uint32_t STAGE_CHUNK = 1024;          // staging entries a workgroup draws from the global cursor at a time
 constexpr uint32_t FIN_WAVE_MAX = 256;          // widest row the one-wave column sort takes
 constexpr uint32_t FIN_LDS_MAX = 4096;          // widest row the LDS bitonic sort takes
@@ -49,6 +48,7 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned int tier_done[NUM_TIERS];    // rows completed per tier
     unsigned int fin_count[2];            // rows needing the LDS-bitonic / HBM-bitonic column sort
     unsigned int pad[2];
+    unsigned long long phase[8];          // diagnostic (cfg.flags & 16): shader-clock cycles per kernel phase, summed over workgroups
 };
 
 struct OvParams {
@@ -57,6 +57,7 @@ struct OvParams {
     uint32_t Mcols;          // number of reads overall (partner id range)
     uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
+    uint32_t dbg;            // diagnostic ablations (cfg.flags): 1 = gathers only (no accumulator updates), 2 = accumulator only (synthetic partners)
     uint32_t *row_cnt;       // [M+1]
     unsigned long long *row_off;   // [M]
     uint32_t *lists;         // [NUM_TIERS][M]
@@ -124,229 +125,7 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
 }
 
 // ---- numeric -----------------------------------------------------------------------------------------------------
-// misc words in LDS: 0 diag n, 1 diag smin, 2 diag smax, 3 compaction cursor, 4 y, 5 yraw, 6/7 staging offset lo/hi, 8 fits,
-//                    9 claimed slots, 10 abandon flag
-template <bool GLOBAL>
-struct Table {
-    uint32_t *keys, *cnt, *smin, *smax, *misc;
-    uint32_t tbits, limit;
-    __device__ __forceinline__ uint32_t size() const { return 1u << tbits; }
-    __device__ __forceinline__ bool abandoned() const { return !GLOBAL && *(volatile uint32_t *)&misc[10] != 0; }
-    __device__ __forceinline__ void insert(uint32_t j, uint32_t s) const
-    {
-        // Once the abandon flag is up no lane starts another insert, so at most 3T/4 + BLOCK slots are ever claimed
-        // (BLOCK <= T/8): the probe loop always meets an empty slot.
-        if (abandoned()) return;
-        const uint32_t mask = size() - 1;
-        uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
-        for (;;) {
-            const uint32_t old = atomicCAS(&keys[slot], EMPTY, j);
-            if (old == j) break;
-            if (old == EMPTY) {
-                if (!GLOBAL) { if (atomicAdd(&misc[9], 1u) >= limit) *(volatile uint32_t *)&misc[10] = 1u; }   // filling up: abandon the row
-                break;
-            }
-            slot = (slot + 1) & mask;
-        }
-        atomicAdd(&cnt[slot], 1u);
-        atomicMin(&smin[slot], s);
-        atomicMax(&smax[slot], s);
-    }
-    __device__ __forceinline__ uint32_t ld(const uint32_t *a, uint32_t slot) const
-    {
-        if (GLOBAL) return __hip_atomic_load(&a[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2, never a stale L1 line
-        return a[slot];
-    }
-};
-
-template <int BLOCK, bool GLOBAL>
-__global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uint32_t lds_tbits)
-{
-    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    uint32_t *misc = GLOBAL ? smem : smem + (size_t)4 * (1u << lds_tbits);
-    const uint32_t tid = threadIdx.x, lane = tid & 63;
-    const uint64_t lt = (1ull << lane) - 1;
-    const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
-    const uint32_t fmask = (1u << p.fbits) - 1;
-    // per-workgroup state kept in registers across the rows of this persistent loop (flushed once at the end)
-    unsigned long long chunk_off = 0, acc_yraw = 0, acc_y = 0;
-    uint32_t chunk_left = 0, acc_done = 0, acc_ndiag = 0;
-    unsigned long long acc_nup = 0;
-    uint32_t acc_mx = 0;
-
-    for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const uint32_t i = p.lists[(size_t)tier * p.M + it];
-        Table<GLOBAL> tab;
-        tab.misc = misc;
-        if (GLOBAL) {
-            tab.tbits = guaranteed_tbits(p.a_rowprod[i], p.Mcols);
-            tab.limit = 0xFFFFFFFFu;
-            uint32_t *base = p.gtable + (size_t)blockIdx.x * 4 * p.gstride;
-            tab.keys = base; tab.cnt = base + p.gstride; tab.smin = base + 2 * p.gstride; tab.smax = base + 3 * p.gstride;
-        } else {
-            tab.tbits = lds_tbits;
-            const uint32_t T = 1u << lds_tbits;
-            tab.limit = (T >> 2) * 3 - 1;            // abandon at 3/4 load
-            tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
-        }
-        const uint32_t T = tab.size();
-        for (uint32_t s = tid; s < T; s += BLOCK) { tab.keys[s] = EMPTY; tab.cnt[s] = 0; tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
-        if (tid < 16) misc[tid] = (tid == 1) ? 0xFFFFFFFFu : 0u;
-        __syncthreads();
-
-        // ---- expand + accumulate: two row entries per lane, SPEC speculative column loads each ----
-        const uint32_t rs = p.a_rowptr[i], re = p.a_rowptr[i + 1];
-        uint32_t dn = 0, dmin = 0xFFFFFFFFu, dmax = 0;
-        for (uint32_t e0 = rs + tid; e0 < re; e0 += 2 * BLOCK) {
-            if (tab.abandoned()) break;
-            const uint32_t e1 = e0 + BLOCK;
-            const bool v1 = e1 < re;
-            // a_csrx[e] = column start << 32 | column length of the entry's k-mer: no colptr indirection on the hot path
-            const uint64_t x0 = p.a_csrx[e0];
-            const uint64_t x1 = v1 ? p.a_csrx[e1] : (x0 & 0xFFFFFFFF00000000ull);
-            const uint32_t a0 = (uint32_t)(x0 >> 32), b0 = a0 + (uint32_t)x0;
-            const uint32_t a1 = (uint32_t)(x1 >> 32), b1 = a1 + (uint32_t)x1;
-            uint64_t c0[SPEC], c1[SPEC];
-#pragma unroll
-            for (int u = 0; u < SPEC; ++u) {
-                c0[u] = p.a_csc[a0 + u < b0 ? a0 + u : a0];
-                c1[u] = p.a_csc[a1 + u < b1 ? a1 + u : a1];
-            }
-            const uint32_t sb0 = (e0 - rs) << p.fbits, sb1 = (e1 - rs) << p.fbits;
-#pragma unroll
-            for (int u = 0; u < SPEC; ++u) {
-                if (a0 + u < b0) {
-                    const uint32_t j = (uint32_t)(c0[u] >> 32), s = sb0 | (uint32_t)u;
-                    if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }   // diagonal: registers, not 1 hot slot
-                    else tab.insert(j, s);
-                }
-            }
-            for (uint32_t f = a0 + SPEC; f < b0; ++f) {                     // columns longer than SPEC (UPPER > 8)
-                const uint32_t j = (uint32_t)(p.a_csc[f] >> 32), s = sb0 | (f - a0);
-                if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
-                else tab.insert(j, s);
-            }
-#pragma unroll
-            for (int u = 0; u < SPEC; ++u) {
-                if (a1 + u < b1) {
-                    const uint32_t j = (uint32_t)(c1[u] >> 32), s = sb1 | (uint32_t)u;
-                    if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
-                    else tab.insert(j, s);
-                }
-            }
-            for (uint32_t f = a1 + SPEC; f < b1; ++f) {
-                const uint32_t j = (uint32_t)(p.a_csc[f] >> 32), s = sb1 | (f - a1);
-                if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
-                else tab.insert(j, s);
-            }
-        }
-        if (dn) { atomicAdd(&misc[0], dn); atomicMin(&misc[1], dmin); atomicMax(&misc[2], dmax); }
-        __syncthreads();
-        if (tab.abandoned()) {
-            // the optimistic table was too small: hand the row to the next tier (its kernel starts after this one ends)
-            if (tid == 0) {
-                const uint32_t at = atomicAdd(&p.ctr->tier_count[tier + 1], 1u);
-                p.lists[(size_t)(tier + 1) * p.M + at] = i;
-            }
-            __syncthreads();
-            continue;
-        }
-
-        // ---- count survivors, reserve staging space ----
-        uint32_t y = 0, yraw = 0;
-        for (uint32_t s = tid; s < T; s += BLOCK) {
-            const uint32_t k = tab.ld(tab.keys, s);
-            if (k != EMPTY) { ++yraw; if (tab.ld(tab.cnt, s) >= 2) ++y; }
-        }
-        y = wave_sum_u32(y); yraw = wave_sum_u32(yraw);
-        if (lane == 0) { atomicAdd(&misc[4], y); atomicAdd(&misc[5], yraw); }
-        __syncthreads();
-        if (tid == 0) {
-            const uint32_t dcount = misc[0];
-            const uint32_t ytot = misc[4] + (dcount >= 2 ? 1u : 0u);
-            // staging space: the workgroup draws CHUNK-sized pieces from the global cursor and sub-allocates its rows
-            // from them (one hot 64-bit counter sustains ~10^8 atomics/s; one atomic per row would cap the kernel)
-            unsigned long long off;
-            if (ytot <= chunk_left) { off = chunk_off; chunk_off += ytot; chunk_left -= ytot; }
-            else if (ytot >= STAGE_CHUNK / 2) off = atomicAdd(&p.ctr->cursor, (unsigned long long)ytot);
-            else { off = atomicAdd(&p.ctr->cursor, (unsigned long long)STAGE_CHUNK); chunk_off = off + ytot; chunk_left = STAGE_CHUNK - ytot; }
-            const bool fits = off + ytot <= p.tmp_cap;
-            if (!fits) atomicOr(&p.ctr->overflow, 1u);
-            p.row_cnt[i] = ytot;
-            p.row_off[i] = off;
-            misc[4] = ytot; misc[6] = (uint32_t)off; misc[7] = (uint32_t)(off >> 32); misc[8] = fits ? 1u : 0u;
-            acc_yraw += misc[5] + (dcount >= 1 ? 1u : 0u);
-            acc_done += 1;
-            acc_ndiag += dcount >= 2 ? 1u : 0u;
-            acc_y += ytot;
-            if (ytot > FIN_WAVE_MAX) {                         // rows too wide for the one-wave column sort
-                const int which = ytot > FIN_LDS_MAX ? 1 : 0;
-                const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
-                p.fin_lists[(size_t)which * p.M + at] = i;
-            }
-        }
-        __syncthreads();
-        const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
-        if (misc[8]) {
-            // ---- ballot compaction + seed decode ----
-            uint32_t nup = 0, mx = 0;
-            for (uint32_t b0 = 0; b0 < T; b0 += BLOCK) {                       // wave-uniform trip count: ballots are safe
-                const uint32_t s0 = b0 + tid;
-                const bool in = s0 < T;
-                uint32_t j = EMPTY, n = 0;
-                if (in) { j = tab.ld(tab.keys, s0); if (j != EMPTY) n = tab.ld(tab.cnt, s0); }
-                const bool keep = n >= 2;
-                const uint64_t bal = __ballot(keep);
-                if (bal == 0) continue;
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&misc[3], (uint32_t)__popcll(bal));
-                base = __shfl(base, 0, 64);
-                if (keep) {
-                    const uint32_t at = base + (uint32_t)__popcll(bal & lt);
-                    const uint32_t a = tab.ld(tab.smin, s0), b = tab.ld(tab.smax, s0);
-                    const uint64_t ea = p.a_csr[rs + (a >> p.fbits)], eb = p.a_csr[rs + (b >> p.fbits)];
-                    elba_seed_t v;
-                    v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[(uint32_t)(p.a_csrx[rs + (a >> p.fbits)] >> 32) + (a & fmask)];
-                    v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[(uint32_t)(p.a_csrx[rs + (b >> p.fbits)] >> 32) + (b & fmask)];
-                    v.numshared = (int32_t)n;
-                    p.tmp_col[off + at] = j;
-                    p.tmp_val[off + at] = v;
-                    if (j > i) ++nup;
-                    mx = n > mx ? n : mx;
-                }
-            }
-            __syncthreads();
-            if (tid == 0 && misc[0] >= 2) {
-                const uint32_t at = misc[3];
-                const uint32_t a = misc[1], b = misc[2];
-                const uint64_t ea = p.a_csr[rs + (a >> p.fbits)], eb = p.a_csr[rs + (b >> p.fbits)];
-                elba_seed_t v;
-                v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[(uint32_t)(p.a_csrx[rs + (a >> p.fbits)] >> 32) + (a & fmask)];
-                v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[(uint32_t)(p.a_csrx[rs + (b >> p.fbits)] >> 32) + (b & fmask)];
-                v.numshared = (int32_t)misc[0];
-                p.tmp_col[off + at] = i;
-                p.tmp_val[off + at] = v;
-                mx = misc[0] > mx ? misc[0] : mx;
-            }
-            acc_nup += nup;
-            acc_mx = mx > acc_mx ? mx : acc_mx;
-        }
-        __syncthreads();    // table and misc are re-initialised by the next row
-    }
-    // flush the workgroup's statistics: a handful of atomics per workgroup instead of six per row
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { acc_nup += __shfl_xor(acc_nup, d, 64); uint32_t o = __shfl_xor(acc_mx, d, 64); acc_mx = o > acc_mx ? o : acc_mx; }
-    if (lane == 0) {
-        if (acc_nup) atomicAdd(&p.ctr->nupper, acc_nup);
-        if (acc_mx) atomicMax(&p.ctr->maxshared, acc_mx);
-    }
-    if (tid == 0 && acc_done) {
-        atomicAdd(&p.ctr->yraw, acc_yraw);
-        atomicAdd(&p.ctr->nnz, acc_y);
-        atomicAdd(&p.ctr->tier_done[tier], acc_done);
-        if (acc_ndiag) atomicAdd(&p.ctr->ndiag, (unsigned long long)acc_ndiag);
-    }
-}
+#include "spgemm_rows.hpp"
 
 // ---- finalize: per-row column sort + move to final CSR ------------------------------------------------------------
 struct FinParams {
@@ -477,14 +256,14 @@ void stage_create_seed_matrix(Ctx &c)
     const int spill_blocks = 64;
     uint64_t gstride = 2;
     while (gstride < 2ull * (uint64_t)(M > 1 ? M : 1)) gstride <<= 1;
-    c.ov_gtable.reserve((size_t)spill_blocks * 4 * gstride * 4);
+    c.ov_gtable.reserve((size_t)spill_blocks * 5 * gstride * 4);
 
     if (c.ov_tmp_cap == 0 && c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / 24;
 
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
     p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_csrx = c.a_csrx.as<uint64_t>();
-    p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits;
+    p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.row_cnt = c.ov_rowcnt.as<uint32_t>();
     p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
     p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
@@ -534,12 +313,12 @@ void stage_create_seed_matrix(Ctx &c)
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
             const size_t X = 64;   // misc words
-            hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * 16), dim3(64), (size_t)16 * 512 + X, s, p, 0, 9u);
-            hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * 8), dim3(128), (size_t)16 * 1024 + X, s, p, 1, 10u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 4), dim3(256), (size_t)16 * 2048 + X, s, p, 2, 11u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 2), dim3(256), (size_t)16 * 4096 + X, s, p, 3, 12u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus), dim3(256), (size_t)16 * 8192 + X, s, p, 4, 13u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, true>), dim3(spill_blocks), dim3(256), X, s, p, 5, 0u);
+            hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * (getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 8)), dim3(64), (size_t)20 * 512 + X, s, p, 0, 9u);
+            hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * 8), dim3(128), (size_t)20 * 1024 + X, s, p, 1, 10u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 4), dim3(256), (size_t)20 * 2048 + X, s, p, 2, 11u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 2), dim3(256), (size_t)20 * 4096 + X, s, p, 3, 12u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, true>), dim3(spill_blocks), dim3(256), X, s, p, NUM_LDS_TIERS, 0u);
+            ELBA_HIP(hipGetLastError());
         }
         c.t_b.stop(s);
         ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
@@ -581,6 +360,10 @@ void stage_create_seed_matrix(Ctx &c)
     c.t_total.stop(s);
     ELBA_HIP(hipStreamSynchronize(s));
 
+    if (c.cfg.flags & 16) {   // diagnostic: per-phase shader-clock totals over all workgroups of the numeric kernels
+        fprintf(stderr, "[elba dbg] phase cycles (sum over %llu workgroups): fetch=%llu init=%llu accumulate=%llu sweep=%llu reserve=%llu decode=%llu\n",
+                hc.phase[6], hc.phase[0], hc.phase[1], hc.phase[2], hc.phase[3], hc.phase[4], hc.phase[5]);
+    }
     st.products = (int64_t)hc.products;
     st.nnz_before_prune = (int64_t)hc.yraw;
     st.nnz = Y;

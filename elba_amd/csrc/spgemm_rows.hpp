@@ -1,0 +1,283 @@
+// spgemm_rows.hpp — the numeric kernel of the overlap SpGEMM (included by spgemm.hip inside its anonymous namespace).
+//
+// One workgroup per row of B.  The kernel is bound by dependent memory round trips, not by bytes or LDS cycles
+// (profiles/: SQ_WAIT_ANY > 50 %, LDS active < 2 % of wave cycles), so it is organised to keep the number of dependent
+// levels per row small and the number of independent loads in flight per lane large:
+//   level 1   entry descriptors of the row (column start | length), coalesced, prefetched one group ahead;
+//   level 2   GRP entries per lane at a time, SPEC column entries each: GRP*SPEC independent 8-byte gathers in flight per
+//             lane, then the LDS accumulator updates for those products;
+//   level 3   one sweep of the table builds the survivor list (ballot + popcount compaction) and the counts;
+//   level 4   all survivors decode their two seeds in parallel (descriptor -> column entry), then store.
+// A row of 834 entries (the median of the ecsample30x-like workload) on a 64-lane workgroup is 1 + 4 + 2 dependent global
+// levels instead of ~30 in the entry-at-a-time form.
+
+// misc words in LDS: 0 diag n, 1 diag smin, 2 diag smax, 3 survivors, 4 y, 5 yraw, 6/7 staging offset lo/hi, 8 fits,
+//                    9 claimed slots, 10 abandon flag
+template <bool GLOBAL>
+struct Table {
+    uint32_t *keys, *cnt, *smin, *smax, *misc;
+    uint32_t tbits, limit;
+    __device__ __forceinline__ uint32_t size() const { return 1u << tbits; }
+    // relaxed workgroup-scope atomics, NOT volatile: a volatile access defeats address-space inference and becomes a FLAT
+    // load/store, which forces s_waitcnt vmcnt(0) lgkmcnt(0) — every insert then drained all gathers in flight
+    __device__ __forceinline__ bool abandoned() const { return !GLOBAL && __hip_atomic_load(&misc[10], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0; }
+    __device__ __forceinline__ void insert(uint32_t j, uint32_t s, bool &full) const
+    {
+        // A lane learns that the table is filling up from the claim counter it bumps when it claims a slot; from then on
+        // it inserts nothing (`full` lives in a register: no per-insert LDS read).  Every lane can overshoot by one claim,
+        // so at most 3T/4 + BLOCK slots are ever claimed (BLOCK <= T/8): the probe loop always meets an empty slot.
+        if (full) return;
+        const uint32_t mask = size() - 1;
+        uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
+        // (A/B measured on MI355X: probing with a plain read before the CAS and guarding min/max with reads is SLOWER —
+        //  0.84 vs 0.76 ms per step — the extra dependent LDS round trips cost more than the atomics they save.)
+        for (;;) {
+            const uint32_t k = atomicCAS(&keys[slot], EMPTY, j);
+            if (k == j) break;
+            if (k == EMPTY) {
+                if (!GLOBAL) { if (atomicAdd(&misc[9], 1u) >= limit) { __hip_atomic_store(&misc[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); full = true; } }   // abandon the row
+                break;
+            }
+            slot = (slot + 1) & mask;
+        }
+        atomicAdd(&cnt[slot], 1u);
+        atomicMin(&smin[slot], s);
+        atomicMax(&smax[slot], s);
+    }
+    __device__ __forceinline__ uint32_t ldrelaxed(const uint32_t *a) const
+    {
+        return __hip_atomic_load(a, __ATOMIC_RELAXED, GLOBAL ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ uint32_t ld(const uint32_t *a, uint32_t slot) const
+    {
+        if (GLOBAL) return __hip_atomic_load(&a[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2, never a stale L1 line
+        return a[slot];
+    }
+};
+
+constexpr int GRP = 4;     // entries whose column gathers are in flight together
+constexpr int SPEC = 8;    // column entries gathered unconditionally per entry; longer columns (UPPER > 8) take a serial tail loop
+
+__device__ __forceinline__ elba_seed_t decode_seed(const OvParams &p, uint32_t rs, uint32_t a, uint32_t b, uint32_t n, uint32_t fmask)
+{
+    const uint32_t ra = rs + (a >> p.fbits), rb = rs + (b >> p.fbits);
+    const uint64_t ea = p.a_csr[ra], eb = p.a_csr[rb];
+    const uint64_t xa = p.a_csrx[ra], xb = p.a_csrx[rb];
+    elba_seed_t v;
+    v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[(uint32_t)(xa >> 32) + (a & fmask)];
+    v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[(uint32_t)(xb >> 32) + (b & fmask)];
+    v.numshared = (int32_t)n;
+    return v;
+}
+
+template <int BLOCK, bool GLOBAL>
+__global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uint32_t lds_tbits)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // LDS tiers: keys | cnt | smin | smax | survivor list (u32 each, T entries) | misc;  spill tier: only misc lives in LDS
+    uint32_t *misc = GLOBAL ? smem : smem + (size_t)5 * (1u << lds_tbits);
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint64_t lt = (1ull << lane) - 1;
+    const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
+    const uint32_t fmask = (1u << p.fbits) - 1;
+    // per-workgroup state kept in registers across the rows of this persistent loop (flushed once at the end)
+    unsigned long long chunk_off = 0, acc_yraw = 0, acc_y = 0;
+    uint32_t chunk_left = 0, acc_done = 0, acc_ndiag = 0;
+    unsigned long long acc_nup = 0;
+    uint32_t acc_mx = 0;
+    // diagnostic phase clock (cfg.flags & 16): 0 fetch row, 1 table init, 2 expand+accumulate, 3 sweep, 4 reserve, 5 decode+store
+    const bool stamp = (p.dbg & 16u) != 0;
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0;
+#define ELBA_STAMP(k) do { if (stamp) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tprev; tprev = tn; } } while (0)
+
+    for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
+        const uint32_t i = p.lists[(size_t)tier * p.M + it];
+        Table<GLOBAL> tab;
+        tab.misc = misc;
+        uint32_t *list;
+        if (GLOBAL) {
+            tab.tbits = guaranteed_tbits(p.a_rowprod[i], p.Mcols);
+            tab.limit = 0xFFFFFFFFu;
+            uint32_t *base = p.gtable + (size_t)blockIdx.x * 5 * p.gstride;
+            tab.keys = base; tab.cnt = base + p.gstride; tab.smin = base + 2 * p.gstride; tab.smax = base + 3 * p.gstride;
+            list = base + 4 * p.gstride;
+        } else {
+            tab.tbits = lds_tbits;
+            const uint32_t T = 1u << lds_tbits;
+            tab.limit = (T >> 2) * 3 - 1;            // abandon at 3/4 load
+            tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
+            list = smem + 4 * T;
+        }
+        const uint32_t T = tab.size();
+        ELBA_STAMP(0);
+        for (uint32_t s = tid; s < T; s += BLOCK) { tab.keys[s] = EMPTY; tab.cnt[s] = 0; tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
+        if (tid < 16) misc[tid] = (tid == 1) ? 0xFFFFFFFFu : 0u;
+        __syncthreads();
+        ELBA_STAMP(1);
+
+        // ---- expand + accumulate ----
+        const uint32_t rs = p.a_rowptr[i], re = p.a_rowptr[i + 1];
+        uint32_t dn = 0, dmin = 0xFFFFFFFFu, dmax = 0;
+        bool full = false;
+        // Software-pipelined, NOT unrolled over the row: the kernel must stay small — a fully unrolled 16x4 inline-insert body
+        // was 49 KB of code and instruction fetch, not memory, bounded it (profiles/r01_notes.md).  Per iteration a lane owns
+        // GRP row entries: their column gathers (GRP*SPEC independent loads) are issued first, then the descriptors of the NEXT
+        // group are prefetched, then the accumulator is updated; descriptors therefore never sit on the critical path.
+        uint64_t xc[GRP];
+#pragma unroll
+        for (int q = 0; q < GRP; ++q) {
+            const uint32_t e = rs + (uint32_t)q * BLOCK + tid;
+            xc[q] = e < re ? p.a_csrx[e] : 0ull;                       // column start << 32 | column length; past the row end: length 0
+        }
+#pragma unroll 1
+        for (uint32_t gb = rs; gb < re; gb += GRP * BLOCK) {
+            uint64_t c[GRP][SPEC];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const uint32_t a = (uint32_t)(xc[q] >> 32), n = (uint32_t)xc[q];
+#pragma unroll
+                for (int u = 0; u < SPEC; ++u) c[q][u] = p.a_csc[(uint32_t)u < n ? a + u : a];
+                if (p.dbg & 2u) {                                       // ablation: no gathers, synthetic partner ids
+#pragma unroll
+                    for (int u = 0; u < SPEC; ++u) c[q][u] = (uint64_t)(((a + u) * 2654435761u) % p.Mcols) << 32;
+                }
+            }
+            uint64_t xn[GRP];
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) {
+                const uint32_t e = gb + (uint32_t)(GRP + q) * BLOCK + tid;
+                xn[q] = e < re ? p.a_csrx[e] : 0ull;
+            }
+            if (p.dbg & 1u) {                                           // ablation: gathers only, keep the loads alive
+                uint32_t sink = 0;
+#pragma unroll
+                for (int q = 0; q < GRP; ++q)
+#pragma unroll
+                    for (int u = 0; u < SPEC; ++u) sink ^= (uint32_t)(c[q][u] >> 32);
+                dn += sink == 0xFFFFFFFFu;
+            } else {
+#pragma unroll
+                for (int q = 0; q < GRP; ++q) {
+                    const uint32_t a = (uint32_t)(xc[q] >> 32), n = (uint32_t)xc[q];
+                    const uint32_t sb = (gb + (uint32_t)q * BLOCK + tid - rs) << p.fbits;
+#pragma unroll
+                    for (int u = 0; u < SPEC; ++u) {
+                        if ((uint32_t)u < n) {
+                            const uint32_t j = (uint32_t)(c[q][u] >> 32), s = sb | (uint32_t)u;
+                            if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }   // diagonal: registers, not 1 hot slot
+                            else tab.insert(j, s, full);
+                        }
+                    }
+                    for (uint32_t f = SPEC; f < n; ++f) {                 // the tail of columns longer than SPEC
+                        const uint32_t j = (uint32_t)(p.a_csc[a + f] >> 32), s = sb | f;
+                        if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
+                        else tab.insert(j, s, full);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < GRP; ++q) xc[q] = xn[q];
+            if (tab.abandoned()) break;
+        }
+        if (dn) { atomicAdd(&misc[0], dn); atomicMin(&misc[1], dmin); atomicMax(&misc[2], dmax); }
+        __syncthreads();
+        ELBA_STAMP(2);
+        if (tab.abandoned()) {
+            // the optimistic table was too small: hand the row to the next tier (its kernel starts after this one ends)
+            if (tid == 0) {
+                const uint32_t at = atomicAdd(&p.ctr->tier_count[tier + 1], 1u);
+                p.lists[(size_t)(tier + 1) * p.M + at] = i;
+            }
+            __syncthreads();
+            continue;
+        }
+
+        // ---- level 3: one table sweep: nnz before prune + ballot-compacted survivor list ----
+        uint32_t yraw = 0;
+        for (uint32_t b0 = 0; b0 < T; b0 += BLOCK) {                       // wave-uniform trip count: ballots are safe
+            const uint32_t s0 = b0 + tid;
+            bool keep = false;
+            if (s0 < T && tab.ld(tab.keys, s0) != EMPTY) { ++yraw; keep = tab.ld(tab.cnt, s0) >= 2; }
+            const uint64_t bal = __ballot(keep);
+            if (bal == 0) continue;
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&misc[3], (uint32_t)__popcll(bal));
+            at = __shfl(at, 0, 64) + (uint32_t)__popcll(bal & lt);
+            if (keep) list[at] = s0;
+        }
+        yraw = wave_sum_u32(yraw);
+        if (lane == 0 && yraw) atomicAdd(&misc[5], yraw);
+        __syncthreads();
+        ELBA_STAMP(3);
+        if (tid == 0) {
+            const uint32_t dcount = misc[0];
+            const uint32_t ytot = misc[3] + (dcount >= 2 ? 1u : 0u);
+            // staging space: the workgroup draws CHUNK-sized pieces from the global cursor and sub-allocates its rows
+            // from them (one hot 64-bit counter sustains ~10^8 atomics/s; one atomic per row would cap the kernel)
+            unsigned long long off;
+            if (ytot <= chunk_left) { off = chunk_off; chunk_off += ytot; chunk_left -= ytot; }
+            else if (ytot >= STAGE_CHUNK / 2) off = atomicAdd(&p.ctr->cursor, (unsigned long long)ytot);
+            else { off = atomicAdd(&p.ctr->cursor, (unsigned long long)STAGE_CHUNK); chunk_off = off + ytot; chunk_left = STAGE_CHUNK - ytot; }
+            const bool fits = off + ytot <= p.tmp_cap;
+            if (!fits) atomicOr(&p.ctr->overflow, 1u);
+            p.row_cnt[i] = ytot;
+            p.row_off[i] = off;
+            misc[6] = (uint32_t)off; misc[7] = (uint32_t)(off >> 32); misc[8] = fits ? 1u : 0u;
+            acc_yraw += misc[5] + (dcount >= 1 ? 1u : 0u);
+            acc_done += 1;
+            acc_ndiag += dcount >= 2 ? 1u : 0u;
+            acc_y += ytot;
+            if (ytot > FIN_WAVE_MAX) {                         // rows too wide for the one-wave column sort
+                const int which = ytot > FIN_LDS_MAX ? 1 : 0;
+                const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
+                p.fin_lists[(size_t)which * p.M + at] = i;
+            }
+        }
+        __syncthreads();
+        ELBA_STAMP(4);
+        if (misc[8]) {
+            // ---- level 4: all survivors decode their seeds in parallel ----
+            const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
+            const uint32_t ysurv = misc[3];
+            uint32_t nup = 0, mx = 0;
+            for (uint32_t t = tid; t < ysurv; t += BLOCK) {
+                const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : list[t];
+                const uint32_t j = tab.ld(tab.keys, s0), n = tab.ld(tab.cnt, s0);
+                const elba_seed_t v = decode_seed(p, rs, tab.ld(tab.smin, s0), tab.ld(tab.smax, s0), n, fmask);
+                p.tmp_col[off + t] = j;
+                p.tmp_val[off + t] = v;
+                if (j > i) ++nup;
+                mx = n > mx ? n : mx;
+            }
+            if (tid == 0 && misc[0] >= 2) {
+                p.tmp_col[off + ysurv] = i;
+                p.tmp_val[off + ysurv] = decode_seed(p, rs, misc[1], misc[2], misc[0], fmask);
+                mx = misc[0] > mx ? misc[0] : mx;
+            }
+            acc_nup += nup;
+            acc_mx = mx > acc_mx ? mx : acc_mx;
+        }
+        __syncthreads();    // table and misc are re-initialised by the next row
+        ELBA_STAMP(5);
+    }
+    if (stamp && tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) atomicAdd(&p.ctr->phase[k], ph[k]);
+        atomicAdd(&p.ctr->phase[6], 1ull);
+    }
+#undef ELBA_STAMP
+    // flush the workgroup's statistics: a handful of atomics per workgroup instead of six per row
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { acc_nup += __shfl_xor(acc_nup, d, 64); uint32_t o = __shfl_xor(acc_mx, d, 64); acc_mx = o > acc_mx ? o : acc_mx; }
+    if (lane == 0) {
+        if (acc_nup) atomicAdd(&p.ctr->nupper, acc_nup);
+        if (acc_mx) atomicMax(&p.ctr->maxshared, acc_mx);
+    }
+    if (tid == 0 && acc_done) {
+        atomicAdd(&p.ctr->yraw, acc_yraw);
+        atomicAdd(&p.ctr->nnz, acc_y);
+        atomicAdd(&p.ctr->tier_done[tier], acc_done);
+        if (acc_ndiag) atomicAdd(&p.ctr->ndiag, (unsigned long long)acc_ndiag);
+    }
+}
