@@ -55,8 +55,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = bool(os.environ.get("ELBA_FORCE_DIST"))      # exercise the multi-GPU driver with world_size 1 (self-test on a 1-GPU box)
+    if world > 1 or force_dist:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
@@ -68,7 +70,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world == 1:
+    if world == 1 and not force_dist:
         from elba_amd.capi import Engine
         t0 = time.time()
         packed, off, lens, info = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"])
@@ -140,7 +142,7 @@ def main():
 
     cpu = None
     parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not force_dist and not args.no_cpu_baseline:
         from oracle import pyoracle as po   # checker + CPU baseline only
         A = runner.export_kmer_matrix()
         o = po.Oracle(k, lo, up)

@@ -332,4 +332,79 @@ int elba_get_device_view(elba_ctx *ctx, elba_device_view *v)
     });
 }
 
+int elba_dist_count_owners(elba_ctx *ctx, int nranks, uint64_t *counts)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(counts, ELBA_ERR_INVALID_ARG, "dist_count_owners: null output");
+        stage_dist_count_owners(c, nranks, counts);
+    });
+}
+
+int elba_dist_fill_send(elba_ctx *ctx, int nranks, void *d_send, const uint64_t *offsets)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(offsets && (d_send || c.I == 0), ELBA_ERR_INVALID_ARG, "dist_fill_send: null argument");
+        stage_dist_fill_send(c, nranks, d_send, offsets);
+    });
+}
+
+int elba_dist_count_records(elba_ctx *ctx, const void *d_records, int64_t nrecords, elba_kmer_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        stage_dist_count_records(c, d_records, nrecords);
+        if (stats) *stats = c.kstats;
+    });
+}
+
+int elba_dist_get_reliable_kmers(elba_ctx *ctx, const void **d_kmers, int64_t *n)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(d_kmers && n, ELBA_ERR_INVALID_ARG, "dist_get_reliable_kmers: null output");
+        ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_get_reliable_kmers: call dist_count_records first");
+        *d_kmers = c.rel_kmers.p; *n = c.N;
+    });
+}
+
+int elba_dist_copy_reliable_kmers(elba_ctx *ctx, void *d_dst, int64_t capacity)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_copy_reliable_kmers: call dist_count_records first");
+        ELBA_REQUIRE(capacity >= c.N && (d_dst || c.N == 0), ELBA_ERR_INVALID_ARG, "dist_copy_reliable_kmers: buffer too small");
+        if (c.N > 0) ELBA_HIP(hipMemcpyAsync(d_dst, c.rel_kmers.p, (size_t)c.N * 8, hipMemcpyDeviceToDevice, c.stream));
+        ELBA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
+int elba_dist_set_global_kmers(elba_ctx *ctx, const void *d_all_kmers, int64_t nall)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_dist_set_global_kmers(c, d_all_kmers, nall); });
+}
+
+int elba_dist_panel_counts(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, uint64_t *counts)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(read_bounds && counts, ELBA_ERR_INVALID_ARG, "dist_panel_counts: null argument");
+        stage_dist_panel(c, nranks, read_bounds, false, nullptr, counts);
+    });
+}
+
+int elba_dist_panel_fill(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, void *d_send, const uint64_t *offsets)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(read_bounds && offsets, ELBA_ERR_INVALID_ARG, "dist_panel_fill: null argument");
+        stage_dist_panel(c, nranks, read_bounds, true, d_send, const_cast<uint64_t *>(offsets));
+    });
+}
+
+int elba_dist_set_panel(elba_ctx *ctx, const void *d_records, int64_t nrecords, int64_t nreads_total, int64_t nkmers_total, int64_t row_lo, int64_t row_hi, elba_matrix_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        EventTimer t;
+        t.start(c.stream);
+        stage_dist_set_panel(c, d_records, nrecords, nreads_total, nkmers_total, row_lo, row_hi);
+        t.stop(c.stream);
+        if (stats) { stats->nrows = c.M; stats->ncols = c.N; stats->nnz = c.Z; stats->max_row_nnz = c.max_row_nnz; stats->ms_total = t.ms(); }
+    });
+}
+
 }  // extern "C"

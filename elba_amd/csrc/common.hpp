@@ -120,6 +120,12 @@ struct Ctx {
     // rows of an A built from reads are local read indices; exported triples carry global ids (src/KmerOps.cpp:215-219)
     int64_t first_global_id_rows() const { return A_has_kmers ? first_global_id : 0; }
 
+    // distributed owner state (kmer.hip, second half)
+    const uint64_t *d_records = nullptr; int64_t nrecords = 0;
+    bool dist_owner = false;
+    DevBuf dist_gid;          // u32[N_local] global k-mer id of each local column
+    int64_t dist_nall = -1;
+
     // B (device)
     bool have_B = false;
     int64_t Y = 0;
@@ -139,5 +145,11 @@ void stage_count_kmers(Ctx &c);                                   // kmer.hip
 void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
 void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip
 void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
+void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host);                                   // kmer.hip
+void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);
+void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec);
+void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall);
+void stage_dist_panel(Ctx &c, int nranks, const uint64_t *bounds_host, bool fill, void *d_send, uint64_t *counts_or_offsets_host);
+void stage_dist_set_panel(Ctx &c, const void *d_rec, int64_t nrec, int64_t M_total, int64_t N_total, int64_t row_lo, int64_t row_hi);
 
 }  // namespace elba

@@ -302,3 +302,300 @@ void stage_create_kmer_matrix(Ctx &c)
 }
 
 }  // namespace elba
+
+// =====================================================================================================================
+// Distributed building blocks: 1D read-row shards x hash-owned k-mer columns.
+//   exchange #1  every k-mer instance (kmer, global read, pos) goes to the rank that owns the k-mer        [all-to-all]
+//   owner        exact count + [LOWER, UPPER] filter on the received records, columns sorted by (read, pos)
+//   ids          reliable k-mers of all owners are all-gathered; global k-mer id = rank of the packed value  [all-gather]
+//   exchange #2  each column goes, whole, to every rank that owns at least one of its reads (the column panel) [all-to-all]
+// The collectives themselves are issued by the host driver (torch.distributed: RCCL on GPUs, gloo in the CPU tests); the
+// kernels below only produce / consume the device buffers.  A record is two u64 words.
+// =====================================================================================================================
+namespace elba {
+
+namespace {
+
+constexpr int MAX_RANKS = 64;
+
+__device__ __forceinline__ uint32_t owner_of(uint64_t km, uint32_t nranks)
+{
+    return (uint32_t)__umul64hi(mix64(km), (uint64_t)nranks);      // uniform over ranks (cf. GetKmerOwner, src/KmerOps.cpp:352-359)
+}
+
+__global__ __launch_bounds__(EN_THREADS) void k_dist_count_owners(EnumParams e, uint32_t nranks, unsigned long long *counts)
+{
+    __shared__ uint32_t hist[MAX_RANKS];
+    if (threadIdx.x < MAX_RANKS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for_each_instance(e, [&](uint64_t, uint32_t, uint32_t, uint64_t km) { atomicAdd(&hist[owner_of(km, nranks)], 1u); });
+    __syncthreads();
+    if (threadIdx.x < nranks && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(EN_THREADS) void k_dist_fill_send(EnumParams e, uint32_t nranks, uint64_t first_global_id, uint64_t *send, unsigned long long *cursors)
+{
+    __shared__ uint32_t hist[MAX_RANKS];
+    __shared__ unsigned long long base[MAX_RANKS];
+    if (threadIdx.x < MAX_RANKS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for_each_instance(e, [&](uint64_t, uint32_t, uint32_t, uint64_t km) { atomicAdd(&hist[owner_of(km, nranks)], 1u); });
+    __syncthreads();
+    if (threadIdx.x < nranks) {
+        base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]) : 0ull;
+        hist[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for_each_instance(e, [&](uint64_t, uint32_t r, uint32_t p, uint64_t km) {
+        const uint32_t o = owner_of(km, nranks);
+        const unsigned long long at = base[o] + atomicAdd(&hist[o], 1u);
+        send[2 * at] = km;
+        send[2 * at + 1] = ((first_global_id + r) << 32) | p;
+    });
+}
+
+__global__ void k_rec_count(const uint64_t *rec, uint64_t n, unsigned long long *keys, uint32_t *vals, uint64_t capmask)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t km = rec[2 * i];
+    uint64_t slot = mix64(km) & capmask;
+    for (;;) {
+        const unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)KEMPTY, (unsigned long long)km);
+        if (old == KEMPTY || old == km) break;
+        slot = (slot + 1) & capmask;
+    }
+    atomicAdd(&vals[slot], 1u);
+}
+
+__global__ void k_rec_lookup(const uint64_t *rec, uint64_t n, const uint64_t *keys, const uint32_t *vals, uint64_t capmask,
+                             const uint32_t *colptr, uint32_t *fill, uint64_t *csc)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t km = rec[2 * i];
+    uint64_t slot = mix64(km) & capmask;
+    while (keys[slot] != km) slot = (slot + 1) & capmask;
+    const uint32_t kid = vals[slot];
+    if (kid != NOT_RELIABLE) csc[colptr[kid] + atomicAdd(&fill[kid], 1u)] = rec[2 * i + 1];
+}
+
+// global id of each local reliable k-mer = its rank in the sorted union of all owners' reliable k-mers
+__global__ void k_global_ids(const uint64_t *local, uint64_t nlocal, const uint64_t *all_sorted, uint64_t nall, uint32_t *gid)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlocal) return;
+    const uint64_t km = local[i];
+    uint64_t lo = 0, hi = nall;               // first index with all_sorted[idx] >= km (k-mers are distinct across owners)
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (all_sorted[mid] < km) lo = mid + 1; else hi = mid; }
+    gid[i] = (uint32_t)lo;
+}
+
+__device__ __forceinline__ uint32_t rank_of_read(const uint64_t *bounds, uint32_t nranks, uint64_t read)
+{
+    uint32_t lo = 0, hi = nranks;             // last r with bounds[r] <= read
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (bounds[mid] <= read) lo = mid; else hi = mid; }
+    return lo;
+}
+
+// one lane per column: the set of ranks that own at least one read of the column; FILL = false counts, true writes
+template <bool FILL>
+__global__ void k_panel(const uint32_t *colptr, const uint64_t *csc, const uint32_t *gid, uint64_t N, const uint64_t *bounds, uint32_t nranks,
+                        unsigned long long *counts_or_cursors, uint64_t *send)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t c0 = colptr[k], c1 = colptr[k + 1];
+    uint64_t mask = 0;
+    for (uint32_t a = c0; a < c1; ++a) mask |= 1ull << rank_of_read(bounds, nranks, csc[a] >> 32);
+    while (mask) {
+        const uint32_t d = (uint32_t)__ffsll((unsigned long long)mask) - 1;
+        mask &= mask - 1;
+        const unsigned long long at = atomicAdd(&counts_or_cursors[d], (unsigned long long)(c1 - c0));
+        if (FILL) {
+            const uint64_t g = gid[k];
+            for (uint32_t a = c0; a < c1; ++a) { send[2 * (at + (a - c0))] = g; send[2 * (at + (a - c0)) + 1] = csc[a]; }
+        }
+    }
+}
+
+__global__ void k_deinterleave(const uint64_t *rec, uint64_t n, uint64_t *k0, uint64_t *v0)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    k0[i] = rec[2 * i];
+    v0[i] = rec[2 * i + 1];
+}
+
+int bits_needed(uint64_t maxval)
+{
+    int b = 1;
+    while (b < 64 && (maxval >> b)) ++b;
+    return b;
+}
+
+}  // namespace
+
+void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host)
+{
+    ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "dist_count_owners: no reads");
+    ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS, ELBA_ERR_INVALID_ARG, "dist_count_owners: 1..64 ranks");
+    hipStream_t s = c.stream;
+    const int k = c.cfg.k;
+    const int64_t M = c.nreads;
+    std::vector<uint64_t> off((size_t)M + 1);
+    uint64_t I = 0;
+    for (int64_t r = 0; r < M; ++r) { off[(size_t)r] = I; if ((int64_t)c.h_len[(size_t)r] >= k) I += (uint64_t)c.h_len[(size_t)r] - k + 1; }
+    off[(size_t)M] = I;
+    ELBA_REQUIRE(I < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "more than 2^32 k-mer instances on one GPU");
+    c.I = (int64_t)I;
+    c.inst_off.reserve((size_t)(M + 1) * 8);
+    ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s));
+    c.ws_scan.reserve(MAX_RANKS * 8);
+    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, MAX_RANKS * 8, s));
+    EnumParams e = make_enum(c);
+    const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+    if (I > 0) hipLaunchKernelGGL(k_dist_count_owners, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, c.ws_scan.as<unsigned long long>());
+    ELBA_HIP(hipMemcpyAsync(counts_host, c.ws_scan.p, (size_t)nranks * 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
+void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host)
+{
+    ELBA_REQUIRE(c.have_reads && c.inst_off.p, ELBA_ERR_STATE, "dist_fill_send: call dist_count_owners first");
+    ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS, ELBA_ERR_INVALID_ARG, "dist_fill_send: 1..64 ranks");
+    hipStream_t s = c.stream;
+    c.ws_scan.reserve(MAX_RANKS * 8);
+    ELBA_HIP(hipMemcpyAsync(c.ws_scan.p, offsets_host, (size_t)nranks * 8, hipMemcpyHostToDevice, s));
+    EnumParams e = make_enum(c);
+    const uint64_t nblocks = ((uint64_t)c.I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+    if (c.I > 0)
+        hipLaunchKernelGGL(k_dist_fill_send, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, (uint64_t)c.first_global_id,
+                           static_cast<uint64_t *>(d_send), c.ws_scan.as<unsigned long long>());
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
+// Owner side of exchange #1: count the received records exactly, keep LOWER <= count <= UPPER, sort the kept k-mers.
+void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
+{
+    ELBA_REQUIRE(nrec >= 0 && (nrec == 0 || d_rec), ELBA_ERR_INVALID_ARG, "dist_count_records: null records");
+    ELBA_REQUIRE(nrec < 0xFFFFFFF0ll, ELBA_ERR_UNSUPPORTED, "more than 2^32 records on one GPU");
+    hipStream_t s = c.stream;
+    const int k = c.cfg.k;
+    c.have_counts = false; c.have_A = false; c.have_B = false;
+    c.d_records = static_cast<const uint64_t *>(d_rec); c.nrecords = nrec;
+    const uint64_t I = (uint64_t)nrec;
+    int cbits = next_pow2_bits(2 * I + 2);
+    if (cbits < 10) cbits = 10;
+    const uint64_t cap = 1ull << cbits;
+    c.tab_cap = (int64_t)cap;
+    c.tab_keys.reserve((size_t)cap * 8);
+    c.tab_vals.reserve((size_t)cap * 4);
+    ELBA_HIP(hipMemsetAsync(c.tab_keys.p, 0xFF, (size_t)cap * 8, s));
+    ELBA_HIP(hipMemsetAsync(c.tab_vals.p, 0, (size_t)cap * 4, s));
+    if (I > 0) hipLaunchKernelGGL(k_rec_count, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, c.d_records, I, c.tab_keys.as<unsigned long long>(), c.tab_vals.as<uint32_t>(), cap - 1);
+    c.ws_scan.reserve(256);
+    SelCounters *dctr = c.ws_scan.as<SelCounters>();
+    ELBA_HIP(hipMemsetAsync(dctr, 0, sizeof(SelCounters), s));
+    const uint64_t maxN = I / (uint64_t)c.cfg.lower + 1;
+    c.ws_a.reserve(maxN * 8); c.ws_b.reserve(maxN * 8); c.ws_c.reserve(maxN * 8); c.ws_d.reserve(maxN * 8);
+    hipLaunchKernelGGL(k_table_select, dim3(c.num_cus * 8), dim3(256), 0, s, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap,
+                       (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), dctr);
+    SelCounters hc{};
+    ELBA_HIP(hipMemcpyAsync(&hc, dctr, sizeof(hc), hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    const uint64_t N = hc.reliable, Z = hc.entries;
+    ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "nnz beyond 32-bit device offsets");
+    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)N, 64 - 2 * k, 64, c.ws_sort);
+    const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>();
+    const uint64_t *sslots = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
+    c.rel_kmers.reserve((size_t)(N + 1) * 8);
+    c.rel_counts.reserve((size_t)(N + 2) * 4);
+    if (N > 0) {
+        ELBA_HIP(hipMemcpyAsync(c.rel_kmers.p, skeys, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_assign_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, sslots, c.tab_vals.as<uint32_t>(), c.rel_counts.as<uint32_t>(), N);
+    }
+    // owner-local columns: colptr by scan, entries by lookup of every record, then per-column sort by (read, pos)
+    c.a_colptr.reserve((size_t)(N + 2) * 4);
+    c.a_csc.reserve((size_t)(Z + 1) * 8);
+    ELBA_HIP(hipMemsetAsync(c.rel_counts.as<uint32_t>() + N, 0, 4, s));
+    exclusive_scan_u32(s, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), (int64_t)N + 1, c.ws_scan);
+    c.ws_e.reserve((size_t)(N + 1) * 4);
+    c.ws_f.reserve((size_t)(Z + 1) * 8);
+    ELBA_HIP(hipMemsetAsync(c.ws_e.p, 0, (size_t)(N + 1) * 4, s));
+    if (I > 0)
+        hipLaunchKernelGGL(k_rec_lookup, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, c.d_records, I, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap - 1,
+                           c.a_colptr.as<uint32_t>(), c.ws_e.as<uint32_t>(), c.a_csc.as<uint64_t>());
+    if (N > 0)
+        hipLaunchKernelGGL(k_sort_columns, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.ws_f.as<uint64_t>(), N);
+    ELBA_HIP(hipStreamSynchronize(s));
+    c.I = nrec; c.ndistinct = (int64_t)hc.distinct; c.N = (int64_t)N; c.Z = (int64_t)Z;
+    c.kstats = elba_kmer_stats{};
+    c.kstats.instances = nrec; c.kstats.distinct = (int64_t)hc.distinct; c.kstats.reliable = (int64_t)N; c.kstats.entries = (int64_t)Z;
+    c.have_counts = true;
+    c.dist_owner = true;
+}
+
+// After the all-gather of every owner's sorted reliable k-mers: global k-mer ids of the local columns.
+void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall)
+{
+    ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_set_global_kmers: call dist_count_records first");
+    ELBA_REQUIRE(nall >= c.N && nall < 0xFFFFFFF0ll, ELBA_ERR_INVALID_ARG, "dist_set_global_kmers: bad global k-mer count");
+    hipStream_t s = c.stream;
+    c.ws_a.reserve((size_t)(nall + 1) * 8); c.ws_b.reserve((size_t)(nall + 1) * 8); c.ws_c.reserve((size_t)(nall + 1) * 8); c.ws_d.reserve((size_t)(nall + 1) * 8);
+    if (nall > 0) ELBA_HIP(hipMemcpyAsync(c.ws_a.p, d_all, (size_t)nall * 8, hipMemcpyDeviceToDevice, s));
+    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), nall, 64 - 2 * c.cfg.k, 64, c.ws_sort);
+    const uint64_t *sorted = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>();
+    c.dist_gid.reserve((size_t)(c.N + 1) * 4);
+    if (c.N > 0)
+        hipLaunchKernelGGL(k_global_ids, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), (uint64_t)c.N, sorted, (uint64_t)nall, c.dist_gid.as<uint32_t>());
+    ELBA_HIP(hipStreamSynchronize(s));
+    c.dist_nall = nall;
+}
+
+void stage_dist_panel(Ctx &c, int nranks, const uint64_t *bounds_host, bool fill, void *d_send, uint64_t *counts_or_offsets_host)
+{
+    ELBA_REQUIRE(c.have_counts && c.dist_owner && c.dist_nall >= 0, ELBA_ERR_STATE, "dist_panel: call dist_set_global_kmers first");
+    ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS, ELBA_ERR_INVALID_ARG, "dist_panel: 1..64 ranks");
+    hipStream_t s = c.stream;
+    c.ws_scan.reserve((size_t)(2 * MAX_RANKS + 2) * 8);
+    unsigned long long *dcnt = c.ws_scan.as<unsigned long long>();
+    uint64_t *dbounds = c.ws_scan.as<uint64_t>() + MAX_RANKS;
+    if (fill) ELBA_HIP(hipMemcpyAsync(dcnt, counts_or_offsets_host, (size_t)nranks * 8, hipMemcpyHostToDevice, s));
+    else ELBA_HIP(hipMemsetAsync(dcnt, 0, MAX_RANKS * 8, s));
+    ELBA_HIP(hipMemcpyAsync(dbounds, bounds_host, (size_t)(nranks + 1) * 8, hipMemcpyHostToDevice, s));
+    if (c.N > 0) {
+        const unsigned nb = (unsigned)((c.N + 255) / 256);
+        if (fill) hipLaunchKernelGGL((k_panel<true>), dim3(nb), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.dist_gid.as<uint32_t>(), (uint64_t)c.N, dbounds, (uint32_t)nranks, dcnt, static_cast<uint64_t *>(d_send));
+        else hipLaunchKernelGGL((k_panel<false>), dim3(nb), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.dist_gid.as<uint32_t>(), (uint64_t)c.N, dbounds, (uint32_t)nranks, dcnt, (uint64_t *)nullptr);
+    }
+    if (!fill) ELBA_HIP(hipMemcpyAsync(counts_or_offsets_host, dcnt, (size_t)nranks * 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
+// Receiver side of exchange #2: records (global kid, read << 32 | pos), each column contiguous and internally ordered.
+// Builds the CSC panel (indexed by GLOBAL k-mer id) and the CSR of every read that appears in it; B is then computed for
+// rows [row_lo, row_hi) only — the rows this rank owns, whose columns are complete by construction.
+void stage_dist_set_panel(Ctx &c, const void *d_rec, int64_t nrec, int64_t M_total, int64_t N_total, int64_t row_lo, int64_t row_hi)
+{
+    ELBA_REQUIRE(nrec >= 0 && (nrec == 0 || d_rec), ELBA_ERR_INVALID_ARG, "dist_set_panel: null records");
+    ELBA_REQUIRE(M_total >= 0 && N_total >= 0 && M_total < 0xFFFFFFFFll && N_total < 0xFFFFFFFFll && nrec < 0xFFFFFFF0ll, ELBA_ERR_UNSUPPORTED, "dist_set_panel: dimension beyond 32 bits");
+    ELBA_REQUIRE(row_lo >= 0 && row_lo <= row_hi && row_hi <= M_total, ELBA_ERR_INVALID_ARG, "dist_set_panel: bad row window");
+    hipStream_t s = c.stream;
+    c.ws_a.reserve((size_t)(nrec + 1) * 8); c.ws_b.reserve((size_t)(nrec + 1) * 8); c.ws_c.reserve((size_t)(nrec + 1) * 8); c.ws_d.reserve((size_t)(nrec + 1) * 8);
+    c.ws_e.reserve((size_t)(nrec + 1) * 8); c.ws_f.reserve((size_t)(nrec + 1) * 8);
+    if (nrec > 0)
+        hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, s, static_cast<const uint64_t *>(d_rec), (uint64_t)nrec, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
+    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), nrec, 0, bits_needed((uint64_t)(N_total > 0 ? N_total - 1 : 0)), c.ws_sort);
+    // stable: a column's entries stay contiguous and ordered by (read, pos).  Move out of the ws_a..d pool (finish reuses it).
+    if (nrec > 0) {
+        ELBA_HIP(hipMemcpyAsync(c.ws_e.p, where ? c.ws_c.p : c.ws_a.p, (size_t)nrec * 8, hipMemcpyDeviceToDevice, s));
+        ELBA_HIP(hipMemcpyAsync(c.ws_f.p, where ? c.ws_d.p : c.ws_b.p, (size_t)nrec * 8, hipMemcpyDeviceToDevice, s));
+    }
+    c.A_has_kmers = false;
+    c.dist_owner = false;
+    finish_matrix_from_sorted_csc(c, M_total, N_total, nrec, c.ws_e.as<uint64_t>(), 0, c.ws_f.as<uint64_t>());
+    c.row_lo = row_lo; c.row_hi = row_hi;
+}
+
+}  // namespace elba

@@ -1,0 +1,217 @@
+"""Multi-GPU driver of the overlap engine: 1D read-row shards x hash-owned k-mer columns.
+
+One process per GPU.  The heavy lifting is in libelba_amd.so (elba_dist_* entry points); this module only sequences the stages and
+issues the collectives through torch.distributed — backend "nccl" (= RCCL over xGMI) on GPUs, "gloo" in the CPU tests, where a
+test-defined backend stands in for the HIP library.  Collectives used, all over the whole world:
+
+    all_to_all_single   #1  k-mer instances (16 B records) to the k-mer's owner rank          (src/KmerOps.cpp:117-151, :244-274)
+    all_gather              each owner's reliable k-mers -> global k-mer ids by value rank      (src/KmerOps.cpp:371-375 Exscan)
+    all_to_all_single   #2  every column, whole, to each rank that owns one of its reads        (SpParMat ctor / Transpose redistribution)
+    all_reduce              scalars only (counts, timings)
+
+There is no bulk all-reduce anywhere; all-to-all on the 8-GPU xGMI mesh drives all 7 links of a GPU at once.
+After exchange #2 every rank holds complete columns for all k-mers of its reads, so the SpGEMM itself (create_seed_matrix) needs no
+communication: the reference's SUMMA broadcasts inside "creating seed matrix (spgemm)" have no counterpart here by construction.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+
+
+def partition_by_bases(lens, nranks):
+    """Contiguous read partition balanced by bases: the greedy rule of src/FastaIndex.cpp:47-94 (rank i takes reads until the next one
+    would push it over total/nranks; the last rank takes the remainder).  Returns bounds[nranks+1]."""
+    lens = np.asarray(lens, dtype=np.int64)
+    total, n = int(lens.sum()), len(lens)
+    avg = total / nranks
+    bounds, r = [0], 0
+    for _ in range(nranks - 1):
+        sofar = 0
+        while r < n and sofar + int(lens[r]) < avg:
+            sofar += int(lens[r]); r += 1
+        bounds.append(r)
+    bounds.append(n)
+    return np.array(bounds, dtype=np.int64)
+
+
+class HipBackend:
+    """The product backend: every method is one C-ABI call on device buffers owned by torch tensors."""
+
+    def __init__(self, k, lower, upper, device):
+        import torch
+        self.torch = torch
+        self.dev = torch.device("cuda", device)
+        self.e = capi.Engine(k, lower, upper, device=device)
+        self.L, self.h = self.e.L, self.e.h
+        L = self.L
+        vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+        L.elba_dist_count_owners.restype = i32; L.elba_dist_count_owners.argtypes = [vp, i32, vp]
+        L.elba_dist_fill_send.restype = i32; L.elba_dist_fill_send.argtypes = [vp, i32, vp, vp]
+        L.elba_dist_count_records.restype = i32; L.elba_dist_count_records.argtypes = [vp, vp, i64, C.POINTER(capi.KmerStats)]
+        L.elba_dist_get_reliable_kmers.restype = i32; L.elba_dist_get_reliable_kmers.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+        L.elba_dist_copy_reliable_kmers.restype = i32; L.elba_dist_copy_reliable_kmers.argtypes = [vp, vp, i64]
+        L.elba_dist_set_global_kmers.restype = i32; L.elba_dist_set_global_kmers.argtypes = [vp, vp, i64]
+        L.elba_dist_panel_counts.restype = i32; L.elba_dist_panel_counts.argtypes = [vp, i32, vp, vp]
+        L.elba_dist_panel_fill.restype = i32; L.elba_dist_panel_fill.argtypes = [vp, i32, vp, vp, vp]
+        L.elba_dist_set_panel.restype = i32; L.elba_dist_set_panel.argtypes = [vp, vp, i64, i64, i64, i64, i64, C.POINTER(capi.MatrixStats)]
+
+    def empty_records(self, n):
+        return self.torch.empty((max(int(n), 0), 2), dtype=self.torch.int64, device=self.dev)
+
+    def empty_words(self, n):
+        return self.torch.empty((max(int(n), 0),), dtype=self.torch.int64, device=self.dev)
+
+    def set_reads(self, packed, off, lens, first_global_id):
+        self.e.set_reads(packed, off, lens, first_global_id)
+
+    def count_owners(self, nranks):
+        out = np.zeros(nranks, dtype=np.uint64)
+        self.e._check(self.L.elba_dist_count_owners(self.h, nranks, out.ctypes.data))
+        return out.astype(np.int64)
+
+    def fill_send(self, nranks, send, offsets):
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.e._check(self.L.elba_dist_fill_send(self.h, nranks, send.data_ptr() if send.numel() else None, off.ctypes.data))
+
+    def count_records(self, rec):
+        self._rec = rec                                   # borrowed by the library until set_global_kmers
+        st = capi.KmerStats()
+        self.e._check(self.L.elba_dist_count_records(self.h, rec.data_ptr() if rec.numel() else None, rec.shape[0], C.byref(st)))
+        return capi._stats(st)
+
+    def reliable_kmers(self, n):
+        out = self.empty_words(n)
+        self.e._check(self.L.elba_dist_copy_reliable_kmers(self.h, out.data_ptr() if n else None, n))
+        return out
+
+    def set_global_kmers(self, allk):
+        self.e._check(self.L.elba_dist_set_global_kmers(self.h, allk.data_ptr() if allk.numel() else None, allk.numel()))
+        self._rec = None
+
+    def panel_counts(self, nranks, bounds):
+        b = np.ascontiguousarray(bounds, dtype=np.uint64)
+        out = np.zeros(nranks, dtype=np.uint64)
+        self.e._check(self.L.elba_dist_panel_counts(self.h, nranks, b.ctypes.data, out.ctypes.data))
+        return out.astype(np.int64)
+
+    def panel_fill(self, nranks, bounds, send, offsets):
+        b = np.ascontiguousarray(bounds, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.e._check(self.L.elba_dist_panel_fill(self.h, nranks, b.ctypes.data, send.data_ptr() if send.numel() else None, off.ctypes.data))
+
+    def set_panel(self, rec, m_total, n_total, row_lo, row_hi):
+        st = capi.MatrixStats()
+        self.e._check(self.L.elba_dist_set_panel(self.h, rec.data_ptr() if rec.numel() else None, rec.shape[0], m_total, n_total, row_lo, row_hi, C.byref(st)))
+        return capi._stats(st)
+
+    def create_seed_matrix(self):
+        return self.e.create_seed_matrix()
+
+    def export_csr(self, row_lo, row_hi):
+        return self.e.export_csr(row_lo, row_hi)
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.dev)
+
+
+class DistributedOverlap:
+    def __init__(self, k, lower, upper, device=0, rank=0, world=1, dist=None, backend=None):
+        self.k, self.lower, self.upper = k, lower, upper
+        self.rank, self.world, self.dist = rank, world, dist
+        self.be = backend if backend is not None else HipBackend(k, lower, upper, device)
+        self.nlocal = 0
+        self.bounds = None
+
+    # ---- inputs -----------------------------------------------------------------------------------------------------
+    def set_reads(self, packed, off, lens, first_global_id, bounds):
+        """This rank's shard of the read set (DnaBuffer layout) and the global partition bounds[world+1]."""
+        self.bounds = np.asarray(bounds, dtype=np.int64)
+        assert len(self.bounds) == self.world + 1 and int(self.bounds[self.rank]) == first_global_id
+        self.nlocal = len(lens)
+        self.be.set_reads(packed, off, lens, first_global_id)
+
+    def generate_and_set_reads(self, w, weak=True):
+        """Synthetic shard: rank r generates reads [bounds[r], bounds[r+1]) of one read set drawn from a genome that grows with the
+        world size (weak scaling: per-GPU reads fixed)."""
+        genome = w["genome"] * (self.world if weak else 1)
+        cfg = capi.SynthCfg(w["seed"], genome, w["depth"], w["avg_len"], w["sd_len"], w["min_len"], w["error"], 0, 0.0, 0, 0, -1)
+        total = int(capi.load_library().elba_synth_num_reads(C.byref(cfg)))
+        per = (total + self.world - 1) // self.world
+        bounds = np.minimum(np.arange(self.world + 1, dtype=np.int64) * per, total)
+        lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
+        packed, off, lens, info = capi.synth_reads(w["seed"], genome, w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"],
+                                                   first_read=lo, num_reads=hi - lo)
+        self.set_reads(packed, off, lens, lo, bounds)
+        info["total_reads"] = total
+        return info
+
+    # ---- collectives ------------------------------------------------------------------------------------------------
+    def _exchange_counts(self, counts):
+        t = self.be.torch.tensor(np.asarray(counts, dtype=np.int64), device=self.be.dev)
+        r = self.be.torch.empty_like(t)
+        self.dist.all_to_all_single(r, t)
+        return r.cpu().numpy()
+
+    def _all_to_all_records(self, send, send_counts, recv_counts):
+        recv = self.be.empty_records(int(np.sum(recv_counts)))
+        self.dist.all_to_all_single(recv, send, output_split_sizes=[int(x) for x in recv_counts], input_split_sizes=[int(x) for x in send_counts])
+        return recv
+
+    def _all_gather_words(self, local, n):
+        torch = self.be.torch
+        ns = [torch.zeros(1, dtype=torch.int64, device=self.be.dev) for _ in range(self.world)]
+        self.dist.all_gather(ns, torch.tensor([n], dtype=torch.int64, device=self.be.dev))
+        ns = [int(x.item()) for x in ns]
+        mx = max(ns + [1])
+        pad = self.be.empty_words(mx)
+        pad.zero_()
+        if n:
+            pad[:n] = local
+        outs = [self.be.empty_words(mx) for _ in range(self.world)]
+        self.dist.all_gather(outs, pad)
+        return torch.cat([o[:m] for o, m in zip(outs, ns)]) if sum(ns) else self.be.empty_words(0), ns
+
+    # ---- stages -----------------------------------------------------------------------------------------------------
+    def build_kmer_matrix(self):
+        """get_kmer_count_map_keys/values + create_kmer_matrix + Transpose, distributed.  Returns (kmer stats, matrix stats)."""
+        W = self.world
+        # exchange #1: instances to owners
+        sc = self.be.count_owners(W)
+        rc = self._exchange_counts(sc)
+        send = self.be.empty_records(int(sc.sum()))
+        self.be.fill_send(W, send, np.concatenate([[0], np.cumsum(sc)[:-1]]))
+        recv = self._all_to_all_records(send, sc, rc)
+        del send
+        ks = self.be.count_records(recv)
+        # global k-mer ids
+        nloc = int(ks["reliable"])
+        allk, ns = self._all_gather_words(self.be.reliable_kmers(nloc), nloc)
+        self.be.set_global_kmers(allk)
+        n_total = int(sum(ns))
+        del recv, allk
+        # exchange #2: column panels to the owners of the reads
+        pc = self.be.panel_counts(W, self.bounds)
+        prc = self._exchange_counts(pc)
+        send = self.be.empty_records(int(pc.sum()))
+        self.be.panel_fill(W, self.bounds, send, np.concatenate([[0], np.cumsum(pc)[:-1]]))
+        panel = self._all_to_all_records(send, pc, prc)
+        del send
+        m_total = int(self.bounds[-1])
+        ms = self.be.set_panel(panel, m_total, n_total, int(self.bounds[self.rank]), int(self.bounds[self.rank + 1]))
+        ks = dict(ks)
+        ks["instances"] = int(sc.sum())          # instances enumerated from THIS rank's reads
+        ks["nreads"] = self.nlocal
+        ms = dict(ms)
+        ms["panel_records"] = int(prc.sum())
+        ms["nnz"] = int(prc.sum())
+        self.exchange_bytes = dict(instances=int(sc.sum()) * 16, panels=int(pc.sum()) * 16)
+        return ks, ms
+
+    def create_seed_matrix(self):
+        return self.be.create_seed_matrix()
+
+    def export_csr(self):
+        """This rank's rows of B (global column ids)."""
+        return self.be.export_csr(int(self.bounds[self.rank]), int(self.bounds[self.rank + 1]))

@@ -184,6 +184,35 @@ int  elba_kmer_histogram(elba_ctx *ctx, int64_t *hist, int64_t len);
 
 int  elba_get_device_view(elba_ctx *ctx, elba_device_view *view);
 
+/* ---- distributed building blocks (one context per rank/GPU; the collectives are issued by the host driver) ----------------
+ * They replace, for a 1D read-row partition over the GPUs of one node, what the reference does with MPI inside the same four
+ * functions: the two k-mer all-to-alls (src/KmerOps.cpp:117-151, :244-274), the k-mer id Exscan (:371-375), and the
+ * redistribution of A / AT to their consumers (SpParMat ctor :396-400, Transpose src/main.cpp:272-273).
+ * A record is two uint64 words.  Exchange #1 records: (packed canonical k-mer, global read id << 32 | pos).
+ * Exchange #2 records: (global k-mer id, global read id << 32 | pos), a column's entries contiguous and ordered by (read,pos). */
+#define ELBA_MAX_RANKS 64
+/* instances of this rank's reads per owner rank (owner = hash of the k-mer, cf. GetKmerOwner src/KmerOps.cpp:352-359) */
+int  elba_dist_count_owners(elba_ctx *ctx, int nranks, uint64_t *counts);
+/* write this rank's records into d_send (device, 16 B per record) grouped by owner; offsets[r] = first record index of owner r */
+int  elba_dist_fill_send(elba_ctx *ctx, int nranks, void *d_send, const uint64_t *offsets);
+/* owner side: exact count + [lower, upper] filter of the received records; builds the owner's columns (device; records are
+ * borrowed until elba_dist_set_global_kmers returns) */
+int  elba_dist_count_records(elba_ctx *ctx, const void *d_records, int64_t nrecords, elba_kmer_stats *stats);
+/* device pointer to this owner's reliable k-mers, ascending (input of the all-gather) */
+int  elba_dist_get_reliable_kmers(elba_ctx *ctx, const void **d_kmers, int64_t *n);
+/* copy them into a caller-owned device buffer of at least n words (e.g. a torch tensor that takes part in the all-gather) */
+int  elba_dist_copy_reliable_kmers(elba_ctx *ctx, void *d_dst, int64_t capacity);
+/* all owners' reliable k-mers concatenated (any order): global k-mer id = rank of the packed value */
+int  elba_dist_set_global_kmers(elba_ctx *ctx, const void *d_all_kmers, int64_t nall);
+/* column panels: read_bounds[r] = first global read id of rank r (read_bounds[nranks] = total reads).  counts[r] = records this
+ * owner sends to rank r: every column, whole, for every rank that owns at least one of its reads */
+int  elba_dist_panel_counts(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, uint64_t *counts);
+int  elba_dist_panel_fill(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, void *d_send, const uint64_t *offsets);
+/* receiver side: the panel of every column touching rows [row_lo,row_hi) -> CSC (global k-mer ids) + CSR; elba_create_seed_matrix
+ * then computes exactly those rows of B (global column ids); elba_export_csr(row_lo,row_hi) / elba_export_dcsc read them */
+int  elba_dist_set_panel(elba_ctx *ctx, const void *d_records, int64_t nrecords, int64_t nreads_total, int64_t nkmers_total,
+                         int64_t row_lo, int64_t row_hi, elba_matrix_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,220 @@
+"""Test-side helpers for the distributed driver (elba_amd/distributed.py):
+
+  * ThreadedGroup — an in-process communicator with torch.distributed's call signatures, so that W ranks can be run as W threads on
+    ONE GPU (the -m gpu tests) exercising the real HIP building blocks with real exchange patterns;
+  * NumpyBackend — a CPU stand-in for the HIP library's elba_dist_* calls, built on the ORACLE's k-mer enumeration and SpGEMM, so that
+    the driver's sequencing and its collectives can be tested under gloo with world_size 2 on a machine without GPUs.
+
+Both live under tests/ on purpose: the product (elba_amd/) never imports the oracle and has no CPU compute path.
+"""
+import threading
+
+import numpy as np
+import torch
+
+from oracle import pyoracle as po
+
+
+class ThreadedGroup:
+    """W ranks = W threads of one process.  handle(rank) returns an object with all_to_all_single / all_gather / all_reduce /
+    barrier that behave like torch.distributed's for that rank."""
+
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+
+    def handle(self, rank):
+        return _Handle(self, rank)
+
+
+class _Handle:
+    class ReduceOp:
+        SUM, MAX = "sum", "max"
+
+    def __init__(self, g, rank):
+        self.g, self.rank = g, rank
+
+    def barrier(self):
+        self.g.bar.wait()
+
+    def all_to_all_single(self, output, input, output_split_sizes=None, input_split_sizes=None):
+        g, W = self.g, self.g.world
+        if input_split_sizes is None:
+            n = input.shape[0] // W
+            input_split_sizes = [n] * W
+            output_split_sizes = [n] * W
+        offs = np.concatenate([[0], np.cumsum(input_split_sizes)]).astype(np.int64)
+        if input.is_cuda:
+            torch.cuda.synchronize()
+        g.slots[self.rank] = [input[int(offs[d]):int(offs[d + 1])] for d in range(W)]
+        g.bar.wait()
+        pos = 0
+        for src in range(W):
+            piece = g.slots[src][self.rank]
+            assert piece.shape[0] == output_split_sizes[src], (piece.shape, output_split_sizes, src, self.rank)
+            output[pos:pos + piece.shape[0]] = piece
+            pos += piece.shape[0]
+        if output.is_cuda:
+            torch.cuda.synchronize()
+        g.bar.wait()
+
+    def all_gather(self, outs, t):
+        g = self.g
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        g.slots[self.rank] = t
+        g.bar.wait()
+        for src in range(g.world):
+            outs[src].copy_(g.slots[src])
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        g.bar.wait()
+
+    def all_reduce(self, t, op="sum"):
+        g = self.g
+        g.slots[self.rank] = t.clone()
+        g.bar.wait()
+        vals = torch.stack([g.slots[s] for s in range(g.world)])
+        res = vals.sum(0) if op == "sum" else vals.max(0).values
+        g.bar.wait()
+        t.copy_(res)
+
+
+def run_ranks(world, fn):
+    """Runs fn(rank, handle) on `world` threads; re-raises the first exception."""
+    g = ThreadedGroup(world)
+    out, err = [None] * world, [None] * world
+
+    def body(r):
+        try:
+            out[r] = fn(r, g.handle(r))
+        except BaseException as e:          # noqa: BLE001
+            err[r] = e
+            g.bar.abort()
+
+    th = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for e in err:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+_M1, _M2 = np.uint64(0xff51afd7ed558ccd), np.uint64(0xc4ceb9fe1a85ec53)
+
+
+def _mix64(k):
+    k = k.astype(np.uint64).copy()
+    with np.errstate(over="ignore"):
+        k ^= k >> np.uint64(33); k *= _M1; k ^= k >> np.uint64(33); k *= _M2; k ^= k >> np.uint64(33)
+    return k
+
+
+class NumpyBackend:
+    """CPU stand-in for HipBackend (same method names and tensor conventions), for the gloo tests only."""
+
+    def __init__(self, k, lower, upper):
+        self.k, self.lower, self.upper = k, lower, upper
+        self.torch = torch
+        self.dev = torch.device("cpu")
+
+    def empty_records(self, n):
+        return torch.zeros((max(int(n), 0), 2), dtype=torch.int64)
+
+    def empty_words(self, n):
+        return torch.zeros((max(int(n), 0),), dtype=torch.int64)
+
+    def set_reads(self, packed, off, lens, first_global_id):
+        L = po.lib()
+        kms, rds, pss = [], [], []
+        for r in range(len(lens)):
+            out = np.zeros(max(1, int(lens[r])), dtype=np.uint64)
+            n = L.orc_read_kmers(packed.ctypes.data + int(off[r]), int(lens[r]), self.k, out.ctypes.data)
+            kms.append(out[:n]); rds.append(np.full(n, first_global_id + r, dtype=np.uint64)); pss.append(np.arange(n, dtype=np.uint64))
+        self.km = np.concatenate(kms) if kms else np.zeros(0, np.uint64)
+        self.rp = ((np.concatenate(rds) << np.uint64(32)) | np.concatenate(pss)) if kms else np.zeros(0, np.uint64)
+
+    def _owner(self, km, W):
+        return ((_mix64(km) >> np.uint64(32)) * np.uint64(W) >> np.uint64(32)).astype(np.int64)
+
+    def count_owners(self, W):
+        self.own = self._owner(self.km, W)
+        return np.bincount(self.own, minlength=W).astype(np.int64)
+
+    def fill_send(self, W, send, offsets):
+        order = np.argsort(self.own, kind="stable")
+        rec = np.stack([self.km[order], self.rp[order]], axis=1).view(np.int64)
+        send.copy_(torch.from_numpy(rec.copy()))
+
+    def count_records(self, rec):
+        a = rec.numpy().view(np.uint64)
+        km, rp = a[:, 0], a[:, 1]
+        order = np.lexsort((rp, km))
+        km, rp = km[order], rp[order]
+        uk, start, cnt = np.unique(km, return_index=True, return_counts=True)
+        keep = (cnt >= self.lower) & (cnt <= self.upper)
+        self.rel = uk[keep]
+        self.cols = [rp[s:s + c] for s, c in zip(start[keep], cnt[keep])]
+        return dict(nreads=0, instances=len(km), distinct=len(uk), reliable=int(keep.sum()), entries=int(cnt[keep].sum()), ms_total=0.0, ms_count=0.0, ms_lookup=0.0, ms_sort=0.0)
+
+    def reliable_kmers(self, n):
+        return torch.from_numpy(self.rel.view(np.int64).copy())
+
+    def set_global_kmers(self, allk):
+        s = np.sort(allk.numpy().view(np.uint64))
+        self.gid = np.searchsorted(s, self.rel).astype(np.uint64)
+
+    def _dests(self, bounds, col):
+        return np.unique(np.searchsorted(np.asarray(bounds, dtype=np.uint64), col >> np.uint64(32), side="right") - 1)
+
+    def panel_counts(self, W, bounds):
+        out = np.zeros(W, dtype=np.int64)
+        for col in self.cols:
+            for d in self._dests(bounds, col):
+                out[d] += len(col)
+        return out
+
+    def panel_fill(self, W, bounds, send, offsets):
+        per = [[] for _ in range(W)]
+        for g, col in zip(self.gid, self.cols):
+            for d in self._dests(bounds, col):
+                per[d].append(np.stack([np.full(len(col), g, dtype=np.uint64), col], axis=1))
+        flat = [np.concatenate(p) if p else np.zeros((0, 2), np.uint64) for p in per]
+        rec = np.concatenate(flat) if flat else np.zeros((0, 2), np.uint64)
+        send.copy_(torch.from_numpy(rec.view(np.int64).copy()))
+
+    def set_panel(self, rec, m_total, n_total, row_lo, row_hi):
+        a = rec.numpy().view(np.uint64)
+        self.o = po.Oracle(self.k, self.lower, self.upper)
+        self.o.set_triples(m_total, n_total, (a[:, 1] >> np.uint64(32)).astype(np.int64), a[:, 0].astype(np.int64), (a[:, 1] & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+        self.win = (row_lo, row_hi)
+        return dict(nrows=m_total, ncols=n_total, nnz=len(a), max_row_nnz=0, ms_total=0.0)
+
+    def create_seed_matrix(self):
+        self.o.spgemm(1)
+        B = self.o.B()
+        lo, hi = self.win
+        e0, e1 = int(B["rowptr"][lo]), int(B["rowptr"][hi])
+        self.B = dict(M=hi - lo, Y=e1 - e0, rowptr=B["rowptr"][lo:hi + 1] - e0, col=B["col"][e0:e1].astype(np.int64), val=B["val"][e0:e1])
+        return dict(nnz=e1 - e0, products=0, algorithmic_bytes=0, ms_total=0.0, ms_numeric=0.0, ms_symbolic=0.0, ms_finalize=0.0)
+
+    def export_csr(self, row_lo, row_hi):
+        return self.B
+
+    def synchronize(self):
+        pass
+
+
+def stitch_rows(parts):
+    """Concatenate per-rank row blocks of B into one CSR."""
+    rowptr, col, val, base = [np.zeros(1, np.int64)], [], [], 0
+    for b in parts:
+        rowptr.append(b["rowptr"][1:] + base)
+        col.append(b["col"]); val.append(b["val"])
+        base += int(b["rowptr"][-1])
+    return dict(rowptr=np.concatenate(rowptr), col=np.concatenate(col), val=np.concatenate(val), Y=base)

@@ -1,0 +1,93 @@
+"""CPU tests of the multi-GPU driver (elba_amd/distributed.py): its sequencing and collectives under torch.distributed `gloo` with
+world_size 2 (real processes), and under the in-process ThreadedGroup with 3 ranks.  The local compute of each rank is the test-side
+NumpyBackend (oracle-based); what is under test is the driver: partition, owner exchange, global k-mer ids, column panels, row windows.
+The stitched per-rank rows of B must equal the single-process oracle's B on the whole read set, bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+import dist_sim
+import elba_amd
+from elba_amd.distributed import DistributedOverlap, partition_by_bases
+from oracle import pyoracle as po
+
+K, LO, UP = 17, 2, 8
+
+
+def _reads():
+    return elba_amd.synth_reads(77, 40000, 10, 2500, 600, error_rate=0.08, min_len=100)
+
+
+def _shard(packed, off, lens, lo, hi):
+    b0 = int(off[lo]) if lo < len(off) else 0
+    b1 = int(off[hi - 1]) + (int(lens[hi - 1]) + 3) // 4 if hi > lo else b0
+    return np.concatenate([packed[b0:b1], np.zeros(16, np.uint8)]), (off[lo:hi] - np.uint64(b0)), lens[lo:hi]
+
+
+def _expected():
+    packed, off, lens, _ = _reads()
+    o = po.Oracle(K, LO, UP)
+    o.count_and_build(packed, off, lens)
+    o.spgemm(2)
+    return o
+
+
+def _run_rank(rank, world, dist, backend):
+    packed, off, lens, _ = _reads()
+    bounds = partition_by_bases(lens, world)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    sp, so, sl = _shard(packed, off, lens, lo, hi)
+    d = DistributedOverlap(K, LO, UP, rank=rank, world=world, dist=dist, backend=backend)
+    d.set_reads(sp, so, sl, lo, bounds)
+    ks, ms = d.build_kmer_matrix()
+    st = d.create_seed_matrix()
+    return d.export_csr(), ks, ms, st
+
+
+def test_partition_rule_matches_reference_greedy():
+    # src/FastaIndex.cpp:47-94: take reads while the next one keeps the rank under total/p; the last rank takes the rest
+    assert partition_by_bases([10, 20, 30, 40, 50, 5, 5], 3).tolist() == [0, 2, 3, 7]
+    assert partition_by_bases([5] * 8, 4).tolist() == [0, 1, 2, 3, 8]          # strict '<' leaves the remainder to the last rank
+    assert partition_by_bases([7, 7, 7], 1).tolist() == [0, 3]
+    b = partition_by_bases(np.random.default_rng(1).integers(100, 5000, 1000), 8)
+    assert b[0] == 0 and b[-1] == 1000 and (np.diff(b) > 0).all()
+
+
+def test_three_ranks_in_process_equal_single_process_oracle():
+    o = _expected()
+    parts = dist_sim.run_ranks(3, lambda r, h: _run_rank(r, 3, h, dist_sim.NumpyBackend(K, LO, UP)))
+    B = dist_sim.stitch_rows([p[0] for p in parts])
+    oB = o.B()
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+    assert sum(p[1]["reliable"] for p in parts) == o.stat("N")          # owners partition the reliable k-mers
+    assert sum(p[1]["entries"] for p in parts) == o.stat("Z")
+    assert sum(p[1]["instances"] for p in parts) == o.stat("I")
+
+
+def _gloo_worker(rank, world, port, outdir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        B, ks, ms, st = _run_rank(rank, world, dist, dist_sim.NumpyBackend(K, LO, UP))
+        np.savez(os.path.join(outdir, "r%d.npz" % rank), rowptr=B["rowptr"], col=B["col"], val=B["val"], reliable=ks["reliable"])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_processes_over_gloo_equal_single_process_oracle(tmp_path):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(os.path.join(str(tmp_path), "r%d.npz" % r)) for r in range(2)]
+    B = dist_sim.stitch_rows([dict(rowptr=p["rowptr"], col=p["col"], val=p["val"]) for p in parts])
+    o = _expected()
+    oB = o.B()
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+    assert sum(int(p["reliable"]) for p in parts) == o.stat("N")

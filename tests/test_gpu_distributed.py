@@ -1,0 +1,61 @@
+"""-m gpu: the distributed building blocks of the HIP library (elba_dist_*) driven by elba_amd/distributed.py with W ranks run as W
+threads on the one GPU of the test box (ThreadedGroup).  The exchange patterns, owner hashing, global k-mer ids, panels and row windows
+are the real ones; only the transport is in-process.  Stitched rows of B must equal the oracle's B on the whole read set."""
+import numpy as np
+import pytest
+
+import dist_sim
+import elba_amd
+from elba_amd.distributed import DistributedOverlap, HipBackend, partition_by_bases
+from oracle import pyoracle as po
+from test_distributed_cpu import _shard
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(world, reads, k, lo, up):
+    packed, off, lens, _ = reads
+    bounds = partition_by_bases(lens, world)
+
+    def body(rank, h):
+        a, b = int(bounds[rank]), int(bounds[rank + 1])
+        sp, so, sl = _shard(packed, off, lens, a, b)
+        d = DistributedOverlap(k, lo, up, device=0, rank=rank, world=world, dist=h, backend=HipBackend(k, lo, up, 0))
+        d.set_reads(sp, so, sl, a, bounds)
+        ks, ms = d.build_kmer_matrix()
+        st = d.create_seed_matrix()
+        out = (d.export_csr(), ks, ms, st)
+        d.be.e.close()
+        return out
+
+    return dist_sim.run_ranks(world, body)
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_sharded_overlap_equals_oracle(world):
+    reads = elba_amd.synth_reads(31, 300000, 15, 4000, 900, error_rate=0.10, min_len=200)
+    o = po.Oracle(17, 2, 8)
+    o.count_and_build(*reads[:3])
+    o.spgemm(4)
+    parts = _run(world, reads, 17, 2, 8)
+    B = dist_sim.stitch_rows([p[0] for p in parts])
+    oB = o.B()
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all()
+    assert (B["val"] == oB["val"]).all()
+    assert sum(p[1]["reliable"] for p in parts) == o.stat("N")
+    assert sum(p[1]["entries"] for p in parts) == o.stat("Z")
+    assert sum(p[1]["instances"] for p in parts) == o.stat("I")
+    assert sum(p[3]["nnz"] for p in parts) == o.stat("Y")
+    assert sum(p[3]["products"] for p in parts) == o.stat("P")
+
+
+def test_uneven_shards_and_empty_rank():
+    """Fewer long reads than ranks can balance: some rank ends up with very few reads; results must not change."""
+    reads = elba_amd.synth_reads(32, 20000, 12, 6000, 3000, error_rate=0.05, min_len=50)
+    o = po.Oracle(17, 2, 12)
+    o.count_and_build(*reads[:3])
+    o.spgemm(2)
+    parts = _run(3, reads, 17, 2, 12)
+    B = dist_sim.stitch_rows([p[0] for p in parts])
+    oB = o.B()
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
