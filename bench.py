@@ -174,7 +174,12 @@ def main():
             "phases_ms": {key: round(v, 4) for key, v in acc.items()},
             "gen_s": round(t_gen, 2),
         }
-        print(json.dumps(out))
+        try:                                     # RCCL prints its version banner through C stdio: flush it first so the JSON line is last
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -117,6 +117,8 @@ class HipBackend:
 
 
 class DistributedOverlap:
+    MAX_RECORDS_PER_PEER = 1 << 25          # 512 MiB of 16-byte records per peer and all-to-all round
+
     def __init__(self, k, lower, upper, device=0, rank=0, world=1, dist=None, backend=None):
         self.k, self.lower, self.upper = k, lower, upper
         self.rank, self.world, self.dist = rank, world, dist
@@ -152,11 +154,38 @@ class DistributedOverlap:
         t = self.be.torch.tensor(np.asarray(counts, dtype=np.int64), device=self.be.dev)
         r = self.be.torch.empty_like(t)
         self.dist.all_to_all_single(r, t)
-        return r.cpu().numpy()
+        return r.cpu().numpy()                      # .cpu() waits for the collective
 
     def _all_to_all_records(self, send, send_counts, recv_counts):
-        recv = self.be.empty_records(int(np.sum(recv_counts)))
-        self.dist.all_to_all_single(recv, send, output_split_sizes=[int(x) for x in recv_counts], input_split_sizes=[int(x) for x in send_counts])
+        torch = self.be.torch
+        sc = np.asarray(send_counts, dtype=np.int64); rc = np.asarray(recv_counts, dtype=np.int64)
+        recv = self.be.empty_records(int(rc.sum()))
+        # Batched like the reference's BatchState (include/KmerOps.hpp:33-56, MAX_ALLTOALL_MEM): at most MAX_RECORDS_PER_PEER
+        # records per peer and round.  Measured on MI355X / RCCL 2.26.6 (scratch test in profiles/r01_notes.md): a single
+        # all_to_all_single message of >= ~2 GiB per peer delivers only its first GiB, silently.
+        CH = self.MAX_RECORDS_PER_PEER
+        rounds = int(max(1, -(-int(max(sc.max(initial=0), rc.max(initial=0))) // CH)))
+        if self.world > 1:
+            t = torch.tensor([rounds], dtype=torch.int64, device=self.be.dev)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            rounds = int(t.item())
+        soff = np.concatenate([[0], np.cumsum(sc)]); roff = np.concatenate([[0], np.cumsum(rc)])
+        if rounds == 1:
+            self.dist.all_to_all_single(recv, send, output_split_sizes=[int(x) for x in rc], input_split_sizes=[int(x) for x in sc])
+        else:
+            for r in range(rounds):
+                s_lo = np.minimum(r * CH, sc); s_hi = np.minimum((r + 1) * CH, sc)
+                r_lo = np.minimum(r * CH, rc); r_hi = np.minimum((r + 1) * CH, rc)
+                part = torch.cat([send[int(soff[p] + s_lo[p]):int(soff[p] + s_hi[p])] for p in range(self.world)])
+                got = self.be.empty_records(int((r_hi - r_lo).sum()))
+                self.dist.all_to_all_single(got, part, output_split_sizes=[int(x) for x in (r_hi - r_lo)], input_split_sizes=[int(x) for x in (s_hi - s_lo)])
+                pos = 0
+                for p in range(self.world):
+                    n = int(r_hi[p] - r_lo[p])
+                    recv[int(roff[p] + r_lo[p]):int(roff[p] + r_hi[p])] = got[pos:pos + n]
+                    pos += n
+        # the collective runs on torch's communication stream, the library on its own HIP stream: make the hand-over explicit
+        self.be.synchronize()
         return recv
 
     def _all_gather_words(self, local, n):
@@ -171,7 +200,9 @@ class DistributedOverlap:
             pad[:n] = local
         outs = [self.be.empty_words(mx) for _ in range(self.world)]
         self.dist.all_gather(outs, pad)
-        return torch.cat([o[:m] for o, m in zip(outs, ns)]) if sum(ns) else self.be.empty_words(0), ns
+        allw = torch.cat([o[:m] for o, m in zip(outs, ns)]) if sum(ns) else self.be.empty_words(0)
+        self.be.synchronize()                       # torch streams -> library stream hand-over
+        return allw, ns
 
     # ---- stages -----------------------------------------------------------------------------------------------------
     def build_kmer_matrix(self):

@@ -69,6 +69,17 @@ def test_three_ranks_in_process_equal_single_process_oracle():
     assert sum(p[1]["instances"] for p in parts) == o.stat("I")
 
 
+def test_batched_all_to_all_rounds_give_the_same_result(monkeypatch):
+    """The exchange is cut into rounds of at most MAX_RECORDS_PER_PEER records per peer (the reference batches its all-to-all too,
+    include/KmerOps.hpp:33-56); force many rounds."""
+    monkeypatch.setattr(DistributedOverlap, "MAX_RECORDS_PER_PEER", 4099)
+    o = _expected()
+    parts = dist_sim.run_ranks(2, lambda r, h: _run_rank(r, 2, h, dist_sim.NumpyBackend(K, LO, UP)))
+    B = dist_sim.stitch_rows([p[0] for p in parts])
+    oB = o.B()
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+
+
 def _gloo_worker(rank, world, port, outdir):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
