@@ -1,0 +1,222 @@
+// elba_host.hpp — C++17 host-side mirror of the reference's operator surface for the overlap hot path, over the C ABI of
+// include/elba_amd.h.  Same function names, argument meaning and ownership conventions as the reference so that
+// src/main.cpp:191-300 reads the same with `elba::` types in place of the CombBLAS ones:
+//
+//   reference                                                        this header
+//   ---------------------------------------------------------------  --------------------------------------------------
+//   DnaBuffer            include/DnaBuffer.hpp:13-38                  elba::DnaBuffer   (same 2-bit layout, src/DnaSeq.cpp:7-29)
+//   KmerCountMap         include/KmerOps.hpp:22                       elba::KmerCountMap (opaque: the counts live in HBM)
+//   get_kmer_count_map_keys / _values   include/KmerOps.hpp:27-30     same names
+//   create_kmer_matrix   include/KmerOps.hpp:24-25                    same name -> elba::KmerMatrix (CSR and CSC both resident)
+//   AT = *A; AT->Transpose()            src/main.cpp:272-273          KmerMatrix copy + Transpose(): no work, both orientations exist
+//   SharedSeeds          include/SharedSeeds.hpp:8-96                 elba::SharedSeeds (same members and accessors)
+//   create_seed_matrix   include/SharedSeeds.hpp:98-99                same name -> elba::SeedMatrix
+//   Bmat.seqptr()->getnnz() / GetDCSC()  src/PairwiseAlignment.cpp:16-19   SeedMatrix::seqptr()->getnnz() / GetDCSC()
+//
+// Errors: the reference asserts/aborts; here every failing C-ABI status throws elba::Error (status + text).
+// There is no CPU path: constructing an engine without a GPU throws ELBA_ERR_NO_DEVICE.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+#include "../../include/elba_amd.h"
+
+namespace elba {
+
+using PosInRead = uint32_t;   // include/KmerOps.hpp:14
+using ReadId = int64_t;       // include/KmerOps.hpp:15
+
+struct Error : std::runtime_error {
+    int status;
+    Error(int s, const std::string &t) : std::runtime_error("elba status " + std::to_string(s) + ": " + t), status(s) {}
+};
+
+// The process grid argument of the reference (std::shared_ptr<CommGrid>): one rank per GPU, 1D here.
+struct Grid {
+    int rank = 0, size = 1, device = 0;
+    int GetRank() const { return rank; }
+    int GetSize() const { return size; }
+};
+
+// 2-bit read buffer, 4 bases per byte, first base in bits 7-6, reads byte-aligned (src/DnaSeq.cpp:7-29, src/DnaBuffer.cpp:22-29).
+class DnaBuffer {
+public:
+    static size_t bytesneeded(size_t n) { return (n + 3) / 4; }                       // include/DnaSeq.hpp:131
+    static size_t computebufsize(const std::vector<size_t> &lens)
+    {
+        size_t s = 0;
+        for (size_t l : lens) s += bytesneeded(l);
+        return s;
+    }
+    explicit DnaBuffer(size_t bufsize = 0) { buf_.reserve(bufsize + 16); }
+    void push_back(char const *s, size_t len)
+    {
+        const size_t nb = bytesneeded(len), at = buf_.size();
+        buf_.resize(at + nb, 0);
+        for (size_t i = 0; i < len; ++i) buf_[at + i / 4] |= (uint8_t)(code(s[i]) << (6 - 2 * (i % 4)));
+        off_.push_back(at);
+        len_.push_back((uint32_t)len);
+    }
+    size_t size() const { return len_.size(); }
+    size_t getbufsize() const { return buf_.size(); }
+    const uint8_t *data() const { return buf_.data(); }
+    const uint64_t *offsets() const { return off_.data(); }
+    const uint32_t *lengths() const { return len_.data(); }
+    int base(size_t read, size_t i) const { return (buf_[off_[read] + i / 4] >> (6 - 2 * (i % 4))) & 3; }   // DnaSeq::operator[]
+
+private:
+    static uint8_t code(char c)                                                        // include/DnaSeq.hpp:136-154
+    {
+        switch (c) {
+        case 'A': case 'a': case 'N': case 'n': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return 4;
+        }
+    }
+    std::vector<uint8_t> buf_;
+    std::vector<uint64_t> off_;
+    std::vector<uint32_t> len_;
+};
+
+// include/SharedSeeds.hpp:8-96 — same members, constructors and accessors (the Semiring runs on the GPU).
+struct SharedSeeds {
+    SharedSeeds() : numshared(0) {}
+    SharedSeeds(PosInRead begQ, PosInRead begT) : numshared(1) { std::get<0>(seeds[0]) = begQ; std::get<1>(seeds[0]) = begT; }
+    SharedSeeds(const std::tuple<PosInRead, PosInRead> &s1, const std::tuple<PosInRead, PosInRead> &s2, int n) : numshared(n) { seeds[0] = s1; seeds[1] = s2; }
+    explicit SharedSeeds(const elba_seed_t &v) : numshared(v.numshared)               // field-wise: never memcpy
+    {
+        std::get<0>(seeds[0]) = v.q0; std::get<1>(seeds[0]) = v.t0;
+        std::get<0>(seeds[1]) = v.q1; std::get<1>(seeds[1]) = v.t1;
+    }
+    int getnumstored() const { return numshared < 2 ? numshared : 2; }
+    int getnumshared() const { return numshared; }
+    const std::tuple<PosInRead, PosInRead> *getseeds() const { return &seeds[0]; }
+    std::tuple<PosInRead, PosInRead> seeds[2];
+    int numshared;
+};
+
+namespace detail {
+struct Engine {
+    elba_ctx *ctx = nullptr;
+    explicit Engine(const elba_cfg &cfg)
+    {
+        int rc = elba_ctx_create(&ctx, &cfg);
+        if (rc != ELBA_OK) throw Error(rc, elba_strerror(rc));
+    }
+    ~Engine() { elba_ctx_destroy(ctx); }
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+    void check(int rc) const { if (rc != ELBA_OK) throw Error(rc, std::string(elba_strerror(rc)) + ": " + elba_last_error(ctx)); }
+};
+}  // namespace detail
+
+// Compile-time constants of the reference (Makefile:1-6, include/compiletime.h) are run-time parameters here.
+struct Params {
+    int kmer_size = 31, lower_kmer_freq = 15, upper_kmer_freq = 35;
+};
+
+class KmerCountMap {
+public:
+    std::shared_ptr<detail::Engine> engine;
+    elba_kmer_stats stats{};
+    size_t size() const { return (size_t)stats.reliable; }       // reliable 'column' k-mers (src/KmerOps.cpp:343-346)
+};
+
+// What the reference's CT<SharedSeeds>::PSpDCCols exposes to PairwiseAlignment (src/PairwiseAlignment.cpp:16-32).
+struct Dcsc {
+    int64_t nzc = 0;
+    std::vector<int64_t> jc, cp, ir;
+    std::vector<SharedSeeds> numx;
+};
+
+class SeqSeedMatrix {
+public:
+    int64_t getnnz() const { return (int64_t)dcsc_.numx.size(); }
+    const Dcsc *GetDCSC() const { return getnnz() ? &dcsc_ : nullptr; }
+    Dcsc dcsc_;
+};
+
+class SeedMatrix {
+public:
+    std::shared_ptr<detail::Engine> engine;
+    elba_overlap_stats stats{};
+    int64_t nrows = 0;
+    int64_t getnnz() const { return stats.nnz; }
+    int64_t getnrow() const { return nrows; }
+    int64_t getncol() const { return nrows; }
+    // local block of this rank's grid cell; one rank: the whole matrix
+    const SeqSeedMatrix *seqptr()
+    {
+        if (!seq_) {
+            elba_dcsc_t d;
+            engine->check(elba_export_dcsc(engine->ctx, 0, nrows, 0, nrows, &d));
+            seq_ = std::make_unique<SeqSeedMatrix>();
+            Dcsc &o = seq_->dcsc_;
+            o.nzc = d.nzc;
+            o.jc.assign(d.jc, d.jc + d.nzc);
+            o.cp.assign(d.cp, d.cp + d.nzc + 1);
+            o.ir.assign(d.ir, d.ir + d.nnz);
+            o.numx.reserve((size_t)d.nnz);
+            for (int64_t i = 0; i < d.nnz; ++i) o.numx.emplace_back(d.numx[i]);
+            elba_free_dcsc(&d);
+        }
+        return seq_.get();
+    }
+
+private:
+    std::unique_ptr<SeqSeedMatrix> seq_;
+};
+
+class KmerMatrix {
+public:
+    std::shared_ptr<detail::Engine> engine;
+    elba_matrix_stats stats{};
+    int64_t getnrow() const { return stats.nrows; }
+    int64_t getncol() const { return stats.ncols; }
+    int64_t getnnz() const { return stats.nnz; }
+    void Transpose() {}        // CSR and CSC of A are both resident on the device: AT is a view, not a copy (src/main.cpp:272-273)
+};
+
+inline std::unique_ptr<KmerCountMap> get_kmer_count_map_keys(const DnaBuffer &myreads, std::shared_ptr<Grid> grid, const Params &prm = Params())
+{
+    if (grid->GetSize() != 1) throw Error(ELBA_ERR_UNSUPPORTED, "the C++ mirror drives one GPU; multi-GPU runs go through the elba_dist_* entry points");
+    elba_cfg cfg{};
+    cfg.k = prm.kmer_size; cfg.lower = prm.lower_kmer_freq; cfg.upper = prm.upper_kmer_freq; cfg.device = grid->device;
+    auto map = std::make_unique<KmerCountMap>();
+    map->engine = std::make_shared<detail::Engine>(cfg);
+    map->engine->check(elba_set_reads(map->engine->ctx, myreads.data(), myreads.offsets(), myreads.lengths(), (int64_t)myreads.size(), 0));
+    // both passes of the reference (keys: src/KmerOps.cpp:18-204, values: :206-350) are one exact count on the GPU
+    map->engine->check(elba_count_kmers(map->engine->ctx, &map->stats));
+    return map;
+}
+
+inline void get_kmer_count_map_values(const DnaBuffer &, KmerCountMap &kmermap, std::shared_ptr<Grid>)
+{
+    if (!kmermap.engine) throw Error(ELBA_ERR_STATE, "get_kmer_count_map_values: empty k-mer map");
+}
+
+inline std::unique_ptr<KmerMatrix> create_kmer_matrix(const DnaBuffer &, const KmerCountMap &kmermap, std::shared_ptr<Grid>)
+{
+    auto A = std::make_unique<KmerMatrix>();
+    A->engine = kmermap.engine;
+    A->engine->check(elba_create_kmer_matrix(A->engine->ctx, &A->stats));
+    return A;
+}
+
+inline std::unique_ptr<SeedMatrix> create_seed_matrix(KmerMatrix &A, KmerMatrix &AT)
+{
+    if (A.engine != AT.engine) throw Error(ELBA_ERR_INVALID_ARG, "create_seed_matrix: A and AT must come from the same create_kmer_matrix");
+    auto B = std::make_unique<SeedMatrix>();
+    B->engine = A.engine;
+    B->nrows = A.stats.nrows;
+    B->engine->check(elba_create_seed_matrix(B->engine->ctx, &B->stats));   // Mult_AnXBn_DoubleBuff + Prune(numshared <= 1), src/SharedSeeds.cpp:7-8
+    return B;
+}
+
+}  // namespace elba

@@ -1,0 +1,61 @@
+// test_host_mirror.cpp — the front half of the reference's main() (src/main.cpp:191-285) written against elba_host.hpp, followed by
+// the DCSC walk of PairwiseAlignment (src/PairwiseAlignment.cpp:28-56).  Prints one JSON line that tests/test_gpu_hostcpp.py
+// compares with the oracle.  Usage: test_host_mirror reads.fa K LOWER UPPER
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include "elba_host.hpp"
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) { std::fprintf(stderr, "usage: %s reads.fa K LOWER UPPER\n", argv[0]); return 2; }
+    elba::Params prm;
+    prm.kmer_size = std::atoi(argv[2]); prm.lower_kmer_freq = std::atoi(argv[3]); prm.upper_kmer_freq = std::atoi(argv[4]);
+    std::ifstream in(argv[1]);
+    std::vector<std::string> seqs;
+    std::string line, cur;
+    while (std::getline(in, line)) {
+        if (!line.empty() && line[0] == '>') { if (!cur.empty()) seqs.push_back(cur); cur.clear(); }
+        else cur += line;
+    }
+    if (!cur.empty()) seqs.push_back(cur);
+    std::vector<size_t> lens;
+    for (auto &s : seqs) lens.push_back(s.size());
+    elba::DnaBuffer mydna(elba::DnaBuffer::computebufsize(lens));
+    for (auto &s : seqs) mydna.push_back(s.c_str(), s.size());
+    auto commgrid = std::make_shared<elba::Grid>();
+    try {
+        auto kmermap = elba::get_kmer_count_map_keys(mydna, commgrid, prm);                 // main.cpp:192
+        elba::get_kmer_count_map_values(mydna, *kmermap, commgrid);                         // main.cpp:225
+        auto A = elba::create_kmer_matrix(mydna, *kmermap, commgrid);                       // main.cpp:259
+        kmermap.reset();                                                                    // main.cpp:266
+        auto AT = std::make_unique<elba::KmerMatrix>(*A);                                   // main.cpp:272
+        AT->Transpose();                                                                    // main.cpp:273
+        auto B = elba::create_seed_matrix(*A, *AT);                                         // main.cpp:281
+        const int64_t nnzA = A->getnnz(), ncol = A->getncol();
+        A.reset(); AT.reset();                                                              // main.cpp:284-285
+        // PairwiseAlignment.cpp:16-56
+        size_t localnnzs = (size_t)B->seqptr()->getnnz();
+        auto dcsc = B->seqptr()->GetDCSC();
+        int64_t nalign = 0;
+        uint64_t checksum = 0;
+        if (dcsc != nullptr)
+            for (int64_t i = 0; i < dcsc->nzc; ++i)
+                for (int64_t j = dcsc->cp[i]; j < dcsc->cp[i + 1]; ++j) {
+                    int64_t localrow = dcsc->ir[j], localcol = dcsc->jc[i];
+                    if ((localrow < localcol) || (localrow <= localcol && localrow < localcol)) {
+                        const elba::SharedSeeds &s = dcsc->numx[j];
+                        ++nalign;
+                        checksum += (uint64_t)std::get<0>(s.getseeds()[0]) * 1000003ull + std::get<1>(s.getseeds()[0]) + (uint64_t)s.getnumshared() * 7919ull
+                                    + (uint64_t)localrow * 31ull + (uint64_t)localcol;
+                    }
+                }
+        std::printf("{\"reads\": %zu, \"nnzA\": %lld, \"kmers\": %lld, \"nnzB\": %zu, \"candidates\": %lld, \"checksum\": %llu}\n", mydna.size(),
+                    (long long)nnzA, (long long)ncol, localnnzs, (long long)nalign, (unsigned long long)checksum);
+    } catch (const elba::Error &e) {
+        std::fprintf(stderr, "%s\n", e.what());
+        return e.status == ELBA_ERR_NO_DEVICE ? 3 : 1;
+    }
+    return 0;
+}

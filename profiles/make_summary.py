@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output directories (gpurun_out/...) into the small, committed summaries under profiles/.
+usage: make_summary.py TAG KERNEL_TRACE_DIR FETCH_PMC_DIR WRITE_PMC_DIR [SQ_PMC_DIR] [STEPS_IN_TRACE]"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def short(n):
+    return re.sub(r"elba::\(anonymous namespace\)::", "", n).split("(")[0].replace("void ", "")
+
+
+def main():
+    tag, ktd, fd, wd = sys.argv[1:5]
+    sqd = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+    ks = glob.glob(os.path.join(ktd, "*", "*kernel_stats.csv"))[0]
+    shutil.copy(ks, os.path.join(HERE, "%s_kernel_stats.csv" % tag))
+    rows = list(csv.DictReader(open(ks)))
+    stats = {short(r["Name"]): dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, total_ms=float(r["TotalDurationNs"]) / 1e6) for r in rows}
+    calls = max(v["calls"] for k, v in stats.items() if k.startswith("k_classify_rows"))      # one classify launch per step
+    spg = {k: v for k, v in stats.items() if k.startswith("k_spgemm_rows")}
+    numeric_us_per_step = sum(v["total_ms"] for v in spg.values()) * 1e3 / calls
+
+    def pmc(d):
+        agg = collections.defaultdict(lambda: collections.defaultdict(float))
+        n = collections.Counter()
+        f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            n[(k, r["Counter_Name"])] += 1
+        return agg, n
+
+    fa, fn = pmc(fd)
+    wa, wn = pmc(wd)
+    steps_f = fn[("k_classify_rows", "FETCH_SIZE")]
+    steps_w = wn[("k_classify_rows", "WRITE_SIZE")]
+    fetch_kb = sum(v["FETCH_SIZE"] for k, v in fa.items() if k.startswith("k_spgemm_rows")) / steps_f
+    write_kb = sum(v["WRITE_SIZE"] for k, v in wa.items() if k.startswith("k_spgemm_rows")) / steps_w
+    hit = sum(v.get("TCC_HIT_sum", 0) for k, v in wa.items() if k.startswith("k_spgemm_rows")) / steps_w
+    miss = sum(v.get("TCC_MISS_sum", 0) for k, v in wa.items() if k.startswith("k_spgemm_rows")) / steps_w
+    out = {
+        "tag": tag, "workload": "ecsample30x-like", "n_gpus": 1,
+        "steps_in_trace": calls,
+        "numeric_kernels_us_per_step": round(numeric_us_per_step, 2),
+        "kernel_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(stats.items()) if k.startswith("k_")},
+        "FETCH_SIZE_KB_per_step": round(fetch_kb, 1), "WRITE_SIZE_KB_per_step": round(write_kb, 1),
+        "TCC_HIT_per_step": round(hit), "TCC_MISS_per_step": round(miss),
+        "bytes_per_TCC_miss": round(fetch_kb * 1024 / max(1, miss), 1),
+        # MI355X_MICROARCH.md §HBM: FETCH_SIZE = TCC_EA0_RDREQ x 64 B and under-reports 128-B streaming requests by 2x.  This kernel's
+        # reads are 8-byte gathers and 512-byte row segments; FETCH_SIZE / TCC_MISS ~ 64 B says the requests are 64-B ones, for which
+        # the counter is taken at face value; the x2 figure is given as the upper bound.
+        "hbm_bytes_per_step_dominant_kernel": int(fetch_kb * 1024 + write_kb * 1024),
+        "hbm_bytes_per_step_upper_bound_if_128B_requests": int(2 * fetch_kb * 1024 + write_kb * 1024),
+    }
+    if sqd:
+        sa, sn = pmc(sqd)
+        steps_s = sn[("k_classify_rows", "SQ_WAVES")] or 1
+        out["SQ_per_step"] = {c: round(sum(v.get(c, 0) for k, v in sa.items() if k.startswith("k_spgemm_rows")) / steps_s)
+                              for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
+    json.dump(out, open(os.path.join(HERE, "%s_summary.json" % tag), "w"), indent=1)
+    json.dump({"workload": out["workload"], "n_gpus": 1, "source": "%s_summary.json" % tag,
+               "hbm_bytes_per_step_dominant_kernel": out["hbm_bytes_per_step_dominant_kernel"]}, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

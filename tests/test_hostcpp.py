@@ -1,0 +1,53 @@
+"""The C++ host mirror (elba_amd/hostcpp/elba_host.hpp): reference-named functions over the C ABI.  The self-test binary runs the front
+half of the reference's main() and PairwiseAlignment's DCSC walk; on the GPU its output must match the oracle."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import util
+from oracle import pyoracle as po
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "elba_amd", "hostcpp", "test_host_mirror")
+
+
+def _build():
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "elba_amd", "hostcpp")], stdout=subprocess.DEVNULL)
+
+
+def test_mirror_builds_and_fails_loudly_without_gpu():
+    _build()
+    p = subprocess.run([BIN, os.path.join(util.GOLDEN, "small_err.fa"), "17", "2", "8"], capture_output=True, text=True)
+    if p.returncode == 3:
+        assert "no HIP device" in p.stderr          # no silent CPU path
+    else:
+        assert p.returncode == 0 and json.loads(p.stdout)["reads"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,idx", [("small_err", 0), ("small_clean", 1)])
+def test_mirror_matches_oracle_on_gpu(name, idx):
+    if not os.path.exists(BIN):
+        _build()
+    m = util.golden_meta()[name][idx]
+    k, lo, up = m["k"], m["lower"], m["upper"]
+    fa = os.path.join(util.GOLDEN, name + ".fa")
+    p = subprocess.run([BIN, fa, str(k), str(lo), str(up)], capture_output=True, text=True, check=True)
+    got = json.loads(p.stdout)
+    packed, off, lens = po.pack_reads(util.read_fasta(fa))
+    o = po.Oracle(k, lo, up)
+    o.count_and_build(packed, off, lens)
+    o.spgemm(1)
+    B = o.B()
+    rows = np.repeat(np.arange(B["M"], dtype=np.uint64), np.diff(B["rowptr"]))
+    cols = B["col"].astype(np.uint64)
+    up_mask = rows < cols
+    v = B["val"][up_mask]
+    chk = (v["q0"].astype(np.uint64) * np.uint64(1000003) + v["t0"].astype(np.uint64) + v["numshared"].astype(np.uint64) * np.uint64(7919)
+           + rows[up_mask] * np.uint64(31) + cols[up_mask])
+    with np.errstate(over="ignore"):
+        checksum = int(chk.sum(dtype=np.uint64))
+    assert got == {"reads": m["M"], "nnzA": m["Z"], "kmers": m["N"], "nnzB": m["Y"], "candidates": o.stat("nupper"), "checksum": checksum}
