@@ -103,15 +103,22 @@ __global__ __launch_bounds__(EN_THREADS) void k_kmer_count(EnumParams e, unsigne
     });
 }
 
-struct SelCounters { unsigned long long distinct, reliable, entries; };
+struct SelCounters { unsigned long long distinct, reliable, entries, cursor; };
+constexpr uint32_t SEL_CHUNK = 256;      // output slots a wavefront draws from the global cursor at a time
 
+// Sweep of the k-mer table: keys with lower <= count <= upper are compacted (wave ballot + popcount prefix) into out_keys/out_slots.
+// A wavefront draws SEL_CHUNK output slots at a time from ONE global cursor (a single hot counter sustains only ~10^8 atomics/s:
+// one atomic per ballot made this kernel 48 ms on 5.4 M reliable k-mers).  out_keys is pre-filled with KEMPTY, so unused chunk tails
+// sort behind every real k-mer; the exact number of reliable k-mers is ctr->reliable.
 __global__ __launch_bounds__(256) void k_table_select(const uint64_t *keys, uint32_t *vals, uint64_t cap, uint32_t lower, uint32_t upper,
                                                       uint64_t *out_keys, uint64_t *out_slots, SelCounters *ctr)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t lt = (1ull << lane) - 1;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long nd = 0, nz = 0;
+    unsigned long long nd = 0, nz = 0, nr = 0;
+    unsigned long long chunk_off = 0;
+    uint32_t chunk_left = 0;
     for (uint64_t s0 = (uint64_t)blockIdx.x * blockDim.x; s0 < cap; s0 += stride) {     // block-uniform trip count
         const uint64_t s = s0 + threadIdx.x;
         bool keep = false;
@@ -122,20 +129,25 @@ __global__ __launch_bounds__(256) void k_table_select(const uint64_t *keys, uint
                 ++nd;
                 const uint32_t c = vals[s];
                 keep = c >= lower && c <= upper;
-                if (keep) nz += c; else vals[s] = NOT_RELIABLE;
+                if (keep) { nz += c; ++nr; } else vals[s] = NOT_RELIABLE;
             }
         }
         const uint64_t bal = __ballot(keep);
         if (bal) {
-            unsigned long long base = 0;
-            if (lane == 0) base = atomicAdd(&ctr->reliable, (unsigned long long)__popcll(bal));
-            base = __shfl(base, 0, 64);
-            if (keep) { const uint64_t at = base + __popcll(bal & lt); out_keys[at] = km; out_slots[at] = s; }
+            const uint32_t n = (uint32_t)__popcll(bal);
+            if (n > chunk_left) {                                   // wave-uniform: abandon the tail (it stays KEMPTY), draw a new chunk
+                unsigned long long base = 0;
+                if (lane == 0) base = atomicAdd(&ctr->cursor, (unsigned long long)SEL_CHUNK);
+                chunk_off = __shfl(base, 0, 64);
+                chunk_left = SEL_CHUNK;
+            }
+            if (keep) { const uint64_t at = chunk_off + __popcll(bal & lt); out_keys[at] = km; out_slots[at] = s; }
+            chunk_off += n; chunk_left -= n;
         }
     }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_xor(nd, d, 64); nz += __shfl_xor(nz, d, 64); }
-    if (lane == 0) { if (nd) atomicAdd(&ctr->distinct, nd); if (nz) atomicAdd(&ctr->entries, nz); }
+    for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_xor(nd, d, 64); nz += __shfl_xor(nz, d, 64); nr += __shfl_xor(nr, d, 64); }
+    if (lane == 0) { if (nd) atomicAdd(&ctr->distinct, nd); if (nz) atomicAdd(&ctr->entries, nz); if (nr) atomicAdd(&ctr->reliable, nr); }
 }
 
 __global__ void k_assign_ids(const uint64_t *sorted_slots, uint32_t *vals, uint32_t *counts, uint64_t N)
@@ -213,8 +225,8 @@ void stage_count_kmers(Ctx &c)
     c.inst_off.reserve((size_t)(M + 1) * 8);
     ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s));
 
-    // table: load factor <= 1/2 (distinct <= I)
-    int cbits = next_pow2_bits(2 * I + 2);
+    // table capacity (power of two)
+    int cbits = next_pow2_bits(I + I / 4 + 2);      // load factor <= 0.8 even if every instance were distinct; ~0.35 on real reads
     if (cbits < 10) cbits = 10;
     size_t free_b = 0, total_b = 0;
     ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -240,20 +252,19 @@ void stage_count_kmers(Ctx &c)
     SelCounters *dctr = c.ws_scan.as<SelCounters>();
     ELBA_HIP(hipMemsetAsync(dctr, 0, sizeof(SelCounters), s));
     // worst case every distinct k-mer is reliable: N <= I / lower
-    const uint64_t maxN = I / (uint64_t)c.cfg.lower + 1;
+    const int sel_blocks = c.num_cus * 8;
+    const uint64_t maxN = I / (uint64_t)c.cfg.lower + 1 + (uint64_t)sel_blocks * 4 * SEL_CHUNK;   // + one open chunk per wavefront
     c.ws_a.reserve(maxN * 8); c.ws_b.reserve(maxN * 8); c.ws_c.reserve(maxN * 8); c.ws_d.reserve(maxN * 8);
-    {
-        int nb = c.num_cus * 8;
-        hipLaunchKernelGGL(k_table_select, dim3(nb), dim3(256), 0, s, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap,
-                           (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), dctr);
-    }
+    ELBA_HIP(hipMemsetAsync(c.ws_a.p, 0xFF, maxN * 8, s));          // KEMPTY: unused chunk tails sort last
+    hipLaunchKernelGGL(k_table_select, dim3(sel_blocks), dim3(256), 0, s, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap,
+                       (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), dctr);
     SelCounters hc{};
     ELBA_HIP(hipMemcpyAsync(&hc, dctr, sizeof(hc), hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
     const uint64_t N = hc.reliable, Z = hc.entries;
     ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
-    // k-mer ids = rank of the packed value
-    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)N, 64 - 2 * k, 64, c.ws_sort);
+    // k-mer ids = rank of the packed value (the hc.cursor - N sentinel keys sort behind the N real ones)
+    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)hc.cursor, 64 - 2 * k, 64, c.ws_sort);
     const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>();
     const uint64_t *sslots = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
     c.rel_kmers.reserve((size_t)(N + 1) * 8);
@@ -485,7 +496,7 @@ void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
     c.have_counts = false; c.have_A = false; c.have_B = false;
     c.d_records = static_cast<const uint64_t *>(d_rec); c.nrecords = nrec;
     const uint64_t I = (uint64_t)nrec;
-    int cbits = next_pow2_bits(2 * I + 2);
+    int cbits = next_pow2_bits(I + I / 4 + 2);      // load factor <= 0.8 even if every instance were distinct; ~0.35 on real reads
     if (cbits < 10) cbits = 10;
     const uint64_t cap = 1ull << cbits;
     c.tab_cap = (int64_t)cap;
@@ -497,16 +508,18 @@ void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
     c.ws_scan.reserve(256);
     SelCounters *dctr = c.ws_scan.as<SelCounters>();
     ELBA_HIP(hipMemsetAsync(dctr, 0, sizeof(SelCounters), s));
-    const uint64_t maxN = I / (uint64_t)c.cfg.lower + 1;
+    const int sel_blocks = c.num_cus * 8;
+    const uint64_t maxN = I / (uint64_t)c.cfg.lower + 1 + (uint64_t)sel_blocks * 4 * SEL_CHUNK;
     c.ws_a.reserve(maxN * 8); c.ws_b.reserve(maxN * 8); c.ws_c.reserve(maxN * 8); c.ws_d.reserve(maxN * 8);
-    hipLaunchKernelGGL(k_table_select, dim3(c.num_cus * 8), dim3(256), 0, s, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap,
+    ELBA_HIP(hipMemsetAsync(c.ws_a.p, 0xFF, maxN * 8, s));
+    hipLaunchKernelGGL(k_table_select, dim3(sel_blocks), dim3(256), 0, s, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap,
                        (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), dctr);
     SelCounters hc{};
     ELBA_HIP(hipMemcpyAsync(&hc, dctr, sizeof(hc), hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
     const uint64_t N = hc.reliable, Z = hc.entries;
     ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "nnz beyond 32-bit device offsets");
-    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)N, 64 - 2 * k, 64, c.ws_sort);
+    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)hc.cursor, 64 - 2 * k, 64, c.ws_sort);
     const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>();
     const uint64_t *sslots = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
     c.rel_kmers.reserve((size_t)(N + 1) * 8);
