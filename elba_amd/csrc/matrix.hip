@@ -97,7 +97,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.M = M; c.N = N; c.Z = Z;
     c.a_colptr.reserve((size_t)(N + 1) * 4);
     c.a_rowptr.reserve((size_t)(M + 1) * 4);
-    c.a_csc.reserve((size_t)(Z + 1) * 8);
+    c.a_csc.reserve((size_t)(Z + 2) * 8);   // +2 guard entries: the SpGEMM reads column entries in 16-byte pairs
     c.a_csr.reserve((size_t)(Z + 1) * 8);
     group_offsets_u32(s, kid_keys, kid_shift, Z, c.a_colptr.as<uint32_t>(), N);
     if (csc != c.a_csc.as<uint64_t>() && Z > 0)

@@ -312,12 +312,16 @@ void stage_create_seed_matrix(Ctx &c)
         if (nrows > 0) {
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
-            const size_t X = 64;   // misc words
-            hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * (getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 8)), dim3(64), (size_t)20 * 512 + X, s, p, 0, 9u);
-            hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * 8), dim3(128), (size_t)20 * 1024 + X, s, p, 1, 10u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 4), dim3(256), (size_t)20 * 2048 + X, s, p, 2, 11u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 2), dim3(256), (size_t)20 * 4096 + X, s, p, 3, 12u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, true>), dim3(spill_blocks), dim3(256), X, s, p, NUM_LDS_TIERS, 0u);
+            const size_t X = 64;   // misc words (+ per-wave product queues: 64 lanes x 8 products x 8 B = 4 KiB per wave)
+            const size_t Q = 4096;
+            const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 8;
+            const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob; 128 x 8 per CU measured best)
+            if (b0 == 128) hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * g0), dim3(128), (size_t)20 * 512 + X + 2 * Q, s, p, 0, 9u);
+            else hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * g0), dim3(64), (size_t)20 * 512 + X + Q, s, p, 0, 9u);
+            hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * 8), dim3(128), (size_t)20 * 1024 + X + 2 * Q, s, p, 1, 10u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 4), dim3(256), (size_t)20 * 2048 + X + 4 * Q, s, p, 2, 11u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 2), dim3(256), (size_t)20 * 4096 + X + 4 * Q, s, p, 3, 12u);
+            hipLaunchKernelGGL((k_spgemm_rows<256, true>), dim3(spill_blocks), dim3(256), X + 4 * Q, s, p, NUM_LDS_TIERS, 0u);
             ELBA_HIP(hipGetLastError());
         }
         c.t_b.stop(s);
