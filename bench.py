@@ -29,6 +29,8 @@ sys.path.insert(0, ROOT)
 WORKLOADS = {
     # name: (reads per GPU, genome bases per GPU, depth, avg_len, sd_len, min_len, error, k, L, U, seed)
     "ecsample30x-like": dict(genome=4_640_000, depth=30.0, avg_len=8240.0, sd_len=2000.0, min_len=1000, error=0.15, k=17, lower=2, upper=8, seed=1),
+    # BASELINE.json configs[2] restated per SURVEY.md §8d-3 (the whole set on ONE GPU when run with --gpus 1; parity-test/scale case, not the bench line)
+    "200k-long-reads": dict(genome=66_700_000, depth=30.0, avg_len=10000.0, sd_len=1500.0, min_len=1000, error=0.15, k=17, lower=2, upper=8, seed=2),
     "plumbing-135": dict(genome=100_000, depth=13.5, avg_len=10000.0, sd_len=1000.0, min_len=1000, error=0.0, k=17, lower=2, upper=8, seed=313),
 }
 
@@ -172,6 +174,7 @@ def main():
             "kmer_stage": {"device_ms": round(ks["ms_total"] + ms["ms_total"], 3), "wall_ms": round(t_kmer_wall * 1e3, 3),
                            "instances_per_s": round(ks["instances"] / max(1e-9, t_kmer_wall), 1), "count_ms": round(ks["ms_count"], 3), "select_sort_ms": round(ks["ms_sort"], 3)},
             "phases_ms": {key: round(v, 4) for key, v in acc.items()},
+            "tiers": {key: int(st[key]) for key in ("rows_lds", "rows_global", "rows_escalated", "nnz_before_prune", "passes") if key in st},
             "gen_s": round(t_gen, 2),
         }
         try:                                     # RCCL prints its version banner through C stdio: flush it first so the JSON line is last

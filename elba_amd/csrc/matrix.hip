@@ -122,6 +122,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_csrx.as<uint64_t>());
     }
     c.row_lo = 0; c.row_hi = -1;
+    c.ov_prior_q16 = 0;            // a new matrix: forget the partner/product ratio measured on the previous one
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
     c.have_A = true;

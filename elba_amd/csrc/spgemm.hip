@@ -35,6 +35,15 @@ constexpr uint32_t STAGE_CHUNK = 1024;          // staging entries a workgroup d
 constexpr uint32_t FIN_WAVE_MAX = 256;          // widest row the one-wave column sort takes
 constexpr uint32_t FIN_LDS_MAX = 4096;          // widest row the LDS bitonic sort takes
 
+// End-of-kernel statistics are flushed into one of 64 shards (each on its own 128-B line): thousands of workgroups adding to a
+// single line serialise at ~15 ns per atomic, which showed up as 0.1-0.2 ms on a 0.6 ms kernel.
+struct alignas(128) OvShard {
+    unsigned long long yraw, nnz, ndiag, nupper, fb_claims, fb_ub;
+    unsigned int maxshared;
+    unsigned int tier_done[NUM_TIERS];
+};
+constexpr int NUM_SHARDS = 64;
+
 struct OvCounters {              // device-side counters, zeroed per call
     unsigned long long cursor;   // next free staging slot
     unsigned long long products; // P
@@ -48,6 +57,9 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned int tier_done[NUM_TIERS];    // rows completed per tier
     unsigned int fin_count[2];            // rows needing the LDS-bitonic / HBM-bitonic column sort
     unsigned int pad[2];
+    unsigned long long pad2[14];          // keep the feedback sums on a cache line of their own
+    unsigned long long fb_claims, fb_ub;  // feedback: distinct partners found / products, summed over rows done so far in this call
+    OvShard shard[NUM_SHARDS];
     unsigned long long phase[8];          // diagnostic (cfg.flags & 16): shader-clock cycles per kernel phase, summed over workgroups
 };
 
@@ -57,6 +69,8 @@ struct OvParams {
     uint32_t Mcols;          // number of reads overall (partner id range)
     uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
+    uint32_t use_feedback;   // 1 on the first call for a matrix (no measured prior yet): in-call self-correction through the hot fb_* sums
+    uint32_t prior_q16;      // distinct-partners / products estimate in 1/65536 units (1/16 before anything is known; measured by the previous call afterwards)
     uint32_t dbg;            // diagnostic ablations (cfg.flags): 1 = gathers only (no accumulator updates), 2 = accumulator only (synthetic partners)
     uint32_t *row_cnt;       // [M+1]
     unsigned long long *row_off;   // [M]
@@ -96,12 +110,13 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
         prod += ub;
         cap += ub < p.Mcols ? ub : p.Mcols;
         const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
-        // optimistic estimate of distinct partners: a sixteenth of the products (measured 0.06 on 15 %-error reads,
-        // far less on accurate ones), at least 128; a wrong guess costs one abandoned attempt, never correctness
-        uint32_t est = ub >> 4;
+        // optimistic estimate of distinct partners = products x prior (1/16 at first: measured 0.06 on 15 %-error reads, far less on
+        // accurate ones; afterwards the ratio the previous call measured, x 1.25), at least 128.  A wrong guess costs an abandoned
+        // attempt, never correctness; within a call the numeric kernel corrects itself from the rows already done.
+        uint32_t est = (uint32_t)(((unsigned long long)ub * p.prior_q16) >> 16);
         if (est < 128) est = 128;
         int tier = 0;
-        while (tier < NUM_LDS_TIERS && est > (1u << (LDS_TBITS0 + tier - 1))) ++tier;      // est <= 1/2 of the table
+        while (tier < NUM_LDS_TIERS && est > ((1u << (LDS_TBITS0 + tier)) >> 2) * 3 - 1) ++tier;      // est <= the tier's abandon limit (3/4 of the table)
         // never start above the tier that is already guaranteed to fit
         const int gt = gbits <= LDS_TBITS0 ? 0 : (int)gbits - LDS_TBITS0;
         if (gt < tier) tier = gt;
@@ -264,6 +279,8 @@ void stage_create_seed_matrix(Ctx &c)
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
     p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_csrx = c.a_csrx.as<uint64_t>();
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
+    p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;
+    p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     p.row_cnt = c.ov_rowcnt.as<uint32_t>();
     p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
     p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
@@ -312,7 +329,7 @@ void stage_create_seed_matrix(Ctx &c)
         if (nrows > 0) {
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
-            const size_t X = 64;   // misc words (+ per-wave product queues: 64 lanes x 8 products x 8 B = 4 KiB per wave)
+            const size_t X = 128;  // misc words (+ per-wave product queues: 64 lanes x 8 products x 8 B = 4 KiB per wave)
             const size_t Q = 4096;
             const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 8;
             const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob; 128 x 8 per CU measured best)
@@ -333,6 +350,13 @@ void stage_create_seed_matrix(Ctx &c)
         c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;      // the bound that cannot overflow
     }
 
+    hc.fb_claims = 0; hc.fb_ub = 0;                 // the hot in-call sums are a subset of what the shards hold
+    for (int sh = 0; sh < NUM_SHARDS; ++sh) {       // fold the statistics shards
+        const OvShard &x = hc.shard[sh];
+        hc.yraw += x.yraw; hc.nnz += x.nnz; hc.ndiag += x.ndiag; hc.nupper += x.nupper; hc.fb_claims += x.fb_claims; hc.fb_ub += x.fb_ub;
+        if (x.maxshared > hc.maxshared) hc.maxshared = x.maxshared;
+        for (int t = 0; t < NUM_TIERS; ++t) hc.tier_done[t] += x.tier_done[t];
+    }
     // row pointers, final arrays
     const int64_t Y = (int64_t)hc.nnz;
     c.t_c.start(s);
@@ -367,6 +391,10 @@ void stage_create_seed_matrix(Ctx &c)
     if (c.cfg.flags & 16) {   // diagnostic: per-phase shader-clock totals over all workgroups of the numeric kernels
         fprintf(stderr, "[elba dbg] phase cycles (sum over %llu workgroups): fetch=%llu init=%llu accumulate=%llu sweep=%llu reserve=%llu decode=%llu\n",
                 hc.phase[6], hc.phase[0], hc.phase[1], hc.phase[2], hc.phase[3], hc.phase[4], hc.phase[5]);
+    }
+    if (hc.fb_ub > 0) {   // remember the measured distinct/products ratio (+25 %) for the next call's starting tiers
+        double r = 1.25 * (double)hc.fb_claims / (double)hc.fb_ub * 65536.0;
+        c.ov_prior_q16 = r < 64.0 ? 64u : (r > 65536.0 ? 65536u : (uint32_t)r);
     }
     st.products = (int64_t)hc.products;
     st.nnz_before_prune = (int64_t)hc.yraw;

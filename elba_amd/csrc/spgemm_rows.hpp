@@ -12,7 +12,7 @@
 // levels instead of ~30 in the entry-at-a-time form.
 
 // misc words in LDS: 0 diag n, 1 diag smin, 2 diag smax, 3 survivors, 4 y, 5 yraw, 6/7 staging offset lo/hi, 8 fits,
-//                    9 claimed slots, 10 abandon flag
+//                    9 claimed slots, 10 abandon flag, 11 row entries consumed when the row was abandoned
 template <bool GLOBAL>
 struct Table {
     uint32_t *keys, *cnt, *smin, *smax, *misc;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     // LDS tiers: keys | cnt | smin | smax | survivor list (u32 each, T entries) | misc;  spill tier: only misc lives in LDS
     uint32_t *misc = GLOBAL ? smem : smem + (size_t)5 * (1u << lds_tbits);
     // per-wave product queue: 64 lanes x SPEC products, partner id and sequence number
-    uint32_t *qj = misc + 16 + (threadIdx.x >> 6) * (2 * 64 * SPEC);
+    uint32_t *qj = misc + 32 + (threadIdx.x >> 6) * (2 * 64 * SPEC);
     uint32_t *qs = qj + 64 * SPEC;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1;
@@ -97,13 +97,56 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #define ELBA_STAMP(k) do { if (stamp) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tprev; tprev = tn; } } while (0)
 
+    unsigned long long fb_c = 0, fb_u = 0;      // this workgroup's contribution to the feedback sums (flushed every few rows)
+    uint32_t fb_n = 0, fb_seen = 0;
+    unsigned long long tot_c = 0, tot_u = 0;    // already pushed to the hot sums (first call only)
+    unsigned long long gu = 0, gc = 0;
+
+    uint32_t i_next = blockIdx.x < nrows ? p.lists[(size_t)tier * p.M + blockIdx.x] : 0u;
     for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const uint32_t i = p.lists[(size_t)tier * p.M + it];
+        // the row id of the NEXT iteration is fetched now; this row's bounds and product count are loaded together, up front:
+        // one memory round trip instead of three dependent ones on the row's critical path
+        const uint32_t i = i_next;
+        if (it + gridDim.x < nrows) i_next = p.lists[(size_t)tier * p.M + it + gridDim.x];
+        const uint32_t rs = p.a_rowptr[i], re = p.a_rowptr[i + 1];
+        const uint32_t ub_i = p.a_rowprod[i];
+        if (!GLOBAL && p.use_feedback) {
+            // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
+            // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
+            // (the sums live on one hot L2 line: lane 0 reads them once per 8 rows of this workgroup and broadcasts through LDS —
+            //  the decision below must be workgroup-uniform, so every lane has to see the SAME snapshot)
+            if ((fb_seen++ & 7u) == 0) {
+                if (tid == 0) {
+                    const unsigned long long u = __hip_atomic_load(&p.ctr->fb_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long c = __hip_atomic_load(&p.ctr->fb_claims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    misc[16] = (uint32_t)u; misc[17] = (uint32_t)(u >> 32); misc[18] = (uint32_t)c; misc[19] = (uint32_t)(c >> 32);
+                }
+                __syncthreads();
+                gu = ((unsigned long long)misc[17] << 32) | misc[16];
+                gc = ((unsigned long long)misc[19] << 32) | misc[18];
+                __syncthreads();
+            }
+            if (gu >= (1ull << 20)) {
+                const double pred = 1.25 * (double)ub_i * (double)gc / (double)gu;
+                const uint32_t Tt = 1u << lds_tbits;
+                // forward only on strong evidence (short rows finish first and have a higher partner/product ratio: the running sums
+                // are biased high early in a call): predicted partners beyond 1.2x the abandon limit
+                if (pred > 1.2 * (double)((Tt >> 2) * 3 - 1) && guaranteed_tbits(ub_i, p.Mcols) > lds_tbits) {
+                    int t2 = tier + 1;
+                    while (t2 < NUM_LDS_TIERS && pred > (double)(((1u << (LDS_TBITS0 + t2)) >> 2) * 3 - 1)) ++t2;
+                    if (tid == 0) {
+                        const uint32_t at = atomicAdd(&p.ctr->tier_count[t2], 1u);
+                        p.lists[(size_t)t2 * p.M + at] = i;
+                    }
+                    continue;
+                }
+            }
+        }
         Table<GLOBAL> tab;
         tab.misc = misc;
         uint32_t *list;
         if (GLOBAL) {
-            tab.tbits = guaranteed_tbits(p.a_rowprod[i], p.Mcols);
+            tab.tbits = guaranteed_tbits(ub_i, p.Mcols);
             tab.limit = 0xFFFFFFFFu;
             uint32_t *base = p.gtable + (size_t)blockIdx.x * 5 * p.gstride;
             tab.keys = base; tab.cnt = base + p.gstride; tab.smin = base + 2 * p.gstride; tab.smax = base + 3 * p.gstride;
@@ -123,7 +166,6 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         ELBA_STAMP(1);
 
         // ---- expand + accumulate ----
-        const uint32_t rs = p.a_rowptr[i], re = p.a_rowptr[i + 1];
         uint32_t dn = 0, dmin = 0xFFFFFFFFu, dmax = 0;
         bool full = false;
         // Software-pipelined, NOT unrolled over the row: the kernel must stay small — a fully unrolled 16x4 inline-insert body
@@ -216,7 +258,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             }
 #pragma unroll
             for (int q = 0; q < GRP; ++q) xc[q] = xn[q];
-            if (tab.abandoned()) break;
+            if (tab.abandoned()) { if (tid == 0) misc[11] = gb + GRP * BLOCK - rs < re - rs ? gb + GRP * BLOCK - rs : re - rs; break; }
         }
         if (dn) { atomicAdd(&misc[0], dn); atomicMin(&misc[1], dmin); atomicMax(&misc[2], dmax); }
         __syncthreads();
@@ -226,6 +268,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             if (tid == 0) {
                 const uint32_t at = atomicAdd(&p.ctr->tier_count[tier + 1], 1u);
                 p.lists[(size_t)(tier + 1) * p.M + at] = i;
+                // the table filled after `gb_done` of the row's entries: extrapolate its distinct-partner count for the feedback
+                const uint32_t done = misc[11] ? misc[11] : 1u, all = re - rs;
+                fb_c += (unsigned long long)misc[9] * all / done; fb_u += ub_i; ++fb_n;
             }
             __syncthreads();
             continue;
@@ -266,6 +311,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             acc_done += 1;
             acc_ndiag += dcount >= 2 ? 1u : 0u;
             acc_y += ytot;
+            if (!GLOBAL) { fb_c += misc[9]; fb_u += ub_i; ++fb_n; }
+            if (p.use_feedback && fb_n >= 8) { atomicAdd(&p.ctr->fb_claims, fb_c); atomicAdd(&p.ctr->fb_ub, fb_u); tot_c += fb_c; tot_u += fb_u; fb_c = 0; fb_u = 0; fb_n = 0; }
             if (ytot > FIN_WAVE_MAX) {                         // rows too wide for the one-wave column sort
                 const int which = ytot > FIN_LDS_MAX ? 1 : 0;
                 const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
@@ -308,14 +355,20 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     // flush the workgroup's statistics: a handful of atomics per workgroup instead of six per row
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { acc_nup += __shfl_xor(acc_nup, d, 64); uint32_t o = __shfl_xor(acc_mx, d, 64); acc_mx = o > acc_mx ? o : acc_mx; }
+    OvShard *sh = &p.ctr->shard[blockIdx.x & (NUM_SHARDS - 1)];
     if (lane == 0) {
-        if (acc_nup) atomicAdd(&p.ctr->nupper, acc_nup);
-        if (acc_mx) atomicMax(&p.ctr->maxshared, acc_mx);
+        if (acc_nup) atomicAdd(&sh->nupper, acc_nup);
+        if (acc_mx) atomicMax(&sh->maxshared, acc_mx);
     }
-    if (tid == 0 && acc_done) {
-        atomicAdd(&p.ctr->yraw, acc_yraw);
-        atomicAdd(&p.ctr->nnz, acc_y);
-        atomicAdd(&p.ctr->tier_done[tier], acc_done);
-        if (acc_ndiag) atomicAdd(&p.ctr->ndiag, (unsigned long long)acc_ndiag);
+    if (tid == 0) {
+        if (p.use_feedback && fb_n) { atomicAdd(&p.ctr->fb_claims, fb_c); atomicAdd(&p.ctr->fb_ub, fb_u); }
+        fb_c += tot_c; fb_u += tot_u;
+        if (fb_u) { atomicAdd(&sh->fb_claims, fb_c); atomicAdd(&sh->fb_ub, fb_u); }
+        if (acc_done) {
+            atomicAdd(&sh->yraw, acc_yraw);
+            atomicAdd(&sh->nnz, acc_y);
+            atomicAdd(&sh->tier_done[tier], acc_done);
+            if (acc_ndiag) atomicAdd(&sh->ndiag, (unsigned long long)acc_ndiag);
+        }
     }
 }
