@@ -115,6 +115,9 @@ struct Ctx {
     int64_t M = 0, N = 0, Z = 0, max_row_nnz = 0, max_col_nnz = 0;
     DevBuf a_rowptr, a_csr, a_colptr, a_csc;   // u32[M+1], u64[Z], u32[N+1], u64[Z]
     DevBuf a_rowprod;                          // u32[M] products per row: sum of the column lengths of the row's k-mers
+    DevBuf a_roworder;                         // u32[M] rows by descending product count (queue order of the SpGEMM)
+    DevBuf a_cscp;                             // u64[Z] columns in first-occurrence order (hot-loop copy of a_csc; see matrix.hip)
+    bool hot_packed = false, a_cscp_is_csc = true;
     DevBuf a_csrx;                             // u64[Z] per CSR entry: column start << 32 | column length (hot-path twin of a_csr)
     int64_t row_lo = 0, row_hi = -1;           // rows of B computed by this context (-1: all)
     // rows of an A built from reads are local read indices; exported triples carry global ids (src/KmerOps.cpp:215-219)

@@ -6,6 +6,7 @@
 // src/KmerOps.cpp:400).
 #include "common.hpp"
 #include "matrix.hpp"
+#include <algorithm>
 
 namespace elba {
 
@@ -66,6 +67,73 @@ __global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, co
     }
 }
 
+// ---- hot format of the SpGEMM: columns stored in FIRST-OCCURRENCE order --------------------------------------------------------
+// k-mer ids are ranks of the k-mer VALUE, i.e. random with respect to the genome: a read's columns are scattered over the whole
+// CSC and every 8-byte column gather costs a 64-byte sector (4.3x the algorithmic bytes measured, profiles/r01_notes.md).  Stored
+// in the order of their first entry (read, pos), the columns a read shares with the reads before it — and all the columns it
+// introduces itself — lie next to each other: 2.2x fewer sectors per row on 15 %-error reads, far fewer on accurate ones.
+// Canonical order is untouched: a_csc / a_colptr / a_csr stay as they are (exports, seed decoding); only the arrays the hot
+// loop walks are permuted: a_cscp (columns) and a_csrx (per-row descriptors sorted by column address).
+__global__ void k_first_entry_keys(const uint32_t *colptr, const uint64_t *csc, uint64_t N, uint64_t *keys, uint64_t *vals)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t c0 = colptr[k], c1 = colptr[k + 1];
+    keys[k] = c1 > c0 ? csc[c0] : ~0ull;            // empty columns (panels index by GLOBAL k-mer id) go last
+    vals[k] = k;
+}
+
+__global__ void k_perm_counts(const uint64_t *sorted_cols, const uint32_t *colptr, uint64_t N, uint32_t *cnt)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const uint64_t k = sorted_cols[r];
+    cnt[r] = colptr[k + 1] - colptr[k];
+}
+
+__global__ void k_perm_copy(const uint64_t *sorted_cols, const uint32_t *newstart_sorted, const uint32_t *colptr, const uint64_t *csc, uint64_t N,
+                            uint32_t *newstart, uint64_t *cscp)
+{
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const uint64_t k = sorted_cols[r];
+    const uint32_t c0 = colptr[k], c1 = colptr[k + 1], d0 = newstart_sorted[r];
+    newstart[k] = d0;
+    for (uint32_t a = c0; a < c1; ++a) cscp[d0 + (a - c0)] = csc[a];
+}
+
+// descriptor of CSR entry e (row i, rank r = e - rowptr[i]): column address << 32 | rank << 8 | column length (<= 255)
+__global__ __launch_bounds__(256) void k_descriptors(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, const uint32_t *newstart, uint32_t M,
+                                                     uint64_t *keys, uint64_t *desc)
+{
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < M; i += nwaves) {
+        const uint32_t rs = rowptr[i], re = rowptr[i + 1];
+        for (uint32_t e = rs + lane; e < re; e += 64) {
+            const uint32_t kid = (uint32_t)(csr[e] >> 32);
+            const uint32_t len = colptr[kid + 1] - colptr[kid], st = newstart[kid];
+            keys[e] = ((uint64_t)i << 32) | st;                 // sort key: (row, column address)
+            desc[e] = ((uint64_t)st << 32) | ((uint64_t)(e - rs) << 8) | len;
+        }
+    }
+}
+
+__global__ void k_roworder_keys(const uint32_t *rowprod, uint64_t M, uint64_t *keys, uint64_t *vals)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    keys[i] = (uint64_t)(0xFFFFFFFFu - rowprod[i]);      // ascending sort of the complement = descending products
+    vals[i] = i;
+}
+
+__global__ void k_narrow_u32(const uint64_t *in, uint64_t n, uint32_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)in[i];
+}
+
 int bits_for(uint64_t maxval)
 {
     int b = 1;
@@ -87,6 +155,45 @@ int64_t max_segment_len(Ctx &c, const uint32_t *ptr, int64_t nseg)
     ELBA_HIP(hipMemcpyAsync(&h, c.ws_scan.p, 8, hipMemcpyDeviceToHost, c.stream));
     ELBA_HIP(hipStreamSynchronize(c.stream));
     return (int64_t)h;
+}
+
+// Permuted columns + per-row descriptors (see the comment above k_first_entry_keys).  Falls back to the canonical layout
+// (a_cscp == a_csc, descriptor = column start << 32 | length, rank = index) when a column is longer than 255 entries or a row has
+// 2^24 entries or more: the packed descriptor has 8 bits for the length and 24 for the rank.
+static void build_hot_format(Ctx &c)
+{
+    hipStream_t s = c.stream;
+    const int64_t M = c.M, N = c.N, Z = c.Z;
+    c.hot_packed = c.max_col_nnz <= 255 && c.max_row_nnz < (1 << 24) && Z > 0 && !getenv("ELBA_NO_PERMUTE");
+    if (!c.hot_packed) { c.a_cscp_is_csc = true; return; }      // k_row_products already wrote the fallback descriptors
+    c.a_cscp_is_csc = false;
+    c.a_cscp.reserve((size_t)(Z + 2) * 8);
+    c.ws_a.reserve((size_t)(std::max(N, Z) + 1) * 8); c.ws_b.reserve((size_t)(std::max(N, Z) + 1) * 8);
+    c.ws_c.reserve((size_t)(std::max(N, Z) + 1) * 8); c.ws_d.reserve((size_t)(std::max(N, Z) + 1) * 8);
+    c.ws_e.reserve((size_t)(N + 2) * 4); c.ws_f.reserve((size_t)(N + 2) * 4);
+    uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
+    const unsigned nbN = (unsigned)((N + 255) / 256);
+    // columns by first entry (read << 32 | pos): LSD over the pos bits, then the read bits (bit 63 set = empty column, last)
+    hipLaunchKernelGGL(k_first_entry_keys, dim3(nbN), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), (uint64_t)N, k0, v0);
+    int w = radix_sort_pairs(s, k0, v0, k1, v1, N, 0, 32, c.ws_sort);
+    uint64_t *ck = w ? k1 : k0, *cv = w ? v1 : v0, *ok = w ? k0 : k1, *ov = w ? v0 : v1;
+    int w2 = radix_sort_pairs(s, ck, cv, ok, ov, N, 32, 64, c.ws_sort);
+    const uint64_t *sorted_cols = w2 ? ov : cv;
+    uint32_t *cnt = c.ws_e.as<uint32_t>(), *newstart = c.ws_f.as<uint32_t>();
+    hipLaunchKernelGGL(k_perm_counts, dim3(nbN), dim3(256), 0, s, sorted_cols, c.a_colptr.as<uint32_t>(), (uint64_t)N, cnt);
+    exclusive_scan_u32(s, cnt, cnt, N, c.ws_scan);
+    hipLaunchKernelGGL(k_perm_copy, dim3(nbN), dim3(256), 0, s, sorted_cols, cnt, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), (uint64_t)N, newstart, c.a_cscp.as<uint64_t>());
+    // descriptors, then each row's descriptors by column address: neighbouring lanes gather neighbouring sectors
+    {
+        int nb = (int)((M + 3) / 4);
+        if (nb > c.num_cus * 8) nb = c.num_cus * 8;
+        hipLaunchKernelGGL(k_descriptors, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), newstart, (uint32_t)M, k0, v0);
+    }
+    int w3 = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, bits_for((uint64_t)Z), c.ws_sort);
+    ck = w3 ? k1 : k0; cv = w3 ? v1 : v0; ok = w3 ? k0 : k1; ov = w3 ? v0 : v1;
+    int w4 = radix_sort_pairs(s, ck, cv, ok, ov, Z, 32, 32 + bits_for((uint64_t)(M > 0 ? M - 1 : 0)), c.ws_sort);
+    ELBA_HIP(hipMemcpyAsync(c.a_csrx.p, w4 ? ov : cv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+    ELBA_HIP(hipStreamSynchronize(s));
 }
 
 // Input: Z entries sorted by (kid, read, pos): kid_keys[z] >> kid_shift = kid, csc[z] = read<<32|pos (device, in c.a_csc or elsewhere).
@@ -121,10 +228,21 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         if (nb > c.num_cus * 8) nb = c.num_cus * 8;
         hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_csrx.as<uint64_t>());
     }
+    // rows by descending product count: the SpGEMM queues them in this order so that a workgroup's static share of a tier
+    // mixes heavy rows first and light rows last (longest-processing-time order: short tail)
+    c.a_roworder.reserve((size_t)(M + 1) * 4);
+    if (M > 0) {
+        c.ws_a.reserve((size_t)(M + 1) * 8); c.ws_b.reserve((size_t)(M + 1) * 8); c.ws_c.reserve((size_t)(M + 1) * 8); c.ws_d.reserve((size_t)(M + 1) * 8);
+        const unsigned nbM = (unsigned)((M + 255) / 256);
+        hipLaunchKernelGGL(k_roworder_keys, dim3(nbM), dim3(256), 0, s, c.a_rowprod.as<uint32_t>(), (uint64_t)M, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
+        int wr = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), M, 0, 32, c.ws_sort);
+        hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>(), (uint64_t)M, c.a_roworder.as<uint32_t>());
+    }
     c.row_lo = 0; c.row_hi = -1;
     c.ov_prior_q16 = 0;            // a new matrix: forget the partner/product ratio measured on the previous one
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
+    build_hot_format(c);
     c.have_A = true;
     c.have_B = false;
 }

@@ -22,6 +22,7 @@
 //
 // No MFMA anywhere: the contraction is index matching plus integer min/max/add.
 #include "common.hpp"
+#include <algorithm>
 
 namespace elba {
 
@@ -60,15 +61,17 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned long long pad2[14];          // keep the feedback sums on a cache line of their own
     unsigned long long fb_claims, fb_ub;  // feedback: distinct partners found / products, summed over rows done so far in this call
     OvShard shard[NUM_SHARDS];
-    unsigned long long phase[8];          // diagnostic (cfg.flags & 16): shader-clock cycles per kernel phase, summed over workgroups
+    unsigned long long phase[12];          // diagnostic (cfg.flags & 16): shader-clock cycles per kernel phase, summed over workgroups
 };
 
 struct OvParams {
-    const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_csrx;
+    const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_csrx; const uint64_t *a_cscp; const uint32_t *a_roworder;
+    uint32_t packed;         // 1: a_csrx = column address << 32 | rank << 8 | length, columns permuted (a_cscp); 0: address << 32 | length, canonical
     uint32_t M;              // number of rows of A held here
     uint32_t Mcols;          // number of reads overall (partner id range)
     uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
+    uint32_t tier_limit[NUM_LDS_TIERS];   // claimed slots at which a row abandons the tier: min(3T/4, T - 2*BLOCK) - 1 (two claims per lane can be in flight)
     uint32_t use_feedback;   // 1 on the first call for a matrix (no measured prior yet): in-call self-correction through the hot fb_* sums
     uint32_t prior_q16;      // distinct-partners / products estimate in 1/65536 units (1/16 before anything is known; measured by the previous call afterwards)
     uint32_t dbg;            // diagnostic ablations (cfg.flags): 1 = gathers only (no accumulator updates), 2 = accumulator only (synthetic partners)
@@ -102,10 +105,12 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t lt = (1ull << lane) - 1;
     unsigned long long prod = 0, cap = 0;
-    for (uint32_t i0 = p.row_lo + blockIdx.x * blockDim.x; i0 < p.row_hi; i0 += stride) {      // block-uniform trip count
-        const uint32_t i = i0 + threadIdx.x;
+    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < p.M; i0 += stride) {      // block-uniform trip count
+        const uint32_t idx = i0 + threadIdx.x;
+        // rows are visited in descending-work order (a_roworder); a row window (multi-GPU shard) filters by row id
+        const uint32_t i = idx < p.M ? p.a_roworder[idx] : 0xFFFFFFFFu;
         int mytier = -1;
-        const uint32_t ub = i < p.row_hi ? p.a_rowprod[i] : 0;   // empty rows: row_cnt was zeroed by the host
+        const uint32_t ub = (i >= p.row_lo && i < p.row_hi) ? p.a_rowprod[i] : 0;   // empty rows: row_cnt was zeroed by the host
         if (ub != 0) {
         prod += ub;
         cap += ub < p.Mcols ? ub : p.Mcols;
@@ -116,7 +121,7 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
         uint32_t est = (uint32_t)(((unsigned long long)ub * p.prior_q16) >> 16);
         if (est < 128) est = 128;
         int tier = 0;
-        while (tier < NUM_LDS_TIERS && est > ((1u << (LDS_TBITS0 + tier)) >> 2) * 3 - 1) ++tier;      // est <= the tier's abandon limit (3/4 of the table)
+        while (tier < NUM_LDS_TIERS && est > p.tier_limit[tier]) ++tier;      // est <= the tier's abandon limit
         // never start above the tier that is already guaranteed to fit
         const int gt = gbits <= LDS_TBITS0 ? 0 : (int)gbits - LDS_TBITS0;
         if (gt < tier) tier = gt;
@@ -277,10 +282,20 @@ void stage_create_seed_matrix(Ctx &c)
 
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
-    p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_csrx = c.a_csrx.as<uint64_t>();
+    p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_csrx = c.a_csrx.as<uint64_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
+    p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>(); p.packed = c.hot_packed ? 1u : 0u;
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
+    const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob)
+    {
+        const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : 128), 128u, 256u, 256u};
+        for (int t = 0; t < NUM_LDS_TIERS; ++t) {
+            const uint32_t T = 1u << (LDS_TBITS0 + t);
+            const uint32_t lim = std::min((T >> 2) * 3, T - 2 * blk[t]);
+            p.tier_limit[t] = lim - 1;
+        }
+    }
     p.row_cnt = c.ov_rowcnt.as<uint32_t>();
     p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
     p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
@@ -305,7 +320,7 @@ void stage_create_seed_matrix(Ctx &c)
         ELBA_HIP(hipMemsetAsync(c.ov_rowcnt.p, 0, (size_t)(M + 2) * 4, s));
         c.t_a.start(s);
         if (nrows > 0) {
-            int nb = (int)((nrows + 255) / 256);
+            int nb = (int)((M + 255) / 256);
             if (nb > cus * 4) nb = cus * 4;
             hipLaunchKernelGGL(k_classify_rows, dim3(nb), dim3(256), 0, s, p);
         }
@@ -332,9 +347,8 @@ void stage_create_seed_matrix(Ctx &c)
             const size_t X = 128;  // misc words (+ per-wave product queues: 64 lanes x 8 products x 8 B = 4 KiB per wave)
             const size_t Q = 4096;
             const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 8;
-            const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob; 128 x 8 per CU measured best)
-            if (b0 == 128) hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * g0), dim3(128), (size_t)20 * 512 + X + 2 * Q, s, p, 0, 9u);
-            else hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * g0), dim3(64), (size_t)20 * 512 + X + Q, s, p, 0, 9u);
+            if (b0 == 64) hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * g0), dim3(64), (size_t)20 * 512 + X + Q, s, p, 0, 9u);
+            else hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * g0), dim3(128), (size_t)20 * 512 + X + 2 * Q, s, p, 0, 9u);
             hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * 8), dim3(128), (size_t)20 * 1024 + X + 2 * Q, s, p, 1, 10u);
             hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 4), dim3(256), (size_t)20 * 2048 + X + 4 * Q, s, p, 2, 11u);
             hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 2), dim3(256), (size_t)20 * 4096 + X + 4 * Q, s, p, 3, 12u);
@@ -389,8 +403,8 @@ void stage_create_seed_matrix(Ctx &c)
     ELBA_HIP(hipStreamSynchronize(s));
 
     if (c.cfg.flags & 16) {   // diagnostic: per-phase shader-clock totals over all workgroups of the numeric kernels
-        fprintf(stderr, "[elba dbg] phase cycles (sum over %llu workgroups): fetch=%llu init=%llu accumulate=%llu sweep=%llu reserve=%llu decode=%llu\n",
-                hc.phase[6], hc.phase[0], hc.phase[1], hc.phase[2], hc.phase[3], hc.phase[4], hc.phase[5]);
+        fprintf(stderr, "[elba dbg] phase cycles (sum over %llu workgroups): fetch=%llu init=%llu accumulate_rest=%llu sweep=%llu reserve=%llu decode=%llu | gather_wait=%llu count_scan_queue=%llu insert=%llu loop_tail=%llu\n",
+                hc.phase[10], hc.phase[0], hc.phase[1], hc.phase[2], hc.phase[3], hc.phase[4], hc.phase[5], hc.phase[6], hc.phase[7], hc.phase[8], hc.phase[9]);
     }
     if (hc.fb_ub > 0) {   // remember the measured distinct/products ratio (+25 %) for the next call's starting tiers
         double r = 1.25 * (double)hc.fb_claims / (double)hc.fb_ub * 65536.0;

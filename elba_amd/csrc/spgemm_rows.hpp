@@ -44,6 +44,25 @@ struct Table {
         atomicMin(&smin[slot], s);
         atomicMax(&smax[slot], s);
     }
+    // two independent inserts with their compare-and-swap round trips in flight together
+    __device__ __forceinline__ void insert2(uint32_t j0, uint32_t s0, uint32_t j1, uint32_t s1, bool two, bool &full) const
+    {
+        if (full) return;
+        const uint32_t mask = size() - 1;
+        uint32_t a = (j0 * 0x9E3779B1u) >> (32 - tbits), b = (j1 * 0x9E3779B1u) >> (32 - tbits);
+        bool da = false, db = !two;
+        uint32_t claimed = 0;
+        while (!(da && db)) {
+            uint32_t ka = j0, kb = j1;
+            if (!da) ka = atomicCAS(&keys[a], EMPTY, j0);
+            if (!db) kb = atomicCAS(&keys[b], EMPTY, j1);
+            if (!da) { if (ka == j0 || ka == EMPTY) { da = true; claimed += ka == EMPTY; } else a = (a + 1) & mask; }
+            if (!db) { if (kb == j1 || kb == EMPTY) { db = true; claimed += kb == EMPTY; } else b = (b + 1) & mask; }
+        }
+        if (!GLOBAL && claimed) { if (atomicAdd(&misc[9], claimed) + claimed > limit) { __hip_atomic_store(&misc[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); full = true; } }
+        atomicAdd(&cnt[a], 1u); atomicMin(&smin[a], s0); atomicMax(&smax[a], s0);
+        if (two) { atomicAdd(&cnt[b], 1u); atomicMin(&smin[b], s1); atomicMax(&smax[b], s1); }
+    }
     __device__ __forceinline__ uint32_t ldrelaxed(const uint32_t *a) const
     {
         return __hip_atomic_load(a, __ATOMIC_RELAXED, GLOBAL ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -58,20 +77,36 @@ struct Table {
 // two adjacent column entries in one 16-byte global load; columns start on 8-byte boundaries only, hence aligned(8)
 struct __attribute__((packed, aligned(8))) pair64 { uint64_t lo, hi; };
 
-constexpr int GRP = 4;     // entries whose column gathers are in flight together
+constexpr int GRP = 2;     // entries whose column gathers are in flight together (4 spills SGPRs and needs 136 VGPRs)
 constexpr int SPEC = 8;    // column entries gathered unconditionally per entry; longer columns (UPPER > 8) take a serial tail loop
 
+// s = rank of the row entry (canonical (kid,pos) order) << fbits | index inside the column: decoded through the CANONICAL arrays
 __device__ __forceinline__ elba_seed_t decode_seed(const OvParams &p, uint32_t rs, uint32_t a, uint32_t b, uint32_t n, uint32_t fmask)
 {
-    const uint32_t ra = rs + (a >> p.fbits), rb = rs + (b >> p.fbits);
-    const uint64_t ea = p.a_csr[ra], eb = p.a_csr[rb];
-    const uint64_t xa = p.a_csrx[ra], xb = p.a_csrx[rb];
+    const uint64_t ea = p.a_csr[rs + (a >> p.fbits)], eb = p.a_csr[rs + (b >> p.fbits)];
+    const uint32_t ca = p.a_colptr[(uint32_t)(ea >> 32)], cb = p.a_colptr[(uint32_t)(eb >> 32)];
     elba_seed_t v;
-    v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[(uint32_t)(xa >> 32) + (a & fmask)];
-    v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[(uint32_t)(xb >> 32) + (b & fmask)];
+    v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[ca + (a & fmask)];
+    v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[cb + (b & fmask)];
     v.numshared = (int32_t)n;
     return v;
 }
+
+// inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8 inside each row of 16, row_bcast 15/31 across rows)
+__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x)
+{
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2 and 3
+    return (uint32_t)v;
+}
+
+// descriptor fields (see matrix.hip: build_hot_format)
+__device__ __forceinline__ uint32_t desc_len(const OvParams &p, uint64_t x) { return p.packed ? ((uint32_t)x & 255u) : (uint32_t)x; }
 
 template <int BLOCK, bool GLOBAL>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uint32_t lds_tbits)
@@ -93,7 +128,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     uint32_t acc_mx = 0;
     // diagnostic phase clock (cfg.flags & 16): 0 fetch row, 1 table init, 2 expand+accumulate, 3 sweep, 4 reserve, 5 decode+store
     const bool stamp = (p.dbg & 16u) != 0;
-    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 6 gather wait, 7 count+scan+queue write, 8 insert loop, 9 loop tail
     unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #define ELBA_STAMP(k) do { if (stamp) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tprev; tprev = tn; } } while (0)
 
@@ -128,12 +163,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             }
             if (gu >= (1ull << 20)) {
                 const double pred = 1.25 * (double)ub_i * (double)gc / (double)gu;
-                const uint32_t Tt = 1u << lds_tbits;
                 // forward only on strong evidence (short rows finish first and have a higher partner/product ratio: the running sums
                 // are biased high early in a call): predicted partners beyond 1.2x the abandon limit
-                if (pred > 1.2 * (double)((Tt >> 2) * 3 - 1) && guaranteed_tbits(ub_i, p.Mcols) > lds_tbits) {
+                if (pred > 1.2 * (double)p.tier_limit[tier] && guaranteed_tbits(ub_i, p.Mcols) > lds_tbits) {
                     int t2 = tier + 1;
-                    while (t2 < NUM_LDS_TIERS && pred > (double)(((1u << (LDS_TBITS0 + t2)) >> 2) * 3 - 1)) ++t2;
+                    while (t2 < NUM_LDS_TIERS && pred > (double)p.tier_limit[t2]) ++t2;
                     if (tid == 0) {
                         const uint32_t at = atomicAdd(&p.ctr->tier_count[t2], 1u);
                         p.lists[(size_t)t2 * p.M + at] = i;
@@ -154,7 +188,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         } else {
             tab.tbits = lds_tbits;
             const uint32_t T = 1u << lds_tbits;
-            tab.limit = (T >> 2) * 3 - 1;            // abandon at 3/4 load
+            tab.limit = p.tier_limit[tier];          // abandon point: at most limit + 2*BLOCK slots are ever claimed, < T
             tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
             list = smem + 4 * T;
         }
@@ -186,12 +220,12 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             uint64_t c[GRP][SPEC];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
-                const uint32_t a = (uint32_t)(xc[q] >> 32), n = (uint32_t)xc[q];
+                const uint32_t a = (uint32_t)(xc[q] >> 32), n = desc_len(p, xc[q]);
 #pragma unroll
                 for (int v = 0; v < SPEC / 2; ++v) {
                     c[q][2 * v] = 0; c[q][2 * v + 1] = 0;
                     if ((uint32_t)(2 * v) < n) {
-                        const pair64 pr = *reinterpret_cast<const pair64 *>(p.a_csc + a + 2 * v);   // a_csc carries 2 guard entries
+                        const pair64 pr = *reinterpret_cast<const pair64 *>(p.a_cscp + a + 2 * v);   // the array carries 2 guard entries
                         c[q][2 * v] = pr.lo; c[q][2 * v + 1] = pr.hi;
                     }
                 }
@@ -216,8 +250,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             } else {
 #pragma unroll
                 for (int q = 0; q < GRP; ++q) {
-                    const uint32_t a = (uint32_t)(xc[q] >> 32), n = (uint32_t)xc[q];
-                    const uint32_t sb = (gb + (uint32_t)q * BLOCK + tid - rs) << p.fbits;
+                    const uint32_t a = (uint32_t)(xc[q] >> 32), n = desc_len(p, xc[q]);
+                    const uint32_t rank = p.packed ? ((uint32_t)xc[q] >> 8) : gb + (uint32_t)q * BLOCK + tid - rs;
+                    const uint32_t sb = rank << p.fbits;
                     // Columns hold 2.6 entries on average but up to SPEC: updating the accumulator lane-by-entry would run SPEC
                     // insert bodies with mostly idle lanes.  Instead the wave's products of this round are FLATTENED through a
                     // per-wave LDS queue (exclusive prefix of the per-lane counts gives each lane its slots) and then inserted with
@@ -232,25 +267,31 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                             } else ++mine;
                         }
                     }
-                    uint32_t incl = mine;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += o; }
-                    const uint32_t total = __shfl(incl, 63, 64);
+                    if (q == 0) ELBA_STAMP(6);
+                    // exclusive prefix of the per-lane product counts by a DPP wave scan (VALU only: no LDS round trips, and none of
+                    // the 64-bit ballot masks whose register pressure made the compiler spill SGPRs through v_writelane/v_readlane)
+                    const uint32_t incl = wave_inclusive_scan_dpp(mine);
+                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     uint32_t w = incl - mine;
 #pragma unroll
                     for (int u = 0; u < SPEC; ++u) {
-                        if ((uint32_t)u < n) {
-                            const uint32_t j = (uint32_t)(c[q][u] >> 32);
-                            if (j != i) { qj[w] = j; qs[w] = sb | (uint32_t)u; ++w; }
-                        }
+                        const uint32_t j = (uint32_t)(c[q][u] >> 32);
+                        if ((uint32_t)u < n && j != i) { qj[w] = j; qs[w] = sb | (uint32_t)u; ++w; }
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
+                    ELBA_STAMP(7);
 #pragma unroll 1
-                    for (uint32_t t = lane; t < total; t += 64) tab.insert(qj[t], qs[t], full);
+                    for (uint32_t t = lane; t < total; t += 128) {          // two products per lane and trip: their LDS round trips overlap
+                        const bool two = t + 64 < total;
+                        const uint32_t j0 = qj[t], s0 = qs[t];
+                        const uint32_t j1 = two ? qj[t + 64] : 0u, s1 = two ? qs[t + 64] : 0u;
+                        tab.insert2(j0, s0, j1, s1, two, full);
+                    }
                     __builtin_amdgcn_wave_barrier();
+                    ELBA_STAMP(8);
                     for (uint32_t f = SPEC; f < n; ++f) {                 // the tail of columns longer than SPEC (UPPER > 8)
-                        const uint32_t j = (uint32_t)(p.a_csc[a + f] >> 32), s = sb | f;
+                        const uint32_t j = (uint32_t)(p.a_cscp[a + f] >> 32), s = sb | f;
                         if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
                         else tab.insert(j, s, full);
                     }
@@ -258,6 +299,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             }
 #pragma unroll
             for (int q = 0; q < GRP; ++q) xc[q] = xn[q];
+            ELBA_STAMP(9);
             if (tab.abandoned()) { if (tid == 0) misc[11] = gb + GRP * BLOCK - rs < re - rs ? gb + GRP * BLOCK - rs : re - rs; break; }
         }
         if (dn) { atomicAdd(&misc[0], dn); atomicMin(&misc[1], dmin); atomicMax(&misc[2], dmax); }
@@ -348,8 +390,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     }
     if (stamp && tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) atomicAdd(&p.ctr->phase[k], ph[k]);
-        atomicAdd(&p.ctr->phase[6], 1ull);
+        for (int k = 0; k < 10; ++k) atomicAdd(&p.ctr->phase[k], ph[k]);
+        atomicAdd(&p.ctr->phase[10], 1ull);
     }
 #undef ELBA_STAMP
     // flush the workgroup's statistics: a handful of atomics per workgroup instead of six per row
