@@ -345,7 +345,7 @@ void stage_create_seed_matrix(Ctx &c)
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
             const size_t X = 128;  // misc words (+ per-wave product queues: 64 lanes x 8 products x 8 B = 4 KiB per wave)
-            const size_t Q = 4096;
+            const size_t Q = 4608;   // 2 x (512 + 64 trash) u32 per wave
             const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 8;
             if (b0 == 64) hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * g0), dim3(64), (size_t)20 * 512 + X + Q, s, p, 0, 9u);
             else hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * g0), dim3(128), (size_t)20 * 512 + X + 2 * Q, s, p, 0, 9u);

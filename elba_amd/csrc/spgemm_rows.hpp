@@ -115,8 +115,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     // LDS tiers: keys | cnt | smin | smax | survivor list (u32 each, T entries) | misc;  spill tier: only misc lives in LDS
     uint32_t *misc = GLOBAL ? smem : smem + (size_t)5 * (1u << lds_tbits);
     // per-wave product queue: 64 lanes x SPEC products, partner id and sequence number
-    uint32_t *qj = misc + 32 + (threadIdx.x >> 6) * (2 * 64 * SPEC);
-    uint32_t *qs = qj + 64 * SPEC;
+    constexpr uint32_t QCAP = 64 * SPEC;        // + 64 trash slots per array (branch-free queue writes)
+    uint32_t *qj = misc + 32 + (threadIdx.x >> 6) * (2 * (QCAP + 64));
+    uint32_t *qs = qj + QCAP + 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1;
     const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
@@ -214,20 +215,17 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
 #pragma unroll 1
         for (uint32_t gb = rs; gb < re; gb += GRP * BLOCK) {
-            // The memory pipe's cost is per active lane and instruction (every lane of a gather touches a different 64-B sector), so:
-            // two entries per 16-byte load, and loads predicated on the column length instead of clamped duplicates —
-            // 1.45 lane-loads per row entry instead of 8 (column lengths 2,3,4,... have frequencies 65 %, 19 %, 9 %, ...).
+            // Column gathers: two entries per 16-byte load.  BRANCH-FREE on purpose: pairs beyond the column's length re-read the
+            // first pair (same sector, L1 hit) instead of sitting under `if`: every predicated region costs an exec-mask
+            // save/restore in SALU and 64-bit SGPRs — the unrolled predicated form of this loop spilled 70-90 SGPRs.
             uint64_t c[GRP][SPEC];
 #pragma unroll
             for (int q = 0; q < GRP; ++q) {
                 const uint32_t a = (uint32_t)(xc[q] >> 32), n = desc_len(p, xc[q]);
 #pragma unroll
                 for (int v = 0; v < SPEC / 2; ++v) {
-                    c[q][2 * v] = 0; c[q][2 * v + 1] = 0;
-                    if ((uint32_t)(2 * v) < n) {
-                        const pair64 pr = *reinterpret_cast<const pair64 *>(p.a_cscp + a + 2 * v);   // the array carries 2 guard entries
-                        c[q][2 * v] = pr.lo; c[q][2 * v + 1] = pr.hi;
-                    }
+                    const pair64 pr = *reinterpret_cast<const pair64 *>(p.a_cscp + a + ((uint32_t)(2 * v) < n ? 2 * v : 0));   // 2 guard entries
+                    c[q][2 * v] = pr.lo; c[q][2 * v + 1] = pr.hi;
                 }
                 if (p.dbg & 2u) {                                       // ablation: no gathers, synthetic partner ids
 #pragma unroll
@@ -257,26 +255,29 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                     // insert bodies with mostly idle lanes.  Instead the wave's products of this round are FLATTENED through a
                     // per-wave LDS queue (exclusive prefix of the per-lane counts gives each lane its slots) and then inserted with
                     // all lanes busy: ceil(products/64) insert bodies instead of SPEC.
+                    // select-only code (no predicated regions): diagonal products (j == i: 38 % of all products) stay in registers
                     uint32_t mine = 0;
 #pragma unroll
                     for (int u = 0; u < SPEC; ++u) {
-                        if ((uint32_t)u < n) {
-                            if ((uint32_t)(c[q][u] >> 32) == i) {       // diagonal: registers, not one hot slot
-                                const uint32_t s = sb | (uint32_t)u;
-                                ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax;
-                            } else ++mine;
-                        }
+                        const bool in = (uint32_t)u < n, dg = in && (uint32_t)(c[q][u] >> 32) == i;
+                        const uint32_t s = sb | (uint32_t)u;
+                        dn += dg ? 1u : 0u;
+                        dmin = (dg && s < dmin) ? s : dmin;
+                        dmax = (dg && s > dmax) ? s : dmax;
+                        mine += (in && !dg) ? 1u : 0u;
                     }
                     if (q == 0) ELBA_STAMP(6);
-                    // exclusive prefix of the per-lane product counts by a DPP wave scan (VALU only: no LDS round trips, and none of
-                    // the 64-bit ballot masks whose register pressure made the compiler spill SGPRs through v_writelane/v_readlane)
+                    // exclusive prefix of the per-lane product counts by a DPP wave scan (VALU only: no LDS round trips, no ballots)
                     const uint32_t incl = wave_inclusive_scan_dpp(mine);
                     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
                     uint32_t w = incl - mine;
 #pragma unroll
                     for (int u = 0; u < SPEC; ++u) {
                         const uint32_t j = (uint32_t)(c[q][u] >> 32);
-                        if ((uint32_t)u < n && j != i) { qj[w] = j; qs[w] = sb | (uint32_t)u; ++w; }
+                        const bool live = (uint32_t)u < n && j != i;
+                        const uint32_t dst = live ? w : QCAP + lane;      // dead products go to this lane's private trash slot
+                        qj[dst] = j; qs[dst] = sb | (uint32_t)u;
+                        w += live ? 1u : 0u;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
