@@ -304,7 +304,8 @@ void stage_create_seed_matrix(Ctx &c)
 
     static bool attr_done = false;
     if (!attr_done) {
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
 
@@ -341,18 +342,24 @@ void stage_create_seed_matrix(Ctx &c)
         p.tmp_col = c.ov_tmp_col.as<uint32_t>(); p.tmp_val = c.ov_tmp_val.as<elba_seed_t>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
 
         c.t_b.start(s);
+        const bool diag = c.cfg.flags != 0;
+#define ELBA_LAUNCH_ROWS(B, G, grid, lds, tier, tb)                                                                          \
+    do {                                                                                                            \
+        if (diag) hipLaunchKernelGGL((k_spgemm_rows<B, G, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));   \
+        else hipLaunchKernelGGL((k_spgemm_rows<B, G, false>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));       \
+    } while (0)
         if (nrows > 0) {
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
             const size_t X = 128;  // misc words (+ per-wave product queues: 64 lanes x 8 products x 8 B = 4 KiB per wave)
-            const size_t Q = 4608;   // 2 x (512 + 64 trash) u32 per wave
+            const size_t Q = 2560;   // per-wave product queue: 2 x (256 + 64 trash) u32; the survivor list aliases the queues when it fits (16 B/slot then)
             const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 8;
-            if (b0 == 64) hipLaunchKernelGGL((k_spgemm_rows<64, false>), dim3(cus * g0), dim3(64), (size_t)20 * 512 + X + Q, s, p, 0, 9u);
-            else hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * g0), dim3(128), (size_t)20 * 512 + X + 2 * Q, s, p, 0, 9u);
-            hipLaunchKernelGGL((k_spgemm_rows<128, false>), dim3(cus * 8), dim3(128), (size_t)20 * 1024 + X + 2 * Q, s, p, 1, 10u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 4), dim3(256), (size_t)20 * 2048 + X + 4 * Q, s, p, 2, 11u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, false>), dim3(cus * 2), dim3(256), (size_t)20 * 4096 + X + 4 * Q, s, p, 3, 12u);
-            hipLaunchKernelGGL((k_spgemm_rows<256, true>), dim3(spill_blocks), dim3(256), X + 4 * Q, s, p, NUM_LDS_TIERS, 0u);
+            if (b0 == 64) ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)16 * 512 + X + Q, 0, 9u);
+            else ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)16 * 512 + X + 2 * Q, 0, 9u);
+            ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)16 * 1024 + X + 2 * Q, 1, 10u);
+            ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)16 * 2048 + X + 4 * Q, 2, 11u);
+            ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)20 * 4096 + X + 4 * Q, 3, 12u);
+            ELBA_LAUNCH_ROWS(256, true, spill_blocks, X + 4 * Q, NUM_LDS_TIERS, 0u);
             ELBA_HIP(hipGetLastError());
         }
         c.t_b.stop(s);

@@ -108,14 +108,16 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x)
 // descriptor fields (see matrix.hip: build_hot_format)
 __device__ __forceinline__ uint32_t desc_len(const OvParams &p, uint64_t x) { return p.packed ? ((uint32_t)x & 255u) : (uint32_t)x; }
 
-template <int BLOCK, bool GLOBAL>
+// DIAG = true compiles the diagnostic ablations and the phase clock in (cfg.flags != 0); the production instantiation carries none of it
+template <int BLOCK, bool GLOBAL, bool DIAG>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uint32_t lds_tbits)
 {
+    const uint32_t dbg = DIAG ? p.dbg : 0u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS tiers: keys | cnt | smin | smax | survivor list (u32 each, T entries) | misc;  spill tier: only misc lives in LDS
-    uint32_t *misc = GLOBAL ? smem : smem + (size_t)5 * (1u << lds_tbits);
+    uint32_t *misc = GLOBAL ? smem : smem + (size_t)(((1u << lds_tbits) <= (BLOCK / 64) * 2 * (256 + 64)) ? 4 : 5) * (1u << lds_tbits);
     // per-wave product queue: 64 lanes x SPEC products, partner id and sequence number
-    constexpr uint32_t QCAP = 64 * SPEC;        // + 64 trash slots per array (branch-free queue writes)
+    constexpr uint32_t QCAP = 256;              // + 64 trash slots per array (branch-free queue writes)
     uint32_t *qj = misc + 32 + (threadIdx.x >> 6) * (2 * (QCAP + 64));
     uint32_t *qs = qj + QCAP + 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
@@ -128,7 +130,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     unsigned long long acc_nup = 0;
     uint32_t acc_mx = 0;
     // diagnostic phase clock (cfg.flags & 16): 0 fetch row, 1 table init, 2 expand+accumulate, 3 sweep, 4 reserve, 5 decode+store
-    const bool stamp = (p.dbg & 16u) != 0;
+    const bool stamp = DIAG && (dbg & 16u) != 0;
     unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 6 gather wait, 7 count+scan+queue write, 8 insert loop, 9 loop tail
     unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #define ELBA_STAMP(k) do { if (stamp) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tprev; tprev = tn; } } while (0)
@@ -191,7 +193,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             const uint32_t T = 1u << lds_tbits;
             tab.limit = p.tier_limit[tier];          // abandon point: at most limit + 2*BLOCK slots are ever claimed, < T
             tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
-            list = smem + 4 * T;
+            // the survivor list is only alive after the accumulate phase: it shares the queues' LDS when it fits
+            list = (T <= (BLOCK / 64) * 2 * (QCAP + 64)) ? misc + 32 : smem + 4 * T;
         }
         const uint32_t T = tab.size();
         ELBA_STAMP(0);
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                     const pair64 pr = *reinterpret_cast<const pair64 *>(p.a_cscp + a + ((uint32_t)(2 * v) < n ? 2 * v : 0));   // 2 guard entries
                     c[q][2 * v] = pr.lo; c[q][2 * v + 1] = pr.hi;
                 }
-                if (p.dbg & 2u) {                                       // ablation: no gathers, synthetic partner ids
+                if (dbg & 2u) {                                       // ablation: no gathers, synthetic partner ids
 #pragma unroll
                     for (int u = 0; u < SPEC; ++u) c[q][u] = (uint64_t)(((a + u) * 2654435761u) % p.Mcols) << 32;
                 }
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 const uint32_t e = gb + (uint32_t)(GRP + q) * BLOCK + tid;
                 xn[q] = e < re ? p.a_csrx[e] : 0ull;
             }
-            if (p.dbg & 1u) {                                           // ablation: gathers only, keep the loads alive
+            if (dbg & 1u) {                                           // ablation: gathers only, keep the loads alive
                 uint32_t sink = 0;
 #pragma unroll
                 for (int q = 0; q < GRP; ++q)
@@ -270,24 +273,31 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                     // exclusive prefix of the per-lane product counts by a DPP wave scan (VALU only: no LDS round trips, no ballots)
                     const uint32_t incl = wave_inclusive_scan_dpp(mine);
                     const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    uint32_t w = incl - mine;
-#pragma unroll
-                    for (int u = 0; u < SPEC; ++u) {
-                        const uint32_t j = (uint32_t)(c[q][u] >> 32);
-                        const bool live = (uint32_t)u < n && j != i;
-                        const uint32_t dst = live ? w : QCAP + lane;      // dead products go to this lane's private trash slot
-                        qj[dst] = j; qs[dst] = sb | (uint32_t)u;
-                        w += live ? 1u : 0u;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    ELBA_STAMP(7);
+                    // The queue holds QCAP products per wave (a round has 64 x 1.6 = 103 live products on average, 512 at most): a
+                    // round that exceeds it is drained in several passes — rare, and wave-uniform.
 #pragma unroll 1
-                    for (uint32_t t = lane; t < total; t += 128) {          // two products per lane and trip: their LDS round trips overlap
-                        const bool two = t + 64 < total;
-                        const uint32_t j0 = qj[t], s0 = qs[t];
-                        const uint32_t j1 = two ? qj[t + 64] : 0u, s1 = two ? qs[t + 64] : 0u;
-                        tab.insert2(j0, s0, j1, s1, two, full);
+                    for (uint32_t qbase = 0; qbase < total; qbase += QCAP) {
+                        uint32_t w = incl - mine - qbase;                 // wraps below zero for products of earlier passes: not < QCAP
+#pragma unroll
+                        for (int u = 0; u < SPEC; ++u) {
+                            const uint32_t j = (uint32_t)(c[q][u] >> 32);
+                            const bool live = (uint32_t)u < n && j != i;
+                            const uint32_t dst = (live && w < QCAP) ? w : QCAP + lane;   // everything else: this lane's private trash slot
+                            qj[dst] = j; qs[dst] = sb | (uint32_t)u;
+                            w += live ? 1u : 0u;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        ELBA_STAMP(7);
+                        const uint32_t here = total - qbase < QCAP ? total - qbase : QCAP;
+#pragma unroll 1
+                        for (uint32_t t = lane; t < here; t += 128) {       // two products per lane and trip: their LDS round trips overlap
+                            const bool two = t + 64 < here;
+                            const uint32_t j0 = qj[t], s0 = qs[t];
+                            const uint32_t j1 = two ? qj[t + 64] : 0u, s1 = two ? qs[t + 64] : 0u;
+                            tab.insert2(j0, s0, j1, s1, two, full);
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
                     __builtin_amdgcn_wave_barrier();
                     ELBA_STAMP(8);
