@@ -134,6 +134,68 @@ __global__ void k_narrow_u32(const uint64_t *in, uint64_t n, uint32_t *out)
     if (i < n) out[i] = (uint32_t)in[i];
 }
 
+// ---- per-row product schedule ---------------------------------------------------------------------------------------------------
+// The SpGEMM's expansion of row i is the list of column entries (i's k-mers x the other reads in those k-mers' columns).  Which
+// (row entry, column position) pairs exist, and which of them are diagonal (the column entry IS read i: 38 % of all products on the
+// bench workload), is structure of A alone, so it is laid out once with A: one 8-byte item per NON-diagonal product,
+//     item = address of the partner's column entry in a_cscp << 32 | s,   s = canonical rank of the row entry << fbits | position in column,
+// in column-address order, plus the diagonal's (count, min s, max s) per row.  The numeric kernel then runs ONE product per lane:
+// no per-entry loops over mostly empty column positions, no cross-lane compaction, no tail for long columns (any UPPER).
+// It still gathers every partner entry (read id, position) from the columns: nothing of B is precomputed.
+__device__ __forceinline__ void desc_fields(uint64_t x, bool packed, uint32_t index_in_row, uint32_t &addr, uint32_t &len, uint32_t &rank)
+{
+    addr = (uint32_t)(x >> 32);
+    len = packed ? ((uint32_t)x & 255u) : (uint32_t)x;
+    rank = packed ? ((uint32_t)x >> 8) : index_in_row;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_products(const uint32_t *rowptr, const uint64_t *csrx, const uint64_t *cscp, uint32_t M, bool packed, uint32_t fbits,
+                                                  uint32_t *cnt, uint32_t *diag, const uint64_t *prodptr, uint64_t *prod)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < M; i += nwaves) {
+        const uint32_t rs = rowptr[i], re = rowptr[i + 1];
+        uint32_t total = 0, dn = 0, dmin = 0xFFFFFFFFu, dmax = 0;
+        uint64_t out = FILL ? prodptr[i] : 0;
+        for (uint32_t e0 = rs; e0 < re; e0 += 64) {                        // wave-uniform trip count
+            const uint32_t e = e0 + lane;
+            uint32_t addr = 0, len = 0, rank = 0, mine = 0;
+            if (e < re) {
+                desc_fields(csrx[e], packed, e - rs, addr, len, rank);
+                for (uint32_t f = 0; f < len; ++f) {
+                    const uint32_t j = (uint32_t)(cscp[addr + f] >> 32), s = (rank << fbits) | f;
+                    if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
+                    else ++mine;
+                }
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += o; }
+            if (FILL) {
+                uint64_t w = out + incl - mine;
+                for (uint32_t f = 0; f < len; ++f) {
+                    const uint32_t j = (uint32_t)(cscp[addr + f] >> 32);
+                    if (j != i) prod[w++] = ((uint64_t)(addr + f) << 32) | ((rank << fbits) | f);
+                }
+            }
+            const uint32_t chunk = __shfl(incl, 63, 64);
+            out += chunk; total += chunk;
+        }
+        if (!FILL) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                dn += __shfl_xor(dn, d, 64);
+                const uint32_t a = __shfl_xor(dmin, d, 64), b = __shfl_xor(dmax, d, 64);
+                dmin = a < dmin ? a : dmin; dmax = b > dmax ? b : dmax;
+            }
+            if (lane == 0) { cnt[i] = total; diag[3 * i] = dn; diag[3 * i + 1] = dmin; diag[3 * i + 2] = dmax; }
+        }
+    }
+}
+
 int bits_for(uint64_t maxval)
 {
     int b = 1;
@@ -196,6 +258,39 @@ static void build_hot_format(Ctx &c)
     ELBA_HIP(hipStreamSynchronize(s));
 }
 
+// Per-row product schedule (see the comment above k_products).  Needs the final descriptors (a_csrx) and column copy (a_cscp or a_csc).
+static void build_product_schedule(Ctx &c)
+{
+    hipStream_t s = c.stream;
+    const int64_t M = c.M;
+    int fb = 1;
+    while (fb < 31 && ((uint64_t)(c.max_col_nnz > 1 ? c.max_col_nnz - 1 : 1) >> fb)) ++fb;
+    c.fbits = (uint32_t)fb;
+    ELBA_REQUIRE(fb < 31 && (uint64_t)c.max_row_nnz <= (1ull << (32 - fb)), ELBA_ERR_UNSUPPORTED,
+                 "row nnz x column nnz exceeds the 32-bit product sequence number");
+    c.a_diag.reserve((size_t)(M + 1) * 12);
+    c.a_prodptr.reserve((size_t)(M + 2) * 8);
+    c.ws_e.reserve((size_t)(M + 2) * 4);
+    uint32_t *cnt = c.ws_e.as<uint32_t>();
+    const uint64_t *cols = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
+    c.Pnd = 0;
+    if (M == 0) return;
+    int nb = (int)((M + 3) / 4);
+    if (nb > c.num_cus * 8) nb = c.num_cus * 8;
+    ELBA_HIP(hipMemsetAsync(cnt, 0, (size_t)(M + 2) * 4, s));
+    hipLaunchKernelGGL((k_products<false>), dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csrx.as<uint64_t>(), cols, (uint32_t)M, c.hot_packed, c.fbits,
+                       cnt, c.a_diag.as<uint32_t>(), (const uint64_t *)nullptr, (uint64_t *)nullptr);
+    exclusive_scan_u32_to_i64(s, cnt, c.a_prodptr.as<int64_t>(), M + 1, c.ws_scan);
+    int64_t total = 0;
+    ELBA_HIP(hipMemcpyAsync(&total, c.a_prodptr.as<int64_t>() + M, 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    c.Pnd = total;
+    c.a_prod.reserve((size_t)(total + 1) * 8);
+    hipLaunchKernelGGL((k_products<true>), dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csrx.as<uint64_t>(), cols, (uint32_t)M, c.hot_packed, c.fbits,
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, c.a_prodptr.as<uint64_t>(), c.a_prod.as<uint64_t>());
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
 // Input: Z entries sorted by (kid, read, pos): kid_keys[z] >> kid_shift = kid, csc[z] = read<<32|pos (device, in c.a_csc or elsewhere).
 // Produces c.a_colptr, c.a_csc (copy if csc is not already c.a_csc), c.a_rowptr, c.a_csr, max_row_nnz, max_col_nnz.
 void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, const uint64_t *kid_keys, int kid_shift, const uint64_t *csc)
@@ -243,6 +338,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
     build_hot_format(c);
+    build_product_schedule(c);
     c.have_A = true;
     c.have_B = false;
 }

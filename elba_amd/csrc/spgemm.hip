@@ -66,6 +66,7 @@ struct OvCounters {              // device-side counters, zeroed per call
 
 struct OvParams {
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_csrx; const uint64_t *a_cscp; const uint32_t *a_roworder;
+    const uint64_t *a_prodptr; const uint64_t *a_prod; const uint32_t *a_diag;   // per-row product schedule (matrix.hip)
     uint32_t packed;         // 1: a_csrx = column address << 32 | rank << 8 | length, columns permuted (a_cscp); 0: address << 32 | length, canonical
     uint32_t M;              // number of rows of A held here
     uint32_t Mcols;          // number of reads overall (partner id range)
@@ -260,7 +261,7 @@ void stage_create_seed_matrix(Ctx &c)
     st.nrows = row_hi - row_lo;
     c.have_B = false;
 
-    const uint32_t fbits = (uint32_t)bits_for_u((uint64_t)(c.max_col_nnz > 1 ? c.max_col_nnz - 1 : 1));
+    const uint32_t fbits = c.fbits;          // fixed when the product schedule was built
     ELBA_REQUIRE(fbits < 31 && (uint64_t)c.max_row_nnz <= (1ull << (32 - fbits)), ELBA_ERR_UNSUPPORTED,
                  "row nnz x column nnz exceeds the 32-bit product sequence number");
     ELBA_REQUIRE((uint64_t)c.max_row_nnz * (uint64_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1) < 0xFFFFFFFFull, ELBA_ERR_UNSUPPORTED,
@@ -283,6 +284,7 @@ void stage_create_seed_matrix(Ctx &c)
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
     p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_csrx = c.a_csrx.as<uint64_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
+    p.a_prodptr = c.a_prodptr.as<uint64_t>(); p.a_prod = c.a_prod.as<uint64_t>(); p.a_diag = c.a_diag.as<uint32_t>();
     p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>(); p.packed = c.hot_packed ? 1u : 0u;
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;
@@ -351,15 +353,14 @@ void stage_create_seed_matrix(Ctx &c)
         if (nrows > 0) {
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
-            const size_t X = 128;  // misc words (+ per-wave product queues: 64 lanes x 8 products x 8 B = 4 KiB per wave)
-            const size_t Q = 2560;   // per-wave product queue: 2 x (256 + 64 trash) u32; the survivor list aliases the queues when it fits (16 B/slot then)
-            const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 8;
-            if (b0 == 64) ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)16 * 512 + X + Q, 0, 9u);
-            else ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)16 * 512 + X + 2 * Q, 0, 9u);
-            ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)16 * 1024 + X + 2 * Q, 1, 10u);
-            ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)16 * 2048 + X + 4 * Q, 2, 11u);
-            ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)20 * 4096 + X + 4 * Q, 3, 12u);
-            ELBA_LAUNCH_ROWS(256, true, spill_blocks, X + 4 * Q, NUM_LDS_TIERS, 0u);
+            const size_t X = 128;  // misc words
+            const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 12;    // resident capacity: 10.4 KB LDS and 70 VGPRs per 128-thread workgroup -> 14 per CU
+            if (b0 == 64) ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)20 * 512 + X, 0, 9u);
+            else ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)20 * 512 + X, 0, 9u);
+            ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)20 * 1024 + X, 1, 10u);
+            ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)20 * 2048 + X, 2, 11u);
+            ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)20 * 4096 + X, 3, 12u);
+            ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u);
             ELBA_HIP(hipGetLastError());
         }
         c.t_b.stop(s);

@@ -1,15 +1,13 @@
 // spgemm_rows.hpp — the numeric kernel of the overlap SpGEMM (included by spgemm.hip inside its anonymous namespace).
 //
-// One workgroup per row of B.  The kernel is bound by dependent memory round trips, not by bytes or LDS cycles
-// (profiles/: SQ_WAIT_ANY > 50 %, LDS active < 2 % of wave cycles), so it is organised to keep the number of dependent
-// levels per row small and the number of independent loads in flight per lane large:
-//   level 1   entry descriptors of the row (column start | length), coalesced, prefetched one group ahead;
-//   level 2   GRP entries per lane at a time, SPEC column entries each: GRP*SPEC independent 8-byte gathers in flight per
-//             lane, then the LDS accumulator updates for those products;
+// One workgroup per row of B.  What bounds it is instruction issue and dependent LDS/memory round trips at the 8-16 waves per
+// CU the LDS tables allow — not bytes and not LDS throughput (profiles/r01_notes.md) — so the kernel is organised to run few,
+// fully populated instructions per product and to keep few dependent levels per row:
+//   level 0   row id of the NEXT row, this row's bounds / product range / diagonal: one round trip, loaded together;
+//   level 1   schedule items of the row (matrix.hip: one 8-byte item per non-diagonal product), coalesced, prefetched one group ahead;
+//   level 2   PK independent 8-byte gathers per lane (the partner's column entry), then the LDS accumulator updates, two at a time;
 //   level 3   one sweep of the table builds the survivor list (ballot + popcount compaction) and the counts;
-//   level 4   all survivors decode their two seeds in parallel (descriptor -> column entry), then store.
-// A row of 834 entries (the median of the ecsample30x-like workload) on a 64-lane workgroup is 1 + 4 + 2 dependent global
-// levels instead of ~30 in the entry-at-a-time form.
+//   level 4   all survivors decode their two seeds in parallel (canonical arrays), then store.
 
 // misc words in LDS: 0 diag n, 1 diag smin, 2 diag smax, 3 survivors, 4 y, 5 yraw, 6/7 staging offset lo/hi, 8 fits,
 //                    9 claimed slots, 10 abandon flag, 11 row entries consumed when the row was abandoned
@@ -77,6 +75,8 @@ struct Table {
 // two adjacent column entries in one 16-byte global load; columns start on 8-byte boundaries only, hence aligned(8)
 struct __attribute__((packed, aligned(8))) pair64 { uint64_t lo, hi; };
 
+constexpr int PK = 4;      // products per lane in flight (schedule items -> gathers -> accumulator)
+constexpr uint64_t NOITEM = ~0ull;
 constexpr int GRP = 2;     // entries whose column gathers are in flight together (4 spills SGPRs and needs 136 VGPRs)
 constexpr int SPEC = 8;    // column entries gathered unconditionally per entry; longer columns (UPPER > 8) take a serial tail loop
 
@@ -115,11 +115,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     const uint32_t dbg = DIAG ? p.dbg : 0u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS tiers: keys | cnt | smin | smax | survivor list (u32 each, T entries) | misc;  spill tier: only misc lives in LDS
-    uint32_t *misc = GLOBAL ? smem : smem + (size_t)(((1u << lds_tbits) <= (BLOCK / 64) * 2 * (256 + 64)) ? 4 : 5) * (1u << lds_tbits);
+    uint32_t *misc = GLOBAL ? smem : smem + (size_t)5 * (1u << lds_tbits);
     // per-wave product queue: 64 lanes x SPEC products, partner id and sequence number
-    constexpr uint32_t QCAP = 256;              // + 64 trash slots per array (branch-free queue writes)
-    uint32_t *qj = misc + 32 + (threadIdx.x >> 6) * (2 * (QCAP + 64));
-    uint32_t *qs = qj + QCAP + 64;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1;
     const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
@@ -146,7 +143,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         // one memory round trip instead of three dependent ones on the row's critical path
         const uint32_t i = i_next;
         if (it + gridDim.x < nrows) i_next = p.lists[(size_t)tier * p.M + it + gridDim.x];
-        const uint32_t rs = p.a_rowptr[i], re = p.a_rowptr[i + 1];
+        const uint32_t rs = p.a_rowptr[i];
+        const uint64_t ps = p.a_prodptr[i], pe = p.a_prodptr[i + 1];
+        const uint32_t dg_n = p.a_diag[3 * i], dg_min = p.a_diag[3 * i + 1], dg_max = p.a_diag[3 * i + 2];   // diagonal of B(i,i): structure of A
         const uint32_t ub_i = p.a_rowprod[i];
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
@@ -193,127 +192,61 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             const uint32_t T = 1u << lds_tbits;
             tab.limit = p.tier_limit[tier];          // abandon point: at most limit + 2*BLOCK slots are ever claimed, < T
             tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
-            // the survivor list is only alive after the accumulate phase: it shares the queues' LDS when it fits
-            list = (T <= (BLOCK / 64) * 2 * (QCAP + 64)) ? misc + 32 : smem + 4 * T;
+            list = smem + 4 * T;
         }
         const uint32_t T = tab.size();
         ELBA_STAMP(0);
         for (uint32_t s = tid; s < T; s += BLOCK) { tab.keys[s] = EMPTY; tab.cnt[s] = 0; tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
-        if (tid < 16) misc[tid] = (tid == 1) ? 0xFFFFFFFFu : 0u;
+        if (tid < 16) misc[tid] = tid == 0 ? dg_n : (tid == 1 ? dg_min : (tid == 2 ? dg_max : 0u));
         __syncthreads();
         ELBA_STAMP(1);
 
-        // ---- expand + accumulate ----
-        uint32_t dn = 0, dmin = 0xFFFFFFFFu, dmax = 0;
+        // ---- accumulate: the row's product schedule, ONE non-diagonal product per lane and slot ----
+        // item = address of the partner's column entry << 32 | s  (matrix.hip: k_products).  PK items per lane are in flight: their
+        // gathers are issued together, the next PK items are prefetched, then the accumulator is updated two products at a time.
         bool full = false;
-        // Software-pipelined, NOT unrolled over the row: the kernel must stay small — a fully unrolled 16x4 inline-insert body
-        // was 49 KB of code and instruction fetch, not memory, bounded it (profiles/r01_notes.md).  Per iteration a lane owns
-        // GRP row entries: their column gathers (GRP*SPEC independent loads) are issued first, then the descriptors of the NEXT
-        // group are prefetched, then the accumulator is updated; descriptors therefore never sit on the critical path.
-        uint64_t xc[GRP];
+        uint64_t itc[PK];
 #pragma unroll
-        for (int q = 0; q < GRP; ++q) {
-            const uint32_t e = rs + (uint32_t)q * BLOCK + tid;
-            xc[q] = e < re ? p.a_csrx[e] : 0ull;                       // column start << 32 | column length; past the row end: length 0
+        for (int k = 0; k < PK; ++k) {
+            const uint64_t idx = ps + (uint64_t)k * BLOCK + tid;
+            itc[k] = idx < pe ? p.a_prod[idx] : NOITEM;
         }
 #pragma unroll 1
-        for (uint32_t gb = rs; gb < re; gb += GRP * BLOCK) {
-            // Column gathers: two entries per 16-byte load.  BRANCH-FREE on purpose: pairs beyond the column's length re-read the
-            // first pair (same sector, L1 hit) instead of sitting under `if`: every predicated region costs an exec-mask
-            // save/restore in SALU and 64-bit SGPRs — the unrolled predicated form of this loop spilled 70-90 SGPRs.
-            uint64_t c[GRP][SPEC];
+        for (uint64_t t0 = ps; t0 < pe; t0 += (uint64_t)PK * BLOCK) {
+            uint64_t ce[PK];
 #pragma unroll
-            for (int q = 0; q < GRP; ++q) {
-                const uint32_t a = (uint32_t)(xc[q] >> 32), n = desc_len(p, xc[q]);
+            for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[itc[k] != NOITEM ? (uint32_t)(itc[k] >> 32) : 0u];
+            if (DIAG && (dbg & 2u)) {                                   // ablation: no gathers, synthetic partner ids
 #pragma unroll
-                for (int v = 0; v < SPEC / 2; ++v) {
-                    const pair64 pr = *reinterpret_cast<const pair64 *>(p.a_cscp + a + ((uint32_t)(2 * v) < n ? 2 * v : 0));   // 2 guard entries
-                    c[q][2 * v] = pr.lo; c[q][2 * v + 1] = pr.hi;
-                }
-                if (dbg & 2u) {                                       // ablation: no gathers, synthetic partner ids
-#pragma unroll
-                    for (int u = 0; u < SPEC; ++u) c[q][u] = (uint64_t)(((a + u) * 2654435761u) % p.Mcols) << 32;
-                }
+                for (int k = 0; k < PK; ++k) ce[k] = (uint64_t)(((uint32_t)(itc[k] >> 32) * 2654435761u) % p.Mcols) << 32;
             }
-            uint64_t xn[GRP];
+            uint64_t itn[PK];
 #pragma unroll
-            for (int q = 0; q < GRP; ++q) {
-                const uint32_t e = gb + (uint32_t)(GRP + q) * BLOCK + tid;
-                xn[q] = e < re ? p.a_csrx[e] : 0ull;
+            for (int k = 0; k < PK; ++k) {
+                const uint64_t idx = t0 + (uint64_t)(PK + k) * BLOCK + tid;
+                itn[k] = idx < pe ? p.a_prod[idx] : NOITEM;
             }
-            if (dbg & 1u) {                                           // ablation: gathers only, keep the loads alive
+            ELBA_STAMP(6);
+            if (DIAG && (dbg & 1u)) {                                   // ablation: gathers only, keep the loads alive
                 uint32_t sink = 0;
 #pragma unroll
-                for (int q = 0; q < GRP; ++q)
-#pragma unroll
-                    for (int u = 0; u < SPEC; ++u) sink ^= (uint32_t)(c[q][u] >> 32);
-                dn += sink == 0xFFFFFFFFu;
+                for (int k = 0; k < PK; ++k) sink ^= (uint32_t)(ce[k] >> 32);
+                if (sink == 0xFFFFFFFFu) misc[15] = 1;
             } else {
 #pragma unroll
-                for (int q = 0; q < GRP; ++q) {
-                    const uint32_t a = (uint32_t)(xc[q] >> 32), n = desc_len(p, xc[q]);
-                    const uint32_t rank = p.packed ? ((uint32_t)xc[q] >> 8) : gb + (uint32_t)q * BLOCK + tid - rs;
-                    const uint32_t sb = rank << p.fbits;
-                    // Columns hold 2.6 entries on average but up to SPEC: updating the accumulator lane-by-entry would run SPEC
-                    // insert bodies with mostly idle lanes.  Instead the wave's products of this round are FLATTENED through a
-                    // per-wave LDS queue (exclusive prefix of the per-lane counts gives each lane its slots) and then inserted with
-                    // all lanes busy: ceil(products/64) insert bodies instead of SPEC.
-                    // select-only code (no predicated regions): diagonal products (j == i: 38 % of all products) stay in registers
-                    uint32_t mine = 0;
-#pragma unroll
-                    for (int u = 0; u < SPEC; ++u) {
-                        const bool in = (uint32_t)u < n, dg = in && (uint32_t)(c[q][u] >> 32) == i;
-                        const uint32_t s = sb | (uint32_t)u;
-                        dn += dg ? 1u : 0u;
-                        dmin = (dg && s < dmin) ? s : dmin;
-                        dmax = (dg && s > dmax) ? s : dmax;
-                        mine += (in && !dg) ? 1u : 0u;
-                    }
-                    if (q == 0) ELBA_STAMP(6);
-                    // exclusive prefix of the per-lane product counts by a DPP wave scan (VALU only: no LDS round trips, no ballots)
-                    const uint32_t incl = wave_inclusive_scan_dpp(mine);
-                    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                    // The queue holds QCAP products per wave (a round has 64 x 1.6 = 103 live products on average, 512 at most): a
-                    // round that exceeds it is drained in several passes — rare, and wave-uniform.
-#pragma unroll 1
-                    for (uint32_t qbase = 0; qbase < total; qbase += QCAP) {
-                        uint32_t w = incl - mine - qbase;                 // wraps below zero for products of earlier passes: not < QCAP
-#pragma unroll
-                        for (int u = 0; u < SPEC; ++u) {
-                            const uint32_t j = (uint32_t)(c[q][u] >> 32);
-                            const bool live = (uint32_t)u < n && j != i;
-                            const uint32_t dst = (live && w < QCAP) ? w : QCAP + lane;   // everything else: this lane's private trash slot
-                            qj[dst] = j; qs[dst] = sb | (uint32_t)u;
-                            w += live ? 1u : 0u;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        ELBA_STAMP(7);
-                        const uint32_t here = total - qbase < QCAP ? total - qbase : QCAP;
-#pragma unroll 1
-                        for (uint32_t t = lane; t < here; t += 128) {       // two products per lane and trip: their LDS round trips overlap
-                            const bool two = t + 64 < here;
-                            const uint32_t j0 = qj[t], s0 = qs[t];
-                            const uint32_t j1 = two ? qj[t + 64] : 0u, s1 = two ? qs[t + 64] : 0u;
-                            tab.insert2(j0, s0, j1, s1, two, full);
-                        }
-                        __builtin_amdgcn_wave_barrier();
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    ELBA_STAMP(8);
-                    for (uint32_t f = SPEC; f < n; ++f) {                 // the tail of columns longer than SPEC (UPPER > 8)
-                        const uint32_t j = (uint32_t)(p.a_cscp[a + f] >> 32), s = sb | f;
-                        if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
-                        else tab.insert(j, s, full);
-                    }
+                for (int k = 0; k < PK; k += 2) {
+                    if (itc[k] != NOITEM)
+                        tab.insert2((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], (uint32_t)(ce[k + 1] >> 32), (uint32_t)itc[k + 1], itc[k + 1] != NOITEM, full);
                 }
             }
+            ELBA_STAMP(8);
 #pragma unroll
-            for (int q = 0; q < GRP; ++q) xc[q] = xn[q];
-            ELBA_STAMP(9);
-            if (tab.abandoned()) { if (tid == 0) misc[11] = gb + GRP * BLOCK - rs < re - rs ? gb + GRP * BLOCK - rs : re - rs; break; }
+            for (int k = 0; k < PK; ++k) itc[k] = itn[k];
+            if (tab.abandoned()) {
+                if (tid == 0) { const uint64_t done = t0 + (uint64_t)PK * BLOCK - ps; misc[11] = (uint32_t)(done < pe - ps ? done : pe - ps); }
+                break;
+            }
         }
-        if (dn) { atomicAdd(&misc[0], dn); atomicMin(&misc[1], dmin); atomicMax(&misc[2], dmax); }
         __syncthreads();
         ELBA_STAMP(2);
         if (tab.abandoned()) {
@@ -322,7 +255,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 const uint32_t at = atomicAdd(&p.ctr->tier_count[tier + 1], 1u);
                 p.lists[(size_t)(tier + 1) * p.M + at] = i;
                 // the table filled after `gb_done` of the row's entries: extrapolate its distinct-partner count for the feedback
-                const uint32_t done = misc[11] ? misc[11] : 1u, all = re - rs;
+                const unsigned long long done = misc[11] ? misc[11] : 1u, all = pe - ps;
                 fb_c += (unsigned long long)misc[9] * all / done; fb_u += ub_i; ++fb_n;
             }
             __syncthreads();
