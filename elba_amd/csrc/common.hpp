@@ -142,6 +142,8 @@ struct Ctx {
     DevBuf ws_scan, ws_sort, ws_a, ws_b, ws_c, ws_d, ws_e, ws_f;
     DevBuf ov_rowub, ov_rowcnt, ov_rowoff, ov_lists, ov_counters, ov_tmp_col, ov_tmp_val, ov_gtable, ov_sortkeys;
     int64_t ov_tmp_cap = 0;
+    bool ov_tiers_known = false, ov_tier_used[8] = {false, false, false, false, false, false, false, false};   // tiers that got rows in the previous call
+    int64_t b_cap_entries = 0;      // capacity of b_col/b_val the next overlap call may assume (0 = unknown: size it after the numeric pass)
     uint32_t ov_prior_q16 = 0;      // distinct-partner / product ratio measured by the previous overlap call (x 65536), 0 = unknown
 
     EventTimer t_total, t_a, t_b, t_c;

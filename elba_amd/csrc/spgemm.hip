@@ -156,6 +156,7 @@ struct FinParams {
     uint32_t M, row_lo, row_hi;
     const uint32_t *fin_lists; const OvCounters *ctr;
     uint64_t *sortkeys; unsigned long long sort_stride;
+    long long b_cap;         // capacity of b_col / b_val in entries: rows that would not fit are left out (the host regrows and reruns)
 };
 
 
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
         if (y == 0 || y > FIN_WAVE_MAX) continue;
         const unsigned long long off = p.row_off[i];
         const int64_t dst = p.b_rowptr[i];
+        if (dst + (int64_t)y > p.b_cap) continue;
         uint32_t mine[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -227,6 +229,7 @@ __global__ __launch_bounds__(256) void k_finalize_block(FinParams p)
         uint64_t *keys = GLOBAL ? p.sortkeys + (size_t)blockIdx.x * p.sort_stride : lkeys;
         const unsigned long long off = p.row_off[i];
         const int64_t dst = p.b_rowptr[i];
+        if (dst + (int64_t)y > p.b_cap) continue;
         uint32_t n2 = 1;
         while (n2 < y) n2 <<= 1;
         for (uint32_t t = threadIdx.x; t < n2; t += 256)
@@ -314,6 +317,7 @@ void stage_create_seed_matrix(Ctx &c)
     const int cus = c.num_cus;
     const int64_t nrows = row_hi - row_lo;
     OvCounters hc{};
+    uint32_t skipped_tiers = 0;
     int passes = 0;
     float ms_sym = 0, ms_num = 0;
     c.t_total.start(s);
@@ -355,21 +359,80 @@ void stage_create_seed_matrix(Ctx &c)
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
             const size_t X = 128;  // misc words
             const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 12;    // resident capacity: 10.4 KB LDS and 70 VGPRs per 128-thread workgroup -> 14 per CU
-            if (b0 == 64) ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)20 * 512 + X, 0, 9u);
-            else ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)20 * 512 + X, 0, 9u);
-            ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)20 * 1024 + X, 1, 10u);
-            ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)20 * 2048 + X, 2, 11u);
-            ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)20 * 4096 + X, 3, 12u);
-            ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u);
+            // Tiers that received no row in the previous call on this matrix are not launched (an empty launch still costs ~5 us of
+            // stream time); should a row reach one of them after all, the call is repeated with every tier (checked after the sync).
+            const bool all_tiers = !c.ov_tiers_known || c.b_cap_entries == 0;
+            skipped_tiers = 0;
+#define ELBA_TIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
+            if (b0 == 64) ELBA_TIER(0, ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)20 * 512 + X, 0, 9u));
+            else ELBA_TIER(0, ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)20 * 512 + X, 0, 9u));
+            ELBA_TIER(1, ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)20 * 1024 + X, 1, 10u));
+            ELBA_TIER(2, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)20 * 2048 + X, 2, 11u));
+            ELBA_TIER(3, ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)20 * 4096 + X, 3, 12u));
+            ELBA_TIER(4, ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u));
             ELBA_HIP(hipGetLastError());
         }
         c.t_b.stop(s);
-        ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
+        // Steady state (staging and output capacities known from an earlier call on this matrix): no host round trip between the
+        // numeric kernels and the finalize pass — everything is queued, ONE synchronisation at the end, and the rare surprises
+        // (staging overflow, more output than last time) are repaired afterwards.  First call: synchronise here to size the output.
+        const bool fast = c.b_cap_entries > 0;
+        if (!fast) {
+            ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
+            ELBA_HIP(hipStreamSynchronize(s));
+            ms_sym += c.t_a.ms(); ms_num += c.t_b.ms();
+            if (hc.overflow) {
+                ELBA_REQUIRE(passes < 3, ELBA_ERR_INTERNAL, "overlap staging area overflowed twice");
+                c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;      // the bound that cannot overflow
+                continue;
+            }
+            int64_t y = 0;
+            for (int sh = 0; sh < NUM_SHARDS; ++sh) y += (int64_t)hc.shard[sh].nnz;
+            c.b_cap_entries = y + y / 4 + 1024;
+        }
+        c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
+        c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
+
+        // row pointers, per-row column sort + move to the final arrays
+        c.t_c.start(s);
+        exclusive_scan_u32_to_i64(s, c.ov_rowcnt.as<uint32_t>(), c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
+        if (nrows > 0) {
+            FinParams f{};
+            f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
+            f.tmp_col = p.tmp_col; f.tmp_val = p.tmp_val; f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
+            f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
+            f.b_cap = c.b_cap_entries;
+            const int gblocks = 32;
+            uint64_t sstride = 2;
+            while (sstride < (uint64_t)M) sstride <<= 1;
+            c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
+            f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
+            int nb = (int)((nrows + 3) / 4);
+            if (nb > cus * 32) nb = cus * 32;      // one row per wavefront where possible: the pass is latency-bound per row
+            hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
+            // the wide-row sorts read their queues' lengths on the device: launched unconditionally (empty queues cost a few us)
+            hipLaunchKernelGGL((k_finalize_block<false>), dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
+            hipLaunchKernelGGL((k_finalize_block<true>), dim3(gblocks), dim3(256), 0, s, f);
+        }
+        c.t_c.stop(s);
+        c.t_total.stop(s);
+        if (fast) ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
         ELBA_HIP(hipStreamSynchronize(s));
-        ms_sym += c.t_a.ms(); ms_num += c.t_b.ms();
-        if (!hc.overflow) break;
-        ELBA_REQUIRE(passes < 3, ELBA_ERR_INTERNAL, "overlap staging area overflowed twice");
-        c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;      // the bound that cannot overflow
+        if (fast) {
+            ms_sym += c.t_a.ms(); ms_num += c.t_b.ms();
+            int64_t y = 0;
+            for (int sh = 0; sh < NUM_SHARDS; ++sh) y += (int64_t)hc.shard[sh].nnz;
+            bool missed = false;
+            for (int t = 0; t < NUM_TIERS; ++t) missed |= ((skipped_tiers >> t) & 1u) && hc.tier_count[t] > 0;
+            if (hc.overflow || y > c.b_cap_entries || missed) {     // a surprise: fall back to the synchronising path and redo the call
+                ELBA_REQUIRE(passes < 4, ELBA_ERR_INTERNAL, "overlap output did not settle");
+                if (hc.overflow) c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;
+                c.b_cap_entries = 0;
+                c.t_total.start(s);
+                continue;
+            }
+        }
+        break;
     }
 
     hc.fb_claims = 0; hc.fb_ub = 0;                 // the hot in-call sums are a subset of what the shards hold
@@ -379,36 +442,9 @@ void stage_create_seed_matrix(Ctx &c)
         if (x.maxshared > hc.maxshared) hc.maxshared = x.maxshared;
         for (int t = 0; t < NUM_TIERS; ++t) hc.tier_done[t] += x.tier_done[t];
     }
-    // row pointers, final arrays
     const int64_t Y = (int64_t)hc.nnz;
-    c.t_c.start(s);
-    exclusive_scan_u32_to_i64(s, c.ov_rowcnt.as<uint32_t>(), c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
-    c.b_col.reserve((size_t)(Y + 1) * 4);
-    c.b_val.reserve((size_t)(Y + 1) * sizeof(elba_seed_t));
-    if (nrows > 0 && Y > 0) {
-        FinParams f{};
-        f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
-        f.tmp_col = p.tmp_col; f.tmp_val = p.tmp_val; f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
-        f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
-        int nb = (int)((nrows + 3) / 4);
-        if (nb > cus * 8) nb = cus * 8;
-        hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
-        if (hc.fin_count[0]) {
-            int nb2 = (int)(hc.fin_count[0] < (unsigned)cus * 8 ? hc.fin_count[0] : (unsigned)cus * 8);
-            hipLaunchKernelGGL((k_finalize_block<false>), dim3(nb2), dim3(256), 0, s, f);
-        }
-        if (hc.fin_count[1]) {
-            const int gblocks = 32;
-            uint64_t sstride = 2;
-            while (sstride < (uint64_t)M) sstride <<= 1;
-            c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
-            f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
-            hipLaunchKernelGGL((k_finalize_block<true>), dim3(gblocks), dim3(256), 0, s, f);
-        }
-    }
-    c.t_c.stop(s);
-    c.t_total.stop(s);
-    ELBA_HIP(hipStreamSynchronize(s));
+    for (int t = 0; t < NUM_TIERS; ++t) c.ov_tier_used[t] = hc.tier_count[t] > 0;
+    c.ov_tiers_known = true;
 
     if (c.cfg.flags & 16) {   // diagnostic: per-phase shader-clock totals over all workgroups of the numeric kernels
         fprintf(stderr, "[elba dbg] phase cycles (sum over %llu workgroups): fetch=%llu init=%llu accumulate_rest=%llu sweep=%llu reserve=%llu decode=%llu | gather_wait=%llu count_scan_queue=%llu insert=%llu loop_tail=%llu\n",
