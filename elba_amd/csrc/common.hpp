@@ -115,6 +115,7 @@ struct Ctx {
     int64_t M = 0, N = 0, Z = 0, max_row_nnz = 0, max_col_nnz = 0;
     DevBuf a_rowptr, a_csr, a_colptr, a_csc;   // u32[M+1], u64[Z], u32[N+1], u64[Z]
     DevBuf a_rowprod;                          // u32[M] products per row: sum of the column lengths of the row's k-mers
+    DevBuf a_dec;                              // u64[Z] by canonical rank: address of the entry's column in a_cscp << 32 | position in the read (seed decoding)
     DevBuf a_prodptr, a_prod, a_diag;          // i64[M+1], u64[Pnd], u32[3M]: per-row product schedule + diagonal (count, min s, max s); matrix.hip
     int64_t Pnd = 0;                           // non-diagonal products
     uint32_t fbits = 1;                        // bits of the column-position field of a product sequence number

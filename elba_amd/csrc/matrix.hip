@@ -47,7 +47,7 @@ __global__ void k_max_seg_len(const uint32_t *ptr, int64_t nseg, unsigned long l
 }
 
 // products per row: ub_i = sum over the row's entries of the length of the entry's column (one wavefront per row)
-__global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, uint32_t M, uint32_t *rowprod, uint64_t *csrx)
+__global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, uint32_t M, uint32_t *rowprod, uint64_t *csrx, uint64_t *dec)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, co
             const uint32_t kid = (uint32_t)(csr[e] >> 32);
             const uint32_t c0 = colptr[kid], len = colptr[kid + 1] - c0;
             csrx[e] = ((uint64_t)c0 << 32) | len;
+            dec[e] = ((uint64_t)c0 << 32) | (uint32_t)csr[e];
             ub += len;
         }
 #pragma unroll
@@ -104,7 +105,7 @@ __global__ void k_perm_copy(const uint64_t *sorted_cols, const uint32_t *newstar
 
 // descriptor of CSR entry e (row i, rank r = e - rowptr[i]): column address << 32 | rank << 8 | column length (<= 255)
 __global__ __launch_bounds__(256) void k_descriptors(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, const uint32_t *newstart, uint32_t M,
-                                                     uint64_t *keys, uint64_t *desc)
+                                                     uint64_t *keys, uint64_t *desc, uint64_t *dec)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -116,6 +117,7 @@ __global__ __launch_bounds__(256) void k_descriptors(const uint32_t *rowptr, con
             const uint32_t len = colptr[kid + 1] - colptr[kid], st = newstart[kid];
             keys[e] = ((uint64_t)i << 32) | st;                 // sort key: (row, column address)
             desc[e] = ((uint64_t)st << 32) | ((uint64_t)(e - rs) << 8) | len;
+            dec[e] = ((uint64_t)st << 32) | (uint32_t)csr[e];      // seed decoding by canonical rank: column address | position in the read
         }
     }
 }
@@ -249,7 +251,7 @@ static void build_hot_format(Ctx &c)
     {
         int nb = (int)((M + 3) / 4);
         if (nb > c.num_cus * 8) nb = c.num_cus * 8;
-        hipLaunchKernelGGL(k_descriptors, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), newstart, (uint32_t)M, k0, v0);
+        hipLaunchKernelGGL(k_descriptors, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), newstart, (uint32_t)M, k0, v0, c.a_dec.as<uint64_t>());
     }
     int w3 = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, bits_for((uint64_t)Z), c.ws_sort);
     ck = w3 ? k1 : k0; cv = w3 ? v1 : v0; ok = w3 ? k0 : k1; ov = w3 ? v0 : v1;
@@ -318,10 +320,11 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
     c.a_rowprod.reserve((size_t)(M + 1) * 4);
     c.a_csrx.reserve((size_t)(Z + 1) * 8);
+    c.a_dec.reserve((size_t)(Z + 1) * 8);
     if (M > 0) {
         int nb = (int)((M + 3) / 4);
         if (nb > c.num_cus * 8) nb = c.num_cus * 8;
-        hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_csrx.as<uint64_t>());
+        hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_csrx.as<uint64_t>(), c.a_dec.as<uint64_t>());
     }
     // rows by descending product count: the SpGEMM queues them in this order so that a workgroup's static share of a tier
     // mixes heavy rows first and light rows last (longest-processing-time order: short tail)

@@ -66,7 +66,7 @@ struct OvCounters {              // device-side counters, zeroed per call
 
 struct OvParams {
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_csrx; const uint64_t *a_cscp; const uint32_t *a_roworder;
-    const uint64_t *a_prodptr; const uint64_t *a_prod; const uint32_t *a_diag;   // per-row product schedule (matrix.hip)
+    const uint64_t *a_prodptr; const uint64_t *a_prod; const uint32_t *a_diag; const uint64_t *a_dec;   // per-row product schedule (matrix.hip)
     uint32_t packed;         // 1: a_csrx = column address << 32 | rank << 8 | length, columns permuted (a_cscp); 0: address << 32 | length, canonical
     uint32_t M;              // number of rows of A held here
     uint32_t Mcols;          // number of reads overall (partner id range)
@@ -287,7 +287,7 @@ void stage_create_seed_matrix(Ctx &c)
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
     p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_csrx = c.a_csrx.as<uint64_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
-    p.a_prodptr = c.a_prodptr.as<uint64_t>(); p.a_prod = c.a_prod.as<uint64_t>(); p.a_diag = c.a_diag.as<uint32_t>();
+    p.a_prodptr = c.a_prodptr.as<uint64_t>(); p.a_prod = c.a_prod.as<uint64_t>(); p.a_diag = c.a_diag.as<uint32_t>(); p.a_dec = c.a_dec.as<uint64_t>();
     p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>(); p.packed = c.hot_packed ? 1u : 0u;
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;

@@ -80,16 +80,23 @@ constexpr uint64_t NOITEM = ~0ull;
 constexpr int GRP = 2;     // entries whose column gathers are in flight together (4 spills SGPRs and needs 136 VGPRs)
 constexpr int SPEC = 8;    // column entries gathered unconditionally per entry; longer columns (UPPER > 8) take a serial tail loop
 
-// s = rank of the row entry (canonical (kid,pos) order) << fbits | index inside the column: decoded through the CANONICAL arrays
+// s = canonical rank of the row entry << fbits | index inside the column.  a_dec[rs + rank] holds the entry's position in the read
+// and the address of its column in a_cscp (still warm in L2: the numeric loop has just gathered it): two loads on two levels per seed
 __device__ __forceinline__ elba_seed_t decode_seed(const OvParams &p, uint32_t rs, uint32_t a, uint32_t b, uint32_t n, uint32_t fmask)
 {
-    const uint64_t ea = p.a_csr[rs + (a >> p.fbits)], eb = p.a_csr[rs + (b >> p.fbits)];
-    const uint32_t ca = p.a_colptr[(uint32_t)(ea >> 32)], cb = p.a_colptr[(uint32_t)(eb >> 32)];
+    const uint64_t ea = p.a_dec[rs + (a >> p.fbits)], eb = p.a_dec[rs + (b >> p.fbits)];
     elba_seed_t v;
-    v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_csc[ca + (a & fmask)];
-    v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_csc[cb + (b & fmask)];
+    v.q0 = (uint32_t)ea; v.t0 = (uint32_t)p.a_cscp[(uint32_t)(ea >> 32) + (a & fmask)];
+    v.q1 = (uint32_t)eb; v.t1 = (uint32_t)p.a_cscp[(uint32_t)(eb >> 32) + (b & fmask)];
     v.numshared = (int32_t)n;
     return v;
+}
+
+// workgroup barrier that orders LDS only: global stores of this row (staging, row_cnt/row_off) may still be in flight — nobody in
+// the workgroup reads them back, and __syncthreads() would wait for their acknowledgement (a full memory round trip per row)
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8 inside each row of 16, row_bcast 15/31 across rows)
@@ -305,31 +312,31 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 p.fin_lists[(size_t)which * p.M + at] = i;
             }
         }
-        __syncthreads();
+        lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
         if (misc[8]) {
             // ---- level 4: all survivors decode their seeds in parallel ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
             const uint32_t ysurv = misc[3];
             uint32_t nup = 0, mx = 0;
-            for (uint32_t t = tid; t < ysurv; t += BLOCK) {
-                const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : list[t];
-                const uint32_t j = tab.ld(tab.keys, s0), n = tab.ld(tab.cnt, s0);
-                const elba_seed_t v = decode_seed(p, rs, tab.ld(tab.smin, s0), tab.ld(tab.smax, s0), n, fmask);
+            // the diagonal entry (its count / min / max come with A) is decoded in the same pass, by the lane after the last survivor
+            const uint32_t hasd = misc[0] >= 2 ? 1u : 0u;
+            for (uint32_t t = tid; t < ysurv + hasd; t += BLOCK) {
+                uint32_t j = i, n = misc[0], a = misc[1], b = misc[2];
+                if (t < ysurv) {
+                    const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : list[t];
+                    j = tab.ld(tab.keys, s0); n = tab.ld(tab.cnt, s0); a = tab.ld(tab.smin, s0); b = tab.ld(tab.smax, s0);
+                }
+                const elba_seed_t v = decode_seed(p, rs, a, b, n, fmask);
                 p.tmp_col[off + t] = j;
                 p.tmp_val[off + t] = v;
                 if (j > i) ++nup;
                 mx = n > mx ? n : mx;
             }
-            if (tid == 0 && misc[0] >= 2) {
-                p.tmp_col[off + ysurv] = i;
-                p.tmp_val[off + ysurv] = decode_seed(p, rs, misc[1], misc[2], misc[0], fmask);
-                mx = misc[0] > mx ? misc[0] : mx;
-            }
             acc_nup += nup;
             acc_mx = mx > acc_mx ? mx : acc_mx;
         }
-        __syncthreads();    // table and misc are re-initialised by the next row
+        lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
         ELBA_STAMP(5);
     }
     if (stamp && tid == 0) {
