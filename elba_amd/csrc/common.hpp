@@ -144,6 +144,9 @@ struct Ctx {
     DevBuf ov_rowub, ov_rowcnt, ov_rowoff, ov_lists, ov_counters, ov_tmp_col, ov_tmp_val, ov_gtable, ov_sortkeys;
     int64_t ov_tmp_cap = 0;
     bool ov_tiers_known = false, ov_tier_used[8] = {false, false, false, false, false, false, false, false};   // tiers that got rows in the previous call
+    bool ov_class_valid = false, ov_sort_used[2] = {false, false};   // cached tier queues (see spgemm.hip), wide-row sorts used last call
+    uint32_t ov_class_prior = 0; int64_t ov_class_lo = 0, ov_class_hi = 0; int ov_class_b0 = 0;
+    DevBuf ov_counters_snap;
     int64_t b_cap_entries = 0;      // capacity of b_col/b_val the next overlap call may assume (0 = unknown: size it after the numeric pass)
     uint32_t ov_prior_q16 = 0;      // distinct-partner / product ratio measured by the previous overlap call (x 65536), 0 = unknown
 

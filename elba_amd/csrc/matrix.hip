@@ -337,7 +337,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>(), (uint64_t)M, c.a_roworder.as<uint32_t>());
     }
     c.row_lo = 0; c.row_hi = -1;
-    c.b_cap_entries = 0; c.ov_tiers_known = false;
+    c.b_cap_entries = 0; c.ov_tiers_known = false; c.ov_class_valid = false;
     c.ov_prior_q16 = 0;            // a new matrix: forget the partner/product ratio measured on the previous one
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
