@@ -24,7 +24,7 @@ def main():
     shutil.copy(ks, os.path.join(HERE, "%s_kernel_stats.csv" % tag))
     rows = list(csv.DictReader(open(ks)))
     stats = {short(r["Name"]): dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, total_ms=float(r["TotalDurationNs"]) / 1e6) for r in rows}
-    calls = max(v["calls"] for k, v in stats.items() if k.startswith("k_classify_rows"))      # one classify launch per step
+    calls = max(v["calls"] for k, v in stats.items() if k.startswith("k_finalize_wave"))      # one finalize launch per step
     spg = {k: v for k, v in stats.items() if k.startswith("k_spgemm_rows")}
     numeric_us_per_step = sum(v["total_ms"] for v in spg.values()) * 1e3 / calls
 
@@ -40,8 +40,8 @@ def main():
 
     fa, fn = pmc(fd)
     wa, wn = pmc(wd)
-    steps_f = fn[("k_classify_rows", "FETCH_SIZE")]
-    steps_w = wn[("k_classify_rows", "WRITE_SIZE")]
+    steps_f = fn[("k_finalize_wave", "FETCH_SIZE")]
+    steps_w = wn[("k_finalize_wave", "WRITE_SIZE")]
     fetch_kb = sum(v["FETCH_SIZE"] for k, v in fa.items() if k.startswith("k_spgemm_rows")) / steps_f
     write_kb = sum(v["WRITE_SIZE"] for k, v in wa.items() if k.startswith("k_spgemm_rows")) / steps_w
     hit = sum(v.get("TCC_HIT_sum", 0) for k, v in wa.items() if k.startswith("k_spgemm_rows")) / steps_w
@@ -62,7 +62,7 @@ def main():
     }
     if sqd:
         sa, sn = pmc(sqd)
-        steps_s = sn[("k_classify_rows", "SQ_WAVES")] or 1
+        steps_s = sn[("k_finalize_wave", "SQ_WAVES")] or 1
         out["SQ_per_step"] = {c: round(sum(v.get(c, 0) for k, v in sa.items() if k.startswith("k_spgemm_rows")) / steps_s)
                               for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
     json.dump(out, open(os.path.join(HERE, "%s_summary.json" % tag), "w"), indent=1)
