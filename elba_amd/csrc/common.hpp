@@ -117,7 +117,8 @@ struct Ctx {
     DevBuf a_rowprod;                          // u32[M] products per row: sum of the column lengths of the row's k-mers
     DevBuf a_dec;                              // u64[Z] by canonical rank: address of the entry's column in a_cscp << 32 | position in the read (seed decoding)
     DevBuf a_prodptr, a_prod, a_diag;          // i64[M+1], u64[Pnd], u32[3M]: per-row product schedule + diagonal (count, min s, max s); matrix.hip
-    int64_t Pnd = 0;                           // non-diagonal products
+    int64_t Pnd = 0;                           // scheduled (non-diagonal, one per unordered in-window pair product) products
+    bool half = true;                          // schedule lists an in-window pair on its smaller row only; the SpGEMM mirrors (matrix.hip)
     uint32_t fbits = 1;                        // bits of the column-position field of a product sequence number
     DevBuf a_roworder;                         // u32[M] rows by descending product count (queue order of the SpGEMM)
     DevBuf a_cscp;                             // u64[Z] columns in first-occurrence order (hot-loop copy of a_csc; see matrix.hip)
@@ -141,7 +142,9 @@ struct Ctx {
 
     // workspaces
     DevBuf ws_scan, ws_sort, ws_a, ws_b, ws_c, ws_d, ws_e, ws_f;
-    DevBuf ov_rowub, ov_rowcnt, ov_rowoff, ov_lists, ov_counters, ov_tmp_col, ov_tmp_val, ov_gtable, ov_sortkeys;
+    DevBuf ov_totcnt, ov_mir, ov_tmp, ov_sum_tmp;  // u32[M+1] mirrored entries per row (ticket counters); mirrored entries laid out like B (32-byte records); staging area (32-byte records)
+    bool ov_low_clean = false;                 // the ticket counters are all zero (handed back clean by the previous call)
+    DevBuf ov_rowub, ov_rowcnt, ov_rowoff, ov_lists, ov_counters, ov_gtable, ov_sortkeys;
     int64_t ov_tmp_cap = 0;
     bool ov_tiers_known = false, ov_tier_used[8] = {false, false, false, false, false, false, false, false};   // tiers that got rows in the previous call
     bool ov_class_valid = false, ov_sort_used[2] = {false, false};   // cached tier queues (see spgemm.hip), wide-row sorts used last call

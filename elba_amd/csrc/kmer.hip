@@ -607,8 +607,7 @@ void stage_dist_set_panel(Ctx &c, const void *d_rec, int64_t nrec, int64_t M_tot
     }
     c.A_has_kmers = false;
     c.dist_owner = false;
-    finish_matrix_from_sorted_csc(c, M_total, N_total, nrec, c.ws_e.as<uint64_t>(), 0, c.ws_f.as<uint64_t>());
-    c.row_lo = row_lo; c.row_hi = row_hi;
+    finish_matrix_from_sorted_csc(c, M_total, N_total, nrec, c.ws_e.as<uint64_t>(), 0, c.ws_f.as<uint64_t>(), row_lo, row_hi);
 }
 
 }  // namespace elba

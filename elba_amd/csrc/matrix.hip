@@ -144,6 +144,12 @@ __global__ void k_narrow_u32(const uint64_t *in, uint64_t n, uint32_t *out)
 // in column-address order, plus the diagonal's (count, min s, max s) per row.  The numeric kernel then runs ONE product per lane:
 // no per-entry loops over mostly empty column positions, no cross-lane compaction, no tail for long columns (any UPPER).
 // It still gathers every partner entry (read id, position) from the columns: nothing of B is precomputed.
+//
+// B is symmetric up to swapping each seed's two positions: the canonical seeds of (i,j) are the lexicographic min/max of
+// (kid, pos in i, pos in j) over a CROSS product of positions per shared k-mer, so min/max of (kid, pos in j, pos in i) is the same
+// pair of products with its positions exchanged — exactly, not approximately.  With `half` the schedule therefore lists a pair only
+// on its smaller row (partner j > i); partners outside the row window [lo, hi) of a multi-GPU shard are listed in full (their own
+// rows live on another rank).  The SpGEMM mirrors the surviving in-window pairs into the partner's row (spgemm.hip: k_mirror).
 __device__ __forceinline__ void desc_fields(uint64_t x, bool packed, uint32_t index_in_row, uint32_t &addr, uint32_t &len, uint32_t &rank)
 {
     addr = (uint32_t)(x >> 32);
@@ -153,12 +159,12 @@ __device__ __forceinline__ void desc_fields(uint64_t x, bool packed, uint32_t in
 
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_products(const uint32_t *rowptr, const uint64_t *csrx, const uint64_t *cscp, uint32_t M, bool packed, uint32_t fbits,
-                                                  uint32_t *cnt, uint32_t *diag, const uint64_t *prodptr, uint64_t *prod)
+                                                  uint32_t *cnt, uint32_t *diag, const uint64_t *prodptr, uint64_t *prod, uint32_t lo, uint32_t hi, bool half)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t i = wave; i < M; i += nwaves) {
+    for (uint32_t i = lo + wave; i < hi; i += nwaves) {             // rows outside the window keep an empty schedule
         const uint32_t rs = rowptr[i], re = rowptr[i + 1];
         uint32_t total = 0, dn = 0, dmin = 0xFFFFFFFFu, dmax = 0;
         uint64_t out = FILL ? prodptr[i] : 0;
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256) void k_products(const uint32_t *rowptr, const 
                 for (uint32_t f = 0; f < len; ++f) {
                     const uint32_t j = (uint32_t)(cscp[addr + f] >> 32), s = (rank << fbits) | f;
                     if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
-                    else ++mine;
+                    else if (!half || j > i || j < lo) ++mine;          // (j >= hi implies j > i)
                 }
             }
             uint32_t incl = mine;
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void k_products(const uint32_t *rowptr, const 
                 uint64_t w = out + incl - mine;
                 for (uint32_t f = 0; f < len; ++f) {
                     const uint32_t j = (uint32_t)(cscp[addr + f] >> 32);
-                    if (j != i) prod[w++] = ((uint64_t)(addr + f) << 32) | ((rank << fbits) | f);
+                    if (j != i && (!half || j > i || j < lo)) prod[w++] = ((uint64_t)(addr + f) << 32) | ((rank << fbits) | f);
                 }
             }
             const uint32_t chunk = __shfl(incl, 63, 64);
@@ -276,12 +282,17 @@ static void build_product_schedule(Ctx &c)
     uint32_t *cnt = c.ws_e.as<uint32_t>();
     const uint64_t *cols = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
     c.Pnd = 0;
+    c.half = !getenv("ELBA_NO_SYMMETRY");
+    c.a_roworder.reserve((size_t)(M + 1) * 4);
     if (M == 0) return;
-    int nb = (int)((M + 3) / 4);
+    const uint32_t lo = (uint32_t)c.row_lo, hi = (uint32_t)(c.row_hi < 0 ? M : c.row_hi);
+    int nb = (int)((hi - lo + 3) / 4);
     if (nb > c.num_cus * 8) nb = c.num_cus * 8;
+    if (nb < 1) nb = 1;
     ELBA_HIP(hipMemsetAsync(cnt, 0, (size_t)(M + 2) * 4, s));
+    ELBA_HIP(hipMemsetAsync(c.a_diag.p, 0, (size_t)(M + 1) * 12, s));
     hipLaunchKernelGGL((k_products<false>), dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csrx.as<uint64_t>(), cols, (uint32_t)M, c.hot_packed, c.fbits,
-                       cnt, c.a_diag.as<uint32_t>(), (const uint64_t *)nullptr, (uint64_t *)nullptr);
+                       cnt, c.a_diag.as<uint32_t>(), (const uint64_t *)nullptr, (uint64_t *)nullptr, lo, hi, c.half);
     exclusive_scan_u32_to_i64(s, cnt, c.a_prodptr.as<int64_t>(), M + 1, c.ws_scan);
     int64_t total = 0;
     ELBA_HIP(hipMemcpyAsync(&total, c.a_prodptr.as<int64_t>() + M, 8, hipMemcpyDeviceToHost, s));
@@ -289,13 +300,21 @@ static void build_product_schedule(Ctx &c)
     c.Pnd = total;
     c.a_prod.reserve((size_t)(total + 1) * 8);
     hipLaunchKernelGGL((k_products<true>), dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csrx.as<uint64_t>(), cols, (uint32_t)M, c.hot_packed, c.fbits,
-                       (uint32_t *)nullptr, (uint32_t *)nullptr, c.a_prodptr.as<uint64_t>(), c.a_prod.as<uint64_t>());
+                       (uint32_t *)nullptr, (uint32_t *)nullptr, c.a_prodptr.as<uint64_t>(), c.a_prod.as<uint64_t>(), lo, hi, c.half);
+    // rows by descending scheduled work: the SpGEMM queues them in this order so that a workgroup's static share of a tier
+    // mixes heavy rows first and light rows last (longest-processing-time order: short tail)
+    c.ws_a.reserve((size_t)(M + 1) * 8); c.ws_b.reserve((size_t)(M + 1) * 8); c.ws_c.reserve((size_t)(M + 1) * 8); c.ws_d.reserve((size_t)(M + 1) * 8);
+    const unsigned nbM = (unsigned)((M + 255) / 256);
+    hipLaunchKernelGGL(k_roworder_keys, dim3(nbM), dim3(256), 0, s, cnt, (uint64_t)M, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
+    int wr = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), M, 0, 32, c.ws_sort);
+    hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>(), (uint64_t)M, c.a_roworder.as<uint32_t>());
     ELBA_HIP(hipStreamSynchronize(s));
 }
 
 // Input: Z entries sorted by (kid, read, pos): kid_keys[z] >> kid_shift = kid, csc[z] = read<<32|pos (device, in c.a_csc or elsewhere).
 // Produces c.a_colptr, c.a_csc (copy if csc is not already c.a_csc), c.a_rowptr, c.a_csr, max_row_nnz, max_col_nnz.
-void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, const uint64_t *kid_keys, int kid_shift, const uint64_t *csc)
+// [win_lo, win_hi) = the rows of B this context computes (win_hi < 0: all); the product schedule is laid out for those rows only.
+void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, const uint64_t *kid_keys, int kid_shift, const uint64_t *csc, int64_t win_lo, int64_t win_hi)
 {
     hipStream_t s = c.stream;
     c.M = M; c.N = N; c.Z = Z;
@@ -326,17 +345,8 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         if (nb > c.num_cus * 8) nb = c.num_cus * 8;
         hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_csrx.as<uint64_t>(), c.a_dec.as<uint64_t>());
     }
-    // rows by descending product count: the SpGEMM queues them in this order so that a workgroup's static share of a tier
-    // mixes heavy rows first and light rows last (longest-processing-time order: short tail)
-    c.a_roworder.reserve((size_t)(M + 1) * 4);
-    if (M > 0) {
-        c.ws_a.reserve((size_t)(M + 1) * 8); c.ws_b.reserve((size_t)(M + 1) * 8); c.ws_c.reserve((size_t)(M + 1) * 8); c.ws_d.reserve((size_t)(M + 1) * 8);
-        const unsigned nbM = (unsigned)((M + 255) / 256);
-        hipLaunchKernelGGL(k_roworder_keys, dim3(nbM), dim3(256), 0, s, c.a_rowprod.as<uint32_t>(), (uint64_t)M, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
-        int wr = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), M, 0, 32, c.ws_sort);
-        hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>(), (uint64_t)M, c.a_roworder.as<uint32_t>());
-    }
-    c.row_lo = 0; c.row_hi = -1;
+    ELBA_REQUIRE(win_lo >= 0 && (win_hi < 0 || (win_lo <= win_hi && win_hi <= M)), ELBA_ERR_INVALID_ARG, "bad row window");
+    c.row_lo = win_lo; c.row_hi = win_hi;
     c.b_cap_entries = 0; c.ov_tiers_known = false; c.ov_class_valid = false;
     c.ov_prior_q16 = 0;            // a new matrix: forget the partner/product ratio measured on the previous one
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);

@@ -92,25 +92,6 @@ void scan_rec(hipStream_t s, const Tin *in, Tout *out, int64_t n, uint64_t *tmp)
     hipLaunchKernelGGL((k_scan_apply<Tin, Tout>), dim3((unsigned)nb), dim3(SCAN_THREADS), 0, s, in, out, (const uint64_t *)sums, n);
 }
 
-constexpr int64_t ONEBLOCK_MAX = 1 << 18;
-
-// exclusive scan of up to 2^18 u32 counts by ONE workgroup of 1024 lanes: each lane owns a contiguous slice
-__global__ __launch_bounds__(1024) void k_scan_one_block(const uint32_t *in, int64_t *out, int64_t n)
-{
-    __shared__ uint64_t wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int64_t per = (n + 1023) / 1024, lo = (int64_t)tid * per, hi = lo + per < n ? lo + per : n;
-    uint64_t s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += in[i];
-    const uint64_t inc = wave_inclusive_scan(s);
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    uint64_t base = 0;
-    for (int i = 0; i < w; ++i) base += wsum[i];
-    uint64_t run = base + inc - s;
-    for (int64_t i = lo; i < hi; ++i) { const uint32_t v = in[i]; out[i] = (int64_t)run; run += v; }
-}
-
 size_t scan_tmp_elems(int64_t n)
 {
     size_t tot = 0;
@@ -240,10 +221,6 @@ void exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, int64_
 
 void exclusive_scan_u32_to_i64(hipStream_t s, const uint32_t *in, int64_t *out, int64_t n, DevBuf &tmp)
 {
-    if (false && n > 0 && n <= ONEBLOCK_MAX) {   // measured: not faster than the three coalesced launches (strided per-lane slices)      // one 1024-thread workgroup: one launch instead of three for the row pointers of <= 256 K rows
-        hipLaunchKernelGGL(k_scan_one_block, dim3(1), dim3(1024), 0, s, in, out, n);
-        return;
-    }
     tmp.reserve(scan_tmp_elems(n) * sizeof(uint64_t));
     scan_rec<uint32_t, int64_t>(s, in, out, n, tmp.as<uint64_t>());
 }

@@ -64,6 +64,11 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned long long phase[12];          // diagnostic (cfg.flags & 16): shader-clock cycles per kernel phase, summed over workgroups
 };
 
+// One staged or mirrored entry of B: 32 bytes, 32-byte aligned, moved as two 16-byte words — a scattered record is one full
+// sector (20-byte seeds at a 20-byte stride straddle sectors and make every scattered store a partial write).
+//   a = (partner read, mirror ticket or ~0, q0, t0)   b = (q1, t1, numshared, 0)
+struct alignas(32) StageRec { uint4 a, b; };
+
 struct OvParams {
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_csrx; const uint64_t *a_cscp; const uint32_t *a_roworder;
     const uint64_t *a_prodptr; const uint64_t *a_prod; const uint32_t *a_diag; const uint64_t *a_dec;   // per-row product schedule (matrix.hip)
@@ -72,16 +77,18 @@ struct OvParams {
     uint32_t Mcols;          // number of reads overall (partner id range)
     uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
+    uint32_t half;           // 1: the schedule lists an in-window pair on its smaller row only; survivors are mirrored into the partner's row
     uint32_t tier_limit[NUM_LDS_TIERS];   // claimed slots at which a row abandons the tier: min(3T/4, T - 2*BLOCK) - 1 (two claims per lane can be in flight)
     uint32_t use_feedback;   // 1 on the first call for a matrix (no measured prior yet): in-call self-correction through the hot fb_* sums
     uint32_t prior_q16;      // distinct-partners / products estimate in 1/65536 units (1/16 before anything is known; measured by the previous call afterwards)
     uint32_t dbg;            // diagnostic ablations (cfg.flags): 1 = gathers only (no accumulator updates), 2 = accumulator only (synthetic partners)
-    uint32_t *row_cnt;       // [M+1]
+    uint32_t *row_cnt;       // [M+1] entries the row staged itself (partners it was scheduled with + diagonal)
+    uint32_t *low_cnt;       // [M+1] zero at entry: mirrored entries per row; its returning atomic hands every mirrored entry its slot
     unsigned long long *row_off;   // [M]
     uint32_t *lists;         // [NUM_TIERS][M]
     uint32_t *fin_lists;     // [2][M]
     OvCounters *ctr;
-    uint32_t *tmp_col; elba_seed_t *tmp_val; unsigned long long tmp_cap;
+    StageRec *tmp; unsigned long long tmp_cap;
     uint32_t *gtable; unsigned long long gstride;   // HBM spill tables: per block 4*gstride u32
 };
 
@@ -111,10 +118,11 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
         // rows are visited in descending-work order (a_roworder); a row window (multi-GPU shard) filters by row id
         const uint32_t i = idx < p.M ? p.a_roworder[idx] : 0xFFFFFFFFu;
         int mytier = -1;
-        const uint32_t ub = (i >= p.row_lo && i < p.row_hi) ? p.a_rowprod[i] : 0;   // empty rows: row_cnt was zeroed by the host
-        if (ub != 0) {
-        prod += ub;
-        cap += ub < p.Mcols ? ub : p.Mcols;
+        const uint32_t full = (i >= p.row_lo && i < p.row_hi) ? p.a_rowprod[i] : 0;   // empty rows: row_cnt was zeroed by the host
+        if (full != 0) {
+        const uint32_t ub = (uint32_t)(p.a_prodptr[i + 1] - p.a_prodptr[i]);        // scheduled products (the diagonal and, with `half`, mirrored pairs are not)
+        prod += full;
+        cap += (ub < p.Mcols ? ub : p.Mcols) + 1;
         const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
         // optimistic estimate of distinct partners = products x prior (1/16 at first: measured 0.06 on 15 %-error reads, far less on
         // accurate ones; afterwards the ratio the previous call measured, x 1.25), at least 128.  A wrong guess costs an abandoned
@@ -148,17 +156,113 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
 // ---- numeric -----------------------------------------------------------------------------------------------------
 #include "spgemm_rows.hpp"
 
-// ---- finalize: per-row column sort + move to final CSR ------------------------------------------------------------
+// ---- finalize: row pointers, mirror, per-row column sort + move to final CSR --------------------------------------------
+// A row's entries come from two places: mirrored ones scattered by k_mirror (mir, laid out like B: the first low_cnt
+// positions of the row's extent) and the ones it staged itself (tmp at row_off, row_cnt of them).
 struct FinParams {
-    const uint32_t *row_cnt; const unsigned long long *row_off; const int64_t *b_rowptr;
-    const uint32_t *tmp_col; const elba_seed_t *tmp_val;
+    const uint32_t *row_cnt; uint32_t *low_cnt; const unsigned long long *row_off; int64_t *b_rowptr;
+    const StageRec *tmp; StageRec *mir;
     uint32_t *b_col; elba_seed_t *b_val;
-    uint32_t M, row_lo, row_hi;
-    const uint32_t *fin_lists; const OvCounters *ctr;
+    uint32_t M, row_lo, row_hi, half;
+    uint32_t *fin_lists; OvCounters *ctr;
     uint64_t *sortkeys; unsigned long long sort_stride;
+    uint32_t *sum_tmp;
     long long b_cap;         // capacity of b_col / b_val in entries: rows that would not fit are left out (the host regrows and reruns)
 };
 
+__device__ __forceinline__ const StageRec *fin_rec(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t)
+{
+    return t < low ? &p.mir[dst + t] : &p.tmp[off + (t - low)];
+}
+__device__ __forceinline__ elba_seed_t rec_seed(const uint4 a, const uint4 b)
+{
+    elba_seed_t v;
+    v.q0 = a.z; v.t0 = a.w; v.q1 = b.x; v.t1 = b.y; v.numshared = (int32_t)b.z;
+    return v;
+}
+
+// Row pointers of B = exclusive scan of (staged + mirrored) counts, M+1 outputs, in ONE launch for up to 2^17 rows: every
+// workgroup sums the counts before its tile itself (L2-resident, a few hundred loads per lane at most) instead of waiting for
+// a second and third launch.
+constexpr int RP_TILE = 1024;
+__global__ __launch_bounds__(256) void k_row_pointers(FinParams p)
+{
+    __shared__ unsigned long long wsum[4], bsum;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t n = p.M + 1, t0 = blockIdx.x * RP_TILE;
+    unsigned long long pre = 0;
+    {   // t0 is a multiple of 1024: 16-byte loads, 8 in flight per lane
+        const uint4 *ca = reinterpret_cast<const uint4 *>(p.row_cnt), *cb = reinterpret_cast<const uint4 *>(p.low_cnt);
+#pragma unroll 4
+        for (uint32_t q = tid; q < t0 / 4; q += 256) {
+            const uint4 x = ca[q], z = cb[q];
+            pre += (unsigned long long)x.x + x.y + x.z + x.w + z.x + z.y + z.z + z.w;
+        }
+    }
+    uint32_t v[4];
+    unsigned long long mine = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t e = t0 + tid * 4 + u;
+        v[u] = e < p.M ? p.row_cnt[e] + p.low_cnt[e] : 0u;
+        mine += v[u];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) pre += __shfl_xor(pre, d, 64);
+    unsigned long long inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    if (tid == 0) bsum = 0;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&bsum, pre);
+    __syncthreads();
+    unsigned long long run = bsum + inc - mine;
+    for (uint32_t k = 0; k < w; ++k) run += wsum[k];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const uint32_t e = t0 + tid * 4 + u;
+        if (e < n) p.b_rowptr[e] = (int64_t)run;
+        run += v[u];
+    }
+}
+
+__global__ void k_sum_counts(FinParams p)
+{
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e <= p.M) p.sum_tmp[e] = e < p.M ? p.row_cnt[e] + p.low_cnt[e] : 0u;
+}
+
+// Mirror pass: every staged entry (i,j) whose partner row j is computed here as well is the transpose's entry (j,i) with the two
+// positions of each seed exchanged (see matrix.hip, above k_products).  Its slot inside row j's extent is the ticket the numeric
+// kernel drew from low_cnt[j]; the extent is known now (b_rowptr).  One wavefront per row; rows too wide for the one-wave sort
+// are queued for the block sorts here (their final length is only known after the scan).
+__global__ __launch_bounds__(256) void k_mirror(FinParams p)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
+        const uint32_t own = p.row_cnt[i];
+        const unsigned long long off = p.row_off[i];
+        const uint32_t y = own + p.low_cnt[i];
+        if (lane == 0 && y > FIN_WAVE_MAX) {
+            const int which = y > FIN_LDS_MAX ? 1 : 0;
+            const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
+            p.fin_lists[(size_t)which * p.M + at] = i;
+        }
+        if (!p.half) continue;
+        for (uint32_t t = lane; t < own; t += 64) {
+            const uint4 a = p.tmp[off + t].a;
+            if (a.y == 0xFFFFFFFFu) continue;
+            const uint4 b = p.tmp[off + t].b;
+            const int64_t at = p.b_rowptr[a.x] + (int64_t)a.y;
+            if (at >= p.b_cap) continue;
+            p.mir[at].a = make_uint4(i, 0xFFFFFFFFu, a.w, a.z);
+            p.mir[at].b = make_uint4(b.y, b.x, b.z, 0u);
+        }
+    }
+}
 
 // rows with <= FIN_WAVE_MAX entries: one wavefront per row; the row's columns are staged in LDS and every lane ranks its
 // (up to 4) elements against all of them — columns are distinct, so ranks are a permutation
@@ -169,17 +273,25 @@ __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
-        const uint32_t y = p.row_cnt[i];
-        if (y == 0 || y > FIN_WAVE_MAX) continue;
-        const unsigned long long off = p.row_off[i];
         const int64_t dst = p.b_rowptr[i];
+        const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
+        const uint32_t low = p.low_cnt[i];
+        if (lane == 0 && low) p.low_cnt[i] = 0;          // the ticket counters are handed back clean (k_mirror, the only other reader, has finished)
+        if (y == 0 || y > FIN_WAVE_MAX) continue;
         if (dst + (int64_t)y > p.b_cap) continue;
+        const unsigned long long off = p.row_off[i];
         uint32_t mine[4];
+        uint4 ra[4], rb[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t t = (uint32_t)lane + 64u * u;
-            mine[u] = t < y ? p.tmp_col[off + t] : 0xFFFFFFFFu;
-            if (t < y) cols[w][t] = mine[u];
+            mine[u] = 0xFFFFFFFFu;
+            if (t < y) {
+                const StageRec *r = fin_rec(p, low, off, dst, t);
+                ra[u] = r->a; rb[u] = r->b;
+                mine[u] = ra[u].x;
+                cols[w][t] = mine[u];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -192,7 +304,7 @@ __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t t = (uint32_t)lane + 64u * u;
-            if (t < y) { p.b_col[dst + rank[u]] = mine[u]; p.b_val[dst + rank[u]] = p.tmp_val[off + t]; }
+            if (t < y) { p.b_col[dst + rank[u]] = mine[u]; p.b_val[dst + rank[u]] = rec_seed(ra[u], rb[u]); }
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -225,21 +337,23 @@ __global__ __launch_bounds__(256) void k_finalize_block(FinParams p)
     const uint32_t n = p.ctr->fin_count[which];
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
         const uint32_t i = p.fin_lists[(size_t)which * p.M + it];
-        const uint32_t y = p.row_cnt[i];
         uint64_t *keys = GLOBAL ? p.sortkeys + (size_t)blockIdx.x * p.sort_stride : lkeys;
-        const unsigned long long off = p.row_off[i];
         const int64_t dst = p.b_rowptr[i];
+        const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
         if (dst + (int64_t)y > p.b_cap) continue;
+        const uint32_t low = y - p.row_cnt[i];          // (low_cnt itself may already have been handed back by k_finalize_wave)
+        const unsigned long long off = p.row_off[i];
         uint32_t n2 = 1;
         while (n2 < y) n2 <<= 1;
         for (uint32_t t = threadIdx.x; t < n2; t += 256)
-            keys[t] = t < y ? (((uint64_t)p.tmp_col[off + t] << 32) | t) : ~0ull;
+            keys[t] = t < y ? (((uint64_t)fin_rec(p, low, off, dst, t)->a.x << 32) | t) : ~0ull;
         __syncthreads();
         bitonic_sort<256>(keys, n2);
         for (uint32_t t = threadIdx.x; t < y; t += 256) {
             const uint64_t k = keys[t];
             p.b_col[dst + t] = (uint32_t)(k >> 32);
-            p.b_val[dst + t] = p.tmp_val[off + (uint32_t)k];
+            const StageRec *r = fin_rec(p, low, off, dst, (uint32_t)k);
+            p.b_val[dst + t] = rec_seed(r->a, r->b);
         }
         __syncthreads();
     }
@@ -282,7 +396,7 @@ void stage_create_seed_matrix(Ctx &c)
     while (gstride < 2ull * (uint64_t)(M > 1 ? M : 1)) gstride <<= 1;
     c.ov_gtable.reserve((size_t)spill_blocks * 5 * gstride * 4);
 
-    if (c.ov_tmp_cap == 0 && c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / 24;
+    if (c.ov_tmp_cap == 0 && c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
 
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
@@ -290,6 +404,7 @@ void stage_create_seed_matrix(Ctx &c)
     p.a_prodptr = c.a_prodptr.as<uint64_t>(); p.a_prod = c.a_prod.as<uint64_t>(); p.a_diag = c.a_diag.as<uint32_t>(); p.a_dec = c.a_dec.as<uint64_t>();
     p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>(); p.packed = c.hot_packed ? 1u : 0u;
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
+    p.half = c.half ? 1u : 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob)
@@ -302,6 +417,9 @@ void stage_create_seed_matrix(Ctx &c)
         }
     }
     p.row_cnt = c.ov_rowcnt.as<uint32_t>();
+    if (c.ov_totcnt.cap < (size_t)(M + 2) * 4) c.ov_low_clean = false;
+    c.ov_totcnt.reserve((size_t)(M + 2) * 4);
+    p.low_cnt = c.ov_totcnt.as<uint32_t>();
     p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
     p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
     p.ctr = c.ov_counters.as<OvCounters>();
@@ -328,6 +446,9 @@ void stage_create_seed_matrix(Ctx &c)
         // memsets and a kernel).  Rows rewrite their own row_cnt entry every call; empty rows keep the zero they were given once.
         const bool cached = c.ov_class_valid && c.ov_class_prior == p.prior_q16 && c.ov_class_lo == row_lo && c.ov_class_hi == row_hi && c.ov_class_b0 == b0 && c.b_cap_entries > 0;
         c.t_a.start(s);
+        // the ticket counters come back clean from a call that ran to its end (k_finalize_wave); otherwise zero them here
+        if (!c.ov_low_clean) ELBA_HIP(hipMemsetAsync(c.ov_totcnt.p, 0, (size_t)(M + 2) * 4, s));
+        c.ov_low_clean = false;
         if (cached) {
             ELBA_HIP(hipMemcpyAsync(c.ov_counters.p, c.ov_counters_snap.p, sizeof(OvCounters), hipMemcpyDeviceToDevice, s));
         } else {
@@ -350,13 +471,12 @@ void stage_create_seed_matrix(Ctx &c)
             size_t free_b = 0, total_b = 0;
             ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
             int64_t want = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;   // + one open chunk per workgroup
-            int64_t budget = (int64_t)(free_b / 2 / 24);
+            int64_t budget = (int64_t)(free_b / 2 / sizeof(StageRec));
             c.ov_tmp_cap = want < budget ? want : budget;
             if (c.ov_tmp_cap < 1024) c.ov_tmp_cap = 1024;
         }
-        c.ov_tmp_col.reserve((size_t)c.ov_tmp_cap * 4);
-        c.ov_tmp_val.reserve((size_t)c.ov_tmp_cap * sizeof(elba_seed_t));
-        p.tmp_col = c.ov_tmp_col.as<uint32_t>(); p.tmp_val = c.ov_tmp_val.as<elba_seed_t>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
+        c.ov_tmp.reserve((size_t)c.ov_tmp_cap * sizeof(StageRec));
+        p.tmp = c.ov_tmp.as<StageRec>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
 
         c.t_b.start(s);
         const bool diag = c.cfg.flags != 0;
@@ -403,14 +523,16 @@ void stage_create_seed_matrix(Ctx &c)
         }
         c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
         c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
+        if (c.half) {
+            c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * sizeof(StageRec));
+        }
 
         // row pointers, per-row column sort + move to the final arrays
         c.t_c.start(s);
-        exclusive_scan_u32_to_i64(s, c.ov_rowcnt.as<uint32_t>(), c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
-        if (nrows > 0) {
+        {
             FinParams f{};
-            f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
-            f.tmp_col = p.tmp_col; f.tmp_val = p.tmp_val; f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
+            f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = p.tmp; f.mir = c.ov_mir.as<StageRec>(); f.half = p.half; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
+            f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
             f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
             f.b_cap = c.b_cap_entries;
             const int gblocks = 32;
@@ -418,8 +540,18 @@ void stage_create_seed_matrix(Ctx &c)
             while (sstride < (uint64_t)M) sstride <<= 1;
             c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
             f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
+            if (M + 1 <= (1 << 17)) {
+                hipLaunchKernelGGL(k_row_pointers, dim3((unsigned)((M + 1 + RP_TILE - 1) / RP_TILE)), dim3(256), 0, s, f);
+            } else {
+                c.ov_sum_tmp.reserve((size_t)(M + 2) * 4);
+                f.sum_tmp = c.ov_sum_tmp.as<uint32_t>();
+                hipLaunchKernelGGL(k_sum_counts, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, s, f);
+                exclusive_scan_u32_to_i64(s, f.sum_tmp, c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
+            }
+          if (nrows > 0) {
             int nb = (int)((nrows + 3) / 4);
             if (nb > cus * 32) nb = cus * 32;      // one row per wavefront where possible: the pass is latency-bound per row
+            hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
             hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
             // the wide-row sorts read their queues' lengths on the device: launched unconditionally (empty queues cost a few us)
             skipped_sorts = 0;
@@ -427,6 +559,7 @@ void stage_create_seed_matrix(Ctx &c)
             else skipped_sorts |= 1u;
             if (!fast || c.ov_sort_used[1]) hipLaunchKernelGGL((k_finalize_block<true>), dim3(gblocks), dim3(256), 0, s, f);
             else skipped_sorts |= 2u;
+          }
         }
         c.t_c.stop(s);
         c.t_total.stop(s);
@@ -447,6 +580,7 @@ void stage_create_seed_matrix(Ctx &c)
                 continue;
             }
         }
+        c.ov_low_clean = true;
         break;
     }
 

@@ -72,13 +72,8 @@ struct Table {
     }
 };
 
-// two adjacent column entries in one 16-byte global load; columns start on 8-byte boundaries only, hence aligned(8)
-struct __attribute__((packed, aligned(8))) pair64 { uint64_t lo, hi; };
-
 constexpr int PK = 4;      // products per lane in flight (schedule items -> gathers -> accumulator)
 constexpr uint64_t NOITEM = ~0ull;
-constexpr int GRP = 2;     // entries whose column gathers are in flight together (4 spills SGPRs and needs 136 VGPRs)
-constexpr int SPEC = 8;    // column entries gathered unconditionally per entry; longer columns (UPPER > 8) take a serial tail loop
 
 // s = canonical rank of the row entry << fbits | index inside the column.  a_dec[rs + rank] holds the entry's position in the read
 // and the address of its column in a_cscp (still warm in L2: the numeric loop has just gathered it): two loads on two levels per seed
@@ -99,22 +94,6 @@ __device__ __forceinline__ void lds_barrier()
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// inclusive prefix sum over the 64 lanes with DPP moves (row_shr 1/2/4/8 inside each row of 16, row_bcast 15/31 across rows)
-__device__ __forceinline__ uint32_t wave_inclusive_scan_dpp(uint32_t x)
-{
-    int v = (int)x;
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);    // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);    // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);    // row_bcast:15 -> rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);    // row_bcast:31 -> rows 2 and 3
-    return (uint32_t)v;
-}
-
-// descriptor fields (see matrix.hip: build_hot_format)
-__device__ __forceinline__ uint32_t desc_len(const OvParams &p, uint64_t x) { return p.packed ? ((uint32_t)x & 255u) : (uint32_t)x; }
-
 // DIAG = true compiles the diagnostic ablations and the phase clock in (cfg.flags != 0); the production instantiation carries none of it
 template <int BLOCK, bool GLOBAL, bool DIAG>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uint32_t lds_tbits)
@@ -129,7 +108,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
     const uint32_t fmask = (1u << p.fbits) - 1;
     // per-workgroup state kept in registers across the rows of this persistent loop (flushed once at the end)
-    unsigned long long chunk_off = 0, acc_yraw = 0, acc_y = 0;
+    unsigned long long chunk_off = 0, acc_yraw = 0, acc_y = 0, acc_mir = 0;
     uint32_t chunk_left = 0, acc_done = 0, acc_ndiag = 0;
     unsigned long long acc_nup = 0;
     uint32_t acc_mx = 0;
@@ -153,7 +132,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         const uint32_t rs = p.a_rowptr[i];
         const uint64_t ps = p.a_prodptr[i], pe = p.a_prodptr[i + 1];
         const uint32_t dg_n = p.a_diag[3 * i], dg_min = p.a_diag[3 * i + 1], dg_max = p.a_diag[3 * i + 2];   // diagonal of B(i,i): structure of A
-        const uint32_t ub_i = p.a_rowprod[i];
+        const uint32_t ub_i = (uint32_t)(pe - ps);           // scheduled products: bounds the row's distinct partners
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
             // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
@@ -274,7 +253,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         for (uint32_t b0 = 0; b0 < T; b0 += BLOCK) {                       // wave-uniform trip count: ballots are safe
             const uint32_t s0 = b0 + tid;
             bool keep = false;
-            if (s0 < T && tab.ld(tab.keys, s0) != EMPTY) { ++yraw; keep = tab.ld(tab.cnt, s0) >= 2; }
+            if (s0 < T) {
+                const uint32_t j = tab.ld(tab.keys, s0);
+                // a pair whose partner row is computed here too (half schedule) stands for both (i,j) and (j,i)
+                if (j != EMPTY) { yraw += (p.half && j >= p.row_lo && j < p.row_hi) ? 2u : 1u; keep = tab.ld(tab.cnt, s0) >= 2; }
+            }
             const uint64_t bal = __ballot(keep);
             if (bal == 0) continue;
             uint32_t at = 0;
@@ -306,11 +289,6 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             acc_y += ytot;
             if (!GLOBAL) { fb_c += misc[9]; fb_u += ub_i; ++fb_n; }
             if (p.use_feedback && fb_n >= 8) { atomicAdd(&p.ctr->fb_claims, fb_c); atomicAdd(&p.ctr->fb_ub, fb_u); tot_c += fb_c; tot_u += fb_u; fb_c = 0; fb_u = 0; fb_n = 0; }
-            if (ytot > FIN_WAVE_MAX) {                         // rows too wide for the one-wave column sort
-                const int which = ytot > FIN_LDS_MAX ? 1 : 0;
-                const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
-                p.fin_lists[(size_t)which * p.M + at] = i;
-            }
         }
         lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
@@ -318,7 +296,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             // ---- level 4: all survivors decode their seeds in parallel ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
             const uint32_t ysurv = misc[3];
-            uint32_t nup = 0, mx = 0;
+            uint32_t nup = 0, mx = 0, nmir = 0;
             // the diagonal entry (its count / min / max come with A) is decoded in the same pass, by the lane after the last survivor
             const uint32_t hasd = misc[0] >= 2 ? 1u : 0u;
             for (uint32_t t = tid; t < ysurv + hasd; t += BLOCK) {
@@ -327,13 +305,17 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                     const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : list[t];
                     j = tab.ld(tab.keys, s0); n = tab.ld(tab.cnt, s0); a = tab.ld(tab.smin, s0); b = tab.ld(tab.smax, s0);
                 }
+                // the partner's row gets the mirrored entry: draw its slot there now (the round trip overlaps the decode's loads);
+                // k_mirror places it once the row pointers are known
+                uint32_t tick = 0xFFFFFFFFu;
+                if (p.half && j != i && j >= p.row_lo && j < p.row_hi) { tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir; }
                 const elba_seed_t v = decode_seed(p, rs, a, b, n, fmask);
-                p.tmp_col[off + t] = j;
-                p.tmp_val[off + t] = v;
+                p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
+                p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);
                 if (j > i) ++nup;
                 mx = n > mx ? n : mx;
             }
-            acc_nup += nup;
+            acc_nup += nup; acc_mir += nmir;
             acc_mx = mx > acc_mx ? mx : acc_mx;
         }
         lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
@@ -347,10 +329,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
 #undef ELBA_STAMP
     // flush the workgroup's statistics: a handful of atomics per workgroup instead of six per row
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { acc_nup += __shfl_xor(acc_nup, d, 64); uint32_t o = __shfl_xor(acc_mx, d, 64); acc_mx = o > acc_mx ? o : acc_mx; }
+    for (int d = 32; d >= 1; d >>= 1) { acc_nup += __shfl_xor(acc_nup, d, 64); acc_mir += __shfl_xor(acc_mir, d, 64); uint32_t o = __shfl_xor(acc_mx, d, 64); acc_mx = o > acc_mx ? o : acc_mx; }
     OvShard *sh = &p.ctr->shard[blockIdx.x & (NUM_SHARDS - 1)];
     if (lane == 0) {
         if (acc_nup) atomicAdd(&sh->nupper, acc_nup);
+        if (acc_mir) atomicAdd(&sh->nnz, acc_mir);
         if (acc_mx) atomicMax(&sh->maxshared, acc_mx);
     }
     if (tid == 0) {
