@@ -67,6 +67,16 @@ struct EventTimer {
     ~EventTimer() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
 };
 
+// Phase marks of one call on one stream: N events, one record per phase boundary (every record costs stream time — the overlap
+// SpGEMM's whole call is a few hundred microseconds, so boundaries are shared instead of bracketing every phase with its own pair)
+template <int N>
+struct PhaseMarks {
+    hipEvent_t e[N] = {};
+    void mark(int k, hipStream_t s) { if (!e[k]) ELBA_HIP(hipEventCreate(&e[k])); ELBA_HIP(hipEventRecord(e[k], s)); }
+    float ms(int from, int to) { float t = 0; ELBA_HIP(hipEventSynchronize(e[to])); ELBA_HIP(hipEventElapsedTime(&t, e[from], e[to])); return t; }
+    ~PhaseMarks() { for (int k = 0; k < N; ++k) if (e[k]) (void)hipEventDestroy(e[k]); }
+};
+
 // ---- primitives (prims.hip) -------------------------------------------------------------------------------------
 // Exclusive prefix sums; in and out may alias.  tmp is grown as needed.
 void exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, int64_t n, DevBuf &tmp);
@@ -154,6 +164,9 @@ struct Ctx {
     uint32_t ov_prior_q16 = 0;      // distinct-partner / product ratio measured by the previous overlap call (x 65536), 0 = unknown
 
     EventTimer t_total, t_a, t_b, t_c;
+    struct PinnedHost { void *p = nullptr; size_t cap = 0; void reserve(size_t n) { if (n <= cap) return; if (p) (void)hipHostFree(p); p = nullptr; cap = 0; ELBA_HIP(hipHostMalloc(&p, n, hipHostMallocDefault)); cap = n; } ~PinnedHost() { if (p) (void)hipHostFree(p); } };
+    PinnedHost ov_host;            // pinned landing area of the per-call counter read-back (a pageable target makes the copy a staged, blocking one)
+    PhaseMarks<5> ov_marks;        // overlap SpGEMM: 0 call start, 1 numeric start, 2 numeric end, 3 call end, 4 finalize start when the host synchronised before it
 };
 
 // ---- stages -----------------------------------------------------------------------------------------------------

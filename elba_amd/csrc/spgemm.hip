@@ -434,18 +434,20 @@ void stage_create_seed_matrix(Ctx &c)
 
     const int cus = c.num_cus;
     const int64_t nrows = row_hi - row_lo;
-    OvCounters hc{};
+    c.ov_host.reserve(sizeof(OvCounters));
+    OvCounters &hc = *static_cast<OvCounters *>(c.ov_host.p);
+    hc = OvCounters{};
     uint32_t skipped_tiers = 0, skipped_sorts = 0;
     int passes = 0;
     float ms_sym = 0, ms_num = 0;
-    c.t_total.start(s);
+    float ms_fin = 0, ms_tot = 0;
     for (;;) {
         ++passes;
         // The queues of the tiers depend only on A, the prior and the row window: in the steady state they are reused and the counter
         // block is restored from the snapshot taken right after the last classification (one 1.4 KB device copy instead of two
         // memsets and a kernel).  Rows rewrite their own row_cnt entry every call; empty rows keep the zero they were given once.
         const bool cached = c.ov_class_valid && c.ov_class_prior == p.prior_q16 && c.ov_class_lo == row_lo && c.ov_class_hi == row_hi && c.ov_class_b0 == b0 && c.b_cap_entries > 0;
-        c.t_a.start(s);
+        c.ov_marks.mark(0, s);
         // the ticket counters come back clean from a call that ran to its end (k_finalize_wave); otherwise zero them here
         if (!c.ov_low_clean) ELBA_HIP(hipMemsetAsync(c.ov_totcnt.p, 0, (size_t)(M + 2) * 4, s));
         c.ov_low_clean = false;
@@ -463,7 +465,6 @@ void stage_create_seed_matrix(Ctx &c)
             ELBA_HIP(hipMemcpyAsync(c.ov_counters_snap.p, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToDevice, s));
             c.ov_class_valid = true; c.ov_class_prior = p.prior_q16; c.ov_class_lo = row_lo; c.ov_class_hi = row_hi; c.ov_class_b0 = b0;
         }
-        c.t_a.stop(s);
         if (c.ov_tmp_cap == 0) {
             // first call on this context: size the staging area from the bound that can never overflow (one sync)
             ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
@@ -478,7 +479,7 @@ void stage_create_seed_matrix(Ctx &c)
         c.ov_tmp.reserve((size_t)c.ov_tmp_cap * sizeof(StageRec));
         p.tmp = c.ov_tmp.as<StageRec>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
 
-        c.t_b.start(s);
+        c.ov_marks.mark(1, s);
         const bool diag = c.cfg.flags != 0;
 #define ELBA_LAUNCH_ROWS(B, G, grid, lds, tier, tb)                                                                          \
     do {                                                                                                            \
@@ -503,7 +504,7 @@ void stage_create_seed_matrix(Ctx &c)
             ELBA_TIER(4, ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u));
             ELBA_HIP(hipGetLastError());
         }
-        c.t_b.stop(s);
+        c.ov_marks.mark(2, s);
         // Steady state (staging and output capacities known from an earlier call on this matrix): no host round trip between the
         // numeric kernels and the finalize pass — everything is queued, ONE synchronisation at the end, and the rare surprises
         // (staging overflow, more output than last time) are repaired afterwards.  First call: synchronise here to size the output.
@@ -511,8 +512,9 @@ void stage_create_seed_matrix(Ctx &c)
         if (!fast) {
             ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
             ELBA_HIP(hipStreamSynchronize(s));
-            ms_sym += c.t_a.ms(); ms_num += c.t_b.ms();
+            ms_sym += c.ov_marks.ms(0, 1); ms_num += c.ov_marks.ms(1, 2);
             if (hc.overflow) {
+                ms_tot += c.ov_marks.ms(0, 2);
                 ELBA_REQUIRE(passes < 3, ELBA_ERR_INTERNAL, "overlap staging area overflowed twice");
                 c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;      // the bound that cannot overflow
                 continue;
@@ -528,7 +530,7 @@ void stage_create_seed_matrix(Ctx &c)
         }
 
         // row pointers, per-row column sort + move to the final arrays
-        c.t_c.start(s);
+        if (!fast) c.ov_marks.mark(4, s);
         {
             FinParams f{};
             f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = p.tmp; f.mir = c.ov_mir.as<StageRec>(); f.half = p.half; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
@@ -561,12 +563,11 @@ void stage_create_seed_matrix(Ctx &c)
             else skipped_sorts |= 2u;
           }
         }
-        c.t_c.stop(s);
-        c.t_total.stop(s);
+        c.ov_marks.mark(3, s);
         if (fast) ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
         ELBA_HIP(hipStreamSynchronize(s));
         if (fast) {
-            ms_sym += c.t_a.ms(); ms_num += c.t_b.ms();
+            ms_sym += c.ov_marks.ms(0, 1); ms_num += c.ov_marks.ms(1, 2);
             int64_t y = 0;
             for (int sh = 0; sh < NUM_SHARDS; ++sh) y += (int64_t)hc.shard[sh].nnz;
             bool missed = false;
@@ -576,10 +577,12 @@ void stage_create_seed_matrix(Ctx &c)
                 ELBA_REQUIRE(passes < 4, ELBA_ERR_INTERNAL, "overlap output did not settle");
                 if (hc.overflow) c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;
                 c.b_cap_entries = 0; c.ov_class_valid = false;
-                c.t_total.start(s);
+                ms_tot += c.ov_marks.ms(0, 3);
                 continue;
             }
         }
+        ms_fin = c.ov_marks.ms(fast ? 2 : 4, 3);
+        ms_tot += c.ov_marks.ms(0, 3);
         c.ov_low_clean = true;
         break;
     }
@@ -618,10 +621,10 @@ void stage_create_seed_matrix(Ctx &c)
     st.rows_escalated = queued - st.rows_lds - st.rows_global;
     st.algorithmic_bytes = 16 * Z + 8 * (2 * M + N + 3) + 24 * Y;
     st.passes = passes;
-    st.ms_total = c.t_total.ms();
+    st.ms_total = ms_tot;
     st.ms_symbolic = ms_sym;
     st.ms_numeric = ms_num;
-    st.ms_finalize = c.t_c.ms();
+    st.ms_finalize = ms_fin;
     c.Y = Y;
     c.ostats = st;
     c.have_B = true;
