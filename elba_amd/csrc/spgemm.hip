@@ -490,7 +490,7 @@ void stage_create_seed_matrix(Ctx &c)
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
             const size_t X = 128;  // misc words
-            const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 12;    // resident capacity: 10.4 KB LDS and 70 VGPRs per 128-thread workgroup -> 14 per CU
+            const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 10;    // resident capacity: 96 VGPRs -> 5 waves per SIMD = 10 two-wave workgroups per CU (LDS would allow 14)
             // Tiers that received no row in the previous call on this matrix are not launched (an empty launch still costs ~5 us of
             // stream time); should a row reach one of them after all, the call is repeated with every tier (checked after the sync).
             const bool all_tiers = !c.ov_tiers_known || c.b_cap_entries == 0;

@@ -87,6 +87,10 @@ __device__ __forceinline__ elba_seed_t decode_seed(const OvParams &p, uint32_t r
     return v;
 }
 
+// workgroup-uniform values belong in scalar registers
+__device__ __forceinline__ uint32_t sfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t sfirst64(uint64_t v) { return ((uint64_t)sfirst((uint32_t)(v >> 32)) << 32) | sfirst((uint32_t)v); }
+
 // workgroup barrier that orders LDS only: global stores of this row (staging, row_cnt/row_off) may still be in flight — nobody in
 // the workgroup reads them back, and __syncthreads() would wait for their acknowledgement (a full memory round trip per row)
 __device__ __forceinline__ void lds_barrier()
@@ -123,16 +127,54 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     unsigned long long tot_c = 0, tot_u = 0;    // already pushed to the hot sums (first call only)
     unsigned long long gu = 0, gc = 0;
 
-    uint32_t i_next = blockIdx.x < nrows ? p.lists[(size_t)tier * p.M + blockIdx.x] : 0u;
+    // ---- software pipeline ACROSS rows -------------------------------------------------------------------------------------------
+    // A row costs ~6 dependent memory round trips (id -> bounds -> schedule items -> partner entries ... -> seed decoding, 2 levels)
+    // and only ~12 rows per CU are in flight, so the row loop is latency-bound.  The next row's bounds are therefore loaded while
+    // this row accumulates, its first PK schedule items while this row's table is swept, and their partner entries while this row's
+    // seeds are decoded: a row whose schedule fits one group (PK x BLOCK products — most rows) meets no memory wait before its
+    // table is complete.  `itc` / `ce` are free between the accumulate loop and the end of the row and carry the prefetch.
+    struct RowHdr { uint32_t i, rs, dg_n, dg_min, dg_max; uint64_t ps, pe; };
+    auto load_hdr = [&](uint32_t i) {
+        RowHdr h;
+        i = sfirst(i);
+        h.i = i; h.rs = sfirst(p.a_rowptr[i]); h.ps = sfirst64(p.a_prodptr[i]); h.pe = sfirst64(p.a_prodptr[i + 1]);
+        h.dg_n = sfirst(p.a_diag[3 * i]); h.dg_min = sfirst(p.a_diag[3 * i + 1]); h.dg_max = sfirst(p.a_diag[3 * i + 2]);   // diagonal of B(i,i): structure of A
+        return h;
+    };
+    uint64_t itc[PK], ce[PK];
+    auto load_items = [&](uint64_t from, uint64_t pe) {       // item = address of the partner's column entry << 32 | s  (matrix.hip: k_products)
+#pragma unroll
+        for (int k = 0; k < PK; ++k) {
+            const uint64_t idx = from + (uint64_t)k * BLOCK + tid;
+            itc[k] = idx < pe ? p.a_prod[idx] : NOITEM;
+        }
+    };
+    auto gather = [&]() {
+#pragma unroll
+        for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[itc[k] != NOITEM ? (uint32_t)(itc[k] >> 32) : 0u];
+        if (DIAG && (dbg & 2u)) {                                   // ablation: no gathers, synthetic partner ids
+#pragma unroll
+            for (int k = 0; k < PK; ++k) ce[k] = (uint64_t)(((uint32_t)(itc[k] >> 32) * 2654435761u) % p.Mcols) << 32;
+        }
+    };
+    const uint32_t *queue = p.lists + (size_t)tier * p.M;
+    RowHdr cur{}, nxt{};
+    uint32_t id_n = 0;
+    if (blockIdx.x < nrows) {
+        cur = load_hdr(queue[blockIdx.x]);
+        if (blockIdx.x + gridDim.x < nrows) id_n = queue[blockIdx.x + gridDim.x];
+        load_items(cur.ps, cur.pe);
+        gather();
+    }
     for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
-        // the row id of the NEXT iteration is fetched now; this row's bounds and product count are loaded together, up front:
-        // one memory round trip instead of three dependent ones on the row's critical path
-        const uint32_t i = i_next;
-        if (it + gridDim.x < nrows) i_next = p.lists[(size_t)tier * p.M + it + gridDim.x];
-        const uint32_t rs = p.a_rowptr[i];
-        const uint64_t ps = p.a_prodptr[i], pe = p.a_prodptr[i + 1];
-        const uint32_t dg_n = p.a_diag[3 * i], dg_min = p.a_diag[3 * i + 1], dg_max = p.a_diag[3 * i + 2];   // diagonal of B(i,i): structure of A
+        const bool has_n = it + gridDim.x < nrows;
+        if (has_n) nxt = load_hdr(id_n);                                        // bounds of the next row; id of the one after it
+        const uint32_t id_nn = (unsigned long long)it + 2ull * gridDim.x < nrows ? queue[it + 2 * gridDim.x] : 0u;
+        const uint32_t i = cur.i, rs = cur.rs;
+        const uint64_t ps = cur.ps, pe = cur.pe;
         const uint32_t ub_i = (uint32_t)(pe - ps);           // scheduled products: bounds the row's distinct partners
+        // leaves this row early: the next row's prefetch is issued back to back
+#define ELBA_NEXT_ROW() do { if (has_n) { load_items(nxt.ps, nxt.pe); gather(); } cur = nxt; id_n = id_nn; } while (0)
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
             // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
@@ -160,6 +202,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                         const uint32_t at = atomicAdd(&p.ctr->tier_count[t2], 1u);
                         p.lists[(size_t)t2 * p.M + at] = i;
                     }
+                    ELBA_NEXT_ROW();
                     continue;
                 }
             }
@@ -183,29 +226,18 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         const uint32_t T = tab.size();
         ELBA_STAMP(0);
         for (uint32_t s = tid; s < T; s += BLOCK) { tab.keys[s] = EMPTY; tab.cnt[s] = 0; tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
-        if (tid < 16) misc[tid] = tid == 0 ? dg_n : (tid == 1 ? dg_min : (tid == 2 ? dg_max : 0u));
-        __syncthreads();
+        if (tid < 16) misc[tid] = tid == 0 ? cur.dg_n : (tid == 1 ? cur.dg_min : (tid == 2 ? cur.dg_max : 0u));
+        // (the LDS tiers use barriers that order LDS only: prefetched loads stay in flight across them; the spill tier's table is
+        //  global memory and keeps full barriers)
+        if (GLOBAL) __syncthreads(); else lds_barrier();
         ELBA_STAMP(1);
 
         // ---- accumulate: the row's product schedule, ONE non-diagonal product per lane and slot ----
-        // item = address of the partner's column entry << 32 | s  (matrix.hip: k_products).  PK items per lane are in flight: their
-        // gathers are issued together, the next PK items are prefetched, then the accumulator is updated two products at a time.
+        // The first group's items and partner entries are already in registers or in flight (prefetched during the previous row).  Per
+        // group: the next PK items are requested, the accumulator is updated two products at a time, then the next gathers are issued.
         bool full = false;
-        uint64_t itc[PK];
-#pragma unroll
-        for (int k = 0; k < PK; ++k) {
-            const uint64_t idx = ps + (uint64_t)k * BLOCK + tid;
-            itc[k] = idx < pe ? p.a_prod[idx] : NOITEM;
-        }
 #pragma unroll 1
         for (uint64_t t0 = ps; t0 < pe; t0 += (uint64_t)PK * BLOCK) {
-            uint64_t ce[PK];
-#pragma unroll
-            for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[itc[k] != NOITEM ? (uint32_t)(itc[k] >> 32) : 0u];
-            if (DIAG && (dbg & 2u)) {                                   // ablation: no gathers, synthetic partner ids
-#pragma unroll
-                for (int k = 0; k < PK; ++k) ce[k] = (uint64_t)(((uint32_t)(itc[k] >> 32) * 2654435761u) % p.Mcols) << 32;
-            }
             uint64_t itn[PK];
 #pragma unroll
             for (int k = 0; k < PK; ++k) {
@@ -226,14 +258,17 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 }
             }
             ELBA_STAMP(8);
-#pragma unroll
-            for (int k = 0; k < PK; ++k) itc[k] = itn[k];
             if (tab.abandoned()) {
                 if (tid == 0) { const uint64_t done = t0 + (uint64_t)PK * BLOCK - ps; misc[11] = (uint32_t)(done < pe - ps ? done : pe - ps); }
                 break;
             }
+            if (t0 + (uint64_t)PK * BLOCK < pe) {
+#pragma unroll
+                for (int k = 0; k < PK; ++k) itc[k] = itn[k];
+                gather();
+            }
         }
-        __syncthreads();
+        if (GLOBAL) __syncthreads(); else lds_barrier();
         ELBA_STAMP(2);
         if (tab.abandoned()) {
             // the optimistic table was too small: hand the row to the next tier (its kernel starts after this one ends)
@@ -245,8 +280,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 fb_c += (unsigned long long)misc[9] * all / done; fb_u += ub_i; ++fb_n;
             }
             __syncthreads();
+            ELBA_NEXT_ROW();
             continue;
         }
+        if (has_n) load_items(nxt.ps, nxt.pe);       // next row, first group: in flight during the sweep
 
         // ---- level 3: one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
@@ -267,7 +304,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         yraw = wave_sum_u32(yraw);
         if (lane == 0 && yraw) atomicAdd(&misc[5], yraw);
-        __syncthreads();
+        if (GLOBAL) __syncthreads(); else lds_barrier();
         ELBA_STAMP(3);
         if (tid == 0) {
             const uint32_t dcount = misc[0];
@@ -292,6 +329,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
+        if (has_n) gather();    // next row, first group's partner entries: in flight during the decode
         if (misc[8]) {
             // ---- level 4: all survivors decode their seeds in parallel ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
@@ -319,8 +357,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             acc_mx = mx > acc_mx ? mx : acc_mx;
         }
         lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
+        cur = nxt; id_n = id_nn;
         ELBA_STAMP(5);
     }
+#undef ELBA_NEXT_ROW
     if (stamp && tid == 0) {
 #pragma unroll
         for (int k = 0; k < 10; ++k) atomicAdd(&p.ctr->phase[k], ph[k]);
