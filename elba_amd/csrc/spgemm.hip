@@ -409,7 +409,7 @@ void stage_create_seed_matrix(Ctx &c)
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob)
     {
-        const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : 128), 128u, 256u, 256u};
+        const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : 128), (uint32_t)(getenv("ELBA_B1") ? atoi(getenv("ELBA_B1")) : 256), 256u, 256u};
         for (int t = 0; t < NUM_LDS_TIERS; ++t) {
             const uint32_t T = 1u << (LDS_TBITS0 + t);
             const uint32_t lim = std::min((T >> 2) * 3, T - 2 * blk[t]);
@@ -498,7 +498,8 @@ void stage_create_seed_matrix(Ctx &c)
 #define ELBA_TIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
             if (b0 == 64) ELBA_TIER(0, ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)20 * 512 + X, 0, 9u));
             else ELBA_TIER(0, ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)20 * 512 + X, 0, 9u));
-            ELBA_TIER(1, ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)20 * 1024 + X, 1, 10u));
+            if (!getenv("ELBA_B1") || atoi(getenv("ELBA_B1")) == 256) ELBA_TIER(1, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)20 * 1024 + X, 1, 10u));
+            else ELBA_TIER(1, ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)20 * 1024 + X, 1, 10u));
             ELBA_TIER(2, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)20 * 2048 + X, 2, 11u));
             ELBA_TIER(3, ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)20 * 4096 + X, 3, 12u));
             ELBA_TIER(4, ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u));

@@ -57,7 +57,19 @@ struct Table {
             if (!da) { if (ka == j0 || ka == EMPTY) { da = true; claimed += ka == EMPTY; } else a = (a + 1) & mask; }
             if (!db) { if (kb == j1 || kb == EMPTY) { db = true; claimed += kb == EMPTY; } else b = (b + 1) & mask; }
         }
-        if (!GLOBAL && claimed) { if (atomicAdd(&misc[9], claimed) + claimed > limit) { __hip_atomic_store(&misc[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); full = true; } }
+        if (!GLOBAL) {
+            // claims are counted per wavefront: two ballots, one LDS atomic by the first claiming lane (left to the compiler, a
+            // uniform-address atomic with per-lane values becomes a serial loop over the active lanes)
+            const uint64_t b1 = __ballot(claimed != 0), b2 = __ballot(claimed == 2);
+            if (b1 != 0) {
+                const uint32_t total = (uint32_t)__popcll(b1) + (uint32_t)__popcll(b2);
+                const uint32_t first = (uint32_t)__builtin_ctzll(b1);
+                uint32_t old = 0;
+                if ((threadIdx.x & 63u) == first) old = atomicAdd(&misc[9], total);
+                old = (uint32_t)__builtin_amdgcn_readlane((int)old, (int)first);
+                if (old + total > limit) { if ((threadIdx.x & 63u) == first) __hip_atomic_store(&misc[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); full = true; }
+            }
+        }
         atomicAdd(&cnt[a], 1u); atomicMin(&smin[a], s0); atomicMax(&smax[a], s0);
         if (two) { atomicAdd(&cnt[b], 1u); atomicMin(&smin[b], s1); atomicMax(&smax[b], s1); }
     }
