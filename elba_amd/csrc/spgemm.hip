@@ -329,19 +329,82 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *keys, uint32_t n2)
     }
 }
 
-template <bool GLOBAL>
-__global__ __launch_bounds__(256) void k_finalize_block(FinParams p)
+// Rows of 257..4096 entries: one workgroup per row, bucket + rank sort in LDS.  Partner ids are spread evenly over [0, M), so the row
+// is cut into ~y/8 equal column ranges: count per bucket, scan, scatter the keys into their buckets, then every element ranks itself
+// inside its bucket (~8 compares).  ~100 instructions per element and 4 barriers per row, against ~45 barrier-separated compare-exchange
+// stages of a bitonic network (this pass was 44 % of the step on the 200 k-read workload, whose rows average 490 entries).  A skewed row
+// (all partners in one range) degrades to a rank sort, never to a wrong result.
+constexpr uint32_t FIN_BUCKETS = 512;
+__global__ __launch_bounds__(256) void k_finalize_bucket(FinParams p)
 {
-    __shared__ uint64_t lkeys[GLOBAL ? 1 : FIN_LDS_MAX];
-    const int which = GLOBAL ? 1 : 0;
-    const uint32_t n = p.ctr->fin_count[which];
+    __shared__ uint64_t lkeys[FIN_LDS_MAX];
+    __shared__ uint32_t bstart[FIN_BUCKETS], bfill[FIN_BUCKETS];
+    __shared__ unsigned long long scale_s;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint32_t n = p.ctr->fin_count[0];
     for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
-        const uint32_t i = p.fin_lists[(size_t)which * p.M + it];
-        uint64_t *keys = GLOBAL ? p.sortkeys + (size_t)blockIdx.x * p.sort_stride : lkeys;
+        const uint32_t i = p.fin_lists[it];
         const int64_t dst = p.b_rowptr[i];
         const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
         if (dst + (int64_t)y > p.b_cap) continue;
         const uint32_t low = y - p.row_cnt[i];          // (low_cnt itself may already have been handed back by k_finalize_wave)
+        const unsigned long long off = p.row_off[i];
+        uint32_t nb = y / 8;
+        nb = nb < 1 ? 1u : (nb > FIN_BUCKETS ? FIN_BUCKETS : nb);
+        // bucket(col) = col * nb / M without a division per element: col * floor(nb * 2^32 / M) >> 32  (monotone in col, < nb)
+        if (tid == 0) scale_s = ((unsigned long long)nb << 32) / (p.M > 0 ? p.M : 1u);
+        for (uint32_t b = tid; b < FIN_BUCKETS; b += 256) { bstart[b] = 0; bfill[b] = 0; }
+        __syncthreads();
+        const unsigned long long scale = scale_s;
+        for (uint32_t t = tid; t < y; t += 256) {
+            const uint32_t col = fin_rec(p, low, off, dst, t)->a.x;
+            atomicAdd(&bstart[(uint32_t)(((unsigned long long)col * scale) >> 32)], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                                    // exclusive scan of <= 512 bucket counts by one wavefront: 8 buckets per lane
+            uint32_t c[8], sum = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { c[u] = bstart[lane * 8 + u]; sum += c[u]; }
+            uint32_t inc = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+            uint32_t run = inc - sum;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { bstart[lane * 8 + u] = run; run += c[u]; }
+        }
+        __syncthreads();
+        for (uint32_t t = tid; t < y; t += 256) {
+            const uint32_t col = fin_rec(p, low, off, dst, t)->a.x;
+            const uint32_t b = (uint32_t)(((unsigned long long)col * scale) >> 32);
+            lkeys[bstart[b] + atomicAdd(&bfill[b], 1u)] = ((uint64_t)col << 32) | t;
+        }
+        __syncthreads();
+        for (uint32_t e = tid; e < y; e += 256) {
+            const uint64_t k = lkeys[e];
+            const uint32_t col = (uint32_t)(k >> 32);
+            const uint32_t b = (uint32_t)(((unsigned long long)col * scale) >> 32);
+            const uint32_t lo = bstart[b], hi = lo + bfill[b];
+            uint32_t rank = 0;
+            for (uint32_t x = lo; x < hi; ++x) rank += lkeys[x] < k ? 1u : 0u;
+            const StageRec *r = fin_rec(p, low, off, dst, (uint32_t)k);
+            p.b_col[dst + lo + rank] = col;
+            p.b_val[dst + lo + rank] = rec_seed(r->a, r->b);
+        }
+        __syncthreads();
+    }
+}
+
+// Rows beyond 4096 entries: bitonic sort of (column << 32 | source index) keys in an HBM scratch slab, one workgroup per row.
+__global__ __launch_bounds__(256) void k_finalize_huge(FinParams p)
+{
+    const uint32_t n = p.ctr->fin_count[1];
+    for (uint32_t it = blockIdx.x; it < n; it += gridDim.x) {
+        const uint32_t i = p.fin_lists[(size_t)p.M + it];
+        uint64_t *keys = p.sortkeys + (size_t)blockIdx.x * p.sort_stride;
+        const int64_t dst = p.b_rowptr[i];
+        const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
+        if (dst + (int64_t)y > p.b_cap) continue;
+        const uint32_t low = y - p.row_cnt[i];
         const unsigned long long off = p.row_off[i];
         uint32_t n2 = 1;
         while (n2 < y) n2 <<= 1;
@@ -558,14 +621,15 @@ void stage_create_seed_matrix(Ctx &c)
             hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
             // the wide-row sorts read their queues' lengths on the device: launched unconditionally (empty queues cost a few us)
             skipped_sorts = 0;
-            if (!fast || c.ov_sort_used[0]) hipLaunchKernelGGL((k_finalize_block<false>), dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
+            if (!fast || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
             else skipped_sorts |= 1u;
-            if (!fast || c.ov_sort_used[1]) hipLaunchKernelGGL((k_finalize_block<true>), dim3(gblocks), dim3(256), 0, s, f);
+            if (!fast || c.ov_sort_used[1]) hipLaunchKernelGGL(k_finalize_huge, dim3(gblocks), dim3(256), 0, s, f);
             else skipped_sorts |= 2u;
           }
         }
         c.ov_marks.mark(3, s);
-        if (fast) ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
+        // (also on the synchronising path: the wide-row sort queues are filled by k_mirror, after the first read-back)
+        ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
         ELBA_HIP(hipStreamSynchronize(s));
         if (fast) {
             ms_sym += c.ov_marks.ms(0, 1); ms_num += c.ov_marks.ms(1, 2);
@@ -575,6 +639,8 @@ void stage_create_seed_matrix(Ctx &c)
             for (int t = 0; t < NUM_TIERS; ++t) missed |= ((skipped_tiers >> t) & 1u) && hc.tier_count[t] > 0;
             missed |= ((skipped_sorts & 1u) && hc.fin_count[0] > 0) || ((skipped_sorts & 2u) && hc.fin_count[1] > 0);
             if (hc.overflow || y > c.b_cap_entries || missed) {     // a surprise: fall back to the synchronising path and redo the call
+                if (getenv("ELBA_TRACE")) fprintf(stderr, "[elba] overlap call repeated: overflow=%u y=%lld cap=%lld missed=%d skipped_tiers=%x skipped_sorts=%x tier_count=%u,%u,%u,%u,%u fin=%u,%u cursor=%llu tmp_cap=%lld\n",
+                                                  hc.overflow, (long long)y, (long long)c.b_cap_entries, (int)missed, skipped_tiers, skipped_sorts, hc.tier_count[0], hc.tier_count[1], hc.tier_count[2], hc.tier_count[3], hc.tier_count[4], hc.fin_count[0], hc.fin_count[1], hc.cursor, (long long)c.ov_tmp_cap);
                 ELBA_REQUIRE(passes < 4, ELBA_ERR_INTERNAL, "overlap output did not settle");
                 if (hc.overflow) c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;
                 c.b_cap_entries = 0; c.ov_class_valid = false;
@@ -606,7 +672,11 @@ void stage_create_seed_matrix(Ctx &c)
     }
     if (hc.fb_ub > 0) {   // remember the measured distinct/products ratio (+25 %) for the next call's starting tiers
         double r = 1.25 * (double)hc.fb_claims / (double)hc.fb_ub * 65536.0;
-        c.ov_prior_q16 = r < 64.0 ? 64u : (r > 65536.0 ? 65536u : (uint32_t)r);
+        const uint32_t q = r < 64.0 ? 64u : (r > 65536.0 ? 65536u : (uint32_t)r);
+        // keep the prior (and with it the cached tier queues) unless the measurement moved by more than 10 %: rows that escalate
+        // in one call and not in the next make the ratio wobble in its last digits
+        const uint32_t old = c.ov_prior_q16;
+        if (old == 0 || q > old + old / 10 || q + old / 10 < old) c.ov_prior_q16 = q;
     }
     st.products = (int64_t)hc.products;
     st.nnz_before_prune = (int64_t)hc.yraw;
