@@ -29,7 +29,7 @@ namespace elba {
 namespace {
 
 constexpr uint32_t EMPTY = 0xFFFFFFFFu;
-constexpr int NUM_LDS_TIERS = 4;                // 512, 1024, 2048, 4096 slots (20 B per slot incl. the survivor list)
+constexpr int NUM_LDS_TIERS = 5;                // 512, 1024, 2048, 4096, 8192 slots (18 B per slot incl. the 16-bit survivor list)
 constexpr int NUM_TIERS = NUM_LDS_TIERS + 1;    // + HBM spill
 constexpr int LDS_TBITS0 = 9;
 constexpr uint32_t STAGE_CHUNK = 1024;          // staging entries a workgroup draws from the global cursor at a time
@@ -454,9 +454,12 @@ void stage_create_seed_matrix(Ctx &c)
     c.b_rowptr.reserve((size_t)(M + 2) * 8);
 
     // HBM spill tables: one per resident workgroup of the spill kernel
-    const int spill_blocks = 64;
     uint64_t gstride = 2;
     while (gstride < 2ull * (uint64_t)(M > 1 ? M : 1)) gstride <<= 1;
+    // as many spill rows in flight as 4 GiB of tables allow (20 B per slot), between 64 and two per CU: a spill row initialises and
+    // sweeps a table of up to 2M slots, so the tier is bound by rows in flight
+    int spill_blocks = (int)((4ull << 30) / (20ull * gstride));
+    spill_blocks = spill_blocks < 64 ? 64 : (spill_blocks > c.num_cus * 2 ? c.num_cus * 2 : spill_blocks);
     c.ov_gtable.reserve((size_t)spill_blocks * 5 * gstride * 4);
 
     if (c.ov_tmp_cap == 0 && c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
@@ -472,7 +475,7 @@ void stage_create_seed_matrix(Ctx &c)
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob)
     {
-        const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : 128), (uint32_t)(getenv("ELBA_B1") ? atoi(getenv("ELBA_B1")) : 256), 256u, 256u};
+        const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : 128), (uint32_t)(getenv("ELBA_B1") ? atoi(getenv("ELBA_B1")) : 256), 256u, 256u, 512u};
         for (int t = 0; t < NUM_LDS_TIERS; ++t) {
             const uint32_t T = 1u << (LDS_TBITS0 + t);
             const uint32_t lim = std::min((T >> 2) * 3, T - 2 * blk[t]);
@@ -492,6 +495,8 @@ void stage_create_seed_matrix(Ctx &c)
     if (!attr_done) {
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<512, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<512, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
 
@@ -559,13 +564,14 @@ void stage_create_seed_matrix(Ctx &c)
             const bool all_tiers = !c.ov_tiers_known || c.b_cap_entries == 0;
             skipped_tiers = 0;
 #define ELBA_TIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
-            if (b0 == 64) ELBA_TIER(0, ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)20 * 512 + X, 0, 9u));
-            else ELBA_TIER(0, ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)20 * 512 + X, 0, 9u));
-            if (!getenv("ELBA_B1") || atoi(getenv("ELBA_B1")) == 256) ELBA_TIER(1, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)20 * 1024 + X, 1, 10u));
-            else ELBA_TIER(1, ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)20 * 1024 + X, 1, 10u));
-            ELBA_TIER(2, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)20 * 2048 + X, 2, 11u));
-            ELBA_TIER(3, ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)20 * 4096 + X, 3, 12u));
-            ELBA_TIER(4, ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u));
+            if (b0 == 64) ELBA_TIER(0, ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
+            else ELBA_TIER(0, ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
+            if (!getenv("ELBA_B1") || atoi(getenv("ELBA_B1")) == 256) ELBA_TIER(1, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)18 * 1024 + X, 1, 10u));
+            else ELBA_TIER(1, ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)18 * 1024 + X, 1, 10u));
+            ELBA_TIER(2, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)18 * 2048 + X, 2, 11u));
+            ELBA_TIER(3, ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)18 * 4096 + X, 3, 12u));
+            ELBA_TIER(4, ELBA_LAUNCH_ROWS(512, false, cus, (size_t)18 * 8192 + X, 4, 13u));
+            ELBA_TIER(5, ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u));
             ELBA_HIP(hipGetLastError());
         }
         c.ov_marks.mark(2, s);

@@ -116,8 +116,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
 {
     const uint32_t dbg = DIAG ? p.dbg : 0u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    // LDS tiers: keys | cnt | smin | smax | survivor list (u32 each, T entries) | misc;  spill tier: only misc lives in LDS
-    uint32_t *misc = GLOBAL ? smem : smem + (size_t)5 * (1u << lds_tbits);
+    // LDS tiers: keys | cnt | smin | smax (u32 each, T entries) | survivor list (u16: T <= 8192) | misc  = 18 B per slot, so that an
+    // 8192-slot table still fits the 160 KB of a CU;  spill tier: only misc lives in LDS
+    uint32_t *misc = GLOBAL ? smem : smem + (size_t)4 * (1u << lds_tbits) + ((size_t)1 << lds_tbits) / 2;
     // per-wave product queue: 64 lanes x SPEC products, partner id and sequence number
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1;
@@ -221,7 +222,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         Table<GLOBAL> tab;
         tab.misc = misc;
-        uint32_t *list;
+        uint32_t *list = nullptr;
+        uint16_t *list16 = nullptr;
         if (GLOBAL) {
             tab.tbits = guaranteed_tbits(ub_i, p.Mcols);
             tab.limit = 0xFFFFFFFFu;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             const uint32_t T = 1u << lds_tbits;
             tab.limit = p.tier_limit[tier];          // abandon point: at most limit + 2*BLOCK slots are ever claimed, < T
             tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
-            list = smem + 4 * T;
+            list16 = reinterpret_cast<uint16_t *>(smem + 4 * T);
         }
         const uint32_t T = tab.size();
         ELBA_STAMP(0);
@@ -312,7 +314,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             uint32_t at = 0;
             if (lane == 0) at = atomicAdd(&misc[3], (uint32_t)__popcll(bal));
             at = __shfl(at, 0, 64) + (uint32_t)__popcll(bal & lt);
-            if (keep) list[at] = s0;
+            if (keep) { if (GLOBAL) list[at] = s0; else list16[at] = (uint16_t)s0; }
         }
         yraw = wave_sum_u32(yraw);
         if (lane == 0 && yraw) atomicAdd(&misc[5], yraw);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             for (uint32_t t = tid; t < ysurv + hasd; t += BLOCK) {
                 uint32_t j = i, n = misc[0], a = misc[1], b = misc[2];
                 if (t < ysurv) {
-                    const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : list[t];
+                    const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)list16[t];
                     j = tab.ld(tab.keys, s0); n = tab.ld(tab.cnt, s0); a = tab.ld(tab.smin, s0); b = tab.ld(tab.smax, s0);
                 }
                 // the partner's row gets the mirrored entry: draw its slot there now (the round trip overlaps the decode's loads);
