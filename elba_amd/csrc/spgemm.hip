@@ -78,7 +78,7 @@ struct OvParams {
     uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
     uint32_t half;           // 1: the schedule lists an in-window pair on its smaller row only; survivors are mirrored into the partner's row
-    uint32_t tier_limit[NUM_LDS_TIERS];   // claimed slots at which a row abandons the tier: min(3T/4, T - 2*BLOCK) - 1 (two claims per lane can be in flight)
+    uint32_t tier_limit[NUM_LDS_TIERS];   // claimed slots at which a row abandons the tier: min(3T/4, T - BLOCK) - 1 (every lane can overshoot by one claim)
     uint32_t use_feedback;   // 1 on the first call for a matrix (no measured prior yet): in-call self-correction through the hot fb_* sums
     uint32_t prior_q16;      // distinct-partners / products estimate in 1/65536 units (1/16 before anything is known; measured by the previous call afterwards)
     uint32_t dbg;            // diagnostic ablations (cfg.flags): 1 = gathers only (no accumulator updates), 2 = accumulator only (synthetic partners)
@@ -478,7 +478,7 @@ void stage_create_seed_matrix(Ctx &c)
         const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : 128), (uint32_t)(getenv("ELBA_B1") ? atoi(getenv("ELBA_B1")) : 256), 256u, 256u, 512u};
         for (int t = 0; t < NUM_LDS_TIERS; ++t) {
             const uint32_t T = 1u << (LDS_TBITS0 + t);
-            const uint32_t lim = std::min((T >> 2) * 3, T - 2 * blk[t]);
+            const uint32_t lim = std::min((T >> 2) * 3, T - blk[t]);      // a lane overshoots by at most one claim (Table::insert_lds)
             p.tier_limit[t] = lim - 1;
         }
     }
