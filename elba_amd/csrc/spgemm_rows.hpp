@@ -45,45 +45,58 @@ struct Table {
     // LDS tables: the probe loop is hand-scheduled.  The kernel is bound by instruction issue (profiles/r01_notes.md) and the compiler's
     // rendering of a divergent compare-and-swap loop spends most of its instructions on exec-mask bookkeeping (~25 per probe round,
     // ~12 here): lanes leave the loop by dropping out of exec, which is restored at the end.
-    __device__ __forceinline__ void insert_lds(uint32_t j, uint32_t s, bool &full) const
+    // `full` is WAVE-UNIFORM here (a scalar): once the claim counter has reached the limit every further claim of any lane returns a
+    // value >= limit, so each wave notices within the insert in which it claims next — at most one claim per lane beyond the limit,
+    // hence limit <= T - BLOCK — and a uniform flag costs a scalar branch where a per-lane one costs ten mask instructions per insert.
+    __device__ __forceinline__ void insert_lds(uint32_t j, uint32_t s, bool valid, bool &full) const
     {
         if (full) return;
         uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
-        uint32_t claimed = 0, old, addr;
+        uint32_t claimed = 0, old, addr = 0;
         unsigned long long save, t;
         const uint32_t base = (uint32_t)(uintptr_t)keys;        // LDS byte offset (a local address is the low half of its flat form)
         const uint32_t mask = size() - 1, empty = EMPTY;
-        asm volatile(
-            "s_mov_b64 %[save], exec\n"
-            ".Lprobe%=:\n\t"
-            "v_lshl_add_u32 %[addr], %[slot], 2, %[base]\n\t"
-            "ds_cmpst_rtn_b32 %[old], %[addr], %[empty], %[j]\n\t"
-            "s_waitcnt lgkmcnt(0)\n\t"
-            "v_cmp_eq_u32_e64 %[t], %[old], %[empty]\n\t"
-            "v_cndmask_b32_e64 %[cl], %[cl], 1, %[t]\n\t"
-            "v_cmp_eq_u32_e32 vcc, %[old], %[j]\n\t"
-            "s_or_b64 vcc, vcc, %[t]\n\t"
-            "s_andn2_b64 exec, exec, vcc\n\t"
-            "s_cbranch_execz .Ldone%=\n\t"
-            "v_add_u32_e32 %[slot], 1, %[slot]\n\t"
-            "v_and_b32_e32 %[slot], %[mask], %[slot]\n\t"
-            "s_branch .Lprobe%=\n"
-            ".Ldone%=:\n\t"
-            "s_mov_b64 exec, %[save]\n"
-            : [save] "=&s"(save), [addr] "=&v"(addr), [old] "=&v"(old), [t] "=&s"(t), [cl] "+v"(claimed), [slot] "+v"(slot)
-            : [base] "s"(base), [empty] "v"(empty), [j] "v"(j), [mask] "s"(mask)
-            : "vcc", "memory");
-        if (claimed) {
-            // every claiming lane adds for itself (same-address LDS atomics serialise in the LDS unit, one cycle each; left to the compiler
-            // this becomes a scalar loop over the claiming lanes): a lane can overshoot the limit by one claim, hence limit <= T - BLOCK
-            uint32_t prev;
-            const uint32_t a9 = (uint32_t)(uintptr_t)&misc[9], one = 1u;
-            asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(prev) : "v"(a9), "v"(one) : "memory");
-            if (prev >= limit) { __hip_atomic_store(&misc[10], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); full = true; }
+        const uint32_t tb = size() * 4;                         // byte distance between the four arrays
+        if (valid) {
+            asm volatile(
+                "s_mov_b64 %[save], exec\n"
+                ".Lprobe%=:\n\t"
+                "v_lshl_add_u32 %[addr], %[slot], 2, %[base]\n\t"
+                "ds_cmpst_rtn_b32 %[old], %[addr], %[empty], %[j]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cmp_eq_u32_e64 %[t], %[old], %[empty]\n\t"
+                "v_cndmask_b32_e64 %[cl], %[cl], 1, %[t]\n\t"
+                "v_cmp_eq_u32_e32 vcc, %[old], %[j]\n\t"
+                "s_or_b64 vcc, vcc, %[t]\n\t"
+                "s_andn2_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz .Ldone%=\n\t"
+                "v_add_u32_e32 %[slot], 1, %[slot]\n\t"
+                "v_and_b32_e32 %[slot], %[mask], %[slot]\n\t"
+                "s_branch .Lprobe%=\n"
+                ".Ldone%=:\n\t"
+                "s_mov_b64 exec, %[save]\n\t"
+                "v_add_u32_e32 %[old], %[tb], %[addr]\n\t"
+                "ds_add_u32 %[old], %[one]\n\t"
+                "v_add_u32_e32 %[old], %[tb], %[old]\n\t"
+                "ds_min_u32 %[old], %[s]\n\t"
+                "v_add_u32_e32 %[old], %[tb], %[old]\n\t"
+                "ds_max_u32 %[old], %[s]\n"
+                : [save] "=&s"(save), [addr] "+v"(addr), [old] "=&v"(old), [t] "=&s"(t), [cl] "+v"(claimed), [slot] "+v"(slot)
+                : [base] "s"(base), [empty] "v"(empty), [j] "v"(j), [mask] "s"(mask), [tb] "s"(tb), [one] "v"(1u), [s] "v"(s)
+                : "vcc", "memory");
         }
-        atomicAdd(&cnt[slot], 1u);
-        atomicMin(&smin[slot], s);
-        atomicMax(&smax[slot], s);
+        // claims: every claiming lane adds for itself (same-address LDS atomics serialise in the LDS unit, one cycle each)
+        if (__ballot(claimed != 0) != 0) {
+            uint32_t prev = 0;
+            if (claimed) {
+                const uint32_t a9 = (uint32_t)(uintptr_t)&misc[9], one = 1u;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(prev) : "v"(a9), "v"(one) : "memory");
+            }
+            if (__ballot(claimed != 0 && prev >= limit) != 0) {
+                misc[10] = 1u;
+                full = true;
+            }
+        }
     }
     // two independent inserts with their compare-and-swap round trips in flight together
     __device__ __forceinline__ void insert2(uint32_t j0, uint32_t s0, uint32_t j1, uint32_t s1, bool two, bool &full) const
@@ -316,9 +329,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                     }
                 } else {
 #pragma unroll
-                    for (int k = 0; k < PK; ++k) {
-                        if (itc[k] != NOITEM) tab.insert_lds((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], full);
-                    }
+                    for (int k = 0; k < PK; ++k) tab.insert_lds((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], itc[k] != NOITEM, full);
                 }
             }
             ELBA_STAMP(8);
