@@ -274,7 +274,7 @@ static void build_product_schedule(Ctx &c)
     int fb = 1;
     while (fb < 31 && ((uint64_t)(c.max_col_nnz > 1 ? c.max_col_nnz - 1 : 1) >> fb)) ++fb;
     c.fbits = (uint32_t)fb;
-    ELBA_REQUIRE(fb < 31 && (uint64_t)c.max_row_nnz <= (1ull << (32 - fb)), ELBA_ERR_UNSUPPORTED,
+    ELBA_REQUIRE(fb < 31 && (uint64_t)c.max_row_nnz < (1ull << (32 - fb)), ELBA_ERR_UNSUPPORTED,
                  "row nnz x column nnz exceeds the 32-bit product sequence number");
     c.a_diag.reserve((size_t)(M + 1) * 12);
     c.a_prodptr.reserve((size_t)(M + 2) * 8);

@@ -442,7 +442,7 @@ void stage_create_seed_matrix(Ctx &c)
     c.have_B = false;
 
     const uint32_t fbits = c.fbits;          // fixed when the product schedule was built
-    ELBA_REQUIRE(fbits < 31 && (uint64_t)c.max_row_nnz <= (1ull << (32 - fbits)), ELBA_ERR_UNSUPPORTED,
+    ELBA_REQUIRE(fbits < 31 && (uint64_t)c.max_row_nnz < (1ull << (32 - fbits)), ELBA_ERR_UNSUPPORTED,
                  "row nnz x column nnz exceeds the 32-bit product sequence number");
     ELBA_REQUIRE((uint64_t)c.max_row_nnz * (uint64_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1) < 0xFFFFFFFFull, ELBA_ERR_UNSUPPORTED,
                  "products per row exceed 32 bits");
@@ -557,7 +557,7 @@ void stage_create_seed_matrix(Ctx &c)
         if (nrows > 0) {
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
-            const size_t X = 128;  // misc words
+            const size_t X = 256;  // bytes of misc words behind the table (spgemm_rows.hpp: W_END words)
             const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 10;    // resident capacity: 96 VGPRs -> 5 waves per SIMD = 10 two-wave workgroups per CU (LDS would allow 14)
             // Tiers that received no row in the previous call on this matrix are not launched (an empty launch still costs ~5 us of
             // stream time); should a row reach one of them after all, the call is repeated with every tier (checked after the sync).

@@ -10,7 +10,14 @@
 //   level 4   all survivors decode their two seeds in parallel (canonical arrays), then store.
 
 // misc words in LDS: 0 diag n, 1 diag smin, 2 diag smax, 3 survivors, 4 y, 5 yraw, 6/7 staging offset lo/hi, 8 fits,
-//                    9 claimed slots, 10 abandon flag, 11 row entries consumed when the row was abandoned
+//                    9 claimed slots, 10 abandon flag, 11 row entries consumed when the row was abandoned   (reset per row)
+//                    16..19 feedback snapshot; from 32: the workgroup's statistics across rows (W_* below).  They are only ever ADDED to,
+//                    by one lane per row: kept in LDS and updated with no-return ds_add they cost no latency, while as registers they
+//                    cost every lane of the kernel ~20 VGPRs
+enum : uint32_t {
+    W_ACC_YRAW = 32 /*u64*/, W_ACC_Y = 34 /*u64*/, W_ACC_DONE = 36, W_ACC_NDIAG = 37, W_FB_N = 38,
+    W_FB_C = 40 /*u64*/, W_FB_U = 42 /*u64*/, W_TOT_C = 44 /*u64*/, W_TOT_U = 46 /*u64*/, W_NUP = 48 /*u64*/, W_MIR = 50 /*u64*/, W_MX = 52, W_END = 54
+};
 template <bool GLOBAL>
 struct Table {
     uint32_t *keys, *cnt, *smin, *smax, *misc;
@@ -155,6 +162,12 @@ __device__ __forceinline__ elba_seed_t decode_seed(const OvParams &p, uint32_t r
     return v;
 }
 
+// no-return LDS atomics, written out: a C++ atomicAdd on an LDS word whose address is uniform is rewritten by the compiler into a scalar
+// loop over the active lanes (its "atomic optimizer"), dozens of instructions where one is meant
+__device__ __forceinline__ void lds_add32(uint32_t *w, uint32_t v) { asm volatile("ds_add_u32 %0, %1" : : "v"((uint32_t)(uintptr_t)w), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_max32(uint32_t *w, uint32_t v) { asm volatile("ds_max_u32 %0, %1" : : "v"((uint32_t)(uintptr_t)w), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_add64(unsigned long long *w, unsigned long long v) { asm volatile("ds_add_u64 %0, %1" : : "v"((uint32_t)(uintptr_t)w), "v"(v) : "memory"); }
+
 // workgroup-uniform values belong in scalar registers
 __device__ __forceinline__ uint32_t sfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 __device__ __forceinline__ uint64_t sfirst64(uint64_t v) { return ((uint64_t)sfirst((uint32_t)(v >> 32)) << 32) | sfirst((uint32_t)v); }
@@ -180,21 +193,19 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     const uint64_t lt = (1ull << lane) - 1;
     const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
     const uint32_t fmask = (1u << p.fbits) - 1;
-    // per-workgroup state kept in registers across the rows of this persistent loop (flushed once at the end)
-    unsigned long long chunk_off = 0, acc_yraw = 0, acc_y = 0, acc_mir = 0;
-    uint32_t chunk_left = 0, acc_done = 0, acc_ndiag = 0;
-    unsigned long long acc_nup = 0;
-    uint32_t acc_mx = 0;
+    // the staging chunk cursor is needed by value every row: registers; the statistics live in LDS (see W_*), flushed once at the end
+    unsigned long long chunk_off = 0;
+    uint32_t chunk_left = 0;
+    auto w64 = [&](uint32_t k) { return reinterpret_cast<unsigned long long *>(&misc[k]); };
+    if (tid >= 32 && tid < W_END) misc[tid] = 0;
+    __syncthreads();
     // diagnostic phase clock (cfg.flags & 16): 0 fetch row, 1 table init, 2 expand+accumulate, 3 sweep, 4 reserve, 5 decode+store
     const bool stamp = DIAG && (dbg & 16u) != 0;
     unsigned long long ph[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // 6 gather wait, 7 count+scan+queue write, 8 insert loop, 9 loop tail
     unsigned long long tprev = stamp ? __builtin_amdgcn_s_memtime() : 0;
 #define ELBA_STAMP(k) do { if (stamp) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tprev; tprev = tn; } } while (0)
 
-    unsigned long long fb_c = 0, fb_u = 0;      // this workgroup's contribution to the feedback sums (flushed every few rows)
-    uint32_t fb_n = 0, fb_seen = 0;
-    unsigned long long tot_c = 0, tot_u = 0;    // already pushed to the hot sums (first call only)
-    unsigned long long gu = 0, gc = 0;
+    uint32_t fb_seen = 0;
 
     // ---- software pipeline ACROSS rows -------------------------------------------------------------------------------------------
     // A row costs ~6 dependent memory round trips (id -> bounds -> schedule items -> partner entries ... -> seed decoding, 2 levels)
@@ -211,16 +222,31 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         return h;
     };
     uint64_t itc[PK], ce[PK];
-    auto load_items = [&](uint64_t from, uint64_t pe) {       // item = address of the partner's column entry << 32 | s  (matrix.hip: k_products)
+    // A group = PK x BLOCK consecutive items of a row's schedule, item k of a lane at offset k*BLOCK + tid.  Offsets are 32-bit and relative
+    // to the row's first item (uniform 64-bit base), and a FULL group needs no per-lane validity selects at all: both matter, the kernel
+    // is bound by instruction issue.
+    constexpr uint32_t GS = (uint32_t)PK * BLOCK;
+    auto load_group = [&](uint64_t *dst, const uint64_t *src, uint32_t at, uint32_t np) {       // item = partner entry address << 32 | s
+        if (at + GS <= np) {
 #pragma unroll
-        for (int k = 0; k < PK; ++k) {
-            const uint64_t idx = from + (uint64_t)k * BLOCK + tid;
-            itc[k] = idx < pe ? p.a_prod[idx] : NOITEM;
+            for (int k = 0; k < PK; ++k) dst[k] = src[at + (uint32_t)k * BLOCK + tid];
+        } else {
+#pragma unroll
+            for (int k = 0; k < PK; ++k) {
+                const uint32_t r = at + (uint32_t)k * BLOCK + tid;
+                dst[k] = r < np ? src[r] : NOITEM;
+            }
         }
     };
-    auto gather = [&]() {
+    auto load_items = [&](uint64_t ps, uint64_t pe) { load_group(itc, p.a_prod + ps, 0u, (uint32_t)(pe - ps)); };
+    auto gather = [&](bool fullg) {
+        if (fullg) {
 #pragma unroll
-        for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[itc[k] != NOITEM ? (uint32_t)(itc[k] >> 32) : 0u];
+            for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[(uint32_t)(itc[k] >> 32)];
+        } else {
+#pragma unroll
+            for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[(uint32_t)itc[k] != 0xFFFFFFFFu ? (uint32_t)(itc[k] >> 32) : 0u];
+        }
         if (DIAG && (dbg & 2u)) {                                   // ablation: no gathers, synthetic partner ids
 #pragma unroll
             for (int k = 0; k < PK; ++k) ce[k] = (uint64_t)(((uint32_t)(itc[k] >> 32) * 2654435761u) % p.Mcols) << 32;
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         cur = load_hdr(queue[blockIdx.x]);
         if (blockIdx.x + gridDim.x < nrows) id_n = queue[blockIdx.x + gridDim.x];
         load_items(cur.ps, cur.pe);
-        gather();
+        gather((uint32_t)(cur.pe - cur.ps) >= GS);
     }
     for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
         const bool has_n = it + gridDim.x < nrows;
@@ -243,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         const uint64_t ps = cur.ps, pe = cur.pe;
         const uint32_t ub_i = (uint32_t)(pe - ps);           // scheduled products: bounds the row's distinct partners
         // leaves this row early: the next row's prefetch is issued back to back
-#define ELBA_NEXT_ROW() do { if (has_n) { load_items(nxt.ps, nxt.pe); gather(); } cur = nxt; id_n = id_nn; } while (0)
+#define ELBA_NEXT_ROW() do { if (has_n) { load_items(nxt.ps, nxt.pe); gather((uint32_t)(nxt.pe - nxt.ps) >= GS); } cur = nxt; id_n = id_nn; } while (0)
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
             // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
@@ -256,10 +282,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                     misc[16] = (uint32_t)u; misc[17] = (uint32_t)(u >> 32); misc[18] = (uint32_t)c; misc[19] = (uint32_t)(c >> 32);
                 }
                 __syncthreads();
-                gu = ((unsigned long long)misc[17] << 32) | misc[16];
-                gc = ((unsigned long long)misc[19] << 32) | misc[18];
-                __syncthreads();
             }
+            const unsigned long long gu = ((unsigned long long)misc[17] << 32) | misc[16], gc = ((unsigned long long)misc[19] << 32) | misc[18];
             if (gu >= (1ull << 20)) {
                 const double pred = 1.25 * (double)ub_i * (double)gc / (double)gu;
                 // forward only on strong evidence (short rows finish first and have a higher partner/product ratio: the running sums
@@ -306,14 +330,13 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         // The first group's items and partner entries are already in registers or in flight (prefetched during the previous row).  Per
         // group: the next PK items are requested, the accumulator is updated two products at a time, then the next gathers are issued.
         bool full = false;
+        const uint64_t *src = p.a_prod + ps;
+        const uint32_t np = ub_i;
 #pragma unroll 1
-        for (uint64_t t0 = ps; t0 < pe; t0 += (uint64_t)PK * BLOCK) {
+        for (uint32_t t0 = 0; t0 < np; t0 += GS) {
             uint64_t itn[PK];
-#pragma unroll
-            for (int k = 0; k < PK; ++k) {
-                const uint64_t idx = t0 + (uint64_t)(PK + k) * BLOCK + tid;
-                itn[k] = idx < pe ? p.a_prod[idx] : NOITEM;
-            }
+            const bool more = t0 + GS < np, fullg = t0 + GS <= np;
+            if (more) load_group(itn, src, t0 + GS, np);
             ELBA_STAMP(6);
             if (DIAG && (dbg & 1u)) {                                   // ablation: gathers only, keep the loads alive
                 uint32_t sink = 0;
@@ -327,20 +350,23 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                         if (itc[k] != NOITEM)
                             tab.insert2((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], (uint32_t)(ce[k + 1] >> 32), (uint32_t)itc[k + 1], itc[k + 1] != NOITEM, full);
                     }
+                } else if (fullg) {
+#pragma unroll
+                    for (int k = 0; k < PK; ++k) tab.insert_lds((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], true, full);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < PK; ++k) tab.insert_lds((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], itc[k] != NOITEM, full);
+                    for (int k = 0; k < PK; ++k) tab.insert_lds((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], (uint32_t)itc[k] != 0xFFFFFFFFu, full);
                 }
             }
             ELBA_STAMP(8);
             if (tab.abandoned()) {
-                if (tid == 0) { const uint64_t done = t0 + (uint64_t)PK * BLOCK - ps; misc[11] = (uint32_t)(done < pe - ps ? done : pe - ps); }
+                if (tid == 0) { const uint32_t done = t0 + GS; misc[11] = done < np ? done : np; }
                 break;
             }
-            if (t0 + (uint64_t)PK * BLOCK < pe) {
+            if (more) {
 #pragma unroll
                 for (int k = 0; k < PK; ++k) itc[k] = itn[k];
-                gather();
+                gather(t0 + 2 * GS <= np);
             }
         }
         if (GLOBAL) __syncthreads(); else lds_barrier();
@@ -352,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 p.lists[(size_t)(tier + 1) * p.M + at] = i;
                 // the table filled after `gb_done` of the row's entries: extrapolate its distinct-partner count for the feedback
                 const unsigned long long done = misc[11] ? misc[11] : 1u, all = pe - ps;
-                fb_c += (unsigned long long)misc[9] * all / done; fb_u += ub_i; ++fb_n;
+                lds_add64(w64(W_FB_C), (unsigned long long)misc[9] * all / done); lds_add64(w64(W_FB_U), (unsigned long long)ub_i); lds_add32(&misc[W_FB_N], 1u);
             }
             __syncthreads();
             ELBA_NEXT_ROW();
@@ -395,16 +421,20 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             p.row_cnt[i] = ytot;
             p.row_off[i] = off;
             misc[6] = (uint32_t)off; misc[7] = (uint32_t)(off >> 32); misc[8] = fits ? 1u : 0u;
-            acc_yraw += misc[5] + (dcount >= 1 ? 1u : 0u);
-            acc_done += 1;
-            acc_ndiag += dcount >= 2 ? 1u : 0u;
-            acc_y += ytot;
-            if (!GLOBAL) { fb_c += misc[9]; fb_u += ub_i; ++fb_n; }
-            if (p.use_feedback && fb_n >= 8) { atomicAdd(&p.ctr->fb_claims, fb_c); atomicAdd(&p.ctr->fb_ub, fb_u); tot_c += fb_c; tot_u += fb_u; fb_c = 0; fb_u = 0; fb_n = 0; }
+            lds_add64(w64(W_ACC_YRAW), (unsigned long long)(misc[5] + (dcount >= 1 ? 1u : 0u)));
+            lds_add32(&misc[W_ACC_DONE], 1u);
+            lds_add32(&misc[W_ACC_NDIAG], dcount >= 2 ? 1u : 0u);
+            lds_add64(w64(W_ACC_Y), (unsigned long long)ytot);
+            if (!GLOBAL) { lds_add64(w64(W_FB_C), (unsigned long long)misc[9]); lds_add64(w64(W_FB_U), (unsigned long long)ub_i); lds_add32(&misc[W_FB_N], 1u); }
+            if (p.use_feedback && misc[W_FB_N] >= 8) {          // first call for a matrix only: push this workgroup's share to the hot sums
+                const unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
+                atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu);
+                *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;
+            }
         }
         lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
-        if (has_n) gather();    // next row, first group's partner entries: in flight during the decode
+        if (has_n) gather((uint32_t)(nxt.pe - nxt.ps) >= GS);    // next row, first group's partner entries: in flight during the decode
         if (misc[8]) {
             // ---- level 4: all survivors decode their seeds in parallel ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
@@ -428,8 +458,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 if (j > i) ++nup;
                 mx = n > mx ? n : mx;
             }
-            acc_nup += nup; acc_mir += nmir;
-            acc_mx = mx > acc_mx ? mx : acc_mx;
+            if (nup) lds_add64(w64(W_NUP), (unsigned long long)nup);
+            if (nmir) lds_add64(w64(W_MIR), (unsigned long long)nmir);
+            if (mx) lds_max32(&misc[W_MX], mx);
         }
         lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
         cur = nxt; id_n = id_nn;
@@ -443,23 +474,21 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     }
 #undef ELBA_STAMP
     // flush the workgroup's statistics: a handful of atomics per workgroup instead of six per row
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { acc_nup += __shfl_xor(acc_nup, d, 64); acc_mir += __shfl_xor(acc_mir, d, 64); uint32_t o = __shfl_xor(acc_mx, d, 64); acc_mx = o > acc_mx ? o : acc_mx; }
+    __syncthreads();
     OvShard *sh = &p.ctr->shard[blockIdx.x & (NUM_SHARDS - 1)];
-    if (lane == 0) {
-        if (acc_nup) atomicAdd(&sh->nupper, acc_nup);
-        if (acc_mir) atomicAdd(&sh->nnz, acc_mir);
-        if (acc_mx) atomicMax(&sh->maxshared, acc_mx);
-    }
     if (tid == 0) {
-        if (p.use_feedback && fb_n) { atomicAdd(&p.ctr->fb_claims, fb_c); atomicAdd(&p.ctr->fb_ub, fb_u); }
-        fb_c += tot_c; fb_u += tot_u;
-        if (fb_u) { atomicAdd(&sh->fb_claims, fb_c); atomicAdd(&sh->fb_ub, fb_u); }
-        if (acc_done) {
-            atomicAdd(&sh->yraw, acc_yraw);
-            atomicAdd(&sh->nnz, acc_y);
-            atomicAdd(&sh->tier_done[tier], acc_done);
-            if (acc_ndiag) atomicAdd(&sh->ndiag, (unsigned long long)acc_ndiag);
+        if (*w64(W_NUP)) atomicAdd(&sh->nupper, *w64(W_NUP));
+        if (*w64(W_MIR)) atomicAdd(&sh->nnz, *w64(W_MIR));
+        if (misc[W_MX]) atomicMax(&sh->maxshared, misc[W_MX]);
+        unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
+        if (p.use_feedback && misc[W_FB_N]) { atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu); }
+        fc += *w64(W_TOT_C); fu += *w64(W_TOT_U);
+        if (fu) { atomicAdd(&sh->fb_claims, fc); atomicAdd(&sh->fb_ub, fu); }
+        if (misc[W_ACC_DONE]) {
+            atomicAdd(&sh->yraw, *w64(W_ACC_YRAW));
+            atomicAdd(&sh->nnz, *w64(W_ACC_Y));
+            atomicAdd(&sh->tier_done[tier], misc[W_ACC_DONE]);
+            if (misc[W_ACC_NDIAG]) atomicAdd(&sh->ndiag, (unsigned long long)misc[W_ACC_NDIAG]);
         }
     }
 }
