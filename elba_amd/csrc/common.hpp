@@ -90,6 +90,20 @@ void fill_u64(hipStream_t s, uint64_t *p, uint64_t v, int64_t n);
 void group_offsets_u32(hipStream_t s, const uint64_t *sorted_keys, int key_shift, int64_t n, uint32_t *ptr, int64_t nkeys);
 uint64_t reduce_max_u64(hipStream_t s, const uint64_t *p, int64_t n, DevBuf &tmp);   // synchronises
 
+// ---- hot format of A for the SpGEMM (matrix.hip builds it, spgemm.hip walks it) ----------------------------------
+// One 16-byte descriptor per (row entry, contiguous range of partner entries in the entry's column):
+//   x = address in a_cscp of the first partner entry      y = sequence number of the first product: rank of the row entry << fbits | index in column
+//   z = number of partner entries (products)              w = (run of the row's own read in that column) - 1, on one descriptor per entry
+// A row's descriptors are stored by descending z, then by address.  Per row: 32 bytes of bounds.
+struct alignas(16) HotDesc { uint32_t x, y, z, w; };
+struct alignas(32) RowHot {
+    uint32_t rs, nnz;        // the row's entries in canonical order: a_dec[rs .. rs + nnz)
+    uint32_t hs, nd;         // its descriptors: a_hot[hs .. hs + nd)
+    uint32_t work;           // products its descriptors stand for (sum of z)
+    uint32_t own0, ownl;     // index of the row's first / last entry inside its own column
+    uint32_t pad;
+};
+
 // ---- context ----------------------------------------------------------------------------------------------------
 struct Ctx {
     elba_cfg cfg{};
@@ -126,14 +140,15 @@ struct Ctx {
     DevBuf a_rowptr, a_csr, a_colptr, a_csc;   // u32[M+1], u64[Z], u32[N+1], u64[Z]
     DevBuf a_rowprod;                          // u32[M] products per row: sum of the column lengths of the row's k-mers
     DevBuf a_dec;                              // u64[Z] by canonical rank: address of the entry's column in a_cscp << 32 | position in the read (seed decoding)
-    DevBuf a_prodptr, a_prod, a_diag;          // i64[M+1], u64[Pnd], u32[3M]: per-row product schedule + diagonal (count, min s, max s); matrix.hip
-    int64_t Pnd = 0;                           // scheduled (non-diagonal, one per unordered in-window pair product) products
-    bool half = true;                          // schedule lists an in-window pair on its smaller row only; the SpGEMM mirrors (matrix.hip)
+    DevBuf a_hdr, a_hot;                       // RowHot[M], HotDesc[H]: per-row header + the row's hot descriptors (one per row entry and partner range); matrix.hip
+    int64_t H = 0;                             // hot descriptors overall
+    int64_t Pnd = 0;                           // products the descriptors stand for (non-diagonal; an in-window pair on its smaller row only)
+    bool half = true;                          // descriptors list an in-window pair on its smaller row only; the SpGEMM mirrors (matrix.hip)
     uint32_t fbits = 1;                        // bits of the column-position field of a product sequence number
     DevBuf a_roworder;                         // u32[M] rows by descending product count (queue order of the SpGEMM)
     DevBuf a_cscp;                             // u64[Z] columns in first-occurrence order (hot-loop copy of a_csc; see matrix.hip)
-    bool hot_packed = false, a_cscp_is_csc = true;
-    DevBuf a_csrx;                             // u64[Z] per CSR entry: column start << 32 | column length (hot-path twin of a_csr)
+    bool a_cscp_is_csc = true;
+    DevBuf a_newstart;                         // u32[N] address of every column in a_cscp
     int64_t row_lo = 0, row_hi = -1;           // rows of B computed by this context (-1: all)
     // rows of an A built from reads are local read indices; exported triples carry global ids (src/KmerOps.cpp:215-219)
     int64_t first_global_id_rows() const { return A_has_kmers ? first_global_id : 0; }

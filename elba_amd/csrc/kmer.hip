@@ -292,7 +292,7 @@ void stage_create_kmer_matrix(Ctx &c)
     c.have_A = false; c.have_B = false;
     c.t_c.start(s);
     c.a_colptr.reserve((size_t)(N + 2) * 4);
-    c.a_csc.reserve((size_t)(Z + 2) * 8);   // +2 guard entries: the SpGEMM reads column entries in 16-byte pairs
+    c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
     // colptr = exclusive scan of the per-k-mer counts
     ELBA_HIP(hipMemsetAsync(c.rel_counts.as<uint32_t>() + N, 0, 4, s));
     exclusive_scan_u32(s, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), N + 1, c.ws_scan);
@@ -530,7 +530,7 @@ void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
     }
     // owner-local columns: colptr by scan, entries by lookup of every record, then per-column sort by (read, pos)
     c.a_colptr.reserve((size_t)(N + 2) * 4);
-    c.a_csc.reserve((size_t)(Z + 2) * 8);   // +2 guard entries: the SpGEMM reads column entries in 16-byte pairs
+    c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
     ELBA_HIP(hipMemsetAsync(c.rel_counts.as<uint32_t>() + N, 0, 4, s));
     exclusive_scan_u32(s, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), (int64_t)N + 1, c.ws_scan);
     c.ws_e.reserve((size_t)(N + 1) * 4);

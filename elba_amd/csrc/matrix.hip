@@ -46,8 +46,9 @@ __global__ void k_max_seg_len(const uint32_t *ptr, int64_t nseg, unsigned long l
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-// products per row: ub_i = sum over the row's entries of the length of the entry's column (one wavefront per row)
-__global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, uint32_t M, uint32_t *rowprod, uint64_t *csrx, uint64_t *dec)
+// products per row: ub_i = sum over the row's entries of the length of the entry's column (one wavefront per row); seed-decoding array
+// for the canonical column layout (replaced by k_dec_permuted when the columns are permuted)
+__global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, uint32_t M, uint32_t *rowprod, uint64_t *dec)
 {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -58,7 +59,6 @@ __global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, co
         for (uint32_t e = rs + lane; e < re; e += 64) {
             const uint32_t kid = (uint32_t)(csr[e] >> 32);
             const uint32_t c0 = colptr[kid], len = colptr[kid + 1] - c0;
-            csrx[e] = ((uint64_t)c0 << 32) | len;
             dec[e] = ((uint64_t)c0 << 32) | (uint32_t)csr[e];
             ub += len;
         }
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, co
 // in the order of their first entry (read, pos), the columns a read shares with the reads before it — and all the columns it
 // introduces itself — lie next to each other: 2.2x fewer sectors per row on 15 %-error reads, far fewer on accurate ones.
 // Canonical order is untouched: a_csc / a_colptr / a_csr stay as they are (exports, seed decoding); only the arrays the hot
-// loop walks are permuted: a_cscp (columns) and a_csrx (per-row descriptors sorted by column address).
+// loop walks are permuted: a_cscp (columns) and the row descriptors that point into it.
 __global__ void k_first_entry_keys(const uint32_t *colptr, const uint64_t *csc, uint64_t N, uint64_t *keys, uint64_t *vals)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -103,30 +103,19 @@ __global__ void k_perm_copy(const uint64_t *sorted_cols, const uint32_t *newstar
     for (uint32_t a = c0; a < c1; ++a) cscp[d0 + (a - c0)] = csc[a];
 }
 
-// descriptor of CSR entry e (row i, rank r = e - rowptr[i]): column address << 32 | rank << 8 | column length (<= 255)
-__global__ __launch_bounds__(256) void k_descriptors(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, const uint32_t *newstart, uint32_t M,
-                                                     uint64_t *keys, uint64_t *desc, uint64_t *dec)
+// seed decoding by canonical rank: address of the entry's column in a_cscp << 32 | position in the read
+__global__ void k_dec_permuted(const uint64_t *csr, const uint32_t *newstart, uint64_t Z, uint64_t *dec)
 {
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t i = wave; i < M; i += nwaves) {
-        const uint32_t rs = rowptr[i], re = rowptr[i + 1];
-        for (uint32_t e = rs + lane; e < re; e += 64) {
-            const uint32_t kid = (uint32_t)(csr[e] >> 32);
-            const uint32_t len = colptr[kid + 1] - colptr[kid], st = newstart[kid];
-            keys[e] = ((uint64_t)i << 32) | st;                 // sort key: (row, column address)
-            desc[e] = ((uint64_t)st << 32) | ((uint64_t)(e - rs) << 8) | len;
-            dec[e] = ((uint64_t)st << 32) | (uint32_t)csr[e];      // seed decoding by canonical rank: column address | position in the read
-        }
-    }
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= Z) return;
+    dec[e] = ((uint64_t)newstart[(uint32_t)(csr[e] >> 32)] << 32) | (uint32_t)csr[e];
 }
 
-__global__ void k_roworder_keys(const uint32_t *rowprod, uint64_t M, uint64_t *keys, uint64_t *vals)
+__global__ void k_roworder_keys(const RowHot *hdr, uint64_t M, uint64_t *keys, uint64_t *vals)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    keys[i] = (uint64_t)(0xFFFFFFFFu - rowprod[i]);      // ascending sort of the complement = descending products
+    keys[i] = (uint64_t)(0xFFFFFFFFu - hdr[i].work);      // ascending sort of the complement = descending products
     vals[i] = i;
 }
 
@@ -136,72 +125,83 @@ __global__ void k_narrow_u32(const uint64_t *in, uint64_t n, uint32_t *out)
     if (i < n) out[i] = (uint32_t)in[i];
 }
 
-// ---- per-row product schedule ---------------------------------------------------------------------------------------------------
-// The SpGEMM's expansion of row i is the list of column entries (i's k-mers x the other reads in those k-mers' columns).  Which
-// (row entry, column position) pairs exist, and which of them are diagonal (the column entry IS read i: 38 % of all products on the
-// bench workload), is structure of A alone, so it is laid out once with A: one 8-byte item per NON-diagonal product,
-//     item = address of the partner's column entry in a_cscp << 32 | s,   s = canonical rank of the row entry << fbits | position in column,
-// in column-address order, plus the diagonal's (count, min s, max s) per row.  The numeric kernel then runs ONE product per lane:
-// no per-entry loops over mostly empty column positions, no cross-lane compaction, no tail for long columns (any UPPER).
-// It still gathers every partner entry (read id, position) from the columns: nothing of B is precomputed.
-//
+// ---- row descriptors ------------------------------------------------------------------------------------------------------------
+// What the SpGEMM walks is a per-ENTRY format of A, O(nnz(A)) like CSR itself: for the row entry (i, k, pos) the contiguous ranges of
+// column k that hold its partners.  Columns are ordered by (read, pos), so with d0..d1 the run of read i itself in column k:
+//     [0, d0)   partners j < i        [d0, d1)   read i itself (the diagonal of B)        [d1, len)   partners j > i.
 // B is symmetric up to swapping each seed's two positions: the canonical seeds of (i,j) are the lexicographic min/max of
 // (kid, pos in i, pos in j) over a CROSS product of positions per shared k-mer, so min/max of (kid, pos in j, pos in i) is the same
-// pair of products with its positions exchanged — exactly, not approximately.  With `half` the schedule therefore lists a pair only
-// on its smaller row (partner j > i); partners outside the row window [lo, hi) of a multi-GPU shard are listed in full (their own
-// rows live on another rank).  The SpGEMM mirrors the surviving in-window pairs into the partner's row (spgemm.hip: k_mirror).
-__device__ __forceinline__ void desc_fields(uint64_t x, bool packed, uint32_t index_in_row, uint32_t &addr, uint32_t &len, uint32_t &rank)
-{
-    addr = (uint32_t)(x >> 32);
-    len = packed ? ((uint32_t)x & 255u) : (uint32_t)x;
-    rank = packed ? ((uint32_t)x >> 8) : index_in_row;
-}
-
+// pair of products with its positions exchanged — exactly, not approximately.  With `half` a pair of rows of this context's window
+// [lo, hi) is therefore described on its smaller row only (range [d1, len)), partners below the window in full ([0, w0), w0 = entries
+// with read < lo: their own rows live on another rank); the SpGEMM mirrors the surviving in-window pairs into the partner's row
+// (spgemm.hip: k_mirror).  Nothing here is a product or a value of B: every partner entry is gathered, every pair accumulated and the
+// diagonal counted inside the SpGEMM call.  Only the order of a row's descriptors is chosen for the kernel: by descending number of
+// partners (the lanes of a wavefront then walk equally long ranges), then by address (neighbouring lanes gather neighbouring sectors).
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_products(const uint32_t *rowptr, const uint64_t *csrx, const uint64_t *cscp, uint32_t M, bool packed, uint32_t fbits,
-                                                  uint32_t *cnt, uint32_t *diag, const uint64_t *prodptr, uint64_t *prod, uint32_t lo, uint32_t hi, bool half)
+__global__ __launch_bounds__(256) void k_entry_ranges(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, const uint32_t *newstart, const uint64_t *cscp,
+                                                      uint32_t fbits, uint32_t lo, uint32_t hi, bool half, uint32_t cbits, uint32_t cmax,
+                                                      uint32_t *cnt, RowHot *hdr, const uint32_t *dptr, HotDesc *desc, uint64_t *key_addr, uint64_t *key_row, uint64_t *val)
 {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t i = lo + wave; i < hi; i += nwaves) {             // rows outside the window keep an empty schedule
+    for (uint32_t i = lo + wave; i < hi; i += nwaves) {             // rows outside the window keep an empty header
         const uint32_t rs = rowptr[i], re = rowptr[i + 1];
-        uint32_t total = 0, dn = 0, dmin = 0xFFFFFFFFu, dmax = 0;
-        uint64_t out = FILL ? prodptr[i] : 0;
-        for (uint32_t e0 = rs; e0 < re; e0 += 64) {                        // wave-uniform trip count
-            const uint32_t e = e0 + lane;
-            uint32_t addr = 0, len = 0, rank = 0, mine = 0;
-            if (e < re) {
-                desc_fields(csrx[e], packed, e - rs, addr, len, rank);
-                for (uint32_t f = 0; f < len; ++f) {
-                    const uint32_t j = (uint32_t)(cscp[addr + f] >> 32), s = (rank << fbits) | f;
-                    if (j == i) { ++dn; dmin = s < dmin ? s : dmin; dmax = s > dmax ? s : dmax; }
-                    else if (!half || j > i || j < lo) ++mine;          // (j >= hi implies j > i)
-                }
+        unsigned long long work = 0;
+        for (uint32_t e = rs + lane; e < re; e += 64) {
+            const uint32_t kid = (uint32_t)(csr[e] >> 32), pos = (uint32_t)csr[e];
+            const uint32_t st = newstart[kid], len = colptr[kid + 1] - colptr[kid];
+            uint32_t d0 = len, d1 = 0, w0 = 0, own = 0;
+            for (uint32_t f = 0; f < len; ++f) {
+                const uint64_t v = cscp[st + f];
+                const uint32_t j = (uint32_t)(v >> 32);
+                if (j < lo) ++w0;
+                if (j == i) { d0 = f < d0 ? f : d0; d1 = f + 1; if ((uint32_t)v == pos) own = f; }
             }
-            uint32_t incl = mine;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if ((int)lane >= d) incl += o; }
-            if (FILL) {
-                uint64_t w = out + incl - mine;
-                for (uint32_t f = 0; f < len; ++f) {
-                    const uint32_t j = (uint32_t)(cscp[addr + f] >> 32);
-                    if (j != i && (!half || j > i || j < lo)) prod[w++] = ((uint64_t)(addr + f) << 32) | ((rank << fbits) | f);
-                }
+            const uint32_t run = d1 - d0;                                  // >= 1: the entry itself
+            const uint32_t cA = half ? w0 : d0, cB = len - d1;
+            uint32_t nde = (cA ? 1u : 0u) + (cB ? 1u : 0u);
+            if (nde == 0 && run >= 2) nde = 1;                              // no partners, but the diagonal count needs the run
+            if (!FILL) {
+                cnt[e] = nde;
+                work += (unsigned long long)cA + cB;
+                if (e == rs) hdr[i].own0 = own;
+                if (e == re - 1) hdr[i].ownl = own;
+            } else {
+                uint32_t at = dptr[e], w = run - 1;
+                const uint32_t rank = e - rs;
+                auto put = [&](uint32_t f0, uint32_t c) {
+                    desc[at] = HotDesc{st + f0, (rank << fbits) | f0, c, w};
+                    key_addr[at] = (uint64_t)(st + f0);
+                    key_row[at] = ((uint64_t)i << cbits) | (uint64_t)(cmax - (c < cmax ? c : cmax));
+                    val[at] = at;
+                    ++at; w = 0;
+                };
+                if (cA) put(0u, cA);
+                if (cB) put(d1, cB);
+                if (!cA && !cB && run >= 2) put(d0, 0u);
             }
-            const uint32_t chunk = __shfl(incl, 63, 64);
-            out += chunk; total += chunk;
         }
         if (!FILL) {
 #pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                dn += __shfl_xor(dn, d, 64);
-                const uint32_t a = __shfl_xor(dmin, d, 64), b = __shfl_xor(dmax, d, 64);
-                dmin = a < dmin ? a : dmin; dmax = b > dmax ? b : dmax;
-            }
-            if (lane == 0) { cnt[i] = total; diag[3 * i] = dn; diag[3 * i + 1] = dmin; diag[3 * i + 2] = dmax; }
+            for (int d = 32; d >= 1; d >>= 1) work += __shfl_xor(work, d, 64);
+            if (lane == 0) { hdr[i].rs = rs; hdr[i].nnz = re - rs; hdr[i].work = work > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)work; }
+        } else if (lane == 0) {
+            hdr[i].hs = dptr[rs]; hdr[i].nd = dptr[re] - dptr[rs];
         }
     }
+}
+
+__global__ void k_gather_keys(const uint64_t *val, const uint64_t *key_by_index, uint64_t n, uint64_t *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = key_by_index[val[t]];
+}
+
+__global__ void k_permute_desc(const uint64_t *val, const HotDesc *in, uint64_t n, HotDesc *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = in[val[t]];
 }
 
 int bits_for(uint64_t maxval)
@@ -227,20 +227,21 @@ int64_t max_segment_len(Ctx &c, const uint32_t *ptr, int64_t nseg)
     return (int64_t)h;
 }
 
-// Permuted columns + per-row descriptors (see the comment above k_first_entry_keys).  Falls back to the canonical layout
-// (a_cscp == a_csc, descriptor = column start << 32 | length, rank = index) when a column is longer than 255 entries or a row has
-// 2^24 entries or more: the packed descriptor has 8 bits for the length and 24 for the rank.
+// Permuted columns (see the comment above k_first_entry_keys).  ELBA_NO_PERMUTE keeps the canonical layout (a_cscp == a_csc).
 static void build_hot_format(Ctx &c)
 {
     hipStream_t s = c.stream;
-    const int64_t M = c.M, N = c.N, Z = c.Z;
-    c.hot_packed = c.max_col_nnz <= 255 && c.max_row_nnz < (1 << 24) && Z > 0 && !getenv("ELBA_NO_PERMUTE");
-    if (!c.hot_packed) { c.a_cscp_is_csc = true; return; }      // k_row_products already wrote the fallback descriptors
-    c.a_cscp_is_csc = false;
-    c.a_cscp.reserve((size_t)(Z + 2) * 8);
+    const int64_t N = c.N, Z = c.Z;
+    c.a_newstart.reserve((size_t)(N + 2) * 4);
+    c.a_cscp_is_csc = Z == 0 || getenv("ELBA_NO_PERMUTE");
+    if (c.a_cscp_is_csc) {          // k_row_products already wrote the canonical seed-decoding array
+        if (N > 0) ELBA_HIP(hipMemcpyAsync(c.a_newstart.p, c.a_colptr.p, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+        return;
+    }
+    c.a_cscp.reserve((size_t)(Z + 8) * 8);       // + guard entries: the SpGEMM gathers up to four consecutive entries without a bounds check
     c.ws_a.reserve((size_t)(std::max(N, Z) + 1) * 8); c.ws_b.reserve((size_t)(std::max(N, Z) + 1) * 8);
     c.ws_c.reserve((size_t)(std::max(N, Z) + 1) * 8); c.ws_d.reserve((size_t)(std::max(N, Z) + 1) * 8);
-    c.ws_e.reserve((size_t)(N + 2) * 4); c.ws_f.reserve((size_t)(N + 2) * 4);
+    c.ws_e.reserve((size_t)(N + 2) * 4);
     uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
     const unsigned nbN = (unsigned)((N + 255) / 256);
     // columns by first entry (read << 32 | pos): LSD over the pos bits, then the read bits (bit 63 set = empty column, last)
@@ -249,66 +250,85 @@ static void build_hot_format(Ctx &c)
     uint64_t *ck = w ? k1 : k0, *cv = w ? v1 : v0, *ok = w ? k0 : k1, *ov = w ? v0 : v1;
     int w2 = radix_sort_pairs(s, ck, cv, ok, ov, N, 32, 64, c.ws_sort);
     const uint64_t *sorted_cols = w2 ? ov : cv;
-    uint32_t *cnt = c.ws_e.as<uint32_t>(), *newstart = c.ws_f.as<uint32_t>();
+    uint32_t *cnt = c.ws_e.as<uint32_t>(), *newstart = c.a_newstart.as<uint32_t>();
     hipLaunchKernelGGL(k_perm_counts, dim3(nbN), dim3(256), 0, s, sorted_cols, c.a_colptr.as<uint32_t>(), (uint64_t)N, cnt);
     exclusive_scan_u32(s, cnt, cnt, N, c.ws_scan);
     hipLaunchKernelGGL(k_perm_copy, dim3(nbN), dim3(256), 0, s, sorted_cols, cnt, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), (uint64_t)N, newstart, c.a_cscp.as<uint64_t>());
-    // descriptors, then each row's descriptors by column address: neighbouring lanes gather neighbouring sectors
-    {
-        int nb = (int)((M + 3) / 4);
-        if (nb > c.num_cus * 8) nb = c.num_cus * 8;
-        hipLaunchKernelGGL(k_descriptors, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), newstart, (uint32_t)M, k0, v0, c.a_dec.as<uint64_t>());
-    }
-    int w3 = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, bits_for((uint64_t)Z), c.ws_sort);
-    ck = w3 ? k1 : k0; cv = w3 ? v1 : v0; ok = w3 ? k0 : k1; ov = w3 ? v0 : v1;
-    int w4 = radix_sort_pairs(s, ck, cv, ok, ov, Z, 32, 32 + bits_for((uint64_t)(M > 0 ? M - 1 : 0)), c.ws_sort);
-    ELBA_HIP(hipMemcpyAsync(c.a_csrx.p, w4 ? ov : cv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+    ELBA_HIP(hipMemsetAsync(c.a_cscp.as<uint64_t>() + Z, 0xFF, 8 * 8, s));
+    hipLaunchKernelGGL(k_dec_permuted, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, c.a_csr.as<uint64_t>(), newstart, (uint64_t)Z, c.a_dec.as<uint64_t>());
     ELBA_HIP(hipStreamSynchronize(s));
 }
 
-// Per-row product schedule (see the comment above k_products).  Needs the final descriptors (a_csrx) and column copy (a_cscp or a_csc).
-static void build_product_schedule(Ctx &c)
+// Row headers + hot descriptors (see the comment above k_entry_ranges).  Needs a_newstart and the column copy (a_cscp or a_csc).
+static void build_row_descriptors(Ctx &c)
 {
     hipStream_t s = c.stream;
-    const int64_t M = c.M;
+    const int64_t M = c.M, Z = c.Z;
     int fb = 1;
     while (fb < 31 && ((uint64_t)(c.max_col_nnz > 1 ? c.max_col_nnz - 1 : 1) >> fb)) ++fb;
     c.fbits = (uint32_t)fb;
     ELBA_REQUIRE(fb < 31 && (uint64_t)c.max_row_nnz < (1ull << (32 - fb)), ELBA_ERR_UNSUPPORTED,
                  "row nnz x column nnz exceeds the 32-bit product sequence number");
-    c.a_diag.reserve((size_t)(M + 1) * 12);
-    c.a_prodptr.reserve((size_t)(M + 2) * 8);
-    c.ws_e.reserve((size_t)(M + 2) * 4);
-    uint32_t *cnt = c.ws_e.as<uint32_t>();
-    const uint64_t *cols = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
-    c.Pnd = 0;
+    c.a_hdr.reserve((size_t)(M + 1) * sizeof(RowHot));
+    c.Pnd = 0; c.H = 0;
     c.half = !getenv("ELBA_NO_SYMMETRY");
     c.a_roworder.reserve((size_t)(M + 1) * 4);
     if (M == 0) return;
+    const uint64_t *cols = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
     const uint32_t lo = (uint32_t)c.row_lo, hi = (uint32_t)(c.row_hi < 0 ? M : c.row_hi);
     int nb = (int)((hi - lo + 3) / 4);
     if (nb > c.num_cus * 8) nb = c.num_cus * 8;
     if (nb < 1) nb = 1;
-    ELBA_HIP(hipMemsetAsync(cnt, 0, (size_t)(M + 2) * 4, s));
-    ELBA_HIP(hipMemsetAsync(c.a_diag.p, 0, (size_t)(M + 1) * 12, s));
-    hipLaunchKernelGGL((k_products<false>), dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csrx.as<uint64_t>(), cols, (uint32_t)M, c.hot_packed, c.fbits,
-                       cnt, c.a_diag.as<uint32_t>(), (const uint64_t *)nullptr, (uint64_t *)nullptr, lo, hi, c.half);
-    exclusive_scan_u32_to_i64(s, cnt, c.a_prodptr.as<int64_t>(), M + 1, c.ws_scan);
-    int64_t total = 0;
-    ELBA_HIP(hipMemcpyAsync(&total, c.a_prodptr.as<int64_t>() + M, 8, hipMemcpyDeviceToHost, s));
+    const uint32_t cmax = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
+    const uint32_t cbits = (uint32_t)bits_for(cmax);
+    DevBuf cntbuf, dptrbuf;         // u32[Z+1] descriptors per entry and their exclusive scan (released when the format is built)
+    cntbuf.reserve((size_t)(Z + 2) * 4);
+    uint32_t *cnt = cntbuf.as<uint32_t>();
+    ELBA_HIP(hipMemsetAsync(cnt, 0, (size_t)(Z + 2) * 4, s));
+    ELBA_HIP(hipMemsetAsync(c.a_hdr.p, 0, (size_t)(M + 1) * sizeof(RowHot), s));
+    hipLaunchKernelGGL((k_entry_ranges<false>), dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), c.a_newstart.as<uint32_t>(), cols,
+                       c.fbits, lo, hi, c.half, cbits, cmax, cnt, c.a_hdr.as<RowHot>(), (const uint32_t *)nullptr, (HotDesc *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr);
+    // descriptors per entry -> offsets (Z + 1 of them); the total must fit 32-bit addressing
+    c.ws_e.reserve((size_t)(Z + 2) * 8);
+    int64_t *dptr64 = c.ws_e.as<int64_t>();
+    exclusive_scan_u32_to_i64(s, cnt, dptr64, Z + 1, c.ws_scan);
+    int64_t H = 0;
+    ELBA_HIP(hipMemcpyAsync(&H, dptr64 + Z, 8, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
-    c.Pnd = total;
-    c.a_prod.reserve((size_t)(total + 1) * 8);
-    hipLaunchKernelGGL((k_products<true>), dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csrx.as<uint64_t>(), cols, (uint32_t)M, c.hot_packed, c.fbits,
-                       (uint32_t *)nullptr, (uint32_t *)nullptr, c.a_prodptr.as<uint64_t>(), c.a_prod.as<uint64_t>(), lo, hi, c.half);
-    // rows by descending scheduled work: the SpGEMM queues them in this order so that a workgroup's static share of a tier
+    ELBA_REQUIRE(H < 0xFFFFFFF0ll, ELBA_ERR_UNSUPPORTED, "row descriptors beyond 32-bit device indices");
+    c.H = H;
+    dptrbuf.reserve((size_t)(Z + 2) * 4);
+    uint32_t *dptr = dptrbuf.as<uint32_t>();
+    hipLaunchKernelGGL(k_narrow_u32, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, (const uint64_t *)dptr64, (uint64_t)(Z + 1), dptr);
+    c.a_hot.reserve((size_t)(H + 1) * sizeof(HotDesc));
+    DevBuf raw;                     // descriptors in entry order, before the per-row sort
+    raw.reserve((size_t)(H + 1) * sizeof(HotDesc));
+    c.ws_a.reserve((size_t)(std::max(H, M) + 1) * 8); c.ws_b.reserve((size_t)(std::max(H, M) + 1) * 8); c.ws_c.reserve((size_t)(std::max(H, M) + 1) * 8); c.ws_d.reserve((size_t)(std::max(H, M) + 1) * 8);
+    c.ws_f.reserve((size_t)(H + 1) * 8);
+    uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
+    uint64_t *key_row = c.ws_f.as<uint64_t>();
+    hipLaunchKernelGGL((k_entry_ranges<true>), dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), c.a_newstart.as<uint32_t>(), cols,
+                       c.fbits, lo, hi, c.half, cbits, cmax, (uint32_t *)nullptr, c.a_hdr.as<RowHot>(), dptr, raw.as<HotDesc>(), k0, key_row, v0);
+    if (H > 0) {
+        // stable LSD: by address, then by (row, descending partner count)
+        int w = radix_sort_pairs(s, k0, v0, k1, v1, H, 0, bits_for((uint64_t)Z + 8), c.ws_sort);
+        uint64_t *cv = w ? v1 : v0, *ck = w ? k1 : k0, *ok = w ? k0 : k1, *ov = w ? v0 : v1;
+        const unsigned nbH = (unsigned)((H + 255) / 256);
+        hipLaunchKernelGGL(k_gather_keys, dim3(nbH), dim3(256), 0, s, cv, key_row, (uint64_t)H, ck);
+        int w2 = radix_sort_pairs(s, ck, cv, ok, ov, H, 0, (int)cbits + bits_for((uint64_t)(M > 0 ? M - 1 : 0)), c.ws_sort);
+        hipLaunchKernelGGL(k_permute_desc, dim3(nbH), dim3(256), 0, s, w2 ? ov : cv, raw.as<HotDesc>(), (uint64_t)H, c.a_hot.as<HotDesc>());
+    }
+    // rows by descending work: the SpGEMM queues them in this order so that a workgroup's static share of a tier
     // mixes heavy rows first and light rows last (longest-processing-time order: short tail)
-    c.ws_a.reserve((size_t)(M + 1) * 8); c.ws_b.reserve((size_t)(M + 1) * 8); c.ws_c.reserve((size_t)(M + 1) * 8); c.ws_d.reserve((size_t)(M + 1) * 8);
     const unsigned nbM = (unsigned)((M + 255) / 256);
-    hipLaunchKernelGGL(k_roworder_keys, dim3(nbM), dim3(256), 0, s, cnt, (uint64_t)M, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
-    int wr = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), M, 0, 32, c.ws_sort);
-    hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>(), (uint64_t)M, c.a_roworder.as<uint32_t>());
+    hipLaunchKernelGGL(k_roworder_keys, dim3(nbM), dim3(256), 0, s, c.a_hdr.as<RowHot>(), (uint64_t)M, k0, v0);
+    int wr = radix_sort_pairs(s, k0, v0, k1, v1, M, 0, 32, c.ws_sort);
+    hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? v1 : v0, (uint64_t)M, c.a_roworder.as<uint32_t>());
+    // products the descriptors stand for (statistics only)
+    std::vector<RowHot> hh((size_t)M);
+    ELBA_HIP(hipMemcpyAsync(hh.data(), c.a_hdr.p, (size_t)M * sizeof(RowHot), hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
+    for (int64_t i = 0; i < M; ++i) c.Pnd += hh[(size_t)i].work;
 }
 
 // Input: Z entries sorted by (kid, read, pos): kid_keys[z] >> kid_shift = kid, csc[z] = read<<32|pos (device, in c.a_csc or elsewhere).
@@ -320,7 +340,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.M = M; c.N = N; c.Z = Z;
     c.a_colptr.reserve((size_t)(N + 1) * 4);
     c.a_rowptr.reserve((size_t)(M + 1) * 4);
-    c.a_csc.reserve((size_t)(Z + 2) * 8);   // +2 guard entries: the SpGEMM reads column entries in 16-byte pairs
+    c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries: the SpGEMM gathers up to four consecutive entries without a bounds check
     c.a_csr.reserve((size_t)(Z + 1) * 8);
     group_offsets_u32(s, kid_keys, kid_shift, Z, c.a_colptr.as<uint32_t>(), N);
     if (csc != c.a_csc.as<uint64_t>() && Z > 0)
@@ -338,12 +358,11 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     group_offsets_u32(s, rk, 0, Z, c.a_rowptr.as<uint32_t>(), M);
     if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
     c.a_rowprod.reserve((size_t)(M + 1) * 4);
-    c.a_csrx.reserve((size_t)(Z + 1) * 8);
     c.a_dec.reserve((size_t)(Z + 1) * 8);
     if (M > 0) {
         int nb = (int)((M + 3) / 4);
         if (nb > c.num_cus * 8) nb = c.num_cus * 8;
-        hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_csrx.as<uint64_t>(), c.a_dec.as<uint64_t>());
+        hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_dec.as<uint64_t>());
     }
     ELBA_REQUIRE(win_lo >= 0 && (win_hi < 0 || (win_lo <= win_hi && win_hi <= M)), ELBA_ERR_INVALID_ARG, "bad row window");
     c.row_lo = win_lo; c.row_hi = win_hi;
@@ -352,7 +371,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
     build_hot_format(c);
-    build_product_schedule(c);
+    build_row_descriptors(c);
     c.have_A = true;
     c.have_B = false;
 }

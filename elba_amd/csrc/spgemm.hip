@@ -70,9 +70,8 @@ struct OvCounters {              // device-side counters, zeroed per call
 struct alignas(32) StageRec { uint4 a, b; };
 
 struct OvParams {
-    const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_csrx; const uint64_t *a_cscp; const uint32_t *a_roworder;
-    const uint64_t *a_prodptr; const uint64_t *a_prod; const uint32_t *a_diag; const uint64_t *a_dec;   // per-row product schedule (matrix.hip)
-    uint32_t packed;         // 1: a_csrx = column address << 32 | rank << 8 | length, columns permuted (a_cscp); 0: address << 32 | length, canonical
+    const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_roworder;
+    const RowHot *a_hdr; const HotDesc *a_hot; const uint64_t *a_dec;   // per-row bounds, per-entry partner ranges, seed decoding by canonical rank (matrix.hip)
     uint32_t M;              // number of rows of A held here
     uint32_t Mcols;          // number of reads overall (partner id range)
     uint32_t row_lo, row_hi; // rows of B computed by this context
@@ -120,7 +119,7 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
         int mytier = -1;
         const uint32_t full = (i >= p.row_lo && i < p.row_hi) ? p.a_rowprod[i] : 0;   // empty rows: row_cnt was zeroed by the host
         if (full != 0) {
-        const uint32_t ub = (uint32_t)(p.a_prodptr[i + 1] - p.a_prodptr[i]);        // scheduled products (the diagonal and, with `half`, mirrored pairs are not)
+        const uint32_t ub = p.a_hdr[i].work;        // products of the row's descriptors (the diagonal and, with `half`, mirrored pairs are not among them)
         prod += full;
         cap += (ub < p.Mcols ? ub : p.Mcols) + 1;
         const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
@@ -466,9 +465,9 @@ void stage_create_seed_matrix(Ctx &c)
 
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
-    p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_csrx = c.a_csrx.as<uint64_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
-    p.a_prodptr = c.a_prodptr.as<uint64_t>(); p.a_prod = c.a_prod.as<uint64_t>(); p.a_diag = c.a_diag.as<uint32_t>(); p.a_dec = c.a_dec.as<uint64_t>();
-    p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>(); p.packed = c.hot_packed ? 1u : 0u;
+    p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
+    p.a_hdr = c.a_hdr.as<RowHot>(); p.a_hot = c.a_hot.as<HotDesc>(); p.a_dec = c.a_dec.as<uint64_t>();
+    p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.half = c.half ? 1u : 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;

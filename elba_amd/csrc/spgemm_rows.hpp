@@ -3,9 +3,11 @@
 // One workgroup per row of B.  What bounds it is instruction issue and dependent LDS/memory round trips at the 8-16 waves per
 // CU the LDS tables allow — not bytes and not LDS throughput (profiles/r01_notes.md) — so the kernel is organised to run few,
 // fully populated instructions per product and to keep few dependent levels per row:
-//   level 0   row id of the NEXT row, this row's bounds / product range / diagonal: one round trip, loaded together;
-//   level 1   schedule items of the row (matrix.hip: one 8-byte item per non-diagonal product), coalesced, prefetched one group ahead;
-//   level 2   PK independent 8-byte gathers per lane (the partner's column entry), then the LDS accumulator updates, two at a time;
+//   level 0   row id of the NEXT row, this row's 32-byte header (bounds of its entries and descriptors): one round trip;
+//   level 1   the row's descriptors (matrix.hip: one 16-byte word per row entry and contiguous range of partner entries in the entry's
+//             column, longest ranges first), one per lane, coalesced, prefetched one trip ahead;
+//   level 2   PK independent 8-byte gathers per lane (the first PK partner entries of the lane's range; longer ranges take further
+//             wave-uniform trips), then the LDS accumulator updates;
 //   level 3   one sweep of the table builds the survivor list (ballot + popcount compaction) and the counts;
 //   level 4   all survivors decode their two seeds in parallel (canonical arrays), then store.
 
@@ -147,8 +149,7 @@ struct Table {
     }
 };
 
-constexpr int PK = 4;      // products per lane in flight (schedule items -> gathers -> accumulator)
-constexpr uint64_t NOITEM = ~0ull;
+constexpr int PK = 4;      // partner entries a lane gathers per descriptor and trip (descriptor -> gathers -> accumulator)
 
 // s = canonical rank of the row entry << fbits | index inside the column.  a_dec[rs + rank] holds the entry's position in the read
 // and the address of its column in a_cscp (still warm in L2: the numeric loop has just gathered it): two loads on two levels per seed
@@ -208,48 +209,36 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     uint32_t fb_seen = 0;
 
     // ---- software pipeline ACROSS rows -------------------------------------------------------------------------------------------
-    // A row costs ~6 dependent memory round trips (id -> bounds -> schedule items -> partner entries ... -> seed decoding, 2 levels)
-    // and only ~12 rows per CU are in flight, so the row loop is latency-bound.  The next row's bounds are therefore loaded while
-    // this row accumulates, its first PK schedule items while this row's table is swept, and their partner entries while this row's
-    // seeds are decoded: a row whose schedule fits one group (PK x BLOCK products — most rows) meets no memory wait before its
-    // table is complete.  `itc` / `ce` are free between the accumulate loop and the end of the row and carry the prefetch.
-    struct RowHdr { uint32_t i, rs, dg_n, dg_min, dg_max; uint64_t ps, pe; };
+    // A row costs ~6 dependent memory round trips (id -> header -> descriptors -> partner entries ... -> seed decoding, 2 levels)
+    // and only ~12 rows per CU are in flight.  The next row's header is therefore loaded while this row accumulates, its first
+    // descriptors while this row's table is swept, and their partner entries while this row's seeds are decoded: a row with at most
+    // BLOCK descriptors meets no memory wait before its table is complete.  `dc` / `ce` are free between the accumulate loop and the
+    // end of the row and carry the prefetch.
+    struct RowHdr { uint32_t i, rs, nnz, hs, nd, work, own0, ownl; };
     auto load_hdr = [&](uint32_t i) {
         RowHdr h;
         i = sfirst(i);
-        h.i = i; h.rs = sfirst(p.a_rowptr[i]); h.ps = sfirst64(p.a_prodptr[i]); h.pe = sfirst64(p.a_prodptr[i + 1]);
-        h.dg_n = sfirst(p.a_diag[3 * i]); h.dg_min = sfirst(p.a_diag[3 * i + 1]); h.dg_max = sfirst(p.a_diag[3 * i + 2]);   // diagonal of B(i,i): structure of A
+        const uint4 *q = reinterpret_cast<const uint4 *>(p.a_hdr + i);
+        const uint4 a = q[0], b = q[1];
+        h.i = i; h.rs = sfirst(a.x); h.nnz = sfirst(a.y); h.hs = sfirst(a.z); h.nd = sfirst(a.w); h.work = sfirst(b.x); h.own0 = sfirst(b.y); h.ownl = sfirst(b.z);
         return h;
     };
-    uint64_t itc[PK], ce[PK];
-    // A group = PK x BLOCK consecutive items of a row's schedule, item k of a lane at offset k*BLOCK + tid.  Offsets are 32-bit and relative
-    // to the row's first item (uniform 64-bit base), and a FULL group needs no per-lane validity selects at all: both matter, the kernel
-    // is bound by instruction issue.
-    constexpr uint32_t GS = (uint32_t)PK * BLOCK;
-    auto load_group = [&](uint64_t *dst, const uint64_t *src, uint32_t at, uint32_t np) {       // item = partner entry address << 32 | s
-        if (at + GS <= np) {
-#pragma unroll
-            for (int k = 0; k < PK; ++k) dst[k] = src[at + (uint32_t)k * BLOCK + tid];
-        } else {
-#pragma unroll
-            for (int k = 0; k < PK; ++k) {
-                const uint32_t r = at + (uint32_t)k * BLOCK + tid;
-                dst[k] = r < np ? src[r] : NOITEM;
-            }
-        }
+    // One descriptor per lane and trip: x = address of the range's first partner entry, y = sequence number of its first product,
+    // z = entries in the range, w = the diagonal's share (run of the row's own read in that column, minus one).  Lanes beyond the row's
+    // last descriptor hold an empty range.  A row's descriptors come longest range first, so the lanes of a wavefront walk (nearly)
+    // equally long ranges and the trips beyond the first PK entries are wave-uniform and rare.
+    uint4 dc = make_uint4(0u, 0u, 0u, 0u);
+    uint64_t ce[PK];
+    auto load_desc = [&](uint32_t hs, uint32_t at, uint32_t nd) {
+        const uint32_t t = at + tid;
+        return t < nd ? reinterpret_cast<const uint4 *>(p.a_hot)[hs + t] : make_uint4(0u, 0u, 0u, 0u);
     };
-    auto load_items = [&](uint64_t ps, uint64_t pe) { load_group(itc, p.a_prod + ps, 0u, (uint32_t)(pe - ps)); };
-    auto gather = [&](bool fullg) {
-        if (fullg) {
+    auto gather = [&](const uint4 &d, uint32_t r0) {       // (entries past the range's end are loaded and ignored: a_cscp ends in guard entries)
 #pragma unroll
-            for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[(uint32_t)(itc[k] >> 32)];
-        } else {
+        for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[d.x + r0 + (uint32_t)k];
+        if (DIAG && (dbg & 2u)) {                                   // ablation: synthetic partner ids
 #pragma unroll
-            for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[(uint32_t)itc[k] != 0xFFFFFFFFu ? (uint32_t)(itc[k] >> 32) : 0u];
-        }
-        if (DIAG && (dbg & 2u)) {                                   // ablation: no gathers, synthetic partner ids
-#pragma unroll
-            for (int k = 0; k < PK; ++k) ce[k] = (uint64_t)(((uint32_t)(itc[k] >> 32) * 2654435761u) % p.Mcols) << 32;
+            for (int k = 0; k < PK; ++k) ce[k] = (uint64_t)(((d.x + r0 + (uint32_t)k) * 2654435761u) % p.Mcols) << 32;
         }
     };
     const uint32_t *queue = p.lists + (size_t)tier * p.M;
@@ -258,18 +247,17 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     if (blockIdx.x < nrows) {
         cur = load_hdr(queue[blockIdx.x]);
         if (blockIdx.x + gridDim.x < nrows) id_n = queue[blockIdx.x + gridDim.x];
-        load_items(cur.ps, cur.pe);
-        gather((uint32_t)(cur.pe - cur.ps) >= GS);
+        dc = load_desc(cur.hs, 0u, cur.nd);
+        gather(dc, 0u);
     }
     for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
         const bool has_n = it + gridDim.x < nrows;
         if (has_n) nxt = load_hdr(id_n);                                        // bounds of the next row; id of the one after it
         const uint32_t id_nn = (unsigned long long)it + 2ull * gridDim.x < nrows ? queue[it + 2 * gridDim.x] : 0u;
-        const uint32_t i = cur.i, rs = cur.rs;
-        const uint64_t ps = cur.ps, pe = cur.pe;
-        const uint32_t ub_i = (uint32_t)(pe - ps);           // scheduled products: bounds the row's distinct partners
+        const uint32_t i = cur.i, rs = cur.rs, hs = cur.hs, nd = cur.nd;
+        const uint32_t ub_i = cur.work;                      // products of the row's descriptors: bounds its distinct partners
         // leaves this row early: the next row's prefetch is issued back to back
-#define ELBA_NEXT_ROW() do { if (has_n) { load_items(nxt.ps, nxt.pe); gather((uint32_t)(nxt.pe - nxt.ps) >= GS); } cur = nxt; id_n = id_nn; } while (0)
+#define ELBA_NEXT_ROW() do { if (has_n) { dc = load_desc(nxt.hs, 0u, nxt.nd); gather(dc, 0u); } cur = nxt; id_n = id_nn; } while (0)
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
             // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
@@ -320,54 +308,61 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         const uint32_t T = tab.size();
         ELBA_STAMP(0);
         for (uint32_t s = tid; s < T; s += BLOCK) { tab.keys[s] = EMPTY; tab.cnt[s] = 0; tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
-        if (tid < 16) misc[tid] = tid == 0 ? cur.dg_n : (tid == 1 ? cur.dg_min : (tid == 2 ? cur.dg_max : 0u));
+        // the diagonal of B(i,i): every row entry pairs with the run of read i in its own column.  Count = nnz + the descriptors' w
+        // (added below); first / last product of the fold = first / last row entry at its own place in its column
+        if (tid < 16) misc[tid] = tid == 0 ? cur.nnz : (tid == 1 ? cur.own0 : (tid == 2 ? (((cur.nnz - 1u) << p.fbits) | cur.ownl) : 0u));
         // (the LDS tiers use barriers that order LDS only: prefetched loads stay in flight across them; the spill tier's table is
         //  global memory and keeps full barriers)
         if (GLOBAL) __syncthreads(); else lds_barrier();
         ELBA_STAMP(1);
 
-        // ---- accumulate: the row's product schedule, ONE non-diagonal product per lane and slot ----
-        // The first group's items and partner entries are already in registers or in flight (prefetched during the previous row).  Per
-        // group: the next PK items are requested, the accumulator is updated two products at a time, then the next gathers are issued.
+        // ---- accumulate: one descriptor per lane and trip ----
+        // The first trip's descriptor and partner entries are already in registers or in flight (prefetched during the previous row).
+        // Per trip: the next descriptor is requested, the accumulator takes the range's products, then the next gathers are issued.
         bool full = false;
-        const uint64_t *src = p.a_prod + ps;
-        const uint32_t np = ub_i;
+        uint32_t dup = 0;
 #pragma unroll 1
-        for (uint32_t t0 = 0; t0 < np; t0 += GS) {
-            uint64_t itn[PK];
-            const bool more = t0 + GS < np, fullg = t0 + GS <= np;
-            if (more) load_group(itn, src, t0 + GS, np);
+        for (uint32_t t0 = 0; t0 < nd; t0 += BLOCK) {
+            uint4 dn = make_uint4(0u, 0u, 0u, 0u);
+            const bool more = t0 + BLOCK < nd;
+            if (more) dn = load_desc(hs, t0 + BLOCK, nd);
             ELBA_STAMP(6);
-            if (DIAG && (dbg & 1u)) {                                   // ablation: gathers only, keep the loads alive
-                uint32_t sink = 0;
+            dup += dc.w;
+            const uint32_t c = dc.z;
+#pragma unroll 1
+            for (uint32_t r0 = 0;;) {
+                if (DIAG && (dbg & 1u)) {                                   // ablation: gathers only, keep the loads alive
+                    uint32_t sink = 0;
 #pragma unroll
-                for (int k = 0; k < PK; ++k) sink ^= (uint32_t)(ce[k] >> 32);
-                if (sink == 0xFFFFFFFFu) misc[15] = 1;
-            } else {
-                if (GLOBAL) {
+                    for (int k = 0; k < PK; ++k) sink ^= (uint32_t)(ce[k] >> 32);
+                    if (sink == 0xFFFFFFFFu) misc[15] = 1;
+                } else if (GLOBAL) {
 #pragma unroll
                     for (int k = 0; k < PK; k += 2) {
-                        if (itc[k] != NOITEM)
-                            tab.insert2((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], (uint32_t)(ce[k + 1] >> 32), (uint32_t)itc[k + 1], itc[k + 1] != NOITEM, full);
+                        if (r0 + (uint32_t)k < c)
+                            tab.insert2((uint32_t)(ce[k] >> 32), dc.y + r0 + (uint32_t)k, (uint32_t)(ce[k + 1] >> 32), dc.y + r0 + (uint32_t)k + 1u, r0 + (uint32_t)k + 1u < c, full);
                     }
-                } else if (fullg) {
-#pragma unroll
-                    for (int k = 0; k < PK; ++k) tab.insert_lds((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], true, full);
                 } else {
 #pragma unroll
-                    for (int k = 0; k < PK; ++k) tab.insert_lds((uint32_t)(ce[k] >> 32), (uint32_t)itc[k], (uint32_t)itc[k] != 0xFFFFFFFFu, full);
+                    for (int k = 0; k < PK; ++k) tab.insert_lds((uint32_t)(ce[k] >> 32), dc.y + r0 + (uint32_t)k, r0 + (uint32_t)k < c, full);
                 }
+                r0 += PK;
+                if (__ballot(c > r0) == 0) break;                            // wave-uniform: ranges longer than PK entries come first in a row
+                gather(dc, r0);
             }
             ELBA_STAMP(8);
             if (tab.abandoned()) {
-                if (tid == 0) { const uint32_t done = t0 + GS; misc[11] = done < np ? done : np; }
+                if (tid == 0) { const uint32_t done = t0 + BLOCK; misc[11] = done < nd ? done : nd; }
                 break;
             }
             if (more) {
-#pragma unroll
-                for (int k = 0; k < PK; ++k) itc[k] = itn[k];
-                gather(t0 + 2 * GS <= np);
+                dc = dn;
+                gather(dc, 0u);
             }
+        }
+        if (__ballot(dup != 0) != 0) {                      // the diagonal's count: nnz (in misc[0] already) + the runs beyond the entry itself
+            dup = wave_sum_u32(dup);
+            if (lane == 0) lds_add32(&misc[0], dup);
         }
         if (GLOBAL) __syncthreads(); else lds_barrier();
         ELBA_STAMP(2);
@@ -376,15 +371,15 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             if (tid == 0) {
                 const uint32_t at = atomicAdd(&p.ctr->tier_count[tier + 1], 1u);
                 p.lists[(size_t)(tier + 1) * p.M + at] = i;
-                // the table filled after `gb_done` of the row's entries: extrapolate its distinct-partner count for the feedback
-                const unsigned long long done = misc[11] ? misc[11] : 1u, all = pe - ps;
+                // the table filled after `done` of the row's descriptors: extrapolate its distinct-partner count for the feedback
+                const unsigned long long all = nd ? nd : 1u, done = misc[11] ? misc[11] : all;
                 lds_add64(w64(W_FB_C), (unsigned long long)misc[9] * all / done); lds_add64(w64(W_FB_U), (unsigned long long)ub_i); lds_add32(&misc[W_FB_N], 1u);
             }
             __syncthreads();
             ELBA_NEXT_ROW();
             continue;
         }
-        if (has_n) load_items(nxt.ps, nxt.pe);       // next row, first group: in flight during the sweep
+        if (has_n) dc = load_desc(nxt.hs, 0u, nxt.nd);       // next row, first trip's descriptors: in flight during the sweep
 
         // ---- level 3: one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
@@ -434,7 +429,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
-        if (has_n) gather((uint32_t)(nxt.pe - nxt.ps) >= GS);    // next row, first group's partner entries: in flight during the decode
+        if (has_n) gather(dc, 0u);    // next row, first trip's partner entries: in flight during the decode
         if (misc[8]) {
             // ---- level 4: all survivors decode their seeds in parallel ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
