@@ -215,49 +215,55 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     // BLOCK descriptors meets no memory wait before its table is complete.  `dc` / `ce` are free between the accumulate loop and the
     // end of the row and carry the prefetch.
     struct RowHdr { uint32_t i, rs, nnz, hs, nd, work, own0, ownl; };
-    auto load_hdr = [&](uint32_t i) {
+    // a header is requested early (two vector loads, nothing waits) and moved to scalar registers where it is first needed
+    uint4 hva = make_uint4(0u, 0u, 0u, 0u), hvb = hva;
+    auto request_hdr = [&](uint32_t i) {
+        const uint4 *q = reinterpret_cast<const uint4 *>(p.a_hdr + sfirst(i));
+        hva = q[0]; hvb = q[1];
+    };
+    auto take_hdr = [&](uint32_t i) {
         RowHdr h;
-        i = sfirst(i);
-        const uint4 *q = reinterpret_cast<const uint4 *>(p.a_hdr + i);
-        const uint4 a = q[0], b = q[1];
-        h.i = i; h.rs = sfirst(a.x); h.nnz = sfirst(a.y); h.hs = sfirst(a.z); h.nd = sfirst(a.w); h.work = sfirst(b.x); h.own0 = sfirst(b.y); h.ownl = sfirst(b.z);
+        h.i = sfirst(i); h.rs = sfirst(hva.x); h.nnz = sfirst(hva.y); h.hs = sfirst(hva.z); h.nd = sfirst(hva.w); h.work = sfirst(hvb.x); h.own0 = sfirst(hvb.y); h.ownl = sfirst(hvb.z);
         return h;
     };
     // One descriptor per lane and trip: x = address of the range's first partner entry, y = sequence number of its first product,
     // z = entries in the range, w = the diagonal's share (run of the row's own read in that column, minus one).  Lanes beyond the row's
     // last descriptor hold an empty range.  A row's descriptors come longest range first, so the lanes of a wavefront walk (nearly)
     // equally long ranges and the trips beyond the first PK entries are wave-uniform and rare.
-    uint4 dc = make_uint4(0u, 0u, 0u, 0u);
-    uint64_t ce[PK];
+    // Two trips are kept in flight: (dc, ce) is the trip being accumulated, (d1, ce1) the one after it.
+    uint4 dc = make_uint4(0u, 0u, 0u, 0u), d1 = dc;
+    uint64_t ce[PK], ce1[PK];
     auto load_desc = [&](uint32_t hs, uint32_t at, uint32_t nd) {
         const uint32_t t = at + tid;
         return t < nd ? reinterpret_cast<const uint4 *>(p.a_hot)[hs + t] : make_uint4(0u, 0u, 0u, 0u);
     };
-    auto gather = [&](const uint4 &d, uint32_t r0) {       // (entries past the range's end are loaded and ignored: a_cscp ends in guard entries)
+    auto gather = [&](uint64_t *out, const uint4 &d, uint32_t r0) {       // (only the lanes whose range reaches entry r0 + k load it: every divergent lane costs the texture unit a cycle)
 #pragma unroll
-        for (int k = 0; k < PK; ++k) ce[k] = p.a_cscp[d.x + r0 + (uint32_t)k];
+        for (int k = 0; k < PK; ++k) out[k] = r0 + (uint32_t)k < d.z ? p.a_cscp[d.x + r0 + (uint32_t)k] : 0ull;
         if (DIAG && (dbg & 2u)) {                                   // ablation: synthetic partner ids
 #pragma unroll
-            for (int k = 0; k < PK; ++k) ce[k] = (uint64_t)(((d.x + r0 + (uint32_t)k) * 2654435761u) % p.Mcols) << 32;
+            for (int k = 0; k < PK; ++k) out[k] = (uint64_t)(((d.x + r0 + (uint32_t)k) * 2654435761u) % p.Mcols) << 32;
         }
     };
     const uint32_t *queue = p.lists + (size_t)tier * p.M;
     RowHdr cur{}, nxt{};
     uint32_t id_n = 0;
     if (blockIdx.x < nrows) {
-        cur = load_hdr(queue[blockIdx.x]);
+        const uint32_t id0 = queue[blockIdx.x];
+        request_hdr(id0);
+        cur = take_hdr(id0);
         if (blockIdx.x + gridDim.x < nrows) id_n = queue[blockIdx.x + gridDim.x];
-        dc = load_desc(cur.hs, 0u, cur.nd);
-        gather(dc, 0u);
+        dc = load_desc(cur.hs, 0u, cur.nd); d1 = load_desc(cur.hs, BLOCK, cur.nd);
+        gather(ce, dc, 0u); gather(ce1, d1, 0u);
     }
     for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
         const bool has_n = it + gridDim.x < nrows;
-        if (has_n) nxt = load_hdr(id_n);                                        // bounds of the next row; id of the one after it
+        if (has_n) request_hdr(id_n);                                           // header of the next row (taken after the accumulate loop); id of the one after it
         const uint32_t id_nn = (unsigned long long)it + 2ull * gridDim.x < nrows ? queue[it + 2 * gridDim.x] : 0u;
         const uint32_t i = cur.i, rs = cur.rs, hs = cur.hs, nd = cur.nd;
         const uint32_t ub_i = cur.work;                      // products of the row's descriptors: bounds its distinct partners
         // leaves this row early: the next row's prefetch is issued back to back
-#define ELBA_NEXT_ROW() do { if (has_n) { dc = load_desc(nxt.hs, 0u, nxt.nd); gather(dc, 0u); } cur = nxt; id_n = id_nn; } while (0)
+#define ELBA_NEXT_ROW() do { if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); d1 = load_desc(nxt.hs, BLOCK, nxt.nd); gather(ce, dc, 0u); gather(ce1, d1, 0u); } cur = nxt; id_n = id_nn; } while (0)
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
             // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
@@ -316,16 +322,17 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         if (GLOBAL) __syncthreads(); else lds_barrier();
         ELBA_STAMP(1);
 
-        // ---- accumulate: one descriptor per lane and trip ----
-        // The first trip's descriptor and partner entries are already in registers or in flight (prefetched during the previous row).
-        // Per trip: the next descriptor is requested, the accumulator takes the range's products, then the next gathers are issued.
+        // ---- accumulate: one descriptor per lane and trip, two trips in flight ----
+        // The first two trips' descriptors and partner entries are already in registers or in flight (prefetched during the previous
+        // row).  Per trip: the descriptor two trips ahead is requested, the accumulator takes this trip's products, the pipeline
+        // advances and the gathers of the trip after next are issued: they have a whole trip's accumulator updates to arrive.
         bool full = false;
         uint32_t dup = 0;
 #pragma unroll 1
         for (uint32_t t0 = 0; t0 < nd; t0 += BLOCK) {
-            uint4 dn = make_uint4(0u, 0u, 0u, 0u);
-            const bool more = t0 + BLOCK < nd;
-            if (more) dn = load_desc(hs, t0 + BLOCK, nd);
+            uint4 d2 = make_uint4(0u, 0u, 0u, 0u);
+            const bool more = t0 + BLOCK < nd, more2 = t0 + 2 * BLOCK < nd;
+            if (more2) d2 = load_desc(hs, t0 + 2 * BLOCK, nd);
             ELBA_STAMP(6);
             dup += dc.w;
             const uint32_t c = dc.z;
@@ -348,7 +355,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 }
                 r0 += PK;
                 if (__ballot(c > r0) == 0) break;                            // wave-uniform: ranges longer than PK entries come first in a row
-                gather(dc, r0);
+                gather(ce, dc, r0);
             }
             ELBA_STAMP(8);
             if (tab.abandoned()) {
@@ -356,8 +363,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 break;
             }
             if (more) {
-                dc = dn;
-                gather(dc, 0u);
+                dc = d1;
+#pragma unroll
+                for (int k = 0; k < PK; ++k) ce[k] = ce1[k];
+                d1 = d2;
+                if (more2) gather(ce1, d1, 0u);
             }
         }
         if (__ballot(dup != 0) != 0) {                      // the diagonal's count: nnz (in misc[0] already) + the runs beyond the entry itself
@@ -379,7 +389,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             ELBA_NEXT_ROW();
             continue;
         }
-        if (has_n) dc = load_desc(nxt.hs, 0u, nxt.nd);       // next row, first trip's descriptors: in flight during the sweep
+        if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); d1 = load_desc(nxt.hs, BLOCK, nxt.nd); }       // next row, first two trips' descriptors: in flight during the sweep
 
         // ---- level 3: one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
@@ -429,7 +439,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
-        if (has_n) gather(dc, 0u);    // next row, first trip's partner entries: in flight during the decode
+        if (has_n) { gather(ce, dc, 0u); gather(ce1, d1, 0u); }    // next row, first two trips' partner entries: in flight during the decode
         if (misc[8]) {
             // ---- level 4: all survivors decode their seeds in parallel ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
@@ -446,8 +456,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 // the partner's row gets the mirrored entry: draw its slot there now (the round trip overlaps the decode's loads);
                 // k_mirror places it once the row pointers are known
                 uint32_t tick = 0xFFFFFFFFu;
-                if (p.half && j != i && j >= p.row_lo && j < p.row_hi) { tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir; }
-                const elba_seed_t v = decode_seed(p, rs, a, b, n, fmask);
+                if (p.half && j != i && j >= p.row_lo && j < p.row_hi) { tick = (DIAG && (dbg & 8u)) ? 0u : atomicAdd(&p.low_cnt[j], 1u); ++nmir; }     // (8: ablation, no ticket atomics)
+                elba_seed_t v;
+                if (DIAG && (dbg & 4u)) { v.q0 = a; v.t0 = b; v.q1 = a; v.t1 = b; v.numshared = (int32_t)n; }          // ablation: no seed decoding loads
+                else v = decode_seed(p, rs, a, b, n, fmask);
                 p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
                 p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);
                 if (j > i) ++nup;
