@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libelba_amd.so")
+    # ELBA_AMD_LIB: another build of the same library (A/B runs of kernel variants); never a different implementation
+    return os.environ.get("ELBA_AMD_LIB") or os.path.join(_HERE, "lib", "libelba_amd.so")
 
 
 class ElbaError(RuntimeError):

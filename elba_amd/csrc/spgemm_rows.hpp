@@ -149,7 +149,14 @@ struct Table {
     }
 };
 
-constexpr int PK = 4;      // partner entries a lane gathers per descriptor and trip (descriptor -> gathers -> accumulator)
+#ifndef ELBA_PIPE
+#define ELBA_PIPE 1    // (A/B on MI355X: 2 needs 93 VGPRs instead of 60 and is 7-10 % SLOWER: the row loop is not bound by the gathers' latency)
+#endif
+#ifndef ELBA_PK
+#define ELBA_PK 4
+#endif
+constexpr int PIPE = ELBA_PIPE;   // descriptor trips in flight per lane (2: the trip after next is gathered while this one accumulates)
+constexpr int PK = ELBA_PK;      // partner entries a lane gathers per descriptor and trip (descriptor -> gathers -> accumulator)
 
 // s = canonical rank of the row entry << fbits | index inside the column.  a_dec[rs + rank] holds the entry's position in the read
 // and the address of its column in a_cscp (still warm in L2: the numeric loop has just gathered it): two loads on two levels per seed
@@ -253,8 +260,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         request_hdr(id0);
         cur = take_hdr(id0);
         if (blockIdx.x + gridDim.x < nrows) id_n = queue[blockIdx.x + gridDim.x];
-        dc = load_desc(cur.hs, 0u, cur.nd); d1 = load_desc(cur.hs, BLOCK, cur.nd);
-        gather(ce, dc, 0u); gather(ce1, d1, 0u);
+        dc = load_desc(cur.hs, 0u, cur.nd); if (PIPE == 2) d1 = load_desc(cur.hs, BLOCK, cur.nd);
+        gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u);
     }
     for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
         const bool has_n = it + gridDim.x < nrows;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         const uint32_t i = cur.i, rs = cur.rs, hs = cur.hs, nd = cur.nd;
         const uint32_t ub_i = cur.work;                      // products of the row's descriptors: bounds its distinct partners
         // leaves this row early: the next row's prefetch is issued back to back
-#define ELBA_NEXT_ROW() do { if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); d1 = load_desc(nxt.hs, BLOCK, nxt.nd); gather(ce, dc, 0u); gather(ce1, d1, 0u); } cur = nxt; id_n = id_nn; } while (0)
+#define ELBA_NEXT_ROW() do { if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE == 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u); } cur = nxt; id_n = id_nn; } while (0)
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
             // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
@@ -332,7 +339,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         for (uint32_t t0 = 0; t0 < nd; t0 += BLOCK) {
             uint4 d2 = make_uint4(0u, 0u, 0u, 0u);
             const bool more = t0 + BLOCK < nd, more2 = t0 + 2 * BLOCK < nd;
-            if (more2) d2 = load_desc(hs, t0 + 2 * BLOCK, nd);
+            if (PIPE == 2) { if (more2) d2 = load_desc(hs, t0 + 2 * BLOCK, nd); }
+            else if (more) d2 = load_desc(hs, t0 + BLOCK, nd);
             ELBA_STAMP(6);
             dup += dc.w;
             const uint32_t c = dc.z;
@@ -363,11 +371,16 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 break;
             }
             if (more) {
-                dc = d1;
+                if (PIPE == 2) {
+                    dc = d1;
 #pragma unroll
-                for (int k = 0; k < PK; ++k) ce[k] = ce1[k];
-                d1 = d2;
-                if (more2) gather(ce1, d1, 0u);
+                    for (int k = 0; k < PK; ++k) ce[k] = ce1[k];
+                    d1 = d2;
+                    if (more2) gather(ce1, d1, 0u);
+                } else {
+                    dc = d2;
+                    gather(ce, dc, 0u);
+                }
             }
         }
         if (__ballot(dup != 0) != 0) {                      // the diagonal's count: nnz (in misc[0] already) + the runs beyond the entry itself
@@ -389,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             ELBA_NEXT_ROW();
             continue;
         }
-        if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); d1 = load_desc(nxt.hs, BLOCK, nxt.nd); }       // next row, first two trips' descriptors: in flight during the sweep
+        if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE == 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); }       // next row, first two trips' descriptors: in flight during the sweep
 
         // ---- level 3: one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
@@ -439,7 +452,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
-        if (has_n) { gather(ce, dc, 0u); gather(ce1, d1, 0u); }    // next row, first two trips' partner entries: in flight during the decode
+        if (has_n) { gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u); }    // next row, first two trips' partner entries: in flight during the decode
         if (misc[8]) {
             // ---- level 4: all survivors decode their seeds in parallel ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
