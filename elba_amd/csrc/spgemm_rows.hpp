@@ -255,18 +255,26 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     const uint32_t *queue = p.lists + (size_t)tier * p.M;
     RowHdr cur{}, nxt{};
     uint32_t id_n = 0;
-    if (blockIdx.x < nrows) {
-        const uint32_t id0 = queue[blockIdx.x];
+    // The queue is (roughly) in descending-work order and every workgroup takes a static share of it.  With a plain grid stride the
+    // first workgroup would get the heaviest row of EVERY round; taking the rounds alternately forwards and backwards (snake order)
+    // evens the shares out without any run-time queueing.
+#ifndef ELBA_SNAKE
+#define ELBA_SNAKE 1
+#endif
+    const uint32_t G = gridDim.x, bx = blockIdx.x;
+    auto qidx = [&](uint32_t r) -> unsigned long long { return (unsigned long long)r * G + ((ELBA_SNAKE && (r & 1u)) ? (G - 1u - bx) : bx); };
+    if (qidx(0) < nrows) {
+        const uint32_t id0 = queue[qidx(0)];
         request_hdr(id0);
         cur = take_hdr(id0);
-        if (blockIdx.x + gridDim.x < nrows) id_n = queue[blockIdx.x + gridDim.x];
+        if (qidx(1) < nrows) id_n = queue[qidx(1)];
         dc = load_desc(cur.hs, 0u, cur.nd); if (PIPE == 2) d1 = load_desc(cur.hs, BLOCK, cur.nd);
         gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u);
     }
-    for (uint32_t it = blockIdx.x; it < nrows; it += gridDim.x) {
-        const bool has_n = it + gridDim.x < nrows;
+    for (uint32_t rnd = 0; qidx(rnd) < nrows; ++rnd) {
+        const bool has_n = qidx(rnd + 1) < nrows;
         if (has_n) request_hdr(id_n);                                           // header of the next row (taken after the accumulate loop); id of the one after it
-        const uint32_t id_nn = (unsigned long long)it + 2ull * gridDim.x < nrows ? queue[it + 2 * gridDim.x] : 0u;
+        const uint32_t id_nn = qidx(rnd + 2) < nrows ? queue[qidx(rnd + 2)] : 0u;
         const uint32_t i = cur.i, rs = cur.rs, hs = cur.hs, nd = cur.nd;
         const uint32_t ub_i = cur.work;                      // products of the row's descriptors: bounds its distinct partners
         // leaves this row early: the next row's prefetch is issued back to back
@@ -320,13 +328,14 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         const uint32_t T = tab.size();
         ELBA_STAMP(0);
+        if (!(DIAG && (dbg & 64u)))                      // (64: ablation, no table initialisation)
         for (uint32_t s = tid; s < T; s += BLOCK) { tab.keys[s] = EMPTY; tab.cnt[s] = 0; tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
         // the diagonal of B(i,i): every row entry pairs with the run of read i in its own column.  Count = nnz + the descriptors' w
         // (added below); first / last product of the fold = first / last row entry at its own place in its column
         if (tid < 16) misc[tid] = tid == 0 ? cur.nnz : (tid == 1 ? cur.own0 : (tid == 2 ? (((cur.nnz - 1u) << p.fbits) | cur.ownl) : 0u));
         // (the LDS tiers use barriers that order LDS only: prefetched loads stay in flight across them; the spill tier's table is
         //  global memory and keeps full barriers)
-        if (GLOBAL) __syncthreads(); else lds_barrier();
+        if (GLOBAL) __syncthreads(); else if (!(DIAG && (dbg & 512u))) lds_barrier();      // (512: ablation, no workgroup barriers in the row loop)
         ELBA_STAMP(1);
 
         // ---- accumulate: one descriptor per lane and trip, two trips in flight ----
@@ -387,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             dup = wave_sum_u32(dup);
             if (lane == 0) lds_add32(&misc[0], dup);
         }
-        if (GLOBAL) __syncthreads(); else lds_barrier();
+        if (GLOBAL) __syncthreads(); else if (!(DIAG && (dbg & 512u))) lds_barrier();
         ELBA_STAMP(2);
         if (tab.abandoned()) {
             // the optimistic table was too small: hand the row to the next tier (its kernel starts after this one ends)
@@ -406,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
 
         // ---- level 3: one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
-        for (uint32_t b0 = 0; b0 < T; b0 += BLOCK) {                       // wave-uniform trip count: ballots are safe
+        for (uint32_t b0 = (DIAG && (dbg & 128u)) ? T : 0u; b0 < T; b0 += BLOCK) {                       // wave-uniform trip count: ballots are safe  (128: ablation, no sweep)
             const uint32_t s0 = b0 + tid;
             bool keep = false;
             if (s0 < T) {
@@ -423,7 +432,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         yraw = wave_sum_u32(yraw);
         if (lane == 0 && yraw) atomicAdd(&misc[5], yraw);
-        if (GLOBAL) __syncthreads(); else lds_barrier();
+        if (GLOBAL) __syncthreads(); else if (!(DIAG && (dbg & 512u))) lds_barrier();
         ELBA_STAMP(3);
         if (tid == 0) {
             const uint32_t dcount = misc[0];
@@ -450,7 +459,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;
             }
         }
-        lds_barrier();          // row_cnt / row_off stores stay in flight
+        if (!(DIAG && (dbg & 512u))) lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
         if (has_n) { gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u); }    // next row, first two trips' partner entries: in flight during the decode
         if (misc[8]) {
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             uint32_t nup = 0, mx = 0, nmir = 0;
             // the diagonal entry (its count / min / max come with A) is decoded in the same pass, by the lane after the last survivor
             const uint32_t hasd = misc[0] >= 2 ? 1u : 0u;
-            for (uint32_t t = tid; t < ysurv + hasd; t += BLOCK) {
+            for (uint32_t t = (DIAG && (dbg & 256u)) ? ysurv + hasd : tid; t < ysurv + hasd; t += BLOCK) {      // (256: ablation, no decode / staging stores)
                 uint32_t j = i, n = misc[0], a = misc[1], b = misc[2];
                 if (t < ysurv) {
                     const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)list16[t];
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             if (nmir) lds_add64(w64(W_MIR), (unsigned long long)nmir);
             if (mx) lds_max32(&misc[W_MX], mx);
         }
-        lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
+        if (!(DIAG && (dbg & 512u))) lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
         cur = nxt; id_n = id_nn;
         ELBA_STAMP(5);
     }
