@@ -4,6 +4,6 @@ The product is libelba_amd.so (hand-written HIP for gfx950 behind the C ABI of i
 ctypes binding used by the tests, the benchmark and the multi-GPU driver.  There is no CPU fallback: importing works anywhere,
 but creating an engine without the built library or without a GPU raises.
 """
-from .capi import (ElbaError, Engine, Seed, SEED_DTYPE, lib_path, load_library, synth_reads, SynthCfg)  # noqa: F401
+from .capi import (ElbaError, Engine, Seed, SEED_DTYPE, OVERLAP_DTYPE, lib_path, load_library, synth_reads, SynthCfg)  # noqa: F401
 
-__all__ = ["ElbaError", "Engine", "Seed", "SEED_DTYPE", "lib_path", "load_library", "synth_reads", "SynthCfg"]
+__all__ = ["ElbaError", "Engine", "Seed", "SEED_DTYPE", "OVERLAP_DTYPE", "lib_path", "load_library", "synth_reads", "SynthCfg"]

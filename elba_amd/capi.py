@@ -46,6 +46,20 @@ class OverlapStats(C.Structure):
                 ("ms_total", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float), ("ms_finalize", C.c_float)]
 
 
+class AlignStats(C.Structure):
+    _fields_ = [("nalignments", C.c_int64), ("seeds_rejected", C.c_int64), ("passed", C.c_int64), ("contained", C.c_int64),
+                ("extensions_strided", C.c_int64), ("cells", C.c_int64), ("ms_total", C.c_float), ("ms_extend", C.c_float)]
+
+
+class Overlaps(C.Structure):
+    _fields_ = [("n", C.c_int64), ("rows", C.c_void_p), ("cols", C.c_void_p), ("vals", C.c_void_p)]
+
+
+# elba_overlap_t (include/elba_amd.h): the fields Overlap::extend_overlap fills (src/Overlap.cpp:24-73)
+OVERLAP_DTYPE = np.dtype([("begQ", "<i4"), ("begT", "<i4"), ("endQ", "<i4"), ("endT", "<i4"), ("score", "<i4"), ("suffix", "<i4"), ("suffixT", "<i4"),
+                          ("direction", "i1"), ("directionT", "i1"), ("rc", "u1"), ("passed", "u1"), ("containedQ", "u1"), ("containedT", "u1"), ("kind", "u1"), ("reserved", "u1")])
+
+
 class Dcsc(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("nzc", C.c_int64),
                 ("jc", C.c_void_p), ("cp", C.c_void_p), ("ir", C.c_void_p), ("numx", C.c_void_p)]
@@ -110,6 +124,9 @@ def load_library():
     L.elba_create_kmer_matrix.restype = i32; L.elba_create_kmer_matrix.argtypes = [vp, C.POINTER(MatrixStats)]
     L.elba_set_kmer_matrix.restype = i32; L.elba_set_kmer_matrix.argtypes = [vp, i64, i64, i64, vp, vp, vp, C.POINTER(MatrixStats)]
     L.elba_create_seed_matrix.restype = i32; L.elba_create_seed_matrix.argtypes = [vp, C.POINTER(OverlapStats)]
+    L.elba_align_seeds.restype = i32; L.elba_align_seeds.argtypes = [vp, i32, i32, i32, i32, C.POINTER(AlignStats)]
+    L.elba_export_overlaps.restype = i32; L.elba_export_overlaps.argtypes = [vp, C.POINTER(Overlaps)]
+    L.elba_free_overlaps.restype = None; L.elba_free_overlaps.argtypes = [C.POINTER(Overlaps)]
     L.elba_export_dcsc.restype = i32; L.elba_export_dcsc.argtypes = [vp, i64, i64, i64, i64, C.POINTER(Dcsc)]
     L.elba_free_dcsc.restype = None; L.elba_free_dcsc.argtypes = [C.POINTER(Dcsc)]
     L.elba_export_csr.restype = i32; L.elba_export_csr.argtypes = [vp, i64, i64, C.POINTER(Csr)]
@@ -220,6 +237,20 @@ class Engine:
         st = OverlapStats()
         self._check(self.L.elba_create_seed_matrix(self.h, C.byref(st)))
         return _stats(st)
+
+    def align_seeds(self, mat=1, mis=-1, gap=-1, dropoff=15):
+        """PairwiseAlignment (src/PairwiseAlignment.cpp:5-106) on one rank: x-drop from seeds[0] of every stored B(i,j), i < j."""
+        st = AlignStats()
+        self._check(self.L.elba_align_seeds(self.h, mat, mis, gap, dropoff, C.byref(st)))
+        return _stats(st)
+
+    def export_overlaps(self):
+        o = Overlaps()
+        self._check(self.L.elba_export_overlaps(self.h, C.byref(o)))
+        try:
+            return dict(n=o.n, rows=_copy(o.rows, o.n, np.int64), cols=_copy(o.cols, o.n, np.int64), vals=_copy(o.vals, o.n, OVERLAP_DTYPE))
+        finally:
+            self.L.elba_free_overlaps(C.byref(o))
 
     # --- outputs ---
     def export_csr(self, row_lo=0, row_hi=None):

@@ -1,0 +1,452 @@
+// align.hip — x-drop seed-and-extend of every candidate pair of B, on the GPU (the step right after the path).
+//
+// Replaces PairwiseAlignment's loop (src/PairwiseAlignment.cpp:28-95) on one rank: every stored B(i,j) with i < j is aligned from
+// seeds[0] by xdrop_aligner (src/XDropAligner.cpp:224-282), classified (classify_alignment, :7-44) and turned into the fields of
+// Overlap that extend_overlap fills (src/Overlap.cpp:24-73).  Results are bit-identical to the reference's: the antidiagonal recurrence,
+// its undef sentinel, the band trimming rules and the "last column of the antidiagonal that beats the best of the antidiagonals before
+// it" choice of the extension's end are those of _extend_seed_one_direction (src/XDropAligner.cpp:46-208).
+//
+// Mapping to CDNA4: one WAVEFRONT per extension (left and right extensions of a pair are independent tasks), one LANE per column of
+// the current antidiagonal.  The three antidiagonals of the recurrence live in registers (two carried, one computed); the neighbour
+// column arrives through a DPP wave shift (one cycle, no LDS); the band's bounds, the best score and the antidiagonal number are
+// wave-uniform scalars; the band trimming loops of the reference become two ballots and a count-leading/trailing-zeros each.  The
+// bases of both reads are unpacked from the 2-bit DnaBuffer layout into two 256-entry LDS rings per wavefront, 64 bases per refill, so
+// the recurrence itself touches no global memory.  Lane l holds column cbase + l; when the band reaches lane 63 the window slides to
+// the band's lower edge.  A band wider than 63 columns (large x-drop values) leaves the fast kernel and is redone by a strided kernel
+// that keeps the antidiagonals in HBM — capacity is a performance tier, never a correctness limit.
+//
+// Integer work throughout (scores are int32, like the reference's); no MFMA.
+#include "common.hpp"
+
+namespace elba {
+
+namespace {
+
+struct AlnTask {               // one candidate pair, prepared by k_aln_prepare
+    uint32_t i, j;             // rows of B: query read i, target read j (i < j)
+    int32_t begQ, endQ;        // seed in the query
+    int32_t begT, endT;        // seed in the target's oriented coordinates (reverse-complemented when rc)
+    int32_t valid, rc;         // xdrop_aligner's prologue: seed accepted / orientation
+};
+struct AlnExt { int32_t score, col, row, overflow; };       // best_ext_score / best_ext_col / best_ext_row of one direction
+
+struct AlnParams {
+    const uint8_t *packed; const uint64_t *byte_off; const uint32_t *len;
+    const int64_t *b_rowptr; const uint32_t *b_col; const elba_seed_t *b_val;
+    uint32_t M, row_lo, row_hi;
+    int32_t k, mat, mis, gap, dropoff;
+    uint32_t *cnt; const int64_t *taskptr;
+    AlnTask *tasks; AlnExt *ext; int64_t ntasks;
+    unsigned int *next;             // work queue cursor
+    unsigned int *ofl_count; uint32_t *ofl_list;     // extensions whose band outgrew the wavefront
+    int *scratch; unsigned long long scratch_stride;  // strided kernel: three antidiagonals per wavefront
+    unsigned long long *cells;      // DP cells computed (statistics)
+    int64_t *out_rows, *out_cols; elba_overlap_t *out;
+};
+
+__device__ __forceinline__ int base_at(const uint8_t *mem, uint32_t i) { return (mem[i >> 2] >> (6 - 2 * (i & 3))) & 3; }    // src/DnaSeq.cpp:48-54
+
+// ---- tasks: the strict upper triangle of B in CSR order (src/PairwiseAlignment.cpp:52 on one rank) --------------------------------
+__global__ void k_aln_count(AlnParams p)
+{
+    const uint32_t i = p.row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.row_hi) return;
+    uint32_t n = 0;
+    for (int64_t e = p.b_rowptr[i]; e < p.b_rowptr[i + 1]; ++e) n += p.b_col[e] > i ? 1u : 0u;
+    p.cnt[i - p.row_lo] = n;
+}
+
+// xdrop_aligner's prologue (src/XDropAligner.cpp:228-256): bounds, the (0,0) rejection, orientation from the middle base, seed check
+__global__ void k_aln_prepare(AlnParams p)
+{
+    const uint32_t i = p.row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.row_hi) return;
+    int64_t at = p.taskptr[i - p.row_lo];
+    const uint8_t *q = p.packed + p.byte_off[i];
+    const int lenQ = (int)p.len[i];
+    for (int64_t e = p.b_rowptr[i]; e < p.b_rowptr[i + 1]; ++e) {
+        const uint32_t j = p.b_col[e];
+        if (j <= i) continue;
+        const uint8_t *t = p.packed + p.byte_off[j];
+        const int lenT = (int)p.len[j];
+        const int begQ = (int)p.b_val[e].q0, begT = (int)p.b_val[e].t0, k = p.k;
+        AlnTask tk{};
+        tk.i = i; tk.j = j;
+        bool ok = !(begQ < 0 || begQ + k > lenQ) && !(begT < 0 || begT + k > lenT) && !(begQ == 0 && begT == 0);
+        if (ok) {
+            const bool rc = base_at(q, (uint32_t)(begQ + (k >> 1))) != base_at(t, (uint32_t)(begT + (k >> 1)));
+            for (int x = 0; x < k && ok; ++x) {
+                // rc: revcomp_at(lenT - begT - k + x) = 3 - T[lenT - 1 - (lenT - begT - k + x)] = 3 - T[begT + k - 1 - x]   (include/DnaSeq.hpp:119)
+                const int tb = rc ? 3 - base_at(t, (uint32_t)(begT + k - 1 - x)) : base_at(t, (uint32_t)(begT + x));
+                ok = base_at(q, (uint32_t)(begQ + x)) == tb;
+            }
+            tk.rc = rc ? 1 : 0;
+            tk.begQ = begQ; tk.endQ = begQ + k;
+            tk.begT = rc ? lenT - begT - k : begT; tk.endT = tk.begT + k;
+        }
+        tk.valid = ok ? 1 : 0;
+        p.tasks[at++] = tk;
+    }
+}
+
+// ---- one direction of one pair -------------------------------------------------------------------------------------------------
+struct ExtGeom {                 // wave-uniform description of an extension
+    const uint8_t *q, *t;
+    int lenT, rc, left;
+    int cols, rows;              // lenQ_ext + 1, lenT_ext + 1
+    int offQ, offT;              // right: endQ / endT;  left: begQ / begT
+};
+// logical column c in [1, cols) -> base of the query; logical row r in [1, rows) -> base of the (oriented) target   (src/XDropAligner.cpp:113-117)
+__device__ __forceinline__ int q_base(const ExtGeom &g, int c) { return base_at(g.q, (uint32_t)(g.left ? g.offQ - c : g.offQ + c - 1)); }
+__device__ __forceinline__ int t_base(const ExtGeom &g, int r)
+{
+    const int posT = g.left ? g.offT - r : g.offT + r - 1;
+    return g.rc ? 3 - base_at(g.t, (uint32_t)(g.lenT - 1 - posT)) : base_at(g.t, (uint32_t)posT);
+}
+
+__device__ __forceinline__ bool ext_geometry(const AlnParams &p, const AlnTask &tk, int left, ExtGeom &g)
+{
+    g.q = p.packed + p.byte_off[tk.i]; g.t = p.packed + p.byte_off[tk.j];
+    const int lenQ = (int)p.len[tk.i];
+    g.lenT = (int)p.len[tk.j]; g.rc = tk.rc; g.left = left;
+    const int lenQ_ext = left ? tk.begQ : lenQ - tk.endQ, lenT_ext = left ? tk.begT : g.lenT - tk.endT;
+    g.cols = lenQ_ext + 1; g.rows = lenT_ext + 1;
+    g.offQ = left ? tk.begQ : tk.endQ; g.offT = left ? tk.begT : tk.endT;
+    return !(g.rows == 1 || g.cols == 1);
+}
+
+__device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+
+constexpr int RING = 256;        // bases per LDS ring (power of two): the band's span (<= 64) + one refill (64) fit with room to spare
+constexpr int ALN_WAVES = 4;     // independent wavefronts per workgroup
+
+// The fast kernel: band <= 63 columns.  Every scalar below is wave-uniform.
+__global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p)
+{
+    __shared__ uint8_t ring[ALN_WAVES][2][RING];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint8_t *rq = ring[w][0], *rt = ring[w][1];
+    unsigned long long cells = 0;
+    const unsigned int ntask2 = (unsigned int)(2 * p.ntasks);
+    for (;;) {
+        unsigned int tk2 = 0;
+        if (lane == 0) tk2 = atomicAdd(p.next, 1u);
+        tk2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk2);
+        if (tk2 >= ntask2) break;
+        const AlnTask tk = p.tasks[tk2 >> 1];
+        const int left = (int)(tk2 & 1u);
+        AlnExt res{0, 0, 0, 0};
+        ExtGeom g;
+        if (!tk.valid || !ext_geometry(p, tk, left, g)) { if (lane == 0) p.ext[tk2] = res; continue; }
+        const int cols = g.cols, rows = g.rows;
+        const int int_min = (int)0x80000000;
+        const int len2 = 2 * (cols > rows ? cols : rows);
+        const int min_err = int_min / len2;
+        const int gap = p.gap > min_err ? p.gap : min_err, mis = p.mis > min_err ? p.mis : min_err, mat = p.mat, dropoff = p.dropoff;
+        const int undef = int_min - gap - mis;
+        // antidiagonal 0 = {col 0: 0}; antidiagonal 1 = {col 0, col 1: gap, or undef when one gap already drops off}   (:70-77)
+        int cbase = 0;
+        const int g1 = (-gap > dropoff) ? undef : gap;
+        int A1 = lane == 0 ? 0 : undef;                  // antidiagonal n-2, column cbase + lane
+        int A2 = lane <= 1 ? g1 : undef;                 // antidiagonal n-1
+        int min_col = 1, max_col = 2, hi2 = 1;           // hi2: last stored column of antidiagonal n-1
+        int best = 0, n = 1;
+        int best_col = 0, best_row = 0, best_score = 0;
+        int qfill = 0, tfill = 0;                        // logical columns / rows unpacked into the rings so far
+        bool overflow = false;
+        unsigned long long mycells = 0;                  // (an extension that leaves for the strided kernel is counted there)
+        while (min_col < max_col) {
+            ++n;
+            const int off3 = min_col - 1, top_max = max_col;      // this antidiagonal is stored for columns [off3, top_max]   (:93-96)
+            if (top_max > cbase + 63) {                  // slide the window down to the band's lower edge
+                const int s = off3 - cbase;
+                if (s <= 0) { overflow = true; break; }
+                const int src = lane + s;
+                const int a1 = __shfl(A1, src & 63, 64), a2 = __shfl(A2, src & 63, 64);
+                A1 = src < 64 ? a1 : undef; A2 = src < 64 ? a2 : undef;
+                cbase += s;
+                if (top_max > cbase + 63) { overflow = true; break; }
+            }
+            // bases: columns up to top_max - 1, rows up to n - min_col
+            while (qfill < top_max - 1) {
+                const int c = qfill + 1 + lane;
+                if (c < cols) rq[c & (RING - 1)] = (uint8_t)q_base(g, c);
+                qfill += 64;
+            }
+            while (tfill < n - min_col) {
+                const int r = tfill + 1 + lane;
+                if (r < rows) rt[r & (RING - 1)] = (uint8_t)t_base(g, r);
+                tfill += 64;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            mycells += (unsigned long long)(top_max - min_col);
+            const int c = cbase + lane;
+            const bool inr = c >= min_col && c < top_max;
+            const int up = wave_shr1(A2, undef), dg = wave_shr1(A1, undef);        // column c - 1 of antidiagonals n-1, n-2
+            const int qb = rq[c & (RING - 1)], tb = rt[(n - c) & (RING - 1)];
+            int temp = (up > A2 ? up : A2) + gap;
+            const int t2 = dg + (qb == tb ? mat : mis);
+            temp = t2 > temp ? t2 : temp;
+            const bool keep = temp >= best - dropoff;
+            int A3 = (inr && keep) ? temp : undef;
+            const bool gi = (long long)n * gap > (long long)best - dropoff;          // the border cells may still be reached by gaps alone (:98-102)
+            if (c == off3) A3 = (gi && off3 == 0) ? n * gap : undef;
+            if (c == top_max) A3 = (gi && n == top_max) ? n * gap : undef;
+            // the extension ends at the LAST column of this antidiagonal that beats the best of the antidiagonals before it (:136-142)
+            const unsigned long long beat = __ballot(inr && temp > best);
+            if (beat != 0) {
+                const int l = 63 - __builtin_clzll(beat);
+                best_col = cbase + l; best_row = n - best_col;
+                best_score = __builtin_amdgcn_readlane(A3, l);
+                const int m = wave_max_i32((inr && keep) ? temp : int_min);
+                best = m > best ? m : best;
+            }
+            // band trimming (:147-156): the first column that is alive on this or the previous antidiagonal ...
+            {
+                const bool dead = (c <= top_max) && A3 == undef && (c - 1 <= hi2) && up == undef;
+                const unsigned long long stop = __ballot(c >= min_col && !dead);
+                min_col = stop ? cbase + (int)__builtin_ctzll(stop) : cbase + 64;
+            }
+            // ... and one past the last
+            {
+                const unsigned long long alive = __ballot(c >= off3 && c < top_max && !(A3 == undef && A2 == undef));
+                max_col = alive ? cbase + 64 - (int)__builtin_clzll(alive) : off3;
+            }
+            ++max_col;
+            if (min_col < n + 2 - rows) min_col = n + 2 - rows;
+            if (max_col > cols) max_col = cols;
+            hi2 = top_max;
+            A1 = A2; A2 = A3;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!overflow) cells += mycells;
+        res.score = best_score; res.col = best_col; res.row = best_row; res.overflow = overflow ? 1 : 0;
+        if (lane == 0) {
+            p.ext[tk2] = res;
+            if (overflow) { const unsigned int at = atomicAdd(p.ofl_count, 1u); p.ofl_list[at] = tk2; }
+        }
+    }
+    if (lane == 0 && cells) atomicAdd(p.cells, cells);
+}
+
+
+// The strided kernel: any band width.  One wavefront per extension that left the fast kernel; the three antidiagonals live in HBM
+// (indexed by absolute column, read and written with agent-scope accesses: lanes exchange cells through L2), lanes stride over the
+// band.  Same recurrence, same trimming, statement for statement (src/XDropAligner.cpp:79-160).
+__device__ __forceinline__ int ld_cell(const int *a, int c) { return __hip_atomic_load(&a[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_cell(int *a, int c, int v) { __hip_atomic_store(&a[c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__global__ __launch_bounds__(64) void k_xdrop_strided(AlnParams p)
+{
+    const int lane = threadIdx.x & 63;
+    const unsigned int nofl = *p.ofl_count;
+    unsigned long long cells = 0;
+    for (unsigned int it = blockIdx.x; it < nofl; it += gridDim.x) {
+        const unsigned int tk2 = p.ofl_list[it];
+        const AlnTask tk = p.tasks[tk2 >> 1];
+        const int left = (int)(tk2 & 1u);
+        ExtGeom g;
+        ext_geometry(p, tk, left, g);
+        const int cols = g.cols, rows = g.rows;
+        const int int_min = (int)0x80000000;
+        const int len2 = 2 * (cols > rows ? cols : rows);
+        const int min_err = int_min / len2;
+        const int gap = p.gap > min_err ? p.gap : min_err, mis = p.mis > min_err ? p.mis : min_err, mat = p.mat, dropoff = p.dropoff;
+        const int undef = int_min - gap - mis;
+        int *ad1 = p.scratch + (size_t)(3 * blockIdx.x + 0) * p.scratch_stride;
+        int *ad2 = p.scratch + (size_t)(3 * blockIdx.x + 1) * p.scratch_stride;
+        int *ad3 = p.scratch + (size_t)(3 * blockIdx.x + 2) * p.scratch_stride;
+        // (cells outside an antidiagonal's stored range [off, top_max] are never read — by the reference's own index bounds — so the
+        //  arrays are neither cleared nor resized when they are recycled)
+        const int g1 = (-gap > dropoff) ? undef : gap;
+        if (lane == 0) { st_cell(ad2, 0, 0); st_cell(ad3, 0, g1); st_cell(ad3, 1, g1); }
+        __builtin_amdgcn_s_waitcnt(0);
+        int min_col = 1, max_col = 2, hi2 = 0, hi3 = 1;
+        int best = 0, n = 1, best_col = 0, best_row = 0, best_score = 0;
+        while (min_col < max_col) {
+            ++n;
+            { int *tb = ad1; ad1 = ad2; ad2 = ad3; ad3 = tb; }
+            hi2 = hi3;
+            const int off3 = min_col - 1, top_max = max_col;
+            hi3 = top_max;
+            cells += (unsigned long long)(top_max - min_col);
+            const bool gi = (long long)n * gap > (long long)best - dropoff;
+            if (lane == 0) {
+                st_cell(ad3, off3, (gi && off3 == 0) ? n * gap : undef);
+                st_cell(ad3, top_max, (gi && n == top_max) ? n * gap : undef);
+            }
+            int my_col = -1, my_score = 0, my_max = int_min;
+            for (int c = min_col + lane; c < top_max; c += 64) {
+                const int up = ld_cell(ad2, c - 1), lf = ld_cell(ad2, c), dg = ld_cell(ad1, c - 1);
+                int temp = (up > lf ? up : lf) + gap;
+                const int t2 = dg + (q_base(g, c) == t_base(g, n - c) ? mat : mis);
+                temp = t2 > temp ? t2 : temp;
+                const bool keep = temp >= best - dropoff;
+                st_cell(ad3, c, keep ? temp : undef);
+                if (keep && temp > my_max) my_max = temp;
+                if (temp > best) { my_col = c; my_score = temp; }          // ascending c per lane: the last one stays
+            }
+            // last column over the whole band that beat `best`: maximum of the lanes' candidates
+            int bc = my_col;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(bc, d, 64); bc = o > bc ? o : bc; }
+            if (bc >= 0) {
+                const unsigned long long who = __ballot(my_col == bc);
+                best_col = bc; best_row = n - bc;
+                best_score = __builtin_amdgcn_readlane(my_score, (int)__builtin_ctzll(who));
+                const int m = wave_max_i32(my_max);
+                best = m > best ? m : best;
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            // trimming, as written in the reference (every lane runs the same scalar loops)
+            while (min_col <= top_max && ld_cell(ad3, min_col) == undef && min_col - 1 <= hi2 && ld_cell(ad2, min_col - 1) == undef) ++min_col;
+            while (max_col - off3 > 0 && ld_cell(ad3, max_col - 1) == undef && ld_cell(ad2, max_col - 1) == undef) --max_col;
+            ++max_col;
+            if (min_col < n + 2 - rows) min_col = n + 2 - rows;
+            if (max_col > cols) max_col = cols;
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+        }
+        if (lane == 0) p.ext[tk2] = AlnExt{best_score, best_col, best_row, 0};
+    }
+    if (lane == 0 && cells) atomicAdd(p.cells, cells);
+}
+
+// ---- xdrop_aligner's epilogue (:258-281), classify_alignment (:7-44), Overlap::extend_overlap (src/Overlap.cpp:24-73) ---------------
+__global__ void k_aln_combine(AlnParams p)
+{
+    const int64_t a = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (a >= p.ntasks) return;
+    const AlnTask tk = p.tasks[a];
+    const int lenQ = (int)p.len[tk.i], lenT = (int)p.len[tk.j];
+    elba_overlap_t o{};
+    o.direction = -1; o.directionT = -1;
+    int begQ = 0, endQ = 0, begT = 0, endT = 0, score = -1, rc = 0;          // XSeed's defaults when the seed is rejected (include/XDropAligner.hpp:22)
+    if (tk.valid) {
+        const AlnExt l = p.ext[2 * a + 1], r = p.ext[2 * a];
+        const int begQ_ext = tk.begQ - l.col, begT_ext = tk.begT - l.row;
+        const int endQ_ext = tk.endQ + r.col, endT_ext = tk.endT + r.row;
+        rc = tk.rc;
+        score = l.score + r.score + p.mat * p.k;
+        begQ = begQ_ext; endQ = endQ_ext;
+        begT = rc ? lenT - endT_ext : begT_ext;
+        endT = rc ? lenT - begT_ext : endT_ext;
+    }
+    int kind = 0;
+    {
+        if (score > 0) {
+            const int begTr = rc ? lenT - endT : begT, endTr = rc ? lenT - begT : endT;
+            const int maplen = ((endT - begT) + (endQ - begQ)) / 2;
+            const int overhang = (begQ < begTr ? begQ : begTr) + ((lenQ - endQ) < (lenT - endTr) ? (lenQ - endQ) : (lenT - endTr));
+            const int overlap = maplen + overhang;
+            const float my_thr = (float)((1.0 - 0.1) * (0.99 * overlap));
+            if (begQ <= begTr && lenQ - endQ <= lenT - endTr) kind = 1;
+            else if (begQ >= begTr && lenQ - endQ >= lenT - endTr) kind = 2;
+            else if ((float)score < my_thr || overlap < 500) kind = 0;
+            else if (begQ > begTr) kind = 3;
+            else kind = 4;
+        }
+    }
+    o.rc = (uint8_t)rc; o.score = score; o.kind = (uint8_t)kind;
+    o.begQ = begQ; o.begT = begT; o.endQ = endQ; o.endT = endT;
+    const int begTr = rc ? lenT - endT : begT, endTr = rc ? lenT - begT : endT;
+    if (kind != 0) {
+        o.passed = 1;
+        if (kind == 1) o.containedQ = 1;
+        else if (kind == 2) o.containedT = 1;
+        else if (kind == 3) { o.direction = rc ? 0 : 1; o.directionT = rc ? 0 : 2; o.suffix = (lenT - endTr) - (lenQ - endQ); o.suffixT = begQ - begTr; }
+        else { o.direction = rc ? 3 : 2; o.directionT = rc ? 3 : 1; o.suffix = begTr - begQ; o.suffixT = (lenQ - endQ) - (lenT - endTr); }
+    }
+    p.out_rows[a] = (int64_t)tk.i; p.out_cols[a] = (int64_t)tk.j; p.out[a] = o;
+}
+
+}  // namespace
+
+void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
+{
+    ELBA_REQUIRE(c.have_reads && c.have_B, ELBA_ERR_STATE, "align_seeds: needs the reads and the seed matrix on this context");
+    ELBA_REQUIRE(c.nreads == c.M && (c.row_hi < 0 || (c.row_lo == 0 && c.row_hi == c.M)), ELBA_ERR_UNSUPPORTED,
+                 "align_seeds: every read of B must be resident on this context (one-rank PairwiseAlignment)");
+    ELBA_REQUIRE(dropoff >= 0, ELBA_ERR_INVALID_ARG, "align_seeds: negative x-drop");
+    hipStream_t s = c.stream;
+    const int64_t M = c.M;
+    c.have_aln = false;
+    AlnParams p{};
+    p.packed = c.d_packed; p.byte_off = c.d_byte_off; p.len = c.d_len;
+    p.b_rowptr = c.b_rowptr.as<int64_t>(); p.b_col = c.b_col.as<uint32_t>(); p.b_val = c.b_val.as<elba_seed_t>();
+    p.M = (uint32_t)M; p.row_lo = 0; p.row_hi = (uint32_t)M;
+    p.k = c.cfg.k; p.mat = mat; p.mis = mis; p.gap = gap; p.dropoff = dropoff;
+    c.t_total.start(s);
+    c.aln_cnt.reserve((size_t)(M + 2) * 4); c.aln_ptr.reserve((size_t)(M + 2) * 8); c.aln_ctr.reserve(256);
+    p.cnt = c.aln_cnt.as<uint32_t>();
+    ELBA_HIP(hipMemsetAsync(c.aln_cnt.p, 0, (size_t)(M + 2) * 4, s));
+    ELBA_HIP(hipMemsetAsync(c.aln_ctr.p, 0, 256, s));
+    const unsigned nbM = (unsigned)((M + 255) / 256);
+    if (M > 0) hipLaunchKernelGGL(k_aln_count, dim3(nbM), dim3(256), 0, s, p);
+    exclusive_scan_u32_to_i64(s, p.cnt, c.aln_ptr.as<int64_t>(), M + 1, c.ws_scan);
+    int64_t K = 0;
+    ELBA_HIP(hipMemcpyAsync(&K, c.aln_ptr.as<int64_t>() + M, 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    ELBA_REQUIRE(2 * K < 0xFFFFFFF0ll, ELBA_ERR_UNSUPPORTED, "align_seeds: more than 2^31 candidate pairs");
+    c.naln = K;
+    c.aln_tasks.reserve((size_t)(K + 1) * sizeof(AlnTask)); c.aln_ext.reserve((size_t)(2 * K + 2) * sizeof(AlnExt)); c.aln_ofl.reserve((size_t)(2 * K + 2) * 4);
+    c.aln_rows.reserve((size_t)(K + 1) * 8); c.aln_cols.reserve((size_t)(K + 1) * 8); c.aln_out.reserve((size_t)(K + 1) * sizeof(elba_overlap_t));
+    p.taskptr = c.aln_ptr.as<int64_t>(); p.tasks = c.aln_tasks.as<AlnTask>(); p.ext = c.aln_ext.as<AlnExt>(); p.ntasks = K;
+    unsigned int *ctr = c.aln_ctr.as<unsigned int>();
+    p.next = ctr; p.ofl_count = ctr + 16; p.cells = reinterpret_cast<unsigned long long *>(ctr + 32);
+    p.ofl_list = c.aln_ofl.as<uint32_t>();
+    p.out_rows = c.aln_rows.as<int64_t>(); p.out_cols = c.aln_cols.as<int64_t>(); p.out = c.aln_out.as<elba_overlap_t>();
+    // strided kernel: three antidiagonals per wavefront, as long as the longest read + 2
+    uint32_t maxlen = 0;
+    for (uint32_t l : c.h_len) maxlen = l > maxlen ? l : maxlen;
+    const int sblocks = c.num_cus * 2;
+    p.scratch_stride = (unsigned long long)maxlen + 8;
+    elba_align_stats st{};
+    st.nalignments = K;
+    if (K > 0) {
+        hipLaunchKernelGGL(k_aln_prepare, dim3(nbM), dim3(256), 0, s, p);
+        c.t_a.start(s);
+        // persistent wavefronts pulling extensions from a queue: durations range from a handful of antidiagonals to tens of thousands
+        int64_t nb = (2 * K + ALN_WAVES - 1) / ALN_WAVES;
+        const int64_t resident = (int64_t)c.num_cus * 8;
+        if (nb > resident) nb = resident;
+        hipLaunchKernelGGL(k_xdrop_wave, dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p);
+        unsigned int nofl = 0;
+        ELBA_HIP(hipMemcpyAsync(&nofl, p.ofl_count, 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        if (nofl > 0) {
+            c.aln_scratch.reserve((size_t)sblocks * 3 * p.scratch_stride * sizeof(int));
+            p.scratch = c.aln_scratch.as<int>();
+            hipLaunchKernelGGL(k_xdrop_strided, dim3((unsigned)(nofl < (unsigned)sblocks ? nofl : (unsigned)sblocks)), dim3(64), 0, s, p);
+        }
+        c.t_a.stop(s);
+        hipLaunchKernelGGL(k_aln_combine, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, p);
+        ELBA_HIP(hipGetLastError());
+        st.extensions_strided = nofl;
+    }
+    c.t_total.stop(s);
+    unsigned long long cells = 0;
+    ELBA_HIP(hipMemcpyAsync(&cells, p.cells, 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    st.cells = (int64_t)cells;
+    st.ms_total = c.t_total.ms();
+    st.ms_extend = K > 0 ? c.t_a.ms() : 0.f;
+    // counts for the statistics come from the results themselves
+    if (K > 0) {
+        std::vector<elba_overlap_t> h((size_t)K);
+        ELBA_HIP(hipMemcpy(h.data(), c.aln_out.p, (size_t)K * sizeof(elba_overlap_t), hipMemcpyDeviceToHost));
+        for (const auto &o : h) { st.seeds_rejected += o.score == -1 && o.endQ == 0 && o.endT == 0; st.passed += o.passed; st.contained += (o.containedQ | o.containedT); }
+    }
+    c.astats = st;
+    c.have_aln = true;
+}
+
+}  // namespace elba

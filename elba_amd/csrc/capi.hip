@@ -200,6 +200,40 @@ int elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats)
     });
 }
 
+int elba_align_seeds(elba_ctx *ctx, int mat, int mis, int gap, int dropoff, elba_align_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        stage_align_seeds(c, mat, mis, gap, dropoff);
+        if (stats) *stats = c.astats;
+    });
+}
+
+int elba_export_overlaps(elba_ctx *ctx, elba_overlaps_t *out)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(out, ELBA_ERR_INVALID_ARG, "export_overlaps: null output");
+        memset(out, 0, sizeof(*out));
+        ELBA_REQUIRE(c.have_aln, ELBA_ERR_STATE, "export_overlaps: no alignments (call elba_align_seeds)");
+        const int64_t n = c.naln;
+        out->n = n;
+        out->rows = host_alloc<int64_t>((size_t)n); out->cols = host_alloc<int64_t>((size_t)n); out->vals = host_alloc<elba_overlap_t>((size_t)n);
+        if (n) {
+            ELBA_HIP(hipMemcpyAsync(out->rows, c.aln_rows.p, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
+            ELBA_HIP(hipMemcpyAsync(out->cols, c.aln_cols.p, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
+            ELBA_HIP(hipMemcpyAsync(out->vals, c.aln_out.p, (size_t)n * sizeof(elba_overlap_t), hipMemcpyDeviceToHost, c.stream));
+        }
+        ELBA_HIP(hipStreamSynchronize(c.stream));
+        for (int64_t a = 0; a < n; ++a) { out->rows[a] += c.first_global_id_rows(); out->cols[a] += c.first_global_id_rows(); }
+    });
+}
+
+void elba_free_overlaps(elba_overlaps_t *o)
+{
+    if (!o) return;
+    free(o->rows); free(o->cols); free(o->vals);
+    memset(o, 0, sizeof(*o));
+}
+
 int elba_export_csr(elba_ctx *ctx, int64_t row_lo, int64_t row_hi, elba_csr_t *out)
 {
     return guarded(ctx, [&](Ctx &c) {

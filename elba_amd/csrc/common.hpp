@@ -165,6 +165,12 @@ struct Ctx {
     DevBuf b_rowptr, b_col, b_val;             // i64[M+1], u32[Y], elba_seed_t[Y]
     elba_overlap_stats ostats{};
 
+    // alignments (align.hip)
+    bool have_aln = false;
+    int64_t naln = 0;
+    DevBuf aln_tasks, aln_ext, aln_cnt, aln_ptr, aln_ctr, aln_ofl, aln_scratch, aln_rows, aln_cols, aln_out;
+    elba_align_stats astats{};
+
     // workspaces
     DevBuf ws_scan, ws_sort, ws_a, ws_b, ws_c, ws_d, ws_e, ws_f;
     DevBuf ov_totcnt, ov_mir, ov_tmp, ov_sum_tmp;  // u32[M+1] mirrored entries per row (ticket counters); mirrored entries laid out like B (32-byte records); staging area (32-byte records)
@@ -189,6 +195,7 @@ void stage_count_kmers(Ctx &c);                                   // kmer.hip
 void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
 void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip
 void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
+void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff);   // align.hip
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host);                                   // kmer.hip
 void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);
 void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec);

@@ -474,7 +474,7 @@ void stage_create_seed_matrix(Ctx &c)
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob)
     {
-        const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : 128), (uint32_t)(getenv("ELBA_B1") ? atoi(getenv("ELBA_B1")) : 256), 256u, 256u, 512u};
+        const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : (b0 == 256 ? 256 : 128)), (uint32_t)(getenv("ELBA_B1") ? atoi(getenv("ELBA_B1")) : 256), 256u, 256u, 512u};
         for (int t = 0; t < NUM_LDS_TIERS; ++t) {
             const uint32_t T = 1u << (LDS_TBITS0 + t);
             const uint32_t lim = std::min((T >> 2) * 3, T - blk[t]);      // a lane overshoots by at most one claim (Table::insert_lds)
@@ -564,6 +564,7 @@ void stage_create_seed_matrix(Ctx &c)
             skipped_tiers = 0;
 #define ELBA_TIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
             if (b0 == 64) ELBA_TIER(0, ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
+            else if (b0 == 256) ELBA_TIER(0, ELBA_LAUNCH_ROWS(256, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
             else ELBA_TIER(0, ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
             if (!getenv("ELBA_B1") || atoi(getenv("ELBA_B1")) == 256) ELBA_TIER(1, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)18 * 1024 + X, 1, 10u));
             else ELBA_TIER(1, ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)18 * 1024 + X, 1, 10u));

@@ -58,6 +58,36 @@ typedef struct elba_ctx elba_ctx;
  * memory, SURVEY.md a11 — never memcpy into it, use std::get<>). */
 typedef struct { uint32_t q0, t0, q1, t1; int32_t numshared; } elba_seed_t;
 
+/* The fields of the reference's Overlap that Overlap::extend_overlap fills (include/Overlap.hpp:22-28, src/Overlap.cpp:24-73),
+ * explicit order (beg/end are std::tuples in the reference: same caveat as above), plus the OverlapClass it was derived from. */
+typedef struct {
+    int32_t begQ, begT, endQ, endT;     /* beg = (begQ, begT), end = (endQ, endT) */
+    int32_t score, suffix, suffixT;
+    int8_t  direction, directionT;      /* -1 = none */
+    uint8_t rc, passed, containedQ, containedT;
+    uint8_t kind;                       /* OverlapClass: 0 BAD_ALIGNMENT, 1 FIRST_CONTAINED, 2 SECOND_CONTAINED, 3 FIRST_TO_SECOND_OVERLAP, 4 SECOND_TO_FIRST_OVERLAP */
+    uint8_t reserved;
+} elba_overlap_t;
+
+typedef struct {
+    int64_t nalignments;    /* candidate pairs aligned: stored B(i,j) with i < j (src/PairwiseAlignment.cpp:52 on one rank) */
+    int64_t seeds_rejected; /* xdrop_aligner returned -1 (src/XDropAligner.cpp:231-245) */
+    int64_t passed;         /* Overlap::passed */
+    int64_t contained;      /* containedQ or containedT */
+    int64_t extensions_strided; /* extensions whose band outgrew one wavefront (redone by the strided kernel) */
+    int64_t cells;          /* DP cells computed (both extensions of every pair) — the unit of the stage's throughput */
+    float   ms_total;       /* device time of the stage */
+    float   ms_extend;      /* the extension kernels (dominant) */
+} elba_align_stats;
+
+/* rows[a], cols[a] (global read ids) and vals[a] of the a-th aligned pair, in CSR order of B's strict upper triangle:
+ * the triples PairwiseAlignment hands to SpParMat<Overlap> (src/PairwiseAlignment.cpp:97-103). */
+typedef struct {
+    int64_t n;
+    int64_t *rows, *cols;
+    elba_overlap_t *vals;
+} elba_overlaps_t;
+
 typedef struct {
     int32_t k;          /* KMER_SIZE: odd, 3..31 here (reference: compile-time, Makefile:1) */
     int32_t lower;      /* LOWER_KMER_FREQ >= 2 (SURVEY.md App. A.4 precondition)            */
@@ -172,6 +202,13 @@ int  elba_set_kmer_matrix(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t n
                           const int64_t *rows, const int64_t *cols, const uint32_t *vals, elba_matrix_stats *stats);
 
 int  elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats);
+
+/* PairwiseAlignment (src/PairwiseAlignment.cpp:5-106) on one rank, on the GPU: x-drop seed-and-extend from seeds[0] of every stored
+ * B(i,j), i < j (xdrop_aligner src/XDropAligner.cpp:224-282 with the reference's defaults mat 1, mis -1, gap -1, dropoff 15,
+ * src/main.cpp:53-56), classification and Overlap fields.  Needs the reads and B resident on this context (all reads local). */
+int  elba_align_seeds(elba_ctx *ctx, int mat, int mis, int gap, int dropoff, elba_align_stats *stats);
+int  elba_export_overlaps(elba_ctx *ctx, elba_overlaps_t *out);
+void elba_free_overlaps(elba_overlaps_t *o);
 
 int  elba_export_dcsc(elba_ctx *ctx, int64_t row_lo, int64_t row_hi, int64_t col_lo, int64_t col_hi, elba_dcsc_t *out);
 void elba_free_dcsc(elba_dcsc_t *d);

@@ -514,6 +514,185 @@ int orc_seed_is_valid(const uint8_t *qmem, uint32_t qlen, const uint8_t *tmem, u
     return a == b || a == orc_kmer_twin(b, k);
 }
 
+
+/* ====================================================================================================================
+ * f1: x-drop seed-and-extend, the consumer of seeds[0] right after the path.
+ * Restates src/XDropAligner.cpp:46-222 (_extend_seed_one_direction), :224-282 (xdrop_aligner), :7-44 (classify_alignment)
+ * and the field mapping of Overlap::extend_overlap (src/Overlap.cpp:24-73).  Pinned against the reference's own
+ * XDropAligner.cpp through oracle/_ref (tests/golden/xdrop_*.txt + live random cross-checks).
+ * ==================================================================================================================== */
+typedef struct { int32_t begQ, endQ, begT, endT, score, rc; } orc_xseed_t;
+typedef struct {
+    int32_t begQ, begT, endQ, endT;   /* Overlap::beg / end (src/Overlap.cpp:38-41) */
+    int32_t score, suffix, suffixT;
+    int8_t direction, directionT;
+    uint8_t rc, passed, containedQ, containedT;
+    uint8_t kind, pad;                /* OverlapClass (include/XDropAligner.hpp:10-17) */
+} orc_overlap_t;
+
+static inline int orc_revcomp_at(const uint8_t *mem, size_t len, size_t i) { return 3 - orc_base_at(mem, len - 1 - i); }   /* include/DnaSeq.hpp:119 */
+
+/* src/XDropAligner.cpp:46-208.  Three antidiagonals ad1 (n-2), ad2 (n-1), ad3 (n), each stored from column offsetK on;
+ * only best_ext_{col,row,score} leave the function (the ext_* tail of the reference, :166-205, has no effect on them). */
+static int orc_extend_one_direction(const uint8_t *q, int lenQ, const uint8_t *t, int lenT, int extleft, orc_xseed_t *xs,
+                                    int mat, int mis, int gap, int dropoff, int64_t *cells)
+{
+    const int lenQ_ext = extleft ? xs->begQ : lenQ - xs->endQ;
+    const int lenT_ext = extleft ? xs->begT : lenT - xs->endT;
+    const int cols = lenQ_ext + 1, rows = lenT_ext + 1;
+    if (rows == 1 || cols == 1) return 0;
+    const int int_min = INT32_MIN;
+    const int len = 2 * (cols > rows ? cols : rows);
+    const int min_err_score = int_min / len;
+    if (gap < min_err_score) gap = min_err_score;
+    if (mis < min_err_score) mis = min_err_score;
+    const int undef = int_min - gap - mis;
+    const int cap = (cols > rows ? cols : rows) + 4;
+    int *b1 = (int *)malloc(sizeof(int) * (size_t)cap), *b2 = (int *)malloc(sizeof(int) * (size_t)cap), *b3 = (int *)malloc(sizeof(int) * (size_t)cap);
+    int *ad1 = b1, *ad2 = b2, *ad3 = b3;
+    int n1 = 0, n2 = 0, n3 = 0;                 /* vector sizes */
+    int min_col = 1, max_col = 2;
+    int offset1 = 0, offset2 = 0, offset3 = 0;
+    ad2[0] = 0; n2 = 1;
+    int best_ext_col = 0, best_ext_row = 0, best_ext_score = 0;
+    n3 = 2; ad3[0] = ad3[1] = (-gap > dropoff) ? undef : gap;
+    int ad_no = 1, best = 0;
+    const int offsetQ = xs->endQ, offsetT = xs->endT;
+    while (min_col < max_col) {
+        ++ad_no;
+        { int *tb = ad1; ad1 = ad2; n1 = n2; ad2 = ad3; n2 = n3; ad3 = tb; }
+        offset1 = offset2; offset2 = offset3; offset3 = min_col - 1;
+        n3 = max_col + 1 - offset3;             /* resize: new cells hold whatever; every one is written below before it is read */
+        for (int i = 0; i < n3; ++i) ad3[i] = 0;
+        ad3[0] = ad3[max_col - offset3] = undef;
+        if ((int64_t)ad_no * gap > (int64_t)best - dropoff) {
+            if (offset3 == 0) ad3[0] = ad_no * gap;
+            if (ad_no - max_col == 0) ad3[max_col - offset3] = ad_no * gap;
+        }
+        int ad_best = ad_no * gap;
+        for (int col = min_col; col < max_col; ++col) {
+            const int i3 = col - offset3, i2 = col - offset2, i1 = col - offset1;
+            const int posQ = extleft ? cols - 1 - col : col - 1 + offsetQ;
+            const int posT = extleft ? rows - 1 + col - ad_no : ad_no - col - 1 + offsetT;
+            int temp = (ad2[i2 - 1] > ad2[i2] ? ad2[i2 - 1] : ad2[i2]) + gap;
+            const int tb = xs->rc ? orc_revcomp_at(t, (size_t)lenT, (size_t)posT) : orc_base_at(t, (size_t)posT);
+            const int temp2 = ad1[i1 - 1] + (orc_base_at(q, (size_t)posQ) == tb ? mat : mis);
+            if (temp2 > temp) temp = temp2;
+            if (temp < best - dropoff) ad3[i3] = undef;
+            else { ad3[i3] = temp; if (temp > ad_best) ad_best = temp; }
+            if (temp > best) { best_ext_col = col; best_ext_row = ad_no - best_ext_col; best_ext_score = ad3[best_ext_col - offset3]; }
+            if (cells) ++*cells;
+        }
+        if (ad_best > best) best = ad_best;
+        while (min_col - offset3 < n3 && ad3[min_col - offset3] == undef && min_col - offset2 - 1 < n2 && ad2[min_col - offset2 - 1] == undef) ++min_col;
+        while (max_col - offset3 > 0 && ad3[max_col - offset3 - 1] == undef && ad2[max_col - offset2 - 1] == undef) --max_col;
+        ++max_col;
+        if (min_col < ad_no + 2 - rows) min_col = ad_no + 2 - rows;
+        if (max_col > cols) max_col = cols;
+    }
+    (void)n1;
+    if (best_ext_score != undef) {
+        if (extleft) { xs->begT -= best_ext_row; xs->begQ -= best_ext_col; }
+        else { xs->endT += best_ext_row; xs->endQ += best_ext_col; }
+    }
+    free(b1); free(b2); free(b3);
+    return best_ext_score;
+}
+
+/* src/XDropAligner.cpp:224-282.  Returns the score, or -1 with *res left at XSeed's defaults (:22) when the seed is rejected. */
+int orc_xdrop_aligner(const uint8_t *q, int lenQ, const uint8_t *t, int lenT, int begQ, int begT, int k,
+                      int mat, int mis, int gap, int dropoff, orc_xseed_t *res, int64_t *cells)
+{
+    res->begQ = res->endQ = res->begT = res->endT = 0; res->score = -1; res->rc = 0;
+    if (begQ < 0 || begQ + k > lenQ) return -1;
+    if (begT < 0 || begT + k > lenT) return -1;
+    if (begQ == 0 && begT == 0) return -1;
+    const int rc = orc_base_at(q, (size_t)(begQ + (k >> 1))) != orc_base_at(t, (size_t)(begT + (k >> 1)));
+    for (int i = 0; i < k; ++i) {
+        const int tb = rc ? orc_revcomp_at(t, (size_t)lenT, (size_t)(lenT - begT - k + i)) : orc_base_at(t, (size_t)(begT + i));
+        if (orc_base_at(q, (size_t)(begQ + i)) != tb) return -1;
+    }
+    orc_xseed_t xs;
+    xs.begQ = begQ; xs.endQ = begQ + k;
+    xs.begT = rc ? lenT - begT - k : begT; xs.endT = xs.begT + k;
+    xs.rc = rc; xs.score = -1;
+    orc_xseed_t l = xs, r = xs;
+    const int lscore = orc_extend_one_direction(q, lenQ, t, lenT, 1, &l, mat, mis, gap, dropoff, cells);
+    const int rscore = orc_extend_one_direction(q, lenQ, t, lenT, 0, &r, mat, mis, gap, dropoff, cells);
+    const int score = lscore + rscore + mat * k;
+    res->begQ = l.begQ; res->endQ = r.endQ;
+    res->begT = rc ? lenT - r.endT : l.begT;
+    res->endT = rc ? lenT - l.begT : r.endT;
+    res->rc = rc; res->score = score;
+    return score;
+}
+
+/* src/XDropAligner.cpp:7-44 */
+int orc_classify_alignment(const orc_xseed_t *ai, int lenQ, int lenT)
+{
+    if (ai->score <= 0) return 0;                                   /* BAD_ALIGNMENT */
+    const int begTr = ai->rc ? lenT - ai->endT : ai->begT;
+    const int endTr = ai->rc ? lenT - ai->begT : ai->endT;
+    const int maplen = ((ai->endT - ai->begT) + (ai->endQ - ai->begQ)) / 2;
+    const int a = ai->begQ < begTr ? ai->begQ : begTr, b = (lenQ - ai->endQ) < (lenT - endTr) ? (lenQ - ai->endQ) : (lenT - endTr);
+    const int overhang = a + b;
+    const int overlap = maplen + overhang;
+    const float my_thr = (float)((1.0 - 0.1) * (0.99 * overlap));   /* DELTACHERNOFF 0.1, include/XDropAligner.hpp:8 */
+    if (ai->begQ <= begTr && lenQ - ai->endQ <= lenT - endTr) return 1;           /* FIRST_CONTAINED */
+    if (ai->begQ >= begTr && lenQ - ai->endQ >= lenT - endTr) return 2;           /* SECOND_CONTAINED */
+    if ((float)ai->score < my_thr || overlap < 500) return 0;
+    if (ai->begQ > begTr) return 3;                                                /* FIRST_TO_SECOND_OVERLAP */
+    return 4;                                                                      /* SECOND_TO_FIRST_OVERLAP */
+}
+
+/* Overlap::Overlap + Overlap::extend_overlap, src/Overlap.cpp:4-11, :24-73 */
+void orc_overlap_extend(const uint8_t *q, int lenQ, const uint8_t *t, int lenT, int seedQ, int seedT, int k,
+                        int mat, int mis, int gap, int dropoff, orc_overlap_t *o, int64_t *cells)
+{
+    orc_xseed_t r;
+    orc_xdrop_aligner(q, lenQ, t, lenT, seedQ, seedT, k, mat, mis, gap, dropoff, &r, cells);
+    const int kind = orc_classify_alignment(&r, lenQ, lenT);
+    memset(o, 0, sizeof *o);
+    o->direction = -1; o->directionT = -1;
+    o->rc = (uint8_t)r.rc; o->score = r.score; o->kind = (uint8_t)kind;
+    o->begQ = r.begQ; o->begT = r.begT; o->endQ = r.endQ; o->endT = r.endT;
+    const int begQr = r.begQ, endQr = r.endQ;
+    const int begTr = r.rc ? lenT - r.endT : r.begT, endTr = r.rc ? lenT - r.begT : r.endT;
+    if (kind != 0) {
+        o->passed = 1;
+        if (kind == 1) o->containedQ = 1;
+        else if (kind == 2) o->containedT = 1;
+        else if (kind == 3) { o->direction = r.rc ? 0 : 1; o->directionT = r.rc ? 0 : 2; o->suffix = (lenT - endTr) - (lenQ - endQr); o->suffixT = begQr - begTr; }
+        else { o->direction = r.rc ? 3 : 2; o->directionT = r.rc ? 3 : 1; o->suffix = begTr - begQr; o->suffixT = (lenQ - endQr) - (lenT - endTr); }
+    }
+}
+
+/* PairwiseAlignment's loop on one rank (src/PairwiseAlignment.cpp:28-95): every stored B(i,j) with i < j is aligned from seeds[0];
+ * out[e] for the e-th such entry in CSR order (rows ascending, columns ascending); returns their number. */
+int64_t orc_align_upper(const orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off, const uint32_t *lens,
+                        int mat, int mis, int gap, int dropoff, int nthreads, int64_t *rows, int64_t *cols, orc_overlap_t *out, int64_t cap, int64_t *cells_total)
+{
+    int64_t n = 0;
+    for (int64_t i = 0; i < c->M; ++i)
+        for (int64_t e = c->b_rowptr[i]; e < c->b_rowptr[i + 1]; ++e)
+            if ((int64_t)c->b_col[e] > i) { if (n < cap) { rows[n] = i; cols[n] = (int64_t)c->b_col[e]; } ++n; }
+    if (n > cap) return -n;
+    int64_t cells = 0;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads) reduction(+ : cells)
+    for (int64_t a = 0; a < n; ++a) {
+        const int64_t i = rows[a], j = cols[a];
+        int64_t e = c->b_rowptr[i];
+        while ((int64_t)c->b_col[e] != j) ++e;
+        int64_t mine = 0;
+        orc_overlap_extend(buf + byte_off[i], (int)lens[i], buf + byte_off[j], (int)lens[j], (int)c->b_val[e].q0, (int)c->b_val[e].t0, c->k,
+                           mat, mis, gap, dropoff, &out[a], &mine);
+        cells += mine;
+    }
+    if (cells_total) *cells_total = cells;
+    return n;
+}
+
 /* getters (ctypes-friendly) */
 int64_t orc_get_i64(const orc_ctx *c, int what)
 {

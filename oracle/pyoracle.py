@@ -17,6 +17,10 @@ class Seed(C.Structure):
 
 
 SEED_DTYPE = np.dtype([("q0", "<u4"), ("t0", "<u4"), ("q1", "<u4"), ("t1", "<u4"), ("numshared", "<i4")])
+# orc_overlap_t == elba_overlap_t (include/elba_amd.h): the fields of the reference's Overlap that extend_overlap fills (src/Overlap.cpp:24-73)
+OVERLAP_DTYPE = np.dtype([("begQ", "<i4"), ("begT", "<i4"), ("endQ", "<i4"), ("endT", "<i4"), ("score", "<i4"), ("suffix", "<i4"), ("suffixT", "<i4"),
+                          ("direction", "i1"), ("directionT", "i1"), ("rc", "u1"), ("passed", "u1"), ("containedQ", "u1"), ("containedT", "u1"), ("kind", "u1"), ("pad", "u1")])
+XSEED_DTYPE = np.dtype([("begQ", "<i4"), ("endQ", "<i4"), ("begT", "<i4"), ("endT", "<i4"), ("score", "<i4"), ("rc", "<i4")])
 
 
 def build(force=False):
@@ -71,6 +75,14 @@ def lib():
         L.orc_free_ptr.argtypes = [C.c_void_p]
         L.orc_seed_is_valid.restype = C.c_int
         L.orc_seed_is_valid.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+        L.orc_xdrop_aligner.restype = C.c_int
+        L.orc_xdrop_aligner.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_classify_alignment.restype = C.c_int
+        L.orc_classify_alignment.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.orc_overlap_extend.restype = None
+        L.orc_overlap_extend.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_align_upper.restype = C.c_int64
+        L.orc_align_upper.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_get_i64.restype = C.c_int64
         L.orc_get_i64.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_ptr.restype = C.c_void_p
@@ -156,6 +168,19 @@ class Oracle:
         g = lambda w, n, dt: _arr(self.L.orc_get_ptr(self.h, w), n, dt)
         return dict(M=M, Y=Y, rowptr=g(8, M + 1, np.int64), col=g(9, Y, np.uint32), val=g(10, Y, SEED_DTYPE))
 
+    def align_upper(self, buf, off, lens, mat=1, mis=-1, gap=-1, dropoff=15, nthreads=1):
+        """PairwiseAlignment on one rank (src/PairwiseAlignment.cpp:28-95): x-drop from seeds[0] of every stored B(i,j), i < j.
+        Returns (rows, cols, overlaps[OVERLAP_DTYPE], DP cells computed)."""
+        buf = np.ascontiguousarray(buf, dtype=np.uint8); off = np.ascontiguousarray(off, dtype=np.uint64); lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        cap = self.stat("nupper") + 1
+        rows = np.zeros(cap, dtype=np.int64); cols = np.zeros(cap, dtype=np.int64); out = np.zeros(cap, dtype=OVERLAP_DTYPE)
+        cells = C.c_int64()
+        n = self.L.orc_align_upper(self.h, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, mat, mis, gap, dropoff, nthreads,
+                                   rows.ctypes.data, cols.ctypes.data, out.ctypes.data, cap, C.byref(cells))
+        if n < 0:
+            raise RuntimeError("orc_align_upper: capacity")
+        return rows[:n], cols[:n], out[:n], cells.value
+
     def export_dcsc(self, row_lo, row_hi, col_lo, col_hi):
         nnz, nzc = C.c_int64(), C.c_int64()
         jc, cp, ir, numx = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -185,6 +210,27 @@ def ref_lib(k):
     R.ref_murmur3_128.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     R.ref_bloom_second_sightings.restype = C.c_int64
     R.ref_bloom_second_sightings.argtypes = [C.c_void_p, C.c_int64, C.c_int64]
+    R.ref_xdrop.restype = None
+    R.ref_xdrop.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     R.ref_replay_count.restype = C.c_int64
     R.ref_replay_count.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     return R
+
+
+def xdrop(qmem, qlen, tmem, tlen, begQ, begT, k, mat=1, mis=-1, gap=-1, dropoff=15):
+    """orc_xdrop_aligner + orc_classify_alignment on one pair -> (ret, begQ, endQ, begT, endT, score, rc, kind)."""
+    L = lib()
+    r = np.zeros(1, dtype=XSEED_DTYPE)
+    qmem = np.ascontiguousarray(qmem, dtype=np.uint8); tmem = np.ascontiguousarray(tmem, dtype=np.uint8)
+    ret = L.orc_xdrop_aligner(qmem.ctypes.data, qlen, tmem.ctypes.data, tlen, begQ, begT, k, mat, mis, gap, dropoff, r.ctypes.data, None)
+    kind = L.orc_classify_alignment(r.ctypes.data, qlen, tlen)
+    x = r[0]
+    return (int(ret), int(x["begQ"]), int(x["endQ"]), int(x["begT"]), int(x["endT"]), int(x["score"]), int(x["rc"]), int(kind))
+
+
+def ref_xdrop(R, qmem, qlen, tmem, tlen, begQ, begT, mat=1, mis=-1, gap=-1, dropoff=15):
+    """The reference's xdrop_aligner + classify_alignment (oracle/_ref) -> same tuple as xdrop()."""
+    out = np.zeros(8, dtype=np.int32)
+    qmem = np.ascontiguousarray(qmem, dtype=np.uint8); tmem = np.ascontiguousarray(tmem, dtype=np.uint8)
+    R.ref_xdrop(qmem.ctypes.data, qlen, tmem.ctypes.data, tlen, begQ, begT, mat, mis, gap, dropoff, out.ctypes.data)
+    return tuple(int(v) for v in out)

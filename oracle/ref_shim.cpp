@@ -8,6 +8,7 @@
  *   Kmer<N>::GetRepKmers / GetKmers / GetTwin / GetRep / GetHash   src/Kmer.cpp:149-242
  *   murmurhash3_64                                  src/HashFuncs.cpp:231-236
  *   Bloom                                           src/Bloom.cpp:6-73
+ *   xdrop_aligner / classify_alignment              src/XDropAligner.cpp:7-44, :224-282  (the step after the path)
  *
  * Built with -DCOMMON_H_ : include/common.h's include guard is predefined so its
  * body (mpi.h + the absent, un-vendored CombBLAS) is skipped; none of the files
@@ -21,6 +22,7 @@
 #include "HashFuncs.hpp"
 #include "DnaSeq.hpp"
 #include "Bloom.hpp"
+#include "XDropAligner.hpp"
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -150,6 +152,21 @@ int64_t ref_replay_count(const uint8_t *buf, const uint64_t *byte_off, const uin
     if ((int64_t)tr.size() > cap) return -1;
     for (size_t i = 0; i < tr.size(); ++i) { out_kmer[i] = std::get<0>(tr[i]); out_read[i] = std::get<1>(tr[i]); out_pos[i] = std::get<2>(tr[i]); }
     return (int64_t)tr.size();
+}
+
+/*
+ * f1: the reference's x-drop seed-and-extend on one pair (src/XDropAligner.cpp:224-282) and its classification (:7-44).
+ * out = {return value, begQ, endQ, begT, endT, score, rc, OverlapClass}
+ */
+void ref_xdrop(const uint8_t *qmem, size_t qlen, const uint8_t *tmem, size_t tlen, int begQ, int begT,
+               int mat, int mis, int gap, int dropoff, int *out)
+{
+    DnaSeq q(qlen, const_cast<uint8_t*>(qmem)), t(tlen, const_cast<uint8_t*>(tmem));
+    XSeed r;
+    int ret = xdrop_aligner(q, t, begQ, begT, mat, mis, gap, dropoff, r);
+    OverlapClass kind;
+    classify_alignment(r, (int)qlen, (int)tlen, kind);
+    out[0] = ret; out[1] = r.begQ; out[2] = r.endQ; out[3] = r.begT; out[4] = r.endT; out[5] = r.score; out[6] = r.rc ? 1 : 0; out[7] = (int)kind;
 }
 
 }

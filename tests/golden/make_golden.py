@@ -155,7 +155,44 @@ def small_set(name, seed, k, lower, upper, **kw):
     return res
 
 
+def xdrop_vectors(name, k, lower, upper, rng):
+    """f1: (i, j, seedQ, seedT, mat, mis, gap, xdrop) -> what the reference's own xdrop_aligner + classify_alignment return
+    (src/XDropAligner.cpp, through oracle/_ref).  The INPUT seeds are the oracle's seeds[0] of the strict upper triangle of B (any
+    shared k-mer would do) plus some perturbed / invalid ones; every expected value comes from the reference's code."""
+    import util
+    R = po.ref_lib(k)
+    seqs = util.read_fasta(os.path.join(HERE, name + ".fa"))
+    buf, off, lens = ref_pack(R, seqs)
+    o = po.Oracle(k, lower, upper); o.count_and_build(buf, off, lens); o.spgemm(1)
+    B = o.B()
+    rows = np.repeat(np.arange(B["M"]), np.diff(B["rowptr"]))
+    params = [(1, -1, -1, 15), (1, -2, -3, 30), (2, -3, -2, 7), (1, -1, -1, 0), (1, -1, -1, 49)]
+    with open(os.path.join(HERE, "xdrop_%s_k%d.txt" % (name, k)), "w") as f:
+        f.write("# i j seedQ seedT mat mis gap xdrop -> ret begQ endQ begT endT score rc OverlapClass   (reference: src/XDropAligner.cpp, KMER_SIZE=%d)\n" % k)
+        n = 0
+        for e in range(B["Y"]):
+            i, j = int(rows[e]), int(B["col"][e])
+            if i >= j:
+                continue
+            q0, t0 = int(B["val"][e]["q0"]), int(B["val"][e]["t0"])
+            cases = [(q0, t0, params[n % len(params)])]
+            if n % 7 == 0:
+                cases.append((q0 + int(rng.integers(-3, 4)), t0, params[0]))          # usually not a shared k-mer any more: rejected
+            if n % 11 == 0:
+                cases.append((int(B["val"][e]["q1"]), int(B["val"][e]["t1"]), params[1]))   # the other stored seed
+            for (a, b, (mat, mis, gap, x)) in cases:
+                out = po.ref_xdrop(R, buf[int(off[i]):], int(lens[i]), buf[int(off[j]):], int(lens[j]), a, b, mat, mis, gap, x)
+                f.write("%d %d %d %d %d %d %d %d %s\n" % (i, j, a, b, mat, mis, gap, x, " ".join(str(v) for v in out)))
+            n += 1
+    return n
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "xdrop":          # only the x-drop vectors (the other fixtures stay as committed)
+        assert po.ref_lib(17) is not None, "run `make -C oracle ref` first"
+        rng = np.random.default_rng(20261004)
+        print(xdrop_vectors("small_err", 17, 2, 8, rng), xdrop_vectors("small_clean", 17, 2, 8, rng))
+        return
     assert os.path.isdir(REF), "needs the reference tree"
     assert po.ref_lib(17) is not None and po.ref_lib(31) is not None, "run `make -C oracle ref` first"
     rng = np.random.default_rng(20261003)
