@@ -669,8 +669,9 @@ void orc_overlap_extend(const uint8_t *q, int lenQ, const uint8_t *t, int lenT, 
 
 /* PairwiseAlignment's loop on one rank (src/PairwiseAlignment.cpp:28-95): every stored B(i,j) with i < j is aligned from seeds[0];
  * out[e] for the e-th such entry in CSR order (rows ascending, columns ascending); returns their number. */
+/* (the omp loop below needs a canonical increment: stride is applied through an index map) */
 int64_t orc_align_upper(const orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off, const uint32_t *lens,
-                        int mat, int mis, int gap, int dropoff, int nthreads, int64_t *rows, int64_t *cols, orc_overlap_t *out, int64_t cap, int64_t *cells_total)
+                        int mat, int mis, int gap, int dropoff, int nthreads, int64_t stride, int64_t *rows, int64_t *cols, orc_overlap_t *out, int64_t cap, int64_t *cells_total)
 {
     int64_t n = 0;
     for (int64_t i = 0; i < c->M; ++i)
@@ -679,8 +680,11 @@ int64_t orc_align_upper(const orc_ctx *c, const uint8_t *buf, const uint64_t *by
     if (n > cap) return -n;
     int64_t cells = 0;
     if (nthreads < 1) nthreads = 1;
+    if (stride < 1) stride = 1;                 /* stride > 1: only every stride-th pair is aligned (bounded CPU baseline samples) */
+    const int64_t nsample = (n + stride - 1) / stride;
 #pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads) reduction(+ : cells)
-    for (int64_t a = 0; a < n; ++a) {
+    for (int64_t sidx = 0; sidx < nsample; ++sidx) {
+        const int64_t a = sidx * stride;
         const int64_t i = rows[a], j = cols[a];
         int64_t e = c->b_rowptr[i];
         while ((int64_t)c->b_col[e] != j) ++e;

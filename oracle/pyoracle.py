@@ -82,7 +82,7 @@ def lib():
         L.orc_overlap_extend.restype = None
         L.orc_overlap_extend.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         L.orc_align_upper.restype = C.c_int64
-        L.orc_align_upper.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+        L.orc_align_upper.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_get_i64.restype = C.c_int64
         L.orc_get_i64.argtypes = [C.c_void_p, C.c_int]
         L.orc_get_ptr.restype = C.c_void_p
@@ -168,14 +168,14 @@ class Oracle:
         g = lambda w, n, dt: _arr(self.L.orc_get_ptr(self.h, w), n, dt)
         return dict(M=M, Y=Y, rowptr=g(8, M + 1, np.int64), col=g(9, Y, np.uint32), val=g(10, Y, SEED_DTYPE))
 
-    def align_upper(self, buf, off, lens, mat=1, mis=-1, gap=-1, dropoff=15, nthreads=1):
+    def align_upper(self, buf, off, lens, mat=1, mis=-1, gap=-1, dropoff=15, nthreads=1, stride=1):
         """PairwiseAlignment on one rank (src/PairwiseAlignment.cpp:28-95): x-drop from seeds[0] of every stored B(i,j), i < j.
-        Returns (rows, cols, overlaps[OVERLAP_DTYPE], DP cells computed)."""
+        Returns (rows, cols, overlaps[OVERLAP_DTYPE], DP cells computed).  stride > 1 aligns only every stride-th pair (the others stay zero)."""
         buf = np.ascontiguousarray(buf, dtype=np.uint8); off = np.ascontiguousarray(off, dtype=np.uint64); lens = np.ascontiguousarray(lens, dtype=np.uint32)
         cap = self.stat("nupper") + 1
         rows = np.zeros(cap, dtype=np.int64); cols = np.zeros(cap, dtype=np.int64); out = np.zeros(cap, dtype=OVERLAP_DTYPE)
         cells = C.c_int64()
-        n = self.L.orc_align_upper(self.h, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, mat, mis, gap, dropoff, nthreads,
+        n = self.L.orc_align_upper(self.h, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, mat, mis, gap, dropoff, nthreads, stride,
                                    rows.ctypes.data, cols.ctypes.data, out.ctypes.data, cap, C.byref(cells))
         if n < 0:
             raise RuntimeError("orc_align_upper: capacity")
