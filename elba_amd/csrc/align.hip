@@ -37,8 +37,6 @@ struct AlnParams {
     int32_t k, mat, mis, gap, dropoff;
     uint32_t *cnt; const int64_t *taskptr;
     AlnTask *tasks; AlnExt *ext; int64_t ntasks;
-    unsigned int *next;             // work queue cursor
-    unsigned int *ofl_count; uint32_t *ofl_list;     // extensions whose band outgrew the wavefront
     int *scratch; unsigned long long scratch_stride;  // strided kernel: three antidiagonals per wavefront
     unsigned long long *cells;      // DP cells computed (statistics)
     int64_t *out_rows, *out_cols; elba_overlap_t *out;
@@ -123,22 +121,28 @@ __device__ __forceinline__ int wave_max_i32(int v)
     return v;
 }
 
-constexpr int RING = 256;        // bases per LDS ring (power of two): the band's span (<= 64) + one refill (64) fit with room to spare
 constexpr int ALN_WAVES = 4;     // independent wavefronts per workgroup
 
-// The fast kernel: band <= 63 columns.  Every scalar below is wave-uniform.
-__global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p)
+// The register kernel: a band of up to 64*KC - 1 columns.  Lane l holds the KC consecutive columns cbase + l*KC ... + KC - 1 of the
+// antidiagonals n-2 and n-1.  Every scalar below is wave-uniform.  Work comes from a queue: all 2*ntasks extensions (in_list == nullptr)
+// or the extensions a narrower instantiation gave up on.
+template <int KC>
+__global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, const uint32_t *in_list, const unsigned int *in_count, unsigned int *next,
+                                                               uint32_t *out_list, unsigned int *out_count)
 {
+    constexpr int W = 64 * KC;              // window of columns the wavefront holds
+    constexpr int RING = 2 * W < 256 ? 256 : 2 * W;   // bases per LDS ring (power of two): the band's span (<= W) + one refill (64) fit with room to spare
     __shared__ uint8_t ring[ALN_WAVES][2][RING];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint8_t *rq = ring[w][0], *rt = ring[w][1];
     unsigned long long cells = 0;
-    const unsigned int ntask2 = (unsigned int)(2 * p.ntasks);
+    const unsigned int nwork = in_list ? *in_count : (unsigned int)(2 * p.ntasks);
     for (;;) {
-        unsigned int tk2 = 0;
-        if (lane == 0) tk2 = atomicAdd(p.next, 1u);
-        tk2 = (unsigned int)__builtin_amdgcn_readfirstlane((int)tk2);
-        if (tk2 >= ntask2) break;
+        unsigned int wk = 0;
+        if (lane == 0) wk = atomicAdd(next, 1u);
+        wk = (unsigned int)__builtin_amdgcn_readfirstlane((int)wk);
+        if (wk >= nwork) break;
+        const unsigned int tk2 = in_list ? in_list[wk] : wk;
         const AlnTask tk = p.tasks[tk2 >> 1];
         const int left = (int)(tk2 & 1u);
         AlnExt res{0, 0, 0, 0};
@@ -153,25 +157,29 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p)
         // antidiagonal 0 = {col 0: 0}; antidiagonal 1 = {col 0, col 1: gap, or undef when one gap already drops off}   (:70-77)
         int cbase = 0;
         const int g1 = (-gap > dropoff) ? undef : gap;
-        int A1 = lane == 0 ? 0 : undef;                  // antidiagonal n-2, column cbase + lane
-        int A2 = lane <= 1 ? g1 : undef;                 // antidiagonal n-1
+        int A1[KC], A2[KC], A3[KC];                      // antidiagonals n-2, n-1, n at columns cbase + lane*KC + k
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { const int c = lane * KC + k; A1[k] = c == 0 ? 0 : undef; A2[k] = c <= 1 ? g1 : undef; }
         int min_col = 1, max_col = 2, hi2 = 1;           // hi2: last stored column of antidiagonal n-1
         int best = 0, n = 1;
         int best_col = 0, best_row = 0, best_score = 0;
         int qfill = 0, tfill = 0;                        // logical columns / rows unpacked into the rings so far
         bool overflow = false;
-        unsigned long long mycells = 0;                  // (an extension that leaves for the strided kernel is counted there)
+        unsigned long long mycells = 0;                  // (an extension that leaves for a wider kernel is counted there)
         while (min_col < max_col) {
             ++n;
             const int off3 = min_col - 1, top_max = max_col;      // this antidiagonal is stored for columns [off3, top_max]   (:93-96)
-            if (top_max > cbase + 63) {                  // slide the window down to the band's lower edge
-                const int s = off3 - cbase;
-                if (s <= 0) { overflow = true; break; }
-                const int src = lane + s;
-                const int a1 = __shfl(A1, src & 63, 64), a2 = __shfl(A2, src & 63, 64);
-                A1 = src < 64 ? a1 : undef; A2 = src < 64 ? a2 : undef;
-                cbase += s;
-                if (top_max > cbase + 63) { overflow = true; break; }
+            if (top_max > cbase + W - 1) {               // slide the window down to the band's lower edge (whole lanes)
+                const int sl = (off3 - cbase) / KC;
+                if (sl <= 0) { overflow = true; break; }
+                const int src = lane + sl;
+#pragma unroll
+                for (int k = 0; k < KC; ++k) {
+                    const int a1 = __shfl(A1[k], src & 63, 64), a2 = __shfl(A2[k], src & 63, 64);
+                    A1[k] = src < 64 ? a1 : undef; A2[k] = src < 64 ? a2 : undef;
+                }
+                cbase += sl * KC;
+                if (top_max > cbase + W - 1) { overflow = true; break; }
             }
             // bases: columns up to top_max - 1, rows up to n - min_col
             while (qfill < top_max - 1) {
@@ -187,55 +195,67 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             mycells += (unsigned long long)(top_max - min_col);
-            const int c = cbase + lane;
-            const bool inr = c >= min_col && c < top_max;
-            const int up = wave_shr1(A2, undef), dg = wave_shr1(A1, undef);        // column c - 1 of antidiagonals n-1, n-2
-            const int qb = rq[c & (RING - 1)], tb = rt[(n - c) & (RING - 1)];
-            int temp = (up > A2 ? up : A2) + gap;
-            const int t2 = dg + (qb == tb ? mat : mis);
-            temp = t2 > temp ? t2 : temp;
-            const bool keep = temp >= best - dropoff;
-            int A3 = (inr && keep) ? temp : undef;
+            const int c0 = cbase + lane * KC;
             const bool gi = (long long)n * gap > (long long)best - dropoff;          // the border cells may still be reached by gaps alone (:98-102)
-            if (c == off3) A3 = (gi && off3 == 0) ? n * gap : undef;
-            if (c == top_max) A3 = (gi && n == top_max) ? n * gap : undef;
+            const int up0 = wave_shr1(A2[KC - 1], undef), dg0 = wave_shr1(A1[KC - 1], undef);     // column c0 - 1 of antidiagonals n-1, n-2
+            int lane_max = int_min, lane_beat = -1, lane_first = KC, lane_last = -1, beat_score = 0;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) {
+                const int c = c0 + k;
+                const bool inr = c >= min_col && c < top_max;
+                const int up = k == 0 ? up0 : A2[k - 1], dg = k == 0 ? dg0 : A1[k - 1];
+                const int qb = rq[c & (RING - 1)], tb = rt[(n - c) & (RING - 1)];
+                int temp = (up > A2[k] ? up : A2[k]) + gap;
+                const int t2 = dg + (qb == tb ? mat : mis);
+                temp = t2 > temp ? t2 : temp;
+                const bool keep = temp >= best - dropoff;
+                int v = (inr && keep) ? temp : undef;
+                if (c == off3) v = (gi && off3 == 0) ? n * gap : undef;
+                if (c == top_max) v = (gi && n == top_max) ? n * gap : undef;
+                A3[k] = v;
+                if (inr && keep && temp > lane_max) lane_max = temp;
+                if (inr && temp > best) { lane_beat = k; beat_score = v; }                 // ascending k: the last one stays
+                // band trimming (:147-156), per column: dead = undef on this antidiagonal and (left neighbour) on the previous one
+                const bool dead = (c <= top_max) && v == undef && (c - 1 <= hi2) && up == undef;
+                if (c >= min_col && !dead && lane_first == KC) lane_first = k;
+                if (c >= off3 && c < top_max && !(v == undef && A2[k] == undef)) lane_last = k;
+            }
             // the extension ends at the LAST column of this antidiagonal that beats the best of the antidiagonals before it (:136-142)
-            const unsigned long long beat = __ballot(inr && temp > best);
+            const unsigned long long beat = __ballot(lane_beat >= 0);
             if (beat != 0) {
                 const int l = 63 - __builtin_clzll(beat);
-                best_col = cbase + l; best_row = n - best_col;
-                best_score = __builtin_amdgcn_readlane(A3, l);
-                const int m = wave_max_i32((inr && keep) ? temp : int_min);
+                best_col = cbase + l * KC + __builtin_amdgcn_readlane(lane_beat, l); best_row = n - best_col;
+                best_score = __builtin_amdgcn_readlane(beat_score, l);
+                const int m = wave_max_i32(lane_max);
                 best = m > best ? m : best;
             }
-            // band trimming (:147-156): the first column that is alive on this or the previous antidiagonal ...
-            {
-                const bool dead = (c <= top_max) && A3 == undef && (c - 1 <= hi2) && up == undef;
-                const unsigned long long stop = __ballot(c >= min_col && !dead);
-                min_col = stop ? cbase + (int)__builtin_ctzll(stop) : cbase + 64;
+            {   // the first column that is alive on this or the previous antidiagonal ...
+                const unsigned long long stop = __ballot(lane_first < KC);
+                if (stop) { const int l = (int)__builtin_ctzll(stop); min_col = cbase + l * KC + __builtin_amdgcn_readlane(lane_first, l); }
+                else min_col = cbase + W;
             }
-            // ... and one past the last
-            {
-                const unsigned long long alive = __ballot(c >= off3 && c < top_max && !(A3 == undef && A2 == undef));
-                max_col = alive ? cbase + 64 - (int)__builtin_clzll(alive) : off3;
+            {   // ... and one past the last
+                const unsigned long long alive = __ballot(lane_last >= 0);
+                if (alive) { const int l = 63 - __builtin_clzll(alive); max_col = cbase + l * KC + __builtin_amdgcn_readlane(lane_last, l) + 1; }
+                else max_col = off3;
             }
             ++max_col;
             if (min_col < n + 2 - rows) min_col = n + 2 - rows;
             if (max_col > cols) max_col = cols;
             hi2 = top_max;
-            A1 = A2; A2 = A3;
+#pragma unroll
+            for (int k = 0; k < KC; ++k) { A1[k] = A2[k]; A2[k] = A3[k]; }
             __builtin_amdgcn_wave_barrier();
         }
         if (!overflow) cells += mycells;
         res.score = best_score; res.col = best_col; res.row = best_row; res.overflow = overflow ? 1 : 0;
         if (lane == 0) {
             p.ext[tk2] = res;
-            if (overflow) { const unsigned int at = atomicAdd(p.ofl_count, 1u); p.ofl_list[at] = tk2; }
+            if (overflow) { const unsigned int at = atomicAdd(out_count, 1u); out_list[at] = tk2; }
         }
     }
     if (lane == 0 && cells) atomicAdd(p.cells, cells);
 }
-
 
 // The strided kernel: any band width.  One wavefront per extension that left the fast kernel; the three antidiagonals live in HBM
 // (indexed by absolute column, read and written with agent-scope accesses: lanes exchange cells through L2), lanes stride over the
@@ -243,13 +263,13 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p)
 __device__ __forceinline__ int ld_cell(const int *a, int c) { return __hip_atomic_load(&a[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_cell(int *a, int c, int v) { __hip_atomic_store(&a[c], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__global__ __launch_bounds__(64) void k_xdrop_strided(AlnParams p)
+__global__ __launch_bounds__(64) void k_xdrop_strided(AlnParams p, const uint32_t *in_list, const unsigned int *in_count)
 {
     const int lane = threadIdx.x & 63;
-    const unsigned int nofl = *p.ofl_count;
+    const unsigned int nofl = *in_count;
     unsigned long long cells = 0;
     for (unsigned int it = blockIdx.x; it < nofl; it += gridDim.x) {
-        const unsigned int tk2 = p.ofl_list[it];
+        const unsigned int tk2 = in_list[it];
         const AlnTask tk = p.tasks[tk2 >> 1];
         const int left = (int)(tk2 & 1u);
         ExtGeom g;
@@ -400,9 +420,10 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
     c.aln_tasks.reserve((size_t)(K + 1) * sizeof(AlnTask)); c.aln_ext.reserve((size_t)(2 * K + 2) * sizeof(AlnExt)); c.aln_ofl.reserve((size_t)(2 * K + 2) * 4);
     c.aln_rows.reserve((size_t)(K + 1) * 8); c.aln_cols.reserve((size_t)(K + 1) * 8); c.aln_out.reserve((size_t)(K + 1) * sizeof(elba_overlap_t));
     p.taskptr = c.aln_ptr.as<int64_t>(); p.tasks = c.aln_tasks.as<AlnTask>(); p.ext = c.aln_ext.as<AlnExt>(); p.ntasks = K;
-    unsigned int *ctr = c.aln_ctr.as<unsigned int>();
-    p.next = ctr; p.ofl_count = ctr + 16; p.cells = reinterpret_cast<unsigned long long *>(ctr + 32);
-    p.ofl_list = c.aln_ofl.as<uint32_t>();
+    unsigned int *ctr = c.aln_ctr.as<unsigned int>();       // [0..7] queue cursors per tier, [16..23] overflow counts per tier, [32] cells
+    p.cells = reinterpret_cast<unsigned long long *>(ctr + 32);
+    c.aln_ofl.reserve((size_t)(4 * K + 4) * 4);
+    uint32_t *lists[2] = {c.aln_ofl.as<uint32_t>(), c.aln_ofl.as<uint32_t>() + 2 * K + 2};
     p.out_rows = c.aln_rows.as<int64_t>(); p.out_cols = c.aln_cols.as<int64_t>(); p.out = c.aln_out.as<elba_overlap_t>();
     // strided kernel: three antidiagonals per wavefront, as long as the longest read + 2
     uint32_t maxlen = 0;
@@ -414,18 +435,31 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
     if (K > 0) {
         hipLaunchKernelGGL(k_aln_prepare, dim3(nbM), dim3(256), 0, s, p);
         c.t_a.start(s);
-        // persistent wavefronts pulling extensions from a queue: durations range from a handful of antidiagonals to tens of thousands
-        int64_t nb = (2 * K + ALN_WAVES - 1) / ALN_WAVES;
+        // persistent wavefronts pulling extensions from a queue: durations range from a handful of antidiagonals to tens of thousands.
+        // Tiers of 64 / 128 / 256 columns per wavefront: an extension whose band outgrows a tier is redone from its seed on the next;
+        // beyond 255 columns the strided kernel takes over.  (ELBA_ALN_TIERS="1,2,4" selects the instantiations, for A/B runs.)
+        int tiers[3] = {1, 2, 4}, ntiers = 3;
+        if (const char *e = getenv("ELBA_ALN_TIERS")) { ntiers = 0; for (const char *q = e; *q && ntiers < 3; ++q) if (*q == '1' || *q == '2' || *q == '4') tiers[ntiers++] = *q - '0'; if (ntiers == 0) { tiers[0] = 1; ntiers = 1; } }
         const int64_t resident = (int64_t)c.num_cus * 8;
-        if (nb > resident) nb = resident;
-        hipLaunchKernelGGL(k_xdrop_wave, dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p);
-        unsigned int nofl = 0;
-        ELBA_HIP(hipMemcpyAsync(&nofl, p.ofl_count, 4, hipMemcpyDeviceToHost, s));
-        ELBA_HIP(hipStreamSynchronize(s));
+        unsigned int nwork = (unsigned int)(2 * K);
+        const uint32_t *in_list = nullptr; const unsigned int *in_count = nullptr;
+        for (int t = 0; t < ntiers && nwork > 0; ++t) {
+            int64_t nb = ((int64_t)nwork + ALN_WAVES - 1) / ALN_WAVES;
+            if (nb > resident) nb = resident;
+            uint32_t *out_list = lists[t & 1]; unsigned int *out_count = ctr + 16 + t;
+            if (tiers[t] == 1) hipLaunchKernelGGL((k_xdrop_wave<1>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
+            else if (tiers[t] == 2) hipLaunchKernelGGL((k_xdrop_wave<2>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
+            else hipLaunchKernelGGL((k_xdrop_wave<4>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
+            ELBA_HIP(hipMemcpyAsync(&nwork, out_count, 4, hipMemcpyDeviceToHost, s));
+            ELBA_HIP(hipStreamSynchronize(s));
+            if (getenv("ELBA_TRACE")) fprintf(stderr, "[elba] x-drop tier %d columns/lane: %u extensions left\n", tiers[t], nwork);
+            in_list = out_list; in_count = out_count;
+        }
+        unsigned int nofl = nwork;
         if (nofl > 0) {
             c.aln_scratch.reserve((size_t)sblocks * 3 * p.scratch_stride * sizeof(int));
             p.scratch = c.aln_scratch.as<int>();
-            hipLaunchKernelGGL(k_xdrop_strided, dim3((unsigned)(nofl < (unsigned)sblocks ? nofl : (unsigned)sblocks)), dim3(64), 0, s, p);
+            hipLaunchKernelGGL(k_xdrop_strided, dim3((unsigned)(nofl < (unsigned)sblocks ? nofl : (unsigned)sblocks)), dim3(64), 0, s, p, in_list, in_count);
         }
         c.t_a.stop(s);
         hipLaunchKernelGGL(k_aln_combine, dim3((unsigned)((K + 255) / 256)), dim3(256), 0, s, p);

@@ -534,6 +534,10 @@ static inline int orc_revcomp_at(const uint8_t *mem, size_t len, size_t i) { ret
 
 /* src/XDropAligner.cpp:46-208.  Three antidiagonals ad1 (n-2), ad2 (n-1), ad3 (n), each stored from column offsetK on;
  * only best_ext_{col,row,score} leave the function (the ext_* tail of the reference, :166-205, has no effect on them). */
+/* diagnostics: widest band (max_col - min_col + 2 stored columns) and antidiagonals of the most recent extension on this thread */
+static _Thread_local int orc_dbg_band = 0, orc_dbg_ads = 0;
+void orc_xdrop_last_shape(int *band, int *ads) { *band = orc_dbg_band; *ads = orc_dbg_ads; }
+
 static int orc_extend_one_direction(const uint8_t *q, int lenQ, const uint8_t *t, int lenT, int extleft, orc_xseed_t *xs,
                                     int mat, int mis, int gap, int dropoff, int64_t *cells)
 {
@@ -558,8 +562,11 @@ static int orc_extend_one_direction(const uint8_t *q, int lenQ, const uint8_t *t
     n3 = 2; ad3[0] = ad3[1] = (-gap > dropoff) ? undef : gap;
     int ad_no = 1, best = 0;
     const int offsetQ = xs->endQ, offsetT = xs->endT;
+    orc_dbg_band = 0; orc_dbg_ads = 0;
     while (min_col < max_col) {
         ++ad_no;
+        if (max_col + 1 - (min_col - 1) > orc_dbg_band) orc_dbg_band = max_col + 1 - (min_col - 1);
+        ++orc_dbg_ads;
         { int *tb = ad1; ad1 = ad2; n1 = n2; ad2 = ad3; n2 = n3; ad3 = tb; }
         offset1 = offset2; offset2 = offset3; offset3 = min_col - 1;
         n3 = max_col + 1 - offset3;             /* resize: new cells hold whatever; every one is written below before it is read */

@@ -51,13 +51,19 @@ def test_align_long_noisy_reads_default_parameters():
     e.close()
 
 
-def test_align_wide_bands_take_the_strided_kernel():
-    """x-drop 90 on accurate reads: the band outgrows one wavefront; those extensions are redone by the strided kernel, same results."""
+@pytest.mark.parametrize("tiers", ["1", "2", "4", "1,2,4", "2,4"])
+def test_align_wide_bands_escalate_and_reach_the_strided_kernel(tiers, monkeypatch):
+    """x-drop 90 on accurate reads: the band outgrows 64 (128, 256) columns; those extensions are redone on the next tier and, past
+    the last one, by the strided kernel — same results whatever the tiers."""
+    monkeypatch.setenv("ELBA_ALN_TIERS", tiers)
     packed, off, lens, info = elba_amd.synth_reads(12, 60000, 12, 3000, 400, error_rate=0.02, min_len=500)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40)
     o = gu.oracle_run(packed, off, lens, 17, 2, 40)
     a = _compare(e, o, packed, off, lens, (1, -1, -1, 90))
-    assert a["extensions_strided"] > 0
+    if tiers == "1":
+        assert a["extensions_strided"] > 0
+    b = _compare(e, o, packed, off, lens, (1, -1, -1, 400))        # bands of several hundred columns: beyond every register tier
+    assert b["extensions_strided"] > 0
     e.close()
 
 
