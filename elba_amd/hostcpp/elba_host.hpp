@@ -11,6 +11,7 @@
 //   AT = *A; AT->Transpose()            src/main.cpp:272-273          KmerMatrix copy + Transpose(): no work, both orientations exist
 //   SharedSeeds          include/SharedSeeds.hpp:8-96                 elba::SharedSeeds (same members and accessors)
 //   create_seed_matrix   include/SharedSeeds.hpp:98-99                same name -> elba::SeedMatrix
+//   PairwiseAlignment    include/PairwiseAlignment.hpp, src/PairwiseAlignment.cpp:5-106     same name -> elba::OverlapMatrix (triples of elba::Overlap)
 //   Bmat.seqptr()->getnnz() / GetDCSC()  src/PairwiseAlignment.cpp:16-19   SeedMatrix::seqptr()->getnnz() / GetDCSC()
 //
 // Errors: the reference asserts/aborts; here every failing C-ABI status throws elba::Error (status + text).
@@ -217,6 +218,49 @@ inline std::unique_ptr<SeedMatrix> create_seed_matrix(KmerMatrix &A, KmerMatrix 
     B->nrows = A.stats.nrows;
     B->engine->check(elba_create_seed_matrix(B->engine->ctx, &B->stats));   // Mult_AnXBn_DoubleBuff + Prune(numshared <= 1), src/SharedSeeds.cpp:7-8
     return B;
+}
+
+// The fields of the reference's Overlap that extend_overlap fills (include/Overlap.hpp:22-28; src/Overlap.cpp:24-73), same names.
+struct Overlap {
+    std::tuple<PosInRead, PosInRead> beg, end, len, seed;
+    int score = 0, suffix = 0, suffixT = 0;
+    int8_t direction = -1, directionT = -1;
+    bool rc = false, passed = false, containedQ = false, containedT = false;
+};
+
+// What PairwiseAlignment hands to SpParMat<Overlap>(numreads, numreads, drows, dcols, dvals, false): the local triples (src/PairwiseAlignment.cpp:97-103)
+class OverlapMatrix {
+public:
+    int64_t numreads = 0;
+    std::vector<int64_t> rows, cols;
+    std::vector<Overlap> vals;
+    elba_align_stats stats{};
+    int64_t getnnz() const { return (int64_t)vals.size(); }
+};
+
+// PairwiseAlignment(dfd, Bmat, mat, mis, gap, dropoff) — src/PairwiseAlignment.cpp:5-106 on one rank: every stored B(i,j), i < j, is
+// aligned from seeds[0] on the GPU (the reads are the ones the k-mer stage was given; DistributedFastaData's row/column buffers are
+// the same buffer on one rank).
+inline std::unique_ptr<OverlapMatrix> PairwiseAlignment(const DnaBuffer &myreads, SeedMatrix &Bmat, int mat, int mis, int gap, int dropoff)
+{
+    auto R = std::make_unique<OverlapMatrix>();
+    R->numreads = Bmat.getnrow();
+    Bmat.engine->check(elba_align_seeds(Bmat.engine->ctx, mat, mis, gap, dropoff, &R->stats));
+    elba_overlaps_t o;
+    Bmat.engine->check(elba_export_overlaps(Bmat.engine->ctx, &o));
+    R->rows.assign(o.rows, o.rows + o.n); R->cols.assign(o.cols, o.cols + o.n);
+    R->vals.resize((size_t)o.n);
+    // (Overlap::seed, a copy of seeds[0] of B(i,j), is not carried back: the caller still owns B)
+    for (int64_t a = 0; a < o.n; ++a) {
+        const elba_overlap_t &v = o.vals[a];
+        Overlap &w = R->vals[(size_t)a];
+        w.beg = std::make_tuple((PosInRead)v.begQ, (PosInRead)v.begT); w.end = std::make_tuple((PosInRead)v.endQ, (PosInRead)v.endT);
+        w.len = std::make_tuple((PosInRead)myreads.lengths()[o.rows[a]], (PosInRead)myreads.lengths()[o.cols[a]]);
+        w.score = v.score; w.suffix = v.suffix; w.suffixT = v.suffixT; w.direction = v.direction; w.directionT = v.directionT;
+        w.rc = v.rc; w.passed = v.passed; w.containedQ = v.containedQ; w.containedT = v.containedT;
+    }
+    elba_free_overlaps(&o);
+    return R;
 }
 
 }  // namespace elba

@@ -51,8 +51,17 @@ int main(int argc, char **argv)
                                     + (uint64_t)localrow * 31ull + (uint64_t)localcol;
                     }
                 }
-        std::printf("{\"reads\": %zu, \"nnzA\": %lld, \"kmers\": %lld, \"nnzB\": %zu, \"candidates\": %lld, \"checksum\": %llu}\n", mydna.size(),
-                    (long long)nnzA, (long long)ncol, localnnzs, (long long)nalign, (unsigned long long)checksum);
+        // main.cpp:300: R = PairwiseAlignment(dfd, *B, mat, mis, gap, xdrop_cutoff) with the defaults of main.cpp:53-56
+        auto R = elba::PairwiseAlignment(mydna, *B, 1, -1, -1, 15);
+        uint64_t achk = 0; int64_t npassed = 0;
+        for (size_t a = 0; a < R->vals.size(); ++a) {
+            const elba::Overlap &o = R->vals[a];
+            npassed += o.passed ? 1 : 0;
+            achk += (uint64_t)(uint32_t)o.score * 1000003ull + std::get<0>(o.beg) * 31ull + std::get<1>(o.beg) * 37ull + std::get<0>(o.end) * 41ull + std::get<1>(o.end) * 43ull
+                    + (uint64_t)(o.rc ? 7 : 0) + (uint64_t)(uint8_t)o.direction * 131ull + (uint64_t)(uint32_t)o.suffix * 8191ull + (uint64_t)R->rows[a] * 3ull + (uint64_t)R->cols[a];
+        }
+        std::printf("{\"reads\": %zu, \"nnzA\": %lld, \"kmers\": %lld, \"nnzB\": %zu, \"candidates\": %lld, \"checksum\": %llu, \"alignments\": %lld, \"passed\": %lld, \"align_checksum\": %llu}\n", mydna.size(),
+                    (long long)nnzA, (long long)ncol, localnnzs, (long long)nalign, (unsigned long long)checksum, (long long)R->getnnz(), (long long)npassed, (unsigned long long)achk);
     } catch (const elba::Error &e) {
         std::fprintf(stderr, "%s\n", e.what());
         return e.status == ELBA_ERR_NO_DEVICE ? 3 : 1;

@@ -50,4 +50,12 @@ def test_mirror_matches_oracle_on_gpu(name, idx):
            + rows[up_mask] * np.uint64(31) + cols[up_mask])
     with np.errstate(over="ignore"):
         checksum = int(chk.sum(dtype=np.uint64))
-    assert got == {"reads": m["M"], "nnzA": m["Z"], "kmers": m["N"], "nnzB": m["Y"], "candidates": o.stat("nupper"), "checksum": checksum}
+    ar, ac, ov, _ = o.align_upper(packed, off, lens)
+    u = lambda a, dt=np.uint32: a.astype(dt).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        achk = (u(ov["score"]) * np.uint64(1000003) + u(ov["begQ"]) * np.uint64(31) + u(ov["begT"]) * np.uint64(37) + u(ov["endQ"]) * np.uint64(41) + u(ov["endT"]) * np.uint64(43)
+                + ov["rc"].astype(np.uint64) * np.uint64(7) + u(ov["direction"], np.uint8) * np.uint64(131) + u(ov["suffix"]) * np.uint64(8191)
+                + ar.astype(np.uint64) * np.uint64(3) + ac.astype(np.uint64))
+        achk = int(achk.sum(dtype=np.uint64))
+    assert got == {"reads": m["M"], "nnzA": m["Z"], "kmers": m["N"], "nnzB": m["Y"], "candidates": o.stat("nupper"), "checksum": checksum,
+                   "alignments": len(ar), "passed": int(ov["passed"].sum()), "align_checksum": achk}
