@@ -27,6 +27,7 @@ struct AlnTask {               // one candidate pair, prepared by k_aln_prepare
     int32_t begQ, endQ;        // seed in the query
     int32_t begT, endT;        // seed in the target's oriented coordinates (reverse-complemented when rc)
     int32_t valid, rc;         // xdrop_aligner's prologue: seed accepted / orientation
+    int32_t numshared;         // of B(i,j): only a hint for the starting tier (few shared k-mers = probably unrelated reads = wide band)
 };
 struct AlnExt { int32_t score, col, row, overflow; };       // best_ext_score / best_ext_col / best_ext_row of one direction
 
@@ -35,6 +36,7 @@ struct AlnParams {
     const int64_t *b_rowptr; const uint32_t *b_col; const elba_seed_t *b_val;
     uint32_t M, row_lo, row_hi;
     int32_t k, mat, mis, gap, dropoff;
+    int32_t wide_hint;         // pairs with numshared <= wide_hint skip the 64-column tier (performance only: any tier gives the same result)
     uint32_t *cnt; const int64_t *taskptr;
     AlnTask *tasks; AlnExt *ext; int64_t ntasks;
     int *scratch; unsigned long long scratch_stride;  // strided kernel: three antidiagonals per wavefront
@@ -69,7 +71,7 @@ __global__ void k_aln_prepare(AlnParams p)
         const int lenT = (int)p.len[j];
         const int begQ = (int)p.b_val[e].q0, begT = (int)p.b_val[e].t0, k = p.k;
         AlnTask tk{};
-        tk.i = i; tk.j = j;
+        tk.i = i; tk.j = j; tk.numshared = p.b_val[e].numshared;
         bool ok = !(begQ < 0 || begQ + k > lenQ) && !(begT < 0 || begT + k > lenT) && !(begQ == 0 && begT == 0);
         if (ok) {
             const bool rc = base_at(q, (uint32_t)(begQ + (k >> 1))) != base_at(t, (uint32_t)(begT + (k >> 1)));
@@ -114,11 +116,18 @@ __device__ __forceinline__ bool ext_geometry(const AlnParams &p, const AlnTask &
 }
 
 __device__ __forceinline__ int wave_shr1(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+// maximum over the wavefront, in registers: four DPP steps make every lane of a 16-lane row hold its row's maximum, two row broadcasts
+// carry it into the last row; the result is read from lane 63.  (A shuffle-based butterfly costs six LDS round trips per antidiagonal.)
 __device__ __forceinline__ int wave_max_i32(int v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-    return v;
+    int t;
+    t = __builtin_amdgcn_update_dpp(v, v, 0xB1 /* quad_perm [1,0,3,2] */, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x4E /* quad_perm [2,3,0,1] */, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x141 /* row_half_mirror */, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x140 /* row_mirror */, 0xf, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x142 /* row_bcast:15 */, 0xa, 0xf, false); v = t > v ? t : v;
+    t = __builtin_amdgcn_update_dpp(v, v, 0x143 /* row_bcast:31 */, 0xc, 0xf, false); v = t > v ? t : v;
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 constexpr int ALN_WAVES = 4;     // independent wavefronts per workgroup
@@ -148,6 +157,10 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
         AlnExt res{0, 0, 0, 0};
         ExtGeom g;
         if (!tk.valid || !ext_geometry(p, tk, left, g)) { if (lane == 0) p.ext[tk2] = res; continue; }
+        if (KC == 1 && in_list == nullptr && tk.numshared <= p.wide_hint) {          // probably a wide band: straight to the next tier
+            if (lane == 0) { const unsigned int at = atomicAdd(out_count, 1u); out_list[at] = tk2; }
+            continue;
+        }
         const int cols = g.cols, rows = g.rows;
         const int int_min = (int)0x80000000;
         const int len2 = 2 * (cols > rows ? cols : rows);
@@ -166,6 +179,13 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
         int qfill = 0, tfill = 0;                        // logical columns / rows unpacked into the rings so far
         bool overflow = false;
         unsigned long long mycells = 0;                  // (an extension that leaves for a wider kernel is counted there)
+        // The bases a lane needs: its KC query bases change only when the window slides or a refill reaches its columns; its target
+        // bases move one row per antidiagonal and are read one antidiagonal AHEAD (the ring is filled one row ahead as well), so the
+        // recurrence never waits for LDS.
+        int qb[KC], tb[KC];
+#pragma unroll
+        for (int k = 0; k < KC; ++k) { qb[k] = 0; tb[k] = 0; }
+        bool reload = true;
         while (min_col < max_col) {
             ++n;
             const int off3 = min_col - 1, top_max = max_col;      // this antidiagonal is stored for columns [off3, top_max]   (:93-96)
@@ -180,23 +200,29 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
                 }
                 cbase += sl * KC;
                 if (top_max > cbase + W - 1) { overflow = true; break; }
+                reload = true;
             }
-            // bases: columns up to top_max - 1, rows up to n - min_col
-            while (qfill < top_max - 1) {
+            // bases: columns up to top_max (one ahead of this antidiagonal's last computed column), rows up to n + 1 - min_col
+            while (qfill < top_max) {
                 const int c = qfill + 1 + lane;
                 if (c < cols) rq[c & (RING - 1)] = (uint8_t)q_base(g, c);
-                qfill += 64;
+                qfill += 64; reload = true;
             }
-            while (tfill < n - min_col) {
+            while (tfill < n + 1 - min_col) {
                 const int r = tfill + 1 + lane;
                 if (r < rows) rt[r & (RING - 1)] = (uint8_t)t_base(g, r);
-                tfill += 64;
+                tfill += 64; reload = true;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            if (reload) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int k = 0; k < KC; ++k) { const int c = cbase + lane * KC + k; qb[k] = rq[c & (RING - 1)]; tb[k] = rt[(n - c) & (RING - 1)]; }
+                reload = false;
+            }
             mycells += (unsigned long long)(top_max - min_col);
             const int c0 = cbase + lane * KC;
-            const bool gi = (long long)n * gap > (long long)best - dropoff;          // the border cells may still be reached by gaps alone (:98-102)
+            const bool gi = n * gap > best - dropoff;          // the border cells may still be reached by gaps alone (:98-102); |n * gap| < 2^31 by the clamp of gap above
             const int up0 = wave_shr1(A2[KC - 1], undef), dg0 = wave_shr1(A1[KC - 1], undef);     // column c0 - 1 of antidiagonals n-1, n-2
             int lane_max = int_min, lane_beat = -1, lane_first = KC, lane_last = -1, beat_score = 0;
 #pragma unroll
@@ -204,9 +230,8 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
                 const int c = c0 + k;
                 const bool inr = c >= min_col && c < top_max;
                 const int up = k == 0 ? up0 : A2[k - 1], dg = k == 0 ? dg0 : A1[k - 1];
-                const int qb = rq[c & (RING - 1)], tb = rt[(n - c) & (RING - 1)];
                 int temp = (up > A2[k] ? up : A2[k]) + gap;
-                const int t2 = dg + (qb == tb ? mat : mis);
+                const int t2 = dg + (qb[k] == tb[k] ? mat : mis);
                 temp = t2 > temp ? t2 : temp;
                 const bool keep = temp >= best - dropoff;
                 int v = (inr && keep) ? temp : undef;
@@ -244,8 +269,7 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
             if (max_col > cols) max_col = cols;
             hi2 = top_max;
 #pragma unroll
-            for (int k = 0; k < KC; ++k) { A1[k] = A2[k]; A2[k] = A3[k]; }
-            __builtin_amdgcn_wave_barrier();
+            for (int k = 0; k < KC; ++k) { A1[k] = A2[k]; A2[k] = A3[k]; tb[k] = rt[(n + 1 - (c0 + k)) & (RING - 1)]; }     // next antidiagonal's target bases
         }
         if (!overflow) cells += mycells;
         res.score = best_score; res.col = best_col; res.row = best_row; res.overflow = overflow ? 1 : 0;
@@ -404,6 +428,7 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
     p.b_rowptr = c.b_rowptr.as<int64_t>(); p.b_col = c.b_col.as<uint32_t>(); p.b_val = c.b_val.as<elba_seed_t>();
     p.M = (uint32_t)M; p.row_lo = 0; p.row_hi = (uint32_t)M;
     p.k = c.cfg.k; p.mat = mat; p.mis = mis; p.gap = gap; p.dropoff = dropoff;
+    p.wide_hint = getenv("ELBA_ALN_WIDE_HINT") ? atoi(getenv("ELBA_ALN_WIDE_HINT")) : 6;
     c.t_total.start(s);
     c.aln_cnt.reserve((size_t)(M + 2) * 4); c.aln_ptr.reserve((size_t)(M + 2) * 8); c.aln_ctr.reserve(256);
     p.cnt = c.aln_cnt.as<uint32_t>();
