@@ -46,6 +46,10 @@ class OverlapStats(C.Structure):
                 ("ms_total", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float), ("ms_finalize", C.c_float)]
 
 
+class IngestStats(C.Structure):
+    _fields_ = [("nreads", C.c_int64), ("bases", C.c_int64), ("packed_bytes", C.c_int64), ("chunk_bytes", C.c_int64), ("ms_total", C.c_float), ("ms_encode", C.c_float)]
+
+
 class AlignStats(C.Structure):
     _fields_ = [("nalignments", C.c_int64), ("seeds_rejected", C.c_int64), ("passed", C.c_int64), ("contained", C.c_int64),
                 ("extensions_strided", C.c_int64), ("cells", C.c_int64), ("ms_total", C.c_float), ("ms_extend", C.c_float)]
@@ -95,7 +99,7 @@ EXPORTED_SYMBOLS = [
     "elba_abi_version", "elba_strerror", "elba_last_error", "elba_ctx_create", "elba_ctx_destroy", "elba_set_reads", "elba_set_reads_device",
     "elba_count_kmers", "elba_create_kmer_matrix", "elba_set_kmer_matrix", "elba_create_seed_matrix", "elba_export_dcsc", "elba_free_dcsc",
     "elba_export_csr", "elba_free_csr", "elba_export_kmer_matrix", "elba_free_kmer_matrix", "elba_kmer_histogram", "elba_get_device_view",
-    "elba_align_seeds", "elba_export_overlaps", "elba_free_overlaps",
+    "elba_align_seeds", "elba_export_overlaps", "elba_free_overlaps", "elba_set_reads_fasta", "elba_export_reads",
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
     "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
     "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_set_panel",
@@ -121,6 +125,8 @@ def load_library():
     L.elba_ctx_destroy.restype = None; L.elba_ctx_destroy.argtypes = [vp]
     L.elba_set_reads.restype = i32; L.elba_set_reads.argtypes = [vp, vp, vp, vp, i64, i64]
     L.elba_set_reads_device.restype = i32; L.elba_set_reads_device.argtypes = [vp, vp, i64, vp, vp, i64, i64]
+    L.elba_set_reads_fasta.restype = i32; L.elba_set_reads_fasta.argtypes = [vp, vp, i64, C.c_uint64, vp, i64, i64, C.POINTER(IngestStats)]
+    L.elba_export_reads.restype = i32; L.elba_export_reads.argtypes = [vp, vp, i64, vp, vp, i64]
     L.elba_count_kmers.restype = i32; L.elba_count_kmers.argtypes = [vp, C.POINTER(KmerStats)]
     L.elba_create_kmer_matrix.restype = i32; L.elba_create_kmer_matrix.argtypes = [vp, C.POINTER(MatrixStats)]
     L.elba_set_kmer_matrix.restype = i32; L.elba_set_kmer_matrix.argtypes = [vp, i64, i64, i64, vp, vp, vp, C.POINTER(MatrixStats)]
@@ -213,6 +219,22 @@ class Engine:
 
     def set_reads_device(self, d_packed, packed_bytes, d_byte_off, d_len, nreads, first_global_id=0):
         self._check(self.L.elba_set_reads_device(self.h, d_packed, packed_bytes, d_byte_off, d_len, nreads, first_global_id))
+
+    def set_reads_fasta(self, chunk, chunk_file_offset, recs, first_global_id=0):
+        """FastaIndex::getmydna (src/FastaIndex.cpp:191-290) with the 2-bit encoding on the GPU: `chunk` = raw FASTA bytes from
+        `chunk_file_offset` on, `recs` = this rank's .fai records (elba_amd.fasta.FAI_DTYPE)."""
+        buf = np.frombuffer(chunk, dtype=np.uint8) if not isinstance(chunk, np.ndarray) else np.ascontiguousarray(chunk, dtype=np.uint8)
+        recs = np.ascontiguousarray(recs)
+        assert recs.dtype.itemsize == 24
+        st = IngestStats()
+        self._check(self.L.elba_set_reads_fasta(self.h, buf.ctypes.data if buf.size else None, buf.size, chunk_file_offset, recs.ctypes.data if recs.size else None,
+                                                len(recs), first_global_id, C.byref(st)))
+        return _stats(st)
+
+    def export_reads(self, nreads, packed_bytes):
+        packed = np.zeros(packed_bytes + 16, dtype=np.uint8); off = np.zeros(nreads, dtype=np.uint64); ln = np.zeros(nreads, dtype=np.uint32)
+        self._check(self.L.elba_export_reads(self.h, packed.ctypes.data, packed_bytes, off.ctypes.data, ln.ctypes.data, nreads))
+        return packed, off, ln
 
     def set_kmer_matrix(self, nrows, ncols, rows, cols, vals):
         rows = np.ascontiguousarray(rows, dtype=np.int64)

@@ -141,6 +141,27 @@ int elba_set_reads(elba_ctx *ctx, const uint8_t *packed, const uint64_t *byte_of
     });
 }
 
+int elba_set_reads_fasta(elba_ctx *ctx, const char *chunk, int64_t chunk_bytes, uint64_t chunk_file_offset, const elba_fasta_record_t *recs, int64_t nreads,
+                         int64_t first_global_id, elba_ingest_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_set_reads_fasta(c, chunk, chunk_bytes, chunk_file_offset, recs, nreads, first_global_id, stats); });
+}
+
+int elba_export_reads(elba_ctx *ctx, uint8_t *packed, int64_t packed_capacity, uint64_t *byte_off, uint32_t *len, int64_t nreads_capacity)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "export_reads: no reads");
+        if (packed) {
+            ELBA_REQUIRE(packed_capacity >= c.packed_bytes, ELBA_ERR_INVALID_ARG, "export_reads: packed buffer too small");
+            if (c.packed_bytes) ELBA_HIP(hipMemcpyAsync(packed, c.d_packed, (size_t)c.packed_bytes, hipMemcpyDeviceToHost, c.stream));
+        }
+        if (byte_off || len) ELBA_REQUIRE(nreads_capacity >= c.nreads, ELBA_ERR_INVALID_ARG, "export_reads: offset/length arrays too small");
+        if (byte_off && c.nreads) ELBA_HIP(hipMemcpyAsync(byte_off, c.d_byte_off, (size_t)c.nreads * 8, hipMemcpyDeviceToHost, c.stream));
+        if (len && c.nreads) ELBA_HIP(hipMemcpyAsync(len, c.d_len, (size_t)c.nreads * 4, hipMemcpyDeviceToHost, c.stream));
+        ELBA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
 int elba_set_reads_device(elba_ctx *ctx, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads, int64_t first_global_id)
 {
     return guarded(ctx, [&](Ctx &c) {

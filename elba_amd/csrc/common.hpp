@@ -191,6 +191,8 @@ struct Ctx {
 };
 
 // ---- stages -----------------------------------------------------------------------------------------------------
+void stage_set_reads_fasta(Ctx &c, const char *chunk, int64_t chunk_bytes, uint64_t chunk_file_offset, const elba_fasta_record_t *recs, int64_t nreads,
+                           int64_t first_global_id, elba_ingest_stats *stats);      // ingest.hip
 void stage_count_kmers(Ctx &c);                                   // kmer.hip
 void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
 void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip

@@ -69,6 +69,16 @@ typedef struct {
     uint8_t reserved;
 } elba_overlap_t;
 
+/* One line of the samtools-style .fai next to the FASTA: FastaIndex::Record (include/FastaIndex.hpp:10; name and line width with
+ * newline are not kept by the reference either: src/FastaIndex.cpp:15-23 reads `name len pos bases`). */
+typedef struct { uint64_t len, pos, bases; } elba_fasta_record_t;
+
+typedef struct {
+    int64_t nreads, bases, packed_bytes, chunk_bytes;
+    float   ms_total;       /* H2D copy of the chunk + encode */
+    float   ms_encode;      /* the encode kernel alone */
+} elba_ingest_stats;
+
 typedef struct {
     int64_t nalignments;    /* candidate pairs aligned: stored B(i,j) with i < j (src/PairwiseAlignment.cpp:52 on one rank) */
     int64_t seeds_rejected; /* xdrop_aligner returned -1 (src/XDropAligner.cpp:231-245) */
@@ -194,6 +204,15 @@ int  elba_set_reads(elba_ctx *ctx, const uint8_t *packed, const uint64_t *byte_o
 int  elba_set_reads_device(elba_ctx *ctx, const void *d_packed, int64_t packed_bytes, const void *d_byte_off,
                            const void *d_len, int64_t nreads, int64_t first_global_id);
 
+/* FastaIndex::getmydna (src/FastaIndex.cpp:191-290) without the host-side parse: `chunk` holds the raw bytes of the FASTA file from
+ * file offset `chunk_file_offset` on (the reference's MPI_File_read_at_all buffer, :236-241), `recs` the .fai records of this rank's
+ * reads in order; the reads are 2-bit encoded on the device straight into the DnaBuffer layout (DnaSeq::compress, src/DnaSeq.cpp:7-29)
+ * and become the context's reads, as after elba_set_reads. */
+int  elba_set_reads_fasta(elba_ctx *ctx, const char *chunk, int64_t chunk_bytes, uint64_t chunk_file_offset,
+                          const elba_fasta_record_t *recs, int64_t nreads, int64_t first_global_id, elba_ingest_stats *stats);
+/* The resident reads back on the host in DnaBuffer layout: packed[packed_bytes], byte_off[nreads], len[nreads] (caller-allocated;
+ * any pointer may be NULL to skip it).  Sizes: elba_ingest_stats, or nreads and sum((len+3)/4). */
+int  elba_export_reads(elba_ctx *ctx, uint8_t *packed, int64_t packed_capacity, uint64_t *byte_off, uint32_t *len, int64_t nreads_capacity);
 int  elba_count_kmers(elba_ctx *ctx, elba_kmer_stats *stats);
 int  elba_create_kmer_matrix(elba_ctx *ctx, elba_matrix_stats *stats);
 
