@@ -27,27 +27,42 @@ __device__ __forceinline__ uint32_t char_code(uint8_t ch)
     }
 }
 
+// One lane encodes 16 consecutive bases into one 32-bit word of the output (the packed bytes of a read are byte-ordered, first base in
+// bits 7-6 of byte 0: the word is assembled byte by byte and stored little-endian; a read's buffer starts on a 4-byte boundary only
+// by accident, so the tail and unaligned reads fall back to byte stores).  The line of the first base costs one 32-bit division per
+// lane and trip; the character codes come from a 256-entry table in LDS.
 __global__ __launch_bounds__(256) void k_fasta_encode(const uint8_t *chunk, uint64_t chunk_off, uint64_t chunk_bytes, const elba_fasta_record_t *recs,
                                                       const uint64_t *byte_off, uint32_t nreads, uint8_t *packed)
 {
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = (uint8_t)char_code((uint8_t)threadIdx.x);
+    __syncthreads();
     for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
-        const uint64_t len = recs[r].len, pos = recs[r].pos - chunk_off, bases = recs[r].bases;
+        const uint32_t len = (uint32_t)recs[r].len;
+        const uint64_t bases64 = recs[r].bases;
+        const uint32_t bases = bases64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bases64;      // a line longer than the read: never wraps
+        const uint8_t *src = chunk + (recs[r].pos - chunk_off);
+        const uint64_t avail = chunk_bytes - (recs[r].pos - chunk_off);                         // bytes of the chunk from the record's first base on
         uint8_t *out = packed + byte_off[r];
-        const uint64_t nbytes = (len + 3) / 4;
-        for (uint64_t b = threadIdx.x; b < nbytes; b += blockDim.x) {
-            const uint64_t p0 = 4 * b;
-            uint64_t line = p0 / bases, rem = p0 - line * bases;
-            uint32_t byte = 0;
+        const uint32_t nbytes = (len + 3) / 4, nwords = (nbytes + 3) / 4;
+        const bool aligned = (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
+        for (uint32_t w = threadIdx.x; w < nwords; w += blockDim.x) {
+            const uint32_t p0 = 16 * w;
+            uint32_t line = p0 / bases, rem = p0 - line * bases;
+            uint32_t word = 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (p0 + (uint64_t)i < len) {
-                    const uint64_t at = pos + p0 + (uint64_t)i + line;
-                    const uint32_t code = at < chunk_bytes ? char_code(chunk[at]) : 4u;
-                    byte |= (code << (6 - 2 * i)) & 0xFFu;
+            for (int i = 0; i < 16; ++i) {
+                if (p0 + (uint32_t)i < len) {
+                    const uint64_t at = (uint64_t)p0 + (uint32_t)i + line;
+                    const uint32_t code = at < avail ? lut[src[at]] : 4u;
+                    const uint32_t byte = (code << (6 - 2 * (i & 3))) & 0xFFu;
+                    word |= byte << (8 * (i >> 2));
                     if (++rem == bases) { rem = 0; ++line; }
                 }
             }
-            out[b] = (uint8_t)byte;
+            const uint32_t b0 = 4 * w;
+            if (aligned && b0 + 4 <= nbytes) *reinterpret_cast<uint32_t *>(out + b0) = word;
+            else for (uint32_t x = 0; x < 4 && b0 + x < nbytes; ++x) out[b0 + x] = (uint8_t)(word >> (8 * x));
         }
     }
 }
@@ -64,7 +79,7 @@ void stage_set_reads_fasta(Ctx &c, const char *chunk, int64_t chunk_bytes, uint6
     std::vector<uint32_t> len((size_t)nreads);
     uint64_t pb = 0, totbases = 0;
     for (int64_t r = 0; r < nreads; ++r) {
-        ELBA_REQUIRE(recs[r].len < 0xFFFFFFFFull && recs[r].bases > 0, ELBA_ERR_INVALID_ARG, "set_reads_fasta: bad .fai record (length >= 2^32 or zero line width)");
+        ELBA_REQUIRE(recs[r].len < 0x7FFFFFF0ull && recs[r].bases > 0, ELBA_ERR_INVALID_ARG, "set_reads_fasta: bad .fai record (length >= 2^31 or zero line width)");
         ELBA_REQUIRE(recs[r].pos >= chunk_file_offset, ELBA_ERR_INVALID_ARG, "set_reads_fasta: record starts before the chunk");
         // last base of the record must lie inside the chunk (src/FastaIndex.cpp:222-224 sizes the chunk the same way)
         const uint64_t last = recs[r].len ? recs[r].pos - chunk_file_offset + (recs[r].len - 1) + (recs[r].len - 1) / recs[r].bases : 0;
