@@ -224,6 +224,41 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
             const int c0 = cbase + lane * KC;
             const bool gi = n * gap > best - dropoff;          // the border cells may still be reached by gaps alone (:98-102); |n * gap| < 2^31 by the clamp of gap above
             const int up0 = wave_shr1(A2[KC - 1], undef), dg0 = wave_shr1(A1[KC - 1], undef);     // column c0 - 1 of antidiagonals n-1, n-2
+            if constexpr (KC == 1) {
+                // One column per lane: the bookkeeping is a handful of lane masks.  (The kernel is bound by instruction issue — scalar
+                // and vector alike, ~26 of 64 lanes carry a cell — so this common instantiation is written out instead of going
+                // through the per-lane first / last / beat indices of the general form below.)
+                const int c = c0;
+                const bool inr = (unsigned)(c - min_col) < (unsigned)(top_max - min_col);
+                int temp = (up0 > A2[0] ? up0 : A2[0]) + gap;
+                const int t2 = dg0 + (qb[0] == tb[0] ? mat : mis);
+                temp = t2 > temp ? t2 : temp;
+                const bool keep = inr && temp >= best - dropoff;
+                int v = keep ? temp : undef;
+                if (gi) {                                   // only while gaps alone stay within the drop-off: the first few antidiagonals
+                    if (c == off3) v = off3 == 0 ? n * gap : undef;
+                    if (c == top_max) v = n == top_max ? n * gap : undef;
+                }
+                A3[0] = v;
+                const unsigned long long beat = __ballot(inr && temp > best);
+                if (beat != 0) {
+                    const int l = 63 - __builtin_clzll(beat);
+                    best_col = cbase + l; best_row = n - best_col;
+                    best_score = __builtin_amdgcn_readlane(v, l);
+                    const int m = wave_max_i32(keep ? temp : int_min);
+                    best = m > best ? m : best;
+                }
+                // trimming (:147-156).  First column >= min_col that is not undef on this antidiagonal or, one column to the left, on the
+                // previous one; the reference's size guards stop the scan at top_max + 1 at the latest (hi2 >= top_max - 1 always).
+                const unsigned long long live3 = __ballot(v != undef);
+                const unsigned long long stop = (live3 | __ballot(up0 != undef)) & (~0ull << (min_col - cbase));
+                int nmin = stop ? cbase + (int)__builtin_ctzll(stop) : top_max + 1;
+                min_col = nmin < top_max + 1 ? nmin : top_max + 1;
+                // one past the last column in [off3, top_max) that is not undef on this or the previous antidiagonal
+                const unsigned long long span = (~0ull << (off3 - cbase)) & ~(~0ull << (top_max - cbase));       // top_max - cbase <= 63 (window check above)
+                const unsigned long long alive = (live3 | __ballot(A2[0] != undef)) & span;
+                max_col = alive ? cbase + 64 - (int)__builtin_clzll(alive) : off3;
+            } else {
             int lane_max = int_min, lane_beat = -1, lane_first = KC, lane_last = -1, beat_score = 0;
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
@@ -263,6 +298,7 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
                 const unsigned long long alive = __ballot(lane_last >= 0);
                 if (alive) { const int l = 63 - __builtin_clzll(alive); max_col = cbase + l * KC + __builtin_amdgcn_readlane(lane_last, l) + 1; }
                 else max_col = off3;
+            }
             }
             ++max_col;
             if (min_col < n + 2 - rows) min_col = n + 2 - rows;
