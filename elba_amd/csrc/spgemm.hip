@@ -3,9 +3,9 @@
 // Replaces create_seed_matrix (src/SharedSeeds.cpp:4-10: CombBLAS Mult_AnXBn_DoubleBuff<SharedSeeds::Semiring> + Prune)
 // with a row-wise hash SpGEMM written for CDNA4:
 //
-//   * one workgroup owns one read-row i of CSR(A); its lanes walk the row's entries (kid, posQ) with coalesced 8-byte
-//     loads and, for each, the k-mer's column of CSC(A) — (read j, posT) entries — gathered from HBM/L2/Infinity Cache;
-//     each lane keeps two row entries and up to 16 speculative column loads in flight (the walk is latency-bound);
+//   * one workgroup owns one read-row i of A; its lanes walk the row's per-entry descriptors (matrix.hip: for the row entry
+//     (i, k, pos) the contiguous ranges of column k that hold its partners, 16 bytes, coalesced) and gather the partner
+//     entries (read j, posT) of those ranges from the k-mer columns in HBM / Infinity Cache, four per lane in flight;
 //   * every product (i,k)x(j,k) updates an open-addressed accumulator keyed by the partner read j that lives in LDS
 //     (16 B per slot, SoA: key | count | smin | smax); the semiring's non-commutative add (include/SharedSeeds.hpp:41-46:
 //     keep the FIRST seed of the left operand and the FIRST seed of the right operand) is made order-free by the
@@ -70,7 +70,7 @@ struct OvCounters {              // device-side counters, zeroed per call
 struct alignas(32) StageRec { uint4 a, b; };
 
 struct OvParams {
-    const uint32_t *a_rowptr; const uint64_t *a_csr; const uint32_t *a_colptr; const uint64_t *a_csc; const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_roworder;
+    const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_roworder;
     const RowHot *a_hdr; const HotDesc *a_hot; const uint64_t *a_dec;   // per-row bounds, per-entry partner ranges, seed decoding by canonical rank (matrix.hip)
     uint32_t M;              // number of rows of A held here
     uint32_t Mcols;          // number of reads overall (partner id range)
@@ -445,6 +445,7 @@ void stage_create_seed_matrix(Ctx &c)
                  "row nnz x column nnz exceeds the 32-bit product sequence number");
     ELBA_REQUIRE((uint64_t)c.max_row_nnz * (uint64_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1) < 0xFFFFFFFFull, ELBA_ERR_UNSUPPORTED,
                  "products per row exceed 32 bits");
+    ELBA_REQUIRE(M < 0xFFFFFF00ll, ELBA_ERR_UNSUPPORTED, "read ids beyond 2^32 - 256 (the top of the id range marks empty slots and idle lanes)");
 
     c.ov_rowcnt.reserve((size_t)(M + 2) * 4);
     c.ov_rowoff.reserve((size_t)(M + 1) * 8);
@@ -464,8 +465,7 @@ void stage_create_seed_matrix(Ctx &c)
     if (c.ov_tmp_cap == 0 && c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
 
     OvParams p{};
-    p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
-    p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>(); p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
+    p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
     p.a_hdr = c.a_hdr.as<RowHot>(); p.a_hot = c.a_hot.as<HotDesc>(); p.a_dec = c.a_dec.as<uint64_t>();
     p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;

@@ -57,7 +57,8 @@ struct Table {
     // `full` is WAVE-UNIFORM here (a scalar): once the claim counter has reached the limit every further claim of any lane returns a
     // value >= limit, so each wave notices within the insert in which it claims next — at most one claim per lane beyond the limit,
     // hence limit <= T - BLOCK — and a uniform flag costs a scalar branch where a per-lane one costs ten mask instructions per insert.
-    __device__ __forceinline__ void insert_lds(uint32_t j, uint32_t s, bool valid, bool &full) const
+    // (cnt products of the same pair at once: their count, their smallest and their largest sequence number — 1, s, s for a single product)
+    __device__ __forceinline__ void insert_lds(uint32_t j, uint32_t s, uint32_t smx, uint32_t cnt, bool valid, bool &full) const
     {
         if (full) return;
         uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
@@ -89,9 +90,9 @@ struct Table {
                 "v_add_u32_e32 %[old], %[tb], %[old]\n\t"
                 "ds_min_u32 %[old], %[s]\n\t"
                 "v_add_u32_e32 %[old], %[tb], %[old]\n\t"
-                "ds_max_u32 %[old], %[s]\n"
+                "ds_max_u32 %[old], %[smx]\n"
                 : [save] "=&s"(save), [addr] "+v"(addr), [old] "=&v"(old), [t] "=&s"(t), [cl] "+v"(claimed), [slot] "+v"(slot)
-                : [base] "s"(base), [empty] "v"(empty), [j] "v"(j), [mask] "s"(mask), [tb] "s"(tb), [one] "v"(1u), [s] "v"(s)
+                : [base] "s"(base), [empty] "v"(empty), [j] "v"(j), [mask] "s"(mask), [tb] "s"(tb), [one] "v"(cnt), [s] "v"(s), [smx] "v"(smx)
                 : "vcc", "memory");
         }
         // claims: every claiming lane adds for itself (same-address LDS atomics serialise in the LDS unit, one cycle each)
@@ -106,6 +107,31 @@ struct Table {
                 full = true;
             }
         }
+    }
+    // Dense data (accurate reads, high UPPER): neighbouring lanes hold neighbouring k-mer columns, whose r-th partner is mostly the SAME
+    // read, so a wavefront's 64 updates hit a handful of slots and LDS atomics on one address serialise (measured: the whole kernel
+    // ran at the pace of 64-way conflicts, 1 300 products per output entry).  Equal partners in adjacent lanes of a 16-lane row are
+    // therefore combined first — a segmented scan over (count, min s, max s) in four DPP row shifts — and only the last lane of each run
+    // updates the table, with the run's count and extremes.  Results are identical: add / min / max are associative and commutative.
+    __device__ __forceinline__ void insert_runs(uint32_t j, uint32_t s, bool valid, bool &full) const
+    {
+        if (full) return;
+        const uint32_t lane = threadIdx.x & 63u;
+        const uint32_t jv = valid ? j : 0xFFFFFF00u + lane;                 // lanes without a product never join a run (partner ids are < 2^32 - 256)
+        const uint32_t jprev = (uint32_t)__builtin_amdgcn_update_dpp((int)~jv, (int)jv, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+        const uint32_t jnext = (uint32_t)__builtin_amdgcn_update_dpp((int)~jv, (int)jv, 0x101 /* row_shl:1 */, 0xf, 0xf, false);
+        uint32_t f = jv != jprev ? 1u : 0u, cnt = valid ? 1u : 0u, mn = s, mx = s;
+#define ELBA_SEG_STEP(CTRL)                                                                                              \
+        {                                                                                                                \
+            const uint32_t pc = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)cnt, CTRL, 0xf, 0xf, false);                \
+            const uint32_t pn = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)mn, CTRL, 0xf, 0xf, false);                \
+            const uint32_t px = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mx, CTRL, 0xf, 0xf, false);                 \
+            const uint32_t pf = (uint32_t)__builtin_amdgcn_update_dpp(1, (int)f, CTRL, 0xf, 0xf, false);                  \
+            if (!f) { cnt += pc; mn = pn < mn ? pn : mn; mx = px > mx ? px : mx; f = pf; }                                \
+        }
+        ELBA_SEG_STEP(0x111) ELBA_SEG_STEP(0x112) ELBA_SEG_STEP(0x114) ELBA_SEG_STEP(0x118)
+#undef ELBA_SEG_STEP
+        insert_lds(j, mn, mx, cnt, valid && jv != jnext, full);
     }
     // two independent inserts with their compare-and-swap round trips in flight together
     __device__ __forceinline__ void insert2(uint32_t j0, uint32_t s0, uint32_t j1, uint32_t s1, bool two, bool &full) const
@@ -156,7 +182,11 @@ struct Table {
 #define ELBA_PK 4
 #endif
 constexpr int PIPE = ELBA_PIPE;   // descriptor trips in flight per lane (2: the trip after next is gathered while this one accumulates)
-constexpr int PK = ELBA_PK;      // partner entries a lane gathers per descriptor and trip (descriptor -> gathers -> accumulator)
+constexpr int PK = ELBA_PK;
+#ifndef ELBA_DENSE_LANES
+#define ELBA_DENSE_LANES 24
+#endif
+constexpr int DENSE_LANES = ELBA_DENSE_LANES;   // lanes (of 64) repeating their left neighbour's partner from which a trip combines runs before the table (65: never)      // partner entries a lane gathers per descriptor and trip (descriptor -> gathers -> accumulator)
 
 // s = canonical rank of the row entry << fbits | index inside the column.  a_dec[rs + rank] holds the entry's position in the read
 // and the address of its column in a_cscp (still warm in L2: the numeric loop has just gathered it): two loads on two levels per seed
@@ -367,8 +397,16 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                             tab.insert2((uint32_t)(ce[k] >> 32), dc.y + r0 + (uint32_t)k, (uint32_t)(ce[k + 1] >> 32), dc.y + r0 + (uint32_t)k + 1u, r0 + (uint32_t)k + 1u < c, full);
                     }
                 } else {
+                    // dense trip?  (most lanes hold the same partner as their left neighbour: decided per trip and wavefront, on the first entries)
+                    const uint32_t j0 = (uint32_t)(ce[0] >> 32);
+                    const uint32_t jl = (uint32_t)__builtin_amdgcn_update_dpp((int)~j0, (int)j0, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    if (__popcll(__ballot(r0 < c && j0 == jl)) >= DENSE_LANES) {
 #pragma unroll
-                    for (int k = 0; k < PK; ++k) tab.insert_lds((uint32_t)(ce[k] >> 32), dc.y + r0 + (uint32_t)k, r0 + (uint32_t)k < c, full);
+                        for (int k = 0; k < PK; ++k) tab.insert_runs((uint32_t)(ce[k] >> 32), dc.y + r0 + (uint32_t)k, r0 + (uint32_t)k < c, full);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < PK; ++k) { const uint32_t sq = dc.y + r0 + (uint32_t)k; tab.insert_lds((uint32_t)(ce[k] >> 32), sq, sq, 1u, r0 + (uint32_t)k < c, full); }
+                    }
                 }
                 r0 += PK;
                 if (__ballot(c > r0) == 0) break;                            // wave-uniform: ranges longer than PK entries come first in a row
