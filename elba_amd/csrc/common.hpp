@@ -124,6 +124,7 @@ struct Ctx {
 
     // k-mer stage results (device)
     bool have_counts = false;
+    bool kmers_sorted = true;   // counts came from the sort-based path: a_colptr / a_csc already hold CSC(A) (kmer.hip)
     int64_t I = 0, ndistinct = 0;
     DevBuf inst_off;      // u64[M+1] instance offset of each read
     DevBuf tab_keys;      // u64[cap]  open-addressed k-mer table

@@ -3,7 +3,16 @@
 // Replaces get_kmer_count_map_keys / get_kmer_count_map_values / create_kmer_matrix (src/KmerOps.cpp:18-401) and the
 // explicit transpose (src/main.cpp:272-273).  The reference's Bloom filter + HyperLogLog + two all-to-all passes have
 // one net effect when LOWER >= 2: a canonical k-mer is kept iff its total instance count c obeys
-// LOWER <= c <= UPPER, and every instance of a kept k-mer becomes one entry (read, pos).  That is computed here exactly:
+// LOWER <= c <= UPPER, and every instance of a kept k-mer becomes one entry (read, pos).  That is computed here exactly, in one of two ways.
+//
+// Default — SORT-BASED, every pass a coalesced stream over HBM (no random atomics):
+//   k_kmer_emit      every k-mer instance -> (canonical packed value, read << 32 | pos), written in instance order = (read, pos) order
+//   radix sort       stable LSD sort of the pairs on the 2k value bits: equal k-mers become one run, its entries still in (read, pos) order
+//   k_run_flags / scan / k_run_heads / k_run_select / scans / k_emit_columns
+//                    run starts -> run lengths = the exact counts -> runs with LOWER <= count <= UPPER are numbered in value order
+//                    (k-mer id = rank of the value) and copied out: that IS the CSC of A, columns already sorted.
+//
+// ELBA_KMER_HASH=1 (and the distributed owner path, whose input is an unordered record stream) — HASH-BASED:
 //
 //   pass 1  k_kmer_count     every k-mer instance -> canonical packed value (rolling-free: each lane rebuilds its window from two
 //                            aligned 8-byte loads of the 2-bit stream, reverse complement by bit tricks) -> open-addressed
@@ -188,6 +197,56 @@ __global__ void k_sort_columns(const uint32_t *colptr, uint64_t *csc, uint64_t *
     for (uint32_t a = c0; a < c1; ++a) kid_keys[a] = k;
 }
 
+// ---- sort-based counting ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit(EnumParams e, uint64_t *keys, uint64_t *vals)
+{
+    for_each_instance(e, [&](uint64_t g, uint32_t r, uint32_t p, uint64_t km) { keys[g] = km; vals[g] = ((uint64_t)r << 32) | p; });
+}
+
+// flag[g] = 1 where a run of equal k-mers starts (flag[I] = 1 closes the last run)
+__global__ void k_run_flags(const uint64_t *keys, uint64_t I, uint32_t *flag)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > I) return;
+    flag[g] = (g == 0 || g == I || keys[g] != keys[g - 1]) ? 1u : 0u;
+}
+
+// headpos[run] = first instance of the run; headpos[nruns] = I
+__global__ void k_run_heads(const uint32_t *flag, const uint32_t *runid, uint64_t I, uint32_t *headpos)
+{
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > I) return;
+    if (flag[g]) headpos[runid[g]] = (uint32_t)g;
+}
+
+// per run: its length is the k-mer's exact count; reliable runs are flagged and their lengths kept (both arrays get a closing zero)
+__global__ void k_run_select(const uint32_t *headpos, uint64_t nruns, uint32_t lower, uint32_t upper, uint32_t *relflag, uint32_t *relcnt)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > nruns) return;
+    uint32_t f = 0, c = 0;
+    if (u < nruns) { c = headpos[u + 1] - headpos[u]; f = (c >= lower && c <= upper) ? 1u : 0u; }
+    relflag[u] = f; relcnt[u] = f ? c : 0u;
+}
+
+// reliable run -> column kid: k-mer value, count, column pointer, entries (already in (read, pos) order: the sort is stable)
+__global__ void k_emit_columns(const uint64_t *keys, const uint64_t *vals, const uint32_t *headpos, const uint32_t *relflag, const uint32_t *kidx, const uint32_t *cptr,
+                               uint64_t nruns, uint64_t *rel_kmers, uint32_t *rel_counts, uint32_t *colptr, uint64_t *csc)
+{
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= nruns || !relflag[u]) return;
+    const uint32_t kid = kidx[u], h = headpos[u], c = headpos[u + 1] - h, at = cptr[u];
+    rel_kmers[kid] = keys[h]; rel_counts[kid] = c; colptr[kid] = at;
+    for (uint32_t t = 0; t < c; ++t) csc[at + t] = vals[h + t];
+}
+
+__global__ void k_column_ids(const uint32_t *colptr, uint64_t *kid_keys, uint64_t N)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    for (uint32_t a = colptr[k]; a < colptr[k + 1]; ++a) kid_keys[a] = k;
+}
+
 int next_pow2_bits(uint64_t v)
 {
     int b = 0;
@@ -224,6 +283,68 @@ void stage_count_kmers(Ctx &c)
     c.I = (int64_t)I;
     c.inst_off.reserve((size_t)(M + 1) * 8);
     ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s));
+
+    c.kmers_sorted = !getenv("ELBA_KMER_HASH");
+    if (c.kmers_sorted) {
+        // ---- sort-based: see the header of this file ----
+        c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_b.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8); c.ws_d.reserve((size_t)(I + 2) * 8);
+        c.ws_e.reserve((size_t)(I + 2) * 4); c.ws_f.reserve((size_t)(I + 2) * 8);        // flags | run ids, head positions
+        c.t_total.start(s);
+        c.t_a.start(s);
+        EnumParams e = make_enum(c);
+        const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+        if (I > 0) hipLaunchKernelGGL(k_kmer_emit, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
+        const int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)I, 64 - 2 * k, 64, c.ws_sort);
+        const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>(), *svals = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
+        uint64_t *spare_k = where ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>(), *spare_v = where ? c.ws_b.as<uint64_t>() : c.ws_d.as<uint64_t>();   // free after the sort
+        c.t_a.stop(s);
+        c.t_b.start(s);
+        uint32_t *flag = c.ws_e.as<uint32_t>();
+        uint32_t *runid = reinterpret_cast<uint32_t *>(spare_k);                        // [I + 1]
+        uint32_t *headpos = c.ws_f.as<uint32_t>();                                      // [nruns + 1] <= I + 1
+        const unsigned nbI = (unsigned)((I + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, I, flag);
+        exclusive_scan_u32(s, flag, runid, (int64_t)I + 1, c.ws_scan);
+        uint32_t nruns32 = 0;
+        ELBA_HIP(hipMemcpyAsync(&nruns32, runid + I, 4, hipMemcpyDeviceToHost, s));      // runs before the closing flag = distinct k-mers
+        hipLaunchKernelGGL(k_run_heads, dim3(nbI), dim3(256), 0, s, flag, runid, I, headpos);
+        ELBA_HIP(hipStreamSynchronize(s));
+        const uint64_t nruns = I > 0 ? nruns32 : 0;
+        uint32_t *relflag = reinterpret_cast<uint32_t *>(spare_v), *relcnt = relflag + (nruns + 2);      // [nruns + 1] each (spare_v holds 2 (I + 2) u32)
+        uint32_t *kidx = flag, *cptr = runid;                                                         // flags and run ids are dead now
+        const unsigned nbR = (unsigned)((nruns + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_run_select, dim3(nbR), dim3(256), 0, s, headpos, nruns, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, relflag, relcnt);
+        exclusive_scan_u32(s, relflag, kidx, (int64_t)nruns + 1, c.ws_scan);
+        uint32_t Nn = 0;
+        ELBA_HIP(hipMemcpyAsync(&Nn, kidx + nruns, 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        const uint64_t N = Nn;
+        // Z <= I < 2^32 always holds (every entry is an instance), so the 32-bit scan cannot wrap
+        exclusive_scan_u32(s, relcnt, cptr, (int64_t)nruns + 1, c.ws_scan);
+        uint32_t Zz = 0;
+        ELBA_HIP(hipMemcpyAsync(&Zz, cptr + nruns, 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        const uint64_t Z = Zz;
+        ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
+        c.rel_kmers.reserve((size_t)(N + 1) * 8);
+        c.rel_counts.reserve((size_t)(N + 2) * 4);
+        c.a_colptr.reserve((size_t)(N + 2) * 4);
+        c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
+        if (nruns > 0)
+            hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, svals, headpos, relflag, kidx, cptr, nruns,
+                               c.rel_kmers.as<uint64_t>(), c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>());
+        ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
+        c.t_b.stop(s);
+        c.t_total.stop(s);
+        ELBA_HIP(hipStreamSynchronize(s));
+        st.instances = (int64_t)I; st.distinct = (int64_t)nruns; st.reliable = (int64_t)N; st.entries = (int64_t)Z;
+        st.ms_total = c.t_total.ms(); st.ms_count = c.t_a.ms(); st.ms_sort = c.t_b.ms(); st.ms_lookup = 0;
+        c.ndistinct = (int64_t)nruns;
+        c.N = (int64_t)N; c.Z = (int64_t)Z;
+        c.kstats = st;
+        c.have_counts = true;
+        return;
+    }
 
     // table capacity (power of two)
     int cbits = next_pow2_bits(I + I / 4 + 2);      // load factor <= 0.8 even if every instance were distinct; ~0.35 on real reads
@@ -290,6 +411,16 @@ void stage_create_kmer_matrix(Ctx &c)
     hipStream_t s = c.stream;
     const int64_t M = c.nreads, N = c.N, Z = c.Z;
     c.have_A = false; c.have_B = false;
+    if (c.kmers_sorted) {           // CSC(A) came out of the counting sort already: only the column id of every entry is still needed
+        c.t_c.start(s);
+        c.ws_f.reserve((size_t)(Z + 1) * 8);
+        if (N > 0) hipLaunchKernelGGL(k_column_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.ws_f.as<uint64_t>(), (uint64_t)N);
+        c.t_c.stop(s);
+        c.A_has_kmers = true;
+        finish_matrix_from_sorted_csc(c, M, N, Z, c.ws_f.as<uint64_t>(), 0, c.a_csc.as<uint64_t>());
+        c.kstats.ms_lookup = c.t_c.ms();
+        return;
+    }
     c.t_c.start(s);
     c.a_colptr.reserve((size_t)(N + 2) * 4);
     c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)

@@ -244,11 +244,15 @@ static void build_hot_format(Ctx &c)
     c.ws_e.reserve((size_t)(N + 2) * 4);
     uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
     const unsigned nbN = (unsigned)((N + 255) / 256);
-    // columns by first entry (read << 32 | pos): LSD over the pos bits, then the read bits (bit 63 set = empty column, last)
+    // columns by first entry (read << 32 | pos): LSD over the pos bits that can be set, then the read bits (an empty column's key is all
+    // ones: it sorts with the largest values, and where it lands among them does not matter — it has no entries)
     hipLaunchKernelGGL(k_first_entry_keys, dim3(nbN), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), (uint64_t)N, k0, v0);
-    int w = radix_sort_pairs(s, k0, v0, k1, v1, N, 0, 32, c.ws_sort);
+    uint32_t maxlen = 1;
+    for (uint32_t l : c.h_len) maxlen = l > maxlen ? l : maxlen;
+    const int posbits = c.have_reads && c.A_has_kmers && !c.h_len.empty() ? bits_for(maxlen) : 32;
+    int w = radix_sort_pairs(s, k0, v0, k1, v1, N, 0, posbits, c.ws_sort);
     uint64_t *ck = w ? k1 : k0, *cv = w ? v1 : v0, *ok = w ? k0 : k1, *ov = w ? v0 : v1;
-    int w2 = radix_sort_pairs(s, ck, cv, ok, ov, N, 32, 64, c.ws_sort);
+    int w2 = radix_sort_pairs(s, ck, cv, ok, ov, N, 32, 32 + bits_for((uint64_t)(c.M > 0 ? c.M : 1)), c.ws_sort);
     const uint64_t *sorted_cols = w2 ? ov : cv;
     uint32_t *cnt = c.ws_e.as<uint32_t>(), *newstart = c.a_newstart.as<uint32_t>();
     hipLaunchKernelGGL(k_perm_counts, dim3(nbN), dim3(256), 0, s, sorted_cols, c.a_colptr.as<uint32_t>(), (uint64_t)N, cnt);

@@ -133,7 +133,10 @@ __global__ void k_reduce_max(const uint64_t *p, int64_t n, unsigned long long *o
 // ---------------------------------------------------------------------------------------------------------------
 // radix sort, 8 bits per pass
 constexpr int RS_THREADS = 256;
-constexpr int RS_ITEMS = 8;
+#ifndef ELBA_RS_ITEMS
+#define ELBA_RS_ITEMS 8
+#endif
+constexpr int RS_ITEMS = ELBA_RS_ITEMS;
 constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
 
