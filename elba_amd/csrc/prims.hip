@@ -155,17 +155,23 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *keys, in
     hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
+// Scatter of one radix pass.  The tile is first ordered by digit in LDS, then written out by consecutive lanes: a store instruction
+// of a wavefront then covers a few digits' chunks (a few pages) instead of up to 64 — on 10^8 items and more, where the 256 output streams of
+// a pass lie megabytes apart, the direct per-item scatter ran at a third of the bandwidth it reaches on 10^7 items (address translation).
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_in, const uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out,
                                                            int64_t n, int shift, const uint32_t *hist_scanned, uint32_t nblocks)
 {
     __shared__ uint32_t whist[RS_WAVES][256];
+    __shared__ uint32_t lstart[256], gbase[256], wsum[RS_WAVES];
+    __shared__ uint64_t lkey[RS_TILE], lval[RS_TILE];
     volatile uint32_t(*vh)[256] = whist;
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1;
     // a wave owns RS_ITEMS*64 CONSECUTIVE items of the tile so that tile order == (wave, round, lane) order: stability
-    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (RS_ITEMS * 64);
+    const int64_t tbase = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t wbase = tbase + (int64_t)w * (RS_ITEMS * 64);
     uint64_t key[RS_ITEMS];
     uint32_t rank[RS_ITEMS];
 #pragma unroll
@@ -192,25 +198,41 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_
     }
     __syncthreads();
     {
+        // per digit: this tile's count, the waves' offsets inside the digit's chunk, the chunk's place in the tile and in the output
         const int d = threadIdx.x;
-        uint32_t off = hist_scanned[(size_t)d * nblocks + blockIdx.x];
+        uint32_t tot = 0;
 #pragma unroll
-        for (int ww = 0; ww < RS_WAVES; ++ww) {
-            uint32_t t = whist[ww][d];
-            whist[ww][d] = off;
-            off += t;
-        }
+        for (int ww = 0; ww < RS_WAVES; ++ww) { const uint32_t t = whist[ww][d]; whist[ww][d] = tot; tot += t; }
+        uint32_t inc = tot;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= s2) inc += o; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int ww = 0; ww < w; ++ww) before += wsum[ww];
+        lstart[d] = before + inc - tot;
+        gbase[d] = hist_scanned[(size_t)d * nblocks + blockIdx.x];
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; ++r) {
         int64_t idx = wbase + r * 64 + lane;
         if (idx < n) {
-            uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
-            uint32_t dst = whist[w][d] + rank[r];
-            keys_out[dst] = key[r];
-            vals_out[dst] = vals_in[idx];
+            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t lp = lstart[d] + whist[w][d] + rank[r];
+            lkey[lp] = key[r];
+            lval[lp] = vals_in[idx];
         }
+    }
+    __syncthreads();
+    const int64_t left = n - tbase;
+    const uint32_t nvalid = left < (int64_t)RS_TILE ? (uint32_t)left : (uint32_t)RS_TILE;
+    for (uint32_t t = threadIdx.x; t < nvalid; t += RS_THREADS) {
+        const uint64_t k = lkey[t];
+        const uint32_t d = (uint32_t)(k >> shift) & 255u;
+        const uint32_t dst = gbase[d] + (t - lstart[d]);
+        keys_out[dst] = k;
+        vals_out[dst] = lval[t];
     }
 }
 
