@@ -35,6 +35,9 @@ struct AlnParams {
     const uint8_t *packed; const uint64_t *byte_off; const uint32_t *len;
     const int64_t *b_rowptr; const uint32_t *b_col; const elba_seed_t *b_val;
     uint32_t M, row_lo, row_hi;
+    uint32_t share;            // 0: one rank, every stored B(i,j) with i < j.  1: rows [row_lo, row_hi) of a row-sharded B, reads replicated: a
+                               // pair {i,j} is stored on both of its rows' ranks; the rank of the smaller row takes it when i + j is even, the
+                               // rank of the larger row when it is odd — every pair exactly once, the shares balanced without any exchange
     int32_t k, mat, mis, gap, dropoff;
     int32_t wide_hint;         // pairs with numshared <= wide_hint skip the 64-column tier (performance only: any tier gives the same result)
     uint32_t *cnt; const int64_t *taskptr;
@@ -52,7 +55,10 @@ __global__ void k_aln_count(AlnParams p)
     const uint32_t i = p.row_lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.row_hi) return;
     uint32_t n = 0;
-    for (int64_t e = p.b_rowptr[i]; e < p.b_rowptr[i + 1]; ++e) n += p.b_col[e] > i ? 1u : 0u;
+    for (int64_t e = p.b_rowptr[i]; e < p.b_rowptr[i + 1]; ++e) {
+        const uint32_t j = p.b_col[e];
+        n += !p.share ? (j > i ? 1u : 0u) : ((j != i && (((i + j) & 1u) == (j > i ? 0u : 1u))) ? 1u : 0u);
+    }
     p.cnt[i - p.row_lo] = n;
 }
 
@@ -62,16 +68,20 @@ __global__ void k_aln_prepare(AlnParams p)
     const uint32_t i = p.row_lo + blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.row_hi) return;
     int64_t at = p.taskptr[i - p.row_lo];
-    const uint8_t *q = p.packed + p.byte_off[i];
-    const int lenQ = (int)p.len[i];
     for (int64_t e = p.b_rowptr[i]; e < p.b_rowptr[i + 1]; ++e) {
-        const uint32_t j = p.b_col[e];
-        if (j <= i) continue;
-        const uint8_t *t = p.packed + p.byte_off[j];
-        const int lenT = (int)p.len[j];
-        const int begQ = (int)p.b_val[e].q0, begT = (int)p.b_val[e].t0, k = p.k;
+        const uint32_t jj = p.b_col[e];
+        if (!p.share ? jj <= i : (jj == i || (((i + jj) & 1u) != (jj > i ? 0u : 1u)))) continue;
+        // the pair is always aligned as (query = smaller read id, target = larger): the entry of the larger read's row is B(i,j) with the
+        // two positions of each seed exchanged, so its seeds[0] is swapped back
+        const bool upper = jj > i;
+        const uint32_t qi = upper ? i : jj, tj = upper ? jj : i;
+        const uint8_t *q = p.packed + p.byte_off[qi];
+        const int lenQ = (int)p.len[qi];
+        const uint8_t *t = p.packed + p.byte_off[tj];
+        const int lenT = (int)p.len[tj];
+        const int begQ = (int)(upper ? p.b_val[e].q0 : p.b_val[e].t0), begT = (int)(upper ? p.b_val[e].t0 : p.b_val[e].q0), k = p.k;
         AlnTask tk{};
-        tk.i = i; tk.j = j; tk.numshared = p.b_val[e].numshared;
+        tk.i = qi; tk.j = tj; tk.numshared = p.b_val[e].numshared;
         bool ok = !(begQ < 0 || begQ + k > lenQ) && !(begT < 0 || begT + k > lenT) && !(begQ == 0 && begT == 0);
         if (ok) {
             const bool rc = base_at(q, (uint32_t)(begQ + (k >> 1))) != base_at(t, (uint32_t)(begT + (k >> 1)));
@@ -452,29 +462,32 @@ __global__ void k_aln_combine(AlnParams p)
 
 void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
 {
-    ELBA_REQUIRE(c.have_reads && c.have_B, ELBA_ERR_STATE, "align_seeds: needs the reads and the seed matrix on this context");
-    ELBA_REQUIRE(c.nreads == c.M && (c.row_hi < 0 || (c.row_lo == 0 && c.row_hi == c.M)), ELBA_ERR_UNSUPPORTED,
-                 "align_seeds: every read of B must be resident on this context (one-rank PairwiseAlignment)");
+    ELBA_REQUIRE(c.have_B, ELBA_ERR_STATE, "align_seeds: needs the seed matrix on this context");
+    const bool shard = c.row_hi >= 0 && !(c.row_lo == 0 && c.row_hi == c.M);        // rows of a row-sharded B (multi-GPU)
+    if (shard) ELBA_REQUIRE(c.aln_all_n == c.M, ELBA_ERR_STATE, "align_seeds: a row shard of B needs every read resident (elba_dist_set_all_reads)");
+    else ELBA_REQUIRE(c.have_reads && c.nreads == c.M, ELBA_ERR_UNSUPPORTED, "align_seeds: every read of B must be resident on this context");
     ELBA_REQUIRE(dropoff >= 0, ELBA_ERR_INVALID_ARG, "align_seeds: negative x-drop");
     hipStream_t s = c.stream;
     const int64_t M = c.M;
     c.have_aln = false;
     AlnParams p{};
-    p.packed = c.d_packed; p.byte_off = c.d_byte_off; p.len = c.d_len;
+    if (shard) { p.packed = c.aln_all_packed.as<uint8_t>(); p.byte_off = c.aln_all_off.as<uint64_t>(); p.len = c.aln_all_len.as<uint32_t>(); }
+    else { p.packed = c.d_packed; p.byte_off = c.d_byte_off; p.len = c.d_len; }
     p.b_rowptr = c.b_rowptr.as<int64_t>(); p.b_col = c.b_col.as<uint32_t>(); p.b_val = c.b_val.as<elba_seed_t>();
-    p.M = (uint32_t)M; p.row_lo = 0; p.row_hi = (uint32_t)M;
+    p.M = (uint32_t)M; p.row_lo = shard ? (uint32_t)c.row_lo : 0u; p.row_hi = shard ? (uint32_t)c.row_hi : (uint32_t)M; p.share = shard ? 1u : 0u;
     p.k = c.cfg.k; p.mat = mat; p.mis = mis; p.gap = gap; p.dropoff = dropoff;
     p.wide_hint = getenv("ELBA_ALN_WIDE_HINT") ? atoi(getenv("ELBA_ALN_WIDE_HINT")) : 6;
     c.t_total.start(s);
-    c.aln_cnt.reserve((size_t)(M + 2) * 4); c.aln_ptr.reserve((size_t)(M + 2) * 8); c.aln_ctr.reserve(256);
+    const int64_t nrows = (int64_t)p.row_hi - (int64_t)p.row_lo;
+    c.aln_cnt.reserve((size_t)(nrows + 2) * 4); c.aln_ptr.reserve((size_t)(nrows + 2) * 8); c.aln_ctr.reserve(256);
     p.cnt = c.aln_cnt.as<uint32_t>();
-    ELBA_HIP(hipMemsetAsync(c.aln_cnt.p, 0, (size_t)(M + 2) * 4, s));
+    ELBA_HIP(hipMemsetAsync(c.aln_cnt.p, 0, (size_t)(nrows + 2) * 4, s));
     ELBA_HIP(hipMemsetAsync(c.aln_ctr.p, 0, 256, s));
-    const unsigned nbM = (unsigned)((M + 255) / 256);
-    if (M > 0) hipLaunchKernelGGL(k_aln_count, dim3(nbM), dim3(256), 0, s, p);
-    exclusive_scan_u32_to_i64(s, p.cnt, c.aln_ptr.as<int64_t>(), M + 1, c.ws_scan);
+    const unsigned nbM = (unsigned)((nrows + 255) / 256);
+    if (nrows > 0) hipLaunchKernelGGL(k_aln_count, dim3(nbM), dim3(256), 0, s, p);
+    exclusive_scan_u32_to_i64(s, p.cnt, c.aln_ptr.as<int64_t>(), nrows + 1, c.ws_scan);
     int64_t K = 0;
-    ELBA_HIP(hipMemcpyAsync(&K, c.aln_ptr.as<int64_t>() + M, 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipMemcpyAsync(&K, c.aln_ptr.as<int64_t>() + nrows, 8, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
     ELBA_REQUIRE(2 * K < 0xFFFFFFF0ll, ELBA_ERR_UNSUPPORTED, "align_seeds: more than 2^31 candidate pairs");
     c.naln = K;
@@ -487,8 +500,8 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
     uint32_t *lists[2] = {c.aln_ofl.as<uint32_t>(), c.aln_ofl.as<uint32_t>() + 2 * K + 2};
     p.out_rows = c.aln_rows.as<int64_t>(); p.out_cols = c.aln_cols.as<int64_t>(); p.out = c.aln_out.as<elba_overlap_t>();
     // strided kernel: three antidiagonals per wavefront, as long as the longest read + 2
-    uint32_t maxlen = 0;
-    for (uint32_t l : c.h_len) maxlen = l > maxlen ? l : maxlen;
+    uint32_t maxlen = shard ? c.aln_all_maxlen : 0;
+    if (!shard) for (uint32_t l : c.h_len) maxlen = l > maxlen ? l : maxlen;
     const int sblocks = c.num_cus * 2;
     p.scratch_stride = (unsigned long long)maxlen + 8;
     elba_align_stats st{};
@@ -542,6 +555,29 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
     }
     c.astats = st;
     c.have_aln = true;
+}
+
+// Multi-GPU alignment: the reads are small next to HBM (2 bits per base), so every rank keeps ALL of them (one all-gather by the
+// driver) and aligns its share of the candidate pairs with no further communication — the reference's DistributedFastaData exchanges
+// row and column read blocks of a 2D grid instead (src/DistributedFastaData.cpp).
+void stage_dist_set_all_reads(Ctx &c, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads_total)
+{
+    ELBA_REQUIRE(nreads_total >= 0 && packed_bytes >= 0 && (nreads_total == 0 || (d_packed && d_byte_off && d_len)), ELBA_ERR_INVALID_ARG, "dist_set_all_reads: null array");
+    hipStream_t s = c.stream;
+    c.aln_all_packed.reserve((size_t)packed_bytes + 16); c.aln_all_off.reserve((size_t)(nreads_total + 1) * 8); c.aln_all_len.reserve((size_t)(nreads_total + 1) * 4);
+    ELBA_HIP(hipMemsetAsync(c.aln_all_packed.p, 0, (size_t)packed_bytes + 16, s));
+    if (packed_bytes) ELBA_HIP(hipMemcpyAsync(c.aln_all_packed.p, d_packed, (size_t)packed_bytes, hipMemcpyDeviceToDevice, s));
+    std::vector<uint32_t> hl((size_t)nreads_total);
+    if (nreads_total) {
+        ELBA_HIP(hipMemcpyAsync(c.aln_all_off.p, d_byte_off, (size_t)nreads_total * 8, hipMemcpyDeviceToDevice, s));
+        ELBA_HIP(hipMemcpyAsync(c.aln_all_len.p, d_len, (size_t)nreads_total * 4, hipMemcpyDeviceToDevice, s));
+        ELBA_HIP(hipMemcpyAsync(hl.data(), d_len, (size_t)nreads_total * 4, hipMemcpyDeviceToHost, s));
+    }
+    ELBA_HIP(hipStreamSynchronize(s));
+    uint32_t mx = 0;
+    for (uint32_t l : hl) mx = l > mx ? l : mx;
+    c.aln_all_maxlen = mx; c.aln_all_n = nreads_total;
+    c.have_aln = false;
 }
 
 }  // namespace elba

@@ -229,6 +229,11 @@ int elba_align_seeds(elba_ctx *ctx, int mat, int mis, int gap, int dropoff, elba
     });
 }
 
+int elba_dist_set_all_reads(elba_ctx *ctx, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads_total)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_dist_set_all_reads(c, d_packed, packed_bytes, d_byte_off, d_len, nreads_total); });
+}
+
 int elba_export_overlaps(elba_ctx *ctx, elba_overlaps_t *out)
 {
     return guarded(ctx, [&](Ctx &c) {

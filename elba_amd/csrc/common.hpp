@@ -171,6 +171,8 @@ struct Ctx {
     int64_t naln = 0;
     DevBuf aln_tasks, aln_ext, aln_cnt, aln_ptr, aln_ctr, aln_ofl, aln_scratch, aln_rows, aln_cols, aln_out;
     elba_align_stats astats{};
+    DevBuf aln_all_packed, aln_all_off, aln_all_len;     // every read of the run, replicated for a row shard's alignments (elba_dist_set_all_reads)
+    int64_t aln_all_n = -1; uint32_t aln_all_maxlen = 0;
 
     // workspaces
     DevBuf ws_scan, ws_sort, ws_a, ws_b, ws_c, ws_d, ws_e, ws_f;
@@ -199,6 +201,7 @@ void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
 void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip
 void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
 void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff);   // align.hip
+void stage_dist_set_all_reads(Ctx &c, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads_total);   // align.hip
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host);                                   // kmer.hip
 void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);
 void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec);

@@ -226,6 +226,11 @@ int  elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats);
  * B(i,j), i < j (xdrop_aligner src/XDropAligner.cpp:224-282 with the reference's defaults mat 1, mis -1, gap -1, dropoff 15,
  * src/main.cpp:53-56), classification and Overlap fields.  Needs the reads and B resident on this context (all reads local). */
 int  elba_align_seeds(elba_ctx *ctx, int mat, int mis, int gap, int dropoff, elba_align_stats *stats);
+/* Multi-GPU: on a row shard of B (after elba_dist_set_panel + elba_create_seed_matrix) elba_align_seeds aligns this rank's share of the
+ * candidate pairs — pair {i < j} belongs to the rank of row i when i + j is even, to the rank of row j when it is odd; always as
+ * (query i, target j) — once every read of the run is resident: device arrays in DnaBuffer layout with GLOBAL read ids, replicated by
+ * the driver with one all-gather (the reads are 2 bits per base). */
+int  elba_dist_set_all_reads(elba_ctx *ctx, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads_total);
 int  elba_export_overlaps(elba_ctx *ctx, elba_overlaps_t *out);
 void elba_free_overlaps(elba_overlaps_t *o);
 

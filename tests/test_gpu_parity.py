@@ -228,3 +228,29 @@ def test_repeated_calls_are_deterministic():
         b = e.export_csr()
         assert (a["rowptr"] == b["rowptr"]).all() and (a["col"] == b["col"]).all() and (a["val"] == b["val"]).all()
     e.close()
+
+
+def test_pattern_and_counts_do_not_depend_on_kmer_id_order():
+    """The reference numbers k-mers by unordered_map iteration order (src/KmerOps.cpp:380-394), this build by value rank.
+    Whatever the numbering: same pattern of B, same numshared; only WHICH shared k-mer lands in seeds[0]/[1] may change — and every stored
+    seed stays a genuine shared k-mer (the reference's test.py:57-65)."""
+    seqs = util.read_fasta(os.path.join(G, "small_err.fa"))
+    packed, off, lens = po.pack_reads(seqs)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 8)
+    A, oB = o.A(), o.B()
+    rows = np.repeat(np.arange(A["M"], dtype=np.int64), np.diff(A["rowptr"]))
+    perm = np.random.default_rng(7).permutation(A["N"])                 # a different k-mer numbering
+    e = elba_amd.Engine(17, 2, 8)
+    e.set_kmer_matrix(A["M"], A["N"], rows, perm[A["csr_kid"]], A["csr_pos"])
+    e.create_seed_matrix()
+    gB = e.export_csr()
+    assert (gB["rowptr"] == oB["rowptr"]).all() and (gB["col"] == oB["col"].astype(np.int64)).all()
+    assert (gB["val"]["numshared"] == oB["val"]["numshared"]).all()
+    assert (gB["val"] != oB["val"]).any()                                 # the seeds themselves do follow the numbering ...
+    L = po.lib()
+    brow = np.repeat(np.arange(gB["M"]), np.diff(gB["rowptr"]))
+    for x in range(gB["Y"]):                                              # ... and are valid all the same
+        i, j, v = int(brow[x]), int(gB["col"][x]), gB["val"][x]
+        for q, t in ((v["q0"], v["t0"]), (v["q1"], v["t1"])):
+            assert L.orc_seed_is_valid(packed.ctypes.data + int(off[i]), int(lens[i]), packed.ctypes.data + int(off[j]), int(lens[j]), int(q), int(t), 17)
+    e.close()
