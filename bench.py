@@ -189,6 +189,17 @@ def main():
                  "gcups": round(al["cells"] / max(1e-9, al["ms_extend"] * 1e-3) / 1e9, 3), "alignments_per_s": round(al["nalignments"] / max(1e-9, al["ms_total"] * 1e-3), 1),
                  "params": {"mat": 1, "mis": -1, "gap": -1, "xdrop": 15}}
 
+    if (world > 1 or force_dist) and not args.dbg and not args.no_align:
+        # sharded alignment: reads replicated with one all-gather, every rank aligns its share of the pairs of its rows (no data-path collective afterwards)
+        t0 = time.perf_counter(); al = runner.align_seeds(); barrier_sync(); t_al = time.perf_counter() - t0
+        tot = torch.tensor([al["nalignments"], al["cells"], al["passed"]], dtype=torch.int64, device="cuda")
+        mx = torch.tensor([al["ms_total"], t_al * 1e3], dtype=torch.float64, device="cuda")
+        if dist is not None:
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        na, nc, npass = [int(x) for x in tot.tolist()]
+        align = {"alignments": na, "passed": npass, "cells": nc, "ms_slowest_rank_device": round(float(mx[0]), 3), "ms_wall_with_read_allgather": round(float(mx[1]), 3),
+                 "gcups": round(nc / max(1e-9, float(mx[0]) * 1e-3) / 1e9, 3), "sharing": "pair {i<j}: rank of row i if i+j even, of row j if odd; reads replicated by all_gather"}
+
     cpu = None
     parity = None
     if rank == 0 and world == 1 and not force_dist and not args.no_cpu_baseline:

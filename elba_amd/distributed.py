@@ -56,6 +56,7 @@ class HipBackend:
         L.elba_dist_panel_counts.restype = i32; L.elba_dist_panel_counts.argtypes = [vp, i32, vp, vp]
         L.elba_dist_panel_fill.restype = i32; L.elba_dist_panel_fill.argtypes = [vp, i32, vp, vp, vp]
         L.elba_dist_set_panel.restype = i32; L.elba_dist_set_panel.argtypes = [vp, vp, i64, i64, i64, i64, i64, C.POINTER(capi.MatrixStats)]
+        L.elba_dist_set_all_reads.restype = i32; L.elba_dist_set_all_reads.argtypes = [vp, vp, i64, vp, vp, i64]
 
     def empty_records(self, n):
         return self.torch.empty((max(int(n), 0), 2), dtype=self.torch.int64, device=self.dev)
@@ -65,6 +66,20 @@ class HipBackend:
 
     def set_reads(self, packed, off, lens, first_global_id):
         self.e.set_reads(packed, off, lens, first_global_id)
+
+    def set_all_reads(self, packed_words, byte_off, lens):
+        """Every read of the run (replicated): packed 2-bit bytes as an int64 word tensor on the device, global byte offsets / lengths on the host."""
+        torch = self.torch
+        off = torch.from_numpy(np.ascontiguousarray(byte_off, dtype=np.uint64).view(np.int64)).to(self.dev)
+        ln = torch.from_numpy(np.ascontiguousarray(lens, dtype=np.uint32).view(np.int32)).to(self.dev)
+        self.e._check(self.L.elba_dist_set_all_reads(self.h, packed_words.data_ptr() if packed_words.numel() else None, packed_words.numel() * 8,
+                                                     off.data_ptr() if len(lens) else None, ln.data_ptr() if len(lens) else None, len(lens)))
+
+    def align_seeds(self, mat, mis, gap, dropoff):
+        return self.e.align_seeds(mat, mis, gap, dropoff)
+
+    def export_overlaps(self):
+        return self.e.export_overlaps()
 
     def count_owners(self, nranks):
         out = np.zeros(nranks, dtype=np.uint64)
@@ -132,6 +147,7 @@ class DistributedOverlap:
         self.bounds = np.asarray(bounds, dtype=np.int64)
         assert len(self.bounds) == self.world + 1 and int(self.bounds[self.rank]) == first_global_id
         self.nlocal = len(lens)
+        self._reads = (np.asarray(packed, dtype=np.uint8), np.asarray(off, dtype=np.uint64), np.asarray(lens, dtype=np.uint32))   # kept for the alignment stage's all-gather
         self.be.set_reads(packed, off, lens, first_global_id)
 
     def generate_and_set_reads(self, w, weak=True):
@@ -242,6 +258,39 @@ class DistributedOverlap:
 
     def create_seed_matrix(self):
         return self.be.create_seed_matrix()
+
+    # ---- the step after the path: x-drop alignment of the candidate pairs, sharded ------------------------------------------
+    def align_seeds(self, mat=1, mis=-1, gap=-1, dropoff=15):
+        """PairwiseAlignment across ranks.  The reads are replicated with ONE all-gather (2 bits per base: the whole read set is small
+        next to a GPU's HBM; the reference moves row/column read blocks of its 2D grid instead, src/DistributedFastaData.cpp), then
+        every rank aligns its share of the stored pairs of ITS rows of B with no further communication: pair {i < j} is taken by the
+        rank of row i when i + j is even and by the rank of row j when it is odd (both ranks store the pair; the seeds of the mirrored
+        entry are swapped back), always as (query i, target j) — the union over ranks is exactly the one-rank result."""
+        packed, off, lens = self._reads
+        nb = int(off[-1]) + (int(lens[-1]) + 3) // 4 if len(lens) else 0
+        nwords = (nb + 7) // 8
+        buf = np.zeros(nwords * 8, dtype=np.uint8); buf[:nb] = packed[:nb]
+        torch = self.be.torch
+        local = torch.from_numpy(buf.view(np.int64).copy()).to(self.be.dev)
+        allw, ns = self._all_gather_words(local, nwords)                          # packed bytes of every rank, 8-byte aligned blocks
+        lens_t = torch.from_numpy(lens.astype(np.int64)).to(self.be.dev)
+        alll, nl = self._all_gather_words(lens_t, len(lens))
+        all_lens = alll.cpu().numpy().astype(np.uint32)
+        # global byte offsets: rank r's block starts behind the blocks of the ranks before it; inside a block reads keep their offsets
+        nbytes = (all_lens.astype(np.int64) + 3) // 4
+        all_off = np.zeros(len(all_lens), dtype=np.uint64)
+        base, at = 0, 0
+        for r in range(self.world):
+            n = nl[r]
+            if n:
+                loc = np.concatenate([[0], np.cumsum(nbytes[at:at + n])[:-1]])
+                all_off[at:at + n] = (base + loc).astype(np.uint64)
+            at += n; base += ns[r] * 8
+        self.be.set_all_reads(allw, all_off, all_lens)
+        return self.be.align_seeds(mat, mis, gap, dropoff)
+
+    def export_overlaps(self):
+        return self.be.export_overlaps()
 
     def export_csr(self):
         """This rank's rows of B (global column ids)."""

@@ -206,6 +206,34 @@ class NumpyBackend:
     def export_csr(self, row_lo, row_hi):
         return self.B
 
+    def set_all_reads(self, packed_words, byte_off, lens):
+        self.all_reads = (packed_words.numpy().view(np.uint8).copy(), np.asarray(byte_off, dtype=np.uint64), np.asarray(lens, dtype=np.uint32))
+
+    def align_seeds(self, mat, mis, gap, dropoff):
+        """The rank's share of the pairs (i + j parity rule of elba_align_seeds on a row shard), aligned with the oracle's x-drop."""
+        buf, off, lens = self.all_reads
+        lo, hi = self.win
+        B = self.B
+        rows_l = np.repeat(np.arange(lo, hi), np.diff(B["rowptr"]))
+        out_r, out_c, out_v = [], [], []
+        L = po.lib()
+        for e in range(B["Y"]):
+            i, j = int(rows_l[e]), int(B["col"][e])
+            if i == j or ((i + j) & 1) != (0 if j > i else 1):
+                continue
+            v = B["val"][e]
+            qi, tj = (i, j) if j > i else (j, i)
+            q0, t0 = (int(v["q0"]), int(v["t0"])) if j > i else (int(v["t0"]), int(v["q0"]))
+            o = np.zeros(1, dtype=po.OVERLAP_DTYPE)
+            L.orc_overlap_extend(buf.ctypes.data + int(off[qi]), int(lens[qi]), buf.ctypes.data + int(off[tj]), int(lens[tj]), q0, t0, self.k, mat, mis, gap, dropoff, o.ctypes.data, None)
+            out_r.append(qi); out_c.append(tj); out_v.append(o[0])
+        self.ov = dict(n=len(out_r), rows=np.array(out_r, dtype=np.int64), cols=np.array(out_c, dtype=np.int64),
+                       vals=np.array(out_v, dtype=po.OVERLAP_DTYPE) if out_v else np.zeros(0, dtype=po.OVERLAP_DTYPE))
+        return dict(nalignments=len(out_r))
+
+    def export_overlaps(self):
+        return self.ov
+
     def synchronize(self):
         pass
 

@@ -37,7 +37,7 @@ def _expected():
     return o
 
 
-def _run_rank(rank, world, dist, backend):
+def _run_rank(rank, world, dist, backend, align=False):
     packed, off, lens, _ = _reads()
     bounds = partition_by_bases(lens, world)
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
@@ -46,6 +46,9 @@ def _run_rank(rank, world, dist, backend):
     d.set_reads(sp, so, sl, lo, bounds)
     ks, ms = d.build_kmer_matrix()
     st = d.create_seed_matrix()
+    if align:
+        d.align_seeds()
+        return d.export_csr(), ks, ms, st, d.export_overlaps()
     return d.export_csr(), ks, ms, st
 
 
@@ -80,6 +83,25 @@ def test_batched_all_to_all_rounds_give_the_same_result(monkeypatch):
     assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
 
 
+def _check_alignment_union(parts):
+    """driver logic of the sharded alignment stage (reads replicated by all-gather, i + j parity shares): union == one-rank oracle"""
+    packed, off, lens, _ = _reads()
+    o = _expected()
+    want_r, want_c, want_v, _ = o.align_upper(packed, off, lens, nthreads=2)
+    rows = np.concatenate([p["rows"] for p in parts]); cols = np.concatenate([p["cols"] for p in parts]); vals = np.concatenate([p["vals"] for p in parts])
+    order = np.lexsort((cols, rows))
+    assert len(rows) == len(want_r) and (rows[order] == want_r).all() and (cols[order] == want_c).all()
+    for f in want_v.dtype.names:
+        if f != "pad":
+            assert (vals[order][f] == want_v[f]).all(), f
+
+
+def test_three_ranks_alignment_shares_cover_every_pair_once():
+    parts = dist_sim.run_ranks(3, lambda r, h: _run_rank(r, 3, h, dist_sim.NumpyBackend(K, LO, UP), align=True))
+    _check_alignment_union([p[4] for p in parts])
+    assert all(p[4]["n"] > 0 for p in parts)
+
+
 def _gloo_worker(rank, world, port, outdir):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import torch.distributed as dist
@@ -87,8 +109,9 @@ def _gloo_worker(rank, world, port, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        B, ks, ms, st = _run_rank(rank, world, dist, dist_sim.NumpyBackend(K, LO, UP))
-        np.savez(os.path.join(outdir, "r%d.npz" % rank), rowptr=B["rowptr"], col=B["col"], val=B["val"], reliable=ks["reliable"])
+        B, ks, ms, st, ov = _run_rank(rank, world, dist, dist_sim.NumpyBackend(K, LO, UP), align=True)
+        np.savez(os.path.join(outdir, "r%d.npz" % rank), rowptr=B["rowptr"], col=B["col"], val=B["val"], reliable=ks["reliable"],
+                 arows=ov["rows"], acols=ov["cols"], avals=ov["vals"])
     finally:
         dist.destroy_process_group()
 
@@ -102,3 +125,4 @@ def test_two_processes_over_gloo_equal_single_process_oracle(tmp_path):
     oB = o.B()
     assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
     assert sum(int(p["reliable"]) for p in parts) == o.stat("N")
+    _check_alignment_union([dict(rows=p["arows"], cols=p["acols"], vals=p["avals"]) for p in parts])

@@ -13,7 +13,7 @@ from test_distributed_cpu import _shard
 pytestmark = pytest.mark.gpu
 
 
-def _run(world, reads, k, lo, up):
+def _run(world, reads, k, lo, up, align=False):
     packed, off, lens, _ = reads
     bounds = partition_by_bases(lens, world)
 
@@ -25,6 +25,9 @@ def _run(world, reads, k, lo, up):
         ks, ms = d.build_kmer_matrix()
         st = d.create_seed_matrix()
         out = (d.export_csr(), ks, ms, st)
+        if align:
+            a = d.align_seeds()
+            out = out + (d.export_overlaps(), a)
         d.be.e.close()
         return out
 
@@ -59,3 +62,29 @@ def test_uneven_shards_and_empty_rank():
     B = dist_sim.stitch_rows([p[0] for p in parts])
     oB = o.B()
     assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+
+
+def merge_overlaps(parts):
+    """Union of the ranks' alignment shares, in the one-rank order (rows ascending, columns ascending)."""
+    rows = np.concatenate([p["rows"] for p in parts]); cols = np.concatenate([p["cols"] for p in parts]); vals = np.concatenate([p["vals"] for p in parts])
+    order = np.lexsort((cols, rows))
+    return rows[order], cols[order], vals[order]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_alignment_equals_one_rank_oracle(world):
+    """Every candidate pair is aligned exactly once across the ranks (i + j parity rule), as (query = smaller id, target = larger id),
+    from the seed the one-rank run would use: the union equals the oracle's PairwiseAlignment on the whole read set, field by field."""
+    reads = elba_amd.synth_reads(33, 120000, 12, 3000, 700, error_rate=0.10, min_len=200)
+    o = po.Oracle(17, 2, 8)
+    o.count_and_build(*reads[:3])
+    o.spgemm(4)
+    want_r, want_c, want_v, _ = o.align_upper(reads[0], reads[1], reads[2], nthreads=8)
+    parts = _run(world, reads, 17, 2, 8, align=True)
+    rows, cols, vals = merge_overlaps([p[4] for p in parts])
+    assert len(rows) == len(want_r) and (rows == want_r).all() and (cols == want_c).all()
+    for f in want_v.dtype.names:
+        if f != "pad":
+            assert (vals[f] == want_v[f]).all(), f
+    shares = [p[5]["nalignments"] for p in parts]
+    assert sum(shares) == len(want_r) and min(shares) > 0.5 * max(shares)          # balanced without any exchange
