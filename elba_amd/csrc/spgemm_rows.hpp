@@ -176,7 +176,7 @@ struct Table {
 };
 
 #ifndef ELBA_PIPE
-#define ELBA_PIPE 1    // (A/B on MI355X: 2 needs 93 VGPRs instead of 60 and is 7-10 % SLOWER: the row loop is not bound by the gathers' latency)
+#define ELBA_PIPE 3    // 1: one trip requested ahead; 2: two (93 VGPRs, 7-10 % slower as written); 3: drain-aware order (see the accumulate loop)
 #endif
 #ifndef ELBA_PK
 #define ELBA_PK 4
@@ -298,7 +298,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         request_hdr(id0);
         cur = take_hdr(id0);
         if (qidx(1) < nrows) id_n = queue[qidx(1)];
-        dc = load_desc(cur.hs, 0u, cur.nd); if (PIPE == 2) d1 = load_desc(cur.hs, BLOCK, cur.nd);
+        dc = load_desc(cur.hs, 0u, cur.nd); if (PIPE >= 2) d1 = load_desc(cur.hs, BLOCK, cur.nd);
         gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u);
     }
     for (uint32_t rnd = 0; qidx(rnd) < nrows; ++rnd) {
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         const uint32_t i = cur.i, rs = cur.rs, hs = cur.hs, nd = cur.nd;
         const uint32_t ub_i = cur.work;                      // products of the row's descriptors: bounds its distinct partners
         // leaves this row early: the next row's prefetch is issued back to back
-#define ELBA_NEXT_ROW() do { if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE == 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u); } cur = nxt; id_n = id_nn; } while (0)
+#define ELBA_NEXT_ROW() do { if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE >= 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u); } cur = nxt; id_n = id_nn; } while (0)
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
             // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
@@ -374,6 +374,51 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         // advances and the gathers of the trip after next are issued: they have a whole trip's accumulator updates to arrive.
         bool full = false;
         uint32_t dup = 0;
+        if (PIPE == 3 && !GLOBAL && !(DIAG && (dbg & 3u))) {
+            // Drain-aware order.  Across control flow the compiler consumes a load behind `s_waitcnt vmcnt(0)`, which also waits for every load
+            // issued since — so loads issued BEFORE a consuming point are not overlapped with anything.  Each trip therefore (1) consumes
+            // what the previous trip requested — this trip's partner entries and the next trip's descriptor: ONE wait — then (2) requests
+            // the next trip's partner entries and the descriptor after next, and only then (3) runs its accumulator updates, which touch
+            // LDS only: the requests have the whole update phase to land.
+#pragma unroll 1
+            for (uint32_t t0 = 0; t0 < nd; t0 += BLOCK) {
+                const bool more = t0 + BLOCK < nd, more2 = t0 + 2 * BLOCK < nd;
+                uint32_t jv[PK];
+#pragma unroll
+                for (int k = 0; k < PK; ++k) jv[k] = (uint32_t)(ce[k] >> 32);
+                const uint32_t c = dc.z, sy = dc.y, x0 = dc.x;
+                dup += dc.w;
+                uint4 dnx = d1;
+                static_assert(PK == 4, "the consume point names PK registers");
+                asm volatile("" : "+v"(jv[0]), "+v"(jv[1]), "+v"(jv[2]), "+v"(jv[3]), "+v"(dnx.x) : : "memory");       // (1) everything requested so far has landed
+                uint4 d2 = make_uint4(0u, 0u, 0u, 0u);
+                if (more) gather(ce, dnx, 0u);                                                                       // (2)
+                if (more2) d2 = load_desc(hs, t0 + 2 * BLOCK, nd);
+                {                                                                                                    // (3)
+                    const uint32_t jl = (uint32_t)__builtin_amdgcn_update_dpp((int)~jv[0], (int)jv[0], 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+                    if (__popcll(__ballot(0u < c && jv[0] == jl)) >= DENSE_LANES) {
+#pragma unroll
+                        for (int k = 0; k < PK; ++k) tab.insert_runs(jv[k], sy + (uint32_t)k, (uint32_t)k < c, full);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < PK; ++k) { const uint32_t sq = sy + (uint32_t)k; tab.insert_lds(jv[k], sq, sq, 1u, (uint32_t)k < c, full); }
+                    }
+                }
+#pragma unroll 1
+                for (uint32_t r0 = PK; __ballot(c > r0) != 0; r0 += PK) {      // ranges longer than PK entries: they come first in a row
+                    uint64_t cx[PK];
+#pragma unroll
+                    for (int k = 0; k < PK; ++k) cx[k] = r0 + (uint32_t)k < c ? p.a_cscp[x0 + r0 + (uint32_t)k] : 0ull;
+#pragma unroll
+                    for (int k = 0; k < PK; ++k) { const uint32_t sq = sy + r0 + (uint32_t)k; tab.insert_lds((uint32_t)(cx[k] >> 32), sq, sq, 1u, r0 + (uint32_t)k < c, full); }
+                }
+                if (tab.abandoned()) {
+                    if (tid == 0) { const uint32_t done = t0 + BLOCK; misc[11] = done < nd ? done : nd; }
+                    break;
+                }
+                dc = dnx; d1 = d2;
+            }
+        } else
 #pragma unroll 1
         for (uint32_t t0 = 0; t0 < nd; t0 += BLOCK) {
             uint4 d2 = make_uint4(0u, 0u, 0u, 0u);
@@ -449,7 +494,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             ELBA_NEXT_ROW();
             continue;
         }
-        if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE == 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); }       // next row, first two trips' descriptors: in flight during the sweep
+        if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE >= 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); }       // next row, first two trips' descriptors: in flight during the sweep
 
         // ---- level 3: one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
