@@ -12,7 +12,7 @@
 //                    run starts -> run lengths = the exact counts -> runs with LOWER <= count <= UPPER are numbered in value order
 //                    (k-mer id = rank of the value) and copied out: that IS the CSC of A, columns already sorted.
 //
-// ELBA_KMER_HASH=1 (and the distributed owner path, whose input is an unordered record stream) — HASH-BASED:
+// ELBA_KMER_HASH=1 — HASH-BASED (kept for A/B runs; the distributed owner counts by sorting too, see stage_dist_count_records):
 //
 //   pass 1  k_kmer_count     every k-mer instance -> canonical packed value (rolling-free: each lane rebuilds its window from two
 //                            aligned 8-byte loads of the 2-bit stream, reverse complement by bit tricks) -> open-addressed
@@ -264,6 +264,51 @@ EnumParams make_enum(Ctx &c)
 
 }  // namespace
 
+// Sorted (k-mer, value) pairs -> runs -> reliable columns: rel_kmers / rel_counts / a_colptr / a_csc of the context (see the file header).
+// spare_k / spare_v: the sort's other buffer pair (2 (I + 2) u32 each), free once the sort is done.  Needs c.ws_e (I + 2 u32) and c.ws_f (I + 2 u64).
+static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals, uint64_t *spare_k, uint64_t *spare_v, uint64_t I,
+                            uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out)
+{
+    hipStream_t s = c.stream;
+    uint32_t *flag = c.ws_e.as<uint32_t>();
+    uint32_t *runid = reinterpret_cast<uint32_t *>(spare_k);                        // [I + 1]
+    uint32_t *headpos = c.ws_f.as<uint32_t>();                                      // [nruns + 1] <= I + 1
+    const unsigned nbI = (unsigned)((I + 1 + 255) / 256);
+    hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, I, flag);
+    exclusive_scan_u32(s, flag, runid, (int64_t)I + 1, c.ws_scan);
+    uint32_t nruns32 = 0;
+    ELBA_HIP(hipMemcpyAsync(&nruns32, runid + I, 4, hipMemcpyDeviceToHost, s));      // runs before the closing flag = distinct k-mers
+    hipLaunchKernelGGL(k_run_heads, dim3(nbI), dim3(256), 0, s, flag, runid, I, headpos);
+    ELBA_HIP(hipStreamSynchronize(s));
+    const uint64_t nruns = I > 0 ? nruns32 : 0;
+    uint32_t *relflag = reinterpret_cast<uint32_t *>(spare_v), *relcnt = relflag + (nruns + 2);      // [nruns + 1] each (spare_v holds 2 (I + 2) u32)
+    uint32_t *kidx = flag, *cptr = runid;                                                         // flags and run ids are dead now
+    const unsigned nbR = (unsigned)((nruns + 1 + 255) / 256);
+    hipLaunchKernelGGL(k_run_select, dim3(nbR), dim3(256), 0, s, headpos, nruns, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, relflag, relcnt);
+    exclusive_scan_u32(s, relflag, kidx, (int64_t)nruns + 1, c.ws_scan);
+    uint32_t Nn = 0;
+    ELBA_HIP(hipMemcpyAsync(&Nn, kidx + nruns, 4, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    const uint64_t N = Nn;
+    // Z <= I < 2^32 always holds (every entry is an instance), so the 32-bit scan cannot wrap
+    exclusive_scan_u32(s, relcnt, cptr, (int64_t)nruns + 1, c.ws_scan);
+    uint32_t Zz = 0;
+    ELBA_HIP(hipMemcpyAsync(&Zz, cptr + nruns, 4, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    const uint64_t Z = Zz;
+    ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
+    c.rel_kmers.reserve((size_t)(N + 1) * 8);
+    c.rel_counts.reserve((size_t)(N + 2) * 4);
+    c.a_colptr.reserve((size_t)(N + 2) * 4);
+    c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
+    if (nruns > 0)
+        hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, svals, headpos, relflag, kidx, cptr, nruns,
+                           c.rel_kmers.as<uint64_t>(), c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>());
+    ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    nruns_out = nruns; N_out = N; Z_out = Z;
+}
+
 void stage_count_kmers(Ctx &c)
 {
     ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "count_kmers: no reads (call elba_set_reads)");
@@ -299,41 +344,8 @@ void stage_count_kmers(Ctx &c)
         uint64_t *spare_k = where ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>(), *spare_v = where ? c.ws_b.as<uint64_t>() : c.ws_d.as<uint64_t>();   // free after the sort
         c.t_a.stop(s);
         c.t_b.start(s);
-        uint32_t *flag = c.ws_e.as<uint32_t>();
-        uint32_t *runid = reinterpret_cast<uint32_t *>(spare_k);                        // [I + 1]
-        uint32_t *headpos = c.ws_f.as<uint32_t>();                                      // [nruns + 1] <= I + 1
-        const unsigned nbI = (unsigned)((I + 1 + 255) / 256);
-        hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, I, flag);
-        exclusive_scan_u32(s, flag, runid, (int64_t)I + 1, c.ws_scan);
-        uint32_t nruns32 = 0;
-        ELBA_HIP(hipMemcpyAsync(&nruns32, runid + I, 4, hipMemcpyDeviceToHost, s));      // runs before the closing flag = distinct k-mers
-        hipLaunchKernelGGL(k_run_heads, dim3(nbI), dim3(256), 0, s, flag, runid, I, headpos);
-        ELBA_HIP(hipStreamSynchronize(s));
-        const uint64_t nruns = I > 0 ? nruns32 : 0;
-        uint32_t *relflag = reinterpret_cast<uint32_t *>(spare_v), *relcnt = relflag + (nruns + 2);      // [nruns + 1] each (spare_v holds 2 (I + 2) u32)
-        uint32_t *kidx = flag, *cptr = runid;                                                         // flags and run ids are dead now
-        const unsigned nbR = (unsigned)((nruns + 1 + 255) / 256);
-        hipLaunchKernelGGL(k_run_select, dim3(nbR), dim3(256), 0, s, headpos, nruns, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, relflag, relcnt);
-        exclusive_scan_u32(s, relflag, kidx, (int64_t)nruns + 1, c.ws_scan);
-        uint32_t Nn = 0;
-        ELBA_HIP(hipMemcpyAsync(&Nn, kidx + nruns, 4, hipMemcpyDeviceToHost, s));
-        ELBA_HIP(hipStreamSynchronize(s));
-        const uint64_t N = Nn;
-        // Z <= I < 2^32 always holds (every entry is an instance), so the 32-bit scan cannot wrap
-        exclusive_scan_u32(s, relcnt, cptr, (int64_t)nruns + 1, c.ws_scan);
-        uint32_t Zz = 0;
-        ELBA_HIP(hipMemcpyAsync(&Zz, cptr + nruns, 4, hipMemcpyDeviceToHost, s));
-        ELBA_HIP(hipStreamSynchronize(s));
-        const uint64_t Z = Zz;
-        ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
-        c.rel_kmers.reserve((size_t)(N + 1) * 8);
-        c.rel_counts.reserve((size_t)(N + 2) * 4);
-        c.a_colptr.reserve((size_t)(N + 2) * 4);
-        c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
-        if (nruns > 0)
-            hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, svals, headpos, relflag, kidx, cptr, nruns,
-                               c.rel_kmers.as<uint64_t>(), c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>());
-        ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
+        uint64_t nruns = 0, N = 0, Z = 0;
+        runs_to_columns(c, skeys, svals, spare_k, spare_v, I, nruns, N, Z);
         c.t_b.stop(s);
         c.t_total.stop(s);
         ELBA_HIP(hipStreamSynchronize(s));
@@ -496,32 +508,6 @@ __global__ __launch_bounds__(EN_THREADS) void k_dist_fill_send(EnumParams e, uin
     });
 }
 
-__global__ void k_rec_count(const uint64_t *rec, uint64_t n, unsigned long long *keys, uint32_t *vals, uint64_t capmask)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t km = rec[2 * i];
-    uint64_t slot = mix64(km) & capmask;
-    for (;;) {
-        const unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)KEMPTY, (unsigned long long)km);
-        if (old == KEMPTY || old == km) break;
-        slot = (slot + 1) & capmask;
-    }
-    atomicAdd(&vals[slot], 1u);
-}
-
-__global__ void k_rec_lookup(const uint64_t *rec, uint64_t n, const uint64_t *keys, const uint32_t *vals, uint64_t capmask,
-                             const uint32_t *colptr, uint32_t *fill, uint64_t *csc)
-{
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t km = rec[2 * i];
-    uint64_t slot = mix64(km) & capmask;
-    while (keys[slot] != km) slot = (slot + 1) & capmask;
-    const uint32_t kid = vals[slot];
-    if (kid != NOT_RELIABLE) csc[colptr[kid] + atomicAdd(&fill[kid], 1u)] = rec[2 * i + 1];
-}
-
 // global id of each local reliable k-mer = its rank in the sorted union of all owners' reliable k-mers
 __global__ void k_global_ids(const uint64_t *local, uint64_t nlocal, const uint64_t *all_sorted, uint64_t nall, uint32_t *gid)
 {
@@ -627,52 +613,22 @@ void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
     c.have_counts = false; c.have_A = false; c.have_B = false;
     c.d_records = static_cast<const uint64_t *>(d_rec); c.nrecords = nrec;
     const uint64_t I = (uint64_t)nrec;
-    int cbits = next_pow2_bits(I + I / 4 + 2);      // load factor <= 0.8 even if every instance were distinct; ~0.35 on real reads
-    if (cbits < 10) cbits = 10;
-    const uint64_t cap = 1ull << cbits;
-    c.tab_cap = (int64_t)cap;
-    c.tab_keys.reserve((size_t)cap * 8);
-    c.tab_vals.reserve((size_t)cap * 4);
-    ELBA_HIP(hipMemsetAsync(c.tab_keys.p, 0xFF, (size_t)cap * 8, s));
-    ELBA_HIP(hipMemsetAsync(c.tab_vals.p, 0, (size_t)cap * 4, s));
-    if (I > 0) hipLaunchKernelGGL(k_rec_count, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, c.d_records, I, c.tab_keys.as<unsigned long long>(), c.tab_vals.as<uint32_t>(), cap - 1);
-    c.ws_scan.reserve(256);
-    SelCounters *dctr = c.ws_scan.as<SelCounters>();
-    ELBA_HIP(hipMemsetAsync(dctr, 0, sizeof(SelCounters), s));
-    const int sel_blocks = c.num_cus * 8;
-    const uint64_t maxN = I / (uint64_t)c.cfg.lower + 1 + (uint64_t)sel_blocks * 4 * SEL_CHUNK;
-    c.ws_a.reserve(maxN * 8); c.ws_b.reserve(maxN * 8); c.ws_c.reserve(maxN * 8); c.ws_d.reserve(maxN * 8);
-    ELBA_HIP(hipMemsetAsync(c.ws_a.p, 0xFF, maxN * 8, s));
-    hipLaunchKernelGGL(k_table_select, dim3(sel_blocks), dim3(256), 0, s, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap,
-                       (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), dctr);
-    SelCounters hc{};
-    ELBA_HIP(hipMemcpyAsync(&hc, dctr, sizeof(hc), hipMemcpyDeviceToHost, s));
-    ELBA_HIP(hipStreamSynchronize(s));
-    const uint64_t N = hc.reliable, Z = hc.entries;
-    ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "nnz beyond 32-bit device offsets");
-    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)hc.cursor, 64 - 2 * k, 64, c.ws_sort);
-    const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>();
-    const uint64_t *sslots = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
-    c.rel_kmers.reserve((size_t)(N + 1) * 8);
-    c.rel_counts.reserve((size_t)(N + 2) * 4);
-    if (N > 0) {
-        ELBA_HIP(hipMemcpyAsync(c.rel_kmers.p, skeys, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_assign_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, sslots, c.tab_vals.as<uint32_t>(), c.rel_counts.as<uint32_t>(), N);
-    }
-    // owner-local columns: colptr by scan, entries by lookup of every record, then per-column sort by (read, pos)
-    c.a_colptr.reserve((size_t)(N + 2) * 4);
-    c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
-    ELBA_HIP(hipMemsetAsync(c.rel_counts.as<uint32_t>() + N, 0, 4, s));
-    exclusive_scan_u32(s, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), (int64_t)N + 1, c.ws_scan);
-    c.ws_e.reserve((size_t)(N + 1) * 4);
+    // The owner counts exactly like the single-GPU path, by sorting (file header): records -> (k-mer, read << 32 | pos) pairs -> stable radix
+    // sort on the k-mer -> runs -> reliable columns.  The records arrive in no particular order, so every column (<= UPPER entries) is
+    // sorted by (read, pos) afterwards.
+    c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_b.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8); c.ws_d.reserve((size_t)(I + 2) * 8);
+    c.ws_e.reserve((size_t)(I + 2) * 4); c.ws_f.reserve((size_t)(I + 2) * 8);
+    if (I > 0) hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, c.d_records, I, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
+    const int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)I, 64 - 2 * k, 64, c.ws_sort);
+    const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>(), *svals = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
+    uint64_t *spare_k = where ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>(), *spare_v = where ? c.ws_b.as<uint64_t>() : c.ws_d.as<uint64_t>();
+    uint64_t nruns = 0, N = 0, Z = 0;
+    runs_to_columns(c, skeys, svals, spare_k, spare_v, I, nruns, N, Z);
     c.ws_f.reserve((size_t)(Z + 1) * 8);
-    ELBA_HIP(hipMemsetAsync(c.ws_e.p, 0, (size_t)(N + 1) * 4, s));
-    if (I > 0)
-        hipLaunchKernelGGL(k_rec_lookup, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, c.d_records, I, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap - 1,
-                           c.a_colptr.as<uint32_t>(), c.ws_e.as<uint32_t>(), c.a_csc.as<uint64_t>());
     if (N > 0)
         hipLaunchKernelGGL(k_sort_columns, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.ws_f.as<uint64_t>(), N);
     ELBA_HIP(hipStreamSynchronize(s));
+    struct { uint64_t distinct; } hc{nruns};
     c.I = nrec; c.ndistinct = (int64_t)hc.distinct; c.N = (int64_t)N; c.Z = (int64_t)Z;
     c.kstats = elba_kmer_stats{};
     c.kstats.instances = nrec; c.kstats.distinct = (int64_t)hc.distinct; c.kstats.reliable = (int64_t)N; c.kstats.entries = (int64_t)Z;
