@@ -27,7 +27,7 @@ SEED_DTYPE = np.dtype([("q0", "<u4"), ("t0", "<u4"), ("q1", "<u4"), ("t1", "<u4"
 
 class Cfg(C.Structure):
     _fields_ = [("k", C.c_int32), ("lower", C.c_int32), ("upper", C.c_int32), ("device", C.c_int32),
-                ("workspace_hint_bytes", C.c_int64), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("workspace_hint_bytes", C.c_int64), ("flags", C.c_int32), ("timing_stride", C.c_int32)]
 
 
 class KmerStats(C.Structure):
@@ -42,7 +42,7 @@ class MatrixStats(C.Structure):
 class OverlapStats(C.Structure):
     _fields_ = [("nrows", C.c_int64), ("products", C.c_int64), ("nnz_before_prune", C.c_int64), ("nnz", C.c_int64), ("nnz_diag", C.c_int64),
                 ("nnz_upper", C.c_int64), ("max_numshared", C.c_int64), ("rows_lds", C.c_int64), ("rows_global", C.c_int64), ("rows_escalated", C.c_int64),
-                ("algorithmic_bytes", C.c_int64), ("passes", C.c_int32), ("reserved", C.c_int32),
+                ("algorithmic_bytes", C.c_int64), ("passes", C.c_int32), ("timed", C.c_int32),
                 ("ms_total", C.c_float), ("ms_symbolic", C.c_float), ("ms_numeric", C.c_float), ("ms_finalize", C.c_float)]
 
 
@@ -185,10 +185,10 @@ class Engine:
     """One context on one GPU.  Method names follow the reference's free functions (include/KmerOps.hpp:24-31,
     include/SharedSeeds.hpp:98-99); each is a single C-ABI call."""
 
-    def __init__(self, k, lower, upper, device=0, workspace_hint_bytes=0, flags=0):
+    def __init__(self, k, lower, upper, device=0, workspace_hint_bytes=0, flags=0, timing_stride=0):
         self.L = load_library()
         self.h = C.c_void_p()
-        cfg = Cfg(k, lower, upper, device, workspace_hint_bytes, flags, 0)
+        cfg = Cfg(k, lower, upper, device, workspace_hint_bytes, flags, timing_stride)
         rc = self.L.elba_ctx_create(C.byref(self.h), C.byref(cfg))
         if rc:
             self.h = C.c_void_p()

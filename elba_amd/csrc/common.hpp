@@ -185,6 +185,7 @@ struct Ctx {
     uint32_t ov_class_prior = 0; int64_t ov_class_lo = 0, ov_class_hi = 0; int ov_class_b0 = 0;
     DevBuf ov_counters_snap;
     int64_t b_cap_entries = 0;      // capacity of b_col/b_val the next overlap call may assume (0 = unknown: size it after the numeric pass)
+    uint64_t ov_calls = 0;          // steady-state overlap calls so far (phase events are recorded on every cfg.timing_stride-th)
     uint32_t ov_prior_q16 = 0;      // distinct-partner / product ratio measured by the previous overlap call (x 65536), 0 = unknown
 
     EventTimer t_total, t_a, t_b, t_c;

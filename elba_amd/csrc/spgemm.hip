@@ -508,13 +508,18 @@ void stage_create_seed_matrix(Ctx &c)
     int passes = 0;
     float ms_sym = 0, ms_num = 0;
     float ms_fin = 0, ms_tot = 0;
+    bool was_timed = true;
     for (;;) {
         ++passes;
         // The queues of the tiers depend only on A, the prior and the row window: in the steady state they are reused and the counter
         // block is restored from the snapshot taken right after the last classification (one 1.4 KB device copy instead of two
         // memsets and a kernel).  Rows rewrite their own row_cnt entry every call; empty rows keep the zero they were given once.
         const bool cached = c.ov_class_valid && c.ov_class_prior == p.prior_q16 && c.ov_class_lo == row_lo && c.ov_class_hi == row_hi && c.ov_class_b0 == b0 && c.b_cap_entries > 0;
-        c.ov_marks.mark(0, s);
+        // phase events: every call on the synchronising path; on the steady-state path every cfg.timing_stride-th call (an event record
+        // costs ~5 us of stream time, four of them 8 % of this call)
+        const int stride = c.cfg.timing_stride > 1 ? c.cfg.timing_stride : 1;
+        const bool timed = !(c.b_cap_entries > 0) || passes > 1 || (c.ov_calls++ % (uint64_t)stride) == 0;
+        if (timed) c.ov_marks.mark(0, s);
         // the ticket counters come back clean from a call that ran to its end (k_finalize_wave); otherwise zero them here
         if (!c.ov_low_clean) ELBA_HIP(hipMemsetAsync(c.ov_totcnt.p, 0, (size_t)(M + 2) * 4, s));
         c.ov_low_clean = false;
@@ -546,7 +551,7 @@ void stage_create_seed_matrix(Ctx &c)
         c.ov_tmp.reserve((size_t)c.ov_tmp_cap * sizeof(StageRec));
         p.tmp = c.ov_tmp.as<StageRec>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
 
-        c.ov_marks.mark(1, s);
+        if (timed) c.ov_marks.mark(1, s);
         const bool diag = c.cfg.flags != 0;
 #define ELBA_LAUNCH_ROWS(B, G, grid, lds, tier, tb)                                                                          \
     do {                                                                                                            \
@@ -574,7 +579,7 @@ void stage_create_seed_matrix(Ctx &c)
             ELBA_TIER(5, ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u));
             ELBA_HIP(hipGetLastError());
         }
-        c.ov_marks.mark(2, s);
+        if (timed) c.ov_marks.mark(2, s);
         // Steady state (staging and output capacities known from an earlier call on this matrix): no host round trip between the
         // numeric kernels and the finalize pass — everything is queued, ONE synchronisation at the end, and the rare surprises
         // (staging overflow, more output than last time) are repaired afterwards.  First call: synchronise here to size the output.
@@ -633,12 +638,12 @@ void stage_create_seed_matrix(Ctx &c)
             else skipped_sorts |= 2u;
           }
         }
-        c.ov_marks.mark(3, s);
+        if (timed) c.ov_marks.mark(3, s);
         // (also on the synchronising path: the wide-row sort queues are filled by k_mirror, after the first read-back)
         ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
         ELBA_HIP(hipStreamSynchronize(s));
         if (fast) {
-            ms_sym += c.ov_marks.ms(0, 1); ms_num += c.ov_marks.ms(1, 2);
+            if (timed) { ms_sym += c.ov_marks.ms(0, 1); ms_num += c.ov_marks.ms(1, 2); }
             int64_t y = 0;
             for (int sh = 0; sh < NUM_SHARDS; ++sh) y += (int64_t)hc.shard[sh].nnz;
             bool missed = false;
@@ -650,12 +655,12 @@ void stage_create_seed_matrix(Ctx &c)
                 ELBA_REQUIRE(passes < 4, ELBA_ERR_INTERNAL, "overlap output did not settle");
                 if (hc.overflow) c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;
                 c.b_cap_entries = 0; c.ov_class_valid = false;
-                ms_tot += c.ov_marks.ms(0, 3);
+                if (timed) ms_tot += c.ov_marks.ms(0, 3);
                 continue;
             }
         }
-        ms_fin = c.ov_marks.ms(fast ? 2 : 4, 3);
-        ms_tot += c.ov_marks.ms(0, 3);
+        if (timed) { ms_fin = c.ov_marks.ms(fast ? 2 : 4, 3); ms_tot += c.ov_marks.ms(0, 3); }
+        was_timed = timed;
         c.ov_low_clean = true;
         break;
     }
@@ -698,6 +703,7 @@ void stage_create_seed_matrix(Ctx &c)
     st.rows_escalated = queued - st.rows_lds - st.rows_global;
     st.algorithmic_bytes = 16 * Z + 8 * (2 * M + N + 3) + 24 * Y;
     st.passes = passes;
+    st.timed = was_timed ? 1 : 0;
     st.ms_total = ms_tot;
     st.ms_symbolic = ms_sym;
     st.ms_numeric = ms_num;

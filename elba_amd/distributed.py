@@ -39,11 +39,11 @@ def partition_by_bases(lens, nranks):
 class HipBackend:
     """The product backend: every method is one C-ABI call on device buffers owned by torch tensors."""
 
-    def __init__(self, k, lower, upper, device):
+    def __init__(self, k, lower, upper, device, timing_stride=0):
         import torch
         self.torch = torch
         self.dev = torch.device("cuda", device)
-        self.e = capi.Engine(k, lower, upper, device=device)
+        self.e = capi.Engine(k, lower, upper, device=device, timing_stride=timing_stride)
         self.L, self.h = self.e.L, self.e.h
         L = self.L
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
@@ -134,10 +134,10 @@ class HipBackend:
 class DistributedOverlap:
     MAX_RECORDS_PER_PEER = 1 << 25          # 512 MiB of 16-byte records per peer and all-to-all round
 
-    def __init__(self, k, lower, upper, device=0, rank=0, world=1, dist=None, backend=None):
+    def __init__(self, k, lower, upper, device=0, rank=0, world=1, dist=None, backend=None, timing_stride=0):
         self.k, self.lower, self.upper = k, lower, upper
         self.rank, self.world, self.dist = rank, world, dist
-        self.be = backend if backend is not None else HipBackend(k, lower, upper, device)
+        self.be = backend if backend is not None else HipBackend(k, lower, upper, device, timing_stride)
         self.nlocal = 0
         self.bounds = None
 

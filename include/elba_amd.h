@@ -105,7 +105,9 @@ typedef struct {
     int32_t device;     /* HIP device ordinal                                                */
     int64_t workspace_hint_bytes; /* 0 = decide from the input; otherwise pre-size the overlap workspace */
     int32_t flags;      /* reserved, 0 */
-    int32_t reserved;
+    int32_t timing_stride; /* elba_create_seed_matrix records its phase events (ms_* of elba_overlap_stats) on every timing_stride-th
+                              steady-state call only; 0 or 1 = every call.  An event record costs ~5 us of stream time on a ~0.25 ms call:
+                              a caller that does not read the phase times every call should not pay for them every call. */
 } elba_cfg;
 
 typedef struct {
@@ -139,7 +141,7 @@ typedef struct {
     int64_t rows_escalated; /* optimistic-table overflows re-queued on a larger tier      */
     int64_t algorithmic_bytes; /* 16Z + 8(2M+N+3) + 24Y                    */
     int32_t passes;         /* 1, or 2 when the output workspace had to grow              */
-    int32_t reserved;
+    int32_t timed;          /* 1: ms_* below were measured in this call; 0: this call recorded no events (cfg.timing_stride), ms_* are 0 */
     float   ms_total;       /* whole timed region: resident A -> resident pruned CSR B    */
     float   ms_symbolic;    /* row upper bounds + binning                                 */
     float   ms_numeric;     /* hash-accumulate kernels (the dominant kernels)             */
