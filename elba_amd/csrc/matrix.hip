@@ -370,7 +370,10 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     }
     ELBA_REQUIRE(win_lo >= 0 && (win_hi < 0 || (win_lo <= win_hi && win_hi <= M)), ELBA_ERR_INVALID_ARG, "bad row window");
     c.row_lo = win_lo; c.row_hi = win_hi;
-    c.b_cap_entries = 0; c.ov_tiers_known = false; c.ov_class_valid = false;
+    // a new matrix: the tier queues and the tier / sort usage of the previous one are forgotten.  The OUTPUT capacity is kept as a guess (the
+    // buffers exist): the first SpGEMM call on this matrix then runs without a host round trip in its middle and checks afterwards that
+    // everything fitted (spgemm.hip repeats the call on the synchronising path otherwise)
+    c.ov_tiers_known = false; c.ov_class_valid = false; c.ov_sort_used[0] = c.ov_sort_used[1] = true;
     c.ov_prior_q16 = 0;            // a new matrix: forget the partner/product ratio measured on the previous one
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
