@@ -239,3 +239,44 @@ def test_live_against_reference_primitives():
             for w in o1[:5].tolist():
                 x = C.c_uint64(w)
                 assert R.ref_kmer_hash(C.byref(x)) == L.orc_kmer_hash(w)
+
+
+@pytest.mark.parametrize("k", [33, 63])
+def test_two_word_kmers_match_reference_vectors(k):
+    """32 < k <= 64 (NLONGS == 2): every canonical k-mer of the sample reads, both words, against the reference's Kmer<2>::GetRepKmers."""
+    L = po.lib()
+    n_checked = 0
+    for line in open(os.path.join(G, "read_kmers2_k%d.txt" % k)):
+        if line[0] == "#":
+            continue
+        s, ks = line.split()
+        buf, off, lens = po.pack_reads([s.encode()])
+        want = [] if ks == "-" else [tuple(int(x, 16) for x in t.split(":")) for t in ks.split(",")]
+        assert len(want) == max(0, len(s) - k + 1)
+        for p_, w in enumerate(want):
+            out = np.zeros(2, dtype=np.uint64)
+            L.orc_kmer2_at(buf.ctypes.data, p_, k, out.ctypes.data)
+            assert (int(out[0]), int(out[1])) == w, (s, p_)
+            n_checked += 1
+    assert n_checked > 200
+
+
+def test_two_word_counting_is_consistent_with_one_word_counting():
+    """The same reads at k = 31 (one word) and k = 33 (two words) go through the same counting code; at k = 33 the reliable set must equal
+    a dictionary count over orc_kmer2_at (itself pinned to the reference above)."""
+    seqs = util.read_fasta(os.path.join(G, "small_clean.fa"))
+    buf, off, lens = po.pack_reads(seqs)
+    o = po.Oracle(33, 2, 12); o.count_and_build(buf, off, lens)
+    L = po.lib()
+    cnt = {}
+    for r in range(len(lens)):
+        for p_ in range(max(0, int(lens[r]) - 33 + 1)):
+            out = np.zeros(2, dtype=np.uint64)
+            L.orc_kmer2_at(buf.ctypes.data + int(off[r]), p_, 33, out.ctypes.data)
+            cnt.setdefault((int(out[0]), int(out[1])), []).append((r, p_))
+    rel = sorted(km for km, v in cnt.items() if 2 <= len(v) <= 12)
+    A = o.A()
+    assert A["N"] == len(rel) and [(int(a), int(b)) for a, b in zip(A["kmers"], A["kmers_lo"])] == rel
+    for kid, km in enumerate(rel):
+        e0, e1 = int(A["colptr"][kid]), int(A["colptr"][kid + 1])
+        assert list(zip(A["csc_read"][e0:e1].tolist(), A["csc_pos"][e0:e1].tolist())) == sorted(cnt[km])
