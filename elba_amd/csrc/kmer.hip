@@ -74,8 +74,57 @@ __device__ __forceinline__ uint64_t canonical_at(const EnumParams &e, uint32_t r
     return tw < fwd ? tw : fwd;
 }
 
-// Calls f(instance index g, read r, pos p, canonical k-mer) for the EN_ITEMS instances of this lane; instances of a wave are
-// consecutive, so the read is found by ONE binary search per wave plus a short forward walk.
+// Two-word k-mers, 32 < k <= 63 (NLONGS == 2, include/Kmer.hpp:95-97): bases 0..31 in the first word, the rest left-aligned in the second;
+// twin = reverse complement over 128 bits; canonical = the smaller of the two, first word compared first (src/Kmer.cpp:118-131, :200-205).
+// Three aligned 8-byte loads cover the window (the k-mer itself spans >= 9 bytes, so the 16 guard bytes behind the reads suffice).
+__device__ __forceinline__ uint64_t rev2bit64(uint64_t x)
+{
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    return __builtin_bswap64(x);
+}
+__device__ __forceinline__ void canonical2_at(const EnumParams &e, uint32_t r, uint32_t p, uint64_t &hi, uint64_t &lo)
+{
+    const uint64_t b = e.byte_off[r] + (p >> 2);
+    const uint64_t a = b & ~7ull;
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(e.packed + a);
+    const uint64_t w0 = __builtin_bswap64(w[0]), w1 = __builtin_bswap64(w[1]), w2 = __builtin_bswap64(w[2]);
+    const uint32_t sh = (uint32_t)(b - a) * 8 + 2 * (p & 3);              // 0..62
+    const uint64_t fh = sh ? ((w0 << sh) | (w1 >> (64 - sh))) : w0;
+    const uint64_t fl = (sh ? ((w1 << sh) | (w2 >> (64 - sh))) : w1) & (~0ull << (2 * (64 - e.k)));
+    // reverse complement of the 128-bit left-aligned value: complement, reverse the 64 two-bit groups, shift the k real ones to the top
+    const uint64_t rh = rev2bit64(~fl), rl = rev2bit64(~fh);
+    const uint32_t s2 = 2 * (64 - (uint32_t)e.k);                          // 2..62
+    const uint64_t th = (rh << s2) | (rl >> (64 - s2)), tl = rl << s2;
+    const bool twin = th < fh || (th == fh && tl < fl);
+    hi = twin ? th : fh; lo = twin ? tl : fl;
+}
+
+// Calls f(instance index g, read r, pos p) for the EN_ITEMS instances of this lane; instances of a wave are consecutive, so the read
+// is found by ONE binary search per wave plus a short forward walk.
+template <class F>
+__device__ __forceinline__ void for_each_position(const EnumParams &e, F &&f)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * EN_THREADS + threadIdx.x) >> 6;
+    const uint64_t g0 = wave * EN_PER_WAVE;
+    if (g0 >= e.I) return;
+    uint32_t lo = 0, hi = e.nreads;                 // last r with inst_off[r] <= g0
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (e.inst_off[mid] <= g0) lo = mid; else hi = mid;
+    }
+    uint32_t r = lo;
+#pragma unroll
+    for (int it = 0; it < EN_ITEMS; ++it) {
+        const uint64_t g = g0 + (uint64_t)it * 64 + lane;
+        if (g >= e.I) break;
+        while (g >= e.inst_off[r + 1]) ++r;         // reads shorter than k have empty ranges and are skipped here
+        f(g, r, (uint32_t)(g - e.inst_off[r]));
+    }
+}
+
+// Calls f(instance index g, read r, pos p, canonical k-mer) for the EN_ITEMS instances of this lane (k <= 31)
 template <class F>
 __device__ __forceinline__ void for_each_instance(const EnumParams &e, F &&f)
 {
@@ -203,12 +252,27 @@ __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit(EnumParams e, uint64_t
     for_each_instance(e, [&](uint64_t g, uint32_t r, uint32_t p, uint64_t km) { keys[g] = km; vals[g] = ((uint64_t)r << 32) | p; });
 }
 
-// flag[g] = 1 where a run of equal k-mers starts (flag[I] = 1 closes the last run)
-__global__ void k_run_flags(const uint64_t *keys, uint64_t I, uint32_t *flag)
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit2(EnumParams e, uint64_t *khi, uint64_t *klo, uint64_t *vals, uint64_t *idx)
+{
+    for_each_position(e, [&](uint64_t g, uint32_t r, uint32_t p) {
+        uint64_t hi, lo;
+        canonical2_at(e, r, p, hi, lo);
+        khi[g] = hi; klo[g] = lo; vals[g] = ((uint64_t)r << 32) | p; idx[g] = g;
+    });
+}
+
+__global__ void k_gather_u64(const uint64_t *idx, const uint64_t *in, uint64_t n, uint64_t *out)
+{
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) out[t] = in[idx[t]];
+}
+
+// flag[g] = 1 where a run of equal k-mers starts (flag[I] = 1 closes the last run); keys_lo: second word of two-word k-mers, or null
+__global__ void k_run_flags(const uint64_t *keys, const uint64_t *keys_lo, uint64_t I, uint32_t *flag)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g > I) return;
-    flag[g] = (g == 0 || g == I || keys[g] != keys[g - 1]) ? 1u : 0u;
+    flag[g] = (g == 0 || g == I || keys[g] != keys[g - 1] || (keys_lo && keys_lo[g] != keys_lo[g - 1])) ? 1u : 0u;
 }
 
 // headpos[run] = first instance of the run; headpos[nruns] = I
@@ -230,13 +294,14 @@ __global__ void k_run_select(const uint32_t *headpos, uint64_t nruns, uint32_t l
 }
 
 // reliable run -> column kid: k-mer value, count, column pointer, entries (already in (read, pos) order: the sort is stable)
-__global__ void k_emit_columns(const uint64_t *keys, const uint64_t *vals, const uint32_t *headpos, const uint32_t *relflag, const uint32_t *kidx, const uint32_t *cptr,
-                               uint64_t nruns, uint64_t *rel_kmers, uint32_t *rel_counts, uint32_t *colptr, uint64_t *csc)
+__global__ void k_emit_columns(const uint64_t *keys, const uint64_t *keys_lo, const uint64_t *vals, const uint32_t *headpos, const uint32_t *relflag, const uint32_t *kidx, const uint32_t *cptr,
+                               uint64_t nruns, uint64_t *rel_kmers, uint64_t *rel_kmers_lo, uint32_t *rel_counts, uint32_t *colptr, uint64_t *csc)
 {
     const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nruns || !relflag[u]) return;
     const uint32_t kid = kidx[u], h = headpos[u], c = headpos[u + 1] - h, at = cptr[u];
     rel_kmers[kid] = keys[h]; rel_counts[kid] = c; colptr[kid] = at;
+    if (keys_lo) rel_kmers_lo[kid] = keys_lo[h];
     for (uint32_t t = 0; t < c; ++t) csc[at + t] = vals[h + t];
 }
 
@@ -267,14 +332,14 @@ EnumParams make_enum(Ctx &c)
 // Sorted (k-mer, value) pairs -> runs -> reliable columns: rel_kmers / rel_counts / a_colptr / a_csc of the context (see the file header).
 // spare_k / spare_v: the sort's other buffer pair (2 (I + 2) u32 each), free once the sort is done.  Needs c.ws_e (I + 2 u32) and c.ws_f (I + 2 u64).
 static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals, uint64_t *spare_k, uint64_t *spare_v, uint64_t I,
-                            uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out)
+                            uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out, const uint64_t *skeys_lo = nullptr)
 {
     hipStream_t s = c.stream;
     uint32_t *flag = c.ws_e.as<uint32_t>();
     uint32_t *runid = reinterpret_cast<uint32_t *>(spare_k);                        // [I + 1]
     uint32_t *headpos = c.ws_f.as<uint32_t>();                                      // [nruns + 1] <= I + 1
     const unsigned nbI = (unsigned)((I + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, I, flag);
+    hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, skeys_lo, I, flag);
     exclusive_scan_u32(s, flag, runid, (int64_t)I + 1, c.ws_scan);
     uint32_t nruns32 = 0;
     ELBA_HIP(hipMemcpyAsync(&nruns32, runid + I, 4, hipMemcpyDeviceToHost, s));      // runs before the closing flag = distinct k-mers
@@ -298,12 +363,14 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
     const uint64_t Z = Zz;
     ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
     c.rel_kmers.reserve((size_t)(N + 1) * 8);
+    if (skeys_lo) c.rel_kmers_lo.reserve((size_t)(N + 1) * 8);
     c.rel_counts.reserve((size_t)(N + 2) * 4);
     c.a_colptr.reserve((size_t)(N + 2) * 4);
     c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
     if (nruns > 0)
-        hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, svals, headpos, relflag, kidx, cptr, nruns,
-                           c.rel_kmers.as<uint64_t>(), c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>());
+        hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, skeys_lo, svals, headpos, relflag, kidx, cptr, nruns,
+                           c.rel_kmers.as<uint64_t>(), skeys_lo ? c.rel_kmers_lo.as<uint64_t>() : (uint64_t *)nullptr, c.rel_counts.as<uint32_t>(),
+                           c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>());
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
     ELBA_HIP(hipStreamSynchronize(s));
     nruns_out = nruns; N_out = N; Z_out = Z;
@@ -329,7 +396,47 @@ void stage_count_kmers(Ctx &c)
     c.inst_off.reserve((size_t)(M + 1) * 8);
     ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s));
 
-    c.kmers_sorted = !getenv("ELBA_KMER_HASH");
+    c.kmers_sorted = !getenv("ELBA_KMER_HASH") || k > 31;
+    if (k > 31) {
+        // ---- two-word k-mers: sort an index permutation, second word first (stable LSD over both words), then gather ----
+        DevBuf khi, klo, val, i0, i1, t0, t1;
+        for (DevBuf *b : {&khi, &klo, &val, &i0, &i1, &t0, &t1}) b->reserve((size_t)(I + 2) * 8);
+        c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_b.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8);
+        c.ws_e.reserve((size_t)(I + 2) * 4); c.ws_f.reserve((size_t)(I + 2) * 8);
+        c.t_total.start(s);
+        c.t_a.start(s);
+        EnumParams e = make_enum(c);
+        const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+        const unsigned nbI = (unsigned)((I + 255) / 256);
+        uint64_t *shi = c.ws_a.as<uint64_t>(), *slo = c.ws_b.as<uint64_t>(), *sval = c.ws_c.as<uint64_t>();
+        if (I > 0) {
+            hipLaunchKernelGGL(k_kmer_emit2, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, khi.as<uint64_t>(), klo.as<uint64_t>(), val.as<uint64_t>(), i0.as<uint64_t>());
+            ELBA_HIP(hipMemcpyAsync(t0.p, klo.p, (size_t)I * 8, hipMemcpyDeviceToDevice, s));
+            int w = radix_sort_pairs(s, t0.as<uint64_t>(), i0.as<uint64_t>(), t1.as<uint64_t>(), i1.as<uint64_t>(), (int64_t)I, 64 - 2 * (k - 32), 64, c.ws_sort);
+            uint64_t *ia = w ? i1.as<uint64_t>() : i0.as<uint64_t>(), *ib = w ? i0.as<uint64_t>() : i1.as<uint64_t>();
+            uint64_t *ka = w ? t1.as<uint64_t>() : t0.as<uint64_t>(), *kb = w ? t0.as<uint64_t>() : t1.as<uint64_t>();
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, ia, khi.as<uint64_t>(), I, ka);
+            int w2 = radix_sort_pairs(s, ka, ia, kb, ib, (int64_t)I, 0, 64, c.ws_sort);
+            const uint64_t *fin = w2 ? ib : ia;
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, fin, khi.as<uint64_t>(), I, shi);
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, fin, klo.as<uint64_t>(), I, slo);
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, fin, val.as<uint64_t>(), I, sval);
+        }
+        c.t_a.stop(s);
+        c.t_b.start(s);
+        uint64_t nruns = 0, N = 0, Z = 0;
+        runs_to_columns(c, shi, sval, t0.as<uint64_t>(), t1.as<uint64_t>(), I, nruns, N, Z, slo);
+        c.t_b.stop(s);
+        c.t_total.stop(s);
+        ELBA_HIP(hipStreamSynchronize(s));
+        st.instances = (int64_t)I; st.distinct = (int64_t)nruns; st.reliable = (int64_t)N; st.entries = (int64_t)Z;
+        st.ms_total = c.t_total.ms(); st.ms_count = c.t_a.ms(); st.ms_sort = c.t_b.ms(); st.ms_lookup = 0;
+        c.ndistinct = (int64_t)nruns;
+        c.N = (int64_t)N; c.Z = (int64_t)Z;
+        c.kstats = st;
+        c.have_counts = true;
+        return;
+    }
     if (c.kmers_sorted) {
         // ---- sort-based: see the header of this file ----
         c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_b.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8); c.ws_d.reserve((size_t)(I + 2) * 8);
@@ -566,6 +673,7 @@ int bits_needed(uint64_t maxval)
 
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host)
 {
+    ELBA_REQUIRE(c.cfg.k <= 31, ELBA_ERR_UNSUPPORTED, "the multi-GPU exchange carries one-word k-mers (k <= 31)");
     ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "dist_count_owners: no reads");
     ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS, ELBA_ERR_INVALID_ARG, "dist_count_owners: 1..64 ranks");
     hipStream_t s = c.stream;

@@ -254,3 +254,24 @@ def test_pattern_and_counts_do_not_depend_on_kmer_id_order():
         for q, t in ((v["q0"], v["t0"]), (v["q1"], v["t1"])):
             assert L.orc_seed_is_valid(packed.ctypes.data + int(off[i]), int(lens[i]), packed.ctypes.data + int(off[j]), int(lens[j]), int(q), int(t), 17)
     e.close()
+
+
+@pytest.mark.parametrize("k,lo,up", [(33, 2, 12), (45, 2, 12), (63, 2, 12)])
+def test_two_word_kmers_full_pipeline(k, lo, up):
+    """32 < k <= 63 (NLONGS == 2 in the reference, include/Kmer.hpp:95-97): reads -> A -> B equal the oracle's, whose two-word k-mers are
+    pinned to the reference's Kmer<2>::GetRepKmers (tests/test_oracle_golden.py).  Reads around byte and word boundaries included."""
+    rng = np.random.default_rng(k)
+    seqs = util.read_fasta(os.path.join(G, "small_clean.fa")) + util.read_fasta(os.path.join(G, "small_err.fa"))
+    seqs += [bytes(rng.choice(list(b"ACGT"), n).tolist()) for n in (k - 1, k, k + 1, k + 2, k + 3, 64, 65, 127, 128, 129)]
+    packed, off, lens = po.pack_reads(seqs)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up)
+    o = gu.oracle_run(packed, off, lens, k, lo, up)
+    assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    a = e.align_seeds()                                             # the seed check of the aligner walks k bases too
+    rows, cols, ov, _ = o.align_upper(packed, off, lens)
+    g = e.export_overlaps()
+    assert (g["rows"] == rows).all() and all((g["vals"][f] == ov[f]).all() for f in ov.dtype.names if f != "pad")
+    e.close()
