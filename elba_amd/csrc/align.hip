@@ -510,10 +510,10 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
         hipLaunchKernelGGL(k_aln_prepare, dim3(nbM), dim3(256), 0, s, p);
         c.t_a.start(s);
         // persistent wavefronts pulling extensions from a queue: durations range from a handful of antidiagonals to tens of thousands.
-        // Tiers of 64 / 128 / 256 columns per wavefront: an extension whose band outgrows a tier is redone from its seed on the next;
-        // beyond 255 columns the strided kernel takes over.  (ELBA_ALN_TIERS="1,2,4" selects the instantiations, for A/B runs.)
-        int tiers[3] = {1, 2, 4}, ntiers = 3;
-        if (const char *e = getenv("ELBA_ALN_TIERS")) { ntiers = 0; for (const char *q = e; *q && ntiers < 3; ++q) if (*q == '1' || *q == '2' || *q == '4') tiers[ntiers++] = *q - '0'; if (ntiers == 0) { tiers[0] = 1; ntiers = 1; } }
+        // Tiers of 64 / 128 / 256 / 512 columns per wavefront: an extension whose band outgrows a tier is redone from its seed on the next;
+        // beyond 511 columns the strided kernel takes over.  (ELBA_ALN_TIERS="1,2,4,8" selects the instantiations, for A/B runs.)
+        int tiers[4] = {1, 2, 4, 8}, ntiers = 4;
+        if (const char *e = getenv("ELBA_ALN_TIERS")) { ntiers = 0; for (const char *q = e; *q && ntiers < 4; ++q) if (*q == '1' || *q == '2' || *q == '4' || *q == '8') tiers[ntiers++] = *q - '0'; if (ntiers == 0) { tiers[0] = 1; ntiers = 1; } }
         const int64_t resident = (int64_t)c.num_cus * 8;
         unsigned int nwork = (unsigned int)(2 * K);
         const uint32_t *in_list = nullptr; const unsigned int *in_count = nullptr;
@@ -523,7 +523,8 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
             uint32_t *out_list = lists[t & 1]; unsigned int *out_count = ctr + 16 + t;
             if (tiers[t] == 1) hipLaunchKernelGGL((k_xdrop_wave<1>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
             else if (tiers[t] == 2) hipLaunchKernelGGL((k_xdrop_wave<2>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
-            else hipLaunchKernelGGL((k_xdrop_wave<4>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
+            else if (tiers[t] == 4) hipLaunchKernelGGL((k_xdrop_wave<4>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
+            else hipLaunchKernelGGL((k_xdrop_wave<8>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
             ELBA_HIP(hipMemcpyAsync(&nwork, out_count, 4, hipMemcpyDeviceToHost, s));
             ELBA_HIP(hipStreamSynchronize(s));
             if (getenv("ELBA_TRACE")) fprintf(stderr, "[elba] x-drop tier %d columns/lane: %u extensions left\n", tiers[t], nwork);

@@ -3,7 +3,7 @@
 TAG=${1:?tag}
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_aln -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline > $R/gpurun_out/${TAG}_aln.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_aln -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/${TAG}_aln.log 2>&1
 f=$(ls -t $R/gpurun_out/${TAG}_aln/*/*kernel_stats.csv | head -1)
 cp $f $R/gpurun_out/${TAG}_align_kernel_stats.csv
 python3 - "$f" <<'PY'

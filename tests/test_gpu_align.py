@@ -51,7 +51,7 @@ def test_align_long_noisy_reads_default_parameters():
     e.close()
 
 
-@pytest.mark.parametrize("tiers", ["1", "2", "4", "1,2,4", "2,4"])
+@pytest.mark.parametrize("tiers", ["1", "2", "4", "8", "1,2,4,8", "2,4"])
 def test_align_wide_bands_escalate_and_reach_the_strided_kernel(tiers, monkeypatch):
     """x-drop 90 on accurate reads: the band outgrows 64 (128, 256) columns; those extensions are redone on the next tier and, past
     the last one, by the strided kernel — same results whatever the tiers."""
@@ -62,7 +62,7 @@ def test_align_wide_bands_escalate_and_reach_the_strided_kernel(tiers, monkeypat
     a = _compare(e, o, packed, off, lens, (1, -1, -1, 90))
     if tiers == "1":
         assert a["extensions_strided"] > 0
-    b = _compare(e, o, packed, off, lens, (1, -1, -1, 400))        # bands of several hundred columns: beyond every register tier
+    b = _compare(e, o, packed, off, lens, (1, -1, -1, 900))        # bands of more than 512 columns: beyond every register tier
     assert b["extensions_strided"] > 0
     e.close()
 
