@@ -40,6 +40,7 @@ struct AlnParams {
                                // rank of the larger row when it is odd — every pair exactly once, the shares balanced without any exchange
     int32_t k, mat, mis, gap, dropoff;
     int32_t wide_hint;         // pairs with numshared <= wide_hint skip the 64-column tier (performance only: any tier gives the same result)
+    int32_t long_hint;         // ... and the 128-column tier too when the shorter side of the extension has at least this many bases
     uint32_t *cnt; const int64_t *taskptr;
     AlnTask *tasks; AlnExt *ext; int64_t ntasks;
     int *scratch; unsigned long long scratch_stride;  // strided kernel: three antidiagonals per wavefront
@@ -167,7 +168,10 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
         AlnExt res{0, 0, 0, 0};
         ExtGeom g;
         if (!tk.valid || !ext_geometry(p, tk, left, g)) { if (lane == 0) p.ext[tk2] = res; continue; }
-        if (KC == 1 && in_list == nullptr && tk.numshared <= p.wide_hint) {          // probably a wide band: straight to the next tier
+        // probably a wide band (few shared k-mers: unrelated reads, which align in the linear regime under +1/-1/-1): straight to the next
+        // tier; and a LONG such extension (the band of a linear-regime alignment keeps growing with its length) skips the 128-column tier too
+        if ((KC == 1 && in_list == nullptr && tk.numshared <= p.wide_hint) ||
+            (KC == 2 && tk.numshared <= p.wide_hint && (g.cols < g.rows ? g.cols : g.rows) >= p.long_hint)) {
             if (lane == 0) { const unsigned int at = atomicAdd(out_count, 1u); out_list[at] = tk2; }
             continue;
         }
@@ -318,6 +322,7 @@ __global__ __launch_bounds__(64 * ALN_WAVES) void k_xdrop_wave(AlnParams p, cons
             for (int k = 0; k < KC; ++k) { A1[k] = A2[k]; A2[k] = A3[k]; tb[k] = rt[(n + 1 - (c0 + k)) & (RING - 1)]; }     // next antidiagonal's target bases
         }
         if (!overflow) cells += mycells;
+        else if (lane == 0) atomicAdd(p.cells + 1, mycells);          // abandoned work (diagnostic: ELBA_TRACE)
         res.score = best_score; res.col = best_col; res.row = best_row; res.overflow = overflow ? 1 : 0;
         if (lane == 0) {
             p.ext[tk2] = res;
@@ -477,6 +482,7 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
     p.M = (uint32_t)M; p.row_lo = shard ? (uint32_t)c.row_lo : 0u; p.row_hi = shard ? (uint32_t)c.row_hi : (uint32_t)M; p.share = shard ? 1u : 0u;
     p.k = c.cfg.k; p.mat = mat; p.mis = mis; p.gap = gap; p.dropoff = dropoff;
     p.wide_hint = getenv("ELBA_ALN_WIDE_HINT") ? atoi(getenv("ELBA_ALN_WIDE_HINT")) : 6;
+    p.long_hint = getenv("ELBA_ALN_LONG_HINT") ? atoi(getenv("ELBA_ALN_LONG_HINT")) : 6000;
     c.t_total.start(s);
     const int64_t nrows = (int64_t)p.row_hi - (int64_t)p.row_lo;
     c.aln_cnt.reserve((size_t)(nrows + 2) * 4); c.aln_ptr.reserve((size_t)(nrows + 2) * 8); c.aln_ctr.reserve(256);
@@ -527,7 +533,11 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
             else hipLaunchKernelGGL((k_xdrop_wave<8>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
             ELBA_HIP(hipMemcpyAsync(&nwork, out_count, 4, hipMemcpyDeviceToHost, s));
             ELBA_HIP(hipStreamSynchronize(s));
-            if (getenv("ELBA_TRACE")) fprintf(stderr, "[elba] x-drop tier %d columns/lane: %u extensions left\n", tiers[t], nwork);
+            if (getenv("ELBA_TRACE")) {
+                unsigned long long wasted = 0;
+                ELBA_HIP(hipMemcpy(&wasted, p.cells + 1, 8, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[elba] x-drop tier %d columns/lane: %u extensions left, %llu cells abandoned so far\n", tiers[t], nwork, wasted);
+            }
             in_list = out_list; in_count = out_count;
         }
         unsigned int nofl = nwork;
