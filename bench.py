@@ -250,6 +250,20 @@ def main():
             same = bool((g["rows"] == rws).all() and (g["cols"] == cls).all() and all((g["vals"][f][idx] == ov[f][idx]).all() for f in ov.dtype.names if f != "pad"))
             align["cpu_baseline"] = {"gcups": round(ccells / ta / 1e9, 4), "cores": 1, "kind": "port", "sample": "every %d-th candidate pair (%d pairs, %d cells)" % (stride, len(idx), ccells), "seconds": round(ta, 3)}
             align["parity_vs_oracle_on_sample"] = same
+            # the reference's OWN x-drop (src/XDropAligner.cpp compiled from /root/reference into oracle/_ref, which travels prebuilt) on the same sample
+            R = po.ref_lib(k)
+            if R is not None and hasattr(R, "ref_xdrop"):
+                t0 = time.perf_counter(); ok = True
+                for a in idx:
+                    i_, j_ = int(rws[a]), int(cls[a])
+                    e0 = int(B["rowptr"][i_]) + int(np.searchsorted(B["col"][int(B["rowptr"][i_]):int(B["rowptr"][i_ + 1])], j_))
+                    r_ = po.ref_xdrop(R, packed[int(off[i_]):], int(lens[i_]), packed[int(off[j_]):], int(lens[j_]), int(B["val"][e0]["q0"]), int(B["val"][e0]["t0"]))
+                    v_ = g["vals"][a]
+                    ok = ok and (r_[1], r_[2], r_[3], r_[4], r_[5], r_[6], r_[7]) == (int(v_["begQ"]), int(v_["endQ"]), int(v_["begT"]), int(v_["endT"]), int(v_["score"]), int(v_["rc"]), int(v_["kind"]))
+                tr = time.perf_counter() - t0
+                align["cpu_baseline_reference"] = {"gcups": round(ccells / tr / 1e9, 4), "cores": 1, "kind": "reference", "seconds": round(tr, 3),
+                                                   "what": "the reference's xdrop_aligner + classify_alignment (g++ -O2) on the same sample, called through ctypes"}
+                align["parity_vs_reference_on_sample"] = bool(ok)
 
     if rank == 0:
         out = {
