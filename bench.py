@@ -227,6 +227,7 @@ def main():
 
     cpu = None
     parity = None
+    kmer_ref = None
     if rank == 0 and world == 1 and not force_dist and not args.no_cpu_baseline:
         from oracle import pyoracle as po   # checker + CPU baseline only
         A = runner.export_kmer_matrix()
@@ -241,6 +242,29 @@ def main():
                "seconds": round(t1, 4), "all_cores": {"value": round(o.stat("Y") / tn, 1), "cores": ncores, "seconds": round(tn, 4)}}
         B = runner.export_csr(); oB = o.B()
         parity = bool(B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"]).all() and (B["val"] == oB["val"]).all())
+        # the reference's OWN k-mer stage on one host core, on a bounded sample of the reads (oracle/_ref: Kmer::GetRepKmers, and the two-pass
+        # Bloom + map control flow of src/KmerOps.cpp replayed on the reference's Bloom / Kmer code) — a reported baseline, nothing more
+        kmer_ref = None
+        R = po.ref_lib(k)
+        if R is not None:
+            ns = min(len(lens), 400)
+            sb = int(off[ns - 1]) + (int(lens[ns - 1]) + 3) // 4
+            sp = np.concatenate([packed[:sb], np.zeros(16, np.uint8)]); so = off[:ns].copy(); sl = lens[:ns].copy()
+            inst = int(np.maximum(sl.astype(np.int64) - k + 1, 0).sum())
+            outk = np.zeros(int(sl.max()) + 8, dtype=np.uint64)
+            t0 = time.perf_counter()
+            for r in range(ns):
+                R.ref_kmers(sp.ctypes.data + int(so[r]), int(sl[r]), outk.ctypes.data, 1)
+            te = time.perf_counter() - t0
+            cap = inst + 8
+            ok_, or_, op_ = np.zeros(cap, np.uint64), np.zeros(cap, np.int64), np.zeros(cap, np.uint32)
+            import ctypes as C
+            k1 = C.c_int64()
+            t0 = time.perf_counter()
+            zz = R.ref_replay_count(sp.ctypes.data, so.ctypes.data, sl.ctypes.data, ns, lo, up, max(1, inst // 3), ok_.ctypes.data, or_.ctypes.data, op_.ctypes.data, cap, C.byref(k1))
+            tc = time.perf_counter() - t0
+            kmer_ref = {"kind": "reference", "cores": 1, "sample": "the first %d reads (%d k-mer instances)" % (ns, inst),
+                        "enumerate_instances_per_s": round(inst / te, 1), "count_two_pass_instances_per_s": round(inst / tc, 1), "entries_on_sample": int(zz)}
         if align is not None:
             # CPU side of the alignment stage: the oracle's x-drop (pinned to the reference's XDropAligner.cpp) on every stride-th pair, one core
             stride = max(1, align["alignments"] // 400)
@@ -282,7 +306,8 @@ def main():
             "ingest_stage": ingest,
             "align_stage": align,
             "kmer_stage": {"device_ms": round(ks["ms_total"] + ms["ms_total"], 3), "matrix_build_ms": round(ms["ms_total"], 3), "wall_ms": round(t_kmer_wall * 1e3, 3),
-                           "instances_per_s": round(ks["instances"] / max(1e-9, t_kmer_wall), 1), "count_ms": round(ks["ms_count"], 3), "select_sort_ms": round(ks["ms_sort"], 3)},
+                           "instances_per_s": round(ks["instances"] / max(1e-9, t_kmer_wall), 1), "count_ms": round(ks["ms_count"], 3), "select_sort_ms": round(ks["ms_sort"], 3),
+                           "cpu_baseline_reference": kmer_ref},
             "phases_ms": {key: round(v, 4) for key, v in acc.items()},
             "tiers": {key: int(st[key]) for key in ("rows_lds", "rows_global", "rows_escalated", "nnz_before_prune", "passes") if key in st},
             "gen_s": round(t_gen, 2),
