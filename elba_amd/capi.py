@@ -74,7 +74,7 @@ class Csr(C.Structure):
 
 
 class KmerMatrix(C.Structure):
-    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("kmers", C.c_void_p), ("kmers_lo", C.c_void_p), ("colptr", C.c_void_p),
+    _fields_ = [("nrows", C.c_int64), ("ncols", C.c_int64), ("nnz", C.c_int64), ("kmers", C.c_void_p), ("kmers_lo", C.c_void_p), ("kmers_lo2", C.c_void_p), ("colptr", C.c_void_p),
                 ("csc_row", C.c_void_p), ("csc_val", C.c_void_p), ("rowptr", C.c_void_p), ("csr_col", C.c_void_p), ("csr_val", C.c_void_p)]
 
 
@@ -301,6 +301,7 @@ class Engine:
         try:
             return dict(M=o.nrows, N=o.ncols, Z=o.nnz, kmers=_copy(o.kmers, o.ncols, np.uint64) if o.kmers else None,
                         kmers_lo=_copy(o.kmers_lo, o.ncols, np.uint64) if o.kmers_lo else None,
+                        kmers_lo2=_copy(o.kmers_lo2, o.ncols, np.uint64) if o.kmers_lo2 else None,
                         colptr=_copy(o.colptr, o.ncols + 1, np.int64), csc_read=_copy(o.csc_row, o.nnz, np.int64), csc_pos=_copy(o.csc_val, o.nnz, np.uint32),
                         rowptr=_copy(o.rowptr, o.nrows + 1, np.int64), csr_kid=_copy(o.csr_col, o.nnz, np.int64), csr_pos=_copy(o.csr_val, o.nnz, np.uint32))
         finally:

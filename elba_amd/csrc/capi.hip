@@ -78,7 +78,7 @@ int elba_ctx_create(elba_ctx **out, const elba_cfg *cfg)
     // include/compiletime.h:10,21: k odd, 2 < k < 96, 0 < L <= U <= 65535.  Here: one 64-bit word per k-mer (k <= 31).
     if (cfg->k < 3 || !(cfg->k & 1) || cfg->k >= 96) return ELBA_ERR_INVALID_ARG;
     if (cfg->lower < 1 || cfg->lower > cfg->upper || cfg->upper > 65535) return ELBA_ERR_INVALID_ARG;
-    if (cfg->k > 63) return ELBA_ERR_UNSUPPORTED;        /* NLONGS <= 2 here (include/Kmer.hpp:95-97 goes to 3) */
+    /* 3 <= k <= 95, odd: the reference's range (include/compiletime.h:10); one, two or three words per k-mer */
     if (cfg->lower < 2) return ELBA_ERR_UNSUPPORTED;   // LOWER == 1 is nondeterministic in the reference
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return ELBA_ERR_NO_DEVICE;
@@ -362,6 +362,10 @@ int elba_export_kmer_matrix(elba_ctx *ctx, elba_kmer_matrix_t *out)
                 out->kmers_lo = host_alloc<uint64_t>(N);
                 if (N) ELBA_HIP(hipMemcpyAsync(out->kmers_lo, c.rel_kmers_lo.p, N * 8, hipMemcpyDeviceToHost, c.stream));
             }
+            if (c.cfg.k > 64) {
+                out->kmers_lo2 = host_alloc<uint64_t>(N);
+                if (N) ELBA_HIP(hipMemcpyAsync(out->kmers_lo2, c.rel_kmers_lo2.p, N * 8, hipMemcpyDeviceToHost, c.stream));
+            }
             ELBA_HIP(hipStreamSynchronize(c.stream));
         }
     });
@@ -370,7 +374,7 @@ int elba_export_kmer_matrix(elba_ctx *ctx, elba_kmer_matrix_t *out)
 void elba_free_kmer_matrix(elba_kmer_matrix_t *m)
 {
     if (!m) return;
-    free(m->kmers); free(m->kmers_lo); free(m->colptr); free(m->csc_row); free(m->csc_val); free(m->rowptr); free(m->csr_col); free(m->csr_val);
+    free(m->kmers); free(m->kmers_lo); free(m->kmers_lo2); free(m->colptr); free(m->csc_row); free(m->csc_val); free(m->rowptr); free(m->csr_col); free(m->csr_val);
     memset(m, 0, sizeof(*m));
 }
 

@@ -132,6 +132,7 @@ struct Ctx {
     int64_t tab_cap = 0;
     DevBuf rel_kmers;     // u64[N] reliable k-mers ascending (right-aligned value order == packed order)
     DevBuf rel_kmers_lo;  // u64[N] their second word when k > 32
+    DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
     elba_kmer_stats kstats{};
 

@@ -100,6 +100,24 @@ __device__ __forceinline__ void canonical2_at(const EnumParams &e, uint32_t r, u
     hi = twin ? th : fh; lo = twin ? tl : fl;
 }
 
+// Three-word k-mers, 64 < k <= 95 (NLONGS == 3): the same over 192 bits, four aligned loads (the k-mer spans >= 17 bytes).
+__device__ __forceinline__ void canonical3_at(const EnumParams &e, uint32_t r, uint32_t p, uint64_t &k0, uint64_t &k1, uint64_t &k2)
+{
+    const uint64_t b = e.byte_off[r] + (p >> 2);
+    const uint64_t a = b & ~7ull;
+    const uint64_t *w = reinterpret_cast<const uint64_t *>(e.packed + a);
+    const uint64_t w0 = __builtin_bswap64(w[0]), w1 = __builtin_bswap64(w[1]), w2 = __builtin_bswap64(w[2]), w3 = __builtin_bswap64(w[3]);
+    const uint32_t sh = (uint32_t)(b - a) * 8 + 2 * (p & 3);              // 0..62
+    const uint64_t f0 = sh ? ((w0 << sh) | (w1 >> (64 - sh))) : w0;
+    const uint64_t f1 = sh ? ((w1 << sh) | (w2 >> (64 - sh))) : w1;
+    const uint64_t f2 = (sh ? ((w2 << sh) | (w3 >> (64 - sh))) : w2) & (~0ull << (2 * (96 - e.k)));
+    const uint64_t r0 = rev2bit64(~f2), r1 = rev2bit64(~f1), r2 = rev2bit64(~f0);     // reversed order of the words
+    const uint32_t s2 = 2 * (96 - (uint32_t)e.k);                                      // 2..62
+    const uint64_t t0 = (r0 << s2) | (r1 >> (64 - s2)), t1 = (r1 << s2) | (r2 >> (64 - s2)), t2 = r2 << s2;
+    const bool twin = t0 != f0 ? t0 < f0 : (t1 != f1 ? t1 < f1 : t2 < f2);
+    k0 = twin ? t0 : f0; k1 = twin ? t1 : f1; k2 = twin ? t2 : f2;
+}
+
 // Calls f(instance index g, read r, pos p) for the EN_ITEMS instances of this lane; instances of a wave are consecutive, so the read
 // is found by ONE binary search per wave plus a short forward walk.
 template <class F>
@@ -261,6 +279,15 @@ __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit2(EnumParams e, uint64_
     });
 }
 
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit3(EnumParams e, uint64_t *k0, uint64_t *k1, uint64_t *k2, uint64_t *vals, uint64_t *idx)
+{
+    for_each_position(e, [&](uint64_t g, uint32_t r, uint32_t p) {
+        uint64_t a, b, c;
+        canonical3_at(e, r, p, a, b, c);
+        k0[g] = a; k1[g] = b; k2[g] = c; vals[g] = ((uint64_t)r << 32) | p; idx[g] = g;
+    });
+}
+
 __global__ void k_gather_u64(const uint64_t *idx, const uint64_t *in, uint64_t n, uint64_t *out)
 {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,11 +295,11 @@ __global__ void k_gather_u64(const uint64_t *idx, const uint64_t *in, uint64_t n
 }
 
 // flag[g] = 1 where a run of equal k-mers starts (flag[I] = 1 closes the last run); keys_lo: second word of two-word k-mers, or null
-__global__ void k_run_flags(const uint64_t *keys, const uint64_t *keys_lo, uint64_t I, uint32_t *flag)
+__global__ void k_run_flags(const uint64_t *keys, const uint64_t *keys_lo, const uint64_t *keys_lo2, uint64_t I, uint32_t *flag)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g > I) return;
-    flag[g] = (g == 0 || g == I || keys[g] != keys[g - 1] || (keys_lo && keys_lo[g] != keys_lo[g - 1])) ? 1u : 0u;
+    flag[g] = (g == 0 || g == I || keys[g] != keys[g - 1] || (keys_lo && keys_lo[g] != keys_lo[g - 1]) || (keys_lo2 && keys_lo2[g] != keys_lo2[g - 1])) ? 1u : 0u;
 }
 
 // headpos[run] = first instance of the run; headpos[nruns] = I
@@ -294,14 +321,15 @@ __global__ void k_run_select(const uint32_t *headpos, uint64_t nruns, uint32_t l
 }
 
 // reliable run -> column kid: k-mer value, count, column pointer, entries (already in (read, pos) order: the sort is stable)
-__global__ void k_emit_columns(const uint64_t *keys, const uint64_t *keys_lo, const uint64_t *vals, const uint32_t *headpos, const uint32_t *relflag, const uint32_t *kidx, const uint32_t *cptr,
-                               uint64_t nruns, uint64_t *rel_kmers, uint64_t *rel_kmers_lo, uint32_t *rel_counts, uint32_t *colptr, uint64_t *csc)
+__global__ void k_emit_columns(const uint64_t *keys, const uint64_t *keys_lo, const uint64_t *keys_lo2, const uint64_t *vals, const uint32_t *headpos, const uint32_t *relflag, const uint32_t *kidx, const uint32_t *cptr,
+                               uint64_t nruns, uint64_t *rel_kmers, uint64_t *rel_kmers_lo, uint64_t *rel_kmers_lo2, uint32_t *rel_counts, uint32_t *colptr, uint64_t *csc)
 {
     const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nruns || !relflag[u]) return;
     const uint32_t kid = kidx[u], h = headpos[u], c = headpos[u + 1] - h, at = cptr[u];
     rel_kmers[kid] = keys[h]; rel_counts[kid] = c; colptr[kid] = at;
     if (keys_lo) rel_kmers_lo[kid] = keys_lo[h];
+    if (keys_lo2) rel_kmers_lo2[kid] = keys_lo2[h];
     for (uint32_t t = 0; t < c; ++t) csc[at + t] = vals[h + t];
 }
 
@@ -332,14 +360,14 @@ EnumParams make_enum(Ctx &c)
 // Sorted (k-mer, value) pairs -> runs -> reliable columns: rel_kmers / rel_counts / a_colptr / a_csc of the context (see the file header).
 // spare_k / spare_v: the sort's other buffer pair (2 (I + 2) u32 each), free once the sort is done.  Needs c.ws_e (I + 2 u32) and c.ws_f (I + 2 u64).
 static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals, uint64_t *spare_k, uint64_t *spare_v, uint64_t I,
-                            uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out, const uint64_t *skeys_lo = nullptr)
+                            uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out, const uint64_t *skeys_lo = nullptr, const uint64_t *skeys_lo2 = nullptr)
 {
     hipStream_t s = c.stream;
     uint32_t *flag = c.ws_e.as<uint32_t>();
     uint32_t *runid = reinterpret_cast<uint32_t *>(spare_k);                        // [I + 1]
     uint32_t *headpos = c.ws_f.as<uint32_t>();                                      // [nruns + 1] <= I + 1
     const unsigned nbI = (unsigned)((I + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, skeys_lo, I, flag);
+    hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, skeys_lo, skeys_lo2, I, flag);
     exclusive_scan_u32(s, flag, runid, (int64_t)I + 1, c.ws_scan);
     uint32_t nruns32 = 0;
     ELBA_HIP(hipMemcpyAsync(&nruns32, runid + I, 4, hipMemcpyDeviceToHost, s));      // runs before the closing flag = distinct k-mers
@@ -364,13 +392,14 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
     ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
     c.rel_kmers.reserve((size_t)(N + 1) * 8);
     if (skeys_lo) c.rel_kmers_lo.reserve((size_t)(N + 1) * 8);
+    if (skeys_lo2) c.rel_kmers_lo2.reserve((size_t)(N + 1) * 8);
     c.rel_counts.reserve((size_t)(N + 2) * 4);
     c.a_colptr.reserve((size_t)(N + 2) * 4);
     c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
     if (nruns > 0)
-        hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, skeys_lo, svals, headpos, relflag, kidx, cptr, nruns,
-                           c.rel_kmers.as<uint64_t>(), skeys_lo ? c.rel_kmers_lo.as<uint64_t>() : (uint64_t *)nullptr, c.rel_counts.as<uint32_t>(),
-                           c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>());
+        hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, skeys_lo, skeys_lo2, svals, headpos, relflag, kidx, cptr, nruns,
+                           c.rel_kmers.as<uint64_t>(), skeys_lo ? c.rel_kmers_lo.as<uint64_t>() : (uint64_t *)nullptr,
+                           skeys_lo2 ? c.rel_kmers_lo2.as<uint64_t>() : (uint64_t *)nullptr, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>());
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
     ELBA_HIP(hipStreamSynchronize(s));
     nruns_out = nruns; N_out = N; Z_out = Z;
@@ -398,9 +427,11 @@ void stage_count_kmers(Ctx &c)
 
     c.kmers_sorted = !getenv("ELBA_KMER_HASH") || k > 31;
     if (k > 31) {
-        // ---- two-word k-mers: sort an index permutation, second word first (stable LSD over both words), then gather ----
-        DevBuf khi, klo, val, i0, i1, t0, t1;
+        // ---- two- and three-word k-mers: sort an index permutation, last word first (stable LSD over all words), then gather ----
+        const int words = k > 64 ? 3 : 2;
+        DevBuf khi, klo, klo2, val, i0, i1, t0, t1, s2buf;
         for (DevBuf *b : {&khi, &klo, &val, &i0, &i1, &t0, &t1}) b->reserve((size_t)(I + 2) * 8);
+        if (words == 3) { klo2.reserve((size_t)(I + 2) * 8); s2buf.reserve((size_t)(I + 2) * 8); }
         c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_b.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8);
         c.ws_e.reserve((size_t)(I + 2) * 4); c.ws_f.reserve((size_t)(I + 2) * 8);
         c.t_total.start(s);
@@ -408,24 +439,30 @@ void stage_count_kmers(Ctx &c)
         EnumParams e = make_enum(c);
         const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
         const unsigned nbI = (unsigned)((I + 255) / 256);
-        uint64_t *shi = c.ws_a.as<uint64_t>(), *slo = c.ws_b.as<uint64_t>(), *sval = c.ws_c.as<uint64_t>();
+        uint64_t *shi = c.ws_a.as<uint64_t>(), *slo = c.ws_b.as<uint64_t>(), *sval = c.ws_c.as<uint64_t>(), *slo2 = words == 3 ? s2buf.as<uint64_t>() : nullptr;
         if (I > 0) {
-            hipLaunchKernelGGL(k_kmer_emit2, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, khi.as<uint64_t>(), klo.as<uint64_t>(), val.as<uint64_t>(), i0.as<uint64_t>());
-            ELBA_HIP(hipMemcpyAsync(t0.p, klo.p, (size_t)I * 8, hipMemcpyDeviceToDevice, s));
-            int w = radix_sort_pairs(s, t0.as<uint64_t>(), i0.as<uint64_t>(), t1.as<uint64_t>(), i1.as<uint64_t>(), (int64_t)I, 64 - 2 * (k - 32), 64, c.ws_sort);
-            uint64_t *ia = w ? i1.as<uint64_t>() : i0.as<uint64_t>(), *ib = w ? i0.as<uint64_t>() : i1.as<uint64_t>();
-            uint64_t *ka = w ? t1.as<uint64_t>() : t0.as<uint64_t>(), *kb = w ? t0.as<uint64_t>() : t1.as<uint64_t>();
-            hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, ia, khi.as<uint64_t>(), I, ka);
-            int w2 = radix_sort_pairs(s, ka, ia, kb, ib, (int64_t)I, 0, 64, c.ws_sort);
-            const uint64_t *fin = w2 ? ib : ia;
+            if (words == 3) hipLaunchKernelGGL(k_kmer_emit3, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, khi.as<uint64_t>(), klo.as<uint64_t>(), klo2.as<uint64_t>(), val.as<uint64_t>(), i0.as<uint64_t>());
+            else hipLaunchKernelGGL(k_kmer_emit2, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, khi.as<uint64_t>(), klo.as<uint64_t>(), val.as<uint64_t>(), i0.as<uint64_t>());
+            uint64_t *ia = i0.as<uint64_t>(), *ib = i1.as<uint64_t>(), *ka = t0.as<uint64_t>(), *kb = t1.as<uint64_t>();
+            const uint64_t *wordsrc[3] = {khi.as<uint64_t>(), klo.as<uint64_t>(), words == 3 ? klo2.as<uint64_t>() : nullptr};
+            for (int wd = words - 1; wd >= 0; --wd) {
+                // keys of this pass = word wd in the current order
+                if (wd == words - 1) ELBA_HIP(hipMemcpyAsync(ka, wordsrc[wd], (size_t)I * 8, hipMemcpyDeviceToDevice, s));
+                else hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, ia, wordsrc[wd], I, ka);
+                const int lo_bit = wd == words - 1 ? 64 - 2 * (k - 32 * (words - 1)) : 0;
+                const int w = radix_sort_pairs(s, ka, ia, kb, ib, (int64_t)I, lo_bit, 64, c.ws_sort);
+                if (w) { uint64_t *t; t = ia; ia = ib; ib = t; t = ka; ka = kb; kb = t; }
+            }
+            const uint64_t *fin = ia;
             hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, fin, khi.as<uint64_t>(), I, shi);
             hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, fin, klo.as<uint64_t>(), I, slo);
+            if (words == 3) hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, fin, klo2.as<uint64_t>(), I, slo2);
             hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, fin, val.as<uint64_t>(), I, sval);
         }
         c.t_a.stop(s);
         c.t_b.start(s);
         uint64_t nruns = 0, N = 0, Z = 0;
-        runs_to_columns(c, shi, sval, t0.as<uint64_t>(), t1.as<uint64_t>(), I, nruns, N, Z, slo);
+        runs_to_columns(c, shi, sval, t0.as<uint64_t>(), t1.as<uint64_t>(), I, nruns, N, Z, slo, slo2);
         c.t_b.stop(s);
         c.t_total.stop(s);
         ELBA_HIP(hipStreamSynchronize(s));

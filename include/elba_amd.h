@@ -99,7 +99,7 @@ typedef struct {
 } elba_overlaps_t;
 
 typedef struct {
-    int32_t k;          /* KMER_SIZE: odd, 3..63 here (one or two 64-bit words per k-mer; reference: compile-time, Makefile:1).  The multi-GPU
+    int32_t k;          /* KMER_SIZE: odd, 3..95 as in the reference (one to three 64-bit words per k-mer; reference: compile-time, Makefile:1).  The multi-GPU
                            exchange (elba_dist_*) carries one-word k-mers: k <= 31 */
     int32_t lower;      /* LOWER_KMER_FREQ >= 2 (SURVEY.md App. A.4 precondition)            */
     int32_t upper;      /* UPPER_KMER_FREQ <= 65535                                          */
@@ -169,7 +169,8 @@ typedef struct {
 typedef struct {
     int64_t nrows, ncols, nnz;
     uint64_t *kmers;       /* [ncols] packed canonical k-mer of each column (NULL if A came from elba_set_kmer_matrix); first word */
-    uint64_t *kmers_lo;    /* [ncols] second word (bases 32..k-1, left-aligned) when k > 32, else NULL */
+    uint64_t *kmers_lo;    /* [ncols] second word (bases 32..63, left-aligned) when k > 32, else NULL */
+    uint64_t *kmers_lo2;   /* [ncols] third word (bases 64..k-1) when k > 64, else NULL */
     int64_t *colptr;       /* [ncols+1] */
     int64_t *csc_row;      /* [nnz] read id, within a column ordered by (read, pos) */
     uint32_t *csc_val;     /* [nnz] position */

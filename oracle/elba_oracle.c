@@ -114,6 +114,21 @@ uint64_t orc_kmer_rep(uint64_t w, int k)
 
 /* Two-word k-mers, 32 < k <= 64 (NLONGS == 2, include/Kmer.hpp:95-97): base i at bits 2*(31 - i%32) of longs[i/32]; twin and rep
  * as above over 128 bits; rep compares longs[0] first (src/Kmer.cpp:118-131).  Built base by base: the oracle favours the obvious. */
+/* General form, NLONGS = ceil(k / 32) <= 3 words (k < 96, include/compiletime.h:10): out[0..nl-1], unused words zero. */
+void orc_kmerN_at(const uint8_t *mem, size_t pos, int k, uint64_t out[3])
+{
+    uint64_t f[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+    for (int i = 0; i < k; ++i) {
+        const uint64_t b = (uint64_t)((mem[(pos + (size_t)i) / 4] >> (6 - 2 * ((pos + (size_t)i) % 4))) & 3);
+        f[i / 32] |= b << (2 * (31 - i % 32));
+        const int j = k - 1 - i;
+        t[j / 32] |= (3 - b) << (2 * (31 - j % 32));
+    }
+    int twin_smaller = 0;
+    for (int w = 0; w < 3; ++w) { if (t[w] != f[w]) { twin_smaller = t[w] < f[w]; break; } }
+    for (int w = 0; w < 3; ++w) out[w] = twin_smaller ? t[w] : f[w];
+}
+
 void orc_kmer2_at(const uint8_t *mem, size_t pos, int k, uint64_t out[2])
 {
     uint64_t f[2] = {0, 0}, t[2] = {0, 0};
@@ -211,6 +226,7 @@ typedef struct {
     int64_t ndistinct;         /* distinct canonical k-mers */
     uint64_t *kmers;           /* [N] packed canonical k-mer values, ascending == k-mer id order */
     uint64_t *kmers_lo;        /* [N] second word of the k-mers when k > 32 (NULL otherwise) */
+    uint64_t *kmers_lo2;       /* [N] third word when k > 64 */
     int64_t *colptr;           /* [N+1] */
     uint32_t *csc_read;        /* [Z] local read index, within column sorted by (read,pos) */
     uint32_t *csc_pos;         /* [Z] */
@@ -227,7 +243,7 @@ typedef struct {
 
 orc_ctx *orc_create(int k, int lower, int upper)
 {
-    if (k < 3 || k > 64 || !(k & 1) || lower < 1 || lower > upper || upper > 65535) return NULL;  /* include/compiletime.h:10,21; NLONGS <= 2 here */
+    if (k < 3 || k > 95 || !(k & 1) || lower < 1 || lower > upper || upper > 65535) return NULL;  /* include/compiletime.h:10,21 */
     orc_ctx *c = (orc_ctx *)calloc(1, sizeof(orc_ctx));
     c->k = k; c->lower = lower; c->upper = upper;
     return c;
@@ -235,9 +251,9 @@ orc_ctx *orc_create(int k, int lower, int upper)
 
 static void orc_free_A(orc_ctx *c)
 {
-    free(c->kmers); free(c->kmers_lo); free(c->colptr); free(c->csc_read); free(c->csc_pos);
+    free(c->kmers); free(c->kmers_lo); free(c->kmers_lo2); free(c->colptr); free(c->csc_read); free(c->csc_pos);
     free(c->rowptr); free(c->csr_kid); free(c->csr_pos); free(c->hist);
-    c->kmers = NULL; c->kmers_lo = NULL; c->colptr = NULL; c->csc_read = c->csc_pos = NULL; c->rowptr = NULL; c->csr_kid = c->csr_pos = NULL; c->hist = NULL;
+    c->kmers = NULL; c->kmers_lo = NULL; c->kmers_lo2 = NULL; c->colptr = NULL; c->csc_read = c->csc_pos = NULL; c->rowptr = NULL; c->csr_kid = c->csr_pos = NULL; c->hist = NULL;
 }
 static void orc_free_B(orc_ctx *c)
 {
@@ -262,7 +278,7 @@ int64_t orc_read_kmers(const uint8_t *mem, uint32_t len, int k, uint64_t *out)
     return n;
 }
 
-typedef struct { uint64_t kmer, kmer2; uint32_t read, pos; } orc_inst_t;      /* kmer2: second word when k > 32, else 0 */
+typedef struct { uint64_t kmer, kmer2, kmer3; uint32_t read, pos; } orc_inst_t;      /* kmer2 / kmer3: second / third word when k > 32 / 64, else 0 */
 
 /* stable LSD radix sort of instances by the k-mer value (11-bit digits): the bits of the second word first (k > 32), then the first word's */
 static int orc_sort_word(orc_inst_t **pa, orc_inst_t **ptmp, int64_t n, int word, int shift0, int bits)
@@ -272,9 +288,11 @@ static int orc_sort_word(orc_inst_t **pa, orc_inst_t **ptmp, int64_t n, int word
     for (int lo = 0; lo < bits; lo += 11, ++passes) {
         int64_t cnt[2049];
         memset(cnt, 0, sizeof(cnt));
-        for (int64_t i = 0; i < n; ++i) cnt[((((word ? a[i].kmer2 : a[i].kmer) >> shift0) >> lo) & 2047) + 1]++;
+#define ORC_WORD(x) (word == 0 ? (x).kmer : (word == 1 ? (x).kmer2 : (x).kmer3))
+        for (int64_t i = 0; i < n; ++i) cnt[(((ORC_WORD(a[i]) >> shift0) >> lo) & 2047) + 1]++;
         for (int d = 0; d < 2048; ++d) cnt[d + 1] += cnt[d];
-        for (int64_t i = 0; i < n; ++i) tmp[cnt[(((word ? a[i].kmer2 : a[i].kmer) >> shift0) >> lo) & 2047]++] = a[i];
+        for (int64_t i = 0; i < n; ++i) tmp[cnt[((ORC_WORD(a[i]) >> shift0) >> lo) & 2047]++] = a[i];
+#undef ORC_WORD
         orc_inst_t *t = a; a = tmp; tmp = t;
     }
     *pa = a; *ptmp = tmp;
@@ -283,7 +301,8 @@ static int orc_sort_word(orc_inst_t **pa, orc_inst_t **ptmp, int64_t n, int word
 /* returns the buffer that holds the sorted instances */
 static orc_inst_t *orc_sort_instances(orc_inst_t *a, orc_inst_t *tmp, int64_t n, int k)
 {
-    if (k > 32) { orc_sort_word(&a, &tmp, n, 1, 64 - 2 * (k - 32), 2 * (k - 32)); orc_sort_word(&a, &tmp, n, 0, 0, 64); }
+    if (k > 64) { orc_sort_word(&a, &tmp, n, 2, 64 - 2 * (k - 64), 2 * (k - 64)); orc_sort_word(&a, &tmp, n, 1, 0, 64); orc_sort_word(&a, &tmp, n, 0, 0, 64); }
+    else if (k > 32) { orc_sort_word(&a, &tmp, n, 1, 64 - 2 * (k - 32), 2 * (k - 32)); orc_sort_word(&a, &tmp, n, 0, 0, 64); }
     else orc_sort_word(&a, &tmp, n, 0, 64 - 2 * k, 2 * k);
     return a;
 }
@@ -313,10 +332,10 @@ int orc_count_and_build(orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off
     for (int64_t r = 0; r < nreads; ++r) {
         if (k > 32) {
             const int64_t n = (int64_t)lens[r] >= k ? (int64_t)lens[r] - k + 1 : 0;
-            for (int64_t p = 0; p < n; ++p) { uint64_t w[2]; orc_kmer2_at(buf + byte_off[r], (size_t)p, k, w); a[z].kmer = w[0]; a[z].kmer2 = w[1]; a[z].read = (uint32_t)r; a[z].pos = (uint32_t)p; ++z; }
+            for (int64_t p = 0; p < n; ++p) { uint64_t w[3]; orc_kmerN_at(buf + byte_off[r], (size_t)p, k, w); a[z].kmer = w[0]; a[z].kmer2 = w[1]; a[z].kmer3 = w[2]; a[z].read = (uint32_t)r; a[z].pos = (uint32_t)p; ++z; }
         } else {
             int64_t n = orc_read_kmers(buf + byte_off[r], lens[r], k, scratch);
-            for (int64_t p = 0; p < n; ++p) { a[z].kmer = scratch[p]; a[z].kmer2 = 0; a[z].read = (uint32_t)r; a[z].pos = (uint32_t)p; ++z; }
+            for (int64_t p = 0; p < n; ++p) { a[z].kmer = scratch[p]; a[z].kmer2 = 0; a[z].kmer3 = 0; a[z].read = (uint32_t)r; a[z].pos = (uint32_t)p; ++z; }
         }
     }
     free(scratch);
@@ -327,7 +346,7 @@ int orc_count_and_build(orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off
     c->hist = (int64_t *)calloc((size_t)c->upper + 2, sizeof(int64_t));
     for (int64_t i = 0; i < I; ) {
         int64_t j = i + 1;
-        while (j < I && s[j].kmer == s[i].kmer && s[j].kmer2 == s[i].kmer2) ++j;
+        while (j < I && s[j].kmer == s[i].kmer && s[j].kmer2 == s[i].kmer2 && s[j].kmer3 == s[i].kmer3) ++j;
         int64_t cnt = j - i;
         ++nd;
         if (cnt >= c->lower && cnt <= c->upper) { ++N; Z += cnt; c->hist[cnt]++; }
@@ -336,6 +355,7 @@ int orc_count_and_build(orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off
     c->N = N; c->Z = Z; c->ndistinct = nd;
     c->kmers = (uint64_t *)malloc((size_t)(N + 1) * sizeof(uint64_t));
     c->kmers_lo = k > 32 ? (uint64_t *)malloc((size_t)(N + 1) * sizeof(uint64_t)) : NULL;
+    c->kmers_lo2 = k > 64 ? (uint64_t *)malloc((size_t)(N + 1) * sizeof(uint64_t)) : NULL;
     c->colptr = (int64_t *)malloc((size_t)(N + 1) * sizeof(int64_t));
     c->csc_read = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
     c->csc_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
@@ -345,11 +365,12 @@ int orc_count_and_build(orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off
     int64_t kid = 0, e = 0;
     for (int64_t i = 0; i < I; ) {
         int64_t j = i + 1;
-        while (j < I && s[j].kmer == s[i].kmer && s[j].kmer2 == s[i].kmer2) ++j;
+        while (j < I && s[j].kmer == s[i].kmer && s[j].kmer2 == s[i].kmer2 && s[j].kmer3 == s[i].kmer3) ++j;
         int64_t cnt = j - i;
         if (cnt >= c->lower && cnt <= c->upper) {
             c->kmers[kid] = s[i].kmer;
             if (c->kmers_lo) c->kmers_lo[kid] = s[i].kmer2;
+            if (c->kmers_lo2) c->kmers_lo2[kid] = s[i].kmer3;
             c->colptr[kid] = e;
             for (int64_t t = i; t < j; ++t) { c->csc_read[e] = s[t].read; c->csc_pos[e] = s[t].pos; c->rowptr[s[t].read + 1]++; ++e; }
             ++kid;
@@ -392,7 +413,7 @@ int orc_set_triples(orc_ctx *c, int64_t M, int64_t N, int64_t Z, const int64_t *
         t[3 * i] = cols[i]; t[3 * i + 1] = rows[i]; t[3 * i + 2] = vals[i];
     }
     qsort(t, (size_t)Z, 3 * sizeof(int64_t), orc_cmp_csc);
-    c->kmers = NULL; c->kmers_lo = NULL;
+    c->kmers = NULL; c->kmers_lo = NULL; c->kmers_lo2 = NULL;
     c->colptr = (int64_t *)calloc((size_t)(N + 2), sizeof(int64_t));
     c->csc_read = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
     c->csc_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
@@ -538,7 +559,7 @@ void orc_free_ptr(void *p) { free(p); }
 int orc_seed_is_valid(const uint8_t *qmem, uint32_t qlen, const uint8_t *tmem, uint32_t tlen, uint32_t q, uint32_t t, int k)
 {
     if ((int64_t)q + k > (int64_t)qlen || (int64_t)t + k > (int64_t)tlen) return 0;
-    if (k > 32) { uint64_t x[2], y[2]; orc_kmer2_at(qmem, q, k, x); orc_kmer2_at(tmem, t, k, y); return x[0] == y[0] && x[1] == y[1]; }   /* same canonical k-mer */
+    if (k > 32) { uint64_t x[3], y[3]; orc_kmerN_at(qmem, q, k, x); orc_kmerN_at(tmem, t, k, y); return x[0] == y[0] && x[1] == y[1] && x[2] == y[2]; }   /* same canonical k-mer */
     uint64_t a = 0, b = 0;
     for (int i = 0; i < k; ++i) { a |= (uint64_t)orc_base_at(qmem, q + (size_t)i) << (2 * (31 - i)); b |= (uint64_t)orc_base_at(tmem, t + (size_t)i) << (2 * (31 - i)); }
     return a == b || a == orc_kmer_twin(b, k);
@@ -748,7 +769,7 @@ const void *orc_get_ptr(const orc_ctx *c, int what)
     switch (what) {
     case 0: return c->kmers; case 1: return c->colptr; case 2: return c->csc_read; case 3: return c->csc_pos;
     case 4: return c->rowptr; case 5: return c->csr_kid; case 6: return c->csr_pos; case 7: return c->hist;
-    case 8: return c->b_rowptr; case 9: return c->b_col; case 10: return c->b_val; case 11: return c->kmers_lo;
+    case 8: return c->b_rowptr; case 9: return c->b_col; case 10: return c->b_val; case 11: return c->kmers_lo; case 12: return c->kmers_lo2;
     default: return NULL;
     }
 }

@@ -53,6 +53,8 @@ def lib():
         L.orc_murmur3_x64_128.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.orc_kmer_owner.restype = C.c_int
         L.orc_kmer_owner.argtypes = [C.c_uint64, C.c_int]
+        L.orc_kmerN_at.restype = None
+        L.orc_kmerN_at.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.orc_kmer2_at.restype = None
         L.orc_kmer2_at.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.orc_read_kmers.restype = C.c_int64
@@ -161,7 +163,7 @@ class Oracle:
         M, N, Z = self.stat("M"), self.stat("N"), self.stat("Z")
         g = lambda w, n, dt: _arr(self.L.orc_get_ptr(self.h, w), n, dt)
         return dict(M=M, N=N, Z=Z,
-                    kmers=g(0, N, np.uint64), kmers_lo=(g(11, N, np.uint64) if self.k > 32 else None), colptr=g(1, N + 1, np.int64), csc_read=g(2, Z, np.uint32), csc_pos=g(3, Z, np.uint32),
+                    kmers=g(0, N, np.uint64), kmers_lo=(g(11, N, np.uint64) if self.k > 32 else None), kmers_lo2=(g(12, N, np.uint64) if self.k > 64 else None), colptr=g(1, N + 1, np.int64), csc_read=g(2, Z, np.uint32), csc_pos=g(3, Z, np.uint32),
                     rowptr=g(4, M + 1, np.int64), csr_kid=g(5, Z, np.uint32), csr_pos=g(6, Z, np.uint32),
                     hist=g(7, self.upper + 2, np.int64))
 

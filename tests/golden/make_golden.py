@@ -190,26 +190,28 @@ def xdrop_vectors(name, k, lower, upper, rng):
 def read_kmer_vectors2(k, rng):
     """Canonical k-mers of whole reads for 32 < k <= 64 (NLONGS == 2): both words of every k-mer, from the reference's Kmer<2>::GetRepKmers."""
     R = po.ref_lib(k)
-    assert R.ref_kmer_nlongs() == 2
+    nl = R.ref_kmer_nlongs()
+    assert nl == (k + 31) // 32 and nl in (2, 3)
     rows = []
-    for ln in (k - 1, k, k + 1, k + 2, k + 3, k + 4, 2 * k + 5, 3 * k, 200):
+    for ln in (k - 1, k, k + 1, k + 2, k + 3, k + 4, 2 * k + 5, 3 * k, 200 if k < 64 else 320):
         s = bytes(rng.choice(list(b"ACGT"), ln).tolist())
-        if ln == 200:
-            s = s[:60] + bytes(reversed(s[:60].translate(bytes.maketrans(b"ACGT", b"TGCA")))) + s[120:]     # a reverse-complement repeat: twin == forward cases nearby
+        if ln in (200, 320):
+            h = ln * 3 // 10
+            s = s[:h] + bytes(reversed(s[:h].translate(bytes.maketrans(b"ACGT", b"TGCA")))) + s[2 * h:]     # a reverse-complement repeat: twin == forward cases nearby
         mem = np.zeros((ln + 3) // 4 + 8, dtype=np.uint8)
         R.ref_encode(s, ln, mem.ctypes.data)
-        out = np.zeros(2 * max(1, ln), dtype=np.uint64)
+        out = np.zeros(nl * max(1, ln), dtype=np.uint64)
         n = R.ref_kmers(mem.ctypes.data, ln, out.ctypes.data, 1)
-        rows.append("%s %s" % (s.decode(), ",".join("%016x:%016x" % (out[2 * i], out[2 * i + 1]) for i in range(n)) or "-"))
+        rows.append("%s %s" % (s.decode(), ",".join(":".join("%016x" % out[nl * i + w] for w in range(nl)) for i in range(n)) or "-"))
     with open(os.path.join(HERE, "read_kmers2_k%d.txt" % k), "w") as fo:
-        fo.write("# ascii_read canonical_kmers_hex (longs[0]:longs[1])   [reference Kmer<2>::GetRepKmers, KMER_SIZE=%d]\n" % k)
+        fo.write("# ascii_read canonical_kmers_hex (longs[0]:longs[1][:longs[2]])   [reference Kmer<%d>::GetRepKmers, KMER_SIZE=%d]\n" % (nl, k))
         fo.write("\n".join(rows) + "\n")
 
 
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "kmers2":         # only the two-word k-mer vectors
         rng = np.random.default_rng(20261005)
-        read_kmer_vectors2(33, rng); read_kmer_vectors2(63, rng)
+        read_kmer_vectors2(33, rng); read_kmer_vectors2(63, rng); read_kmer_vectors2(65, rng); read_kmer_vectors2(95, rng)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "xdrop":          # only the x-drop vectors (the other fixtures stay as committed)
         assert po.ref_lib(17) is not None, "run `make -C oracle ref` first"

@@ -18,6 +18,8 @@ def assert_A_equal(gA, oA):
         assert (gA["kmers"] == oA["kmers"]).all()
         if oA.get("kmers_lo") is not None:
             assert gA.get("kmers_lo") is not None and (gA["kmers_lo"] == oA["kmers_lo"]).all()
+        if oA.get("kmers_lo2") is not None:
+            assert gA.get("kmers_lo2") is not None and (gA["kmers_lo2"] == oA["kmers_lo2"]).all()
     assert (gA["colptr"] == oA["colptr"]).all()
     assert (gA["csc_read"] == oA["csc_read"].astype(np.int64)).all()
     assert (gA["csc_pos"] == oA["csc_pos"]).all()

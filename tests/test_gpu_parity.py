@@ -256,13 +256,13 @@ def test_pattern_and_counts_do_not_depend_on_kmer_id_order():
     e.close()
 
 
-@pytest.mark.parametrize("k,lo,up", [(33, 2, 12), (45, 2, 12), (63, 2, 12)])
+@pytest.mark.parametrize("k,lo,up", [(33, 2, 12), (45, 2, 12), (63, 2, 12), (65, 2, 12), (77, 2, 12), (95, 2, 12)])
 def test_two_word_kmers_full_pipeline(k, lo, up):
     """32 < k <= 63 (NLONGS == 2 in the reference, include/Kmer.hpp:95-97): reads -> A -> B equal the oracle's, whose two-word k-mers are
     pinned to the reference's Kmer<2>::GetRepKmers (tests/test_oracle_golden.py).  Reads around byte and word boundaries included."""
     rng = np.random.default_rng(k)
     seqs = util.read_fasta(os.path.join(G, "small_clean.fa")) + util.read_fasta(os.path.join(G, "small_err.fa"))
-    seqs += [bytes(rng.choice(list(b"ACGT"), n).tolist()) for n in (k - 1, k, k + 1, k + 2, k + 3, 64, 65, 127, 128, 129)]
+    seqs += [bytes(rng.choice(list(b"ACGT"), n).tolist()) for n in (k - 1, k, k + 1, k + 2, k + 3, 64, 65, 96, 97, 127, 128, 129)]
     packed, off, lens = po.pack_reads(seqs)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up)
     o = gu.oracle_run(packed, off, lens, k, lo, up)

@@ -241,9 +241,9 @@ def test_live_against_reference_primitives():
                 assert R.ref_kmer_hash(C.byref(x)) == L.orc_kmer_hash(w)
 
 
-@pytest.mark.parametrize("k", [33, 63])
+@pytest.mark.parametrize("k", [33, 63, 65, 95])
 def test_two_word_kmers_match_reference_vectors(k):
-    """32 < k <= 64 (NLONGS == 2): every canonical k-mer of the sample reads, both words, against the reference's Kmer<2>::GetRepKmers."""
+    """32 < k < 96 (NLONGS == 2 and 3): every canonical k-mer of the sample reads, every word, against the reference's Kmer<N>::GetRepKmers."""
     L = po.lib()
     n_checked = 0
     for line in open(os.path.join(G, "read_kmers2_k%d.txt" % k)):
@@ -254,9 +254,13 @@ def test_two_word_kmers_match_reference_vectors(k):
         want = [] if ks == "-" else [tuple(int(x, 16) for x in t.split(":")) for t in ks.split(",")]
         assert len(want) == max(0, len(s) - k + 1)
         for p_, w in enumerate(want):
-            out = np.zeros(2, dtype=np.uint64)
-            L.orc_kmer2_at(buf.ctypes.data, p_, k, out.ctypes.data)
-            assert (int(out[0]), int(out[1])) == w, (s, p_)
+            out = np.zeros(3, dtype=np.uint64)
+            L.orc_kmerN_at(buf.ctypes.data, p_, k, out.ctypes.data)
+            assert tuple(int(x) for x in out[:len(w)]) == w and all(int(x) == 0 for x in out[len(w):]), (s, p_)
+            if k <= 64:
+                o2 = np.zeros(2, dtype=np.uint64)
+                L.orc_kmer2_at(buf.ctypes.data, p_, k, o2.ctypes.data)
+                assert (int(o2[0]), int(o2[1])) == w
             n_checked += 1
     assert n_checked > 200
 
