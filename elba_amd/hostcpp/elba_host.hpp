@@ -11,6 +11,8 @@
 //   AT = *A; AT->Transpose()            src/main.cpp:272-273          KmerMatrix copy + Transpose(): no work, both orientations exist
 //   SharedSeeds          include/SharedSeeds.hpp:8-96                 elba::SharedSeeds (same members and accessors)
 //   create_seed_matrix   include/SharedSeeds.hpp:98-99                same name -> elba::SeedMatrix
+//   FastaIndex           include/FastaIndex.hpp, src/FastaIndex.cpp          same name: .fai records, base-balanced partition, chunk bounds;
+//                                                                             the reads are 2-bit encoded on the GPU (elba_set_reads_fasta)
 //   PairwiseAlignment    include/PairwiseAlignment.hpp, src/PairwiseAlignment.cpp:5-106     same name -> elba::OverlapMatrix (triples of elba::Overlap)
 //   Bmat.seqptr()->getnnz() / GetDCSC()  src/PairwiseAlignment.cpp:16-19   SeedMatrix::seqptr()->getnnz() / GetDCSC()
 //
@@ -19,7 +21,9 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <fstream>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -83,6 +87,74 @@ private:
     std::vector<uint8_t> buf_;
     std::vector<uint64_t> off_;
     std::vector<uint32_t> len_;
+};
+
+// include/FastaIndex.hpp — the host side of the ingest: the .fai next to the FASTA (`name len pos bases [width]`, src/FastaIndex.cpp:15-23), the
+// greedy base-balanced contiguous partition (:47-94: a rank takes reads while the next one keeps it under total / nprocs, the last rank
+// the rest) and the bytes of the file a rank needs (:222-224).  What getmydna does after reading that chunk — stripping line ends and
+// DnaSeq::compress — runs on the GPU instead: get_kmer_count_map_keys(index, ...) below hands the raw chunk to elba_set_reads_fasta.
+class FastaIndex {
+public:
+    typedef elba_fasta_record_t Record;                       // {len, pos, bases}: FastaIndex::Record, include/FastaIndex.hpp:10
+    FastaIndex(const std::string &fasta_fname, std::shared_ptr<Grid> commgrid) : commgrid(commgrid), fasta_fname(fasta_fname)
+    {
+        std::ifstream in(get_faidx_fname());
+        if (!in) throw Error(ELBA_ERR_INVALID_ARG, "cannot open " + get_faidx_fname());
+        std::string line, name;
+        while (std::getline(in, line)) {
+            std::istringstream ls(line);
+            Record r{};
+            if (!(ls >> name >> r.len >> r.pos >> r.bases)) continue;      // get_faidx_record, src/FastaIndex.cpp:15-23
+            rootrecords.push_back(r); rootnames.push_back(name);
+        }
+        const int nprocs = commgrid->GetSize();
+        size_t totbases = 0;
+        for (auto &r : rootrecords) totbases += r.len;
+        const double avg = (double)totbases / nprocs;
+        readdispls.assign((size_t)nprocs + 1, 0);
+        size_t at = 0;
+        for (int i = 0; i < nprocs - 1; ++i) {                               // getpartition, src/FastaIndex.cpp:47-94
+            size_t sofar = 0;
+            while (at < rootrecords.size() && sofar + rootrecords[at].len < avg) sofar += rootrecords[at++].len;
+            readdispls[(size_t)i + 1] = at;
+        }
+        readdispls[(size_t)nprocs] = rootrecords.size();
+        const size_t lo = readdispls[(size_t)commgrid->GetRank()], hi = readdispls[(size_t)commgrid->GetRank() + 1];
+        myrecords.assign(rootrecords.begin() + (std::ptrdiff_t)lo, rootrecords.begin() + (std::ptrdiff_t)hi);
+    }
+    std::string get_fasta_fname() const { return fasta_fname; }
+    std::string get_faidx_fname() const { return fasta_fname + ".fai"; }
+    size_t gettotrecords() const { return rootrecords.size(); }
+    size_t getmyreadcount() const { return myrecords.size(); }
+    size_t getmyreaddispl() const { return readdispls[(size_t)commgrid->GetRank()]; }
+    const std::vector<Record> &getmyrecords() const { return myrecords; }
+    const std::vector<size_t> &getreaddispls() const { return readdispls; }
+    const std::vector<std::string> &getnames() const { return rootnames; }
+    std::shared_ptr<Grid> getcommgrid() const { return commgrid; }
+    // the raw bytes of the file that hold this rank's records, and the file offset of the first one (src/FastaIndex.cpp:222-241)
+    std::vector<char> readmychunk(uint64_t &startpos) const
+    {
+        std::vector<char> buf;
+        startpos = 0;
+        if (myrecords.empty()) return buf;
+        std::ifstream in(fasta_fname, std::ios::binary | std::ios::ate);
+        if (!in) throw Error(ELBA_ERR_INVALID_ARG, "cannot open " + fasta_fname);
+        const uint64_t filesize = (uint64_t)in.tellg();
+        startpos = myrecords.front().pos;
+        uint64_t endpos = myrecords.back().pos + myrecords.back().len + myrecords.back().len / myrecords.back().bases;
+        if (endpos > filesize) endpos = filesize;
+        buf.resize((size_t)(endpos - startpos));
+        in.seekg((std::streamoff)startpos);
+        in.read(buf.data(), (std::streamsize)buf.size());
+        return buf;
+    }
+
+private:
+    std::shared_ptr<Grid> commgrid;
+    std::vector<Record> myrecords, rootrecords;
+    std::vector<size_t> readdispls;
+    std::vector<std::string> rootnames;
+    std::string fasta_fname;
 };
 
 // include/SharedSeeds.hpp:8-96 — same members, constructors and accessors (the Semiring runs on the GPU).
@@ -193,6 +265,26 @@ inline std::unique_ptr<KmerCountMap> get_kmer_count_map_keys(const DnaBuffer &my
     map->engine = std::make_shared<detail::Engine>(cfg);
     map->engine->check(elba_set_reads(map->engine->ctx, myreads.data(), myreads.offsets(), myreads.lengths(), (int64_t)myreads.size(), 0));
     // both passes of the reference (keys: src/KmerOps.cpp:18-204, values: :206-350) are one exact count on the GPU
+    map->engine->check(elba_count_kmers(map->engine->ctx, &map->stats));
+    return map;
+}
+
+// The same entry point for a caller that has not parsed its reads yet: the rank's chunk of the FASTA goes to the GPU as it is in the file.
+// index.getmydna()'s result can still be had from the context (elba_export_reads) — e.g. for the lengths PairwiseAlignment needs: `reads` is
+// filled with them here (the mirror's DnaBuffer keeps lengths and offsets; the packed bytes are fetched only on demand).
+inline std::unique_ptr<KmerCountMap> get_kmer_count_map_keys(const FastaIndex &index, std::shared_ptr<Grid> grid, const Params &prm, elba_ingest_stats *ingest = nullptr)
+{
+    if (grid->GetSize() != 1) throw Error(ELBA_ERR_UNSUPPORTED, "the C++ mirror drives one GPU; multi-GPU runs go through the elba_dist_* entry points");
+    elba_cfg cfg{};
+    cfg.k = prm.kmer_size; cfg.lower = prm.lower_kmer_freq; cfg.upper = prm.upper_kmer_freq; cfg.device = grid->device;
+    auto map = std::make_unique<KmerCountMap>();
+    map->engine = std::make_shared<detail::Engine>(cfg);
+    uint64_t startpos = 0;
+    const std::vector<char> chunk = index.readmychunk(startpos);
+    elba_ingest_stats is{};
+    map->engine->check(elba_set_reads_fasta(map->engine->ctx, chunk.data(), (int64_t)chunk.size(), startpos, index.getmyrecords().data(),
+                                            (int64_t)index.getmyreadcount(), (int64_t)index.getmyreaddispl(), &is));
+    if (ingest) *ingest = is;
     map->engine->check(elba_count_kmers(map->engine->ctx, &map->stats));
     return map;
 }

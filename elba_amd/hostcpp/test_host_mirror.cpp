@@ -9,7 +9,8 @@
 
 int main(int argc, char **argv)
 {
-    if (argc < 5) { std::fprintf(stderr, "usage: %s reads.fa K LOWER UPPER\n", argv[0]); return 2; }
+    if (argc < 5) { std::fprintf(stderr, "usage: %s reads.fa K LOWER UPPER [fai]   (fai: reads.fa.fai exists; ingest through FastaIndex + the GPU encoder)\n", argv[0]); return 2; }
+    const bool use_fai = argc > 5 && std::string(argv[5]) == "fai";
     elba::Params prm;
     prm.kmer_size = std::atoi(argv[2]); prm.lower_kmer_freq = std::atoi(argv[3]); prm.upper_kmer_freq = std::atoi(argv[4]);
     std::ifstream in(argv[1]);
@@ -26,7 +27,20 @@ int main(int argc, char **argv)
     for (auto &s : seqs) mydna.push_back(s.c_str(), s.size());
     auto commgrid = std::make_shared<elba::Grid>();
     try {
-        auto kmermap = elba::get_kmer_count_map_keys(mydna, commgrid, prm);                 // main.cpp:192
+        int ingest_equal = -1;
+        std::unique_ptr<elba::KmerCountMap> kmermap;
+        if (use_fai) {
+            // main.cpp:157-176: FastaIndex index(fasta_fname, commgrid); DnaBuffer mydna = index.getmydna(); — the encoding happens on the GPU here
+            elba::FastaIndex index(argv[1], commgrid);
+            kmermap = elba::get_kmer_count_map_keys(index, commgrid, prm);
+            std::vector<uint8_t> packed(mydna.getbufsize() + 16);
+            std::vector<uint64_t> offs(mydna.size());
+            std::vector<uint32_t> lens2(mydna.size());
+            kmermap->engine->check(elba_export_reads(kmermap->engine->ctx, packed.data(), (int64_t)mydna.getbufsize(), offs.data(), lens2.data(), (int64_t)mydna.size()));
+            ingest_equal = index.gettotrecords() == mydna.size() && std::memcmp(packed.data(), mydna.data(), mydna.getbufsize()) == 0
+                           && std::memcmp(offs.data(), mydna.offsets(), offs.size() * 8) == 0 && std::memcmp(lens2.data(), mydna.lengths(), lens2.size() * 4) == 0;
+        } else
+            kmermap = elba::get_kmer_count_map_keys(mydna, commgrid, prm);                 // main.cpp:192
         elba::get_kmer_count_map_values(mydna, *kmermap, commgrid);                         // main.cpp:225
         auto A = elba::create_kmer_matrix(mydna, *kmermap, commgrid);                       // main.cpp:259
         kmermap.reset();                                                                    // main.cpp:266
@@ -60,8 +74,8 @@ int main(int argc, char **argv)
             achk += (uint64_t)(uint32_t)o.score * 1000003ull + std::get<0>(o.beg) * 31ull + std::get<1>(o.beg) * 37ull + std::get<0>(o.end) * 41ull + std::get<1>(o.end) * 43ull
                     + (uint64_t)(o.rc ? 7 : 0) + (uint64_t)(uint8_t)o.direction * 131ull + (uint64_t)(uint32_t)o.suffix * 8191ull + (uint64_t)R->rows[a] * 3ull + (uint64_t)R->cols[a];
         }
-        std::printf("{\"reads\": %zu, \"nnzA\": %lld, \"kmers\": %lld, \"nnzB\": %zu, \"candidates\": %lld, \"checksum\": %llu, \"alignments\": %lld, \"passed\": %lld, \"align_checksum\": %llu}\n", mydna.size(),
-                    (long long)nnzA, (long long)ncol, localnnzs, (long long)nalign, (unsigned long long)checksum, (long long)R->getnnz(), (long long)npassed, (unsigned long long)achk);
+        std::printf("{\"reads\": %zu, \"nnzA\": %lld, \"kmers\": %lld, \"nnzB\": %zu, \"candidates\": %lld, \"checksum\": %llu, \"alignments\": %lld, \"passed\": %lld, \"align_checksum\": %llu, \"ingest_equal\": %d}\n", mydna.size(),
+                    (long long)nnzA, (long long)ncol, localnnzs, (long long)nalign, (unsigned long long)checksum, (long long)R->getnnz(), (long long)npassed, (unsigned long long)achk, ingest_equal);
     } catch (const elba::Error &e) {
         std::fprintf(stderr, "%s\n", e.what());
         return e.status == ELBA_ERR_NO_DEVICE ? 3 : 1;

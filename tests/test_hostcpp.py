@@ -57,5 +57,16 @@ def test_mirror_matches_oracle_on_gpu(name, idx):
                 + ov["rc"].astype(np.uint64) * np.uint64(7) + u(ov["direction"], np.uint8) * np.uint64(131) + u(ov["suffix"]) * np.uint64(8191)
                 + ar.astype(np.uint64) * np.uint64(3) + ac.astype(np.uint64))
         achk = int(achk.sum(dtype=np.uint64))
-    assert got == {"reads": m["M"], "nnzA": m["Z"], "kmers": m["N"], "nnzB": m["Y"], "candidates": o.stat("nupper"), "checksum": checksum,
-                   "alignments": len(ar), "passed": int(ov["passed"].sum()), "align_checksum": achk}
+    want = {"reads": m["M"], "nnzA": m["Z"], "kmers": m["N"], "nnzB": m["Y"], "candidates": o.stat("nupper"), "checksum": checksum,
+            "alignments": len(ar), "passed": int(ov["passed"].sum()), "align_checksum": achk, "ingest_equal": -1}
+    assert got == want
+    # the same run fed through the C++ FastaIndex mirror and the GPU encoder (reads.fa.fai next to a copy of the FASTA)
+    import shutil, tempfile
+    from elba_amd import fasta as efa
+    with tempfile.TemporaryDirectory() as td:
+        fa2 = os.path.join(td, "reads.fa")
+        shutil.copy(fa, fa2)
+        efa.write_fai(fa2)
+        p2 = subprocess.run([BIN, fa2, str(k), str(lo), str(up), "fai"], capture_output=True, text=True, check=True)
+    want["ingest_equal"] = 1
+    assert json.loads(p2.stdout) == want
