@@ -29,40 +29,61 @@ __device__ __forceinline__ uint32_t char_code(uint8_t ch)
 
 // One lane encodes 16 consecutive bases into one 32-bit word of the output (the packed bytes of a read are byte-ordered, first base in
 // bits 7-6 of byte 0: the word is assembled byte by byte and stored little-endian; a read's buffer starts on a 4-byte boundary only
-// by accident, so the tail and unaligned reads fall back to byte stores).  The line of the first base costs one 32-bit division per
-// lane and trip; the character codes come from a 256-entry table in LDS.
-__global__ __launch_bounds__(256) void k_fasta_encode(const uint8_t *chunk, uint64_t chunk_off, uint64_t chunk_bytes, const elba_fasta_record_t *recs,
-                                                      const uint64_t *byte_off, uint32_t nreads, uint8_t *packed)
+// by accident, so the tail and unaligned reads fall back to byte stores).  Per trip a workgroup handles 256 words = 4096 bases: the
+// bytes of the file that hold them (4096 + one newline per line: at most 8192 for one-base lines) are first brought into LDS with
+// aligned 16-byte loads, consecutive lanes consecutive addresses — the file is read exactly once, coalesced — and the lanes then
+// pick their characters from LDS.  The line of a lane's first base costs one 32-bit division per trip; the character codes come from
+// a 256-entry table in LDS.
+constexpr uint32_t ENC_THREADS = 256, ENC_BASES = 16 * ENC_THREADS, ENC_SPAN = 2 * ENC_BASES + 32;
+__global__ __launch_bounds__(ENC_THREADS) void k_fasta_encode(const uint8_t *chunk, uint64_t chunk_off, uint64_t chunk_bytes, const elba_fasta_record_t *recs,
+                                                              const uint64_t *byte_off, uint32_t nreads, uint8_t *packed)
 {
     __shared__ uint8_t lut[256];
+    __shared__ __attribute__((aligned(16))) uint8_t span[ENC_SPAN];
     lut[threadIdx.x] = (uint8_t)char_code((uint8_t)threadIdx.x);
     __syncthreads();
     for (uint32_t r = blockIdx.x; r < nreads; r += gridDim.x) {
         const uint32_t len = (uint32_t)recs[r].len;
         const uint64_t bases64 = recs[r].bases;
         const uint32_t bases = bases64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)bases64;      // a line longer than the read: never wraps
-        const uint8_t *src = chunk + (recs[r].pos - chunk_off);
-        const uint64_t avail = chunk_bytes - (recs[r].pos - chunk_off);                         // bytes of the chunk from the record's first base on
+        const uint64_t rec0 = recs[r].pos - chunk_off;                                          // offset of the record's first base in the chunk
         uint8_t *out = packed + byte_off[r];
         const uint32_t nbytes = (len + 3) / 4, nwords = (nbytes + 3) / 4;
         const bool aligned = (reinterpret_cast<uintptr_t>(out) & 3u) == 0;
-        for (uint32_t w = threadIdx.x; w < nwords; w += blockDim.x) {
-            const uint32_t p0 = 16 * w;
-            uint32_t line = p0 / bases, rem = p0 - line * bases;
-            uint32_t word = 0;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                if (p0 + (uint32_t)i < len) {
-                    const uint64_t at = (uint64_t)p0 + (uint32_t)i + line;
-                    const uint32_t code = at < avail ? lut[src[at]] : 4u;
-                    const uint32_t byte = (code << (6 - 2 * (i & 3))) & 0xFFu;
-                    word |= byte << (8 * (i >> 2));
-                    if (++rem == bases) { rem = 0; ++line; }
-                }
+        for (uint32_t w0 = 0; w0 < nwords; w0 += ENC_THREADS) {
+            // file bytes of bases [16 w0, 16 w0 + 4096): from the first base's offset to the last one's, aligned down to 16
+            const uint32_t pb = 16 * w0, pe = pb + ENC_BASES < len ? pb + ENC_BASES : len;      // [pb, pe)
+            const uint64_t f0 = rec0 + pb + pb / bases, f1 = rec0 + (pe - 1) + (pe - 1) / bases + 1;       // [f0, f1) in the chunk
+            const uint64_t a0 = f0 & ~15ull;
+            const uint32_t nvec = (uint32_t)((f1 - a0 + 15) / 16);                               // <= ENC_SPAN / 16
+            for (uint32_t v = threadIdx.x; v < nvec; v += ENC_THREADS) {
+                const uint64_t at = a0 + 16ull * v;
+                uint4 x = make_uint4(0x58585858u, 0x58585858u, 0x58585858u, 0x58585858u);       // 'X' beyond the chunk: code 4, like a missing byte
+                if (at + 16 <= chunk_bytes) x = *reinterpret_cast<const uint4 *>(chunk + at);
+                else for (uint32_t q = 0; q < 16 && at + q < chunk_bytes; ++q) reinterpret_cast<uint8_t *>(&x)[q] = chunk[at + q];
+                *reinterpret_cast<uint4 *>(span + 16u * v) = x;
             }
-            const uint32_t b0 = 4 * w;
-            if (aligned && b0 + 4 <= nbytes) *reinterpret_cast<uint32_t *>(out + b0) = word;
-            else for (uint32_t x = 0; x < 4 && b0 + x < nbytes; ++x) out[b0 + x] = (uint8_t)(word >> (8 * x));
+            __syncthreads();
+            const uint32_t w = w0 + threadIdx.x;
+            if (w < nwords) {
+                const uint32_t p0 = 16 * w;
+                uint32_t line = p0 / bases, rem = p0 - line * bases;
+                uint32_t word = 0;
+                const uint32_t sbase = (uint32_t)(rec0 - a0);                                    // span offset of the record's first base (mod the trip)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    if (p0 + (uint32_t)i < len) {
+                        const uint32_t code = lut[span[sbase + p0 + (uint32_t)i + line]];
+                        const uint32_t byte = (code << (6 - 2 * (i & 3))) & 0xFFu;
+                        word |= byte << (8 * (i >> 2));
+                        if (++rem == bases) { rem = 0; ++line; }
+                    }
+                }
+                const uint32_t b0 = 4 * w;
+                if (aligned && b0 + 4 <= nbytes) *reinterpret_cast<uint32_t *>(out + b0) = word;
+                else for (uint32_t x = 0; x < 4 && b0 + x < nbytes; ++x) out[b0 + x] = (uint8_t)(word >> (8 * x));
+            }
+            __syncthreads();
         }
     }
 }
