@@ -55,6 +55,12 @@ class AlignStats(C.Structure):
                 ("extensions_strided", C.c_int64), ("cells", C.c_int64), ("ms_total", C.c_float), ("ms_extend", C.c_float)]
 
 
+class StringStats(C.Structure):
+    _fields_ = [("nreads", C.c_int64), ("nedges", C.c_int64), ("bad_reads", C.c_int64), ("edges_passed", C.c_int64), ("contained_reads", C.c_int64),
+                ("edges_kept", C.c_int64), ("products", C.c_int64), ("marked", C.c_int64), ("removed", C.c_int64), ("nnz", C.c_int64),
+                ("iterations", C.c_int32), ("reserved", C.c_int32), ("ms_total", C.c_float), ("ms_minplus", C.c_float)]
+
+
 class Overlaps(C.Structure):
     _fields_ = [("n", C.c_int64), ("rows", C.c_void_p), ("cols", C.c_void_p), ("vals", C.c_void_p)]
 
@@ -99,7 +105,7 @@ EXPORTED_SYMBOLS = [
     "elba_abi_version", "elba_strerror", "elba_last_error", "elba_ctx_create", "elba_ctx_destroy", "elba_set_reads", "elba_set_reads_device",
     "elba_count_kmers", "elba_create_kmer_matrix", "elba_set_kmer_matrix", "elba_create_seed_matrix", "elba_export_dcsc", "elba_free_dcsc",
     "elba_export_csr", "elba_free_csr", "elba_export_kmer_matrix", "elba_free_kmer_matrix", "elba_kmer_histogram", "elba_get_device_view",
-    "elba_align_seeds", "elba_export_overlaps", "elba_free_overlaps", "elba_set_reads_fasta", "elba_export_reads", "elba_dist_set_all_reads",
+    "elba_align_seeds", "elba_export_overlaps", "elba_free_overlaps", "elba_set_overlaps", "elba_transitive_reduction", "elba_export_string_graph", "elba_export_read_flags", "elba_set_reads_fasta", "elba_export_reads", "elba_dist_set_all_reads",
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
     "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
     "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_set_panel",
@@ -134,6 +140,10 @@ def load_library():
     L.elba_align_seeds.restype = i32; L.elba_align_seeds.argtypes = [vp, i32, i32, i32, i32, C.POINTER(AlignStats)]
     L.elba_export_overlaps.restype = i32; L.elba_export_overlaps.argtypes = [vp, C.POINTER(Overlaps)]
     L.elba_free_overlaps.restype = None; L.elba_free_overlaps.argtypes = [C.POINTER(Overlaps)]
+    L.elba_set_overlaps.restype = i32; L.elba_set_overlaps.argtypes = [vp, i64, vp, vp, vp, i64]
+    L.elba_transitive_reduction.restype = i32; L.elba_transitive_reduction.argtypes = [vp, C.c_double, i32, C.POINTER(StringStats)]
+    L.elba_export_string_graph.restype = i32; L.elba_export_string_graph.argtypes = [vp, C.POINTER(Overlaps)]
+    L.elba_export_read_flags.restype = i32; L.elba_export_read_flags.argtypes = [vp, vp, i64]
     L.elba_export_dcsc.restype = i32; L.elba_export_dcsc.argtypes = [vp, i64, i64, i64, i64, C.POINTER(Dcsc)]
     L.elba_free_dcsc.restype = None; L.elba_free_dcsc.argtypes = [C.POINTER(Dcsc)]
     L.elba_export_csr.restype = i32; L.elba_export_csr.argtypes = [vp, i64, i64, C.POINTER(Csr)]
@@ -274,6 +284,37 @@ class Engine:
             return dict(n=o.n, rows=_copy(o.rows, o.n, np.int64), cols=_copy(o.cols, o.n, np.int64), vals=_copy(o.vals, o.n, OVERLAP_DTYPE))
         finally:
             self.L.elba_free_overlaps(C.byref(o))
+
+    # --- string graph (src/main.cpp:305-312) ---
+    def set_overlaps(self, nreads, rows, cols, vals):
+        """Load aligned pairs (rows < cols, ascending in (row, col)) instead of using this engine's own alignments."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64); cols = np.ascontiguousarray(cols, dtype=np.int64); vals = np.ascontiguousarray(vals, dtype=OVERLAP_DTYPE)
+        if not (len(rows) == len(cols) == len(vals)):
+            raise ValueError("set_overlaps: rows, cols, vals differ in length")
+        self._check(self.L.elba_set_overlaps(self.h, int(nreads), rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, len(rows)))
+
+    def transitive_reduction(self, bad_read_cutoff=0.65, fuzz=1000):
+        """find_bad_reads / find_contained_reads + prunes (src/main.cpp:305-311) and TransitiveReduction (src/TransitiveReduction.cpp:3-90)."""
+        st = StringStats()
+        self._check(self.L.elba_transitive_reduction(self.h, float(bad_read_cutoff), int(fuzz), C.byref(st)))
+        d = _stats(st)
+        d.pop("reserved", None)
+        return d
+
+    def export_string_graph(self):
+        """Entries of S in the order parallel_write_paf walks them (columns ascending, rows ascending within a column)."""
+        o = Overlaps()
+        self._check(self.L.elba_export_string_graph(self.h, C.byref(o)))
+        try:
+            return dict(n=o.n, rows=_copy(o.rows, o.n, np.int64), cols=_copy(o.cols, o.n, np.int64), vals=_copy(o.vals, o.n, OVERLAP_DTYPE))
+        finally:
+            self.L.elba_free_overlaps(C.byref(o))
+
+    def export_read_flags(self, nreads):
+        """One byte per read: bit 0 = bad read, bit 1 = contained read."""
+        f = np.zeros(int(nreads), dtype=np.uint8)
+        self._check(self.L.elba_export_read_flags(self.h, f.ctypes.data, int(nreads)))
+        return f
 
     # --- outputs ---
     def export_csr(self, row_lo=0, row_hi=None):

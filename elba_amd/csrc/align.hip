@@ -475,6 +475,7 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
     hipStream_t s = c.stream;
     const int64_t M = c.M;
     c.have_aln = false;
+    c.have_edges = false; c.have_S = false;        // fresh alignments replace a loaded edge list as the string graph's input (tr.hip)
     AlnParams p{};
     if (shard) { p.packed = c.aln_all_packed.as<uint8_t>(); p.byte_off = c.aln_all_off.as<uint64_t>(); p.len = c.aln_all_len.as<uint32_t>(); }
     else { p.packed = c.d_packed; p.byte_off = c.d_byte_off; p.len = c.d_len; }

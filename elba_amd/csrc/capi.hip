@@ -260,6 +260,48 @@ void elba_free_overlaps(elba_overlaps_t *o)
     memset(o, 0, sizeof(*o));
 }
 
+int elba_set_overlaps(elba_ctx *ctx, int64_t nreads, const int64_t *rows, const int64_t *cols, const elba_overlap_t *vals, int64_t n)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_set_overlaps(c, nreads, rows, cols, vals, n); });
+}
+
+int elba_transitive_reduction(elba_ctx *ctx, double bad_read_cutoff, int fuzz, elba_string_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        stage_transitive_reduction(c, bad_read_cutoff, fuzz);
+        if (stats) *stats = c.sstats;
+    });
+}
+
+int elba_export_string_graph(elba_ctx *ctx, elba_overlaps_t *out)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(out, ELBA_ERR_INVALID_ARG, "export_string_graph: null output");
+        memset(out, 0, sizeof(*out));
+        ELBA_REQUIRE(c.have_S, ELBA_ERR_STATE, "export_string_graph: no string graph (call elba_transitive_reduction)");
+        const int64_t n = c.tr_nnz;
+        out->n = n;
+        out->rows = host_alloc<int64_t>((size_t)n); out->cols = host_alloc<int64_t>((size_t)n); out->vals = host_alloc<elba_overlap_t>((size_t)n);
+        if (n) {
+            ELBA_HIP(hipMemcpyAsync(out->rows, c.tr_out_rows.p, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
+            ELBA_HIP(hipMemcpyAsync(out->cols, c.tr_out_cols.p, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
+            ELBA_HIP(hipMemcpyAsync(out->vals, c.tr_out_vals.p, (size_t)n * sizeof(elba_overlap_t), hipMemcpyDeviceToHost, c.stream));
+        }
+        ELBA_HIP(hipStreamSynchronize(c.stream));
+        for (int64_t a = 0; a < n; ++a) { out->rows[a] += c.tr_id_base; out->cols[a] += c.tr_id_base; }
+    });
+}
+
+int elba_export_read_flags(elba_ctx *ctx, uint8_t *flags, int64_t nreads)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(c.have_S, ELBA_ERR_STATE, "export_read_flags: no string graph (call elba_transitive_reduction)");
+        ELBA_REQUIRE(nreads == c.tr_M && (flags || nreads == 0), ELBA_ERR_INVALID_ARG, "export_read_flags: need one byte per read of the graph");
+        if (nreads) ELBA_HIP(hipMemcpyAsync(flags, c.tr_flags.p, (size_t)nreads, hipMemcpyDeviceToHost, c.stream));
+        ELBA_HIP(hipStreamSynchronize(c.stream));
+    });
+}
+
 int elba_export_csr(elba_ctx *ctx, int64_t row_lo, int64_t row_hi, elba_csr_t *out)
 {
     return guarded(ctx, [&](Ctx &c) {

@@ -176,6 +176,15 @@ struct Ctx {
     DevBuf aln_all_packed, aln_all_off, aln_all_len;     // every read of the run, replicated for a row shard's alignments (elba_dist_set_all_reads)
     int64_t aln_all_n = -1; uint32_t aln_all_maxlen = 0;
 
+    // string graph (tr.hip)
+    bool have_edges = false;                   // an edge list loaded with elba_set_overlaps (otherwise this context's alignments are the input)
+    int64_t tr_in_M = 0, tr_in_n = 0;
+    DevBuf tr_in_rows, tr_in_cols, tr_in_vals;
+    bool have_S = false;
+    int64_t tr_M = 0, tr_nnz = 0, tr_id_base = 0;
+    DevBuf tr_deg, tr_pas, tr_flags, tr_k0, tr_v0, tr_k1, tr_v1, tr_ptr, tr_sym, tr_src, tr_mark, tr_ctr, tr_sel, tr_out_rows, tr_out_cols, tr_out_vals;
+    elba_string_stats sstats{};
+
     // workspaces
     DevBuf ws_scan, ws_sort, ws_a, ws_b, ws_c, ws_d, ws_e, ws_f;
     DevBuf ov_totcnt, ov_mir, ov_tmp, ov_sum_tmp;  // u32[M+1] mirrored entries per row (ticket counters); mirrored entries laid out like B (32-byte records); staging area (32-byte records)
@@ -205,6 +214,8 @@ void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_
 void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
 void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff);   // align.hip
 void stage_dist_set_all_reads(Ctx &c, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads_total);   // align.hip
+void stage_set_overlaps(Ctx &c, int64_t nreads, const int64_t *rows, const int64_t *cols, const elba_overlap_t *vals, int64_t n);   // tr.hip
+void stage_transitive_reduction(Ctx &c, double bad_read_cutoff, int fuzz);   // tr.hip
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host);                                   // kmer.hip
 void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);
 void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec);

@@ -98,6 +98,23 @@ typedef struct {
     elba_overlap_t *vals;
 } elba_overlaps_t;
 
+/* From the aligned pairs to the string graph (src/main.cpp:305-312). */
+typedef struct {
+    int64_t nreads, nedges;     /* reads, aligned pairs handed in (entries of the upper-triangular R of PairwiseAlignment) */
+    int64_t bad_reads;          /* find_bad_reads (src/main.cpp:553-571) */
+    int64_t edges_passed;       /* entries left by Prune(!passed) + PruneFull(bad reads) */
+    int64_t contained_reads;    /* find_contained_reads (src/main.cpp:573-583) */
+    int64_t edges_kept;         /* entries left by PruneFull(contained reads): the R handed to TransitiveReduction (upper triangle) */
+    int64_t products;           /* semiring products of R (x) R on the symmetrised R = sum over reads of degree^2: lookups done */
+    int64_t marked;             /* nnz(I) before it is symmetrised: entries of R with suffix + FUZZ >= the two-edge path of their direction */
+    int64_t removed;            /* nnz(T) */
+    int64_t nnz;                /* nnz(S): both triangles */
+    int32_t iterations;         /* passes of the reference's do-while this stands for (2 when something was removed, else 1; see tr.hip) */
+    int32_t reserved;
+    float   ms_total;           /* device time of the stage */
+    float   ms_minplus;         /* the masked min-plus kernel alone */
+} elba_string_stats;
+
 typedef struct {
     int32_t k;          /* KMER_SIZE: odd, 3..95 as in the reference (one to three 64-bit words per k-mer; reference: compile-time, Makefile:1).  The multi-GPU
                            exchange (elba_dist_*) carries one-word k-mers: k <= 31 */
@@ -238,6 +255,21 @@ int  elba_align_seeds(elba_ctx *ctx, int mat, int mis, int gap, int dropoff, elb
 int  elba_dist_set_all_reads(elba_ctx *ctx, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads_total);
 int  elba_export_overlaps(elba_ctx *ctx, elba_overlaps_t *out);
 void elba_free_overlaps(elba_overlaps_t *o);
+
+/* The string graph: what src/main.cpp:305-312 does to the R of PairwiseAlignment —
+ *   find_bad_reads (src/main.cpp:553-571; reads whose (passed + 1) / (aligned + 1) <= bad_read_cutoff), Prune(!passed), PruneFull(bad),
+ *   find_contained_reads (:573-583), PruneFull(contained), TransitiveReduction (src/TransitiveReduction.cpp:3-90; MinPlusSR,
+ *   include/TransitiveReduction.hpp:78-110; fuzz = FUZZ, :16, 1000 in the reference).
+ * Works on the alignments elba_align_seeds left on this context (one context holding the whole of B), or on an edge list loaded with
+ * elba_set_overlaps: host arrays, rows[a] < cols[a] < nreads, strictly ascending in (row, col) — the order elba_export_overlaps gives;
+ * a multi-GPU driver concatenates its ranks' shares (merged into that order) and hands them to every rank or to one.
+ * elba_export_string_graph returns the entries of S, both triangles, in the order parallel_write_paf walks the reference's S
+ * (src/main.cpp:527-541: columns ascending, rows ascending within a column); an entry below the diagonal carries Overlap::Transpose
+ * (include/Overlap.hpp:43-69) of its mirror image.  elba_export_read_flags: flags[v] bit 0 = bad read, bit 1 = contained read. */
+int  elba_set_overlaps(elba_ctx *ctx, int64_t nreads, const int64_t *rows, const int64_t *cols, const elba_overlap_t *vals, int64_t n);
+int  elba_transitive_reduction(elba_ctx *ctx, double bad_read_cutoff, int fuzz, elba_string_stats *stats);
+int  elba_export_string_graph(elba_ctx *ctx, elba_overlaps_t *out);
+int  elba_export_read_flags(elba_ctx *ctx, uint8_t *flags, int64_t nreads);
 
 int  elba_export_dcsc(elba_ctx *ctx, int64_t row_lo, int64_t row_hi, int64_t col_lo, int64_t col_hi, elba_dcsc_t *out);
 void elba_free_dcsc(elba_dcsc_t *d);

@@ -773,3 +773,174 @@ const void *orc_get_ptr(const orc_ctx *c, int what)
     default: return NULL;
     }
 }
+
+/* ====================================================================================================================
+ * f2: from the aligned pairs to the string graph — the statements of src/main.cpp:305-312:
+ *   find_bad_reads (:553-571), R->Prune(!passed), PruneFull(bad), find_contained_reads (:573-583), PruneFull(contained),
+ *   TransitiveReduction (src/TransitiveReduction.cpp:3-90) over MinPlusSR (include/TransitiveReduction.hpp:78-110).
+ * Followed literally, loop and all: P = R; do { N = P (x) R; prune no-path; P = N; I = (F >= N[dir]); I |= I^T; T |= I } while
+ * nnz(T) changes; S = R \ T.  The product is computed in full (every (i,j) reachable through some k, all four path slots), with a
+ * dense per-row accumulator — nothing is masked by R's pattern here; the HIP path computes only what the comparison reads.
+ * **parity unpinned**: the matrix algebra (Mult_AnXBn_DoubleBuff, EWiseApply, Prune, PruneFull, Reduce, operator+=) lives in
+ * CombBLAS (absent) and the reference holds no fixture for this stage; min and + over int are order-free, so the fold order that
+ * leaves the seed values of a13 unpinned does not matter here.  Known-answer cases: tests/test_oracle_string_graph.py.
+ * ==================================================================================================================== */
+typedef struct { int32_t dir, suffix; int32_t paths[4]; } orc_mp_t;     /* the fields of Overlap MinPlusSR touches */
+#define ORC_INF 0x7fffffff
+
+/* Overlap::Transpose, include/Overlap.hpp:43-69 (len is not carried: it is the lengths of the two reads, swapped with them) */
+static orc_overlap_t orc_overlap_transpose(orc_overlap_t o)
+{
+    orc_overlap_t t = o;
+    t.begQ = o.begT; t.begT = o.begQ; t.endQ = o.endT; t.endT = o.endQ;
+    t.suffix = o.suffixT; t.suffixT = o.suffix;
+    t.direction = o.directionT; t.directionT = o.direction;
+    t.containedQ = o.containedT; t.containedT = o.containedQ;
+    return t;
+}
+
+/* MinPlusSR::multiply, include/TransitiveReduction.hpp:88-104; Overlap::arrows include/Overlap.hpp:33-41 */
+static int orc_mp_multiply(const orc_mp_t *e1, const orc_mp_t *e2, int32_t out[4])
+{
+    out[0] = out[1] = out[2] = out[3] = ORC_INF;
+    if (e1->dir == -1 || e2->dir == -1) return 0;
+    const int t1 = (e1->dir >> 1) & 1, h1 = e1->dir & 1, t2 = (e2->dir >> 1) & 1, h2 = e2->dir & 1;
+    if (t2 == h1) return 0;
+    out[2 * t1 + h2] = e1->suffix + e2->suffix;
+    return 1;
+}
+
+typedef struct { int64_t row, col; orc_overlap_t v; } orc_edge_t;
+static int orc_cmp_i64(const void *x, const void *y) { const int64_t a = *(const int64_t *)x, b = *(const int64_t *)y; return a < b ? -1 : (a > b); }
+static int orc_cmp_edge_rc(const void *x, const void *y)
+{
+    const orc_edge_t *a = (const orc_edge_t *)x, *b = (const orc_edge_t *)y;
+    if (a->row != b->row) return a->row < b->row ? -1 : 1;
+    return a->col < b->col ? -1 : (a->col > b->col);
+}
+static int orc_cmp_edge_cr(const void *x, const void *y)
+{
+    const orc_edge_t *a = (const orc_edge_t *)x, *b = (const orc_edge_t *)y;
+    if (a->col != b->col) return a->col < b->col ? -1 : 1;
+    return a->row < b->row ? -1 : (a->row > b->row);
+}
+
+/* In: the n aligned pairs (rows[a] < cols[a], no pair twice) of an M-read set.  Out: the entries of S in the order parallel_write_paf
+ * walks them (DCSC: columns ascending, rows ascending within a column; src/main.cpp:527-541); read_flags[v] bit 0 = bad read, bit 1 =
+ * contained read; stats[0..9] = bad reads, entries after the passed/bad prune, contained reads, entries handed to TransitiveReduction
+ * (upper triangle), semiring products of the first P (x) R, nnz(N) of it after the no-path prune, nnz(I) before symmetrising,
+ * nnz(T), nnz(S), loop iterations.  Returns nnz(S), or -(needed) when cap is too small, or INT64_MIN on bad input. */
+int64_t orc_string_graph(int64_t M, int64_t n, const int64_t *rows, const int64_t *cols, const orc_overlap_t *vals, double cutoff, int fuzz,
+                         int64_t *out_rows, int64_t *out_cols, orc_overlap_t *out_vals, int64_t cap, uint8_t *read_flags, int64_t *stats)
+{
+    for (int64_t a = 0; a < n; ++a) if (rows[a] < 0 || cols[a] >= M || rows[a] >= cols[a]) return INT64_MIN;
+    int64_t st[10] = {0};
+    /* find_bad_reads: (passed entries in row + column + 1) / (entries in row + column + 1) <= cutoff */
+    int32_t *deg = calloc((size_t)M + 1, 4), *pas = calloc((size_t)M + 1, 4);
+    uint8_t *bad = calloc((size_t)M + 1, 1), *cont = calloc((size_t)M + 1, 1);
+    for (int64_t a = 0; a < n; ++a) { ++deg[rows[a]]; ++deg[cols[a]]; if (vals[a].passed) { ++pas[rows[a]]; ++pas[cols[a]]; } }
+    for (int64_t v = 0; v < M; ++v) { const double r = ((double)pas[v] + 1) / ((double)deg[v] + 1); if (r <= cutoff) { bad[v] = 1; ++st[0]; } }
+    /* R->Prune(!passed); R->PruneFull(bad, bad) */
+    orc_edge_t *e = malloc(sizeof(orc_edge_t) * (size_t)(2 * n + 1));
+    int64_t m = 0;
+    for (int64_t a = 0; a < n; ++a) if (vals[a].passed && !bad[rows[a]] && !bad[cols[a]]) { e[m].row = rows[a]; e[m].col = cols[a]; e[m].v = vals[a]; ++m; }
+    st[1] = m;
+    /* find_contained_reads: containedQ marks the row's read, containedT the column's */
+    for (int64_t a = 0; a < m; ++a) { if (e[a].v.containedQ) cont[e[a].row] = 1; if (e[a].v.containedT) cont[e[a].col] = 1; }
+    for (int64_t v = 0; v < M; ++v) st[2] += cont[v];
+    int64_t m2 = 0;
+    for (int64_t a = 0; a < m; ++a) if (!cont[e[a].row] && !cont[e[a].col]) e[m2++] = e[a];
+    st[3] = m2;
+    if (read_flags) for (int64_t v = 0; v < M; ++v) read_flags[v] = (uint8_t)(bad[v] | (cont[v] << 1));
+    /* RT = R^T with Overlap::Transpose applied; R += RT */
+    for (int64_t a = 0; a < m2; ++a) { e[m2 + a].row = e[a].col; e[m2 + a].col = e[a].row; e[m2 + a].v = orc_overlap_transpose(e[a].v); }
+    const int64_t E = 2 * m2;
+    qsort(e, (size_t)E, sizeof *e, orc_cmp_edge_rc);
+    int64_t *rp = calloc((size_t)M + 2, 8);
+    for (int64_t a = 0; a < E; ++a) ++rp[e[a].row + 1];
+    for (int64_t v = 0; v < M; ++v) rp[v + 1] += rp[v];
+    /* P: pattern + values as a CSR that changes per iteration; R fixed */
+    orc_mp_t *Rv = malloc(sizeof(orc_mp_t) * (size_t)(E + 1));
+    for (int64_t a = 0; a < E; ++a) { Rv[a].dir = e[a].v.direction; Rv[a].suffix = e[a].v.suffix; for (int s = 0; s < 4; ++s) Rv[a].paths[s] = ORC_INF; }
+    int64_t *Prp = malloc(8 * (size_t)(M + 2)); memcpy(Prp, rp, 8 * (size_t)(M + 2));
+    int64_t Pn = E; int64_t *Pcol = malloc(8 * (size_t)(E + 1)); orc_mp_t *Pv = malloc(sizeof(orc_mp_t) * (size_t)(E + 1));
+    for (int64_t a = 0; a < E; ++a) { Pcol[a] = e[a].col; Pv[a] = Rv[a]; }
+    uint8_t *T = calloc((size_t)E + 1, 1), *I = malloc((size_t)E + 1);     /* T, I: flags on R's entries (I and T are subsets of R's pattern) */
+    int32_t (*acc)[4] = malloc(sizeof(int32_t[4]) * (size_t)(M + 1));
+    uint8_t *seen = calloc((size_t)M + 1, 1);
+    int64_t *touched = malloc(8 * (size_t)(M + 1));
+    int64_t nnzT = 0, prev, iters = 0;
+    do {
+        prev = nnzT;
+        /* N = P (x) R, row by row; N.Prune(NoPathSRing) */
+        int64_t Ncap = E + 16, Nn = 0, products = 0;
+        int64_t *Nrp = calloc((size_t)M + 2, 8), *Ncol = malloc(8 * (size_t)Ncap);
+        orc_mp_t *Nv = malloc(sizeof(orc_mp_t) * (size_t)Ncap);
+        for (int64_t i = 0; i < M; ++i) {
+            int64_t nt = 0;
+            for (int64_t x = Prp[i]; x < Prp[i + 1]; ++x) {
+                const int64_t k = Pcol[x];
+                for (int64_t y = rp[k]; y < rp[k + 1]; ++y) {
+                    const int64_t j = e[y].col;
+                    int32_t prod[4];
+                    orc_mp_multiply(&Pv[x], &Rv[y], prod);
+                    ++products;
+                    if (!seen[j]) { seen[j] = 1; touched[nt++] = j; for (int s = 0; s < 4; ++s) acc[j][s] = ORC_INF; }
+                    for (int s = 0; s < 4; ++s) if (prod[s] < acc[j][s]) acc[j][s] = prod[s];            /* opmin, src/TransitiveReduction.cpp:92-100 */
+                }
+            }
+            /* columns ascending within the row */
+            qsort(touched, (size_t)nt, 8, orc_cmp_i64);
+            for (int64_t a = 0; a < nt; ++a) {
+                const int64_t j = touched[a];
+                seen[j] = 0;
+                if (acc[j][0] == ORC_INF && acc[j][1] == ORC_INF && acc[j][2] == ORC_INF && acc[j][3] == ORC_INF) continue;   /* NoPathSRing */
+                if (Nn == Ncap) { Ncap *= 2; Ncol = realloc(Ncol, 8 * (size_t)Ncap); Nv = realloc(Nv, sizeof(orc_mp_t) * (size_t)Ncap); }
+                Ncol[Nn] = j; Nv[Nn].dir = -1; Nv[Nn].suffix = 0;                                         /* Overlap() of multiply: direction -1, suffix 0 */
+                for (int s = 0; s < 4; ++s) Nv[Nn].paths[s] = acc[j][s];
+                ++Nn;
+            }
+            Nrp[i + 1] = Nn;
+        }
+        if (iters == 0) { st[4] = products; st[5] = Nn; }
+        /* I = EWiseApply(F, N, GreaterThanSR) on the intersection, F = R with suffix + FUZZ; prune false */
+        int64_t nI = 0;
+        memset(I, 0, (size_t)E + 1);
+        for (int64_t i = 0; i < M; ++i) {
+            int64_t y = Nrp[i];
+            for (int64_t x = rp[i]; x < rp[i + 1]; ++x) {
+                while (y < Nrp[i + 1] && Ncol[y] < e[x].col) ++y;
+                if (y < Nrp[i + 1] && Ncol[y] == e[x].col) {
+                    const int dir = Rv[x].dir;
+                    if (dir != -1 && Rv[x].suffix + fuzz >= Nv[y].paths[dir]) { I[x] = 1; ++nI; }
+                }
+            }
+        }
+        if (iters == 0) st[6] = nI;
+        /* I += I^T; T += I */
+        for (int64_t x = 0; x < E; ++x) if (I[x]) {
+            orc_edge_t key; key.row = e[x].col; key.col = e[x].row;
+            const orc_edge_t *r = bsearch(&key, e, (size_t)E, sizeof *e, orc_cmp_edge_rc);
+            if (!T[x]) { T[x] = 1; ++nnzT; }
+            if (!T[r - e]) { T[r - e] = 1; ++nnzT; }
+        }
+        free(Prp); free(Pcol); free(Pv);
+        Prp = Nrp; Pcol = Ncol; Pv = Nv; Pn = Nn;
+        ++iters;
+    } while (nnzT != prev);
+    (void)Pn;
+    st[7] = nnzT; st[9] = iters;
+    /* R = EWiseApply(R, T, TransitiveRemoval, not-T); R.Prune(direction == -1) */
+    int64_t ns = 0;
+    for (int64_t x = 0; x < E; ++x) if (!T[x] && e[x].v.direction != -1) e[ns++] = e[x];
+    st[8] = ns;
+    int64_t ret = ns;
+    if (ns > cap) ret = -ns;
+    else {
+        qsort(e, (size_t)ns, sizeof *e, orc_cmp_edge_cr);
+        for (int64_t a = 0; a < ns; ++a) { out_rows[a] = e[a].row; out_cols[a] = e[a].col; out_vals[a] = e[a].v; }
+    }
+    if (stats) memcpy(stats, st, sizeof st);
+    free(deg); free(pas); free(bad); free(cont); free(e); free(rp); free(Rv); free(Prp); free(Pcol); free(Pv); free(T); free(I); free(acc); free(seen); free(touched);
+    return ret;
+}

@@ -85,6 +85,8 @@ def lib():
         L.orc_classify_alignment.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.orc_overlap_extend.restype = None
         L.orc_overlap_extend.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.orc_string_graph.restype = C.c_int64
+        L.orc_string_graph.argtypes = [C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
         L.orc_align_upper.restype = C.c_int64
         L.orc_align_upper.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
         L.orc_get_i64.restype = C.c_int64
@@ -194,6 +196,25 @@ class Oracle:
         for p in (jc, cp, ir, numx):
             self.L.orc_free_ptr(p)
         return out
+
+
+STRING_STATS = ("bad_reads", "edges_passed", "contained_reads", "edges_kept", "products", "nnzN", "marked", "removed", "nnz", "iterations")
+
+
+def string_graph(nreads, rows, cols, vals, cutoff=0.65, fuzz=1000):
+    """src/main.cpp:305-312: bad-read and contained-read removal + TransitiveReduction on the aligned pairs (rows < cols).
+    Returns dict(rows, cols, vals) of S in the order parallel_write_paf walks it (columns, then rows), read flags (bit 0 bad, bit 1 contained), stats."""
+    L = lib()
+    rows = np.ascontiguousarray(rows, dtype=np.int64); cols = np.ascontiguousarray(cols, dtype=np.int64); vals = np.ascontiguousarray(vals, dtype=OVERLAP_DTYPE)
+    n = len(rows)
+    cap = 2 * n + 1
+    orow = np.zeros(cap, dtype=np.int64); ocol = np.zeros(cap, dtype=np.int64); oval = np.zeros(cap, dtype=OVERLAP_DTYPE)
+    flags = np.zeros(nreads + 1, dtype=np.uint8); st = np.zeros(10, dtype=np.int64)
+    ns = L.orc_string_graph(nreads, n, rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, cutoff, fuzz, orow.ctypes.data, ocol.ctypes.data, oval.ctypes.data, cap,
+                            flags.ctypes.data, st.ctypes.data)
+    if ns < 0:
+        raise ValueError("orc_string_graph: bad input (rows must be < cols, ids within [0, nreads))")
+    return dict(n=int(ns), rows=orow[:ns], cols=ocol[:ns], vals=oval[:ns]), flags[:nreads], dict(zip(STRING_STATS, (int(v) for v in st)))
 
 
 def ref_lib(k):

@@ -37,6 +37,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(capi.OverlapStats) == 11 * 8 + 2 * 4 + 4 * 4
     assert capi.OVERLAP_DTYPE.itemsize == 36      # elba_overlap_t: 7 x int32 + 8 x int8
     assert C.sizeof(capi.AlignStats) == 6 * 8 + 2 * 4
+    assert C.sizeof(capi.StringStats) == 10 * 8 + 2 * 4 + 2 * 4
 
 
 def test_bad_configurations_are_rejected():
