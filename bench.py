@@ -212,6 +212,40 @@ def main():
     if world == 1 and not force_dist and not args.dbg and not args.no_align:
         align = guarded("align_stage", run_align)
 
+    # ... and the step after that: bad / contained read removal + transitive reduction of the aligned pairs.  On the
+    # bench workload (15 % errors) the reference's default x-drop lets ~17 % of the alignments pass and find_bad_reads (cutoff 0.65) then
+    # discards nearly every read — the graph is empty (reported below as it comes out).  The stage is therefore also run on a companion
+    # set of accurate reads (0.5 % errors, the regime the default alignment parameters produce a string graph in), through the whole
+    # chain reads -> B -> alignments -> S on a context of its own.
+    string_graph = None
+    sg_eng = None
+    SG_CFG = {"genome": 1500000, "depth": 20.0, "avg_len": 8000, "sd_len": 1500, "error": 0.005, "k": 17, "lower": 8, "upper": 30, "seed": 7}
+
+    def sg_numbers(sg_):
+        sym_bytes = 2 * sg_["edges_kept"] * 16 + (sg_["nreads"] + 1) * 4      # the symmetrised R the masked product reads: 16-byte entries + row pointers
+        return {"reads": int(sg_["nreads"]), "aligned_pairs": int(sg_["nedges"]), "bad_reads": int(sg_["bad_reads"]), "contained_reads": int(sg_["contained_reads"]),
+                "edges_kept": int(sg_["edges_kept"]), "products": int(sg_["products"]), "marked": int(sg_["marked"]), "removed": int(sg_["removed"]), "nnz": int(sg_["nnz"]),
+                "ms": round(sg_["ms_total"], 4), "ms_minplus_kernel": round(sg_["ms_minplus"], 4),
+                "products_per_s": round(sg_["products"] / max(1e-9, sg_["ms_minplus"] * 1e-3), 1) if sg_["ms_minplus"] > 0 else None,
+                "kernel_frac_of_hbm_peak": round(sym_bytes / (sg_["ms_minplus"] * 1e-3) / 1e9 / peak_gbs, 5) if sg_["ms_minplus"] > 0 else None}
+
+    def run_string_graph():
+        nonlocal sg_eng
+        eng.transitive_reduction()                         # warm-up (allocations)
+        res = {"params": {"bad_read_cutoff": 0.65, "fuzz": 1000}, "on_bench_workload": sg_numbers(eng.transitive_reduction())}
+        c_ = SG_CFG
+        sp, so, sl, _ = elba_amd.synth_reads(c_["seed"], c_["genome"], c_["depth"], c_["avg_len"], c_["sd_len"], error_rate=c_["error"], min_len=1000)
+        sg_eng = Engine(c_["k"], c_["lower"], c_["upper"], device=local_rank)
+        sg_eng.set_reads(sp, so, sl)
+        sg_eng.count_kmers(); sg_eng.create_kmer_matrix(); ov_ = sg_eng.create_seed_matrix()
+        al_ = sg_eng.align_seeds()
+        sg_eng.transitive_reduction()
+        res["accurate_reads"] = dict(sg_numbers(sg_eng.transitive_reduction()), config=c_, overlap_nnz=int(ov_["nnz"]), alignments_passed=int(al_["passed"]), align_ms=round(al_["ms_total"], 3))
+        return res
+
+    if align is not None:
+        string_graph = guarded("string_graph_stage", run_string_graph)
+
     # N > 1: opt-in (--align-sharded).  The stage has collectives of its own (one all-gather of the reads); it is covered by the gloo /
     # threaded tests, and the default multi-GPU line stays the SpGEMM step alone.
     if (world > 1 or force_dist) and not args.dbg and args.align_sharded:
@@ -289,6 +323,22 @@ def main():
                                                    "what": "the reference's xdrop_aligner + classify_alignment (g++ -O2) on the same sample, called through ctypes"}
                 align["parity_vs_reference_on_sample"] = bool(ok)
 
+        if string_graph is not None and align is not None:
+            # CPU side: the oracle runs the reference's statements literally (full min-plus SpGEMM, loop included) on the GPU's own aligned pairs
+            def sg_check(e_, nreads_, into):
+                g_ = e_.export_overlaps()
+                t0 = time.perf_counter(); S_, fl_, sst = po.string_graph(nreads_, g_["rows"], g_["cols"], g_["vals"]); ts = time.perf_counter() - t0
+                gs = e_.export_string_graph()
+                into["parity_vs_oracle"] = bool(gs["n"] == S_["n"] and (gs["rows"] == S_["rows"]).all() and (gs["cols"] == S_["cols"]).all()
+                                                and all((gs["vals"][f] == S_["vals"][f]).all() for f in S_["vals"].dtype.names if f != "pad")
+                                                and (e_.export_read_flags(nreads_) == fl_).all()
+                                                and all(into[k_] == sst[k_] for k_ in ("bad_reads", "contained_reads", "edges_kept", "products", "marked", "removed", "nnz")))
+                into["cpu_baseline"] = {"products_per_s": round(sst["products"] / ts, 1), "cores": 1, "kind": "port", "seconds": round(ts, 4),
+                                        "sample": "the whole stage once (oracle/elba_oracle.c orc_string_graph: prunes + full R(x)R + compare, %d loop passes)" % sst["iterations"]}
+            sg_check(eng, len(lens), string_graph["on_bench_workload"])
+            if sg_eng is not None and "accurate_reads" in string_graph:
+                sg_check(sg_eng, string_graph["accurate_reads"]["reads"], string_graph["accurate_reads"])
+
     if rank == 0:
         out = {
             "metric": "overlap nnz/sec (A·Aᵀ SpGEMM, SharedSeeds semiring, after Prune(numshared<=1))",
@@ -305,6 +355,7 @@ def main():
             "aux_errors": aux_errors or None,
             "ingest_stage": ingest,
             "align_stage": align,
+            "string_graph_stage": string_graph,
             "kmer_stage": {"device_ms": round(ks["ms_total"] + ms["ms_total"], 3), "matrix_build_ms": round(ms["ms_total"], 3), "wall_ms": round(t_kmer_wall * 1e3, 3),
                            "instances_per_s": round(ks["instances"] / max(1e-9, t_kmer_wall), 1), "count_ms": round(ks["ms_count"], 3), "select_sort_ms": round(ks["ms_sort"], 3),
                            "cpu_baseline_reference": kmer_ref},
