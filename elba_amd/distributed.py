@@ -81,6 +81,18 @@ class HipBackend:
     def export_overlaps(self):
         return self.e.export_overlaps()
 
+    def set_overlaps(self, nreads, rows, cols, vals):
+        self.e.set_overlaps(nreads, rows, cols, vals)
+
+    def transitive_reduction(self, bad_read_cutoff, fuzz):
+        return self.e.transitive_reduction(bad_read_cutoff, fuzz)
+
+    def export_string_graph(self):
+        return self.e.export_string_graph()
+
+    def export_read_flags(self, nreads):
+        return self.e.export_read_flags(nreads)
+
     def count_owners(self, nranks):
         out = np.zeros(nranks, dtype=np.uint64)
         self.e._check(self.L.elba_dist_count_owners(self.h, nranks, out.ctypes.data))
@@ -291,6 +303,37 @@ class DistributedOverlap:
 
     def export_overlaps(self):
         return self.be.export_overlaps()
+
+    # ---- and the step after that: the string graph -------------------------------------------------------------------------
+    def transitive_reduction(self, bad_read_cutoff=0.65, fuzz=1000):
+        """src/main.cpp:305-312 across ranks.  The aligned pairs are small next to everything before them (52 bytes per pair): every
+        rank gathers the others' shares with ONE all-gather, merges them into (row, col) order and runs the whole reduction itself —
+        replicas, no further exchange (the reference runs a distributed SpGEMM and several distributed element-wise passes here).
+        Every rank ends up holding all of S; export_string_graph(local=True) cuts out the rows of this rank's reads."""
+        torch = self.be.torch
+        g = self.be.export_overlaps()
+        n = int(g["n"])
+        rec = np.zeros((n, 7), dtype=np.int64)                    # row, col, 36 bytes of Overlap padded to 40
+        if n:
+            rec[:, 0] = g["rows"]; rec[:, 1] = g["cols"]
+            v = np.zeros((n, 40), dtype=np.uint8); v[:, :36] = np.ascontiguousarray(g["vals"]).view(np.uint8).reshape(n, 36)
+            rec[:, 2:] = v.view(np.int64).reshape(n, 5)
+        local = torch.from_numpy(rec.reshape(-1).copy()).to(self.be.dev)
+        allw, ns = self._all_gather_words(local, n * 7)
+        a = allw.cpu().numpy().reshape(-1, 7)
+        rows, cols = a[:, 0].copy(), a[:, 1].copy()
+        vals = np.ascontiguousarray(a[:, 2:]).view(np.uint8).reshape(-1, 40)[:, :36].copy().view(capi.OVERLAP_DTYPE).reshape(-1)
+        order = np.lexsort((cols, rows))
+        m_total = int(self.bounds[-1])
+        self.be.set_overlaps(m_total, rows[order], cols[order], vals[order])
+        return self.be.transitive_reduction(bad_read_cutoff, fuzz)
+
+    def export_string_graph(self, local=False):
+        S = self.be.export_string_graph()
+        if local:
+            keep = (S["rows"] >= int(self.bounds[self.rank])) & (S["rows"] < int(self.bounds[self.rank + 1]))
+            S = dict(n=int(keep.sum()), rows=S["rows"][keep], cols=S["cols"][keep], vals=S["vals"][keep])
+        return S
 
     def export_csr(self):
         """This rank's rows of B (global column ids)."""

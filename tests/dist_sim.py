@@ -234,6 +234,16 @@ class NumpyBackend:
     def export_overlaps(self):
         return self.ov
 
+    def set_overlaps(self, nreads, rows, cols, vals):
+        self.edges = (nreads, rows, cols, vals)
+
+    def transitive_reduction(self, bad_read_cutoff, fuzz):
+        self.S, self.flags, st = po.string_graph(*self.edges, cutoff=bad_read_cutoff, fuzz=fuzz)
+        return st
+
+    def export_string_graph(self):
+        return self.S
+
     def synchronize(self):
         pass
 

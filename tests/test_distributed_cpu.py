@@ -20,7 +20,7 @@ K, LO, UP = 17, 2, 8
 
 
 def _reads():
-    return elba_amd.synth_reads(77, 40000, 10, 2500, 600, error_rate=0.08, min_len=100)
+    return elba_amd.synth_reads(77, 40000, 10, 2500, 600, error_rate=0.03, min_len=100)
 
 
 def _shard(packed, off, lens, lo, hi):
@@ -48,7 +48,9 @@ def _run_rank(rank, world, dist, backend, align=False):
     st = d.create_seed_matrix()
     if align:
         d.align_seeds()
-        return d.export_csr(), ks, ms, st, d.export_overlaps()
+        ov = d.export_overlaps()
+        sst = d.transitive_reduction(0.65, 1000)
+        return d.export_csr(), ks, ms, st, ov, (sst, d.export_string_graph(), d.export_string_graph(local=True))
     return d.export_csr(), ks, ms, st
 
 
@@ -96,10 +98,27 @@ def _check_alignment_union(parts):
             assert (vals[order][f] == want_v[f]).all(), f
 
 
+def _check_string_graphs(parts):
+    """every rank gathered all shares and reduced the whole graph: each holds the one-rank S; the local cuts partition it"""
+    packed, off, lens, _ = _reads()
+    o = _expected()
+    want_r, want_c, want_v, _ = o.align_upper(packed, off, lens, nthreads=2)
+    S, _, st = po.string_graph(len(lens), want_r, want_c, want_v, cutoff=0.65, fuzz=1000)
+    assert S["n"] > 0
+    for sst, whole, local in parts:
+        assert sst["nnz"] == S["n"] and (whole["rows"] == S["rows"]).all() and (whole["cols"] == S["cols"]).all()
+        for f in S["vals"].dtype.names:
+            if f != "pad":
+                assert (whole["vals"][f] == S["vals"][f]).all(), f
+    assert sum(local["n"] for _, _, local in parts) == S["n"]
+    assert sorted(zip(np.concatenate([l["rows"] for _, _, l in parts]).tolist(), np.concatenate([l["cols"] for _, _, l in parts]).tolist())) == sorted(zip(S["rows"].tolist(), S["cols"].tolist()))
+
+
 def test_three_ranks_alignment_shares_cover_every_pair_once():
     parts = dist_sim.run_ranks(3, lambda r, h: _run_rank(r, 3, h, dist_sim.NumpyBackend(K, LO, UP), align=True))
     _check_alignment_union([p[4] for p in parts])
     assert all(p[4]["n"] > 0 for p in parts)
+    _check_string_graphs([p[5] for p in parts])
 
 
 def _gloo_worker(rank, world, port, outdir):
@@ -109,9 +128,10 @@ def _gloo_worker(rank, world, port, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        B, ks, ms, st, ov = _run_rank(rank, world, dist, dist_sim.NumpyBackend(K, LO, UP), align=True)
+        B, ks, ms, st, ov, (sst, S, Sl) = _run_rank(rank, world, dist, dist_sim.NumpyBackend(K, LO, UP), align=True)
         np.savez(os.path.join(outdir, "r%d.npz" % rank), rowptr=B["rowptr"], col=B["col"], val=B["val"], reliable=ks["reliable"],
-                 arows=ov["rows"], acols=ov["cols"], avals=ov["vals"])
+                 arows=ov["rows"], acols=ov["cols"], avals=ov["vals"], snnz=sst["nnz"], srows=S["rows"], scols=S["cols"], svals=S["vals"],
+                 lrows=Sl["rows"], lcols=Sl["cols"], lvals=Sl["vals"])
     finally:
         dist.destroy_process_group()
 
@@ -126,3 +146,5 @@ def test_two_processes_over_gloo_equal_single_process_oracle(tmp_path):
     assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
     assert sum(int(p["reliable"]) for p in parts) == o.stat("N")
     _check_alignment_union([dict(rows=p["arows"], cols=p["acols"], vals=p["avals"]) for p in parts])
+    _check_string_graphs([(dict(nnz=int(p["snnz"])), dict(rows=p["srows"], cols=p["scols"], vals=p["svals"]),
+                           dict(n=len(p["lrows"]), rows=p["lrows"], cols=p["lcols"], vals=p["lvals"])) for p in parts])

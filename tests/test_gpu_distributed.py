@@ -28,6 +28,8 @@ def _run(world, reads, k, lo, up, align=False):
         if align:
             a = d.align_seeds()
             out = out + (d.export_overlaps(), a)
+            sst = d.transitive_reduction()
+            out = out + ((sst, d.export_string_graph(), d.export_string_graph(local=True)),)
         d.be.e.close()
         return out
 
@@ -88,3 +90,24 @@ def test_sharded_alignment_equals_one_rank_oracle(world):
             assert (vals[f] == want_v[f]).all(), f
     shares = [p[5]["nalignments"] for p in parts]
     assert sum(shares) == len(want_r) and min(shares) > 0.5 * max(shares)          # balanced without any exchange
+
+
+def test_string_graph_from_gathered_shares_equals_one_rank_oracle():
+    """Every rank gathers the others' aligned pairs (one all-gather), merges them and reduces the whole graph on its GPU context: each
+    holds the one-rank S of the oracle; the local cuts (rows of the rank's reads) partition it."""
+    reads = elba_amd.synth_reads(34, 100000, 12, 3000, 700, error_rate=0.02, min_len=300)
+    o = po.Oracle(17, 2, 12)
+    o.count_and_build(*reads[:3])
+    o.spgemm(4)
+    want_r, want_c, want_v, _ = o.align_upper(reads[0], reads[1], reads[2], nthreads=8)
+    S, _, st = po.string_graph(len(reads[2]), want_r, want_c, want_v)
+    assert S["n"] > 0 and st["marked"] > 0
+    parts = _run(3, reads, 17, 2, 12, align=True)
+    for p in parts:
+        sst, whole, local = p[6]
+        assert all(sst[k] == st[k] for k in ("bad_reads", "contained_reads", "edges_kept", "products", "marked", "removed", "nnz"))
+        assert (whole["rows"] == S["rows"]).all() and (whole["cols"] == S["cols"]).all()
+        for f in S["vals"].dtype.names:
+            if f != "pad":
+                assert (whole["vals"][f] == S["vals"][f]).all(), f
+    assert sum(p[6][2]["n"] for p in parts) == S["n"]
