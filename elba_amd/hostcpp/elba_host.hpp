@@ -15,6 +15,9 @@
 //                                                                             the reads are 2-bit encoded on the GPU (elba_set_reads_fasta)
 //   PairwiseAlignment    include/PairwiseAlignment.hpp, src/PairwiseAlignment.cpp:5-106     same name -> elba::OverlapMatrix (triples of elba::Overlap)
 //   Bmat.seqptr()->getnnz() / GetDCSC()  src/PairwiseAlignment.cpp:16-19   SeedMatrix::seqptr()->getnnz() / GetDCSC()
+//   find_bad_reads / find_contained_reads / TransitiveReduction   src/main.cpp:305-312, src/TransitiveReduction.cpp:3-90
+//                                                                             elba::TransitiveReduction(R, cutoff): the prunes and the reduction in one
+//                                                                             call on the GPU -> elba::StringGraph (S + the two read lists)
 //
 // Errors: the reference asserts/aborts; here every failing C-ABI status throws elba::Error (status + text).
 // There is no CPU path: constructing an engine without a GPU throws ELBA_ERR_NO_DEVICE.
@@ -327,6 +330,7 @@ public:
     std::vector<int64_t> rows, cols;
     std::vector<Overlap> vals;
     elba_align_stats stats{};
+    std::shared_ptr<detail::Engine> engine;  // the alignments stay on the device for the string-graph stage
     int64_t getnnz() const { return (int64_t)vals.size(); }
 };
 
@@ -337,6 +341,7 @@ inline std::unique_ptr<OverlapMatrix> PairwiseAlignment(const DnaBuffer &myreads
 {
     auto R = std::make_unique<OverlapMatrix>();
     R->numreads = Bmat.getnrow();
+    R->engine = Bmat.engine;
     Bmat.engine->check(elba_align_seeds(Bmat.engine->ctx, mat, mis, gap, dropoff, &R->stats));
     elba_overlaps_t o;
     Bmat.engine->check(elba_export_overlaps(Bmat.engine->ctx, &o));
@@ -353,6 +358,48 @@ inline std::unique_ptr<OverlapMatrix> PairwiseAlignment(const DnaBuffer &myreads
     }
     elba_free_overlaps(&o);
     return R;
+}
+
+// The string graph S of src/main.cpp:312 with what main() derives on the way: the reads find_bad_reads (:305) and find_contained_reads
+// (:310) return.  Entries in the order parallel_write_paf walks S (:527-541): columns ascending, rows ascending within a column.
+class StringGraph {
+public:
+    int64_t numreads = 0;
+    std::vector<int64_t> rows, cols;
+    std::vector<Overlap> vals;
+    std::vector<int64_t> bad_reads, contained_reads;
+    elba_string_stats stats{};
+    int64_t getnnz() const { return (int64_t)vals.size(); }
+};
+
+// src/main.cpp:305-312 — bad_reads = find_bad_reads(*R, cutoff); R->Prune(!passed); R->PruneFull(bad_reads, bad_reads);
+// contained = find_contained_reads(*R); R->PruneFull(contained, contained); S = TransitiveReduction(*R) — as one call on the
+// alignments PairwiseAlignment left on the device.  R itself is not modified (the reference prunes it in place and then drops it).
+inline std::unique_ptr<StringGraph> TransitiveReduction(const DnaBuffer &myreads, OverlapMatrix &R, double bad_read_cutoff, int fuzz = 1000)
+{
+    auto S = std::make_unique<StringGraph>();
+    S->numreads = R.numreads;
+    R.engine->check(elba_transitive_reduction(R.engine->ctx, bad_read_cutoff, fuzz, &S->stats));
+    elba_overlaps_t o;
+    R.engine->check(elba_export_string_graph(R.engine->ctx, &o));
+    S->rows.assign(o.rows, o.rows + o.n); S->cols.assign(o.cols, o.cols + o.n);
+    S->vals.resize((size_t)o.n);
+    for (int64_t a = 0; a < o.n; ++a) {
+        const elba_overlap_t &v = o.vals[a];
+        Overlap &w = S->vals[(size_t)a];
+        w.beg = std::make_tuple((PosInRead)v.begQ, (PosInRead)v.begT); w.end = std::make_tuple((PosInRead)v.endQ, (PosInRead)v.endT);
+        w.len = std::make_tuple((PosInRead)myreads.lengths()[o.rows[a]], (PosInRead)myreads.lengths()[o.cols[a]]);
+        w.score = v.score; w.suffix = v.suffix; w.suffixT = v.suffixT; w.direction = v.direction; w.directionT = v.directionT;
+        w.rc = v.rc; w.passed = v.passed; w.containedQ = v.containedQ; w.containedT = v.containedT;
+    }
+    elba_free_overlaps(&o);
+    std::vector<uint8_t> flags((size_t)R.numreads);
+    R.engine->check(elba_export_read_flags(R.engine->ctx, flags.data(), R.numreads));
+    for (int64_t v = 0; v < R.numreads; ++v) {
+        if (flags[(size_t)v] & 1) S->bad_reads.push_back(v);
+        if (flags[(size_t)v] & 2) S->contained_reads.push_back(v);
+    }
+    return S;
 }
 
 }  // namespace elba

@@ -74,8 +74,18 @@ int main(int argc, char **argv)
             achk += (uint64_t)(uint32_t)o.score * 1000003ull + std::get<0>(o.beg) * 31ull + std::get<1>(o.beg) * 37ull + std::get<0>(o.end) * 41ull + std::get<1>(o.end) * 43ull
                     + (uint64_t)(o.rc ? 7 : 0) + (uint64_t)(uint8_t)o.direction * 131ull + (uint64_t)(uint32_t)o.suffix * 8191ull + (uint64_t)R->rows[a] * 3ull + (uint64_t)R->cols[a];
         }
-        std::printf("{\"reads\": %zu, \"nnzA\": %lld, \"kmers\": %lld, \"nnzB\": %zu, \"candidates\": %lld, \"checksum\": %llu, \"alignments\": %lld, \"passed\": %lld, \"align_checksum\": %llu, \"ingest_equal\": %d}\n", mydna.size(),
-                    (long long)nnzA, (long long)ncol, localnnzs, (long long)nalign, (unsigned long long)checksum, (long long)R->getnnz(), (long long)npassed, (unsigned long long)achk, ingest_equal);
+        // main.cpp:305-312 with bad_read_cutoff of main.cpp:61
+        auto S = elba::TransitiveReduction(mydna, *R, 0.65);
+        uint64_t schk = 0;
+        for (size_t a = 0; a < S->vals.size(); ++a) {
+            const elba::Overlap &o = S->vals[a];
+            schk += (uint64_t)S->rows[a] * 1000003ull + (uint64_t)S->cols[a] * 31ull + (uint64_t)(uint8_t)o.direction * 131ull + (uint64_t)(uint32_t)o.suffix * 8191ull
+                    + std::get<0>(o.beg) * 37ull + std::get<1>(o.end) * 43ull + std::get<0>(o.len) * 3ull + std::get<1>(o.len) + (uint64_t)a * 7ull;
+        }
+        std::printf("{\"reads\": %zu, \"nnzA\": %lld, \"kmers\": %lld, \"nnzB\": %zu, \"candidates\": %lld, \"checksum\": %llu, \"alignments\": %lld, \"passed\": %lld, \"align_checksum\": %llu, \"ingest_equal\": %d, "
+                    "\"bad_reads\": %zu, \"contained_reads\": %zu, \"string_nnz\": %lld, \"string_checksum\": %llu}\n", mydna.size(),
+                    (long long)nnzA, (long long)ncol, localnnzs, (long long)nalign, (unsigned long long)checksum, (long long)R->getnnz(), (long long)npassed, (unsigned long long)achk, ingest_equal,
+                    S->bad_reads.size(), S->contained_reads.size(), (long long)S->getnnz(), (unsigned long long)schk);
     } catch (const elba::Error &e) {
         std::fprintf(stderr, "%s\n", e.what());
         return e.status == ELBA_ERR_NO_DEVICE ? 3 : 1;

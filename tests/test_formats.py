@@ -67,3 +67,23 @@ def test_overlap_and_paf_lines(tmp_path):
     t = open(p).read().split("\n")[a].split("\t")
     assert t[0] == names[i] and t[5] == names[j] and int(t[9]) == int(ov[a]["score"]) and t[11] == "255" and t[12] == "1"
     assert int(t[10]) == max(int(ov[a]["endQ"]) - int(ov[a]["begQ"]), 0)                # the reference's maplen expression (src/main.cpp:536)
+
+
+def test_string_paf_lists_the_reduced_graph_in_the_reference_order(tmp_path):
+    """parallel_write_paf(*S, ...) (src/main.cpp:315): S's entries column by column; a line below the diagonal carries the transposed
+    record (query = the row's read)."""
+    seqs, buf, off, lens, o = _oracle("small_clean")
+    rows, cols, ov, _ = o.align_upper(buf, off, lens)
+    S, flags, st = po.string_graph(len(lens), rows, cols, ov, cutoff=0.0)
+    assert S["n"] >= 10 and st["removed"] > 0
+    names = ["r%d" % x for x in range(len(seqs))]
+    p = str(tmp_path / "out.string.paf")
+    fm.write_paf(p, S, names, lens)
+    L = [x.split("\t") for x in open(p).read().split("\n") if x]
+    assert len(L) == S["n"] == st["nnz"]
+    keys = [(int(c), int(r)) for r, c in zip(S["rows"], S["cols"])]
+    assert keys == sorted(keys)
+    for a, t in enumerate(L):
+        i, j = int(S["rows"][a]), int(S["cols"][a])
+        assert t[0] == names[i] and int(t[1]) == int(lens[i]) and t[5] == names[j] and int(t[6]) == int(lens[j]) and t[12] == "1"
+        assert int(t[2]) == int(S["vals"][a]["begQ"]) and int(t[7]) == int(S["vals"][a]["begT"])

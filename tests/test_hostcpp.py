@@ -57,8 +57,16 @@ def test_mirror_matches_oracle_on_gpu(name, idx):
                 + ov["rc"].astype(np.uint64) * np.uint64(7) + u(ov["direction"], np.uint8) * np.uint64(131) + u(ov["suffix"]) * np.uint64(8191)
                 + ar.astype(np.uint64) * np.uint64(3) + ac.astype(np.uint64))
         achk = int(achk.sum(dtype=np.uint64))
+    S, flags, sst = po.string_graph(len(lens), ar, ac, ov, cutoff=0.65, fuzz=1000)
+    with np.errstate(over="ignore"):
+        sv = S["vals"]
+        schk = (S["rows"].astype(np.uint64) * np.uint64(1000003) + S["cols"].astype(np.uint64) * np.uint64(31) + u(sv["direction"], np.uint8) * np.uint64(131)
+                + u(sv["suffix"]) * np.uint64(8191) + u(sv["begQ"]) * np.uint64(37) + u(sv["endT"]) * np.uint64(43) + lens[S["rows"]].astype(np.uint64) * np.uint64(3)
+                + lens[S["cols"]].astype(np.uint64) + np.arange(S["n"], dtype=np.uint64) * np.uint64(7))
+        schk = int(schk.sum(dtype=np.uint64))
     want = {"reads": m["M"], "nnzA": m["Z"], "kmers": m["N"], "nnzB": m["Y"], "candidates": o.stat("nupper"), "checksum": checksum,
-            "alignments": len(ar), "passed": int(ov["passed"].sum()), "align_checksum": achk, "ingest_equal": -1}
+            "alignments": len(ar), "passed": int(ov["passed"].sum()), "align_checksum": achk, "ingest_equal": -1,
+            "bad_reads": sst["bad_reads"], "contained_reads": sst["contained_reads"], "string_nnz": S["n"], "string_checksum": schk}
     assert got == want
     # the same run fed through the C++ FastaIndex mirror and the GPU encoder (reads.fa.fai next to a copy of the FASTA)
     import shutil, tempfile
