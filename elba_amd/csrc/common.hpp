@@ -151,6 +151,7 @@ struct Ctx {
     DevBuf a_roworder;                         // u32[M] rows by descending product count (queue order of the SpGEMM)
     DevBuf a_cscp;                             // u64[Z] columns in first-occurrence order (hot-loop copy of a_csc; see matrix.hip)
     bool a_cscp_is_csc = true;
+    DevBuf a_cscj;                             // u32[Z + 8] the partner read of every entry of a_cscp: all the numeric loop needs of an entry (half the bytes, four per 16-byte load)
     DevBuf a_newstart;                         // u32[N] address of every column in a_cscp
     int64_t row_lo = 0, row_hi = -1;           // rows of B computed by this context (-1: all)
     // rows of an A built from reads are local read indices; exported triples carry global ids (src/KmerOps.cpp:215-219)

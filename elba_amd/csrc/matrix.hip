@@ -119,6 +119,14 @@ __global__ void k_roworder_keys(const RowHot *hdr, uint64_t M, uint64_t *keys, u
     vals[i] = i;
 }
 
+// partner read of every column entry (+ guard entries), the numeric loop's gather target
+__global__ void k_high_u32(const uint64_t *in, uint64_t n, uint64_t nguard, uint32_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint32_t)(in[i] >> 32);
+    else if (i < n + nguard) out[i] = 0xFFFFFFFFu;
+}
+
 __global__ void k_narrow_u32(const uint64_t *in, uint64_t n, uint32_t *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -279,6 +287,8 @@ static void build_row_descriptors(Ctx &c)
     c.a_roworder.reserve((size_t)(M + 1) * 4);
     if (M == 0) return;
     const uint64_t *cols = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
+    c.a_cscj.reserve((size_t)(Z + 8) * 4);
+    hipLaunchKernelGGL(k_high_u32, dim3((unsigned)((Z + 8 + 255) / 256)), dim3(256), 0, s, cols, (uint64_t)Z, (uint64_t)8, c.a_cscj.as<uint32_t>());
     const uint32_t lo = (uint32_t)c.row_lo, hi = (uint32_t)(c.row_hi < 0 ? M : c.row_hi);
     int nb = (int)((hi - lo + 3) / 4);
     if (nb > c.num_cus * 8) nb = c.num_cus * 8;

@@ -70,7 +70,7 @@ struct OvCounters {              // device-side counters, zeroed per call
 struct alignas(32) StageRec { uint4 a, b; };
 
 struct OvParams {
-    const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_roworder;
+    const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_cscj; const uint32_t *a_roworder;
     const RowHot *a_hdr; const HotDesc *a_hot; const uint64_t *a_dec;   // per-row bounds, per-entry partner ranges, seed decoding by canonical rank (matrix.hip)
     uint32_t M;              // number of rows of A held here
     uint32_t Mcols;          // number of reads overall (partner id range)
@@ -468,6 +468,7 @@ void stage_create_seed_matrix(Ctx &c)
     p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
     p.a_hdr = c.a_hdr.as<RowHot>(); p.a_hot = c.a_hot.as<HotDesc>(); p.a_dec = c.a_dec.as<uint64_t>();
     p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
+    p.a_cscj = c.a_cscj.as<uint32_t>();
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.half = c.half ? 1u : 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;

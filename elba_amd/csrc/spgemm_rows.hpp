@@ -269,17 +269,23 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     // equally long ranges and the trips beyond the first PK entries are wave-uniform and rare.
     // Two trips are kept in flight: (dc, ce) is the trip being accumulated, (d1, ce1) the one after it.
     uint4 dc = make_uint4(0u, 0u, 0u, 0u), d1 = dc;
-    uint64_t ce[PK], ce1[PK];
+    uint32_t ce[PK], ce1[PK];              // partner reads of the trip's first PK range entries
     auto load_desc = [&](uint32_t hs, uint32_t at, uint32_t nd) {
         const uint32_t t = at + tid;
         return t < nd ? reinterpret_cast<const uint4 *>(p.a_hot)[hs + t] : make_uint4(0u, 0u, 0u, 0u);
     };
-    auto gather = [&](uint64_t *out, const uint4 &d, uint32_t r0) {       // (only the lanes whose range reaches entry r0 + k load it: every divergent lane costs the texture unit a cycle)
-#pragma unroll
-        for (int k = 0; k < PK; ++k) out[k] = r0 + (uint32_t)k < d.z ? p.a_cscp[d.x + r0 + (uint32_t)k] : 0ull;
+    // ONE 16-byte load per lane: the partner reads of four consecutive range entries (a_cscj holds nothing else; the load is 4-byte
+    // aligned and may run past the range — the surplus is never used, and the array ends in guard entries).  Only the lanes whose
+    // range reaches entry r0 load: every divergent lane costs the texture unit a cycle.
+    static_assert(PK == 4, "one 16-byte load carries PK = 4 partner reads");
+    struct __attribute__((packed, aligned(4))) Quad { uint32_t a, b, c, d; };
+    auto gather = [&](uint32_t *out, const uint4 &d, uint32_t r0) {
+        Quad q{0u, 0u, 0u, 0u};
+        if (r0 < d.z) q = *reinterpret_cast<const Quad *>(p.a_cscj + d.x + r0);
+        out[0] = q.a; out[1] = q.b; out[2] = q.c; out[3] = q.d;
         if (DIAG && (dbg & 2u)) {                                   // ablation: synthetic partner ids
 #pragma unroll
-            for (int k = 0; k < PK; ++k) out[k] = (uint64_t)(((d.x + r0 + (uint32_t)k) * 2654435761u) % p.Mcols) << 32;
+            for (int k = 0; k < PK; ++k) out[k] = ((d.x + r0 + (uint32_t)k) * 2654435761u) % p.Mcols;
         }
     };
     const uint32_t *queue = p.lists + (size_t)tier * p.M;
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 const bool more = t0 + BLOCK < nd, more2 = t0 + 2 * BLOCK < nd;
                 uint32_t jv[PK];
 #pragma unroll
-                for (int k = 0; k < PK; ++k) jv[k] = (uint32_t)(ce[k] >> 32);
+                for (int k = 0; k < PK; ++k) jv[k] = ce[k];
                 const uint32_t c = dc.z, sy = dc.y, x0 = dc.x;
                 dup += dc.w;
                 uint4 dnx = d1;
@@ -406,11 +412,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 }
 #pragma unroll 1
                 for (uint32_t r0 = PK; __ballot(c > r0) != 0; r0 += PK) {      // ranges longer than PK entries: they come first in a row
-                    uint64_t cx[PK];
+                    uint32_t cx[PK];
+                    { uint4 dx = make_uint4(x0, 0u, c, 0u); gather(cx, dx, r0); }
 #pragma unroll
-                    for (int k = 0; k < PK; ++k) cx[k] = r0 + (uint32_t)k < c ? p.a_cscp[x0 + r0 + (uint32_t)k] : 0ull;
-#pragma unroll
-                    for (int k = 0; k < PK; ++k) { const uint32_t sq = sy + r0 + (uint32_t)k; tab.insert_lds((uint32_t)(cx[k] >> 32), sq, sq, 1u, r0 + (uint32_t)k < c, full); }
+                    for (int k = 0; k < PK; ++k) { const uint32_t sq = sy + r0 + (uint32_t)k; tab.insert_lds(cx[k], sq, sq, 1u, r0 + (uint32_t)k < c, full); }
                 }
                 if (tab.abandoned()) {
                     if (tid == 0) { const uint32_t done = t0 + BLOCK; misc[11] = done < nd ? done : nd; }
@@ -433,24 +438,24 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 if (DIAG && (dbg & 1u)) {                                   // ablation: gathers only, keep the loads alive
                     uint32_t sink = 0;
 #pragma unroll
-                    for (int k = 0; k < PK; ++k) sink ^= (uint32_t)(ce[k] >> 32);
+                    for (int k = 0; k < PK; ++k) sink ^= ce[k];
                     if (sink == 0xFFFFFFFFu) misc[15] = 1;
                 } else if (GLOBAL) {
 #pragma unroll
                     for (int k = 0; k < PK; k += 2) {
                         if (r0 + (uint32_t)k < c)
-                            tab.insert2((uint32_t)(ce[k] >> 32), dc.y + r0 + (uint32_t)k, (uint32_t)(ce[k + 1] >> 32), dc.y + r0 + (uint32_t)k + 1u, r0 + (uint32_t)k + 1u < c, full);
+                            tab.insert2(ce[k], dc.y + r0 + (uint32_t)k, ce[k + 1], dc.y + r0 + (uint32_t)k + 1u, r0 + (uint32_t)k + 1u < c, full);
                     }
                 } else {
                     // dense trip?  (most lanes hold the same partner as their left neighbour: decided per trip and wavefront, on the first entries)
-                    const uint32_t j0 = (uint32_t)(ce[0] >> 32);
+                    const uint32_t j0 = ce[0];
                     const uint32_t jl = (uint32_t)__builtin_amdgcn_update_dpp((int)~j0, (int)j0, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
                     if (__popcll(__ballot(r0 < c && j0 == jl)) >= DENSE_LANES) {
 #pragma unroll
-                        for (int k = 0; k < PK; ++k) tab.insert_runs((uint32_t)(ce[k] >> 32), dc.y + r0 + (uint32_t)k, r0 + (uint32_t)k < c, full);
+                        for (int k = 0; k < PK; ++k) tab.insert_runs(ce[k], dc.y + r0 + (uint32_t)k, r0 + (uint32_t)k < c, full);
                     } else {
 #pragma unroll
-                        for (int k = 0; k < PK; ++k) { const uint32_t sq = dc.y + r0 + (uint32_t)k; tab.insert_lds((uint32_t)(ce[k] >> 32), sq, sq, 1u, r0 + (uint32_t)k < c, full); }
+                        for (int k = 0; k < PK; ++k) { const uint32_t sq = dc.y + r0 + (uint32_t)k; tab.insert_lds(ce[k], sq, sq, 1u, r0 + (uint32_t)k < c, full); }
                     }
                 }
                 r0 += PK;
