@@ -119,6 +119,15 @@ __global__ void k_roworder_keys(const RowHot *hdr, uint64_t M, uint64_t *keys, u
     vals[i] = i;
 }
 
+// 16-byte descriptors -> 8-byte words (the dominant stream of the SpGEMM's numeric loop: half the bytes, half the cache lines)
+__global__ void k_pack_desc(const HotDesc *in, uint64_t n, uint32_t xb, uint32_t yb, uint32_t zb, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const HotDesc d = in[i];
+    out[i] = (uint64_t)d.x | (uint64_t)d.y << xb | (uint64_t)d.z << (xb + yb) | (uint64_t)d.w << (xb + yb + zb);
+}
+
 // partner read of every column entry (+ guard entries), the numeric loop's gather target
 __global__ void k_high_u32(const uint64_t *in, uint64_t n, uint64_t nguard, uint32_t *out)
 {
@@ -338,6 +347,16 @@ static void build_row_descriptors(Ctx &c)
     hipLaunchKernelGGL(k_roworder_keys, dim3(nbM), dim3(256), 0, s, c.a_hdr.as<RowHot>(), (uint64_t)M, k0, v0);
     int wr = radix_sort_pairs(s, k0, v0, k1, v1, M, 0, 32, c.ws_sort);
     hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? v1 : v0, (uint64_t)M, c.a_roworder.as<uint32_t>());
+    // packed form: x < Z + 8, y < max_row_nnz << fbits, z <= max_col_nnz, w < max_col_nnz
+    {
+        const uint32_t xb = (uint32_t)bits_for((uint64_t)Z + 8), yb = (uint32_t)bits_for((uint64_t)(c.max_row_nnz > 0 ? c.max_row_nnz : 1)) + c.fbits, zb = (uint32_t)bits_for((uint64_t)cmax + 1);
+        c.hot_xb = 0;
+        if (xb + yb + 2 * zb <= 64 && xb <= 32 && yb <= 32 && !getenv("ELBA_DESC16")) {
+            c.a_hot8.reserve((size_t)(H + 1) * 8);
+            if (H > 0) hipLaunchKernelGGL(k_pack_desc, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, s, c.a_hot.as<HotDesc>(), (uint64_t)H, xb, yb, zb, c.a_hot8.as<uint64_t>());
+            c.hot_xb = xb; c.hot_yb = yb; c.hot_zb = zb;
+        }
+    }
     // products the descriptors stand for (statistics only)
     std::vector<RowHot> hh((size_t)M);
     ELBA_HIP(hipMemcpyAsync(hh.data(), c.a_hdr.p, (size_t)M * sizeof(RowHot), hipMemcpyDeviceToHost, s));

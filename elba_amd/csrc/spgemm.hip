@@ -76,6 +76,7 @@ struct OvParams {
     uint32_t Mcols;          // number of reads overall (partner id range)
     uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
+    const uint64_t *a_hot8; uint32_t hot_xb, hot_yb, hot_zb;   // 8-byte descriptors (hot_xb != 0) instead of a_hot
     uint32_t half;           // 1: the schedule lists an in-window pair on its smaller row only; survivors are mirrored into the partner's row
     uint32_t tier_limit[NUM_LDS_TIERS];   // claimed slots at which a row abandons the tier: min(3T/4, T - BLOCK) - 1 (every lane can overshoot by one claim)
     uint32_t use_feedback;   // 1 on the first call for a matrix (no measured prior yet): in-call self-correction through the hot fb_* sums
@@ -469,6 +470,7 @@ void stage_create_seed_matrix(Ctx &c)
     p.a_hdr = c.a_hdr.as<RowHot>(); p.a_hot = c.a_hot.as<HotDesc>(); p.a_dec = c.a_dec.as<uint64_t>();
     p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
     p.a_cscj = c.a_cscj.as<uint32_t>();
+    p.a_hot8 = c.a_hot8.as<uint64_t>(); p.hot_xb = c.hot_xb; p.hot_yb = c.hot_yb; p.hot_zb = c.hot_zb;
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.half = c.half ? 1u : 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;

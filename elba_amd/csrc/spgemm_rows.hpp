@@ -270,9 +270,28 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
     // Two trips are kept in flight: (dc, ce) is the trip being accumulated, (d1, ce1) the one after it.
     uint4 dc = make_uint4(0u, 0u, 0u, 0u), d1 = dc;
     uint32_t ce[PK], ce1[PK];              // partner reads of the trip's first PK range entries
+    // A descriptor travels raw (d1, d2: in flight) and is unpacked where it is first used (dc): unpacking at the load would put the
+    // wait for the load right behind it.  Packed form: 8 bytes, field widths from the matrix (matrix.hip); otherwise the 16-byte form.
+    const bool packed = p.hot_xb != 0;
+    const uint32_t xb = p.hot_xb, yb = p.hot_yb, zb = p.hot_zb;
     auto load_desc = [&](uint32_t hs, uint32_t at, uint32_t nd) {
         const uint32_t t = at + tid;
-        return t < nd ? reinterpret_cast<const uint4 *>(p.a_hot)[hs + t] : make_uint4(0u, 0u, 0u, 0u);
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (t < nd) {
+            if (packed) { const uint2 q = reinterpret_cast<const uint2 *>(p.a_hot8)[hs + t]; r.x = q.x; r.y = q.y; }
+            else r = reinterpret_cast<const uint4 *>(p.a_hot)[hs + t];
+        }
+        return r;
+    };
+    auto unpack = [&](const uint4 &r) {
+        if (!packed) return r;
+        const uint64_t q = ((uint64_t)r.y << 32) | r.x;
+        uint4 d;
+        d.x = (uint32_t)q & (uint32_t)((1ull << xb) - 1);
+        d.y = (uint32_t)(q >> xb) & (uint32_t)((1ull << yb) - 1);
+        d.z = (uint32_t)(q >> (xb + yb)) & ((1u << zb) - 1u);
+        d.w = (uint32_t)(q >> (xb + yb + zb));
+        return d;
     };
     // ONE 16-byte load per lane: the partner reads of four consecutive range entries (a_cscj holds nothing else; the load is 4-byte
     // aligned and may run past the range — the surplus is never used, and the array ends in guard entries).  Only the lanes whose
@@ -304,8 +323,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         request_hdr(id0);
         cur = take_hdr(id0);
         if (qidx(1) < nrows) id_n = queue[qidx(1)];
-        dc = load_desc(cur.hs, 0u, cur.nd); if (PIPE >= 2) d1 = load_desc(cur.hs, BLOCK, cur.nd);
-        gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u);
+        dc = unpack(load_desc(cur.hs, 0u, cur.nd)); if (PIPE >= 2) d1 = load_desc(cur.hs, BLOCK, cur.nd);
+        gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, unpack(d1), 0u);
     }
     for (uint32_t rnd = 0; qidx(rnd) < nrows; ++rnd) {
         const bool has_n = qidx(rnd + 1) < nrows;
@@ -314,7 +333,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         const uint32_t i = cur.i, rs = cur.rs, hs = cur.hs, nd = cur.nd;
         const uint32_t ub_i = cur.work;                      // products of the row's descriptors: bounds its distinct partners
         // leaves this row early: the next row's prefetch is issued back to back
-#define ELBA_NEXT_ROW() do { if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE >= 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u); } cur = nxt; id_n = id_nn; } while (0)
+#define ELBA_NEXT_ROW() do { if (has_n) { nxt = take_hdr(id_n); dc = unpack(load_desc(nxt.hs, 0u, nxt.nd)); if (PIPE >= 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, unpack(d1), 0u); } cur = nxt; id_n = id_nn; } while (0)
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call: rows already done (here or on lower tiers) tell how many distinct partners a product
             // brings on THIS data; a row that is predicted not to fit is forwarded without an attempt.
@@ -394,9 +413,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 for (int k = 0; k < PK; ++k) jv[k] = ce[k];
                 const uint32_t c = dc.z, sy = dc.y, x0 = dc.x;
                 dup += dc.w;
-                uint4 dnx = d1;
+                uint4 draw = d1;
                 static_assert(PK == 4, "the consume point names PK registers");
-                asm volatile("" : "+v"(jv[0]), "+v"(jv[1]), "+v"(jv[2]), "+v"(jv[3]), "+v"(dnx.x) : : "memory");       // (1) everything requested so far has landed
+                asm volatile("" : "+v"(jv[0]), "+v"(jv[1]), "+v"(jv[2]), "+v"(jv[3]), "+v"(draw.x) : : "memory");      // (1) everything requested so far has landed
+                const uint4 dnx = unpack(draw);
                 uint4 d2 = make_uint4(0u, 0u, 0u, 0u);
                 if (more) gather(ce, dnx, 0u);                                                                       // (2)
                 if (more2) d2 = load_desc(hs, t0 + 2 * BLOCK, nd);
@@ -469,13 +489,13 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             }
             if (more) {
                 if (PIPE == 2) {
-                    dc = d1;
+                    dc = unpack(d1);
 #pragma unroll
                     for (int k = 0; k < PK; ++k) ce[k] = ce1[k];
                     d1 = d2;
-                    if (more2) gather(ce1, d1, 0u);
+                    if (more2) gather(ce1, unpack(d1), 0u);
                 } else {
-                    dc = d2;
+                    dc = unpack(d2);
                     gather(ce, dc, 0u);
                 }
             }
@@ -499,7 +519,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             ELBA_NEXT_ROW();
             continue;
         }
-        if (has_n) { nxt = take_hdr(id_n); dc = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE >= 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); }       // next row, first two trips' descriptors: in flight during the sweep
+        uint4 dc_raw = make_uint4(0u, 0u, 0u, 0u);
+        if (has_n) { nxt = take_hdr(id_n); dc_raw = load_desc(nxt.hs, 0u, nxt.nd); if (PIPE >= 2) d1 = load_desc(nxt.hs, BLOCK, nxt.nd); }   // next row, first two trips' descriptors: in flight during the sweep
 
         // ---- level 3: one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
@@ -549,7 +570,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         if (!(DIAG && (dbg & 512u))) lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_STAMP(4);
-        if (has_n) { gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, d1, 0u); }    // next row, first two trips' partner entries: in flight during the decode
+        if (has_n) { dc = unpack(dc_raw); gather(ce, dc, 0u); if (PIPE == 2) gather(ce1, unpack(d1), 0u); }    // next row, first two trips' partner entries: in flight during the decode
         if (misc[8]) {
             // ---- level 4: all survivors decode their seeds in parallel ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
