@@ -270,6 +270,15 @@ __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit(EnumParams e, uint64_t
     for_each_instance(e, [&](uint64_t g, uint32_t r, uint32_t p, uint64_t km) { keys[g] = km; vals[g] = ((uint64_t)r << 32) | p; });
 }
 
+// One word per instance: canonical value (right-aligned) << ib | instance index.  The index is the payload: (read, pos) follow from it
+// through the instance offsets, and they are needed for the few instances that survive the count filter only — the sort moves
+// 8 bytes per instance instead of 16.
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit_packed(EnumParams e, int ib, uint64_t *words)
+{
+    const int k2 = 2 * e.k;
+    for_each_instance(e, [&](uint64_t g, uint32_t, uint32_t, uint64_t km) { words[g] = ((km >> (64 - k2)) << ib) | g; });
+}
+
 __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit2(EnumParams e, uint64_t *khi, uint64_t *klo, uint64_t *vals, uint64_t *idx)
 {
     for_each_position(e, [&](uint64_t g, uint32_t r, uint32_t p) {
@@ -295,11 +304,12 @@ __global__ void k_gather_u64(const uint64_t *idx, const uint64_t *in, uint64_t n
 }
 
 // flag[g] = 1 where a run of equal k-mers starts (flag[I] = 1 closes the last run); keys_lo: second word of two-word k-mers, or null
-__global__ void k_run_flags(const uint64_t *keys, const uint64_t *keys_lo, const uint64_t *keys_lo2, uint64_t I, uint32_t *flag)
+// (ib > 0: packed words, the k-mer value sits above the ib index bits)
+__global__ void k_run_flags(const uint64_t *keys, const uint64_t *keys_lo, const uint64_t *keys_lo2, uint64_t I, uint32_t *flag, int ib)
 {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g > I) return;
-    flag[g] = (g == 0 || g == I || keys[g] != keys[g - 1] || (keys_lo && keys_lo[g] != keys_lo[g - 1]) || (keys_lo2 && keys_lo2[g] != keys_lo2[g - 1])) ? 1u : 0u;
+    flag[g] = (g == 0 || g == I || (keys[g] >> ib) != (keys[g - 1] >> ib) || (keys_lo && keys_lo[g] != keys_lo[g - 1]) || (keys_lo2 && keys_lo2[g] != keys_lo2[g - 1])) ? 1u : 0u;
 }
 
 // headpos[run] = first instance of the run; headpos[nruns] = I
@@ -321,16 +331,31 @@ __global__ void k_run_select(const uint32_t *headpos, uint64_t nruns, uint32_t l
 }
 
 // reliable run -> column kid: k-mer value, count, column pointer, entries (already in (read, pos) order: the sort is stable)
+// Packed words (ib > 0, vals == nullptr): the value is shifted back to its left-aligned form and an entry's (read, pos) is looked up
+// from its instance index in the instance offsets (binary search over the reads; the offsets stay in L2).
 __global__ void k_emit_columns(const uint64_t *keys, const uint64_t *keys_lo, const uint64_t *keys_lo2, const uint64_t *vals, const uint32_t *headpos, const uint32_t *relflag, const uint32_t *kidx, const uint32_t *cptr,
-                               uint64_t nruns, uint64_t *rel_kmers, uint64_t *rel_kmers_lo, uint64_t *rel_kmers_lo2, uint32_t *rel_counts, uint32_t *colptr, uint64_t *csc)
+                               uint64_t nruns, uint64_t *rel_kmers, uint64_t *rel_kmers_lo, uint64_t *rel_kmers_lo2, uint32_t *rel_counts, uint32_t *colptr, uint64_t *csc,
+                               int ib, int k2, const uint64_t *inst_off, uint32_t nreads)
 {
     const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= nruns || !relflag[u]) return;
     const uint32_t kid = kidx[u], h = headpos[u], c = headpos[u + 1] - h, at = cptr[u];
-    rel_kmers[kid] = keys[h]; rel_counts[kid] = c; colptr[kid] = at;
+    rel_kmers[kid] = ib ? (keys[h] >> ib) << (64 - k2) : keys[h]; rel_counts[kid] = c; colptr[kid] = at;
     if (keys_lo) rel_kmers_lo[kid] = keys_lo[h];
     if (keys_lo2) rel_kmers_lo2[kid] = keys_lo2[h];
-    for (uint32_t t = 0; t < c; ++t) csc[at + t] = vals[h + t];
+    if (!ib) { for (uint32_t t = 0; t < c; ++t) csc[at + t] = vals[h + t]; return; }
+    for (uint32_t t = 0; t < c; ++t) csc[at + t] = keys[h + t] & ((1ull << ib) - 1);      // instance index: turned into (read, pos) by k_instance_entries
+}
+
+// instance index -> read << 32 | pos, one lane per entry (binary search over the reads' instance offsets, which stay in L2)
+__global__ void k_instance_entries(uint64_t *csc, uint64_t Z, const uint64_t *inst_off, uint32_t nreads)
+{
+    const uint64_t z = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    const uint64_t g = csc[z];
+    uint32_t lo = 0, hi = nreads;                                   // last read with inst_off[read] <= g
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (inst_off[mid] <= g) lo = mid; else hi = mid; }
+    csc[z] = ((uint64_t)lo << 32) | (uint32_t)(g - inst_off[lo]);
 }
 
 __global__ void k_column_ids(const uint32_t *colptr, uint64_t *kid_keys, uint64_t N)
@@ -360,14 +385,14 @@ EnumParams make_enum(Ctx &c)
 // Sorted (k-mer, value) pairs -> runs -> reliable columns: rel_kmers / rel_counts / a_colptr / a_csc of the context (see the file header).
 // spare_k / spare_v: the sort's other buffer pair (2 (I + 2) u32 each), free once the sort is done.  Needs c.ws_e (I + 2 u32) and c.ws_f (I + 2 u64).
 static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals, uint64_t *spare_k, uint64_t *spare_v, uint64_t I,
-                            uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out, const uint64_t *skeys_lo = nullptr, const uint64_t *skeys_lo2 = nullptr)
+                            uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out, const uint64_t *skeys_lo = nullptr, const uint64_t *skeys_lo2 = nullptr, int ib = 0)
 {
     hipStream_t s = c.stream;
     uint32_t *flag = c.ws_e.as<uint32_t>();
     uint32_t *runid = reinterpret_cast<uint32_t *>(spare_k);                        // [I + 1]
     uint32_t *headpos = c.ws_f.as<uint32_t>();                                      // [nruns + 1] <= I + 1
     const unsigned nbI = (unsigned)((I + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, skeys_lo, skeys_lo2, I, flag);
+    hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, skeys_lo, skeys_lo2, I, flag, ib);
     exclusive_scan_u32(s, flag, runid, (int64_t)I + 1, c.ws_scan);
     uint32_t nruns32 = 0;
     ELBA_HIP(hipMemcpyAsync(&nruns32, runid + I, 4, hipMemcpyDeviceToHost, s));      // runs before the closing flag = distinct k-mers
@@ -399,7 +424,9 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
     if (nruns > 0)
         hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, skeys_lo, skeys_lo2, svals, headpos, relflag, kidx, cptr, nruns,
                            c.rel_kmers.as<uint64_t>(), skeys_lo ? c.rel_kmers_lo.as<uint64_t>() : (uint64_t *)nullptr,
-                           skeys_lo2 ? c.rel_kmers_lo2.as<uint64_t>() : (uint64_t *)nullptr, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>());
+                           skeys_lo2 ? c.rel_kmers_lo2.as<uint64_t>() : (uint64_t *)nullptr, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(),
+                           ib, 2 * c.cfg.k, c.inst_off.as<uint64_t>(), (uint32_t)c.nreads);
+    if (ib && Z > 0) hipLaunchKernelGGL(k_instance_entries, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, c.a_csc.as<uint64_t>(), Z, c.inst_off.as<uint64_t>(), (uint32_t)c.nreads);
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
     ELBA_HIP(hipStreamSynchronize(s));
     nruns_out = nruns; N_out = N; Z_out = Z;
@@ -482,14 +509,25 @@ void stage_count_kmers(Ctx &c)
         c.t_a.start(s);
         EnumParams e = make_enum(c);
         const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
-        if (I > 0) hipLaunchKernelGGL(k_kmer_emit, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
-        const int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)I, 64 - 2 * k, 64, c.ws_sort);
-        const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>(), *svals = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
-        uint64_t *spare_k = where ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>(), *spare_v = where ? c.ws_b.as<uint64_t>() : c.ws_d.as<uint64_t>();   // free after the sort
+        // the instance index fits beside the value in one word (2k + bits(I) <= 64: k = 17 up to 2^30 instances): sort bare words
+        int ib = 1;
+        while (ib < 63 && (I >> ib)) ++ib;
+        const bool packed_words = 2 * k + ib <= 64 && !getenv("ELBA_KMER_PAIRS");
+        if (!packed_words) ib = 0;
+        int where = 0;
+        if (packed_words) {
+            if (I > 0) hipLaunchKernelGGL(k_kmer_emit_packed, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, ib, c.ws_a.as<uint64_t>());
+            where = radix_sort_keys(s, c.ws_a.as<uint64_t>(), c.ws_c.as<uint64_t>(), (int64_t)I, ib, ib + 2 * k, c.ws_sort);
+        } else {
+            if (I > 0) hipLaunchKernelGGL(k_kmer_emit, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
+            where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)I, 64 - 2 * k, 64, c.ws_sort);
+        }
+        const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>(), *svals = packed_words ? (const uint64_t *)nullptr : (where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>());
+        uint64_t *spare_k = where ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>(), *spare_v = packed_words ? c.ws_b.as<uint64_t>() : (where ? c.ws_b.as<uint64_t>() : c.ws_d.as<uint64_t>());   // free after the sort
         c.t_a.stop(s);
         c.t_b.start(s);
         uint64_t nruns = 0, N = 0, Z = 0;
-        runs_to_columns(c, skeys, svals, spare_k, spare_v, I, nruns, N, Z);
+        runs_to_columns(c, skeys, svals, spare_k, spare_v, I, nruns, N, Z, nullptr, nullptr, ib);
         c.t_b.stop(s);
         c.t_total.stop(s);
         ELBA_HIP(hipStreamSynchronize(s));

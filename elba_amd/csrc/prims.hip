@@ -158,12 +158,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *keys, in
 // Scatter of one radix pass.  The tile is first ordered by digit in LDS, then written out by consecutive lanes: a store instruction
 // of a wavefront then covers a few digits' chunks (a few pages) instead of up to 64 — on 10^8 items and more, where the 256 output streams of
 // a pass lie megabytes apart, the direct per-item scatter ran at a third of the bandwidth it reaches on 10^7 items (address translation).
+template <bool HAS_VAL>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_in, const uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out,
                                                            int64_t n, int shift, const uint32_t *hist_scanned, uint32_t nblocks)
 {
     __shared__ uint32_t whist[RS_WAVES][256];
     __shared__ uint32_t lstart[256], gbase[256], wsum[RS_WAVES];
-    __shared__ uint64_t lkey[RS_TILE], lval[RS_TILE];
+    __shared__ uint64_t lkey[RS_TILE], lval[HAS_VAL ? RS_TILE : 1];
     volatile uint32_t(*vh)[256] = whist;
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_
             const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
             const uint32_t lp = lstart[d] + whist[w][d] + rank[r];
             lkey[lp] = key[r];
-            lval[lp] = vals_in[idx];
+            if (HAS_VAL) lval[lp] = vals_in[idx];
         }
     }
     __syncthreads();
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_
         const uint32_t d = (uint32_t)(k >> shift) & 255u;
         const uint32_t dst = gbase[d] + (t - lstart[d]);
         keys_out[dst] = k;
-        vals_out[dst] = lval[t];
+        if (HAS_VAL) vals_out[dst] = lval[t];
     }
 }
 
@@ -286,7 +287,8 @@ uint64_t reduce_max_u64(hipStream_t s, const uint64_t *p, int64_t n, DevBuf &tmp
     return h;
 }
 
-int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
+template <bool HAS_VAL>
+static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
 {
     if (n <= 1 || bit_hi <= bit_lo) return 0;
     ELBA_REQUIRE(n < (int64_t)0xFFFFFFFFLL, ELBA_ERR_UNSUPPORTED, "radix sort of >= 2^32 items");
@@ -301,13 +303,23 @@ int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, ui
     for (int shift = bit_lo; shift < bit_hi; shift += 8) {
         hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, ki, n, shift, hist, nblocks);
         scan_rec<uint32_t, uint32_t>(s, hist, hist, (int64_t)hist_elems, scan_tmp);
-        hipLaunchKernelGGL(k_rs_scatter, dim3(nblocks), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift, hist, nblocks);
+        hipLaunchKernelGGL(k_rs_scatter<HAS_VAL>, dim3(nblocks), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift, hist, nblocks);
         uint64_t *t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
         cur ^= 1;
     }
     return cur;
+}
+
+int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
+{
+    return radix_sort_impl<true>(s, k0, v0, k1, v1, n, bit_lo, bit_hi, tmp);
+}
+
+int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
+{
+    return radix_sort_impl<false>(s, k0, nullptr, k1, nullptr, n, bit_lo, bit_hi, tmp);
 }
 
 }  // namespace elba
