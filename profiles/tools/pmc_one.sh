@@ -3,7 +3,7 @@
 TAG=${1:?tag}; shift
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-include-regex "k_spgemm_rows" --output-format csv -d $R/gpurun_out/${TAG} -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-align > $R/gpurun_out/${TAG}.log 2>&1 || echo "pass failed: $@"
+timeout -k 10 240 rocprofv3 --pmc "$@" --kernel-include-regex "k_spgemm_rows" --output-format csv -d $R/gpurun_out/${TAG} -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-align $BENCH_EXTRA > $R/gpurun_out/${TAG}.log 2>&1 || echo "pass failed: $@"
 python3 - $R/gpurun_out/$TAG <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.defaultdict(lambda: collections.defaultdict(int))
