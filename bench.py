@@ -151,6 +151,19 @@ def main():
                 "frac_whole_region": round(my_bytes / (acc["ms_total"] * 1e-3) / 1e9 / peak_gbs, 6) if acc["ms_total"] > 0 else 0.0,
                 "expanded_stream_bytes": 8 * st["products"] + 8 * ms["nnz"] + 24 * st["nnz"]}
 
+    # the resource that actually binds (profiles/r01_notes.md): L2 requests of the numeric kernels (PMC, collected offline like `traffic`) over
+    # the kernel time measured live, against the random-gather request ceiling measured on this machine class (profiles/microbench/gather.hip)
+    rpath = os.path.join(ROOT, "profiles", "requests.json")
+    if os.path.exists(rpath) and acc["ms_numeric"] > 0:
+        try:
+            rj = json.load(open(rpath))
+            if rj.get("workload") == args.workload and rj.get("n_gpus", 1) == world:
+                rate = rj["tcc_requests_per_step"] / (acc["ms_numeric"] * 1e-3) / 1e9
+                roofline["l2_requests"] = {"per_step": rj["tcc_requests_per_step"], "achieved_G_per_s": round(rate, 2), "measured_ceiling_G_per_s": rj["ceiling_G_requests_per_s"],
+                                           "frac_of_ceiling": round(rate / max(rj["ceiling_G_requests_per_s"]), 4)}
+        except Exception:
+            pass
+
     # one COLD call: A rebuilt (which forgets the tier prior, the cached queues and the output capacity measured by earlier calls), then
     # a single elba_create_seed_matrix — what a caller that multiplies each matrix once pays (buffers stay allocated)
     cold_ms = None
