@@ -128,12 +128,26 @@ __global__ void k_pack_desc(const HotDesc *in, uint64_t n, uint32_t xb, uint32_t
     out[i] = (uint64_t)d.x | (uint64_t)d.y << xb | (uint64_t)d.z << (xb + yb) | (uint64_t)d.w << (xb + yb + zb);
 }
 
-// partner read of every column entry (+ guard entries), the numeric loop's gather target
-__global__ void k_high_u32(const uint64_t *in, uint64_t n, uint64_t nguard, uint32_t *out)
+// partner read of every column entry (+ guard entries), the numeric loop's gather target; pb != 0: partner read << pb | position in it
+__global__ void k_high_u32(const uint64_t *in, uint64_t n, uint64_t nguard, uint32_t pb, uint32_t *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (uint32_t)(in[i] >> 32);
+    if (i < n) out[i] = pb ? ((uint32_t)(in[i] >> 32) << pb) | (uint32_t)in[i] : (uint32_t)(in[i] >> 32);
     else if (i < n + nguard) out[i] = 0xFFFFFFFFu;
+}
+
+// packed descriptors that also carry the position of their row entry in its read (above w): one workgroup per row, which knows where
+// the row's entries start in a_dec (rank of the entry = y >> fbits)
+__global__ __launch_bounds__(256) void k_pack_desc_pos(const RowHot *hdr, uint32_t M, const HotDesc *in, const uint64_t *dec, uint32_t fbits, uint32_t xb, uint32_t yb, uint32_t zb, uint64_t *out)
+{
+    for (uint32_t i = blockIdx.x; i < M; i += gridDim.x) {
+        const RowHot h = hdr[i];
+        for (uint32_t t = threadIdx.x; t < h.nd; t += blockDim.x) {
+            const HotDesc d = in[h.hs + t];
+            const uint64_t qpos = (uint32_t)dec[h.rs + (d.y >> fbits)];
+            out[h.hs + t] = (uint64_t)d.x | (uint64_t)d.y << xb | (uint64_t)d.z << (xb + yb) | (uint64_t)d.w << (xb + yb + zb) | qpos << (xb + yb + 2 * zb);
+        }
+    }
 }
 
 __global__ void k_narrow_u32(const uint64_t *in, uint64_t n, uint32_t *out)
@@ -296,14 +310,27 @@ static void build_row_descriptors(Ctx &c)
     c.a_roworder.reserve((size_t)(M + 1) * 4);
     if (M == 0) return;
     const uint64_t *cols = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
+    const uint32_t cmax = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
+    const uint32_t cbits = (uint32_t)bits_for(cmax);
+    // Field widths of the packed descriptor: x < Z + 8, y < max_row_nnz << fbits, z <= max_col_nnz, w < max_col_nnz.
+    // Position-carrying formats (the SpGEMM's 64-bit accumulators, spgemm_rows.hpp): every position of every read of the matrix fits
+    // pb <= 16 bits, a partner read and a position fit one 32-bit word, and the descriptor has pb bits to spare.  Needs the lengths of
+    // ALL reads of the matrix on this context (a multi-GPU shard knows only its own).
+    const uint32_t hxb = (uint32_t)bits_for((uint64_t)Z + 8), hyb = (uint32_t)bits_for((uint64_t)(c.max_row_nnz > 0 ? c.max_row_nnz : 1)) + c.fbits, hzb = (uint32_t)bits_for((uint64_t)cmax + 1);
+    const bool can_pack = hxb + hyb + 2 * hzb <= 64 && hxb <= 32 && hyb <= 32 && !getenv("ELBA_DESC16");
+    c.pay_pb = 0;
+    if (can_pack && c.have_reads && c.A_has_kmers && c.nreads == M && !c.h_len.empty() && !getenv("ELBA_NO_PAY")) {
+        uint32_t maxlen = 1;
+        for (uint32_t l : c.h_len) maxlen = l > maxlen ? l : maxlen;
+        const uint32_t pb = (uint32_t)bits_for(maxlen);
+        if (pb <= 16 && (uint32_t)bits_for((uint64_t)M) + pb <= 32 && hxb + hyb + 2 * hzb + pb <= 64) c.pay_pb = pb;
+    }
     c.a_cscj.reserve((size_t)(Z + 8) * 4);
-    hipLaunchKernelGGL(k_high_u32, dim3((unsigned)((Z + 8 + 255) / 256)), dim3(256), 0, s, cols, (uint64_t)Z, (uint64_t)8, c.a_cscj.as<uint32_t>());
+    hipLaunchKernelGGL(k_high_u32, dim3((unsigned)((Z + 8 + 255) / 256)), dim3(256), 0, s, cols, (uint64_t)Z, (uint64_t)8, c.pay_pb, c.a_cscj.as<uint32_t>());
     const uint32_t lo = (uint32_t)c.row_lo, hi = (uint32_t)(c.row_hi < 0 ? M : c.row_hi);
     int nb = (int)((hi - lo + 3) / 4);
     if (nb > c.num_cus * 8) nb = c.num_cus * 8;
     if (nb < 1) nb = 1;
-    const uint32_t cmax = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
-    const uint32_t cbits = (uint32_t)bits_for(cmax);
     DevBuf cntbuf, dptrbuf;         // u32[Z+1] descriptors per entry and their exclusive scan (released when the format is built)
     cntbuf.reserve((size_t)(Z + 2) * 4);
     uint32_t *cnt = cntbuf.as<uint32_t>();
@@ -347,15 +374,14 @@ static void build_row_descriptors(Ctx &c)
     hipLaunchKernelGGL(k_roworder_keys, dim3(nbM), dim3(256), 0, s, c.a_hdr.as<RowHot>(), (uint64_t)M, k0, v0);
     int wr = radix_sort_pairs(s, k0, v0, k1, v1, M, 0, 32, c.ws_sort);
     hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? v1 : v0, (uint64_t)M, c.a_roworder.as<uint32_t>());
-    // packed form: x < Z + 8, y < max_row_nnz << fbits, z <= max_col_nnz, w < max_col_nnz
-    {
-        const uint32_t xb = (uint32_t)bits_for((uint64_t)Z + 8), yb = (uint32_t)bits_for((uint64_t)(c.max_row_nnz > 0 ? c.max_row_nnz : 1)) + c.fbits, zb = (uint32_t)bits_for((uint64_t)cmax + 1);
-        c.hot_xb = 0;
-        if (xb + yb + 2 * zb <= 64 && xb <= 32 && yb <= 32 && !getenv("ELBA_DESC16")) {
-            c.a_hot8.reserve((size_t)(H + 1) * 8);
-            if (H > 0) hipLaunchKernelGGL(k_pack_desc, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, s, c.a_hot.as<HotDesc>(), (uint64_t)H, xb, yb, zb, c.a_hot8.as<uint64_t>());
-            c.hot_xb = xb; c.hot_yb = yb; c.hot_zb = zb;
-        }
+    c.hot_xb = 0;
+    if (can_pack) {
+        c.a_hot8.reserve((size_t)(H + 1) * 8);
+        if (H > 0 && c.pay_pb)
+            hipLaunchKernelGGL(k_pack_desc_pos, dim3((unsigned)std::min<int64_t>(M, (int64_t)c.num_cus * 16)), dim3(256), 0, s, c.a_hdr.as<RowHot>(), (uint32_t)M, c.a_hot.as<HotDesc>(),
+                               c.a_dec.as<uint64_t>(), c.fbits, hxb, hyb, hzb, c.a_hot8.as<uint64_t>());
+        else if (H > 0) hipLaunchKernelGGL(k_pack_desc, dim3((unsigned)((H + 255) / 256)), dim3(256), 0, s, c.a_hot.as<HotDesc>(), (uint64_t)H, hxb, hyb, hzb, c.a_hot8.as<uint64_t>());
+        c.hot_xb = hxb; c.hot_yb = hyb; c.hot_zb = hzb;
     }
     // products the descriptors stand for (statistics only)
     std::vector<RowHot> hh((size_t)M);

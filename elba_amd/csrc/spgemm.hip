@@ -77,6 +77,7 @@ struct OvParams {
     uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
     const uint64_t *a_hot8; uint32_t hot_xb, hot_yb, hot_zb;   // 8-byte descriptors (hot_xb != 0) instead of a_hot
+    uint32_t pay_pb;         // != 0: position-carrying formats — a_cscj words are partner read << pay_pb | position, descriptors carry the row entry's position (matrix.hip)
     uint32_t half;           // 1: the schedule lists an in-window pair on its smaller row only; survivors are mirrored into the partner's row
     uint32_t tier_limit[NUM_LDS_TIERS];   // claimed slots at which a row abandons the tier: min(3T/4, T - BLOCK) - 1 (every lane can overshoot by one claim)
     uint32_t use_feedback;   // 1 on the first call for a matrix (no measured prior yet): in-call self-correction through the hot fb_* sums
@@ -471,6 +472,7 @@ void stage_create_seed_matrix(Ctx &c)
     p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
     p.a_cscj = c.a_cscj.as<uint32_t>();
     p.a_hot8 = c.a_hot8.as<uint64_t>(); p.hot_xb = c.hot_xb; p.hot_yb = c.hot_yb; p.hot_zb = c.hot_zb;
+    p.pay_pb = c.pay_pb;
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.half = c.half ? 1u : 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;
@@ -499,6 +501,7 @@ void stage_create_seed_matrix(Ctx &c)
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<512, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<512, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
 
@@ -561,6 +564,9 @@ void stage_create_seed_matrix(Ctx &c)
         if (diag) hipLaunchKernelGGL((k_spgemm_rows<B, G, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));   \
         else hipLaunchKernelGGL((k_spgemm_rows<B, G, false>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));       \
     } while (0)
+        // position-carrying formats + production kernels + default block sizes: 64-bit accumulators on the tiers whose table still fits (26 B per slot)
+        const bool pay = p.pay_pb != 0 && !diag && b0 == 128 && (!getenv("ELBA_B1") || atoi(getenv("ELBA_B1")) == 256);
+#define ELBA_LAUNCH_PAY(B, grid, lds, tier, tb) hipLaunchKernelGGL((k_spgemm_rows<B, false, false, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb))
         if (nrows > 0) {
             // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
             // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
@@ -571,6 +577,12 @@ void stage_create_seed_matrix(Ctx &c)
             const bool all_tiers = !c.ov_tiers_known || c.b_cap_entries == 0;
             skipped_tiers = 0;
 #define ELBA_TIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
+            if (pay) {
+                ELBA_TIER(0, ELBA_LAUNCH_PAY(128, cus * g0, (size_t)26 * 512 + X, 0, 9u));
+                ELBA_TIER(1, ELBA_LAUNCH_PAY(256, cus * 4, (size_t)26 * 1024 + X, 1, 10u));
+                ELBA_TIER(2, ELBA_LAUNCH_PAY(256, cus * 4, (size_t)26 * 2048 + X, 2, 11u));
+                ELBA_TIER(3, ELBA_LAUNCH_PAY(256, cus * 2, (size_t)26 * 4096 + X, 3, 12u));
+            } else {
             if (b0 == 64) ELBA_TIER(0, ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
             else if (b0 == 256) ELBA_TIER(0, ELBA_LAUNCH_ROWS(256, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
             else ELBA_TIER(0, ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
@@ -578,6 +590,7 @@ void stage_create_seed_matrix(Ctx &c)
             else ELBA_TIER(1, ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)18 * 1024 + X, 1, 10u));
             ELBA_TIER(2, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)18 * 2048 + X, 2, 11u));
             ELBA_TIER(3, ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)18 * 4096 + X, 3, 12u));
+            }
             ELBA_TIER(4, ELBA_LAUNCH_ROWS(512, false, cus, (size_t)18 * 8192 + X, 4, 13u));
             ELBA_TIER(5, ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u));
             ELBA_HIP(hipGetLastError());

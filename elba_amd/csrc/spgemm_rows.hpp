@@ -23,6 +23,7 @@ enum : uint32_t {
 template <bool GLOBAL>
 struct Table {
     uint32_t *keys, *cnt, *smin, *smax, *misc;
+    unsigned long long *vmin, *vmax;      // payload-carrying accumulators (insert_lds64): sequence number << 32 | payload, instead of smin / smax
     uint32_t tbits, limit;
     __device__ __forceinline__ uint32_t size() const { return 1u << tbits; }
     // relaxed workgroup-scope atomics, NOT volatile: a volatile access defeats address-space inference and becomes a FLAT
@@ -96,6 +97,59 @@ struct Table {
                 : "vcc", "memory");
         }
         // claims: every claiming lane adds for itself (same-address LDS atomics serialise in the LDS unit, one cycle each)
+        if (__ballot(claimed != 0) != 0) {
+            uint32_t prev = 0;
+            if (claimed) {
+                const uint32_t a9 = (uint32_t)(uintptr_t)&misc[9], one = 1u;
+                asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(prev) : "v"(a9), "v"(one) : "memory");
+            }
+            if (__ballot(claimed != 0 && prev >= limit) != 0) {
+                misc[10] = 1u;
+                full = true;
+            }
+        }
+    }
+    // The same with 64-bit extremes: `lo` / `hi` = sequence number << 32 | payload of the smallest / largest product handed in.  ds_min_u64 /
+    // ds_max_u64 keep the payload of the extreme sequence number, so the seed positions travel with the extremes and nothing is
+    // looked up after the sweep.  Table layout: keys | cnt (u32) | vmin | vmax (u64).
+    __device__ __forceinline__ void insert_lds64(uint32_t j, unsigned long long lo, unsigned long long hi, uint32_t cnt, bool valid, bool &full) const
+    {
+        if (full) return;
+        uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
+        uint32_t claimed = 0, old, addr = 0;
+        unsigned long long save, t;
+        const uint32_t base = (uint32_t)(uintptr_t)keys;
+        const uint32_t base64 = (uint32_t)(uintptr_t)vmin;
+        const uint32_t mask = size() - 1, empty = EMPTY;
+        const uint32_t tb = size() * 4, tb8 = size() * 8;
+        if (valid) {
+            asm volatile(
+                "s_mov_b64 %[save], exec\n"
+                ".Lprobe%=:\n\t"
+                "v_lshl_add_u32 %[addr], %[slot], 2, %[base]\n\t"
+                "ds_cmpst_rtn_b32 %[old], %[addr], %[empty], %[j]\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cmp_eq_u32_e64 %[t], %[old], %[empty]\n\t"
+                "v_cndmask_b32_e64 %[cl], %[cl], 1, %[t]\n\t"
+                "v_cmp_eq_u32_e32 vcc, %[old], %[j]\n\t"
+                "s_or_b64 vcc, vcc, %[t]\n\t"
+                "s_andn2_b64 exec, exec, vcc\n\t"
+                "s_cbranch_execz .Ldone%=\n\t"
+                "v_add_u32_e32 %[slot], 1, %[slot]\n\t"
+                "v_and_b32_e32 %[slot], %[mask], %[slot]\n\t"
+                "s_branch .Lprobe%=\n"
+                ".Ldone%=:\n\t"
+                "s_mov_b64 exec, %[save]\n\t"
+                "v_add_u32_e32 %[old], %[tb], %[addr]\n\t"
+                "ds_add_u32 %[old], %[one]\n\t"
+                "v_lshl_add_u32 %[old], %[slot], 3, %[base64]\n\t"
+                "ds_min_u64 %[old], %[lo]\n\t"
+                "v_add_u32_e32 %[old], %[tb8], %[old]\n\t"
+                "ds_max_u64 %[old], %[hi]\n"
+                : [save] "=&s"(save), [addr] "+v"(addr), [old] "=&v"(old), [t] "=&s"(t), [cl] "+v"(claimed), [slot] "+v"(slot)
+                : [base] "s"(base), [base64] "s"(base64), [empty] "v"(empty), [j] "v"(j), [mask] "s"(mask), [tb] "s"(tb), [tb8] "s"(tb8), [one] "v"(cnt), [lo] "v"(lo), [hi] "v"(hi)
+                : "vcc", "memory");
+        }
         if (__ballot(claimed != 0) != 0) {
             uint32_t prev = 0;
             if (claimed) {
@@ -218,14 +272,19 @@ __device__ __forceinline__ void lds_barrier()
 }
 
 // DIAG = true compiles the diagnostic ablations and the phase clock in (cfg.flags != 0); the production instantiation carries none of it
-template <int BLOCK, bool GLOBAL, bool DIAG>
+// PAY = true (LDS tiers up to 4096 slots, matrices whose formats carry the positions: p.pay_pb != 0): the accumulators are 64 bits wide and
+// hold the seed positions of the extreme products beside their sequence numbers (Table::insert_lds64) — the two dependent rounds of
+// seed-decoding loads after the sweep, half of the kernel's read requests, disappear.
+template <int BLOCK, bool GLOBAL, bool DIAG, bool PAY = false>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uint32_t lds_tbits)
 {
+    static_assert(!PAY || (!GLOBAL && !DIAG), "payload accumulators: production LDS tiers only");
     const uint32_t dbg = DIAG ? p.dbg : 0u;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS tiers: keys | cnt | smin | smax (u32 each, T entries) | survivor list (u16: T <= 8192) | misc  = 18 B per slot, so that an
-    // 8192-slot table still fits the 160 KB of a CU;  spill tier: only misc lives in LDS
-    uint32_t *misc = GLOBAL ? smem : smem + (size_t)4 * (1u << lds_tbits) + ((size_t)1 << lds_tbits) / 2;
+    // 8192-slot table still fits the 160 KB of a CU;  spill tier: only misc lives in LDS.
+    // PAY: keys | cnt (u32) | vmin | vmax (u64) | survivor list | misc = 26 B per slot
+    uint32_t *misc = GLOBAL ? smem : smem + (size_t)(PAY ? 6 : 4) * (1u << lds_tbits) + ((size_t)1 << lds_tbits) / 2;
     // per-wave product queue: 64 lanes x SPEC products, partner id and sequence number
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1;
@@ -283,6 +342,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         }
         return r;
     };
+    // (w: the diagonal's share in the low 16 bits; with position-carrying formats, p.pay_pb != 0, the row entry's position in the read above them)
+    const uint32_t pb = p.pay_pb, pmask = (1u << pb) - 1u;
     auto unpack = [&](const uint4 &r) {
         if (!packed) return r;
         const uint64_t q = ((uint64_t)r.y << 32) | r.x;
@@ -290,7 +351,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
         d.x = (uint32_t)q & (uint32_t)((1ull << xb) - 1);
         d.y = (uint32_t)(q >> xb) & (uint32_t)((1ull << yb) - 1);
         d.z = (uint32_t)(q >> (xb + yb)) & ((1u << zb) - 1u);
-        d.w = (uint32_t)(q >> (xb + yb + zb));
+        const uint32_t wq = (uint32_t)(q >> (xb + yb + zb));
+        d.w = pb ? ((wq & ((1u << zb) - 1u)) | (wq >> zb) << 16) : wq;
         return d;
     };
     // ONE 16-byte load per lane: the partner reads of four consecutive range entries (a_cscj holds nothing else; the load is 4-byte
@@ -379,12 +441,16 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             const uint32_t T = 1u << lds_tbits;
             tab.limit = p.tier_limit[tier];          // abandon point: at most limit + 2*BLOCK slots are ever claimed, < T
             tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
-            list16 = reinterpret_cast<uint16_t *>(smem + 4 * T);
+            tab.vmin = reinterpret_cast<unsigned long long *>(smem + 2 * T); tab.vmax = tab.vmin + T;
+            list16 = reinterpret_cast<uint16_t *>(smem + (PAY ? 6 : 4) * T);
         }
         const uint32_t T = tab.size();
         ELBA_STAMP(0);
         if (!(DIAG && (dbg & 64u)))                      // (64: ablation, no table initialisation)
-        for (uint32_t s = tid; s < T; s += BLOCK) { tab.keys[s] = EMPTY; tab.cnt[s] = 0; tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
+        for (uint32_t s = tid; s < T; s += BLOCK) {
+            tab.keys[s] = EMPTY; tab.cnt[s] = 0;
+            if (PAY) { tab.vmin[s] = ~0ull; tab.vmax[s] = 0ull; } else { tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
+        }
         // the diagonal of B(i,i): every row entry pairs with the run of read i in its own column.  Count = nnz + the descriptors' w
         // (added below); first / last product of the fold = first / last row entry at its own place in its column
         if (tid < 16) misc[tid] = tid == 0 ? cur.nnz : (tid == 1 ? cur.own0 : (tid == 2 ? (((cur.nnz - 1u) << p.fbits) | cur.ownl) : 0u));
@@ -411,8 +477,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 uint32_t jv[PK];
 #pragma unroll
                 for (int k = 0; k < PK; ++k) jv[k] = ce[k];
-                const uint32_t c = dc.z, sy = dc.y, x0 = dc.x;
-                dup += dc.w;
+                const uint32_t c = dc.z, sy = dc.y, x0 = dc.x, qs = (dc.w >> 16) << 16;      // qs: the row entry's position, where the payload wants it
+                dup += dc.w & 0xFFFFu;
                 uint4 draw = d1;
                 static_assert(PK == 4, "the consume point names PK registers");
                 asm volatile("" : "+v"(jv[0]), "+v"(jv[1]), "+v"(jv[2]), "+v"(jv[3]), "+v"(draw.x) : : "memory");      // (1) everything requested so far has landed
@@ -420,7 +486,18 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 uint4 d2 = make_uint4(0u, 0u, 0u, 0u);
                 if (more) gather(ce, dnx, 0u);                                                                       // (2)
                 if (more2) d2 = load_desc(hs, t0 + 2 * BLOCK, nd);
-                {                                                                                                    // (3)
+                if (PAY) {                                                                                           // (3)
+                    // gathered word = partner read << pb | its position: sequence number, then both positions, into the 64-bit extremes
+#pragma unroll
+                    for (int k = 0; k < PK; ++k) {
+                        const unsigned long long v = ((unsigned long long)(sy + (uint32_t)k) << 32) | (qs | (jv[k] & pmask));
+                        tab.insert_lds64(jv[k] >> pb, v, v, 1u, (uint32_t)k < c, full);
+                    }
+                } else {
+                    if (pb) {
+#pragma unroll
+                        for (int k = 0; k < PK; ++k) jv[k] >>= pb;
+                    }
                     const uint32_t jl = (uint32_t)__builtin_amdgcn_update_dpp((int)~jv[0], (int)jv[0], 0x111 /* row_shr:1 */, 0xf, 0xf, false);
                     if (__popcll(__ballot(0u < c && jv[0] == jl)) >= DENSE_LANES) {
 #pragma unroll
@@ -435,7 +512,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                     uint32_t cx[PK];
                     { uint4 dx = make_uint4(x0, 0u, c, 0u); gather(cx, dx, r0); }
 #pragma unroll
-                    for (int k = 0; k < PK; ++k) { const uint32_t sq = sy + r0 + (uint32_t)k; tab.insert_lds(cx[k], sq, sq, 1u, r0 + (uint32_t)k < c, full); }
+                    for (int k = 0; k < PK; ++k) {
+                        const uint32_t sq = sy + r0 + (uint32_t)k;
+                        if (PAY) { const unsigned long long v = ((unsigned long long)sq << 32) | (qs | (cx[k] & pmask)); tab.insert_lds64(cx[k] >> pb, v, v, 1u, r0 + (uint32_t)k < c, full); }
+                        else tab.insert_lds(cx[k] >> pb, sq, sq, 1u, r0 + (uint32_t)k < c, full);
+                    }
                 }
                 if (tab.abandoned()) {
                     if (tid == 0) { const uint32_t done = t0 + BLOCK; misc[11] = done < nd ? done : nd; }
@@ -451,8 +532,12 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             if (PIPE == 2) { if (more2) d2 = load_desc(hs, t0 + 2 * BLOCK, nd); }
             else if (more) d2 = load_desc(hs, t0 + BLOCK, nd);
             ELBA_STAMP(6);
-            dup += dc.w;
+            dup += dc.w & 0xFFFFu;
             const uint32_t c = dc.z;
+            if (pb) {                                       // position-carrying words: this path keeps the partner reads only
+#pragma unroll
+                for (int k = 0; k < PK; ++k) ce[k] >>= pb;
+            }
 #pragma unroll 1
             for (uint32_t r0 = 0;;) {
                 if (DIAG && (dbg & 1u)) {                                   // ablation: gathers only, keep the loads alive
@@ -481,6 +566,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 r0 += PK;
                 if (__ballot(c > r0) == 0) break;                            // wave-uniform: ranges longer than PK entries come first in a row
                 gather(ce, dc, r0);
+                if (pb) {
+#pragma unroll
+                    for (int k = 0; k < PK; ++k) ce[k] >>= pb;
+                }
             }
             ELBA_STAMP(8);
             if (tab.abandoned()) {
@@ -580,9 +669,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
             const uint32_t hasd = misc[0] >= 2 ? 1u : 0u;
             for (uint32_t t = (DIAG && (dbg & 256u)) ? ysurv + hasd : tid; t < ysurv + hasd; t += BLOCK) {      // (256: ablation, no decode / staging stores)
                 uint32_t j = i, n = misc[0], a = misc[1], b = misc[2];
+                unsigned long long va = 0, vb = 0;
                 if (t < ysurv) {
                     const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)list16[t];
-                    j = tab.ld(tab.keys, s0); n = tab.ld(tab.cnt, s0); a = tab.ld(tab.smin, s0); b = tab.ld(tab.smax, s0);
+                    j = tab.ld(tab.keys, s0); n = tab.ld(tab.cnt, s0);
+                    if (PAY) { va = tab.vmin[s0]; vb = tab.vmax[s0]; } else { a = tab.ld(tab.smin, s0); b = tab.ld(tab.smax, s0); }
                 }
                 // the partner's row gets the mirrored entry: draw its slot there now (the round trip overlaps the decode's loads);
                 // k_mirror places it once the row pointers are known
@@ -590,7 +681,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 if (p.half && j != i && j >= p.row_lo && j < p.row_hi) { tick = (DIAG && (dbg & 8u)) ? 0u : atomicAdd(&p.low_cnt[j], 1u); ++nmir; }     // (8: ablation, no ticket atomics)
                 elba_seed_t v;
                 if (DIAG && (dbg & 4u)) { v.q0 = a; v.t0 = b; v.q1 = a; v.t1 = b; v.numshared = (int32_t)n; }          // ablation: no seed decoding loads
-                else v = decode_seed(p, rs, a, b, n, fmask);
+                else if (PAY && t < ysurv) {                // the positions came with the extremes: payload = position in this read << 16 | position in the partner
+                    v.q0 = (uint32_t)va >> 16; v.t0 = (uint32_t)va & 0xFFFFu; v.q1 = (uint32_t)vb >> 16; v.t1 = (uint32_t)vb & 0xFFFFu; v.numshared = (int32_t)n;
+                }
+                else v = decode_seed(p, rs, a, b, n, fmask);       // (the diagonal entry, one per row, is still looked up)
                 p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
                 p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);
                 if (j > i) ++nup;

@@ -275,3 +275,34 @@ def test_two_word_kmers_full_pipeline(k, lo, up):
     g = e.export_overlaps()
     assert (g["rows"] == rows).all() and all((g["vals"][f] == ov[f]).all() for f in ov.dtype.names if f != "pad")
     e.close()
+
+
+@pytest.mark.parametrize("knob", ["ELBA_NO_PAY", "ELBA_DESC16"])
+def test_position_carrying_accumulators_equal_the_looked_up_seeds(knob, monkeypatch):
+    """Reads whose positions fit 16 bits get formats that carry the positions and 64-bit accumulators (no seed-decoding loads);
+    ELBA_NO_PAY / ELBA_DESC16 at matrix-build time keep the 32-bit accumulators + lookups: same B, bit for bit, on every tier."""
+    noisy = elba_amd.synth_reads(51, 150000, 14, 2500, 1800, error_rate=0.10, min_len=60)
+    deep = elba_amd.synth_reads(52, 3000, 120, 120, 10, error_rate=0.0, min_len=60)
+    packed, off, lens = _concat([noisy, deep])
+    o = gu.oracle_run(packed, off, lens, 17, 2, 300, threads=8)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 300)
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+    monkeypatch.setenv(knob, "1")
+    e2, ks2, ms2, st2 = gu.gpu_full(packed, off, lens, 17, 2, 300)
+    gu.assert_B_equal(e2.export_csr(), o.B())
+    gu.assert_stats_equal(st2, o)
+    e2.close()
+
+
+def test_reads_longer_than_16_bit_positions_use_the_lookup_path():
+    """One read beyond 65 535 bases: positions no longer fit the payload, the matrix keeps the plain formats."""
+    long_ = elba_amd.synth_reads(53, 90000, 6, 70000, 4000, error_rate=0.05, min_len=66000)
+    short = elba_amd.synth_reads(54, 90000, 6, 3000, 500, error_rate=0.05, min_len=500)
+    packed, off, lens = _concat([short, long_])
+    assert lens.max() > 65535
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 30)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 30, threads=8)
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.close()
