@@ -46,6 +46,18 @@ __global__ void k_max_seg_len(const uint32_t *ptr, int64_t nseg, unsigned long l
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// largest position (low word) among the column entries
+__global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long m = 0;
+    for (; i < n; i += stride) { const unsigned long long l = (uint32_t)v[i]; m = l > m ? l : m; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
 // products per row: ub_i = sum over the row's entries of the length of the entry's column (one wavefront per row); seed-decoding array
 // for the canonical column layout (replaced by k_dec_permuted when the columns are permuted)
 __global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, uint32_t M, uint32_t *rowprod, uint64_t *dec)
@@ -314,16 +326,23 @@ static void build_row_descriptors(Ctx &c)
     const uint32_t cbits = (uint32_t)bits_for(cmax);
     // Field widths of the packed descriptor: x < Z + 8, y < max_row_nnz << fbits, z <= max_col_nnz, w < max_col_nnz.
     // Position-carrying formats (the SpGEMM's 64-bit accumulators, spgemm_rows.hpp): every position of every read of the matrix fits
-    // pb <= 16 bits, a partner read and a position fit one 32-bit word, and the descriptor has pb bits to spare.  Needs the lengths of
-    // ALL reads of the matrix on this context (a multi-GPU shard knows only its own).
+    // pb <= 16 bits, a partner read and a position fit one 32-bit word, and the descriptor has pb bits to spare.  The largest position is
+    // taken from the entries themselves (a multi-GPU shard does not know the lengths of the other ranks' reads, a matrix handed over as
+    // triples comes without reads).
     const uint32_t hxb = (uint32_t)bits_for((uint64_t)Z + 8), hyb = (uint32_t)bits_for((uint64_t)(c.max_row_nnz > 0 ? c.max_row_nnz : 1)) + c.fbits, hzb = (uint32_t)bits_for((uint64_t)cmax + 1);
     const bool can_pack = hxb + hyb + 2 * hzb <= 64 && hxb <= 32 && hyb <= 32 && !getenv("ELBA_DESC16");
     c.pay_pb = 0;
-    if (can_pack && c.have_reads && c.A_has_kmers && c.nreads == M && !c.h_len.empty() && !getenv("ELBA_NO_PAY")) {
-        uint32_t maxlen = 1;
-        for (uint32_t l : c.h_len) maxlen = l > maxlen ? l : maxlen;
-        const uint32_t pb = (uint32_t)bits_for(maxlen);
-        if (pb <= 16 && (uint32_t)bits_for((uint64_t)M) + pb <= 32 && hxb + hyb + 2 * hzb + pb <= 64) c.pay_pb = pb;
+    if (can_pack && Z > 0 && !getenv("ELBA_NO_PAY")) {
+        c.ws_scan.reserve(64);
+        ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
+        int64_t nbz = (Z + 255) / 256;
+        if (nbz > 2048) nbz = 2048;
+        hipLaunchKernelGGL(k_max_low32, dim3((unsigned)nbz), dim3(256), 0, s, cols, Z, c.ws_scan.as<unsigned long long>());
+        uint64_t maxpos = 0;
+        ELBA_HIP(hipMemcpyAsync(&maxpos, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        const uint32_t pb = (uint32_t)bits_for(maxpos);
+        if (pb <= 16 && (uint32_t)bits_for((uint64_t)(M > 0 ? M - 1 : 0)) + pb <= 32 && hxb + hyb + 2 * hzb + pb <= 64) c.pay_pb = pb;
     }
     c.a_cscj.reserve((size_t)(Z + 8) * 4);
     hipLaunchKernelGGL(k_high_u32, dim3((unsigned)((Z + 8 + 255) / 256)), dim3(256), 0, s, cols, (uint64_t)Z, (uint64_t)8, c.pay_pb, c.a_cscj.as<uint32_t>());
