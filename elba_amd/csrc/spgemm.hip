@@ -578,7 +578,9 @@ void stage_create_seed_matrix(Ctx &c)
             skipped_tiers = 0;
 #define ELBA_TIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
             if (pay) {
-                ELBA_TIER(0, ELBA_LAUNCH_PAY(128, cus * g0, (size_t)26 * 512 + X, 0, 9u));
+                // (11 workgroups of 13.6 KB fill a CU's LDS exactly; measured 8 / 10 / 11 / 12 per CU: 0.150 / 0.156 / 0.146 / 0.170 ms)
+                const int g0p = getenv("ELBA_G0") ? g0 : 11;
+                ELBA_TIER(0, ELBA_LAUNCH_PAY(128, cus * g0p, (size_t)26 * 512 + X, 0, 9u));
                 ELBA_TIER(1, ELBA_LAUNCH_PAY(256, cus * 4, (size_t)26 * 1024 + X, 1, 10u));
                 ELBA_TIER(2, ELBA_LAUNCH_PAY(256, cus * 4, (size_t)26 * 2048 + X, 2, 11u));
                 ELBA_TIER(3, ELBA_LAUNCH_PAY(256, cus * 2, (size_t)26 * 4096 + X, 3, 12u));
