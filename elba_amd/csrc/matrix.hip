@@ -58,6 +58,30 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// 16-byte descriptors that carry the position of their row entry in the upper half of w (the packed form has no room for it)
+__global__ __launch_bounds__(256) void k_fold_desc_pos(const RowHot *hdr, uint32_t M, HotDesc *hot, const uint64_t *dec, uint32_t fbits)
+{
+    for (uint32_t i = blockIdx.x; i < M; i += gridDim.x) {
+        const RowHot h = hdr[i];
+        for (uint32_t t = threadIdx.x; t < h.nd; t += blockDim.x) {
+            const HotDesc d = hot[h.hs + t];
+            hot[h.hs + t].w = (d.w & 0xFFFFu) | (uint32_t)dec[h.rs + (d.y >> fbits)] << 16;
+        }
+    }
+}
+
+// entries whose position is >= thr
+__global__ void k_count_pos_ge(const uint64_t *v, int64_t n, uint32_t thr, unsigned long long *out)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    unsigned long long m = 0;
+    for (; i < n; i += stride) m += (uint32_t)v[i] >= thr ? 1u : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m += __shfl_xor(m, d, 64);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out, m);
+}
+
 // products per row: ub_i = sum over the row's entries of the length of the entry's column (one wavefront per row); seed-decoding array
 // for the canonical column layout (replaced by k_dec_permuted when the columns are permuted)
 __global__ __launch_bounds__(256) void k_row_products(const uint32_t *rowptr, const uint64_t *csr, const uint32_t *colptr, uint32_t M, uint32_t *rowprod, uint64_t *dec)
@@ -144,7 +168,10 @@ __global__ void k_pack_desc(const HotDesc *in, uint64_t n, uint32_t xb, uint32_t
 __global__ void k_high_u32(const uint64_t *in, uint64_t n, uint64_t nguard, uint32_t pb, uint32_t *out)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = pb ? ((uint32_t)(in[i] >> 32) << pb) | (uint32_t)in[i] : (uint32_t)(in[i] >> 32);
+    if (i < n) {
+        const uint32_t esc = (1u << pb) - 1u, pos = (uint32_t)in[i];          // a position that does not fit is written as all ones: "look it up" (spgemm_rows.hpp)
+        out[i] = pb ? ((uint32_t)(in[i] >> 32) << pb) | (pos < esc ? pos : esc) : (uint32_t)(in[i] >> 32);
+    }
     else if (i < n + nguard) out[i] = 0xFFFFFFFFu;
 }
 
@@ -326,13 +353,14 @@ static void build_row_descriptors(Ctx &c)
     const uint32_t cbits = (uint32_t)bits_for(cmax);
     // Field widths of the packed descriptor: x < Z + 8, y < max_row_nnz << fbits, z <= max_col_nnz, w < max_col_nnz.
     // Position-carrying formats (the SpGEMM's 64-bit accumulators, spgemm_rows.hpp): every position of every read of the matrix fits
-    // pb <= 16 bits, a partner read and a position fit one 32-bit word, and the descriptor has pb bits to spare.  The largest position is
+    // pb <= 16 bits, a partner read and a position fit one 32-bit word (or nearly: see below), and the descriptor has pb bits to spare.  The largest position is
     // taken from the entries themselves (a multi-GPU shard does not know the lengths of the other ranks' reads, a matrix handed over as
     // triples comes without reads).
     const uint32_t hxb = (uint32_t)bits_for((uint64_t)Z + 8), hyb = (uint32_t)bits_for((uint64_t)(c.max_row_nnz > 0 ? c.max_row_nnz : 1)) + c.fbits, hzb = (uint32_t)bits_for((uint64_t)cmax + 1);
     const bool can_pack = hxb + hyb + 2 * hzb <= 64 && hxb <= 32 && hyb <= 32 && !getenv("ELBA_DESC16");
     c.pay_pb = 0;
-    if (can_pack && Z > 0 && !getenv("ELBA_NO_PAY")) {
+    uint32_t pay_qbits = 16;                         // bits of the largest position (the descriptor's field)
+    if (Z > 0 && !getenv("ELBA_NO_PAY")) {
         c.ws_scan.reserve(64);
         ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
         int64_t nbz = (Z + 255) / 256;
@@ -341,9 +369,24 @@ static void build_row_descriptors(Ctx &c)
         uint64_t maxpos = 0;
         ELBA_HIP(hipMemcpyAsync(&maxpos, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
         ELBA_HIP(hipStreamSynchronize(s));
-        const uint32_t pb = (uint32_t)bits_for(maxpos);
-        if (pb <= 16 && (uint32_t)bits_for((uint64_t)(M > 0 ? M - 1 : 0)) + pb <= 32 && hxb + hyb + 2 * hzb + pb <= 64) c.pay_pb = pb;
+        const uint32_t pb = (uint32_t)bits_for(maxpos), mb = (uint32_t)bits_for((uint64_t)(M > 0 ? M - 1 : 0));
+        pay_qbits = pb <= 16 ? pb : 16;
+        if (pb <= 16) {
+            if (mb + pb <= 32) c.pay_pb = pb;
+            else if (mb < 32 && 32 - mb + 2 >= pb) {
+                // One or two bits short (many reads, a few very long ones): the word keeps 32 - mb position bits and the entries beyond
+                // them are marked "look it up" — worth it while they are rare (here: under 1 in 64)
+                const uint32_t wb = 32 - mb;
+                ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
+                hipLaunchKernelGGL(k_count_pos_ge, dim3((unsigned)nbz), dim3(256), 0, s, cols, Z, (1u << wb) - 1u, c.ws_scan.as<unsigned long long>());
+                uint64_t nesc = 0;
+                ELBA_HIP(hipMemcpyAsync(&nesc, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
+                ELBA_HIP(hipStreamSynchronize(s));
+                if (nesc * 64 <= (uint64_t)Z) c.pay_pb = wb;
+            }
+        }
     }
+    if (getenv("ELBA_TRACE")) fprintf(stderr, "[elba] hot format: packed descriptors %d (x %u y %u z %u bits), position-carrying words: %u position bits\n", (int)can_pack, hxb, hyb, hzb, c.pay_pb);
     c.a_cscj.reserve((size_t)(Z + 8) * 4);
     hipLaunchKernelGGL(k_high_u32, dim3((unsigned)((Z + 8 + 255) / 256)), dim3(256), 0, s, cols, (uint64_t)Z, (uint64_t)8, c.pay_pb, c.a_cscj.as<uint32_t>());
     const uint32_t lo = (uint32_t)c.row_lo, hi = (uint32_t)(c.row_hi < 0 ? M : c.row_hi);
@@ -394,7 +437,11 @@ static void build_row_descriptors(Ctx &c)
     int wr = radix_sort_pairs(s, k0, v0, k1, v1, M, 0, 32, c.ws_sort);
     hipLaunchKernelGGL(k_narrow_u32, dim3(nbM), dim3(256), 0, s, wr ? v1 : v0, (uint64_t)M, c.a_roworder.as<uint32_t>());
     c.hot_xb = 0;
-    if (can_pack) {
+    if (c.pay_pb && !(can_pack && hxb + hyb + 2 * hzb + pay_qbits <= 64)) {
+        // position-carrying formats whose descriptors cannot spare the bits in 8 bytes: the 16-byte form, position folded into w
+        if (H > 0) hipLaunchKernelGGL(k_fold_desc_pos, dim3((unsigned)std::min<int64_t>(M, (int64_t)c.num_cus * 16)), dim3(256), 0, s, c.a_hdr.as<RowHot>(), (uint32_t)M, c.a_hot.as<HotDesc>(),
+                                      c.a_dec.as<uint64_t>(), c.fbits);
+    } else if (can_pack) {
         c.a_hot8.reserve((size_t)(H + 1) * 8);
         if (H > 0 && c.pay_pb)
             hipLaunchKernelGGL(k_pack_desc_pos, dim3((unsigned)std::min<int64_t>(M, (int64_t)c.num_cus * 16)), dim3(256), 0, s, c.a_hdr.as<RowHot>(), (uint32_t)M, c.a_hot.as<HotDesc>(),

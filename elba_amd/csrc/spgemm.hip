@@ -582,8 +582,9 @@ void stage_create_seed_matrix(Ctx &c)
                 const int g0p = getenv("ELBA_G0") ? g0 : 11;
                 ELBA_TIER(0, ELBA_LAUNCH_PAY(128, cus * g0p, (size_t)26 * 512 + X, 0, 9u));
                 ELBA_TIER(1, ELBA_LAUNCH_PAY(256, cus * 4, (size_t)26 * 1024 + X, 1, 10u));
-                ELBA_TIER(2, ELBA_LAUNCH_PAY(256, cus * 4, (size_t)26 * 2048 + X, 2, 11u));
-                ELBA_TIER(3, ELBA_LAUNCH_PAY(256, cus * 2, (size_t)26 * 4096 + X, 3, 12u));
+                // (from 2048 slots on the wider slots would halve the workgroups a CU holds: 32-bit accumulators + look-ups there)
+                ELBA_TIER(2, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)18 * 2048 + X, 2, 11u));
+                ELBA_TIER(3, ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)18 * 4096 + X, 3, 12u));
             } else {
             if (b0 == 64) ELBA_TIER(0, ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
             else if (b0 == 256) ELBA_TIER(0, ELBA_LAUNCH_ROWS(256, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));

@@ -683,6 +683,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_rows(OvParams p, int tier, uin
                 if (DIAG && (dbg & 4u)) { v.q0 = a; v.t0 = b; v.q1 = a; v.t1 = b; v.numshared = (int32_t)n; }          // ablation: no seed decoding loads
                 else if (PAY && t < ysurv) {                // the positions came with the extremes: payload = position in this read << 16 | position in the partner
                     v.q0 = (uint32_t)va >> 16; v.t0 = (uint32_t)va & 0xFFFFu; v.q1 = (uint32_t)vb >> 16; v.t1 = (uint32_t)vb & 0xFFFFu; v.numshared = (int32_t)n;
+                    // (a partner position that did not fit the gathered word arrives as all ones: that seed is looked up — rare by construction, matrix.hip)
+                    if (v.t0 == pmask || v.t1 == pmask) v = decode_seed(p, rs, (uint32_t)(va >> 32), (uint32_t)(vb >> 32), n, fmask);
                 }
                 else v = decode_seed(p, rs, a, b, n, fmask);       // (the diagonal entry, one per row, is still looked up)
                 p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);

@@ -306,3 +306,33 @@ def test_reads_longer_than_16_bit_positions_use_the_lookup_path():
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
     e.close()
+
+
+def test_words_one_or_two_bits_short_mark_rare_positions_for_lookup():
+    """Many reads (19 id bits) and a few long ones (positions up to 2^15): read id + position need 34 bits.  The gathered word keeps 13
+    position bits; the 1 % of entries beyond them are marked and their seeds looked up — B equals the oracle's, seeds included."""
+    rng = np.random.default_rng(77)
+    M, ncol = 300000, 6000
+    rows, cols, vals = [], [], []
+    hot = rng.choice(M, 900, replace=False)                  # reads that actually share k-mers (so that pairs share >= 2 of them)
+    for c in range(ncol):
+        r = np.unique(rng.choice(hot, int(rng.integers(2, 7))))
+        rows.append(r); cols.append(np.full(len(r), c))
+        v = rng.integers(0, 6000, len(r))
+        far = rng.random(len(r)) < 0.01
+        v[far] = rng.integers(8191, 30000, int(far.sum()))
+        vals.append(v)
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals).astype(np.uint32)
+    assert (vals >= 8191).sum() > 50 and vals.max() < 32768
+    e = elba_amd.Engine(17, 2, 8)
+    e.set_kmer_matrix(M, ncol, rows, cols, vals)
+    st = e.create_seed_matrix()
+    o = po.Oracle(17, 2, 8)
+    o.set_triples(M, ncol, rows, cols, vals)
+    o.spgemm(8)
+    B = e.export_csr(); oB = o.B()
+    gu.assert_B_equal(B, oB)
+    gu.assert_stats_equal(st, o)
+    # some surviving seed really sits on a marked position
+    assert ((oB["val"]["t0"] >= 8191) | (oB["val"]["t1"] >= 8191)).sum() > 0
+    e.close()
