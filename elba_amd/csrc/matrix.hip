@@ -377,14 +377,15 @@ static void build_row_descriptors(Ctx &c)
             if (mb + pb <= 32) c.pay_pb = pb;
             else if (mb < 32 && 32 - mb + 2 >= pb) {
                 // One or two bits short (many reads, a few very long ones): the word keeps 32 - mb position bits and the entries beyond
-                // them are marked "look it up" — worth it while they are rare (here: under 1 in 64)
+                // them are marked "look it up" — worth it while they are rare (here: under 1 in 16: a marked position costs its seed the
+                // two look-ups every seed used to pay)
                 const uint32_t wb = 32 - mb;
                 ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
                 hipLaunchKernelGGL(k_count_pos_ge, dim3((unsigned)nbz), dim3(256), 0, s, cols, Z, (1u << wb) - 1u, c.ws_scan.as<unsigned long long>());
                 uint64_t nesc = 0;
                 ELBA_HIP(hipMemcpyAsync(&nesc, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
                 ELBA_HIP(hipStreamSynchronize(s));
-                if (nesc * 64 <= (uint64_t)Z) c.pay_pb = wb;
+                if (nesc * 16 <= (uint64_t)Z) c.pay_pb = wb;
             }
         }
     }
