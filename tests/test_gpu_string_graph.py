@@ -122,3 +122,27 @@ def test_loaded_overlaps_take_precedence_and_ids_are_global():
     S, _, _ = po.string_graph(60, rows, cols, vals, cutoff=0.0)
     assert (g["rows"] == S["rows"] + 20).all() and (g["cols"] == S["cols"] + 20).all() and st["nnz"] == S["n"]
     e.close()
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_gpu_equals_the_literal_python_restatement(seed):
+    """Not through the C oracle: the GPU's S against the pure-Python statement-by-statement restatement of src/main.cpp:305-312 and
+    src/TransitiveReduction.cpp (tests/string_graph_util.py), which shares no code with either."""
+    rng = np.random.default_rng(900 + seed)
+    M = int(rng.integers(5, 60))
+    rows, cols, vals = sg.random_overlaps(rng, M, density=float(rng.uniform(0.1, 0.6)), p_fail=0.1, p_contained=0.02 if seed % 2 else 0.0, p_nodir=0.05, suffix_range=2500)
+    cutoff, fuzz = float(rng.choice([0.0, 0.65])), int(rng.choice([0, 1000]))
+    e = elba_amd.Engine(17, 2, 8)
+    e.set_overlaps(M, rows, cols, vals)
+    st = e.transitive_reduction(cutoff, fuzz)
+    g = e.export_string_graph()
+    want, wflags, wst = sg.python_string_graph(M, rows, cols, vals, cutoff, fuzz)
+    assert [(int(r), int(c)) for r, c in zip(g["rows"], g["cols"])] == [(r, c) for r, c, _ in want]
+    for a, (_, _, v) in enumerate(want):
+        for f in po.OVERLAP_DTYPE.names:
+            if f != "pad":
+                assert g["vals"][a][f] == v[f], (a, f)
+    assert list(e.export_read_flags(M)) == list(wflags)
+    for key in ("bad_reads", "edges_passed", "contained_reads", "edges_kept", "products", "marked", "removed", "nnz", "iterations"):
+        assert st[key] == wst[key], key
+    e.close()
