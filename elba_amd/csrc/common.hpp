@@ -148,6 +148,7 @@ struct Ctx {
     DevBuf a_hdr, a_hot;                       // RowHot[M], HotDesc[H]: per-row header + the row's hot descriptors (one per row entry and partner range); matrix.hip
     DevBuf a_hot8;                             // u64[H]: the same descriptors packed into 8 bytes (x | y << xb | z << (xb+yb) | w << (xb+yb+zb)) when the fields fit: what the SpGEMM then reads
     uint32_t hot_xb = 0, hot_yb = 0, hot_zb = 0; // field widths of the packed form; hot_xb == 0: not packed (a_hot is read)
+    bool pos16 = false;                        // every position among the entries is < 65536 (mirrored entries of B travel as 16-byte records then)
     uint32_t pay_pb = 0;                       // != 0: position-carrying formats (a_cscj word = partner read << pay_pb | position, packed descriptors carry the row entry's position): the SpGEMM's 64-bit accumulators
     int64_t H = 0;                             // hot descriptors overall
     int64_t Pnd = 0;                           // products the descriptors stand for (non-diagonal; an in-window pair on its smaller row only)

@@ -362,15 +362,18 @@ static void build_row_descriptors(Ctx &c)
     uint32_t pay_qbits = 16;                         // bits of the largest position (the descriptor's field)
     // (not for dense data — long columns, mean length >= 8: accurate reads with a high UPPER — where the 32-bit kernels combine runs of
     //  equal partners across lanes before the table, Table::insert_runs: measured 34.5 vs 51 ms on the dense-repeats set)
-    if (Z > 0 && Z < 8 * c.N && !getenv("ELBA_NO_PAY")) {
+    uint64_t maxpos = 0;
+    int64_t nbz = (Z + 255) / 256;
+    if (nbz > 2048) nbz = 2048;
+    if (Z > 0) {
         c.ws_scan.reserve(64);
         ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
-        int64_t nbz = (Z + 255) / 256;
-        if (nbz > 2048) nbz = 2048;
         hipLaunchKernelGGL(k_max_low32, dim3((unsigned)nbz), dim3(256), 0, s, cols, Z, c.ws_scan.as<unsigned long long>());
-        uint64_t maxpos = 0;
         ELBA_HIP(hipMemcpyAsync(&maxpos, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
         ELBA_HIP(hipStreamSynchronize(s));
+    }
+    c.pos16 = maxpos < 65536;                        // every position fits 16 bits: the mirror pass writes 16-byte records (spgemm.hip)
+    if (Z > 0 && Z < 8 * c.N && !getenv("ELBA_NO_PAY")) {
         const uint32_t pb = (uint32_t)bits_for(maxpos), mb = (uint32_t)bits_for((uint64_t)(M > 0 ? M - 1 : 0));
         pay_qbits = pb <= 16 ? pb : 16;
         if (pb <= 16) {

@@ -169,11 +169,23 @@ struct FinParams {
     uint64_t *sortkeys; unsigned long long sort_stride;
     uint32_t *sum_tmp;
     long long b_cap;         // capacity of b_col / b_val in entries: rows that would not fit are left out (the host regrows and reruns)
+    uint32_t mir16;          // positions fit 16 bits: a mirrored entry is ONE 16-byte word (i, q0 | t0 << 16, q1 | t1 << 16, numshared) — one store
+                             // request per scattered entry instead of two, half the bytes read back
 };
 
-__device__ __forceinline__ const StageRec *fin_rec(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t)
+// entry t of a row's extent: mirrored (the first `low`) or staged by the row itself; as the two halves of a staged record
+__device__ __forceinline__ void fin_load(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t, uint4 &a, uint4 &b)
 {
-    return t < low ? &p.mir[dst + t] : &p.tmp[off + (t - low)];
+    if (t >= low) { const StageRec *r = &p.tmp[off + (t - low)]; a = r->a; b = r->b; }
+    else if (p.mir16) {
+        const uint4 m = reinterpret_cast<const uint4 *>(p.mir)[dst + t];
+        a = make_uint4(m.x, 0xFFFFFFFFu, m.y & 0xFFFFu, m.y >> 16); b = make_uint4(m.z & 0xFFFFu, m.z >> 16, m.w, 0u);
+    } else { const StageRec *r = &p.mir[dst + t]; a = r->a; b = r->b; }
+}
+__device__ __forceinline__ uint32_t fin_col(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t)
+{
+    if (t >= low) return p.tmp[off + (t - low)].a.x;
+    return p.mir16 ? reinterpret_cast<const uint4 *>(p.mir)[dst + t].x : p.mir[dst + t].a.x;
 }
 __device__ __forceinline__ elba_seed_t rec_seed(const uint4 a, const uint4 b)
 {
@@ -259,8 +271,11 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
             const uint4 b = p.tmp[off + t].b;
             const int64_t at = p.b_rowptr[a.x] + (int64_t)a.y;
             if (at >= p.b_cap) continue;
-            p.mir[at].a = make_uint4(i, 0xFFFFFFFFu, a.w, a.z);
-            p.mir[at].b = make_uint4(b.y, b.x, b.z, 0u);
+            if (p.mir16) reinterpret_cast<uint4 *>(p.mir)[at] = make_uint4(i, a.w | a.z << 16, b.y | b.x << 16, b.z);
+            else {
+                p.mir[at].a = make_uint4(i, 0xFFFFFFFFu, a.w, a.z);
+                p.mir[at].b = make_uint4(b.y, b.x, b.z, 0u);
+            }
         }
     }
 }
@@ -288,8 +303,7 @@ __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
             const uint32_t t = (uint32_t)lane + 64u * u;
             mine[u] = 0xFFFFFFFFu;
             if (t < y) {
-                const StageRec *r = fin_rec(p, low, off, dst, t);
-                ra[u] = r->a; rb[u] = r->b;
+                fin_load(p, low, off, dst, t, ra[u], rb[u]);
                 mine[u] = ra[u].x;
                 cols[w][t] = mine[u];
             }
@@ -358,7 +372,7 @@ __global__ __launch_bounds__(256) void k_finalize_bucket(FinParams p)
         __syncthreads();
         const unsigned long long scale = scale_s;
         for (uint32_t t = tid; t < y; t += 256) {
-            const uint32_t col = fin_rec(p, low, off, dst, t)->a.x;
+            const uint32_t col = fin_col(p, low, off, dst, t);
             atomicAdd(&bstart[(uint32_t)(((unsigned long long)col * scale) >> 32)], 1u);
         }
         __syncthreads();
@@ -375,7 +389,7 @@ __global__ __launch_bounds__(256) void k_finalize_bucket(FinParams p)
         }
         __syncthreads();
         for (uint32_t t = tid; t < y; t += 256) {
-            const uint32_t col = fin_rec(p, low, off, dst, t)->a.x;
+            const uint32_t col = fin_col(p, low, off, dst, t);
             const uint32_t b = (uint32_t)(((unsigned long long)col * scale) >> 32);
             lkeys[bstart[b] + atomicAdd(&bfill[b], 1u)] = ((uint64_t)col << 32) | t;
         }
@@ -387,9 +401,10 @@ __global__ __launch_bounds__(256) void k_finalize_bucket(FinParams p)
             const uint32_t lo = bstart[b], hi = lo + bfill[b];
             uint32_t rank = 0;
             for (uint32_t x = lo; x < hi; ++x) rank += lkeys[x] < k ? 1u : 0u;
-            const StageRec *r = fin_rec(p, low, off, dst, (uint32_t)k);
+            uint4 ra, rb;
+            fin_load(p, low, off, dst, (uint32_t)k, ra, rb);
             p.b_col[dst + lo + rank] = col;
-            p.b_val[dst + lo + rank] = rec_seed(r->a, r->b);
+            p.b_val[dst + lo + rank] = rec_seed(ra, rb);
         }
         __syncthreads();
     }
@@ -410,14 +425,15 @@ __global__ __launch_bounds__(256) void k_finalize_huge(FinParams p)
         uint32_t n2 = 1;
         while (n2 < y) n2 <<= 1;
         for (uint32_t t = threadIdx.x; t < n2; t += 256)
-            keys[t] = t < y ? (((uint64_t)fin_rec(p, low, off, dst, t)->a.x << 32) | t) : ~0ull;
+            keys[t] = t < y ? (((uint64_t)fin_col(p, low, off, dst, t) << 32) | t) : ~0ull;
         __syncthreads();
         bitonic_sort<256>(keys, n2);
         for (uint32_t t = threadIdx.x; t < y; t += 256) {
             const uint64_t k = keys[t];
             p.b_col[dst + t] = (uint32_t)(k >> 32);
-            const StageRec *r = fin_rec(p, low, off, dst, (uint32_t)k);
-            p.b_val[dst + t] = rec_seed(r->a, r->b);
+            uint4 ra, rb;
+            fin_load(p, low, off, dst, (uint32_t)k, ra, rb);
+            p.b_val[dst + t] = rec_seed(ra, rb);
         }
         __syncthreads();
     }
@@ -631,6 +647,7 @@ void stage_create_seed_matrix(Ctx &c)
             f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
             f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
             f.b_cap = c.b_cap_entries;
+            f.mir16 = c.pos16 && !getenv("ELBA_MIR32") ? 1u : 0u;
             const int gblocks = 32;
             uint64_t sstride = 2;
             while (sstride < (uint64_t)M) sstride <<= 1;
