@@ -275,6 +275,7 @@ def main():
     cpu = None
     parity = None
     kmer_ref = None
+    distributions = None
     if rank == 0 and world == 1 and not force_dist and not args.no_cpu_baseline:
         from oracle import pyoracle as po   # checker + CPU baseline only
         A = runner.export_kmer_matrix()
@@ -288,6 +289,17 @@ def main():
                "sample": "the full workload's SpGEMM region (same A, P=%d products) once, oracle/elba_oracle.c orc_spgemm, gcc -O3" % o.stat("P"),
                "seconds": round(t1, 4), "all_cores": {"value": round(o.stat("Y") / tn, 1), "cores": ncores, "seconds": round(tn, 4)}}
         B = runner.export_csr(); oB = o.B()
+        # value distributions of the run: k-mer multiplicities, nnz per row of A, partners per row of B, products per output entry
+        try:
+            def _q(v):
+                v = np.asarray(v, dtype=np.int64)
+                return {"min": int(v.min()), "p50": int(np.percentile(v, 50)), "p90": int(np.percentile(v, 90)), "p99": int(np.percentile(v, 99)), "max": int(v.max()), "mean": round(float(v.mean()), 2)} if len(v) else None
+            hist = eng.kmer_histogram()
+            distributions = {"kmer_multiplicity_histogram": {str(c_): int(n_) for c_, n_ in enumerate(hist) if n_},
+                             "row_nnz_A": _q(np.diff(A["rowptr"])), "partners_per_row_B": _q(np.diff(B["rowptr"])),
+                             "numshared": _q(B["val"]["numshared"]), "products_per_overlap_nnz": round(st["products"] / max(1, st["nnz"]), 2)}
+        except Exception as ex:               # noqa: BLE001
+            distributions = {"error": "%s: %s" % (type(ex).__name__, ex)}
         parity = bool(B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"]).all() and (B["val"] == oB["val"]).all())
         # the reference's OWN k-mer stage on one host core, on a bounded sample of the reads (oracle/_ref: Kmer::GetRepKmers, and the two-pass
         # Bloom + map control flow of src/KmerOps.cpp replayed on the reference's Bloom / Kmer code) — a reported baseline, nothing more
@@ -364,6 +376,7 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_vs_oracle": parity,
+            "distributions": distributions,
             "cold_call_ms": None if cold_ms is None else round(cold_ms, 4),
             "aux_errors": aux_errors or None,
             "ingest_stage": ingest,
