@@ -336,3 +336,19 @@ def test_words_one_or_two_bits_short_mark_rare_positions_for_lookup():
     # some surviving seed really sits on a marked position
     assert ((oB["val"]["t0"] >= 8191) | (oB["val"]["t1"] >= 8191)).sum() > 0
     e.close()
+
+
+@pytest.mark.parametrize("knob", ["ELBA_NO_SYMMETRY", "ELBA_NO_PERMUTE", "ELBA_KMER_HASH", "ELBA_KMER_PAIRS", "ELBA_MIR32"])
+def test_alternative_paths_kept_for_ab_runs_give_the_same_matrices(knob, monkeypatch):
+    """Build-time / run-time alternatives kept behind environment knobs (both triangles described instead of one + mirror, canonical column
+    order, hash-based counting, (value, payload) pairs through the k-mer sort, 32-byte mirror records): A and B must not change."""
+    monkeypatch.setenv(knob, "1")
+    packed, off, lens, info = elba_amd.synth_reads(61, 200000, 16, 3000, 900, error_rate=0.10, min_len=200)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 8)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    st2 = e.create_seed_matrix()                       # steady-state call on the same matrix
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
