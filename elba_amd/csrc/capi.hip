@@ -471,6 +471,7 @@ int elba_dist_get_reliable_kmers(elba_ctx *ctx, const void **d_kmers, int64_t *n
     return guarded(ctx, [&](Ctx &c) {
         ELBA_REQUIRE(d_kmers && n, ELBA_ERR_INVALID_ARG, "dist_get_reliable_kmers: null output");
         ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_get_reliable_kmers: call dist_count_records first");
+        ELBA_REQUIRE(c.cfg.k <= 31, ELBA_ERR_UNSUPPORTED, "dist_get_reliable_kmers: multi-word k-mers are handed out interleaved by elba_dist_copy_reliable_kmers");
         *d_kmers = c.rel_kmers.p; *n = c.N;
     });
 }
@@ -480,8 +481,7 @@ int elba_dist_copy_reliable_kmers(elba_ctx *ctx, void *d_dst, int64_t capacity)
     return guarded(ctx, [&](Ctx &c) {
         ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_copy_reliable_kmers: call dist_count_records first");
         ELBA_REQUIRE(capacity >= c.N && (d_dst || c.N == 0), ELBA_ERR_INVALID_ARG, "dist_copy_reliable_kmers: buffer too small");
-        if (c.N > 0) ELBA_HIP(hipMemcpyAsync(d_dst, c.rel_kmers.p, (size_t)c.N * 8, hipMemcpyDeviceToDevice, c.stream));
-        ELBA_HIP(hipStreamSynchronize(c.stream));
+        stage_dist_copy_reliable_kmers(c, d_dst);
     });
 }
 

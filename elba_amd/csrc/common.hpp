@@ -226,6 +226,7 @@ void stage_transitive_reduction(Ctx &c, double bad_read_cutoff, int fuzz);   // 
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host);                                   // kmer.hip
 void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);
 void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec);
+void stage_dist_copy_reliable_kmers(Ctx &c, void *d_dst);       // N k-mers of 1 + (k > 32) + (k > 64) words each, interleaved
 void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall);
 void stage_dist_panel(Ctx &c, int nranks, const uint64_t *bounds_host, bool fill, void *d_send, uint64_t *counts_or_offsets_host);
 void stage_dist_set_panel(Ctx &c, const void *d_rec, int64_t nrec, int64_t M_total, int64_t N_total, int64_t row_lo, int64_t row_hi);

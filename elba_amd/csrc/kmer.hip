@@ -646,7 +646,7 @@ void stage_create_kmer_matrix(Ctx &c)
 //   ids          reliable k-mers of all owners are all-gathered; global k-mer id = rank of the packed value  [all-gather]
 //   exchange #2  each column goes, whole, to every rank that owns at least one of its reads (the column panel) [all-to-all]
 // The collectives themselves are issued by the host driver (torch.distributed: RCCL on GPUs, gloo in the CPU tests); the
-// kernels below only produce / consume the device buffers.  A record is two u64 words.
+// kernels below only produce / consume the device buffers.  A record of exchange #1 is W + 1 u64 words (W words of k-mer, 1 for k <= 31), of exchange #2 two.
 // =====================================================================================================================
 namespace elba {
 
@@ -659,35 +659,99 @@ __device__ __forceinline__ uint32_t owner_of(uint64_t km, uint32_t nranks)
     return (uint32_t)__umul64hi(mix64(km), (uint64_t)nranks);      // uniform over ranks (cf. GetKmerOwner, src/KmerOps.cpp:352-359)
 }
 
+// W = 64-bit words per k-mer (1 for k <= 31, 2 up to 63, 3 up to 95).  A record of exchange #1 is W + 1 words: the k-mer, most
+// significant word first, then global read << 32 | pos.  The owner of a multi-word k-mer hashes all its words.
+template <int W, class F>
+__device__ __forceinline__ void for_each_kmer_words(const EnumParams &e, F &&f)
+{
+    if constexpr (W == 1) for_each_instance(e, [&](uint64_t g, uint32_t r, uint32_t p, uint64_t km) { f(g, r, p, km, 0ull, 0ull); });
+    else for_each_position(e, [&](uint64_t g, uint32_t r, uint32_t p) {
+        uint64_t a, b, c2 = 0;
+        if constexpr (W == 2) canonical2_at(e, r, p, a, b); else canonical3_at(e, r, p, a, b, c2);
+        f(g, r, p, a, b, c2);
+    });
+}
+template <int W>
+__device__ __forceinline__ uint32_t owner_of_words(uint64_t a, uint64_t b, uint64_t c2, uint32_t nranks)
+{
+    if constexpr (W == 1) return owner_of(a, nranks);
+    else return (uint32_t)__umul64hi(mix64(a ^ mix64(b ^ mix64(c2))), (uint64_t)nranks);
+}
+
+template <int W>
 __global__ __launch_bounds__(EN_THREADS) void k_dist_count_owners(EnumParams e, uint32_t nranks, unsigned long long *counts)
 {
     __shared__ uint32_t hist[MAX_RANKS];
     if (threadIdx.x < MAX_RANKS) hist[threadIdx.x] = 0;
     __syncthreads();
-    for_each_instance(e, [&](uint64_t, uint32_t, uint32_t, uint64_t km) { atomicAdd(&hist[owner_of(km, nranks)], 1u); });
+    for_each_kmer_words<W>(e, [&](uint64_t, uint32_t, uint32_t, uint64_t a, uint64_t b, uint64_t c2) { atomicAdd(&hist[owner_of_words<W>(a, b, c2, nranks)], 1u); });
     __syncthreads();
     if (threadIdx.x < nranks && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
+template <int W>
 __global__ __launch_bounds__(EN_THREADS) void k_dist_fill_send(EnumParams e, uint32_t nranks, uint64_t first_global_id, uint64_t *send, unsigned long long *cursors)
 {
     __shared__ uint32_t hist[MAX_RANKS];
     __shared__ unsigned long long base[MAX_RANKS];
     if (threadIdx.x < MAX_RANKS) hist[threadIdx.x] = 0;
     __syncthreads();
-    for_each_instance(e, [&](uint64_t, uint32_t, uint32_t, uint64_t km) { atomicAdd(&hist[owner_of(km, nranks)], 1u); });
+    for_each_kmer_words<W>(e, [&](uint64_t, uint32_t, uint32_t, uint64_t a, uint64_t b, uint64_t c2) { atomicAdd(&hist[owner_of_words<W>(a, b, c2, nranks)], 1u); });
     __syncthreads();
     if (threadIdx.x < nranks) {
         base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]) : 0ull;
         hist[threadIdx.x] = 0;
     }
     __syncthreads();
-    for_each_instance(e, [&](uint64_t, uint32_t r, uint32_t p, uint64_t km) {
-        const uint32_t o = owner_of(km, nranks);
+    for_each_kmer_words<W>(e, [&](uint64_t, uint32_t r, uint32_t p, uint64_t a, uint64_t b, uint64_t c2) {
+        const uint32_t o = owner_of_words<W>(a, b, c2, nranks);
         const unsigned long long at = base[o] + atomicAdd(&hist[o], 1u);
-        send[2 * at] = km;
-        send[2 * at + 1] = ((first_global_id + r) << 32) | p;
+        uint64_t *rec = send + (size_t)(W + 1) * at;
+        rec[0] = a;
+        if constexpr (W >= 2) rec[1] = b;
+        if constexpr (W >= 3) rec[2] = c2;
+        rec[W] = ((first_global_id + r) << 32) | p;
     });
+}
+
+// records of W + 1 words -> W word arrays + the payload
+__global__ void k_split_records(const uint64_t *rec, uint64_t n, int rw, uint64_t *w0, uint64_t *w1, uint64_t *w2, uint64_t *val, uint64_t *idx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t *r = rec + (size_t)rw * i;
+    w0[i] = r[0];
+    if (w1) w1[i] = r[1];
+    if (w2) w2[i] = r[2];
+    if (val) val[i] = r[rw - 1];
+    if (idx) idx[i] = i;
+}
+
+// W word arrays -> interleaved words (what travels in the all-gather of the reliable k-mers)
+__global__ void k_join_words(const uint64_t *w0, const uint64_t *w1, const uint64_t *w2, uint64_t n, int W, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[(size_t)W * i] = w0[i];
+    if (W >= 2) out[(size_t)W * i + 1] = w1[i];
+    if (W >= 3) out[(size_t)W * i + 2] = w2[i];
+}
+
+// global id of a multi-word k-mer: its rank in the sorted union (word arrays, lexicographic)
+__global__ void k_global_ids_words(const uint64_t *l0, const uint64_t *l1, const uint64_t *l2, uint64_t nlocal, const uint64_t *a0, const uint64_t *a1, const uint64_t *a2, uint64_t nall,
+                                   uint32_t *gid)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlocal) return;
+    const uint64_t x0 = l0[i], x1 = l1[i], x2 = l2 ? l2[i] : 0;
+    uint64_t lo = 0, hi = nall;               // first index whose k-mer is >= (x0, x1, x2)
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint64_t y0 = a0[mid], y1 = a1[mid], y2 = a2 ? a2[mid] : 0;
+        const bool less = y0 < x0 || (y0 == x0 && (y1 < x1 || (y1 == x1 && y2 < x2)));
+        if (less) lo = mid + 1; else hi = mid;
+    }
+    gid[i] = (uint32_t)lo;
 }
 
 // global id of each local reliable k-mer = its rank in the sorted union of all owners' reliable k-mers
@@ -746,9 +810,26 @@ int bits_needed(uint64_t maxval)
 
 }  // namespace
 
+static int kmer_words(int k) { return k > 64 ? 3 : (k > 32 ? 2 : 1); }      // (k is odd: 31 is the last one-word k, 63 the last two-word k)
+
+// Stable LSD sort of n multi-word keys (src[0] most significant) through an index permutation, last word first; `perm` receives the
+// order (perm[j] = index of the j-th smallest key).  Scratch: four n-word buffers.
+static const uint64_t *sort_words_permutation(Ctx &c, int words, const uint64_t *const src[3], uint64_t n, int k, uint64_t *ia, uint64_t *ib, uint64_t *ka, uint64_t *kb)
+{
+    hipStream_t s = c.stream;
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    for (int wd = words - 1; wd >= 0; --wd) {
+        if (wd == words - 1) ELBA_HIP(hipMemcpyAsync(ka, src[wd], (size_t)n * 8, hipMemcpyDeviceToDevice, s));     // ia is the identity here
+        else hipLaunchKernelGGL(k_gather_u64, dim3(nb), dim3(256), 0, s, ia, src[wd], n, ka);
+        const int lo_bit = wd == words - 1 ? 64 - 2 * (k - 32 * (words - 1)) : 0;
+        const int w = radix_sort_pairs(s, ka, ia, kb, ib, (int64_t)n, lo_bit, 64, c.ws_sort);
+        if (w) { uint64_t *t; t = ia; ia = ib; ib = t; t = ka; ka = kb; kb = t; }
+    }
+    return ia;
+}
+
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host)
 {
-    ELBA_REQUIRE(c.cfg.k <= 31, ELBA_ERR_UNSUPPORTED, "the multi-GPU exchange carries one-word k-mers (k <= 31)");
     ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "dist_count_owners: no reads");
     ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS, ELBA_ERR_INVALID_ARG, "dist_count_owners: 1..64 ranks");
     hipStream_t s = c.stream;
@@ -766,7 +847,12 @@ void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host)
     ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, MAX_RANKS * 8, s));
     EnumParams e = make_enum(c);
     const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
-    if (I > 0) hipLaunchKernelGGL(k_dist_count_owners, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, c.ws_scan.as<unsigned long long>());
+    if (I > 0) {
+        const int W = kmer_words(k);
+        if (W == 1) hipLaunchKernelGGL(k_dist_count_owners<1>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, c.ws_scan.as<unsigned long long>());
+        else if (W == 2) hipLaunchKernelGGL(k_dist_count_owners<2>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, c.ws_scan.as<unsigned long long>());
+        else hipLaunchKernelGGL(k_dist_count_owners<3>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, c.ws_scan.as<unsigned long long>());
+    }
     ELBA_HIP(hipMemcpyAsync(counts_host, c.ws_scan.p, (size_t)nranks * 8, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
 }
@@ -780,9 +866,14 @@ void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offs
     ELBA_HIP(hipMemcpyAsync(c.ws_scan.p, offsets_host, (size_t)nranks * 8, hipMemcpyHostToDevice, s));
     EnumParams e = make_enum(c);
     const uint64_t nblocks = ((uint64_t)c.I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
-    if (c.I > 0)
-        hipLaunchKernelGGL(k_dist_fill_send, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, (uint64_t)c.first_global_id,
-                           static_cast<uint64_t *>(d_send), c.ws_scan.as<unsigned long long>());
+    if (c.I > 0) {
+        const int W = kmer_words(c.cfg.k);
+        uint64_t *snd = static_cast<uint64_t *>(d_send);
+        unsigned long long *cur = c.ws_scan.as<unsigned long long>();
+        if (W == 1) hipLaunchKernelGGL(k_dist_fill_send<1>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, (uint64_t)c.first_global_id, snd, cur);
+        else if (W == 2) hipLaunchKernelGGL(k_dist_fill_send<2>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, (uint64_t)c.first_global_id, snd, cur);
+        else hipLaunchKernelGGL(k_dist_fill_send<3>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, (uint64_t)c.first_global_id, snd, cur);
+    }
     ELBA_HIP(hipStreamSynchronize(s));
 }
 
@@ -801,12 +892,34 @@ void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
     // sorted by (read, pos) afterwards.
     c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_b.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8); c.ws_d.reserve((size_t)(I + 2) * 8);
     c.ws_e.reserve((size_t)(I + 2) * 4); c.ws_f.reserve((size_t)(I + 2) * 8);
+    uint64_t nruns = 0, N = 0, Z = 0;
+    const int W = kmer_words(k);
+    if (W > 1) {
+        // multi-word k-mers: records of W + 1 words -> word arrays, an index permutation sorted last word first, everything gathered in that order
+        DevBuf w0, w1, w2, val, i0, i1, t0, t1, s2;
+        for (DevBuf *b : {&w0, &w1, &val, &i0, &i1, &t0, &t1}) b->reserve((size_t)(I + 2) * 8);
+        if (W == 3) { w2.reserve((size_t)(I + 2) * 8); s2.reserve((size_t)(I + 2) * 8); }
+        const unsigned nbI = (unsigned)((I + 255) / 256);
+        uint64_t *shi = c.ws_a.as<uint64_t>(), *slo = c.ws_b.as<uint64_t>(), *sval = c.ws_c.as<uint64_t>(), *slo2 = W == 3 ? s2.as<uint64_t>() : nullptr;
+        if (I > 0) {
+            hipLaunchKernelGGL(k_split_records, dim3(nbI), dim3(256), 0, s, c.d_records, I, W + 1, w0.as<uint64_t>(), w1.as<uint64_t>(), W == 3 ? w2.as<uint64_t>() : (uint64_t *)nullptr,
+                               val.as<uint64_t>(), i0.as<uint64_t>());
+            const uint64_t *src[3] = {w0.as<uint64_t>(), w1.as<uint64_t>(), W == 3 ? w2.as<uint64_t>() : nullptr};
+            const uint64_t *perm = sort_words_permutation(c, W, src, I, k, i0.as<uint64_t>(), i1.as<uint64_t>(), t0.as<uint64_t>(), t1.as<uint64_t>());
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, perm, w0.as<uint64_t>(), I, shi);
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, perm, w1.as<uint64_t>(), I, slo);
+            if (W == 3) hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, perm, w2.as<uint64_t>(), I, slo2);
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, perm, val.as<uint64_t>(), I, sval);
+        }
+        // (the permutation buffers are dead once the gathers are queued: runs_to_columns may use two of them as scratch)
+        runs_to_columns(c, shi, sval, t0.as<uint64_t>(), t1.as<uint64_t>(), I, nruns, N, Z, slo, slo2);
+    } else {
     if (I > 0) hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, c.d_records, I, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
     const int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)I, 64 - 2 * k, 64, c.ws_sort);
     const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>(), *svals = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
     uint64_t *spare_k = where ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>(), *spare_v = where ? c.ws_b.as<uint64_t>() : c.ws_d.as<uint64_t>();
-    uint64_t nruns = 0, N = 0, Z = 0;
     runs_to_columns(c, skeys, svals, spare_k, spare_v, I, nruns, N, Z);
+    }
     c.ws_f.reserve((size_t)(Z + 1) * 8);
     if (N > 0)
         hipLaunchKernelGGL(k_sort_columns, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.ws_f.as<uint64_t>(), N);
@@ -819,12 +932,49 @@ void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
     c.dist_owner = true;
 }
 
+void stage_dist_copy_reliable_kmers(Ctx &c, void *d_dst)
+{
+    hipStream_t s = c.stream;
+    const int W = kmer_words(c.cfg.k);
+    if (c.N > 0) {
+        if (W == 1) ELBA_HIP(hipMemcpyAsync(d_dst, c.rel_kmers.p, (size_t)c.N * 8, hipMemcpyDeviceToDevice, s));
+        else hipLaunchKernelGGL(k_join_words, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), c.rel_kmers_lo.as<uint64_t>(),
+                                W == 3 ? c.rel_kmers_lo2.as<uint64_t>() : (const uint64_t *)nullptr, (uint64_t)c.N, W, static_cast<uint64_t *>(d_dst));
+    }
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
 // After the all-gather of every owner's sorted reliable k-mers: global k-mer ids of the local columns.
 void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall)
 {
     ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_set_global_kmers: call dist_count_records first");
     ELBA_REQUIRE(nall >= c.N && nall < 0xFFFFFFF0ll, ELBA_ERR_INVALID_ARG, "dist_set_global_kmers: bad global k-mer count");
     hipStream_t s = c.stream;
+    const int W = kmer_words(c.cfg.k);
+    if (W > 1) {
+        // d_all: nall k-mers of W interleaved words each
+        DevBuf w0, w1, w2, i0, i1, t0, t1, s0, s1, s2;
+        for (DevBuf *b : {&w0, &w1, &i0, &i1, &t0, &t1, &s0, &s1}) b->reserve((size_t)(nall + 2) * 8);
+        if (W == 3) { w2.reserve((size_t)(nall + 2) * 8); s2.reserve((size_t)(nall + 2) * 8); }
+        const unsigned nbA = (unsigned)((nall + 255) / 256);
+        c.dist_gid.reserve((size_t)(c.N + 1) * 4);
+        if (nall > 0) {
+            hipLaunchKernelGGL(k_split_records, dim3(nbA), dim3(256), 0, s, static_cast<const uint64_t *>(d_all), (uint64_t)nall, W, w0.as<uint64_t>(), w1.as<uint64_t>(),
+                               W == 3 ? w2.as<uint64_t>() : (uint64_t *)nullptr, (uint64_t *)nullptr, i0.as<uint64_t>());
+            const uint64_t *src[3] = {w0.as<uint64_t>(), w1.as<uint64_t>(), W == 3 ? w2.as<uint64_t>() : nullptr};
+            const uint64_t *perm = sort_words_permutation(c, W, src, (uint64_t)nall, c.cfg.k, i0.as<uint64_t>(), i1.as<uint64_t>(), t0.as<uint64_t>(), t1.as<uint64_t>());
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbA), dim3(256), 0, s, perm, w0.as<uint64_t>(), (uint64_t)nall, s0.as<uint64_t>());
+            hipLaunchKernelGGL(k_gather_u64, dim3(nbA), dim3(256), 0, s, perm, w1.as<uint64_t>(), (uint64_t)nall, s1.as<uint64_t>());
+            if (W == 3) hipLaunchKernelGGL(k_gather_u64, dim3(nbA), dim3(256), 0, s, perm, w2.as<uint64_t>(), (uint64_t)nall, s2.as<uint64_t>());
+        }
+        if (c.N > 0)
+            hipLaunchKernelGGL(k_global_ids_words, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), c.rel_kmers_lo.as<uint64_t>(),
+                               W == 3 ? c.rel_kmers_lo2.as<uint64_t>() : (const uint64_t *)nullptr, (uint64_t)c.N, s0.as<uint64_t>(), s1.as<uint64_t>(),
+                               W == 3 ? s2.as<uint64_t>() : (const uint64_t *)nullptr, (uint64_t)nall, c.dist_gid.as<uint32_t>());
+        ELBA_HIP(hipStreamSynchronize(s));
+        c.dist_nall = nall;
+        return;
+    }
     c.ws_a.reserve((size_t)(nall + 1) * 8); c.ws_b.reserve((size_t)(nall + 1) * 8); c.ws_c.reserve((size_t)(nall + 1) * 8); c.ws_d.reserve((size_t)(nall + 1) * 8);
     if (nall > 0) ELBA_HIP(hipMemcpyAsync(c.ws_a.p, d_all, (size_t)nall * 8, hipMemcpyDeviceToDevice, s));
     int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), nall, 64 - 2 * c.cfg.k, 64, c.ws_sort);

@@ -36,6 +36,11 @@ def partition_by_bases(lens, nranks):
     return np.array(bounds, dtype=np.int64)
 
 
+def kmer_words(k):
+    """64-bit words per k-mer (NLONGS, include/Kmer.hpp:95-97): a record of exchange #1 is that many words + one of (read << 32 | pos)."""
+    return 3 if k > 64 else (2 if k > 32 else 1)
+
+
 class HipBackend:
     """The product backend: every method is one C-ABI call on device buffers owned by torch tensors."""
 
@@ -58,8 +63,8 @@ class HipBackend:
         L.elba_dist_set_panel.restype = i32; L.elba_dist_set_panel.argtypes = [vp, vp, i64, i64, i64, i64, i64, C.POINTER(capi.MatrixStats)]
         L.elba_dist_set_all_reads.restype = i32; L.elba_dist_set_all_reads.argtypes = [vp, vp, i64, vp, vp, i64]
 
-    def empty_records(self, n):
-        return self.torch.empty((max(int(n), 0), 2), dtype=self.torch.int64, device=self.dev)
+    def empty_records(self, n, width=2):
+        return self.torch.empty((max(int(n), 0), int(width)), dtype=self.torch.int64, device=self.dev)
 
     def empty_words(self, n):
         return self.torch.empty((max(int(n), 0),), dtype=self.torch.int64, device=self.dev)
@@ -109,12 +114,14 @@ class HipBackend:
         return capi._stats(st)
 
     def reliable_kmers(self, n):
-        out = self.empty_words(n)
+        """n k-mers of kmer_words(k) interleaved words each."""
+        out = self.empty_words(n * kmer_words(self.e.k))
         self.e._check(self.L.elba_dist_copy_reliable_kmers(self.h, out.data_ptr() if n else None, n))
         return out
 
     def set_global_kmers(self, allk):
-        self.e._check(self.L.elba_dist_set_global_kmers(self.h, allk.data_ptr() if allk.numel() else None, allk.numel()))
+        nall = allk.numel() // kmer_words(self.e.k)
+        self.e._check(self.L.elba_dist_set_global_kmers(self.h, allk.data_ptr() if allk.numel() else None, nall))
         self._rec = None
 
     def panel_counts(self, nranks, bounds):
@@ -187,7 +194,8 @@ class DistributedOverlap:
     def _all_to_all_records(self, send, send_counts, recv_counts):
         torch = self.be.torch
         sc = np.asarray(send_counts, dtype=np.int64); rc = np.asarray(recv_counts, dtype=np.int64)
-        recv = self.be.empty_records(int(rc.sum()))
+        width = int(send.shape[1])
+        recv = self.be.empty_records(int(rc.sum()), width)
         # Batched like the reference's BatchState (include/KmerOps.hpp:33-56, MAX_ALLTOALL_MEM): at most MAX_RECORDS_PER_PEER
         # records per peer and round.  Measured on MI355X / RCCL 2.26.6 (scratch test in profiles/r01_notes.md): a single
         # all_to_all_single message of >= ~2 GiB per peer delivers only its first GiB, silently.
@@ -205,7 +213,7 @@ class DistributedOverlap:
                 s_lo = np.minimum(r * CH, sc); s_hi = np.minimum((r + 1) * CH, sc)
                 r_lo = np.minimum(r * CH, rc); r_hi = np.minimum((r + 1) * CH, rc)
                 part = torch.cat([send[int(soff[p] + s_lo[p]):int(soff[p] + s_hi[p])] for p in range(self.world)])
-                got = self.be.empty_records(int((r_hi - r_lo).sum()))
+                got = self.be.empty_records(int((r_hi - r_lo).sum()), width)
                 self.dist.all_to_all_single(got, part, output_split_sizes=[int(x) for x in (r_hi - r_lo)], input_split_sizes=[int(x) for x in (s_hi - s_lo)])
                 pos = 0
                 for p in range(self.world):
@@ -239,16 +247,17 @@ class DistributedOverlap:
         # exchange #1: instances to owners
         sc = self.be.count_owners(W)
         rc = self._exchange_counts(sc)
-        send = self.be.empty_records(int(sc.sum()))
+        kw = kmer_words(self.k)
+        send = self.be.empty_records(int(sc.sum()), kw + 1)
         self.be.fill_send(W, send, np.concatenate([[0], np.cumsum(sc)[:-1]]))
         recv = self._all_to_all_records(send, sc, rc)
         del send
         ks = self.be.count_records(recv)
         # global k-mer ids
         nloc = int(ks["reliable"])
-        allk, ns = self._all_gather_words(self.be.reliable_kmers(nloc), nloc)
+        allk, ns = self._all_gather_words(self.be.reliable_kmers(nloc), nloc * kw)
         self.be.set_global_kmers(allk)
-        n_total = int(sum(ns))
+        n_total = int(sum(ns)) // kw
         del recv, allk
         # exchange #2: column panels to the owners of the reads
         pc = self.be.panel_counts(W, self.bounds)
@@ -265,7 +274,7 @@ class DistributedOverlap:
         ms = dict(ms)
         ms["panel_records"] = int(prc.sum())
         ms["nnz"] = int(prc.sum())
-        self.exchange_bytes = dict(instances=int(sc.sum()) * 16, panels=int(pc.sum()) * 16)
+        self.exchange_bytes = dict(instances=int(sc.sum()) * 8 * (kw + 1), panels=int(pc.sum()) * 16)
         return ks, ms
 
     def create_seed_matrix(self):

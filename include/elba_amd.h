@@ -116,8 +116,7 @@ typedef struct {
 } elba_string_stats;
 
 typedef struct {
-    int32_t k;          /* KMER_SIZE: odd, 3..95 as in the reference (one to three 64-bit words per k-mer; reference: compile-time, Makefile:1).  The multi-GPU
-                           exchange (elba_dist_*) carries one-word k-mers: k <= 31 */
+    int32_t k;          /* KMER_SIZE: odd, 3..95 as in the reference (one to three 64-bit words per k-mer; reference: compile-time, Makefile:1) */
     int32_t lower;      /* LOWER_KMER_FREQ >= 2 (SURVEY.md App. A.4 precondition)            */
     int32_t upper;      /* UPPER_KMER_FREQ <= 65535                                          */
     int32_t device;     /* HIP device ordinal                                                */
@@ -286,21 +285,23 @@ int  elba_get_device_view(elba_ctx *ctx, elba_device_view *view);
  * They replace, for a 1D read-row partition over the GPUs of one node, what the reference does with MPI inside the same four
  * functions: the two k-mer all-to-alls (src/KmerOps.cpp:117-151, :244-274), the k-mer id Exscan (:371-375), and the
  * redistribution of A / AT to their consumers (SpParMat ctor :396-400, Transpose src/main.cpp:272-273).
- * A record is two uint64 words.  Exchange #1 records: (packed canonical k-mer, global read id << 32 | pos).
- * Exchange #2 records: (global k-mer id, global read id << 32 | pos), a column's entries contiguous and ordered by (read,pos). */
+ * Exchange #1 records: (packed canonical k-mer, global read id << 32 | pos) — W + 1 uint64 words, W = words per k-mer (1 for k <= 31,
+ * 2 up to 63, 3 up to 95; NLONGS of include/Kmer.hpp:95-97), most significant word first.
+ * Exchange #2 records: two words, (global k-mer id, global read id << 32 | pos), a column's entries contiguous and ordered by (read,pos). */
 #define ELBA_MAX_RANKS 64
 /* instances of this rank's reads per owner rank (owner = hash of the k-mer, cf. GetKmerOwner src/KmerOps.cpp:352-359) */
 int  elba_dist_count_owners(elba_ctx *ctx, int nranks, uint64_t *counts);
-/* write this rank's records into d_send (device, 16 B per record) grouped by owner; offsets[r] = first record index of owner r */
+/* write this rank's records into d_send (device, 8 (W + 1) bytes per record) grouped by owner; offsets[r] = first record index of owner r */
 int  elba_dist_fill_send(elba_ctx *ctx, int nranks, void *d_send, const uint64_t *offsets);
 /* owner side: exact count + [lower, upper] filter of the received records; builds the owner's columns (device; records are
  * borrowed until elba_dist_set_global_kmers returns) */
 int  elba_dist_count_records(elba_ctx *ctx, const void *d_records, int64_t nrecords, elba_kmer_stats *stats);
-/* device pointer to this owner's reliable k-mers, ascending (input of the all-gather) */
+/* device pointer to this owner's reliable k-mers, ascending (input of the all-gather); one-word k-mers only */
 int  elba_dist_get_reliable_kmers(elba_ctx *ctx, const void **d_kmers, int64_t *n);
-/* copy them into a caller-owned device buffer of at least n words (e.g. a torch tensor that takes part in the all-gather) */
+/* copy them into a caller-owned device buffer of at least W * capacity words, the W words of a k-mer adjacent (e.g. a torch tensor that
+ * takes part in the all-gather); capacity counts k-mers */
 int  elba_dist_copy_reliable_kmers(elba_ctx *ctx, void *d_dst, int64_t capacity);
-/* all owners' reliable k-mers concatenated (any order): global k-mer id = rank of the packed value */
+/* all owners' reliable k-mers concatenated (any order; nall k-mers of W adjacent words): global k-mer id = rank of the packed value */
 int  elba_dist_set_global_kmers(elba_ctx *ctx, const void *d_all_kmers, int64_t nall);
 /* column panels: read_bounds[r] = first global read id of rank r (read_bounds[nranks] = total reads).  counts[r] = records this
  * owner sends to rank r: every column, whole, for every rank that owns at least one of its reads */

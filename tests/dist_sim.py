@@ -123,14 +123,28 @@ class NumpyBackend:
         self.torch = torch
         self.dev = torch.device("cpu")
 
-    def empty_records(self, n):
-        return torch.zeros((max(int(n), 0), 2), dtype=torch.int64)
+    def empty_records(self, n, width=2):
+        return torch.zeros((max(int(n), 0), int(width)), dtype=torch.int64)
 
     def empty_words(self, n):
         return torch.zeros((max(int(n), 0),), dtype=torch.int64)
 
+    @property
+    def kw(self):
+        return 3 if self.k > 64 else (2 if self.k > 32 else 1)
+
     def set_reads(self, packed, off, lens, first_global_id):
         L = po.lib()
+        if self.kw > 1:                                    # multi-word k-mers: one oracle call per position (test sizes only)
+            rows, rp = [], []
+            w = np.zeros(3, dtype=np.uint64)
+            for r in range(len(lens)):
+                for p in range(max(0, int(lens[r]) - self.k + 1)):
+                    L.orc_kmerN_at(packed.ctypes.data + int(off[r]), p, self.k, w.ctypes.data)
+                    rows.append(w[:self.kw].copy()); rp.append(((first_global_id + r) << 32) | p)
+            self.km = np.array(rows, dtype=np.uint64).reshape(-1, self.kw)
+            self.rp = np.array(rp, dtype=np.uint64)
+            return
         kms, rds, pss = [], [], []
         for r in range(len(lens)):
             out = np.zeros(max(1, int(lens[r])), dtype=np.uint64)
@@ -140,6 +154,9 @@ class NumpyBackend:
         self.rp = ((np.concatenate(rds) << np.uint64(32)) | np.concatenate(pss)) if kms else np.zeros(0, np.uint64)
 
     def _owner(self, km, W):
+        if km.ndim == 2:                                   # every word takes part in the owner hash
+            h = _mix64(km[:, 2]) if km.shape[1] == 3 else _mix64(np.zeros(len(km), dtype=np.uint64))
+            km = km[:, 0] ^ _mix64(km[:, 1] ^ h)
         return ((_mix64(km) >> np.uint64(32)) * np.uint64(W) >> np.uint64(32)).astype(np.int64)
 
     def count_owners(self, W):
@@ -148,11 +165,27 @@ class NumpyBackend:
 
     def fill_send(self, W, send, offsets):
         order = np.argsort(self.own, kind="stable")
-        rec = np.stack([self.km[order], self.rp[order]], axis=1).view(np.int64)
+        km = self.km[order] if self.km.ndim == 2 else self.km[order][:, None]
+        rec = np.concatenate([km, self.rp[order][:, None]], axis=1).view(np.int64)
         send.copy_(torch.from_numpy(rec.copy()))
 
     def count_records(self, rec):
         a = rec.numpy().view(np.uint64)
+        if self.kw > 1:
+            kw = self.kw
+            rp = a[:, kw]
+            order = np.lexsort([rp] + [a[:, w] for w in range(kw - 1, -1, -1)])      # by words (first word most significant), then (read, pos)
+            a = a[order]
+            keys = a[:, :kw]
+            new = np.ones(len(a), dtype=bool)
+            if len(a) > 1:
+                new[1:] = (keys[1:] != keys[:-1]).any(axis=1)
+            start = np.flatnonzero(new)
+            cnt = np.diff(np.append(start, len(a)))
+            keep = (cnt >= self.lower) & (cnt <= self.upper)
+            self.rel = keys[start[keep]]
+            self.cols = [a[s:s + c, kw] for s, c in zip(start[keep], cnt[keep])]
+            return dict(nreads=0, instances=len(a), distinct=len(start), reliable=int(keep.sum()), entries=int(cnt[keep].sum()), ms_total=0.0, ms_count=0.0, ms_lookup=0.0, ms_sort=0.0)
         km, rp = a[:, 0], a[:, 1]
         order = np.lexsort((rp, km))
         km, rp = km[order], rp[order]
@@ -163,9 +196,15 @@ class NumpyBackend:
         return dict(nreads=0, instances=len(km), distinct=len(uk), reliable=int(keep.sum()), entries=int(cnt[keep].sum()), ms_total=0.0, ms_count=0.0, ms_lookup=0.0, ms_sort=0.0)
 
     def reliable_kmers(self, n):
-        return torch.from_numpy(self.rel.view(np.int64).copy())
+        return torch.from_numpy(np.ascontiguousarray(self.rel).reshape(-1).view(np.int64).copy())
 
     def set_global_kmers(self, allk):
+        if self.kw > 1:
+            rows = allk.numpy().view(np.uint64).reshape(-1, self.kw)
+            order = np.lexsort([rows[:, w] for w in range(self.kw - 1, -1, -1)])
+            rank = {tuple(int(x) for x in rows[i]): j for j, i in enumerate(order)}
+            self.gid = np.array([rank[tuple(int(x) for x in r)] for r in self.rel], dtype=np.uint64)
+            return
         s = np.sort(allk.numpy().view(np.uint64))
         self.gid = np.searchsorted(s, self.rel).astype(np.uint64)
 

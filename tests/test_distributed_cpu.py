@@ -148,3 +148,30 @@ def test_two_processes_over_gloo_equal_single_process_oracle(tmp_path):
     _check_alignment_union([dict(rows=p["arows"], cols=p["acols"], vals=p["avals"]) for p in parts])
     _check_string_graphs([(dict(nnz=int(p["snnz"])), dict(rows=p["srows"], cols=p["scols"], vals=p["svals"]),
                            dict(n=len(p["lrows"]), rows=p["lrows"], cols=p["lcols"], vals=p["lvals"])) for p in parts])
+
+
+@pytest.mark.parametrize("k", [33, 65])
+def test_multi_word_kmers_through_the_exchange(k):
+    """k > 31: a record of exchange #1 carries two or three k-mer words + (read, pos); owners hash every word; global ids = rank in the
+    lexicographically sorted union.  Two in-process ranks, driver logic only (NumpyBackend)."""
+    packed, off, lens, _ = elba_amd.synth_reads(91, 6000, 8, 700, 150, error_rate=0.01, min_len=120)
+    o = po.Oracle(k, 2, 10)
+    o.count_and_build(packed, off, lens)
+    o.spgemm(2)
+
+    def body(rank, h):
+        bounds = partition_by_bases(lens, 2)
+        lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+        sp, so, sl = _shard(packed, off, lens, lo, hi)
+        d = DistributedOverlap(k, 2, 10, rank=rank, world=2, dist=h, backend=dist_sim.NumpyBackend(k, 2, 10))
+        d.set_reads(sp, so, sl, lo, bounds)
+        ks, ms = d.build_kmer_matrix()
+        d.create_seed_matrix()
+        return d.export_csr(), ks
+
+    parts = dist_sim.run_ranks(2, body)
+    B = dist_sim.stitch_rows([p[0] for p in parts])
+    oB = o.B()
+    assert o.stat("Y") > 50
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+    assert sum(p[1]["reliable"] for p in parts) == o.stat("N") and sum(p[1]["entries"] for p in parts) == o.stat("Z")

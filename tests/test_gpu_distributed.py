@@ -111,3 +111,20 @@ def test_string_graph_from_gathered_shares_equals_one_rank_oracle():
             if f != "pad":
                 assert (whole["vals"][f] == S["vals"][f]).all(), f
     assert sum(p[6][2]["n"] for p in parts) == S["n"]
+
+
+@pytest.mark.parametrize("k,world", [(33, 2), (63, 3), (65, 2), (95, 3)])
+def test_multi_word_kmers_sharded_overlap_equals_oracle(k, world):
+    """k > 31 across ranks: records of two / three k-mer words + (read, pos), every word in the owner hash, the owner's multi-word sort
+    (index permutation, last word first), global ids by lexicographic rank in the gathered union."""
+    reads = elba_amd.synth_reads(35, 120000, 10, 2500, 600, error_rate=0.02, min_len=200)
+    o = po.Oracle(k, 2, 12)
+    o.count_and_build(*reads[:3])
+    o.spgemm(4)
+    assert o.stat("Y") > 500
+    parts = _run(world, reads, k, 2, 12)
+    B = dist_sim.stitch_rows([p[0] for p in parts])
+    oB = o.B()
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+    assert sum(p[1]["reliable"] for p in parts) == o.stat("N") and sum(p[1]["entries"] for p in parts) == o.stat("Z")
+    assert sum(p[1]["instances"] for p in parts) == o.stat("I")
