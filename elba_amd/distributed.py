@@ -199,7 +199,7 @@ class DistributedOverlap:
         # Batched like the reference's BatchState (include/KmerOps.hpp:33-56, MAX_ALLTOALL_MEM): at most MAX_RECORDS_PER_PEER
         # records per peer and round.  Measured on MI355X / RCCL 2.26.6 (scratch test in profiles/r01_notes.md): a single
         # all_to_all_single message of >= ~2 GiB per peer delivers only its first GiB, silently.
-        CH = self.MAX_RECORDS_PER_PEER
+        CH = max(1, self.MAX_RECORDS_PER_PEER * 2 // width)          # the cap is in bytes per peer: wider records, fewer of them
         rounds = int(max(1, -(-int(max(sc.max(initial=0), rc.max(initial=0))) // CH)))
         if self.world > 1:
             t = torch.tensor([rounds], dtype=torch.int64, device=self.be.dev)
