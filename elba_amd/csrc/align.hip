@@ -12,8 +12,9 @@
 // wave-uniform scalars; the band trimming loops of the reference become two ballots and a count-leading/trailing-zeros each.  The
 // bases of both reads are unpacked from the 2-bit DnaBuffer layout into two 256-entry LDS rings per wavefront, 64 bases per refill, so
 // the recurrence itself touches no global memory.  Lane l holds column cbase + l; when the band reaches lane 63 the window slides to
-// the band's lower edge.  A band wider than 63 columns (large x-drop values) leaves the fast kernel and is redone by a strided kernel
-// that keeps the antidiagonals in HBM — capacity is a performance tier, never a correctness limit.
+// the band's lower edge.  Register tiers hold 1, 2, 4 or 8 columns per lane (bands up to 64 / 128 / 256 / 512 columns): an extension whose
+// band outgrows its tier is redone from the seed on the next one, and beyond 511 columns by a strided kernel that keeps the
+// antidiagonals in HBM — capacity is a performance tier, never a correctness limit.
 //
 // Integer work throughout (scores are int32, like the reference's); no MFMA.
 #include "common.hpp"
@@ -580,14 +581,18 @@ void stage_dist_set_all_reads(Ctx &c, const void *d_packed, int64_t packed_bytes
     ELBA_HIP(hipMemsetAsync(c.aln_all_packed.p, 0, (size_t)packed_bytes + 16, s));
     if (packed_bytes) ELBA_HIP(hipMemcpyAsync(c.aln_all_packed.p, d_packed, (size_t)packed_bytes, hipMemcpyDeviceToDevice, s));
     std::vector<uint32_t> hl((size_t)nreads_total);
+    std::vector<uint64_t> ho((size_t)nreads_total);
     if (nreads_total) {
         ELBA_HIP(hipMemcpyAsync(c.aln_all_off.p, d_byte_off, (size_t)nreads_total * 8, hipMemcpyDeviceToDevice, s));
         ELBA_HIP(hipMemcpyAsync(c.aln_all_len.p, d_len, (size_t)nreads_total * 4, hipMemcpyDeviceToDevice, s));
         ELBA_HIP(hipMemcpyAsync(hl.data(), d_len, (size_t)nreads_total * 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipMemcpyAsync(ho.data(), d_byte_off, (size_t)nreads_total * 8, hipMemcpyDeviceToHost, s));
     }
     ELBA_HIP(hipStreamSynchronize(s));
     uint32_t mx = 0;
     for (uint32_t l : hl) mx = l > mx ? l : mx;
+    for (int64_t r = 0; r < nreads_total; ++r)          // the x-drop kernels trust these offsets (as elba_set_reads_device checks its own)
+        ELBA_REQUIRE((int64_t)ho[(size_t)r] + ((int64_t)hl[(size_t)r] + 3) / 4 <= packed_bytes, ELBA_ERR_INVALID_ARG, "dist_set_all_reads: read exceeds the packed buffer");
     c.aln_all_maxlen = mx; c.aln_all_n = nreads_total;
     c.have_aln = false;
 }

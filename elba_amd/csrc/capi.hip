@@ -137,7 +137,9 @@ int elba_set_reads(elba_ctx *ctx, const uint8_t *packed, const uint64_t *byte_of
         c.h_len.assign(len, len + nreads);
         c.h_byte_off.assign(byte_off, byte_off + nreads);
         c.nreads = nreads; c.first_global_id = first_global_id; c.packed_bytes = pb;
-        c.have_reads = true; c.have_counts = false;
+        // a new read set invalidates everything derived from the old one (as stage_set_reads_fasta does)
+        c.have_reads = true; c.have_counts = false; c.have_aln = false; c.have_edges = false; c.have_S = false;
+        if (c.A_has_kmers) { c.have_A = false; c.have_B = false; }      // (an A handed over as triples / a panel does not come from these reads)
     });
 }
 
@@ -179,7 +181,9 @@ int elba_set_reads_device(elba_ctx *ctx, const void *d_packed, int64_t packed_by
         for (int64_t r = 0; r < nreads; ++r)
             ELBA_REQUIRE((int64_t)c.h_byte_off[r] + ((int64_t)c.h_len[r] + 3) / 4 <= packed_bytes, ELBA_ERR_INVALID_ARG, "set_reads_device: read exceeds the packed buffer");
         c.nreads = nreads; c.first_global_id = first_global_id; c.packed_bytes = packed_bytes;
-        c.have_reads = true; c.have_counts = false;
+        // a new read set invalidates everything derived from the old one (as stage_set_reads_fasta does)
+        c.have_reads = true; c.have_counts = false; c.have_aln = false; c.have_edges = false; c.have_S = false;
+        if (c.A_has_kmers) { c.have_A = false; c.have_B = false; }      // (an A handed over as triples / a panel does not come from these reads)
     });
 }
 

@@ -134,7 +134,8 @@ void stage_set_reads_fasta(Ctx &c, const char *chunk, int64_t chunk_bytes, uint6
     c.d_packed = c.own_packed.as<uint8_t>(); c.d_byte_off = c.own_byte_off.as<uint64_t>(); c.d_len = c.own_len.as<uint32_t>();
     c.h_len = len; off.pop_back(); c.h_byte_off = off;
     c.nreads = nreads; c.first_global_id = first_global_id; c.packed_bytes = (int64_t)pb;
-    c.have_reads = true; c.have_counts = false; c.have_A = false; c.have_B = false; c.have_aln = false;
+    c.have_reads = true; c.have_counts = false; c.have_aln = false; c.have_edges = false; c.have_S = false;
+    if (c.A_has_kmers) { c.have_A = false; c.have_B = false; }
     if (stats) {
         stats->nreads = nreads; stats->bases = (int64_t)totbases; stats->packed_bytes = (int64_t)pb; stats->chunk_bytes = chunk_bytes;
         stats->ms_total = c.t_total.ms(); stats->ms_encode = nreads ? c.t_a.ms() : 0.f;

@@ -288,9 +288,18 @@ class DistributedOverlap:
         rank of row i when i + j is even and by the rank of row j when it is odd (both ranks store the pair; the seeds of the mirrored
         entry are swapped back), always as (query i, target j) — the union over ranks is exactly the one-rank result."""
         packed, off, lens = self._reads
-        nb = int(off[-1]) + (int(lens[-1]) + 3) // 4 if len(lens) else 0
+        # the caller's byte offsets may be padded, aligned or reordered (elba_set_reads accepts any layout): the block that travels is
+        # re-packed densely — read r at the sum of the byte counts before it — which is the layout the receivers rebuild below
+        rb = (lens.astype(np.int64) + 3) // 4
+        dense = np.concatenate([[0], np.cumsum(rb)]).astype(np.int64) if len(lens) else np.zeros(1, np.int64)
+        nb = int(dense[-1])
         nwords = (nb + 7) // 8
-        buf = np.zeros(nwords * 8, dtype=np.uint8); buf[:nb] = packed[:nb]
+        buf = np.zeros(nwords * 8, dtype=np.uint8)
+        if len(lens) and np.array_equal(off.astype(np.int64), dense[:-1]):
+            buf[:nb] = packed[:nb]
+        else:
+            for r in range(len(lens)):
+                buf[int(dense[r]):int(dense[r + 1])] = packed[int(off[r]):int(off[r]) + int(rb[r])]
         torch = self.be.torch
         local = torch.from_numpy(buf.view(np.int64).copy()).to(self.be.dev)
         allw, ns = self._all_gather_words(local, nwords)                          # packed bytes of every rank, 8-byte aligned blocks
