@@ -104,7 +104,7 @@ class SynthReads(C.Structure):
 EXPORTED_SYMBOLS = [
     "elba_abi_version", "elba_strerror", "elba_last_error", "elba_ctx_create", "elba_ctx_destroy", "elba_set_reads", "elba_set_reads_device",
     "elba_count_kmers", "elba_create_kmer_matrix", "elba_set_kmer_matrix", "elba_create_seed_matrix", "elba_export_dcsc", "elba_free_dcsc",
-    "elba_export_csr", "elba_free_csr", "elba_export_kmer_matrix", "elba_free_kmer_matrix", "elba_kmer_histogram", "elba_get_device_view",
+    "elba_export_csr", "elba_free_csr", "elba_export_kmer_matrix", "elba_free_kmer_matrix", "elba_kmer_histogram", "elba_get_device_view", "elba_set_option",
     "elba_align_seeds", "elba_export_overlaps", "elba_free_overlaps", "elba_set_overlaps", "elba_transitive_reduction", "elba_export_string_graph", "elba_export_read_flags", "elba_set_reads_fasta", "elba_export_reads", "elba_dist_set_all_reads",
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
     "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
@@ -152,6 +152,7 @@ def load_library():
     L.elba_free_kmer_matrix.restype = None; L.elba_free_kmer_matrix.argtypes = [C.POINTER(KmerMatrix)]
     L.elba_kmer_histogram.restype = i32; L.elba_kmer_histogram.argtypes = [vp, vp, i64]
     L.elba_get_device_view.restype = i32; L.elba_get_device_view.argtypes = [vp, C.POINTER(DeviceView)]
+    L.elba_set_option.restype = i32; L.elba_set_option.argtypes = [vp, C.c_char_p, i64]
     L.elba_synth_num_reads.restype = i64; L.elba_synth_num_reads.argtypes = [C.POINTER(SynthCfg)]
     L.elba_synth_generate.restype = i32; L.elba_synth_generate.argtypes = [C.POINTER(SynthCfg), C.POINTER(SynthReads)]
     L.elba_synth_free.restype = None; L.elba_synth_free.argtypes = [C.POINTER(SynthReads)]
@@ -253,6 +254,9 @@ class Engine:
         st = MatrixStats()
         self._check(self.L.elba_set_kmer_matrix(self.h, nrows, ncols, len(rows), rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, C.byref(st)))
         return _stats(st)
+
+    def set_option(self, name, value):
+        self._check(self.L.elba_set_option(self.h, name.encode(), int(value)))
 
     # --- stages ---
     def count_kmers(self):

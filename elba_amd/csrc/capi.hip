@@ -446,6 +446,15 @@ int elba_get_device_view(elba_ctx *ctx, elba_device_view *v)
     });
 }
 
+int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(name, ELBA_ERR_INVALID_ARG, "set_option: null name");
+        if (!strcmp(name, "overlap_cold_calls")) c.cold_calls = value != 0;
+        else throw Error{ELBA_ERR_INVALID_ARG, std::string("set_option: unknown option ") + name};
+    });
+}
+
 int elba_dist_count_owners(elba_ctx *ctx, int nranks, uint64_t *counts)
 {
     return guarded(ctx, [&](Ctx &c) {

@@ -143,6 +143,12 @@ struct Ctx {
     bool A_has_kmers = false;
     int64_t M = 0, N = 0, Z = 0, max_row_nnz = 0, max_col_nnz = 0;
     DevBuf a_rowptr, a_csr, a_colptr, a_csc;   // u32[M+1], u64[Z], u32[N+1], u64[Z]
+    DevBuf a_ell;                              // u64[N << s_log2]: the columns padded to a power-of-two stride (entries, then all ones) — the column store the
+                                               // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid << s_log2, no pointer
+    bool use_ell = false;
+    uint32_t s_log2 = 2, lpc_log2 = 1;         // padded column stride 2^s_log2 entries; lanes of the SpGEMM per row entry 2^lpc_log2
+    bool plan = false;                         // ELBA_PLAN=1 (A/B runs): the round-1 per-entry descriptor format is built with A and the descriptor kernel runs
+    bool cold_calls = false;                   // every elba_create_seed_matrix call forgets what earlier calls learned (prior, tier usage): elba_set_option
     DevBuf a_rowprod;                          // u32[M] products per row: sum of the column lengths of the row's k-mers
     DevBuf a_dec;                              // u64[Z] by canonical rank: address of the entry's column in a_cscp << 32 | position in the read (seed decoding)
     DevBuf a_hdr, a_hot;                       // RowHot[M], HotDesc[H]: per-row header + the row's hot descriptors (one per row entry and partner range); matrix.hip

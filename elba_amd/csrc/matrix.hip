@@ -58,6 +58,15 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
+// padded column store: entry z of column kid goes to slot (kid << sb) + (z - colptr[kid]); the buffer was filled with all ones before
+__global__ void k_fill_ell(const uint64_t *kid_keys, int kid_shift, const uint32_t *colptr, const uint64_t *csc, int64_t Z, uint32_t sb, uint64_t *ell)
+{
+    const int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    const uint64_t kid = kid_keys[z] >> kid_shift;
+    ell[(kid << sb) + ((uint32_t)z - colptr[kid])] = csc[z];
+}
+
 // 16-byte descriptors that carry the position of their row entry in the upper half of w (the packed form has no room for it)
 __global__ __launch_bounds__(256) void k_fold_desc_pos(const RowHot *hdr, uint32_t M, HotDesc *hot, const uint64_t *dec, uint32_t fbits)
 {
@@ -488,15 +497,18 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;
     group_offsets_u32(s, rk, 0, Z, c.a_rowptr.as<uint32_t>(), M);
     if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
-    c.a_rowprod.reserve((size_t)(M + 1) * 4);
-    c.a_dec.reserve((size_t)(Z + 1) * 8);
-    if (M > 0) {
-        int nb = (int)((M + 3) / 4);
-        if (nb > c.num_cus * 8) nb = c.num_cus * 8;
-        hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_dec.as<uint64_t>());
-    }
     ELBA_REQUIRE(win_lo >= 0 && (win_hi < 0 || (win_lo <= win_hi && win_hi <= M)), ELBA_ERR_INVALID_ARG, "bad row window");
     c.row_lo = win_lo; c.row_hi = win_hi;
+    c.plan = getenv("ELBA_PLAN") != nullptr;
+    if (c.plan) {
+        c.a_rowprod.reserve((size_t)(M + 1) * 4);
+        c.a_dec.reserve((size_t)(Z + 1) * 8);
+        if (M > 0) {
+            int nb = (int)((M + 3) / 4);
+            if (nb > c.num_cus * 8) nb = c.num_cus * 8;
+            hipLaunchKernelGGL(k_row_products, dim3(nb), dim3(256), 0, s, c.a_rowptr.as<uint32_t>(), c.a_csr.as<uint64_t>(), c.a_colptr.as<uint32_t>(), (uint32_t)M, c.a_rowprod.as<uint32_t>(), c.a_dec.as<uint64_t>());
+        }
+    }
     // a new matrix: the tier queues and the tier / sort usage of the previous one are forgotten.  The OUTPUT capacity is kept as a guess (the
     // buffers exist): the first SpGEMM call on this matrix then runs without a host round trip in its middle and checks afterwards that
     // everything fitted (spgemm.hip repeats the call on the synchronising path otherwise)
@@ -504,8 +516,52 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.ov_prior_q16 = 0;            // a new matrix: forget the partner/product ratio measured on the previous one
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
-    build_hot_format(c);
-    build_row_descriptors(c);
+    // largest position among the entries: below 2^16 the SpGEMM's 64-bit accumulators carry both positions of a seed (spgemm_direct.hpp)
+    {
+        uint64_t maxpos = 0;
+        if (Z > 0) {
+            int64_t nbz = (Z + 255) / 256;
+            if (nbz > 2048) nbz = 2048;
+            c.ws_scan.reserve(64);
+            ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
+            hipLaunchKernelGGL(k_max_low32, dim3((unsigned)nbz), dim3(256), 0, s, c.a_csc.as<uint64_t>(), Z, c.ws_scan.as<unsigned long long>());
+            ELBA_HIP(hipMemcpyAsync(&maxpos, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
+            ELBA_HIP(hipStreamSynchronize(s));
+        }
+        c.pos16 = maxpos < 65536;
+    }
+    // The column store the SpGEMM gathers from.  No column longer than 64 entries (UPPER <= 64: every configuration the reference
+    // documents): columns padded to S = 2^s_log2 >= 4 entries, column kid at kid * S — its address is arithmetic, and a group of S/2
+    // lanes reads it as one aligned segment.  Longer columns (or no room for the padding): the plain CSC, reached through a_colptr.
+    {
+        const uint32_t mc = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
+        uint32_t sb = 2;
+        while ((1u << sb) < mc) ++sb;
+        size_t free_b = 0, total_b = 0;
+        ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
+        const size_t ell_bytes = ((size_t)N << sb) * 8;
+        c.use_ell = mc <= 64 && N > 0 && !getenv("ELBA_NO_ELL") && ell_bytes <= (free_b + c.a_ell.cap) / 3 && ((uint64_t)N << sb) < (1ull << 40);
+        if (c.use_ell) {
+            c.s_log2 = sb; c.lpc_log2 = sb - 1; c.fbits = sb;
+            c.a_ell.reserve(ell_bytes + 64);
+            ELBA_HIP(hipMemsetAsync(c.a_ell.p, 0xFF, ell_bytes + 64, s));
+            if (Z > 0) hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), Z, sb, c.a_ell.as<uint64_t>());
+        } else {
+            // lanes per row entry: half the longest column, between 2 and 64 (a column is walked in chunks of 2 * lanes entries)
+            uint32_t lb = 1;
+            while (lb < 6 && (2u << lb) < mc) ++lb;
+            c.lpc_log2 = lb; c.s_log2 = 0;
+            int fb = 1;
+            while (fb < 31 && ((uint64_t)(mc > 1 ? mc - 1 : 1) >> fb)) ++fb;
+            c.fbits = (uint32_t)fb;
+        }
+        ELBA_REQUIRE(c.fbits < 31 && (uint64_t)c.max_row_nnz < (1ull << (32 - c.fbits)), ELBA_ERR_UNSUPPORTED,
+                     "row nnz x column nnz exceeds the 32-bit product sequence number");
+    }
+    if (c.plan) {
+        build_hot_format(c);
+        build_row_descriptors(c);
+    }
     c.have_A = true;
     c.have_B = false;
 }

@@ -39,7 +39,7 @@ constexpr uint32_t FIN_LDS_MAX = 4096;          // widest row the LDS bitonic so
 // End-of-kernel statistics are flushed into one of 64 shards (each on its own 128-B line): thousands of workgroups adding to a
 // single line serialise at ~15 ns per atomic, which showed up as 0.1-0.2 ms on a 0.6 ms kernel.
 struct alignas(128) OvShard {
-    unsigned long long yraw, nnz, ndiag, nupper, fb_claims, fb_ub;
+    unsigned long long yraw, nnz, ndiag, nupper, fb_claims, fb_ub, products;
     unsigned int maxshared;
     unsigned int tier_done[NUM_TIERS];
 };
@@ -59,6 +59,8 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned int fin_count[2];            // rows needing the LDS-bitonic / HBM-bitonic column sort
     unsigned int pad[2];
     unsigned long long pad2[14];          // keep the feedback sums on a cache line of their own
+    alignas(128) unsigned int tier_next[NUM_TIERS];    // plan-free kernel: next unclaimed position of every tier's queue (one atomic per row)
+    alignas(128)
     unsigned long long fb_claims, fb_ub;  // feedback: distinct partners found / products, summed over rows done so far in this call
     OvShard shard[NUM_SHARDS];
     unsigned long long phase[12];          // diagnostic (cfg.flags & 16): shader-clock cycles per kernel phase, summed over workgroups
@@ -70,6 +72,9 @@ struct OvCounters {              // device-side counters, zeroed per call
 struct alignas(32) StageRec { uint4 a, b; };
 
 struct OvParams {
+    // plan-free path (spgemm_direct.hpp): the two orientations of A and nothing else
+    const uint32_t *a_rowptr; const uint64_t *a_csr; const uint64_t *a_ell; const uint32_t *a_colptr; const uint64_t *a_csc;
+    uint32_t s_log2, lpc_log2, max_col;      // padded column stride 2^s_log2 (a_ell); lanes per row entry 2^lpc_log2; longest column
     const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_cscj; const uint32_t *a_roworder;
     const RowHot *a_hdr; const HotDesc *a_hot; const uint64_t *a_dec;   // per-row bounds, per-entry partner ranges, seed decoding by canonical rank (matrix.hip)
     uint32_t M;              // number of rows of A held here
@@ -156,6 +161,7 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
 
 // ---- numeric -----------------------------------------------------------------------------------------------------
 #include "spgemm_rows.hpp"
+#include "spgemm_direct.hpp"
 
 // ---- finalize: row pointers, mirror, per-row column sort + move to final CSR --------------------------------------------
 // A row's entries come from two places: mirrored ones scattered by k_mirror (mir, laid out like B: the first low_cnt
@@ -448,9 +454,232 @@ int bits_for_u(uint64_t v)
 
 }  // namespace
 
+// ---- the plan-free call: CSR + columns of A -> pruned CSR B, everything in between computed here ---------------------------------
+// Launch sequence (one stream, ONE host synchronisation at the end when nothing overflows):
+//   counters = 0, row_cnt = 0 | k_classify_direct | k_spgemm_direct on every table tier, ascending (+ the HBM-table tier) |
+//   k_row_pointers (scan of the rows' counts) | k_mirror (only queues the wide rows: nothing is mirrored, both triangles were computed) |
+//   k_finalize_wave / _bucket / _huge (per-row column sort + move to b_col / b_val) | counter read-back.
+// What a call may remember from earlier calls on the same matrix is a HINT only — the distinct-partner / row-entry ratio that picks the
+// starting tiers, which tiers and sorts got rows — and `cold_calls` (elba_set_option) or a new matrix forgets it: then the ratio starts at
+// 1/4 and the kernel corrects itself from the rows already done, every tier is launched.  Capacities (staging, output) start from nnz(A)
+// and only ever grow; a call that overflows them is repeated with what it measured.
+static void create_seed_matrix_direct(Ctx &c)
+{
+    hipStream_t s = c.stream;
+    const int64_t M = c.M, N = c.N, Z = c.Z;
+    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? M : c.row_hi;
+    elba_overlap_stats st{};
+    st.nrows = row_hi - row_lo;
+    c.have_B = false;
+    ELBA_REQUIRE(M < 0xFFFFFF00ll, ELBA_ERR_UNSUPPORTED, "read ids beyond 2^32 - 256 (the top of the id range marks empty slots and idle lanes)");
+    if (c.cold_calls) { c.ov_prior_q16 = 0; c.ov_tiers_known = false; c.ov_sort_used[0] = c.ov_sort_used[1] = true; }
+
+    c.ov_rowcnt.reserve((size_t)(M + 2) * 4);
+    c.ov_rowoff.reserve((size_t)(M + 1) * 8);
+    c.ov_lists.reserve((size_t)(NUM_TIERS + 2) * (size_t)(M + 1) * 4);
+    c.ov_counters.reserve(sizeof(OvCounters));
+    c.b_rowptr.reserve((size_t)(M + 2) * 8);
+    if (c.ov_totcnt.cap < (size_t)(M + 2) * 4) c.ov_low_clean = false;
+    c.ov_totcnt.reserve((size_t)(M + 2) * 4);
+
+    uint64_t gstride = 2;
+    while (gstride < 2ull * (uint64_t)(M > 1 ? M : 1)) gstride <<= 1;
+    int spill_blocks = (int)((4ull << 30) / (20ull * gstride));
+    spill_blocks = spill_blocks < 64 ? 64 : (spill_blocks > c.num_cus * 2 ? c.num_cus * 2 : spill_blocks);
+    c.ov_gtable.reserve((size_t)spill_blocks * 5 * gstride * 4);
+
+    const int cus = c.num_cus;
+    const int64_t nrows = row_hi - row_lo;
+    const int64_t slack = (int64_t)cus * 32 * STAGE_CHUNK + 64;      // one open chunk per resident workgroup
+    if (c.ov_tmp_cap == 0) {
+        if (c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
+        else {
+            // nnz(B) <= products / 2 and, on every read set seen so far, < nnz(A) / 4: start from nnz(A) (bounded by half the free memory)
+            size_t free_b = 0, total_b = 0;
+            ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
+            const int64_t budget = (int64_t)(free_b / 2 / (sizeof(StageRec) + 24));
+            c.ov_tmp_cap = std::min<int64_t>(std::max<int64_t>(Z, 1 << 16) + slack, std::max<int64_t>(budget, 1024));
+        }
+        if (c.ov_tmp_cap < 1024) c.ov_tmp_cap = 1024;
+    }
+
+    OvParams p{};
+    p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
+    p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
+    p.s_log2 = c.s_log2; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
+    p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
+    p.half = 0;
+    p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
+    p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
+    const bool pay = c.pos16 && !getenv("ELBA_NO_PAY");
+    // workgroup sizes grow with the table so that the largest tiers still bring enough waves to a CU (one or two workgroups fit its LDS)
+    const uint32_t blk[NUM_LDS_TIERS] = {128u, 256u, 512u, 1024u, 1024u};
+    for (int t = 0; t < NUM_LDS_TIERS; ++t) {
+        const uint32_t T = 1u << (LDS_TBITS0 + t);
+        p.tier_limit[t] = std::min((T >> 2) * 3, T - blk[t]) - 1;      // a lane overshoots by at most one claim (Table::insert_lds)
+    }
+    p.row_cnt = c.ov_rowcnt.as<uint32_t>(); p.low_cnt = c.ov_totcnt.as<uint32_t>();
+    p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
+    p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
+    p.ctr = c.ov_counters.as<OvCounters>();
+    p.gtable = c.ov_gtable.as<uint32_t>(); p.gstride = gstride;
+
+    static bool attr_done = false;
+    if (!attr_done) {
+        const int lds = 160 * 1024;
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_done = true;
+    }
+
+    c.ov_host.reserve(sizeof(OvCounters));
+    OvCounters &hc = *static_cast<OvCounters *>(c.ov_host.p);
+    hc = OvCounters{};
+    uint32_t skipped_tiers = 0, skipped_sorts = 0;
+    int passes = 0;
+    float ms_sym = 0, ms_num = 0, ms_fin = 0, ms_tot = 0;
+    bool was_timed = true;
+    for (;;) {
+        ++passes;
+        const int stride = c.cfg.timing_stride > 1 ? c.cfg.timing_stride : 1;
+        const bool timed = passes > 1 || (c.ov_calls++ % (uint64_t)stride) == 0;
+        c.ov_tmp.reserve((size_t)c.ov_tmp_cap * sizeof(StageRec));
+        p.tmp = c.ov_tmp.as<StageRec>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
+        c.b_cap_entries = c.ov_tmp_cap;                      // the output cannot be larger than what was staged
+        c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
+        c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
+
+        if (timed) c.ov_marks.mark(0, s);
+        if (!c.ov_low_clean) ELBA_HIP(hipMemsetAsync(c.ov_totcnt.p, 0, (size_t)(M + 2) * 4, s));      // (nothing is mirrored: stays zero)
+        c.ov_low_clean = true;
+        ELBA_HIP(hipMemsetAsync(c.ov_counters.p, 0, sizeof(OvCounters), s));
+        ELBA_HIP(hipMemsetAsync(c.ov_rowcnt.p, 0, (size_t)(M + 2) * 4, s));
+        if (nrows > 0) {
+            int nb = (int)((nrows + 255) / 256);
+            if (nb > cus * 4) nb = cus * 4;
+            hipLaunchKernelGGL(k_classify_direct, dim3(nb), dim3(256), 0, s, p);
+        }
+        if (timed) c.ov_marks.mark(1, s);
+        if (nrows > 0) {
+            const size_t X = 256;      // bytes of misc words behind the table
+            const bool all_tiers = !c.ov_tiers_known;
+            skipped_tiers = 0;
+#define ELBA_DTIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
+#define ELBA_LAUNCH_D(B, G, P, grid, lds, tier, tb) hipLaunchKernelGGL((k_spgemm_direct<B, G, P>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb))
+            if (pay) {
+                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, true, cus * 11, (size_t)26 * 512 + X, 0, 9u));
+                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, true, cus * 5, (size_t)26 * 1024 + X, 1, 10u));
+                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, true, cus * 3, (size_t)26 * 2048 + X, 2, 11u));
+                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X, 3, 12u));
+            } else {
+                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, false, cus * 12, (size_t)18 * 512 + X, 0, 9u));
+                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, false, cus * 8, (size_t)18 * 1024 + X, 1, 10u));
+                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, false, cus * 4, (size_t)18 * 2048 + X, 2, 11u));
+                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, false, cus * 2, (size_t)18 * 4096 + X, 3, 12u));
+            }
+            ELBA_DTIER(4, ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 8192 + X, 4, 13u));
+            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, X, NUM_LDS_TIERS, 0u));
+#undef ELBA_LAUNCH_D
+#undef ELBA_DTIER
+            ELBA_HIP(hipGetLastError());
+        }
+        if (timed) c.ov_marks.mark(2, s);
+        {
+            FinParams f{};
+            f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = p.tmp; f.mir = nullptr; f.half = 0; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
+            f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
+            f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
+            f.b_cap = c.b_cap_entries;
+            f.mir16 = 0;
+            const int gblocks = 32;
+            uint64_t sstride = 2;
+            while (sstride < (uint64_t)M) sstride <<= 1;
+            c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
+            f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
+            if (M + 1 <= (1 << 17)) {
+                hipLaunchKernelGGL(k_row_pointers, dim3((unsigned)((M + 1 + RP_TILE - 1) / RP_TILE)), dim3(256), 0, s, f);
+            } else {
+                c.ov_sum_tmp.reserve((size_t)(M + 2) * 4);
+                f.sum_tmp = c.ov_sum_tmp.as<uint32_t>();
+                hipLaunchKernelGGL(k_sum_counts, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, s, f);
+                exclusive_scan_u32_to_i64(s, f.sum_tmp, c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
+            }
+            if (nrows > 0) {
+                int nb = (int)((nrows + 3) / 4);
+                if (nb > cus * 32) nb = cus * 32;
+                hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
+                hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
+                skipped_sorts = 0;
+                const bool all_sorts = !c.ov_tiers_known;
+                if (all_sorts || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
+                else skipped_sorts |= 1u;
+                if (all_sorts || c.ov_sort_used[1]) hipLaunchKernelGGL(k_finalize_huge, dim3(gblocks), dim3(256), 0, s, f);
+                else skipped_sorts |= 2u;
+            }
+        }
+        if (timed) c.ov_marks.mark(3, s);
+        ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        if (timed) { ms_sym += c.ov_marks.ms(0, 1); ms_num += c.ov_marks.ms(1, 2); ms_fin = c.ov_marks.ms(2, 3); ms_tot += c.ov_marks.ms(0, 3); }
+        was_timed = timed;
+        bool missed = false;
+        for (int t = 0; t < NUM_TIERS; ++t) missed |= ((skipped_tiers >> t) & 1u) && hc.tier_count[t] > 0;
+        missed |= ((skipped_sorts & 1u) && hc.fin_count[0] > 0) || ((skipped_sorts & 2u) && hc.fin_count[1] > 0);
+        if (hc.overflow || missed) {      // staging too small, or a row reached a tier / sort that was not launched: repeat with what is known now
+            if (getenv("ELBA_TRACE")) fprintf(stderr, "[elba] overlap call repeated: overflow=%u missed=%d cursor=%llu tmp_cap=%lld\n", hc.overflow, (int)missed, hc.cursor, (long long)c.ov_tmp_cap);
+            ELBA_REQUIRE(passes < 4, ELBA_ERR_INTERNAL, "overlap output did not settle");
+            if (hc.overflow) c.ov_tmp_cap = (int64_t)hc.cursor + slack;      // every row drew its space even when it did not fit: the cursor is the need
+            c.ov_tiers_known = false;
+            continue;
+        }
+        break;
+    }
+
+    for (int sh = 0; sh < NUM_SHARDS; ++sh) {       // fold the statistics shards
+        const OvShard &x = hc.shard[sh];
+        hc.yraw += x.yraw; hc.nnz += x.nnz; hc.ndiag += x.ndiag; hc.nupper += x.nupper; hc.products += x.products;
+        if (x.maxshared > hc.maxshared) hc.maxshared = x.maxshared;
+        for (int t = 0; t < NUM_TIERS; ++t) hc.tier_done[t] += x.tier_done[t];
+    }
+    unsigned long long fbc = 0, fbu = 0;
+    for (int sh = 0; sh < NUM_SHARDS; ++sh) { fbc += hc.shard[sh].fb_claims; fbu += hc.shard[sh].fb_ub; }
+    const int64_t Y = (int64_t)hc.nnz;
+    for (int t = 0; t < NUM_TIERS; ++t) c.ov_tier_used[t] = hc.tier_count[t] > 0;
+    c.ov_tiers_known = true;
+    c.ov_sort_used[0] = hc.fin_count[0] > 0; c.ov_sort_used[1] = hc.fin_count[1] > 0;
+    if (fbu > 0) {   // the measured distinct-partner / row-entry ratio (+25 %) picks the next call's starting tiers
+        double r = 1.25 * (double)fbc / (double)fbu * 65536.0;
+        const uint32_t q = r < 64.0 ? 64u : (r > 4.0e9 ? 4000000000u : (uint32_t)r);
+        const uint32_t old = c.ov_prior_q16;
+        if (old == 0 || q > old + old / 10 || q + old / 10 < old) c.ov_prior_q16 = q;
+    }
+    st.products = (int64_t)hc.products;
+    st.nnz_before_prune = (int64_t)hc.yraw;
+    st.nnz = Y;
+    st.nnz_diag = (int64_t)hc.ndiag;
+    st.nnz_upper = (int64_t)hc.nupper;
+    st.max_numshared = (int64_t)hc.maxshared;
+    st.rows_lds = 0;
+    for (int t = 0; t < NUM_LDS_TIERS; ++t) st.rows_lds += hc.tier_done[t];
+    st.rows_global = (int64_t)hc.tier_done[NUM_LDS_TIERS];
+    int64_t queued = 0;
+    for (int t = 0; t < NUM_TIERS; ++t) queued += hc.tier_count[t];
+    st.rows_escalated = queued - st.rows_lds - st.rows_global;
+    st.algorithmic_bytes = 16 * Z + 8 * (2 * M + N + 3) + 24 * Y;
+    st.passes = passes;
+    st.timed = was_timed ? 1 : 0;
+    st.ms_total = ms_tot; st.ms_symbolic = ms_sym; st.ms_numeric = ms_num; st.ms_finalize = ms_fin;
+    c.Y = Y;
+    c.ostats = st;
+    c.have_B = true;
+}
+
 void stage_create_seed_matrix(Ctx &c)
 {
     ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "create_seed_matrix: no k-mer matrix (call elba_create_kmer_matrix or elba_set_kmer_matrix)");
+    if (!c.plan) { create_seed_matrix_direct(c); return; }
     hipStream_t s = c.stream;
     const int64_t M = c.M, N = c.N, Z = c.Z;
     const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? M : c.row_hi;

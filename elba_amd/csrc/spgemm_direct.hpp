@@ -1,0 +1,336 @@
+// spgemm_direct.hpp — the numeric kernel of the overlap SpGEMM, PLAN-FREE (included by spgemm.hip inside its anonymous namespace).
+//
+// Input is A as the k-mer stage leaves it and nothing else: CSR (a_rowptr, a_csr: kid << 32 | pos, rows in (kid, pos) order) and the
+// k-mer columns — padded to a power-of-two stride (a_ell: column kid occupies the S = 2^s_log2 consecutive 8-byte words from kid * S,
+// entries (read << 32 | pos) in (read, pos) order, the rest all ones) when no column is longer than 64 entries, else plain CSC
+// (a_colptr, a_csc).  No per-row schedule, no descriptors, no row order, no product counts: whatever the product needs beyond the two
+// orientations of A is computed inside the call (reference region: src/SharedSeeds.cpp:4-10 under the timer of src/main.cpp:280-282).
+//
+// One workgroup per row of B, rows claimed from the tier's queue with one atomic per row (claimed one row ahead).
+//   * a group of LPC = S/2 lanes takes one row entry (i, kid, posQ): the entry is ONE 8-byte load (the lanes of a group share it), the
+//     column ONE aligned 16-byte load per lane — the group reads the whole padded column as a single contiguous S*8-byte segment, so a
+//     column costs the L1 one request per 64 bytes and the address needs no column pointer: kid * S.  (CSC matrices pay the dependent
+//     colptr load and walk long columns in chunks of 2 * LPC entries.)
+//   * every lane then holds two candidate partners (read j, posT): all ones = padding, j == i = the diagonal (counted, never inserted),
+//     anything else is a product and updates the LDS accumulator of partner j: count, and first / last product of the ascending-k left
+//     fold through ds_min / ds_max of the sequence number (rank of the row entry << fbits | index in the column), which is monotone in
+//     (kid, posQ, posT).  With PAY the 64-bit extremes carry posQ and posT themselves: no seed look-ups afterwards.
+//   * both triangles are computed (row i meets every partner j, smaller or larger): no mirror pass, a row's output is complete when its
+//     workgroup is done with it.
+//   * table tiers, optimistic sizing, escalation, HBM spill tier, ballot compaction of the survivors, staging: as before (spgemm.hip).
+
+enum : uint32_t { D_NEXT = 20, D_FB0 = 16, W_ACC_P = 54 /*u64*/, W_END2 = 56 };
+constexpr uint32_t NOROW = 0xFFFFFFFFu;
+
+template <int BLOCK, bool GLOBAL, bool PAY>
+__global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits)
+{
+    static_assert(!PAY || !GLOBAL, "payload accumulators: LDS tiers only");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *misc = GLOBAL ? smem : smem + (size_t)(PAY ? 6 : 4) * (1u << lds_tbits) + ((size_t)1 << lds_tbits) / 2;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    const uint64_t lt = (1ull << lane) - 1;
+    const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
+    const uint32_t lb = p.lpc_log2, sub = tid & ((1u << lb) - 1u), grp = tid >> lb, EPT = (uint32_t)BLOCK >> lb;
+    const uint32_t fbits = p.fbits, fmask = (1u << fbits) - 1u, sb = p.s_log2;
+    const bool ell = p.a_ell != nullptr;
+    const uint2 *csr2 = reinterpret_cast<const uint2 *>(p.a_csr);      // .x = position in the read, .y = k-mer id
+    unsigned long long chunk_off = 0;
+    uint32_t chunk_left = 0;
+    auto w64 = [&](uint32_t k) { return reinterpret_cast<unsigned long long *>(&misc[k]); };
+    if (tid >= 32 && tid < W_END2) misc[tid] = 0;
+    const uint32_t *queue = p.lists + (size_t)tier * p.M;
+    if (tid == 0) {
+        const uint32_t idx = atomicAdd(&p.ctr->tier_next[tier], 1u);
+        misc[D_NEXT] = idx < nrows ? queue[idx] : NOROW;
+    }
+    __syncthreads();
+    uint32_t fb_seen = 0;
+
+    for (;;) {
+        const uint32_t i = sfirst(misc[D_NEXT]);
+        if (i == NOROW) break;
+        uint32_t nidx = 0;
+        if (tid == 0) nidx = atomicAdd(&p.ctr->tier_next[tier], 1u);      // the row after this one: the round trip hides behind this row
+        const uint32_t rs = sfirst(p.a_rowptr[i]), nnz = sfirst(p.a_rowptr[i + 1]) - rs;
+        // distinct partners of the row <= min(products, reads); products <= nnz * longest column
+        const unsigned long long prod_ub = (unsigned long long)nnz * p.max_col;
+        const uint32_t ub_i = prod_ub < (unsigned long long)p.Mcols ? (uint32_t)prod_ub : p.Mcols;
+        auto publish_next = [&]() { if (tid == 0) misc[D_NEXT] = nidx < nrows ? queue[nidx] : NOROW; };
+
+        if (!GLOBAL && p.use_feedback) {
+            // Self-correction inside a call (no prior for this matrix): rows already done tell how many distinct partners a row entry
+            // brings on THIS data; a row predicted not to fit is forwarded without an attempt.  (lane 0 reads the hot sums once per 8 rows
+            // and broadcasts through LDS: the decision must be workgroup-uniform)
+            if ((fb_seen++ & 7u) == 0) {
+                if (tid == 0) {
+                    const unsigned long long u = __hip_atomic_load(&p.ctr->fb_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const unsigned long long c = __hip_atomic_load(&p.ctr->fb_claims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    misc[D_FB0] = (uint32_t)u; misc[D_FB0 + 1] = (uint32_t)(u >> 32); misc[D_FB0 + 2] = (uint32_t)c; misc[D_FB0 + 3] = (uint32_t)(c >> 32);
+                }
+                __syncthreads();
+            }
+            const unsigned long long gu = ((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0], gc = ((unsigned long long)misc[D_FB0 + 3] << 32) | misc[D_FB0 + 2];
+            if (gu >= (1ull << 18)) {
+                const double pred = 1.25 * (double)nnz * (double)gc / (double)gu;
+                if (pred > 1.2 * (double)p.tier_limit[tier] && guaranteed_tbits(ub_i, p.Mcols) > lds_tbits) {
+                    int t2 = tier + 1;
+                    while (t2 < NUM_LDS_TIERS && pred > (double)p.tier_limit[t2]) ++t2;
+                    if (tid == 0) {
+                        const uint32_t at = atomicAdd(&p.ctr->tier_count[t2], 1u);
+                        p.lists[(size_t)t2 * p.M + at] = i;
+                    }
+                    __syncthreads();          // every wave has read this row's id before the next one is published
+                    publish_next();
+                    __syncthreads();
+                    continue;
+                }
+            }
+        }
+
+        Table<GLOBAL> tab;
+        tab.misc = misc;
+        uint32_t *list = nullptr;
+        uint16_t *list16 = nullptr;
+        if (GLOBAL) {
+            tab.tbits = guaranteed_tbits(ub_i, p.Mcols);
+            tab.limit = 0xFFFFFFFFu;
+            uint32_t *base = p.gtable + (size_t)blockIdx.x * 5 * p.gstride;
+            tab.keys = base; tab.cnt = base + p.gstride; tab.smin = base + 2 * p.gstride; tab.smax = base + 3 * p.gstride;
+            list = base + 4 * p.gstride;
+        } else {
+            tab.tbits = lds_tbits;
+            const uint32_t T = 1u << lds_tbits;
+            tab.limit = p.tier_limit[tier];
+            tab.keys = smem; tab.cnt = smem + T; tab.smin = smem + 2 * T; tab.smax = smem + 3 * T;
+            tab.vmin = reinterpret_cast<unsigned long long *>(smem + 2 * T); tab.vmax = tab.vmin + T;
+            list16 = reinterpret_cast<uint16_t *>(smem + (PAY ? 6 : 4) * T);
+        }
+        const uint32_t T = tab.size();
+        for (uint32_t s = tid; s < T; s += BLOCK) {
+            tab.keys[s] = EMPTY; tab.cnt[s] = 0;
+            if (PAY) { tab.vmin[s] = ~0ull; tab.vmax[s] = 0ull; } else { tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
+        }
+        if (tid < 16) misc[tid] = 0;
+        if (GLOBAL) __syncthreads(); else lds_barrier();
+
+        // ---- accumulate -----------------------------------------------------------------------------------------------------
+        bool full = false;
+        uint32_t dg = 0, pr = 0;                 // this lane's diagonal products / all products (valid column entries) of the row
+        auto update = [&](uint32_t j, uint32_t posT, uint32_t seq, uint32_t posQ, bool valid) {
+            const bool isd = valid && j == i;
+            dg += isd ? 1u : 0u; pr += valid ? 1u : 0u;
+            const bool ins = valid && !isd;
+            if (PAY) {
+                const unsigned long long v = ((unsigned long long)seq << 32) | (posQ << 16) | posT;
+                tab.insert_lds64(j, v, v, 1u, ins, full);
+            } else if (GLOBAL) {
+                if (ins) tab.insert(j, seq, full);
+            } else tab.insert_lds(j, seq, seq, 1u, ins, full);
+        };
+        if (ell) {
+            // Two trips in flight.  Each trip (1) consumes what the previous one requested — this trip's column words and the next trip's
+            // row entries: one wait — (2) requests the next trip's column words and the row entries after next, (3) updates the
+            // accumulator (LDS only), during which the requests land.
+            const uint4 ones = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+            auto load_ce = [&](uint32_t t0) { const uint32_t r = t0 + grp; return r < nnz ? csr2[rs + r] : make_uint2(0u, 0u); };
+            auto gather = [&](const uint2 &c, uint32_t t0) {
+                return t0 + grp < nnz ? *reinterpret_cast<const uint4 *>(p.a_ell + (((unsigned long long)c.y << sb) + 2u * sub)) : ones;
+            };
+            uint2 c_cur = load_ce(0u);
+            uint4 x_cur = gather(c_cur, 0u);
+            uint2 c_nxt = load_ce(EPT);
+#pragma unroll 1
+            for (uint32_t t0 = 0; t0 < nnz; t0 += EPT) {
+                asm volatile("" : "+v"(x_cur.x), "+v"(x_cur.y), "+v"(x_cur.z), "+v"(x_cur.w), "+v"(c_nxt.x), "+v"(c_nxt.y) : : "memory");      // (1)
+                const uint4 x_nxt = gather(c_nxt, t0 + EPT);                                                                                     // (2)
+                const uint2 c_nn = load_ce(t0 + 2u * EPT);
+                const uint32_t seq = ((t0 + grp) << fbits) | (2u * sub);                                                                          // (3)
+                update(x_cur.y, x_cur.x, seq, c_cur.x, x_cur.y != EMPTY);
+                update(x_cur.w, x_cur.z, seq + 1u, c_cur.x, x_cur.w != EMPTY);
+                if (tab.abandoned()) {
+                    if (tid == 0) { const uint32_t done = t0 + EPT; misc[11] = done < nnz ? done : nnz; }
+                    break;
+                }
+                c_cur = c_nxt; x_cur = x_nxt; c_nxt = c_nn;
+            }
+        } else {
+#pragma unroll 1
+            for (uint32_t t0 = 0; t0 < nnz; t0 += EPT) {
+                const uint32_t r = t0 + grp;
+                uint2 c = make_uint2(0u, 0u);
+                uint32_t c0 = 0, len = 0;
+                if (r < nnz) { c = csr2[rs + r]; c0 = p.a_colptr[c.y]; len = p.a_colptr[c.y + 1] - c0; }
+#pragma unroll 1
+                for (uint32_t b = 2u * sub; __ballot(b < len) != 0; b += 2u << lb) {      // wave-uniform trip count: chunks of 2 * LPC entries
+                    uint2 e0 = make_uint2(0u, EMPTY), e1 = e0;
+                    if (b < len) e0 = reinterpret_cast<const uint2 *>(p.a_csc)[c0 + b];
+                    if (b + 1u < len) e1 = reinterpret_cast<const uint2 *>(p.a_csc)[c0 + b + 1u];
+                    const uint32_t seq = (r << fbits) | b;
+                    update(e0.y, e0.x, seq, c.x, b < len);
+                    update(e1.y, e1.x, seq + 1u, c.x, b + 1u < len);
+                }
+                if (tab.abandoned()) {
+                    if (tid == 0) { const uint32_t done = t0 + EPT; misc[11] = done < nnz ? done : nnz; }
+                    break;
+                }
+            }
+        }
+        if (__ballot(pr != 0) != 0) {
+            dg = wave_sum_u32(dg); pr = wave_sum_u32(pr);
+            if (lane == 0) { lds_add32(&misc[0], dg); lds_add32(&misc[12], pr); }
+        }
+        publish_next();
+        if (GLOBAL) __syncthreads(); else lds_barrier();
+        if (tab.abandoned()) {
+            // the optimistic table was too small: hand the row to the next tier (its kernel starts after this one ends)
+            if (tid == 0) {
+                const uint32_t at = atomicAdd(&p.ctr->tier_count[tier + 1], 1u);
+                p.lists[(size_t)(tier + 1) * p.M + at] = i;
+                const unsigned long long all = nnz ? nnz : 1u, done = misc[11] ? misc[11] : all;
+                lds_add64(w64(W_FB_C), (unsigned long long)misc[9] * all / done); lds_add64(w64(W_FB_U), (unsigned long long)nnz); lds_add32(&misc[W_FB_N], 1u);
+            }
+            __syncthreads();
+            continue;
+        }
+
+        // ---- one table sweep: nnz before prune + ballot-compacted survivor list ----
+        uint32_t yraw = 0;
+        for (uint32_t b0 = 0; b0 < T; b0 += BLOCK) {                       // wave-uniform trip count: ballots are safe
+            const uint32_t s0 = b0 + tid;
+            bool keep = false;
+            if (s0 < T) {
+                const uint32_t j = tab.ld(tab.keys, s0);
+                if (j != EMPTY) { ++yraw; keep = tab.ld(tab.cnt, s0) >= 2; }
+            }
+            const uint64_t bal = __ballot(keep);
+            if (bal == 0) continue;
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&misc[3], (uint32_t)__popcll(bal));
+            at = __shfl(at, 0, 64) + (uint32_t)__popcll(bal & lt);
+            if (keep) { if (GLOBAL) list[at] = s0; else list16[at] = (uint16_t)s0; }
+        }
+        yraw = wave_sum_u32(yraw);
+        if (lane == 0 && yraw) atomicAdd(&misc[5], yraw);
+        if (GLOBAL) __syncthreads(); else lds_barrier();
+        if (tid == 0) {
+            const uint32_t dcount = misc[0];
+            const uint32_t ytot = misc[3] + (dcount >= 2 ? 1u : 0u);
+            unsigned long long off;
+            if (ytot <= chunk_left) { off = chunk_off; chunk_off += ytot; chunk_left -= ytot; }
+            else if (ytot >= STAGE_CHUNK / 2) off = atomicAdd(&p.ctr->cursor, (unsigned long long)ytot);
+            else { off = atomicAdd(&p.ctr->cursor, (unsigned long long)STAGE_CHUNK); chunk_off = off + ytot; chunk_left = STAGE_CHUNK - ytot; }
+            const bool fits = off + ytot <= p.tmp_cap;
+            if (!fits) atomicOr(&p.ctr->overflow, 1u);
+            p.row_cnt[i] = fits ? ytot : 0u;      // (a row that found no room stages nothing: the finalize pass must not read behind the area; the call is repeated)
+            p.row_off[i] = off;
+            misc[6] = (uint32_t)off; misc[7] = (uint32_t)(off >> 32); misc[8] = fits ? 1u : 0u;
+            lds_add64(w64(W_ACC_YRAW), (unsigned long long)(misc[5] + (dcount >= 1 ? 1u : 0u)));
+            lds_add64(w64(W_ACC_P), (unsigned long long)misc[12]);
+            lds_add32(&misc[W_ACC_DONE], 1u);
+            lds_add32(&misc[W_ACC_NDIAG], dcount >= 2 ? 1u : 0u);
+            lds_add64(w64(W_ACC_Y), (unsigned long long)ytot);
+            if (!GLOBAL) { lds_add64(w64(W_FB_C), (unsigned long long)misc[9]); lds_add64(w64(W_FB_U), (unsigned long long)nnz); lds_add32(&misc[W_FB_N], 1u); }
+            if (p.use_feedback && misc[W_FB_N] >= 8) {          // no prior yet: push this workgroup's share to the hot sums
+                const unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
+                atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu);
+                *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;
+            }
+        }
+        lds_barrier();          // row_cnt / row_off stores stay in flight
+        if (misc[8]) {
+            // ---- all survivors (and the diagonal, by the lane after the last of them) write their staging records ----
+            const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
+            const uint32_t ysurv = misc[3];
+            const uint32_t hasd = misc[0] >= 2 ? 1u : 0u;
+            uint32_t nup = 0, mx = 0;
+            auto seed_at = [&](uint32_t a, uint32_t &q, uint32_t &t) {      // sequence number -> the two positions (32-bit accumulators only)
+                const uint2 ce = csr2[rs + (a >> fbits)];
+                q = ce.x;
+                t = ell ? (uint32_t)p.a_ell[((unsigned long long)ce.y << sb) + (a & fmask)] : (uint32_t)p.a_csc[p.a_colptr[ce.y] + (a & fmask)];
+            };
+            for (uint32_t t = tid; t < ysurv + hasd; t += BLOCK) {
+                elba_seed_t v;
+                uint32_t j = i;
+                if (t < ysurv) {
+                    const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)list16[t];
+                    j = tab.ld(tab.keys, s0); v.numshared = (int32_t)tab.ld(tab.cnt, s0);
+                    if (PAY) {
+                        const uint32_t va = (uint32_t)tab.vmin[s0], vb = (uint32_t)tab.vmax[s0];
+                        v.q0 = va >> 16; v.t0 = va & 0xFFFFu; v.q1 = vb >> 16; v.t1 = vb & 0xFFFFu;
+                    } else {
+                        seed_at(tab.ld(tab.smin, s0), v.q0, v.t0);
+                        seed_at(tab.ld(tab.smax, s0), v.q1, v.t1);
+                    }
+                } else {
+                    // B(i,i): first / last product of the fold = the row's first / last entry paired with itself (rows are in (kid, pos)
+                    // order, columns in (read, pos) order: the first entry of the row is the first of read i in its column)
+                    v.numshared = (int32_t)misc[0];
+                    v.q0 = v.t0 = csr2[rs].x; v.q1 = v.t1 = csr2[rs + nnz - 1u].x;
+                }
+                p.tmp[off + t].a = make_uint4(j, 0xFFFFFFFFu, v.q0, v.t0);
+                p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);
+                if (j > i) ++nup;
+                mx = (uint32_t)v.numshared > mx ? (uint32_t)v.numshared : mx;
+            }
+            if (nup) lds_add64(w64(W_NUP), (unsigned long long)nup);
+            if (mx) lds_max32(&misc[W_MX], mx);
+        }
+        if (GLOBAL) __syncthreads(); else lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
+    }
+    // flush the workgroup's statistics
+    __syncthreads();
+    OvShard *sh = &p.ctr->shard[blockIdx.x & (NUM_SHARDS - 1)];
+    if (tid == 0) {
+        if (*w64(W_NUP)) atomicAdd(&sh->nupper, *w64(W_NUP));
+        if (misc[W_MX]) atomicMax(&sh->maxshared, misc[W_MX]);
+        unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
+        if (p.use_feedback && misc[W_FB_N]) { atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu); }
+        fc += *w64(W_TOT_C); fu += *w64(W_TOT_U);
+        if (fu) { atomicAdd(&sh->fb_claims, fc); atomicAdd(&sh->fb_ub, fu); }
+        if (misc[W_ACC_DONE]) {
+            atomicAdd(&sh->yraw, *w64(W_ACC_YRAW));
+            atomicAdd(&sh->nnz, *w64(W_ACC_Y));
+            atomicAdd(&sh->products, *w64(W_ACC_P));
+            atomicAdd(&sh->tier_done[tier], misc[W_ACC_DONE]);
+            if (misc[W_ACC_NDIAG]) atomicAdd(&sh->ndiag, (unsigned long long)misc[W_ACC_NDIAG]);
+        }
+    }
+}
+
+// ---- symbolic: queue every non-empty row of the window on its starting tier, in row order ----------------------------------------
+// All that is known of a row before the product is its length: distinct partners are estimated as nnz x prior (1/4 before anything is
+// known of the matrix — the kernel corrects itself from the rows already done — afterwards the measured ratio).
+__global__ __launch_bounds__(256) void k_classify_direct(OvParams p)
+{
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t lt = (1ull << lane) - 1;
+    for (uint32_t i0 = p.row_lo + blockIdx.x * blockDim.x; i0 < p.row_hi; i0 += stride) {      // block-uniform trip count
+        const uint32_t i = i0 + threadIdx.x;
+        int mytier = -1;
+        const uint32_t nnz = i < p.row_hi ? p.a_rowptr[i + 1] - p.a_rowptr[i] : 0u;
+        if (nnz != 0) {
+            const unsigned long long prod_ub = (unsigned long long)nnz * p.max_col;
+            const uint32_t ub = prod_ub < (unsigned long long)p.Mcols ? (uint32_t)prod_ub : p.Mcols;
+            const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
+            uint32_t est = (uint32_t)(((unsigned long long)nnz * p.prior_q16) >> 16);
+            if (est < 64) est = 64;
+            int tier = 0;
+            while (tier < NUM_LDS_TIERS && est > p.tier_limit[tier]) ++tier;
+            const int gt = gbits <= LDS_TBITS0 ? 0 : (int)gbits - LDS_TBITS0;      // never start above the tier that is guaranteed to fit
+            if (gt < tier) tier = gt;
+            if (tier > NUM_LDS_TIERS) tier = NUM_LDS_TIERS;
+            mytier = tier;
+        }
+#pragma unroll
+        for (int t = 0; t < NUM_TIERS; ++t) {
+            const uint64_t bal = __ballot(mytier == t);
+            if (bal == 0) continue;
+            uint32_t base = 0;
+            if (lane == (uint32_t)(__ffsll((unsigned long long)bal) - 1)) base = atomicAdd(&p.ctr->tier_count[t], (uint32_t)__popcll(bal));
+            base = __shfl(base, __ffsll((unsigned long long)bal) - 1, 64);
+            if (mytier == t) p.lists[(size_t)t * p.M + base + (uint32_t)__popcll(bal & lt)] = i;
+        }
+    }
+}

@@ -281,6 +281,13 @@ int  elba_kmer_histogram(elba_ctx *ctx, int64_t *hist, int64_t len);
 
 int  elba_get_device_view(elba_ctx *ctx, elba_device_view *view);
 
+/* Run-time options by name (unknown name: ELBA_ERR_INVALID_ARG).
+ *   "overlap_cold_calls" (0 | 1): 1 = every elba_create_seed_matrix call forgets what earlier calls on the same matrix learned (the
+ *       distinct-partner ratio that picks the starting table tiers, which tiers and column sorts received rows): what a caller that
+ *       multiplies every matrix once pays — the reference's create_seed_matrix is called once per A (src/main.cpp:281).  Buffers stay
+ *       allocated.  Default 0. */
+int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
+
 /* ---- distributed building blocks (one context per rank/GPU; the collectives are issued by the host driver) ----------------
  * They replace, for a 1D read-row partition over the GPUs of one node, what the reference does with MPI inside the same four
  * functions: the two k-mer all-to-alls (src/KmerOps.cpp:117-151, :244-274), the k-mer id Exscan (:371-375), and the
