@@ -59,7 +59,7 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned int fin_count[2];            // rows needing the LDS-bitonic / HBM-bitonic column sort
     unsigned int pad[2];
     unsigned long long pad2[14];          // keep the feedback sums on a cache line of their own
-    alignas(128) unsigned int tier_next[NUM_TIERS];    // plan-free kernel: next unclaimed position of every tier's queue (one atomic per row)
+    alignas(128) unsigned int tier_next[NUM_TIERS][8][32]; // plan-free kernel: heads ([..][..][0]) of every tier's 8 interleaved sub-queues, a 128-byte line each
     alignas(128)
     unsigned long long fb_claims, fb_ub;  // feedback: distinct partners found / products, summed over rows done so far in this call
     OvShard shard[NUM_SHARDS];
@@ -490,6 +490,10 @@ static void create_seed_matrix_direct(Ctx &c)
 
     const int cus = c.num_cus;
     const int64_t nrows = row_hi - row_lo;
+    // B is symmetric up to exchanging the two positions of every seed (exactly: the canonical seeds are min / max over a cross product of
+    // positions per shared k-mer): a pair of rows of this context's window is accumulated on its smaller row only and the surviving
+    // entries are mirrored into the partner's row afterwards (k_mirror) — half the accumulator updates, tables half as full.
+    const bool half = !getenv("ELBA_NO_SYMMETRY");
     const int64_t slack = (int64_t)cus * 32 * STAGE_CHUNK + 64;      // one open chunk per resident workgroup
     if (c.ov_tmp_cap == 0) {
         if (c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
@@ -497,8 +501,8 @@ static void create_seed_matrix_direct(Ctx &c)
             // nnz(B) <= products / 2 and, on every read set seen so far, < nnz(A) / 4: start from nnz(A) (bounded by half the free memory)
             size_t free_b = 0, total_b = 0;
             ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
-            const int64_t budget = (int64_t)(free_b / 2 / (sizeof(StageRec) + 24));
-            c.ov_tmp_cap = std::min<int64_t>(std::max<int64_t>(Z, 1 << 16) + slack, std::max<int64_t>(budget, 1024));
+            const int64_t budget = (int64_t)(free_b / 2 / (sizeof(StageRec) + (half ? 2 * (24 + 32) : 24)));
+            c.ov_tmp_cap = std::min<int64_t>(std::max<int64_t>(half ? Z / 2 : Z, 1 << 16) + slack, std::max<int64_t>(budget, 1024));
         }
         if (c.ov_tmp_cap < 1024) c.ov_tmp_cap = 1024;
     }
@@ -508,12 +512,12 @@ static void create_seed_matrix_direct(Ctx &c)
     p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
     p.s_log2 = c.s_log2; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
-    p.half = 0;
+    p.half = half ? 1u : 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     const bool pay = c.pos16 && !getenv("ELBA_NO_PAY");
     // workgroup sizes grow with the table so that the largest tiers still bring enough waves to a CU (one or two workgroups fit its LDS)
-    const uint32_t blk[NUM_LDS_TIERS] = {128u, 256u, 512u, 1024u, 1024u};
+    const uint32_t blk[NUM_LDS_TIERS] = {128u, 256u, 512u, 1024u, 512u};
     for (int t = 0; t < NUM_LDS_TIERS; ++t) {
         const uint32_t T = 1u << (LDS_TBITS0 + t);
         p.tier_limit[t] = std::min((T >> 2) * 3, T - blk[t]) - 1;      // a lane overshoots by at most one claim (Table::insert_lds)
@@ -527,10 +531,10 @@ static void create_seed_matrix_direct(Ctx &c)
     static bool attr_done = false;
     if (!attr_done) {
         const int lds = 160 * 1024;
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#define ELBA_ATTR(B, P, D) ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<B, false, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+        ELBA_ATTR(512, true, 1); ELBA_ATTR(512, true, 2); ELBA_ATTR(512, true, 4); ELBA_ATTR(1024, true, 1); ELBA_ATTR(1024, true, 2); ELBA_ATTR(1024, true, 4);
+        ELBA_ATTR(512, false, 1); ELBA_ATTR(512, false, 2); ELBA_ATTR(512, false, 4); ELBA_ATTR(1024, false, 1); ELBA_ATTR(1024, false, 2); ELBA_ATTR(1024, false, 4);
+#undef ELBA_ATTR
         attr_done = true;
     }
 
@@ -547,13 +551,16 @@ static void create_seed_matrix_direct(Ctx &c)
         const bool timed = passes > 1 || (c.ov_calls++ % (uint64_t)stride) == 0;
         c.ov_tmp.reserve((size_t)c.ov_tmp_cap * sizeof(StageRec));
         p.tmp = c.ov_tmp.as<StageRec>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
-        c.b_cap_entries = c.ov_tmp_cap;                      // the output cannot be larger than what was staged
+        c.b_cap_entries = half ? 2 * c.ov_tmp_cap : c.ov_tmp_cap;      // the output cannot be larger than what was staged (and mirrored)
         c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
         c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
+        const bool mir16 = c.pos16 && !getenv("ELBA_MIR32");
+        if (half) c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * (mir16 ? 16 : sizeof(StageRec)));
 
         if (timed) c.ov_marks.mark(0, s);
-        if (!c.ov_low_clean) ELBA_HIP(hipMemsetAsync(c.ov_totcnt.p, 0, (size_t)(M + 2) * 4, s));      // (nothing is mirrored: stays zero)
-        c.ov_low_clean = true;
+        // the ticket counters come back clean from a call that ran to its end (k_finalize_wave); otherwise zero them here
+        if (!c.ov_low_clean) ELBA_HIP(hipMemsetAsync(c.ov_totcnt.p, 0, (size_t)(M + 2) * 4, s));
+        c.ov_low_clean = false;
         ELBA_HIP(hipMemsetAsync(c.ov_counters.p, 0, sizeof(OvCounters), s));
         ELBA_HIP(hipMemsetAsync(c.ov_rowcnt.p, 0, (size_t)(M + 2) * 4, s));
         if (nrows > 0) {
@@ -563,24 +570,31 @@ static void create_seed_matrix_direct(Ctx &c)
         }
         if (timed) c.ov_marks.mark(1, s);
         if (nrows > 0) {
-            const size_t X = 256;      // bytes of misc words behind the table
+            // bytes behind the table: misc words + one product ring per wavefront (128 entries of 12 / 8 bytes)
+            auto X = [&](int B, bool P) { return (size_t)256 + (size_t)(B / 64) * (P ? 1536 : 1024); };
             const bool all_tiers = !c.ov_tiers_known;
             skipped_tiers = 0;
 #define ELBA_DTIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
-#define ELBA_LAUNCH_D(B, G, P, grid, lds, tier, tb) hipLaunchKernelGGL((k_spgemm_direct<B, G, P>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb))
+#define ELBA_LAUNCH_D(B, G, P, grid, lds, tier, tb)                                                                                       \
+    do {                                                                                                                                  \
+        if (dk == 1) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 1>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));                   \
+        else if (dk == 4) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 4>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));              \
+        else hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 2>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));                           \
+    } while (0)
+            const int dk = getenv("ELBA_DK") ? atoi(getenv("ELBA_DK")) : 2;      // rounds of DK trips in flight (tuning knob)
             if (pay) {
-                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, true, cus * 11, (size_t)26 * 512 + X, 0, 9u));
-                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, true, cus * 5, (size_t)26 * 1024 + X, 1, 10u));
-                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, true, cus * 3, (size_t)26 * 2048 + X, 2, 11u));
-                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X, 3, 12u));
+                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, true, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u));
+                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, true, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u));
+                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, true, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u));
+                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u));
             } else {
-                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, false, cus * 12, (size_t)18 * 512 + X, 0, 9u));
-                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, false, cus * 8, (size_t)18 * 1024 + X, 1, 10u));
-                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, false, cus * 4, (size_t)18 * 2048 + X, 2, 11u));
-                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, false, cus * 2, (size_t)18 * 4096 + X, 3, 12u));
+                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, false, cus * 12, (size_t)18 * 512 + X(128, false), 0, 9u));
+                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, false, cus * 7, (size_t)18 * 1024 + X(256, false), 1, 10u));
+                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, false, cus * 3, (size_t)18 * 2048 + X(512, false), 2, 11u));
+                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 4096 + X(1024, false), 3, 12u));
             }
-            ELBA_DTIER(4, ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 8192 + X, 4, 13u));
-            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, X, NUM_LDS_TIERS, 0u));
+            ELBA_DTIER(4, ELBA_LAUNCH_D(512, false, false, cus, (size_t)18 * 8192 + X(512, false), 4, 13u));
+            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, (size_t)256, NUM_LDS_TIERS, 0u));
 #undef ELBA_LAUNCH_D
 #undef ELBA_DTIER
             ELBA_HIP(hipGetLastError());
@@ -588,11 +602,11 @@ static void create_seed_matrix_direct(Ctx &c)
         if (timed) c.ov_marks.mark(2, s);
         {
             FinParams f{};
-            f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = p.tmp; f.mir = nullptr; f.half = 0; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
+            f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = p.tmp; f.mir = half ? c.ov_mir.as<StageRec>() : nullptr; f.half = p.half; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
             f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
             f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
             f.b_cap = c.b_cap_entries;
-            f.mir16 = 0;
+            f.mir16 = mir16 ? 1u : 0u;
             const int gblocks = 32;
             uint64_t sstride = 2;
             while (sstride < (uint64_t)M) sstride <<= 1;
@@ -634,9 +648,15 @@ static void create_seed_matrix_direct(Ctx &c)
             c.ov_tiers_known = false;
             continue;
         }
+        c.ov_low_clean = true;
         break;
     }
 
+#ifdef ELBA_PHASE_CLOCK
+    fprintf(stderr, "[elba phase] wave-0 cycles summed over %llu workgroups: header=%llu init=%llu accumulate=%llu handoff=%llu sweep=%llu reserve=%llu store=%llu | rows %u,%u,%u,%u,%u,%u\n",
+            hc.phase[10], hc.phase[0], hc.phase[1], hc.phase[2], hc.phase[3], hc.phase[4], hc.phase[5], hc.phase[6],
+            hc.tier_count[0], hc.tier_count[1], hc.tier_count[2], hc.tier_count[3], hc.tier_count[4], hc.tier_count[5]);
+#endif
     for (int sh = 0; sh < NUM_SHARDS; ++sh) {       // fold the statistics shards
         const OvShard &x = hc.shard[sh];
         hc.yraw += x.yraw; hc.nnz += x.nnz; hc.ndiag += x.ndiag; hc.nupper += x.nupper; hc.products += x.products;

@@ -20,9 +20,19 @@
 //   * table tiers, optimistic sizing, escalation, HBM spill tier, ballot compaction of the survivors, staging: as before (spgemm.hip).
 
 enum : uint32_t { D_NEXT = 20, D_FB0 = 16, W_ACC_P = 54 /*u64*/, W_END2 = 56 };
-constexpr uint32_t NOROW = 0xFFFFFFFFu;
+constexpr uint32_t RING = 128;      // per-wavefront product ring (entries): < 64 left over + <= 64 new ones per candidate slot
+constexpr uint32_t NOROW = 0xFFFFFFFFu, UNRESOLVED = 0xFFFFFFFEu;
 
-template <int BLOCK, bool GLOBAL, bool PAY>
+// `half`: which of the two rows of a pair {i, j} accumulates it (the other row receives the mirrored entry).  The smaller row when i + j is
+// even, the larger when it is odd: every row then owns about half of its partners whatever its place in the matrix (owned by the smaller
+// row alone, the first rows would own all of theirs and need tables twice the size).  A partner outside this context's row window is
+// always kept: its row lives on another rank.
+__device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t row_lo, uint32_t row_hi)
+{
+    return j < row_lo || j >= row_hi || ((((i ^ j) & 1u) != 0u) ? j < i : j > i);
+}
+
+template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits)
 {
     static_assert(!PAY || !GLOBAL, "payload accumulators: LDS tiers only");
@@ -40,29 +50,56 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
     auto w64 = [&](uint32_t k) { return reinterpret_cast<unsigned long long *>(&misc[k]); };
     if (tid >= 32 && tid < W_END2) misc[tid] = 0;
     const uint32_t *queue = p.lists + (size_t)tier * p.M;
-    if (tid == 0) {
-        const uint32_t idx = atomicAdd(&p.ctr->tier_next[tier], 1u);
-        misc[D_NEXT] = idx < nrows ? queue[idx] : NOROW;
-    }
+    // Rows are claimed one at a time, one row ahead.  One head word saturates at ~88 claims/us (MI355X_MICROARCH.md, "dequeue"); the queue
+    // is therefore cut into 8 interleaved sub-queues (positions congruent modulo 8) with a head each, a workgroup draws from the one of
+    // its XCD (workgroups go to the XCDs round-robin) and moves on to the next sub-queue when its own is exhausted.
+    uint32_t qshard = blockIdx.x & 7u, qtried = 0;
+    // (thread 0 only) draw: one atomic, nothing waits for it; resolve: where the draw is first needed — a draw beyond the end of the
+    // sub-queue moves on to the next one (then, and only then, the claim is a synchronous round trip)
+    auto draw = [&]() -> uint32_t { return atomicAdd(&p.ctr->tier_next[tier][qshard][0], 1u); };
+    auto resolve = [&](uint32_t k) -> uint32_t {
+        for (;;) {
+            const unsigned long long idx = (unsigned long long)k * 8u + qshard;
+            if (idx < nrows) return queue[idx];
+            if (++qtried >= 8u) return NOROW;
+            qshard = (qshard + 1u) & 7u;
+            k = draw();
+        }
+    };
+    if (tid == 0) misc[D_NEXT] = resolve(draw());
     __syncthreads();
     uint32_t fb_seen = 0;
+#ifdef ELBA_PHASE_CLOCK
+    // diagnostic build only (make dbg): shader-clock cycles of wave 0 per phase, summed over workgroups into ctr->phase
+    //   0 row header  1 table init  2 accumulate  3 next-row hand-off + barrier  4 sweep  5 reserve  6 staging stores
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#define ELBA_DSTAMP(k) do { const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += tn - tprev; tprev = tn; } while (0)
+#else
+#define ELBA_DSTAMP(k) do { } while (0)
+#endif
 
     for (;;) {
         const uint32_t i = sfirst(misc[D_NEXT]);
         if (i == NOROW) break;
-        uint32_t nidx = 0;
-        if (tid == 0) nidx = atomicAdd(&p.ctr->tier_next[tier], 1u);      // the row after this one: the round trip hides behind this row
+        uint32_t nidx = 0, nrow = UNRESOLVED;
+        if (tid == 0 && qtried < 8u) nidx = draw();      // the row after this one: the round trip hides behind this row
         const uint32_t rs = sfirst(p.a_rowptr[i]), nnz = sfirst(p.a_rowptr[i + 1]) - rs;
         // distinct partners of the row <= min(products, reads); products <= nnz * longest column
         const unsigned long long prod_ub = (unsigned long long)nnz * p.max_col;
         const uint32_t ub_i = prod_ub < (unsigned long long)p.Mcols ? (uint32_t)prod_ub : p.Mcols;
-        auto publish_next = [&]() { if (tid == 0) misc[D_NEXT] = nidx < nrows ? queue[nidx] : NOROW; };
+        // the draw has returned by the time the first round's column words have (loads and returning atomics come back in order): its queue
+        // entry is requested there and arrives with the second round's words — the hand-off below then waits for nothing
+        auto resolve_early = [&]() {
+            if (tid == 0 && qtried < 8u) { const unsigned long long idx = (unsigned long long)nidx * 8u + qshard; if (idx < nrows) nrow = queue[idx]; }
+        };
+        auto publish_next = [&]() { if (tid == 0) misc[D_NEXT] = nrow != UNRESOLVED ? nrow : (qtried < 8u ? resolve(nidx) : NOROW); };
 
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call (no prior for this matrix): rows already done tell how many distinct partners a row entry
             // brings on THIS data; a row predicted not to fit is forwarded without an attempt.  (lane 0 reads the hot sums once per 8 rows
             // and broadcasts through LDS: the decision must be workgroup-uniform)
-            if ((fb_seen++ & 7u) == 0) {
+            if ((fb_seen++ & 15u) == 0) {
                 if (tid == 0) {
                     const unsigned long long u = __hip_atomic_load(&p.ctr->fb_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long c = __hip_atomic_load(&p.ctr->fb_claims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -107,6 +144,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             list16 = reinterpret_cast<uint16_t *>(smem + (PAY ? 6 : 4) * T);
         }
         const uint32_t T = tab.size();
+        ELBA_DSTAMP(0);
         for (uint32_t s = tid; s < T; s += BLOCK) {
             tab.keys[s] = EMPTY; tab.cnt[s] = 0;
             if (PAY) { tab.vmin[s] = ~0ull; tab.vmax[s] = 0ull; } else { tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
@@ -115,44 +153,90 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
         if (GLOBAL) __syncthreads(); else lds_barrier();
 
         // ---- accumulate -----------------------------------------------------------------------------------------------------
+        // Products are COMPACTED before they meet the table.  Of the candidate slots a wavefront looks at, one in five holds a product on
+        // 15 %-error reads (columns of 2-3 entries padded to 8, one of them the row's own): inserting slot by slot ran the hand-scheduled
+        // probe loop — a chain of LDS round trips, as long as the unluckiest lane's — at a fifth of its width, and that chain, not the
+        // gathers, bounded the kernel.  Each wavefront therefore appends its products to a 128-entry ring in LDS (ballot + popcount prefix:
+        // partner id and the 64-bit payload, or the 32-bit sequence number) and runs the probe loop once per 64 products, every lane busy.
         bool full = false;
-        uint32_t dg = 0, pr = 0;                 // this lane's diagonal products / all products (valid column entries) of the row
-        auto update = [&](uint32_t j, uint32_t posT, uint32_t seq, uint32_t posQ, bool valid) {
-            const bool isd = valid && j == i;
-            dg += isd ? 1u : 0u; pr += valid ? 1u : 0u;
-            const bool ins = valid && !isd;
-            if (PAY) {
-                const unsigned long long v = ((unsigned long long)seq << 32) | (posQ << 16) | posT;
-                tab.insert_lds64(j, v, v, 1u, ins, full);
-            } else if (GLOBAL) {
-                if (ins) tab.insert(j, seq, full);
-            } else tab.insert_lds(j, seq, seq, 1u, ins, full);
+        uint32_t dg = 0, pr = 0;                 // diagonal products / all products (valid column entries) of the row, as seen by this wavefront (uniform)
+        uint32_t head = 0, tail = 0;             // ring positions (uniform)
+        uint32_t *qj = misc + 64 + (tid >> 6) * (PAY ? 384u : 256u);
+        uint32_t *qs = qj + RING;
+        unsigned long long *qv = reinterpret_cast<unsigned long long *>(qj + RING);
+        auto drain = [&](uint32_t n) {           // n <= 64 products leave the ring, one per lane
+            const uint32_t at = (head + lane) & (RING - 1u);
+            const uint32_t j = qj[at];
+            if (PAY) { const unsigned long long v = qv[at]; tab.insert_lds64(j, v, v, 1u, lane < n, full); }
+            else { const uint32_t sq = qs[at]; tab.insert_lds(j, sq, sq, 1u, lane < n, full); }
+            head += n;
+        };
+        // one candidate slot per lane: j == EMPTY is padding (or a lane without a row entry), j == i the diagonal; with `half` a pair of rows
+        // of the window is accumulated on its smaller row only and mirrored afterwards (partners below the window live on another rank: kept)
+        auto slot = [&](uint32_t j, uint32_t posT, uint32_t seq, uint32_t posQ) {
+            const uint64_t mv = __ballot(j != EMPTY);
+            if (mv == 0) return;
+            const uint64_t md = __ballot(j == i);
+            pr += (uint32_t)__popcll(mv); dg += (uint32_t)__popcll(md);
+            uint64_t mi = mv & ~md;
+            if (p.half) mi &= __ballot(owns_pair(i, j, p.row_lo, p.row_hi));
+            if (mi == 0) return;
+            const bool ins = (mi >> lane) & 1ull;
+            if (GLOBAL) { if (ins) tab.insert(j, seq, full); return; }
+            const uint32_t at = (tail + (uint32_t)__popcll(mi & lt)) & (RING - 1u);
+            if (ins) {
+                qj[at] = j;
+                if (PAY) qv[at] = ((unsigned long long)seq << 32) | (posQ << 16) | posT; else qs[at] = seq;
+            }
+            tail += (uint32_t)__popcll(mi);
+            if (tail - head >= 64u) drain(64u);
         };
         if (ell) {
-            // Two trips in flight.  Each trip (1) consumes what the previous one requested — this trip's column words and the next trip's
-            // row entries: one wait — (2) requests the next trip's column words and the row entries after next, (3) updates the
-            // accumulator (LDS only), during which the requests land.
+            // DK trips of the workgroup travel together (a "round": DK row entries and DK column words per lane), two rounds in flight.
+            // Each round (1) consumes what the previous one requested — this round's column words and the next round's row entries: one
+            // wait — (2) requests the next round's column words and the row entries of the round after it, (3) updates the accumulator
+            // (LDS only), during which the requests land.  What bounds the loop is the number of 64-byte lines a CU has in flight
+            // (profiles/r02_gather64_microbench.txt: 46-52 G random lines/s chip-wide, reached only with hundreds of lines in flight per
+            // CU): 16 lines per wave-instruction, 2 * DK instructions in flight per wave.
             const uint4 ones = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-            auto load_ce = [&](uint32_t t0) { const uint32_t r = t0 + grp; return r < nnz ? csr2[rs + r] : make_uint2(0u, 0u); };
-            auto gather = [&](const uint2 &c, uint32_t t0) {
-                return t0 + grp < nnz ? *reinterpret_cast<const uint4 *>(p.a_ell + (((unsigned long long)c.y << sb) + 2u * sub)) : ones;
+            constexpr uint32_t RND = (uint32_t)DK;
+            const uint32_t EPR = EPT * RND;                       // row entries per round
+            uint2 c_cur[DK], c_nxt[DK];
+            uint4 x_cur[DK];
+            auto load_ce = [&](uint2 *c, uint32_t t0) {
+#pragma unroll
+                for (int k = 0; k < DK; ++k) { const uint32_t r = t0 + (uint32_t)k * EPT + grp; c[k] = r < nnz ? csr2[rs + r] : make_uint2(0u, 0u); }
             };
-            uint2 c_cur = load_ce(0u);
-            uint4 x_cur = gather(c_cur, 0u);
-            uint2 c_nxt = load_ce(EPT);
+            auto gather = [&](uint4 *x, const uint2 *c, uint32_t t0) {
+#pragma unroll
+                for (int k = 0; k < DK; ++k)
+                    x[k] = t0 + (uint32_t)k * EPT + grp < nnz ? *reinterpret_cast<const uint4 *>(p.a_ell + (((unsigned long long)c[k].y << sb) + 2u * sub)) : ones;
+            };
+            load_ce(c_cur, 0u);
+            gather(x_cur, c_cur, 0u);
+            load_ce(c_nxt, EPR);
 #pragma unroll 1
-            for (uint32_t t0 = 0; t0 < nnz; t0 += EPT) {
-                asm volatile("" : "+v"(x_cur.x), "+v"(x_cur.y), "+v"(x_cur.z), "+v"(x_cur.w), "+v"(c_nxt.x), "+v"(c_nxt.y) : : "memory");      // (1)
-                const uint4 x_nxt = gather(c_nxt, t0 + EPT);                                                                                     // (2)
-                const uint2 c_nn = load_ce(t0 + 2u * EPT);
-                const uint32_t seq = ((t0 + grp) << fbits) | (2u * sub);                                                                          // (3)
-                update(x_cur.y, x_cur.x, seq, c_cur.x, x_cur.y != EMPTY);
-                update(x_cur.w, x_cur.z, seq + 1u, c_cur.x, x_cur.w != EMPTY);
+            for (uint32_t t0 = 0; t0 < nnz; t0 += EPR) {
+#pragma unroll
+                for (int k = 0; k < DK; ++k)
+                    asm volatile("" : "+v"(x_cur[k].x), "+v"(x_cur[k].y), "+v"(x_cur[k].z), "+v"(x_cur[k].w), "+v"(c_nxt[k].x), "+v"(c_nxt[k].y) : : "memory");      // (1)
+                uint4 x_nxt[DK];
+                uint2 c_nn[DK];
+                gather(x_nxt, c_nxt, t0 + EPR);                                                                                                   // (2)
+                load_ce(c_nn, t0 + 2u * EPR);
+                if (t0 == 0) resolve_early();
+#pragma unroll
+                for (int k = 0; k < DK; ++k) {                                                                                                    // (3)
+                    const uint32_t seq = ((t0 + (uint32_t)k * EPT + grp) << fbits) | (2u * sub);
+                    slot(x_cur[k].y, x_cur[k].x, seq, c_cur[k].x);
+                    slot(x_cur[k].w, x_cur[k].z, seq + 1u, c_cur[k].x);
+                }
                 if (tab.abandoned()) {
-                    if (tid == 0) { const uint32_t done = t0 + EPT; misc[11] = done < nnz ? done : nnz; }
+                    if (tid == 0) { const uint32_t done = t0 + EPR; misc[11] = done < nnz ? done : nnz; }
                     break;
                 }
-                c_cur = c_nxt; x_cur = x_nxt; c_nxt = c_nn;
+#pragma unroll
+                for (int k = 0; k < DK; ++k) { c_cur[k] = c_nxt[k]; x_cur[k] = x_nxt[k]; c_nxt[k] = c_nn[k]; }
             }
         } else {
 #pragma unroll 1
@@ -167,8 +251,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                     if (b < len) e0 = reinterpret_cast<const uint2 *>(p.a_csc)[c0 + b];
                     if (b + 1u < len) e1 = reinterpret_cast<const uint2 *>(p.a_csc)[c0 + b + 1u];
                     const uint32_t seq = (r << fbits) | b;
-                    update(e0.y, e0.x, seq, c.x, b < len);
-                    update(e1.y, e1.x, seq + 1u, c.x, b + 1u < len);
+                    slot(e0.y, e0.x, seq, c.x);
+                    slot(e1.y, e1.x, seq + 1u, c.x);
                 }
                 if (tab.abandoned()) {
                     if (tid == 0) { const uint32_t done = t0 + EPT; misc[11] = done < nnz ? done : nnz; }
@@ -176,12 +260,12 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 }
             }
         }
-        if (__ballot(pr != 0) != 0) {
-            dg = wave_sum_u32(dg); pr = wave_sum_u32(pr);
-            if (lane == 0) { lds_add32(&misc[0], dg); lds_add32(&misc[12], pr); }
-        }
+        if (!GLOBAL && tail != head) drain(tail - head);
+        if (pr != 0 && lane == 0) { lds_add32(&misc[0], dg); lds_add32(&misc[12], pr); }
+        ELBA_DSTAMP(2);
         publish_next();
         if (GLOBAL) __syncthreads(); else lds_barrier();
+        ELBA_DSTAMP(3);
         if (tab.abandoned()) {
             // the optimistic table was too small: hand the row to the next tier (its kernel starts after this one ends)
             if (tid == 0) {
@@ -189,6 +273,12 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 p.lists[(size_t)(tier + 1) * p.M + at] = i;
                 const unsigned long long all = nnz ? nnz : 1u, done = misc[11] ? misc[11] : all;
                 lds_add64(w64(W_FB_C), (unsigned long long)misc[9] * all / done); lds_add64(w64(W_FB_U), (unsigned long long)nnz); lds_add32(&misc[W_FB_N], 1u);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (p.use_feedback && misc[W_FB_N] >= 2) {          // abandoned rows are the strongest evidence: publish at once
+                    const unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
+                    atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu);
+                    *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;
+                }
             }
             __syncthreads();
             continue;
@@ -201,7 +291,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             bool keep = false;
             if (s0 < T) {
                 const uint32_t j = tab.ld(tab.keys, s0);
-                if (j != EMPTY) { ++yraw; keep = tab.ld(tab.cnt, s0) >= 2; }
+                if (j != EMPTY) { yraw += (p.half && j >= p.row_lo && j < p.row_hi) ? 2u : 1u; keep = tab.ld(tab.cnt, s0) >= 2; }
             }
             const uint64_t bal = __ballot(keep);
             if (bal == 0) continue;
@@ -213,6 +303,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
         yraw = wave_sum_u32(yraw);
         if (lane == 0 && yraw) atomicAdd(&misc[5], yraw);
         if (GLOBAL) __syncthreads(); else lds_barrier();
+        ELBA_DSTAMP(4);
         if (tid == 0) {
             const uint32_t dcount = misc[0];
             const uint32_t ytot = misc[3] + (dcount >= 2 ? 1u : 0u);
@@ -231,19 +322,20 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             lds_add32(&misc[W_ACC_NDIAG], dcount >= 2 ? 1u : 0u);
             lds_add64(w64(W_ACC_Y), (unsigned long long)ytot);
             if (!GLOBAL) { lds_add64(w64(W_FB_C), (unsigned long long)misc[9]); lds_add64(w64(W_FB_U), (unsigned long long)nnz); lds_add32(&misc[W_FB_N], 1u); }
-            if (p.use_feedback && misc[W_FB_N] >= 8) {          // no prior yet: push this workgroup's share to the hot sums
+            if (p.use_feedback && misc[W_FB_N] >= 4) {          // no prior yet: push this workgroup's share to the hot sums
                 const unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
                 atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu);
                 *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;
             }
         }
         lds_barrier();          // row_cnt / row_off stores stay in flight
+        ELBA_DSTAMP(5);
         if (misc[8]) {
             // ---- all survivors (and the diagonal, by the lane after the last of them) write their staging records ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
             const uint32_t ysurv = misc[3];
             const uint32_t hasd = misc[0] >= 2 ? 1u : 0u;
-            uint32_t nup = 0, mx = 0;
+            uint32_t nup = 0, mx = 0, nmir = 0;
             auto seed_at = [&](uint32_t a, uint32_t &q, uint32_t &t) {      // sequence number -> the two positions (32-bit accumulators only)
                 const uint2 ce = csr2[rs + (a >> fbits)];
                 q = ce.x;
@@ -268,21 +360,35 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                     v.numshared = (int32_t)misc[0];
                     v.q0 = v.t0 = csr2[rs].x; v.q1 = v.t1 = csr2[rs + nnz - 1u].x;
                 }
-                p.tmp[off + t].a = make_uint4(j, 0xFFFFFFFFu, v.q0, v.t0);
+                // the partner's row gets the mirrored entry: draw its slot there now; k_mirror places it once the row pointers are known
+                uint32_t tick = 0xFFFFFFFFu;
+                if (p.half && j != i && j >= p.row_lo && j < p.row_hi) { tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir; }
+                p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
                 p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);
                 if (j > i) ++nup;
                 mx = (uint32_t)v.numshared > mx ? (uint32_t)v.numshared : mx;
             }
             if (nup) lds_add64(w64(W_NUP), (unsigned long long)nup);
+            if (nmir) lds_add64(w64(W_MIR), (unsigned long long)nmir);
             if (mx) lds_max32(&misc[W_MX], mx);
         }
         if (GLOBAL) __syncthreads(); else lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
+        ELBA_DSTAMP(6);
     }
+#ifdef ELBA_PHASE_CLOCK
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) atomicAdd(&p.ctr->phase[k], ph[k]);
+        atomicAdd(&p.ctr->phase[10], 1ull);
+    }
+#endif
+#undef ELBA_DSTAMP
     // flush the workgroup's statistics
     __syncthreads();
     OvShard *sh = &p.ctr->shard[blockIdx.x & (NUM_SHARDS - 1)];
     if (tid == 0) {
         if (*w64(W_NUP)) atomicAdd(&sh->nupper, *w64(W_NUP));
+        if (*w64(W_MIR)) atomicAdd(&sh->nnz, *w64(W_MIR));
         if (misc[W_MX]) atomicMax(&sh->maxshared, misc[W_MX]);
         unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
         if (p.use_feedback && misc[W_FB_N]) { atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu); }
