@@ -120,6 +120,18 @@ def load_library():
     if _lib is not None:
         return _lib
     p = lib_path()
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64 (same SONAME as the system one).  Whichever is loaded first
+    # serves both; when the system one came first, torch found no GPU afterwards (measured on the GPU box: "No HIP GPUs are available").
+    # The binding hands device memory to torch tensors (tests, bench.py, the multi-GPU driver), so torch's copy is loaded first when there is one.
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is not None and spec.submodule_search_locations:
+            hip = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+            if os.path.exists(hip):
+                C.CDLL(hip, mode=C.RTLD_GLOBAL)
+    except Exception:      # noqa: BLE001 — without torch the system runtime is the only one
+        pass
     if not os.path.exists(p):
         raise ElbaError(-1, "libelba_amd.so is not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C elba_amd/csrc`" % p)
     L = C.CDLL(p)

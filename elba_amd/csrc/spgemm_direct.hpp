@@ -365,7 +365,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 if (p.half && j != i && j >= p.row_lo && j < p.row_hi) { tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir; }
                 p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
                 p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);
-                if (j > i) ++nup;
+                // strict-upper entries: an in-window pair accumulated here stands for (i,j) and (j,i) — one of the two is upper
+                if (j != i && ((p.half && j >= p.row_lo && j < p.row_hi) || j > i)) ++nup;
                 mx = (uint32_t)v.numshared > mx ? (uint32_t)v.numshared : mx;
             }
             if (nup) lds_add64(w64(W_NUP), (unsigned long long)nup);

@@ -1,0 +1,212 @@
+"""-m gpu: BASELINE.json configs 3, 4 and 5 (restated per SURVEY.md §8d) on ONE MI355X, through the C ABI.
+
+At these sizes the oracle cannot rerun the whole pipeline in seconds, so every configuration is judged by
+  * size-independent properties: Y = diag + 2 * upper, P = sum_k c_k^2, columns ascending, pattern and numshared symmetric, mirrored
+    seeds, idempotence of a second (cold) call, every sampled seed a genuine shared k-mer (the reference's test.py:57-65);
+  * ORACLE EQUALITY ON SAMPLED ROWS: for a few hundred random rows the entries of A they touch (the rows themselves and every column they
+    meet, whole) are fetched from the device, handed to the oracle as triples, and the oracle's rows of B must equal the GPU's bit for
+    bit — pattern, numshared and both seeds.  (The sub-matrix contains every column of a sampled row completely, so the oracle's fold
+    over it is that row's fold over all of A.)
+  config 3  200 100 reads x 10 kb, 66.7 Mb genome, 30x, 15 % error, U = 8: as written, whole, on one GPU
+  config 4  C. elegans-HiFi-like, 0.5 % error, U = 4: half the genome (50 Mb, 133 k reads of 15 kb, 2.0 G k-mer instances) — the whole set
+            has 4 G instances, past one context's 32-bit instance index: the configuration names 8 GPUs for it
+  config 5  20 repeat families, 1 % error, U = 35: 1/25 of the genome (80 k reads, 10.8 G products): the dense / spill stress at a size one GPU holds
+"""
+import os
+
+import numpy as np
+import pytest
+
+import elba_amd
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+CONFIGS = {
+    "config3-200k-long-reads": dict(seed=2, genome=66_700_000, depth=30.0, avg=10000.0, sd=1500.0, err=0.15, min_len=1000, k=17, L=2, U=8, rep=(0, 0.0, 0), nsample=200),
+    "config4-celegans-hifi-half": dict(seed=3, genome=50_000_000, depth=40.0, avg=15000.0, sd=2000.0, err=0.005, min_len=1000, k=17, L=2, U=4, rep=(0, 0.0, 0), nsample=300),
+    "config5-dense-repeats-25th": dict(seed=4, genome=20_000_000, depth=40.0, avg=10000.0, sd=1000.0, err=0.01, min_len=1000, k=17, L=2, U=35, rep=(20, 0.05, 5000), nsample=60),
+}
+
+
+class _DevArray:
+    """A device pointer of the library as something torch can wrap without a copy (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def _device_tensors(e):
+    import torch
+    v = e.device_view()
+    t = lambda ptr, n, ts: torch.as_tensor(_DevArray(ptr, n, ts), device="cuda")      # noqa: E731
+    return dict(M=v["M"], N=v["N"], Z=v["Z"],
+                rowptr=t(v["a_rowptr"], v["M"] + 1, "<i4"), csr=t(v["a_csr"], v["Z"], "<i8"),
+                colptr=t(v["a_colptr"], v["N"] + 1, "<i4"), csc=t(v["a_csc"], v["Z"], "<i8"))
+
+
+def _sampled_rows_equal_oracle(e, B, k, lo, up, nsample, seed=0, d=None):
+    """See the module docstring.  Returns the number of rows compared."""
+    import torch
+    d = d or _device_tensors(e)
+    dev = d["csr"].device
+    M = d["M"]
+    rp = d["rowptr"].to(torch.int64) & 0xFFFFFFFF
+    nnz = (rp[1:] - rp[:-1]).cpu().numpy()
+    rng = np.random.default_rng(seed)
+    cand = np.nonzero(nnz > 0)[0]
+    rows = np.sort(rng.choice(cand, size=min(nsample, len(cand)), replace=False))
+    rpc = rp.cpu().numpy()
+    idx = np.concatenate([np.arange(rpc[r], rpc[r + 1]) for r in rows])
+    ent = d["csr"][torch.from_numpy(idx).to(dev)]
+    kids = torch.unique((ent >> 32) & 0xFFFFFFFF)                       # every column a sampled row meets, ascending
+    cp = d["colptr"].to(torch.int64) & 0xFFFFFFFF
+    c0, c1 = cp[kids], cp[kids + 1]
+    lens_ = (c1 - c0)
+    tot = int(lens_.sum().item())
+    starts = torch.cumsum(lens_, 0) - lens_
+    which = torch.repeat_interleave(torch.arange(len(kids), device=dev), lens_)
+    within = torch.arange(tot, device=dev) - starts[which]
+    cent = d["csc"][c0[which] + within]
+    t_rows = ((cent >> 32) & 0xFFFFFFFF).cpu().numpy().astype(np.int64)
+    t_pos = (cent & 0xFFFFFFFF).cpu().numpy().astype(np.uint32)
+    t_cols = which.cpu().numpy().astype(np.int64)                     # relabelled 0..len(kids)-1 in ascending k-mer id: the canonical order is kept
+    o = po.Oracle(k, lo, up)
+    o.set_triples(M, len(kids), t_rows, t_cols, t_pos)
+    o.spgemm(8)
+    oB = o.B()
+    for r in rows:
+        g0, g1 = int(B["rowptr"][r]), int(B["rowptr"][r + 1])
+        w0, w1 = int(oB["rowptr"][r]), int(oB["rowptr"][r + 1])
+        assert g1 - g0 == w1 - w0, (r, g1 - g0, w1 - w0)
+        assert (B["col"][g0:g1] == oB["col"][w0:w1].astype(np.int64)).all(), r
+        assert (B["val"][g0:g1] == oB["val"][w0:w1]).all(), r
+    return len(rows)
+
+
+def _properties(e, B, st, ks, packed, off, lens, k, upper):
+    assert st["nnz"] == B["Y"] == int(B["rowptr"][-1])
+    assert st["nnz"] == st["nnz_diag"] + 2 * st["nnz_upper"]
+    h = e.kmer_histogram(upper + 2)
+    assert int((h * np.arange(len(h)) ** 2).sum()) == st["products"] and int(h.sum()) == ks["reliable"] and int((h * np.arange(len(h))).sum()) == ks["entries"]
+    M = B["M"]
+    rows = np.repeat(np.arange(M, dtype=np.int64), np.diff(B["rowptr"])); cols = B["col"]
+    assert ((np.diff(cols) > 0) | (np.diff(rows) > 0)).all()                      # columns strictly ascending in every row
+    key = rows * M + cols; tkey = cols * M + rows
+    order = np.argsort(tkey, kind="stable")
+    assert (tkey[order] == key).all()                                             # pattern symmetric
+    v = B["val"]; vt = v[order]
+    assert (v["numshared"] == vt["numshared"]).all() and (v["numshared"] >= 2).all()
+    assert (v["q0"] == vt["t0"]).all() and (v["t0"] == vt["q0"]).all() and (v["q1"] == vt["t1"]).all() and (v["t1"] == vt["q1"]).all()      # B(j,i) = B(i,j) with positions exchanged
+    L = po.lib(); rng = np.random.default_rng(0); bad = 0
+    for x in rng.choice(B["Y"], size=min(5000, B["Y"]), replace=False):
+        i, j, s = int(rows[x]), int(cols[x]), v[x]
+        for (q, t) in ((s["q0"], s["t0"]), (s["q1"], s["t1"])):
+            bad += not L.orc_seed_is_valid(packed.ctypes.data + int(off[i]), int(lens[i]), packed.ctypes.data + int(off[j]), int(lens[j]), int(q), int(t), k)
+    assert bad == 0
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_baseline_config_properties_and_sampled_rows(name):
+    w = CONFIGS[name]
+    packed, off, lens, info = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg"], w["sd"], error_rate=w["err"], min_len=w["min_len"],
+                                                   repeat_families=w["rep"][0], repeat_fraction=w["rep"][1], repeat_len=w["rep"][2])
+    k = w["k"]
+    e = elba_amd.Engine(k, w["L"], w["U"])
+    e.set_reads(packed, off, lens)
+    ks = e.count_kmers(); ms = e.create_kmer_matrix()
+    assert ks["instances"] == int(np.maximum(lens.astype(np.int64) - k + 1, 0).sum()) and ms["nnz"] == ks["entries"] and ms["ncols"] == ks["reliable"]
+    st = e.create_seed_matrix()
+    B = e.export_csr()
+    _properties(e, B, st, ks, packed, off, lens, k, w["U"])
+    assert _sampled_rows_equal_oracle(e, B, k, w["L"], w["U"], w["nsample"]) >= min(50, w["nsample"])
+    # a second call, cold (nothing remembered), returns the identical matrix
+    e.set_option("overlap_cold_calls", 1)
+    st2 = e.create_seed_matrix()
+    assert all(st2[f] == st[f] for f in ("nnz", "products", "nnz_before_prune", "nnz_diag", "nnz_upper", "max_numshared"))
+    B2 = e.export_csr(0, min(B["M"], 20000))
+    n2 = int(B2["rowptr"][-1])
+    assert (B2["rowptr"] == B["rowptr"][:len(B2["rowptr"])]).all() and (B2["col"] == B["col"][:n2]).all() and (B2["val"] == B["val"][:n2]).all()
+    e.close()
+
+
+def test_distributed_driver_over_rccl_world_of_one():
+    """elba_amd/distributed.py end to end on the real collectives (torch.distributed backend "nccl" = RCCL), world size 1 on this box:
+    both all-to-alls, the all-gather, the panel, the row window — B must equal the oracle's."""
+    import torch
+    import torch.distributed as dist
+    from elba_amd.distributed import DistributedOverlap
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        reads = elba_amd.synth_reads(33, 400000, 15, 4000, 900, error_rate=0.10, min_len=200)
+        packed, off, lens, _ = reads
+        d = DistributedOverlap(17, 2, 8, device=0, rank=0, world=1, dist=dist)
+        d.set_reads(packed, off, lens, 0, np.array([0, len(lens)], dtype=np.int64))
+        ks, ms = d.build_kmer_matrix()
+        st = d.create_seed_matrix()
+        B = d.export_csr()
+        o = po.Oracle(17, 2, 8); o.count_and_build(packed, off, lens); o.spgemm(4)
+        oB = o.B()
+        assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+        assert (ks["reliable"], ks["entries"], st["products"], st["nnz_before_prune"]) == (o.stat("N"), o.stat("Z"), o.stat("P"), o.stat("Yraw"))
+        al = d.align_seeds()
+        rows, cols, ov, _ = o.align_upper(packed, off, lens)
+        g = d.export_overlaps()
+        assert al["nalignments"] == len(rows) and (g["rows"] == rows).all() and (g["cols"] == cols).all()
+        assert all((g["vals"][f] == ov[f]).all() for f in ov.dtype.names if f != "pad")
+        d.be.e.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_text_formats_from_gpu_output(tmp_path):
+    """SURVEY.md §8f-4 driven by the GPU's own B and overlaps: B.mtx in the reference's SharedSeeds notation, the dump its test.py reads
+    (and test.py's seed check on it), PAF lines — each compared with the same writer fed from the oracle."""
+    import util
+    from elba_amd import formats as fm
+    seqs = util.read_fasta(os.path.join(util.GOLDEN, "small_err.fa"))
+    packed, off, lens = po.pack_reads(seqs)
+    e = elba_amd.Engine(17, 2, 8)
+    e.set_reads(packed, off, lens); e.count_kmers(); e.create_kmer_matrix(); e.create_seed_matrix()
+    o = po.Oracle(17, 2, 8); o.count_and_build(packed, off, lens); o.spgemm(1)
+    B, oB = e.export_csr(), o.B()
+    M = B["M"]
+    pg, pw = str(tmp_path / "g.mtx"), str(tmp_path / "o.mtx")
+    fm.write_seed_matrix_mm(pg, e.export_dcsc(0, M, 0, M), M)
+    fm.write_seed_matrix_mm(pw, o.export_dcsc(0, M, 0, M), M)
+    assert open(pg).read() == open(pw).read() and os.path.getsize(pg) > 1000
+    dg, dw = str(tmp_path / "g.dump"), str(tmp_path / "o.dump")
+    fm.write_testpy_dump(dg, dict(M=M, Y=B["Y"], rowptr=B["rowptr"], col=B["col"], val=B["val"]))
+    fm.write_testpy_dump(dw, oB)
+    assert open(dg).read() == open(dw).read()
+    correct, incorrect = fm.check_seed_dump(dg, [s.upper() for s in seqs], 17)
+    assert incorrect == 0 and correct > 0
+    e.align_seeds()
+    g = e.export_overlaps()
+    rows, cols, ov, _ = o.align_upper(packed, off, lens)
+    names = ["read%d" % r for r in range(M)]
+    fg, fw = str(tmp_path / "g.paf"), str(tmp_path / "o.paf")
+    fm.write_paf(fg, g, names, lens)
+    fm.write_paf(fw, dict(n=len(rows), rows=rows, cols=cols, vals=ov), names, lens)
+    assert open(fg).read() == open(fw).read() and g["n"] > 0
+    e.close()
+
+
+def test_new_reads_invalidate_results_built_from_the_old_ones():
+    """after elba_set_reads the stages downstream of the OLD reads must refuse to run (ELBA_ERR_STATE = 5), not answer from stale state."""
+    a = elba_amd.synth_reads(71, 60000, 10, 3000, 300, error_rate=0.05)
+    b = elba_amd.synth_reads(72, 60000, 10, 3000, 300, error_rate=0.05)
+    e = elba_amd.Engine(17, 2, 8)
+    e.set_reads(*a[:3]); e.count_kmers(); e.create_kmer_matrix(); e.create_seed_matrix(); e.align_seeds()
+    n = min(len(a[2]), len(b[2]))
+    e.set_reads(b[0], b[1][:n], b[2][:n])
+    for call in (e.align_seeds, e.export_csr, e.create_seed_matrix, e.create_kmer_matrix, e.export_overlaps):
+        with pytest.raises(elba_amd.ElbaError) as ei:
+            call()
+        assert ei.value.status == 5, call
+    e.count_kmers(); e.create_kmer_matrix(); st = e.create_seed_matrix()
+    o = po.Oracle(17, 2, 8); o.count_and_build(b[0], b[1][:n], b[2][:n]); o.spgemm(2)
+    assert st["nnz"] == o.stat("Y")
+    e.close()

@@ -128,18 +128,18 @@ def test_wide_rows_use_block_and_global_sorts():
 
 def test_optimistic_tables_escalate_and_spill_to_hbm():
     """Collision/overflow stress: rows whose distinct-partner count defeats every optimistic LDS table.  A is handed over as
-    triples: `dense` columns each hold ALL reads (every row then has M partners, M > 3/4 of the largest LDS table -> HBM spill),
+    triples: `dense` columns each hold ALL reads (every row then has M partners, M / 2 > 3/4 of the largest LDS table -> HBM spill),
     a band of medium columns makes rows that overflow the small tiers only (escalation), singletons make rows that fit at once."""
-    M, rng = 7000, np.random.default_rng(12)
+    M, rng = 14000, np.random.default_rng(12)
     rows, cols, vals = [], [], []
     ncol = 0
-    for c in range(2):                                   # two dense columns over rows 0..3499 -> 3500 partners, numshared 2
-        r = np.arange(3500); rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1
-    for c in range(2):                                   # rows 0..6999 in two more dense columns -> 7000 partners
-        r = np.arange(M); rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1
+    for c in range(2):                                   # two dense columns over rows 0..6999 -> 7000 partners, numshared 2
+        r = np.arange(7000); rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1
+    for c in range(2):                                   # rows 0..13999 in two more dense columns -> 14000 partners: a row accumulates half of
+        r = np.arange(M); rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1      # them (the other half is mirrored), still more than 3/4 of the largest LDS table
     for b in range(0, 3000, 500):                        # medium: groups of 500 rows sharing 2 columns
         for c in range(2):
-            r = 3500 + np.arange(b, b + 500) % 3500; rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1
+            r = 7000 + np.arange(b, b + 500) % 3500; rows.append(r); cols.append(np.full(len(r), ncol)); vals.append(rng.integers(0, 5000, len(r))); ncol += 1
     rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals).astype(np.uint32)
     e = elba_amd.Engine(17, 2, 8)
     e.set_kmer_matrix(M, ncol, rows, cols, vals)
@@ -338,10 +338,11 @@ def test_words_one_or_two_bits_short_mark_rare_positions_for_lookup():
     e.close()
 
 
-@pytest.mark.parametrize("knob", ["ELBA_NO_SYMMETRY", "ELBA_NO_PERMUTE", "ELBA_KMER_HASH", "ELBA_KMER_PAIRS", "ELBA_MIR32"])
+@pytest.mark.parametrize("knob", ["ELBA_NO_SYMMETRY", "ELBA_NO_ELL", "ELBA_NO_PAY", "ELBA_PLAN", "ELBA_KMER_HASH", "ELBA_KMER_PAIRS", "ELBA_MIR32"])
 def test_alternative_paths_kept_for_ab_runs_give_the_same_matrices(knob, monkeypatch):
-    """Build-time / run-time alternatives kept behind environment knobs (both triangles described instead of one + mirror, canonical column
-    order, hash-based counting, (value, payload) pairs through the k-mer sort, 32-byte mirror records): A and B must not change."""
+    """Build-time / run-time alternatives kept behind environment knobs (both triangles accumulated instead of one + mirror, plain CSC columns
+    instead of the padded ones, 32-bit accumulators + seed look-ups, the round-1 descriptor plan + kernel, hash-based counting, (value,
+    payload) pairs through the k-mer sort, 32-byte mirror records): A and B must not change."""
     monkeypatch.setenv(knob, "1")
     packed, off, lens, info = elba_amd.synth_reads(61, 200000, 16, 3000, 900, error_rate=0.10, min_len=200)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
@@ -351,4 +352,8 @@ def test_alternative_paths_kept_for_ab_runs_give_the_same_matrices(knob, monkeyp
     gu.assert_stats_equal(st, o)
     st2 = e.create_seed_matrix()                       # steady-state call on the same matrix
     gu.assert_B_equal(e.export_csr(), o.B())
+    e.set_option("overlap_cold_calls", 1)              # and a cold one
+    st3 = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st3, o)
     e.close()
