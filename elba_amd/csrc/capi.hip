@@ -455,6 +455,21 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
     });
 }
 
+int elba_dist_value_histogram(elba_ctx *ctx, uint64_t *hist, int64_t nbins)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_dist_value_histogram(c, hist, nbins); });
+}
+
+int elba_dist_set_owner_ranges(elba_ctx *ctx, int nranks, const uint32_t *upper_bins)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_dist_set_owner_ranges(c, nranks, upper_bins); });
+}
+
+int elba_dist_set_kmer_id_base(elba_ctx *ctx, int64_t base, int64_t nall)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_dist_set_kmer_id_base(c, base, nall); });
+}
+
 int elba_dist_count_owners(elba_ctx *ctx, int nranks, uint64_t *counts)
 {
     return guarded(ctx, [&](Ctx &c) {
@@ -526,7 +541,7 @@ int elba_dist_set_panel(elba_ctx *ctx, const void *d_records, int64_t nrecords, 
         t.start(c.stream);
         stage_dist_set_panel(c, d_records, nrecords, nreads_total, nkmers_total, row_lo, row_hi);
         t.stop(c.stream);
-        if (stats) { stats->nrows = c.M; stats->ncols = c.N; stats->nnz = c.Z; stats->max_row_nnz = c.max_row_nnz; stats->ms_total = t.ms(); }
+        if (stats) { stats->nrows = c.M; stats->ncols = c.N_global >= 0 ? c.N_global : c.N; stats->nnz = c.Z; stats->max_row_nnz = c.max_row_nnz; stats->ms_total = t.ms(); }
     });
 }
 

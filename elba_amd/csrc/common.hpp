@@ -174,6 +174,8 @@ struct Ctx {
     bool dist_owner = false;
     DevBuf dist_gid;          // u32[N_local] global k-mer id of each local column
     int64_t dist_nall = -1;
+    std::vector<uint32_t> owner_upper;   // value-range owners: rank r owns the value bins [owner_upper[r-1], owner_upper[r]) (kmer.hip)
+    int64_t N_global = -1;    // a panel context: k-mers of the whole run (its own columns are renumbered locally)
 
     // B (device)
     bool have_B = false;
@@ -230,6 +232,9 @@ void stage_dist_set_all_reads(Ctx &c, const void *d_packed, int64_t packed_bytes
 void stage_set_overlaps(Ctx &c, int64_t nreads, const int64_t *rows, const int64_t *cols, const elba_overlap_t *vals, int64_t n);   // tr.hip
 void stage_transitive_reduction(Ctx &c, double bad_read_cutoff, int fuzz);   // tr.hip
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host);                                   // kmer.hip
+void stage_dist_value_histogram(Ctx &c, uint64_t *hist_host, int64_t nbins);
+void stage_dist_set_owner_ranges(Ctx &c, int nranks, const uint32_t *upper_bins);
+void stage_dist_set_kmer_id_base(Ctx &c, int64_t base, int64_t nall);
 void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);
 void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec);
 void stage_dist_copy_reliable_kmers(Ctx &c, void *d_dst);       // N k-mers of 1 + (k > 32) + (k > 64) words each, interleaved

@@ -654,9 +654,20 @@ namespace {
 
 constexpr int MAX_RANKS = 64;
 
-__device__ __forceinline__ uint32_t owner_of(uint64_t km, uint32_t nranks)
+// Owner of a k-mer = the rank whose VALUE RANGE holds it.  The value space is cut into 2^OWNER_BITS equal bins by the leading bits of
+// the packed canonical k-mer (first word); the driver picks, from the all-reduced bin histogram of the instances, OWNER boundaries
+// upper[r] (exclusive, in bins) that balance the instances, and rank r owns the bins [upper[r-1], upper[r]).  Ranges instead of the
+// reference's hash (GetKmerOwner, src/KmerOps.cpp:352-359) because the owners' reliable k-mers are then disjoint ascending value
+// ranges: the global k-mer id — rank of the value, SURVEY.md §8c-2 — is the owner's local index plus an exclusive scan of the owners'
+// counts (the reference's Exscan, src/KmerOps.cpp:371-375), and no rank ever needs the other ranks' k-mers.
+constexpr int OWNER_BITS = 12;
+struct OwnerMap { uint32_t nranks; uint32_t upper[MAX_RANKS]; };
+__device__ __forceinline__ uint32_t owner_of(uint64_t first_word, const OwnerMap &om)
 {
-    return (uint32_t)__umul64hi(mix64(km), (uint64_t)nranks);      // uniform over ranks (cf. GetKmerOwner, src/KmerOps.cpp:352-359)
+    const uint32_t bin = (uint32_t)(first_word >> (64 - OWNER_BITS));
+    uint32_t lo = 0, hi = om.nranks - 1u;             // first r with bin < upper[r]
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (bin < om.upper[mid]) hi = mid; else lo = mid + 1u; }
+    return lo;
 }
 
 // W = 64-bit words per k-mer (1 for k <= 31, 2 up to 63, 3 up to 95).  A record of exchange #1 is W + 1 words: the k-mer, most
@@ -671,40 +682,45 @@ __device__ __forceinline__ void for_each_kmer_words(const EnumParams &e, F &&f)
         f(g, r, p, a, b, c2);
     });
 }
+// histogram of the instances over the 2^OWNER_BITS value bins (what the driver all-reduces to place the owners' boundaries)
 template <int W>
-__device__ __forceinline__ uint32_t owner_of_words(uint64_t a, uint64_t b, uint64_t c2, uint32_t nranks)
+__global__ __launch_bounds__(EN_THREADS) void k_dist_value_hist(EnumParams e, unsigned long long *hist)
 {
-    if constexpr (W == 1) return owner_of(a, nranks);
-    else return (uint32_t)__umul64hi(mix64(a ^ mix64(b ^ mix64(c2))), (uint64_t)nranks);
+    __shared__ uint32_t h[1 << OWNER_BITS];
+    for (uint32_t b = threadIdx.x; b < (1u << OWNER_BITS); b += EN_THREADS) h[b] = 0;
+    __syncthreads();
+    for_each_kmer_words<W>(e, [&](uint64_t, uint32_t, uint32_t, uint64_t a, uint64_t, uint64_t) { atomicAdd(&h[(uint32_t)(a >> (64 - OWNER_BITS))], 1u); });
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < (1u << OWNER_BITS); b += EN_THREADS) if (h[b]) atomicAdd(&hist[b], (unsigned long long)h[b]);
 }
 
 template <int W>
-__global__ __launch_bounds__(EN_THREADS) void k_dist_count_owners(EnumParams e, uint32_t nranks, unsigned long long *counts)
+__global__ __launch_bounds__(EN_THREADS) void k_dist_count_owners(EnumParams e, OwnerMap om, unsigned long long *counts)
 {
     __shared__ uint32_t hist[MAX_RANKS];
     if (threadIdx.x < MAX_RANKS) hist[threadIdx.x] = 0;
     __syncthreads();
-    for_each_kmer_words<W>(e, [&](uint64_t, uint32_t, uint32_t, uint64_t a, uint64_t b, uint64_t c2) { atomicAdd(&hist[owner_of_words<W>(a, b, c2, nranks)], 1u); });
+    for_each_kmer_words<W>(e, [&](uint64_t, uint32_t, uint32_t, uint64_t a, uint64_t, uint64_t) { atomicAdd(&hist[owner_of(a, om)], 1u); });
     __syncthreads();
-    if (threadIdx.x < nranks && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    if (threadIdx.x < om.nranks && hist[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
 }
 
 template <int W>
-__global__ __launch_bounds__(EN_THREADS) void k_dist_fill_send(EnumParams e, uint32_t nranks, uint64_t first_global_id, uint64_t *send, unsigned long long *cursors)
+__global__ __launch_bounds__(EN_THREADS) void k_dist_fill_send(EnumParams e, OwnerMap om, uint64_t first_global_id, uint64_t *send, unsigned long long *cursors)
 {
     __shared__ uint32_t hist[MAX_RANKS];
     __shared__ unsigned long long base[MAX_RANKS];
     if (threadIdx.x < MAX_RANKS) hist[threadIdx.x] = 0;
     __syncthreads();
-    for_each_kmer_words<W>(e, [&](uint64_t, uint32_t, uint32_t, uint64_t a, uint64_t b, uint64_t c2) { atomicAdd(&hist[owner_of_words<W>(a, b, c2, nranks)], 1u); });
+    for_each_kmer_words<W>(e, [&](uint64_t, uint32_t, uint32_t, uint64_t a, uint64_t, uint64_t) { atomicAdd(&hist[owner_of(a, om)], 1u); });
     __syncthreads();
-    if (threadIdx.x < nranks) {
+    if (threadIdx.x < om.nranks) {
         base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]) : 0ull;
         hist[threadIdx.x] = 0;
     }
     __syncthreads();
     for_each_kmer_words<W>(e, [&](uint64_t, uint32_t r, uint32_t p, uint64_t a, uint64_t b, uint64_t c2) {
-        const uint32_t o = owner_of_words<W>(a, b, c2, nranks);
+        const uint32_t o = owner_of(a, om);
         const unsigned long long at = base[o] + atomicAdd(&hist[o], 1u);
         uint64_t *rec = send + (size_t)(W + 1) * at;
         rec[0] = a;
@@ -793,6 +809,19 @@ __global__ void k_panel(const uint32_t *colptr, const uint64_t *csc, const uint3
     }
 }
 
+__global__ void k_iota_u32(uint32_t *out, uint64_t n, uint32_t base)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = base + (uint32_t)i;
+}
+
+// sorted global column ids -> local ones: id of a record = number of distinct ids before it (flag: 1 where a new id starts; excl: its exclusive scan)
+__global__ void k_local_ids(const uint32_t *flag, const uint32_t *excl, uint64_t n, uint64_t *lid)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) lid[i] = (uint64_t)(excl[i] + flag[i] - 1u);
+}
+
 __global__ void k_deinterleave(const uint64_t *rec, uint64_t n, uint64_t *k0, uint64_t *v0)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -828,11 +857,19 @@ static const uint64_t *sort_words_permutation(Ctx &c, int words, const uint64_t 
     return ia;
 }
 
-void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host)
+// the owners' boundaries set by elba_dist_set_owner_ranges (one rank: everything is rank 0's; otherwise they must have been set for this world size)
+static OwnerMap owner_map(Ctx &c, int nranks)
 {
-    ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "dist_count_owners: no reads");
-    ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS, ELBA_ERR_INVALID_ARG, "dist_count_owners: 1..64 ranks");
-    hipStream_t s = c.stream;
+    OwnerMap om{};
+    om.nranks = (uint32_t)nranks;
+    if (nranks == 1) { om.upper[0] = 1u << OWNER_BITS; return om; }
+    ELBA_REQUIRE((int)c.owner_upper.size() == nranks, ELBA_ERR_STATE, "owner value ranges not set for this many ranks (call elba_dist_set_owner_ranges)");
+    for (int r = 0; r < nranks; ++r) om.upper[r] = c.owner_upper[(size_t)r];
+    return om;
+}
+
+static uint64_t upload_instance_offsets(Ctx &c)
+{
     const int k = c.cfg.k;
     const int64_t M = c.nreads;
     std::vector<uint64_t> off((size_t)M + 1);
@@ -842,16 +879,68 @@ void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host)
     ELBA_REQUIRE(I < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "more than 2^32 k-mer instances on one GPU");
     c.I = (int64_t)I;
     c.inst_off.reserve((size_t)(M + 1) * 8);
-    ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s));
+    ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, c.stream));
+    ELBA_HIP(hipStreamSynchronize(c.stream));      // `off` goes out of scope
+    return I;
+}
+
+void stage_dist_value_histogram(Ctx &c, uint64_t *hist_host, int64_t nbins)
+{
+    ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "dist_value_histogram: no reads");
+    ELBA_REQUIRE(nbins == (1 << OWNER_BITS) && hist_host, ELBA_ERR_INVALID_ARG, "dist_value_histogram: the histogram has 4096 bins");
+    hipStream_t s = c.stream;
+    const uint64_t I = upload_instance_offsets(c);
+    c.ws_scan.reserve((size_t)nbins * 8);
+    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, (size_t)nbins * 8, s));
+    EnumParams e = make_enum(c);
+    const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+    if (I > 0) {
+        const int W = kmer_words(c.cfg.k);
+        if (W == 1) hipLaunchKernelGGL(k_dist_value_hist<1>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.ws_scan.as<unsigned long long>());
+        else if (W == 2) hipLaunchKernelGGL(k_dist_value_hist<2>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.ws_scan.as<unsigned long long>());
+        else hipLaunchKernelGGL(k_dist_value_hist<3>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.ws_scan.as<unsigned long long>());
+    }
+    ELBA_HIP(hipMemcpyAsync(hist_host, c.ws_scan.p, (size_t)nbins * 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
+void stage_dist_set_owner_ranges(Ctx &c, int nranks, const uint32_t *upper_bins)
+{
+    ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS && upper_bins, ELBA_ERR_INVALID_ARG, "dist_set_owner_ranges: 1..64 ranks");
+    uint32_t prev = 0;
+    for (int r = 0; r < nranks; ++r) { ELBA_REQUIRE(upper_bins[r] >= prev && upper_bins[r] <= (1u << OWNER_BITS), ELBA_ERR_INVALID_ARG, "dist_set_owner_ranges: boundaries must ascend within [0, 4096]"); prev = upper_bins[r]; }
+    ELBA_REQUIRE(upper_bins[nranks - 1] == (1u << OWNER_BITS), ELBA_ERR_INVALID_ARG, "dist_set_owner_ranges: the last rank's range must end at 4096");
+    c.owner_upper.assign(upper_bins, upper_bins + nranks);
+}
+
+// global k-mer ids of this owner's columns: base + local index (the owners hold ascending value ranges)
+void stage_dist_set_kmer_id_base(Ctx &c, int64_t base, int64_t nall)
+{
+    ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_set_kmer_id_base: call dist_count_records first");
+    ELBA_REQUIRE(base >= 0 && base + c.N <= nall && nall < 0xFFFFFFF0ll, ELBA_ERR_INVALID_ARG, "dist_set_kmer_id_base: bad id range");
+    c.dist_gid.reserve((size_t)(c.N + 1) * 4);
+    if (c.N > 0) hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, c.stream, c.dist_gid.as<uint32_t>(), (uint64_t)c.N, (uint32_t)base);
+    ELBA_HIP(hipStreamSynchronize(c.stream));
+    c.dist_nall = nall;
+}
+
+void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host)
+{
+    ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "dist_count_owners: no reads");
+    ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS, ELBA_ERR_INVALID_ARG, "dist_count_owners: 1..64 ranks");
+    hipStream_t s = c.stream;
+    const int k = c.cfg.k;
+    const uint64_t I = upload_instance_offsets(c);
     c.ws_scan.reserve(MAX_RANKS * 8);
     ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, MAX_RANKS * 8, s));
     EnumParams e = make_enum(c);
     const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+    const OwnerMap om = owner_map(c, nranks);
     if (I > 0) {
         const int W = kmer_words(k);
-        if (W == 1) hipLaunchKernelGGL(k_dist_count_owners<1>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, c.ws_scan.as<unsigned long long>());
-        else if (W == 2) hipLaunchKernelGGL(k_dist_count_owners<2>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, c.ws_scan.as<unsigned long long>());
-        else hipLaunchKernelGGL(k_dist_count_owners<3>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, c.ws_scan.as<unsigned long long>());
+        if (W == 1) hipLaunchKernelGGL(k_dist_count_owners<1>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, c.ws_scan.as<unsigned long long>());
+        else if (W == 2) hipLaunchKernelGGL(k_dist_count_owners<2>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, c.ws_scan.as<unsigned long long>());
+        else hipLaunchKernelGGL(k_dist_count_owners<3>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, c.ws_scan.as<unsigned long long>());
     }
     ELBA_HIP(hipMemcpyAsync(counts_host, c.ws_scan.p, (size_t)nranks * 8, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
@@ -870,9 +959,10 @@ void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offs
         const int W = kmer_words(c.cfg.k);
         uint64_t *snd = static_cast<uint64_t *>(d_send);
         unsigned long long *cur = c.ws_scan.as<unsigned long long>();
-        if (W == 1) hipLaunchKernelGGL(k_dist_fill_send<1>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, (uint64_t)c.first_global_id, snd, cur);
-        else if (W == 2) hipLaunchKernelGGL(k_dist_fill_send<2>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, (uint64_t)c.first_global_id, snd, cur);
-        else hipLaunchKernelGGL(k_dist_fill_send<3>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, (uint32_t)nranks, (uint64_t)c.first_global_id, snd, cur);
+        const OwnerMap om = owner_map(c, nranks);
+        if (W == 1) hipLaunchKernelGGL(k_dist_fill_send<1>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, (uint64_t)c.first_global_id, snd, cur);
+        else if (W == 2) hipLaunchKernelGGL(k_dist_fill_send<2>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, (uint64_t)c.first_global_id, snd, cur);
+        else hipLaunchKernelGGL(k_dist_fill_send<3>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, (uint64_t)c.first_global_id, snd, cur);
     }
     ELBA_HIP(hipStreamSynchronize(s));
 }
@@ -1025,9 +1115,25 @@ void stage_dist_set_panel(Ctx &c, const void *d_rec, int64_t nrec, int64_t M_tot
         ELBA_HIP(hipMemcpyAsync(c.ws_e.p, where ? c.ws_c.p : c.ws_a.p, (size_t)nrec * 8, hipMemcpyDeviceToDevice, s));
         ELBA_HIP(hipMemcpyAsync(c.ws_f.p, where ? c.ws_d.p : c.ws_b.p, (size_t)nrec * 8, hipMemcpyDeviceToDevice, s));
     }
+    // Columns are renumbered by their rank among the columns PRESENT in this panel (ascending global id: the canonical order of a row's
+    // entries, hence every seed, is unchanged): the padded column store then holds the panel's columns only, not all N_total of the run.
+    int64_t N_local = 0;
+    if (nrec > 0) {
+        DevBuf flagbuf, exclbuf;
+        flagbuf.reserve((size_t)(nrec + 2) * 4); exclbuf.reserve((size_t)(nrec + 2) * 4);
+        const unsigned nb = (unsigned)((nrec + 1 + 255) / 256);
+        hipLaunchKernelGGL(k_run_flags, dim3(nb), dim3(256), 0, s, c.ws_e.as<uint64_t>(), (const uint64_t *)nullptr, (const uint64_t *)nullptr, (uint64_t)nrec, flagbuf.as<uint32_t>(), 0);
+        exclusive_scan_u32(s, flagbuf.as<uint32_t>(), exclbuf.as<uint32_t>(), nrec + 1, c.ws_scan);
+        uint32_t nd = 0;
+        ELBA_HIP(hipMemcpyAsync(&nd, exclbuf.as<uint32_t>() + nrec, 4, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_local_ids, dim3(nb), dim3(256), 0, s, flagbuf.as<uint32_t>(), exclbuf.as<uint32_t>(), (uint64_t)nrec, c.ws_e.as<uint64_t>());
+        ELBA_HIP(hipStreamSynchronize(s));
+        N_local = (int64_t)nd;
+    }
     c.A_has_kmers = false;
     c.dist_owner = false;
-    finish_matrix_from_sorted_csc(c, M_total, N_total, nrec, c.ws_e.as<uint64_t>(), 0, c.ws_f.as<uint64_t>(), row_lo, row_hi);
+    finish_matrix_from_sorted_csc(c, M_total, N_local, nrec, c.ws_e.as<uint64_t>(), 0, c.ws_f.as<uint64_t>(), row_lo, row_hi);
+    c.N_global = N_total;
 }
 
 }  // namespace elba

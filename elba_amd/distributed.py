@@ -5,7 +5,7 @@ issues the collectives through torch.distributed — backend "nccl" (= RCCL over
 test-defined backend stands in for the HIP library.  Collectives used, all over the whole world:
 
     all_to_all_single   #1  k-mer instances (16 B records) to the k-mer's owner rank          (src/KmerOps.cpp:117-151, :244-274)
-    all_gather              each owner's reliable k-mers -> global k-mer ids by value rank      (src/KmerOps.cpp:371-375 Exscan)
+    all_reduce + all_gather value histogram (4096 bins) -> owners by value range; owners' counts -> global k-mer ids (src/KmerOps.cpp:371-375 Exscan)
     all_to_all_single   #2  every column, whole, to each rank that owns one of its reads        (SpParMat ctor / Transpose redistribution)
     all_reduce              scalars only (counts, timings)
 
@@ -36,6 +36,23 @@ def partition_by_bases(lens, nranks):
     return np.array(bounds, dtype=np.int64)
 
 
+OWNER_BINS = 4096          # ELBA_OWNER_BINS of include/elba_amd.h
+
+
+def owner_ranges_from_histogram(hist, nranks):
+    """Boundaries (exclusive upper bins) of `nranks` contiguous value ranges holding about the same number of k-mer instances each:
+    rank r ends at the first bin where the running count reaches (r + 1) / nranks of the total.  Deterministic in `hist`."""
+    cum = np.cumsum(np.asarray(hist, dtype=np.int64))
+    total = int(cum[-1]) if len(cum) else 0
+    upper = np.empty(nranks, dtype=np.int64)
+    for r in range(nranks):
+        target = -(-total * (r + 1) // nranks)
+        upper[r] = int(np.searchsorted(cum, target, side="left")) + 1 if total else (len(cum) * (r + 1)) // nranks
+    upper = np.minimum(np.maximum.accumulate(upper), len(cum))
+    upper[-1] = len(cum)
+    return upper.astype(np.uint32)
+
+
 def kmer_words(k):
     """64-bit words per k-mer (NLONGS, include/Kmer.hpp:95-97): a record of exchange #1 is that many words + one of (read << 32 | pos)."""
     return 3 if k > 64 else (2 if k > 32 else 1)
@@ -52,6 +69,9 @@ class HipBackend:
         self.L, self.h = self.e.L, self.e.h
         L = self.L
         vp, i64, i32 = C.c_void_p, C.c_int64, C.c_int
+        L.elba_dist_value_histogram.restype = i32; L.elba_dist_value_histogram.argtypes = [vp, vp, i64]
+        L.elba_dist_set_owner_ranges.restype = i32; L.elba_dist_set_owner_ranges.argtypes = [vp, i32, vp]
+        L.elba_dist_set_kmer_id_base.restype = i32; L.elba_dist_set_kmer_id_base.argtypes = [vp, i64, i64]
         L.elba_dist_count_owners.restype = i32; L.elba_dist_count_owners.argtypes = [vp, i32, vp]
         L.elba_dist_fill_send.restype = i32; L.elba_dist_fill_send.argtypes = [vp, i32, vp, vp]
         L.elba_dist_count_records.restype = i32; L.elba_dist_count_records.argtypes = [vp, vp, i64, C.POINTER(capi.KmerStats)]
@@ -97,6 +117,19 @@ class HipBackend:
 
     def export_read_flags(self, nreads):
         return self.e.export_read_flags(nreads)
+
+    def value_histogram(self):
+        out = np.zeros(OWNER_BINS, dtype=np.uint64)
+        self.e._check(self.L.elba_dist_value_histogram(self.h, out.ctypes.data, OWNER_BINS))
+        return out.astype(np.int64)
+
+    def set_owner_ranges(self, upper_bins):
+        u = np.ascontiguousarray(upper_bins, dtype=np.uint32)
+        self.e._check(self.L.elba_dist_set_owner_ranges(self.h, len(u), u.ctypes.data))
+
+    def set_kmer_id_base(self, base, nall):
+        self.e._check(self.L.elba_dist_set_kmer_id_base(self.h, int(base), int(nall)))
+        self._rec = None
 
     def count_owners(self, nranks):
         out = np.zeros(nranks, dtype=np.uint64)
@@ -244,6 +277,12 @@ class DistributedOverlap:
     def build_kmer_matrix(self):
         """get_kmer_count_map_keys/values + create_kmer_matrix + Transpose, distributed.  Returns (kmer stats, matrix stats)."""
         W = self.world
+        torch = self.be.torch
+        # owners: value ranges balanced on the all-reduced histogram of the instances (4096 bins: 32 KB per rank)
+        if W > 1:
+            h = torch.from_numpy(self.be.value_histogram()).to(self.be.dev)
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM)
+            self.be.set_owner_ranges(owner_ranges_from_histogram(h.cpu().numpy(), W))
         # exchange #1: instances to owners
         sc = self.be.count_owners(W)
         rc = self._exchange_counts(sc)
@@ -253,12 +292,15 @@ class DistributedOverlap:
         recv = self._all_to_all_records(send, sc, rc)
         del send
         ks = self.be.count_records(recv)
-        # global k-mer ids
+        # global k-mer ids: the owners hold ascending value ranges, so id = exclusive scan of the owners' counts + local index
+        # (src/KmerOps.cpp:371-375: MPI_Exscan of the local map sizes) — one all-gather of W integers, no k-mer leaves its owner
         nloc = int(ks["reliable"])
-        allk, ns = self._all_gather_words(self.be.reliable_kmers(nloc), nloc * kw)
-        self.be.set_global_kmers(allk)
-        n_total = int(sum(ns)) // kw
-        del recv, allk
+        cnt = [torch.zeros(1, dtype=torch.int64, device=self.be.dev) for _ in range(W)]
+        self.dist.all_gather(cnt, torch.tensor([nloc], dtype=torch.int64, device=self.be.dev))
+        ns = [int(x.item()) for x in cnt]
+        n_total = int(sum(ns))
+        self.be.set_kmer_id_base(int(sum(ns[:self.rank])), n_total)
+        del recv
         # exchange #2: column panels to the owners of the reads
         pc = self.be.panel_counts(W, self.bounds)
         prc = self._exchange_counts(pc)

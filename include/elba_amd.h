@@ -296,7 +296,18 @@ int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
  * 2 up to 63, 3 up to 95; NLONGS of include/Kmer.hpp:95-97), most significant word first.
  * Exchange #2 records: two words, (global k-mer id, global read id << 32 | pos), a column's entries contiguous and ordered by (read,pos). */
 #define ELBA_MAX_RANKS 64
-/* instances of this rank's reads per owner rank (owner = hash of the k-mer, cf. GetKmerOwner src/KmerOps.cpp:352-359) */
+/* Owners by VALUE RANGE.  The value space of the packed canonical k-mers is cut into ELBA_OWNER_BINS equal bins (leading 12 bits of the
+ * first word); elba_dist_value_histogram counts this rank's instances per bin; the driver all-reduces the histograms, picks boundaries
+ * that balance the instances and announces them with elba_dist_set_owner_ranges: rank r owns the bins [upper_bins[r-1], upper_bins[r]),
+ * upper_bins[nranks-1] == ELBA_OWNER_BINS.  (The reference hashes, GetKmerOwner src/KmerOps.cpp:352-359; with ranges the owners'
+ * reliable k-mers are disjoint ascending runs, so the global k-mer id — rank of the value — is the owner's local index plus the
+ * exclusive scan of the owners' counts, the reference's MPI_Exscan of src/KmerOps.cpp:371-375: elba_dist_set_kmer_id_base.) */
+#define ELBA_OWNER_BINS 4096
+int  elba_dist_value_histogram(elba_ctx *ctx, uint64_t *hist, int64_t nbins);
+int  elba_dist_set_owner_ranges(elba_ctx *ctx, int nranks, const uint32_t *upper_bins);
+/* after elba_dist_count_records: global id of this owner's i-th reliable k-mer = base + i; nall = reliable k-mers of all owners */
+int  elba_dist_set_kmer_id_base(elba_ctx *ctx, int64_t base, int64_t nall);
+/* instances of this rank's reads per owner rank */
 int  elba_dist_count_owners(elba_ctx *ctx, int nranks, uint64_t *counts);
 /* write this rank's records into d_send (device, 8 (W + 1) bytes per record) grouped by owner; offsets[r] = first record index of owner r */
 int  elba_dist_fill_send(elba_ctx *ctx, int nranks, void *d_send, const uint64_t *offsets);
@@ -308,13 +319,14 @@ int  elba_dist_get_reliable_kmers(elba_ctx *ctx, const void **d_kmers, int64_t *
 /* copy them into a caller-owned device buffer of at least W * capacity words, the W words of a k-mer adjacent (e.g. a torch tensor that
  * takes part in the all-gather); capacity counts k-mers */
 int  elba_dist_copy_reliable_kmers(elba_ctx *ctx, void *d_dst, int64_t capacity);
-/* all owners' reliable k-mers concatenated (any order; nall k-mers of W adjacent words): global k-mer id = rank of the packed value */
+/* alternative to elba_dist_set_kmer_id_base for owners that are not value ranges: all owners' reliable k-mers concatenated (any order;
+ * nall k-mers of W adjacent words): global k-mer id = rank of the packed value */
 int  elba_dist_set_global_kmers(elba_ctx *ctx, const void *d_all_kmers, int64_t nall);
 /* column panels: read_bounds[r] = first global read id of rank r (read_bounds[nranks] = total reads).  counts[r] = records this
  * owner sends to rank r: every column, whole, for every rank that owns at least one of its reads */
 int  elba_dist_panel_counts(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, uint64_t *counts);
 int  elba_dist_panel_fill(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, void *d_send, const uint64_t *offsets);
-/* receiver side: the panel of every column touching rows [row_lo,row_hi) -> CSC (global k-mer ids) + CSR; elba_create_seed_matrix
+/* receiver side: the panel of every column touching rows [row_lo,row_hi) -> columns (renumbered by rank among the columns present) + CSR; elba_create_seed_matrix
  * then computes exactly those rows of B (global column ids); elba_export_csr(row_lo,row_hi) / elba_export_dcsc read them */
 int  elba_dist_set_panel(elba_ctx *ctx, const void *d_records, int64_t nrecords, int64_t nreads_total, int64_t nkmers_total,
                          int64_t row_lo, int64_t row_hi, elba_matrix_stats *stats);

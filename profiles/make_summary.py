@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 output directories (gpurun_out/...) into the small, committed summaries under profiles/.
-usage: make_summary.py TAG KERNEL_TRACE_DIR FETCH_PMC_DIR WRITE_PMC_DIR [SQ_PMC_DIR] [STEPS_IN_TRACE]"""
+usage: make_summary.py TAG KERNEL_TRACE_DIR FETCH_PMC_DIR WRITE_PMC_DIR [SQ_PMC_DIR|-] [REQ_PMC_DIR|-] [WORKLOAD]"""
 import collections
 import csv
 import glob
@@ -17,15 +17,20 @@ def short(n):
     return re.sub(r"elba::\(anonymous namespace\)::", "", n).split("(")[0].replace("void ", "")
 
 
+NUMERIC = ("k_spgemm_direct", "k_spgemm_rows")      # the numeric kernels (plan-free; round-1 descriptor kernel)
+
+
 def main():
     tag, ktd, fd, wd = sys.argv[1:5]
     sqd = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
+    rqd = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] != "-" else None
+    workload = sys.argv[7] if len(sys.argv) > 7 else "200k-long-reads"
     ks = glob.glob(os.path.join(ktd, "*", "*kernel_stats.csv"))[0]
     shutil.copy(ks, os.path.join(HERE, "%s_kernel_stats.csv" % tag))
     rows = list(csv.DictReader(open(ks)))
     stats = {short(r["Name"]): dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, total_ms=float(r["TotalDurationNs"]) / 1e6) for r in rows}
     calls = max(v["calls"] for k, v in stats.items() if k.startswith("k_finalize_wave"))      # one finalize launch per step
-    spg = {k: v for k, v in stats.items() if k.startswith("k_spgemm_rows")}
+    spg = {k: v for k, v in stats.items() if k.startswith(NUMERIC)}
     numeric_us_per_step = sum(v["total_ms"] for v in spg.values()) * 1e3 / calls
 
     def pmc(d):
@@ -42,12 +47,12 @@ def main():
     wa, wn = pmc(wd)
     steps_f = fn[("k_finalize_wave", "FETCH_SIZE")]
     steps_w = wn[("k_finalize_wave", "WRITE_SIZE")]
-    fetch_kb = sum(v["FETCH_SIZE"] for k, v in fa.items() if k.startswith("k_spgemm_rows")) / steps_f
-    write_kb = sum(v["WRITE_SIZE"] for k, v in wa.items() if k.startswith("k_spgemm_rows")) / steps_w
-    hit = sum(v.get("TCC_HIT_sum", 0) for k, v in wa.items() if k.startswith("k_spgemm_rows")) / steps_w
-    miss = sum(v.get("TCC_MISS_sum", 0) for k, v in wa.items() if k.startswith("k_spgemm_rows")) / steps_w
+    fetch_kb = sum(v["FETCH_SIZE"] for k, v in fa.items() if k.startswith(NUMERIC)) / steps_f
+    write_kb = sum(v["WRITE_SIZE"] for k, v in wa.items() if k.startswith(NUMERIC)) / steps_w
+    hit = sum(v.get("TCC_HIT_sum", 0) for k, v in wa.items() if k.startswith(NUMERIC)) / steps_w
+    miss = sum(v.get("TCC_MISS_sum", 0) for k, v in wa.items() if k.startswith(NUMERIC)) / steps_w
     out = {
-        "tag": tag, "workload": "ecsample30x-like", "n_gpus": 1,
+        "tag": tag, "workload": workload, "n_gpus": 1,
         "steps_in_trace": calls,
         "numeric_kernels_us_per_step": round(numeric_us_per_step, 2),
         "kernel_avg_us": {k: round(v["avg_us"], 2) for k, v in sorted(stats.items()) if k.startswith("k_")},
@@ -63,8 +68,18 @@ def main():
     if sqd:
         sa, sn = pmc(sqd)
         steps_s = sn[("k_finalize_wave", "SQ_WAVES")] or 1
-        out["SQ_per_step"] = {c: round(sum(v.get(c, 0) for k, v in sa.items() if k.startswith("k_spgemm_rows")) / steps_s)
+        out["SQ_per_step"] = {c: round(sum(v.get(c, 0) for k, v in sa.items() if k.startswith(NUMERIC)) / steps_s)
                               for c in ("SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS")}
+    if rqd:
+        ra, rn = pmc(rqd)
+        steps_r = rn[("k_finalize_wave", "TCC_REQ_sum")] or 1
+        req = {c: round(sum(v.get(c, 0) for k, v in ra.items() if k.startswith(NUMERIC)) / steps_r) for c in ("TCC_REQ_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_TCC_ATOMIC_WITH_RET_REQ_sum")}
+        out["L2_requests_per_step"] = req
+        json.dump({"workload": workload, "n_gpus": 1, "source": "%s_summary.json (rocprofv3 --pmc TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum, numeric kernels of one step)" % tag,
+                   "tcc_requests_per_step": req["TCC_REQ_sum"], "read_requests_per_step": req["TCP_TCC_READ_REQ_sum"], "write_requests_per_step": req["TCP_TCC_WRITE_REQ_sum"],
+                   "returning_atomics_per_step": req["TCP_TCC_ATOMIC_WITH_RET_REQ_sum"],
+                   "ceiling_source": "profiles/microbench/gather64.hip (profiles/r02_gather64_microbench.txt): random 64-byte lines read by 4 lanes x 16 B, 350 MB and 12.9 GB arrays",
+                   "ceiling_G_requests_per_s": [46.5, 52.5]}, open(os.path.join(HERE, "requests.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(HERE, "%s_summary.json" % tag), "w"), indent=1)
     json.dump({"workload": out["workload"], "n_gpus": 1, "source": "%s_summary.json" % tag,
                "hbm_bytes_per_step_dominant_kernel": out["hbm_bytes_per_step_dominant_kernel"]}, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)

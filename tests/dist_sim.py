@@ -153,11 +153,20 @@ class NumpyBackend:
         self.km = np.concatenate(kms) if kms else np.zeros(0, np.uint64)
         self.rp = ((np.concatenate(rds) << np.uint64(32)) | np.concatenate(pss)) if kms else np.zeros(0, np.uint64)
 
+    def _first_word(self):
+        return self.km[:, 0] if self.km.ndim == 2 else self.km
+
+    def value_histogram(self):
+        return np.bincount((self._first_word() >> np.uint64(52)).astype(np.int64), minlength=4096).astype(np.int64)
+
+    def set_owner_ranges(self, upper_bins):
+        self.range_upper = np.asarray(upper_bins, dtype=np.int64)
+
     def _owner(self, km, W):
-        if km.ndim == 2:                                   # every word takes part in the owner hash
-            h = _mix64(km[:, 2]) if km.shape[1] == 3 else _mix64(np.zeros(len(km), dtype=np.uint64))
-            km = km[:, 0] ^ _mix64(km[:, 1] ^ h)
-        return ((_mix64(km) >> np.uint64(32)) * np.uint64(W) >> np.uint64(32)).astype(np.int64)
+        if W == 1:
+            return np.zeros(len(km), dtype=np.int64)
+        first = km[:, 0] if km.ndim == 2 else km
+        return np.searchsorted(self.range_upper, (first >> np.uint64(52)).astype(np.int64), side="right").astype(np.int64)
 
     def count_owners(self, W):
         self.own = self._owner(self.km, W)
@@ -197,6 +206,9 @@ class NumpyBackend:
 
     def reliable_kmers(self, n):
         return torch.from_numpy(np.ascontiguousarray(self.rel).reshape(-1).view(np.int64).copy())
+
+    def set_kmer_id_base(self, base, nall):
+        self.gid = (np.uint64(base) + np.arange(len(self.rel), dtype=np.uint64)).astype(np.uint64)
 
     def set_global_kmers(self, allk):
         if self.kw > 1:
