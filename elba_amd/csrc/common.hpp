@@ -136,6 +136,7 @@ struct Ctx {
     DevBuf rel_kmers_lo;  // u64[N] their second word when k > 32
     DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
+    DevBuf kid_of_entry;  // u64[Z] k-mer id of every entry of a_csc (written with the columns; what the CSR build sorts by read)
     elba_kmer_stats kstats{};
 
     // A (device)

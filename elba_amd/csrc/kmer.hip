@@ -273,10 +273,10 @@ __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit(EnumParams e, uint64_t
 // One word per instance: canonical value (right-aligned) << ib | instance index.  The index is the payload: (read, pos) follow from it
 // through the instance offsets, and they are needed for the few instances that survive the count filter only — the sort moves
 // 8 bytes per instance instead of 16.
-__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit_packed(EnumParams e, int ib, uint64_t *words)
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit_packed(EnumParams e, int pb, int drop, uint64_t *words)
 {
     const int k2 = 2 * e.k;
-    for_each_instance(e, [&](uint64_t g, uint32_t, uint32_t, uint64_t km) { words[g] = ((km >> (64 - k2)) << ib) | g; });
+    for_each_instance(e, [&](uint64_t g, uint32_t, uint32_t, uint64_t km) { words[g] = ((km >> (64 - k2)) << pb) | (g >> drop); });
 }
 
 __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit2(EnumParams e, uint64_t *khi, uint64_t *klo, uint64_t *vals, uint64_t *idx)
@@ -312,50 +312,144 @@ __global__ void k_run_flags(const uint64_t *keys, const uint64_t *keys_lo, const
     flag[g] = (g == 0 || g == I || (keys[g] >> ib) != (keys[g - 1] >> ib) || (keys_lo && keys_lo[g] != keys_lo[g - 1]) || (keys_lo2 && keys_lo2[g] != keys_lo2[g - 1])) ? 1u : 0u;
 }
 
-// headpos[run] = first instance of the run; headpos[nruns] = I
-__global__ void k_run_heads(const uint32_t *flag, const uint32_t *runid, uint64_t I, uint32_t *headpos)
+// ---- runs -> reliable columns, fused -------------------------------------------------------------------------------------------------
+// After the sort equal k-mers are adjacent.  A lane owns RUN_ITEMS consecutive items; an item whose left neighbour holds another k-mer
+// heads a run, and the head measures its run by walking right (at most UPPER + 1 steps: longer runs are unreliable whatever their
+// length) — no flag array, no run ids, no head positions, no scans over the instance stream.  Two passes with the same walk:
+//   k_runs<false>  per block: reliable runs, their entries, all runs (= distinct k-mers)            -> three u32 per 2048 items
+//   (exclusive scans of those per-block triples: a few MB)
+//   k_runs<true>   block-local scan on top of the block's offsets: every reliable head knows its k-mer id (rank of the value) and its
+//                  column pointer and writes the k-mer, the count, the pointer, and for each entry its payload and its k-mer id.
+constexpr int RUN_THREADS = 256, RUN_ITEMS = 8, RUN_TILE = RUN_THREADS * RUN_ITEMS;
+struct RunParams {
+    const uint64_t *keys, *lo, *lo2, *vals;      // sorted words (value above `ib` payload bits) or (k-mer words, payload) arrays
+    uint64_t I;
+    int ib, k2;
+    uint32_t lower, upper;
+};
+__device__ __forceinline__ bool same_kmer(const RunParams &p, uint64_t a, uint64_t b)
 {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > I) return;
-    if (flag[g]) headpos[runid[g]] = (uint32_t)g;
+    return (p.keys[a] >> p.ib) == (p.keys[b] >> p.ib) && (!p.lo || p.lo[a] == p.lo[b]) && (!p.lo2 || p.lo2[a] == p.lo2[b]);
+}
+template <bool EMIT>
+__global__ __launch_bounds__(RUN_THREADS) void k_runs(RunParams p, uint32_t *blk_rel, uint32_t *blk_ent, uint32_t *blk_heads, const uint32_t *off_rel, const uint32_t *off_ent,
+                                                      uint64_t *rel_kmers, uint64_t *rel_kmers_lo, uint64_t *rel_kmers_lo2, uint32_t *rel_counts, uint32_t *colptr,
+                                                      uint64_t *payload, uint64_t *kid_of_entry)
+{
+    // Item q of the tile (q = i * 256 + tid: consecutive lanes, consecutive items — coalesced) is compared with its left neighbour once;
+    // the answers live in LDS as one bit per item (+ 64 items of halo behind the tile), and a head reads its run length off the bits:
+    // the number of consecutive "same as my left neighbour" bits that follow it.  Only a run that outgrows the halo walks global memory.
+    constexpr int NW = RUN_THREADS / 64, SLICES = RUN_ITEMS * NW;
+    __shared__ uint64_t eqmask[SLICES + 2];
+    __shared__ uint32_t srel[SLICES + 1], sent[SLICES + 1], shead[NW];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t lt = (1ull << lane) - 1;
+    const uint64_t T0 = (uint64_t)blockIdx.x * RUN_TILE;
+#pragma unroll
+    for (int i = 0; i < RUN_ITEMS; ++i) {
+        const uint64_t g = T0 + (uint64_t)i * RUN_THREADS + tid;
+        const uint64_t bal = __ballot(g < p.I && g > 0 && same_kmer(p, g, g - 1));
+        if (lane == 0) eqmask[i * NW + w] = bal;
+    }
+    if (w == 0) {
+        const uint64_t g = T0 + RUN_TILE + lane;
+        const uint64_t bal = __ballot(g < p.I && same_kmer(p, g, g - 1));
+        if (lane == 0) { eqmask[SLICES] = bal; eqmask[SLICES + 1] = 0; }
+    }
+    __syncthreads();
+    uint32_t len[RUN_ITEMS];                      // 0: not a head; else run length, capped at upper + 1
+    uint32_t nheads = 0;
+#pragma unroll
+    for (int i = 0; i < RUN_ITEMS; ++i) {
+        const uint32_t q = (uint32_t)i * RUN_THREADS + tid;
+        const uint64_t g = T0 + q;
+        len[i] = 0;
+        const bool head = g < p.I && !((eqmask[q >> 6] >> (q & 63u)) & 1ull);
+        uint32_t l = 0;
+        if (head) {
+            const uint32_t q1 = q + 1u, s1 = q1 & 63u;
+            const uint64_t w0 = eqmask[q1 >> 6], w1 = eqmask[(q1 >> 6) + 1];
+            const uint64_t win = s1 ? (w0 >> s1) | (w1 << (64u - s1)) : w0;      // the 64 bits that follow the head
+            const uint32_t ones = win == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~win);
+            l = 1u + ones;
+            // the window ends at the halo's end: a run that fills it (or the part of it the bits cover) goes on in global memory
+            const uint32_t covered = (uint32_t)RUN_TILE + 64u - q1;               // bits behind the head that the masks hold
+            if (ones >= (covered < 64u ? covered : 64u)) {
+                l = 1u + (covered < 64u ? covered : 64u);
+                while (l <= p.upper && g + l < p.I && same_kmer(p, g, g + l)) ++l;
+            }
+            if (l > p.upper + 1u) l = p.upper + 1u;
+            len[i] = l;
+        }
+        const bool rel = head && l >= p.lower && l <= p.upper;
+        const uint64_t bh = __ballot(head), br = __ballot(rel);
+        uint32_t e = rel ? l : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) e += __shfl_xor(e, d, 64);
+        nheads += (uint32_t)__popcll(bh);
+        if (lane == 0) { srel[i * NW + w] = (uint32_t)__popcll(br); sent[i * NW + w] = e; }
+    }
+    if (lane == 0) shead[w] = nheads;
+    __syncthreads();
+    if (!EMIT) {
+        if (tid == 0) {
+            uint32_t x = 0, y = 0, z = 0;
+            for (int k2 = 0; k2 < SLICES; ++k2) { x += srel[k2]; y += sent[k2]; }
+            for (int k2 = 0; k2 < NW; ++k2) z += shead[k2];
+            blk_rel[blockIdx.x] = x; blk_ent[blockIdx.x] = y; blk_heads[blockIdx.x] = z;
+        }
+        return;
+    }
+    if (tid == 0) {                               // exclusive prefixes over the slices, in item order (slice = i * NW + wave)
+        uint32_t x = off_rel[blockIdx.x], y = off_ent[blockIdx.x];
+        for (int k2 = 0; k2 < SLICES; ++k2) { const uint32_t a = srel[k2], b2 = sent[k2]; srel[k2] = x; sent[k2] = y; x += a; y += b2; }
+    }
+    __syncthreads();
+    const uint64_t pmask = p.ib ? (1ull << p.ib) - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < RUN_ITEMS; ++i) {
+        const uint32_t l = len[i];
+        const bool rel = l != 0 && l >= p.lower && l <= p.upper;
+        const uint64_t br = __ballot(rel);
+        // entries of the reliable heads before this lane in its slice: wave-wide exclusive scan
+        uint32_t inc = rel ? l : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+        if (rel) {
+            const uint64_t g = T0 + (uint64_t)i * RUN_THREADS + tid;
+            const uint32_t kid = srel[i * NW + w] + (uint32_t)__popcll(br & lt), at = sent[i * NW + w] + inc - l;
+            rel_kmers[kid] = p.ib ? (p.keys[g] >> p.ib) << (64 - p.k2) : p.keys[g];
+            if (p.lo) rel_kmers_lo[kid] = p.lo[g];
+            if (p.lo2) rel_kmers_lo2[kid] = p.lo2[g];
+            rel_counts[kid] = l; colptr[kid] = at;
+            for (uint32_t t = 0; t < l; ++t) { payload[at + t] = p.ib ? (p.keys[g + t] & pmask) : p.vals[g + t]; kid_of_entry[at + t] = kid; }
+        }
+    }
 }
 
-// per run: its length is the k-mer's exact count; reliable runs are flagged and their lengths kept (both arrays get a closing zero)
-__global__ void k_run_select(const uint32_t *headpos, uint64_t nruns, uint32_t lower, uint32_t upper, uint32_t *relflag, uint32_t *relcnt)
-{
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u > nruns) return;
-    uint32_t f = 0, c = 0;
-    if (u < nruns) { c = headpos[u + 1] - headpos[u]; f = (c >= lower && c <= upper) ? 1u : 0u; }
-    relflag[u] = f; relcnt[u] = f ? c : 0u;
-}
-
-// reliable run -> column kid: k-mer value, count, column pointer, entries (already in (read, pos) order: the sort is stable)
-// Packed words (ib > 0, vals == nullptr): the value is shifted back to its left-aligned form and an entry's (read, pos) is looked up
-// from its instance index in the instance offsets (binary search over the reads; the offsets stay in L2).
-__global__ void k_emit_columns(const uint64_t *keys, const uint64_t *keys_lo, const uint64_t *keys_lo2, const uint64_t *vals, const uint32_t *headpos, const uint32_t *relflag, const uint32_t *kidx, const uint32_t *cptr,
-                               uint64_t nruns, uint64_t *rel_kmers, uint64_t *rel_kmers_lo, uint64_t *rel_kmers_lo2, uint32_t *rel_counts, uint32_t *colptr, uint64_t *csc,
-                               int ib, int k2, const uint64_t *inst_off, uint32_t nreads)
-{
-    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (u >= nruns || !relflag[u]) return;
-    const uint32_t kid = kidx[u], h = headpos[u], c = headpos[u + 1] - h, at = cptr[u];
-    rel_kmers[kid] = ib ? (keys[h] >> ib) << (64 - k2) : keys[h]; rel_counts[kid] = c; colptr[kid] = at;
-    if (keys_lo) rel_kmers_lo[kid] = keys_lo[h];
-    if (keys_lo2) rel_kmers_lo2[kid] = keys_lo2[h];
-    if (!ib) { for (uint32_t t = 0; t < c; ++t) csc[at + t] = vals[h + t]; return; }
-    for (uint32_t t = 0; t < c; ++t) csc[at + t] = keys[h + t] & ((1ull << ib) - 1);      // instance index: turned into (read, pos) by k_instance_entries
-}
-
-// instance index -> read << 32 | pos, one lane per entry (binary search over the reads' instance offsets, which stay in L2)
-__global__ void k_instance_entries(uint64_t *csc, uint64_t Z, const uint64_t *inst_off, uint32_t nreads)
+// Payload -> read << 32 | pos, one lane per entry.  The payload is the instance index with its `drop` lowest bits cut off (they did not
+// fit beside the value in one 64-bit word, see stage_count_kmers): the entry is the dup-th instance among the 2^drop candidates whose
+// canonical k-mer is the column's, dup = entries of the same column with the same payload before this one (equal payloads are adjacent:
+// the sort is stable).  The instance's read is found by binary search in the reads' instance offsets (they stay in L2).
+__global__ void k_instance_entries(const uint64_t *payload, const uint64_t *kid_of_entry, const uint64_t *rel_kmers, uint64_t *csc, uint64_t Z, EnumParams e, int drop)
 {
     const uint64_t z = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= Z) return;
-    const uint64_t g = csc[z];
-    uint32_t lo = 0, hi = nreads;                                   // last read with inst_off[read] <= g
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (inst_off[mid] <= g) lo = mid; else hi = mid; }
-    csc[z] = ((uint64_t)lo << 32) | (uint32_t)(g - inst_off[lo]);
+    const uint64_t h = payload[z];
+    uint64_t g = h << drop;
+    uint32_t lo = 0, hi = e.nreads;                                   // last read with inst_off[read] <= g
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (e.inst_off[mid] <= g) lo = mid; else hi = mid; }
+    if (drop) {
+        const uint64_t kid = kid_of_entry[z], want = rel_kmers[kid];
+        uint32_t dup = 0;
+        for (uint64_t y = z; y > 0 && kid_of_entry[y - 1] == kid && payload[y - 1] == h; --y) ++dup;
+        const uint64_t gend = g + (1ull << drop) < e.I ? g + (1ull << drop) : e.I;
+        for (; g < gend; ++g) {
+            while (g >= e.inst_off[lo + 1]) ++lo;
+            if (canonical_at(e, lo, (uint32_t)(g - e.inst_off[lo])) == want) { if (dup == 0) break; --dup; }
+        }
+    }
+    csc[z] = ((uint64_t)lo << 32) | (uint32_t)(g - e.inst_off[lo]);
 }
 
 __global__ void k_column_ids(const uint32_t *colptr, uint64_t *kid_keys, uint64_t N)
@@ -382,38 +476,34 @@ EnumParams make_enum(Ctx &c)
 
 }  // namespace
 
-// Sorted (k-mer, value) pairs -> runs -> reliable columns: rel_kmers / rel_counts / a_colptr / a_csc of the context (see the file header).
-// spare_k / spare_v: the sort's other buffer pair (2 (I + 2) u32 each), free once the sort is done.  Needs c.ws_e (I + 2 u32) and c.ws_f (I + 2 u64).
-static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals, uint64_t *spare_k, uint64_t *spare_v, uint64_t I,
-                            uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out, const uint64_t *skeys_lo = nullptr, const uint64_t *skeys_lo2 = nullptr, int ib = 0)
+// Sorted words / (k-mer, value) pairs -> runs -> reliable columns: rel_kmers / rel_counts / a_colptr / a_csc / kid_of_entry of the context
+// (see the comment above k_runs).  ib: payload bits below the value in `skeys` (0: the payload is svals); drop: low bits of the instance
+// index that were cut off the payload.  scratch: at least (Z + 8) u64 (entry payloads), allocated by the caller's pool.
+static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals, uint64_t I, uint64_t &nruns_out, uint64_t &N_out, uint64_t &Z_out,
+                            const uint64_t *skeys_lo = nullptr, const uint64_t *skeys_lo2 = nullptr, int ib = 0, int drop = 0)
 {
     hipStream_t s = c.stream;
-    uint32_t *flag = c.ws_e.as<uint32_t>();
-    uint32_t *runid = reinterpret_cast<uint32_t *>(spare_k);                        // [I + 1]
-    uint32_t *headpos = c.ws_f.as<uint32_t>();                                      // [nruns + 1] <= I + 1
-    const unsigned nbI = (unsigned)((I + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_run_flags, dim3(nbI), dim3(256), 0, s, skeys, skeys_lo, skeys_lo2, I, flag, ib);
-    exclusive_scan_u32(s, flag, runid, (int64_t)I + 1, c.ws_scan);
-    uint32_t nruns32 = 0;
-    ELBA_HIP(hipMemcpyAsync(&nruns32, runid + I, 4, hipMemcpyDeviceToHost, s));      // runs before the closing flag = distinct k-mers
-    hipLaunchKernelGGL(k_run_heads, dim3(nbI), dim3(256), 0, s, flag, runid, I, headpos);
-    ELBA_HIP(hipStreamSynchronize(s));
-    const uint64_t nruns = I > 0 ? nruns32 : 0;
-    uint32_t *relflag = reinterpret_cast<uint32_t *>(spare_v), *relcnt = relflag + (nruns + 2);      // [nruns + 1] each (spare_v holds 2 (I + 2) u32)
-    uint32_t *kidx = flag, *cptr = runid;                                                         // flags and run ids are dead now
-    const unsigned nbR = (unsigned)((nruns + 1 + 255) / 256);
-    hipLaunchKernelGGL(k_run_select, dim3(nbR), dim3(256), 0, s, headpos, nruns, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, relflag, relcnt);
-    exclusive_scan_u32(s, relflag, kidx, (int64_t)nruns + 1, c.ws_scan);
-    uint32_t Nn = 0;
-    ELBA_HIP(hipMemcpyAsync(&Nn, kidx + nruns, 4, hipMemcpyDeviceToHost, s));
-    ELBA_HIP(hipStreamSynchronize(s));
-    const uint64_t N = Nn;
-    // Z <= I < 2^32 always holds (every entry is an instance), so the 32-bit scan cannot wrap
-    exclusive_scan_u32(s, relcnt, cptr, (int64_t)nruns + 1, c.ws_scan);
-    uint32_t Zz = 0;
-    ELBA_HIP(hipMemcpyAsync(&Zz, cptr + nruns, 4, hipMemcpyDeviceToHost, s));
-    ELBA_HIP(hipStreamSynchronize(s));
-    const uint64_t Z = Zz;
+    const uint32_t nblocks = (uint32_t)((I + RUN_TILE - 1) / RUN_TILE);
+    c.ws_e.reserve((size_t)(nblocks + 2) * 4 * 5);
+    uint32_t *blk_rel = c.ws_e.as<uint32_t>(), *blk_ent = blk_rel + (nblocks + 2), *blk_heads = blk_ent + (nblocks + 2), *off_rel = blk_heads + (nblocks + 2), *off_ent = off_rel + (nblocks + 2);
+    RunParams p{};
+    p.keys = skeys; p.lo = skeys_lo; p.lo2 = skeys_lo2; p.vals = svals; p.I = I; p.ib = ib; p.k2 = 2 * c.cfg.k;
+    p.lower = (uint32_t)c.cfg.lower; p.upper = (uint32_t)c.cfg.upper;
+    uint64_t nruns = 0, N = 0, Z = 0;
+    if (I > 0) {
+        ELBA_HIP(hipMemsetAsync(blk_rel, 0, (size_t)(nblocks + 2) * 4 * 3, s));
+        hipLaunchKernelGGL((k_runs<false>), dim3(nblocks), dim3(RUN_THREADS), 0, s, p, blk_rel, blk_ent, blk_heads, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                           (uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr);
+        exclusive_scan_u32(s, blk_rel, off_rel, (int64_t)nblocks + 1, c.ws_scan);
+        exclusive_scan_u32(s, blk_ent, off_ent, (int64_t)nblocks + 1, c.ws_scan);      // Z <= I < 2^32: the 32-bit scan cannot wrap
+        exclusive_scan_u32(s, blk_heads, blk_heads, (int64_t)nblocks + 1, c.ws_scan);
+        uint32_t h3[3] = {0, 0, 0};
+        ELBA_HIP(hipMemcpyAsync(&h3[0], off_rel + nblocks, 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipMemcpyAsync(&h3[1], off_ent + nblocks, 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipMemcpyAsync(&h3[2], blk_heads + nblocks, 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        N = h3[0]; Z = h3[1]; nruns = h3[2];
+    }
     ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
     c.rel_kmers.reserve((size_t)(N + 1) * 8);
     if (skeys_lo) c.rel_kmers_lo.reserve((size_t)(N + 1) * 8);
@@ -421,12 +511,20 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
     c.rel_counts.reserve((size_t)(N + 2) * 4);
     c.a_colptr.reserve((size_t)(N + 2) * 4);
     c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
-    if (nruns > 0)
-        hipLaunchKernelGGL(k_emit_columns, dim3((unsigned)((nruns + 255) / 256)), dim3(256), 0, s, skeys, skeys_lo, skeys_lo2, svals, headpos, relflag, kidx, cptr, nruns,
-                           c.rel_kmers.as<uint64_t>(), skeys_lo ? c.rel_kmers_lo.as<uint64_t>() : (uint64_t *)nullptr,
-                           skeys_lo2 ? c.rel_kmers_lo2.as<uint64_t>() : (uint64_t *)nullptr, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(),
-                           ib, 2 * c.cfg.k, c.inst_off.as<uint64_t>(), (uint32_t)c.nreads);
-    if (ib && Z > 0) hipLaunchKernelGGL(k_instance_entries, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, c.a_csc.as<uint64_t>(), Z, c.inst_off.as<uint64_t>(), (uint32_t)c.nreads);
+    c.kid_of_entry.reserve((size_t)(Z + 8) * 8);
+    // entry payloads: written straight into a_csc when they are final (pairs: read << 32 | pos), else into scratch and converted
+    DevBuf &scratch = c.ws_f;
+    if (ib) scratch.reserve((size_t)(Z + 8) * 8);
+    uint64_t *pay = ib ? scratch.as<uint64_t>() : c.a_csc.as<uint64_t>();
+    if (I > 0)
+        hipLaunchKernelGGL((k_runs<true>), dim3(nblocks), dim3(RUN_THREADS), 0, s, p, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, off_rel, off_ent,
+                           c.rel_kmers.as<uint64_t>(), skeys_lo ? c.rel_kmers_lo.as<uint64_t>() : (uint64_t *)nullptr, skeys_lo2 ? c.rel_kmers_lo2.as<uint64_t>() : (uint64_t *)nullptr,
+                           c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), pay, c.kid_of_entry.as<uint64_t>());
+    if (ib && Z > 0) {
+        EnumParams e = make_enum(c);
+        hipLaunchKernelGGL(k_instance_entries, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, pay, c.kid_of_entry.as<uint64_t>(), c.rel_kmers.as<uint64_t>(), c.a_csc.as<uint64_t>(), Z, e, drop);
+    }
+    const uint32_t Zz = (uint32_t)Z;
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
     ELBA_HIP(hipStreamSynchronize(s));
     nruns_out = nruns; N_out = N; Z_out = Z;
@@ -489,7 +587,7 @@ void stage_count_kmers(Ctx &c)
         c.t_a.stop(s);
         c.t_b.start(s);
         uint64_t nruns = 0, N = 0, Z = 0;
-        runs_to_columns(c, shi, sval, t0.as<uint64_t>(), t1.as<uint64_t>(), I, nruns, N, Z, slo, slo2);
+        runs_to_columns(c, shi, sval, I, nruns, N, Z, slo, slo2);
         c.t_b.stop(s);
         c.t_total.stop(s);
         ELBA_HIP(hipStreamSynchronize(s));
@@ -509,25 +607,29 @@ void stage_count_kmers(Ctx &c)
         c.t_a.start(s);
         EnumParams e = make_enum(c);
         const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
-        // the instance index fits beside the value in one word (2k + bits(I) <= 64: k = 17 up to 2^30 instances): sort bare words
+        // One 64-bit word per instance: value << pb | (instance index >> drop).  The index is the payload — (read, pos) follow from it
+        // through the instance offsets, for the entries that survive the count filter only — and when value and index are a few bits too
+        // many for one word (k = 17 beyond 2^30 instances) its `drop` lowest bits are left out: the candidates they stand for are told
+        // apart afterwards by recomputing their k-mers (k_instance_entries).  The sort then moves 8 bytes per instance, not 16.
         int ib = 1;
         while (ib < 63 && (I >> ib)) ++ib;
-        const bool packed_words = 2 * k + ib <= 64 && !getenv("ELBA_KMER_PAIRS");
-        if (!packed_words) ib = 0;
+        int drop = 2 * k + ib > 64 ? 2 * k + ib - 64 : 0;
+        const bool packed_words = drop <= 3 && !getenv("ELBA_KMER_PAIRS");
+        if (!packed_words) { ib = 0; drop = 0; }
+        const int pb = ib - drop;                  // payload bits below the value
         int where = 0;
         if (packed_words) {
-            if (I > 0) hipLaunchKernelGGL(k_kmer_emit_packed, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, ib, c.ws_a.as<uint64_t>());
-            where = radix_sort_keys(s, c.ws_a.as<uint64_t>(), c.ws_c.as<uint64_t>(), (int64_t)I, ib, ib + 2 * k, c.ws_sort);
+            if (I > 0) hipLaunchKernelGGL(k_kmer_emit_packed, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, pb, drop, c.ws_a.as<uint64_t>());
+            where = radix_sort_keys(s, c.ws_a.as<uint64_t>(), c.ws_c.as<uint64_t>(), (int64_t)I, pb, pb + 2 * k, c.ws_sort);
         } else {
             if (I > 0) hipLaunchKernelGGL(k_kmer_emit, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
             where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)I, 64 - 2 * k, 64, c.ws_sort);
         }
         const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>(), *svals = packed_words ? (const uint64_t *)nullptr : (where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>());
-        uint64_t *spare_k = where ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>(), *spare_v = packed_words ? c.ws_b.as<uint64_t>() : (where ? c.ws_b.as<uint64_t>() : c.ws_d.as<uint64_t>());   // free after the sort
         c.t_a.stop(s);
         c.t_b.start(s);
         uint64_t nruns = 0, N = 0, Z = 0;
-        runs_to_columns(c, skeys, svals, spare_k, spare_v, I, nruns, N, Z, nullptr, nullptr, ib);
+        runs_to_columns(c, skeys, svals, I, nruns, N, Z, nullptr, nullptr, pb, drop);
         c.t_b.stop(s);
         c.t_total.stop(s);
         ELBA_HIP(hipStreamSynchronize(s));
@@ -607,11 +709,9 @@ void stage_create_kmer_matrix(Ctx &c)
     c.have_A = false; c.have_B = false;
     if (c.kmers_sorted) {           // CSC(A) came out of the counting sort already: only the column id of every entry is still needed
         c.t_c.start(s);
-        c.ws_f.reserve((size_t)(Z + 1) * 8);
-        if (N > 0) hipLaunchKernelGGL(k_column_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.ws_f.as<uint64_t>(), (uint64_t)N);
         c.t_c.stop(s);
         c.A_has_kmers = true;
-        finish_matrix_from_sorted_csc(c, M, N, Z, c.ws_f.as<uint64_t>(), 0, c.a_csc.as<uint64_t>());
+        finish_matrix_from_sorted_csc(c, M, N, Z, c.kid_of_entry.as<uint64_t>(), 0, c.a_csc.as<uint64_t>());      // (the column id of every entry was written with the columns: k_runs)
         c.kstats.ms_lookup = c.t_c.ms();
         return;
     }
@@ -1002,13 +1102,12 @@ void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
             hipLaunchKernelGGL(k_gather_u64, dim3(nbI), dim3(256), 0, s, perm, val.as<uint64_t>(), I, sval);
         }
         // (the permutation buffers are dead once the gathers are queued: runs_to_columns may use two of them as scratch)
-        runs_to_columns(c, shi, sval, t0.as<uint64_t>(), t1.as<uint64_t>(), I, nruns, N, Z, slo, slo2);
+        runs_to_columns(c, shi, sval, I, nruns, N, Z, slo, slo2);
     } else {
     if (I > 0) hipLaunchKernelGGL(k_deinterleave, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, c.d_records, I, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
     const int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)I, 64 - 2 * k, 64, c.ws_sort);
     const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>(), *svals = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
-    uint64_t *spare_k = where ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>(), *spare_v = where ? c.ws_b.as<uint64_t>() : c.ws_d.as<uint64_t>();
-    runs_to_columns(c, skeys, svals, spare_k, spare_v, I, nruns, N, Z);
+    runs_to_columns(c, skeys, svals, I, nruns, N, Z);
     }
     c.ws_f.reserve((size_t)(Z + 1) * 8);
     if (N > 0)
