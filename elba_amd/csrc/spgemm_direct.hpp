@@ -22,6 +22,7 @@
 enum : uint32_t { D_NEXT = 20, D_FB0 = 16, W_ACC_P = 54 /*u64*/, W_END2 = 56 };
 constexpr uint32_t RING = 128;      // per-wavefront product ring (entries): < 64 left over + <= 64 new ones per candidate slot
 constexpr uint32_t NOROW = 0xFFFFFFFFu, UNRESOLVED = 0xFFFFFFFEu;
+constexpr unsigned long long FB_ENOUGH = 1ull << 23;      // row entries behind the in-call partner / entry ratio at which it counts as settled
 
 // `half`: which of the two rows of a pair {i, j} accumulates it (the other row receives the mirrored entry).  The smaller row when i + j is
 // even, the larger when it is odd: every row then owns about half of its partners whatever its place in the matrix (owned by the smaller
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
     uint32_t chunk_left = 0;
     auto w64 = [&](uint32_t k) { return reinterpret_cast<unsigned long long *>(&misc[k]); };
     if (tid >= 32 && tid < W_END2) misc[tid] = 0;
+    if (tid >= D_FB0 && tid < D_FB0 + 4u) misc[tid] = 0;
     const uint32_t *queue = p.lists + (size_t)tier * p.M;
     // Rows are claimed one at a time, one row ahead.  One head word saturates at ~88 claims/us (MI355X_MICROARCH.md, "dequeue"); the queue
     // is therefore cut into 8 interleaved sub-queues (positions congruent modulo 8) with a head each, a workgroup draws from the one of
@@ -99,7 +101,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             // Self-correction inside a call (no prior for this matrix): rows already done tell how many distinct partners a row entry
             // brings on THIS data; a row predicted not to fit is forwarded without an attempt.  (lane 0 reads the hot sums once per 8 rows
             // and broadcasts through LDS: the decision must be workgroup-uniform)
-            if ((fb_seen++ & 15u) == 0) {
+            // (read before each of the workgroup's first rows — a wrong cold guess should cost a workgroup one abandoned row, not sixteen — then
+            //  every 16th; once the sums cover FB_ENOUGH row entries the ratio is settled: nobody reads or adds to the hot line any more)
+            const bool fb_settled = (((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0]) >= FB_ENOUGH;
+            if (!fb_settled && (fb_seen < 4u || (fb_seen & 15u) == 0)) {
                 if (tid == 0) {
                     const unsigned long long u = __hip_atomic_load(&p.ctr->fb_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long c = __hip_atomic_load(&p.ctr->fb_claims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 }
                 __syncthreads();
             }
+            ++fb_seen;
             const unsigned long long gu = ((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0], gc = ((unsigned long long)misc[D_FB0 + 3] << 32) | misc[D_FB0 + 2];
             if (gu >= (1ull << 18)) {
                 const double pred = 1.25 * (double)nnz * (double)gc / (double)gu;
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 const unsigned long long all = nnz ? nnz : 1u, done = misc[11] ? misc[11] : all;
                 lds_add64(w64(W_FB_C), (unsigned long long)misc[9] * all / done); lds_add64(w64(W_FB_U), (unsigned long long)nnz); lds_add32(&misc[W_FB_N], 1u);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (p.use_feedback && misc[W_FB_N] >= 2) {          // abandoned rows are the strongest evidence: publish at once
+                if (p.use_feedback && misc[W_FB_N] >= 2 && ((((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0]) < FB_ENOUGH)) {          // abandoned rows are the strongest evidence: publish at once
                     const unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
                     atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu);
                     *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             lds_add32(&misc[W_ACC_NDIAG], dcount >= 2 ? 1u : 0u);
             lds_add64(w64(W_ACC_Y), (unsigned long long)ytot);
             if (!GLOBAL) { lds_add64(w64(W_FB_C), (unsigned long long)misc[9]); lds_add64(w64(W_FB_U), (unsigned long long)nnz); lds_add32(&misc[W_FB_N], 1u); }
-            if (p.use_feedback && misc[W_FB_N] >= 4) {          // no prior yet: push this workgroup's share to the hot sums
+            if (p.use_feedback && misc[W_FB_N] >= 4 && ((((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0]) < FB_ENOUGH)) {          // no prior yet: push this workgroup's share to the hot sums
                 const unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
                 atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu);
                 *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;

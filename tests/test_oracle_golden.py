@@ -284,3 +284,36 @@ def test_two_word_counting_is_consistent_with_one_word_counting():
     for kid, km in enumerate(rel):
         e0, e1 = int(A["colptr"][kid]), int(A["colptr"][kid + 1])
         assert list(zip(A["csc_read"][e0:e1].tolist(), A["csc_pos"][e0:e1].tolist())) == sorted(cnt[km])
+
+
+def test_reference_kmer_numbering_replay_matches_the_survey_and_leaves_pattern_and_counts_unchanged():
+    """SURVEY.md §8c-3.  tests/golden/*.order hold the k-mer ids of a one-rank reference run (unordered_map iteration order after
+    reserve(ceil(HLL)), replayed on the reference's own compiled code).  (a) For the reference's bundled reads.fa the replay's HLL
+    estimate, bucket count, keys after pass 1 and N are the figures the survey measured from the reference's own KmerOps.cpp (App. B).
+    (b) Under that numbering the oracle's B has the same pattern and the same numshared as under the canonical (value-rank) numbering;
+    the seeds follow the numbering, and each is still the min / max product of ITS numbering (checked against a brute-force fold)."""
+    order, meta = util.read_order(os.path.join(G, "reads_ref_k17_L2_U8.order"))
+    assert len(order) == 14751 and int(meta["buckets"]) == 299951 and int(meta["keys_after_pass1"]) == 136991 and round(meta["hll"]) == 283870
+    rd, ref_ids, ps, canon_ids, N, _ = util.libstdcxx_triples("small_err")
+    M = util.golden_meta()["small_err"][0]["M"]
+    oc = po.Oracle(17, 2, 8); oc.set_triples(M, N, rd, canon_ids, ps); oc.spgemm(1)
+    orf = po.Oracle(17, 2, 8); orf.set_triples(M, N, rd, ref_ids, ps); orf.spgemm(1)
+    Bc, Br = oc.B(), orf.B()
+    assert (Bc["rowptr"] == Br["rowptr"]).all() and (Bc["col"] == Br["col"]).all() and (Bc["val"]["numshared"] == Br["val"]["numshared"]).all()
+    assert (Bc["val"] != Br["val"]).any()
+    # brute-force fold under the reference numbering: seeds[0] / seeds[1] = products with minimal / maximal (id, posQ, posT)
+    cols = {}
+    for r, c, p in zip(rd.tolist(), ref_ids.tolist(), ps.tolist()):
+        cols.setdefault(c, []).append((r, p))
+    best = {}
+    for c, ents in cols.items():
+        for (i, pq) in ents:
+            for (j, pt) in ents:
+                key, cand = (i, j), (c, pq, pt)
+                lo, hi = best.get(key, (cand, cand))
+                best[key] = (min(lo, cand), max(hi, cand))
+    rows = np.repeat(np.arange(M), np.diff(Br["rowptr"]))
+    for x in range(0, Br["Y"], 7):
+        i, j, v = int(rows[x]), int(Br["col"][x]), Br["val"][x]
+        lo, hi = best[(i, j)]
+        assert (int(v["q0"]), int(v["t0"]), int(v["q1"]), int(v["t1"])) == (lo[1], lo[2], hi[1], hi[2])

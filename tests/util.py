@@ -53,3 +53,23 @@ def triples_from_A(A):
 def b_triplets(B):
     rows = np.repeat(np.arange(B["M"], dtype=np.int64), np.diff(B["rowptr"]))
     return np.stack([rows, B["col"].astype(np.int64), B["val"]["numshared"].astype(np.int64)], axis=1)
+
+
+def read_order(path):
+    """tests/golden/*.order: (k-mers by reference k-mer id, header fields) — see tests/golden/make_order_golden.py."""
+    head = open(path).readline()
+    meta = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in head.split() if "=" in kv}
+    km = np.array([int(line, 16) for line in open(path) if line[0] != "#"], dtype=np.uint64)
+    return km, meta
+
+
+def libstdcxx_triples(name):
+    """The golden A triples of `name` renumbered the way a one-rank reference run numbers its k-mers:
+    returns (M-agnostic) reads, k-mer ids under the reference order, positions, the canonical (value-rank) ids, N."""
+    gk, gr, gp = read_triples(os.path.join(GOLDEN, "%s_k17_L2_U8.triples" % name))
+    order, meta = read_order(os.path.join(GOLDEN, "%s_k17_L2_U8.order" % name))
+    uk, canon = np.unique(gk, return_inverse=True)
+    assert len(order) == len(uk) and (np.sort(order) == uk).all()          # the reference's map holds exactly the reliable k-mers
+    id_of_value = {int(v): i for i, v in enumerate(order.tolist())}
+    ref_ids = np.array([id_of_value[int(v)] for v in gk.tolist()], dtype=np.int64)
+    return gr, ref_ids, gp, canon.astype(np.int64), len(uk), meta
