@@ -75,6 +75,7 @@ struct OvParams {
     // plan-free path (spgemm_direct.hpp): the two orientations of A and nothing else
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint64_t *a_ell; const uint32_t *a_colptr; const uint64_t *a_csc;
     uint32_t s_log2, lpc_log2, max_col;      // padded column stride 2^s_log2 (a_ell); lanes per row entry 2^lpc_log2; longest column
+    unsigned long long fb_enough;            // row entries behind the in-call partner / entry ratio at which it counts as settled (nobody touches the hot sums any more)
     const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_cscj; const uint32_t *a_roworder;
     const RowHot *a_hdr; const HotDesc *a_hot; const uint64_t *a_dec;   // per-row bounds, per-entry partner ranges, seed decoding by canonical rank (matrix.hip)
     uint32_t M;              // number of rows of A held here
@@ -515,6 +516,7 @@ static void create_seed_matrix_direct(Ctx &c)
     p.half = half ? 1u : 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
+    p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);
     const bool pay = c.pos16 && !getenv("ELBA_NO_PAY");
     // workgroup sizes grow with the table so that the largest tiers still bring enough waves to a CU (one or two workgroups fit its LDS)
     const uint32_t blk[NUM_LDS_TIERS] = {128u, 256u, 512u, 1024u, 512u};

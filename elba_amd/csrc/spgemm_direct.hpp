@@ -22,7 +22,6 @@
 enum : uint32_t { D_NEXT = 20, D_FB0 = 16, W_ACC_P = 54 /*u64*/, W_END2 = 56 };
 constexpr uint32_t RING = 128;      // per-wavefront product ring (entries): < 64 left over + <= 64 new ones per candidate slot
 constexpr uint32_t NOROW = 0xFFFFFFFFu, UNRESOLVED = 0xFFFFFFFEu;
-constexpr unsigned long long FB_ENOUGH = 1ull << 23;      // row entries behind the in-call partner / entry ratio at which it counts as settled
 
 // `half`: which of the two rows of a pair {i, j} accumulates it (the other row receives the mirrored entry).  The smaller row when i + j is
 // even, the larger when it is odd: every row then owns about half of its partners whatever its place in the matrix (owned by the smaller
@@ -71,6 +70,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
     if (tid == 0) misc[D_NEXT] = resolve(draw());
     __syncthreads();
     uint32_t fb_seen = 0;
+    bool fb_settled = false;
 #ifdef ELBA_PHASE_CLOCK
     // diagnostic build only (make dbg): shader-clock cycles of wave 0 per phase, summed over workgroups into ctr->phase
     //   0 row header  1 table init  2 accumulate  3 next-row hand-off + barrier  4 sweep  5 reserve  6 staging stores
@@ -102,9 +102,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             // brings on THIS data; a row predicted not to fit is forwarded without an attempt.  (lane 0 reads the hot sums once per 8 rows
             // and broadcasts through LDS: the decision must be workgroup-uniform)
             // (read before each of the workgroup's first rows — a wrong cold guess should cost a workgroup one abandoned row, not sixteen — then
-            //  every 16th; once the sums cover FB_ENOUGH row entries the ratio is settled: nobody reads or adds to the hot line any more)
-            const bool fb_settled = (((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0]) >= FB_ENOUGH;
-            if (!fb_settled && (fb_seen < 4u || (fb_seen & 15u) == 0)) {
+            //  every 16th; once the sums cover p.fb_enough row entries the ratio is settled: nobody reads or adds to the hot line any more)
+            if (!fb_settled && (fb_seen < 4u || (fb_seen & 15u) == 0)) {      // (fb_settled: a register set from the snapshot BEHIND the barrier: workgroup-uniform)
                 if (tid == 0) {
                     const unsigned long long u = __hip_atomic_load(&p.ctr->fb_ub, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     const unsigned long long c = __hip_atomic_load(&p.ctr->fb_claims, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -114,6 +113,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             }
             ++fb_seen;
             const unsigned long long gu = ((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0], gc = ((unsigned long long)misc[D_FB0 + 3] << 32) | misc[D_FB0 + 2];
+            fb_settled = gu >= p.fb_enough;
             if (gu >= (1ull << 18)) {
                 const double pred = 1.25 * (double)nnz * (double)gc / (double)gu;
                 if (pred > 1.2 * (double)p.tier_limit[tier] && guaranteed_tbits(ub_i, p.Mcols) > lds_tbits) {
@@ -280,7 +280,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 const unsigned long long all = nnz ? nnz : 1u, done = misc[11] ? misc[11] : all;
                 lds_add64(w64(W_FB_C), (unsigned long long)misc[9] * all / done); lds_add64(w64(W_FB_U), (unsigned long long)nnz); lds_add32(&misc[W_FB_N], 1u);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (p.use_feedback && misc[W_FB_N] >= 2 && ((((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0]) < FB_ENOUGH)) {          // abandoned rows are the strongest evidence: publish at once
+                if (p.use_feedback && misc[W_FB_N] >= 2 && ((((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0]) < p.fb_enough)) {          // abandoned rows are the strongest evidence: publish at once
                     const unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
                     atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu);
                     *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             lds_add32(&misc[W_ACC_NDIAG], dcount >= 2 ? 1u : 0u);
             lds_add64(w64(W_ACC_Y), (unsigned long long)ytot);
             if (!GLOBAL) { lds_add64(w64(W_FB_C), (unsigned long long)misc[9]); lds_add64(w64(W_FB_U), (unsigned long long)nnz); lds_add32(&misc[W_FB_N], 1u); }
-            if (p.use_feedback && misc[W_FB_N] >= 4 && ((((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0]) < FB_ENOUGH)) {          // no prior yet: push this workgroup's share to the hot sums
+            if (p.use_feedback && misc[W_FB_N] >= 8 && ((((unsigned long long)misc[D_FB0 + 1] << 32) | misc[D_FB0]) < p.fb_enough)) {          // no prior yet: push this workgroup's share to the hot sums
                 const unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
                 atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu);
                 *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;

@@ -88,8 +88,13 @@ def paf_line(o, nameQ, nameT, lenQ, lenT):
                                                                  int(o["begT"]), int(o["endT"]), int(o["score"]), maplen, int(o["passed"]))
 
 
-def write_paf(path, overlaps, names, lens):
+def write_paf(path, overlaps, names, lens, dcsc_order=False):
+    """dcsc_order: walk the triples as parallel_write_paf walks the local DCSC (columns ascending, rows ascending within a column)
+    instead of in the order given."""
+    idx = range(overlaps["n"])
+    if dcsc_order:
+        idx = np.lexsort((overlaps["rows"], overlaps["cols"])).tolist()
     with open(path, "w") as f:
-        for a in range(overlaps["n"]):
+        for a in idx:
             i, j = int(overlaps["rows"][a]), int(overlaps["cols"][a])
             f.write(paf_line(overlaps["vals"][a], names[i], names[j], int(lens[i]), int(lens[j])) + "\n")

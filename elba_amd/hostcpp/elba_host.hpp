@@ -23,8 +23,10 @@
 // There is no CPU path: constructing an engine without a GPU throws ELBA_ERR_NO_DEVICE.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <cstring>
 #include <fstream>
+#include <ostream>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -401,5 +403,63 @@ inline std::unique_ptr<StringGraph> TransitiveReduction(const DnaBuffer &myreads
     }
     return S;
 }
+
+// ---- the reference's text outputs -------------------------------------------------------------------------------
+// SharedSeeds as operator<< prints it (include/SharedSeeds.hpp:75-88): `{(q0,t0),(q1,t1),n}` with min(numshared, 2) seeds.
+inline std::ostream &operator<<(std::ostream &os, const SharedSeeds &o)
+{
+    const int seedstoprint = o.getnumstored() < 2 ? o.getnumstored() : 2;
+    os << "{";
+    for (int i = 0; i < seedstoprint; ++i) os << "(" << std::get<0>(o.seeds[i]) << "," << std::get<1>(o.seeds[i]) << "),";
+    os << o.getnumshared() << "}";
+    return os;
+}
+
+// Overlap as operator<< prints it (include/Overlap.hpp:78-83)
+inline std::ostream &operator<<(std::ostream &os, const Overlap &o)
+{
+    os << std::get<0>(o.len) << "\t" << std::get<0>(o.beg) << "\t" << std::get<0>(o.end) << "\t" << (o.rc ? '-' : '+') << "\t" << std::get<1>(o.len) << "\t" << std::get<1>(o.beg) << "\t"
+       << std::get<1>(o.end) << "\t" << o.score << "\t" << static_cast<int>(o.direction) << "\t" << static_cast<int>(o.suffix);
+    return os;
+}
+
+// ELBALogger::log_seed_matrix (src/ELBALogger.cpp:22-35): B.ParallelWriteMM("B.mtx", true, SharedSeeds::IOHandler()) — MatrixMarket
+// coordinate file, one-based indices, entries as the local DCSC stores them (column by column, rows ascending), values through
+// IOHandler::save = operator<<.  (CombBLAS's writer itself is un-vendored: the header line follows the MatrixMarket convention.)
+inline void log_seed_matrix(SeedMatrix &B, const std::string &fname)
+{
+    std::ofstream os(fname);
+    if (!os) throw Error(ELBA_ERR_INVALID_ARG, "cannot open " + fname);
+    const SeqSeedMatrix *seq = B.seqptr();
+    const Dcsc *dcsc = seq->GetDCSC();
+    os << "%%MatrixMarket matrix coordinate real general\n" << B.getnrow() << " " << B.getncol() << " " << seq->getnnz() << "\n";
+    if (dcsc)
+        for (int64_t i = 0; i < dcsc->nzc; ++i)
+            for (int64_t j = dcsc->cp[(size_t)i]; j < dcsc->cp[(size_t)i + 1]; ++j) os << dcsc->ir[(size_t)j] + 1 << "\t" << dcsc->jc[(size_t)i] + 1 << "\t" << dcsc->numx[(size_t)j] << "\n";
+}
+
+// parallel_write_paf (src/main.cpp:514-551) for the triples of R or S: the reference walks the local DCSC (columns ascending, rows ascending
+// within a column) and prints `maplen` as written there (:536: max(endQ - begQ, endT - endT)).
+namespace detail {
+template <class M>
+inline void write_paf(const M &R, const std::vector<std::string> &names, const std::string &pafname)
+{
+    std::vector<size_t> order(R.vals.size());
+    for (size_t a = 0; a < order.size(); ++a) order[a] = a;
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return R.cols[x] != R.cols[y] ? R.cols[x] < R.cols[y] : R.rows[x] < R.rows[y]; });
+    std::ofstream ss(pafname);
+    if (!ss) throw Error(ELBA_ERR_INVALID_ARG, "cannot open " + pafname);
+    for (size_t a : order) {
+        const Overlap &o = R.vals[a];
+        const long long begQ = std::get<0>(o.beg), endQ = std::get<0>(o.end), endT = std::get<1>(o.end);
+        const long long maplen = std::max(endQ - begQ, endT - endT);
+        ss << names[(size_t)R.rows[a]] << "\t" << std::get<0>(o.len) << "\t" << std::get<0>(o.beg) << "\t" << std::get<0>(o.end) << "\t" << "+-"[o.rc ? 1 : 0] << "\t"
+           << names[(size_t)R.cols[a]] << "\t" << std::get<1>(o.len) << "\t" << std::get<1>(o.beg) << "\t" << std::get<1>(o.end) << "\t" << o.score << "\t" << maplen << "\t255\t"
+           << static_cast<int>(o.passed) << "\n";
+    }
+}
+}  // namespace detail
+inline void parallel_write_paf(const OverlapMatrix &R, const std::vector<std::string> &names, const std::string &pafname) { detail::write_paf(R, names, pafname); }
+inline void parallel_write_paf(const StringGraph &S, const std::vector<std::string> &names, const std::string &pafname) { detail::write_paf(S, names, pafname); }
 
 }  // namespace elba

@@ -82,6 +82,14 @@ int main(int argc, char **argv)
             schk += (uint64_t)S->rows[a] * 1000003ull + (uint64_t)S->cols[a] * 31ull + (uint64_t)(uint8_t)o.direction * 131ull + (uint64_t)(uint32_t)o.suffix * 8191ull
                     + std::get<0>(o.beg) * 37ull + std::get<1>(o.end) * 43ull + std::get<0>(o.len) * 3ull + std::get<1>(o.len) + (uint64_t)a * 7ull;
         }
+        // main.cpp:287 (elbalog.log_seed_matrix(*B)), :303 and :317 (parallel_write_paf of R and of S): written when ELBA_OUT_PREFIX is set
+        if (const char *pfx = std::getenv("ELBA_OUT_PREFIX")) {
+            std::vector<std::string> names;
+            for (size_t r = 0; r < mydna.size(); ++r) names.push_back("read" + std::to_string(r));
+            elba::log_seed_matrix(*B, std::string(pfx) + "B.mtx");
+            elba::parallel_write_paf(*R, names, std::string(pfx) + "overlap.paf");
+            elba::parallel_write_paf(*S, names, std::string(pfx) + "string.paf");
+        }
         std::printf("{\"reads\": %zu, \"nnzA\": %lld, \"kmers\": %lld, \"nnzB\": %zu, \"candidates\": %lld, \"checksum\": %llu, \"alignments\": %lld, \"passed\": %lld, \"align_checksum\": %llu, \"ingest_equal\": %d, "
                     "\"bad_reads\": %zu, \"contained_reads\": %zu, \"string_nnz\": %lld, \"string_checksum\": %llu}\n", mydna.size(),
                     (long long)nnzA, (long long)ncol, localnnzs, (long long)nalign, (unsigned long long)checksum, (long long)R->getnnz(), (long long)npassed, (unsigned long long)achk, ingest_equal,
