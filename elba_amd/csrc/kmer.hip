@@ -60,10 +60,10 @@ struct EnumParams {
     uint32_t nreads; uint64_t I; int k;
 };
 
-// canonical k-mer of read `r` at position `p` (two aligned 8-byte loads; the buffer carries 16 guard bytes)
-__device__ __forceinline__ uint64_t canonical_at(const EnumParams &e, uint32_t r, uint32_t p)
+// canonical k-mer at position `p` of the read that starts at byte `boff` (two aligned 8-byte loads; the buffer carries 16 guard bytes)
+__device__ __forceinline__ uint64_t canonical_at_off(const EnumParams &e, uint64_t boff, uint32_t p)
 {
-    const uint64_t b = e.byte_off[r] + (p >> 2);
+    const uint64_t b = boff + (p >> 2);
     const uint64_t a = b & ~7ull;
     const uint64_t *w = reinterpret_cast<const uint64_t *>(e.packed + a);
     const uint64_t hi = __builtin_bswap64(w[0]), lo = __builtin_bswap64(w[1]);
@@ -73,6 +73,7 @@ __device__ __forceinline__ uint64_t canonical_at(const EnumParams &e, uint32_t r
     const uint64_t tw = twin64(fwd, e.k);
     return tw < fwd ? tw : fwd;
 }
+__device__ __forceinline__ uint64_t canonical_at(const EnumParams &e, uint32_t r, uint32_t p) { return canonical_at_off(e, e.byte_off[r], p); }
 
 // Two-word k-mers, 32 < k <= 63 (NLONGS == 2, include/Kmer.hpp:95-97): bases 0..31 in the first word, the rest left-aligned in the second;
 // twin = reverse complement over 128 bits; canonical = the smaller of the two, first word compared first (src/Kmer.cpp:118-131, :200-205).
@@ -431,25 +432,46 @@ __global__ __launch_bounds__(RUN_THREADS) void k_runs(RunParams p, uint32_t *blk
 // fit beside the value in one 64-bit word, see stage_count_kmers): the entry is the dup-th instance among the 2^drop candidates whose
 // canonical k-mer is the column's, dup = entries of the same column with the same payload before this one (equal payloads are adjacent:
 // the sort is stable).  The instance's read is found by binary search in the reads' instance offsets (they stay in L2).
-__global__ void k_instance_entries(const uint64_t *payload, const uint64_t *kid_of_entry, const uint64_t *rel_kmers, uint64_t *csc, uint64_t Z, EnumParams e, int drop)
+// read of the first instance of every block of 2^IB_SHIFT instances: an entry then finds its read with ONE table load and a step or two
+// along the instance offsets instead of a binary search over all reads (18 dependent L2 round trips per entry on 200 k reads: the
+// search was 54 ms of the 219 ms k-mer stage of the 200 k-read set)
+constexpr int IB_SHIFT = 11;
+struct alignas(32) BlockInfo { uint32_t read, pad; uint64_t off_lo, off_hi, byte_off; };      // the read holding the block's first instance: one 32-byte load
+__global__ void k_block_reads(const uint64_t *inst_off, const uint64_t *byte_off, uint32_t nreads, uint64_t nblocks, BlockInfo *block_read)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint64_t g = b << IB_SHIFT;
+    uint32_t lo = 0, hi = nreads;                                     // last read with inst_off[read] <= g
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (inst_off[mid] <= g) lo = mid; else hi = mid; }
+    block_read[b] = BlockInfo{lo, 0u, inst_off[lo], inst_off[lo + 1], byte_off[lo]};
+}
+
+__global__ void k_instance_entries(const uint64_t *payload, const uint64_t *kid_of_entry, const uint64_t *rel_kmers, uint64_t *csc, uint64_t Z, EnumParams e, int drop,
+                                   const BlockInfo *block_read)
 {
     const uint64_t z = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= Z) return;
     const uint64_t h = payload[z];
     uint64_t g = h << drop;
-    uint32_t lo = 0, hi = e.nreads;                                   // last read with inst_off[read] <= g
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (e.inst_off[mid] <= g) lo = mid; else hi = mid; }
+    const BlockInfo bi = block_read[g >> IB_SHIFT];
+    uint32_t lo = bi.read;                                            // last read with inst_off[read] <= g
+    uint64_t off_lo = bi.off_lo, off_hi = bi.off_hi, boff = bi.byte_off;
+    auto advance = [&](uint64_t gg) {                                 // (a block that holds a read boundary: walk on through the global arrays)
+        while (gg >= off_hi) { ++lo; off_lo = off_hi; off_hi = e.inst_off[lo + 1]; boff = e.byte_off[lo]; }
+    };
+    advance(g);
     if (drop) {
         const uint64_t kid = kid_of_entry[z], want = rel_kmers[kid];
         uint32_t dup = 0;
         for (uint64_t y = z; y > 0 && kid_of_entry[y - 1] == kid && payload[y - 1] == h; --y) ++dup;
         const uint64_t gend = g + (1ull << drop) < e.I ? g + (1ull << drop) : e.I;
         for (; g < gend; ++g) {
-            while (g >= e.inst_off[lo + 1]) ++lo;
-            if (canonical_at(e, lo, (uint32_t)(g - e.inst_off[lo])) == want) { if (dup == 0) break; --dup; }
+            advance(g);
+            if (canonical_at_off(e, boff, (uint32_t)(g - off_lo)) == want) { if (dup == 0) break; --dup; }
         }
     }
-    csc[z] = ((uint64_t)lo << 32) | (uint32_t)(g - e.inst_off[lo]);
+    csc[z] = ((uint64_t)lo << 32) | (uint32_t)(g - off_lo);
 }
 
 __global__ void k_column_ids(const uint32_t *colptr, uint64_t *kid_keys, uint64_t N)
@@ -522,7 +544,11 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
                            c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), pay, c.kid_of_entry.as<uint64_t>());
     if (ib && Z > 0) {
         EnumParams e = make_enum(c);
-        hipLaunchKernelGGL(k_instance_entries, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, pay, c.kid_of_entry.as<uint64_t>(), c.rel_kmers.as<uint64_t>(), c.a_csc.as<uint64_t>(), Z, e, drop);
+        const uint64_t nib = (I >> IB_SHIFT) + 1;
+        c.ws_b.reserve((size_t)(nib + 1) * sizeof(BlockInfo));
+        hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
+        hipLaunchKernelGGL(k_instance_entries, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, pay, c.kid_of_entry.as<uint64_t>(), c.rel_kmers.as<uint64_t>(), c.a_csc.as<uint64_t>(), Z, e, drop,
+                           c.ws_b.as<BlockInfo>());
     }
     const uint32_t Zz = (uint32_t)Z;
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));

@@ -22,6 +22,23 @@ __global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, const
     csr_vals[z] = (kid << 32) | (e & 0xFFFFFFFFull);         // kid | pos
 }
 
+// CSR build with ONE word per entry when read, k-mer id and position fit 64 bits together: read << (nb + pb) | kid << pb | pos, sorted
+// (stably) on the read bits only — the radix passes move 8 bytes per entry instead of 16 — and unpacked into kid << 32 | pos afterwards
+__global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, const uint64_t *csc, int64_t Z, int nb, int pb, uint64_t *words)
+{
+    int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    const uint64_t kid = kid_keys[z] >> kid_shift, e = csc[z];
+    words[z] = ((e >> 32) << (nb + pb)) | (kid << pb) | (e & 0xFFFFFFFFull);
+}
+__global__ void k_unpack_csr_words(const uint64_t *words, int64_t Z, int nb, int pb, uint64_t *csr)
+{
+    int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    const uint64_t w = words[z];
+    csr[z] = (((w >> pb) & ((1ull << nb) - 1)) << 32) | (w & ((1ull << pb) - 1));
+}
+
 __global__ void k_colrow_to_csc(const uint64_t *colrow, const uint64_t *pos, int64_t Z, uint64_t *csc)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -485,18 +502,41 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     group_offsets_u32(s, kid_keys, kid_shift, Z, c.a_colptr.as<uint32_t>(), N);
     if (csc != c.a_csc.as<uint64_t>() && Z > 0)
         ELBA_HIP(hipMemcpyAsync(c.a_csc.p, csc, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
-    // stable sort by read: rows come out ordered by (kid, pos)
-    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_b.reserve((size_t)(Z + 1) * 8);
-    c.ws_c.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
-    uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
+    // largest position among the entries: below 2^16 the SpGEMM's 64-bit accumulators carry both positions of a seed (spgemm_direct.hpp);
+    // it also decides whether an entry fits one word for the CSR sort
+    uint64_t maxpos = 0;
     if (Z > 0) {
-        int64_t nb = (Z + 255) / 256;
-        hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nb), dim3(256), 0, s, kid_keys, kid_shift, c.a_csc.as<uint64_t>(), Z, k0, v0);
+        int64_t nbz = (Z + 255) / 256;
+        if (nbz > 2048) nbz = 2048;
+        c.ws_scan.reserve(64);
+        ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
+        hipLaunchKernelGGL(k_max_low32, dim3((unsigned)nbz), dim3(256), 0, s, c.a_csc.as<uint64_t>(), Z, c.ws_scan.as<unsigned long long>());
+        ELBA_HIP(hipMemcpyAsync(&maxpos, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
     }
-    int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, bits_for((uint64_t)(M > 0 ? M - 1 : 0)), c.ws_sort);
-    const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;
-    group_offsets_u32(s, rk, 0, Z, c.a_rowptr.as<uint32_t>(), M);
-    if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+    c.pos16 = maxpos < 65536;
+    // stable sort by read: rows come out ordered by (kid, pos)
+    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_c.reserve((size_t)(Z + 1) * 8);
+    const int mb = bits_for((uint64_t)(M > 0 ? M - 1 : 0)), nb = bits_for((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_for(maxpos);
+    if (mb + nb + pb <= 64 && !getenv("ELBA_CSR_PAIRS")) {
+        uint64_t *w0 = c.ws_a.as<uint64_t>(), *w1 = c.ws_c.as<uint64_t>();
+        if (Z > 0) hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
+        const int where = radix_sort_keys(s, w0, w1, Z, nb + pb, nb + pb + mb, c.ws_sort);
+        const uint64_t *sorted = where ? w1 : w0;
+        group_offsets_u32(s, sorted, nb + pb, Z, c.a_rowptr.as<uint32_t>(), M);
+        if (Z > 0) hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, c.a_csr.as<uint64_t>());
+    } else {
+        c.ws_b.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
+        uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
+        if (Z > 0) {
+            int64_t nbk = (Z + 255) / 256;
+            hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kid_keys, kid_shift, c.a_csc.as<uint64_t>(), Z, k0, v0);
+        }
+        int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, mb, c.ws_sort);
+        const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;
+        group_offsets_u32(s, rk, 0, Z, c.a_rowptr.as<uint32_t>(), M);
+        if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+    }
     ELBA_REQUIRE(win_lo >= 0 && (win_hi < 0 || (win_lo <= win_hi && win_hi <= M)), ELBA_ERR_INVALID_ARG, "bad row window");
     c.row_lo = win_lo; c.row_hi = win_hi;
     c.plan = getenv("ELBA_PLAN") != nullptr;
@@ -516,20 +556,6 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.ov_prior_q16 = 0;            // a new matrix: forget the partner/product ratio measured on the previous one
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
-    // largest position among the entries: below 2^16 the SpGEMM's 64-bit accumulators carry both positions of a seed (spgemm_direct.hpp)
-    {
-        uint64_t maxpos = 0;
-        if (Z > 0) {
-            int64_t nbz = (Z + 255) / 256;
-            if (nbz > 2048) nbz = 2048;
-            c.ws_scan.reserve(64);
-            ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
-            hipLaunchKernelGGL(k_max_low32, dim3((unsigned)nbz), dim3(256), 0, s, c.a_csc.as<uint64_t>(), Z, c.ws_scan.as<unsigned long long>());
-            ELBA_HIP(hipMemcpyAsync(&maxpos, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
-            ELBA_HIP(hipStreamSynchronize(s));
-        }
-        c.pos16 = maxpos < 65536;
-    }
     // The column store the SpGEMM gathers from.  No column longer than 64 entries (UPPER <= 64: every configuration the reference
     // documents): columns padded to S = 2^s_log2 >= 4 entries, column kid at kid * S — its address is arithmetic, and a group of S/2
     // lanes reads it as one aligned segment.  Longer columns (or no room for the padding): the plain CSC, reached through a_colptr.
