@@ -108,7 +108,7 @@ EXPORTED_SYMBOLS = [
     "elba_align_seeds", "elba_export_overlaps", "elba_free_overlaps", "elba_set_overlaps", "elba_transitive_reduction", "elba_export_string_graph", "elba_export_read_flags", "elba_set_reads_fasta", "elba_export_reads", "elba_dist_set_all_reads",
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
     "elba_dist_value_histogram", "elba_dist_set_owner_ranges", "elba_dist_set_kmer_id_base", "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
-    "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_set_panel",
+    "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_panel_counts_win", "elba_dist_panel_fill_win", "elba_dist_set_panel",
 ]
 
 _lib = None

@@ -500,7 +500,7 @@ int elba_dist_get_reliable_kmers(elba_ctx *ctx, const void **d_kmers, int64_t *n
         ELBA_REQUIRE(d_kmers && n, ELBA_ERR_INVALID_ARG, "dist_get_reliable_kmers: null output");
         ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_get_reliable_kmers: call dist_count_records first");
         ELBA_REQUIRE(c.cfg.k <= 31, ELBA_ERR_UNSUPPORTED, "dist_get_reliable_kmers: multi-word k-mers are handed out interleaved by elba_dist_copy_reliable_kmers");
-        *d_kmers = c.rel_kmers.p; *n = c.N;
+        *d_kmers = c.rel_kmers.p; *n = c.own_N;
     });
 }
 
@@ -508,7 +508,7 @@ int elba_dist_copy_reliable_kmers(elba_ctx *ctx, void *d_dst, int64_t capacity)
 {
     return guarded(ctx, [&](Ctx &c) {
         ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_copy_reliable_kmers: call dist_count_records first");
-        ELBA_REQUIRE(capacity >= c.N && (d_dst || c.N == 0), ELBA_ERR_INVALID_ARG, "dist_copy_reliable_kmers: buffer too small");
+        ELBA_REQUIRE(capacity >= c.own_N && (d_dst || c.own_N == 0), ELBA_ERR_INVALID_ARG, "dist_copy_reliable_kmers: buffer too small");
         stage_dist_copy_reliable_kmers(c, d_dst);
     });
 }
@@ -522,7 +522,7 @@ int elba_dist_panel_counts(elba_ctx *ctx, int nranks, const uint64_t *read_bound
 {
     return guarded(ctx, [&](Ctx &c) {
         ELBA_REQUIRE(read_bounds && counts, ELBA_ERR_INVALID_ARG, "dist_panel_counts: null argument");
-        stage_dist_panel(c, nranks, read_bounds, false, nullptr, counts);
+        stage_dist_panel(c, nranks, read_bounds, nullptr, nullptr, false, nullptr, counts);
     });
 }
 
@@ -530,7 +530,23 @@ int elba_dist_panel_fill(elba_ctx *ctx, int nranks, const uint64_t *read_bounds,
 {
     return guarded(ctx, [&](Ctx &c) {
         ELBA_REQUIRE(read_bounds && offsets, ELBA_ERR_INVALID_ARG, "dist_panel_fill: null argument");
-        stage_dist_panel(c, nranks, read_bounds, true, d_send, const_cast<uint64_t *>(offsets));
+        stage_dist_panel(c, nranks, read_bounds, nullptr, nullptr, true, d_send, const_cast<uint64_t *>(offsets));
+    });
+}
+
+int elba_dist_panel_counts_win(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, const uint64_t *win_lo, const uint64_t *win_hi, uint64_t *counts)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(read_bounds && win_lo && win_hi && counts, ELBA_ERR_INVALID_ARG, "dist_panel_counts_win: null argument");
+        stage_dist_panel(c, nranks, read_bounds, win_lo, win_hi, false, nullptr, counts);
+    });
+}
+
+int elba_dist_panel_fill_win(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, const uint64_t *win_lo, const uint64_t *win_hi, void *d_send, const uint64_t *offsets)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(read_bounds && win_lo && win_hi && offsets, ELBA_ERR_INVALID_ARG, "dist_panel_fill_win: null argument");
+        stage_dist_panel(c, nranks, read_bounds, win_lo, win_hi, true, d_send, const_cast<uint64_t *>(offsets));
     });
 }
 

@@ -56,6 +56,7 @@ struct DevBuf {
         cap = want;
     }
     template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+    void swap(DevBuf &o) { void *tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
 };
 
 struct EventTimer {
@@ -177,6 +178,8 @@ struct Ctx {
     int64_t dist_nall = -1;
     std::vector<uint32_t> owner_upper;   // value-range owners: rank r owns the value bins [owner_upper[r-1], owner_upper[r]) (kmer.hip)
     int64_t N_global = -1;    // a panel context: k-mers of the whole run (its own columns are renumbered locally)
+    DevBuf own_colptr, own_csc;   // the columns this rank OWNS (u32[own_N + 1], u64[own_Z]): kept apart from the context's A, which the panels overwrite —
+    int64_t own_N = 0, own_Z = 0; // a rank serves one panel per row block of every rank (elba_dist_panel_*_win)
 
     // B (device)
     bool have_B = false;
@@ -240,7 +243,7 @@ void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offs
 void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec);
 void stage_dist_copy_reliable_kmers(Ctx &c, void *d_dst);       // N k-mers of 1 + (k > 32) + (k > 64) words each, interleaved
 void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall);
-void stage_dist_panel(Ctx &c, int nranks, const uint64_t *bounds_host, bool fill, void *d_send, uint64_t *counts_or_offsets_host);
+void stage_dist_panel(Ctx &c, int nranks, const uint64_t *bounds_host, const uint64_t *win_lo_host, const uint64_t *win_hi_host, bool fill, void *d_send, uint64_t *counts_or_offsets_host);
 void stage_dist_set_panel(Ctx &c, const void *d_rec, int64_t nrec, int64_t M_total, int64_t N_total, int64_t row_lo, int64_t row_hi);
 
 }  // namespace elba

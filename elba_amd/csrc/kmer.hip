@@ -915,15 +915,20 @@ __device__ __forceinline__ uint32_t rank_of_read(const uint64_t *bounds, uint32_
 }
 
 // one lane per column: the set of ranks that own at least one read of the column; FILL = false counts, true writes
+// (win != nullptr: a rank is a destination only if the column has a read inside that rank's current row block [win[r], win[nranks + r]))
 template <bool FILL>
-__global__ void k_panel(const uint32_t *colptr, const uint64_t *csc, const uint32_t *gid, uint64_t N, const uint64_t *bounds, uint32_t nranks,
+__global__ void k_panel(const uint32_t *colptr, const uint64_t *csc, const uint32_t *gid, uint64_t N, const uint64_t *bounds, uint32_t nranks, const uint64_t *win,
                         unsigned long long *counts_or_cursors, uint64_t *send)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     const uint32_t c0 = colptr[k], c1 = colptr[k + 1];
     uint64_t mask = 0;
-    for (uint32_t a = c0; a < c1; ++a) mask |= 1ull << rank_of_read(bounds, nranks, csc[a] >> 32);
+    for (uint32_t a = c0; a < c1; ++a) {
+        const uint64_t read = csc[a] >> 32;
+        const uint32_t r = rank_of_read(bounds, nranks, read);
+        if (!win || (read >= win[r] && read < win[nranks + r])) mask |= 1ull << r;
+    }
     while (mask) {
         const uint32_t d = (uint32_t)__ffsll((unsigned long long)mask) - 1;
         mask &= mask - 1;
@@ -1043,9 +1048,9 @@ void stage_dist_set_owner_ranges(Ctx &c, int nranks, const uint32_t *upper_bins)
 void stage_dist_set_kmer_id_base(Ctx &c, int64_t base, int64_t nall)
 {
     ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_set_kmer_id_base: call dist_count_records first");
-    ELBA_REQUIRE(base >= 0 && base + c.N <= nall && nall < 0xFFFFFFF0ll, ELBA_ERR_INVALID_ARG, "dist_set_kmer_id_base: bad id range");
-    c.dist_gid.reserve((size_t)(c.N + 1) * 4);
-    if (c.N > 0) hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, c.stream, c.dist_gid.as<uint32_t>(), (uint64_t)c.N, (uint32_t)base);
+    ELBA_REQUIRE(base >= 0 && base + c.own_N <= nall && nall < 0xFFFFFFF0ll, ELBA_ERR_INVALID_ARG, "dist_set_kmer_id_base: bad id range");
+    c.dist_gid.reserve((size_t)(c.own_N + 1) * 4);
+    if (c.own_N > 0) hipLaunchKernelGGL(k_iota_u32, dim3((unsigned)((c.own_N + 255) / 256)), dim3(256), 0, c.stream, c.dist_gid.as<uint32_t>(), (uint64_t)c.own_N, (uint32_t)base);
     ELBA_HIP(hipStreamSynchronize(c.stream));
     c.dist_nall = nall;
 }
@@ -1145,16 +1150,20 @@ void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec)
     c.kstats.instances = nrec; c.kstats.distinct = (int64_t)hc.distinct; c.kstats.reliable = (int64_t)N; c.kstats.entries = (int64_t)Z;
     c.have_counts = true;
     c.dist_owner = true;
+    // the owner's columns leave the context's A (which every panel this rank RECEIVES overwrites) for buffers of their own
+    c.a_colptr.swap(c.own_colptr); c.a_csc.swap(c.own_csc);
+    c.own_N = (int64_t)N; c.own_Z = (int64_t)Z;
+    c.have_A = false;
 }
 
 void stage_dist_copy_reliable_kmers(Ctx &c, void *d_dst)
 {
     hipStream_t s = c.stream;
     const int W = kmer_words(c.cfg.k);
-    if (c.N > 0) {
-        if (W == 1) ELBA_HIP(hipMemcpyAsync(d_dst, c.rel_kmers.p, (size_t)c.N * 8, hipMemcpyDeviceToDevice, s));
-        else hipLaunchKernelGGL(k_join_words, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), c.rel_kmers_lo.as<uint64_t>(),
-                                W == 3 ? c.rel_kmers_lo2.as<uint64_t>() : (const uint64_t *)nullptr, (uint64_t)c.N, W, static_cast<uint64_t *>(d_dst));
+    if (c.own_N > 0) {
+        if (W == 1) ELBA_HIP(hipMemcpyAsync(d_dst, c.rel_kmers.p, (size_t)c.own_N * 8, hipMemcpyDeviceToDevice, s));
+        else hipLaunchKernelGGL(k_join_words, dim3((unsigned)((c.own_N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), c.rel_kmers_lo.as<uint64_t>(),
+                                W == 3 ? c.rel_kmers_lo2.as<uint64_t>() : (const uint64_t *)nullptr, (uint64_t)c.own_N, W, static_cast<uint64_t *>(d_dst));
     }
     ELBA_HIP(hipStreamSynchronize(s));
 }
@@ -1163,7 +1172,7 @@ void stage_dist_copy_reliable_kmers(Ctx &c, void *d_dst)
 void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall)
 {
     ELBA_REQUIRE(c.have_counts && c.dist_owner, ELBA_ERR_STATE, "dist_set_global_kmers: call dist_count_records first");
-    ELBA_REQUIRE(nall >= c.N && nall < 0xFFFFFFF0ll, ELBA_ERR_INVALID_ARG, "dist_set_global_kmers: bad global k-mer count");
+    ELBA_REQUIRE(nall >= c.own_N && nall < 0xFFFFFFF0ll, ELBA_ERR_INVALID_ARG, "dist_set_global_kmers: bad global k-mer count");
     hipStream_t s = c.stream;
     const int W = kmer_words(c.cfg.k);
     if (W > 1) {
@@ -1172,7 +1181,7 @@ void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall)
         for (DevBuf *b : {&w0, &w1, &i0, &i1, &t0, &t1, &s0, &s1}) b->reserve((size_t)(nall + 2) * 8);
         if (W == 3) { w2.reserve((size_t)(nall + 2) * 8); s2.reserve((size_t)(nall + 2) * 8); }
         const unsigned nbA = (unsigned)((nall + 255) / 256);
-        c.dist_gid.reserve((size_t)(c.N + 1) * 4);
+        c.dist_gid.reserve((size_t)(c.own_N + 1) * 4);
         if (nall > 0) {
             hipLaunchKernelGGL(k_split_records, dim3(nbA), dim3(256), 0, s, static_cast<const uint64_t *>(d_all), (uint64_t)nall, W, w0.as<uint64_t>(), w1.as<uint64_t>(),
                                W == 3 ? w2.as<uint64_t>() : (uint64_t *)nullptr, (uint64_t *)nullptr, i0.as<uint64_t>());
@@ -1182,9 +1191,9 @@ void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall)
             hipLaunchKernelGGL(k_gather_u64, dim3(nbA), dim3(256), 0, s, perm, w1.as<uint64_t>(), (uint64_t)nall, s1.as<uint64_t>());
             if (W == 3) hipLaunchKernelGGL(k_gather_u64, dim3(nbA), dim3(256), 0, s, perm, w2.as<uint64_t>(), (uint64_t)nall, s2.as<uint64_t>());
         }
-        if (c.N > 0)
-            hipLaunchKernelGGL(k_global_ids_words, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), c.rel_kmers_lo.as<uint64_t>(),
-                               W == 3 ? c.rel_kmers_lo2.as<uint64_t>() : (const uint64_t *)nullptr, (uint64_t)c.N, s0.as<uint64_t>(), s1.as<uint64_t>(),
+        if (c.own_N > 0)
+            hipLaunchKernelGGL(k_global_ids_words, dim3((unsigned)((c.own_N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), c.rel_kmers_lo.as<uint64_t>(),
+                               W == 3 ? c.rel_kmers_lo2.as<uint64_t>() : (const uint64_t *)nullptr, (uint64_t)c.own_N, s0.as<uint64_t>(), s1.as<uint64_t>(),
                                W == 3 ? s2.as<uint64_t>() : (const uint64_t *)nullptr, (uint64_t)nall, c.dist_gid.as<uint32_t>());
         ELBA_HIP(hipStreamSynchronize(s));
         c.dist_nall = nall;
@@ -1194,28 +1203,36 @@ void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall)
     if (nall > 0) ELBA_HIP(hipMemcpyAsync(c.ws_a.p, d_all, (size_t)nall * 8, hipMemcpyDeviceToDevice, s));
     int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), nall, 64 - 2 * c.cfg.k, 64, c.ws_sort);
     const uint64_t *sorted = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>();
-    c.dist_gid.reserve((size_t)(c.N + 1) * 4);
-    if (c.N > 0)
-        hipLaunchKernelGGL(k_global_ids, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), (uint64_t)c.N, sorted, (uint64_t)nall, c.dist_gid.as<uint32_t>());
+    c.dist_gid.reserve((size_t)(c.own_N + 1) * 4);
+    if (c.own_N > 0)
+        hipLaunchKernelGGL(k_global_ids, dim3((unsigned)((c.own_N + 255) / 256)), dim3(256), 0, s, c.rel_kmers.as<uint64_t>(), (uint64_t)c.own_N, sorted, (uint64_t)nall, c.dist_gid.as<uint32_t>());
     ELBA_HIP(hipStreamSynchronize(s));
     c.dist_nall = nall;
 }
 
-void stage_dist_panel(Ctx &c, int nranks, const uint64_t *bounds_host, bool fill, void *d_send, uint64_t *counts_or_offsets_host)
+void stage_dist_panel(Ctx &c, int nranks, const uint64_t *bounds_host, const uint64_t *win_lo_host, const uint64_t *win_hi_host, bool fill, void *d_send, uint64_t *counts_or_offsets_host)
 {
-    ELBA_REQUIRE(c.have_counts && c.dist_owner && c.dist_nall >= 0, ELBA_ERR_STATE, "dist_panel: call dist_set_global_kmers first");
+    ELBA_REQUIRE(c.own_N >= 0 && c.dist_nall >= 0 && c.own_colptr.p, ELBA_ERR_STATE, "dist_panel: call dist_count_records and dist_set_kmer_id_base (or dist_set_global_kmers) first");
     ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS, ELBA_ERR_INVALID_ARG, "dist_panel: 1..64 ranks");
+    ELBA_REQUIRE((win_lo_host == nullptr) == (win_hi_host == nullptr), ELBA_ERR_INVALID_ARG, "dist_panel: both window arrays or none");
     hipStream_t s = c.stream;
-    c.ws_scan.reserve((size_t)(2 * MAX_RANKS + 2) * 8);
+    c.ws_scan.reserve((size_t)(4 * MAX_RANKS + 2) * 8);
     unsigned long long *dcnt = c.ws_scan.as<unsigned long long>();
-    uint64_t *dbounds = c.ws_scan.as<uint64_t>() + MAX_RANKS;
+    uint64_t *dbounds = c.ws_scan.as<uint64_t>() + MAX_RANKS, *dwin = c.ws_scan.as<uint64_t>() + 2 * MAX_RANKS + 2;
     if (fill) ELBA_HIP(hipMemcpyAsync(dcnt, counts_or_offsets_host, (size_t)nranks * 8, hipMemcpyHostToDevice, s));
     else ELBA_HIP(hipMemsetAsync(dcnt, 0, MAX_RANKS * 8, s));
     ELBA_HIP(hipMemcpyAsync(dbounds, bounds_host, (size_t)(nranks + 1) * 8, hipMemcpyHostToDevice, s));
-    if (c.N > 0) {
-        const unsigned nb = (unsigned)((c.N + 255) / 256);
-        if (fill) hipLaunchKernelGGL((k_panel<true>), dim3(nb), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.dist_gid.as<uint32_t>(), (uint64_t)c.N, dbounds, (uint32_t)nranks, dcnt, static_cast<uint64_t *>(d_send));
-        else hipLaunchKernelGGL((k_panel<false>), dim3(nb), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.dist_gid.as<uint32_t>(), (uint64_t)c.N, dbounds, (uint32_t)nranks, dcnt, (uint64_t *)nullptr);
+    if (win_lo_host) {
+        for (int r = 0; r < nranks; ++r)
+            ELBA_REQUIRE(win_lo_host[r] >= bounds_host[r] && win_lo_host[r] <= win_hi_host[r] && win_hi_host[r] <= bounds_host[r + 1], ELBA_ERR_INVALID_ARG, "dist_panel: a row block must lie inside its rank's rows");
+        ELBA_HIP(hipMemcpyAsync(dwin, win_lo_host, (size_t)nranks * 8, hipMemcpyHostToDevice, s));
+        ELBA_HIP(hipMemcpyAsync(dwin + nranks, win_hi_host, (size_t)nranks * 8, hipMemcpyHostToDevice, s));
+    }
+    const uint64_t *win = win_lo_host ? dwin : nullptr;
+    if (c.own_N > 0) {
+        const unsigned nb = (unsigned)((c.own_N + 255) / 256);
+        if (fill) hipLaunchKernelGGL((k_panel<true>), dim3(nb), dim3(256), 0, s, c.own_colptr.as<uint32_t>(), c.own_csc.as<uint64_t>(), c.dist_gid.as<uint32_t>(), (uint64_t)c.own_N, dbounds, (uint32_t)nranks, win, dcnt, static_cast<uint64_t *>(d_send));
+        else hipLaunchKernelGGL((k_panel<false>), dim3(nb), dim3(256), 0, s, c.own_colptr.as<uint32_t>(), c.own_csc.as<uint64_t>(), c.dist_gid.as<uint32_t>(), (uint64_t)c.own_N, dbounds, (uint32_t)nranks, win, dcnt, (uint64_t *)nullptr);
     }
     if (!fill) ELBA_HIP(hipMemcpyAsync(counts_or_offsets_host, dcnt, (size_t)nranks * 8, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
@@ -1256,7 +1273,6 @@ void stage_dist_set_panel(Ctx &c, const void *d_rec, int64_t nrec, int64_t M_tot
         N_local = (int64_t)nd;
     }
     c.A_has_kmers = false;
-    c.dist_owner = false;
     finish_matrix_from_sorted_csc(c, M_total, N_local, nrec, c.ws_e.as<uint64_t>(), 0, c.ws_f.as<uint64_t>(), row_lo, row_hi);
     c.N_global = N_total;
 }

@@ -80,6 +80,8 @@ class HipBackend:
         L.elba_dist_set_global_kmers.restype = i32; L.elba_dist_set_global_kmers.argtypes = [vp, vp, i64]
         L.elba_dist_panel_counts.restype = i32; L.elba_dist_panel_counts.argtypes = [vp, i32, vp, vp]
         L.elba_dist_panel_fill.restype = i32; L.elba_dist_panel_fill.argtypes = [vp, i32, vp, vp, vp]
+        L.elba_dist_panel_counts_win.restype = i32; L.elba_dist_panel_counts_win.argtypes = [vp, i32, vp, vp, vp, vp]
+        L.elba_dist_panel_fill_win.restype = i32; L.elba_dist_panel_fill_win.argtypes = [vp, i32, vp, vp, vp, vp, vp]
         L.elba_dist_set_panel.restype = i32; L.elba_dist_set_panel.argtypes = [vp, vp, i64, i64, i64, i64, i64, C.POINTER(capi.MatrixStats)]
         L.elba_dist_set_all_reads.restype = i32; L.elba_dist_set_all_reads.argtypes = [vp, vp, i64, vp, vp, i64]
 
@@ -167,6 +169,17 @@ class HipBackend:
         b = np.ascontiguousarray(bounds, dtype=np.uint64)
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.e._check(self.L.elba_dist_panel_fill(self.h, nranks, b.ctypes.data, send.data_ptr() if send.numel() else None, off.ctypes.data))
+
+    def panel_counts_win(self, nranks, bounds, win_lo, win_hi):
+        b = np.ascontiguousarray(bounds, dtype=np.uint64); lo = np.ascontiguousarray(win_lo, dtype=np.uint64); hi = np.ascontiguousarray(win_hi, dtype=np.uint64)
+        out = np.zeros(nranks, dtype=np.uint64)
+        self.e._check(self.L.elba_dist_panel_counts_win(self.h, nranks, b.ctypes.data, lo.ctypes.data, hi.ctypes.data, out.ctypes.data))
+        return out.astype(np.int64)
+
+    def panel_fill_win(self, nranks, bounds, win_lo, win_hi, send, offsets):
+        b = np.ascontiguousarray(bounds, dtype=np.uint64); lo = np.ascontiguousarray(win_lo, dtype=np.uint64); hi = np.ascontiguousarray(win_hi, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.e._check(self.L.elba_dist_panel_fill_win(self.h, nranks, b.ctypes.data, lo.ctypes.data, hi.ctypes.data, send.data_ptr() if send.numel() else None, off.ctypes.data))
 
     def set_panel(self, rec, m_total, n_total, row_lo, row_hi):
         st = capi.MatrixStats()
@@ -274,8 +287,9 @@ class DistributedOverlap:
         return allw, ns
 
     # ---- stages -----------------------------------------------------------------------------------------------------
-    def build_kmer_matrix(self):
-        """get_kmer_count_map_keys/values + create_kmer_matrix + Transpose, distributed.  Returns (kmer stats, matrix stats)."""
+    def build_kmer_matrix(self, row_batches=1):
+        """get_kmer_count_map_keys/values + create_kmer_matrix + Transpose, distributed.  Returns (kmer stats, matrix stats).
+        row_batches > 1: the owners are set up and the caller loads the panels row block by row block (load_row_block)."""
         W = self.world
         torch = self.be.torch
         # owners: value ranges balanced on the all-reduced histogram of the instances (4096 bins: 32 KB per rank)
@@ -301,23 +315,50 @@ class DistributedOverlap:
         n_total = int(sum(ns))
         self.be.set_kmer_id_base(int(sum(ns[:self.rank])), n_total)
         del recv
-        # exchange #2: column panels to the owners of the reads
-        pc = self.be.panel_counts(W, self.bounds)
-        prc = self._exchange_counts(pc)
-        send = self.be.empty_records(int(pc.sum()))
-        self.be.panel_fill(W, self.bounds, send, np.concatenate([[0], np.cumsum(pc)[:-1]]))
-        panel = self._all_to_all_records(send, pc, prc)
-        del send
-        m_total = int(self.bounds[-1])
-        ms = self.be.set_panel(panel, m_total, n_total, int(self.bounds[self.rank]), int(self.bounds[self.rank + 1]))
+        self.n_total = n_total
         ks = dict(ks)
         ks["instances"] = int(sc.sum())          # instances enumerated from THIS rank's reads
         ks["nreads"] = self.nlocal
-        ms = dict(ms)
+        self.exchange_bytes = dict(instances=int(sc.sum()) * 8 * (kw + 1), panels=0)
+        if row_batches > 1:
+            self.row_batches = row_batches
+            return ks, None                      # the caller walks the row blocks: load_row_block(t), create_seed_matrix(), export_csr()
+        self.row_batches = 1
+        ms = self.load_row_block(0)
+        return ks, ms
+
+    def row_block(self, rank, t):
+        """Rows [lo, hi) of rank `rank` in row block t of self.row_batches (equal read counts; the last block takes the remainder)."""
+        lo, hi = int(self.bounds[rank]), int(self.bounds[rank + 1])
+        per = -(-(hi - lo) // self.row_batches) if hi > lo else 0
+        return min(hi, lo + t * per), min(hi, lo + (t + 1) * per)
+
+    def load_row_block(self, t):
+        """Exchange #2 for row block t of every rank (all ranks call this together): every column, whole, to each rank that has one of its
+        reads in that rank's block; then the block's panel becomes the context's A.  One block = the whole shard unless build_kmer_matrix was
+        given row_batches > 1 (a shard whose full panel would not fit: dense columns reach nearly every rank; the reference batches its
+        exchange too, include/KmerOps.hpp:33-56)."""
+        W = self.world
+        if self.row_batches == 1:
+            pc = self.be.panel_counts(W, self.bounds)
+        else:
+            wl = np.array([self.row_block(r, t)[0] for r in range(W)], dtype=np.int64); wh = np.array([self.row_block(r, t)[1] for r in range(W)], dtype=np.int64)
+            pc = self.be.panel_counts_win(W, self.bounds, wl, wh)
+        prc = self._exchange_counts(pc)
+        send = self.be.empty_records(int(pc.sum()))
+        if self.row_batches == 1:
+            self.be.panel_fill(W, self.bounds, send, np.concatenate([[0], np.cumsum(pc)[:-1]]))
+        else:
+            self.be.panel_fill_win(W, self.bounds, wl, wh, send, np.concatenate([[0], np.cumsum(pc)[:-1]]))
+        panel = self._all_to_all_records(send, pc, prc)
+        del send
+        m_total = int(self.bounds[-1])
+        self.block = self.row_block(self.rank, t) if self.row_batches > 1 else (int(self.bounds[self.rank]), int(self.bounds[self.rank + 1]))
+        ms = dict(self.be.set_panel(panel, m_total, self.n_total, self.block[0], self.block[1]))
         ms["panel_records"] = int(prc.sum())
         ms["nnz"] = int(prc.sum())
-        self.exchange_bytes = dict(instances=int(sc.sum()) * 8 * (kw + 1), panels=int(pc.sum()) * 16)
-        return ks, ms
+        self.exchange_bytes["panels"] += int(pc.sum()) * 16
+        return ms
 
     def create_seed_matrix(self):
         return self.be.create_seed_matrix()
@@ -396,5 +437,5 @@ class DistributedOverlap:
         return S
 
     def export_csr(self):
-        """This rank's rows of B (global column ids)."""
-        return self.be.export_csr(int(self.bounds[self.rank]), int(self.bounds[self.rank + 1]))
+        """This rank's rows of B (global column ids) — of the current row block when the shard is walked in blocks."""
+        return self.be.export_csr(self.block[0], self.block[1])

@@ -326,6 +326,12 @@ int  elba_dist_set_global_kmers(elba_ctx *ctx, const void *d_all_kmers, int64_t 
  * owner sends to rank r: every column, whole, for every rank that owns at least one of its reads */
 int  elba_dist_panel_counts(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, uint64_t *counts);
 int  elba_dist_panel_fill(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, void *d_send, const uint64_t *offsets);
+/* Row-block batching: the same with one ROW BLOCK per rank, [win_lo[r], win_hi[r]) inside rank r's rows — a column goes to rank r only
+ * if it has a read in that block.  A rank whose whole panel would not fit (dense columns: nearly every column reaches every rank, cf.
+ * the reference's batched exchange, include/KmerOps.hpp:33-56) walks its rows block by block: panel_*_win -> all-to-all ->
+ * elba_dist_set_panel(block) -> elba_create_seed_matrix -> rows of the block -> next block.  The owner's columns stay resident. */
+int  elba_dist_panel_counts_win(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, const uint64_t *win_lo, const uint64_t *win_hi, uint64_t *counts);
+int  elba_dist_panel_fill_win(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, const uint64_t *win_lo, const uint64_t *win_hi, void *d_send, const uint64_t *offsets);
 /* receiver side: the panel of every column touching rows [row_lo,row_hi) -> columns (renumbered by rank among the columns present) + CSR; elba_create_seed_matrix
  * then computes exactly those rows of B (global column ids); elba_export_csr(row_lo,row_hi) / elba_export_dcsc read them */
 int  elba_dist_set_panel(elba_ctx *ctx, const void *d_records, int64_t nrecords, int64_t nreads_total, int64_t nkmers_total,

@@ -223,6 +223,28 @@ class NumpyBackend:
     def _dests(self, bounds, col):
         return np.unique(np.searchsorted(np.asarray(bounds, dtype=np.uint64), col >> np.uint64(32), side="right") - 1)
 
+    def _dests_win(self, bounds, wl, wh, col):
+        reads = col >> np.uint64(32)
+        r = np.searchsorted(np.asarray(bounds, dtype=np.uint64), reads, side="right") - 1
+        ok = (reads >= np.asarray(wl, dtype=np.uint64)[r]) & (reads < np.asarray(wh, dtype=np.uint64)[r])
+        return np.unique(r[ok])
+
+    def panel_counts_win(self, W, bounds, wl, wh):
+        out = np.zeros(W, dtype=np.int64)
+        for col in self.cols:
+            for d in self._dests_win(bounds, wl, wh, col):
+                out[d] += len(col)
+        return out
+
+    def panel_fill_win(self, W, bounds, wl, wh, send, offsets):
+        per = [[] for _ in range(W)]
+        for g, col in zip(self.gid, self.cols):
+            for d in self._dests_win(bounds, wl, wh, col):
+                per[d].append(np.stack([np.full(len(col), g, dtype=np.uint64), col], axis=1))
+        flat = [np.concatenate(p) if p else np.zeros((0, 2), np.uint64) for p in per]
+        rec = np.concatenate(flat) if flat else np.zeros((0, 2), np.uint64)
+        send.copy_(torch.from_numpy(rec.view(np.int64).copy()))
+
     def panel_counts(self, W, bounds):
         out = np.zeros(W, dtype=np.int64)
         for col in self.cols:

@@ -74,6 +74,33 @@ def test_three_ranks_in_process_equal_single_process_oracle():
     assert sum(p[1]["instances"] for p in parts) == o.stat("I")
 
 
+def _run_rank_blocks(rank, world, handle, backend, nblocks):
+    """The shard walked in row blocks: the owners are set up once, every block gets its own panel exchange, SpGEMM and rows of B."""
+    packed, off, lens, _ = _reads()
+    bounds = partition_by_bases(lens, world)
+    a, b = int(bounds[rank]), int(bounds[rank + 1])
+    sp, so, sl = _shard(packed, off, lens, a, b)
+    d = DistributedOverlap(K, LO, UP, rank=rank, world=world, dist=handle, backend=backend)
+    d.set_reads(sp, so, sl, a, bounds)
+    ks, ms = d.build_kmer_matrix(row_batches=nblocks)
+    assert ms is None
+    rows = []
+    for t in range(nblocks):
+        d.load_row_block(t)
+        d.create_seed_matrix()
+        rows.append(d.export_csr())
+    return dist_sim.stitch_rows(rows)
+
+
+def test_row_block_batching_gives_the_same_rows():
+    """A shard whose panel would not fit is walked block by block (elba_dist_panel_*_win): 2 ranks x 3 blocks must stitch to the oracle's B."""
+    o = _expected()
+    parts = dist_sim.run_ranks(2, lambda r, h: _run_rank_blocks(r, 2, h, dist_sim.NumpyBackend(K, LO, UP), 3))
+    B = dist_sim.stitch_rows(parts)
+    oB = o.B()
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+
+
 def test_batched_all_to_all_rounds_give_the_same_result(monkeypatch):
     """The exchange is cut into rounds of at most MAX_RECORDS_PER_PEER records per peer (the reference batches its all-to-all too,
     include/KmerOps.hpp:33-56); force many rounds."""

@@ -128,3 +128,34 @@ def test_multi_word_kmers_sharded_overlap_equals_oracle(k, world):
     assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
     assert sum(p[1]["reliable"] for p in parts) == o.stat("N") and sum(p[1]["entries"] for p in parts) == o.stat("Z")
     assert sum(p[1]["instances"] for p in parts) == o.stat("I")
+
+
+def test_row_block_batching_on_the_gpu():
+    """Row-block batching with the real HIP building blocks (elba_dist_panel_counts_win / _fill_win, the owner's columns kept apart from the
+    panels that overwrite the context's A): 2 ranks x 4 blocks and 3 ranks x 2 blocks stitch to the oracle's B."""
+    reads = elba_amd.synth_reads(35, 250000, 15, 4000, 900, error_rate=0.10, min_len=200)
+    packed, off, lens, _ = reads
+    o = po.Oracle(17, 2, 8); o.count_and_build(packed, off, lens); o.spgemm(4)
+    oB = o.B()
+    for world, nblocks in ((2, 4), (3, 2)):
+        bounds = partition_by_bases(lens, world)
+
+        def body(rank, h):
+            a, b = int(bounds[rank]), int(bounds[rank + 1])
+            sp, so, sl = _shard(packed, off, lens, a, b)
+            d = DistributedOverlap(17, 2, 8, device=0, rank=rank, world=world, dist=h, backend=HipBackend(17, 2, 8, 0))
+            d.set_reads(sp, so, sl, a, bounds)
+            ks, ms = d.build_kmer_matrix(row_batches=nblocks)
+            rows, prod = [], 0
+            for t in range(nblocks):
+                d.load_row_block(t)
+                st = d.create_seed_matrix()
+                prod += st["products"]
+                rows.append(d.export_csr())
+            d.be.e.close()
+            return dist_sim.stitch_rows(rows), prod
+
+        parts = dist_sim.run_ranks(world, body)
+        B = dist_sim.stitch_rows([p[0] for p in parts])
+        assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+        assert sum(p[1] for p in parts) == o.stat("P")
