@@ -107,7 +107,7 @@ EXPORTED_SYMBOLS = [
     "elba_export_csr", "elba_free_csr", "elba_export_kmer_matrix", "elba_free_kmer_matrix", "elba_kmer_histogram", "elba_get_device_view", "elba_set_option",
     "elba_align_seeds", "elba_export_overlaps", "elba_free_overlaps", "elba_set_overlaps", "elba_transitive_reduction", "elba_export_string_graph", "elba_export_read_flags", "elba_set_reads_fasta", "elba_export_reads", "elba_dist_set_all_reads",
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
-    "elba_dist_value_histogram", "elba_dist_set_owner_ranges", "elba_dist_set_kmer_id_base", "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
+    "elba_kmer_hash_owner", "elba_dist_value_histogram", "elba_dist_set_owner_ranges", "elba_dist_set_kmer_id_base", "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
     "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_panel_counts_win", "elba_dist_panel_fill_win", "elba_dist_set_panel",
 ]
 
@@ -165,6 +165,7 @@ def load_library():
     L.elba_kmer_histogram.restype = i32; L.elba_kmer_histogram.argtypes = [vp, vp, i64]
     L.elba_get_device_view.restype = i32; L.elba_get_device_view.argtypes = [vp, C.POINTER(DeviceView)]
     L.elba_set_option.restype = i32; L.elba_set_option.argtypes = [vp, C.c_char_p, i64]
+    L.elba_kmer_hash_owner.restype = i32; L.elba_kmer_hash_owner.argtypes = [vp, vp, i64, i32, vp, vp]
     L.elba_synth_num_reads.restype = i64; L.elba_synth_num_reads.argtypes = [C.POINTER(SynthCfg)]
     L.elba_synth_generate.restype = i32; L.elba_synth_generate.argtypes = [C.POINTER(SynthCfg), C.POINTER(SynthReads)]
     L.elba_synth_free.restype = None; L.elba_synth_free.argtypes = [C.POINTER(SynthReads)]
@@ -266,6 +267,15 @@ class Engine:
         st = MatrixStats()
         self._check(self.L.elba_set_kmer_matrix(self.h, nrows, ncols, len(rows), rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, C.byref(st)))
         return _stats(st)
+
+    def kmer_hash_owner(self, kmers, nprocs):
+        """Kmer::GetHash and GetKmerOwner of the reference, computed on the device: kmers = n x W packed words."""
+        km = np.ascontiguousarray(kmers, dtype=np.uint64)
+        W = 3 if self.k > 64 else (2 if self.k > 32 else 1)
+        n = km.size // W
+        h = np.zeros(n, dtype=np.uint64); ow = np.zeros(n, dtype=np.int32)
+        self._check(self.L.elba_kmer_hash_owner(self.h, km.ctypes.data if n else None, n, int(nprocs), h.ctypes.data, ow.ctypes.data))
+        return h, ow
 
     def set_option(self, name, value):
         self._check(self.L.elba_set_option(self.h, name.encode(), int(value)))

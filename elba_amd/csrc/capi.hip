@@ -455,6 +455,11 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
     });
 }
 
+int elba_kmer_hash_owner(elba_ctx *ctx, const uint64_t *kmers, int64_t n, int nprocs, uint64_t *hash, int32_t *owner)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_ref_hash_owner(c, kmers, n, nprocs, hash, owner); });
+}
+
 int elba_dist_value_histogram(elba_ctx *ctx, uint64_t *hist, int64_t nbins)
 {
     return guarded(ctx, [&](Ctx &c) { stage_dist_value_histogram(c, hist, nbins); });

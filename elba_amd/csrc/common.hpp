@@ -237,6 +237,7 @@ void stage_set_overlaps(Ctx &c, int64_t nreads, const int64_t *rows, const int64
 void stage_transitive_reduction(Ctx &c, double bad_read_cutoff, int fuzz);   // tr.hip
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host);                                   // kmer.hip
 void stage_dist_value_histogram(Ctx &c, uint64_t *hist_host, int64_t nbins);
+void stage_ref_hash_owner(Ctx &c, const uint64_t *kmers_host, int64_t n, int nprocs, uint64_t *hash_host, int32_t *owner_host);
 void stage_dist_set_owner_ranges(Ctx &c, int nranks, const uint32_t *upper_bins);
 void stage_dist_set_kmer_id_base(Ctx &c, int64_t base, int64_t nall);
 void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);

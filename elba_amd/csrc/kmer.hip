@@ -1055,6 +1055,56 @@ void stage_dist_set_kmer_id_base(Ctx &c, int64_t base, int64_t nall)
     c.dist_nall = nall;
 }
 
+// ---- the reference's own k-mer hash and owner, on the device -------------------------------------------------------
+// Kmer::GetHash (src/Kmer.cpp:207-213) = h1 of murmurhash3_x64_128 (src/HashFuncs.cpp:40-117) over the 8 * NLONGS key bytes (the words
+// of `longs`, little-endian, first word first), seed 313; GetKmerOwner (src/KmerOps.cpp:352-359) = (size_t)(double(h) * double(p) /
+// double(UINT64_MAX)).  This build places k-mers by value range instead (the results do not depend on the placement); the reference's
+// placement is offered for callers that want to reproduce it, and checked against the reference's own vectors (tests/golden/kmer_vectors_*).
+namespace {
+__device__ __forceinline__ uint64_t rotl64d(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__global__ void k_ref_hash_owner(const uint64_t *kmers, uint64_t n, int W, int nprocs, uint64_t *hash, int32_t *owner)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t c1 = 0x87c37b91114253d5ULL, c2 = 0x4cf5ad432745937fULL;
+    const uint64_t *w = kmers + (size_t)W * i;
+    uint64_t h1 = 313, h2 = 313;
+    if (W >= 2) {                                   // one 16-byte block
+        uint64_t k1 = w[0], k2 = w[1];
+        k1 *= c1; k1 = rotl64d(k1, 31); k1 *= c2; h1 ^= k1;
+        h1 = rotl64d(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+        k2 *= c2; k2 = rotl64d(k2, 33); k2 *= c1; h2 ^= k2;
+        h2 = rotl64d(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+    }
+    if (W != 2) {                                   // an 8-byte tail: the only word (W == 1) or the third (W == 3)
+        uint64_t k1 = w[W - 1];
+        k1 *= c1; k1 = rotl64d(k1, 31); k1 *= c2; h1 ^= k1;
+    }
+    const uint64_t len = 8ull * (uint64_t)W;
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = mix64(h1); h2 = mix64(h2);                 // fmix64
+    h1 += h2;
+    if (hash) hash[i] = h1;
+    if (owner) owner[i] = (int32_t)(size_t)((double)h1 * (double)nprocs / (double)0xFFFFFFFFFFFFFFFFull);
+}
+}  // namespace
+
+void stage_ref_hash_owner(Ctx &c, const uint64_t *kmers_host, int64_t n, int nprocs, uint64_t *hash_host, int32_t *owner_host)
+{
+    ELBA_REQUIRE(n >= 0 && (n == 0 || kmers_host) && nprocs >= 1, ELBA_ERR_INVALID_ARG, "kmer_hash_owner: bad argument");
+    if (n == 0) return;
+    hipStream_t s = c.stream;
+    const int W = kmer_words(c.cfg.k);
+    DevBuf dk, dh, dow;
+    dk.reserve((size_t)n * W * 8); dh.reserve((size_t)n * 8); dow.reserve((size_t)n * 4);
+    ELBA_HIP(hipMemcpyAsync(dk.p, kmers_host, (size_t)n * W * 8, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_ref_hash_owner, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, dk.as<uint64_t>(), (uint64_t)n, W, nprocs, dh.as<uint64_t>(), dow.as<int32_t>());
+    if (hash_host) ELBA_HIP(hipMemcpyAsync(hash_host, dh.p, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    if (owner_host) ELBA_HIP(hipMemcpyAsync(owner_host, dow.p, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
 void stage_dist_count_owners(Ctx &c, int nranks, uint64_t *counts_host)
 {
     ELBA_REQUIRE(c.have_reads, ELBA_ERR_STATE, "dist_count_owners: no reads");

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             k = draw();
         }
     };
-    if (tid == 0) misc[D_NEXT] = resolve(draw());
+    if (tid == 0) { const uint32_t r0 = resolve(draw()); misc[D_NEXT] = r0; if (r0 != NOROW) { misc[D_NEXT + 1] = p.a_rowptr[r0]; misc[D_NEXT + 2] = p.a_rowptr[r0 + 1]; } }
     __syncthreads();
     uint32_t fb_seen = 0;
     bool fb_settled = false;
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
     for (;;) {
         const uint32_t i = sfirst(misc[D_NEXT]);
         if (i == NOROW) break;
-        uint32_t nidx = 0, nrow = UNRESOLVED;
+        uint32_t nidx = 0, nrow = UNRESOLVED, nrs = 0, nre = 0;
         if (tid == 0 && qtried < 8u) nidx = draw();      // the row after this one: the round trip hides behind this row
-        const uint32_t rs = sfirst(p.a_rowptr[i]), nnz = sfirst(p.a_rowptr[i + 1]) - rs;
+        const uint32_t rs = sfirst(misc[D_NEXT + 1]), nnz = sfirst(misc[D_NEXT + 2]) - rs;      // (the row's bounds travel with its id: thread 0 fetched them a row ago)
         // distinct partners of the row <= min(products, reads); products <= nnz * longest column
         const unsigned long long prod_ub = (unsigned long long)nnz * p.max_col;
         const uint32_t ub_i = prod_ub < (unsigned long long)p.Mcols ? (uint32_t)prod_ub : p.Mcols;
@@ -95,7 +95,16 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
         auto resolve_early = [&]() {
             if (tid == 0 && qtried < 8u) { const unsigned long long idx = (unsigned long long)nidx * 8u + qshard; if (idx < nrows) nrow = queue[idx]; }
         };
-        auto publish_next = [&]() { if (tid == 0) misc[D_NEXT] = nrow != UNRESOLVED ? nrow : (qtried < 8u ? resolve(nidx) : NOROW); };
+        // ... and the next row's bounds with the second round's (they depend on the queue entry)
+        auto bounds_early = [&]() { if (tid == 0 && nrow != UNRESOLVED && nrow != NOROW) { nrs = p.a_rowptr[nrow]; nre = p.a_rowptr[nrow + 1]; } };
+        auto publish_next = [&]() {
+            if (tid == 0) {
+                const bool early = nrow != UNRESOLVED;
+                if (!early) nrow = qtried < 8u ? resolve(nidx) : NOROW;
+                if (nrow != NOROW && (!early || nre == 0)) { nrs = p.a_rowptr[nrow]; nre = p.a_rowptr[nrow + 1]; }      // (short rows: fetched here, one exposed round trip)
+                misc[D_NEXT] = nrow; misc[D_NEXT + 1] = nrs; misc[D_NEXT + 2] = nre;
+            }
+        };
 
         if (!GLOBAL && p.use_feedback) {
             // Self-correction inside a call (no prior for this matrix): rows already done tell how many distinct partners a row entry
@@ -230,7 +239,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 uint2 c_nn[DK];
                 gather(x_nxt, c_nxt, t0 + EPR);                                                                                                   // (2)
                 load_ce(c_nn, t0 + 2u * EPR);
-                if (t0 == 0) resolve_early();
+                if (t0 == 0) resolve_early(); else if (t0 == EPR) bounds_early();
 #pragma unroll
                 for (int k = 0; k < DK; ++k) {                                                                                                    // (3)
                     const uint32_t seq = ((t0 + (uint32_t)k * EPT + grp) << fbits) | (2u * sub);

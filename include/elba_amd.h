@@ -296,6 +296,11 @@ int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
  * 2 up to 63, 3 up to 95; NLONGS of include/Kmer.hpp:95-97), most significant word first.
  * Exchange #2 records: two words, (global k-mer id, global read id << 32 | pos), a column's entries contiguous and ordered by (read,pos). */
 #define ELBA_MAX_RANKS 64
+/* The reference's own k-mer hash and owner on the device: Kmer::GetHash (src/Kmer.cpp:207-213: h1 of murmurhash3_x64_128, seed 313, over
+ * the 8 * NLONGS key bytes) and GetKmerOwner (src/KmerOps.cpp:352-359: (size_t)(double(h) * nprocs / double(UINT64_MAX))).  kmers: n
+ * packed k-mers of W = NLONGS adjacent words each (first word first); hash / owner: host outputs, either may be NULL. */
+int  elba_kmer_hash_owner(elba_ctx *ctx, const uint64_t *kmers, int64_t n, int nprocs, uint64_t *hash, int32_t *owner);
+
 /* Owners by VALUE RANGE.  The value space of the packed canonical k-mers is cut into ELBA_OWNER_BINS equal bins (leading 12 bits of the
  * first word); elba_dist_value_histogram counts this rank's instances per bin; the driver all-reduces the histograms, picks boundaries
  * that balance the instances and announces them with elba_dist_set_owner_ranges: rank r owns the bins [upper_bins[r-1], upper_bins[r]),

@@ -376,3 +376,32 @@ def test_reference_kmer_numbering_through_set_kmer_matrix():
     Bc = oc.B()
     assert (gB["rowptr"] == Bc["rowptr"]).all() and (gB["col"] == Bc["col"].astype(np.int64)).all() and (gB["val"]["numshared"] == Bc["val"]["numshared"]).all()
     e.close()
+
+
+@pytest.mark.parametrize("k", [17, 31, 33, 65])
+def test_reference_kmer_hash_and_owner_on_the_device(k):
+    """SURVEY.md a3 / a4: Kmer::GetHash (murmur3_x64_128, seed 313, h1) and GetKmerOwner computed on the GPU.  One-word k-mers: the reference's
+    own vectors (tests/golden/kmer_vectors_k*.txt: murmur of rep and of fwd, generated by the reference's compiled Kmer<1>::GetHash); multi-word
+    k-mers: the oracle's murmur3 (pinned to the reference's HashFuncs vectors, tests/golden/murmur_vectors.txt) over the 16 / 24 key bytes.
+    Owners: the reference's double-precision formula (oracle/elba_oracle.c:orc_kmer_owner, src/KmerOps.cpp:352-359) for p in 1..16."""
+    import ctypes as C
+    L = po.lib()
+    e = elba_amd.Engine(k, 2, 8)
+    if k <= 31:
+        rows = [line.split() for line in open(os.path.join(G, "kmer_vectors_k%d.txt" % k)) if line[0] != "#"]
+        km = np.array([int(r[3], 16) for r in rows] + [int(r[1], 16) for r in rows], dtype=np.uint64)
+        want = np.array([int(r[4], 16) for r in rows] + [int(r[5], 16) for r in rows], dtype=np.uint64)
+        W = 1
+    else:
+        W = 3 if k > 64 else 2
+        km = np.random.default_rng(k).integers(0, 2**63, size=(500, W), dtype=np.int64).astype(np.uint64)
+        want = np.zeros(len(km), dtype=np.uint64)
+        out = (C.c_uint64 * 2)()
+        for i in range(len(km)):
+            L.orc_murmur3_x64_128(km[i].tobytes(), 8 * W, 313, out)
+            want[i] = out[0]
+    for p in (1, 2, 4, 8, 16):
+        h, ow = e.kmer_hash_owner(km, p)
+        assert (h == want).all()
+        assert ow.tolist() == [L.orc_kmer_owner(C.c_uint64(int(x)), p) for x in want.tolist()] and ow.max() < p
+    e.close()
