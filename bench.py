@@ -15,8 +15,9 @@ pays, as ELBA does.  Buffers stay allocated.  The steady state (hints kept betwe
 Workload at N = 1: BASELINE.json configs[2] restated per SURVEY.md §8d-3 ("200k-long-reads": 200 100 reads of ~10 kb, 66.7 Mb genome,
 30x, 15 % sub/ins/del error, k=17, L=2, U=8, seed 2) — the configuration the metric's scaling is quoted on, and it fits one GPU.
 At N > 1 the SAME read set is sharded by contiguous row blocks over the ranks (strong scaling); k-mer instances go to the owner of
-their value range and come back as column panels (two RCCL all-to-alls, a 32 KB all-reduce and a scalar all-gather while A is built);
-the step itself has no data-path collective.
+their value range and come back as column panels (two RCCL all-to-alls, a 32 KB all-reduce and a scalar all-gather while A is built).
+The step then has ONE collective: every pair of rows that live on two ranks is accumulated by one of them and its mirrored entry (32 bytes)
+is sent to the other — each rank does 1/N of the one-GPU work instead of computing every cross-rank pair twice.
 `--workload ecsample30x-like` is BASELINE.json configs[1] (16 893 reads), kept as a parity-test / profiling case.
 """
 import argparse
@@ -112,7 +113,7 @@ def main():
         t0 = time.perf_counter(); ks, ms = runner.build_kmer_matrix(); barrier_sync(); t_kmer_wall = time.perf_counter() - t0
         eng = runner.be.e
         bases_local = int(runner._reads[2].astype(np.int64).sum())
-        extra_cfg = {"partition": "1D read rows x value-range-owned k-mer columns", "exchange": "RCCL all_to_all_single x2 (+ a 32 KB all_reduce and a scalar all_gather) while A is built; none inside the step",
+        extra_cfg = {"partition": "1D read rows x value-range-owned k-mer columns", "exchange": "RCCL all_to_all_single x2 (+ a 32 KB all_reduce and a scalar all_gather) while A is built; inside the step ONE all_to_all_single of mirrored entries (32 B each): a pair of rows on two ranks is accumulated by one of them",
                      "exchange_bytes_this_rank": getattr(runner, "exchange_bytes", None)}
     step = runner.create_seed_matrix
 

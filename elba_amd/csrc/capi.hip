@@ -225,6 +225,27 @@ int elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats)
     });
 }
 
+int elba_seed_matrix_begin(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, uint64_t *send_counts)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_seed_matrix_begin(c, nranks, read_bounds, send_counts); });
+}
+
+int elba_seed_matrix_fill(elba_ctx *ctx, void *d_send, const uint64_t *offsets)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(offsets, ELBA_ERR_INVALID_ARG, "seed_matrix_fill: null offsets");
+        stage_seed_matrix_fill(c, d_send, offsets);
+    });
+}
+
+int elba_seed_matrix_end(elba_ctx *ctx, const void *d_recv, int64_t nrecords, elba_overlap_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        stage_seed_matrix_end(c, d_recv, nrecords);
+        if (stats) *stats = c.ostats;
+    });
+}
+
 int elba_align_seeds(elba_ctx *ctx, int mat, int mis, int gap, int dropoff, elba_align_stats *stats)
 {
     return guarded(ctx, [&](Ctx &c) {

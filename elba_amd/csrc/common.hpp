@@ -217,6 +217,11 @@ struct Ctx {
     int64_t b_cap_entries = 0;      // capacity of b_col/b_val the next overlap call may assume (0 = unknown: size it after the numeric pass)
     uint64_t ov_calls = 0;          // steady-state overlap calls so far (phase events are recorded on every cfg.timing_stride-th)
     uint32_t ov_prior_q16 = 0;      // distinct-partner / product ratio measured by the previous overlap call (x 65536), 0 = unknown
+    // sharded call with mirror exchange (spgemm.hip: stage_seed_matrix_begin / _fill / _end)
+    int ov_phase = 0;               // 1: begin has run (numeric done, staged records waiting), end not yet
+    int ov_pend_passes = 1; bool ov_pend_timed = false; float ov_pend_ms[3] = {0, 0, 0};
+    std::vector<uint64_t> ov_remote_bounds;
+    DevBuf ov_remote;               // mirror images received from other ranks (32-byte records)
 
     EventTimer t_total, t_a, t_b, t_c;
     struct PinnedHost { void *p = nullptr; size_t cap = 0; void reserve(size_t n) { if (n <= cap) return; if (p) (void)hipHostFree(p); p = nullptr; cap = 0; ELBA_HIP(hipHostMalloc(&p, n, hipHostMallocDefault)); cap = n; } ~PinnedHost() { if (p) (void)hipHostFree(p); } };
@@ -231,6 +236,9 @@ void stage_count_kmers(Ctx &c);                                   // kmer.hip
 void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
 void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip
 void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
+void stage_seed_matrix_begin(Ctx &c, int nranks, const uint64_t *bounds_host, uint64_t *send_counts_host);
+void stage_seed_matrix_fill(Ctx &c, void *d_send, const uint64_t *offsets_host);
+void stage_seed_matrix_end(Ctx &c, const void *d_recv, int64_t nrecv);
 void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff);   // align.hip
 void stage_dist_set_all_reads(Ctx &c, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads_total);   // align.hip
 void stage_set_overlaps(Ctx &c, int64_t nreads, const int64_t *rows, const int64_t *cols, const elba_overlap_t *vals, int64_t n);   // tr.hip

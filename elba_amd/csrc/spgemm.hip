@@ -464,10 +464,189 @@ int bits_for_u(uint64_t v)
 // starting tiers, which tiers and sorts got rows — and `cold_calls` (elba_set_option) or a new matrix forgets it: then the ratio starts at
 // 1/4 and the kernel corrects itself from the rows already done, every tier is launched.  Capacities (staging, output) start from nnz(A)
 // and only ever grow; a call that overflows them is repeated with what it measured.
-static void create_seed_matrix_direct(Ctx &c)
+// ---- mirror exchange between ranks (sharded call with global pair ownership) ---------------------------------------------------------
+// A pair {i, j} whose rows live on two ranks is accumulated by ONE of them (owns_pair's parity rule, whatever the window); the other rank
+// receives the mirrored entry.  k_remote_mirror walks the staged records of this rank's rows, picks those whose partner row is another
+// rank's and counts (FILL = false) or writes (FILL = true) their mirror images grouped by destination rank: a block takes 64 rows, counts
+// per destination in LDS, reserves its share of every destination's segment with one atomic each, then writes.
+// Record on the wire (32 bytes): a = (destination row j, partner i, position in j, position in i), b = (the same of seeds[1], numshared, 0).
+constexpr int REMOTE_MAX_RANKS = 64, REMOTE_ROWS_PER_BLOCK = 64;
+struct RemoteParams {
+    const uint32_t *row_cnt; const unsigned long long *row_off; const StageRec *tmp;
+    uint32_t row_lo, row_hi, nranks;
+    uint64_t bounds[REMOTE_MAX_RANKS + 1];
+};
+__device__ __forceinline__ uint32_t remote_rank_of(const RemoteParams &p, uint64_t read)
+{
+    uint32_t lo = 0, hi = p.nranks;             // last r with bounds[r] <= read
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (p.bounds[mid] <= read) lo = mid; else hi = mid; }
+    return lo;
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_remote_mirror(RemoteParams p, unsigned long long *cnt_or_cursor, StageRec *send)
+{
+    __shared__ uint32_t cnt[REMOTE_MAX_RANKS], fill[REMOTE_MAX_RANKS];
+    __shared__ unsigned long long base[REMOTE_MAX_RANKS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t r0 = p.row_lo + blockIdx.x * REMOTE_ROWS_PER_BLOCK, r1 = min(r0 + (uint32_t)REMOTE_ROWS_PER_BLOCK, p.row_hi);
+    if (tid < REMOTE_MAX_RANKS) { cnt[tid] = 0; fill[tid] = 0; }
+    __syncthreads();
+    for (uint32_t i = r0 + w; i < r1; i += 4) {
+        const uint32_t n = p.row_cnt[i];
+        const unsigned long long off = p.row_off[i];
+        for (uint32_t t = lane; t < n; t += 64) {
+            const uint32_t j = p.tmp[off + t].a.x;
+            if (j != i && (j < p.row_lo || j >= p.row_hi)) atomicAdd(&cnt[remote_rank_of(p, j)], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < p.nranks && cnt[tid]) {
+        const unsigned long long b = atomicAdd(&cnt_or_cursor[tid], (unsigned long long)cnt[tid]);
+        if (FILL) base[tid] = b;
+    }
+    if (!FILL) return;
+    __syncthreads();
+    for (uint32_t i = r0 + w; i < r1; i += 4) {
+        const uint32_t n = p.row_cnt[i];
+        const unsigned long long off = p.row_off[i];
+        for (uint32_t t = lane; t < n; t += 64) {
+            const uint4 a = p.tmp[off + t].a;
+            const uint32_t j = a.x;
+            if (j != i && (j < p.row_lo || j >= p.row_hi)) {
+                const uint4 b = p.tmp[off + t].b;
+                const uint32_t d = remote_rank_of(p, j);
+                const unsigned long long at = base[d] + atomicAdd(&fill[d], 1u);
+                send[at].a = make_uint4(j, i, a.w, a.z);
+                send[at].b = make_uint4(b.y, b.x, b.z, 0u);
+            }
+        }
+    }
+}
+
+// received mirror images: every record draws its slot in its row's mirror extent (the ticket lands in b.w) before the row pointers are summed
+__global__ void k_ingest_remote(StageRec *rem, unsigned long long n, uint32_t *low_cnt, uint32_t row_lo, uint32_t row_hi, unsigned long long *bad, unsigned long long *nupper)
+{
+    const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long up = 0;
+    if (r < n) {
+        const uint32_t j = rem[r].a.x;
+        if (j < row_lo || j >= row_hi) atomicAdd(bad, 1ull);      // not one of this rank's rows: the driver mixed up its buffers
+        else { rem[r].b.w = atomicAdd(&low_cnt[j], 1u); up = rem[r].a.y > j ? 1u : 0u; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) up += __shfl_xor(up, d, 64);
+    if ((threadIdx.x & 63) == 0 && up) atomicAdd(nupper, up);
+}
+
+// ... and are placed like the local mirror images (k_mirror), once the row pointers are known
+__global__ void k_place_remote(FinParams p, const StageRec *rem, unsigned long long n)
+{
+    for (unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (unsigned long long)gridDim.x * blockDim.x) {
+        const uint4 a = rem[r].a, b = rem[r].b;
+        if (a.x < p.row_lo || a.x >= p.row_hi) continue;
+        const int64_t at = p.b_rowptr[a.x] + (int64_t)b.w;
+        if (at >= p.b_cap) continue;
+        if (p.mir16) reinterpret_cast<uint4 *>(p.mir)[at] = make_uint4(a.y, a.z | a.w << 16, b.x | b.y << 16, b.z);
+        else { p.mir[at].a = make_uint4(a.y, 0xFFFFFFFFu, a.z, a.w); p.mir[at].b = make_uint4(b.x, b.y, b.z, 0u); }
+    }
+}
+
+// row pointers, mirror pass (local pairs, and the mirrored entries other ranks sent: `remote`), per-row column sort + move to b_col / b_val
+static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &skipped_sorts, const StageRec *remote, int64_t nremote)
 {
     hipStream_t s = c.stream;
+    const int64_t M = c.M;
+    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? M : c.row_hi, nrows = row_hi - row_lo;
+    const int cus = c.num_cus;
+    const bool mir16 = c.pos16 && !getenv("ELBA_MIR32");
+    FinParams f{};
+    f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = c.ov_tmp.as<StageRec>(); f.mir = half ? c.ov_mir.as<StageRec>() : nullptr; f.half = half; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
+    f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
+    f.M = (uint32_t)M; f.row_lo = (uint32_t)row_lo; f.row_hi = (uint32_t)row_hi; f.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1); f.ctr = c.ov_counters.as<OvCounters>();
+    f.b_cap = c.b_cap_entries;
+    f.mir16 = mir16 ? 1u : 0u;
+    const int gblocks = 32;
+    uint64_t sstride = 2;
+    while (sstride < (uint64_t)M) sstride <<= 1;
+    c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
+    f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
+    if (M + 1 <= (1 << 17)) {
+        hipLaunchKernelGGL(k_row_pointers, dim3((unsigned)((M + 1 + RP_TILE - 1) / RP_TILE)), dim3(256), 0, s, f);
+    } else {
+        c.ov_sum_tmp.reserve((size_t)(M + 2) * 4);
+        f.sum_tmp = c.ov_sum_tmp.as<uint32_t>();
+        hipLaunchKernelGGL(k_sum_counts, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, s, f);
+        exclusive_scan_u32_to_i64(s, f.sum_tmp, c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
+    }
+    if (nrows > 0) {
+        int nb = (int)((nrows + 3) / 4);
+        if (nb > cus * 32) nb = cus * 32;
+        hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
+        if (nremote > 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((nremote + 255) / 256, (int64_t)cus * 32)), dim3(256), 0, s, f, remote, (unsigned long long)nremote);
+        hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
+        skipped_sorts = 0;
+        if (all_sorts || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
+        else skipped_sorts |= 1u;
+        if (all_sorts || c.ov_sort_used[1]) hipLaunchKernelGGL(k_finalize_huge, dim3(gblocks), dim3(256), 0, s, f);
+        else skipped_sorts |= 2u;
+    }
+}
+
+// fold the counter read-back into elba_overlap_stats and remember the hints for the next call; `extra_*`: entries / strict-upper entries that
+// arrived from other ranks (mirror exchange)
+static void ov_finish_stats(Ctx &c, OvCounters &hc, elba_overlap_stats &st, int passes, bool was_timed, float ms_tot, float ms_sym, float ms_num, float ms_fin, int64_t extra_nnz, int64_t extra_upper)
+{
     const int64_t M = c.M, N = c.N, Z = c.Z;
+#ifdef ELBA_PHASE_CLOCK
+    fprintf(stderr, "[elba phase] wave-0 cycles summed over %llu workgroups: header=%llu init=%llu accumulate=%llu handoff=%llu sweep=%llu reserve=%llu store=%llu | rows %u,%u,%u,%u,%u,%u\n",
+            hc.phase[10], hc.phase[0], hc.phase[1], hc.phase[2], hc.phase[3], hc.phase[4], hc.phase[5], hc.phase[6],
+            hc.tier_count[0], hc.tier_count[1], hc.tier_count[2], hc.tier_count[3], hc.tier_count[4], hc.tier_count[5]);
+#endif
+    for (int sh = 0; sh < NUM_SHARDS; ++sh) {       // fold the statistics shards
+        const OvShard &x = hc.shard[sh];
+        hc.yraw += x.yraw; hc.nnz += x.nnz; hc.ndiag += x.ndiag; hc.nupper += x.nupper; hc.products += x.products;
+        if (x.maxshared > hc.maxshared) hc.maxshared = x.maxshared;
+        for (int t = 0; t < NUM_TIERS; ++t) hc.tier_done[t] += x.tier_done[t];
+    }
+    unsigned long long fbc = 0, fbu = 0;
+    for (int sh = 0; sh < NUM_SHARDS; ++sh) { fbc += hc.shard[sh].fb_claims; fbu += hc.shard[sh].fb_ub; }
+    const int64_t Y = (int64_t)hc.nnz + extra_nnz;
+    for (int t = 0; t < NUM_TIERS; ++t) c.ov_tier_used[t] = hc.tier_count[t] > 0;
+    c.ov_tiers_known = true;
+    c.ov_sort_used[0] = hc.fin_count[0] > 0; c.ov_sort_used[1] = hc.fin_count[1] > 0;
+    if (fbu > 0) {   // the measured distinct-partner / row-entry ratio (+25 %) picks the next call's starting tiers
+        double r = 1.25 * (double)fbc / (double)fbu * 65536.0;
+        const uint32_t q = r < 64.0 ? 64u : (r > 4.0e9 ? 4000000000u : (uint32_t)r);
+        const uint32_t old = c.ov_prior_q16;
+        if (old == 0 || q > old + old / 10 || q + old / 10 < old) c.ov_prior_q16 = q;
+    }
+    st.products = (int64_t)hc.products;
+    st.nnz_before_prune = (int64_t)hc.yraw;
+    st.nnz = Y;
+    st.nnz_diag = (int64_t)hc.ndiag;
+    st.nnz_upper = (int64_t)hc.nupper + extra_upper;
+    st.max_numshared = (int64_t)hc.maxshared;
+    st.rows_lds = 0;
+    for (int t = 0; t < NUM_LDS_TIERS; ++t) st.rows_lds += hc.tier_done[t];
+    st.rows_global = (int64_t)hc.tier_done[NUM_LDS_TIERS];
+    int64_t queued = 0;
+    for (int t = 0; t < NUM_TIERS; ++t) queued += hc.tier_count[t];
+    st.rows_escalated = queued - st.rows_lds - st.rows_global;
+    st.algorithmic_bytes = 16 * Z + 8 * (2 * M + N + 3) + 24 * Y;
+    st.passes = passes;
+    st.timed = was_timed ? 1 : 0;
+    st.ms_total = ms_tot; st.ms_symbolic = ms_sym; st.ms_numeric = ms_num; st.ms_finalize = ms_fin;
+    c.Y = Y;
+    c.ostats = st;
+    c.have_B = true;
+}
+
+// phase 0: the whole call.  phase 1: the first half of a sharded call with mirror exchange (stage_seed_matrix_begin): classify + numeric with
+// GLOBAL pair ownership, stops before the finalize pass.
+static void create_seed_matrix_direct(Ctx &c, int phase)
+{
+    hipStream_t s = c.stream;
+    const int64_t M = c.M, Z = c.Z;
     const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? M : c.row_hi;
     elba_overlap_stats st{};
     st.nrows = row_hi - row_lo;
@@ -494,7 +673,7 @@ static void create_seed_matrix_direct(Ctx &c)
     // B is symmetric up to exchanging the two positions of every seed (exactly: the canonical seeds are min / max over a cross product of
     // positions per shared k-mer): a pair of rows of this context's window is accumulated on its smaller row only and the surviving
     // entries are mirrored into the partner's row afterwards (k_mirror) — half the accumulator updates, tables half as full.
-    const bool half = !getenv("ELBA_NO_SYMMETRY");
+    const bool half = phase == 1 || !getenv("ELBA_NO_SYMMETRY");
     const int64_t slack = (int64_t)cus * 32 * STAGE_CHUNK + 64;      // one open chunk per resident workgroup
     if (c.ov_tmp_cap == 0) {
         if (c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
@@ -513,7 +692,7 @@ static void create_seed_matrix_direct(Ctx &c)
     p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
     p.s_log2 = c.s_log2; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
-    p.half = half ? 1u : 0u;
+    p.half = phase == 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);
@@ -602,39 +781,7 @@ static void create_seed_matrix_direct(Ctx &c)
             ELBA_HIP(hipGetLastError());
         }
         if (timed) c.ov_marks.mark(2, s);
-        {
-            FinParams f{};
-            f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = p.tmp; f.mir = half ? c.ov_mir.as<StageRec>() : nullptr; f.half = p.half; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
-            f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
-            f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
-            f.b_cap = c.b_cap_entries;
-            f.mir16 = mir16 ? 1u : 0u;
-            const int gblocks = 32;
-            uint64_t sstride = 2;
-            while (sstride < (uint64_t)M) sstride <<= 1;
-            c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
-            f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
-            if (M + 1 <= (1 << 17)) {
-                hipLaunchKernelGGL(k_row_pointers, dim3((unsigned)((M + 1 + RP_TILE - 1) / RP_TILE)), dim3(256), 0, s, f);
-            } else {
-                c.ov_sum_tmp.reserve((size_t)(M + 2) * 4);
-                f.sum_tmp = c.ov_sum_tmp.as<uint32_t>();
-                hipLaunchKernelGGL(k_sum_counts, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, s, f);
-                exclusive_scan_u32_to_i64(s, f.sum_tmp, c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
-            }
-            if (nrows > 0) {
-                int nb = (int)((nrows + 3) / 4);
-                if (nb > cus * 32) nb = cus * 32;
-                hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
-                hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
-                skipped_sorts = 0;
-                const bool all_sorts = !c.ov_tiers_known;
-                if (all_sorts || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
-                else skipped_sorts |= 1u;
-                if (all_sorts || c.ov_sort_used[1]) hipLaunchKernelGGL(k_finalize_huge, dim3(gblocks), dim3(256), 0, s, f);
-                else skipped_sorts |= 2u;
-            }
-        }
+        if (phase == 0) ov_launch_finalize(c, p.half, !c.ov_tiers_known, skipped_sorts, nullptr, 0);
         if (timed) c.ov_marks.mark(3, s);
         ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
         ELBA_HIP(hipStreamSynchronize(s));
@@ -650,58 +797,103 @@ static void create_seed_matrix_direct(Ctx &c)
             c.ov_tiers_known = false;
             continue;
         }
-        c.ov_low_clean = true;
+        c.ov_low_clean = phase == 0;
         break;
     }
+    if (phase == 1) { c.ov_pend_passes = passes; c.ov_pend_timed = was_timed; c.ov_pend_ms[0] = ms_tot; c.ov_pend_ms[1] = ms_sym; c.ov_pend_ms[2] = ms_num; c.ov_phase = 1; return; }
 
-#ifdef ELBA_PHASE_CLOCK
-    fprintf(stderr, "[elba phase] wave-0 cycles summed over %llu workgroups: header=%llu init=%llu accumulate=%llu handoff=%llu sweep=%llu reserve=%llu store=%llu | rows %u,%u,%u,%u,%u,%u\n",
-            hc.phase[10], hc.phase[0], hc.phase[1], hc.phase[2], hc.phase[3], hc.phase[4], hc.phase[5], hc.phase[6],
-            hc.tier_count[0], hc.tier_count[1], hc.tier_count[2], hc.tier_count[3], hc.tier_count[4], hc.tier_count[5]);
-#endif
-    for (int sh = 0; sh < NUM_SHARDS; ++sh) {       // fold the statistics shards
-        const OvShard &x = hc.shard[sh];
-        hc.yraw += x.yraw; hc.nnz += x.nnz; hc.ndiag += x.ndiag; hc.nupper += x.nupper; hc.products += x.products;
-        if (x.maxshared > hc.maxshared) hc.maxshared = x.maxshared;
-        for (int t = 0; t < NUM_TIERS; ++t) hc.tier_done[t] += x.tier_done[t];
+    ov_finish_stats(c, hc, st, passes, was_timed, ms_tot, ms_sym, ms_num, ms_fin, 0, 0);
+}
+
+
+
+// ---- sharded call with mirror exchange: begin -> (counts, fill: the driver's all-to-all) -> end -----------------------------------------
+static RemoteParams remote_params(Ctx &c)
+{
+    RemoteParams r{};
+    r.row_cnt = c.ov_rowcnt.as<uint32_t>(); r.row_off = c.ov_rowoff.as<unsigned long long>(); r.tmp = c.ov_tmp.as<StageRec>();
+    r.row_lo = (uint32_t)c.row_lo; r.row_hi = (uint32_t)(c.row_hi < 0 ? c.M : c.row_hi); r.nranks = (uint32_t)c.ov_remote_bounds.size() - 1u;
+    for (size_t k = 0; k < c.ov_remote_bounds.size(); ++k) r.bounds[k] = c.ov_remote_bounds[k];
+    return r;
+}
+
+void stage_seed_matrix_begin(Ctx &c, int nranks, const uint64_t *bounds_host, uint64_t *send_counts_host)
+{
+    ELBA_REQUIRE(c.have_A && !c.plan, ELBA_ERR_STATE, "seed_matrix_begin: no k-mer matrix");
+    ELBA_REQUIRE(nranks >= 1 && nranks <= REMOTE_MAX_RANKS && bounds_host && send_counts_host, ELBA_ERR_INVALID_ARG, "seed_matrix_begin: 1..64 ranks, read bounds and a count array");
+    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? c.M : c.row_hi;
+    bool found = false;
+    for (int r = 0; r < nranks; ++r) found |= (int64_t)bounds_host[r] == row_lo && (int64_t)bounds_host[r + 1] == row_hi;
+    ELBA_REQUIRE(found && (int64_t)bounds_host[nranks] == c.M, ELBA_ERR_INVALID_ARG, "seed_matrix_begin: this context's row window is not one of the ranks' row ranges");
+    c.ov_remote_bounds.assign(bounds_host, bounds_host + nranks + 1);
+    create_seed_matrix_direct(c, 1);
+    hipStream_t s = c.stream;
+    c.ws_scan.reserve(REMOTE_MAX_RANKS * 8);
+    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, REMOTE_MAX_RANKS * 8, s));
+    const int64_t nrows = row_hi - row_lo;
+    if (nrows > 0 && nranks > 1)
+        hipLaunchKernelGGL((k_remote_mirror<false>), dim3((unsigned)((nrows + REMOTE_ROWS_PER_BLOCK - 1) / REMOTE_ROWS_PER_BLOCK)), dim3(256), 0, s, remote_params(c), c.ws_scan.as<unsigned long long>(), (StageRec *)nullptr);
+    ELBA_HIP(hipMemcpyAsync(send_counts_host, c.ws_scan.p, (size_t)nranks * 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
+void stage_seed_matrix_fill(Ctx &c, void *d_send, const uint64_t *offsets_host)
+{
+    ELBA_REQUIRE(c.ov_phase == 1, ELBA_ERR_STATE, "seed_matrix_fill: call seed_matrix_begin first");
+    hipStream_t s = c.stream;
+    const int nranks = (int)c.ov_remote_bounds.size() - 1;
+    c.ws_scan.reserve(REMOTE_MAX_RANKS * 8);
+    ELBA_HIP(hipMemcpyAsync(c.ws_scan.p, offsets_host, (size_t)nranks * 8, hipMemcpyHostToDevice, s));
+    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? c.M : c.row_hi, nrows = row_hi - row_lo;
+    if (nrows > 0 && nranks > 1)
+        hipLaunchKernelGGL((k_remote_mirror<true>), dim3((unsigned)((nrows + REMOTE_ROWS_PER_BLOCK - 1) / REMOTE_ROWS_PER_BLOCK)), dim3(256), 0, s, remote_params(c), c.ws_scan.as<unsigned long long>(), static_cast<StageRec *>(d_send));
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
+void stage_seed_matrix_end(Ctx &c, const void *d_recv, int64_t nrecv)
+{
+    ELBA_REQUIRE(c.ov_phase == 1, ELBA_ERR_STATE, "seed_matrix_end: call seed_matrix_begin first");
+    ELBA_REQUIRE(nrecv >= 0 && (nrecv == 0 || d_recv), ELBA_ERR_INVALID_ARG, "seed_matrix_end: null records");
+    hipStream_t s = c.stream;
+    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? c.M : c.row_hi;
+    OvCounters &hc = *static_cast<OvCounters *>(c.ov_host.p);          // the numeric phase's counters (read back by begin)
+    int64_t staged = 0;
+    for (int sh = 0; sh < NUM_SHARDS; ++sh) staged += (int64_t)hc.shard[sh].nnz;
+    // the output holds what was staged, mirrored locally and received
+    if (c.b_cap_entries < staged + nrecv + 1) c.b_cap_entries = staged + nrecv + 1;
+    c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
+    c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
+    const bool mir16 = c.pos16 && !getenv("ELBA_MIR32");
+    c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * (mir16 ? 16 : sizeof(StageRec)));
+    c.ov_marks.mark(2, s);
+    c.ov_remote.reserve((size_t)(nrecv + 1) * sizeof(StageRec));
+    c.ws_scan.reserve(64);
+    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 16, s));
+    if (nrecv > 0) {
+        ELBA_HIP(hipMemcpyAsync(c.ov_remote.p, d_recv, (size_t)nrecv * sizeof(StageRec), hipMemcpyDeviceToDevice, s));
+        hipLaunchKernelGGL(k_ingest_remote, dim3((unsigned)((nrecv + 255) / 256)), dim3(256), 0, s, c.ov_remote.as<StageRec>(), (unsigned long long)nrecv, c.ov_totcnt.as<uint32_t>(),
+                           (uint32_t)row_lo, (uint32_t)row_hi, c.ws_scan.as<unsigned long long>(), c.ws_scan.as<unsigned long long>() + 1);
     }
-    unsigned long long fbc = 0, fbu = 0;
-    for (int sh = 0; sh < NUM_SHARDS; ++sh) { fbc += hc.shard[sh].fb_claims; fbu += hc.shard[sh].fb_ub; }
-    const int64_t Y = (int64_t)hc.nnz;
-    for (int t = 0; t < NUM_TIERS; ++t) c.ov_tier_used[t] = hc.tier_count[t] > 0;
-    c.ov_tiers_known = true;
-    c.ov_sort_used[0] = hc.fin_count[0] > 0; c.ov_sort_used[1] = hc.fin_count[1] > 0;
-    if (fbu > 0) {   // the measured distinct-partner / row-entry ratio (+25 %) picks the next call's starting tiers
-        double r = 1.25 * (double)fbc / (double)fbu * 65536.0;
-        const uint32_t q = r < 64.0 ? 64u : (r > 4.0e9 ? 4000000000u : (uint32_t)r);
-        const uint32_t old = c.ov_prior_q16;
-        if (old == 0 || q > old + old / 10 || q + old / 10 < old) c.ov_prior_q16 = q;
-    }
-    st.products = (int64_t)hc.products;
-    st.nnz_before_prune = (int64_t)hc.yraw;
-    st.nnz = Y;
-    st.nnz_diag = (int64_t)hc.ndiag;
-    st.nnz_upper = (int64_t)hc.nupper;
-    st.max_numshared = (int64_t)hc.maxshared;
-    st.rows_lds = 0;
-    for (int t = 0; t < NUM_LDS_TIERS; ++t) st.rows_lds += hc.tier_done[t];
-    st.rows_global = (int64_t)hc.tier_done[NUM_LDS_TIERS];
-    int64_t queued = 0;
-    for (int t = 0; t < NUM_TIERS; ++t) queued += hc.tier_count[t];
-    st.rows_escalated = queued - st.rows_lds - st.rows_global;
-    st.algorithmic_bytes = 16 * Z + 8 * (2 * M + N + 3) + 24 * Y;
-    st.passes = passes;
-    st.timed = was_timed ? 1 : 0;
-    st.ms_total = ms_tot; st.ms_symbolic = ms_sym; st.ms_numeric = ms_num; st.ms_finalize = ms_fin;
-    c.Y = Y;
-    c.ostats = st;
-    c.have_B = true;
+    unsigned long long chk[2] = {0, 0};
+    ELBA_HIP(hipMemcpyAsync(chk, c.ws_scan.p, 16, hipMemcpyDeviceToHost, s));
+    uint32_t skipped_sorts = 0;
+    ov_launch_finalize(c, 2u, true, skipped_sorts, c.ov_remote.as<StageRec>(), nrecv);
+    c.ov_marks.mark(3, s);
+    ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    ELBA_REQUIRE(chk[0] == 0, ELBA_ERR_INVALID_ARG, "seed_matrix_end: received records for rows outside this context's window");
+    c.ov_low_clean = true;
+    c.ov_phase = 0;
+    elba_overlap_stats st{};
+    st.nrows = row_hi - row_lo;
+    const float ms_fin = c.ov_marks.ms(2, 3);
+    ov_finish_stats(c, hc, st, c.ov_pend_passes, c.ov_pend_timed, c.ov_pend_ms[0] + ms_fin, c.ov_pend_ms[1], c.ov_pend_ms[2], ms_fin, nrecv, (int64_t)chk[1]);
 }
 
 void stage_create_seed_matrix(Ctx &c)
 {
     ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "create_seed_matrix: no k-mer matrix (call elba_create_kmer_matrix or elba_set_kmer_matrix)");
-    if (!c.plan) { create_seed_matrix_direct(c); return; }
+    if (!c.plan) { create_seed_matrix_direct(c, 0); return; }
     hipStream_t s = c.stream;
     const int64_t M = c.M, N = c.N, Z = c.Z;
     const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? M : c.row_hi;

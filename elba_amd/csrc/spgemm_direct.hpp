@@ -194,7 +194,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             const uint64_t md = __ballot(j == i);
             pr += (uint32_t)__popcll(mv); dg += (uint32_t)__popcll(md);
             uint64_t mi = mv & ~md;
-            if (p.half) mi &= __ballot(owns_pair(i, j, p.row_lo, p.row_hi));
+            if (p.half) mi &= __ballot(owns_pair(i, j, p.half == 2u ? 0u : p.row_lo, p.half == 2u ? 0xFFFFFFFFu : p.row_hi));      // (2: the rule holds for every partner, wherever its row lives)
             if (mi == 0) return;
             const bool ins = (mi >> lane) & 1ull;
             if (GLOBAL) { if (ins) tab.insert(j, seq, full); return; }
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             bool keep = false;
             if (s0 < T) {
                 const uint32_t j = tab.ld(tab.keys, s0);
-                if (j != EMPTY) { yraw += (p.half && j >= p.row_lo && j < p.row_hi) ? 2u : 1u; keep = tab.ld(tab.cnt, s0) >= 2; }
+                if (j != EMPTY) { yraw += (p.half == 2u || (p.half && j >= p.row_lo && j < p.row_hi)) ? 2u : 1u; keep = tab.ld(tab.cnt, s0) >= 2; }
             }
             const uint64_t bal = __ballot(keep);
             if (bal == 0) continue;

@@ -82,6 +82,9 @@ class HipBackend:
         L.elba_dist_panel_fill.restype = i32; L.elba_dist_panel_fill.argtypes = [vp, i32, vp, vp, vp]
         L.elba_dist_panel_counts_win.restype = i32; L.elba_dist_panel_counts_win.argtypes = [vp, i32, vp, vp, vp, vp]
         L.elba_dist_panel_fill_win.restype = i32; L.elba_dist_panel_fill_win.argtypes = [vp, i32, vp, vp, vp, vp, vp]
+        L.elba_seed_matrix_begin.restype = i32; L.elba_seed_matrix_begin.argtypes = [vp, i32, vp, vp]
+        L.elba_seed_matrix_fill.restype = i32; L.elba_seed_matrix_fill.argtypes = [vp, vp, vp]
+        L.elba_seed_matrix_end.restype = i32; L.elba_seed_matrix_end.argtypes = [vp, vp, i64, C.POINTER(capi.OverlapStats)]
         L.elba_dist_set_panel.restype = i32; L.elba_dist_set_panel.argtypes = [vp, vp, i64, i64, i64, i64, i64, C.POINTER(capi.MatrixStats)]
         L.elba_dist_set_all_reads.restype = i32; L.elba_dist_set_all_reads.argtypes = [vp, vp, i64, vp, vp, i64]
 
@@ -189,6 +192,22 @@ class HipBackend:
     def create_seed_matrix(self):
         return self.e.create_seed_matrix()
 
+    # sharded call with mirror exchange (elba_seed_matrix_begin / _fill / _end)
+    def seed_begin(self, nranks, bounds):
+        b = np.ascontiguousarray(bounds, dtype=np.uint64)
+        out = np.zeros(nranks, dtype=np.uint64)
+        self.e._check(self.L.elba_seed_matrix_begin(self.h, nranks, b.ctypes.data, out.ctypes.data))
+        return out.astype(np.int64)
+
+    def seed_fill(self, send, offsets):
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.e._check(self.L.elba_seed_matrix_fill(self.h, send.data_ptr() if send.numel() else None, off.ctypes.data))
+
+    def seed_end(self, recv):
+        st = capi.OverlapStats()
+        self.e._check(self.L.elba_seed_matrix_end(self.h, recv.data_ptr() if recv.numel() else None, recv.shape[0], C.byref(st)))
+        return capi._stats(st)
+
     def export_csr(self, row_lo, row_hi):
         return self.e.export_csr(row_lo, row_hi)
 
@@ -205,6 +224,7 @@ class DistributedOverlap:
         self.be = backend if backend is not None else HipBackend(k, lower, upper, device, timing_stride)
         self.nlocal = 0
         self.bounds = None
+        self.row_batches = 1
 
     # ---- inputs -----------------------------------------------------------------------------------------------------
     def set_reads(self, packed, off, lens, first_global_id, bounds):
@@ -360,8 +380,24 @@ class DistributedOverlap:
         self.exchange_bytes["panels"] += int(pc.sum()) * 16
         return ms
 
-    def create_seed_matrix(self):
-        return self.be.create_seed_matrix()
+    def create_seed_matrix(self, exchange=None):
+        """This rank's rows of B.  With more than one rank (and unless exchange=False) every pair of rows that live on two ranks is
+        accumulated by ONE of them and its mirror image travels to the other in one all-to-all of 32-byte records (elba_seed_matrix_begin /
+        _fill / _end): each rank then does 1/world of the one-GPU work instead of computing every cross-rank pair twice.  Without the
+        exchange the call has no communication at all."""
+        if exchange is None:
+            exchange = self.world > 1 and self.row_batches == 1 and hasattr(self.be, "seed_begin")
+        if not exchange:
+            return self.be.create_seed_matrix()
+        W = self.world
+        sc = self.be.seed_begin(W, self.bounds)
+        rc = self._exchange_counts(sc)
+        send = self.be.empty_records(int(sc.sum()), 4)
+        self.be.seed_fill(send, np.concatenate([[0], np.cumsum(sc)[:-1]]))
+        recv = self._all_to_all_records(send, sc, rc)
+        del send
+        self.mirror_bytes = int(sc.sum()) * 32
+        return self.be.seed_end(recv)
 
     # ---- the step after the path: x-drop alignment of the candidate pairs, sharded ------------------------------------------
     def align_seeds(self, mat=1, mis=-1, gap=-1, dropoff=15):

@@ -9,7 +9,7 @@
 //   (k-mer, read, pos) seeds (pass 2)                 :117-151,:244-274  ONE all-to-all of (k-mer, read << 32 | pos) records: grouped ncclSend / ncclRecv
 //   MPI_Exscan of the local map sizes -> k-mer ids    :371-375          ncclAllGather of the owners' counts, exclusive scan on the host
 //   SpParMat ctor / Transpose() redistribute A, AT    :396-400, main.cpp:272-273   ONE all-to-all of column panels: each column, whole, to every rank owning one of its reads
-//   SUMMA broadcasts inside create_seed_matrix        src/SharedSeeds.cpp:7       none: every rank's rows of B need only its panel
+//   SUMMA broadcasts inside create_seed_matrix        src/SharedSeeds.cpp:7       ONE all-to-all of mirrored entries: a cross-rank pair is accumulated by one rank only
 //
 // All-to-all rounds are capped at 512 MiB per peer (the reference batches too, include/KmerOps.hpp:33-56; RCCL 2.26 was seen to deliver
 // only the first GiB of a >= 2 GiB message, profiles/r01_notes.md).  Needs <rccl/rccl.h> and the HIP runtime API (device buffers, one stream).
@@ -152,13 +152,28 @@ public:
         exchange_bytes_ = sum(sc) * rw * 8 + sum(pc) * 16;
     }
 
-    // create_seed_matrix (include/SharedSeeds.hpp:98-99) for this rank's rows of B: no communication
-    elba_overlap_stats create_seed_matrix()
+    // create_seed_matrix (include/SharedSeeds.hpp:98-99) for this rank's rows of B.  With more than one rank every pair of rows that live on
+    // two ranks is accumulated by ONE of them (elba_seed_matrix_begin) and its mirror image travels to the other in one all-to-all of
+    // 32-byte records (the only exchange inside the call; the reference's SUMMA stages have no other counterpart), then elba_seed_matrix_end
+    // completes the rows.  exchange = false: no communication, both ranks accumulate the pair.
+    elba_overlap_stats create_seed_matrix(bool exchange = true)
     {
         elba_overlap_stats st{};
-        engine_->check(elba_create_seed_matrix(engine_->ctx, &st));
+        const int W = grid_->size;
+        if (!exchange) { engine_->check(elba_create_seed_matrix(engine_->ctx, &st)); return st; }   // (one rank: the same calls with empty messages)
+        std::vector<uint64_t> ub(bounds_.begin(), bounds_.end()), sc((size_t)W), rc;
+        engine_->check(elba_seed_matrix_begin(engine_->ctx, W, ub.data(), sc.data()));
+        rc = exchange_counts(sc);
+        send_.reserve(sum(sc) * 32);
+        const std::vector<uint64_t> soff = offsets(sc);
+        engine_->check(elba_seed_matrix_fill(engine_->ctx, send_.p, soff.data()));
+        recv_.reserve(sum(rc) * 32);
+        all_to_all(send_, sc, recv_, rc, 32);
+        engine_->check(elba_seed_matrix_end(engine_->ctx, recv_.p, (int64_t)sum(rc), &st));
+        mirror_bytes_ = sum(sc) * 32;
         return st;
     }
+    uint64_t mirror_bytes() const { return mirror_bytes_; }
     uint64_t exchange_bytes() const { return exchange_bytes_; }
 
 private:
@@ -227,7 +242,7 @@ private:
     std::vector<int64_t> bounds_;
     detail::DevMem send_, recv_, scratch_;
     int kw_ = 1;
-    uint64_t exchange_bytes_ = 0;
+    uint64_t exchange_bytes_ = 0, mirror_bytes_ = 0;
 };
 
 }  // namespace elba

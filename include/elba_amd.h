@@ -337,6 +337,16 @@ int  elba_dist_panel_fill(elba_ctx *ctx, int nranks, const uint64_t *read_bounds
  * elba_dist_set_panel(block) -> elba_create_seed_matrix -> rows of the block -> next block.  The owner's columns stay resident. */
 int  elba_dist_panel_counts_win(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, const uint64_t *win_lo, const uint64_t *win_hi, uint64_t *counts);
 int  elba_dist_panel_fill_win(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, const uint64_t *win_lo, const uint64_t *win_hi, void *d_send, const uint64_t *offsets);
+/* create_seed_matrix on a row shard WITH mirror exchange.  elba_create_seed_matrix on a shard accumulates every pair that has a row
+ * outside the shard on both ranks concerned (no communication, about twice the accumulator work and table sizes of a one-GPU run).  The
+ * three calls below accumulate each pair {i, j} on ONE rank — the rank of the smaller row when i + j is even, of the larger when odd —
+ * and hand the mirrored entry to the other: begin (classify + numeric; send_counts[r] = 32-byte records for rank r), fill (writes them
+ * grouped by rank at offsets[r]), the driver's all-to-all, end (merges what arrived, row pointers, per-row column sort: this rank's rows of
+ * B are then complete, exactly as after elba_create_seed_matrix).  read_bounds as in elba_dist_panel_counts.  The only exchange inside
+ * the reference's create_seed_matrix this corresponds to are the SUMMA stages of Mult_AnXBn_DoubleBuff (src/SharedSeeds.cpp:7). */
+int  elba_seed_matrix_begin(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, uint64_t *send_counts);
+int  elba_seed_matrix_fill(elba_ctx *ctx, void *d_send, const uint64_t *offsets);
+int  elba_seed_matrix_end(elba_ctx *ctx, const void *d_recv, int64_t nrecords, elba_overlap_stats *stats);
 /* receiver side: the panel of every column touching rows [row_lo,row_hi) -> columns (renumbered by rank among the columns present) + CSR; elba_create_seed_matrix
  * then computes exactly those rows of B (global column ids); elba_export_csr(row_lo,row_hi) / elba_export_dcsc read them */
 int  elba_dist_set_panel(elba_ctx *ctx, const void *d_records, int64_t nrecords, int64_t nreads_total, int64_t nkmers_total,

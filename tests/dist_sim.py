@@ -279,6 +279,55 @@ class NumpyBackend:
     def export_csr(self, row_lo, row_hi):
         return self.B
 
+    # ---- stand-in for elba_seed_matrix_begin / _fill / _end: ONE rank accumulates a cross-rank pair, the other receives its mirror image ----
+    @staticmethod
+    def _owns(i, j):
+        return (j < i) if ((i ^ j) & 1) else (j > i)
+
+    def seed_begin(self, W, bounds):
+        self.o.spgemm(1)
+        B = self.o.B()
+        lo, hi = self.win
+        self._kept, self._remote = {}, [[] for _ in range(W)]
+        b = np.asarray(bounds, dtype=np.int64)
+        for i in range(lo, hi):
+            for e in range(int(B["rowptr"][i]), int(B["rowptr"][i + 1])):
+                j, v = int(B["col"][e]), B["val"][e]
+                if j != i and not self._owns(i, j):
+                    continue
+                self._kept.setdefault(i, []).append((j, v))
+                if j != i:
+                    mv = np.zeros(1, dtype=po.SEED_DTYPE)[0]
+                    mv["q0"], mv["t0"], mv["q1"], mv["t1"], mv["numshared"] = v["t0"], v["q0"], v["t1"], v["q1"], v["numshared"]
+                    if lo <= j < hi:
+                        self._kept.setdefault(j, []).append((i, mv.copy()))
+                    else:
+                        d = int(np.searchsorted(b, j, side="right") - 1)
+                        self._remote[d].append((j, i, int(mv["q0"]), int(mv["t0"]), int(mv["q1"]), int(mv["t1"]), int(mv["numshared"]), 0))
+        return np.array([len(x) for x in self._remote], dtype=np.int64)
+
+    def seed_fill(self, send, offsets):
+        flat = [r for per in self._remote for r in per]
+        rec = np.array(flat, dtype=np.uint32).reshape(-1, 8) if flat else np.zeros((0, 8), np.uint32)
+        send.copy_(torch.from_numpy(rec.view(np.int64).reshape(-1, 4).copy()))
+
+    def seed_end(self, recv):
+        lo, hi = self.win
+        r = recv.numpy().view(np.uint32).reshape(-1, 8)
+        for (j, i, q0, t0, q1, t1, n, _) in r.tolist():
+            assert lo <= j < hi
+            mv = np.zeros(1, dtype=po.SEED_DTYPE)[0]
+            mv["q0"], mv["t0"], mv["q1"], mv["t1"], mv["numshared"] = q0, t0, q1, t1, n
+            self._kept.setdefault(j, []).append((i, mv.copy()))
+        rowptr, col, val = [0], [], []
+        for i in range(lo, hi):
+            ents = sorted(self._kept.get(i, []), key=lambda x: x[0])
+            col += [e[0] for e in ents]; val += [e[1] for e in ents]
+            rowptr.append(len(col))
+        self.B = dict(M=hi - lo, Y=len(col), rowptr=np.array(rowptr, dtype=np.int64), col=np.array(col, dtype=np.int64),
+                      val=np.array(val, dtype=po.SEED_DTYPE) if val else np.zeros(0, dtype=po.SEED_DTYPE))
+        return dict(nnz=len(col), products=0, algorithmic_bytes=0, ms_total=0.0, ms_numeric=0.0, ms_symbolic=0.0, ms_finalize=0.0)
+
     def set_all_reads(self, packed_words, byte_off, lens):
         self.all_reads = (packed_words.numpy().view(np.uint8).copy(), np.asarray(byte_off, dtype=np.uint64), np.asarray(lens, dtype=np.uint32))
 

@@ -101,6 +101,26 @@ def test_row_block_batching_gives_the_same_rows():
     assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
 
 
+def test_without_the_mirror_exchange_the_rows_are_the_same():
+    """create_seed_matrix(exchange=False): every rank accumulates its cross-rank pairs itself (no communication inside the call)."""
+    o = _expected()
+
+    def body(rank, h):
+        packed, off, lens, _ = _reads()
+        bounds = partition_by_bases(lens, 2)
+        a, b = int(bounds[rank]), int(bounds[rank + 1])
+        sp, so, sl = _shard(packed, off, lens, a, b)
+        d = DistributedOverlap(K, LO, UP, rank=rank, world=2, dist=h, backend=dist_sim.NumpyBackend(K, LO, UP))
+        d.set_reads(sp, so, sl, a, bounds)
+        d.build_kmer_matrix()
+        d.create_seed_matrix(exchange=False)
+        return d.export_csr()
+
+    B = dist_sim.stitch_rows(dist_sim.run_ranks(2, body))
+    oB = o.B()
+    assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+
+
 def test_batched_all_to_all_rounds_give_the_same_result(monkeypatch):
     """The exchange is cut into rounds of at most MAX_RECORDS_PER_PEER records per peer (the reference batches its all-to-all too,
     include/KmerOps.hpp:33-56); force many rounds."""

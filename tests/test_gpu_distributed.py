@@ -159,3 +159,36 @@ def test_row_block_batching_on_the_gpu():
         B = dist_sim.stitch_rows([p[0] for p in parts])
         assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
         assert sum(p[1] for p in parts) == o.stat("P")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_with_and_without_the_mirror_exchange(world):
+    """Default at world > 1: every cross-rank pair is accumulated by ONE rank and its mirror image sent to the other (elba_seed_matrix_begin /
+    _fill / _end + one all-to-all); exchange=False: both ranks accumulate it, no communication.  Same rows of B either way (the oracle's),
+    and with the exchange the ranks' products add up to the ONE-GPU symmetric schedule's, not to twice the cross-rank part."""
+    reads = elba_amd.synth_reads(36, 250000, 15, 4000, 900, error_rate=0.10, min_len=200)
+    packed, off, lens, _ = reads
+    o = po.Oracle(17, 2, 8); o.count_and_build(packed, off, lens); o.spgemm(4)
+    oB = o.B()
+    bounds = partition_by_bases(lens, world)
+    for exchange in (True, False):
+        def body(rank, h):
+            a, b = int(bounds[rank]), int(bounds[rank + 1])
+            sp, so, sl = _shard(packed, off, lens, a, b)
+            d = DistributedOverlap(17, 2, 8, device=0, rank=rank, world=world, dist=h, backend=HipBackend(17, 2, 8, 0))
+            d.set_reads(sp, so, sl, a, bounds)
+            d.build_kmer_matrix()
+            st = d.create_seed_matrix(exchange=exchange)
+            st2 = d.create_seed_matrix(exchange=exchange)          # a second call on the same panel
+            out = (d.export_csr(), st, st2)
+            d.be.e.close()
+            return out
+
+        parts = dist_sim.run_ranks(world, body)
+        B = dist_sim.stitch_rows([p[0] for p in parts])
+        assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+        assert sum(p[1]["nnz"] for p in parts) == o.stat("Y") == sum(p[2]["nnz"] for p in parts)
+        assert sum(p[1]["nnz_upper"] for p in parts) == o.stat("nupper") and sum(p[1]["nnz_diag"] for p in parts) == o.stat("ndiag")
+        assert sum(p[1]["products"] for p in parts) == o.stat("P")
+        if exchange:
+            assert sum(p[1]["nnz_before_prune"] for p in parts) == o.stat("Yraw")
