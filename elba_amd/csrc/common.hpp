@@ -137,6 +137,8 @@ struct Ctx {
     DevBuf rel_kmers_lo;  // u64[N] their second word when k > 32
     DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
+    DevBuf csr_words;     // u64[Z] read << (pre_nb + pre_pb) | k-mer id << pre_pb | pos of every entry of a_csc, when pre_words (k_runs_emit -> the CSR build's sort)
+    bool pre_ready = false, pre_words = false; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
     DevBuf kid_of_entry;  // u64[Z] k-mer id of every entry of a_csc (written with the columns; what the CSR build sorts by read)
     elba_kmer_stats kstats{};
 

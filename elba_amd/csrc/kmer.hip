@@ -447,6 +447,135 @@ __global__ void k_block_reads(const uint64_t *inst_off, const uint64_t *byte_off
     block_read[b] = BlockInfo{lo, 0u, inst_off[lo], inst_off[lo + 1], byte_off[lo]};
 }
 
+// Second pass over the sorted words, fused with the entries' (read, pos): EVERY item of a reliable run writes its own entry — consecutive
+// lanes hold consecutive items and the entries of consecutive reliable runs are consecutive in the output, so the stores coalesce (the
+// per-head loops of k_runs<true> wrote one 8-byte word per lane and step, and k_instance_entries read all of it back).  An item finds its
+// head by counting the "same as my left neighbour" bits that end at it (LDS bit masks, as above), the head leaves its k-mer id and column
+// pointer in LDS; runs that reach across the tile's end are finished by the tile of their head (64 items of halo), so UPPER <= 62 here.
+// The entry is the dup-th instance among the 2^drop candidates behind the payload whose canonical k-mer is the run's (see
+// k_instance_entries); its read comes from the block table.  With `csr_words` the entry is also written as the one-word sort key of the CSR
+// build (read << (nb + pb) | k-mer id << pb | pos, matrix.hip): no column-id array, no conversion pass.
+struct EmitOut {
+    uint64_t *rel_kmers; uint32_t *rel_counts, *colptr;
+    uint64_t *csc, *csr_words, *kid_of_entry;
+    int nb, pb;
+};
+__global__ __launch_bounds__(RUN_THREADS) void k_runs_emit(RunParams p, EnumParams e, const BlockInfo *block_read, int drop, const uint32_t *off_rel, const uint32_t *off_ent, EmitOut o)
+{
+    constexpr int NW = RUN_THREADS / 64, SLICES = RUN_ITEMS * NW;
+    __shared__ uint64_t eqmask[SLICES + 2];
+    __shared__ uint32_t srel[SLICES + 1], sent[SLICES + 1];
+    __shared__ uint32_t hkid[RUN_TILE], hat[RUN_TILE];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t lt = (1ull << lane) - 1;
+    const uint64_t T0 = (uint64_t)blockIdx.x * RUN_TILE;
+    const int ib = p.ib;
+    uint64_t word[RUN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < RUN_ITEMS; ++i) {
+        const uint64_t g = T0 + (uint64_t)i * RUN_THREADS + tid;
+        word[i] = g < p.I ? p.keys[g] : 0;
+        const uint64_t left = g > 0 && g < p.I ? p.keys[g - 1] : 0;
+        const uint64_t bal = __ballot(g < p.I && g > 0 && (word[i] >> ib) == (left >> ib));
+        if (lane == 0) eqmask[i * NW + w] = bal;
+    }
+    uint64_t hword = 0;
+    if (w == 0) {
+        const uint64_t g = T0 + RUN_TILE + lane;
+        hword = g < p.I ? p.keys[g] : 0;
+        const uint64_t left = g < p.I ? p.keys[g - 1] : 0;
+        const uint64_t bal = __ballot(g < p.I && (hword >> ib) == (left >> ib));
+        if (lane == 0) { eqmask[SLICES] = bal; eqmask[SLICES + 1] = 0; }
+    }
+    __syncthreads();
+    uint32_t len[RUN_ITEMS];                      // 0: not a head; else run length (anything beyond 63 reads as 64: unreliable, UPPER <= 62)
+#pragma unroll
+    for (int i = 0; i < RUN_ITEMS; ++i) {
+        const uint32_t q = (uint32_t)i * RUN_THREADS + tid;
+        const uint64_t g = T0 + q;
+        const bool head = g < p.I && !((eqmask[q >> 6] >> (q & 63u)) & 1ull);
+        uint32_t l = 0;
+        if (head) {
+            const uint32_t q1 = q + 1u, s1 = q1 & 63u;
+            const uint64_t w0 = eqmask[q1 >> 6], w1 = eqmask[(q1 >> 6) + 1];
+            const uint64_t win = s1 ? (w0 >> s1) | (w1 << (64u - s1)) : w0;      // the 64 bits that follow the head (tile + halo always hold them)
+            l = 1u + (win == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~win));
+        }
+        len[i] = l;
+        const bool rel = head && l >= p.lower && l <= p.upper;
+        const uint64_t br = __ballot(rel);
+        uint32_t en = rel ? l : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) en += __shfl_xor(en, d, 64);
+        if (lane == 0) { srel[i * NW + w] = (uint32_t)__popcll(br); sent[i * NW + w] = en; }
+    }
+    __syncthreads();
+    if (tid == 0) {                               // exclusive prefixes over the slices, in item order (slice = i * NW + wave)
+        uint32_t x = off_rel[blockIdx.x], y = off_ent[blockIdx.x];
+        for (int k2 = 0; k2 < SLICES; ++k2) { const uint32_t a = srel[k2], b2 = sent[k2]; srel[k2] = x; sent[k2] = y; x += a; y += b2; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RUN_ITEMS; ++i) {
+        const uint32_t l = len[i];
+        const bool rel = l != 0 && l >= p.lower && l <= p.upper;
+        const uint64_t br = __ballot(rel);
+        uint32_t inc = rel ? l : 0u;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o2 = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o2; }
+        const uint32_t q = (uint32_t)i * RUN_THREADS + tid;
+        if (rel) {
+            const uint32_t kid = srel[i * NW + w] + (uint32_t)__popcll(br & lt), at = sent[i * NW + w] + inc - l;
+            o.rel_kmers[kid] = (word[i] >> ib) << (64 - p.k2);
+            o.rel_counts[kid] = l; o.colptr[kid] = at;
+            hkid[q] = kid; hat[q] = at;
+        } else if (l != 0) hat[q] = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    const uint64_t pmask = (1ull << ib) - 1;
+    auto emit = [&](uint32_t q, uint64_t wd) {        // q: place in tile + halo; wd: its word
+        const uint32_t a = q >> 6, s = q & 63u;
+        const uint64_t cur = eqmask[a], prv = a ? eqmask[a - 1] : ~0ull;
+        const uint64_t win = (cur << (63u - s)) | (s < 63u ? prv >> (s + 1u) : 0ull);       // bit 63 = this item's bit, bit 62 = its left neighbour's, ...
+        const uint32_t dist = win == ~0ull ? 64u : (uint32_t)__builtin_clzll(~win);
+        if (dist > q || dist >= 63u) return;          // the head sits in the previous tile (its tile writes this entry), or the run is too long to be reliable
+        const uint32_t h = q - dist;
+        if (h >= (uint32_t)RUN_TILE) return;          // (halo items only) the head is in the halo: the next tile's
+        const uint32_t at = hat[h];
+        if (at == 0xFFFFFFFFu) return;
+        const uint32_t kid = hkid[h];
+        const uint64_t gq = T0 + q;
+        const uint64_t hp = wd & pmask;
+        uint64_t g = hp << drop;
+        const BlockInfo bi = block_read[g >> IB_SHIFT];
+        uint32_t lo = bi.read;
+        uint64_t off_lo = bi.off_lo, off_hi = bi.off_hi, boff = bi.byte_off;
+        auto advance = [&](uint64_t gg) { while (gg >= off_hi) { ++lo; off_lo = off_hi; off_hi = e.inst_off[lo + 1]; boff = e.byte_off[lo]; } };
+        advance(g);
+        if (drop) {
+            const uint64_t want = (wd >> ib) << (64 - p.k2);
+            uint32_t dup = 0;
+            for (uint32_t t = 1; t <= dist && t < (1u << drop) && p.keys[gq - t] == wd; ++t) ++dup;
+            const uint64_t gend = g + (1ull << drop) < e.I ? g + (1ull << drop) : e.I;
+            for (; g < gend; ++g) {
+                advance(g);
+                if (canonical_at_off(e, boff, (uint32_t)(g - off_lo)) == want) { if (dup == 0) break; --dup; }
+            }
+        }
+        const uint32_t pos = (uint32_t)(g - off_lo);
+        const uint32_t z = at + dist;
+        o.csc[z] = ((uint64_t)lo << 32) | pos;
+        if (o.csr_words) o.csr_words[z] = ((uint64_t)lo << (o.nb + o.pb)) | ((uint64_t)kid << o.pb) | pos;
+        else o.kid_of_entry[z] = kid;
+    };
+#pragma unroll
+    for (int i = 0; i < RUN_ITEMS; ++i) {
+        const uint32_t q = (uint32_t)i * RUN_THREADS + tid;
+        if (T0 + q < p.I) emit(q, word[i]);
+    }
+    if (w == 0 && T0 + RUN_TILE + lane < p.I) emit((uint32_t)RUN_TILE + lane, hword);
+}
+
 __global__ void k_instance_entries(const uint64_t *payload, const uint64_t *kid_of_entry, const uint64_t *rel_kmers, uint64_t *csc, uint64_t Z, EnumParams e, int drop,
                                    const BlockInfo *block_read)
 {
@@ -479,6 +608,13 @@ __global__ void k_column_ids(const uint32_t *colptr, uint64_t *kid_keys, uint64_
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= N) return;
     for (uint32_t a = colptr[k]; a < colptr[k + 1]; ++a) kid_keys[a] = k;
+}
+
+int bits_needed(uint64_t maxval)
+{
+    int b = 1;
+    while (b < 64 && (maxval >> b)) ++b;
+    return b;
 }
 
 int next_pow2_bits(uint64_t v)
@@ -534,6 +670,27 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
     c.a_colptr.reserve((size_t)(N + 2) * 4);
     c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
     c.kid_of_entry.reserve((size_t)(Z + 8) * 8);
+    // Packed words with UPPER <= 62: one fused pass writes the columns, the entries' (read, pos) and — when read, k-mer id and position fit
+    // one word — the sort keys of the CSR build (k_runs_emit).  Otherwise: heads write payloads and column ids, a second kernel converts.
+    c.pre_ready = false;
+    const bool fused = ib && p.upper <= 62 && !getenv("ELBA_KMER_UNFUSED");
+    if (fused && Z > 0) {
+        EnumParams e = make_enum(c);
+        const uint64_t nib = (I >> IB_SHIFT) + 1;
+        c.ws_b.reserve((size_t)(nib + 1) * sizeof(BlockInfo));
+        hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
+        uint32_t maxlen = 0;
+        for (int64_t r = 0; r < c.nreads; ++r) maxlen = c.h_len[(size_t)r] > maxlen ? c.h_len[(size_t)r] : maxlen;
+        const uint64_t maxpos = maxlen >= (uint32_t)c.cfg.k ? maxlen - (uint32_t)c.cfg.k : 0;      // (a bound: the largest position any entry can have)
+        const int mb = bits_needed((uint64_t)(c.nreads > 0 ? c.nreads - 1 : 0)), nb = bits_needed((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_needed(maxpos);
+        const bool words = mb + nb + pb <= 64 && !getenv("ELBA_CSR_PAIRS");
+        EmitOut o{};
+        o.rel_kmers = c.rel_kmers.as<uint64_t>(); o.rel_counts = c.rel_counts.as<uint32_t>(); o.colptr = c.a_colptr.as<uint32_t>();
+        o.csc = c.a_csc.as<uint64_t>(); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); o.nb = nb; o.pb = pb;
+        if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
+        hipLaunchKernelGGL(k_runs_emit, dim3(nblocks), dim3(RUN_THREADS), 0, s, p, e, (const BlockInfo *)c.ws_b.as<BlockInfo>(), drop, (const uint32_t *)off_rel, (const uint32_t *)off_ent, o);
+        c.pre_ready = true; c.pre_words = words; c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos;
+    } else {
     // entry payloads: written straight into a_csc when they are final (pairs: read << 32 | pos), else into scratch and converted
     DevBuf &scratch = c.ws_f;
     if (ib) scratch.reserve((size_t)(Z + 8) * 8);
@@ -549,6 +706,7 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
         hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
         hipLaunchKernelGGL(k_instance_entries, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, pay, c.kid_of_entry.as<uint64_t>(), c.rel_kmers.as<uint64_t>(), c.a_csc.as<uint64_t>(), Z, e, drop,
                            c.ws_b.as<BlockInfo>());
+    }
     }
     const uint32_t Zz = (uint32_t)Z;
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
@@ -737,7 +895,7 @@ void stage_create_kmer_matrix(Ctx &c)
         c.t_c.start(s);
         c.t_c.stop(s);
         c.A_has_kmers = true;
-        finish_matrix_from_sorted_csc(c, M, N, Z, c.kid_of_entry.as<uint64_t>(), 0, c.a_csc.as<uint64_t>());      // (the column id of every entry was written with the columns: k_runs)
+        finish_matrix_from_sorted_csc(c, M, N, Z, c.kid_of_entry.as<uint64_t>(), 0, c.a_csc.as<uint64_t>(), 0, -1, c.pre_ready);      // (column ids — or the CSR sort keys — were written with the columns: k_runs / k_runs_emit)
         c.kstats.ms_lookup = c.t_c.ms();
         return;
     }
@@ -959,13 +1117,6 @@ __global__ void k_deinterleave(const uint64_t *rec, uint64_t n, uint64_t *k0, ui
     if (i >= n) return;
     k0[i] = rec[2 * i];
     v0[i] = rec[2 * i + 1];
-}
-
-int bits_needed(uint64_t maxval)
-{
-    int b = 1;
-    while (b < 64 && (maxval >> b)) ++b;
-    return b;
 }
 
 }  // namespace

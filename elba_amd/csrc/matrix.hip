@@ -75,13 +75,16 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-// padded column store: entry z of column kid goes to slot (kid << sb) + (z - colptr[kid]); the buffer was filled with all ones before
-__global__ void k_fill_ell(const uint64_t *kid_keys, int kid_shift, const uint32_t *colptr, const uint64_t *csc, int64_t Z, uint32_t sb, uint64_t *ell)
+// padded column store: slot j of column kid (at (kid << sb) + j) holds the column's j-th entry, or all ones behind its end; one lane per
+// slot, so the stores of a wavefront are one contiguous 512 bytes (no fill pass before, no column-id array)
+__global__ void k_fill_ell(const uint32_t *colptr, const uint64_t *csc, uint64_t nslots, uint32_t sb, uint64_t *ell)
 {
-    const int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (z >= Z) return;
-    const uint64_t kid = kid_keys[z] >> kid_shift;
-    ell[(kid << sb) + ((uint32_t)z - colptr[kid])] = csc[z];
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nslots; t += stride) {
+        const uint64_t kid = t >> sb;
+        const uint32_t j = (uint32_t)t & ((1u << sb) - 1u), c0 = colptr[kid], c1 = colptr[kid + 1];
+        ell[t] = j < c1 - c0 ? csc[c0 + j] : ~0ull;
+    }
 }
 
 // 16-byte descriptors that carry the position of their row entry in the upper half of w (the packed form has no room for it)
@@ -491,21 +494,22 @@ static void build_row_descriptors(Ctx &c)
 // Input: Z entries sorted by (kid, read, pos): kid_keys[z] >> kid_shift = kid, csc[z] = read<<32|pos (device, in c.a_csc or elsewhere).
 // Produces c.a_colptr, c.a_csc (copy if csc is not already c.a_csc), c.a_rowptr, c.a_csr, max_row_nnz, max_col_nnz.
 // [win_lo, win_hi) = the rows of B this context computes (win_hi < 0: all); the product schedule is laid out for those rows only.
-void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, const uint64_t *kid_keys, int kid_shift, const uint64_t *csc, int64_t win_lo, int64_t win_hi)
+void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, const uint64_t *kid_keys, int kid_shift, const uint64_t *csc, int64_t win_lo, int64_t win_hi, bool pre)
 {
+    // pre: the k-mer stage left the column pointers, a bound on the positions and (pre_words) the CSR sort keys behind (k_runs_emit, kmer.hip)
     hipStream_t s = c.stream;
     c.M = M; c.N = N; c.Z = Z;
     c.a_colptr.reserve((size_t)(N + 1) * 4);
     c.a_rowptr.reserve((size_t)(M + 1) * 4);
     c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries: the SpGEMM gathers up to four consecutive entries without a bounds check
     c.a_csr.reserve((size_t)(Z + 1) * 8);
-    group_offsets_u32(s, kid_keys, kid_shift, Z, c.a_colptr.as<uint32_t>(), N);
+    if (!pre) group_offsets_u32(s, kid_keys, kid_shift, Z, c.a_colptr.as<uint32_t>(), N);
     if (csc != c.a_csc.as<uint64_t>() && Z > 0)
         ELBA_HIP(hipMemcpyAsync(c.a_csc.p, csc, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
     // largest position among the entries: below 2^16 the SpGEMM's 64-bit accumulators carry both positions of a seed (spgemm_direct.hpp);
     // it also decides whether an entry fits one word for the CSR sort
-    uint64_t maxpos = 0;
-    if (Z > 0) {
+    uint64_t maxpos = pre ? c.pre_maxpos : 0;
+    if (Z > 0 && !pre) {
         int64_t nbz = (Z + 255) / 256;
         if (nbz > 2048) nbz = 2048;
         c.ws_scan.reserve(64);
@@ -519,8 +523,9 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_c.reserve((size_t)(Z + 1) * 8);
     const int mb = bits_for((uint64_t)(M > 0 ? M - 1 : 0)), nb = bits_for((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_for(maxpos);
     if (mb + nb + pb <= 64 && !getenv("ELBA_CSR_PAIRS")) {
-        uint64_t *w0 = c.ws_a.as<uint64_t>(), *w1 = c.ws_c.as<uint64_t>();
-        if (Z > 0) hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
+        const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;
+        uint64_t *w0 = have_words ? c.csr_words.as<uint64_t>() : c.ws_a.as<uint64_t>(), *w1 = c.ws_c.as<uint64_t>();
+        if (Z > 0 && !have_words) hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
         const int where = radix_sort_keys(s, w0, w1, Z, nb + pb, nb + pb + mb, c.ws_sort);
         const uint64_t *sorted = where ? w1 : w0;
         group_offsets_u32(s, sorted, nb + pb, Z, c.a_rowptr.as<uint32_t>(), M);
@@ -570,8 +575,9 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         if (c.use_ell) {
             c.s_log2 = sb; c.lpc_log2 = sb - 1; c.fbits = sb;
             c.a_ell.reserve(ell_bytes + 64);
-            ELBA_HIP(hipMemsetAsync(c.a_ell.p, 0xFF, ell_bytes + 64, s));
-            if (Z > 0) hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), Z, sb, c.a_ell.as<uint64_t>());
+            ELBA_HIP(hipMemsetAsync(c.a_ell.as<char>() + ell_bytes, 0xFF, 64, s));      // (guard words behind the last column)
+            const uint64_t nslots = (uint64_t)N << sb;
+            hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)std::min<uint64_t>((nslots + 255) / 256, 1ull << 30)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), nslots, sb, c.a_ell.as<uint64_t>());
         } else {
             // lanes per row entry: half the longest column, between 2 and 64 (a column is walked in chunks of 2 * lanes entries)
             uint32_t lb = 1;

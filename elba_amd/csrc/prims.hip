@@ -131,64 +131,154 @@ __global__ void k_reduce_max(const uint64_t *p, int64_t n, unsigned long long *o
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// radix sort, 8 bits per pass
-constexpr int RS_THREADS = 256;
-#ifndef ELBA_RS_ITEMS
-#define ELBA_RS_ITEMS 8
+// Stable LSD radix sort, digits of up to 9 bits (34 key bits = 4 passes of 9/9/8/8, 18 bits = 2 passes).  One pass:
+//   k_rs_hist      a workgroup counts the digits of its tile of 4096 keys in LDS and stores the row  hist[tile][digit]   (one coalesced row)
+//   column scan    exclusive prefix down every digit's column (+ the totals of all smaller digits): hist[tile][digit] becomes the place in
+//                  the output of the tile's first key with that digit.  k_cs_sums / k_cs_top / k_cs_apply: thread d walks rows of
+//                  column d, so a wavefront always touches 64 consecutive counters.
+//   k_rs_scatter   ranks the tile's keys per digit (wave ballots), orders the tile by digit in LDS and writes it out by consecutive lanes.
+// The histogram is tile-major: the digit-major layout of round 1 cost a scattered 4-byte store per (tile, digit) in the histogram kernel and
+// the same scattered load again in the scatter — 5*10^8 extra memory requests per pass over 2*10^9 keys, as many as the keys themselves make.
+// (A one-sweep variant — one kernel per pass, decoupled look-back over per-tile status words — was measured here and was 1.7x slower per
+// pass: with ~770 tiles in flight the look-back reads dozens of predecessors' status rows, each an agent-scope 8-byte access.)
+#ifndef ELBA_RS_KEY_ITEMS
+#define ELBA_RS_KEY_ITEMS 32
 #endif
-constexpr int RS_ITEMS = ELBA_RS_ITEMS;
+constexpr int RS_THREADS = 256;
 constexpr int RS_WAVES = RS_THREADS / 64;
-constexpr int RS_TILE = RS_THREADS * RS_ITEMS;
+constexpr int RS_MAXBITS = 9;
+constexpr int RS_MAXBINS = 1 << RS_MAXBITS;
+constexpr int CS_ROWS = 128;           // rows of the histogram one workgroup of the column scan folds
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *keys, int64_t n, int shift, uint32_t *hist, uint32_t nblocks)
+template <int ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *keys, int64_t n, int shift, int bits, uint32_t *hist)
 {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0;
+    __shared__ uint32_t h[RS_MAXBINS];
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
+    for (uint32_t i = threadIdx.x; i < nbins; i += RS_THREADS) h[i] = 0;
     __syncthreads();
-    int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * ITEMS);
+    uint64_t k[ITEMS];
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        int64_t idx = base + r * RS_THREADS + threadIdx.x;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255], 1u);
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t idx = base + r * RS_THREADS + threadIdx.x;
+        k[r] = idx < n ? keys[idx] : 0;
+    }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t idx = base + r * RS_THREADS + threadIdx.x;
+        if (idx < n) atomicAdd(&h[(uint32_t)(k[r] >> shift) & dmask], 1u);
     }
     __syncthreads();
-    hist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (uint32_t i = threadIdx.x; i < nbins; i += RS_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
 }
 
-// Scatter of one radix pass.  The tile is first ordered by digit in LDS, then written out by consecutive lanes: a store instruction
-// of a wavefront then covers a few digits' chunks (a few pages) instead of up to 64 — on 10^8 items and more, where the 256 output streams of
-// a pass lie megabytes apart, the direct per-item scatter ran at a third of the bandwidth it reaches on 10^7 items (address translation).
-template <bool HAS_VAL>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_in, const uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out,
-                                                           int64_t n, int shift, const uint32_t *hist_scanned, uint32_t nblocks)
+// column sums of CS_ROWS rows: out[chunk][d] = sum over the chunk's rows of in[row][d]; blockDim.x = nbins
+__global__ void k_cs_sums(const uint32_t *in, int64_t nrows, uint32_t nbins, uint32_t *out)
 {
-    __shared__ uint32_t whist[RS_WAVES][256];
-    __shared__ uint32_t lstart[256], gbase[256], wsum[RS_WAVES];
-    __shared__ uint64_t lkey[RS_TILE], lval[HAS_VAL ? RS_TILE : 1];
-    volatile uint32_t(*vh)[256] = whist;
-    for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&whist[0][0])[i] = 0;
+    const uint32_t d = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = r0 + CS_ROWS < nrows ? r0 + CS_ROWS : nrows;
+    uint32_t s = 0;
+#pragma unroll 16
+    for (int64_t r = r0; r < r1; ++r) s += in[(size_t)r * nbins + d];
+    out[(size_t)blockIdx.x * nbins + d] = s;
+}
+
+// the last level (any number of rows, one workgroup of nbins threads): exclusive prefix down every column, plus the totals of all smaller digits
+__global__ void k_cs_top(uint32_t *rows, int64_t nrows, uint32_t nbins)
+{
+    __shared__ uint32_t wsum[RS_MAXBINS / 64];
+    const uint32_t d = threadIdx.x, lane = d & 63, w = d >> 6;
+    uint32_t tot = 0;
+#pragma unroll 8
+    for (int64_t r = 0; r < nrows; ++r) tot += rows[(size_t)r * nbins + d];
+    uint32_t inc = tot;
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= (uint32_t)s2) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - tot;
+    for (uint32_t ww = 0; ww < w; ++ww) run += wsum[ww];
+    for (int64_t r = 0; r < nrows; ++r) { const uint32_t x = rows[(size_t)r * nbins + d]; rows[(size_t)r * nbins + d] = run; run += x; }
+}
+
+// rows[chunk's rows][d] -> exclusive prefix inside the chunk + base[chunk][d]
+__global__ void k_cs_apply(uint32_t *rows, int64_t nrows, uint32_t nbins, const uint32_t *base)
+{
+    const uint32_t d = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * CS_ROWS, r1 = r0 + CS_ROWS < nrows ? r0 + CS_ROWS : nrows;
+    uint32_t run = base[(size_t)blockIdx.x * nbins + d];
+    for (int64_t r = r0; r < r1; r += 8) {
+        uint32_t x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x[u] = r + u < r1 ? rows[(size_t)(r + u) * nbins + d] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { if (r + u < r1) rows[(size_t)(r + u) * nbins + d] = run; run += x[u]; }
+    }
+}
+
+void column_scan(hipStream_t s, uint32_t *rows, int64_t nrows, uint32_t nbins, uint32_t *tmp)
+{
+    if (nrows <= 2 * CS_ROWS) {
+        hipLaunchKernelGGL(k_cs_top, dim3(1), dim3(nbins), 0, s, rows, nrows, nbins);
+        return;
+    }
+    const int64_t nchunks = (nrows + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(k_cs_sums, dim3((unsigned)nchunks), dim3(nbins), 0, s, (const uint32_t *)rows, nrows, nbins, tmp);
+    column_scan(s, tmp, nchunks, nbins, tmp + (size_t)nchunks * nbins);
+    hipLaunchKernelGGL(k_cs_apply, dim3((unsigned)nchunks), dim3(nbins), 0, s, rows, nrows, nbins, (const uint32_t *)tmp);
+}
+
+size_t column_scan_tmp_elems(int64_t nrows, uint32_t nbins)
+{
+    size_t tot = 0;
+    while (nrows > 2 * CS_ROWS) { nrows = (nrows + CS_ROWS - 1) / CS_ROWS; tot += (size_t)nrows * nbins; }
+    return tot + 64;
+}
+
+template <bool HAS_VAL, int ITEMS>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_in, const uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out,
+                                                           int64_t n, int shift, int bits, const uint32_t *hist_scanned)
+{
+    constexpr int TILE = RS_THREADS * ITEMS;
+    __shared__ uint32_t whist[RS_WAVES][RS_MAXBINS];
+    __shared__ uint32_t lstart[RS_MAXBINS], gbase[RS_MAXBINS], wsum[RS_WAVES];
+    __shared__ uint64_t lkey[TILE], lval[HAS_VAL ? TILE : 1];
+    volatile uint32_t(*vh)[RS_MAXBINS] = whist;
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
+    for (int i = threadIdx.x; i < RS_WAVES * RS_MAXBINS; i += RS_THREADS) (&whist[0][0])[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1;
-    // a wave owns RS_ITEMS*64 CONSECUTIVE items of the tile so that tile order == (wave, round, lane) order: stability
-    const int64_t tbase = (int64_t)blockIdx.x * RS_TILE;
-    const int64_t wbase = tbase + (int64_t)w * (RS_ITEMS * 64);
-    uint64_t key[RS_ITEMS];
-    uint32_t rank[RS_ITEMS];
+    // a wave owns ITEMS*64 CONSECUTIVE items of the tile so that tile order == (wave, round, lane) order: stability
+    const int64_t tbase = (int64_t)blockIdx.x * TILE;
+    const int64_t wbase = tbase + (int64_t)w * (ITEMS * 64);
+    uint64_t key[ITEMS];
+    uint32_t rank[ITEMS];
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        int64_t idx = wbase + r * 64 + lane;
-        bool valid = idx < n;
-        key[r] = valid ? keys_in[idx] : 0;
-        uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t idx = wbase + r * 64 + lane;
+        key[r] = idx < n ? keys_in[idx] : 0;
+    }
+    // (the tile's row of output places: one coalesced load, in flight while the ranks are computed)
+    uint32_t gb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) { const uint32_t d = threadIdx.x + u * RS_THREADS; gb[u] = d < nbins ? hist_scanned[(size_t)blockIdx.x * nbins + d] : 0u; }
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t idx = wbase + r * 64 + lane;
+        const bool valid = idx < n;
+        const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
         uint64_t mask = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            uint64_t bal = __ballot((d >> b) & 1u);
-            mask &= ((d >> b) & 1u) ? bal : ~bal;
+        for (int b = 0; b < RS_MAXBITS; ++b) {
+            if (b < bits) {
+                const uint64_t bal = __ballot((d >> b) & 1u);
+                mask &= ((d >> b) & 1u) ? bal : ~bal;
+            }
         }
-        int leader = valid ? (__ffsll((unsigned long long)mask) - 1) : lane;
-        uint32_t cnt = (uint32_t)__popcll(mask);
+        const int leader = valid ? (__ffsll((unsigned long long)mask) - 1) : lane;
+        const uint32_t cnt = (uint32_t)__popcll(mask);
         uint32_t pre = 0;
         if (valid && lane == leader) {
             pre = vh[w][d];
@@ -199,27 +289,37 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_
     }
     __syncthreads();
     {
-        // per digit: this tile's count, the waves' offsets inside the digit's chunk, the chunk's place in the tile and in the output
-        const int d = threadIdx.x;
-        uint32_t tot = 0;
+        // per digit (thread t: digits 2t, 2t + 1): this tile's count, the waves' offsets inside the digit's chunk, the chunk's place in the tile
+        uint32_t tot[2];
 #pragma unroll
-        for (int ww = 0; ww < RS_WAVES; ++ww) { const uint32_t t = whist[ww][d]; whist[ww][d] = tot; tot += t; }
-        uint32_t inc = tot;
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t d = 2 * threadIdx.x + u;
+            uint32_t t = 0;
+            if (d < nbins) {
+#pragma unroll
+                for (int ww = 0; ww < RS_WAVES; ++ww) { const uint32_t x = whist[ww][d]; whist[ww][d] = t; t += x; }
+            }
+            tot[u] = t;
+        }
+        const uint32_t both = tot[0] + tot[1];
+        uint32_t inc = both;
 #pragma unroll
         for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= s2) inc += o; }
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
         uint32_t before = 0;
         for (int ww = 0; ww < w; ++ww) before += wsum[ww];
-        lstart[d] = before + inc - tot;
-        gbase[d] = hist_scanned[(size_t)d * nblocks + blockIdx.x];
+        if (2 * threadIdx.x < nbins) lstart[2 * threadIdx.x] = before + inc - both;
+        if (2 * threadIdx.x + 1 < nbins) lstart[2 * threadIdx.x + 1] = before + inc - both + tot[0];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const uint32_t d = threadIdx.x + u * RS_THREADS; if (d < nbins) gbase[d] = gb[u]; }
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < RS_ITEMS; ++r) {
-        int64_t idx = wbase + r * 64 + lane;
+    for (int r = 0; r < ITEMS; ++r) {
+        const int64_t idx = wbase + r * 64 + lane;
         if (idx < n) {
-            const uint32_t d = (uint32_t)(key[r] >> shift) & 255u;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
             const uint32_t lp = lstart[d] + whist[w][d] + rank[r];
             lkey[lp] = key[r];
             if (HAS_VAL) lval[lp] = vals_in[idx];
@@ -227,10 +327,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_
     }
     __syncthreads();
     const int64_t left = n - tbase;
-    const uint32_t nvalid = left < (int64_t)RS_TILE ? (uint32_t)left : (uint32_t)RS_TILE;
+    const uint32_t nvalid = left < (int64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
     for (uint32_t t = threadIdx.x; t < nvalid; t += RS_THREADS) {
         const uint64_t k = lkey[t];
-        const uint32_t d = (uint32_t)(k >> shift) & 255u;
+        const uint32_t d = (uint32_t)(k >> shift) & dmask;
         const uint32_t dst = gbase[d] + (t - lstart[d]);
         keys_out[dst] = k;
         if (HAS_VAL) vals_out[dst] = lval[t];
@@ -287,23 +387,31 @@ uint64_t reduce_max_u64(hipStream_t s, const uint64_t *p, int64_t n, DevBuf &tmp
     return h;
 }
 
+
+namespace {
+
 template <bool HAS_VAL>
 static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
 {
     if (n <= 1 || bit_hi <= bit_lo) return 0;
     ELBA_REQUIRE(n < (int64_t)0xFFFFFFFFLL, ELBA_ERR_UNSUPPORTED, "radix sort of >= 2^32 items");
-    const uint32_t nblocks = (uint32_t)((n + RS_TILE - 1) / RS_TILE);
-    const size_t hist_elems = (size_t)256 * nblocks;
-    const size_t hist_bytes = (hist_elems * sizeof(uint32_t) + 255) & ~(size_t)255;
-    tmp.reserve(hist_bytes + scan_tmp_elems((int64_t)hist_elems) * sizeof(uint64_t));
-    uint32_t *hist = tmp.as<uint32_t>();
-    uint64_t *scan_tmp = reinterpret_cast<uint64_t *>(tmp.as<char>() + hist_bytes);
+    constexpr int ITEMS = HAS_VAL ? 8 : ELBA_RS_KEY_ITEMS, TILE = RS_THREADS * ITEMS;
+    const int maxbits = getenv("ELBA_RS_BITS") ? atoi(getenv("ELBA_RS_BITS")) : RS_MAXBITS;     // (8: the digits of round 1, for A/B runs)
+    const int B = bit_hi - bit_lo, mb = maxbits < 1 ? 1 : (maxbits > RS_MAXBITS ? RS_MAXBITS : maxbits);
+    const int npass = (B + mb - 1) / mb;
+    const uint32_t nblocks = (uint32_t)((n + TILE - 1) / TILE);
+    const size_t hist_elems = (size_t)nblocks << RS_MAXBITS;
+    tmp.reserve((hist_elems + column_scan_tmp_elems((int64_t)nblocks, RS_MAXBINS)) * sizeof(uint32_t));
+    uint32_t *hist = tmp.as<uint32_t>(), *scan_tmp = hist + hist_elems;
     int cur = 0;
     uint64_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
-    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
-        hipLaunchKernelGGL(k_rs_hist, dim3(nblocks), dim3(RS_THREADS), 0, s, ki, n, shift, hist, nblocks);
-        scan_rec<uint32_t, uint32_t>(s, hist, hist, (int64_t)hist_elems, scan_tmp);
-        hipLaunchKernelGGL(k_rs_scatter<HAS_VAL>, dim3(nblocks), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift, hist, nblocks);
+    for (int q = 0, shift = bit_lo; q < npass; ++q) {
+        const int bits = B / npass + (q < B % npass ? 1 : 0);       // digits as even as they come: 34 bits = 9 + 9 + 8 + 8
+        const uint32_t nbins = 1u << bits;
+        hipLaunchKernelGGL((k_rs_hist<ITEMS>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const uint64_t *)ki, n, shift, bits, hist);
+        column_scan(s, hist, (int64_t)nblocks, nbins, scan_tmp);
+        hipLaunchKernelGGL((k_rs_scatter<HAS_VAL, ITEMS>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const uint64_t *)ki, (const uint64_t *)vi, ko, vo, n, shift, bits, (const uint32_t *)hist);
+        shift += bits;
         uint64_t *t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
@@ -311,6 +419,8 @@ static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *
     }
     return cur;
 }
+
+}  // namespace
 
 int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
 {
