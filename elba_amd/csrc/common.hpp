@@ -84,6 +84,22 @@ void exclusive_scan_u32(hipStream_t s, const uint32_t *in, uint32_t *out, int64_
 void exclusive_scan_u32_to_i64(hipStream_t s, const uint32_t *in, int64_t *out, int64_t n, DevBuf &tmp);
 // Stable LSD radix sort of (key u64, value u64) pairs on key bits [bit_lo, bit_hi).  Ping-pongs between the two
 // buffer pairs; returns 0 if the result is in (k0,v0), 1 if in (k1,v1).
+// hint bits (see Ctx::csr_hints) of the entry of read i in a column of L <= 64 entries (read << 32 | pos)
+__device__ __forceinline__ uint32_t column_hint(const uint64_t *col, uint32_t L, uint32_t i, uint32_t win_lo, uint32_t win_hi)
+{
+    bool own_g = false, own_w = false;
+    uint32_t mult = 0;
+    for (uint32_t t = 0; t < L; ++t) {
+        const uint32_t j = (uint32_t)(col[t] >> 32);
+        if (j == i) { ++mult; continue; }
+        const bool par = ((i ^ j) & 1u) ? j < i : j > i;
+        own_g |= par; own_w |= par || j < win_lo || j >= win_hi;
+    }
+    if (mult >= 2) return 0u;
+    return (own_g ? 0u : 1u) | (own_w ? 0u : 2u);
+}
+constexpr uint32_t HINT_MAX_COL = 64;
+
 int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
 // The same for bare 64-bit words (whatever rides in the bits outside [bit_lo, bit_hi) moves with them): returns 0 if the result is in k0, 1 if in k1.
 int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
@@ -138,7 +154,15 @@ struct Ctx {
     DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
     DevBuf csr_words;     // u64[Z] read << (pre_nb + pre_pb) | k-mer id << pre_pb | pos of every entry of a_csc, when pre_words (k_runs_emit -> the CSR build's sort)
-    bool pre_ready = false, pre_words = false; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
+    bool pre_ready = false, pre_words = false, pre_hints = false; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
+    // Ownership hints of the SpGEMM, two bits in every a_csr entry (kid << 32 | hint << 30 | pos; positions below 2^30): bit 30 = under the
+    // parity rule of owns_pair (spgemm_direct.hpp) this row accumulates NO pair of the entry's column and appears in it once — the column
+    // need not be fetched at all, the entry only counts one diagonal product; bit 31 = the same with every partner outside the row window
+    // counted as owned (calls without the mirror exchange between ranks).  They are a property of A, written when A is built (k_runs_emit /
+    // k_csc_to_csr_words: every entry sees its whole column there anyway).  csr_hints false: both bits are zero / positions use all 32 bits.
+    bool csr_hints = false, ov_hints_used = false;
+    int64_t A_products = 0;   // sum over the window's row entries of their column's length (what the SpGEMM reports as `products`)
+    DevBuf prod_ctr;
     DevBuf kid_of_entry;  // u64[Z] k-mer id of every entry of a_csc (written with the columns; what the CSR build sorts by read)
     elba_kmer_stats kstats{};
 

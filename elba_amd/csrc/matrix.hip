@@ -12,31 +12,50 @@ namespace elba {
 
 namespace {
 
-__global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, const uint64_t *csc, int64_t Z, uint64_t *row_keys, uint64_t *csr_vals)
+// hint bits of entry z (read i) from its column, and the column's length added to the window's product count (one atomic per wavefront)
+__device__ __forceinline__ uint32_t entry_hint(const uint32_t *colptr, const uint64_t *csc, uint64_t kid, uint32_t i, bool hints, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr)
 {
-    int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (z >= Z) return;
-    uint64_t kid = kid_keys[z] >> kid_shift;
-    uint64_t e = csc[z];
-    row_keys[z] = e >> 32;                                   // read
-    csr_vals[z] = (kid << 32) | (e & 0xFFFFFFFFull);         // kid | pos
+    const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0;
+    unsigned long long mine = i >= win_lo && i < win_hi ? L : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(prod_ctr, mine);
+    return hints && L <= HINT_MAX_COL ? column_hint(csc + c0, L, i, win_lo, win_hi) : 0u;
 }
 
-// CSR build with ONE word per entry when read, k-mer id and position fit 64 bits together: read << (nb + pb) | kid << pb | pos, sorted
-// (stably) on the read bits only — the radix passes move 8 bytes per entry instead of 16 — and unpacked into kid << 32 | pos afterwards
-__global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, const uint64_t *csc, int64_t Z, int nb, int pb, uint64_t *words)
+__global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, const uint32_t *colptr, const uint64_t *csc, int64_t Z, uint64_t *row_keys, uint64_t *csr_vals,
+                                  bool hints, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (z >= Z) return;
+    const bool in = z < Z;
+    if (!in) z = Z - 1;                                      // (whole wavefronts reach the reduction inside entry_hint)
+    uint64_t kid = kid_keys[z] >> kid_shift;
+    uint64_t e = csc[z];
+    const uint32_t h = entry_hint(colptr, csc, kid, in ? (uint32_t)(e >> 32) : 0xFFFFFFFFu, hints && in, in ? win_lo : 0u, in ? win_hi : 0u, prod_ctr);
+    if (!in) return;
+    row_keys[z] = e >> 32;                                   // read
+    csr_vals[z] = (kid << 32) | ((uint64_t)h << 30) | (e & 0xFFFFFFFFull);         // kid | hint | pos
+}
+
+// CSR build with ONE word per entry when read, k-mer id, the two hint bits and the position fit 64 bits together:
+// read << (nb + pb + 2) | kid << (pb + 2) | hint << pb | pos, sorted on the read bits only (stable: rows come out in (kid, pos) order)
+__global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, const uint32_t *colptr, const uint64_t *csc, int64_t Z, int nb, int pb, uint64_t *words,
+                                   bool hints, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr)
+{
+    int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = z < Z;
+    if (!in) z = Z - 1;
     const uint64_t kid = kid_keys[z] >> kid_shift, e = csc[z];
-    words[z] = ((e >> 32) << (nb + pb)) | (kid << pb) | (e & 0xFFFFFFFFull);
+    const uint32_t h = entry_hint(colptr, csc, kid, in ? (uint32_t)(e >> 32) : 0xFFFFFFFFu, hints && in, in ? win_lo : 0u, in ? win_hi : 0u, prod_ctr);
+    if (!in) return;
+    words[z] = ((e >> 32) << (nb + pb + 2)) | (kid << (pb + 2)) | ((uint64_t)h << pb) | (e & 0xFFFFFFFFull);
 }
 __global__ void k_unpack_csr_words(const uint64_t *words, int64_t Z, int nb, int pb, uint64_t *csr)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= Z) return;
     const uint64_t w = words[z];
-    csr[z] = (((w >> pb) & ((1ull << nb) - 1)) << 32) | (w & ((1ull << pb) - 1));
+    csr[z] = (((w >> (pb + 2)) & ((1ull << nb) - 1)) << 32) | (((w >> pb) & 3ull) << 30) | (w & ((1ull << pb) - 1));
 }
 
 __global__ void k_colrow_to_csc(const uint64_t *colrow, const uint64_t *pos, int64_t Z, uint64_t *csc)
@@ -519,32 +538,50 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         ELBA_HIP(hipStreamSynchronize(s));
     }
     c.pos16 = maxpos < 65536;
+    ELBA_REQUIRE(win_lo >= 0 && (win_hi < 0 || (win_lo <= win_hi && win_hi <= M)), ELBA_ERR_INVALID_ARG, "bad row window");
+    c.plan = getenv("ELBA_PLAN") != nullptr;
     // stable sort by read: rows come out ordered by (kid, pos)
     c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_c.reserve((size_t)(Z + 1) * 8);
     const int mb = bits_for((uint64_t)(M > 0 ? M - 1 : 0)), nb = bits_for((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_for(maxpos);
-    if (mb + nb + pb <= 64 && !getenv("ELBA_CSR_PAIRS")) {
+    const bool hints = pre ? c.pre_hints : (pb <= 30 && !c.plan && !getenv("ELBA_NO_HINTS"));
+    const uint32_t wlo = (uint32_t)win_lo, whi = (uint32_t)(win_hi < 0 ? M : win_hi);
+    c.prod_ctr.reserve(64);
+    unsigned long long *prod_ctr = c.prod_ctr.as<unsigned long long>();
+    if (!pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 8, s));      // (pre: k_runs_emit has counted)
+    if (mb + nb + pb + 2 <= 64 && !getenv("ELBA_CSR_PAIRS")) {
         const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;
         uint64_t *w0 = have_words ? c.csr_words.as<uint64_t>() : c.ws_a.as<uint64_t>(), *w1 = c.ws_c.as<uint64_t>();
-        if (Z > 0 && !have_words) hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
-        const int where = radix_sort_keys(s, w0, w1, Z, nb + pb, nb + pb + mb, c.ws_sort);
+        ELBA_REQUIRE(!pre || have_words, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
+        if (Z > 0 && !have_words)
+            hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0,
+                               hints, wlo, whi, prod_ctr);
+        const int where = radix_sort_keys(s, w0, w1, Z, nb + pb + 2, nb + pb + 2 + mb, c.ws_sort);
         const uint64_t *sorted = where ? w1 : w0;
-        group_offsets_u32(s, sorted, nb + pb, Z, c.a_rowptr.as<uint32_t>(), M);
+        group_offsets_u32(s, sorted, nb + pb + 2, Z, c.a_rowptr.as<uint32_t>(), M);
         if (Z > 0) hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, c.a_csr.as<uint64_t>());
     } else {
+        ELBA_REQUIRE(!pre || !c.pre_words, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
         c.ws_b.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
         uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
         if (Z > 0) {
             int64_t nbk = (Z + 255) / 256;
-            hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kid_keys, kid_shift, c.a_csc.as<uint64_t>(), Z, k0, v0);
+            if (pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 8, s));
+            hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, k0, v0,
+                               hints, wlo, whi, prod_ctr);
         }
         int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, mb, c.ws_sort);
         const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;
         group_offsets_u32(s, rk, 0, Z, c.a_rowptr.as<uint32_t>(), M);
         if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
     }
-    ELBA_REQUIRE(win_lo >= 0 && (win_hi < 0 || (win_lo <= win_hi && win_hi <= M)), ELBA_ERR_INVALID_ARG, "bad row window");
+    c.csr_hints = hints;
+    {
+        unsigned long long hp = 0;
+        ELBA_HIP(hipMemcpyAsync(&hp, prod_ctr, 8, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        c.A_products = (int64_t)hp;
+    }
     c.row_lo = win_lo; c.row_hi = win_hi;
-    c.plan = getenv("ELBA_PLAN") != nullptr;
     if (c.plan) {
         c.a_rowprod.reserve((size_t)(M + 1) * 4);
         c.a_dec.reserve((size_t)(Z + 1) * 8);

@@ -74,6 +74,7 @@ struct alignas(32) StageRec { uint4 a, b; };
 struct OvParams {
     // plan-free path (spgemm_direct.hpp): the two orientations of A and nothing else
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint64_t *a_ell; const uint32_t *a_colptr; const uint64_t *a_csc;
+    uint32_t hint_mask, pos_mask;   // which hint bit of a row entry lets this call skip its column (0: none) / the position bits (Ctx::csr_hints)
     uint32_t s_log2, lpc_log2, max_col;      // padded column stride 2^s_log2 (a_ell); lanes per row entry 2^lpc_log2; longest column
     unsigned long long fb_enough;            // row entries behind the in-call partner / entry ratio at which it counts as settled (nobody touches the hot sums any more)
     const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_cscj; const uint32_t *a_roworder;
@@ -620,7 +621,7 @@ static void ov_finish_stats(Ctx &c, OvCounters &hc, elba_overlap_stats &st, int 
         const uint32_t old = c.ov_prior_q16;
         if (old == 0 || q > old + old / 10 || q + old / 10 < old) c.ov_prior_q16 = q;
     }
-    st.products = (int64_t)hc.products;
+    st.products = c.ov_hints_used ? c.A_products : (int64_t)hc.products;      // (entries that skip their column do not see its length: counted when A was built)
     st.nnz_before_prune = (int64_t)hc.yraw;
     st.nnz = Y;
     st.nnz_diag = (int64_t)hc.ndiag;
@@ -693,6 +694,9 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.s_log2 = c.s_log2; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
     p.half = phase == 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
+    p.pos_mask = c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu;
+    p.hint_mask = !c.csr_hints ? 0u : (p.half == 2u ? 1u << 30 : (p.half == 1u ? 1u << 31 : 0u));
+    c.ov_hints_used = p.hint_mask != 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);
@@ -934,6 +938,7 @@ void stage_create_seed_matrix(Ctx &c)
     p.pay_pb = c.pay_pb;
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
     p.half = c.half ? 1u : 0u;
+    p.pos_mask = 0xFFFFFFFFu; c.ov_hints_used = false;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob)

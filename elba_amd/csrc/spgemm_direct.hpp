@@ -1,6 +1,6 @@
 // spgemm_direct.hpp — the numeric kernel of the overlap SpGEMM, PLAN-FREE (included by spgemm.hip inside its anonymous namespace).
 //
-// Input is A as the k-mer stage leaves it and nothing else: CSR (a_rowptr, a_csr: kid << 32 | pos, rows in (kid, pos) order) and the
+// Input is A as the k-mer stage leaves it and nothing else: CSR (a_rowptr, a_csr: kid << 32 | hint << 30 | pos, rows in (kid, pos) order) and the
 // k-mer columns — padded to a power-of-two stride (a_ell: column kid occupies the S = 2^s_log2 consecutive 8-byte words from kid * S,
 // entries (read << 32 | pos) in (read, pos) order, the rest all ones) when no column is longer than 64 entries, else plain CSC
 // (a_colptr, a_csc).  No per-row schedule, no descriptors, no row order, no product counts: whatever the product needs beyond the two
@@ -44,6 +44,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
     const uint32_t lb = p.lpc_log2, sub = tid & ((1u << lb) - 1u), grp = tid >> lb, EPT = (uint32_t)BLOCK >> lb;
     const uint32_t fbits = p.fbits, fmask = (1u << fbits) - 1u, sb = p.s_log2;
     const bool ell = p.a_ell != nullptr;
+    const uint32_t hmask = p.hint_mask, pmask = p.pos_mask;      // ownership hints in the row entries (Ctx::csr_hints): skip bit of this call's mode, position bits
     const uint2 *csr2 = reinterpret_cast<const uint2 *>(p.a_csr);      // .x = position in the read, .y = k-mer id
     unsigned long long chunk_off = 0;
     uint32_t chunk_left = 0;
@@ -224,8 +225,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             };
             auto gather = [&](uint4 *x, const uint2 *c, uint32_t t0) {
 #pragma unroll
-                for (int k = 0; k < DK; ++k)
-                    x[k] = t0 + (uint32_t)k * EPT + grp < nnz ? *reinterpret_cast<const uint4 *>(p.a_ell + (((unsigned long long)c[k].y << sb) + 2u * sub)) : ones;
+                for (int k = 0; k < DK; ++k)      // (an entry hinted "owns no pair of its column" fetches nothing: Ctx::csr_hints)
+                    x[k] = t0 + (uint32_t)k * EPT + grp < nnz && !(c[k].x & hmask) ? *reinterpret_cast<const uint4 *>(p.a_ell + (((unsigned long long)c[k].y << sb) + 2u * sub)) : ones;
             };
             load_ce(c_cur, 0u);
             gather(x_cur, c_cur, 0u);
@@ -243,8 +244,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
 #pragma unroll
                 for (int k = 0; k < DK; ++k) {                                                                                                    // (3)
                     const uint32_t seq = ((t0 + (uint32_t)k * EPT + grp) << fbits) | (2u * sub);
-                    slot(x_cur[k].y, x_cur[k].x, seq, c_cur[k].x);
-                    slot(x_cur[k].w, x_cur[k].z, seq + 1u, c_cur[k].x);
+                    if (hmask) dg += (uint32_t)__popcll(__ballot(sub == 0 && (c_cur[k].x & hmask) != 0u));      // skipped entries: their one diagonal product (a lane beyond the row holds zeros)
+                    slot(x_cur[k].y, x_cur[k].x, seq, c_cur[k].x & pmask);
+                    slot(x_cur[k].w, x_cur[k].z, seq + 1u, c_cur[k].x & pmask);
                 }
                 if (tab.abandoned()) {
                     if (tid == 0) { const uint32_t done = t0 + EPR; misc[11] = done < nnz ? done : nnz; }
@@ -259,15 +261,16 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 const uint32_t r = t0 + grp;
                 uint2 c = make_uint2(0u, 0u);
                 uint32_t c0 = 0, len = 0;
-                if (r < nnz) { c = csr2[rs + r]; c0 = p.a_colptr[c.y]; len = p.a_colptr[c.y + 1] - c0; }
+                if (r < nnz) { c = csr2[rs + r]; if (!(c.x & hmask)) { c0 = p.a_colptr[c.y]; len = p.a_colptr[c.y + 1] - c0; } }
+                if (hmask) dg += (uint32_t)__popcll(__ballot(sub == 0 && (c.x & hmask) != 0u));
 #pragma unroll 1
                 for (uint32_t b = 2u * sub; __ballot(b < len) != 0; b += 2u << lb) {      // wave-uniform trip count: chunks of 2 * LPC entries
                     uint2 e0 = make_uint2(0u, EMPTY), e1 = e0;
                     if (b < len) e0 = reinterpret_cast<const uint2 *>(p.a_csc)[c0 + b];
                     if (b + 1u < len) e1 = reinterpret_cast<const uint2 *>(p.a_csc)[c0 + b + 1u];
                     const uint32_t seq = (r << fbits) | b;
-                    slot(e0.y, e0.x, seq, c.x);
-                    slot(e1.y, e1.x, seq + 1u, c.x);
+                    slot(e0.y, e0.x, seq, c.x & pmask);
+                    slot(e1.y, e1.x, seq + 1u, c.x & pmask);
                 }
                 if (tab.abandoned()) {
                     if (tid == 0) { const uint32_t done = t0 + EPT; misc[11] = done < nnz ? done : nnz; }
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             }
         }
         if (!GLOBAL && tail != head) drain(tail - head);
-        if (pr != 0 && lane == 0) { lds_add32(&misc[0], dg); lds_add32(&misc[12], pr); }
+        if ((pr | dg) != 0 && lane == 0) { lds_add32(&misc[0], dg); lds_add32(&misc[12], pr); }
         ELBA_DSTAMP(2);
         publish_next();
         if (GLOBAL) __syncthreads(); else lds_barrier();
@@ -353,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             uint32_t nup = 0, mx = 0, nmir = 0;
             auto seed_at = [&](uint32_t a, uint32_t &q, uint32_t &t) {      // sequence number -> the two positions (32-bit accumulators only)
                 const uint2 ce = csr2[rs + (a >> fbits)];
-                q = ce.x;
+                q = ce.x & pmask;
                 t = ell ? (uint32_t)p.a_ell[((unsigned long long)ce.y << sb) + (a & fmask)] : (uint32_t)p.a_csc[p.a_colptr[ce.y] + (a & fmask)];
             };
             for (uint32_t t = tid; t < ysurv + hasd; t += BLOCK) {
@@ -373,7 +376,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                     // B(i,i): first / last product of the fold = the row's first / last entry paired with itself (rows are in (kid, pos)
                     // order, columns in (read, pos) order: the first entry of the row is the first of read i in its column)
                     v.numshared = (int32_t)misc[0];
-                    v.q0 = v.t0 = csr2[rs].x; v.q1 = v.t1 = csr2[rs + nnz - 1u].x;
+                    v.q0 = v.t0 = csr2[rs].x & pmask; v.q1 = v.t1 = csr2[rs + nnz - 1u].x & pmask;
                 }
                 // the partner's row gets the mirrored entry: draw its slot there now; k_mirror places it once the row pointers are known
                 uint32_t tick = 0xFFFFFFFFu;

@@ -200,7 +200,8 @@ typedef struct {
 typedef struct {
     int64_t M, N, Z, Y;
     const void *a_rowptr;  /* u32[M+1] */
-    const void *a_csr;     /* u64[Z]: kid<<32 | pos */
+    const void *a_csr;     /* u64[Z]: kid<<32 | hint<<30 | pos: positions below 2^30 (else hint = 0 and pos takes 32 bits); hint = two ownership bits
+                              the SpGEMM reads (an entry whose row accumulates no pair of its column skips the column) */
     const void *a_colptr;  /* u32[N+1] */
     const void *a_csc;     /* u64[Z]: read<<32 | pos */
     const void *b_rowptr;  /* i64[M+1] */
