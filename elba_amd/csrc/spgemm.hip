@@ -718,6 +718,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         const int lds = 160 * 1024;
 #define ELBA_ATTR(B, P, D) ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<B, false, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
         ELBA_ATTR(512, true, 1); ELBA_ATTR(512, true, 2); ELBA_ATTR(512, true, 4); ELBA_ATTR(1024, true, 1); ELBA_ATTR(1024, true, 2); ELBA_ATTR(1024, true, 4);
+        ELBA_ATTR(256, false, 1); ELBA_ATTR(256, false, 2); ELBA_ATTR(256, false, 4);
         ELBA_ATTR(512, false, 1); ELBA_ATTR(512, false, 2); ELBA_ATTR(512, false, 4); ELBA_ATTR(1024, false, 1); ELBA_ATTR(1024, false, 2); ELBA_ATTR(1024, false, 4);
 #undef ELBA_ATTR
         attr_done = true;
@@ -755,8 +756,8 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         }
         if (timed) c.ov_marks.mark(1, s);
         if (nrows > 0) {
-            // bytes behind the table: misc words + one product ring per wavefront (128 entries of 12 / 8 bytes)
-            auto X = [&](int B, bool P) { return (size_t)256 + (size_t)(B / 64) * (P ? 1536 : 1024); };
+            // bytes behind the table: misc words + per wavefront one product ring (128 entries of 12 / 8 bytes) and one row-entry FIFO (128 x 12 bytes)
+            auto X = [&](int B, bool P) { return (size_t)256 + (size_t)(B / 64) * (P ? 3072 : 2560); };
             const bool all_tiers = !c.ov_tiers_known;
             skipped_tiers = 0;
 #define ELBA_DTIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
@@ -778,8 +779,8 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
                 ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, false, cus * 3, (size_t)18 * 2048 + X(512, false), 2, 11u));
                 ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 4096 + X(1024, false), 3, 12u));
             }
-            ELBA_DTIER(4, ELBA_LAUNCH_D(512, false, false, cus, (size_t)18 * 8192 + X(512, false), 4, 13u));
-            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, (size_t)256, NUM_LDS_TIERS, 0u));
+            ELBA_DTIER(4, ELBA_LAUNCH_D(256, false, false, cus, (size_t)18 * 8192 + X(256, false), 4, 13u));      // (4 wavefronts: 8192 slots + their rings fill the 160 KB)
+            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, X(256, false), NUM_LDS_TIERS, 0u));
 #undef ELBA_LAUNCH_D
 #undef ELBA_DTIER
             ELBA_HIP(hipGetLastError());

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
         bool full = false;
         uint32_t dg = 0, pr = 0;                 // diagonal products / all products (valid column entries) of the row, as seen by this wavefront (uniform)
         uint32_t head = 0, tail = 0;             // ring positions (uniform)
-        uint32_t *qj = misc + 64 + (tid >> 6) * (PAY ? 384u : 256u);
+        uint32_t *qj = misc + 64 + (tid >> 6) * (PAY ? 768u : 640u);      // per wavefront: product ring (128 x 12 or 8 bytes), then the entry FIFO of the padded-column path (128 x 12 bytes)
         uint32_t *qs = qj + RING;
         unsigned long long *qv = reinterpret_cast<unsigned long long *>(qj + RING);
         auto drain = [&](uint32_t n) {           // n <= 64 products leave the ring, one per lane
@@ -208,52 +208,86 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             if (tail - head >= 64u) drain(64u);
         };
         if (ell) {
-            // DK trips of the workgroup travel together (a "round": DK row entries and DK column words per lane), two rounds in flight.
-            // Each round (1) consumes what the previous one requested — this round's column words and the next round's row entries: one
-            // wait — (2) requests the next round's column words and the row entries of the round after it, (3) updates the accumulator
-            // (LDS only), during which the requests land.  What bounds the loop is the number of 64-byte lines a CU has in flight
-            // (profiles/r02_gather64_microbench.txt: 46-52 G random lines/s chip-wide, reached only with hundreds of lines in flight per
-            // CU): 16 lines per wave-instruction, 2 * DK instructions in flight per wave.
+            // Every wavefront walks the row in chunks of 64 consecutive entries (chunk c belongs to wave c mod #waves: one coalesced 512-byte
+            // load) and COMPACTS them: an entry hinted "this row accumulates no pair of its column" (Ctx::csr_hints: 55 % of the entries of
+            // 15 %-error reads) only counts its one diagonal product; the others join a 128-entry FIFO in LDS (ballot + popcount prefix).
+            // Groups of LPC lanes then take entries off the FIFO, TR wave-trips per iteration, and fetch their columns — every lane of every
+            // gather instruction fetches a column that is needed.  Two iterations are in flight: an iteration (1) consumes the column words
+            // the previous one requested, (2) refills the FIFO from the chunks prefetched an iteration ago and requests the next ones,
+            // (3) requests the next TR trips' column words, (4) updates the accumulator (LDS only) while the requests land.  What bounds the
+            // loop is the number of 64-byte lines a CU has in flight (profiles/r02_gather64_microbench.txt: 46-52 G random lines/s chip-wide).
             const uint4 ones = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-            constexpr uint32_t RND = (uint32_t)DK;
-            const uint32_t EPR = EPT * RND;                       // row entries per round
-            uint2 c_cur[DK], c_nxt[DK];
-            uint4 x_cur[DK];
-            auto load_ce = [&](uint2 *c, uint32_t t0) {
-#pragma unroll
-                for (int k = 0; k < DK; ++k) { const uint32_t r = t0 + (uint32_t)k * EPT + grp; c[k] = r < nnz ? csr2[rs + r] : make_uint2(0u, 0u); }
+            constexpr int TR = 2 * DK;
+            constexpr uint32_t FQ = 128, NWV = (uint32_t)BLOCK / 64u, NONE = 0xFFFFFFFFu;
+            const uint32_t gw = lane >> lb, EW = 64u >> lb;               // this lane's entry within a wave-trip, entries per wave-trip
+            uint32_t *fq = qj + (PAY ? 384u : 256u);                      // FIFO: 3 words per entry (position, k-mer id, rank in the row), behind the product ring
+            uint32_t fh = 0, ft = 0;                                      // FIFO positions (uniform)
+            uint32_t cnext = (tid >> 6) * 64u;                            // first row entry of the next chunk to request
+            uint2 ea, eb;
+            uint32_t ca, cb;                                              // the two chunks on their way (first row entry, or NONE)
+            auto load_chunk = [&](uint2 &en, uint32_t &cbase) {
+                cbase = cnext < nnz ? cnext : NONE;
+                en = cbase != NONE && cbase + lane < nnz ? csr2[rs + cbase + lane] : make_uint2(0u, 0u);
+                if (cbase != NONE) cnext += NWV * 64u;
             };
-            auto gather = [&](uint4 *x, const uint2 *c, uint32_t t0) {
-#pragma unroll
-                for (int k = 0; k < DK; ++k)      // (an entry hinted "owns no pair of its column" fetches nothing: Ctx::csr_hints)
-                    x[k] = t0 + (uint32_t)k * EPT + grp < nnz && !(c[k].x & hmask) ? *reinterpret_cast<const uint4 *>(p.a_ell + (((unsigned long long)c[k].y << sb) + 2u * sub)) : ones;
+            auto consume = [&]() {                                        // chunk `ea` -> FIFO; the chunk after it moves up, the one after that is requested
+                const bool valid = ca + lane < nnz;
+                const bool need = valid && !(ea.x & hmask);
+                const uint64_t mn = __ballot(need);
+                dg += (uint32_t)__popcll(__ballot(valid && !need));       // skipped entries: their one diagonal product
+                if (need) {
+                    const uint32_t at = ((ft + (uint32_t)__popcll(mn & lt)) & (FQ - 1u)) * 3u;
+                    fq[at] = ea.x & pmask; fq[at + 1u] = ea.y; fq[at + 2u] = ca + lane;
+                }
+                ft += (uint32_t)__popcll(mn);
+                ea = eb; ca = cb;
+                load_chunk(eb, cb);
             };
-            load_ce(c_cur, 0u);
-            gather(x_cur, c_cur, 0u);
-            load_ce(c_nxt, EPR);
+            auto issue = [&](uint4 *x, uint32_t *pq, uint32_t *rk) {      // the next TR trips leave the FIFO: their column words are requested
+#pragma unroll
+                for (int u = 0; u < TR; ++u) {
+                    const uint32_t k = (uint32_t)u * EW + gw;
+                    x[u] = ones; pq[u] = 0; rk[u] = 0;
+                    if (k < ft - fh) {
+                        const uint32_t at = ((fh + k) & (FQ - 1u)) * 3u;
+                        pq[u] = fq[at]; rk[u] = fq[at + 2u];
+                        x[u] = *reinterpret_cast<const uint4 *>(p.a_ell + (((unsigned long long)fq[at + 1u] << sb) + 2u * sub));
+                    }
+                }
+                const uint32_t n = ft - fh;
+                fh += n < (uint32_t)TR * EW ? n : (uint32_t)TR * EW;
+            };
+            load_chunk(ea, ca); load_chunk(eb, cb);
+            if (ca != NONE) consume();
+            if (ca != NONE && ft - fh <= 64u) consume();
+            uint4 x_cur[TR];
+            uint32_t pq_cur[TR], rk_cur[TR];
+            issue(x_cur, pq_cur, rk_cur);
 #pragma unroll 1
-            for (uint32_t t0 = 0; t0 < nnz; t0 += EPR) {
+            for (uint32_t it = 0;; ++it) {
 #pragma unroll
-                for (int k = 0; k < DK; ++k)
-                    asm volatile("" : "+v"(x_cur[k].x), "+v"(x_cur[k].y), "+v"(x_cur[k].z), "+v"(x_cur[k].w), "+v"(c_nxt[k].x), "+v"(c_nxt[k].y) : : "memory");      // (1)
-                uint4 x_nxt[DK];
-                uint2 c_nn[DK];
-                gather(x_nxt, c_nxt, t0 + EPR);                                                                                                   // (2)
-                load_ce(c_nn, t0 + 2u * EPR);
-                if (t0 == 0) resolve_early(); else if (t0 == EPR) bounds_early();
+                for (int u = 0; u < TR; ++u) asm volatile("" : "+v"(x_cur[u].x), "+v"(x_cur[u].y), "+v"(x_cur[u].z), "+v"(x_cur[u].w) : : "memory");                   // (1)
+                asm volatile("" : "+v"(ea.x), "+v"(ea.y) : : "memory");
+                if (ca != NONE && ft - fh <= 64u) consume();                                                                                          // (2)
+                if (ca != NONE && ft - fh <= 64u) consume();
+                const bool last = ft == fh && ca == NONE;                 // nothing left to request: this iteration's words are the row's last
+                uint4 x_nxt[TR];
+                uint32_t pq_nxt[TR], rk_nxt[TR];
+                issue(x_nxt, pq_nxt, rk_nxt);                                                                                                         // (3)
+                if (it == 0) resolve_early(); else if (it == 1) bounds_early();
 #pragma unroll
-                for (int k = 0; k < DK; ++k) {                                                                                                    // (3)
-                    const uint32_t seq = ((t0 + (uint32_t)k * EPT + grp) << fbits) | (2u * sub);
-                    if (hmask) dg += (uint32_t)__popcll(__ballot(sub == 0 && (c_cur[k].x & hmask) != 0u));      // skipped entries: their one diagonal product (a lane beyond the row holds zeros)
-                    slot(x_cur[k].y, x_cur[k].x, seq, c_cur[k].x & pmask);
-                    slot(x_cur[k].w, x_cur[k].z, seq + 1u, c_cur[k].x & pmask);
+                for (int u = 0; u < TR; ++u) {                                                                                                        // (4)
+                    const uint32_t seq = (rk_cur[u] << fbits) | (2u * sub);
+                    slot(x_cur[u].y, x_cur[u].x, seq, pq_cur[u]);
+                    slot(x_cur[u].w, x_cur[u].z, seq + 1u, pq_cur[u]);
                 }
                 if (tab.abandoned()) {
-                    if (tid == 0) { const uint32_t done = t0 + EPR; misc[11] = done < nnz ? done : nnz; }
+                    if (tid == 0) { const uint32_t done = ca != NONE ? ca : nnz; misc[11] = done < nnz ? done : nnz; }
                     break;
                 }
+                if (last) break;
 #pragma unroll
-                for (int k = 0; k < DK; ++k) { c_cur[k] = c_nxt[k]; x_cur[k] = x_nxt[k]; c_nxt[k] = c_nn[k]; }
+                for (int u = 0; u < TR; ++u) { x_cur[u] = x_nxt[u]; pq_cur[u] = pq_nxt[u]; rk_cur[u] = rk_nxt[u]; }
             }
         } else {
 #pragma unroll 1
