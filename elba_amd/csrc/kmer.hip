@@ -454,21 +454,19 @@ __global__ void k_block_reads(const uint64_t *inst_off, const uint64_t *byte_off
 // pointer in LDS; runs that reach across the tile's end are finished by the tile of their head (64 items of halo), so UPPER <= 62 here.
 // The entry is the dup-th instance among the 2^drop candidates behind the payload whose canonical k-mer is the run's (see
 // k_instance_entries); its read comes from the block table.  With `csr_words` the entry is also written as the one-word sort key of the CSR
-// build (read << (nb + pb) | k-mer id << pb | pos, matrix.hip): no column-id array, no conversion pass.
+// build (read << (nb + pb + 2) | k-mer id << (pb + 2) | pos, matrix.hip: its two hint bits are added there): no column-id array, no conversion pass.
 struct EmitOut {
     uint64_t *rel_kmers; uint32_t *rel_counts, *colptr;
     uint64_t *csc, *csr_words, *kid_of_entry;
     unsigned long long *prod_ctr;     // += sum over reliable runs of length^2 (the SpGEMM's product count, Ctx::A_products)
     int nb, pb;
-    bool hints;                       // write the ownership hints of the SpGEMM into the sort keys (Ctx::csr_hints)
 };
 __global__ __launch_bounds__(RUN_THREADS) void k_runs_emit(RunParams p, EnumParams e, const BlockInfo *block_read, int drop, const uint32_t *off_rel, const uint32_t *off_ent, EmitOut o)
 {
     constexpr int NW = RUN_THREADS / 64, SLICES = RUN_ITEMS * NW;
     __shared__ uint64_t eqmask[SLICES + 2];
     __shared__ uint32_t srel[SLICES + 1], sent[SLICES + 1];
-    __shared__ uint32_t hkid[RUN_TILE], hat[RUN_TILE], hread[RUN_TILE + 64];
-    __shared__ uint8_t hlen[RUN_TILE];
+    __shared__ uint32_t hkid[RUN_TILE], hat[RUN_TILE];
     const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint64_t lt = (1ull << lane) - 1;
     const uint64_t T0 = (uint64_t)blockIdx.x * RUN_TILE;
@@ -516,7 +514,7 @@ __global__ __launch_bounds__(RUN_THREADS) void k_runs_emit(RunParams p, EnumPara
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d, 64);
-    if (lane == 0 && sq) atomicAdd(o.prod_ctr, sq);
+    if (lane == 0 && sq) atomicAdd(&o.prod_ctr[(blockIdx.x & 63u) * 16u], sq);      // (64 counters on lines of their own: one hot word would serialise 4 M wavefronts)
     __syncthreads();
     if (tid == 0) {                               // exclusive prefixes over the slices, in item order (slice = i * NW + wave)
         uint32_t x = off_rel[blockIdx.x], y = off_ent[blockIdx.x];
@@ -536,21 +534,22 @@ __global__ __launch_bounds__(RUN_THREADS) void k_runs_emit(RunParams p, EnumPara
             const uint32_t kid = srel[i * NW + w] + (uint32_t)__popcll(br & lt), at = sent[i * NW + w] + inc - l;
             o.rel_kmers[kid] = (word[i] >> ib) << (64 - p.k2);
             o.rel_counts[kid] = l; o.colptr[kid] = at;
-            hkid[q] = kid; hat[q] = at; hlen[q] = (uint8_t)l;
+            hkid[q] = kid; hat[q] = at;
         } else if (l != 0) hat[q] = 0xFFFFFFFFu;
     }
     __syncthreads();
     const uint64_t pmask = (1ull << ib) - 1;
-    // q: place in tile + halo; wd: its word.  Returns the place of the item's head (in the tile, reliable) or ~0; rd / pos: the instance behind it
-    auto resolve = [&](uint32_t q, uint64_t wd, uint32_t &rd, uint32_t &pos) -> uint32_t {
+    auto emit = [&](uint32_t q, uint64_t wd) {        // q: place in tile + halo; wd: its word
         const uint32_t a = q >> 6, s = q & 63u;
         const uint64_t cur = eqmask[a], prv = a ? eqmask[a - 1] : ~0ull;
         const uint64_t win = (cur << (63u - s)) | (s < 63u ? prv >> (s + 1u) : 0ull);       // bit 63 = this item's bit, bit 62 = its left neighbour's, ...
         const uint32_t dist = win == ~0ull ? 64u : (uint32_t)__builtin_clzll(~win);
-        if (dist > q || dist >= 63u) return 0xFFFFFFFFu;          // the head sits in the previous tile (its tile writes this entry), or the run is too long to be reliable
+        if (dist > q || dist >= 63u) return;          // the head sits in the previous tile (its tile writes this entry), or the run is too long to be reliable
         const uint32_t h = q - dist;
-        if (h >= (uint32_t)RUN_TILE) return 0xFFFFFFFFu;          // (halo items only) the head is in the halo: the next tile's
-        if (hat[h] == 0xFFFFFFFFu) return 0xFFFFFFFFu;
+        if (h >= (uint32_t)RUN_TILE) return;          // (halo items only) the head is in the halo: the next tile's
+        const uint32_t at = hat[h];
+        if (at == 0xFFFFFFFFu) return;
+        const uint32_t kid = hkid[h];
         const uint64_t gq = T0 + q;
         const uint64_t hp = wd & pmask;
         uint64_t g = hp << drop;
@@ -569,41 +568,18 @@ __global__ __launch_bounds__(RUN_THREADS) void k_runs_emit(RunParams p, EnumPara
                 if (canonical_at_off(e, boff, (uint32_t)(g - off_lo)) == want) { if (dup == 0) break; --dup; }
             }
         }
-        rd = lo; pos = (uint32_t)(g - off_lo);
-        hread[q] = lo;
-        return h;
+        const uint32_t pos = (uint32_t)(g - off_lo);
+        const uint32_t z = at + dist;
+        o.csc[z] = ((uint64_t)lo << 32) | pos;
+        if (o.csr_words) o.csr_words[z] = ((uint64_t)lo << (o.nb + o.pb + 2)) | ((uint64_t)kid << (o.pb + 2)) | pos;      // (hint bits: k_add_hints, matrix.hip)
+        else o.kid_of_entry[z] = kid;
     };
-    uint32_t hh[RUN_ITEMS + 1], rd[RUN_ITEMS + 1], ps[RUN_ITEMS + 1];
 #pragma unroll
     for (int i = 0; i < RUN_ITEMS; ++i) {
         const uint32_t q = (uint32_t)i * RUN_THREADS + tid;
-        hh[i] = T0 + q < p.I ? resolve(q, word[i], rd[i], ps[i]) : 0xFFFFFFFFu;
+        if (T0 + q < p.I) emit(q, word[i]);
     }
-    hh[RUN_ITEMS] = (w == 0 && T0 + RUN_TILE + lane < p.I) ? resolve((uint32_t)RUN_TILE + lane, hword, rd[RUN_ITEMS], ps[RUN_ITEMS]) : 0xFFFFFFFFu;
-    __syncthreads();                              // every entry of a run can now see the reads of the others (hread)
-    auto write = [&](uint32_t q, uint32_t h, uint32_t rdv, uint32_t pos) {
-        const uint32_t at = hat[h], kid = hkid[h], z = at + (q - h);
-        o.csc[z] = ((uint64_t)rdv << 32) | pos;
-        if (o.csr_words) {
-            uint32_t hint = 0;
-            if (o.hints) {                        // the parity rule of owns_pair (spgemm_direct.hpp): does this read accumulate any pair of the column?
-                const uint32_t l = hlen[h];
-                bool own = false;
-                uint32_t mult = 0;
-                for (uint32_t t = 0; t < l; ++t) {
-                    const uint32_t j = hread[h + t];
-                    if (j == rdv) { ++mult; continue; }
-                    own |= ((rdv ^ j) & 1u) ? j < rdv : j > rdv;
-                }
-                hint = (own || mult >= 2) ? 0u : 3u;      // (the window is the whole matrix here: both bits agree)
-            }
-            o.csr_words[z] = ((uint64_t)rdv << (o.nb + o.pb + 2)) | ((uint64_t)kid << (o.pb + 2)) | ((uint64_t)hint << o.pb) | pos;
-        } else o.kid_of_entry[z] = kid;
-    };
-#pragma unroll
-    for (int i = 0; i < RUN_ITEMS; ++i)
-        if (hh[i] != 0xFFFFFFFFu) write((uint32_t)i * RUN_THREADS + tid, hh[i], rd[i], ps[i]);
-    if (hh[RUN_ITEMS] != 0xFFFFFFFFu) write((uint32_t)RUN_TILE + lane, hh[RUN_ITEMS], rd[RUN_ITEMS], ps[RUN_ITEMS]);
+    if (w == 0 && T0 + RUN_TILE + lane < p.I) emit((uint32_t)RUN_TILE + lane, hword);
 }
 
 __global__ void k_instance_entries(const uint64_t *payload, const uint64_t *kid_of_entry, const uint64_t *rel_kmers, uint64_t *csc, uint64_t Z, EnumParams e, int drop,
@@ -715,10 +691,10 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
         const int mb = bits_needed((uint64_t)(c.nreads > 0 ? c.nreads - 1 : 0)), nb = bits_needed((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_needed(maxpos);
         const bool words = mb + nb + pb + 2 <= 64 && !getenv("ELBA_CSR_PAIRS");
         const bool hints = pb <= 30 && !getenv("ELBA_PLAN") && !getenv("ELBA_NO_HINTS");
-        c.prod_ctr.reserve(64);
-        ELBA_HIP(hipMemsetAsync(c.prod_ctr.p, 0, 8, s));
+        c.prod_ctr.reserve(64 * 128);
+        ELBA_HIP(hipMemsetAsync(c.prod_ctr.p, 0, 64 * 128, s));
         EmitOut o{};
-        o.prod_ctr = c.prod_ctr.as<unsigned long long>(); o.hints = hints;
+        o.prod_ctr = c.prod_ctr.as<unsigned long long>();
         o.rel_kmers = c.rel_kmers.as<uint64_t>(); o.rel_counts = c.rel_counts.as<uint32_t>(); o.colptr = c.a_colptr.as<uint32_t>();
         o.csc = c.a_csc.as<uint64_t>(); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); o.nb = nb; o.pb = pb;
         if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }

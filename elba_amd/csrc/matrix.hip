@@ -19,7 +19,7 @@ __device__ __forceinline__ uint32_t entry_hint(const uint32_t *colptr, const uin
     unsigned long long mine = i >= win_lo && i < win_hi ? L : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(prod_ctr, mine);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&prod_ctr[(blockIdx.x & 63u) * 16u], mine);      // (64 counters on lines of their own)
     return hints && L <= HINT_MAX_COL ? column_hint(csc + c0, L, i, win_lo, win_hi) : 0u;
 }
 
@@ -49,6 +49,16 @@ __global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, cons
     const uint32_t h = entry_hint(colptr, csc, kid, in ? (uint32_t)(e >> 32) : 0xFFFFFFFFu, hints && in, in ? win_lo : 0u, in ? win_hi : 0u, prod_ctr);
     if (!in) return;
     words[z] = ((e >> 32) << (nb + pb + 2)) | (kid << (pb + 2)) | ((uint64_t)h << pb) | (e & 0xFFFFFFFFull);
+}
+// hint bits for sort keys that came without them (k_runs_emit, kmer.hip): the entry's k-mer id is in the word, its column in the CSC
+__global__ void k_add_hints(const uint32_t *colptr, const uint64_t *csc, int64_t Z, int nb, int pb, uint64_t *words)
+{
+    const int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= Z) return;
+    const uint64_t w = words[z];
+    const uint64_t kid = (w >> (pb + 2)) & ((1ull << nb) - 1);
+    const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0;
+    if (L <= HINT_MAX_COL) words[z] = w | ((uint64_t)column_hint(csc + c0, L, (uint32_t)(csc[z] >> 32), 0u, 0xFFFFFFFFu) << pb);      // (the window is the whole matrix)
 }
 __global__ void k_unpack_csr_words(const uint64_t *words, int64_t Z, int nb, int pb, uint64_t *csr)
 {
@@ -545,9 +555,9 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     const int mb = bits_for((uint64_t)(M > 0 ? M - 1 : 0)), nb = bits_for((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_for(maxpos);
     const bool hints = pre ? c.pre_hints : (pb <= 30 && !c.plan && !getenv("ELBA_NO_HINTS"));
     const uint32_t wlo = (uint32_t)win_lo, whi = (uint32_t)(win_hi < 0 ? M : win_hi);
-    c.prod_ctr.reserve(64);
+    c.prod_ctr.reserve(64 * 128);
     unsigned long long *prod_ctr = c.prod_ctr.as<unsigned long long>();
-    if (!pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 8, s));      // (pre: k_runs_emit has counted)
+    if (!pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 64 * 128, s));      // (pre: k_runs_emit has counted)
     if (mb + nb + pb + 2 <= 64 && !getenv("ELBA_CSR_PAIRS")) {
         const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;
         uint64_t *w0 = have_words ? c.csr_words.as<uint64_t>() : c.ws_a.as<uint64_t>(), *w1 = c.ws_c.as<uint64_t>();
@@ -555,6 +565,8 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         if (Z > 0 && !have_words)
             hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0,
                                hints, wlo, whi, prod_ctr);
+        if (Z > 0 && have_words && hints)
+            hipLaunchKernelGGL(k_add_hints, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
         const int where = radix_sort_keys(s, w0, w1, Z, nb + pb + 2, nb + pb + 2 + mb, c.ws_sort);
         const uint64_t *sorted = where ? w1 : w0;
         group_offsets_u32(s, sorted, nb + pb + 2, Z, c.a_rowptr.as<uint32_t>(), M);
@@ -565,7 +577,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
         if (Z > 0) {
             int64_t nbk = (Z + 255) / 256;
-            if (pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 8, s));
+            if (pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 64 * 128, s));
             hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, k0, v0,
                                hints, wlo, whi, prod_ctr);
         }
@@ -576,10 +588,11 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     }
     c.csr_hints = hints;
     {
-        unsigned long long hp = 0;
-        ELBA_HIP(hipMemcpyAsync(&hp, prod_ctr, 8, hipMemcpyDeviceToHost, s));
+        unsigned long long hp[64 * 16];
+        ELBA_HIP(hipMemcpyAsync(hp, prod_ctr, sizeof(hp), hipMemcpyDeviceToHost, s));
         ELBA_HIP(hipStreamSynchronize(s));
-        c.A_products = (int64_t)hp;
+        c.A_products = 0;
+        for (int q = 0; q < 64; ++q) c.A_products += (int64_t)hp[q * 16];
     }
     c.row_lo = win_lo; c.row_hi = win_hi;
     if (c.plan) {

@@ -33,7 +33,8 @@ constexpr int NUM_LDS_TIERS = 5;                // 512, 1024, 2048, 4096, 8192 s
 constexpr int NUM_TIERS = NUM_LDS_TIERS + 1;    // + HBM spill
 constexpr int LDS_TBITS0 = 9;
 constexpr uint32_t STAGE_CHUNK = 1024;          // staging entries a workgroup draws from the global cursor at a time
-constexpr uint32_t FIN_WAVE_MAX = 256;          // widest row the one-wave column sort takes
+constexpr uint32_t FIN_WAVE_MAX = 256;          // widest row the one-wave rank sort takes
+constexpr uint32_t FIN_WAVE2_MAX = 1024;        // widest row the one-wave bucket sort takes (wider rows: one workgroup each)
 constexpr uint32_t FIN_LDS_MAX = 4096;          // widest row the LDS bitonic sort takes
 
 // End-of-kernel statistics are flushed into one of 64 shards (each on its own 128-B line): thousands of workgroups adding to a
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
         const uint32_t own = p.row_cnt[i];
         const unsigned long long off = p.row_off[i];
         const uint32_t y = own + p.low_cnt[i];
-        if (lane == 0 && y > FIN_WAVE_MAX) {
+        if (lane == 0 && y > FIN_WAVE2_MAX) {
             const int which = y > FIN_LDS_MAX ? 1 : 0;
             const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
             p.fin_lists[(size_t)which * p.M + at] = i;
@@ -288,47 +289,108 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
     }
 }
 
-// rows with <= FIN_WAVE_MAX entries: one wavefront per row; the row's columns are staged in LDS and every lane ranks its
-// (up to 4) elements against all of them — columns are distinct, so ranks are a permutation
+// Rows of up to FIN_WAVE2_MAX entries: one wavefront per row (16 rows in flight per CU, no workgroup barriers).
+//   <= 256 entries: the row's columns are staged in LDS and every lane ranks its (up to 4) elements against all of them — columns are distinct,
+//      so ranks are a permutation;
+//   <= 1024: bucket + rank sort, as k_finalize_bucket below but by one wavefront — ~y/8 equal column ranges, count, scan, scatter the keys
+//      into their buckets, rank inside the bucket (~8 compares).  The 200 k-read set's rows average 490 entries: with a workgroup per
+//      row (4 barriers and three dependent global loads each, 4 rows in flight per CU) this pass took 1.9 ms of a 15 ms call.
 __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
 {
-    __shared__ uint32_t cols[4][FIN_WAVE_MAX];
+    __shared__ uint64_t lkeys[4][FIN_WAVE2_MAX];
+    __shared__ uint32_t bst[4][128], bfl[4][128];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t *cols = reinterpret_cast<uint32_t *>(lkeys[w]);
     for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
         const int64_t dst = p.b_rowptr[i];
         const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
         const uint32_t low = p.low_cnt[i];
         if (lane == 0 && low) p.low_cnt[i] = 0;          // the ticket counters are handed back clean (k_mirror, the only other reader, has finished)
-        if (y == 0 || y > FIN_WAVE_MAX) continue;
+        if (y == 0 || y > FIN_WAVE2_MAX) continue;
         if (dst + (int64_t)y > p.b_cap) continue;
         const unsigned long long off = p.row_off[i];
-        uint32_t mine[4];
-        uint4 ra[4], rb[4];
+        if (y <= FIN_WAVE_MAX) {
+            uint32_t mine[4];
+            uint4 ra[4], rb[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t t = (uint32_t)lane + 64u * u;
-            mine[u] = 0xFFFFFFFFu;
-            if (t < y) {
-                fin_load(p, low, off, dst, t, ra[u], rb[u]);
-                mine[u] = ra[u].x;
-                cols[w][t] = mine[u];
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t t = (uint32_t)lane + 64u * u;
+                mine[u] = 0xFFFFFFFFu;
+                if (t < y) {
+                    fin_load(p, low, off, dst, t, ra[u], rb[u]);
+                    mine[u] = ra[u].x;
+                    cols[t] = mine[u];
+                }
             }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            uint32_t rank[4] = {0, 0, 0, 0};
+            for (uint32_t l = 0; l < y; ++l) {
+                const uint32_t c = cols[l];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) rank[u] += c < mine[u] ? 1u : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t t = (uint32_t)lane + 64u * u;
+                if (t < y) { p.b_col[dst + rank[u]] = mine[u]; p.b_val[dst + rank[u]] = rec_seed(ra[u], rb[u]); }
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
         }
+        uint32_t nb = y / 8;
+        nb = nb > 128u ? 128u : nb;
+        const unsigned long long scale = ((unsigned long long)nb << 32) / (p.M > 0 ? p.M : 1u);       // bucket(col) = col * nb / M, monotone in col, < nb
+        bst[w][lane] = 0; bst[w][lane + 64] = 0; bfl[w][lane] = 0; bfl[w][lane + 64] = 0;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        uint32_t rank[4] = {0, 0, 0, 0};
-        for (uint32_t l = 0; l < y; ++l) {
-            const uint32_t c = cols[w][l];
+        uint32_t col[FIN_WAVE2_MAX / 64];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) rank[u] += c < mine[u] ? 1u : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < (int)(FIN_WAVE2_MAX / 64); ++u) {
             const uint32_t t = (uint32_t)lane + 64u * u;
-            if (t < y) { p.b_col[dst + rank[u]] = mine[u]; p.b_val[dst + rank[u]] = rec_seed(ra[u], rb[u]); }
+            col[u] = t < y ? fin_col(p, low, off, dst, t) : 0u;
         }
+#pragma unroll
+        for (int u = 0; u < (int)(FIN_WAVE2_MAX / 64); ++u)
+            if ((uint32_t)lane + 64u * u < y) atomicAdd(&bst[w][(uint32_t)(((unsigned long long)col[u] * scale) >> 32)], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {   // exclusive scan of the <= 128 bucket counts: 2 per lane
+            const uint32_t c0 = bst[w][2 * lane], c1 = bst[w][2 * lane + 1];
+            uint32_t inc = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+            const uint32_t ex = inc - c0 - c1;
+            __builtin_amdgcn_wave_barrier();
+            bst[w][2 * lane] = ex; bst[w][2 * lane + 1] = ex + c0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < (int)(FIN_WAVE2_MAX / 64); ++u) {
+            const uint32_t t = (uint32_t)lane + 64u * u;
+            if (t < y) {
+                const uint32_t b = (uint32_t)(((unsigned long long)col[u] * scale) >> 32);
+                lkeys[w][bst[w][b] + atomicAdd(&bfl[w][b], 1u)] = ((uint64_t)col[u] << 32) | t;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t e = (uint32_t)lane; e < y; e += 64u) {
+            const uint64_t k = lkeys[w][e];
+            const uint32_t c = (uint32_t)(k >> 32);
+            const uint32_t b = (uint32_t)(((unsigned long long)c * scale) >> 32);
+            const uint32_t lo = bst[w][b], hi = lo + bfl[w][b];
+            uint32_t rank = 0;
+            for (uint32_t x = lo; x < hi; ++x) rank += lkeys[w][x] < k ? 1u : 0u;
+            uint4 ra, rb;
+            fin_load(p, low, off, dst, (uint32_t)k, ra, rb);
+            p.b_col[dst + lo + rank] = c;
+            p.b_val[dst + lo + rank] = rec_seed(ra, rb);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -352,7 +414,7 @@ __device__ __forceinline__ void bitonic_sort(uint64_t *keys, uint32_t n2)
     }
 }
 
-// Rows of 257..4096 entries: one workgroup per row, bucket + rank sort in LDS.  Partner ids are spread evenly over [0, M), so the row
+// Rows of 1025..4096 entries: one workgroup per row, bucket + rank sort in LDS.  Partner ids are spread evenly over [0, M), so the row
 // is cut into ~y/8 equal column ranges: count per bucket, scan, scatter the keys into their buckets, then every element ranks itself
 // inside its bucket (~8 compares).  ~100 instructions per element and 4 barriers per row, against ~45 barrier-separated compare-exchange
 // stages of a bitonic network (this pass was 44 % of the step on the 200 k-read workload, whose rows average 490 entries).  A skewed row
