@@ -160,7 +160,7 @@ struct Ctx {
     // need not be fetched at all, the entry only counts one diagonal product; bit 31 = the same with every partner outside the row window
     // counted as owned (calls without the mirror exchange between ranks).  They are a property of A, written when A is built (k_runs_emit /
     // k_csc_to_csr_words: every entry sees its whole column there anyway).  csr_hints false: both bits are zero / positions use all 32 bits.
-    bool csr_hints = false, ov_hints_used = false;
+    bool csr_hints = false, ov_hints_used = false, ov_rec16 = false;
     int64_t A_products = 0;   // sum over the window's row entries of their column's length (what the SpGEMM reports as `products`)
     DevBuf prod_ctr;
     DevBuf kid_of_entry;  // u64[Z] k-mer id of every entry of a_csc (written with the columns; what the CSR build sorts by read)

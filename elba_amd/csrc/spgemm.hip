@@ -98,6 +98,7 @@ struct OvParams {
     uint32_t *fin_lists;     // [2][M]
     OvCounters *ctr;
     StageRec *tmp; unsigned long long tmp_cap;
+    uint32_t rec16; uint4 *rec; uint32_t *tick;     // rec16: positions fit 16 bits — a staged entry is ONE 16-byte word (partner, q0 | t0 << 16, q1 | t1 << 16, numshared) in `rec` (the staging area itself) + its mirror ticket in `tick` (behind the tmp_cap words)
     uint32_t *gtable; unsigned long long gstride;   // HBM spill tables: per block 4*gstride u32
 };
 
@@ -172,6 +173,7 @@ __global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
 struct FinParams {
     const uint32_t *row_cnt; uint32_t *low_cnt; const unsigned long long *row_off; int64_t *b_rowptr;
     const StageRec *tmp; StageRec *mir;
+    uint32_t rec16; const uint4 *rec; const uint32_t *tick;      // (OvParams::rec16)
     uint32_t *b_col; elba_seed_t *b_val;
     uint32_t M, row_lo, row_hi, half;
     uint32_t *fin_lists; OvCounters *ctr;
@@ -185,7 +187,12 @@ struct FinParams {
 // entry t of a row's extent: mirrored (the first `low`) or staged by the row itself; as the two halves of a staged record
 __device__ __forceinline__ void fin_load(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t, uint4 &a, uint4 &b)
 {
-    if (t >= low) { const StageRec *r = &p.tmp[off + (t - low)]; a = r->a; b = r->b; }
+    if (t >= low) {
+        if (p.rec16) {
+            const uint4 m = p.rec[off + (t - low)];
+            a = make_uint4(m.x, 0xFFFFFFFFu, m.y & 0xFFFFu, m.y >> 16); b = make_uint4(m.z & 0xFFFFu, m.z >> 16, m.w, 0u);
+        } else { const StageRec *r = &p.tmp[off + (t - low)]; a = r->a; b = r->b; }
+    }
     else if (p.mir16) {
         const uint4 m = reinterpret_cast<const uint4 *>(p.mir)[dst + t];
         a = make_uint4(m.x, 0xFFFFFFFFu, m.y & 0xFFFFu, m.y >> 16); b = make_uint4(m.z & 0xFFFFu, m.z >> 16, m.w, 0u);
@@ -193,7 +200,7 @@ __device__ __forceinline__ void fin_load(const FinParams &p, uint32_t low, unsig
 }
 __device__ __forceinline__ uint32_t fin_col(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t)
 {
-    if (t >= low) return p.tmp[off + (t - low)].a.x;
+    if (t >= low) return p.rec16 ? p.rec[off + (t - low)].x : p.tmp[off + (t - low)].a.x;
     return p.mir16 ? reinterpret_cast<const uint4 *>(p.mir)[dst + t].x : p.mir[dst + t].a.x;
 }
 __device__ __forceinline__ elba_seed_t rec_seed(const uint4 a, const uint4 b)
@@ -274,6 +281,17 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
             p.fin_lists[(size_t)which * p.M + at] = i;
         }
         if (!p.half) continue;
+        if (p.rec16) {           // one 16-byte word in, one out: the two positions of each seed change places
+            for (uint32_t t = lane; t < own; t += 64) {
+                const uint32_t tk = p.tick[off + t];
+                if (tk == 0xFFFFFFFFu) continue;
+                const uint4 r = p.rec[off + t];
+                const int64_t at = p.b_rowptr[r.x] + (int64_t)tk;
+                if (at >= p.b_cap) continue;
+                reinterpret_cast<uint4 *>(p.mir)[at] = make_uint4(i, (r.y >> 16) | (r.y << 16), (r.z >> 16) | (r.z << 16), r.w);
+            }
+            continue;
+        }
         for (uint32_t t = lane; t < own; t += 64) {
             const uint4 a = p.tmp[off + t].a;
             if (a.y == 0xFFFFFFFFu) continue;
@@ -536,6 +554,7 @@ int bits_for_u(uint64_t v)
 constexpr int REMOTE_MAX_RANKS = 64, REMOTE_ROWS_PER_BLOCK = 64;
 struct RemoteParams {
     const uint32_t *row_cnt; const unsigned long long *row_off; const StageRec *tmp;
+    uint32_t rec16; const uint4 *rec;
     uint32_t row_lo, row_hi, nranks;
     uint64_t bounds[REMOTE_MAX_RANKS + 1];
 };
@@ -558,7 +577,7 @@ __global__ __launch_bounds__(256) void k_remote_mirror(RemoteParams p, unsigned 
         const uint32_t n = p.row_cnt[i];
         const unsigned long long off = p.row_off[i];
         for (uint32_t t = lane; t < n; t += 64) {
-            const uint32_t j = p.tmp[off + t].a.x;
+            const uint32_t j = p.rec16 ? p.rec[off + t].x : p.tmp[off + t].a.x;
             if (j != i && (j < p.row_lo || j >= p.row_hi)) atomicAdd(&cnt[remote_rank_of(p, j)], 1u);
         }
     }
@@ -573,10 +592,12 @@ __global__ __launch_bounds__(256) void k_remote_mirror(RemoteParams p, unsigned 
         const uint32_t n = p.row_cnt[i];
         const unsigned long long off = p.row_off[i];
         for (uint32_t t = lane; t < n; t += 64) {
-            const uint4 a = p.tmp[off + t].a;
+            uint4 a, b = make_uint4(0u, 0u, 0u, 0u);
+            if (p.rec16) { const uint4 m = p.rec[off + t]; a = make_uint4(m.x, 0u, m.y & 0xFFFFu, m.y >> 16); b = make_uint4(m.z & 0xFFFFu, m.z >> 16, m.w, 0u); }
+            else a = p.tmp[off + t].a;
             const uint32_t j = a.x;
             if (j != i && (j < p.row_lo || j >= p.row_hi)) {
-                const uint4 b = p.tmp[off + t].b;
+                if (!p.rec16) b = p.tmp[off + t].b;
                 const uint32_t d = remote_rank_of(p, j);
                 const unsigned long long at = base[d] + atomicAdd(&fill[d], 1u);
                 send[at].a = make_uint4(j, i, a.w, a.z);
@@ -628,6 +649,7 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
     f.M = (uint32_t)M; f.row_lo = (uint32_t)row_lo; f.row_hi = (uint32_t)row_hi; f.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1); f.ctr = c.ov_counters.as<OvCounters>();
     f.b_cap = c.b_cap_entries;
     f.mir16 = mir16 ? 1u : 0u;
+    f.rec16 = c.ov_rec16 ? 1u : 0u; f.rec = c.ov_tmp.as<uint4>(); f.tick = reinterpret_cast<const uint32_t *>(c.ov_tmp.as<char>() + (size_t)c.ov_tmp_cap * 16);
     const int gblocks = 32;
     uint64_t sstride = 2;
     while (sstride < (uint64_t)M) sstride <<= 1;
@@ -799,10 +821,12 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         const bool timed = passes > 1 || (c.ov_calls++ % (uint64_t)stride) == 0;
         c.ov_tmp.reserve((size_t)c.ov_tmp_cap * sizeof(StageRec));
         p.tmp = c.ov_tmp.as<StageRec>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
+        const bool mir16 = c.pos16 && !getenv("ELBA_MIR32");
+        c.ov_rec16 = mir16;
+        p.rec16 = mir16 ? 1u : 0u; p.rec = c.ov_tmp.as<uint4>(); p.tick = reinterpret_cast<uint32_t *>(c.ov_tmp.as<char>() + (size_t)c.ov_tmp_cap * 16);
         c.b_cap_entries = half ? 2 * c.ov_tmp_cap : c.ov_tmp_cap;      // the output cannot be larger than what was staged (and mirrored)
         c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
         c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
-        const bool mir16 = c.pos16 && !getenv("ELBA_MIR32");
         if (half) c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * (mir16 ? 16 : sizeof(StageRec)));
 
         if (timed) c.ov_marks.mark(0, s);
@@ -878,7 +902,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
 static RemoteParams remote_params(Ctx &c)
 {
     RemoteParams r{};
-    r.row_cnt = c.ov_rowcnt.as<uint32_t>(); r.row_off = c.ov_rowoff.as<unsigned long long>(); r.tmp = c.ov_tmp.as<StageRec>();
+    r.row_cnt = c.ov_rowcnt.as<uint32_t>(); r.row_off = c.ov_rowoff.as<unsigned long long>(); r.tmp = c.ov_tmp.as<StageRec>(); r.rec16 = c.ov_rec16 ? 1u : 0u; r.rec = c.ov_tmp.as<uint4>();
     r.row_lo = (uint32_t)c.row_lo; r.row_hi = (uint32_t)(c.row_hi < 0 ? c.M : c.row_hi); r.nranks = (uint32_t)c.ov_remote_bounds.size() - 1u;
     for (size_t k = 0; k < c.ov_remote_bounds.size(); ++k) r.bounds[k] = c.ov_remote_bounds[k];
     return r;

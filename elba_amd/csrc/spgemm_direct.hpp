@@ -415,8 +415,11 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 // the partner's row gets the mirrored entry: draw its slot there now; k_mirror places it once the row pointers are known
                 uint32_t tick = 0xFFFFFFFFu;
                 if (p.half && j != i && j >= p.row_lo && j < p.row_hi) { tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir; }
-                p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
-                p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);
+                if (p.rec16) { p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared); p.tick[off + t] = tick; }
+                else {
+                    p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
+                    p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);
+                }
                 // strict-upper entries: an in-window pair accumulated here stands for (i,j) and (j,i) — one of the two is upper
                 if (j != i && ((p.half && j >= p.row_lo && j < p.row_hi) || j > i)) ++nup;
                 mx = (uint32_t)v.numshared > mx ? (uint32_t)v.numshared : mx;
