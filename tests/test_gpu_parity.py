@@ -338,11 +338,12 @@ def test_words_one_or_two_bits_short_mark_rare_positions_for_lookup():
     e.close()
 
 
-@pytest.mark.parametrize("knob", ["ELBA_NO_SYMMETRY", "ELBA_NO_ELL", "ELBA_NO_PAY", "ELBA_PLAN", "ELBA_KMER_HASH", "ELBA_KMER_PAIRS", "ELBA_MIR32", "ELBA_KMER_UNFUSED", "ELBA_CSR_PAIRS"])
+@pytest.mark.parametrize("knob", ["ELBA_NO_SYMMETRY", "ELBA_NO_ELL", "ELBA_NO_PAY", "ELBA_PLAN", "ELBA_KMER_HASH", "ELBA_KMER_PAIRS", "ELBA_MIR32", "ELBA_KMER_UNFUSED", "ELBA_CSR_PAIRS", "ELBA_NO_HINTS", "ELBA_RS_BITS"])
 def test_alternative_paths_kept_for_ab_runs_give_the_same_matrices(knob, monkeypatch):
     """Build-time / run-time alternatives kept behind environment knobs (both triangles accumulated instead of one + mirror, plain CSC columns
     instead of the padded ones, 32-bit accumulators + seed look-ups, the round-1 descriptor plan + kernel, hash-based counting, (value,
-    payload) pairs through the k-mer sort, 32-byte mirror records): A and B must not change."""
+    payload) pairs through the k-mer sort, 32-byte mirror / staging records, per-head column emission, (read, entry) pairs through the CSR sort,
+    no ownership hints in the rows of A, one-bit radix digits): A and B must not change."""
     monkeypatch.setenv(knob, "1")
     packed, off, lens, info = elba_amd.synth_reads(61, 200000, 16, 3000, 900, error_rate=0.10, min_len=200)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
