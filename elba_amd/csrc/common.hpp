@@ -102,7 +102,8 @@ constexpr uint32_t HINT_MAX_COL = 64;
 
 int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
 // The same for bare 64-bit words (whatever rides in the bits outside [bit_lo, bit_hi) moves with them): returns 0 if the result is in k0, 1 if in k1.
-int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
+int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done = false);
+uint32_t *radix_first_histogram(int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, int *shift, int *bits, int *tile);      // (prims.hip)
 void fill_u32(hipStream_t s, uint32_t *p, uint32_t v, int64_t n);
 void fill_u64(hipStream_t s, uint64_t *p, uint64_t v, int64_t n);
 // ptr[k] = first index z with keys[z] >= k, for k in [0, nkeys]; keys ascending (sorted group ids -> CSR/CSC pointers)

@@ -143,13 +143,11 @@ __device__ __forceinline__ void for_each_position(const EnumParams &e, F &&f)
     }
 }
 
-// Calls f(instance index g, read r, pos p, canonical k-mer) for the EN_ITEMS instances of this lane (k <= 31)
+// Calls f(instance index g, read r, pos p, canonical k-mer) for the EN_ITEMS instances of this lane among the EN_PER_WAVE that start at g0 (k <= 31)
 template <class F>
-__device__ __forceinline__ void for_each_instance(const EnumParams &e, F &&f)
+__device__ __forceinline__ void for_each_instance_from(const EnumParams &e, uint64_t g0, F &&f)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t wave = ((uint64_t)blockIdx.x * EN_THREADS + threadIdx.x) >> 6;
-    const uint64_t g0 = wave * EN_PER_WAVE;
     if (g0 >= e.I) return;
     uint32_t lo = 0, hi = e.nreads;                 // last r with inst_off[r] <= g0
     while (hi - lo > 1) {
@@ -165,6 +163,11 @@ __device__ __forceinline__ void for_each_instance(const EnumParams &e, F &&f)
         const uint32_t p = (uint32_t)(g - e.inst_off[r]);
         f(g, r, p, canonical_at(e, r, p));
     }
+}
+template <class F>
+__device__ __forceinline__ void for_each_instance(const EnumParams &e, F &&f)
+{
+    for_each_instance_from(e, (((uint64_t)blockIdx.x * EN_THREADS + threadIdx.x) >> 6) * EN_PER_WAVE, f);
 }
 
 __global__ __launch_bounds__(EN_THREADS) void k_kmer_count(EnumParams e, unsigned long long *keys, uint32_t *vals, uint64_t capmask)
@@ -278,6 +281,28 @@ __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit_packed(EnumParams e, i
 {
     const int k2 = 2 * e.k;
     for_each_instance(e, [&](uint64_t g, uint32_t, uint32_t, uint64_t km) { words[g] = ((km >> (64 - k2)) << pb) | (g >> drop); });
+}
+
+// The same, and the first radix pass's histogram with it: a workgroup writes one tile of the sort (SUB * EN_PER_BLOCK words) and the row of
+// digit counts the sort expects for it (radix_first_histogram, prims.hip) — the sort then starts with its scatter.
+template <int SUB>
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit_packed_hist(EnumParams e, int pb, int drop, uint64_t *words, int shift, int bits, uint32_t *hist)
+{
+    __shared__ uint32_t h[512];
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
+    for (uint32_t i = threadIdx.x; i < nbins; i += EN_THREADS) h[i] = 0;
+    __syncthreads();
+    const int k2 = 2 * e.k;
+    const uint64_t base = ((uint64_t)blockIdx.x * (EN_THREADS / 64) + (threadIdx.x >> 6)) * (uint64_t)(SUB * EN_PER_WAVE);
+#pragma unroll 1
+    for (int sr = 0; sr < SUB; ++sr)
+        for_each_instance_from(e, base + (uint64_t)sr * EN_PER_WAVE, [&](uint64_t g, uint32_t, uint32_t, uint64_t km) {
+            const uint64_t wd = ((km >> (64 - k2)) << pb) | (g >> drop);
+            words[g] = wd;
+            atomicAdd(&h[(uint32_t)(wd >> shift) & dmask], 1u);
+        });
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nbins; i += EN_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
 }
 
 __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit2(EnumParams e, uint64_t *khi, uint64_t *klo, uint64_t *vals, uint64_t *idx)
@@ -436,7 +461,19 @@ __global__ __launch_bounds__(RUN_THREADS) void k_runs(RunParams p, uint32_t *blk
 // along the instance offsets instead of a binary search over all reads (18 dependent L2 round trips per entry on 200 k reads: the
 // search was 54 ms of the 219 ms k-mer stage of the 200 k-read set)
 constexpr int IB_SHIFT = 11;
-struct alignas(32) BlockInfo { uint32_t read, pad; uint64_t off_lo, off_hi, byte_off; };      // the read holding the block's first instance: one 32-byte load
+// the read holding the block's first instance, in ONE 16-byte load: its index, the block's first position in it, the instances it still
+// holds from there, and its byte offset (0xFFFFFFFF: does not fit 32 bits — fetched from the reads' offsets instead)
+struct alignas(16) BlockInfo { uint32_t read, pos0, remain, byte_off; };
+struct ReadCursor { uint32_t lo; uint64_t off_lo, off_hi, boff; };
+__device__ __forceinline__ ReadCursor cursor_at(const EnumParams &e, const BlockInfo *block_read, uint64_t g)
+{
+    const uint64_t g0 = g & ~((1ull << IB_SHIFT) - 1);
+    const BlockInfo bi = block_read[g >> IB_SHIFT];
+    ReadCursor c;
+    c.lo = bi.read; c.off_lo = g0 - bi.pos0; c.off_hi = g0 + bi.remain;
+    c.boff = bi.byte_off != 0xFFFFFFFFu ? (uint64_t)bi.byte_off : e.byte_off[bi.read];
+    return c;
+}
 __global__ void k_block_reads(const uint64_t *inst_off, const uint64_t *byte_off, uint32_t nreads, uint64_t nblocks, BlockInfo *block_read)
 {
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -444,7 +481,8 @@ __global__ void k_block_reads(const uint64_t *inst_off, const uint64_t *byte_off
     const uint64_t g = b << IB_SHIFT;
     uint32_t lo = 0, hi = nreads;                                     // last read with inst_off[read] <= g
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (inst_off[mid] <= g) lo = mid; else hi = mid; }
-    block_read[b] = BlockInfo{lo, 0u, inst_off[lo], inst_off[lo + 1], byte_off[lo]};
+    const uint64_t rem = inst_off[lo + 1] - g, bo = byte_off[lo];      // (g beyond the last instance: the table's closing entry, never dereferenced past)
+    block_read[b] = BlockInfo{lo, (uint32_t)(g - inst_off[lo]), (uint32_t)(inst_off[lo + 1] > g ? rem : 0u), bo < 0xFFFFFFFFull ? (uint32_t)bo : 0xFFFFFFFFu};
 }
 
 // Second pass over the sorted words, fused with the entries' (read, pos): EVERY item of a reliable run writes its own entry — consecutive
@@ -461,7 +499,7 @@ struct EmitOut {
     unsigned long long *prod_ctr;     // += sum over reliable runs of length^2 (the SpGEMM's product count, Ctx::A_products)
     int nb, pb;
 };
-__global__ __launch_bounds__(RUN_THREADS) void k_runs_emit(RunParams p, EnumParams e, const BlockInfo *block_read, int drop, const uint32_t *off_rel, const uint32_t *off_ent, EmitOut o)
+__global__ __launch_bounds__(RUN_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void k_runs_emit(RunParams p, EnumParams e, const BlockInfo *block_read, int drop, const uint32_t *off_rel, const uint32_t *off_ent, EmitOut o)
 {
     constexpr int NW = RUN_THREADS / 64, SLICES = RUN_ITEMS * NW;
     __shared__ uint64_t eqmask[SLICES + 2];
@@ -553,9 +591,9 @@ __global__ __launch_bounds__(RUN_THREADS) void k_runs_emit(RunParams p, EnumPara
         const uint64_t gq = T0 + q;
         const uint64_t hp = wd & pmask;
         uint64_t g = hp << drop;
-        const BlockInfo bi = block_read[g >> IB_SHIFT];
-        uint32_t lo = bi.read;
-        uint64_t off_lo = bi.off_lo, off_hi = bi.off_hi, boff = bi.byte_off;
+        const ReadCursor rc = cursor_at(e, block_read, g);
+        uint32_t lo = rc.lo;
+        uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
         auto advance = [&](uint64_t gg) { while (gg >= off_hi) { ++lo; off_lo = off_hi; off_hi = e.inst_off[lo + 1]; boff = e.byte_off[lo]; } };
         advance(g);
         if (drop) {
@@ -589,9 +627,9 @@ __global__ void k_instance_entries(const uint64_t *payload, const uint64_t *kid_
     if (z >= Z) return;
     const uint64_t h = payload[z];
     uint64_t g = h << drop;
-    const BlockInfo bi = block_read[g >> IB_SHIFT];
-    uint32_t lo = bi.read;                                            // last read with inst_off[read] <= g
-    uint64_t off_lo = bi.off_lo, off_hi = bi.off_hi, boff = bi.byte_off;
+    const ReadCursor rc = cursor_at(e, block_read, g);
+    uint32_t lo = rc.lo;                                              // last read with inst_off[read] <= g
+    uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
     auto advance = [&](uint64_t gg) {                                 // (a block that holds a read boundary: walk on through the global arrays)
         while (gg >= off_hi) { ++lo; off_lo = off_hi; off_hi = e.inst_off[lo + 1]; boff = e.byte_off[lo]; }
     };
@@ -813,8 +851,12 @@ void stage_count_kmers(Ctx &c)
         const int pb = ib - drop;                  // payload bits below the value
         int where = 0;
         if (packed_words) {
-            if (I > 0) hipLaunchKernelGGL(k_kmer_emit_packed, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, pb, drop, c.ws_a.as<uint64_t>());
-            where = radix_sort_keys(s, c.ws_a.as<uint64_t>(), c.ws_c.as<uint64_t>(), (int64_t)I, pb, pb + 2 * k, c.ws_sort);
+            int sh0 = 0, b0 = 0, tile = 0;
+            uint32_t *hist0 = I > 1 ? radix_first_histogram((int64_t)I, pb, pb + 2 * k, c.ws_sort, &sh0, &b0, &tile) : nullptr;
+            const bool fuse_hist = hist0 && tile == 4 * EN_PER_BLOCK && b0 <= 9 && !getenv("ELBA_EMIT_PLAIN");      // (the emit writes whole tiles of the sort and counts their first digit)
+            if (fuse_hist) hipLaunchKernelGGL((k_kmer_emit_packed_hist<4>), dim3((unsigned)((I + tile - 1) / tile)), dim3(EN_THREADS), 0, s, e, pb, drop, c.ws_a.as<uint64_t>(), sh0, b0, hist0);
+            else if (I > 0) hipLaunchKernelGGL(k_kmer_emit_packed, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, pb, drop, c.ws_a.as<uint64_t>());
+            where = radix_sort_keys(s, c.ws_a.as<uint64_t>(), c.ws_c.as<uint64_t>(), (int64_t)I, pb, pb + 2 * k, c.ws_sort, fuse_hist);
         } else {
             if (I > 0) hipLaunchKernelGGL(k_kmer_emit, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>());
             where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)I, 64 - 2 * k, 64, c.ws_sort);

@@ -390,28 +390,37 @@ uint64_t reduce_max_u64(hipStream_t s, const uint64_t *p, int64_t n, DevBuf &tmp
 
 namespace {
 
+// digits of a sort of the bits [bit_lo, bit_hi): as even as they come, at most `maxbits` wide (34 bits = 9 + 9 + 8 + 8)
+static int radix_digits(int bit_lo, int bit_hi, int *shift, int *bits)
+{
+    const int maxbits = getenv("ELBA_RS_BITS") ? atoi(getenv("ELBA_RS_BITS")) : RS_MAXBITS;     // (8: the digits of round 1, for A/B runs)
+    const int B = bit_hi - bit_lo, mb = maxbits < 1 ? 1 : (maxbits > RS_MAXBITS ? RS_MAXBITS : maxbits);
+    const int npass = (B + mb - 1) / mb;
+    for (int q = 0, at = bit_lo; q < npass; ++q) { bits[q] = B / npass + (q < B % npass ? 1 : 0); shift[q] = at; at += bits[q]; }
+    return npass;
+}
+
 template <bool HAS_VAL>
-static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
+static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done)
 {
     if (n <= 1 || bit_hi <= bit_lo) return 0;
     ELBA_REQUIRE(n < (int64_t)0xFFFFFFFFLL, ELBA_ERR_UNSUPPORTED, "radix sort of >= 2^32 items");
     constexpr int ITEMS = HAS_VAL ? 8 : ELBA_RS_KEY_ITEMS, TILE = RS_THREADS * ITEMS;
-    const int maxbits = getenv("ELBA_RS_BITS") ? atoi(getenv("ELBA_RS_BITS")) : RS_MAXBITS;     // (8: the digits of round 1, for A/B runs)
-    const int B = bit_hi - bit_lo, mb = maxbits < 1 ? 1 : (maxbits > RS_MAXBITS ? RS_MAXBITS : maxbits);
-    const int npass = (B + mb - 1) / mb;
+    int shifts[64], widths[64];
+    const int npass = radix_digits(bit_lo, bit_hi, shifts, widths);
     const uint32_t nblocks = (uint32_t)((n + TILE - 1) / TILE);
     const size_t hist_elems = (size_t)nblocks << RS_MAXBITS;
-    tmp.reserve((hist_elems + column_scan_tmp_elems((int64_t)nblocks, RS_MAXBINS)) * sizeof(uint32_t));
+    tmp.reserve((hist_elems + column_scan_tmp_elems((int64_t)nblocks, RS_MAXBINS)) * sizeof(uint32_t));      // (never reallocates behind radix_first_histogram: same size)
     uint32_t *hist = tmp.as<uint32_t>(), *scan_tmp = hist + hist_elems;
     int cur = 0;
     uint64_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
-    for (int q = 0, shift = bit_lo; q < npass; ++q) {
-        const int bits = B / npass + (q < B % npass ? 1 : 0);       // digits as even as they come: 34 bits = 9 + 9 + 8 + 8
+    for (int q = 0; q < npass; ++q) {
+        const int shift = shifts[q], bits = widths[q];
         const uint32_t nbins = 1u << bits;
-        hipLaunchKernelGGL((k_rs_hist<ITEMS>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const uint64_t *)ki, n, shift, bits, hist);
+        if (q > 0 || !first_hist_done)
+            hipLaunchKernelGGL((k_rs_hist<ITEMS>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const uint64_t *)ki, n, shift, bits, hist);
         column_scan(s, hist, (int64_t)nblocks, nbins, scan_tmp);
         hipLaunchKernelGGL((k_rs_scatter<HAS_VAL, ITEMS>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const uint64_t *)ki, (const uint64_t *)vi, ko, vo, n, shift, bits, (const uint32_t *)hist);
-        shift += bits;
         uint64_t *t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
@@ -422,14 +431,29 @@ static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *
 
 }  // namespace
 
-int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
+// For a producer that writes the keys of a radix_sort_keys call itself: where the first pass expects its histogram — row t = the digit
+// counts (1 << *bits of them, digit = key >> *shift) of the keys [t * tile, (t + 1) * tile) — so that the producer can count while it writes
+// and the sort skips its first histogram pass (radix_sort_keys(..., first_hist_done = true) with the same n, bits and workspace).
+uint32_t *radix_first_histogram(int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, int *shift, int *bits, int *tile)
 {
-    return radix_sort_impl<true>(s, k0, v0, k1, v1, n, bit_lo, bit_hi, tmp);
+    constexpr int TILE = RS_THREADS * ELBA_RS_KEY_ITEMS;
+    int shifts[64], widths[64];
+    radix_digits(bit_lo, bit_hi, shifts, widths);
+    const uint32_t nblocks = (uint32_t)((n + TILE - 1) / TILE);
+    const size_t hist_elems = (size_t)nblocks << RS_MAXBITS;
+    tmp.reserve((hist_elems + column_scan_tmp_elems((int64_t)nblocks, RS_MAXBINS)) * sizeof(uint32_t));
+    *shift = shifts[0]; *bits = widths[0]; *tile = TILE;
+    return tmp.as<uint32_t>();
 }
 
-int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
+int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
 {
-    return radix_sort_impl<false>(s, k0, nullptr, k1, nullptr, n, bit_lo, bit_hi, tmp);
+    return radix_sort_impl<true>(s, k0, v0, k1, v1, n, bit_lo, bit_hi, tmp, false);
+}
+
+int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done)
+{
+    return radix_sort_impl<false>(s, k0, nullptr, k1, nullptr, n, bit_lo, bit_hi, tmp, first_hist_done);
 }
 
 }  // namespace elba
