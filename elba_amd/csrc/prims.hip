@@ -141,11 +141,13 @@ __global__ void k_reduce_max(const uint64_t *p, int64_t n, unsigned long long *o
 // the same scattered load again in the scatter — 5*10^8 extra memory requests per pass over 2*10^9 keys, as many as the keys themselves make.
 // (A one-sweep variant — one kernel per pass, decoupled look-back over per-tile status words — was measured here and was 1.7x slower per
 // pass: with ~770 tiles in flight the look-back reads dozens of predecessors' status rows, each an agent-scope 8-byte access.)
+#ifndef ELBA_RS_SCATTER_THREADS
+#define ELBA_RS_SCATTER_THREADS 256
+#endif
 #ifndef ELBA_RS_KEY_ITEMS
 #define ELBA_RS_KEY_ITEMS 32
 #endif
 constexpr int RS_THREADS = 256;
-constexpr int RS_WAVES = RS_THREADS / 64;
 constexpr int RS_MAXBITS = 9;
 constexpr int RS_MAXBINS = 1 << RS_MAXBITS;
 constexpr int CS_ROWS = 128;           // rows of the histogram one workgroup of the column scan folds
@@ -236,17 +238,18 @@ size_t column_scan_tmp_elems(int64_t nrows, uint32_t nbins)
     return tot + 64;
 }
 
-template <bool HAS_VAL, int ITEMS>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_in, const uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out,
-                                                           int64_t n, int shift, int bits, const uint32_t *hist_scanned)
+template <bool HAS_VAL, int THREADS, int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint64_t *keys_in, const uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out,
+                                                        int64_t n, int shift, int bits, const uint32_t *hist_scanned)
 {
-    constexpr int TILE = RS_THREADS * ITEMS;
-    __shared__ uint32_t whist[RS_WAVES][RS_MAXBINS];
-    __shared__ uint32_t lstart[RS_MAXBINS], gbase[RS_MAXBINS], wsum[RS_WAVES];
+    constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DPT = RS_MAXBINS / THREADS;      // digits per thread in the per-digit step
+    static_assert(DPT >= 1 && ITEMS * 64 < 65536, "one thread per digit at least; a wave's count of a digit fits 16 bits");
+    __shared__ uint16_t whist[WAVES][RS_MAXBINS];
+    __shared__ uint32_t lstart[RS_MAXBINS], gbase[RS_MAXBINS], wsum[WAVES];
     __shared__ uint64_t lkey[TILE], lval[HAS_VAL ? TILE : 1];
-    volatile uint32_t(*vh)[RS_MAXBINS] = whist;
+    volatile uint16_t(*vh)[RS_MAXBINS] = whist;
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
-    for (int i = threadIdx.x; i < RS_WAVES * RS_MAXBINS; i += RS_THREADS) (&whist[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < WAVES * RS_MAXBINS / 2; i += THREADS) reinterpret_cast<uint32_t *>(&whist[0][0])[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint64_t lt = (1ull << lane) - 1;
@@ -261,9 +264,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_
         key[r] = idx < n ? keys_in[idx] : 0;
     }
     // (the tile's row of output places: one coalesced load, in flight while the ranks are computed)
-    uint32_t gb[2];
+    uint32_t gb[DPT];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) { const uint32_t d = threadIdx.x + u * RS_THREADS; gb[u] = d < nbins ? hist_scanned[(size_t)blockIdx.x * nbins + d] : 0u; }
+    for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * THREADS; gb[u] = d < nbins ? hist_scanned[(size_t)blockIdx.x * nbins + d] : 0u; }
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t idx = wbase + r * 64 + lane;
@@ -282,37 +285,36 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_
         uint32_t pre = 0;
         if (valid && lane == leader) {
             pre = vh[w][d];
-            vh[w][d] = pre + cnt;
+            vh[w][d] = (uint16_t)(pre + cnt);
         }
         pre = __shfl(pre, leader, 64);
         rank[r] = pre + (uint32_t)__popcll(mask & lt);
     }
     __syncthreads();
     {
-        // per digit (thread t: digits 2t, 2t + 1): this tile's count, the waves' offsets inside the digit's chunk, the chunk's place in the tile
-        uint32_t tot[2];
+        // per digit (thread t: digits DPT * t ...): this tile's count, the waves' offsets inside the digit's chunk, the chunk's place in the tile
+        uint32_t tot[DPT], both = 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t d = 2 * threadIdx.x + u;
+        for (int u = 0; u < DPT; ++u) {
+            const uint32_t d = DPT * threadIdx.x + u;
             uint32_t t = 0;
             if (d < nbins) {
 #pragma unroll
-                for (int ww = 0; ww < RS_WAVES; ++ww) { const uint32_t x = whist[ww][d]; whist[ww][d] = t; t += x; }
+                for (int ww = 0; ww < WAVES; ++ww) { const uint32_t x = whist[ww][d]; whist[ww][d] = (uint16_t)t; t += x; }
             }
-            tot[u] = t;
+            tot[u] = t; both += t;
         }
-        const uint32_t both = tot[0] + tot[1];
         uint32_t inc = both;
 #pragma unroll
         for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= s2) inc += o; }
         if (lane == 63) wsum[w] = inc;
         __syncthreads();
-        uint32_t before = 0;
-        for (int ww = 0; ww < w; ++ww) before += wsum[ww];
-        if (2 * threadIdx.x < nbins) lstart[2 * threadIdx.x] = before + inc - both;
-        if (2 * threadIdx.x + 1 < nbins) lstart[2 * threadIdx.x + 1] = before + inc - both + tot[0];
+        uint32_t run = inc - both;
+        for (int ww = 0; ww < w; ++ww) run += wsum[ww];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) { const uint32_t d = threadIdx.x + u * RS_THREADS; if (d < nbins) gbase[d] = gb[u]; }
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = DPT * threadIdx.x + u; if (d < nbins) lstart[d] = run; run += tot[u]; }
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * THREADS; if (d < nbins) gbase[d] = gb[u]; }
     }
     __syncthreads();
 #pragma unroll
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const uint64_t *keys_
     __syncthreads();
     const int64_t left = n - tbase;
     const uint32_t nvalid = left < (int64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
-    for (uint32_t t = threadIdx.x; t < nvalid; t += RS_THREADS) {
+    for (uint32_t t = threadIdx.x; t < nvalid; t += THREADS) {
         const uint64_t k = lkey[t];
         const uint32_t d = (uint32_t)(k >> shift) & dmask;
         const uint32_t dst = gbase[d] + (t - lstart[d]);
@@ -406,6 +408,7 @@ static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *
     if (n <= 1 || bit_hi <= bit_lo) return 0;
     ELBA_REQUIRE(n < (int64_t)0xFFFFFFFFLL, ELBA_ERR_UNSUPPORTED, "radix sort of >= 2^32 items");
     constexpr int ITEMS = HAS_VAL ? 8 : ELBA_RS_KEY_ITEMS, TILE = RS_THREADS * ITEMS;
+    constexpr int STHREADS = HAS_VAL ? RS_THREADS : ELBA_RS_SCATTER_THREADS;      // the scatter's workgroup (512 threads on the same 8192-key tile were measured: 14.1-14.9 ms per pass against 10.8-13.7)
     int shifts[64], widths[64];
     const int npass = radix_digits(bit_lo, bit_hi, shifts, widths);
     const uint32_t nblocks = (uint32_t)((n + TILE - 1) / TILE);
@@ -420,7 +423,7 @@ static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *
         if (q > 0 || !first_hist_done)
             hipLaunchKernelGGL((k_rs_hist<ITEMS>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const uint64_t *)ki, n, shift, bits, hist);
         column_scan(s, hist, (int64_t)nblocks, nbins, scan_tmp);
-        hipLaunchKernelGGL((k_rs_scatter<HAS_VAL, ITEMS>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const uint64_t *)ki, (const uint64_t *)vi, ko, vo, n, shift, bits, (const uint32_t *)hist);
+        hipLaunchKernelGGL((k_rs_scatter<HAS_VAL, STHREADS, TILE / STHREADS>), dim3(nblocks), dim3(STHREADS), 0, s, (const uint64_t *)ki, (const uint64_t *)vi, ko, vo, n, shift, bits, (const uint32_t *)hist);
         uint64_t *t;
         t = ki; ki = ko; ko = t;
         t = vi; vi = vo; vo = t;
