@@ -162,6 +162,7 @@ struct Ctx {
     // counted as owned (calls without the mirror exchange between ranks).  They are a property of A, written when A is built (k_runs_emit /
     // k_csc_to_csr_words: every entry sees its whole column there anyway).  csr_hints false: both bits are zero / positions use all 32 bits.
     bool csr_hints = false, ov_hints_used = false, ov_rec16 = false;
+    DevBuf ov_sample;         // u32[256]: the rows a cold SpGEMM call computes first (spgemm.hip)
     int64_t A_products = 0;   // sum over the window's row entries of their column's length (what the SpGEMM reports as `products`)
     DevBuf prod_ctr;
     DevBuf kid_of_entry;  // u64[Z] k-mer id of every entry of a_csc (written with the columns; what the CSR build sorts by read)
@@ -172,10 +173,10 @@ struct Ctx {
     bool A_has_kmers = false;
     int64_t M = 0, N = 0, Z = 0, max_row_nnz = 0, max_col_nnz = 0;
     DevBuf a_rowptr, a_csr, a_colptr, a_csc;   // u32[M+1], u64[Z], u32[N+1], u64[Z]
-    DevBuf a_ell;                              // u64[N << s_log2]: the columns padded to a power-of-two stride (entries, then all ones) — the column store the
-                                               // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid << s_log2, no pointer
+    DevBuf a_ell;                              // u64[N * s_stride]: the columns padded to a common stride (entries, then all ones) — the column store the
+                                               // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid * s_stride, no pointer
     bool use_ell = false;
-    uint32_t s_log2 = 2, lpc_log2 = 1;         // padded column stride 2^s_log2 entries; lanes of the SpGEMM per row entry 2^lpc_log2
+    uint32_t s_stride = 4, lpc_log2 = 1;       // padded column stride in entries (4, or a multiple of 8: a whole number of 64-byte lines); lanes of the SpGEMM per row entry 2^lpc_log2 >= s_stride / 2
     bool plan = false;                         // ELBA_PLAN=1 (A/B runs): the round-1 per-entry descriptor format is built with A and the descriptor kernel runs
     bool cold_calls = false;                   // every elba_create_seed_matrix call forgets what earlier calls learned (prior, tier usage): elba_set_option
     DevBuf a_rowprod;                          // u32[M] products per row: sum of the column lengths of the row's k-mers

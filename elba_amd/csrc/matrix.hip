@@ -104,16 +104,16 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
     if ((threadIdx.x & 63) == 0) atomicMax(out, m);
 }
 
-// padded column store: slot j of column kid (at (kid << sb) + j) holds the column's j-th entry, or all ones behind its end; one lane per
+// padded column store: slot j of column kid (at kid * stride + j) holds the column's j-th entry, or all ones behind its end; one lane per
 // slot, so the stores of a wavefront are one contiguous 512 bytes (no fill pass before, no column-id array)
-__global__ void k_fill_ell(const uint32_t *colptr, const uint64_t *csc, uint64_t nslots, uint32_t sb, uint64_t *ell)
+__global__ void k_fill_ell(const uint32_t *colptr, const uint64_t *csc, uint64_t nslots, uint32_t cs, uint64_t *ell)
 {
-    // two slots (16 bytes) per lane: S >= 4, so a pair never straddles two columns.  (Adding the hint bits of the entries here, by the lane
+    // two slots (16 bytes) per lane: the stride is even, so a pair never straddles two columns.  (Adding the hint bits of the entries here, by the lane
     // that copies them, was measured: 15.8 ms against 4.8 + 5.2 for this kernel and k_add_hints — most lanes hold padding.)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, npairs = nslots >> 1;
     for (uint64_t t2 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t2 < npairs; t2 += stride) {
-        const uint64_t t = t2 << 1, kid = t >> sb;
-        const uint32_t j = (uint32_t)t & ((1u << sb) - 1u), c0 = colptr[kid], L = colptr[kid + 1] - c0;
+        const uint64_t t = t2 << 1, kid = t / cs;
+        const uint32_t j = (uint32_t)(t - kid * cs), c0 = colptr[kid], L = colptr[kid + 1] - c0;
         ulonglong2 v;
         v.x = j < L ? csc[c0 + j] : ~0ull;
         v.y = j + 1u < L ? csc[c0 + j + 1u] : ~0ull;
@@ -564,28 +564,32 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     unsigned long long *prod_ctr = c.prod_ctr.as<unsigned long long>();
     if (!pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 64 * 128, s));      // (pre: k_runs_emit has counted)
     // The column store the SpGEMM gathers from.  No column longer than 64 entries (UPPER <= 64: every configuration the reference
-    // documents): columns padded to S = 2^s_log2 >= 4 entries, column kid at kid * S — its address is arithmetic, and a group of S/2
+    // documents): columns padded to a common stride S (4 entries, or whole 64-byte lines), column kid at kid * S — its address is arithmetic, and a group of S/2
     // lanes reads it as one aligned segment.  Longer columns (or no room for the padding): the plain CSC, reached through a_colptr.
     c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
     {
         const uint32_t mc = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
-        uint32_t sb = 2;
-        while ((1u << sb) < mc) ++sb;
+        // stride: 4 entries, else the longest column rounded up to whole 64-byte lines (8 entries) — a power of two is not needed: the kernel
+        // multiplies (U = 35: 40 entries = 5 lines per gather where 64 entries would fetch 8)
+        const uint32_t stride = mc <= 4 ? 4u : (mc + 7u) & ~7u;
         size_t free_b = 0, total_b = 0;
         ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
-        const size_t ell_bytes = ((size_t)N << sb) * 8;
-        c.use_ell = mc <= 64 && N > 0 && !getenv("ELBA_NO_ELL") && ell_bytes <= (free_b + c.a_ell.cap) / 3 && ((uint64_t)N << sb) < (1ull << 40);
+        const size_t ell_bytes = (size_t)N * stride * 8;
+        c.use_ell = mc <= 64 && N > 0 && !getenv("ELBA_NO_ELL") && ell_bytes <= (free_b + c.a_ell.cap) / 3 && (uint64_t)N * stride < (1ull << 40);
         if (c.use_ell) {
-            c.s_log2 = sb; c.lpc_log2 = sb - 1; c.fbits = sb;
+            uint32_t lb = 1, fb = 2;
+            while ((2u << lb) < stride) ++lb;              // lanes per row entry: 16 bytes (two entries) each
+            while ((1u << fb) < stride) ++fb;
+            c.s_stride = stride; c.lpc_log2 = lb; c.fbits = fb;
             c.a_ell.reserve(ell_bytes + 64);
             ELBA_HIP(hipMemsetAsync(c.a_ell.as<char>() + ell_bytes, 0xFF, 64, s));      // (guard words behind the last column)
-            const uint64_t nslots = (uint64_t)N << sb;
-            hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 30)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), nslots, sb, c.a_ell.as<uint64_t>());
+            const uint64_t nslots = (uint64_t)N * stride;
+            hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 30)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), nslots, stride, c.a_ell.as<uint64_t>());
         } else {
             // lanes per row entry: half the longest column, between 2 and 64 (a column is walked in chunks of 2 * lanes entries)
             uint32_t lb = 1;
             while (lb < 6 && (2u << lb) < mc) ++lb;
-            c.lpc_log2 = lb; c.s_log2 = 0;
+            c.lpc_log2 = lb; c.s_stride = 0;
             int fb = 1;
             while (fb < 31 && ((uint64_t)(mc > 1 ? mc - 1 : 1) >> fb)) ++fb;
             c.fbits = (uint32_t)fb;

@@ -57,9 +57,11 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned int overflow;       // staging area too small: rerun after growing
     unsigned int tier_count[NUM_TIERS];   // rows queued per tier (grows while lower tiers escalate rows)
     unsigned int tier_done[NUM_TIERS];    // rows completed per tier
-    unsigned int fin_count[2];            // rows needing the LDS-bitonic / HBM-bitonic column sort
+    unsigned int fin_count[2];            // rows needing the workgroup bucket sort / the HBM-bitonic sort of their columns
     unsigned int pad[2];
     unsigned long long pad2[14];          // keep the feedback sums on a cache line of their own
+    alignas(128) unsigned int sample_next[8][32];          // the same for the sample queue (below)
+    unsigned int sample_count;                             // rows of the sample queue: a few hundred rows computed FIRST on a cold call — their distinct-partner ratio then picks the other rows' tiers
     alignas(128) unsigned int tier_next[NUM_TIERS][8][32]; // plan-free kernel: heads ([..][..][0]) of every tier's 8 interleaved sub-queues, a 128-byte line each
     alignas(128)
     unsigned long long fb_claims, fb_ub;  // feedback: distinct partners found / products, summed over rows done so far in this call
@@ -76,7 +78,7 @@ struct OvParams {
     // plan-free path (spgemm_direct.hpp): the two orientations of A and nothing else
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint64_t *a_ell; const uint32_t *a_colptr; const uint64_t *a_csc;
     uint32_t hint_mask, pos_mask;   // which hint bit of a row entry lets this call skip its column (0: none) / the position bits (Ctx::csr_hints)
-    uint32_t s_log2, lpc_log2, max_col;      // padded column stride 2^s_log2 (a_ell); lanes per row entry 2^lpc_log2; longest column
+    uint32_t s_stride, lpc_log2, max_col;    // padded column stride in entries (a_ell); lanes per row entry 2^lpc_log2; longest column
     unsigned long long fb_enough;            // row entries behind the in-call partner / entry ratio at which it counts as settled (nobody touches the hot sums any more)
     const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_cscj; const uint32_t *a_roworder;
     const RowHot *a_hdr; const HotDesc *a_hot; const uint64_t *a_dec;   // per-row bounds, per-entry partner ranges, seed decoding by canonical rank (matrix.hip)
@@ -95,6 +97,7 @@ struct OvParams {
     uint32_t *low_cnt;       // [M+1] zero at entry: mirrored entries per row; its returning atomic hands every mirrored entry its slot
     unsigned long long *row_off;   // [M]
     uint32_t *lists;         // [NUM_TIERS][M]
+    uint32_t *sample_list; uint32_t nsample, sstep;      // cold calls: rows row_lo + q * sstep, q < nsample, are the sample (k_classify_direct, mode 1)
     uint32_t *fin_lists;     // [2][M]
     OvCounters *ctr;
     StageRec *tmp; unsigned long long tmp_cap;
@@ -307,57 +310,70 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
     }
 }
 
-// Rows of up to FIN_WAVE2_MAX entries: one wavefront per row (16 rows in flight per CU, no workgroup barriers).
-//   <= 256 entries: the row's columns are staged in LDS and every lane ranks its (up to 4) elements against all of them — columns are distinct,
-//      so ranks are a permutation;
-//   <= 1024: bucket + rank sort, as k_finalize_bucket below but by one wavefront — ~y/8 equal column ranges, count, scan, scatter the keys
-//      into their buckets, rank inside the bucket (~8 compares).  The 200 k-read set's rows average 490 entries: with a workgroup per
-//      row (4 barriers and three dependent global loads each, 4 rows in flight per CU) this pass took 1.9 ms of a 15 ms call.
+// Rows of up to FIN_WAVE_MAX entries: one wavefront per row; the row's columns are staged in LDS and every lane ranks its (up to 4)
+// elements against all of them — columns are distinct, so ranks are a permutation.  (Every row passes here once: the ticket counters are
+// handed back clean.)
 __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
+{
+    __shared__ uint32_t colsm[4][FIN_WAVE_MAX];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    uint32_t *cols = colsm[w];
+    for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
+        const int64_t dst = p.b_rowptr[i];
+        const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
+        const uint32_t low = p.low_cnt[i];
+        if (lane == 0 && low) p.low_cnt[i] = 0;          // the ticket counters are handed back clean (k_mirror, the only other reader, has finished)
+        if (y == 0 || y > FIN_WAVE_MAX) continue;
+        if (dst + (int64_t)y > p.b_cap) continue;
+        const unsigned long long off = p.row_off[i];
+        uint32_t mine[4];
+        uint4 ra[4], rb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = (uint32_t)lane + 64u * u;
+            mine[u] = 0xFFFFFFFFu;
+            if (t < y) {
+                fin_load(p, low, off, dst, t, ra[u], rb[u]);
+                mine[u] = ra[u].x;
+                cols[t] = mine[u];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t rank[4] = {0, 0, 0, 0};
+        for (uint32_t l = 0; l < y; ++l) {
+            const uint32_t c = cols[l];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) rank[u] += c < mine[u] ? 1u : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t t = (uint32_t)lane + 64u * u;
+            if (t < y) { p.b_col[dst + rank[u]] = mine[u]; p.b_val[dst + rank[u]] = rec_seed(ra[u], rb[u]); }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Rows of FIN_WAVE_MAX + 1 .. FIN_WAVE2_MAX entries: still ONE WAVEFRONT per row — 16 rows in flight per CU, no workgroup
+// barriers — with a bucket + rank sort as in k_finalize_bucket below: ~y/8 equal column ranges, count, scan, scatter the keys into their
+// buckets, rank inside the bucket (~8 compares).  The 200 k-read set's rows average 490 entries.
+__global__ __launch_bounds__(256) void k_finalize_mid(FinParams p)
 {
     __shared__ uint64_t lkeys[4][FIN_WAVE2_MAX];
     __shared__ uint32_t bst[4][128], bfl[4][128];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    uint32_t *cols = reinterpret_cast<uint32_t *>(lkeys[w]);
-    for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
+    for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {      // (no queue: 200 k rows drawing slots from one counter cost more than looking at every row's length)
         const int64_t dst = p.b_rowptr[i];
         const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
-        const uint32_t low = p.low_cnt[i];
-        if (lane == 0 && low) p.low_cnt[i] = 0;          // the ticket counters are handed back clean (k_mirror, the only other reader, has finished)
-        if (y == 0 || y > FIN_WAVE2_MAX) continue;
+        if (y <= FIN_WAVE_MAX || y > FIN_WAVE2_MAX) continue;
         if (dst + (int64_t)y > p.b_cap) continue;
+        const uint32_t low = y - p.row_cnt[i];          // (low_cnt itself has been handed back by k_finalize_wave)
         const unsigned long long off = p.row_off[i];
-        if (y <= FIN_WAVE_MAX) {
-            uint32_t mine[4];
-            uint4 ra[4], rb[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t t = (uint32_t)lane + 64u * u;
-                mine[u] = 0xFFFFFFFFu;
-                if (t < y) {
-                    fin_load(p, low, off, dst, t, ra[u], rb[u]);
-                    mine[u] = ra[u].x;
-                    cols[t] = mine[u];
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            uint32_t rank[4] = {0, 0, 0, 0};
-            for (uint32_t l = 0; l < y; ++l) {
-                const uint32_t c = cols[l];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) rank[u] += c < mine[u] ? 1u : 0u;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t t = (uint32_t)lane + 64u * u;
-                if (t < y) { p.b_col[dst + rank[u]] = mine[u]; p.b_val[dst + rank[u]] = rec_seed(ra[u], rb[u]); }
-            }
-            __builtin_amdgcn_wave_barrier();
-            continue;
-        }
         uint32_t nb = y / 8;
         nb = nb > 128u ? 128u : nb;
         const unsigned long long scale = ((unsigned long long)nb << 32) / (p.M > 0 ? p.M : 1u);       // bucket(col) = col * nb / M, monotone in col, < nb
@@ -669,6 +685,7 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
         hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
         if (nremote > 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((nremote + 255) / 256, (int64_t)cus * 32)), dim3(256), 0, s, f, remote, (unsigned long long)nremote);
         hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
+        hipLaunchKernelGGL(k_finalize_mid, dim3(nb), dim3(256), 0, s, f);
         skipped_sorts = 0;
         if (all_sorts || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
         else skipped_sorts |= 1u;
@@ -716,6 +733,7 @@ static void ov_finish_stats(Ctx &c, OvCounters &hc, elba_overlap_stats &st, int 
     st.rows_global = (int64_t)hc.tier_done[NUM_LDS_TIERS];
     int64_t queued = 0;
     for (int t = 0; t < NUM_TIERS; ++t) queued += hc.tier_count[t];
+    queued += hc.sample_count;
     st.rows_escalated = queued - st.rows_lds - st.rows_global;
     st.algorithmic_bytes = 16 * Z + 8 * (2 * M + N + 3) + 24 * Y;
     st.passes = passes;
@@ -775,7 +793,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
     p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
-    p.s_log2 = c.s_log2; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
+    p.s_stride = c.s_stride; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
     p.half = phase == 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
     p.pos_mask = c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu;
@@ -835,11 +853,15 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         c.ov_low_clean = false;
         ELBA_HIP(hipMemsetAsync(c.ov_counters.p, 0, sizeof(OvCounters), s));
         ELBA_HIP(hipMemsetAsync(c.ov_rowcnt.p, 0, (size_t)(M + 2) * 4, s));
-        if (nrows > 0) {
-            int nb = (int)((nrows + 255) / 256);
-            if (nb > cus * 4) nb = cus * 4;
-            hipLaunchKernelGGL(k_classify_direct, dim3(nb), dim3(256), 0, s, p);
-        }
+        // A cold call on a matrix of some size computes a SAMPLE of its rows first (every sstep-th row, on the 4096-slot tier): what they find
+        // — distinct partners per row entry — picks the starting tier of all the others, instead of a guess that sends most rows of a
+        // 15 %-error read set to a tier too small (an abandoned attempt or a forwarding each: 0.9 ms of a 14.7 ms call on the 200 k-read set).
+        p.use_feedback = c.ov_prior_q16 ? 0u : 1u;      // (a repeated pass starts like the first)
+        const bool sampling = p.use_feedback && nrows >= 8192 && !getenv("ELBA_NO_SAMPLE");
+        p.nsample = sampling ? 256u : 0u; p.sstep = sampling ? (uint32_t)(nrows / 256) : 1u;
+        c.ov_sample.reserve(256 * 4);
+        p.sample_list = c.ov_sample.as<uint32_t>();
+        if (sampling) hipLaunchKernelGGL(k_classify_direct, dim3(1), dim3(256), 0, s, p, 1);
         if (timed) c.ov_marks.mark(1, s);
         if (nrows > 0) {
             // bytes behind the table: misc words + per wavefront one product ring (128 entries of 12 / 8 bytes) and one row-entry FIFO (128 x 12 bytes)
@@ -847,26 +869,36 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
             const bool all_tiers = !c.ov_tiers_known;
             skipped_tiers = 0;
 #define ELBA_DTIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
-#define ELBA_LAUNCH_D(B, G, P, grid, lds, tier, tb)                                                                                       \
+#define ELBA_LAUNCH_D(B, G, P, grid, lds, tier, tb, smp)                                                                                  \
     do {                                                                                                                                  \
-        if (dk == 1) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 1>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));                   \
-        else if (dk == 4) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 4>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));              \
-        else hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 2>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));                           \
+        if (dk == 1) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 1>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));            \
+        else if (dk == 4) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 4>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));       \
+        else hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 2>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));                    \
     } while (0)
             const int dk = getenv("ELBA_DK") ? atoi(getenv("ELBA_DK")) : 2;      // rounds of DK trips in flight (tuning knob)
-            if (pay) {
-                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, true, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u));
-                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, true, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u));
-                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, true, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u));
-                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u));
-            } else {
-                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, false, cus * 12, (size_t)18 * 512 + X(128, false), 0, 9u));
-                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, false, cus * 7, (size_t)18 * 1024 + X(256, false), 1, 10u));
-                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, false, cus * 3, (size_t)18 * 2048 + X(512, false), 2, 11u));
-                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 4096 + X(1024, false), 3, 12u));
+            if (sampling) {
+                if (pay) ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
+                else ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 4096 + X(1024, false), 3, 12u, 1u);
+                p.use_feedback = 0;      // the ratio is measured: nothing is forwarded on a prediction any more, nobody touches the hot sums
             }
-            ELBA_DTIER(4, ELBA_LAUNCH_D(256, false, false, cus, (size_t)18 * 8192 + X(256, false), 4, 13u));      // (4 wavefronts: 8192 slots + their rings fill the 160 KB)
-            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, X(256, false), NUM_LDS_TIERS, 0u));
+            {
+                int nb = (int)((nrows + 255) / 256);
+                if (nb > cus * 4) nb = cus * 4;
+                hipLaunchKernelGGL(k_classify_direct, dim3(nb), dim3(256), 0, s, p, 0);
+            }
+            if (pay) {
+                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, true, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u, 0u));
+                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, true, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u, 0u));
+                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, true, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u, 0u));
+                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 0u));
+            } else {
+                ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, false, cus * 12, (size_t)18 * 512 + X(128, false), 0, 9u, 0u));
+                ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, false, cus * 7, (size_t)18 * 1024 + X(256, false), 1, 10u, 0u));
+                ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, false, cus * 3, (size_t)18 * 2048 + X(512, false), 2, 11u, 0u));
+                ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 4096 + X(1024, false), 3, 12u, 0u));
+            }
+            ELBA_DTIER(4, ELBA_LAUNCH_D(256, false, false, cus, (size_t)18 * 8192 + X(256, false), 4, 13u, 0u));      // (4 wavefronts: 8192 slots + their rings fill the 160 KB)
+            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, X(256, false), NUM_LDS_TIERS, 0u, 0u));
 #undef ELBA_LAUNCH_D
 #undef ELBA_DTIER
             ELBA_HIP(hipGetLastError());
@@ -1201,6 +1233,7 @@ void stage_create_seed_matrix(Ctx &c)
             if (nb > cus * 32) nb = cus * 32;      // one row per wavefront where possible: the pass is latency-bound per row
             hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
             hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
+            hipLaunchKernelGGL(k_finalize_mid, dim3(nb), dim3(256), 0, s, f);
             // the wide-row sorts read their queues' lengths on the device: launched unconditionally (empty queues cost a few us)
             skipped_sorts = 0;
             if (!fast || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);

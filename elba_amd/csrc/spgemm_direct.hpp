@@ -1,7 +1,7 @@
 // spgemm_direct.hpp — the numeric kernel of the overlap SpGEMM, PLAN-FREE (included by spgemm.hip inside its anonymous namespace).
 //
 // Input is A as the k-mer stage leaves it and nothing else: CSR (a_rowptr, a_csr: kid << 32 | hint << 30 | pos, rows in (kid, pos) order) and the
-// k-mer columns — padded to a power-of-two stride (a_ell: column kid occupies the S = 2^s_log2 consecutive 8-byte words from kid * S,
+// k-mer columns — padded to a common stride (a_ell: column kid occupies the S = s_stride consecutive 8-byte words from kid * S,
 // entries (read << 32 | pos) in (read, pos) order, the rest all ones) when no column is longer than 64 entries, else plain CSC
 // (a_colptr, a_csc).  No per-row schedule, no descriptors, no row order, no product counts: whatever the product needs beyond the two
 // orientations of A is computed inside the call (reference region: src/SharedSeeds.cpp:4-10 under the timer of src/main.cpp:280-282).
@@ -33,16 +33,16 @@ __device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t row_l
 }
 
 template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2>
-__global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits)
+__global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits, uint32_t sample)
 {
     static_assert(!PAY || !GLOBAL, "payload accumulators: LDS tiers only");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *misc = GLOBAL ? smem : smem + (size_t)(PAY ? 6 : 4) * (1u << lds_tbits) + ((size_t)1 << lds_tbits) / 2;
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1;
-    const uint32_t nrows = p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream)
+    const uint32_t nrows = sample ? p.ctr->sample_count : p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream); sample: the rows computed before all others on a cold call
     const uint32_t lb = p.lpc_log2, sub = tid & ((1u << lb) - 1u), grp = tid >> lb, EPT = (uint32_t)BLOCK >> lb;
-    const uint32_t fbits = p.fbits, fmask = (1u << fbits) - 1u, sb = p.s_log2;
+    const uint32_t fbits = p.fbits, fmask = (1u << fbits) - 1u, stride = p.s_stride;
     const bool ell = p.a_ell != nullptr;
     const uint32_t hmask = p.hint_mask, pmask = p.pos_mask;      // ownership hints in the row entries (Ctx::csr_hints): skip bit of this call's mode, position bits
     const uint2 *csr2 = reinterpret_cast<const uint2 *>(p.a_csr);      // .x = position in the read, .y = k-mer id
@@ -51,14 +51,14 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
     auto w64 = [&](uint32_t k) { return reinterpret_cast<unsigned long long *>(&misc[k]); };
     if (tid >= 32 && tid < W_END2) misc[tid] = 0;
     if (tid >= D_FB0 && tid < D_FB0 + 4u) misc[tid] = 0;
-    const uint32_t *queue = p.lists + (size_t)tier * p.M;
+    const uint32_t *queue = sample ? p.sample_list : p.lists + (size_t)tier * p.M;
     // Rows are claimed one at a time, one row ahead.  One head word saturates at ~88 claims/us (MI355X_MICROARCH.md, "dequeue"); the queue
     // is therefore cut into 8 interleaved sub-queues (positions congruent modulo 8) with a head each, a workgroup draws from the one of
     // its XCD (workgroups go to the XCDs round-robin) and moves on to the next sub-queue when its own is exhausted.
     uint32_t qshard = blockIdx.x & 7u, qtried = 0;
     // (thread 0 only) draw: one atomic, nothing waits for it; resolve: where the draw is first needed — a draw beyond the end of the
     // sub-queue moves on to the next one (then, and only then, the claim is a synchronous round trip)
-    auto draw = [&]() -> uint32_t { return atomicAdd(&p.ctr->tier_next[tier][qshard][0], 1u); };
+    auto draw = [&]() -> uint32_t { return atomicAdd(sample ? &p.ctr->sample_next[qshard][0] : &p.ctr->tier_next[tier][qshard][0], 1u); };
     auto resolve = [&](uint32_t k) -> uint32_t {
         for (;;) {
             const unsigned long long idx = (unsigned long long)k * 8u + qshard;
@@ -248,10 +248,10 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 for (int u = 0; u < TR; ++u) {
                     const uint32_t k = (uint32_t)u * EW + gw;
                     x[u] = ones; pq[u] = 0; rk[u] = 0;
-                    if (k < ft - fh) {
+                    if (k < ft - fh && 2u * sub < stride) {      // (a stride that is no power of two leaves the group's last lanes without a word)
                         const uint32_t at = ((fh + k) & (FQ - 1u)) * 3u;
                         pq[u] = fq[at]; rk[u] = fq[at + 2u];
-                        x[u] = *reinterpret_cast<const uint4 *>(p.a_ell + (((unsigned long long)fq[at + 1u] << sb) + 2u * sub));
+                        x[u] = *reinterpret_cast<const uint4 *>(p.a_ell + ((unsigned long long)fq[at + 1u] * stride + 2u * sub));
                     }
                 }
                 const uint32_t n = ft - fh;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             auto seed_at = [&](uint32_t a, uint32_t &q, uint32_t &t) {      // sequence number -> the two positions (32-bit accumulators only)
                 const uint2 ce = csr2[rs + (a >> fbits)];
                 q = ce.x & pmask;
-                t = ell ? (uint32_t)p.a_ell[((unsigned long long)ce.y << sb) + (a & fmask)] : (uint32_t)p.a_csc[p.a_colptr[ce.y] + (a & fmask)];
+                t = ell ? (uint32_t)p.a_ell[(unsigned long long)ce.y * stride + (a & fmask)] : (uint32_t)p.a_csc[p.a_colptr[ce.y] + (a & fmask)];
             };
             for (uint32_t t = tid; t < ysurv + hasd; t += BLOCK) {
                 elba_seed_t v;
@@ -463,20 +463,35 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
 // ---- symbolic: queue every non-empty row of the window on its starting tier, in row order ----------------------------------------
 // All that is known of a row before the product is its length: distinct partners are estimated as nnz x prior (1/4 before anything is
 // known of the matrix — the kernel corrects itself from the rows already done — afterwards the measured ratio).
-__global__ __launch_bounds__(256) void k_classify_direct(OvParams p)
+__global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
 {
+    // mode 1: queue the sample — rows row_lo + q * sstep, q < nsample — and nothing else; mode 0: every (other) row on its starting tier.
+    // With a sample the ratio comes from what its rows found (fb_claims / fb_ub: flushed by the sample launch), + 25 %.
     const uint32_t stride = gridDim.x * blockDim.x;
     const uint32_t lane = threadIdx.x & 63;
     const uint64_t lt = (1ull << lane) - 1;
+    if (mode == 1) {
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < p.nsample; q += stride) {
+            const uint32_t i = p.row_lo + q * p.sstep;
+            if (i < p.row_hi && p.a_rowptr[i + 1] != p.a_rowptr[i]) p.sample_list[atomicAdd(&p.ctr->sample_count, 1u)] = i;
+        }
+        return;
+    }
+    uint32_t prior_q16 = p.prior_q16;
+    if (p.nsample) {
+        const unsigned long long u = p.ctr->fb_ub, cl = p.ctr->fb_claims;
+        if (u) { const double r = 1.25 * (double)cl / (double)u * 65536.0; prior_q16 = r < 64.0 ? 64u : (r > 4.0e9 ? 4000000000u : (uint32_t)r); }
+    }
     for (uint32_t i0 = p.row_lo + blockIdx.x * blockDim.x; i0 < p.row_hi; i0 += stride) {      // block-uniform trip count
         const uint32_t i = i0 + threadIdx.x;
         int mytier = -1;
-        const uint32_t nnz = i < p.row_hi ? p.a_rowptr[i + 1] - p.a_rowptr[i] : 0u;
+        uint32_t nnz = i < p.row_hi ? p.a_rowptr[i + 1] - p.a_rowptr[i] : 0u;
+        if (p.nsample && i < p.row_hi && (i - p.row_lo) % p.sstep == 0 && (i - p.row_lo) / p.sstep < p.nsample) nnz = 0;      // a row of the sample: done already
         if (nnz != 0) {
             const unsigned long long prod_ub = (unsigned long long)nnz * p.max_col;
             const uint32_t ub = prod_ub < (unsigned long long)p.Mcols ? (uint32_t)prod_ub : p.Mcols;
             const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
-            uint32_t est = (uint32_t)(((unsigned long long)nnz * p.prior_q16) >> 16);
+            uint32_t est = (uint32_t)(((unsigned long long)nnz * prior_q16) >> 16);
             if (est < 64) est = 64;
             int tier = 0;
             while (tier < NUM_LDS_TIERS && est > p.tier_limit[tier]) ++tier;
