@@ -406,3 +406,44 @@ def test_reference_kmer_hash_and_owner_on_the_device(k):
         assert (h == want).all()
         assert ow.tolist() == [L.orc_kmer_owner(C.c_uint64(int(x)), p) for x in want.tolist()] and ow.max() < p
     e.close()
+
+
+@pytest.mark.parametrize("shape", ["pairs", "wide"])
+def test_reads_that_hold_a_kmer_twice_and_the_ownership_hints(shape):
+    """The rows of A carry a hint per entry: "this row accumulates no pair of this column"  — an entry so marked never
+    fetches its column.  The cases the rule has to get right: a read that holds the k-mer twice (it owes itself the cross products), columns
+    of two reads (exactly one of them fetches), read ids of equal and of different parity, and long columns.  B, P and the diagonal
+    equal the oracle's, on a cold, a warm and a hint-free call."""
+    rng = np.random.default_rng(5 if shape == "pairs" else 6)
+    M, ncol = 3000, 40000
+    rows, cols, vals = [], [], []
+    hot = rng.choice(M, 400, replace=False)
+    for c in range(ncol):
+        n = 2 if shape == "pairs" and c % 4 else int(rng.integers(2, 9 if shape == "pairs" else 40))
+        r = rng.choice(hot, n, replace=True)              # with replacement: a read may hold the k-mer more than once
+        if c % 7 == 0: r[1] = r[0]                         # ... and every 7th column certainly does
+        r = np.sort(r)
+        p = rng.integers(0, 5000, n)
+        for rr in np.unique(r):                            # (read, pos) pairs of a column are distinct and ascending per read
+            m = r == rr
+            p[m] = np.sort(rng.choice(5000, int(m.sum()), replace=False))
+        rows.append(r); cols.append(np.full(n, c)); vals.append(p)
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals).astype(np.uint32)
+    up = 8 if shape == "pairs" else 40
+    o = po.Oracle(17, 2, up)
+    o.set_triples(M, ncol, rows, cols, vals)
+    o.spgemm(8)
+    oB = o.B()
+    for env in ({}, {"ELBA_NO_HINTS": "1"}):
+        for k_, v_ in env.items(): os.environ[k_] = v_
+        try:
+            e = elba_amd.Engine(17, 2, up)
+            e.set_kmer_matrix(M, ncol, rows, cols, vals)
+            st = e.create_seed_matrix()
+            gu.assert_B_equal(e.export_csr(), oB)
+            gu.assert_stats_equal(st, o)
+            e.create_seed_matrix()
+            gu.assert_B_equal(e.export_csr(), oB)
+            e.close()
+        finally:
+            for k_ in env: os.environ.pop(k_, None)
