@@ -51,6 +51,7 @@ __global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, cons
     words[z] = ((e >> 32) << (nb + pb + 2)) | (kid << (pb + 2)) | ((uint64_t)h << pb) | (e & 0xFFFFFFFFull);
 }
 // hint bits for sort keys that came without them (k_runs_emit, kmer.hip): the entry's k-mer id is in the word, its column in the CSC
+// (one lane per entry; one lane per COLUMN, its entries in registers, was measured: 7.0 ms against 5.2)
 __global__ void k_add_hints(const uint32_t *colptr, const uint64_t *csc, int64_t Z, int nb, int pb, uint64_t *words)
 {
     const int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -60,12 +61,18 @@ __global__ void k_add_hints(const uint32_t *colptr, const uint64_t *csc, int64_t
     const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0;
     if (L <= HINT_MAX_COL) words[z] = w | ((uint64_t)column_hint(csc + c0, L, (uint32_t)(csc[z] >> 32), 0u, 0xFFFFFFFFu) << pb);      // (the window is the whole matrix)
 }
-__global__ void k_unpack_csr_words(const uint64_t *words, int64_t Z, int nb, int pb, uint64_t *csr)
+// sorted keys -> CSR entries, and the row pointers with them: entry z opens the rows (read of z - 1, read of z]; launched with Z + 1 lanes,
+// the last of which closes the rows behind the last entry
+__global__ void k_unpack_csr_words(const uint64_t *words, int64_t Z, int nb, int pb, uint64_t *csr, uint32_t *rowptr, int64_t M)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (z >= Z) return;
-    const uint64_t w = words[z];
-    csr[z] = (((w >> (pb + 2)) & ((1ull << nb) - 1)) << 32) | (((w >> pb) & 3ull) << 30) | (w & ((1ull << pb) - 1));
+    if (z > Z) return;
+    const int rs = nb + pb + 2;
+    const int64_t prev = z == 0 ? -1 : (int64_t)(words[z - 1] >> rs);
+    const uint64_t w = z < Z ? words[z] : 0;
+    const int64_t cur = z < Z ? (int64_t)(w >> rs) : M;
+    for (int64_t k = prev + 1; k <= cur; ++k) rowptr[k] = (uint32_t)z;
+    if (z < Z) csr[z] = (((w >> (pb + 2)) & ((1ull << nb) - 1)) << 32) | (((w >> pb) & 3ull) << 30) | (w & ((1ull << pb) - 1));
 }
 
 __global__ void k_colrow_to_csc(const uint64_t *colrow, const uint64_t *pos, int64_t Z, uint64_t *csc)
@@ -606,8 +613,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
             hipLaunchKernelGGL(k_add_hints, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
         const int where = radix_sort_keys(s, w0, w1, Z, nb + pb + 2, nb + pb + 2 + mb, c.ws_sort);
         const uint64_t *sorted = where ? w1 : w0;
-        group_offsets_u32(s, sorted, nb + pb + 2, Z, c.a_rowptr.as<uint32_t>(), M);
-        if (Z > 0) hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, c.a_csr.as<uint64_t>());
+        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
     } else {
         ELBA_REQUIRE(!pre || !c.pre_words, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
         c.ws_b.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
