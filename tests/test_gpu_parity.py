@@ -338,7 +338,7 @@ def test_words_one_or_two_bits_short_mark_rare_positions_for_lookup():
     e.close()
 
 
-@pytest.mark.parametrize("knob", ["ELBA_NO_SYMMETRY", "ELBA_NO_ELL", "ELBA_NO_PAY", "ELBA_PLAN", "ELBA_KMER_HASH", "ELBA_KMER_PAIRS", "ELBA_MIR32", "ELBA_KMER_UNFUSED", "ELBA_CSR_PAIRS", "ELBA_NO_HINTS", "ELBA_RS_BITS"])
+@pytest.mark.parametrize("knob", ["ELBA_NO_SYMMETRY", "ELBA_NO_ELL", "ELBA_NO_PAY", "ELBA_PLAN", "ELBA_KMER_HASH", "ELBA_KMER_PAIRS", "ELBA_MIR32", "ELBA_KMER_UNFUSED", "ELBA_CSR_PAIRS", "ELBA_NO_HINTS", "ELBA_RS_BITS", "ELBA_EMIT_PLAIN", "ELBA_NO_SAMPLE"])
 def test_alternative_paths_kept_for_ab_runs_give_the_same_matrices(knob, monkeypatch):
     """Build-time / run-time alternatives kept behind environment knobs (both triangles accumulated instead of one + mirror, plain CSC columns
     instead of the padded ones, 32-bit accumulators + seed look-ups, the round-1 descriptor plan + kernel, hash-based counting, (value,
