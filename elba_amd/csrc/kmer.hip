@@ -155,13 +155,14 @@ __device__ __forceinline__ void for_each_instance_from(const EnumParams &e, uint
         if (e.inst_off[mid] <= g0) lo = mid; else hi = mid;
     }
     uint32_t r = lo;
+    uint64_t off_lo = e.inst_off[r], off_hi = e.inst_off[r + 1], boff = e.byte_off[r];      // the read's bounds stay in registers: reloaded only where a lane crosses into the next read
 #pragma unroll
     for (int it = 0; it < EN_ITEMS; ++it) {
         const uint64_t g = g0 + (uint64_t)it * 64 + lane;
         if (g >= e.I) break;
-        while (g >= e.inst_off[r + 1]) ++r;         // reads shorter than k have empty ranges and are skipped here
-        const uint32_t p = (uint32_t)(g - e.inst_off[r]);
-        f(g, r, p, canonical_at(e, r, p));
+        while (g >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }         // reads shorter than k have empty ranges and are skipped here
+        const uint32_t p = (uint32_t)(g - off_lo);
+        f(g, r, p, canonical_at_off(e, boff, p));
     }
 }
 template <class F>
@@ -268,6 +269,34 @@ __global__ void k_sort_columns(const uint32_t *colptr, uint64_t *csc, uint64_t *
     for (uint32_t a = c0; a < c1; ++a) kid_keys[a] = k;
 }
 
+// read of the first instance of every block of 2^IB_SHIFT instances: an entry then finds its read with ONE table load and a step or two
+// along the instance offsets instead of a binary search over all reads (18 dependent L2 round trips per entry on 200 k reads: the
+// search was 54 ms of the 219 ms k-mer stage of the 200 k-read set)
+constexpr int IB_SHIFT = 11;
+// the read holding the block's first instance, in ONE 16-byte load: its index, the block's first position in it, the instances it still
+// holds from there, and its byte offset (0xFFFFFFFF: does not fit 32 bits — fetched from the reads' offsets instead)
+struct alignas(16) BlockInfo { uint32_t read, pos0, remain, byte_off; };
+struct ReadCursor { uint32_t lo; uint64_t off_lo, off_hi, boff; };
+__device__ __forceinline__ ReadCursor cursor_at(const EnumParams &e, const BlockInfo *block_read, uint64_t g)
+{
+    const uint64_t g0 = g & ~((1ull << IB_SHIFT) - 1);
+    const BlockInfo bi = block_read[g >> IB_SHIFT];
+    ReadCursor c;
+    c.lo = bi.read; c.off_lo = g0 - bi.pos0; c.off_hi = g0 + bi.remain;
+    c.boff = bi.byte_off != 0xFFFFFFFFu ? (uint64_t)bi.byte_off : e.byte_off[bi.read];
+    return c;
+}
+__global__ void k_block_reads(const uint64_t *inst_off, const uint64_t *byte_off, uint32_t nreads, uint64_t nblocks, BlockInfo *block_read)
+{
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nblocks) return;
+    const uint64_t g = b << IB_SHIFT;
+    uint32_t lo = 0, hi = nreads;                                     // last read with inst_off[read] <= g
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (inst_off[mid] <= g) lo = mid; else hi = mid; }
+    const uint64_t rem = inst_off[lo + 1] - g, bo = byte_off[lo];      // (g beyond the last instance: the table's closing entry, never dereferenced past)
+    block_read[b] = BlockInfo{lo, (uint32_t)(g - inst_off[lo]), (uint32_t)(inst_off[lo + 1] > g ? rem : 0u), bo < 0xFFFFFFFFull ? (uint32_t)bo : 0xFFFFFFFFu};
+}
+
 // ---- sort-based counting ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit(EnumParams e, uint64_t *keys, uint64_t *vals)
 {
@@ -286,21 +315,33 @@ __global__ __launch_bounds__(EN_THREADS) void k_kmer_emit_packed(EnumParams e, i
 // The same, and the first radix pass's histogram with it: a workgroup writes one tile of the sort (SUB * EN_PER_BLOCK words) and the row of
 // digit counts the sort expects for it (radix_first_histogram, prims.hip) — the sort then starts with its scatter.
 template <int SUB>
-__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit_packed_hist(EnumParams e, int pb, int drop, uint64_t *words, int shift, int bits, uint32_t *hist)
+__global__ __launch_bounds__(EN_THREADS) void k_kmer_emit_packed_hist(EnumParams e, const BlockInfo *block_read, int pb, int drop, uint64_t *words, int shift, int bits, uint32_t *hist)
 {
+    static_assert(SUB * EN_PER_WAVE == (1 << IB_SHIFT), "a wavefront's share of the tile is one block of the instance -> read table");
     __shared__ uint32_t h[512];
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
     for (uint32_t i = threadIdx.x; i < nbins; i += EN_THREADS) h[i] = 0;
     __syncthreads();
     const int k2 = 2 * e.k;
+    const uint32_t lane = threadIdx.x & 63;
     const uint64_t base = ((uint64_t)blockIdx.x * (EN_THREADS / 64) + (threadIdx.x >> 6)) * (uint64_t)(SUB * EN_PER_WAVE);
-#pragma unroll 1
-    for (int sr = 0; sr < SUB; ++sr)
-        for_each_instance_from(e, base + (uint64_t)sr * EN_PER_WAVE, [&](uint64_t g, uint32_t, uint32_t, uint64_t km) {
+    if (base < e.I) {
+        // the read of the wavefront's first instance: ONE table load (a binary search over the reads is 18 dependent loads, and was repeated for
+        // every 512 instances); every lane then walks on by itself, the read's bounds in registers
+        const ReadCursor rc = cursor_at(e, block_read, base);
+        uint32_t r = rc.lo;
+        uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
+#pragma unroll 8
+        for (int it = 0; it < SUB * EN_ITEMS; ++it) {
+            const uint64_t g = base + (uint64_t)it * 64 + lane;
+            if (g >= e.I) break;
+            while (g >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }
+            const uint64_t km = canonical_at_off(e, boff, (uint32_t)(g - off_lo));
             const uint64_t wd = ((km >> (64 - k2)) << pb) | (g >> drop);
             words[g] = wd;
             atomicAdd(&h[(uint32_t)(wd >> shift) & dmask], 1u);
-        });
+        }
+    }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nbins; i += EN_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
 }
@@ -457,34 +498,6 @@ __global__ __launch_bounds__(RUN_THREADS) void k_runs(RunParams p, uint32_t *blk
 // fit beside the value in one 64-bit word, see stage_count_kmers): the entry is the dup-th instance among the 2^drop candidates whose
 // canonical k-mer is the column's, dup = entries of the same column with the same payload before this one (equal payloads are adjacent:
 // the sort is stable).  The instance's read is found by binary search in the reads' instance offsets (they stay in L2).
-// read of the first instance of every block of 2^IB_SHIFT instances: an entry then finds its read with ONE table load and a step or two
-// along the instance offsets instead of a binary search over all reads (18 dependent L2 round trips per entry on 200 k reads: the
-// search was 54 ms of the 219 ms k-mer stage of the 200 k-read set)
-constexpr int IB_SHIFT = 11;
-// the read holding the block's first instance, in ONE 16-byte load: its index, the block's first position in it, the instances it still
-// holds from there, and its byte offset (0xFFFFFFFF: does not fit 32 bits — fetched from the reads' offsets instead)
-struct alignas(16) BlockInfo { uint32_t read, pos0, remain, byte_off; };
-struct ReadCursor { uint32_t lo; uint64_t off_lo, off_hi, boff; };
-__device__ __forceinline__ ReadCursor cursor_at(const EnumParams &e, const BlockInfo *block_read, uint64_t g)
-{
-    const uint64_t g0 = g & ~((1ull << IB_SHIFT) - 1);
-    const BlockInfo bi = block_read[g >> IB_SHIFT];
-    ReadCursor c;
-    c.lo = bi.read; c.off_lo = g0 - bi.pos0; c.off_hi = g0 + bi.remain;
-    c.boff = bi.byte_off != 0xFFFFFFFFu ? (uint64_t)bi.byte_off : e.byte_off[bi.read];
-    return c;
-}
-__global__ void k_block_reads(const uint64_t *inst_off, const uint64_t *byte_off, uint32_t nreads, uint64_t nblocks, BlockInfo *block_read)
-{
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nblocks) return;
-    const uint64_t g = b << IB_SHIFT;
-    uint32_t lo = 0, hi = nreads;                                     // last read with inst_off[read] <= g
-    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (inst_off[mid] <= g) lo = mid; else hi = mid; }
-    const uint64_t rem = inst_off[lo + 1] - g, bo = byte_off[lo];      // (g beyond the last instance: the table's closing entry, never dereferenced past)
-    block_read[b] = BlockInfo{lo, (uint32_t)(g - inst_off[lo]), (uint32_t)(inst_off[lo + 1] > g ? rem : 0u), bo < 0xFFFFFFFFull ? (uint32_t)bo : 0xFFFFFFFFu};
-}
-
 // Second pass over the sorted words, fused with the entries' (read, pos): EVERY item of a reliable run writes its own entry — consecutive
 // lanes hold consecutive items and the entries of consecutive reliable runs are consecutive in the output, so the stores coalesce (the
 // per-head loops of k_runs<true> wrote one 8-byte word per lane and step, and k_instance_entries read all of it back).  An item finds its
@@ -854,7 +867,12 @@ void stage_count_kmers(Ctx &c)
             int sh0 = 0, b0 = 0, tile = 0;
             uint32_t *hist0 = I > 1 ? radix_first_histogram((int64_t)I, pb, pb + 2 * k, c.ws_sort, &sh0, &b0, &tile) : nullptr;
             const bool fuse_hist = hist0 && tile == 4 * EN_PER_BLOCK && b0 <= 9 && !getenv("ELBA_EMIT_PLAIN");      // (the emit writes whole tiles of the sort and counts their first digit)
-            if (fuse_hist) hipLaunchKernelGGL((k_kmer_emit_packed_hist<4>), dim3((unsigned)((I + tile - 1) / tile)), dim3(EN_THREADS), 0, s, e, pb, drop, c.ws_a.as<uint64_t>(), sh0, b0, hist0);
+            if (fuse_hist) {
+                const uint64_t nib = (I >> IB_SHIFT) + 1;
+                c.ws_b.reserve((size_t)(nib + 1) * sizeof(BlockInfo));
+                hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
+                hipLaunchKernelGGL((k_kmer_emit_packed_hist<4>), dim3((unsigned)((I + tile - 1) / tile)), dim3(EN_THREADS), 0, s, e, (const BlockInfo *)c.ws_b.as<BlockInfo>(), pb, drop, c.ws_a.as<uint64_t>(), sh0, b0, hist0);
+            }
             else if (I > 0) hipLaunchKernelGGL(k_kmer_emit_packed, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, pb, drop, c.ws_a.as<uint64_t>());
             where = radix_sort_keys(s, c.ws_a.as<uint64_t>(), c.ws_c.as<uint64_t>(), (int64_t)I, pb, pb + 2 * k, c.ws_sort, fuse_hist);
         } else {
