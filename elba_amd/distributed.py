@@ -251,13 +251,23 @@ class DistributedOverlap:
         return info
 
     # ---- collectives ------------------------------------------------------------------------------------------------
-    def _exchange_counts(self, counts):
-        t = self.be.torch.tensor(np.asarray(counts, dtype=np.int64), device=self.be.dev)
+    def _exchange_counts(self, counts, with_max=False):
+        """counts[p] = records this rank sends to rank p -> what it receives from every rank.  with_max: every rank also learns the largest
+        single message of the whole exchange (each rank sends its own largest beside the count), so that the ranks agree on the number of
+        all-to-all rounds without another collective."""
+        c = np.asarray(counts, dtype=np.int64)
+        if not with_max:
+            t = self.be.torch.tensor(c, device=self.be.dev)
+            r = self.be.torch.empty_like(t)
+            self.dist.all_to_all_single(r, t)
+            return r.cpu().numpy()                      # .cpu() waits for the collective
+        t = self.be.torch.tensor(np.stack([c, np.full_like(c, c.max(initial=0))], axis=1).reshape(-1), device=self.be.dev)
         r = self.be.torch.empty_like(t)
         self.dist.all_to_all_single(r, t)
-        return r.cpu().numpy()                      # .cpu() waits for the collective
+        r = r.cpu().numpy().reshape(-1, 2)
+        return r[:, 0].copy(), int(max(r[:, 1].max(initial=0), c.max(initial=0)))
 
-    def _all_to_all_records(self, send, send_counts, recv_counts):
+    def _all_to_all_records(self, send, send_counts, recv_counts, largest=None):
         torch = self.be.torch
         sc = np.asarray(send_counts, dtype=np.int64); rc = np.asarray(recv_counts, dtype=np.int64)
         width = int(send.shape[1])
@@ -266,8 +276,8 @@ class DistributedOverlap:
         # records per peer and round.  Measured on MI355X / RCCL 2.26.6 (scratch test in profiles/r01_notes.md): a single
         # all_to_all_single message of >= ~2 GiB per peer delivers only its first GiB, silently.
         CH = max(1, self.MAX_RECORDS_PER_PEER * 2 // width)          # the cap is in bytes per peer: wider records, fewer of them
-        rounds = int(max(1, -(-int(max(sc.max(initial=0), rc.max(initial=0))) // CH)))
-        if self.world > 1:
+        rounds = int(max(1, -(-int(max(sc.max(initial=0), rc.max(initial=0)) if largest is None else largest) // CH)))
+        if self.world > 1 and largest is None:      # (largest: the biggest message of the whole exchange is known to every rank already)
             t = torch.tensor([rounds], dtype=torch.int64, device=self.be.dev)
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
             rounds = int(t.item())
@@ -391,10 +401,10 @@ class DistributedOverlap:
             return self.be.create_seed_matrix()
         W = self.world
         sc = self.be.seed_begin(W, self.bounds)
-        rc = self._exchange_counts(sc)
+        rc, largest = self._exchange_counts(sc, with_max=True)
         send = self.be.empty_records(int(sc.sum()), 4)
         self.be.seed_fill(send, np.concatenate([[0], np.cumsum(sc)[:-1]]))
-        recv = self._all_to_all_records(send, sc, rc)
+        recv = self._all_to_all_records(send, sc, rc, largest=largest)
         del send
         self.mirror_bytes = int(sc.sum()) * 32
         return self.be.seed_end(recv)
