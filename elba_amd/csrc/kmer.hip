@@ -6,11 +6,15 @@
 // LOWER <= c <= UPPER, and every instance of a kept k-mer becomes one entry (read, pos).  That is computed here exactly, in one of two ways.
 //
 // Default — SORT-BASED, every pass a coalesced stream over HBM (no random atomics):
-//   k_kmer_emit      every k-mer instance -> (canonical packed value, read << 32 | pos), written in instance order = (read, pos) order
-//   radix sort       stable LSD sort of the pairs on the 2k value bits: equal k-mers become one run, its entries still in (read, pos) order
-//   k_run_flags / scan / k_run_heads / k_run_select / scans / k_emit_columns
-//                    run starts -> run lengths = the exact counts -> runs with LOWER <= count <= UPPER are numbered in value order
-//                    (k-mer id = rank of the value) and copied out: that IS the CSC of A, columns already sorted.
+//   k_kmer_emit_packed_hist   every k-mer instance -> ONE word, canonical value << pb | (instance index >> drop), written in instance order =
+//                             (read, pos) order, a whole tile of the sort per workgroup together with the tile's first-digit counts
+//                             ((value, read << 32 | pos) pairs — k_kmer_emit — when more than 3 index bits would have to be dropped)
+//   radix sort (prims.hip)    stable LSD sort on the 2k value bits: equal k-mers become one run, its entries still in (read, pos) order
+//   k_runs<false>             run lengths = the exact counts; per block: reliable runs (LOWER <= count <= UPPER), their entries, all runs
+//   k_runs_emit               reliable runs numbered in value order (k-mer id = rank of the value); every item of a reliable
+//                             run writes its entry (read, pos) — that IS the CSC of A, columns already sorted — and the entry's one-word
+//                             sort key for the CSR build.  (UPPER > 62 or pairs: k_runs<true> + k_instance_entries.)
+//   Multi-word k-mers (k > 31): k_kmer_emit2/3, an index permutation sorted last word first, runs compare every word.
 //
 // ELBA_KMER_HASH=1 — HASH-BASED (kept for A/B runs; the distributed owner counts by sorting too, see stage_dist_count_records):
 //
@@ -658,13 +662,6 @@ __global__ void k_instance_entries(const uint64_t *payload, const uint64_t *kid_
         }
     }
     csc[z] = ((uint64_t)lo << 32) | (uint32_t)(g - off_lo);
-}
-
-__global__ void k_column_ids(const uint32_t *colptr, uint64_t *kid_keys, uint64_t N)
-{
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    for (uint32_t a = colptr[k]; a < colptr[k + 1]; ++a) kid_keys[a] = k;
 }
 
 int bits_needed(uint64_t maxval)
