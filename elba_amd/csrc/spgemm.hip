@@ -3,22 +3,20 @@
 // Replaces create_seed_matrix (src/SharedSeeds.cpp:4-10: CombBLAS Mult_AnXBn_DoubleBuff<SharedSeeds::Semiring> + Prune)
 // with a row-wise hash SpGEMM written for CDNA4:
 //
-//   * one workgroup owns one read-row i of A; its lanes walk the row's per-entry descriptors (matrix.hip: for the row entry
-//     (i, k, pos) the contiguous ranges of column k that hold its partners, 16 bytes, coalesced) and gather the partner
-//     entries (read j, posT) of those ranges from the k-mer columns in HBM / Infinity Cache, four per lane in flight;
+//   * one workgroup owns one read-row i of A (spgemm_direct.hpp, the plan-free kernel: it walks CSR(A) and fetches the k-mer columns as the
+//     k-mer stage leaves them; spgemm_rows.hpp is round 1's kernel on per-entry descriptors, behind ELBA_PLAN=1 for A/B runs);
 //   * every product (i,k)x(j,k) updates an open-addressed accumulator keyed by the partner read j that lives in LDS
-//     (16 B per slot, SoA: key | count | smin | smax); the semiring's non-commutative add (include/SharedSeeds.hpp:41-46:
-//     keep the FIRST seed of the left operand and the FIRST seed of the right operand) is made order-free by the
-//     canonical rule of SURVEY.md §8c-2: the row's products carry a sequence number s = (entry index in row << fbits) |
-//     (entry index in column) that is monotone in (kid, posQ, posT); ds_min_u32/ds_max_u32 of s give exactly the first
-//     and last operand of an ascending-k left fold, ds_add_u32 gives numshared;
-//   * tables are sized OPTIMISTICALLY (512 ... 8192 slots) from the row's product count, which over-estimates the
-//     number of distinct partners by 10-1000x on real read sets; a row that fills its table beyond 3/4 is abandoned and
-//     re-queued on the next tier; the last tier keeps the table in HBM, sized by the bound that cannot overflow
-//     (min(products, reads)).  LDS capacity is therefore a performance tier, never a correctness limit;
-//   * survivors (numshared >= 2) are compacted with wavefront ballots + popcount prefix, their two seed positions are
-//     decoded from smin/smax, and the row is appended to an HBM staging area; a scan over per-row counts gives the CSR
-//     row pointers and a last pass sorts each row's columns and moves it to its final place.
+//     (SoA: key | count | first | last); the semiring's non-commutative add (include/SharedSeeds.hpp:41-46: keep the FIRST seed of the left
+//     operand and the FIRST seed of the right operand) is made order-free by the canonical rule of SURVEY.md §8c-2: the row's products carry
+//     a sequence number s = (entry index in row << fbits) | (entry index in column) that is monotone in (kid, posQ, posT); ds_min / ds_max
+//     of s give exactly the first and last operand of an ascending-k left fold, ds_add_u32 gives numshared;
+//   * tables are sized OPTIMISTICALLY (512 ... 8192 slots) from an estimate of the row's distinct partners (row entries x a ratio that a
+//     cold call measures on a sample of rows first); a row that fills its table beyond 3/4 is abandoned and re-queued on the next tier; the
+//     last tier keeps the table in HBM, sized by the bound that cannot overflow (min(products, reads)).  LDS capacity is therefore a
+//     performance tier, never a correctness limit;
+//   * a pair of rows is accumulated on ONE of them (owns_pair); survivors (numshared >= 2) are compacted with wavefront ballots + popcount
+//     prefix and appended to an HBM staging area; a scan over per-row counts gives the CSR row pointers, k_mirror hands every survivor's
+//     transposed image to the partner's row, and a last pass sorts each row's columns and moves it to its final place.
 //
 // No MFMA anywhere: the contraction is index matching plus integer min/max/add.
 #include "common.hpp"

@@ -7,17 +7,18 @@
 // orientations of A is computed inside the call (reference region: src/SharedSeeds.cpp:4-10 under the timer of src/main.cpp:280-282).
 //
 // One workgroup per row of B, rows claimed from the tier's queue with one atomic per row (claimed one row ahead).
-//   * a group of LPC = S/2 lanes takes one row entry (i, kid, posQ): the entry is ONE 8-byte load (the lanes of a group share it), the
-//     column ONE aligned 16-byte load per lane — the group reads the whole padded column as a single contiguous S*8-byte segment, so a
-//     column costs the L1 one request per 64 bytes and the address needs no column pointer: kid * S.  (CSC matrices pay the dependent
-//     colptr load and walk long columns in chunks of 2 * LPC entries.)
+//   * every wavefront walks the row in chunks of 64 consecutive entries and compacts those that must fetch their column into an LDS FIFO:
+//     an entry whose hint bit says "this row accumulates no pair of this column" (Ctx::csr_hints) only counts its diagonal product;
+//   * a group of LPC lanes takes one FIFO entry (kid, posQ, rank in the row) and reads the padded column as one contiguous segment, one
+//     aligned 16-byte load per lane: a column costs the L1 one request per 64 bytes and the address needs no column pointer: kid * S.
+//     (CSC matrices pay the dependent colptr load and walk long columns in chunks of 2 * LPC entries.)
 //   * every lane then holds two candidate partners (read j, posT): all ones = padding, j == i = the diagonal (counted, never inserted),
-//     anything else is a product and updates the LDS accumulator of partner j: count, and first / last product of the ascending-k left
-//     fold through ds_min / ds_max of the sequence number (rank of the row entry << fbits | index in the column), which is monotone in
-//     (kid, posQ, posT).  With PAY the 64-bit extremes carry posQ and posT themselves: no seed look-ups afterwards.
-//   * both triangles are computed (row i meets every partner j, smaller or larger): no mirror pass, a row's output is complete when its
-//     workgroup is done with it.
-//   * table tiers, optimistic sizing, escalation, HBM spill tier, ballot compaction of the survivors, staging: as before (spgemm.hip).
+//     anything else is a product; a pair of rows is accumulated on ONE of them (owns_pair below) and mirrored into the other afterwards
+//     (spgemm.hip: k_mirror, or the exchange between ranks).  Products are compacted into a per-wavefront ring and update the LDS
+//     accumulator of partner j: count, and first / last product of the ascending-k left fold through ds_min / ds_max of the sequence number
+//     (rank of the row entry << fbits | index in the column), which is monotone in (kid, posQ, posT).  With PAY the 64-bit
+//     extremes carry posQ and posT themselves: no seed look-ups afterwards.
+//   * table tiers, optimistic sizing, escalation, HBM spill tier, ballot compaction of the survivors, staging: spgemm.hip.
 
 enum : uint32_t { D_NEXT = 20, D_FB0 = 16, W_ACC_P = 54 /*u64*/, W_END2 = 56 };
 constexpr uint32_t RING = 128;      // per-wavefront product ring (entries): < 64 left over + <= 64 new ones per candidate slot
