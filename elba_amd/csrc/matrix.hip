@@ -3,7 +3,8 @@
 //   CSR(A)  = the reference's A  (src/KmerOps.cpp:361-401): row read, entries (kid, pos) ordered by (kid, pos)
 // Entries are single u64 words (hi = read or kid, lo = pos) so that one 8-byte load fetches an entry and a row /
 // column segment sorted as u64 is in canonical order.  Duplicate (read,kid) entries are kept (SumDuplicates=false,
-// src/KmerOps.cpp:400).
+// src/KmerOps.cpp:400).  A CSR entry also carries two ownership bits above its position (Ctx::csr_hints, common.hpp), and the columns
+// exist a second time padded to a common stride (a_ell): the store the SpGEMM fetches from.
 #include "common.hpp"
 #include "matrix.hpp"
 #include <algorithm>

@@ -1,5 +1,5 @@
 // prims.hip — device-wide plumbing primitives written for 64-wide wavefronts: exclusive scan, stable LSD radix
-// sort of (u64,u64) pairs, fills, group offsets.  Used by the k-mer stage and the matrix builders; the SpGEMM
+// sort of u64 keys and of (u64,u64) pairs (tile-major histograms + column scan), fills, group offsets.  Used by the k-mer stage and the matrix builders; the SpGEMM
 // hot loop does not call into here except for the row-pointer scan.
 #include "common.hpp"
 
