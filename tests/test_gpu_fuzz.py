@@ -1,0 +1,65 @@
+"""Seeded random cases against the oracle, through the C ABI: matrices handed over as triples (ownership hints, reads that hold a k-mer
+twice, columns of 1 .. 100 entries, positions beyond 16 bits, empty and tiny rows) and whole read sets (k = 7 .. 95, LOWER / UPPER incl.
+UPPER > 62, error-free to 12 % error, reads of 10 bases to a few thousand).  Bit-exact, cold and warm calls."""
+import numpy as np
+import pytest
+
+import elba_amd
+import gpu_util as gu
+from oracle import pyoracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_matrix_against_oracle(case):
+    rng = np.random.default_rng(1000 + case)
+    M = int(rng.choice([5, 64, 300, 3000, 40000]))
+    ncol = int(rng.choice([1, 50, 2000, 30000]))
+    maxlen = int(rng.choice([2, 3, 8, 20, 64, 100]))
+    maxpos = int(rng.choice([100, 5000, 65535, 200000]))
+    hot = rng.choice(M, min(M, int(rng.choice([3, 40, 500]))), replace=False)
+    rows, cols, vals = [], [], []
+    for c in range(ncol):
+        n = int(rng.integers(1, maxlen + 1))
+        r = np.sort(rng.choice(hot, n, replace=bool(rng.random() < 0.3) or n > len(hot)))
+        p = rng.integers(0, maxpos + 1, n)
+        for rr in np.unique(r):                          # (read, pos) pairs of a column are distinct, positions ascending per read
+            m = r == rr
+            p[m] = np.sort(rng.choice(maxpos + 1, int(m.sum()), replace=False))
+        rows.append(r); cols.append(np.full(n, c)); vals.append(p)
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals).astype(np.uint32)
+    up = max(2, maxlen)
+    o = po.Oracle(17, 2, up)
+    o.set_triples(M, ncol, rows, cols, vals)
+    o.spgemm(8)
+    oB = o.B()
+    e = elba_amd.Engine(17, 2, up)
+    e.set_kmer_matrix(M, ncol, rows, cols, vals)
+    st = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), oB)
+    gu.assert_stats_equal(st, o)
+    e.set_option("overlap_cold_calls", 1)
+    st = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), oB)
+    gu.assert_stats_equal(st, o)
+    e.close()
+
+
+@pytest.mark.parametrize("case", range(24))
+def test_random_read_set_against_oracle(case):
+    rng = np.random.default_rng(5000 + case)
+    k = int(rng.choice([7, 11, 15, 17, 21, 25, 31, 33, 45, 63, 65, 95]))
+    lo = int(rng.choice([2, 2, 3]))
+    up = max(lo, int(rng.choice([lo, 4, 8, 20, 50, 70])))
+    genome = int(rng.choice([500, 20000, 300000]))
+    depth = float(rng.choice([3, 10, 25]))
+    avg = float(rng.choice([60, 400, 3000]))
+    err = float(rng.choice([0.0, 0.02, 0.12]))
+    packed, off, lens, _ = elba_amd.synth_reads(100 + case, genome, depth, avg, avg / 4, error_rate=err, min_len=max(10, int(avg / 6)))
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up)
+    o = gu.oracle_run(packed, off, lens, k, lo, up, threads=8)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.close()
