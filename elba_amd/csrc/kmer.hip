@@ -1146,19 +1146,32 @@ __global__ void k_panel(const uint32_t *colptr, const uint64_t *csc, const uint3
                         unsigned long long *counts_or_cursors, uint64_t *send)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= N) return;
-    const uint32_t c0 = colptr[k], c1 = colptr[k + 1];
+    const uint32_t c0 = k < N ? colptr[k] : 0u, c1 = k < N ? colptr[k + 1] : 0u;      // (lanes behind the last column stay for the wave scans: empty columns)
     uint64_t mask = 0;
     for (uint32_t a = c0; a < c1; ++a) {
         const uint64_t read = csc[a] >> 32;
         const uint32_t r = rank_of_read(bounds, nranks, read);
         if (!win || (read >= win[r] && read < win[nranks + r])) mask |= 1ull << r;
     }
-    while (mask) {
-        const uint32_t d = (uint32_t)__ffsll((unsigned long long)mask) - 1;
-        mask &= mask - 1;
-        const unsigned long long at = atomicAdd(&counts_or_cursors[d], (unsigned long long)(c1 - c0));
-        if (FILL) {
+    // one atomic per wavefront and destination (its lanes' columns take consecutive places): a lane per (column, destination) sent
+    // 10^8 adds to at most 64 words — 334 ms for 58 M columns, of a 0.5 s distributed build
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t any = mask;
+#pragma unroll
+    for (int dd = 32; dd >= 1; dd >>= 1) any |= __shfl_xor(any, dd, 64);
+    while (any) {                                  // (wave-uniform)
+        const uint32_t d = (uint32_t)__ffsll((unsigned long long)any) - 1;
+        any &= any - 1;
+        const uint32_t mine = ((mask >> d) & 1ull) ? c1 - c0 : 0u;
+        uint32_t inc = mine;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const uint32_t o = __shfl_up(inc, dd, 64); if ((int)lane >= dd) inc += o; }
+        const uint32_t total = __shfl(inc, 63, 64);
+        unsigned long long base = 0;
+        if (lane == 63) base = atomicAdd(&counts_or_cursors[d], (unsigned long long)total);
+        base = __shfl(base, 63, 64);
+        if (FILL && mine) {
+            const unsigned long long at = base + (inc - mine);
             const uint64_t g = gid[k];
             for (uint32_t a = c0; a < c1; ++a) { send[2 * (at + (a - c0))] = g; send[2 * (at + (a - c0)) + 1] = csc[a]; }
         }
