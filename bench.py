@@ -38,6 +38,9 @@ WORKLOADS = {
     "200k-long-reads": dict(genome=66_700_000, depth=30.0, avg_len=10000.0, sd_len=1500.0, min_len=1000, error=0.15, k=17, lower=2, upper=8, seed=2),
     "ecsample30x-like": dict(genome=4_640_000, depth=30.0, avg_len=8240.0, sd_len=2000.0, min_len=1000, error=0.15, k=17, lower=2, upper=8, seed=1),
     "plumbing-135": dict(genome=100_000, depth=13.5, avg_len=10000.0, sd_len=1000.0, min_len=1000, error=0.0, k=17, lower=2, upper=8, seed=313),
+    # profiling cases (single GPU; not the driver's line): BASELINE configs[3] at half the genome and configs[4] at 1/25 of it
+    "hifi-half": dict(genome=50_000_000, depth=40.0, avg_len=15000.0, sd_len=2000.0, min_len=1000, error=0.005, k=17, lower=2, upper=4, seed=3),
+    "dense-repeats-25th": dict(genome=20_000_000, depth=40.0, avg_len=10000.0, sd_len=1000.0, min_len=1000, error=0.01, k=17, lower=2, upper=35, seed=4, repeats=(20, 0.05, 5000)),
 }
 PEAK_GBS = 8000.0          # HBM3E peak, MI355X_MICROARCH.md
 
@@ -94,7 +97,9 @@ def main():
     if single:
         from elba_amd.capi import Engine
         t0 = time.time()
-        packed, off, lens, info = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"])
+        rep = w.get("repeats", (0, 0.0, 0))
+        packed, off, lens, info = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"],
+                                                       repeat_families=rep[0], repeat_fraction=rep[1], repeat_len=rep[2])
         t_gen = time.time() - t0
         eng = Engine(k, lo, up, device=local_rank, timing_stride=args.timing_stride)
         # inputs resident in HBM before anything is timed
@@ -236,7 +241,8 @@ def main():
             sp, so, sl = packed, off, lens
             es = eng
         else:
-            sp, so, sl, _ = elba_amd.synth_reads(w["seed"], max(20000, w["genome"] // div), w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"])
+            sp, so, sl, _ = elba_amd.synth_reads(w["seed"], max(20000, w["genome"] // div), w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"],
+                                                 repeat_families=w.get("repeats", (0, 0.0, 0))[0], repeat_fraction=w.get("repeats", (0, 0.0, 0))[1], repeat_len=w.get("repeats", (0, 0.0, 0))[2])
             es = Engine(k, lo, up, device=local_rank)
             es.set_reads(sp, so, sl); es.count_kmers(); es.create_kmer_matrix()
         tg = time.perf_counter(); sst = es.create_seed_matrix(); tg = (time.perf_counter() - tg) * 1e3
