@@ -98,7 +98,7 @@ __device__ __forceinline__ uint32_t column_hint(const uint64_t *col, uint32_t L,
     if (mult >= 2) return 0u;
     return (own_g ? 0u : 1u) | (own_w ? 0u : 2u);
 }
-constexpr uint32_t HINT_MAX_COL = 64;
+constexpr uint32_t HINT_MAX_COL = 12;     // longer columns are not examined: a row owns no pair of an L-read column with probability 2^-(L-1), and the test costs L loads
 
 int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
 // The same for bare 64-bit words (whatever rides in the bits outside [bit_lo, bit_hi) moves with them): returns 0 if the result is in k0, 1 if in k1.
