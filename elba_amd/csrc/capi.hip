@@ -420,7 +420,7 @@ int elba_export_kmer_matrix(elba_ctx *ctx, elba_kmer_matrix_t *out)
         for (size_t i = 0; i <= M; ++i) out->rowptr[i] = rp[i];
         for (size_t z = 0; z < Z; ++z) {
             out->csc_row[z] = (int64_t)(csc[z] >> 32) + c.first_global_id_rows(); out->csc_val[z] = (uint32_t)csc[z];
-            out->csr_col[z] = (int64_t)(csr[z] >> 32); out->csr_val[z] = (uint32_t)csr[z] & (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu);      // (bits 30-31: SpGEMM hints)
+            out->csr_col[z] = (int64_t)(csr[z] >> 32); out->csr_val[z] = (uint32_t)csr[z] & (c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu));      // (above the position: SpGEMM hints, or column length and place of a dense matrix)
         }
         if (c.A_has_kmers) {
             out->kmers = host_alloc<uint64_t>(N);

@@ -162,6 +162,7 @@ struct Ctx {
     // counted as owned (calls without the mirror exchange between ranks).  They are a property of A, written when A is built (k_runs_emit /
     // k_csc_to_csr_words: every entry sees its whole column there anyway).  csr_hints false: both bits are zero / positions use all 32 bits.
     bool csr_hints = false, ov_hints_used = false, ov_rec16 = false;
+    bool csr_suffix = false;  // dense matrices: a_csr entries are kid << 32 | column length << 23 | own place in the column << 16 | pos, pairs owned by the smaller row (matrix.hip)
     DevBuf ov_sample;         // u32[256]: the rows a cold SpGEMM call computes first (spgemm.hip)
     int64_t A_products = 0;   // sum over the window's row entries of their column's length (what the SpGEMM reports as `products`)
     DevBuf prod_ctr;

@@ -24,18 +24,21 @@ __device__ __forceinline__ uint32_t entry_hint(const uint32_t *colptr, const uin
     return hints && L <= HINT_MAX_COL ? column_hint(csc + c0, L, i, win_lo, win_hi) : 0u;
 }
 
-__global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, const uint32_t *colptr, const uint64_t *csc, int64_t Z, uint64_t *row_keys, uint64_t *csr_vals,
-                                  bool hints, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr)
+__global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, uint64_t kid_mask, const uint32_t *colptr, const uint64_t *csc, int64_t Z, uint64_t *row_keys, uint64_t *csr_vals,
+                                  bool hints, bool suffix, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = z < Z;
     if (!in) z = Z - 1;                                      // (whole wavefronts reach the reduction inside entry_hint)
-    uint64_t kid = kid_keys[z] >> kid_shift;
+    uint64_t kid = (kid_keys[z] >> kid_shift) & kid_mask;
     uint64_t e = csc[z];
     const uint32_t h = entry_hint(colptr, csc, kid, in ? (uint32_t)(e >> 32) : 0xFFFFFFFFu, hints && in, in ? win_lo : 0u, in ? win_hi : 0u, prod_ctr);
     if (!in) return;
     row_keys[z] = e >> 32;                                   // read
-    csr_vals[z] = (kid << 32) | ((uint64_t)h << 30) | (e & 0xFFFFFFFFull);         // kid | hint | pos
+    if (suffix) {      // dense matrices (Ctx::csr_suffix): the entry knows its column's length and its own place in it — kid | L << 23 | idx << 16 | pos (16 bits)
+        const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0, idx = (uint32_t)z - c0;
+        csr_vals[z] = (kid << 32) | ((uint64_t)L << 23) | ((uint64_t)idx << 16) | (e & 0xFFFFull);
+    } else csr_vals[z] = (kid << 32) | ((uint64_t)h << 30) | (e & 0xFFFFFFFFull);         // kid | hint | pos
 }
 
 // CSR build with ONE word per entry when read, k-mer id, the two hint bits and the position fit 64 bits together:
@@ -566,7 +569,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     // stable sort by read: rows come out ordered by (kid, pos)
     c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_c.reserve((size_t)(Z + 1) * 8);
     const int mb = bits_for((uint64_t)(M > 0 ? M - 1 : 0)), nb = bits_for((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_for(maxpos);
-    const bool hints = pre ? c.pre_hints : (pb <= 30 && !c.plan && !getenv("ELBA_NO_HINTS"));
+    bool hints = pre ? c.pre_hints : (pb <= 30 && !c.plan && !getenv("ELBA_NO_HINTS"));
     const uint32_t wlo = (uint32_t)win_lo, whi = (uint32_t)(win_hi < 0 ? M : win_hi);
     c.prod_ctr.reserve(64 * 128);
     unsigned long long *prod_ctr = c.prod_ctr.as<unsigned long long>();
@@ -603,7 +606,13 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
             c.fbits = (uint32_t)fb;
         }
     }
-    if (mb + nb + pb + 2 <= 64 && !getenv("ELBA_CSR_PAIRS")) {
+    // Dense matrices (columns of more than 16 reads, e.g. UPPER = 35 on 40x low-error reads: every row owns pairs of every column, hundreds of
+    // products per surviving pair): pairs are owned by their SMALLER row and an entry's owned candidates are the column's entries behind its
+    // own — the row entries then carry the column's length and their own place in it, and the SpGEMM hands out exactly those candidates to
+    // its lanes (spgemm_direct.hpp, "suffix" path).  One GPU / whole-matrix window, positions below 2^16, the padded column store.
+    c.csr_suffix = c.use_ell && c.pos16 && c.max_col_nnz > 16 && !c.plan && win_lo == 0 && (win_hi < 0 || win_hi == M) && !getenv("ELBA_NO_PAY") && !getenv("ELBA_NO_SUFFIX");
+    if (c.csr_suffix) hints = false;
+    if (!c.csr_suffix && mb + nb + pb + 2 <= 64 && !getenv("ELBA_CSR_PAIRS")) {
         const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;
         uint64_t *w0 = have_words ? c.csr_words.as<uint64_t>() : c.ws_a.as<uint64_t>(), *w1 = c.ws_c.as<uint64_t>();
         ELBA_REQUIRE(!pre || have_words, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
@@ -616,14 +625,18 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         const uint64_t *sorted = where ? w1 : w0;
         hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
     } else {
-        ELBA_REQUIRE(!pre || !c.pre_words, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
+        ELBA_REQUIRE(!pre || !c.pre_words || c.csr_suffix, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
+        const bool kid_in_words = pre && c.pre_words;        // (k_runs_emit left sort keys, not column ids: the k-mer id is a field of the word)
+        const uint64_t *kk = kid_in_words ? c.csr_words.as<uint64_t>() : kid_keys;
+        const int ks = kid_in_words ? c.pre_pb + 2 : kid_shift;
+        const uint64_t km = kid_in_words ? (1ull << c.pre_nb) - 1 : ~0ull;
         c.ws_b.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
         uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
         if (Z > 0) {
             int64_t nbk = (Z + 255) / 256;
             if (pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 64 * 128, s));
-            hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, k0, v0,
-                               hints, wlo, whi, prod_ctr);
+            hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kk, ks, km, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, k0, v0,
+                               hints, c.csr_suffix, wlo, whi, prod_ctr);
         }
         int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, mb, c.ws_sort);
         const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;

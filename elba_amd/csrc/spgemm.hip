@@ -76,6 +76,7 @@ struct OvParams {
     // plan-free path (spgemm_direct.hpp): the two orientations of A and nothing else
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint64_t *a_ell; const uint32_t *a_colptr; const uint64_t *a_csc;
     uint32_t hint_mask, pos_mask;   // which hint bit of a row entry lets this call skip its column (0: none) / the position bits (Ctx::csr_hints)
+    uint32_t suffix;                // dense matrices (Ctx::csr_suffix): row entries carry column length and own place, the smaller row owns a pair
     uint32_t s_stride, lpc_log2, max_col;    // padded column stride in entries (a_ell); lanes per row entry 2^lpc_log2; longest column
     unsigned long long fb_enough;            // row entries behind the in-call partner / entry ratio at which it counts as settled (nobody touches the hot sums any more)
     const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_cscj; const uint32_t *a_roworder;
@@ -794,9 +795,11 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.s_stride = c.s_stride; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
     p.half = phase == 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
-    p.pos_mask = c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu;
+    p.pos_mask = c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu);
     p.hint_mask = !c.csr_hints ? 0u : (p.half == 2u ? 1u << 30 : (p.half == 1u ? 1u << 31 : 0u));
-    c.ov_hints_used = p.hint_mask != 0u;
+    ELBA_REQUIRE(!c.csr_suffix || (row_lo == 0 && row_hi == M), ELBA_ERR_INTERNAL, "a matrix built for the dense path has a row window");
+    p.suffix = c.csr_suffix && p.half == 1u ? 1u : 0u;      // (both triangles, ELBA_NO_SYMMETRY: the general path reads the same entries through pos_mask)
+    c.ov_hints_used = p.hint_mask != 0u || p.suffix != 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);

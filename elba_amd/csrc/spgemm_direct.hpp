@@ -28,9 +28,11 @@ constexpr uint32_t NOROW = 0xFFFFFFFFu, UNRESOLVED = 0xFFFFFFFEu;
 // even, the larger when it is odd: every row then owns about half of its partners whatever its place in the matrix (owned by the smaller
 // row alone, the first rows would own all of theirs and need tables twice the size).  A partner outside this context's row window is
 // always kept: its row lives on another rank.
-__device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t row_lo, uint32_t row_hi)
+__device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t row_lo, uint32_t row_hi, bool upper = false)
 {
-    return j < row_lo || j >= row_hi || ((((i ^ j) & 1u) != 0u) ? j < i : j > i);
+    // upper (dense matrices, OvParams::suffix): the smaller row owns the pair — the owned candidates of a row entry are then the entries of
+    // its column BEHIND its own (columns are in read order); tables are small there (a few hundred partners), balance does not matter
+    return j < row_lo || j >= row_hi || (upper ? j > i : ((((i ^ j) & 1u) != 0u) ? j < i : j > i));
 }
 
 template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2>
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             const uint64_t md = __ballot(j == i);
             pr += (uint32_t)__popcll(mv); dg += (uint32_t)__popcll(md);
             uint64_t mi = mv & ~md;
-            if (p.half) mi &= __ballot(owns_pair(i, j, p.half == 2u ? 0u : p.row_lo, p.half == 2u ? 0xFFFFFFFFu : p.row_hi));      // (2: the rule holds for every partner, wherever its row lives)
+            if (p.half) mi &= __ballot(owns_pair(i, j, p.half == 2u ? 0u : p.row_lo, p.half == 2u ? 0xFFFFFFFFu : p.row_hi, p.suffix != 0u));      // (2: the rule holds for every partner, wherever its row lives)
             if (mi == 0) return;
             const bool ins = (mi >> lane) & 1ull;
             if (GLOBAL) { if (ins) tab.insert(j, seq, full); return; }
@@ -208,7 +210,65 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             tail += (uint32_t)__popcll(mi);
             if (tail - head >= 64u) drain(64u);
         };
-        if (ell) {
+        if (PAY && p.suffix) {
+            // Dense matrices (matrix.hip: Ctx::csr_suffix).  A row entry carries its column's length L and its own place idx in it; the pairs
+            // it owns (smaller row owns) are exactly the column's entries idx + 1 .. L - 1.  A wavefront takes 64 consecutive row entries,
+            // prefix-sums their numbers of owned candidates and hands the candidates out to its lanes, 64 at a time: a lane finds its entry
+            // by a 6-step search over the prefix sums (LDS), fetches ONE 8-byte candidate and inserts it straight into the table — every lane
+            // a product (but for a read that holds the k-mer twice: the diagonal), no padding, no ownership test, no ring.  The general
+            // path spends ~150 wave-instructions per 28 products here (two padded columns per trip, half of their entries not owned).
+            constexpr uint32_t NWV = (uint32_t)BLOCK / 64u, UN = 2;
+            uint32_t *skid = qj + (PAY ? 384u : 256u), *spi = skid + 64, *spre = skid + 128;      // per wavefront: k-mer id, position | idx << 16, exclusive prefix (65 words)
+#pragma unroll 1
+            for (uint32_t cbase = (tid >> 6) * 64u; cbase < nnz; cbase += NWV * 64u) {
+                const bool valid = cbase + lane < nnz;
+                const uint2 en = valid ? csr2[rs + cbase + lane] : make_uint2(0u, 0u);
+                const uint32_t L = (en.x >> 23) & 127u, idx = (en.x >> 16) & 127u;
+                const uint32_t w = valid ? L - idx - 1u : 0u;
+                uint32_t inc = w;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+                const uint32_t T = __shfl(inc, 63, 64);
+                dg += (uint32_t)__popcll(__ballot(valid));                     // every entry's product with itself
+                __builtin_amdgcn_wave_barrier();                                // (the previous chunk's searches are done)
+                skid[lane] = en.y; spi[lane] = (en.x & 0xFFFFu) | idx << 16; spre[lane] = inc - w;
+                if (lane == 63) spre[64] = T;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (cbase == (tid >> 6) * 64u) { resolve_early(); } else if (cbase == (tid >> 6) * 64u + NWV * 64u) bounds_early();
+#pragma unroll 1
+                for (uint32_t base = 0; base < T; base += 64u * UN) {
+                    unsigned long long x[UN];
+                    uint32_t pq[UN], sq[UN];
+                    bool ok[UN];
+#pragma unroll
+                    for (int u = 0; u < (int)UN; ++u) {
+                        const uint32_t c = base + (uint32_t)u * 64u + lane;
+                        ok[u] = c < T;
+                        uint32_t lo = 0, hi = 64;                              // largest e with spre[e] <= c
+#pragma unroll
+                        for (int st = 0; st < 6; ++st) { const uint32_t mid = (lo + hi) >> 1; if (spre[mid] <= c) lo = mid; else hi = mid; }
+                        const uint32_t pi = spi[lo], sl = (pi >> 16) + 1u + (c - spre[lo]);
+                        pq[u] = pi & 0xFFFFu; sq[u] = ((cbase + lo) << fbits) | sl;
+                        x[u] = ok[u] ? p.a_ell[(unsigned long long)skid[lo] * stride + sl] : ~0ull;
+                    }
+#pragma unroll
+                    for (int u = 0; u < (int)UN; ++u) {
+                        const uint32_t j = (uint32_t)(x[u] >> 32), posT = (uint32_t)x[u];
+                        const bool dgn = ok[u] && j == i;                       // the read holds the k-mer again behind this entry: the pair of entries counts twice on the diagonal
+                        const uint64_t md = __ballot(dgn);
+                        if (md) dg += 2u * (uint32_t)__popcll(md);
+                        const unsigned long long v = ((unsigned long long)sq[u] << 32) | (pq[u] << 16) | posT;
+                        tab.insert_lds64(j, v, v, 1u, ok[u] && !dgn, full);
+                    }
+                    if (tab.abandoned()) break;
+                }
+                if (tab.abandoned()) {
+                    if (tid == 0) { const uint32_t done = cbase + 64u; misc[11] = done < nnz ? done : nnz; }
+                    break;
+                }
+            }
+        } else if (ell) {
             // Every wavefront walks the row in chunks of 64 consecutive entries (chunk c belongs to wave c mod #waves: one coalesced 512-byte
             // load) and COMPACTS them: an entry hinted "this row accumulates no pair of its column" (Ctx::csr_hints: 55 % of the entries of
             // 15 %-error reads) only counts its one diagonal product; the others join a 128-entry FIFO in LDS (ballot + popcount prefix).

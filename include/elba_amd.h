@@ -201,7 +201,9 @@ typedef struct {
     int64_t M, N, Z, Y;
     const void *a_rowptr;  /* u32[M+1] */
     const void *a_csr;     /* u64[Z]: kid<<32 | hint<<30 | pos: positions below 2^30 (else hint = 0 and pos takes 32 bits); hint = two ownership bits
-                              the SpGEMM reads (an entry whose row accumulates no pair of its column skips the column) */
+                              the SpGEMM reads (an entry whose row accumulates no pair of its column skips the column).  Dense matrices (a column longer than 16
+                              entries, positions below 2^16): kid<<32 | column length<<23 | the entry's place in its column<<16 | pos.
+                              elba_export_kmer_matrix returns plain positions */
     const void *a_colptr;  /* u32[N+1] */
     const void *a_csc;     /* u64[Z]: read<<32 | pos */
     const void *b_rowptr;  /* i64[M+1] */
