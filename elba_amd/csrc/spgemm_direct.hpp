@@ -217,7 +217,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             // by a 6-step search over the prefix sums (LDS), fetches ONE 8-byte candidate and inserts it straight into the table — every lane
             // a product (but for a read that holds the k-mer twice: the diagonal), no padding, no ownership test, no ring.  The general
             // path spends ~150 wave-instructions per 28 products here (two padded columns per trip, half of their entries not owned).
-            constexpr uint32_t NWV = (uint32_t)BLOCK / 64u, UN = 2;
+            constexpr uint32_t NWV = (uint32_t)BLOCK / 64u, UN = 4;
             uint32_t *skid = qj + (PAY ? 384u : 256u), *spi = skid + 64, *spre = skid + 128;      // per wavefront: k-mer id, position | idx << 16, exclusive prefix (65 words)
 #pragma unroll 1
             for (uint32_t cbase = (tid >> 6) * 64u; cbase < nnz; cbase += NWV * 64u) {
