@@ -820,6 +820,8 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     if (!attr_done) {
         const int lds = 160 * 1024;
 #define ELBA_ATTR(B, P, D) ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<B, false, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_ATTR(512, true, 1); ELBA_ATTR(512, true, 2); ELBA_ATTR(512, true, 4); ELBA_ATTR(1024, true, 1); ELBA_ATTR(1024, true, 2); ELBA_ATTR(1024, true, 4);
         ELBA_ATTR(256, false, 1); ELBA_ATTR(256, false, 2); ELBA_ATTR(256, false, 4);
         ELBA_ATTR(512, false, 1); ELBA_ATTR(512, false, 2); ELBA_ATTR(512, false, 4); ELBA_ATTR(1024, false, 1); ELBA_ATTR(1024, false, 2); ELBA_ATTR(1024, false, 4);
@@ -877,8 +879,10 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         else hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 2>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));                    \
     } while (0)
             const int dk = getenv("ELBA_DK") ? atoi(getenv("ELBA_DK")) : 2;      // rounds of DK trips in flight (tuning knob)
+#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) hipLaunchKernelGGL((k_spgemm_direct<B, false, true, 2, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp))
             if (sampling) {
-                if (pay) ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
+                if (p.suffix) ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
+                else if (pay) ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
                 else ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 4096 + X(1024, false), 3, 12u, 1u);
                 p.use_feedback = 0;      // the ratio is measured: nothing is forwarded on a prediction any more, nobody touches the hot sums
             }
@@ -887,7 +891,12 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
                 if (nb > cus * 4) nb = cus * 4;
                 hipLaunchKernelGGL(k_classify_direct, dim3(nb), dim3(256), 0, s, p, 0);
             }
-            if (pay) {
+            if (p.suffix) {      // (dense matrices: the LDS tiers with 64-bit accumulators run the dense path; p.suffix implies pay)
+                ELBA_DTIER(0, ELBA_LAUNCH_S(128, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u, 0u));
+                ELBA_DTIER(1, ELBA_LAUNCH_S(256, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u, 0u));
+                ELBA_DTIER(2, ELBA_LAUNCH_S(512, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u, 0u));
+                ELBA_DTIER(3, ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 0u));
+            } else if (pay) {
                 ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, true, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u, 0u));
                 ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, true, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u, 0u));
                 ELBA_DTIER(2, ELBA_LAUNCH_D(512, false, true, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u, 0u));
@@ -900,6 +909,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
             }
             ELBA_DTIER(4, ELBA_LAUNCH_D(256, false, false, cus, (size_t)18 * 8192 + X(256, false), 4, 13u, 0u));      // (4 wavefronts: 8192 slots + their rings fill the 160 KB)
             ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, X(256, false), NUM_LDS_TIERS, 0u, 0u));
+#undef ELBA_LAUNCH_S
 #undef ELBA_LAUNCH_D
 #undef ELBA_DTIER
             ELBA_HIP(hipGetLastError());

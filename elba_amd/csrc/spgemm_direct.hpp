@@ -35,7 +35,8 @@ __device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t row_l
     return j < row_lo || j >= row_hi || (upper ? j > i : ((((i ^ j) & 1u) != 0u) ? j < i : j > i));
 }
 
-template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2>
+// SUFFIX: the dense path (OvParams::suffix) instead of the general one — an instantiation of its own, so that the general kernel does not carry its registers
+template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2, bool SUFFIX = false>
 __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits, uint32_t sample)
 {
     static_assert(!PAY || !GLOBAL, "payload accumulators: LDS tiers only");
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             const uint64_t md = __ballot(j == i);
             pr += (uint32_t)__popcll(mv); dg += (uint32_t)__popcll(md);
             uint64_t mi = mv & ~md;
-            if (p.half) mi &= __ballot(owns_pair(i, j, p.half == 2u ? 0u : p.row_lo, p.half == 2u ? 0xFFFFFFFFu : p.row_hi, p.suffix != 0u));      // (2: the rule holds for every partner, wherever its row lives)
+            if (p.half) mi &= __ballot(owns_pair(i, j, p.half == 2u ? 0u : p.row_lo, p.half == 2u ? 0xFFFFFFFFu : p.row_hi, !PAY && p.suffix != 0u));      // (dense matrices reach this path on the tiers without 64-bit accumulators only)      // (2: the rule holds for every partner, wherever its row lives)
             if (mi == 0) return;
             const bool ins = (mi >> lane) & 1ull;
             if (GLOBAL) { if (ins) tab.insert(j, seq, full); return; }
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             tail += (uint32_t)__popcll(mi);
             if (tail - head >= 64u) drain(64u);
         };
-        if (PAY && p.suffix) {
+        if (SUFFIX) {
             // Dense matrices (matrix.hip: Ctx::csr_suffix).  A row entry carries its column's length L and its own place idx in it; the pairs
             // it owns (smaller row owns) are exactly the column's entries idx + 1 .. L - 1.  A wavefront takes 64 consecutive row entries,
             // prefix-sums their numbers of owned candidates and hands the candidates out to its lanes, 64 at a time: a lane finds its entry
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                     break;
                 }
             }
-        } else if (ell) {
+        } else if (!SUFFIX && ell) {
             // Every wavefront walks the row in chunks of 64 consecutive entries (chunk c belongs to wave c mod #waves: one coalesced 512-byte
             // load) and COMPACTS them: an entry hinted "this row accumulates no pair of its column" (Ctx::csr_hints: 55 % of the entries of
             // 15 %-error reads) only counts its one diagonal product; the others join a 128-entry FIFO in LDS (ballot + popcount prefix).
@@ -350,7 +351,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
 #pragma unroll
                 for (int u = 0; u < TR; ++u) { x_cur[u] = x_nxt[u]; pq_cur[u] = pq_nxt[u]; rk_cur[u] = rk_nxt[u]; }
             }
-        } else {
+        } else if (!SUFFIX) {
 #pragma unroll 1
             for (uint32_t t0 = 0; t0 < nnz; t0 += EPT) {
                 const uint32_t r = t0 + grp;
