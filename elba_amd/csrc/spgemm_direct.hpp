@@ -24,6 +24,19 @@ enum : uint32_t { D_NEXT = 20, D_FB0 = 16, W_ACC_P = 54 /*u64*/, W_END2 = 56 };
 constexpr uint32_t RING = 128;      // per-wavefront product ring (entries): < 64 left over + <= 64 new ones per candidate slot
 constexpr uint32_t NOROW = 0xFFFFFFFFu, UNRESOLVED = 0xFFFFFFFEu;
 
+// inclusive maximum over the lanes 0 .. own of a wavefront, values >= 0: six DPP steps, no LDS round trip
+__device__ __forceinline__ uint32_t wave_max_scan(uint32_t v)
+{
+    int x = (int)v, t;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false); x = t > x ? t : x;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false); x = t > x ? t : x;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false); x = t > x ? t : x;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false); x = t > x ? t : x;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false); x = t > x ? t : x;
+    t = __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false); x = t > x ? t : x;
+    return (uint32_t)x;
+}
+
 // `half`: which of the two rows of a pair {i, j} accumulates it (the other row receives the mirrored entry).  The smaller row when i + j is
 // even, the larger when it is odd: every row then owns about half of its partners whatever its place in the matrix (owned by the smaller
 // row alone, the first rows would own all of theirs and need tables twice the size).  A partner outside this context's row window is
@@ -219,7 +232,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             // a product (but for a read that holds the k-mer twice: the diagonal), no padding, no ownership test, no ring.  The general
             // path spends ~150 wave-instructions per 28 products here (two padded columns per trip, half of their entries not owned).
             constexpr uint32_t NWV = (uint32_t)BLOCK / 64u, UN = 4;
-            uint32_t *skid = qj + (PAY ? 384u : 256u), *spi = skid + 64, *spre = skid + 128;      // per wavefront: k-mer id, position | idx << 16, exclusive prefix (65 words)
+            static_assert(UN % 2 == 0, "windows of two batches");
+            uint32_t *skid = qj + (PAY ? 384u : 256u), *spi = skid + 64, *spre = skid + 128, *sown = skid + 200;      // per wavefront: k-mer id, position | idx << 16, exclusive prefix (65 words), window marks (128)
 #pragma unroll 1
             for (uint32_t cbase = (tid >> 6) * 64u; cbase < nnz; cbase += NWV * 64u) {
                 const bool valid = cbase + lane < nnz;
@@ -242,16 +256,36 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                     unsigned long long x[UN];
                     uint32_t pq[UN], sq[UN];
                     bool ok[UN];
+                    // candidate -> entry, 128 candidates at a time: every entry that starts inside the window (or covers its first place) marks
+                    // its first place with its number, a DPP maximum scan spreads the marks to the right — one LDS round trip where a binary
+                    // search over the prefix sums made six dependent ones
 #pragma unroll
-                    for (int u = 0; u < (int)UN; ++u) {
-                        const uint32_t c = base + (uint32_t)u * 64u + lane;
-                        ok[u] = c < T;
-                        uint32_t lo = 0, hi = 64;                              // largest e with spre[e] <= c
+                    for (int hw = 0; hw < (int)UN / 2; ++hw) {
+                        const uint32_t B = base + (uint32_t)hw * 128u;
+                        sown[lane] = 0; sown[lane + 64u] = 0;
+                        __builtin_amdgcn_wave_barrier();
+                        if (w != 0u) {
+                            const uint32_t pre = inc - w;
+                            if (pre >= B && pre - B < 128u) sown[pre - B] = lane + 1u;
+                            else if (pre < B && inc > B) sown[0] = lane + 1u;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const uint32_t m0 = wave_max_scan(sown[lane]);
+                        const uint32_t carry = (uint32_t)__builtin_amdgcn_readlane((int)m0, 63);
+                        uint32_t m1 = wave_max_scan(sown[lane + 64u]);
+                        m1 = m1 > carry ? m1 : carry;
 #pragma unroll
-                        for (int st = 0; st < 6; ++st) { const uint32_t mid = (lo + hi) >> 1; if (spre[mid] <= c) lo = mid; else hi = mid; }
-                        const uint32_t pi = spi[lo], sl = (pi >> 16) + 1u + (c - spre[lo]);
-                        pq[u] = pi & 0xFFFFu; sq[u] = ((cbase + lo) << fbits) | sl;
-                        x[u] = ok[u] ? p.a_ell[(unsigned long long)skid[lo] * stride + sl] : ~0ull;
+                        for (int v2 = 0; v2 < 2; ++v2) {
+                            const int u = 2 * hw + v2;
+                            const uint32_t c = B + (uint32_t)v2 * 64u + lane;
+                            ok[u] = c < T;
+                            const uint32_t en1 = v2 ? m1 : m0, lo = ok[u] ? en1 - 1u : 0u;
+                            const uint32_t pi = spi[lo], sl = (pi >> 16) + 1u + (c - spre[lo]);
+                            pq[u] = pi & 0xFFFFu; sq[u] = ((cbase + lo) << fbits) | sl;
+                            x[u] = ok[u] ? p.a_ell[(unsigned long long)skid[lo] * stride + sl] : ~0ull;
+                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
 #pragma unroll
                     for (int u = 0; u < (int)UN; ++u) {
