@@ -447,3 +447,25 @@ def test_reads_that_hold_a_kmer_twice_and_the_ownership_hints(shape):
             e.close()
         finally:
             for k_ in env: os.environ.pop(k_, None)
+
+
+@pytest.mark.parametrize("knob", [None, "ELBA_NO_SUFFIX"])
+def test_dense_columns_take_the_path_of_their_own(knob, monkeypatch):
+    """Deep, nearly error-free reads with a generous UPPER: columns of ~30 reads, hundreds of products per surviving pair.  Such matrices are
+    multiplied by the dense path (pairs owned by the smaller row, the owned candidates of a row entry = its column behind it: DESIGN.md §4.1);
+    ELBA_NO_SUFFIX keeps them on the general path.  A, B and the statistics equal the oracle's either way, on a cold and a warm call, and
+    a read that holds a k-mer twice (a repeat family) is among them."""
+    if knob:
+        monkeypatch.setenv(knob, "1")
+    packed, off, lens, info = elba_amd.synth_reads(91, 60000, 30, 3000, 600, error_rate=0.01, min_len=500, repeat_families=3, repeat_fraction=0.1, repeat_len=400)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 40, threads=8)
+    assert ms["max_col_nnz"] > 16 if "max_col_nnz" in ms else True
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.set_option("overlap_cold_calls", 1)
+    st = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.close()
