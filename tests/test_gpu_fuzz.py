@@ -63,3 +63,31 @@ def test_random_read_set_against_oracle(case):
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
     e.close()
+
+
+@pytest.mark.parametrize("M,ncol,L", [(6000, 20000, 40), (20000, 60000, 60)])
+def test_dense_matrix_with_thousands_of_partners_per_row(M, ncol, L):
+    """Columns of L random reads out of M: every row meets most other rows.  The dense path (smaller row owns) starts on the small table tiers,
+    abandons and escalates; the 8192-slot tier and the HBM tables run the general kernel under the same ownership rule.  Equal to the
+    oracle, cold and warm."""
+    rng = np.random.default_rng(M)
+    rows, cols, vals = [], [], []
+    for c in range(ncol):
+        r = np.sort(rng.choice(M, L, replace=False))
+        rows.append(r); cols.append(np.full(L, c)); vals.append(rng.integers(0, 60000, L))
+    rows, cols, vals = np.concatenate(rows), np.concatenate(cols), np.concatenate(vals).astype(np.uint32)
+    o = po.Oracle(17, 2, 64)
+    o.set_triples(M, ncol, rows, cols, vals)
+    o.spgemm(8)
+    oB = o.B()
+    e = elba_amd.Engine(17, 2, 64)
+    e.set_kmer_matrix(M, ncol, rows, cols, vals)
+    st = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), oB)
+    gu.assert_stats_equal(st, o)
+    assert st["rows_escalated"] > 0 or st["rows_global"] > 0
+    e.set_option("overlap_cold_calls", 1)
+    st = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), oB)
+    gu.assert_stats_equal(st, o)
+    e.close()
