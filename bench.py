@@ -10,7 +10,7 @@ matrix (spgemm)", src/main.cpp:280-282 around src/SharedSeeds.cpp:4-10).  There 
 no descriptors, no row order, no product counts are built with A (elba_amd/csrc/spgemm_direct.hpp).  What A's rows do carry, from the
 k-mer stage that builds them (timed in `kmer_stage`, at no measurable cost: every entry sees its whole column there anyway), is two
 hint bits per entry — "under the parity rule that assigns every pair of rows to one of them, this row accumulates no pair of this
-column": such an entry (55 % of them on this workload) does not fetch its column.  Every timed step runs COLD
+column": such an entry (40 % of them on this workload) does not fetch its column.  Every timed step runs COLD
 (elba_set_option "overlap_cold_calls"): it forgets what earlier calls on the same matrix learned (the distinct-partner ratio that picks
 the starting table tiers, which tiers and column sorts received rows), so that each step is what a caller that multiplies a matrix once
 pays, as ELBA does.  Buffers stay allocated.  The steady state (hints kept between calls) is reported as a secondary key.

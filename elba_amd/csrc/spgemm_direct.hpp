@@ -305,7 +305,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             }
         } else if (!SUFFIX && ell) {
             // Every wavefront walks the row in chunks of 64 consecutive entries (chunk c belongs to wave c mod #waves: one coalesced 512-byte
-            // load) and COMPACTS them: an entry hinted "this row accumulates no pair of its column" (Ctx::csr_hints: 55 % of the entries of
+            // load) and COMPACTS them: an entry hinted "this row accumulates no pair of its column" (Ctx::csr_hints: 40 % of the entries of
             // 15 %-error reads) only counts its one diagonal product; the others join a 128-entry FIFO in LDS (ballot + popcount prefix).
             // Groups of LPC lanes then take entries off the FIFO, TR wave-trips per iteration, and fetch their columns — every lane of every
             // gather instruction fetches a column that is needed.  Two iterations are in flight: an iteration (1) consumes the column words
