@@ -856,6 +856,7 @@ void stage_count_kmers(Ctx &c)
         int ib = 1;
         while (ib < 63 && (I >> ib)) ++ib;
         int drop = 2 * k + ib > 64 ? 2 * k + ib - 64 : 0;
+        if (getenv("ELBA_KMER_DROP")) { const int want = atoi(getenv("ELBA_KMER_DROP")); if (want > drop && want <= 3 && want < ib) drop = want; }      // (test hook: small inputs through the dropped-index-bit path)
         const bool packed_words = drop <= 3 && !getenv("ELBA_KMER_PAIRS");
         if (!packed_words) { ib = 0; drop = 0; }
         const int pb = ib - drop;                  // payload bits below the value

@@ -469,3 +469,23 @@ def test_dense_columns_take_the_path_of_their_own(knob, monkeypatch):
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
     e.close()
+
+
+@pytest.mark.parametrize("drop", [1, 2, 3])
+def test_dropped_index_bits_are_recovered_from_the_reads(drop, monkeypatch):
+    """A k-mer instance travels through the counting sort as ONE word, value << pb | (instance index >> drop); beyond 2^30 instances at
+    k = 17 the lowest index bits do not fit and the kept entries find their instance among the 2^drop candidates by recomputing the
+    candidates' k-mers (k_runs_emit).  ELBA_KMER_DROP forces that path on a small input, low-complexity reads included (neighbouring
+    positions that hold the SAME k-mer: the dup-th candidate is the right one)."""
+    monkeypatch.setenv("ELBA_KMER_DROP", str(drop))
+    reads, _ = synth.make_reads(77, 60000, 14, 2500, 700, error=0.08, min_len=100)
+    # a few homopolymer / dinucleotide reads: runs of equal canonical k-mers at consecutive positions
+    extra = [b"A" * 300, b"AC" * 200, b"T" * 150 + b"G" * 150, b"ACG" * 120] * 3
+    seqs = list(reads) + extra
+    np.random.default_rng(3).shuffle(seqs)
+    packed, off, lens = po.pack_reads(seqs)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 12)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 12, threads=8)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
