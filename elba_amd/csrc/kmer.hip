@@ -843,8 +843,6 @@ void stage_count_kmers(Ctx &c)
     }
     if (c.kmers_sorted) {
         // ---- sort-based: see the header of this file ----
-        c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_b.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8); c.ws_d.reserve((size_t)(I + 2) * 8);
-        c.ws_e.reserve((size_t)(I + 2) * 4); c.ws_f.reserve((size_t)(I + 2) * 8);        // flags | run ids, head positions
         c.t_total.start(s);
         c.t_a.start(s);
         EnumParams e = make_enum(c);
@@ -860,6 +858,9 @@ void stage_count_kmers(Ctx &c)
         const bool packed_words = drop <= 3 && !getenv("ELBA_KMER_PAIRS");
         if (!packed_words) { ib = 0; drop = 0; }
         const int pb = ib - drop;                  // payload bits below the value
+        // workspaces: the words and their ping-pong copy; (value, payload) pairs need two more arrays (the other buffers are sized where they are used)
+        c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8);
+        if (!packed_words) { c.ws_b.reserve((size_t)(I + 2) * 8); c.ws_d.reserve((size_t)(I + 2) * 8); }
         int where = 0;
         if (packed_words) {
             int sh0 = 0, b0 = 0, tile = 0;
