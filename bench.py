@@ -38,7 +38,8 @@ WORKLOADS = {
     "200k-long-reads": dict(genome=66_700_000, depth=30.0, avg_len=10000.0, sd_len=1500.0, min_len=1000, error=0.15, k=17, lower=2, upper=8, seed=2),
     "ecsample30x-like": dict(genome=4_640_000, depth=30.0, avg_len=8240.0, sd_len=2000.0, min_len=1000, error=0.15, k=17, lower=2, upper=8, seed=1),
     "plumbing-135": dict(genome=100_000, depth=13.5, avg_len=10000.0, sd_len=1000.0, min_len=1000, error=0.0, k=17, lower=2, upper=8, seed=313),
-    # profiling cases (single GPU; not the driver's line): BASELINE configs[3] at half the genome and configs[4] at 1/25 of it
+    # profiling cases (single GPU; not the driver's line): BASELINE configs[3] at half the genome (the whole set — 4.0 G instances — runs too:
+    # tests/test_gpu_configs.py) and configs[4] at 1/25 of it
     "hifi-half": dict(genome=50_000_000, depth=40.0, avg_len=15000.0, sd_len=2000.0, min_len=1000, error=0.005, k=17, lower=2, upper=4, seed=3),
     "dense-repeats-25th": dict(genome=20_000_000, depth=40.0, avg_len=10000.0, sd_len=1000.0, min_len=1000, error=0.01, k=17, lower=2, upper=35, seed=4, repeats=(20, 0.05, 5000)),
 }

@@ -8,8 +8,8 @@ At these sizes the oracle cannot rerun the whole pipeline in seconds, so every c
     bit — pattern, numshared and both seeds.  (The sub-matrix contains every column of a sampled row completely, so the oracle's fold
     over it is that row's fold over all of A.)
   config 3  200 100 reads x 10 kb, 66.7 Mb genome, 30x, 15 % error, U = 8: as written, whole, on one GPU
-  config 4  C. elegans-HiFi-like, 0.5 % error, U = 4: half the genome (50 Mb, 133 k reads of 15 kb, 2.0 G k-mer instances) — the whole set
-            has 4 G instances, past one context's 32-bit instance index: the configuration names 8 GPUs for it
+  config 4  C. elegans-HiFi-like, 100 Mb genome, 40x, 0.5 % error, U = 4: as written, whole, on one GPU (266 666 reads of 15 kb, 4.0 G k-mer
+            instances: just inside one context's 32-bit instance index, two index bits dropped from the sort words and recovered)
   config 5  20 repeat families, 1 % error, U = 35: 1/25 of the genome (80 k reads, 10.8 G products): the dense / spill stress at a size one GPU holds
 """
 import os
@@ -24,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 CONFIGS = {
     "config3-200k-long-reads": dict(seed=2, genome=66_700_000, depth=30.0, avg=10000.0, sd=1500.0, err=0.15, min_len=1000, k=17, L=2, U=8, rep=(0, 0.0, 0), nsample=200),
-    "config4-celegans-hifi-half": dict(seed=3, genome=50_000_000, depth=40.0, avg=15000.0, sd=2000.0, err=0.005, min_len=1000, k=17, L=2, U=4, rep=(0, 0.0, 0), nsample=300),
+    "config4-celegans-hifi": dict(seed=3, genome=100_000_000, depth=40.0, avg=15000.0, sd=2000.0, err=0.005, min_len=1000, k=17, L=2, U=4, rep=(0, 0.0, 0), nsample=300),
     "config5-dense-repeats-25th": dict(seed=4, genome=20_000_000, depth=40.0, avg=10000.0, sd=1000.0, err=0.01, min_len=1000, k=17, L=2, U=35, rep=(20, 0.05, 5000), nsample=60),
 }
 
