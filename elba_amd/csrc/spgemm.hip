@@ -822,6 +822,8 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
 #define ELBA_ATTR(B, P, D) ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<B, false, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_ATTR(512, true, 1); ELBA_ATTR(512, true, 2); ELBA_ATTR(512, true, 4); ELBA_ATTR(1024, true, 1); ELBA_ATTR(1024, true, 2); ELBA_ATTR(1024, true, 4);
         ELBA_ATTR(256, false, 1); ELBA_ATTR(256, false, 2); ELBA_ATTR(256, false, 4);
         ELBA_ATTR(512, false, 1); ELBA_ATTR(512, false, 2); ELBA_ATTR(512, false, 4); ELBA_ATTR(1024, false, 1); ELBA_ATTR(1024, false, 2); ELBA_ATTR(1024, false, 4);
@@ -879,7 +881,9 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         else hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 2>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));                    \
     } while (0)
             const int dk = getenv("ELBA_DK") ? atoi(getenv("ELBA_DK")) : 2;      // rounds of DK trips in flight (tuning knob)
-#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) hipLaunchKernelGGL((k_spgemm_direct<B, false, true, 2, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp))
+// (dense path: 32-bit accumulators + seed look-ups for the few survivors — 18.0 vs 19.1 ms on config 5 at 1/25; ELBA_SUFFIX64: the 64-bit ones)
+#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) do { if (!getenv("ELBA_SUFFIX64")) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3(grid), dim3(B), (size_t)18 * (1u << (tb)) + X(B, false), s, p, (tier), (tb), (smp)); \
+                                                          else hipLaunchKernelGGL((k_spgemm_direct<B, false, true, 2, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp)); } while (0)
             if (sampling) {
                 if (p.suffix) ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
                 else if (pay) ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);

@@ -293,8 +293,8 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                         const bool dgn = ok[u] && j == i;                       // the read holds the k-mer again behind this entry: the pair of entries counts twice on the diagonal
                         const uint64_t md = __ballot(dgn);
                         if (md) dg += 2u * (uint32_t)__popcll(md);
-                        const unsigned long long v = ((unsigned long long)sq[u] << 32) | (pq[u] << 16) | posT;
-                        tab.insert_lds64(j, v, v, 1u, ok[u] && !dgn, full);
+                        if (PAY) { const unsigned long long v = ((unsigned long long)sq[u] << 32) | (pq[u] << 16) | posT; tab.insert_lds64(j, v, v, 1u, ok[u] && !dgn, full); }
+                        else tab.insert_lds(j, sq[u], sq[u], 1u, ok[u] && !dgn, full);
                     }
                     if (tab.abandoned()) break;
                 }
