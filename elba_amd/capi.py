@@ -87,7 +87,8 @@ class KmerMatrix(C.Structure):
 class DeviceView(C.Structure):
     _fields_ = [("M", C.c_int64), ("N", C.c_int64), ("Z", C.c_int64), ("Y", C.c_int64),
                 ("a_rowptr", C.c_void_p), ("a_csr", C.c_void_p), ("a_colptr", C.c_void_p), ("a_csc", C.c_void_p),
-                ("b_rowptr", C.c_void_p), ("b_col", C.c_void_p), ("b_val", C.c_void_p), ("stream", C.c_void_p)]
+                ("b_rowptr", C.c_void_p), ("b_col", C.c_void_p), ("b_val", C.c_void_p), ("stream", C.c_void_p),
+                ("a_csr_format", C.c_uint32), ("a_csr_pos_mask", C.c_uint32)]
 
 
 class SynthCfg(C.Structure):
@@ -210,7 +211,7 @@ class Engine:
     """One context on one GPU.  Method names follow the reference's free functions (include/KmerOps.hpp:24-31,
     include/SharedSeeds.hpp:98-99); each is a single C-ABI call."""
 
-    def __init__(self, k, lower, upper, device=0, workspace_hint_bytes=0, flags=0, timing_stride=0):
+    def __init__(self, k, lower, upper, device=0, workspace_hint_bytes=0, flags=0, timing_stride=0, options=None):
         self.L = load_library()
         self.h = C.c_void_p()
         cfg = Cfg(k, lower, upper, device, workspace_hint_bytes, flags, timing_stride)
@@ -219,6 +220,8 @@ class Engine:
             self.h = C.c_void_p()
             raise ElbaError(rc, self.L.elba_strerror(rc).decode())
         self.k, self.lower, self.upper, self.device = k, lower, upper, device
+        for name, value in (options or {}).items():
+            self.set_option(name, value)
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:

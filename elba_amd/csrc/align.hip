@@ -483,8 +483,8 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
     p.b_rowptr = c.b_rowptr.as<int64_t>(); p.b_col = c.b_col.as<uint32_t>(); p.b_val = c.b_val.as<elba_seed_t>();
     p.M = (uint32_t)M; p.row_lo = shard ? (uint32_t)c.row_lo : 0u; p.row_hi = shard ? (uint32_t)c.row_hi : (uint32_t)M; p.share = shard ? 1u : 0u;
     p.k = c.cfg.k; p.mat = mat; p.mis = mis; p.gap = gap; p.dropoff = dropoff;
-    p.wide_hint = getenv("ELBA_ALN_WIDE_HINT") ? atoi(getenv("ELBA_ALN_WIDE_HINT")) : 6;
-    p.long_hint = getenv("ELBA_ALN_LONG_HINT") ? atoi(getenv("ELBA_ALN_LONG_HINT")) : 6000;
+    p.wide_hint = c.opt.aln_wide_hint;
+    p.long_hint = c.opt.aln_long_hint;
     c.t_total.start(s);
     const int64_t nrows = (int64_t)p.row_hi - (int64_t)p.row_lo;
     c.aln_cnt.reserve((size_t)(nrows + 2) * 4); c.aln_ptr.reserve((size_t)(nrows + 2) * 8); c.aln_ctr.reserve(256);
@@ -519,9 +519,15 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
         c.t_a.start(s);
         // persistent wavefronts pulling extensions from a queue: durations range from a handful of antidiagonals to tens of thousands.
         // Tiers of 64 / 128 / 256 / 512 columns per wavefront: an extension whose band outgrows a tier is redone from its seed on the next;
-        // beyond 511 columns the strided kernel takes over.  (ELBA_ALN_TIERS="1,2,4,8" selects the instantiations, for A/B runs.)
+        // beyond 511 columns the strided kernel takes over.  (option "aln_tiers" selects the instantiations, for A/B runs.)
         int tiers[4] = {1, 2, 4, 8}, ntiers = 4;
-        if (const char *e = getenv("ELBA_ALN_TIERS")) { ntiers = 0; for (const char *q = e; *q && ntiers < 4; ++q) if (*q == '1' || *q == '2' || *q == '4' || *q == '8') tiers[ntiers++] = *q - '0'; if (ntiers == 0) { tiers[0] = 1; ntiers = 1; } }
+        if (c.opt.aln_tiers > 0) {      // decimal digits, first tier first: 1248 = all four, 24 = the 128- and 256-column tiers only
+            int digits[8], nd = 0;
+            for (int64_t v = c.opt.aln_tiers; v > 0 && nd < 8; v /= 10) digits[nd++] = (int)(v % 10);
+            ntiers = 0;
+            for (int q = nd - 1; q >= 0 && ntiers < 4; --q) if (digits[q] == 1 || digits[q] == 2 || digits[q] == 4 || digits[q] == 8) tiers[ntiers++] = digits[q];
+            if (ntiers == 0) { tiers[0] = 1; ntiers = 1; }
+        }
         const int64_t resident = (int64_t)c.num_cus * 8;
         unsigned int nwork = (unsigned int)(2 * K);
         const uint32_t *in_list = nullptr; const unsigned int *in_count = nullptr;
@@ -535,7 +541,7 @@ void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff)
             else hipLaunchKernelGGL((k_xdrop_wave<8>), dim3((unsigned)nb), dim3(64 * ALN_WAVES), 0, s, p, in_list, in_count, ctr + t, out_list, out_count);
             ELBA_HIP(hipMemcpyAsync(&nwork, out_count, 4, hipMemcpyDeviceToHost, s));
             ELBA_HIP(hipStreamSynchronize(s));
-            if (getenv("ELBA_TRACE")) {
+            if (c.opt.trace) {
                 unsigned long long wasted = 0;
                 ELBA_HIP(hipMemcpy(&wasted, p.cells + 1, 8, hipMemcpyDeviceToHost));
                 fprintf(stderr, "[elba] x-drop tier %d columns/lane: %u extensions left, %llu cells abandoned so far\n", tiers[t], nwork, wasted);

@@ -462,7 +462,9 @@ int elba_get_device_view(elba_ctx *ctx, elba_device_view *v)
         ELBA_REQUIRE(v, ELBA_ERR_INVALID_ARG, "get_device_view: null output");
         memset(v, 0, sizeof(*v));
         v->stream = (void *)c.stream;
-        if (c.have_A) { v->M = c.M; v->N = c.N; v->Z = c.Z; v->a_rowptr = c.a_rowptr.p; v->a_csr = c.a_csr.p; v->a_colptr = c.a_colptr.p; v->a_csc = c.a_csc.p; }
+        if (c.have_A) { v->M = c.M; v->N = c.N; v->Z = c.Z; v->a_rowptr = c.a_rowptr.p; v->a_csr = c.a_csr.p; v->a_colptr = c.a_colptr.p; v->a_csc = c.a_csc.p;
+                        v->a_csr_format = c.csr_suffix ? ELBA_CSR_DENSE : (c.csr_hints ? ELBA_CSR_HINTS : ELBA_CSR_PLAIN);
+                        v->a_csr_pos_mask = c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu); }
         if (c.have_B) { v->Y = c.Y; v->b_rowptr = c.b_rowptr.p; v->b_col = c.b_col.p; v->b_val = c.b_val.p; }
     });
 }
@@ -471,7 +473,16 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
 {
     return guarded(ctx, [&](Ctx &c) {
         ELBA_REQUIRE(name, ELBA_ERR_INVALID_ARG, "set_option: null name");
-        if (!strcmp(name, "overlap_cold_calls")) c.cold_calls = value != 0;
+        struct { const char *n; bool *b; } flags[] = {
+            {"overlap_cold_calls", &c.cold_calls}, {"no_symmetry", &c.opt.no_symmetry}, {"no_ell", &c.opt.no_ell}, {"no_pay", &c.opt.no_pay}, {"mir32", &c.opt.mir32},
+            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_suffix", &c.opt.no_suffix}, {"suffix64", &c.opt.suffix64}, {"kmer_pairs", &c.opt.kmer_pairs},
+            {"kmer_unfused", &c.opt.kmer_unfused}, {"kmer_no_msd", &c.opt.kmer_no_msd}, {"csr_pairs", &c.opt.csr_pairs}, {"emit_plain", &c.opt.emit_plain}, {"trace", &c.opt.trace}};
+        for (auto &f : flags) if (!strcmp(name, f.n)) { *f.b = value != 0; return; }
+        if (!strcmp(name, "kmer_drop")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: kmer_drop is 0..3"); c.opt.kmer_drop = (int)value; }
+        else if (!strcmp(name, "dk")) { ELBA_REQUIRE(value == 1 || value == 2 || value == 4, ELBA_ERR_INVALID_ARG, "set_option: dk is 1, 2 or 4"); c.opt.dk = (int)value; }
+        else if (!strcmp(name, "aln_tiers")) { ELBA_REQUIRE(value >= 0, ELBA_ERR_INVALID_ARG, "set_option: aln_tiers is a string of the digits 1, 2, 4, 8"); c.opt.aln_tiers = value; }
+        else if (!strcmp(name, "aln_wide_hint")) c.opt.aln_wide_hint = (int)value;
+        else if (!strcmp(name, "aln_long_hint")) c.opt.aln_long_hint = (int)value;
         else throw Error{ELBA_ERR_INVALID_ARG, std::string("set_option: unknown option ") + name};
     });
 }

@@ -110,23 +110,34 @@ void fill_u64(hipStream_t s, uint64_t *p, uint64_t v, int64_t n);
 void group_offsets_u32(hipStream_t s, const uint64_t *sorted_keys, int key_shift, int64_t n, uint32_t *ptr, int64_t nkeys);
 uint64_t reduce_max_u64(hipStream_t s, const uint64_t *p, int64_t n, DevBuf &tmp);   // synchronises
 
-// ---- hot format of A for the SpGEMM (matrix.hip builds it, spgemm.hip walks it) ----------------------------------
-// One 16-byte descriptor per (row entry, contiguous range of partner entries in the entry's column):
-//   x = address in a_cscp of the first partner entry      y = sequence number of the first product: rank of the row entry << fbits | index in column
-//   z = number of partner entries (products)              w = (run of the row's own read in that column) - 1, on one descriptor per entry
-// A row's descriptors are stored by descending z, then by address.  Per row: 32 bytes of bounds.
-struct alignas(16) HotDesc { uint32_t x, y, z, w; };
-struct alignas(32) RowHot {
-    uint32_t rs, nnz;        // the row's entries in canonical order: a_dec[rs .. rs + nnz)
-    uint32_t hs, nd;         // its descriptors: a_hot[hs .. hs + nd)
-    uint32_t work;           // products its descriptors stand for (sum of z)
-    uint32_t own0, ownl;     // index of the row's first / last entry inside its own column
-    uint32_t pad;
+// ---- tuning and A/B switches (elba_set_option) --------------------------------------------------------------------------
+// Every default is the production path and none of them changes a result: the alternatives are kept for measurements and for the parity
+// tests that walk them.  They used to be environment variables read inside the stages; a library does not read its caller's environment.
+struct Options {
+    bool no_symmetry = false;   // SpGEMM: accumulate both triangles instead of one + mirror
+    bool no_ell = false;        // plain CSC columns instead of the padded column store
+    bool no_pay = false;        // 32-bit accumulators + seed look-ups instead of the position-carrying 64-bit ones
+    bool mir32 = false;         // 32-byte staging / mirror records instead of 16-byte words
+    bool no_hints = false;      // no ownership bits in the rows of A
+    bool no_sample = false;     // a cold call does not compute a sample of rows first
+    bool no_suffix = false;     // dense matrices stay on the general kernel
+    bool suffix64 = false;      // dense path with 64-bit accumulators
+    bool kmer_pairs = false;    // (value, payload) pairs through the k-mer sort instead of one packed word
+    bool kmer_unfused = false;  // per-head column emission (k_runs<true> + k_instance_entries) instead of k_runs_emit
+    bool kmer_no_msd = false;   // k <= 17: keep the LSD sort of the whole value instead of the two-level partition + LDS count (kmer_msd.hip)
+    bool csr_pairs = false;     // (read, entry) pairs through the CSR sort instead of one word
+    bool emit_plain = false;    // k-mer emit without the fused first histogram
+    bool trace = false;         // progress lines on stderr
+    int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
+    int dk = 2;                 // SpGEMM: rounds of gather trips in flight (1, 2, 4)
+    int64_t aln_tiers = 0;      // x-drop register tiers as decimal digits (1248 = all), 0 = default
+    int aln_wide_hint = 6, aln_long_hint = 6000;
 };
 
 // ---- context ----------------------------------------------------------------------------------------------------
 struct Ctx {
     elba_cfg cfg{};
+    Options opt;
     int device = 0;
     hipStream_t stream = nullptr;
     std::string last_error;
@@ -144,18 +155,14 @@ struct Ctx {
 
     // k-mer stage results (device)
     bool have_counts = false;
-    bool kmers_sorted = true;   // counts came from the sort-based path: a_colptr / a_csc already hold CSC(A) (kmer.hip)
     int64_t I = 0, ndistinct = 0;
     DevBuf inst_off;      // u64[M+1] instance offset of each read
-    DevBuf tab_keys;      // u64[cap]  open-addressed k-mer table
-    DevBuf tab_vals;      // u32[cap]  count, later k-mer id (or 0xFFFFFFFF = not reliable)
-    int64_t tab_cap = 0;
     DevBuf rel_kmers;     // u64[N] reliable k-mers ascending (right-aligned value order == packed order)
     DevBuf rel_kmers_lo;  // u64[N] their second word when k > 32
     DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
     DevBuf csr_words;     // u64[Z] read << (pre_nb + pre_pb) | k-mer id << pre_pb | pos of every entry of a_csc, when pre_words (k_runs_emit -> the CSR build's sort)
-    bool pre_ready = false, pre_words = false, pre_hints = false; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
+    bool pre_ready = false, pre_consumed = false, pre_words = false, pre_hints = false; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
     // Ownership hints of the SpGEMM, two bits in every a_csr entry (kid << 32 | hint << 30 | pos; positions below 2^30): bit 30 = under the
     // parity rule of owns_pair (spgemm_direct.hpp) this row accumulates NO pair of the entry's column and appears in it once — the column
     // need not be fetched at all, the entry only counts one diagonal product; bit 31 = the same with every partner outside the row window
@@ -178,24 +185,9 @@ struct Ctx {
                                                // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid * s_stride, no pointer
     bool use_ell = false;
     uint32_t s_stride = 4, lpc_log2 = 1;       // padded column stride in entries (4, or a multiple of 8: a whole number of 64-byte lines); lanes of the SpGEMM per row entry 2^lpc_log2 >= s_stride / 2
-    bool plan = false;                         // ELBA_PLAN=1 (A/B runs): the round-1 per-entry descriptor format is built with A and the descriptor kernel runs
     bool cold_calls = false;                   // every elba_create_seed_matrix call forgets what earlier calls learned (prior, tier usage): elba_set_option
-    DevBuf a_rowprod;                          // u32[M] products per row: sum of the column lengths of the row's k-mers
-    DevBuf a_dec;                              // u64[Z] by canonical rank: address of the entry's column in a_cscp << 32 | position in the read (seed decoding)
-    DevBuf a_hdr, a_hot;                       // RowHot[M], HotDesc[H]: per-row header + the row's hot descriptors (one per row entry and partner range); matrix.hip
-    DevBuf a_hot8;                             // u64[H]: the same descriptors packed into 8 bytes (x | y << xb | z << (xb+yb) | w << (xb+yb+zb)) when the fields fit: what the SpGEMM then reads
-    uint32_t hot_xb = 0, hot_yb = 0, hot_zb = 0; // field widths of the packed form; hot_xb == 0: not packed (a_hot is read)
     bool pos16 = false;                        // every position among the entries is < 65536 (mirrored entries of B travel as 16-byte records then)
-    uint32_t pay_pb = 0;                       // != 0: position-carrying formats (a_cscj word = partner read << pay_pb | position, packed descriptors carry the row entry's position): the SpGEMM's 64-bit accumulators
-    int64_t H = 0;                             // hot descriptors overall
-    int64_t Pnd = 0;                           // products the descriptors stand for (non-diagonal; an in-window pair on its smaller row only)
-    bool half = true;                          // descriptors list an in-window pair on its smaller row only; the SpGEMM mirrors (matrix.hip)
     uint32_t fbits = 1;                        // bits of the column-position field of a product sequence number
-    DevBuf a_roworder;                         // u32[M] rows by descending product count (queue order of the SpGEMM)
-    DevBuf a_cscp;                             // u64[Z] columns in first-occurrence order (hot-loop copy of a_csc; see matrix.hip)
-    bool a_cscp_is_csc = true;
-    DevBuf a_cscj;                             // u32[Z + 8] the partner read of every entry of a_cscp: all the numeric loop needs of an entry (half the bytes, four per 16-byte load)
-    DevBuf a_newstart;                         // u32[N] address of every column in a_cscp
     int64_t row_lo = 0, row_hi = -1;           // rows of B computed by this context (-1: all)
     // rows of an A built from reads are local read indices; exported triples carry global ids (src/KmerOps.cpp:215-219)
     int64_t first_global_id_rows() const { return A_has_kmers ? first_global_id : 0; }
@@ -239,10 +231,8 @@ struct Ctx {
     bool ov_low_clean = false;                 // the ticket counters are all zero (handed back clean by the previous call)
     DevBuf ov_rowub, ov_rowcnt, ov_rowoff, ov_lists, ov_counters, ov_gtable, ov_sortkeys;
     int64_t ov_tmp_cap = 0;
+    bool ov_sort_used[2] = {false, false};      // wide-row sorts used by the previous call
     bool ov_tiers_known = false, ov_tier_used[8] = {false, false, false, false, false, false, false, false};   // tiers that got rows in the previous call
-    bool ov_class_valid = false, ov_sort_used[2] = {false, false};   // cached tier queues (see spgemm.hip), wide-row sorts used last call
-    uint32_t ov_class_prior = 0; int64_t ov_class_lo = 0, ov_class_hi = 0; int ov_class_b0 = 0;
-    DevBuf ov_counters_snap;
     int64_t b_cap_entries = 0;      // capacity of b_col/b_val the next overlap call may assume (0 = unknown: size it after the numeric pass)
     uint64_t ov_calls = 0;          // steady-state overlap calls so far (phase events are recorded on every cfg.timing_stride-th)
     uint32_t ov_prior_q16 = 0;      // distinct-partner / product ratio measured by the previous overlap call (x 65536), 0 = unknown

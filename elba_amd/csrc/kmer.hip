@@ -3,9 +3,8 @@
 // Replaces get_kmer_count_map_keys / get_kmer_count_map_values / create_kmer_matrix (src/KmerOps.cpp:18-401) and the
 // explicit transpose (src/main.cpp:272-273).  The reference's Bloom filter + HyperLogLog + two all-to-all passes have
 // one net effect when LOWER >= 2: a canonical k-mer is kept iff its total instance count c obeys
-// LOWER <= c <= UPPER, and every instance of a kept k-mer becomes one entry (read, pos).  That is computed here exactly, in one of two ways.
-//
-// Default — SORT-BASED, every pass a coalesced stream over HBM (no random atomics):
+// LOWER <= c <= UPPER, and every instance of a kept k-mer becomes one entry (read, pos).  That is computed here exactly, by SORTING:
+// every pass is a coalesced stream over HBM (no random atomics):
 //   k_kmer_emit_packed_hist   every k-mer instance -> ONE word, canonical value << pb | (instance index >> drop), written in instance order =
 //                             (read, pos) order, a whole tile of the sort per workgroup together with the tile's first-digit counts
 //                             ((value, read << 32 | pos) pairs — k_kmer_emit — when more than 3 index bits would have to be dropped)
@@ -16,18 +15,6 @@
 //                             sort key for the CSR build.  (UPPER > 62 or pairs: k_runs<true> + k_instance_entries.)
 //   Multi-word k-mers (k > 31): k_kmer_emit2/3, an index permutation sorted last word first, runs compare every word.
 //
-// ELBA_KMER_HASH=1 — HASH-BASED (kept for A/B runs; the distributed owner counts by sorting too, see stage_dist_count_records):
-//
-//   pass 1  k_kmer_count     every k-mer instance -> canonical packed value (rolling-free: each lane rebuilds its window from two
-//                            aligned 8-byte loads of the 2-bit stream, reverse complement by bit tricks) -> open-addressed
-//                            HBM table (u64 key CAS + u32 count add)
-//           k_table_select   table sweep, wave-ballot compaction of the keys with LOWER <= count <= UPPER
-//           radix sort       reliable keys by value: k-mer id = rank (canonical order)
-//   pass 2  k_kmer_lookup    second enumeration (the reference also enumerates twice, src/KmerOps.cpp:219), table lookup,
-//                            scatter of (read,pos) into the k-mer's column; columns (<= UPPER entries) are then sorted in
-//                            registers so the result does not depend on arrival order
-//           CSR              stable radix sort of the CSC stream by read (matrix.hip)
-//
 // Packed k-mer layout (src/Kmer.cpp:67-87): base i at bits 2*(31-i), low 64-2k bits zero; canonical = min(kmer, twin)
 // (src/Kmer.cpp:200-205); position = forward start index (include/KmerOps.hpp:91-103).
 #include "common.hpp"
@@ -37,8 +24,6 @@ namespace elba {
 
 namespace {
 
-constexpr uint64_t KEMPTY = ~0ull;
-constexpr uint32_t NOT_RELIABLE = 0xFFFFFFFFu;
 constexpr int EN_ITEMS = 8;                    // instances per lane
 constexpr int EN_THREADS = 256;
 constexpr int EN_PER_WAVE = 64 * EN_ITEMS;
@@ -175,90 +160,8 @@ __device__ __forceinline__ void for_each_instance(const EnumParams &e, F &&f)
     for_each_instance_from(e, (((uint64_t)blockIdx.x * EN_THREADS + threadIdx.x) >> 6) * EN_PER_WAVE, f);
 }
 
-__global__ __launch_bounds__(EN_THREADS) void k_kmer_count(EnumParams e, unsigned long long *keys, uint32_t *vals, uint64_t capmask)
-{
-    for_each_instance(e, [&](uint64_t, uint32_t, uint32_t, uint64_t km) {
-        uint64_t slot = mix64(km) & capmask;
-        for (;;) {
-            const unsigned long long old = atomicCAS(&keys[slot], (unsigned long long)KEMPTY, (unsigned long long)km);
-            if (old == KEMPTY || old == km) break;
-            slot = (slot + 1) & capmask;
-        }
-        atomicAdd(&vals[slot], 1u);
-    });
-}
-
-struct SelCounters { unsigned long long distinct, reliable, entries, cursor; };
-constexpr uint32_t SEL_CHUNK = 256;      // output slots a wavefront draws from the global cursor at a time
-
-// Sweep of the k-mer table: keys with lower <= count <= upper are compacted (wave ballot + popcount prefix) into out_keys/out_slots.
-// A wavefront draws SEL_CHUNK output slots at a time from ONE global cursor (a single hot counter sustains only ~10^8 atomics/s:
-// one atomic per ballot made this kernel 48 ms on 5.4 M reliable k-mers).  out_keys is pre-filled with KEMPTY, so unused chunk tails
-// sort behind every real k-mer; the exact number of reliable k-mers is ctr->reliable.
-__global__ __launch_bounds__(256) void k_table_select(const uint64_t *keys, uint32_t *vals, uint64_t cap, uint32_t lower, uint32_t upper,
-                                                      uint64_t *out_keys, uint64_t *out_slots, SelCounters *ctr)
-{
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t lt = (1ull << lane) - 1;
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    unsigned long long nd = 0, nz = 0, nr = 0;
-    unsigned long long chunk_off = 0;
-    uint32_t chunk_left = 0;
-    for (uint64_t s0 = (uint64_t)blockIdx.x * blockDim.x; s0 < cap; s0 += stride) {     // block-uniform trip count
-        const uint64_t s = s0 + threadIdx.x;
-        bool keep = false;
-        uint64_t km = 0;
-        if (s < cap) {
-            km = keys[s];
-            if (km != KEMPTY) {
-                ++nd;
-                const uint32_t c = vals[s];
-                keep = c >= lower && c <= upper;
-                if (keep) { nz += c; ++nr; } else vals[s] = NOT_RELIABLE;
-            }
-        }
-        const uint64_t bal = __ballot(keep);
-        if (bal) {
-            const uint32_t n = (uint32_t)__popcll(bal);
-            if (n > chunk_left) {                                   // wave-uniform: abandon the tail (it stays KEMPTY), draw a new chunk
-                unsigned long long base = 0;
-                if (lane == 0) base = atomicAdd(&ctr->cursor, (unsigned long long)SEL_CHUNK);
-                chunk_off = __shfl(base, 0, 64);
-                chunk_left = SEL_CHUNK;
-            }
-            if (keep) { const uint64_t at = chunk_off + __popcll(bal & lt); out_keys[at] = km; out_slots[at] = s; }
-            chunk_off += n; chunk_left -= n;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { nd += __shfl_xor(nd, d, 64); nz += __shfl_xor(nz, d, 64); nr += __shfl_xor(nr, d, 64); }
-    if (lane == 0) { if (nd) atomicAdd(&ctr->distinct, nd); if (nz) atomicAdd(&ctr->entries, nz); if (nr) atomicAdd(&ctr->reliable, nr); }
-}
-
-__global__ void k_assign_ids(const uint64_t *sorted_slots, uint32_t *vals, uint32_t *counts, uint64_t N)
-{
-    const uint64_t kid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (kid >= N) return;
-    const uint64_t slot = sorted_slots[kid];
-    counts[kid] = vals[slot];
-    vals[slot] = (uint32_t)kid;
-}
-
-__global__ __launch_bounds__(EN_THREADS) void k_kmer_lookup(EnumParams e, const uint64_t *keys, const uint32_t *vals, uint64_t capmask,
-                                                            const uint32_t *colptr, uint32_t *fill, uint64_t *csc)
-{
-    for_each_instance(e, [&](uint64_t, uint32_t r, uint32_t p, uint64_t km) {
-        uint64_t slot = mix64(km) & capmask;
-        while (keys[slot] != km) slot = (slot + 1) & capmask;     // every instance was inserted in pass 1
-        const uint32_t kid = vals[slot];
-        if (kid != NOT_RELIABLE) {
-            const uint32_t at = atomicAdd(&fill[kid], 1u);
-            csc[colptr[kid] + at] = ((uint64_t)r << 32) | p;
-        }
-    });
-}
-
 // one lane per column: sort its (<= UPPER) entries ascending as u64 == by (read, pos); also emits the column id of every entry
+// (the distributed owner: its records arrive in no particular order)
 __global__ void k_sort_columns(const uint32_t *colptr, uint64_t *csc, uint64_t *kid_keys, uint64_t N)
 {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -726,8 +629,8 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
     c.kid_of_entry.reserve((size_t)(Z + 8) * 8);
     // Packed words with UPPER <= 62: one fused pass writes the columns, the entries' (read, pos) and — when read, k-mer id and position fit
     // one word — the sort keys of the CSR build (k_runs_emit).  Otherwise: heads write payloads and column ids, a second kernel converts.
-    c.pre_ready = false;
-    const bool fused = ib && p.upper <= 62 && !getenv("ELBA_KMER_UNFUSED");
+    c.pre_ready = false; c.pre_consumed = false;
+    const bool fused = ib && p.upper <= 62 && !c.opt.kmer_unfused;
     if (fused && Z > 0) {
         EnumParams e = make_enum(c);
         const uint64_t nib = (I >> IB_SHIFT) + 1;
@@ -737,8 +640,8 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
         for (int64_t r = 0; r < c.nreads; ++r) maxlen = c.h_len[(size_t)r] > maxlen ? c.h_len[(size_t)r] : maxlen;
         const uint64_t maxpos = maxlen >= (uint32_t)c.cfg.k ? maxlen - (uint32_t)c.cfg.k : 0;      // (a bound: the largest position any entry can have)
         const int mb = bits_needed((uint64_t)(c.nreads > 0 ? c.nreads - 1 : 0)), nb = bits_needed((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_needed(maxpos);
-        const bool words = mb + nb + pb + 2 <= 64 && !getenv("ELBA_CSR_PAIRS");
-        const bool hints = pb <= 30 && !getenv("ELBA_PLAN") && !getenv("ELBA_NO_HINTS");
+        const bool words = mb + nb + pb + 2 <= 64 && !c.opt.csr_pairs;
+        const bool hints = pb <= 30 && !c.opt.no_hints;
         c.prod_ctr.reserve(64 * 128);
         ELBA_HIP(hipMemsetAsync(c.prod_ctr.p, 0, 64 * 128, s));
         EmitOut o{};
@@ -778,7 +681,7 @@ void stage_count_kmers(Ctx &c)
     hipStream_t s = c.stream;
     const int k = c.cfg.k;
     const int64_t M = c.nreads;
-    c.have_counts = false; c.have_A = false; c.have_B = false;
+    c.have_counts = false; c.have_A = false; c.have_B = false; c.dist_owner = false;
     elba_kmer_stats st{};
     st.nreads = M;
 
@@ -792,7 +695,6 @@ void stage_count_kmers(Ctx &c)
     c.inst_off.reserve((size_t)(M + 1) * 8);
     ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s));
 
-    c.kmers_sorted = !getenv("ELBA_KMER_HASH") || k > 31;
     if (k > 31) {
         // ---- two- and three-word k-mers: sort an index permutation, last word first (stable LSD over all words), then gather ----
         const int words = k > 64 ? 3 : 2;
@@ -841,8 +743,8 @@ void stage_count_kmers(Ctx &c)
         c.have_counts = true;
         return;
     }
-    if (c.kmers_sorted) {
-        // ---- sort-based: see the header of this file ----
+    {
+        // ---- one-word k-mers: see the header of this file ----
         c.t_total.start(s);
         c.t_a.start(s);
         EnumParams e = make_enum(c);
@@ -854,8 +756,8 @@ void stage_count_kmers(Ctx &c)
         int ib = 1;
         while (ib < 63 && (I >> ib)) ++ib;
         int drop = 2 * k + ib > 64 ? 2 * k + ib - 64 : 0;
-        if (getenv("ELBA_KMER_DROP")) { const int want = atoi(getenv("ELBA_KMER_DROP")); if (want > drop && want <= 3 && want < ib) drop = want; }      // (test hook: small inputs through the dropped-index-bit path)
-        const bool packed_words = drop <= 3 && !getenv("ELBA_KMER_PAIRS");
+        if (c.opt.kmer_drop) { const int want = c.opt.kmer_drop; if (want > drop && want <= 3 && want < ib) drop = want; }      // (test hook: small inputs through the dropped-index-bit path)
+        const bool packed_words = drop <= 3 && !c.opt.kmer_pairs;
         if (!packed_words) { ib = 0; drop = 0; }
         const int pb = ib - drop;                  // payload bits below the value
         // workspaces: the words and their ping-pong copy; (value, payload) pairs need two more arrays (the other buffers are sized where they are used)
@@ -865,7 +767,7 @@ void stage_count_kmers(Ctx &c)
         if (packed_words) {
             int sh0 = 0, b0 = 0, tile = 0;
             uint32_t *hist0 = I > 1 ? radix_first_histogram((int64_t)I, pb, pb + 2 * k, c.ws_sort, &sh0, &b0, &tile) : nullptr;
-            const bool fuse_hist = hist0 && tile == 4 * EN_PER_BLOCK && b0 <= 9 && !getenv("ELBA_EMIT_PLAIN");      // (the emit writes whole tiles of the sort and counts their first digit)
+            const bool fuse_hist = hist0 && tile == 4 * EN_PER_BLOCK && b0 <= 9 && !c.opt.emit_plain;      // (the emit writes whole tiles of the sort and counts their first digit)
             if (fuse_hist) {
                 const uint64_t nib = (I >> IB_SHIFT) + 1;
                 c.ws_b.reserve((size_t)(nib + 1) * sizeof(BlockInfo));
@@ -895,98 +797,36 @@ void stage_count_kmers(Ctx &c)
         return;
     }
 
-    // table capacity (power of two)
-    int cbits = next_pow2_bits(I + I / 4 + 2);      // load factor <= 0.8 even if every instance were distinct; ~0.35 on real reads
-    if (cbits < 10) cbits = 10;
-    size_t free_b = 0, total_b = 0;
-    ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
-    while (cbits > 10 && ((size_t)12 << cbits) > free_b / 2 + c.tab_keys.cap + c.tab_vals.cap && (1ull << (cbits - 1)) > I + I / 4) --cbits;
-    const uint64_t cap = 1ull << cbits;
-    c.tab_cap = (int64_t)cap;
-    c.tab_keys.reserve((size_t)cap * 8);
-    c.tab_vals.reserve((size_t)cap * 4);
+}
 
-    c.t_total.start(s);
-    c.t_a.start(s);
-    ELBA_HIP(hipMemsetAsync(c.tab_keys.p, 0xFF, (size_t)cap * 8, s));
-    ELBA_HIP(hipMemsetAsync(c.tab_vals.p, 0, (size_t)cap * 4, s));
-    EnumParams e = make_enum(c);
-    const uint64_t nblocks = (I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
-    if (I > 0)
-        hipLaunchKernelGGL(k_kmer_count, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.tab_keys.as<unsigned long long>(), c.tab_vals.as<uint32_t>(), cap - 1);
-    c.t_a.stop(s);
-
-    // select reliable keys
-    c.t_b.start(s);
-    c.ws_scan.reserve(256);
-    SelCounters *dctr = c.ws_scan.as<SelCounters>();
-    ELBA_HIP(hipMemsetAsync(dctr, 0, sizeof(SelCounters), s));
-    // worst case every distinct k-mer is reliable: N <= I / lower
-    const int sel_blocks = c.num_cus * 8;
-    const uint64_t maxN = I / (uint64_t)c.cfg.lower + 1 + (uint64_t)sel_blocks * 4 * SEL_CHUNK;   // + one open chunk per wavefront
-    c.ws_a.reserve(maxN * 8); c.ws_b.reserve(maxN * 8); c.ws_c.reserve(maxN * 8); c.ws_d.reserve(maxN * 8);
-    ELBA_HIP(hipMemsetAsync(c.ws_a.p, 0xFF, maxN * 8, s));          // KEMPTY: unused chunk tails sort last
-    hipLaunchKernelGGL(k_table_select, dim3(sel_blocks), dim3(256), 0, s, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(), cap,
-                       (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), dctr);
-    SelCounters hc{};
-    ELBA_HIP(hipMemcpyAsync(&hc, dctr, sizeof(hc), hipMemcpyDeviceToHost, s));
-    ELBA_HIP(hipStreamSynchronize(s));
-    const uint64_t N = hc.reliable, Z = hc.entries;
-    ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
-    // k-mer ids = rank of the packed value (the hc.cursor - N sentinel keys sort behind the N real ones)
-    int where = radix_sort_pairs(s, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_c.as<uint64_t>(), c.ws_d.as<uint64_t>(), (int64_t)hc.cursor, 64 - 2 * k, 64, c.ws_sort);
-    const uint64_t *skeys = where ? c.ws_c.as<uint64_t>() : c.ws_a.as<uint64_t>();
-    const uint64_t *sslots = where ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
-    c.rel_kmers.reserve((size_t)(N + 1) * 8);
-    c.rel_counts.reserve((size_t)(N + 2) * 4);
-    if (N > 0) {
-        ELBA_HIP(hipMemcpyAsync(c.rel_kmers.p, skeys, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-        hipLaunchKernelGGL(k_assign_ids, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, sslots, c.tab_vals.as<uint32_t>(), c.rel_counts.as<uint32_t>(), N);
-    }
-    c.t_b.stop(s);
-    c.t_total.stop(s);
-    ELBA_HIP(hipStreamSynchronize(s));
-    st.instances = (int64_t)I; st.distinct = (int64_t)hc.distinct; st.reliable = (int64_t)N; st.entries = (int64_t)Z;
-    st.ms_total = c.t_total.ms(); st.ms_count = c.t_a.ms(); st.ms_sort = c.t_b.ms(); st.ms_lookup = 0;
-    c.ndistinct = (int64_t)hc.distinct;
-    c.N = (int64_t)N; c.Z = (int64_t)Z;
-    c.kstats = st;
-    c.have_counts = true;
+// column id of every entry, from the column pointers (one lane per column: columns hold at most UPPER entries)
+__global__ void k_expand_colptr(const uint32_t *colptr, uint64_t N, uint64_t *kid_of_entry)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    for (uint32_t z = colptr[k], z1 = colptr[k + 1]; z < z1; ++z) kid_of_entry[z] = k;
 }
 
 void stage_create_kmer_matrix(Ctx &c)
 {
     ELBA_REQUIRE(c.have_counts, ELBA_ERR_STATE, "create_kmer_matrix: no k-mer counts (call elba_count_kmers)");
+    ELBA_REQUIRE(!c.dist_owner, ELBA_ERR_STATE, "create_kmer_matrix: this context counted exchanged records (elba_dist_count_records); its matrix is a panel (elba_dist_set_panel)");
     hipStream_t s = c.stream;
     const int64_t M = c.nreads, N = c.N, Z = c.Z;
     c.have_A = false; c.have_B = false;
-    if (c.kmers_sorted) {           // CSC(A) came out of the counting sort already: only the column id of every entry is still needed
-        c.t_c.start(s);
-        c.t_c.stop(s);
-        c.A_has_kmers = true;
-        finish_matrix_from_sorted_csc(c, M, N, Z, c.kid_of_entry.as<uint64_t>(), 0, c.a_csc.as<uint64_t>(), 0, -1, c.pre_ready);      // (column ids — or the CSR sort keys — were written with the columns: k_runs / k_runs_emit)
-        c.kstats.ms_lookup = c.t_c.ms();
-        return;
+    // CSC(A) came out of the counting sort already; the CSR build needs the column id of every entry.  The fused column pass (k_runs_emit) left
+    // them as ready-made sort keys (csr_words), which the build CONSUMES (hint bits are ORed in, the sort ping-pongs over them): a second call
+    // after one elba_count_kmers rebuilds the column ids from the column pointers instead.
+    const bool pre = c.pre_ready;
+    if (!pre && c.pre_consumed && N > 0) {
+        c.kid_of_entry.reserve((size_t)(Z + 8) * 8);
+        hipLaunchKernelGGL(k_expand_colptr, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (uint64_t)N, c.kid_of_entry.as<uint64_t>());
     }
     c.t_c.start(s);
-    c.a_colptr.reserve((size_t)(N + 2) * 4);
-    c.a_csc.reserve((size_t)(Z + 8) * 8);   // + guard entries (matrix.hip)
-    // colptr = exclusive scan of the per-k-mer counts
-    ELBA_HIP(hipMemsetAsync(c.rel_counts.as<uint32_t>() + N, 0, 4, s));
-    exclusive_scan_u32(s, c.rel_counts.as<uint32_t>(), c.a_colptr.as<uint32_t>(), N + 1, c.ws_scan);
-    c.ws_e.reserve((size_t)(N + 1) * 4);
-    c.ws_f.reserve((size_t)(Z + 1) * 8);
-    ELBA_HIP(hipMemsetAsync(c.ws_e.p, 0, (size_t)(N + 1) * 4, s));
-    EnumParams e = make_enum(c);
-    const uint64_t nblocks = ((uint64_t)c.I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
-    if (c.I > 0)
-        hipLaunchKernelGGL(k_kmer_lookup, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, c.tab_keys.as<uint64_t>(), c.tab_vals.as<uint32_t>(),
-                           (uint64_t)c.tab_cap - 1, c.a_colptr.as<uint32_t>(), c.ws_e.as<uint32_t>(), c.a_csc.as<uint64_t>());
-    if (N > 0)
-        hipLaunchKernelGGL(k_sort_columns, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), c.ws_f.as<uint64_t>(), (uint64_t)N);
     c.t_c.stop(s);
     c.A_has_kmers = true;
-    finish_matrix_from_sorted_csc(c, M, N, Z, c.ws_f.as<uint64_t>(), 0, c.a_csc.as<uint64_t>());
+    finish_matrix_from_sorted_csc(c, M, N, Z, c.kid_of_entry.as<uint64_t>(), 0, c.a_csc.as<uint64_t>(), 0, -1, pre);      // (column ids — or the CSR sort keys — were written with the columns: k_runs / k_runs_emit)
+    if (pre) { c.pre_ready = false; c.pre_consumed = true; }
     c.kstats.ms_lookup = c.t_c.ms();
 }
 

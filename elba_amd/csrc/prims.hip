@@ -395,8 +395,7 @@ namespace {
 // digits of a sort of the bits [bit_lo, bit_hi): as even as they come, at most `maxbits` wide (34 bits = 9 + 9 + 8 + 8)
 static int radix_digits(int bit_lo, int bit_hi, int *shift, int *bits)
 {
-    const int maxbits = getenv("ELBA_RS_BITS") ? atoi(getenv("ELBA_RS_BITS")) : RS_MAXBITS;     // (8: the digits of round 1, for A/B runs)
-    const int B = bit_hi - bit_lo, mb = maxbits < 1 ? 1 : (maxbits > RS_MAXBITS ? RS_MAXBITS : maxbits);
+    const int B = bit_hi - bit_lo, mb = RS_MAXBITS;
     const int npass = (B + mb - 1) / mb;
     for (int q = 0, at = bit_lo; q < npass; ++q) { bits[q] = B / npass + (q < B % npass ? 1 : 0); shift[q] = at; at += bits[q]; }
     return npass;

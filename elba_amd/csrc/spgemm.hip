@@ -4,7 +4,7 @@
 // with a row-wise hash SpGEMM written for CDNA4:
 //
 //   * one workgroup owns one read-row i of A (spgemm_direct.hpp, the plan-free kernel: it walks CSR(A) and fetches the k-mer columns as the
-//     k-mer stage leaves them; spgemm_rows.hpp is round 1's kernel on per-entry descriptors, behind ELBA_PLAN=1 for A/B runs);
+//     k-mer stage leaves them);
 //   * every product (i,k)x(j,k) updates an open-addressed accumulator keyed by the partner read j that lives in LDS
 //     (SoA: key | count | first | last); the semiring's non-commutative add (include/SharedSeeds.hpp:41-46: keep the FIRST seed of the left
 //     operand and the FIRST seed of the right operand) is made order-free by the canonical rule of SURVEY.md §8c-2: the row's products carry
@@ -79,19 +79,14 @@ struct OvParams {
     uint32_t suffix;                // dense matrices (Ctx::csr_suffix): row entries carry column length and own place, the smaller row owns a pair
     uint32_t s_stride, lpc_log2, max_col;    // padded column stride in entries (a_ell); lanes per row entry 2^lpc_log2; longest column
     unsigned long long fb_enough;            // row entries behind the in-call partner / entry ratio at which it counts as settled (nobody touches the hot sums any more)
-    const uint32_t *a_rowprod; const uint64_t *a_cscp; const uint32_t *a_cscj; const uint32_t *a_roworder;
-    const RowHot *a_hdr; const HotDesc *a_hot; const uint64_t *a_dec;   // per-row bounds, per-entry partner ranges, seed decoding by canonical rank (matrix.hip)
     uint32_t M;              // number of rows of A held here
     uint32_t Mcols;          // number of reads overall (partner id range)
     uint32_t row_lo, row_hi; // rows of B computed by this context
     uint32_t fbits;
-    const uint64_t *a_hot8; uint32_t hot_xb, hot_yb, hot_zb;   // 8-byte descriptors (hot_xb != 0) instead of a_hot
-    uint32_t pay_pb;         // != 0: position-carrying formats — a_cscj words are partner read << pay_pb | position, descriptors carry the row entry's position (matrix.hip)
     uint32_t half;           // 1: the schedule lists an in-window pair on its smaller row only; survivors are mirrored into the partner's row
     uint32_t tier_limit[NUM_LDS_TIERS];   // claimed slots at which a row abandons the tier: min(3T/4, T - BLOCK) - 1 (every lane can overshoot by one claim)
     uint32_t use_feedback;   // 1 on the first call for a matrix (no measured prior yet): in-call self-correction through the hot fb_* sums
     uint32_t prior_q16;      // distinct-partners / products estimate in 1/65536 units (1/16 before anything is known; measured by the previous call afterwards)
-    uint32_t dbg;            // diagnostic ablations (cfg.flags): 1 = gathers only (no accumulator updates), 2 = accumulator only (synthetic partners)
     uint32_t *row_cnt;       // [M+1] entries the row staged itself (partners it was scheduled with + diagonal)
     uint32_t *low_cnt;       // [M+1] zero at entry: mirrored entries per row; its returning atomic hands every mirrored entry its slot
     unsigned long long *row_off;   // [M]
@@ -117,56 +112,8 @@ __device__ __forceinline__ uint32_t guaranteed_tbits(uint32_t ub, uint32_t mcols
     return need <= 1 ? 1u : (uint32_t)(32 - __clz(2 * need - 1));   // ceil(log2(2*need)): load factor <= 1/2
 }
 
-// ---- symbolic: queue every non-empty row on its starting tier ------------------------------------------------------
-// The per-row product count ub_i = sum_{k in row i} c_k is part of A's device format (built with A, matrix.hip).
-__global__ __launch_bounds__(256) void k_classify_rows(OvParams p)
-{
-    const uint32_t stride = gridDim.x * blockDim.x;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t lt = (1ull << lane) - 1;
-    unsigned long long prod = 0, cap = 0;
-    for (uint32_t i0 = blockIdx.x * blockDim.x; i0 < p.M; i0 += stride) {      // block-uniform trip count
-        const uint32_t idx = i0 + threadIdx.x;
-        // rows are visited in descending-work order (a_roworder); a row window (multi-GPU shard) filters by row id
-        const uint32_t i = idx < p.M ? p.a_roworder[idx] : 0xFFFFFFFFu;
-        int mytier = -1;
-        const uint32_t full = (i >= p.row_lo && i < p.row_hi) ? p.a_rowprod[i] : 0;   // empty rows: row_cnt was zeroed by the host
-        if (full != 0) {
-        const uint32_t ub = p.a_hdr[i].work;        // products of the row's descriptors (the diagonal and, with `half`, mirrored pairs are not among them)
-        prod += full;
-        cap += (ub < p.Mcols ? ub : p.Mcols) + 1;
-        const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
-        // optimistic estimate of distinct partners = products x prior (1/16 at first: measured 0.06 on 15 %-error reads, far less on
-        // accurate ones; afterwards the ratio the previous call measured, x 1.25), at least 128.  A wrong guess costs an abandoned
-        // attempt, never correctness; within a call the numeric kernel corrects itself from the rows already done.
-        uint32_t est = (uint32_t)(((unsigned long long)ub * p.prior_q16) >> 16);
-        if (est < 128) est = 128;
-        int tier = 0;
-        while (tier < NUM_LDS_TIERS && est > p.tier_limit[tier]) ++tier;      // est <= the tier's abandon limit
-        // never start above the tier that is already guaranteed to fit
-        const int gt = gbits <= LDS_TBITS0 ? 0 : (int)gbits - LDS_TBITS0;
-        if (gt < tier) tier = gt;
-        if (tier > NUM_LDS_TIERS) tier = NUM_LDS_TIERS;
-        mytier = tier;
-        }
-        // one atomic per wavefront and tier (a single hot counter sustains only ~10^8 atomics/s)
-#pragma unroll
-        for (int t = 0; t < NUM_TIERS; ++t) {
-            const uint64_t bal = __ballot(mytier == t);
-            if (bal == 0) continue;
-            uint32_t base = 0;
-            if (lane == (uint32_t)(__ffsll((unsigned long long)bal) - 1)) base = atomicAdd(&p.ctr->tier_count[t], (uint32_t)__popcll(bal));
-            base = __shfl(base, __ffsll((unsigned long long)bal) - 1, 64);
-            if (mytier == t) p.lists[(size_t)t * p.M + base + (uint32_t)__popcll(bal & lt)] = i;
-        }
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { prod += __shfl_xor(prod, d, 64); cap += __shfl_xor(cap, d, 64); }
-    if ((threadIdx.x & 63) == 0 && prod) { atomicAdd(&p.ctr->products, prod); atomicAdd(&p.ctr->cap_need, cap); }
-}
-
 // ---- numeric -----------------------------------------------------------------------------------------------------
-#include "spgemm_rows.hpp"
+#include "spgemm_table.hpp"
 #include "spgemm_direct.hpp"
 
 // ---- finalize: row pointers, mirror, per-row column sort + move to final CSR --------------------------------------------
@@ -657,7 +604,7 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
     const int64_t M = c.M;
     const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? M : c.row_hi, nrows = row_hi - row_lo;
     const int cus = c.num_cus;
-    const bool mir16 = c.pos16 && !getenv("ELBA_MIR32");
+    const bool mir16 = c.pos16 && !c.opt.mir32;
     FinParams f{};
     f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = c.ov_tmp.as<StageRec>(); f.mir = half ? c.ov_mir.as<StageRec>() : nullptr; f.half = half; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
     f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
@@ -753,6 +700,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     elba_overlap_stats st{};
     st.nrows = row_hi - row_lo;
     c.have_B = false;
+    c.ov_phase = 0;      // (a begun sharded call that was never ended is abandoned here: its staged records are about to be overwritten)
     ELBA_REQUIRE(M < 0xFFFFFF00ll, ELBA_ERR_UNSUPPORTED, "read ids beyond 2^32 - 256 (the top of the id range marks empty slots and idle lanes)");
     if (c.cold_calls) { c.ov_prior_q16 = 0; c.ov_tiers_known = false; c.ov_sort_used[0] = c.ov_sort_used[1] = true; }
 
@@ -775,7 +723,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     // B is symmetric up to exchanging the two positions of every seed (exactly: the canonical seeds are min / max over a cross product of
     // positions per shared k-mer): a pair of rows of this context's window is accumulated on its smaller row only and the surviving
     // entries are mirrored into the partner's row afterwards (k_mirror) — half the accumulator updates, tables half as full.
-    const bool half = phase == 1 || !getenv("ELBA_NO_SYMMETRY");
+    const bool half = phase == 1 || !c.opt.no_symmetry;
     const int64_t slack = (int64_t)cus * 32 * STAGE_CHUNK + 64;      // one open chunk per resident workgroup
     if (c.ov_tmp_cap == 0) {
         if (c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
@@ -803,7 +751,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);
-    const bool pay = c.pos16 && !getenv("ELBA_NO_PAY");
+    const bool pay = c.pos16 && !c.opt.no_pay;
     // workgroup sizes grow with the table so that the largest tiers still bring enough waves to a CU (one or two workgroups fit its LDS)
     const uint32_t blk[NUM_LDS_TIERS] = {128u, 256u, 512u, 1024u, 512u};
     for (int t = 0; t < NUM_LDS_TIERS; ++t) {
@@ -844,7 +792,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         const bool timed = passes > 1 || (c.ov_calls++ % (uint64_t)stride) == 0;
         c.ov_tmp.reserve((size_t)c.ov_tmp_cap * sizeof(StageRec));
         p.tmp = c.ov_tmp.as<StageRec>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
-        const bool mir16 = c.pos16 && !getenv("ELBA_MIR32");
+        const bool mir16 = c.pos16 && !c.opt.mir32;
         c.ov_rec16 = mir16;
         p.rec16 = mir16 ? 1u : 0u; p.rec = c.ov_tmp.as<uint4>(); p.tick = reinterpret_cast<uint32_t *>(c.ov_tmp.as<char>() + (size_t)c.ov_tmp_cap * 16);
         c.b_cap_entries = half ? 2 * c.ov_tmp_cap : c.ov_tmp_cap;      // the output cannot be larger than what was staged (and mirrored)
@@ -862,7 +810,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         // — distinct partners per row entry — picks the starting tier of all the others, instead of a guess that sends most rows of a
         // 15 %-error read set to a tier too small (an abandoned attempt or a forwarding each: 0.9 ms of a 14.7 ms call on the 200 k-read set).
         p.use_feedback = c.ov_prior_q16 ? 0u : 1u;      // (a repeated pass starts like the first)
-        const bool sampling = p.use_feedback && nrows >= 8192 && !getenv("ELBA_NO_SAMPLE");
+        const bool sampling = p.use_feedback && nrows >= 8192 && !c.opt.no_sample;
         p.nsample = sampling ? 256u : 0u; p.sstep = sampling ? (uint32_t)(nrows / 256) : 1u;
         c.ov_sample.reserve(256 * 4);
         p.sample_list = c.ov_sample.as<uint32_t>();
@@ -880,9 +828,9 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         else if (dk == 4) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 4>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));       \
         else hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 2>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));                    \
     } while (0)
-            const int dk = getenv("ELBA_DK") ? atoi(getenv("ELBA_DK")) : 2;      // rounds of DK trips in flight (tuning knob)
+            const int dk = c.opt.dk;      // rounds of DK trips in flight (tuning knob)
 // (dense path: 32-bit accumulators + seed look-ups for the few survivors — 18.0 vs 19.1 ms on config 5 at 1/25; ELBA_SUFFIX64: the 64-bit ones)
-#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) do { if (!getenv("ELBA_SUFFIX64")) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3(grid), dim3(B), (size_t)18 * (1u << (tb)) + X(B, false), s, p, (tier), (tb), (smp)); \
+#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) do { if (!c.opt.suffix64) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3(grid), dim3(B), (size_t)18 * (1u << (tb)) + X(B, false), s, p, (tier), (tb), (smp)); \
                                                           else hipLaunchKernelGGL((k_spgemm_direct<B, false, true, 2, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp)); } while (0)
             if (sampling) {
                 if (p.suffix) ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
@@ -929,7 +877,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         for (int t = 0; t < NUM_TIERS; ++t) missed |= ((skipped_tiers >> t) & 1u) && hc.tier_count[t] > 0;
         missed |= ((skipped_sorts & 1u) && hc.fin_count[0] > 0) || ((skipped_sorts & 2u) && hc.fin_count[1] > 0);
         if (hc.overflow || missed) {      // staging too small, or a row reached a tier / sort that was not launched: repeat with what is known now
-            if (getenv("ELBA_TRACE")) fprintf(stderr, "[elba] overlap call repeated: overflow=%u missed=%d cursor=%llu tmp_cap=%lld\n", hc.overflow, (int)missed, hc.cursor, (long long)c.ov_tmp_cap);
+            if (c.opt.trace) fprintf(stderr, "[elba] overlap call repeated: overflow=%u missed=%d cursor=%llu tmp_cap=%lld\n", hc.overflow, (int)missed, hc.cursor, (long long)c.ov_tmp_cap);
             ELBA_REQUIRE(passes < 4, ELBA_ERR_INTERNAL, "overlap output did not settle");
             if (hc.overflow) c.ov_tmp_cap = (int64_t)hc.cursor + slack;      // every row drew its space even when it did not fit: the cursor is the need
             c.ov_tiers_known = false;
@@ -957,7 +905,7 @@ static RemoteParams remote_params(Ctx &c)
 
 void stage_seed_matrix_begin(Ctx &c, int nranks, const uint64_t *bounds_host, uint64_t *send_counts_host)
 {
-    ELBA_REQUIRE(c.have_A && !c.plan, ELBA_ERR_STATE, "seed_matrix_begin: no k-mer matrix");
+    ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "seed_matrix_begin: no k-mer matrix");
     ELBA_REQUIRE(nranks >= 1 && nranks <= REMOTE_MAX_RANKS && bounds_host && send_counts_host, ELBA_ERR_INVALID_ARG, "seed_matrix_begin: 1..64 ranks, read bounds and a count array");
     const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? c.M : c.row_hi;
     bool found = false;
@@ -1001,7 +949,7 @@ void stage_seed_matrix_end(Ctx &c, const void *d_recv, int64_t nrecv)
     if (c.b_cap_entries < staged + nrecv + 1) c.b_cap_entries = staged + nrecv + 1;
     c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
     c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
-    const bool mir16 = c.pos16 && !getenv("ELBA_MIR32");
+    const bool mir16 = c.pos16 && !c.opt.mir32;
     c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * (mir16 ? 16 : sizeof(StageRec)));
     c.ov_marks.mark(2, s);
     c.ov_remote.reserve((size_t)(nrecv + 1) * sizeof(StageRec));
@@ -1031,305 +979,7 @@ void stage_seed_matrix_end(Ctx &c, const void *d_recv, int64_t nrecv)
 void stage_create_seed_matrix(Ctx &c)
 {
     ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "create_seed_matrix: no k-mer matrix (call elba_create_kmer_matrix or elba_set_kmer_matrix)");
-    if (!c.plan) { create_seed_matrix_direct(c, 0); return; }
-    hipStream_t s = c.stream;
-    const int64_t M = c.M, N = c.N, Z = c.Z;
-    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? M : c.row_hi;
-    elba_overlap_stats st{};
-    st.nrows = row_hi - row_lo;
-    c.have_B = false;
-
-    const uint32_t fbits = c.fbits;          // fixed when the product schedule was built
-    ELBA_REQUIRE(fbits < 31 && (uint64_t)c.max_row_nnz < (1ull << (32 - fbits)), ELBA_ERR_UNSUPPORTED,
-                 "row nnz x column nnz exceeds the 32-bit product sequence number");
-    ELBA_REQUIRE((uint64_t)c.max_row_nnz * (uint64_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1) < 0xFFFFFFFFull, ELBA_ERR_UNSUPPORTED,
-                 "products per row exceed 32 bits");
-    ELBA_REQUIRE(M < 0xFFFFFF00ll, ELBA_ERR_UNSUPPORTED, "read ids beyond 2^32 - 256 (the top of the id range marks empty slots and idle lanes)");
-
-    c.ov_rowcnt.reserve((size_t)(M + 2) * 4);
-    c.ov_rowoff.reserve((size_t)(M + 1) * 8);
-    c.ov_lists.reserve((size_t)(NUM_TIERS + 2) * (size_t)(M + 1) * 4);
-    c.ov_counters.reserve(sizeof(OvCounters));
-    c.b_rowptr.reserve((size_t)(M + 2) * 8);
-
-    // HBM spill tables: one per resident workgroup of the spill kernel
-    uint64_t gstride = 2;
-    while (gstride < 2ull * (uint64_t)(M > 1 ? M : 1)) gstride <<= 1;
-    // as many spill rows in flight as 4 GiB of tables allow (20 B per slot), between 64 and two per CU: a spill row initialises and
-    // sweeps a table of up to 2M slots, so the tier is bound by rows in flight
-    int spill_blocks = (int)((4ull << 30) / (20ull * gstride));
-    spill_blocks = spill_blocks < 64 ? 64 : (spill_blocks > c.num_cus * 2 ? c.num_cus * 2 : spill_blocks);
-    c.ov_gtable.reserve((size_t)spill_blocks * 5 * gstride * 4);
-
-    if (c.ov_tmp_cap == 0 && c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
-
-    OvParams p{};
-    p.a_rowprod = c.a_rowprod.as<uint32_t>(); p.a_roworder = c.a_roworder.as<uint32_t>();
-    p.a_hdr = c.a_hdr.as<RowHot>(); p.a_hot = c.a_hot.as<HotDesc>(); p.a_dec = c.a_dec.as<uint64_t>();
-    p.a_cscp = c.a_cscp_is_csc ? c.a_csc.as<uint64_t>() : c.a_cscp.as<uint64_t>();
-    p.a_cscj = c.a_cscj.as<uint32_t>();
-    p.a_hot8 = c.a_hot8.as<uint64_t>(); p.hot_xb = c.hot_xb; p.hot_yb = c.hot_yb; p.hot_zb = c.hot_zb;
-    p.pay_pb = c.pay_pb;
-    p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = fbits; p.dbg = (uint32_t)c.cfg.flags;
-    p.half = c.half ? 1u : 0u;
-    p.pos_mask = 0xFFFFFFFFu; c.ov_hints_used = false;
-    p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 4096u;
-    p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
-    const int b0 = getenv("ELBA_B0") ? atoi(getenv("ELBA_B0")) : 128;      // workgroup size of the 512-slot tier (tuning knob)
-    {
-        const uint32_t blk[NUM_LDS_TIERS] = {(uint32_t)(b0 == 64 ? 64 : (b0 == 256 ? 256 : 128)), (uint32_t)(getenv("ELBA_B1") ? atoi(getenv("ELBA_B1")) : 256), 256u, 256u, 512u};
-        for (int t = 0; t < NUM_LDS_TIERS; ++t) {
-            const uint32_t T = 1u << (LDS_TBITS0 + t);
-            const uint32_t lim = std::min((T >> 2) * 3, T - blk[t]);      // a lane overshoots by at most one claim (Table::insert_lds)
-            p.tier_limit[t] = lim - 1;
-        }
-    }
-    p.row_cnt = c.ov_rowcnt.as<uint32_t>();
-    if (c.ov_totcnt.cap < (size_t)(M + 2) * 4) c.ov_low_clean = false;
-    c.ov_totcnt.reserve((size_t)(M + 2) * 4);
-    p.low_cnt = c.ov_totcnt.as<uint32_t>();
-    p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
-    p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
-    p.ctr = c.ov_counters.as<OvCounters>();
-    p.gtable = c.ov_gtable.as<uint32_t>(); p.gstride = gstride;
-
-    static bool attr_done = false;
-    if (!attr_done) {
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<512, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<512, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_rows<256, false, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_done = true;
-    }
-
-    const int cus = c.num_cus;
-    const int64_t nrows = row_hi - row_lo;
-    c.ov_host.reserve(sizeof(OvCounters));
-    OvCounters &hc = *static_cast<OvCounters *>(c.ov_host.p);
-    hc = OvCounters{};
-    uint32_t skipped_tiers = 0, skipped_sorts = 0;
-    int passes = 0;
-    float ms_sym = 0, ms_num = 0;
-    float ms_fin = 0, ms_tot = 0;
-    bool was_timed = true;
-    for (;;) {
-        ++passes;
-        // The queues of the tiers depend only on A, the prior and the row window: in the steady state they are reused and the counter
-        // block is restored from the snapshot taken right after the last classification (one 1.4 KB device copy instead of two
-        // memsets and a kernel).  Rows rewrite their own row_cnt entry every call; empty rows keep the zero they were given once.
-        const bool cached = c.ov_class_valid && c.ov_class_prior == p.prior_q16 && c.ov_class_lo == row_lo && c.ov_class_hi == row_hi && c.ov_class_b0 == b0 && c.b_cap_entries > 0;
-        // phase events: every call on the synchronising path; on the steady-state path every cfg.timing_stride-th call (an event record
-        // costs ~5 us of stream time, four of them 8 % of this call)
-        const int stride = c.cfg.timing_stride > 1 ? c.cfg.timing_stride : 1;
-        const bool timed = !(c.b_cap_entries > 0) || passes > 1 || (c.ov_calls++ % (uint64_t)stride) == 0;
-        if (timed) c.ov_marks.mark(0, s);
-        // the ticket counters come back clean from a call that ran to its end (k_finalize_wave); otherwise zero them here
-        if (!c.ov_low_clean) ELBA_HIP(hipMemsetAsync(c.ov_totcnt.p, 0, (size_t)(M + 2) * 4, s));
-        c.ov_low_clean = false;
-        if (cached) {
-            ELBA_HIP(hipMemcpyAsync(c.ov_counters.p, c.ov_counters_snap.p, sizeof(OvCounters), hipMemcpyDeviceToDevice, s));
-        } else {
-            ELBA_HIP(hipMemsetAsync(c.ov_counters.p, 0, sizeof(OvCounters), s));
-            ELBA_HIP(hipMemsetAsync(c.ov_rowcnt.p, 0, (size_t)(M + 2) * 4, s));
-            if (nrows > 0) {
-                int nb = (int)((M + 255) / 256);
-                if (nb > cus * 4) nb = cus * 4;
-                hipLaunchKernelGGL(k_classify_rows, dim3(nb), dim3(256), 0, s, p);
-            }
-            c.ov_counters_snap.reserve(sizeof(OvCounters));
-            ELBA_HIP(hipMemcpyAsync(c.ov_counters_snap.p, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToDevice, s));
-            c.ov_class_valid = true; c.ov_class_prior = p.prior_q16; c.ov_class_lo = row_lo; c.ov_class_hi = row_hi; c.ov_class_b0 = b0;
-        }
-        if (c.ov_tmp_cap == 0) {
-            // first call on this context: size the staging area from the bound that can never overflow (one sync)
-            ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
-            ELBA_HIP(hipStreamSynchronize(s));
-            size_t free_b = 0, total_b = 0;
-            ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
-            int64_t want = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;   // + one open chunk per workgroup
-            int64_t budget = (int64_t)(free_b / 2 / sizeof(StageRec));
-            c.ov_tmp_cap = want < budget ? want : budget;
-            if (c.ov_tmp_cap < 1024) c.ov_tmp_cap = 1024;
-        }
-        c.ov_tmp.reserve((size_t)c.ov_tmp_cap * sizeof(StageRec));
-        p.tmp = c.ov_tmp.as<StageRec>(); p.tmp_cap = (unsigned long long)c.ov_tmp_cap;
-
-        if (timed) c.ov_marks.mark(1, s);
-        const bool diag = c.cfg.flags != 0;
-#define ELBA_LAUNCH_ROWS(B, G, grid, lds, tier, tb)                                                                          \
-    do {                                                                                                            \
-        if (diag) hipLaunchKernelGGL((k_spgemm_rows<B, G, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));   \
-        else hipLaunchKernelGGL((k_spgemm_rows<B, G, false>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb));       \
-    } while (0)
-        // position-carrying formats + production kernels + default block sizes: 64-bit accumulators on the tiers whose table still fits (26 B per slot)
-        const bool pay = p.pay_pb != 0 && !diag && b0 == 128 && (!getenv("ELBA_B1") || atoi(getenv("ELBA_B1")) == 256);
-#define ELBA_LAUNCH_PAY(B, grid, lds, tier, tb) hipLaunchKernelGGL((k_spgemm_rows<B, false, false, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb))
-        if (nrows > 0) {
-            // LDS tiers of 16-byte slots; the block grows with the table so that a lane owns >= 8 slots and BLOCK <= T/4.
-            // Launched in ascending order on one stream: a tier's queue is complete when its kernel starts.
-            const size_t X = 256;  // bytes of misc words behind the table (spgemm_rows.hpp: W_END words)
-            const int g0 = getenv("ELBA_G0") ? atoi(getenv("ELBA_G0")) : 10;    // resident capacity: 96 VGPRs -> 5 waves per SIMD = 10 two-wave workgroups per CU (LDS would allow 14)
-            // Tiers that received no row in the previous call on this matrix are not launched (an empty launch still costs ~5 us of
-            // stream time); should a row reach one of them after all, the call is repeated with every tier (checked after the sync).
-            const bool all_tiers = !c.ov_tiers_known || c.b_cap_entries == 0;
-            skipped_tiers = 0;
-#define ELBA_TIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
-            if (pay) {
-                // (11 workgroups of 13.6 KB fill a CU's LDS exactly; measured 8 / 10 / 11 / 12 per CU: 0.150 / 0.156 / 0.146 / 0.170 ms)
-                const int g0p = getenv("ELBA_G0") ? g0 : 11;
-                ELBA_TIER(0, ELBA_LAUNCH_PAY(128, cus * g0p, (size_t)26 * 512 + X, 0, 9u));
-                ELBA_TIER(1, ELBA_LAUNCH_PAY(256, cus * 4, (size_t)26 * 1024 + X, 1, 10u));
-                // (from 2048 slots on the wider slots would halve the workgroups a CU holds: 32-bit accumulators + look-ups there)
-                ELBA_TIER(2, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)18 * 2048 + X, 2, 11u));
-                ELBA_TIER(3, ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)18 * 4096 + X, 3, 12u));
-            } else {
-            if (b0 == 64) ELBA_TIER(0, ELBA_LAUNCH_ROWS(64, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
-            else if (b0 == 256) ELBA_TIER(0, ELBA_LAUNCH_ROWS(256, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
-            else ELBA_TIER(0, ELBA_LAUNCH_ROWS(128, false, cus * g0, (size_t)18 * 512 + X, 0, 9u));
-            if (!getenv("ELBA_B1") || atoi(getenv("ELBA_B1")) == 256) ELBA_TIER(1, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)18 * 1024 + X, 1, 10u));
-            else ELBA_TIER(1, ELBA_LAUNCH_ROWS(128, false, cus * 8, (size_t)18 * 1024 + X, 1, 10u));
-            ELBA_TIER(2, ELBA_LAUNCH_ROWS(256, false, cus * 4, (size_t)18 * 2048 + X, 2, 11u));
-            ELBA_TIER(3, ELBA_LAUNCH_ROWS(256, false, cus * 2, (size_t)18 * 4096 + X, 3, 12u));
-            }
-            ELBA_TIER(4, ELBA_LAUNCH_ROWS(512, false, cus, (size_t)18 * 8192 + X, 4, 13u));
-            ELBA_TIER(5, ELBA_LAUNCH_ROWS(256, true, spill_blocks, X, NUM_LDS_TIERS, 0u));
-            ELBA_HIP(hipGetLastError());
-        }
-        if (timed) c.ov_marks.mark(2, s);
-        // Steady state (staging and output capacities known from an earlier call on this matrix): no host round trip between the
-        // numeric kernels and the finalize pass — everything is queued, ONE synchronisation at the end, and the rare surprises
-        // (staging overflow, more output than last time) are repaired afterwards.  First call: synchronise here to size the output.
-        const bool fast = c.b_cap_entries > 0;
-        if (!fast) {
-            ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
-            ELBA_HIP(hipStreamSynchronize(s));
-            ms_sym += c.ov_marks.ms(0, 1); ms_num += c.ov_marks.ms(1, 2);
-            if (hc.overflow) {
-                ms_tot += c.ov_marks.ms(0, 2);
-                ELBA_REQUIRE(passes < 3, ELBA_ERR_INTERNAL, "overlap staging area overflowed twice");
-                c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;      // the bound that cannot overflow
-                continue;
-            }
-            int64_t y = 0;
-            for (int sh = 0; sh < NUM_SHARDS; ++sh) y += (int64_t)hc.shard[sh].nnz;
-            c.b_cap_entries = y + y / 4 + 1024;
-        }
-        c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
-        c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
-        if (c.half) {
-            c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * sizeof(StageRec));
-        }
-
-        // row pointers, per-row column sort + move to the final arrays
-        if (!fast) c.ov_marks.mark(4, s);
-        {
-            FinParams f{};
-            f.row_cnt = c.ov_rowcnt.as<uint32_t>(); f.low_cnt = c.ov_totcnt.as<uint32_t>(); f.tmp = p.tmp; f.mir = c.ov_mir.as<StageRec>(); f.half = p.half; f.row_off = c.ov_rowoff.as<unsigned long long>(); f.b_rowptr = c.b_rowptr.as<int64_t>();
-            f.b_col = c.b_col.as<uint32_t>(); f.b_val = c.b_val.as<elba_seed_t>();
-            f.M = (uint32_t)M; f.row_lo = p.row_lo; f.row_hi = p.row_hi; f.fin_lists = p.fin_lists; f.ctr = p.ctr;
-            f.b_cap = c.b_cap_entries;
-            f.mir16 = c.pos16 && !getenv("ELBA_MIR32") ? 1u : 0u;
-            const int gblocks = 32;
-            uint64_t sstride = 2;
-            while (sstride < (uint64_t)M) sstride <<= 1;
-            c.ov_sortkeys.reserve((size_t)gblocks * sstride * 8);
-            f.sortkeys = c.ov_sortkeys.as<uint64_t>(); f.sort_stride = sstride;
-            if (M + 1 <= (1 << 17)) {
-                hipLaunchKernelGGL(k_row_pointers, dim3((unsigned)((M + 1 + RP_TILE - 1) / RP_TILE)), dim3(256), 0, s, f);
-            } else {
-                c.ov_sum_tmp.reserve((size_t)(M + 2) * 4);
-                f.sum_tmp = c.ov_sum_tmp.as<uint32_t>();
-                hipLaunchKernelGGL(k_sum_counts, dim3((unsigned)((M + 1 + 255) / 256)), dim3(256), 0, s, f);
-                exclusive_scan_u32_to_i64(s, f.sum_tmp, c.b_rowptr.as<int64_t>(), M + 1, c.ws_scan);
-            }
-          if (nrows > 0) {
-            int nb = (int)((nrows + 3) / 4);
-            if (nb > cus * 32) nb = cus * 32;      // one row per wavefront where possible: the pass is latency-bound per row
-            hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
-            hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
-            hipLaunchKernelGGL(k_finalize_mid, dim3(nb), dim3(256), 0, s, f);
-            // the wide-row sorts read their queues' lengths on the device: launched unconditionally (empty queues cost a few us)
-            skipped_sorts = 0;
-            if (!fast || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
-            else skipped_sorts |= 1u;
-            if (!fast || c.ov_sort_used[1]) hipLaunchKernelGGL(k_finalize_huge, dim3(gblocks), dim3(256), 0, s, f);
-            else skipped_sorts |= 2u;
-          }
-        }
-        if (timed) c.ov_marks.mark(3, s);
-        // (also on the synchronising path: the wide-row sort queues are filled by k_mirror, after the first read-back)
-        ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
-        ELBA_HIP(hipStreamSynchronize(s));
-        if (fast) {
-            if (timed) { ms_sym += c.ov_marks.ms(0, 1); ms_num += c.ov_marks.ms(1, 2); }
-            int64_t y = 0;
-            for (int sh = 0; sh < NUM_SHARDS; ++sh) y += (int64_t)hc.shard[sh].nnz;
-            bool missed = false;
-            for (int t = 0; t < NUM_TIERS; ++t) missed |= ((skipped_tiers >> t) & 1u) && hc.tier_count[t] > 0;
-            missed |= ((skipped_sorts & 1u) && hc.fin_count[0] > 0) || ((skipped_sorts & 2u) && hc.fin_count[1] > 0);
-            if (hc.overflow || y > c.b_cap_entries || missed) {     // a surprise: fall back to the synchronising path and redo the call
-                if (getenv("ELBA_TRACE")) fprintf(stderr, "[elba] overlap call repeated: overflow=%u y=%lld cap=%lld missed=%d skipped_tiers=%x skipped_sorts=%x tier_count=%u,%u,%u,%u,%u fin=%u,%u cursor=%llu tmp_cap=%lld\n",
-                                                  hc.overflow, (long long)y, (long long)c.b_cap_entries, (int)missed, skipped_tiers, skipped_sorts, hc.tier_count[0], hc.tier_count[1], hc.tier_count[2], hc.tier_count[3], hc.tier_count[4], hc.fin_count[0], hc.fin_count[1], hc.cursor, (long long)c.ov_tmp_cap);
-                ELBA_REQUIRE(passes < 4, ELBA_ERR_INTERNAL, "overlap output did not settle");
-                if (hc.overflow) c.ov_tmp_cap = (int64_t)hc.cap_need + (int64_t)cus * 32 * STAGE_CHUNK + 64;
-                c.b_cap_entries = 0; c.ov_class_valid = false;
-                if (timed) ms_tot += c.ov_marks.ms(0, 3);
-                continue;
-            }
-        }
-        if (timed) { ms_fin = c.ov_marks.ms(fast ? 2 : 4, 3); ms_tot += c.ov_marks.ms(0, 3); }
-        was_timed = timed;
-        c.ov_low_clean = true;
-        break;
-    }
-
-    hc.fb_claims = 0; hc.fb_ub = 0;                 // the hot in-call sums are a subset of what the shards hold
-    for (int sh = 0; sh < NUM_SHARDS; ++sh) {       // fold the statistics shards
-        const OvShard &x = hc.shard[sh];
-        hc.yraw += x.yraw; hc.nnz += x.nnz; hc.ndiag += x.ndiag; hc.nupper += x.nupper; hc.fb_claims += x.fb_claims; hc.fb_ub += x.fb_ub;
-        if (x.maxshared > hc.maxshared) hc.maxshared = x.maxshared;
-        for (int t = 0; t < NUM_TIERS; ++t) hc.tier_done[t] += x.tier_done[t];
-    }
-    const int64_t Y = (int64_t)hc.nnz;
-    for (int t = 0; t < NUM_TIERS; ++t) c.ov_tier_used[t] = hc.tier_count[t] > 0;
-    c.ov_tiers_known = true;
-    c.ov_sort_used[0] = hc.fin_count[0] > 0; c.ov_sort_used[1] = hc.fin_count[1] > 0;
-
-    if (c.cfg.flags & 16) {   // diagnostic: per-phase shader-clock totals over all workgroups of the numeric kernels
-        fprintf(stderr, "[elba dbg] phase cycles (sum over %llu workgroups): fetch=%llu init=%llu accumulate_rest=%llu sweep=%llu reserve=%llu decode=%llu | gather_wait=%llu count_scan_queue=%llu insert=%llu loop_tail=%llu\n",
-                hc.phase[10], hc.phase[0], hc.phase[1], hc.phase[2], hc.phase[3], hc.phase[4], hc.phase[5], hc.phase[6], hc.phase[7], hc.phase[8], hc.phase[9]);
-    }
-    if (hc.fb_ub > 0) {   // remember the measured distinct/products ratio (+25 %) for the next call's starting tiers
-        double r = 1.25 * (double)hc.fb_claims / (double)hc.fb_ub * 65536.0;
-        const uint32_t q = r < 64.0 ? 64u : (r > 65536.0 ? 65536u : (uint32_t)r);
-        // keep the prior (and with it the cached tier queues) unless the measurement moved by more than 10 %: rows that escalate
-        // in one call and not in the next make the ratio wobble in its last digits
-        const uint32_t old = c.ov_prior_q16;
-        if (old == 0 || q > old + old / 10 || q + old / 10 < old) c.ov_prior_q16 = q;
-    }
-    st.products = (int64_t)hc.products;
-    st.nnz_before_prune = (int64_t)hc.yraw;
-    st.nnz = Y;
-    st.nnz_diag = (int64_t)hc.ndiag;
-    st.nnz_upper = (int64_t)hc.nupper;
-    st.max_numshared = (int64_t)hc.maxshared;
-    st.rows_lds = 0;
-    for (int t = 0; t < NUM_LDS_TIERS; ++t) st.rows_lds += hc.tier_done[t];
-    st.rows_global = (int64_t)hc.tier_done[NUM_LDS_TIERS];
-    int64_t queued = 0;
-    for (int t = 0; t < NUM_TIERS; ++t) queued += hc.tier_count[t];
-    st.rows_escalated = queued - st.rows_lds - st.rows_global;
-    st.algorithmic_bytes = 16 * Z + 8 * (2 * M + N + 3) + 24 * Y;
-    st.passes = passes;
-    st.timed = was_timed ? 1 : 0;
-    st.ms_total = ms_tot;
-    st.ms_symbolic = ms_sym;
-    st.ms_numeric = ms_num;
-    st.ms_finalize = ms_fin;
-    c.Y = Y;
-    c.ostats = st;
-    c.have_B = true;
+    create_seed_matrix_direct(c, 0);
 }
 
 }  // namespace elba

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ELBA_ABI_VERSION 1
+#define ELBA_ABI_VERSION 2
 
 enum {
     ELBA_OK = 0,
@@ -210,7 +210,10 @@ typedef struct {
     const void *b_col;     /* u32[Y] */
     const void *b_val;     /* elba_seed_t[Y] */
     void *stream;          /* hipStream_t the library launches on */
+    uint32_t a_csr_format; /* which of the three encodings of a_csr is active (ELBA_CSR_*) */
+    uint32_t a_csr_pos_mask; /* position of an a_csr entry = low word & a_csr_pos_mask, whatever the format */
 } elba_device_view;
+enum { ELBA_CSR_PLAIN = 0 /* kid<<32 | pos */, ELBA_CSR_HINTS = 1 /* kid<<32 | hint<<30 | pos */, ELBA_CSR_DENSE = 2 /* kid<<32 | L<<23 | idx<<16 | pos */ };
 
 int  elba_abi_version(void);
 const char *elba_strerror(int status);
@@ -284,7 +287,10 @@ int  elba_kmer_histogram(elba_ctx *ctx, int64_t *hist, int64_t len);
 
 int  elba_get_device_view(elba_ctx *ctx, elba_device_view *view);
 
-/* Run-time options by name (unknown name: ELBA_ERR_INVALID_ARG).
+/* Run-time options by name (unknown name: ELBA_ERR_INVALID_ARG).  Besides the one below: tuning and A/B switches that never change a
+ * result (struct Options in elba_amd/csrc/common.hpp lists them: "no_symmetry", "no_ell", "no_pay", "mir32", "no_hints", "no_sample",
+ * "no_suffix", "suffix64", "kmer_pairs", "kmer_unfused", "kmer_no_msd", "csr_pairs", "emit_plain", "trace", "kmer_drop", "dk", "aln_tiers", ...).
+ * Options that shape A must be set before elba_count_kmers / elba_set_kmer_matrix.
  *   "overlap_cold_calls" (0 | 1): 1 = every elba_create_seed_matrix call forgets what earlier calls on the same matrix learned (the
  *       distinct-partner ratio that picks the starting table tiers, which tiers and column sorts received rows): what a caller that
  *       multiplies every matrix once pays — the reference's create_seed_matrix is called once per A (src/main.cpp:281).  Buffers stay

@@ -277,10 +277,9 @@ def test_two_word_kmers_full_pipeline(k, lo, up):
     e.close()
 
 
-@pytest.mark.parametrize("knob", ["ELBA_NO_PAY", "ELBA_DESC16"])
-def test_position_carrying_accumulators_equal_the_looked_up_seeds(knob, monkeypatch):
-    """Reads whose positions fit 16 bits get formats that carry the positions and 64-bit accumulators (no seed-decoding loads);
-    ELBA_NO_PAY / ELBA_DESC16 at matrix-build time keep the 32-bit accumulators + lookups: same B, bit for bit, on every tier."""
+def test_position_carrying_accumulators_equal_the_looked_up_seeds():
+    """Reads whose positions fit 16 bits get 64-bit accumulators that carry the positions (no seed-decoding loads); the option "no_pay"
+    keeps the 32-bit accumulators + look-ups: same B, bit for bit, on every tier."""
     noisy = elba_amd.synth_reads(51, 150000, 14, 2500, 1800, error_rate=0.10, min_len=60)
     deep = elba_amd.synth_reads(52, 3000, 120, 120, 10, error_rate=0.0, min_len=60)
     packed, off, lens = _concat([noisy, deep])
@@ -288,8 +287,7 @@ def test_position_carrying_accumulators_equal_the_looked_up_seeds(knob, monkeypa
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 300)
     gu.assert_B_equal(e.export_csr(), o.B())
     e.close()
-    monkeypatch.setenv(knob, "1")
-    e2, ks2, ms2, st2 = gu.gpu_full(packed, off, lens, 17, 2, 300)
+    e2, ks2, ms2, st2 = gu.gpu_full(packed, off, lens, 17, 2, 300, options={"no_pay": 1})
     gu.assert_B_equal(e2.export_csr(), o.B())
     gu.assert_stats_equal(st2, o)
     e2.close()
@@ -338,15 +336,14 @@ def test_words_one_or_two_bits_short_mark_rare_positions_for_lookup():
     e.close()
 
 
-@pytest.mark.parametrize("knob", ["ELBA_NO_SYMMETRY", "ELBA_NO_ELL", "ELBA_NO_PAY", "ELBA_PLAN", "ELBA_KMER_HASH", "ELBA_KMER_PAIRS", "ELBA_MIR32", "ELBA_KMER_UNFUSED", "ELBA_CSR_PAIRS", "ELBA_NO_HINTS", "ELBA_RS_BITS", "ELBA_EMIT_PLAIN", "ELBA_NO_SAMPLE"])
-def test_alternative_paths_kept_for_ab_runs_give_the_same_matrices(knob, monkeypatch):
-    """Build-time / run-time alternatives kept behind environment knobs (both triangles accumulated instead of one + mirror, plain CSC columns
-    instead of the padded ones, 32-bit accumulators + seed look-ups, the round-1 descriptor plan + kernel, hash-based counting, (value,
-    payload) pairs through the k-mer sort, 32-byte mirror / staging records, per-head column emission, (read, entry) pairs through the CSR sort,
-    no ownership hints in the rows of A, one-bit radix digits): A and B must not change."""
-    monkeypatch.setenv(knob, "1")
+@pytest.mark.parametrize("knob", ["no_symmetry", "no_ell", "no_pay", "kmer_pairs", "mir32", "kmer_unfused", "csr_pairs", "no_hints", "emit_plain", "no_sample", "kmer_no_msd"])
+def test_alternative_paths_kept_for_ab_runs_give_the_same_matrices(knob):
+    """Alternatives kept behind elba_set_option (both triangles accumulated instead of one + mirror, plain CSC columns instead of the
+    padded ones, 32-bit accumulators + seed look-ups, (value, payload) pairs through the k-mer sort, 32-byte mirror / staging records,
+    per-head column emission, (read, entry) pairs through the CSR sort, no ownership hints in the rows of A, the k-mer emit without its
+    fused histogram, no sampled rows on a cold call, the LSD sort instead of the two-level partition): A and B must not change."""
     packed, off, lens, info = elba_amd.synth_reads(61, 200000, 16, 3000, 900, error_rate=0.10, min_len=200)
-    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8, options={knob: 1})
     o = gu.oracle_run(packed, off, lens, 17, 2, 8)
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
@@ -434,31 +431,25 @@ def test_reads_that_hold_a_kmer_twice_and_the_ownership_hints(shape):
     o.set_triples(M, ncol, rows, cols, vals)
     o.spgemm(8)
     oB = o.B()
-    for env in ({}, {"ELBA_NO_HINTS": "1"}):
-        for k_, v_ in env.items(): os.environ[k_] = v_
-        try:
-            e = elba_amd.Engine(17, 2, up)
-            e.set_kmer_matrix(M, ncol, rows, cols, vals)
-            st = e.create_seed_matrix()
-            gu.assert_B_equal(e.export_csr(), oB)
-            gu.assert_stats_equal(st, o)
-            e.create_seed_matrix()
-            gu.assert_B_equal(e.export_csr(), oB)
-            e.close()
-        finally:
-            for k_ in env: os.environ.pop(k_, None)
+    for opts in ({}, {"no_hints": 1}):
+        e = elba_amd.Engine(17, 2, up, options=opts)
+        e.set_kmer_matrix(M, ncol, rows, cols, vals)
+        st = e.create_seed_matrix()
+        gu.assert_B_equal(e.export_csr(), oB)
+        gu.assert_stats_equal(st, o)
+        e.create_seed_matrix()
+        gu.assert_B_equal(e.export_csr(), oB)
+        e.close()
 
 
-@pytest.mark.parametrize("knob", [None, "ELBA_NO_SUFFIX"])
-def test_dense_columns_take_the_path_of_their_own(knob, monkeypatch):
+@pytest.mark.parametrize("knob", [None, "no_suffix", "suffix64"])
+def test_dense_columns_take_the_path_of_their_own(knob):
     """Deep, nearly error-free reads with a generous UPPER: columns of ~30 reads, hundreds of products per surviving pair.  Such matrices are
     multiplied by the dense path (pairs owned by the smaller row, the owned candidates of a row entry = its column behind it: DESIGN.md §4.1);
-    ELBA_NO_SUFFIX keeps them on the general path.  A, B and the statistics equal the oracle's either way, on a cold and a warm call, and
+    the option "no_suffix" keeps them on the general path, "suffix64" runs the dense path with 64-bit accumulators.  A, B and the statistics equal the oracle's either way, on a cold and a warm call, and
     a read that holds a k-mer twice (a repeat family) is among them."""
-    if knob:
-        monkeypatch.setenv(knob, "1")
     packed, off, lens, info = elba_amd.synth_reads(91, 60000, 30, 3000, 600, error_rate=0.01, min_len=500, repeat_families=3, repeat_fraction=0.1, repeat_len=400)
-    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40, options={knob: 1} if knob else None)
     o = gu.oracle_run(packed, off, lens, 17, 2, 40, threads=8)
     assert ms["max_col_nnz"] > 16 if "max_col_nnz" in ms else True
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
@@ -472,20 +463,35 @@ def test_dense_columns_take_the_path_of_their_own(knob, monkeypatch):
 
 
 @pytest.mark.parametrize("drop", [1, 2, 3])
-def test_dropped_index_bits_are_recovered_from_the_reads(drop, monkeypatch):
+def test_dropped_index_bits_are_recovered_from_the_reads(drop):
     """A k-mer instance travels through the counting sort as ONE word, value << pb | (instance index >> drop); beyond 2^30 instances at
     k = 17 the lowest index bits do not fit and the kept entries find their instance among the 2^drop candidates by recomputing the
-    candidates' k-mers (k_runs_emit).  ELBA_KMER_DROP forces that path on a small input, low-complexity reads included (neighbouring
+    candidates' k-mers (k_runs_emit).  The option "kmer_drop" forces that path on a small input, low-complexity reads included (neighbouring
     positions that hold the SAME k-mer: the dup-th candidate is the right one)."""
-    monkeypatch.setenv("ELBA_KMER_DROP", str(drop))
     reads, _ = synth.make_reads(77, 60000, 14, 2500, 700, error=0.08, min_len=100)
     # a few homopolymer / dinucleotide reads: runs of equal canonical k-mers at consecutive positions
     extra = [b"A" * 300, b"AC" * 200, b"T" * 150 + b"G" * 150, b"ACG" * 120] * 3
     seqs = list(reads) + extra
     np.random.default_rng(3).shuffle(seqs)
     packed, off, lens = po.pack_reads(seqs)
-    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 12)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 12, options={"kmer_drop": drop})
     o = gu.oracle_run(packed, off, lens, 17, 2, 12, threads=8)
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+
+
+def test_create_kmer_matrix_twice_after_one_count_gives_the_same_matrices():
+    """elba_create_kmer_matrix consumes the CSR sort keys the fused column pass left behind (hint bits are ORed into them, the sort
+    ping-pongs over them); a second call after ONE elba_count_kmers must rebuild what it needs and give the same A and B."""
+    packed, off, lens, info = elba_amd.synth_reads(62, 150000, 14, 3000, 900, error_rate=0.10, min_len=200)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 8)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.create_kmer_matrix()
+    st2 = e.create_seed_matrix()
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st2, o)
     e.close()
