@@ -103,6 +103,7 @@ constexpr uint32_t HINT_MAX_COL = 12;     // longer columns are not examined: a 
 int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
 // The same for bare 64-bit words (whatever rides in the bits outside [bit_lo, bit_hi) moves with them): returns 0 if the result is in k0, 1 if in k1.
 int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done = false);
+void radix_column_scan(hipStream_t s, uint32_t *rows, int64_t nrows, uint32_t nbins, DevBuf &tmp);      // (prims.hip)
 uint32_t *radix_first_histogram(int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, int *shift, int *bits, int *tile);      // (prims.hip)
 void fill_u32(hipStream_t s, uint32_t *p, uint32_t v, int64_t n);
 void fill_u64(hipStream_t s, uint64_t *p, uint64_t v, int64_t n);
@@ -124,6 +125,7 @@ struct Options {
     bool suffix64 = false;      // dense path with 64-bit accumulators
     bool kmer_pairs = false;    // (value, payload) pairs through the k-mer sort instead of one packed word
     bool kmer_unfused = false;  // per-head column emission (k_runs<true> + k_instance_entries) instead of k_runs_emit
+    bool kmer_msd = false;      // force the two-level partition path on inputs below its size threshold (tests)
     bool kmer_no_msd = false;   // k <= 17: keep the LSD sort of the whole value instead of the two-level partition + LDS count (kmer_msd.hip)
     bool csr_pairs = false;     // (read, entry) pairs through the CSR sort instead of one word
     bool emit_plain = false;    // k-mer emit without the fused first histogram
@@ -162,7 +164,7 @@ struct Ctx {
     DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
     DevBuf csr_words;     // u64[Z] read << (pre_nb + pre_pb) | k-mer id << pre_pb | pos of every entry of a_csc, when pre_words (k_runs_emit -> the CSR build's sort)
-    bool pre_ready = false, pre_consumed = false, pre_words = false, pre_hints = false; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
+    bool pre_ready = false, pre_consumed = false, pre_words = false, pre_hints = false, pre_hints_done = false, pre_ell_done = false; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
     // Ownership hints of the SpGEMM, two bits in every a_csr entry (kid << 32 | hint << 30 | pos; positions below 2^30): bit 30 = under the
     // parity rule of owns_pair (spgemm_direct.hpp) this row accumulates NO pair of the entry's column and appears in it once — the column
     // need not be fetched at all, the entry only counts one diagonal product; bit 31 = the same with every partner outside the row window
@@ -253,6 +255,8 @@ void stage_set_reads_fasta(Ctx &c, const char *chunk, int64_t chunk_bytes, uint6
                            int64_t first_global_id, elba_ingest_stats *stats);      // ingest.hip
 void stage_count_kmers(Ctx &c);                                   // kmer.hip
 void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
+bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st);   // kmer_msd.hip: false = not applicable (the caller sorts)
+void choose_column_store(Ctx &c, int64_t N, int64_t max_col);     // matrix.hip: padded column store or plain CSC, strides, sequence-number bits
 void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip
 void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
 void stage_seed_matrix_begin(Ctx &c, int nranks, const uint64_t *bounds_host, uint64_t *send_counts_host);

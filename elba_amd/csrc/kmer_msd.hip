@@ -1,0 +1,654 @@
+// kmer_msd.hip — k-mer counting for k <= 17 by a two-level value partition and an LDS count table per bucket.
+//
+// Replaces, for the k every run recipe of the reference uses (README.md:104-109: k = 17), the sort of kmer.hip as the way to compute what
+// get_kmer_count_map_keys / get_kmer_count_map_values compute (src/KmerOps.cpp:18-350): the canonical k-mers with LOWER <= count <= UPPER and
+// the (read, pos) of each of their instances.  The LSD sort of kmer.hip moves every instance four times over HBM
+// (2k = 34 value bits, 9-bit digits) and, because 34 value bits + 31 index bits do not fit one word, has to recompute k-mers afterwards.
+// Here an instance moves twice and is read twice more:
+//
+//   k_msd_hist1     enumerate the k-mers of every tile of 8192 instances, count the tile's FIRST digit (the top b1 value bits)
+//   k_msd_scatter   <ENUM> enumerate again and write every instance as ONE word straight into its first-digit bucket (stable): the word
+//                   no longer holds the first digit — word = remaining value bits << PB | read << pbits | pos — so read and position travel
+//                   with the instance and nothing is recomputed or looked up afterwards;
+//   k_msd_hist2 / k_msd_segscan / k_msd_scatter<MEM>   the same on the SECOND digit inside every first-digit bucket (tiles never straddle buckets):
+//                   after it the instances sit grouped by their top b1 + b2 = 2k - 16 value bits, 2^(2k-16) buckets;
+//   k_msd_bucket    one workgroup per bucket: the 16 value bits left index a table of 16-bit counters IN LDS (two halves of 2^15 values, 64 KB):
+//                   one LDS atomic per instance gives the exact counts, a scan over the table numbers the reliable k-mers in value order
+//                   (k-mer id = rank of the value) and places their columns; <false> counts per bucket (N, Z), <true> — after the
+//                   scan over the buckets — writes the k-mers, the column pointers, the columns sorted by (read, pos), the padded column store
+//                   the SpGEMM gathers from, and the CSR build's sort keys with their ownership hints: everything k_runs / k_runs_emit /
+//                   k_add_hints / k_fill_ell of the sort path produce, from the bucket while it sits in LDS.
+//
+// HBM traffic per instance: 8 B written + 8 B read (hist2) + 8 B read + 8 B written + 2 x 8 B read = 48 B, against ~112 B on the sort path.
+#include "common.hpp"
+#include "matrix.hpp"
+#include <algorithm>
+
+namespace elba {
+
+namespace {
+
+#include "kmer_enum.hpp"
+
+constexpr int MT_THREADS = 256, MT_ITEMS = 32, MT_TILE = MT_THREADS * MT_ITEMS;      // 8192 instances per tile: a wavefront's share is one block of the instance -> read table
+constexpr int MT_MAXBITS = 9, MT_MAXBINS = 1 << MT_MAXBITS;
+constexpr int VBITS = 16;                     // value bits left to the bucket kernel (two halves of 2^15 values)
+constexpr int BK_THREADS = 1024;
+constexpr uint32_t EW = 2048;                 // entries of a bucket half staged at a time (a window of its columns)
+constexpr uint32_t KW = EW / 2 + 1;           // columns such a window can hold (a reliable column has >= 2 entries)
+constexpr uint32_t EPAD = 256;                // the last column of a window may reach this far beyond it (UPPER <= 255)
+constexpr uint32_t BK_TAB = 16384, BK_ENT = BK_TAB + 2048 + 128 + 2 * (KW + 1);      // word offsets in the bucket kernel's LDS (BK_ENT even: 8-byte aligned)
+static_assert(BK_ENT % 2 == 0, "staged entries are 8-byte words");
+constexpr size_t BK_LDS_COUNT = (size_t)(BK_TAB + 2048 + 128) * 4, BK_LDS_EMIT = (size_t)BK_ENT * 4 + (size_t)(EW + EPAD) * 10;
+constexpr int KPT = 8;                        // instances of a bucket a lane keeps in registers (8192 per workgroup; beyond: re-read from L2)
+static_assert(MT_ITEMS * 64 == (1 << IB_SHIFT), "a wavefront's share of a tile is one block of the instance -> read table");
+
+struct MsdParams {
+    int k2;                 // 2k value bits
+    int b1, b2;             // digit widths: b1 + b2 + VBITS == k2
+    int pbits, PB;          // payload = read << pbits | pos, PB = bits of the payload
+    uint64_t I;
+};
+
+// ---- first digit: count ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(MT_THREADS) void k_msd_hist1(EnumParams e, const BlockInfo *block_read, MsdParams m, uint32_t *hist)
+{
+    __shared__ uint32_t h[MT_MAXBINS];
+    const uint32_t nbins = 1u << m.b1;
+    for (uint32_t i = threadIdx.x; i < nbins; i += MT_THREADS) h[i] = 0;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t base = ((uint64_t)blockIdx.x * (MT_THREADS / 64) + (threadIdx.x >> 6)) * (uint64_t)(MT_ITEMS * 64);
+    if (base < e.I) {
+        const ReadCursor rc = cursor_at(e, block_read, base);
+        uint32_t r = rc.lo;
+        uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
+#pragma unroll 8
+        for (int it = 0; it < MT_ITEMS; ++it) {
+            const uint64_t g = base + (uint64_t)it * 64 + lane;
+            if (g >= e.I) break;
+            while (g >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }
+            const uint64_t km = canonical_at_off(e, boff, (uint32_t)(g - off_lo));
+            atomicAdd(&h[(uint32_t)(km >> (64 - m.b1))], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nbins; i += MT_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
+}
+
+// ---- tiles of the second pass: none of them straddles two first-digit buckets ------------------------------------------------------------
+// b1start[d] = place of bucket d (row 0 of the scanned first histogram), tile0[d] = first tile of bucket d; one workgroup of 512 threads
+__global__ __launch_bounds__(MT_MAXBINS) void k_msd_tiles(const uint32_t *hist1_row0, uint32_t nb1, uint64_t I, uint32_t *b1start, uint32_t *tile0)
+{
+    __shared__ uint32_t wsum[MT_MAXBINS / 64];
+    const uint32_t d = threadIdx.x, lane = d & 63, w = d >> 6;
+    const uint32_t st = d < nb1 ? hist1_row0[d] : (uint32_t)I, en = d + 1 < nb1 ? hist1_row0[d + 1] : (uint32_t)I;
+    const uint32_t nt = d < nb1 ? (en - st + MT_TILE - 1) / MT_TILE : 0u;
+    uint32_t inc = nt;
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= (uint32_t)s2) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - nt;
+    for (uint32_t ww = 0; ww < w; ++ww) run += wsum[ww];
+    if (d < nb1) { b1start[d] = st; tile0[d] = run; }
+    if (d == nb1 - 1) { b1start[nb1] = (uint32_t)I; tile0[nb1] = run + nt; }
+}
+
+struct SegTiles { const uint32_t *b1start, *tile0; uint32_t nb1; };
+// tile t of the second pass: its bucket (last b with tile0[b] <= t: empty buckets share their successor's first tile), first key, keys
+__device__ __forceinline__ void seg_tile(const SegTiles &sg, uint32_t t, uint32_t &bucket, uint32_t &start, uint32_t &count)
+{
+    uint32_t lo = 0, hi = sg.nb1;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sg.tile0[mid] <= t) lo = mid; else hi = mid; }
+    bucket = lo;
+    start = sg.b1start[lo] + (t - sg.tile0[lo]) * (uint32_t)MT_TILE;
+    const uint32_t end = sg.b1start[lo + 1];
+    count = end - start < (uint32_t)MT_TILE ? end - start : (uint32_t)MT_TILE;
+}
+
+__global__ __launch_bounds__(MT_THREADS) void k_msd_hist2(const uint64_t *words, SegTiles sg, int shift, int bits, uint32_t *hist)
+{
+    __shared__ uint32_t h[MT_MAXBINS];
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
+    if (blockIdx.x >= sg.tile0[sg.nb1]) return;
+    for (uint32_t i = threadIdx.x; i < nbins; i += MT_THREADS) h[i] = 0;
+    __syncthreads();
+    uint32_t bucket, start, count;
+    seg_tile(sg, blockIdx.x, bucket, start, count);
+    uint64_t k[MT_ITEMS];
+#pragma unroll
+    for (int r = 0; r < MT_ITEMS; ++r) { const uint32_t q = (uint32_t)r * MT_THREADS + threadIdx.x; k[r] = q < count ? words[start + q] : 0; }
+#pragma unroll
+    for (int r = 0; r < MT_ITEMS; ++r) { const uint32_t q = (uint32_t)r * MT_THREADS + threadIdx.x; if (q < count) atomicAdd(&h[(uint32_t)(k[r] >> shift) & dmask], 1u); }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nbins; i += MT_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
+}
+
+// Second-digit places: one workgroup per first-digit bucket, thread d walks column d of the bucket's tile rows.  hist[t][d] becomes the place
+// of tile t's first key with digit d; b2start[bucket * nb2 + d] the place of the (bucket, d) sub-bucket — the buckets the count kernel walks.
+__global__ __launch_bounds__(MT_MAXBINS) void k_msd_segscan(uint32_t *hist, SegTiles sg, uint32_t nb2, uint32_t *b2start, uint64_t I)
+{
+    __shared__ uint32_t wsum[MT_MAXBINS / 64];
+    const uint32_t b = blockIdx.x, d = threadIdx.x, lane = d & 63, w = d >> 6;
+    const uint32_t t0 = sg.tile0[b], t1 = sg.tile0[b + 1];
+    uint32_t run = 0;
+    if (d < nb2) {
+        for (uint32_t t = t0; t < t1; t += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = t + u < t1 ? hist[(size_t)(t + u) * nb2 + d] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { if (t + u < t1) hist[(size_t)(t + u) * nb2 + d] = run; run += x[u]; }
+        }
+    }
+    uint32_t inc = run;
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= (uint32_t)s2) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = sg.b1start[b] + inc - run;
+    for (uint32_t ww = 0; ww < w; ++ww) base += wsum[ww];
+    if (d < nb2) {
+        b2start[(size_t)b * nb2 + d] = base;
+        for (uint32_t t = t0; t < t1; t += 8) {
+            uint32_t x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = t + u < t1 ? hist[(size_t)(t + u) * nb2 + d] : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (t + u < t1) hist[(size_t)(t + u) * nb2 + d] = x[u] + base;
+        }
+    }
+    if (b == gridDim.x - 1 && d == 0) b2start[(size_t)gridDim.x * nb2] = (uint32_t)I;
+}
+
+// ---- stable scatter of one tile by one digit --------------------------------------------------------------------------------------
+// ENUM: the tile's keys are enumerated from the reads (tile = 8192 consecutive instances) and the digit is the top b1 value bits, which the word
+// written does not hold any more.  !ENUM: the tile's keys are read from `in` (a bucket-aligned tile) and the digit is (word >> shift) & mask.
+// Ranking as in the radix sort of prims.hip: wave ballots per digit bit, per-wave digit counts in LDS, the tile ordered by digit in LDS and
+// written out by consecutive lanes (a digit's keys of one tile are one contiguous run in the output).
+template <bool ENUM>
+__global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const BlockInfo *block_read, MsdParams m, const uint64_t *in, SegTiles sg, int shift, int bits,
+                                                           const uint32_t *hist_scanned, uint64_t *out)
+{
+    constexpr int WAVES = MT_THREADS / 64, DPT = MT_MAXBINS / MT_THREADS;
+    __shared__ uint16_t whist[WAVES][MT_MAXBINS];
+    __shared__ uint32_t lstart[MT_MAXBINS], gbase[MT_MAXBINS], wsum[WAVES];
+    __shared__ uint64_t lkey[MT_TILE];
+    __shared__ unsigned long long hbits[MT_TILE / 64];
+    __shared__ uint32_t hpre[MT_TILE / 64], delta[MT_MAXBINS];
+    volatile uint16_t(*vh)[MT_MAXBINS] = whist;
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
+    if (!ENUM && blockIdx.x >= sg.tile0[sg.nb1]) return;
+    for (int i = threadIdx.x; i < WAVES * MT_MAXBINS / 2; i += MT_THREADS) reinterpret_cast<uint32_t *>(&whist[0][0])[i] = 0;
+    if (threadIdx.x < MT_TILE / 64) hbits[threadIdx.x] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint64_t lt = (1ull << lane) - 1;
+    uint64_t key[MT_ITEMS];
+    uint32_t dig2[MT_ITEMS / 2];    // the items' digits, two per register (0xFFFF: no key)
+    uint32_t count = 0;
+    auto digit = [&](int it) -> uint32_t { return (dig2[it >> 1] >> ((it & 1) * 16)) & 0xFFFFu; };
+    auto set_digit = [&](int it, uint32_t d) { if (it & 1) dig2[it >> 1] |= d << 16; else dig2[it >> 1] = d; };
+    if (ENUM) {
+        const uint64_t tbase = (uint64_t)blockIdx.x * MT_TILE, base = tbase + (uint64_t)w * (MT_ITEMS * 64);
+        const uint64_t left = e.I - tbase;
+        count = left < (uint64_t)MT_TILE ? (uint32_t)left : (uint32_t)MT_TILE;
+        uint32_t r = 0;
+        uint64_t off_lo = 0, off_hi = 0, boff = 0;
+        if (base < e.I) { const ReadCursor rc = cursor_at(e, block_read, base); r = rc.lo; off_lo = rc.off_lo; off_hi = rc.off_hi; boff = rc.boff; }
+        const uint64_t vmask = (1ull << (m.k2 - m.b1)) - 1;
+#pragma unroll
+        for (int it = 0; it < MT_ITEMS; ++it) {
+            const uint64_t g = base + (uint64_t)it * 64 + lane;
+            key[it] = 0;
+            uint32_t dg = 0xFFFFu;
+            if (g < e.I) {
+                while (g >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }
+                const uint32_t p = (uint32_t)(g - off_lo);
+                const uint64_t km = canonical_at_off(e, boff, p);
+                dg = (uint32_t)(km >> (64 - m.b1));
+                key[it] = (((km >> (64 - m.k2)) & vmask) << m.PB) | ((uint64_t)r << m.pbits) | p;
+            }
+            set_digit(it, dg);
+        }
+    } else {
+        uint32_t bucket, start;
+        seg_tile(sg, blockIdx.x, bucket, start, count);
+        const uint32_t wb = (uint32_t)w * (MT_ITEMS * 64);
+#pragma unroll
+        for (int it = 0; it < MT_ITEMS; ++it) {
+            const uint32_t q = wb + (uint32_t)it * 64 + lane;
+            key[it] = q < count ? in[start + q] : 0;
+        }
+#pragma unroll
+        for (int it = 0; it < MT_ITEMS; ++it) {
+            const uint32_t q = wb + (uint32_t)it * 64 + lane;
+            set_digit(it, q < count ? (uint32_t)(key[it] >> shift) & dmask : 0xFFFFu);
+        }
+    }
+    // (the tile's row of output places: one coalesced load, in flight while the ranks are computed)
+    uint32_t gb[DPT];
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * MT_THREADS; gb[u] = d < nbins ? hist_scanned[(size_t)blockIdx.x * nbins + d] : 0u; }
+    uint32_t rank[MT_ITEMS];
+#pragma unroll
+    for (int it = 0; it < MT_ITEMS; ++it) {
+        const uint32_t d = digit(it);
+        const bool valid = d != 0xFFFFu;
+        uint64_t mask = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < MT_MAXBITS; ++b) {
+            if (b < bits) {
+                const uint64_t bal = __ballot((d >> b) & 1u);
+                mask &= ((d >> b) & 1u) ? bal : ~bal;
+            }
+        }
+        const int leader = valid ? (__ffsll((unsigned long long)mask) - 1) : lane;
+        const uint32_t cnt = (uint32_t)__popcll(mask);
+        uint32_t pre = 0;
+        if (valid && lane == leader) { pre = vh[w][d]; vh[w][d] = (uint16_t)(pre + cnt); }
+        pre = __shfl(pre, leader, 64);
+        rank[it] = pre + (uint32_t)__popcll(mask & lt);
+    }
+    __syncthreads();
+    {
+        uint32_t tot[DPT], both = 0;
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const uint32_t d = DPT * threadIdx.x + u;
+            uint32_t t = 0;
+            if (d < nbins) {
+#pragma unroll
+                for (int ww = 0; ww < WAVES; ++ww) { const uint32_t x = whist[ww][d]; whist[ww][d] = (uint16_t)t; t += x; }
+            }
+            tot[u] = t; both += t;
+        }
+        uint32_t inc = both;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= s2) inc += o; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t run = inc - both;
+        for (int ww = 0; ww < w; ++ww) run += wsum[ww];
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = DPT * threadIdx.x + u; if (d < nbins) lstart[d] = run; run += tot[u]; }
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * MT_THREADS; if (d < nbins) gbase[d] = gb[u]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < MT_ITEMS; ++it) {
+        const uint32_t d = digit(it);
+        if (d != 0xFFFFu) lkey[lstart[d] + whist[w][d] + rank[it]] = key[it];
+    }
+    // The tile now lies ordered by digit in LDS, but an ENUM word does not hold its digit any more.  A place finds its digit's run from a
+    // bitmap of the run starts: run number = set bits at or before the place, delta[run] = the run's place in the output - its place in the tile.
+    {
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) {
+            const uint32_t d = DPT * threadIdx.x + u;
+            if (d < nbins) { const uint32_t ls = lstart[d], le = d + 1 < nbins ? lstart[d + 1] : count; if (le > ls) atomicOr(&hbits[ls >> 6], 1ull << (ls & 63u)); }
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        const uint32_t c0 = (uint32_t)__popcll(hbits[2 * lane]), c1 = (uint32_t)__popcll(hbits[2 * lane + 1]);
+        uint32_t inc = c0 + c1;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= s2) inc += o; }
+        hpre[2 * lane] = inc - c0 - c1; hpre[2 * lane + 1] = inc - c1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) {
+        const uint32_t d = DPT * threadIdx.x + u;
+        if (d < nbins) {
+            const uint32_t ls = lstart[d], le = d + 1 < nbins ? lstart[d + 1] : count;
+            if (le > ls) delta[hpre[ls >> 6] + (uint32_t)__popcll(hbits[ls >> 6] & ((1ull << (ls & 63u)) - 1ull))] = gbase[d] - ls;
+        }
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < count; t += MT_THREADS) {
+        const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & ((2ull << (t & 63u)) - 1ull)) - 1u;
+        out[delta[run] + t] = lkey[t];
+    }
+}
+
+// ---- the bucket kernel ---------------------------------------------------------------------------------------------------------------
+// One workgroup per bucket (the instances whose top 2k - 16 value bits agree), in two halves of 2^15 values each:
+//   count      every instance adds 1 to its value's 16-bit counter in LDS (two counters per word);
+//   classify   every instance looks its value's count up; reliable (LOWER <= count <= UPPER) values are marked in a bitmap (1024 words: one per
+//              lane), every value seen in another (the number of distinct k-mers);
+//   number     lane t walks the SET BITS of word t — in value order — and sums their counts; a scan over the lanes gives the k-mer id and the
+//              column pointer of every reliable value (k-mer id = rank of the value).  <false> stops here: N, Z of the bucket.
+//   windows    <true>: the reliable columns are staged EW entries at a time: the lanes write their values' window-local column numbers into the
+//              table (16-bit stores over the counts), every instance of such a value draws a slot in its column (LDS atomic) and leaves its
+//              payload there; one lane per column sorts it by (read, pos) and computes the ownership hints of its entries; the staged window
+//              leaves as coalesced streams: columns, CSR sort keys, padded columns.
+// Per bucket the work is proportional to its instances and reliable values (plus zeroing 72 KB of LDS), not to the 2^16 values it spans.
+struct BucketStats { unsigned long long distinct, sumsq; unsigned int maxcol, pad; };
+struct BucketOut {
+    uint64_t *rel_kmers; uint32_t *rel_counts, *colptr;
+    uint64_t *csc, *csr_words, *kid_of_entry, *ell;
+    uint32_t ell_stride;      // 0: no padded column store
+    int nb, pb;               // CSR sort key: read << (nb + pb + 2) | kid << (pb + 2) | hint << pb | pos
+    uint32_t hints;           // write the ownership bits (Ctx::csr_hints)
+};
+
+template <bool EMIT>
+__global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words, const uint32_t *b2start, uint32_t nbuckets, MsdParams m, uint32_t lower, uint32_t upper,
+                                                          uint32_t *bN, uint32_t *bZ, BucketStats *gstat, const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    // LDS, in words: table 16384 | reliable bitmap 1024 | seen bitmap 1024 | misc 64 | scan partials 64 | headpos KW + 1 | fill KW + 1 | staged entries | their columns
+    uint32_t *tab = smem;                                   // 2^15 counters of 16 bits; in a window: the window-local column number of the reliable values
+    uint16_t *tab16 = reinterpret_cast<uint16_t *>(smem);
+    uint32_t *relbits = smem + BK_TAB, *seenbits = relbits + 1024;
+    uint32_t *misc = smem + BK_TAB + 2048;
+    uint32_t *wsc = misc + 64;
+    uint32_t *headpos = wsc + 64;
+    uint32_t *fill = headpos + (KW + 1);
+    uint64_t *ent = reinterpret_cast<uint64_t *>(smem + BK_ENT);
+    uint16_t *entk = reinterpret_cast<uint16_t *>(ent + (EW + EPAD));
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t paymask = (1ull << m.PB) - 1, posmask = (1ull << m.pbits) - 1;
+    unsigned long long st_distinct = 0, st_sumsq = 0;
+    uint32_t st_maxcol = 0;
+
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
+        if (n == 0) { if (!EMIT && tid == 0) { bN[b] = 0; bZ[b] = 0; } continue; }
+        // the bucket's instances: the first KPT * 1024 live in registers, the rest (crowded buckets) is re-read from L2 in every pass
+        uint64_t kreg[KPT];
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; kreg[u] = i < n ? words[s0 + i] : 0; }
+        const bool guard = n > 65535u;          // a value's count could run over its 16 bits: stop counting beyond 2^15 (UPPER <= 255: unreliable anyway)
+        uint32_t n0 = 0, z0 = 0, nall = 0, zall = 0;
+#pragma unroll 1
+        for (uint32_t h = 0; h < 2; ++h) {
+            {   // zero the table and the two bitmaps (18 K words: 4.5 uint4 per lane)
+                uint4 *t4 = reinterpret_cast<uint4 *>(smem);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t4[(uint32_t)u * BK_THREADS + tid] = make_uint4(0u, 0u, 0u, 0u);
+                if (tid < 512) t4[4096 + tid] = make_uint4(0u, 0u, 0u, 0u);
+            }
+            __syncthreads();
+            auto for_keys = [&](auto &&f) {      // f(word) for every instance of this half
+#pragma unroll
+                for (int u = 0; u < KPT; ++u) if ((uint32_t)u * BK_THREADS + tid < n && (((uint32_t)(kreg[u] >> (m.PB + 15)) & 1u) == h)) f(kreg[u]);
+                for (uint32_t i = (uint32_t)KPT * BK_THREADS + tid; i < n; i += BK_THREADS) { const uint64_t wd = words[s0 + i]; if ((((uint32_t)(wd >> (m.PB + 15)) & 1u) == h)) f(wd); }
+            };
+            for_keys([&](uint64_t wd) {
+                const uint32_t idx = (uint32_t)(wd >> m.PB) & 0x7FFFu;
+                if (guard && tab16[idx] >= 0x8000u) return;
+                atomicAdd(&tab[idx >> 1], 1u << ((idx & 1u) * 16u));
+            });
+            __syncthreads();
+            for_keys([&](uint64_t wd) {
+                const uint32_t idx = (uint32_t)(wd >> m.PB) & 0x7FFFu, cnt = tab16[idx];
+                if (!EMIT) atomicOr(&seenbits[idx >> 5], 1u << (idx & 31u));
+                if (cnt >= lower && cnt <= upper) atomicOr(&relbits[idx >> 5], 1u << (idx & 31u));
+            });
+            __syncthreads();
+            // lane t owns the values 32 t .. 32 t + 31: its reliable ones, in value order, are the set bits of word t
+            const uint32_t mybits = relbits[tid];
+            uint32_t nrel = (uint32_t)__popc(mybits), nent = 0;
+            for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
+                const uint32_t cnt = tab16[tid * 32u + (uint32_t)__ffs((int)bits) - 1u];
+                nent += cnt;
+                if (!EMIT) { st_sumsq += (unsigned long long)cnt * cnt; st_maxcol = cnt > st_maxcol ? cnt : st_maxcol; }
+            }
+            if (!EMIT) st_distinct += (unsigned long long)__popc(seenbits[tid]);
+            // exclusive scan of (nrel, nent) over the 1024 lanes
+            uint32_t ir = nrel, ie = nent;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t a = __shfl_up(ir, d, 64), c2 = __shfl_up(ie, d, 64); if ((int)lane >= d) { ir += a; ie += c2; } }
+            if (lane == 63) { wsc[wv] = ir; wsc[16 + wv] = ie; }
+            __syncthreads();
+            uint32_t R = ir - nrel, E = ie - nent, totR = 0, totE = 0;
+#pragma unroll
+            for (uint32_t ww = 0; ww < BK_THREADS / 64; ++ww) { const uint32_t a = wsc[ww], c2 = wsc[16 + ww]; if (ww < wv) { R += a; E += c2; } totR += a; totE += c2; }
+            if (h == 0) { n0 = totR; z0 = totE; }
+            nall += totR; zall += totE;
+            if (EMIT && totR != 0) {
+                const uint32_t kb = kidbase[b] + (h ? n0 : 0u), eb = entbase[b] + (h ? z0 : 0u);
+                {   // the reliable k-mers of this lane's values: k-mer (left-aligned, src/Kmer.cpp:78-86), count, column pointer
+                    uint32_t r2 = R, e2 = E;
+                    for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
+                        const uint32_t idx = tid * 32u + (uint32_t)__ffs((int)bits) - 1u, cnt = tab16[idx];
+                        const uint64_t value = ((uint64_t)b << VBITS) | (h << 15) | idx;
+                        o.rel_kmers[kb + r2] = value << (64 - m.k2); o.rel_counts[kb + r2] = cnt; o.colptr[kb + r2] = eb + e2;
+                        ++r2; e2 += cnt;
+                    }
+                }
+                // Windows of EW staged entries.  A window's values carry their window-local column number in the table while it is staged (bit 15
+                // set: a reliable count is <= 255) and get their count back — fill[], every instance of the column placed — when it is done.
+                const uint32_t nwin = (totE + EW - 1) / EW;
+#pragma unroll 1
+                for (uint32_t wn = 0; wn < nwin; ++wn) {
+                    const uint32_t wlo = wn * EW;
+                    __syncthreads();                       // (the previous window's staging area is free; wsc has been read)
+                    if (tid == 0) { misc[0] = 0xFFFFFFFFu; misc[1] = 0; misc[2] = 0; }
+                    __syncthreads();
+                    {   // first column of the window
+                        uint32_t r2 = R, e2 = E;
+                        for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
+                            const uint32_t cnt = tab16[tid * 32u + (uint32_t)__ffs((int)bits) - 1u];
+                            if (e2 >= wlo && e2 < wlo + EW) { atomicMin(&misc[0], r2); break; }
+                            ++r2; e2 += cnt;
+                        }
+                    }
+                    __syncthreads();
+                    const uint32_t klo = misc[0];
+                    {   // the table now maps the window's values to their column's number inside the window; the columns' places in the staging area
+                        uint32_t r2 = R, e2 = E, kmax = 0, emax = 0;
+                        for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
+                            const uint32_t idx = tid * 32u + (uint32_t)__ffs((int)bits) - 1u, cnt = tab16[idx];
+                            if (e2 >= wlo && e2 < wlo + EW) {
+                                const uint32_t kl = r2 - klo;
+                                tab16[idx] = (uint16_t)(0x8000u | kl); headpos[kl] = e2 - wlo; fill[kl] = 0;
+                                kmax = kl + 1; emax = e2 - wlo + cnt;
+                            }
+                            ++r2; e2 += cnt;
+                        }
+                        if (kmax) { atomicMax(&misc[1], kmax); atomicMax(&misc[2], emax); }
+                    }
+                    __syncthreads();
+                    const uint32_t ncolw = misc[1], nentw = misc[2];
+                    for_keys([&](uint64_t wd) {
+                        const uint32_t idx = (uint32_t)(wd >> m.PB) & 0x7FFFu;
+                        if (!((relbits[idx >> 5] >> (idx & 31u)) & 1u)) return;
+                        const uint32_t code = tab16[idx];
+                        if (!(code & 0x8000u)) return;       // a reliable value of another window (its count, <= 255, sits there)
+                        const uint32_t kl = code & 0x7FFFu;
+                        const uint32_t at = headpos[kl] + atomicAdd(&fill[kl], 1u);
+                        ent[at] = wd & paymask; entk[at] = (uint16_t)kl;
+                    });
+                    __syncthreads();
+                    // the window's values get their counts back (the next window tells its columns from the others by the code bit)
+                    for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
+                        const uint32_t idx = tid * 32u + (uint32_t)__ffs((int)bits) - 1u, code = tab16[idx];
+                        if (code & 0x8000u) tab16[idx] = (uint16_t)fill[code & 0x7FFFu];
+                    }
+                    // every column of the window is sorted by (read, pos) = by payload, by one lane; the ownership hints of its entries with it
+                    for (uint32_t kl = tid; kl < ncolw; kl += BK_THREADS) {
+                        const uint32_t p0 = headpos[kl], L = fill[kl];
+                        for (uint32_t a = 1; a < L; ++a) {
+                            const uint64_t v = ent[p0 + a];
+                            uint32_t q = a;
+                            while (q > 0 && ent[p0 + q - 1] > v) { ent[p0 + q] = ent[p0 + q - 1]; --q; }
+                            ent[p0 + q] = v;
+                        }
+                        if (o.hints && L <= HINT_MAX_COL) {
+                            // Ctx::csr_hints: an entry whose row accumulates no pair of this column under the parity rule (and occurs in it once) is marked
+                            for (uint32_t a = 0; a < L; ++a) {
+                                const uint32_t i = (uint32_t)(ent[p0 + a] >> m.pbits);
+                                bool own = false; uint32_t mult = 0;
+                                for (uint32_t t = 0; t < L; ++t) {
+                                    const uint32_t j = (uint32_t)((ent[p0 + t] & paymask) >> m.pbits);
+                                    if (j == i) { ++mult; continue; }
+                                    own |= ((i ^ j) & 1u) ? j < i : j > i;
+                                }
+                                if (mult < 2 && !own) ent[p0 + a] |= 3ull << 62;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    for (uint32_t p = headpos[0] + tid; p < nentw; p += BK_THREADS) {      // (the window's first column may start a few places in: the previous window's last column reaches that far)
+                        const uint64_t x = ent[p];
+                        const uint64_t read = (x & paymask) >> m.pbits, pos = x & posmask, hint = x >> 62;
+                        const uint32_t z = eb + wlo + p, kid = kb + klo + entk[p];
+                        o.csc[z] = (read << 32) | pos;
+                        if (o.csr_words) o.csr_words[z] = (read << (o.nb + o.pb + 2)) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
+                        else o.kid_of_entry[z] = kid;
+                    }
+                    if (o.ell_stride) {
+                        const uint32_t S = o.ell_stride, nq = ncolw * S;
+                        uint64_t *dst = o.ell + (uint64_t)(kb + klo) * S;
+                        for (uint32_t q = tid; q < nq; q += BK_THREADS) {
+                            const uint32_t kl = q / S, j = q - kl * S;
+                            uint64_t v = ~0ull;
+                            if (j < fill[kl]) { const uint64_t x = ent[headpos[kl] + j]; v = (((x & paymask) >> m.pbits) << 32) | (x & posmask); }
+                            dst[q] = v;
+                        }
+                    }
+                }
+            }
+            __syncthreads();                               // wsc, the table and the staging area are reused by the next half / bucket
+        }
+        if (!EMIT && tid == 0) { bN[b] = nall; bZ[b] = zall; }
+    }
+    if (!EMIT) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            st_distinct += __shfl_xor(st_distinct, d, 64); st_sumsq += __shfl_xor(st_sumsq, d, 64);
+            const uint32_t o2 = __shfl_xor(st_maxcol, d, 64); st_maxcol = o2 > st_maxcol ? o2 : st_maxcol;
+        }
+        if (lane == 0) { if (st_distinct) atomicAdd(&gstat->distinct, st_distinct); if (st_sumsq) atomicAdd(&gstat->sumsq, st_sumsq); if (st_maxcol) atomicMax(&gstat->maxcol, st_maxcol); }
+    }
+}
+
+int bits_needed_u(uint64_t maxval)
+{
+    int b = 1;
+    while (b < 64 && (maxval >> b)) ++b;
+    return b;
+}
+
+}  // namespace
+
+// The k-mer stage of one GPU for 9 <= k <= 17 (see the file header).  Leaves behind exactly what runs_to_columns (kmer.hip) leaves: rel_kmers,
+// rel_counts, a_colptr, a_csc, the CSR sort keys (csr_words, hint bits included) or kid_of_entry — plus the padded column store.
+bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
+{
+    const int k = c.cfg.k, k2 = 2 * k, T = k2 - VBITS;
+    if (c.opt.kmer_no_msd || c.opt.kmer_pairs || c.opt.kmer_unfused || c.opt.emit_plain || c.opt.kmer_drop) return false;
+    if (T < 2 || T > 2 * MT_MAXBITS || c.cfg.upper > 255 || I == 0) return false;
+    // worth it from ~1024 instances per bucket on (the bucket kernel pays ~2 us per bucket whatever it holds); smaller inputs keep the sort
+    if (!c.opt.kmer_msd && I < ((uint64_t)1024 << T)) return false;
+    uint32_t maxlen = 0;
+    for (int64_t r = 0; r < c.nreads; ++r) maxlen = c.h_len[(size_t)r] > maxlen ? c.h_len[(size_t)r] : maxlen;
+    const uint64_t maxpos = maxlen >= (uint32_t)k ? maxlen - (uint32_t)k : 0;
+    MsdParams m{};
+    m.k2 = k2; m.b1 = (T + 1) / 2; m.b2 = T - m.b1; m.I = I;
+    m.pbits = bits_needed_u(maxpos);
+    const int mb = bits_needed_u((uint64_t)(c.nreads > 0 ? c.nreads - 1 : 0));
+    m.PB = mb + m.pbits;
+    if (m.b2 + VBITS + m.PB > 62) return false;      // (the two top bits of a staged entry carry its hint)
+    hipStream_t s = c.stream;
+    const uint32_t nb1 = 1u << m.b1, nb2 = 1u << m.b2, nbuckets = nb1 * nb2;
+    const uint32_t ntiles1 = (uint32_t)((I + MT_TILE - 1) / MT_TILE), ntiles2 = ntiles1 + nb1;
+
+    c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8);
+    c.ws_sort.reserve(((size_t)ntiles2 << MT_MAXBITS) * 4 + 4096);
+    c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 5 + (size_t)(2 * nb1 + 8) * 4 + 256);
+    uint32_t *hist = c.ws_sort.as<uint32_t>();
+    BucketStats *gstat = c.ws_e.as<BucketStats>();
+    uint32_t *b2start = c.ws_e.as<uint32_t>() + 16, *bN = b2start + (nbuckets + 2), *bZ = bN + (nbuckets + 2), *kidbase = bZ + (nbuckets + 2), *entbase = kidbase + (nbuckets + 2);
+    uint32_t *b1start = entbase + (nbuckets + 2), *tile0 = b1start + (nb1 + 2);
+    uint64_t *wa = c.ws_a.as<uint64_t>(), *wb = c.ws_c.as<uint64_t>();
+
+    c.t_total.start(s);
+    c.t_a.start(s);
+    EnumParams e{};
+    e.packed = c.d_packed; e.byte_off = c.d_byte_off; e.len = c.d_len; e.inst_off = c.inst_off.as<uint64_t>();
+    e.nreads = (uint32_t)c.nreads; e.I = I; e.k = k;
+    const uint64_t nib = (I >> IB_SHIFT) + 1;
+    c.ws_b.reserve((size_t)(nib + 1) * sizeof(BlockInfo));
+    const BlockInfo *bi = c.ws_b.as<BlockInfo>();
+    hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
+    // first digit
+    hipLaunchKernelGGL(k_msd_hist1, dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, hist);
+    radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
+    SegTiles sg{b1start, tile0, nb1};
+    hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
+    hipLaunchKernelGGL((k_msd_scatter<true>), dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa);
+    // second digit, inside every first-digit bucket
+    const int shift2 = m.PB + VBITS;
+    hipLaunchKernelGGL(k_msd_hist2, dim3(ntiles2), dim3(MT_THREADS), 0, s, (const uint64_t *)wa, sg, shift2, m.b2, hist);
+    hipLaunchKernelGGL(k_msd_segscan, dim3(nb1), dim3(MT_MAXBINS), 0, s, hist, sg, nb2, b2start, I);
+    hipLaunchKernelGGL((k_msd_scatter<false>), dim3(ntiles2), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sg, shift2, m.b2, (const uint32_t *)hist, wb);
+    c.t_a.stop(s);
+    // buckets: count
+    c.t_b.start(s);
+    static bool attr_done = false;
+    const size_t lds_count = BK_LDS_COUNT, lds_emit = BK_LDS_EMIT;
+    if (!attr_done) {
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_bucket<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_bucket<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
+    const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 2u);
+    BucketOut o{};
+    hipLaunchKernelGGL((k_msd_bucket<false>), dim3(bgrid), dim3(BK_THREADS), lds_count, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper,
+                       bN, bZ, gstat, (const uint32_t *)nullptr, (const uint32_t *)nullptr, o);
+    ELBA_HIP(hipMemsetAsync(bN + nbuckets, 0, 4, s)); ELBA_HIP(hipMemsetAsync(bZ + nbuckets, 0, 4, s));
+    exclusive_scan_u32(s, bN, kidbase, (int64_t)nbuckets + 1, c.ws_scan);
+    exclusive_scan_u32(s, bZ, entbase, (int64_t)nbuckets + 1, c.ws_scan);      // Z <= I < 2^32
+    uint32_t h2[2] = {0, 0};
+    BucketStats hs{};
+    ELBA_HIP(hipMemcpyAsync(&h2[0], kidbase + nbuckets, 4, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipMemcpyAsync(&h2[1], entbase + nbuckets, 4, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipMemcpyAsync(&hs, gstat, sizeof(hs), hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    const uint64_t N = h2[0], Z = h2[1];
+    ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
+    // buckets: emit
+    c.rel_kmers.reserve((size_t)(N + 1) * 8);
+    c.rel_counts.reserve((size_t)(N + 2) * 4);
+    c.a_colptr.reserve((size_t)(N + 2) * 4);
+    c.a_csc.reserve((size_t)(Z + 8) * 8);
+    const int nb = bits_needed_u((uint64_t)(N > 0 ? N - 1 : 0)), pb = m.pbits;
+    const bool words = mb + nb + pb + 2 <= 64 && !c.opt.csr_pairs;
+    const bool hints = pb <= 30 && !c.opt.no_hints;
+    o.rel_kmers = c.rel_kmers.as<uint64_t>(); o.rel_counts = c.rel_counts.as<uint32_t>(); o.colptr = c.a_colptr.as<uint32_t>();
+    o.csc = c.a_csc.as<uint64_t>(); o.nb = nb; o.pb = pb; o.hints = hints && words ? 1u : 0u;
+    if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
+    else { c.kid_of_entry.reserve((size_t)(Z + 8) * 8); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); }
+    c.max_col_nnz = (int64_t)hs.maxcol;
+    choose_column_store(c, (int64_t)N, c.max_col_nnz);
+    o.ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; o.ell_stride = c.use_ell ? c.s_stride : 0u;
+    if (Z > 0)
+        hipLaunchKernelGGL((k_msd_bucket<true>), dim3(bgrid), dim3(BK_THREADS), lds_emit, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper,
+                           bN, bZ, gstat, (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+    const uint32_t Zz = (uint32_t)Z;
+    ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
+    c.prod_ctr.reserve(64 * 128);
+    ELBA_HIP(hipMemsetAsync(c.prod_ctr.p, 0, 64 * 128, s));
+    const unsigned long long sq = hs.sumsq;
+    ELBA_HIP(hipMemcpyAsync(c.prod_ctr.p, &sq, 8, hipMemcpyHostToDevice, s));
+    c.t_b.stop(s);
+    c.t_total.stop(s);
+    ELBA_HIP(hipStreamSynchronize(s));
+    c.pre_ready = true; c.pre_consumed = false; c.pre_words = words; c.pre_hints = hints; c.pre_hints_done = hints && words; c.pre_ell_done = true;
+    c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos;
+    st.instances = (int64_t)I; st.distinct = (int64_t)hs.distinct; st.reliable = (int64_t)N; st.entries = (int64_t)Z;
+    st.ms_total = c.t_total.ms(); st.ms_count = c.t_a.ms(); st.ms_sort = c.t_b.ms(); st.ms_lookup = 0;
+    c.ndistinct = (int64_t)hs.distinct;
+    c.N = (int64_t)N; c.Z = (int64_t)Z;
+    return true;
+}
+
+}  // namespace elba

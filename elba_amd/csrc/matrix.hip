@@ -155,6 +155,39 @@ int64_t max_segment_len(Ctx &c, const uint32_t *ptr, int64_t nseg)
     return (int64_t)h;
 }
 
+// The column store the SpGEMM gathers from.  No column longer than 64 entries (UPPER <= 64: every configuration the reference
+// documents): columns padded to a common stride S (4 entries, or whole 64-byte lines), column kid at kid * S — its address is arithmetic, and a
+// group of S/2 lanes reads it as one aligned segment.  Longer columns (or no room for the padding): the plain CSC, reached through a_colptr.
+// Sets use_ell, s_stride, lpc_log2, fbits and reserves a_ell (guard words written); the caller fills it.
+void choose_column_store(Ctx &c, int64_t N, int64_t max_col)
+{
+    hipStream_t s = c.stream;
+    const uint32_t mc = (uint32_t)(max_col > 0 ? max_col : 1);
+    // stride: 4 entries, else the longest column rounded up to whole 64-byte lines (8 entries) — a power of two is not needed: the kernel
+    // multiplies (U = 35: 40 entries = 5 lines per gather where 64 entries would fetch 8)
+    const uint32_t stride = mc <= 4 ? 4u : (mc + 7u) & ~7u;
+    size_t free_b = 0, total_b = 0;
+    ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
+    const size_t ell_bytes = (size_t)N * stride * 8;
+    c.use_ell = mc <= 64 && N > 0 && !c.opt.no_ell && ell_bytes <= (free_b + c.a_ell.cap) / 3 && (uint64_t)N * stride < (1ull << 40);
+    if (c.use_ell) {
+        uint32_t lb = 1, fb = 2;
+        while ((2u << lb) < stride) ++lb;              // lanes per row entry: 16 bytes (two entries) each
+        while ((1u << fb) < stride) ++fb;
+        c.s_stride = stride; c.lpc_log2 = lb; c.fbits = fb;
+        c.a_ell.reserve(ell_bytes + 64);
+        ELBA_HIP(hipMemsetAsync(c.a_ell.as<char>() + ell_bytes, 0xFF, 64, s));      // (guard words behind the last column)
+    } else {
+        // lanes per row entry: half the longest column, between 2 and 64 (a column is walked in chunks of 2 * lanes entries)
+        uint32_t lb = 1;
+        while (lb < 6 && (2u << lb) < mc) ++lb;
+        c.lpc_log2 = lb; c.s_stride = 0;
+        int fb = 1;
+        while (fb < 31 && ((uint64_t)(mc > 1 ? mc - 1 : 1) >> fb)) ++fb;
+        c.fbits = (uint32_t)fb;
+    }
+}
+
 // Input: Z entries sorted by (kid, read, pos): kid_keys[z] >> kid_shift = kid, csc[z] = read<<32|pos (device, in c.a_csc or elsewhere).
 // Produces c.a_colptr, c.a_csc (copy if csc is not already c.a_csc), c.a_rowptr, c.a_csr, max_row_nnz, max_col_nnz.
 // [win_lo, win_hi) = the rows of B this context computes (win_hi < 0: all); the product schedule is laid out for those rows only.
@@ -192,36 +225,12 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.prod_ctr.reserve(64 * 128);
     unsigned long long *prod_ctr = c.prod_ctr.as<unsigned long long>();
     if (!pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 64 * 128, s));      // (pre: k_runs_emit has counted)
-    // The column store the SpGEMM gathers from.  No column longer than 64 entries (UPPER <= 64: every configuration the reference
-    // documents): columns padded to a common stride S (4 entries, or whole 64-byte lines), column kid at kid * S — its address is arithmetic, and a group of S/2
-    // lanes reads it as one aligned segment.  Longer columns (or no room for the padding): the plain CSC, reached through a_colptr.
-    c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
-    {
-        const uint32_t mc = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
-        // stride: 4 entries, else the longest column rounded up to whole 64-byte lines (8 entries) — a power of two is not needed: the kernel
-        // multiplies (U = 35: 40 entries = 5 lines per gather where 64 entries would fetch 8)
-        const uint32_t stride = mc <= 4 ? 4u : (mc + 7u) & ~7u;
-        size_t free_b = 0, total_b = 0;
-        ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
-        const size_t ell_bytes = (size_t)N * stride * 8;
-        c.use_ell = mc <= 64 && N > 0 && !c.opt.no_ell && ell_bytes <= (free_b + c.a_ell.cap) / 3 && (uint64_t)N * stride < (1ull << 40);
+    if (!(pre && c.pre_ell_done)) {      // (the two-level partition of kmer_msd.hip writes the padded columns with the columns themselves)
+        c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
+        choose_column_store(c, N, c.max_col_nnz);
         if (c.use_ell) {
-            uint32_t lb = 1, fb = 2;
-            while ((2u << lb) < stride) ++lb;              // lanes per row entry: 16 bytes (two entries) each
-            while ((1u << fb) < stride) ++fb;
-            c.s_stride = stride; c.lpc_log2 = lb; c.fbits = fb;
-            c.a_ell.reserve(ell_bytes + 64);
-            ELBA_HIP(hipMemsetAsync(c.a_ell.as<char>() + ell_bytes, 0xFF, 64, s));      // (guard words behind the last column)
-            const uint64_t nslots = (uint64_t)N * stride;
-            hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 30)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), nslots, stride, c.a_ell.as<uint64_t>());
-        } else {
-            // lanes per row entry: half the longest column, between 2 and 64 (a column is walked in chunks of 2 * lanes entries)
-            uint32_t lb = 1;
-            while (lb < 6 && (2u << lb) < mc) ++lb;
-            c.lpc_log2 = lb; c.s_stride = 0;
-            int fb = 1;
-            while (fb < 31 && ((uint64_t)(mc > 1 ? mc - 1 : 1) >> fb)) ++fb;
-            c.fbits = (uint32_t)fb;
+            const uint64_t nslots = (uint64_t)N * c.s_stride;
+            hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 30)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), nslots, c.s_stride, c.a_ell.as<uint64_t>());
         }
     }
     // Dense matrices (columns of more than 16 reads, e.g. UPPER = 35 on 40x low-error reads: every row owns pairs of every column, hundreds of
@@ -237,7 +246,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         if (Z > 0 && !have_words)
             hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0,
                                hints, wlo, whi, prod_ctr);
-        if (Z > 0 && have_words && hints)
+        if (Z > 0 && have_words && hints && !c.pre_hints_done)
             hipLaunchKernelGGL(k_add_hints, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
         const int where = radix_sort_keys(s, w0, w1, Z, nb + pb + 2, nb + pb + 2 + mb, c.ws_sort);
         const uint64_t *sorted = where ? w1 : w0;

@@ -433,6 +433,14 @@ static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *
 
 }  // namespace
 
+// Exclusive prefix down every column of a tile-major histogram rows[nrows][nbins] plus the totals of all smaller digits (the sort's own
+// column scan, for the two-level partition of kmer_msd.hip)
+void radix_column_scan(hipStream_t s, uint32_t *rows, int64_t nrows, uint32_t nbins, DevBuf &tmp)
+{
+    tmp.reserve(column_scan_tmp_elems(nrows, nbins) * sizeof(uint32_t));
+    column_scan(s, rows, nrows, nbins, tmp.as<uint32_t>());
+}
+
 // For a producer that writes the keys of a radix_sort_keys call itself: where the first pass expects its histogram — row t = the digit
 // counts (1 << *bits of them, digit = key >> *shift) of the keys [t * tile, (t + 1) * tile) — so that the producer can count while it writes
 // and the sort skips its first histogram pass (radix_sort_keys(..., first_hist_done = true) with the same n, bits and workspace).

@@ -495,3 +495,50 @@ def test_create_kmer_matrix_twice_after_one_count_gives_the_same_matrices():
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st2, o)
     e.close()
+
+
+@pytest.mark.parametrize("k,lo,up", [(17, 2, 8), (17, 2, 40), (17, 3, 12), (15, 2, 8), (13, 2, 30), (11, 2, 60), (9, 2, 200)])
+def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up):
+    """k <= 17: the k-mer stage counts by a two-level value partition and an LDS count table per bucket (kmer_msd.hip) on inputs of some size;
+    the option "kmer_msd" forces it on a small one (most buckets empty or tiny).  Low-complexity reads (runs of one canonical k-mer at
+    neighbouring positions, k-mers far beyond UPPER), reads shorter than k and reads around the word boundaries of the packed stream included:
+    reliable k-mers, columns, rows, hints-carrying B and every statistic equal the oracle's."""
+    reads, _ = synth.make_reads(78 + k, 60000, 14, 2500, 700, error=0.08, min_len=100)
+    rng = np.random.default_rng(k)
+    extra = [b"A" * 300, b"AC" * 200, b"T" * 150 + b"G" * 150, b"ACG" * 120, b"ACGT" * 90] * 3
+    extra += [bytes(rng.choice(list(b"ACGT"), n).tolist()) for n in (k - 1, k, k + 1, k + 2, 31, 32, 33, 63, 64, 65, 3)]
+    seqs = list(reads) + extra
+    np.random.default_rng(5).shuffle(seqs)
+    packed, off, lens = po.pack_reads(seqs)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up, options={"kmer_msd": 1})
+    o = gu.oracle_run(packed, off, lens, k, lo, up, threads=8)
+    assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.create_kmer_matrix()                                  # the repeat call rebuilds from the column pointers (the sort keys were consumed)
+    st2 = e.create_seed_matrix()
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+
+
+def test_two_level_partition_windows_of_a_crowded_bucket():
+    """A genome of few distinct k-mers at high depth: single buckets of the two-level partition hold thousands of reliable columns and tens of
+    thousands of entries — more than one staging window per bucket half (kmer_msd.hip: EW) — and instances beyond what a workgroup keeps in registers."""
+    rng = np.random.default_rng(11)
+    unit = bytes(rng.choice(list(b"ACGT"), 24).tolist())
+    seqs = []
+    for r in range(1500):
+        # reads built from short mutations of one unit: a few thousand distinct k-mers that share their leading bases
+        s = bytearray(unit * 12)
+        for _ in range(6):
+            s[int(rng.integers(0, len(s)))] = int(rng.choice(list(b"ACGT")))
+        seqs.append(bytes(s))
+    packed, off, lens = po.pack_reads(seqs)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 250, options={"kmer_msd": 1})
+    o = gu.oracle_run(packed, off, lens, 17, 2, 250, threads=8)
+    assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
