@@ -130,6 +130,7 @@ struct Options {
     bool csr_pairs = false;     // (read, entry) pairs through the CSR sort instead of one word
     bool emit_plain = false;    // k-mer emit without the fused first histogram
     bool trace = false;         // progress lines on stderr
+    int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
     int dk = 2;                 // SpGEMM: rounds of gather trips in flight (1, 2, 4)
     int64_t aln_tiers = 0;      // x-drop register tiers as decimal digits (1248 = all), 0 = default

@@ -39,7 +39,7 @@ constexpr uint32_t KW = EW / 2 + 1;           // columns such a window can hold 
 constexpr uint32_t EPAD = 256;                // the last column of a window may reach this far beyond it (UPPER <= 255)
 constexpr uint32_t BK_TAB = 16384, BK_ENT = BK_TAB + 2048 + 128 + 2 * (KW + 1);      // word offsets in the bucket kernel's LDS (BK_ENT even: 8-byte aligned)
 static_assert(BK_ENT % 2 == 0, "staged entries are 8-byte words");
-constexpr size_t BK_LDS_COUNT = (size_t)(BK_TAB + 2048 + 128) * 4, BK_LDS_EMIT = (size_t)BK_ENT * 4 + (size_t)(EW + EPAD) * 10;
+constexpr size_t BK_LDS_EMIT = (size_t)BK_ENT * 4 + (size_t)(EW + EPAD) * 10;
 constexpr int KPT = 8;                        // instances of a bucket a lane keeps in registers (8192 per workgroup; beyond: re-read from L2)
 static_assert(MT_ITEMS * 64 == (1 << IB_SHIFT), "a wavefront's share of a tile is one block of the instance -> read table");
 
@@ -315,19 +315,10 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     }
 }
 
-// ---- the bucket kernel ---------------------------------------------------------------------------------------------------------------
-// One workgroup per bucket (the instances whose top 2k - 16 value bits agree), in two halves of 2^15 values each:
-//   count      every instance adds 1 to its value's 16-bit counter in LDS (two counters per word);
-//   classify   every instance looks its value's count up; reliable (LOWER <= count <= UPPER) values are marked in a bitmap (1024 words: one per
-//              lane), every value seen in another (the number of distinct k-mers);
-//   number     lane t walks the SET BITS of word t — in value order — and sums their counts; a scan over the lanes gives the k-mer id and the
-//              column pointer of every reliable value (k-mer id = rank of the value).  <false> stops here: N, Z of the bucket.
-//   windows    <true>: the reliable columns are staged EW entries at a time: the lanes write their values' window-local column numbers into the
-//              table (16-bit stores over the counts), every instance of such a value draws a slot in its column (LDS atomic) and leaves its
-//              payload there; one lane per column sorts it by (read, pos) and computes the ownership hints of its entries; the staged window
-//              leaves as coalesced streams: columns, CSR sort keys, padded columns.
-// Per bucket the work is proportional to its instances and reliable values (plus zeroing 72 KB of LDS), not to the 2^16 values it spans.
-struct BucketStats { unsigned long long distinct, sumsq; unsigned int maxcol, pad; };
+// LDS-only workgroup barrier: the global stores of a bucket (never read back by the workgroup) stay in flight
+__device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+struct BucketStats { unsigned long long distinct, sumsq; unsigned int maxcol, ncrowded; };
 struct BucketOut {
     uint64_t *rel_kmers; uint32_t *rel_counts, *colptr;
     uint64_t *csc, *csr_words, *kid_of_entry, *ell;
@@ -336,15 +327,246 @@ struct BucketOut {
     uint32_t hints;           // write the ownership bits (Ctx::csr_hints)
 };
 
+// ---- buckets: count ------------------------------------------------------------------------------------------------------------------
+// One workgroup per bucket (the instances whose top 2k - 16 value bits agree).  The 16 value bits left index a table of 16-bit counters in LDS
+// (two per word, 128 KB): one LDS atomic per instance gives the exact counts.  Every instance then looks its value's count up; reliable values
+// (LOWER <= count <= UPPER) are marked in a bitmap, the values seen at all in another (the number of distinct k-mers), and the instances of
+// reliable values — the entries of A — are copied, in no particular order, to the front of the bucket's place in `wrel`: the emit kernels read
+// those alone (a quarter of the instances on 15 %-error reads).  Out: reliable k-mers and entries per bucket (the scan over the buckets gives the
+// k-mer ids and column pointers), buckets too crowded for the small emit kernel.
+constexpr uint32_t CT_TAB = 32768, CT_BITS = 2048;      // words
+constexpr size_t CT_LDS = (size_t)(CT_TAB + 2 * CT_BITS + 64) * 4;
+__global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words, const uint32_t *b2start, uint32_t nbuckets, MsdParams m, uint32_t lower, uint32_t upper, uint32_t small_cap,
+                                                         uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint32_t *crowded, uint64_t *wrel)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t *tab = smem;
+    const uint16_t *tab16 = reinterpret_cast<const uint16_t *>(smem);
+    uint32_t *relbits = smem + CT_TAB, *seenbits = relbits + CT_BITS, *misc = seenbits + CT_BITS;
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    unsigned long long st_distinct = 0, st_sumsq = 0;
+    uint32_t st_maxcol = 0;
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
+        if (n == 0) { if (tid == 0) { bN[b] = 0; bZ[b] = 0; } continue; }
+        uint64_t kreg[KPT];
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; kreg[u] = i < n ? words[s0 + i] : 0; }
+        {   // zero the table and the two bitmaps (36 K words = 9 uint4 per lane), and the counters
+            uint4 *t4 = reinterpret_cast<uint4 *>(smem);
+#pragma unroll
+            for (int u = 0; u < 9; ++u) t4[(uint32_t)u * BK_THREADS + tid] = make_uint4(0u, 0u, 0u, 0u);
+            if (tid < 16) misc[tid] = 0;
+        }
+        lds_sync();
+        const bool guard = n > 65535u;          // a value's count could run over its 16 bits: stop counting beyond 2^15 (UPPER <= 255: unreliable anyway)
+        auto for_keys = [&](auto &&f) {
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) if ((uint32_t)u * BK_THREADS + tid < n) f(kreg[u]);
+            for (uint32_t i = (uint32_t)KPT * BK_THREADS + tid; i < n; i += BK_THREADS) f(words[s0 + i]);
+        };
+        for_keys([&](uint64_t wd) {
+            const uint32_t v = (uint32_t)(wd >> m.PB) & 0xFFFFu;
+            if (guard && tab16[v] >= 0x8000u) return;
+            atomicAdd(&tab[v >> 1], 1u << ((v & 1u) * 16u));
+        });
+        lds_sync();
+        for_keys([&](uint64_t wd) {
+            const uint32_t v = (uint32_t)(wd >> m.PB) & 0xFFFFu, cnt = tab16[v];
+            atomicOr(&seenbits[v >> 5], 1u << (v & 31u));
+            if (cnt >= lower && cnt <= upper) {
+                atomicOr(&relbits[v >> 5], 1u << (v & 31u));
+                wrel[s0 + atomicAdd(&misc[0], 1u)] = wd;
+            }
+        });
+        lds_sync();
+        uint32_t nrel = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t wi = (uint32_t)q * BK_THREADS + tid, mybits = relbits[wi];
+            nrel += (uint32_t)__popc(mybits);
+            st_distinct += (unsigned long long)__popc(seenbits[wi]);
+            for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
+                const uint32_t cnt = tab16[wi * 32u + (uint32_t)__ffs((int)bits) - 1u];
+                st_sumsq += (unsigned long long)cnt * cnt; st_maxcol = cnt > st_maxcol ? cnt : st_maxcol;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nrel += __shfl_xor(nrel, d, 64);
+        if (lane == 0 && nrel) atomicAdd(&misc[1], nrel);
+        lds_sync();
+        if (tid == 0) {
+            const uint32_t Zb = misc[0], Nb = misc[1];
+            bN[b] = Nb; bZ[b] = Zb;
+            if (Zb > small_cap) crowded[atomicAdd(&gstat->ncrowded, 1u)] = b;
+        }
+        lds_sync();                               // (misc is zeroed for the next bucket)
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        st_distinct += __shfl_xor(st_distinct, d, 64); st_sumsq += __shfl_xor(st_sumsq, d, 64);
+        const uint32_t o2 = __shfl_xor(st_maxcol, d, 64); st_maxcol = o2 > st_maxcol ? o2 : st_maxcol;
+    }
+    if (lane == 0) { if (st_distinct) atomicAdd(&gstat->distinct, st_distinct); if (st_sumsq) atomicAdd(&gstat->sumsq, st_sumsq); if (st_maxcol) atomicMax(&gstat->maxcol, st_maxcol); }
+}
+
+// ---- buckets: emit (the usual case: at most ES_CAP entries) --------------------------------------------------------------------------------
+// The bucket's entries (wrel: instances of reliable k-mers, word = ... value16 << PB | read << pbits | pos, all with the same bits above) are
+// SORTED as 64-bit words in LDS — that is by (k-mer value, read, pos): columns in value order, each ordered by (read, pos) — with a bucket + rank
+// sort (the 16 value bits are spread evenly over a bucket: ~Z/8 equal value ranges, count, scan, scatter, then every entry ranks itself among
+// the handful that share its range).  A run of equal values is a column: its number (k-mer id = rank of the value) is the
+// number of run heads before it, its pointer the head's place.  Everything the sort path's k_runs_emit / k_add_hints / k_fill_ell produce
+// leaves from here as coalesced streams.  256 lanes, 44 KB of LDS: three workgroups per CU hide one another's barriers and memory waits.
+constexpr int ES_THREADS = 256, ES_KPT = 16;
+constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, ES_NSB = 512;
+__global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *wrel, const uint32_t *b2start, const uint32_t *bZ, uint32_t nbuckets, MsdParams m, uint32_t small_cap,
+                                                              const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
+{
+    __shared__ uint64_t A[ES_CAP];
+    __shared__ uint32_t sbcnt[ES_NSB], sbstart[ES_NSB + 1], H[ES_CAP / 2 + 2], hcnt[ES_KPT * 4 + 1], wsum[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t lt = (1ull << lane) - 1;
+    const uint64_t paymask = (1ull << m.PB) - 1, posmask = (1ull << m.pbits) - 1;
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        const uint32_t Z = bZ[b];
+        if (Z == 0 || Z > small_cap) continue;      // (crowded buckets: k_msd_bucket)
+        const uint32_t s0 = b2start[b];
+        uint64_t key[ES_KPT];
+#pragma unroll
+        for (int u = 0; u < ES_KPT; ++u) { const uint32_t i = (uint32_t)u * ES_THREADS + tid; key[u] = i < Z ? wrel[s0 + i] : ~0ull; }
+        // value ranges of the sort: 2^(16 - sh) of them, 4-8 entries each
+        uint32_t sh = 7;
+        while (sh < 16 && (Z >> (16 - sh)) < 4u) ++sh;
+        sbcnt[tid] = 0; sbcnt[tid + ES_THREADS] = 0;
+        lds_sync();
+        uint32_t slot[ES_KPT];
+#pragma unroll
+        for (int u = 0; u < ES_KPT; ++u) {
+            slot[u] = 0;
+            if ((uint32_t)u * ES_THREADS + tid < Z) slot[u] = atomicAdd(&sbcnt[((uint32_t)(key[u] >> m.PB) & 0xFFFFu) >> sh], 1u);
+        }
+        lds_sync();
+        {   // exclusive scan of the <= 512 range counts: 2 per lane
+            const uint32_t c0 = sbcnt[2 * tid], c1 = sbcnt[2 * tid + 1];
+            uint32_t inc = c0 + c1;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+            if (lane == 63) wsum[wv] = inc;
+            lds_sync();
+            uint32_t ex = inc - c0 - c1;
+            for (uint32_t ww = 0; ww < wv; ++ww) ex += wsum[ww];
+            sbstart[2 * tid] = ex; sbstart[2 * tid + 1] = ex + c0;
+            if (tid == ES_THREADS - 1) sbstart[ES_NSB] = ex + c0 + c1;
+        }
+        lds_sync();
+#pragma unroll
+        for (int u = 0; u < ES_KPT; ++u)
+            if ((uint32_t)u * ES_THREADS + tid < Z) A[sbstart[((uint32_t)(key[u] >> m.PB) & 0xFFFFu) >> sh] + slot[u]] = key[u];
+        lds_sync();
+#pragma unroll
+        for (int u = 0; u < ES_KPT; ++u) {
+            if ((uint32_t)u * ES_THREADS + tid < Z) {
+                const uint32_t sb = ((uint32_t)(key[u] >> m.PB) & 0xFFFFu) >> sh, lo = sbstart[sb], hi = sbstart[sb + 1];
+                uint32_t rank = 0;
+                for (uint32_t x = lo; x < hi; ++x) rank += A[x] < key[u] ? 1u : 0u;
+                slot[u] = lo + rank;
+            }
+        }
+        lds_sync();
+#pragma unroll
+        for (int u = 0; u < ES_KPT; ++u) if ((uint32_t)u * ES_THREADS + tid < Z) A[slot[u]] = key[u];
+        lds_sync();
+        // run heads, in place order p = u * 256 + tid; the column of place p = heads at or before it - 1
+        uint32_t headmask = 0;      // bit u: place u * 256 + tid heads a column
+#pragma unroll
+        for (int u = 0; u < ES_KPT; ++u) {
+            const uint32_t p = (uint32_t)u * ES_THREADS + tid;
+            const bool head = p < Z && (p == 0 || ((uint32_t)(A[p - 1] >> m.PB) & 0xFFFFu) != ((uint32_t)(A[p] >> m.PB) & 0xFFFFu));
+            const uint64_t bal = __ballot(head);
+            if (head) headmask |= 1u << u;
+            slot[u] = (uint32_t)__popcll(bal & lt) + (head ? 1u : 0u);      // heads at or before this place within its wavefront's 64 places
+            if (lane == 0) hcnt[u * 4 + wv] = (uint32_t)__popcll(bal);
+        }
+        lds_sync();
+        if (wv == 0) {      // exclusive scan of the 64 (u, wave) head counts, in place order
+            const uint32_t c = hcnt[lane];
+            uint32_t inc = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+            hcnt[lane] = inc - c;
+            if (lane == 63) hcnt[64] = inc;
+        }
+        lds_sync();
+        const uint32_t Nb = hcnt[64], kb = kidbase[b], eb = entbase[b];
+#pragma unroll
+        for (int u = 0; u < ES_KPT; ++u) {
+            slot[u] = hcnt[u * 4 + wv] + slot[u] - 1u;                      // the column of place u * 256 + tid
+            if ((headmask >> u) & 1u) H[slot[u]] = (uint32_t)u * ES_THREADS + tid;
+        }
+        if (tid == 0) H[Nb] = Z;
+        lds_sync();
+#pragma unroll
+        for (int u = 0; u < ES_KPT; ++u) {
+            const uint32_t p = (uint32_t)u * ES_THREADS + tid;
+            if (p < Z) {
+                const uint64_t x = A[p];
+                const uint32_t kl = slot[u], h0 = H[kl], L = H[kl + 1] - h0;
+                const uint64_t read = (x & paymask) >> m.pbits, pos = x & posmask;
+                uint64_t hint = 0;
+                if (o.hints && L <= HINT_MAX_COL) {
+                    // Ctx::csr_hints: an entry whose row accumulates no pair of this column under the parity rule (and occurs in it once) is marked
+                    bool own = false; uint32_t mult = 0;
+                    const uint32_t i = (uint32_t)read;
+                    for (uint32_t t = 0; t < L; ++t) {
+                        const uint32_t j = (uint32_t)((A[h0 + t] & paymask) >> m.pbits);
+                        if (j == i) { ++mult; continue; }
+                        own |= ((i ^ j) & 1u) ? j < i : j > i;
+                    }
+                    if (mult < 2 && !own) hint = 3;
+                }
+                const uint32_t z = eb + p, kid = kb + kl;
+                o.csc[z] = (read << 32) | pos;
+                if (o.csr_words) o.csr_words[z] = (read << (o.nb + o.pb + 2)) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
+                else o.kid_of_entry[z] = kid;
+                if ((headmask >> u) & 1u) {
+                    const uint64_t value = ((uint64_t)b << VBITS) | ((uint32_t)(x >> m.PB) & 0xFFFFu);
+                    o.rel_kmers[kid] = value << (64 - m.k2); o.rel_counts[kid] = L; o.colptr[kid] = z;
+                }
+            }
+        }
+        if (o.ell_stride) {
+            const uint32_t S = o.ell_stride, nq = Nb * S;
+            uint64_t *dst = o.ell + (uint64_t)kb * S;
+            for (uint32_t q = tid; q < nq; q += ES_THREADS) {
+                const uint32_t kl = q / S, j = q - kl * S, h0 = H[kl];
+                uint64_t v = ~0ull;
+                if (h0 + j < H[kl + 1]) { const uint64_t x = A[h0 + j]; v = (((x & paymask) >> m.pbits) << 32) | (x & posmask); }
+                dst[q] = v;
+            }
+        }
+        lds_sync();                               // A, H and the counters are reused by the next bucket
+    }
+}
+
+// ---- buckets: emit, crowded buckets (more than ES_CAP entries: repeats, very deep coverage) -------------------------------------------------------
+// One workgroup of 1024 lanes per bucket of the `crowded` list, reading ALL the bucket's instances again, in two halves of 2^15 values each:
+//   count, classify   as k_msd_count, on a 64 KB table;
+//   number     lane t walks the set bits of word t of the reliable bitmap — in value order — and sums their counts; a scan over the lanes gives
+//              the k-mer id and the column pointer of every reliable value;
+//   windows    the reliable columns are staged EW entries at a time: the lanes write their values' window-local column numbers into the
+//              table (16-bit stores over the counts), every instance of such a value draws a slot in its column (LDS atomic) and leaves its
+//              payload there; one lane per column sorts it by (read, pos) and computes the ownership hints of its entries; the staged window
+//              leaves as coalesced streams: columns, CSR sort keys, padded columns.
+// Any number of entries per bucket; ~45 us per bucket, which is why the usual buckets go through k_msd_emit_small.
 template <bool EMIT>
 __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words, const uint32_t *b2start, uint32_t nbuckets, MsdParams m, uint32_t lower, uint32_t upper,
-                                                          uint32_t *bN, uint32_t *bZ, BucketStats *gstat, const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
+                                                          const uint32_t *crowded, const BucketStats *gstat, const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     // LDS, in words: table 16384 | reliable bitmap 1024 | seen bitmap 1024 | misc 64 | scan partials 64 | headpos KW + 1 | fill KW + 1 | staged entries | their columns
     uint32_t *tab = smem;                                   // 2^15 counters of 16 bits; in a window: the window-local column number of the reliable values
     uint16_t *tab16 = reinterpret_cast<uint16_t *>(smem);
-    uint32_t *relbits = smem + BK_TAB, *seenbits = relbits + 1024;
+    uint32_t *relbits = smem + BK_TAB;      // (+ 1024 spare words)
     uint32_t *misc = smem + BK_TAB + 2048;
     uint32_t *wsc = misc + 64;
     uint32_t *headpos = wsc + 64;
@@ -353,18 +575,18 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
     uint16_t *entk = reinterpret_cast<uint16_t *>(ent + (EW + EPAD));
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t paymask = (1ull << m.PB) - 1, posmask = (1ull << m.pbits) - 1;
-    unsigned long long st_distinct = 0, st_sumsq = 0;
-    uint32_t st_maxcol = 0;
 
-    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+    const uint32_t ncrowded = gstat->ncrowded;
+    for (uint32_t li = blockIdx.x; li < ncrowded; li += gridDim.x) {
+        const uint32_t b = crowded[li];
         const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
-        if (n == 0) { if (!EMIT && tid == 0) { bN[b] = 0; bZ[b] = 0; } continue; }
+        if (n == 0 || b >= nbuckets) continue;
         // the bucket's instances: the first KPT * 1024 live in registers, the rest (crowded buckets) is re-read from L2 in every pass
         uint64_t kreg[KPT];
 #pragma unroll
         for (int u = 0; u < KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; kreg[u] = i < n ? words[s0 + i] : 0; }
         const bool guard = n > 65535u;          // a value's count could run over its 16 bits: stop counting beyond 2^15 (UPPER <= 255: unreliable anyway)
-        uint32_t n0 = 0, z0 = 0, nall = 0, zall = 0;
+        uint32_t n0 = 0, z0 = 0;
 #pragma unroll 1
         for (uint32_t h = 0; h < 2; ++h) {
             {   // zero the table and the two bitmaps (18 K words: 4.5 uint4 per lane)
@@ -387,7 +609,6 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
             __syncthreads();
             for_keys([&](uint64_t wd) {
                 const uint32_t idx = (uint32_t)(wd >> m.PB) & 0x7FFFu, cnt = tab16[idx];
-                if (!EMIT) atomicOr(&seenbits[idx >> 5], 1u << (idx & 31u));
                 if (cnt >= lower && cnt <= upper) atomicOr(&relbits[idx >> 5], 1u << (idx & 31u));
             });
             __syncthreads();
@@ -397,9 +618,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
             for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
                 const uint32_t cnt = tab16[tid * 32u + (uint32_t)__ffs((int)bits) - 1u];
                 nent += cnt;
-                if (!EMIT) { st_sumsq += (unsigned long long)cnt * cnt; st_maxcol = cnt > st_maxcol ? cnt : st_maxcol; }
             }
-            if (!EMIT) st_distinct += (unsigned long long)__popc(seenbits[tid]);
             // exclusive scan of (nrel, nent) over the 1024 lanes
             uint32_t ir = nrel, ie = nent;
 #pragma unroll
@@ -410,7 +629,6 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
 #pragma unroll
             for (uint32_t ww = 0; ww < BK_THREADS / 64; ++ww) { const uint32_t a = wsc[ww], c2 = wsc[16 + ww]; if (ww < wv) { R += a; E += c2; } totR += a; totE += c2; }
             if (h == 0) { n0 = totR; z0 = totE; }
-            nall += totR; zall += totE;
             if (EMIT && totR != 0) {
                 const uint32_t kb = kidbase[b] + (h ? n0 : 0u), eb = entbase[b] + (h ? z0 : 0u);
                 {   // the reliable k-mers of this lane's values: k-mer (left-aligned, src/Kmer.cpp:78-86), count, column pointer
@@ -517,15 +735,6 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
             }
             __syncthreads();                               // wsc, the table and the staging area are reused by the next half / bucket
         }
-        if (!EMIT && tid == 0) { bN[b] = nall; bZ[b] = zall; }
-    }
-    if (!EMIT) {
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            st_distinct += __shfl_xor(st_distinct, d, 64); st_sumsq += __shfl_xor(st_sumsq, d, 64);
-            const uint32_t o2 = __shfl_xor(st_maxcol, d, 64); st_maxcol = o2 > st_maxcol ? o2 : st_maxcol;
-        }
-        if (lane == 0) { if (st_distinct) atomicAdd(&gstat->distinct, st_distinct); if (st_sumsq) atomicAdd(&gstat->sumsq, st_sumsq); if (st_maxcol) atomicMax(&gstat->maxcol, st_maxcol); }
     }
 }
 
@@ -562,11 +771,11 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
 
     c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8);
     c.ws_sort.reserve(((size_t)ntiles2 << MT_MAXBITS) * 4 + 4096);
-    c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 5 + (size_t)(2 * nb1 + 8) * 4 + 256);
+    c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 6 + (size_t)(2 * nb1 + 8) * 4 + 256);
     uint32_t *hist = c.ws_sort.as<uint32_t>();
     BucketStats *gstat = c.ws_e.as<BucketStats>();
     uint32_t *b2start = c.ws_e.as<uint32_t>() + 16, *bN = b2start + (nbuckets + 2), *bZ = bN + (nbuckets + 2), *kidbase = bZ + (nbuckets + 2), *entbase = kidbase + (nbuckets + 2);
-    uint32_t *b1start = entbase + (nbuckets + 2), *tile0 = b1start + (nb1 + 2);
+    uint32_t *crowded = entbase + (nbuckets + 2), *b1start = crowded + (nbuckets + 2), *tile0 = b1start + (nb1 + 2);
     uint64_t *wa = c.ws_a.as<uint64_t>(), *wb = c.ws_c.as<uint64_t>();
 
     c.t_total.start(s);
@@ -593,17 +802,18 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     // buckets: count
     c.t_b.start(s);
     static bool attr_done = false;
-    const size_t lds_count = BK_LDS_COUNT, lds_emit = BK_LDS_EMIT;
     if (!attr_done) {
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_bucket<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_bucket<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_done = true;
     }
     ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
-    const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 2u);
+    const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus);
+    const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < ES_CAP ? (uint32_t)c.opt.msd_small_cap : ES_CAP;
     BucketOut o{};
-    hipLaunchKernelGGL((k_msd_bucket<false>), dim3(bgrid), dim3(BK_THREADS), lds_count, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper,
-                       bN, bZ, gstat, (const uint32_t *)nullptr, (const uint32_t *)nullptr, o);
+    // (the first pass's words are dead: their buffer takes the entries — the instances of reliable k-mers —, bucket by bucket)
+    hipLaunchKernelGGL(k_msd_count, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, small_cap,
+                       bN, bZ, gstat, crowded, wa);
     ELBA_HIP(hipMemsetAsync(bN + nbuckets, 0, 4, s)); ELBA_HIP(hipMemsetAsync(bZ + nbuckets, 0, 4, s));
     exclusive_scan_u32(s, bN, kidbase, (int64_t)nbuckets + 1, c.ws_scan);
     exclusive_scan_u32(s, bZ, entbase, (int64_t)nbuckets + 1, c.ws_scan);      // Z <= I < 2^32
@@ -630,9 +840,14 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     c.max_col_nnz = (int64_t)hs.maxcol;
     choose_column_store(c, (int64_t)N, c.max_col_nnz);
     o.ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; o.ell_stride = c.use_ell ? c.s_stride : 0u;
-    if (Z > 0)
-        hipLaunchKernelGGL((k_msd_bucket<true>), dim3(bgrid), dim3(BK_THREADS), lds_emit, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper,
-                           bN, bZ, gstat, (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+    if (Z > 0) {
+        // (bZ of a crowded bucket is set to 0 for the small kernel by leaving it out there: it skips Z > ES_CAP itself; with a lowered cap — tests — the list says so)
+        hipLaunchKernelGGL(k_msd_emit_small, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 12u)), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, small_cap,
+                           (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+        if (hs.ncrowded)
+            hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,
+                               (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, (const uint32_t *)crowded, (const BucketStats *)gstat, (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+    }
     const uint32_t Zz = (uint32_t)Z;
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
     c.prod_ctr.reserve(64 * 128);

@@ -497,12 +497,13 @@ def test_create_kmer_matrix_twice_after_one_count_gives_the_same_matrices():
     e.close()
 
 
-@pytest.mark.parametrize("k,lo,up", [(17, 2, 8), (17, 2, 40), (17, 3, 12), (15, 2, 8), (13, 2, 30), (11, 2, 60), (9, 2, 200)])
-def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up):
+@pytest.mark.parametrize("k,lo,up,cap", [(17, 2, 8, 0), (17, 2, 40, 0), (17, 3, 12, 0), (15, 2, 8, 0), (13, 2, 30, 0), (11, 2, 60, 0), (9, 2, 200, 0), (17, 2, 8, 2), (13, 2, 30, 100), (9, 2, 200, 1000)])
+def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up, cap):
     """k <= 17: the k-mer stage counts by a two-level value partition and an LDS count table per bucket (kmer_msd.hip) on inputs of some size;
     the option "kmer_msd" forces it on a small one (most buckets empty or tiny).  Low-complexity reads (runs of one canonical k-mer at
     neighbouring positions, k-mers far beyond UPPER), reads shorter than k and reads around the word boundaries of the packed stream included:
-    reliable k-mers, columns, rows, hints-carrying B and every statistic equal the oracle's."""
+    reliable k-mers, columns, rows, hints-carrying B and every statistic equal the oracle's.  cap > 0: buckets with more entries than that are
+    emitted by the crowded-bucket kernel (windows of staged columns) instead of the LDS sort of the small ones — both kernels in one run."""
     reads, _ = synth.make_reads(78 + k, 60000, 14, 2500, 700, error=0.08, min_len=100)
     rng = np.random.default_rng(k)
     extra = [b"A" * 300, b"AC" * 200, b"T" * 150 + b"G" * 150, b"ACG" * 120, b"ACGT" * 90] * 3
@@ -510,7 +511,7 @@ def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up):
     seqs = list(reads) + extra
     np.random.default_rng(5).shuffle(seqs)
     packed, off, lens = po.pack_reads(seqs)
-    e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up, options={"kmer_msd": 1})
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up, options={"kmer_msd": 1, "msd_small_cap": cap})
     o = gu.oracle_run(packed, off, lens, k, lo, up, threads=8)
     assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
