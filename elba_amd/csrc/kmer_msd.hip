@@ -7,7 +7,7 @@
 // Here an instance moves twice and is read twice more:
 //
 //   k_msd_hist1     enumerate the k-mers of every tile of 8192 instances, count the tile's FIRST digit (the top b1 value bits)
-//   k_msd_scatter   <ENUM> enumerate again and write every instance as ONE word straight into its first-digit bucket (stable): the word
+//   k_msd_scatter   <ENUM> enumerate again and write every instance as ONE word straight into its first-digit bucket: the word
 //                   no longer holds the first digit — word = remaining value bits << PB | read << pbits | pos — so read and position travel
 //                   with the instance and nothing is recomputed or looked up afterwards;
 //   k_msd_hist2 / k_msd_segscan / k_msd_scatter<MEM>   the same on the SECOND digit inside every first-digit bucket (tiles never straddle buckets):
@@ -50,6 +50,52 @@ struct MsdParams {
     uint64_t I;
 };
 
+// Enumeration for the partition kernels: a lane takes 32 CONSECUTIVE instances (g = wbase + 32 * lane + it) and rolls its k-mer window along
+// the read — three aligned 8-byte loads per lane instead of two per instance, ~20 integer operations per instance instead of ~40: the forward
+// k-mer is the top 2k bits of a 192-bit window shifted left by one base per step, the twin takes the complement of the entering base at its
+// front (src/Kmer.cpp:149-165 rolls the same way; :167-198 is the twin).  Nothing downstream of the partition needs the instances in (read, pos)
+// order — the bucket kernels sort every column — so the tile may hold them in any order.  f(it, canonical k-mer, read, pos), `it` a constant.
+template <class F>
+__device__ __forceinline__ void enum_consecutive(const EnumParams &e, const BlockInfo *block_read, uint64_t wbase, F &&f)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t g0 = wbase + (uint64_t)lane * MT_ITEMS;
+    const int k = e.k;
+    const uint64_t kmask = ~0ull << (64 - 2 * k);
+    if (wbase >= e.I) return;
+    const ReadCursor rc = cursor_at(e, block_read, wbase);
+    uint32_t r = rc.lo;
+    uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
+    uint64_t hi = 0, mid = 0, lo = 0, tw = 0;
+#pragma unroll
+    for (int it = 0; it < MT_ITEMS; ++it) {
+        const uint64_t g = g0 + (uint64_t)it;
+        if (g >= e.I) break;
+        uint64_t fwd;
+        if (it == 0 || g >= off_hi) {
+            while (g >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }      // reads shorter than k have empty ranges and are skipped here
+            const uint32_t p = (uint32_t)(g - off_lo);
+            const uint64_t left = off_hi - g;                     // instances of this read from here on: the window must reach left (<= 32 - it) + k - 1 bases
+            const uint32_t nbases = (uint32_t)(left < (uint64_t)(MT_ITEMS - it) ? left : (uint64_t)(MT_ITEMS - it)) + (uint32_t)k - 1u;
+            const uint64_t b = boff + (p >> 2), a = b & ~7ull, last = boff + ((p + nbases - 1u) >> 2);
+            const uint64_t *w = reinterpret_cast<const uint64_t *>(e.packed + a);
+            const uint64_t w0 = __builtin_bswap64(w[0]), w1 = __builtin_bswap64(w[1]), w2 = a + 16 <= last ? __builtin_bswap64(w[2]) : 0ull;      // (16 guard bytes follow the reads: the third word is read only where the read itself reaches it)
+            const uint32_t sh = (uint32_t)(b - a) * 8 + 2 * (p & 3);              // 0..62
+            hi = sh ? (w0 << sh) | (w1 >> (64 - sh)) : w0;
+            mid = sh ? (w1 << sh) | (w2 >> (64 - sh)) : w1;
+            lo = w2 << sh;
+            fwd = hi & kmask;
+            tw = twin64(fwd, k);
+        } else {
+            const uint64_t nb = (hi >> (62 - 2 * k)) & 3ull;      // the base that enters the window
+            hi = (hi << 2) | (mid >> 62); mid = (mid << 2) | (lo >> 62); lo <<= 2;
+            fwd = hi & kmask;
+            tw = ((tw >> 2) & kmask) | ((3ull - nb) << 62);
+        }
+        f(it, tw < fwd ? tw : fwd, r, (uint32_t)(g - off_lo));
+    }
+}
+
 // ---- first digit: count ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(MT_THREADS) void k_msd_hist1(EnumParams e, const BlockInfo *block_read, MsdParams m, uint32_t *hist)
 {
@@ -57,21 +103,8 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_hist1(EnumParams e, const Bl
     const uint32_t nbins = 1u << m.b1;
     for (uint32_t i = threadIdx.x; i < nbins; i += MT_THREADS) h[i] = 0;
     __syncthreads();
-    const uint32_t lane = threadIdx.x & 63;
     const uint64_t base = ((uint64_t)blockIdx.x * (MT_THREADS / 64) + (threadIdx.x >> 6)) * (uint64_t)(MT_ITEMS * 64);
-    if (base < e.I) {
-        const ReadCursor rc = cursor_at(e, block_read, base);
-        uint32_t r = rc.lo;
-        uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
-#pragma unroll 8
-        for (int it = 0; it < MT_ITEMS; ++it) {
-            const uint64_t g = base + (uint64_t)it * 64 + lane;
-            if (g >= e.I) break;
-            while (g >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }
-            const uint64_t km = canonical_at_off(e, boff, (uint32_t)(g - off_lo));
-            atomicAdd(&h[(uint32_t)(km >> (64 - m.b1))], 1u);
-        }
-    }
+    enum_consecutive(e, block_read, base, [&](int, uint64_t km, uint32_t, uint32_t) { atomicAdd(&h[(uint32_t)(km >> (64 - m.b1))], 1u); });
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nbins; i += MT_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
 }
@@ -194,24 +227,16 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         const uint64_t tbase = (uint64_t)blockIdx.x * MT_TILE, base = tbase + (uint64_t)w * (MT_ITEMS * 64);
         const uint64_t left = e.I - tbase;
         count = left < (uint64_t)MT_TILE ? (uint32_t)left : (uint32_t)MT_TILE;
-        uint32_t r = 0;
-        uint64_t off_lo = 0, off_hi = 0, boff = 0;
-        if (base < e.I) { const ReadCursor rc = cursor_at(e, block_read, base); r = rc.lo; off_lo = rc.off_lo; off_hi = rc.off_hi; boff = rc.boff; }
         const uint64_t vmask = (1ull << (m.k2 - m.b1)) - 1;
 #pragma unroll
-        for (int it = 0; it < MT_ITEMS; ++it) {
-            const uint64_t g = base + (uint64_t)it * 64 + lane;
-            key[it] = 0;
-            uint32_t dg = 0xFFFFu;
-            if (g < e.I) {
-                while (g >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }
-                const uint32_t p = (uint32_t)(g - off_lo);
-                const uint64_t km = canonical_at_off(e, boff, p);
-                dg = (uint32_t)(km >> (64 - m.b1));
-                key[it] = (((km >> (64 - m.k2)) & vmask) << m.PB) | ((uint64_t)r << m.pbits) | p;
-            }
-            set_digit(it, dg);
-        }
+        for (int it = 0; it < MT_ITEMS; ++it) key[it] = 0;
+#pragma unroll
+        for (int q = 0; q < MT_ITEMS / 2; ++q) dig2[q] = 0xFFFFFFFFu;
+        enum_consecutive(e, block_read, base, [&](int it, uint64_t km, uint32_t r, uint32_t p) {
+            key[it] = (((km >> (64 - m.k2)) & vmask) << m.PB) | ((uint64_t)r << m.pbits) | p;
+            const uint32_t dg = (uint32_t)(km >> (64 - m.b1));
+            dig2[it >> 1] = (it & 1) ? (dig2[it >> 1] & 0xFFFFu) | (dg << 16) : (dig2[it >> 1] & 0xFFFF0000u) | dg;
+        });
     } else {
         uint32_t bucket, start;
         seg_tile(sg, blockIdx.x, bucket, start, count);
@@ -318,7 +343,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
 // LDS-only workgroup barrier: the global stores of a bucket (never read back by the workgroup) stay in flight
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct BucketStats { unsigned long long distinct, sumsq; unsigned int maxcol, ncrowded; };
+struct BucketStats { unsigned long long distinct, sumsq; unsigned int maxcol, ncrowded, nmid, pad; };
 struct BucketOut {
     uint64_t *rel_kmers; uint32_t *rel_counts, *colptr;
     uint64_t *csc, *csr_words, *kid_of_entry, *ell;
@@ -346,12 +371,29 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     unsigned long long st_distinct = 0, st_sumsq = 0;
     uint32_t st_maxcol = 0;
-    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-        const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
-        if (n == 0) { if (tid == 0) { bN[b] = 0; bZ[b] = 0; } continue; }
-        uint64_t kreg[KPT];
+    // the instances of the NEXT bucket are requested before this one is processed (one workgroup per CU: nobody else hides the round trip)
+    uint32_t b = blockIdx.x, s0 = 0, n = 0;
+    uint64_t kreg[KPT];
 #pragma unroll
-        for (int u = 0; u < KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; kreg[u] = i < n ? words[s0 + i] : 0; }
+    for (int u = 0; u < KPT; ++u) kreg[u] = 0;
+    if (b < nbuckets) {
+        s0 = b2start[b]; n = b2start[b + 1] - s0;
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; if (i < n) kreg[u] = words[s0 + i]; }
+    }
+    for (; b < nbuckets;) {
+        const uint32_t bnext = b + gridDim.x;
+        uint32_t s0n = 0, nn = 0;
+        uint64_t knext[KPT];
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) knext[u] = 0;
+        if (bnext < nbuckets) {
+            s0n = b2start[bnext]; nn = b2start[bnext + 1] - s0n;
+#pragma unroll
+            for (int u = 0; u < KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; if (i < nn) knext[u] = words[s0n + i]; }
+        }
+        if (n == 0) { if (tid == 0) { bN[b] = 0; bZ[b] = 0; } }
+        else {
         {   // zero the table and the two bitmaps (36 K words = 9 uint4 per lane), and the counters
             uint4 *t4 = reinterpret_cast<uint4 *>(smem);
 #pragma unroll
@@ -399,8 +441,13 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
             const uint32_t Zb = misc[0], Nb = misc[1];
             bN[b] = Nb; bZ[b] = Zb;
             if (Zb > small_cap) crowded[atomicAdd(&gstat->ncrowded, 1u)] = b;
+            else if (Zb > 4096u) atomicAdd(&gstat->nmid, 1u);
         }
         lds_sync();                               // (misc is zeroed for the next bucket)
+        }
+#pragma unroll
+        for (int u = 0; u < KPT; ++u) kreg[u] = knext[u];
+        b = bnext; s0 = s0n; n = nn;
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
@@ -417,19 +464,23 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
 // the handful that share its range).  A run of equal values is a column: its number (k-mer id = rank of the value) is the
 // number of run heads before it, its pointer the head's place.  Everything the sort path's k_runs_emit / k_add_hints / k_fill_ell produce
 // leaves from here as coalesced streams.  256 lanes, 44 KB of LDS: three workgroups per CU hide one another's barriers and memory waits.
-constexpr int ES_THREADS = 256, ES_KPT = 16;
-constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, ES_NSB = 512;
-__global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *wrel, const uint32_t *b2start, const uint32_t *bZ, uint32_t nbuckets, MsdParams m, uint32_t small_cap,
+// <16>: up to 4096 entries, three workgroups per CU; <32>: up to 8192 (the canonical k-mer is the smaller of two: low values are twice as dense as
+// the average, and the fullest buckets of a large input land here), one workgroup per CU.
+constexpr int ES_THREADS = 256;
+constexpr uint32_t ES_NSB = 512;
+template <int ES_KPT>
+__global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *wrel, const uint32_t *b2start, const uint32_t *bZ, uint32_t nbuckets, MsdParams m, uint32_t cap_lo, uint32_t cap_hi,
                                                               const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
 {
+    constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, NH = ES_KPT * 4;      // entries; (u, wavefront) head counts
     __shared__ uint64_t A[ES_CAP];
-    __shared__ uint32_t sbcnt[ES_NSB], sbstart[ES_NSB + 1], H[ES_CAP / 2 + 2], hcnt[ES_KPT * 4 + 1], wsum[4];
+    __shared__ uint32_t sbcnt[ES_NSB], sbstart[ES_NSB + 1], H[ES_CAP / 2 + 2], hcnt[NH + 1], wsum[4];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t lt = (1ull << lane) - 1;
     const uint64_t paymask = (1ull << m.PB) - 1, posmask = (1ull << m.pbits) - 1;
     for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
         const uint32_t Z = bZ[b];
-        if (Z == 0 || Z > small_cap) continue;      // (crowded buckets: k_msd_bucket)
+        if (Z <= cap_lo || Z > cap_hi) continue;      // (other sizes: the other instantiation, or k_msd_bucket)
         const uint32_t s0 = b2start[b];
         uint64_t key[ES_KPT];
 #pragma unroll
@@ -488,16 +539,21 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
             if (lane == 0) hcnt[u * 4 + wv] = (uint32_t)__popcll(bal);
         }
         lds_sync();
-        if (wv == 0) {      // exclusive scan of the 64 (u, wave) head counts, in place order
-            const uint32_t c = hcnt[lane];
-            uint32_t inc = c;
+        if (wv == 0) {      // exclusive scan of the NH (u, wave) head counts, in place order: NH / 64 consecutive ones per lane
+            constexpr int PL = NH / 64;
+            uint32_t c[PL], sum = 0;
+#pragma unroll
+            for (int q = 0; q < PL; ++q) { c[q] = hcnt[lane * PL + q]; sum += c[q]; }
+            uint32_t inc = sum;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
-            hcnt[lane] = inc - c;
-            if (lane == 63) hcnt[64] = inc;
+            uint32_t run = inc - sum;
+#pragma unroll
+            for (int q = 0; q < PL; ++q) { hcnt[lane * PL + q] = run; run += c[q]; }
+            if (lane == 63) hcnt[NH] = inc;
         }
         lds_sync();
-        const uint32_t Nb = hcnt[64], kb = kidbase[b], eb = entbase[b];
+        const uint32_t Nb = hcnt[NH], kb = kidbase[b], eb = entbase[b];
 #pragma unroll
         for (int u = 0; u < ES_KPT; ++u) {
             slot[u] = hcnt[u * 4 + wv] + slot[u] - 1u;                      // the column of place u * 256 + tid
@@ -535,10 +591,10 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
             }
         }
         if (o.ell_stride) {
-            const uint32_t S = o.ell_stride, nq = Nb * S;
+            const uint32_t S = o.ell_stride, nq = Nb * S, sl = (S & (S - 1u)) ? 0u : (uint32_t)__ffs((int)S) - 1u;
             uint64_t *dst = o.ell + (uint64_t)kb * S;
             for (uint32_t q = tid; q < nq; q += ES_THREADS) {
-                const uint32_t kl = q / S, j = q - kl * S, h0 = H[kl];
+                const uint32_t kl = (S & (S - 1u)) ? q / S : q >> sl, j = q - kl * S, h0 = H[kl];
                 uint64_t v = ~0ull;
                 if (h0 + j < H[kl + 1]) { const uint64_t x = A[h0 + j]; v = (((x & paymask) >> m.pbits) << 32) | (x & posmask); }
                 dst[q] = v;
@@ -809,7 +865,8 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     }
     ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
     const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus);
-    const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < ES_CAP ? (uint32_t)c.opt.msd_small_cap : ES_CAP;
+    // entries per bucket: up to 4096 -> k_msd_emit_small<16>, up to 8192 -> <32>, beyond -> k_msd_bucket (option "msd_small_cap": tests lower the last bound)
+    const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < 8192u ? (uint32_t)c.opt.msd_small_cap : 8192u;
     BucketOut o{};
     // (the first pass's words are dead: their buffer takes the entries — the instances of reliable k-mers —, bucket by bucket)
     hipLaunchKernelGGL(k_msd_count, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, small_cap,
@@ -841,9 +898,12 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     choose_column_store(c, (int64_t)N, c.max_col_nnz);
     o.ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; o.ell_stride = c.use_ell ? c.s_stride : 0u;
     if (Z > 0) {
-        // (bZ of a crowded bucket is set to 0 for the small kernel by leaving it out there: it skips Z > ES_CAP itself; with a lowered cap — tests — the list says so)
-        hipLaunchKernelGGL(k_msd_emit_small, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 12u)), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, small_cap,
+        const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u);
+        hipLaunchKernelGGL((k_msd_emit_small<16>), dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 12u)), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap16,
                            (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+        if (small_cap > 4096u && hs.nmid)
+            hipLaunchKernelGGL((k_msd_emit_small<32>), dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 4u)), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
+                               (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (hs.ncrowded)
             hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,
                                (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, (const uint32_t *)crowded, (const BucketStats *)gstat, (const uint32_t *)kidbase, (const uint32_t *)entbase, o);

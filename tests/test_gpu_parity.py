@@ -524,13 +524,15 @@ def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up, cap):
     e.close()
 
 
-def test_two_level_partition_windows_of_a_crowded_bucket():
-    """A genome of few distinct k-mers at high depth: single buckets of the two-level partition hold thousands of reliable columns and tens of
-    thousands of entries — more than one staging window per bucket half (kmer_msd.hip: EW) — and instances beyond what a workgroup keeps in registers."""
+@pytest.mark.parametrize("nreads", [500, 1500])
+def test_two_level_partition_windows_of_a_crowded_bucket(nreads):
+    """A genome of few distinct k-mers at high depth: single buckets of the two-level partition hold thousands of reliable columns and, with
+    1500 reads, tens of thousands of entries — more than one staging window per bucket half (kmer_msd.hip: EW), instances beyond what a
+    workgroup keeps in registers (k_msd_bucket); with 500 reads 4-8 thousand entries: the wide instantiation of the LDS sort (k_msd_emit_small<32>)."""
     rng = np.random.default_rng(11)
     unit = bytes(rng.choice(list(b"ACGT"), 24).tolist())
     seqs = []
-    for r in range(1500):
+    for r in range(nreads):
         # reads built from short mutations of one unit: a few thousand distinct k-mers that share their leading bases
         s = bytearray(unit * 12)
         for _ in range(6):
