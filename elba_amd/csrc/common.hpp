@@ -187,6 +187,7 @@ struct Ctx {
     DevBuf a_ell;                              // u64[N * s_stride]: the columns padded to a common stride (entries, then all ones) — the column store the
                                                // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid * s_stride, no pointer
     bool use_ell = false;
+    DevBuf col_w0;                             // u8[N]: rotation of every padded column of a dense matrix with a row window (matrix.hip: k_fill_ell)
     uint32_t s_stride = 4, lpc_log2 = 1;       // padded column stride in entries (4, or a multiple of 8: a whole number of 64-byte lines); lanes of the SpGEMM per row entry 2^lpc_log2 >= s_stride / 2
     bool cold_calls = false;                   // every elba_create_seed_matrix call forgets what earlier calls learned (prior, tier usage): elba_set_option
     bool pos16 = false;                        // every position among the entries is < 65536 (mirrored entries of B travel as 16-byte records then)

@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t entry_hint(const uint32_t *colptr, const uin
 }
 
 __global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, uint64_t kid_mask, const uint32_t *colptr, const uint64_t *csc, int64_t Z, uint64_t *row_keys, uint64_t *csr_vals,
-                                  bool hints, bool suffix, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr)
+                                  bool hints, bool suffix, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr, const uint8_t *colw0)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool in = z < Z;
@@ -36,7 +36,9 @@ __global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, uint6
     if (!in) return;
     row_keys[z] = e >> 32;                                   // read
     if (suffix) {      // dense matrices (Ctx::csr_suffix): the entry knows its column's length and its own place in it — kid | L << 23 | idx << 16 | pos (16 bits)
-        const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0, idx = (uint32_t)z - c0;
+        const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0;
+        uint32_t idx = (uint32_t)z - c0;
+        if (colw0) { const uint32_t w0 = colw0[kid]; idx = idx >= w0 ? idx - w0 : idx + L - w0; }      // (a row window: the padded column is stored rotated, see k_fill_ell)
         csr_vals[z] = (kid << 32) | ((uint64_t)L << 23) | ((uint64_t)idx << 16) | (e & 0xFFFFull);
     } else csr_vals[z] = (kid << 32) | ((uint64_t)h << 30) | (e & 0xFFFFFFFFull);         // kid | hint | pos
 }
@@ -117,17 +119,30 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
 
 // padded column store: slot j of column kid (at kid * stride + j) holds the column's j-th entry, or all ones behind its end; one lane per
 // slot, so the stores of a wavefront are one contiguous 512 bytes (no fill pass before, no column-id array)
-__global__ void k_fill_ell(const uint32_t *colptr, const uint64_t *csc, uint64_t nslots, uint32_t cs, uint64_t *ell)
+// colw0 (dense matrices with a row window): column kid is stored ROTATED by colw0[kid] = its entries of reads below the window — the window's
+// entries first, then the reads above it, then the reads below it.  With pairs owned by the smaller row INSIDE the window and every partner
+// outside it kept (owns_pair), the candidates a window row's entry owns are then exactly the slots behind its own, as without a window.
+// (Relative order inside each of the three groups is kept, so a product's sequence number still orders the products of one pair.)
+__global__ void k_col_w0(const uint32_t *colptr, const uint64_t *csc, uint64_t N, uint32_t win_lo, uint8_t *colw0)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    const uint32_t c0 = colptr[k], L = colptr[k + 1] - c0;
+    uint32_t w0 = 0;
+    while (w0 < L && (uint32_t)(csc[c0 + w0] >> 32) < win_lo) ++w0;
+    colw0[k] = (uint8_t)(w0 == L ? 0u : w0);      // (a column wholly below the window — it holds no window row — keeps its order)
+}
+__global__ void k_fill_ell(const uint32_t *colptr, const uint64_t *csc, uint64_t nslots, uint32_t cs, uint64_t *ell, const uint8_t *colw0)
 {
     // two slots (16 bytes) per lane: the stride is even, so a pair never straddles two columns.  (Adding the hint bits of the entries here, by the lane
     // that copies them, was measured: 15.8 ms against 4.8 + 5.2 for this kernel and k_add_hints — most lanes hold padding.)
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, npairs = nslots >> 1;
     for (uint64_t t2 = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t2 < npairs; t2 += stride) {
         const uint64_t t = t2 << 1, kid = t / cs;
-        const uint32_t j = (uint32_t)(t - kid * cs), c0 = colptr[kid], L = colptr[kid + 1] - c0;
+        const uint32_t j = (uint32_t)(t - kid * cs), c0 = colptr[kid], L = colptr[kid + 1] - c0, w0 = colw0 ? colw0[kid] : 0u;
         ulonglong2 v;
-        v.x = j < L ? csc[c0 + j] : ~0ull;
-        v.y = j + 1u < L ? csc[c0 + j + 1u] : ~0ull;
+        v.x = j < L ? csc[c0 + (j + w0 < L ? j + w0 : j + w0 - L)] : ~0ull;
+        v.y = j + 1u < L ? csc[c0 + (j + 1u + w0 < L ? j + 1u + w0 : j + 1u + w0 - L)] : ~0ull;
         reinterpret_cast<ulonglong2 *>(ell)[t2] = v;
     }
 }
@@ -225,19 +240,27 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.prod_ctr.reserve(64 * 128);
     unsigned long long *prod_ctr = c.prod_ctr.as<unsigned long long>();
     if (!pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 64 * 128, s));      // (pre: k_runs_emit has counted)
-    if (!(pre && c.pre_ell_done)) {      // (the two-level partition of kmer_msd.hip writes the padded columns with the columns themselves)
-        c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
-        choose_column_store(c, N, c.max_col_nnz);
-        if (c.use_ell) {
-            const uint64_t nslots = (uint64_t)N * c.s_stride;
-            hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 30)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), nslots, c.s_stride, c.a_ell.as<uint64_t>());
-        }
-    }
     // Dense matrices (columns of more than 16 reads, e.g. UPPER = 35 on 40x low-error reads: every row owns pairs of every column, hundreds of
     // products per surviving pair): pairs are owned by their SMALLER row and an entry's owned candidates are the column's entries behind its
     // own — the row entries then carry the column's length and their own place in it, and the SpGEMM hands out exactly those candidates to
-    // its lanes (spgemm_direct.hpp, "suffix" path).  One GPU / whole-matrix window, positions below 2^16, the padded column store.
-    c.csr_suffix = c.use_ell && c.pos16 && c.max_col_nnz > 16 && win_lo == 0 && (win_hi < 0 || win_hi == M) && !c.opt.no_pay && !c.opt.no_suffix;
+    // its lanes (spgemm_direct.hpp, "suffix" path).  Positions below 2^16, the padded column store.  With a row window (a shard, a row block
+    // of a shard: elba_dist_set_panel) the padded columns are stored rotated so that this stays true (k_fill_ell).
+    const bool windowed = !(win_lo == 0 && (win_hi < 0 || win_hi == M));
+    const uint8_t *colw0 = nullptr;
+    if (!(pre && c.pre_ell_done)) {      // (the two-level partition of kmer_msd.hip writes the padded columns with the columns themselves)
+        c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
+        choose_column_store(c, N, c.max_col_nnz);
+    }
+    c.csr_suffix = c.use_ell && c.pos16 && c.max_col_nnz > 16 && !c.opt.no_pay && !c.opt.no_suffix;
+    if (c.csr_suffix && windowed && N > 0) {
+        c.col_w0.reserve((size_t)N + 16);
+        hipLaunchKernelGGL(k_col_w0, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), (uint64_t)N, wlo, c.col_w0.as<uint8_t>());
+        colw0 = c.col_w0.as<uint8_t>();
+    }
+    if (!(pre && c.pre_ell_done) && c.use_ell) {
+        const uint64_t nslots = (uint64_t)N * c.s_stride;
+        hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 30)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), nslots, c.s_stride, c.a_ell.as<uint64_t>(), colw0);
+    }
     if (c.csr_suffix) hints = false;
     if (!c.csr_suffix && mb + nb + pb + 2 <= 64 && !c.opt.csr_pairs) {
         const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;
@@ -263,7 +286,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
             int64_t nbk = (Z + 255) / 256;
             if (pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 64 * 128, s));
             hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kk, ks, km, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, k0, v0,
-                               hints, c.csr_suffix, wlo, whi, prod_ctr);
+                               hints, c.csr_suffix, wlo, whi, prod_ctr, colw0);
         }
         int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, mb, c.ws_sort);
         const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;

@@ -745,8 +745,10 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.half = phase == 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
     p.pos_mask = c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu);
     p.hint_mask = !c.csr_hints ? 0u : (p.half == 2u ? 1u << 30 : (p.half == 1u ? 1u << 31 : 0u));
-    ELBA_REQUIRE(!c.csr_suffix || (row_lo == 0 && row_hi == M), ELBA_ERR_INTERNAL, "a matrix built for the dense path has a row window");
-    p.suffix = c.csr_suffix && p.half == 1u ? 1u : 0u;      // (both triangles, ELBA_NO_SYMMETRY: the general path reads the same entries through pos_mask)
+    // (the dense path: one triangle per window, partners outside the window kept — its candidate hand-out knows no other rule.  Both triangles
+    //  ("no_symmetry") and the mirror exchange between ranks (half == 2: the parity rule over all ranks) take the general path, which reads the
+    //  same entries through pos_mask)
+    p.suffix = c.csr_suffix && p.half == 1u ? 1u : 0u;
     c.ov_hints_used = p.hint_mask != 0u || p.suffix != 0u;
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;

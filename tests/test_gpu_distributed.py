@@ -192,3 +192,49 @@ def test_with_and_without_the_mirror_exchange(world):
         assert sum(p[1]["products"] for p in parts) == o.stat("P")
         if exchange:
             assert sum(p[1]["nnz_before_prune"] for p in parts) == o.stat("Yraw")
+
+
+@pytest.mark.parametrize("world,nblocks", [(2, 1), (2, 3), (3, 2)])
+def test_dense_columns_on_shards_and_row_blocks_take_the_dense_path(world, nblocks):
+    """Deep, nearly error-free reads with a generous UPPER (columns of ~30 reads: BASELINE config 5's shape) on row shards and on row blocks of
+    shards.  A context with a row window stores its padded columns rotated — the window's reads first — so that "the smaller row owns a pair of
+    the window, partners outside it are kept" still means "the candidates of a row entry are the column's slots behind its own": the dense
+    kernel runs there too (a_csr_format says so), and the stitched rows equal the oracle's B, seeds included.  nblocks == 1: whole shards,
+    with the mirror exchange (general kernel on the same dense-format matrix) and without it (dense kernel)."""
+    reads = elba_amd.synth_reads(91, 60000, 30, 3000, 600, error_rate=0.01, min_len=500, repeat_families=3, repeat_fraction=0.1, repeat_len=400)
+    packed, off, lens, _ = reads
+    o = po.Oracle(17, 2, 40); o.count_and_build(packed, off, lens); o.spgemm(8)
+    oB = o.B()
+    bounds = partition_by_bases(lens, world)
+    for exchange in ((True, False) if nblocks == 1 else (False,)):
+        def body(rank, h):
+            a, b = int(bounds[rank]), int(bounds[rank + 1])
+            sp, so, sl = _shard(packed, off, lens, a, b)
+            d = DistributedOverlap(17, 2, 40, device=0, rank=rank, world=world, dist=h, backend=HipBackend(17, 2, 40, 0))
+            d.set_reads(sp, so, sl, a, bounds)
+            if nblocks == 1:
+                d.build_kmer_matrix()
+                fmt = d.be.e.device_view()["a_csr_format"]
+                st = d.create_seed_matrix(exchange=exchange)
+                out = (d.export_csr(), st["products"], fmt, st["nnz"])
+            else:
+                d.build_kmer_matrix(row_batches=nblocks)
+                rows, prod, fmt, nnz = [], 0, 2, 0
+                for t in range(nblocks):
+                    d.load_row_block(t)
+                    fmt = min(fmt, d.be.e.device_view()["a_csr_format"])
+                    st = d.create_seed_matrix()
+                    prod += st["products"]; nnz += st["nnz"]
+                    rows.append(d.export_csr())
+                out = (dist_sim.stitch_rows(rows), prod, fmt, nnz)
+            d.be.e.close()
+            return out
+
+        parts = dist_sim.run_ranks(world, body)
+        assert all(p[2] == 2 for p in parts)                   # ELBA_CSR_DENSE on every shard / row block
+        B = dist_sim.stitch_rows([p[0] for p in parts])
+        assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all()
+        bad = np.nonzero(B["val"] != oB["val"])[0]
+        assert len(bad) == 0, (len(bad), B["val"][bad[:4]], oB["val"][bad[:4]])
+        assert sum(p[3] for p in parts) == o.stat("Y")
+        assert sum(p[1] for p in parts) == o.stat("P")
