@@ -132,6 +132,7 @@ struct Options {
     bool trace = false;         // progress lines on stderr
     int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
+    int dense_wgs = 13;         // SpGEMM, dense path: workgroups of the 512-slot tier per CU
     int dk = 2;                 // SpGEMM: rounds of gather trips in flight (1, 2, 4)
     int64_t aln_tiers = 0;      // x-drop register tiers as decimal digits (1248 = all), 0 = default
     int aln_wide_hint = 6, aln_long_hint = 6000;
@@ -187,6 +188,7 @@ struct Ctx {
     DevBuf a_ell;                              // u64[N * s_stride]: the columns padded to a common stride (entries, then all ones) — the column store the
                                                // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid * s_stride, no pointer
     bool use_ell = false;
+    DevBuf a_ellj;                             // u32[N * s_stride]: the partner read of every slot of a_ell (dense matrices, Ctx::csr_suffix)
     DevBuf col_w0;                             // u8[N]: rotation of every padded column of a dense matrix with a row window (matrix.hip: k_fill_ell)
     uint32_t s_stride = 4, lpc_log2 = 1;       // padded column stride in entries (4, or a multiple of 8: a whole number of 64-byte lines); lanes of the SpGEMM per row entry 2^lpc_log2 >= s_stride / 2
     bool cold_calls = false;                   // every elba_create_seed_matrix call forgets what earlier calls learned (prior, tier usage): elba_set_option

@@ -119,6 +119,15 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
 
 // padded column store: slot j of column kid (at kid * stride + j) holds the column's j-th entry, or all ones behind its end; one lane per
 // slot, so the stores of a wavefront are one contiguous 512 bytes (no fill pass before, no column-id array)
+// partner read of every slot of the padded column store (padding stays all ones)
+__global__ void k_ell_partners(const uint64_t *ell, uint64_t nslots, uint32_t *ellj)
+{
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nslots / 2; t += stride) {
+        const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(ell)[t];
+        reinterpret_cast<uint2 *>(ellj)[t] = make_uint2((uint32_t)(v.x >> 32), (uint32_t)(v.y >> 32));
+    }
+}
 // colw0 (dense matrices with a row window): column kid is stored ROTATED by colw0[kid] = its entries of reads below the window — the window's
 // entries first, then the reads above it, then the reads below it.  With pairs owned by the smaller row INSIDE the window and every partner
 // outside it kept (owns_pair), the candidates a window row's entry owns are then exactly the slots behind its own, as without a window.
@@ -261,7 +270,13 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         const uint64_t nslots = (uint64_t)N * c.s_stride;
         hipLaunchKernelGGL(k_fill_ell, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 30)), dim3(256), 0, s, c.a_colptr.as<uint32_t>(), c.a_csc.as<uint64_t>(), nslots, c.s_stride, c.a_ell.as<uint64_t>(), colw0);
     }
-    if (c.csr_suffix) hints = false;
+    if (c.csr_suffix) {
+        hints = false;
+        const uint64_t nslots = (uint64_t)N * c.s_stride;      // (even: the stride is)
+        c.a_ellj.reserve((size_t)nslots * 4 + 64);
+        ELBA_HIP(hipMemsetAsync(c.a_ellj.as<char>() + nslots * 4, 0xFF, 64, s));
+        hipLaunchKernelGGL(k_ell_partners, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 20)), dim3(256), 0, s, (const uint64_t *)c.a_ell.as<uint64_t>(), nslots, c.a_ellj.as<uint32_t>());
+    }
     if (!c.csr_suffix && mb + nb + pb + 2 <= 64 && !c.opt.csr_pairs) {
         const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;
         uint64_t *w0 = have_words ? c.csr_words.as<uint64_t>() : c.ws_a.as<uint64_t>(), *w1 = c.ws_c.as<uint64_t>();

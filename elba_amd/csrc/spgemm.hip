@@ -21,6 +21,7 @@
 // No MFMA anywhere: the contraction is index matching plus integer min/max/add.
 #include "common.hpp"
 #include <algorithm>
+#include <type_traits>
 
 namespace elba {
 
@@ -75,6 +76,7 @@ struct alignas(32) StageRec { uint4 a, b; };
 struct OvParams {
     // plan-free path (spgemm_direct.hpp): the two orientations of A and nothing else
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint64_t *a_ell; const uint32_t *a_colptr; const uint64_t *a_csc;
+    const uint32_t *a_ellj;         // dense matrices: the partner read of every slot of a_ell (what the dense path gathers: half the bytes per candidate)
     uint32_t hint_mask, pos_mask;   // which hint bit of a row entry lets this call skip its column (0: none) / the position bits (Ctx::csr_hints)
     uint32_t suffix;                // dense matrices (Ctx::csr_suffix): row entries carry column length and own place, the smaller row owns a pair
     uint32_t s_stride, lpc_log2, max_col;    // padded column stride in entries (a_ell); lanes per row entry 2^lpc_log2; longest column
@@ -739,7 +741,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
 
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
-    p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
+    p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_ellj = c.csr_suffix ? c.a_ellj.as<uint32_t>() : nullptr; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
     p.s_stride = c.s_stride; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
     p.half = phase == 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
@@ -832,7 +834,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     } while (0)
             const int dk = c.opt.dk;      // rounds of DK trips in flight (tuning knob)
 // (dense path: 32-bit accumulators + seed look-ups for the few survivors — 18.0 vs 19.1 ms on config 5 at 1/25; ELBA_SUFFIX64: the 64-bit ones)
-#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) do { if (!c.opt.suffix64) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3(grid), dim3(B), (size_t)18 * (1u << (tb)) + X(B, false), s, p, (tier), (tb), (smp)); \
+#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) do { if (!c.opt.suffix64) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3((tier) == 0 ? cus * c.opt.dense_wgs : (grid)), dim3(B), (size_t)18 * (1u << (tb)) + 256 + (size_t)((B) / 64) * 1344, s, p, (tier), (tb), (smp)); \
                                                           else hipLaunchKernelGGL((k_spgemm_direct<B, false, true, 2, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp)); } while (0)
             if (sampling) {
                 if (p.suffix) ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);

@@ -194,7 +194,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
         bool full = false;
         uint32_t dg = 0, pr = 0;                 // diagonal products / all products (valid column entries) of the row, as seen by this wavefront (uniform)
         uint32_t head = 0, tail = 0;             // ring positions (uniform)
-        uint32_t *qj = misc + 64 + (tid >> 6) * (PAY ? 768u : 640u);      // per wavefront: product ring (128 x 12 or 8 bytes), then the entry FIFO of the padded-column path (128 x 12 bytes)
+        // per wavefront: product ring (128 x 12 or 8 bytes), then the entry FIFO of the padded-column path (128 x 12 bytes); the dense path with
+        // 32-bit accumulators keeps neither: its 336 words of hand-out tables only (more workgroups per CU: the path waits two thirds of its time)
+        uint32_t *qj = misc + 64 + (tid >> 6) * (SUFFIX && !PAY ? 336u : (PAY ? 768u : 640u));
         uint32_t *qs = qj + RING;
         unsigned long long *qv = reinterpret_cast<unsigned long long *>(qj + RING);
         auto drain = [&](uint32_t n) {           // n <= 64 products leave the ring, one per lane
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             // path spends ~150 wave-instructions per 28 products here (two padded columns per trip, half of their entries not owned).
             constexpr uint32_t NWV = (uint32_t)BLOCK / 64u, UN = 4;
             static_assert(UN % 2 == 0, "windows of two batches");
-            uint32_t *skid = qj + (PAY ? 384u : 256u), *spi = skid + 64, *spre = skid + 128, *sown = skid + 200;      // per wavefront: k-mer id, position | idx << 16, exclusive prefix (65 words), window marks (128)
+            uint32_t *skid = PAY ? qj + 384u : qj, *spi = skid + 64, *spre = skid + 128, *sown = skid + 200;      // per wavefront: k-mer id, position | idx << 16, exclusive prefix (65 words), window marks (128)
 #pragma unroll 1
             for (uint32_t cbase = (tid >> 6) * 64u; cbase < nnz; cbase += NWV * 64u) {
                 const bool valid = cbase + lane < nnz;
@@ -253,7 +255,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                 if (cbase == (tid >> 6) * 64u) { resolve_early(); } else if (cbase == (tid >> 6) * 64u + NWV * 64u) bounds_early();
 #pragma unroll 1
                 for (uint32_t base = 0; base < T; base += 64u * UN) {
-                    unsigned long long x[UN];
+                    // (32-bit accumulators: the hot loop needs the partner alone — fetched from the 4-byte copy of the padded columns, 16 candidates
+                    //  per 64-byte line.  The path is bound by line requests: 5.2 G candidates of config 5 at 1/25 were 703 M requests at 8 bytes each)
+                    typename std::conditional<PAY, unsigned long long, uint32_t>::type x[UN];
                     uint32_t pq[UN], sq[UN];
                     bool ok[UN];
                     // candidate -> entry, 128 candidates at a time: every entry that starts inside the window (or covers its first place) marks
@@ -283,13 +287,15 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                             const uint32_t en1 = v2 ? m1 : m0, lo = ok[u] ? en1 - 1u : 0u;
                             const uint32_t pi = spi[lo], sl = (pi >> 16) + 1u + (c - spre[lo]);
                             pq[u] = pi & 0xFFFFu; sq[u] = ((cbase + lo) << fbits) | sl;
-                            x[u] = ok[u] ? p.a_ell[(unsigned long long)skid[lo] * stride + sl] : ~0ull;
+                            if constexpr (PAY) x[u] = ok[u] ? p.a_ell[(unsigned long long)skid[lo] * stride + sl] : ~0ull;
+                            else x[u] = ok[u] ? p.a_ellj[(unsigned long long)skid[lo] * stride + sl] : EMPTY;
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
 #pragma unroll
                     for (int u = 0; u < (int)UN; ++u) {
-                        const uint32_t j = (uint32_t)(x[u] >> 32), posT = (uint32_t)x[u];
+                        uint32_t j, posT = 0;
+                        if constexpr (PAY) { j = (uint32_t)(x[u] >> 32); posT = (uint32_t)x[u]; } else j = x[u];
                         const bool dgn = ok[u] && j == i;                       // the read holds the k-mer again behind this entry: the pair of entries counts twice on the diagonal
                         const uint64_t md = __ballot(dgn);
                         if (md) dg += 2u * (uint32_t)__popcll(md);
