@@ -110,7 +110,7 @@ EXPORTED_SYMBOLS = [
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
     "elba_kmer_hash_owner", "elba_dist_value_histogram", "elba_dist_set_owner_ranges", "elba_dist_set_kmer_id_base", "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
     "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_panel_counts_win", "elba_dist_panel_fill_win", "elba_dist_set_panel",
-    "elba_seed_matrix_begin", "elba_seed_matrix_fill", "elba_seed_matrix_end",
+    "elba_seed_matrix_begin", "elba_seed_matrix_fill", "elba_seed_matrix_end", "elba_set_stream", "elba_seed_matrix_send", "elba_seed_matrix_recv",
 ]
 
 _lib = None

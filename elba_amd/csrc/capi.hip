@@ -65,6 +65,7 @@ const char *elba_strerror(int status)
     case ELBA_ERR_STATE: return "stage called out of order";
     case ELBA_ERR_UNSUPPORTED: return "unsupported configuration";
     case ELBA_ERR_INTERNAL: return "internal error";
+    case ELBA_ERR_RETRY: return "some rank ran out of room: repeat the step";
     default: return "unknown status";
     }
 }
@@ -102,7 +103,7 @@ void elba_ctx_destroy(elba_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->c.device);
-    if (ctx->c.stream) { (void)hipStreamSynchronize(ctx->c.stream); (void)hipStreamDestroy(ctx->c.stream); }
+    if (ctx->c.stream) { (void)hipStreamSynchronize(ctx->c.stream); if (ctx->c.own_stream) (void)hipStreamDestroy(ctx->c.stream); }
     delete ctx;
 }
 
@@ -228,6 +229,31 @@ int elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats)
 int elba_seed_matrix_begin(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, uint64_t *send_counts)
 {
     return guarded(ctx, [&](Ctx &c) { stage_seed_matrix_begin(c, nranks, read_bounds, send_counts); });
+}
+
+int elba_set_stream(elba_ctx *ctx, void *hip_stream)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        if (c.stream) ELBA_HIP(hipStreamSynchronize(c.stream));
+        if (c.own_stream && c.stream) (void)hipStreamDestroy(c.stream);
+        c.stream = static_cast<hipStream_t>(hip_stream);
+        c.own_stream = false;
+    });
+}
+
+int elba_seed_matrix_send(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, void *d_send, int64_t slot_records)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_seed_matrix_send(c, nranks, read_bounds, d_send, slot_records); });
+}
+
+int elba_seed_matrix_recv(elba_ctx *ctx, void *d_recv, int64_t slot_records, elba_overlap_stats *stats, int64_t *slot_records_needed)
+{
+    bool done = false;
+    const int rc = guarded(ctx, [&](Ctx &c) {
+        done = stage_seed_matrix_recv(c, d_recv, slot_records, slot_records_needed);
+        if (done && stats) *stats = c.ostats;
+    });
+    return rc != ELBA_OK ? rc : (done ? ELBA_OK : ELBA_ERR_RETRY);
 }
 
 int elba_seed_matrix_fill(elba_ctx *ctx, void *d_send, const uint64_t *offsets)

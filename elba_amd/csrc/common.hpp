@@ -247,6 +247,8 @@ struct Ctx {
     int ov_pend_passes = 1; bool ov_pend_timed = false; float ov_pend_ms[3] = {0, 0, 0};
     std::vector<uint64_t> ov_remote_bounds;
     DevBuf ov_remote;               // mirror images received from other ranks (32-byte records)
+    DevBuf ov_cursors;              // per-destination cursors of the fixed-slot exchange + the receive side's check words (stage_seed_matrix_send / _recv)
+    bool own_stream = true;         // c.stream was created by the context (elba_set_stream: the caller's)
 
     EventTimer t_total, t_a, t_b, t_c;
     struct PinnedHost { void *p = nullptr; size_t cap = 0; void reserve(size_t n) { if (n <= cap) return; if (p) (void)hipHostFree(p); p = nullptr; cap = 0; ELBA_HIP(hipHostMalloc(&p, n, hipHostMallocDefault)); cap = n; } ~PinnedHost() { if (p) (void)hipHostFree(p); } };
@@ -266,6 +268,8 @@ void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
 void stage_seed_matrix_begin(Ctx &c, int nranks, const uint64_t *bounds_host, uint64_t *send_counts_host);
 void stage_seed_matrix_fill(Ctx &c, void *d_send, const uint64_t *offsets_host);
 void stage_seed_matrix_end(Ctx &c, const void *d_recv, int64_t nrecv);
+void stage_seed_matrix_send(Ctx &c, int nranks, const uint64_t *bounds_host, void *d_send, int64_t slot);
+bool stage_seed_matrix_recv(Ctx &c, void *d_recv, int64_t slot, int64_t *slot_needed);
 void stage_align_seeds(Ctx &c, int mat, int mis, int gap, int dropoff);   // align.hip
 void stage_dist_set_all_reads(Ctx &c, const void *d_packed, int64_t packed_bytes, const void *d_byte_off, const void *d_len, int64_t nreads_total);   // align.hip
 void stage_set_overlaps(Ctx &c, int64_t nreads, const int64_t *rows, const int64_t *cols, const elba_overlap_t *vals, int64_t n);   // tr.hip

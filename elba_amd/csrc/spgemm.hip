@@ -587,9 +587,11 @@ __global__ void k_ingest_remote(StageRec *rem, unsigned long long n, uint32_t *l
 }
 
 // ... and are placed like the local mirror images (k_mirror), once the row pointers are known
-__global__ void k_place_remote(FinParams p, const StageRec *rem, unsigned long long n)
+// (slot != 0: rem is nranks slots of `slot` records each, record 0 of a slot its header — the count of records behind it in a.x)
+__global__ void k_place_remote(FinParams p, const StageRec *rem, unsigned long long n, unsigned long long slot)
 {
     for (unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (unsigned long long)gridDim.x * blockDim.x) {
+        if (slot) { const unsigned long long idx = r % slot; if (idx == 0 || idx > rem[r - idx].a.x) continue; }
         const uint4 a = rem[r].a, b = rem[r].b;
         if (a.x < p.row_lo || a.x >= p.row_hi) continue;
         const int64_t at = p.b_rowptr[a.x] + (int64_t)b.w;
@@ -600,7 +602,7 @@ __global__ void k_place_remote(FinParams p, const StageRec *rem, unsigned long l
 }
 
 // row pointers, mirror pass (local pairs, and the mirrored entries other ranks sent: `remote`), per-row column sort + move to b_col / b_val
-static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &skipped_sorts, const StageRec *remote, int64_t nremote)
+static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &skipped_sorts, const StageRec *remote, int64_t nremote, int64_t slot = 0)
 {
     hipStream_t s = c.stream;
     const int64_t M = c.M;
@@ -631,7 +633,7 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
         int nb = (int)((nrows + 3) / 4);
         if (nb > cus * 32) nb = cus * 32;
         hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
-        if (nremote > 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((nremote + 255) / 256, (int64_t)cus * 32)), dim3(256), 0, s, f, remote, (unsigned long long)nremote);
+        if (nremote > 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((nremote + 255) / 256, (int64_t)cus * 32)), dim3(256), 0, s, f, remote, (unsigned long long)nremote, (unsigned long long)slot);
         hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
         hipLaunchKernelGGL(k_finalize_mid, dim3(nb), dim3(256), 0, s, f);
         skipped_sorts = 0;
@@ -693,7 +695,8 @@ static void ov_finish_stats(Ctx &c, OvCounters &hc, elba_overlap_stats &st, int 
 }
 
 // phase 0: the whole call.  phase 1: the first half of a sharded call with mirror exchange (stage_seed_matrix_begin): classify + numeric with
-// GLOBAL pair ownership, stops before the finalize pass.
+// GLOBAL pair ownership, stops before the finalize pass.  phase 2: the same, only QUEUED — every tier is launched, nothing is read back and the
+// host does not wait (stage_seed_matrix_send; what phase 1 checks after its synchronisation, stage_seed_matrix_recv checks at the end of the step).
 static void create_seed_matrix_direct(Ctx &c, int phase)
 {
     hipStream_t s = c.stream;
@@ -725,7 +728,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     // B is symmetric up to exchanging the two positions of every seed (exactly: the canonical seeds are min / max over a cross product of
     // positions per shared k-mer): a pair of rows of this context's window is accumulated on its smaller row only and the surviving
     // entries are mirrored into the partner's row afterwards (k_mirror) — half the accumulator updates, tables half as full.
-    const bool half = phase == 1 || !c.opt.no_symmetry;
+    const bool half = phase >= 1 || !c.opt.no_symmetry;
     const int64_t slack = (int64_t)cus * 32 * STAGE_CHUNK + 64;      // one open chunk per resident workgroup
     if (c.ov_tmp_cap == 0) {
         if (c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);
@@ -744,7 +747,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_ellj = c.csr_suffix ? c.a_ellj.as<uint32_t>() : nullptr; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
     p.s_stride = c.s_stride; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
-    p.half = phase == 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
+    p.half = phase >= 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
     p.pos_mask = c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu);
     p.hint_mask = !c.csr_hints ? 0u : (p.half == 2u ? 1u << 30 : (p.half == 1u ? 1u << 31 : 0u));
     // (the dense path: one triangle per window, partners outside the window kept — its candidate hand-out knows no other rule.  Both triangles
@@ -823,7 +826,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         if (nrows > 0) {
             // bytes behind the table: misc words + per wavefront one product ring (128 entries of 12 / 8 bytes) and one row-entry FIFO (128 x 12 bytes)
             auto X = [&](int B, bool P) { return (size_t)256 + (size_t)(B / 64) * (P ? 3072 : 2560); };
-            const bool all_tiers = !c.ov_tiers_known;
+            const bool all_tiers = !c.ov_tiers_known || phase == 2;
             skipped_tiers = 0;
 #define ELBA_DTIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
 #define ELBA_LAUNCH_D(B, G, P, grid, lds, tier, tb, smp)                                                                                  \
@@ -871,6 +874,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
             ELBA_HIP(hipGetLastError());
         }
         if (timed) c.ov_marks.mark(2, s);
+        if (phase == 2) { c.ov_pend_passes = 1; c.ov_pend_timed = timed; c.ov_phase = 2; return; }      // (queued: no read-back, no wait)
         if (phase == 0) ov_launch_finalize(c, p.half, !c.ov_tiers_known, skipped_sorts, nullptr, 0);
         if (timed) c.ov_marks.mark(3, s);
         ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
@@ -978,6 +982,155 @@ void stage_seed_matrix_end(Ctx &c, const void *d_recv, int64_t nrecv)
     st.nrows = row_hi - row_lo;
     const float ms_fin = c.ov_marks.ms(2, 3);
     ov_finish_stats(c, hc, st, c.ov_pend_passes, c.ov_pend_timed, c.ov_pend_ms[0] + ms_fin, c.ov_pend_ms[1], c.ov_pend_ms[2], ms_fin, nrecv, (int64_t)chk[1]);
+}
+
+// ---- the same step with ONE host synchronisation: fixed-size slots, nothing about the exchange is known on the host ------------------------
+// d_send = nranks slots of `slot` 32-byte records: record 0 of slot r is a header — a = (count, flags, need lo, need hi): records for rank r that
+// follow, 1 = "this rank ran out of room: every rank repeats the step", the slot size this rank would have needed — written on the device.
+// The all-to-all has equal splits; every rank receives a header from every rank, so all of them reach the same verdict.
+__global__ __launch_bounds__(256) void k_remote_mirror_slots(RemoteParams p, unsigned long long *cursors, StageRec *send, unsigned long long slot)
+{
+    __shared__ uint32_t cnt[REMOTE_MAX_RANKS], fill[REMOTE_MAX_RANKS];
+    __shared__ unsigned long long base[REMOTE_MAX_RANKS];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t r0 = p.row_lo + blockIdx.x * REMOTE_ROWS_PER_BLOCK, r1 = min(r0 + (uint32_t)REMOTE_ROWS_PER_BLOCK, p.row_hi);
+    if (tid < REMOTE_MAX_RANKS) { cnt[tid] = 0; fill[tid] = 0; }
+    __syncthreads();
+    for (uint32_t i = r0 + w; i < r1; i += 4) {
+        const uint32_t n = p.row_cnt[i];
+        const unsigned long long off = p.row_off[i];
+        for (uint32_t t = lane; t < n; t += 64) {
+            const uint32_t j = p.rec16 ? p.rec[off + t].x : p.tmp[off + t].a.x;
+            if (j != i && (j < p.row_lo || j >= p.row_hi)) atomicAdd(&cnt[remote_rank_of(p, j)], 1u);
+        }
+    }
+    __syncthreads();
+    if (tid < p.nranks && cnt[tid]) base[tid] = atomicAdd(&cursors[tid], (unsigned long long)cnt[tid]);
+    __syncthreads();
+    for (uint32_t i = r0 + w; i < r1; i += 4) {
+        const uint32_t n = p.row_cnt[i];
+        const unsigned long long off = p.row_off[i];
+        for (uint32_t t = lane; t < n; t += 64) {
+            uint4 a, b = make_uint4(0u, 0u, 0u, 0u);
+            if (p.rec16) { const uint4 m = p.rec[off + t]; a = make_uint4(m.x, 0u, m.y & 0xFFFFu, m.y >> 16); b = make_uint4(m.z & 0xFFFFu, m.z >> 16, m.w, 0u); }
+            else a = p.tmp[off + t].a;
+            const uint32_t j = a.x;
+            if (j != i && (j < p.row_lo || j >= p.row_hi)) {
+                if (!p.rec16) b = p.tmp[off + t].b;
+                const uint32_t d = remote_rank_of(p, j);
+                const unsigned long long k = base[d] + atomicAdd(&fill[d], 1u);
+                if (k + 1 < slot) {                                     // (beyond the slot: dropped — the header says so and the step is repeated)
+                    StageRec *dst = send + (unsigned long long)d * slot + 1 + k;
+                    dst->a = make_uint4(j, i, a.w, a.z);
+                    dst->b = make_uint4(b.y, b.x, b.z, 0u);
+                }
+            }
+        }
+    }
+}
+__global__ void k_slot_headers(const unsigned long long *cursors, const OvCounters *ctr, StageRec *send, unsigned long long slot, uint32_t nranks)
+{
+    __shared__ unsigned long long need;
+    if (threadIdx.x == 0) need = 0;
+    __syncthreads();
+    const uint32_t d = threadIdx.x;
+    if (d < nranks) atomicMax(&need, cursors[d] + 1);
+    __syncthreads();
+    if (d < nranks) {
+        const bool over = need > slot || ctr->overflow != 0;
+        const unsigned long long cntd = cursors[d] + 1 <= slot ? cursors[d] : slot - 1;
+        send[(unsigned long long)d * slot].a = make_uint4((uint32_t)cntd, over ? 1u : 0u, (uint32_t)need, (uint32_t)(need >> 32));
+        send[(unsigned long long)d * slot].b = make_uint4(0u, 0u, 0u, 0u);
+    }
+}
+// received slots: every record draws its place in its row's mirror extent; chk = {records for rows outside the window, strict-upper entries, retry flags, slot need}
+__global__ void k_ingest_remote_slots(StageRec *rem, unsigned long long n, unsigned long long slot, uint32_t *low_cnt, uint32_t row_lo, uint32_t row_hi, unsigned long long *chk)
+{
+    const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long up = 0, got = 0;
+    if (r < n) {
+        const unsigned long long idx = r % slot;
+        if (idx == 0) {
+            const uint4 h = rem[r].a;
+            if (h.y) atomicOr(&chk[2], 1ull);
+            atomicMax(&chk[3], ((unsigned long long)h.w << 32) | h.z);
+        } else if (idx <= rem[r - idx].a.x) {
+            const uint32_t j = rem[r].a.x;
+            if (j < row_lo || j >= row_hi) atomicAdd(&chk[0], 1ull);
+            else { rem[r].b.w = atomicAdd(&low_cnt[j], 1u); up = rem[r].a.y > j ? 1u : 0u; got = 1; }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { up += __shfl_xor(up, d, 64); got += __shfl_xor(got, d, 64); }
+    if ((threadIdx.x & 63) == 0) { if (up) atomicAdd(&chk[1], up); if (got) atomicAdd(&chk[4], got); }
+}
+
+void stage_seed_matrix_send(Ctx &c, int nranks, const uint64_t *bounds_host, void *d_send, int64_t slot)
+{
+    ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "seed_matrix_send: no k-mer matrix");
+    ELBA_REQUIRE(nranks >= 1 && nranks <= REMOTE_MAX_RANKS && bounds_host && d_send && slot >= 2, ELBA_ERR_INVALID_ARG, "seed_matrix_send: 1..64 ranks, read bounds, a send buffer of nranks slots of >= 2 records");
+    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? c.M : c.row_hi;
+    bool found = false;
+    for (int r = 0; r < nranks; ++r) found |= (int64_t)bounds_host[r] == row_lo && (int64_t)bounds_host[r + 1] == row_hi;
+    ELBA_REQUIRE(found && (int64_t)bounds_host[nranks] == c.M, ELBA_ERR_INVALID_ARG, "seed_matrix_send: this context's row window is not one of the ranks' row ranges");
+    c.ov_remote_bounds.assign(bounds_host, bounds_host + nranks + 1);
+    create_seed_matrix_direct(c, 2);
+    hipStream_t s = c.stream;
+    c.ov_cursors.reserve(REMOTE_MAX_RANKS * 8 + 64);
+    ELBA_HIP(hipMemsetAsync(c.ov_cursors.p, 0, REMOTE_MAX_RANKS * 8 + 64, s));
+    const int64_t nrows = row_hi - row_lo;
+    if (nrows > 0 && nranks > 1)
+        hipLaunchKernelGGL(k_remote_mirror_slots, dim3((unsigned)((nrows + REMOTE_ROWS_PER_BLOCK - 1) / REMOTE_ROWS_PER_BLOCK)), dim3(256), 0, s, remote_params(c), c.ov_cursors.as<unsigned long long>(),
+                           static_cast<StageRec *>(d_send), (unsigned long long)slot);
+    hipLaunchKernelGGL(k_slot_headers, dim3(1), dim3(64), 0, s, (const unsigned long long *)c.ov_cursors.as<unsigned long long>(), (const OvCounters *)c.ov_counters.as<OvCounters>(),
+                       static_cast<StageRec *>(d_send), (unsigned long long)slot, (uint32_t)nranks);
+    ELBA_HIP(hipGetLastError());
+}
+
+// returns false when the step has to be repeated (this rank or any sender ran out of room; *slot_needed = the slot size that would have done)
+bool stage_seed_matrix_recv(Ctx &c, void *d_recv, int64_t slot, int64_t *slot_needed)
+{
+    ELBA_REQUIRE(c.ov_phase == 2, ELBA_ERR_STATE, "seed_matrix_recv: call seed_matrix_send first");
+    ELBA_REQUIRE(d_recv && slot >= 2, ELBA_ERR_INVALID_ARG, "seed_matrix_recv: null records");
+    hipStream_t s = c.stream;
+    const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? c.M : c.row_hi;
+    const int nranks = (int)c.ov_remote_bounds.size() - 1;
+    const int64_t nslotrec = (int64_t)nranks * slot;
+    // the output holds what was staged, mirrored locally (both bounded by the staging capacity) and received (bounded by the slots)
+    c.b_cap_entries = 2 * c.ov_tmp_cap + nslotrec + 1;
+    c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
+    c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
+    const bool mir16 = c.pos16 && !c.opt.mir32;
+    c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * (mir16 ? 16 : sizeof(StageRec)));
+    c.ov_marks.mark(4, s);
+    unsigned long long *chk = c.ov_cursors.as<unsigned long long>() + REMOTE_MAX_RANKS;      // (zeroed by send)
+    hipLaunchKernelGGL(k_ingest_remote_slots, dim3((unsigned)((nslotrec + 255) / 256)), dim3(256), 0, s, static_cast<StageRec *>(d_recv), (unsigned long long)nslotrec, (unsigned long long)slot,
+                       c.ov_totcnt.as<uint32_t>(), (uint32_t)row_lo, (uint32_t)row_hi, chk);
+    uint32_t skipped_sorts = 0;
+    ov_launch_finalize(c, 2u, true, skipped_sorts, static_cast<const StageRec *>(d_recv), nslotrec, slot);
+    c.ov_marks.mark(3, s);
+    OvCounters &hc = *static_cast<OvCounters *>(c.ov_host.p);
+    unsigned long long hchk[5] = {0, 0, 0, 0, 0};
+    ELBA_HIP(hipMemcpyAsync(&hc, c.ov_counters.p, sizeof(OvCounters), hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipMemcpyAsync(hchk, chk, sizeof(hchk), hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));      // the step's one synchronisation
+    c.ov_phase = 0;
+    ELBA_REQUIRE(hchk[0] == 0, ELBA_ERR_INVALID_ARG, "seed_matrix_recv: received records for rows outside this context's window");
+    if (hc.overflow || hchk[2]) {
+        // some rank's staging area or slot was too small: every rank saw the flag (it travels in every header) and repeats the step
+        const int64_t slack = (int64_t)c.num_cus * 32 * STAGE_CHUNK + 64;
+        if (hc.overflow) c.ov_tmp_cap = (int64_t)hc.cursor + slack;
+        if (slot_needed) *slot_needed = std::max<int64_t>((int64_t)hchk[3] + (int64_t)hchk[3] / 8 + 16, slot);
+        c.ov_low_clean = false;
+        return false;
+    }
+    if (slot_needed) *slot_needed = slot;
+    c.ov_low_clean = true;
+    elba_overlap_stats st{};
+    st.nrows = row_hi - row_lo;
+    const float ms_sym = c.ov_pend_timed ? c.ov_marks.ms(0, 1) : 0.f, ms_num = c.ov_pend_timed ? c.ov_marks.ms(1, 2) : 0.f, ms_fin = c.ov_marks.ms(4, 3);
+    ov_finish_stats(c, hc, st, 1, c.ov_pend_timed, c.ov_pend_timed ? c.ov_marks.ms(0, 3) : ms_fin, ms_sym, ms_num, ms_fin, (int64_t)hchk[4], (int64_t)hchk[1]);
+    return true;
 }
 
 void stage_create_seed_matrix(Ctx &c)

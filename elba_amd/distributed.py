@@ -85,6 +85,9 @@ class HipBackend:
         L.elba_seed_matrix_begin.restype = i32; L.elba_seed_matrix_begin.argtypes = [vp, i32, vp, vp]
         L.elba_seed_matrix_fill.restype = i32; L.elba_seed_matrix_fill.argtypes = [vp, vp, vp]
         L.elba_seed_matrix_end.restype = i32; L.elba_seed_matrix_end.argtypes = [vp, vp, i64, C.POINTER(capi.OverlapStats)]
+        L.elba_set_stream.restype = i32; L.elba_set_stream.argtypes = [vp, vp]
+        L.elba_seed_matrix_send.restype = i32; L.elba_seed_matrix_send.argtypes = [vp, i32, vp, vp, i64]
+        L.elba_seed_matrix_recv.restype = i32; L.elba_seed_matrix_recv.argtypes = [vp, vp, i64, C.POINTER(capi.OverlapStats), C.POINTER(i64)]
         L.elba_dist_set_panel.restype = i32; L.elba_dist_set_panel.argtypes = [vp, vp, i64, i64, i64, i64, i64, C.POINTER(capi.MatrixStats)]
         L.elba_dist_set_all_reads.restype = i32; L.elba_dist_set_all_reads.argtypes = [vp, vp, i64, vp, vp, i64]
 
@@ -208,6 +211,26 @@ class HipBackend:
         self.e._check(self.L.elba_seed_matrix_end(self.h, recv.data_ptr() if recv.numel() else None, recv.shape[0], C.byref(st)))
         return capi._stats(st)
 
+    # the same with fixed-size slots and ONE host synchronisation per step (elba_set_stream / elba_seed_matrix_send / _recv)
+    def use_current_stream(self):
+        """The library launches on torch's current stream from now on: its kernels and torch's collectives are ordered by the stream."""
+        self.e._check(self.L.elba_set_stream(self.h, C.c_void_p(self.torch.cuda.current_stream(self.dev).cuda_stream)))
+        self.shares_stream = True
+
+    def seed_send(self, nranks, bounds, send, slot):
+        b = np.ascontiguousarray(bounds, dtype=np.uint64)
+        self.e._check(self.L.elba_seed_matrix_send(self.h, nranks, b.ctypes.data, send.data_ptr(), int(slot)))
+
+    def seed_recv(self, recv, slot):
+        """-> (stats, slot) when the step is complete, (None, slot needed) when every rank has to repeat it."""
+        st = capi.OverlapStats()
+        need = C.c_int64(0)
+        rc = self.L.elba_seed_matrix_recv(self.h, recv.data_ptr(), int(slot), C.byref(st), C.byref(need))
+        if rc == 8:                                   # ELBA_ERR_RETRY
+            return None, int(need.value)
+        self.e._check(rc)
+        return capi._stats(st), int(need.value)
+
     def export_csr(self, row_lo, row_hi):
         return self.e.export_csr(row_lo, row_hi)
 
@@ -225,6 +248,9 @@ class DistributedOverlap:
         self.nlocal = 0
         self.bounds = None
         self.row_batches = 1
+        self.time_phases = False          # record (send, exchange, recv) device times of every step with the fixed-slot exchange (bench.py)
+        self.phase_ms = None
+        self.panel_records = 0
 
     # ---- inputs -----------------------------------------------------------------------------------------------------
     def set_reads(self, packed, off, lens, first_global_id, bounds):
@@ -386,6 +412,8 @@ class DistributedOverlap:
         self.block = self.row_block(self.rank, t) if self.row_batches > 1 else (int(self.bounds[self.rank]), int(self.bounds[self.rank + 1]))
         ms = dict(self.be.set_panel(panel, m_total, self.n_total, self.block[0], self.block[1]))
         ms["panel_records"] = int(prc.sum())
+        self.panel_records = int(prc.sum())
+        self._slot = 0                    # a new panel: the slot size of the mirror exchange is guessed afresh
         ms["nnz"] = int(prc.sum())
         self.exchange_bytes["panels"] += int(pc.sum()) * 16
         return ms
@@ -399,6 +427,8 @@ class DistributedOverlap:
             exchange = self.world > 1 and self.row_batches == 1 and hasattr(self.be, "seed_begin")
         if not exchange:
             return self.be.create_seed_matrix()
+        if exchange != "counted" and hasattr(self.be, "seed_send"):
+            return self._create_seed_matrix_slots()
         W = self.world
         sc = self.be.seed_begin(W, self.bounds)
         rc, largest = self._exchange_counts(sc, with_max=True)
@@ -408,6 +438,42 @@ class DistributedOverlap:
         del send
         self.mirror_bytes = int(sc.sum()) * 32
         return self.be.seed_end(recv)
+
+    def _create_seed_matrix_slots(self):
+        """The step with ONE host synchronisation.  The mirror images travel in fixed-size slots (equal splits: no counts cross the host, no
+        buffer is sized from a count), the library and the collective run on one stream, and what the counted variant checks in between —
+        did everything fit? — is checked once at the end, by every rank alike (a flag in every slot's header).  The slot size starts from
+        an upper-bound guess that all ranks compute from the same numbers and only grows."""
+        W, torch = self.world, self.be.torch
+        if not getattr(self.be, "shares_stream", False):
+            self.be.use_current_stream()
+        if getattr(self, "_slot", 0) == 0:
+            # a first guess every rank agrees on: nnz(B) of a shard is below nnz(A) / 4 on every read set seen, the cross-rank part of it is spread
+            # over W - 1 peers; all-reduced so that the largest shard decides
+            g = torch.tensor([max(int(self.panel_records) // (4 * max(W - 1, 1)), 1 << 12)], dtype=torch.int64, device=self.be.dev)
+            if W > 1:
+                self.dist.all_reduce(g, op=self.dist.ReduceOp.MAX)
+            self._slot = int(g.item()) + 1
+        for attempt in range(6):
+            slot = self._slot
+            if getattr(self, "_slot_bufs", (0, None, None))[0] != slot:
+                self._slot_bufs = (slot, self.be.empty_records(W * slot, 4), self.be.empty_records(W * slot, 4))
+            _, send, recv = self._slot_bufs
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if self.time_phases else None
+            if ev: ev[0].record()
+            self.be.seed_send(W, self.bounds, send, slot)
+            if ev: ev[1].record()
+            self.dist.all_to_all_single(recv, send)
+            if ev: ev[2].record()
+            st, need = self.be.seed_recv(recv, slot)
+            if ev:
+                ev[3].record(); ev[3].synchronize()
+                self.phase_ms = dict(send=ev[0].elapsed_time(ev[1]), exchange=ev[1].elapsed_time(ev[2]), recv=ev[2].elapsed_time(ev[3]))
+            self._slot = max(self._slot, need)
+            if st is not None:
+                self.mirror_bytes = W * slot * 32
+                return st
+        raise RuntimeError("create_seed_matrix: the mirror exchange did not settle")
 
     # ---- the step after the path: x-drop alignment of the candidate pairs, sharded ------------------------------------------
     def align_seeds(self, mat=1, mis=-1, gap=-1, dropoff=15):

@@ -49,7 +49,8 @@ enum {
     ELBA_ERR_OUT_OF_MEMORY = 4,
     ELBA_ERR_STATE         = 5,  /* stage called before its inputs exist */
     ELBA_ERR_UNSUPPORTED   = 6,  /* k > 31 (NLONGS > 1), index ranges beyond 32 bit */
-    ELBA_ERR_INTERNAL      = 7
+    ELBA_ERR_INTERNAL      = 7,
+    ELBA_ERR_RETRY         = 8   /* elba_seed_matrix_recv: some rank ran out of room; every rank got this answer: repeat the step */
 };
 
 typedef struct elba_ctx elba_ctx;
@@ -356,6 +357,19 @@ int  elba_dist_panel_fill_win(elba_ctx *ctx, int nranks, const uint64_t *read_bo
 int  elba_seed_matrix_begin(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, uint64_t *send_counts);
 int  elba_seed_matrix_fill(elba_ctx *ctx, void *d_send, const uint64_t *offsets);
 int  elba_seed_matrix_end(elba_ctx *ctx, const void *d_recv, int64_t nrecords, elba_overlap_stats *stats);
+/* The same step with ONE host synchronisation — nothing about the exchange has to be known on the host:
+ *   elba_set_stream         the library launches on the caller's HIP stream from now on (the stream its collectives are ordered against)
+ *   elba_seed_matrix_send   queues classify + numeric + the grouping of the cross-rank mirror images into d_send = nranks slots of slot_records
+ *                           32-byte records: record 0 of slot r is a header written on the device (count, "repeat" flag, slot size needed), the
+ *                           images for rank r follow.  Does not wait.
+ *   (the driver's all-to-all with EQUAL splits: slot r of d_send -> slot <this rank> of rank r's d_recv)
+ *   elba_seed_matrix_recv   queues the merge of d_recv's slots (d_recv is scratch: tickets are written into it), row pointers, column sort;
+ *                           synchronises once.  ELBA_OK: this rank's rows of B are complete.  ELBA_ERR_RETRY: this rank's staging area or some
+ *                           rank's slot was too small — the flag travels in every header, so every rank gets this answer in the same step —
+ *                           capacities have grown: repeat send / all-to-all / recv with *slot_records_needed (the same value on every rank). */
+int  elba_set_stream(elba_ctx *ctx, void *hip_stream);
+int  elba_seed_matrix_send(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, void *d_send, int64_t slot_records);
+int  elba_seed_matrix_recv(elba_ctx *ctx, void *d_recv, int64_t slot_records, elba_overlap_stats *stats, int64_t *slot_records_needed);
 /* receiver side: the panel of every column touching rows [row_lo,row_hi) -> columns (renumbered by rank among the columns present) + CSR; elba_create_seed_matrix
  * then computes exactly those rows of B (global column ids); elba_export_csr(row_lo,row_hi) / elba_export_dcsc read them */
 int  elba_dist_set_panel(elba_ctx *ctx, const void *d_records, int64_t nrecords, int64_t nreads_total, int64_t nkmers_total,

@@ -171,15 +171,19 @@ def test_with_and_without_the_mirror_exchange(world):
     o = po.Oracle(17, 2, 8); o.count_and_build(packed, off, lens); o.spgemm(4)
     oB = o.B()
     bounds = partition_by_bases(lens, world)
-    for exchange in (True, False):
+    # True: fixed-size slots, one host synchronisation per step (elba_seed_matrix_send / _recv); "tiny": the same from a slot of 4 records — every
+    # rank is told to repeat the step with the size that was needed; "counted": begin / fill / end with counts crossing the host
+    for exchange in (True, "tiny", "counted", False):
         def body(rank, h):
             a, b = int(bounds[rank]), int(bounds[rank + 1])
             sp, so, sl = _shard(packed, off, lens, a, b)
             d = DistributedOverlap(17, 2, 8, device=0, rank=rank, world=world, dist=h, backend=HipBackend(17, 2, 8, 0))
             d.set_reads(sp, so, sl, a, bounds)
             d.build_kmer_matrix()
-            st = d.create_seed_matrix(exchange=exchange)
-            st2 = d.create_seed_matrix(exchange=exchange)          # a second call on the same panel
+            if exchange == "tiny":
+                d._slot = 4
+            st = d.create_seed_matrix(exchange=True if exchange == "tiny" else exchange)
+            st2 = d.create_seed_matrix(exchange=True if exchange == "tiny" else exchange)          # a second call on the same panel
             out = (d.export_csr(), st, st2)
             d.be.e.close()
             return out
