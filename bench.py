@@ -59,6 +59,7 @@ def main():
     ap.add_argument("--workload", default="200k-long-reads", choices=sorted(WORKLOADS))
     ap.add_argument("--steady-steps", type=int, default=10, help="untimed-by-the-contract steps with the hints of earlier calls kept (secondary figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-accounting", action="store_true", help="skip spgemm_prep / from_triples (two more contexts)")
     ap.add_argument("--cpu-sample-div", type=int, default=0, help="CPU baseline sample: the same generator with the genome divided by this (0: chosen for ~10-30 s of CPU work)")
     ap.add_argument("--timing-stride", type=int, default=4, help="the library records its phase events (kernel_ms of the roofline) on every N-th step only: "
                     "an event record costs ~5 us of stream time; kernel_ms is the mean over the steps that were measured")
@@ -115,6 +116,7 @@ def main():
     else:
         from elba_amd.distributed import DistributedOverlap
         runner = DistributedOverlap(k, lo, up, device=local_rank, rank=rank, world=world, dist=dist, timing_stride=args.timing_stride)
+        runner.time_phases = True                 # (send, all-to-all, recv) device times of every step, per rank
         t0 = time.time()
         info = runner.generate_and_set_reads(w, weak=args.weak)
         t_gen = time.time() - t0
@@ -134,12 +136,16 @@ def main():
     t0 = time.perf_counter()
     acc = dict(ms_total=0.0, ms_numeric=0.0, ms_symbolic=0.0, ms_finalize=0.0)
     ntimed = 0
+    rank_phase = dict(send=0.0, exchange=0.0, recv=0.0)
     for _ in range(args.steps):
         st = step()
         if st.get("timed", 1):
             ntimed += 1
             for key in acc:
                 acc[key] += st[key]
+        if not single and getattr(runner, "phase_ms", None):
+            for key in rank_phase:
+                rank_phase[key] += runner.phase_ms[key] / max(1, args.steps)
     barrier_sync()
     dt = time.perf_counter() - t0
     st_cold = st
@@ -150,7 +156,13 @@ def main():
         tot = torch.tensor([st["nnz"], st["products"], st["algorithmic_bytes"], ks["instances"], ms["nnz"], bases_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         Y, P, abytes, I_tot, Z_tot, bases_tot = [int(x) for x in tot.tolist()]
+        # every rank's step phases (device time on its stream): queue numeric + group the mirror images | all-to-all | merge + finalize + the one host wait
+        ph = torch.tensor([rank_phase["send"], rank_phase["exchange"], rank_phase["recv"], float(st["nnz"]), float(st["products"])], dtype=torch.float64, device="cuda")
+        allph = [torch.zeros_like(ph) for _ in range(world)]
+        dist.all_gather(allph, ph)
+        rank_phases = [dict(rank=r, send_ms=round(float(x[0]), 4), exchange_ms=round(float(x[1]), 4), recv_ms=round(float(x[2]), 4), nnz=int(x[3]), products=int(x[4])) for r, x in enumerate(allph)]
     else:
+        rank_phases = None
         Y, P, abytes, I_tot, Z_tot, bases_tot = st["nnz"], st["products"], st["algorithmic_bytes"], ks["instances"], ms["nnz"], bases_local
     steps = max(1, args.steps)
     ms_step = dt / steps * 1e3
@@ -185,17 +197,22 @@ def main():
     my_bytes = st_cold["algorithmic_bytes"]
     achieved = my_bytes / (acc["ms_numeric"] * 1e-3) / 1e9 if acc["ms_numeric"] > 0 else 0.0
     traffic = None
+    traffic_note = None
     tj = None
+    fingerprint = elba_amd.capi.numeric_source_fingerprint()
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
             if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
-                traffic = tj.get("hbm_bytes_per_step_dominant_kernel")
+                if tj.get("numeric_source_sha16") == fingerprint:
+                    traffic = tj.get("hbm_bytes_per_step_dominant_kernel")
+                else:
+                    traffic_note = "profiles/traffic.json was measured on other kernel sources (%s, now %s): not quoted" % (tj.get("numeric_source_sha16"), fingerprint)
         except Exception:
             traffic = None
     roofline = {"bound": "hbm", "kernel": "k_spgemm_direct (plan-free LDS-hash numeric, all tiers)", "achieved": round(achieved, 3), "peak": PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / PEAK_GBS, 6), "traffic": traffic,
+                "frac": round(achieved / PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                 "algorithmic_bytes_per_step": my_bytes, "bytes_per_nnz": round(my_bytes / max(1, st_cold["nnz"]), 2),
                 "kernel_ms": round(acc["ms_numeric"], 4), "kernel_ms_measured_on_steps": ntimed, "region_ms_device": round(acc["ms_total"], 4),
                 "frac_whole_region": round(my_bytes / (acc["ms_total"] * 1e-3) / 1e9 / PEAK_GBS, 6) if acc["ms_total"] > 0 else 0.0,
@@ -206,7 +223,7 @@ def main():
     if os.path.exists(rpath) and acc["ms_numeric"] > 0:
         try:
             rj = json.load(open(rpath))
-            if rj.get("workload") == args.workload and rj.get("n_gpus", 1) == world:
+            if rj.get("workload") == args.workload and rj.get("n_gpus", 1) == world and rj.get("numeric_source_sha16") == fingerprint:
                 rate = rj["tcc_requests_per_step"] / (acc["ms_numeric"] * 1e-3) / 1e9
                 roofline["l2_requests"] = {"per_step": rj["tcc_requests_per_step"], "achieved_G_per_s": round(rate, 2), "measured_ceiling_G_per_s": rj["ceiling_G_requests_per_s"],
                                            "frac_of_ceiling": round(rate / max(rj["ceiling_G_requests_per_s"]), 4)}
@@ -230,6 +247,42 @@ def main():
     e2e_s = t_kmer_wall + dt / steps
     end_to_end = {"ms": round(e2e_s * 1e3, 3), "what": "packed reads on the device -> B: k-mer stage + one cold SpGEMM step (reference timers src/main.cpp:191-282)",
                   "overlap_nnz_per_s": round(Y / e2e_s, 1), "bytes": kb + abytes, "frac": round((kb + abytes) / e2e_s / 1e9 / PEAK_GBS / world, 6)}
+
+    # ---- honest accounting of what the SpGEMM region leans on (N = 1) ------------------------------------------------------------------------
+    # (a) the k-mer stage writes two things for the product's sake alone: the padded column store and the ownership bits of the row entries.
+    #     Their cost = this k-mer stage minus the same stage built without them ("no_ell", "no_hints"), on a context of its own.
+    # (b) what a replacement of create_seed_matrix(A, AT) alone pays (option B): A arrives as device-resident triples,
+    #     elba_set_kmer_matrix_device rebuilds CSR + columns + hints, then ONE cold call.
+    prep = None
+    from_triples = None
+    if single and rank == 0 and not args.no_accounting:
+        e2 = Engine(k, lo, up, device=local_rank, options={"no_ell": 1, "no_hints": 1})
+        e2.set_reads_device(d_packed.data_ptr(), int(packed.size) - 16, d_off.data_ptr(), d_len.data_ptr(), len(lens))
+        e2.count_kmers(); e2.create_kmer_matrix(); torch.cuda.synchronize()
+        t0 = time.perf_counter(); e2.count_kmers(); e2.create_kmer_matrix(); torch.cuda.synchronize(); t_plain = time.perf_counter() - t0
+        e2.close()
+        prep_ms = max(0.0, (t_kmer_wall - t_plain) * 1e3)
+        prep = {"spgemm_prep_ms": round(prep_ms, 3), "what": "padded column store + ownership hint bits: k-mer stage with them (%.3f ms) minus without (%.3f ms)" % (t_kmer_wall * 1e3, t_plain * 1e3),
+                "frac_incl_prep": round(my_bytes / ((acc["ms_numeric"] + prep_ms) * 1e-3) / 1e9 / PEAK_GBS, 6) if acc["ms_numeric"] > 0 else None,
+                "frac_whole_region_incl_prep": round(my_bytes / ((acc["ms_total"] + prep_ms) * 1e-3) / 1e9 / PEAK_GBS, 6) if acc["ms_total"] > 0 else None}
+        Zt = int(ms["nnz"])
+        d_rows = torch.empty(Zt, dtype=torch.int64, device="cuda"); d_cols = torch.empty(Zt, dtype=torch.int64, device="cuda"); d_vals = torch.empty(Zt, dtype=torch.int32, device="cuda")
+        eng.export_triples_device(d_rows.data_ptr(), d_cols.data_ptr(), d_vals.data_ptr())
+        e3 = Engine(k, lo, up, device=local_rank)
+        e3.set_kmer_matrix_device(int(ms["nrows"]), int(ms["ncols"]), Zt, d_rows.data_ptr(), d_cols.data_ptr(), d_vals.data_ptr()); e3.create_seed_matrix(); torch.cuda.synchronize()      # allocations
+        e3.set_option("overlap_cold_calls", 1)
+        t0 = time.perf_counter(); m3 = e3.set_kmer_matrix_device(int(ms["nrows"]), int(ms["ncols"]), Zt, d_rows.data_ptr(), d_cols.data_ptr(), d_vals.data_ptr()); torch.cuda.synchronize(); t_set = time.perf_counter() - t0
+        t0 = time.perf_counter(); s3 = e3.create_seed_matrix(); torch.cuda.synchronize(); t_call = time.perf_counter() - t0
+        from_triples = {"set_kmer_matrix_device_ms": round(t_set * 1e3, 3), "first_cold_call_ms": round(t_call * 1e3, 3), "ms": round((t_set + t_call) * 1e3, 3),
+                        "overlap_nnz_per_s": round(s3["nnz"] / (t_set + t_call), 1), "same_nnz_and_products": bool(s3["nnz"] == st_cold["nnz"] and s3["products"] == st_cold["products"]),
+                        "what": "device-resident COO triples of A (int64, int64, uint32) -> CSR + k-mer columns + hints + padded columns, then one cold elba_create_seed_matrix"}
+        e3.close()
+        del d_rows, d_cols, d_vals
+    # the reference's five stage timers (src/main.cpp:193,226,260,274,282) and what runs under each label here
+    ref_timers = {"collecting distinct k-mers": round(ks.get("ms_count", 0.0), 3), "counting recording k-mer seeds": round(ks.get("ms_sort", 0.0), 3),
+                  "creating k-mer matrix": round(ms["ms_total"] if ms else 0.0, 3), "copying and transposing k-mer matrix": 0.0,
+                  "creating seed matrix (spgemm)": round(ms_step, 4),
+                  "note": "device ms of this rank; labels 1-2 = the two halves of elba_count_kmers (value partition | bucket count + columns), label 4 is empty: both orientations of A leave the k-mer stage together"}
 
     # ---- CPU baseline + parity on a bounded sample of the same workload (rank 0, N = 1) ------------------------------------------------
     cpu = None
@@ -265,6 +318,17 @@ def main():
                "gpu_on_the_same_sample": {"ms_cold_call": round(sst["ms_total"], 4), "value": round(sst["nnz"] / max(1e-9, sst["ms_total"] * 1e-3), 1)}}
         if es is not eng:
             es.close()
+        # the k-mer stage and the whole reads -> B region on the host (reference timers src/main.cpp:191-282): the oracle's count_and_build is a
+        # scalar port (1 core), timed on a third of the SpGEMM sample's genome so that it stays within ~10 s
+        kp, ko, kl, _ = elba_amd.synth_reads(w["seed"], max(20000, w["genome"] // (div * 3)), w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"],
+                                             repeat_families=w.get("repeats", (0, 0.0, 0))[0], repeat_fraction=w.get("repeats", (0, 0.0, 0))[1], repeat_len=w.get("repeats", (0, 0.0, 0))[2])
+        o2 = po.Oracle(k, lo, up)
+        t0 = time.perf_counter(); o2.count_and_build(kp, ko, kl); tk1 = time.perf_counter() - t0
+        t0 = time.perf_counter(); o2.spgemm(1); ts1 = time.perf_counter() - t0
+        cpu["kmer_stage"] = {"instances_per_s": round(o2.stat("I") / tk1, 1), "seconds": round(tk1, 3), "cores": 1, "instances": int(o2.stat("I")),
+                             "sample": "genome divided by %d (%d reads)" % (div * 3, len(kl)), "gpu_instances_per_s": kmer_stage["instances_per_s"]}
+        cpu["end_to_end"] = {"overlap_nnz_per_s": round(o2.stat("Y") / (tk1 + ts1), 1), "seconds": round(tk1 + ts1, 3), "cores": 1, "overlap_nnz": int(o2.stat("Y")),
+                             "gpu_overlap_nnz_per_s": end_to_end["overlap_nnz_per_s"]}
 
     aux = None
     if args.aux and single and rank == 0:
@@ -286,6 +350,10 @@ def main():
             "steady_state": steady,
             "kmer_stage": kmer_stage,
             "end_to_end": end_to_end,
+            "spgemm_prep": prep,
+            "from_triples": from_triples,
+            "reference_stage_timers_ms": ref_timers,
+            "rank_phases_ms": rank_phases,
             "phases_ms": {key: round(v, 4) for key, v in acc.items()},
             "tiers": {key: int(st_cold[key]) for key in ("rows_lds", "rows_global", "rows_escalated", "nnz_before_prune", "passes") if key in st_cold},
             "aux_stages": aux,

@@ -12,6 +12,17 @@ def lib_path():
     return os.environ.get("ELBA_AMD_LIB") or os.path.join(_HERE, "lib", "libelba_amd.so")
 
 
+def numeric_source_fingerprint():
+    """sha256 (16 hex digits) of the sources of the SpGEMM's numeric kernel: what a rocprof counter summary under profiles/ is valid for.
+    bench.py quotes `roofline.traffic` from profiles/traffic.json only while this matches the value stored there."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("spgemm.hip", "spgemm_direct.hpp", "spgemm_table.hpp"):
+        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 class ElbaError(RuntimeError):
     def __init__(self, status, text):
         super().__init__("elba status %d: %s" % (status, text))
@@ -110,7 +121,7 @@ EXPORTED_SYMBOLS = [
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
     "elba_kmer_hash_owner", "elba_dist_value_histogram", "elba_dist_set_owner_ranges", "elba_dist_set_kmer_id_base", "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
     "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_panel_counts_win", "elba_dist_panel_fill_win", "elba_dist_set_panel",
-    "elba_seed_matrix_begin", "elba_seed_matrix_fill", "elba_seed_matrix_end", "elba_set_stream", "elba_seed_matrix_send", "elba_seed_matrix_recv",
+    "elba_seed_matrix_begin", "elba_seed_matrix_fill", "elba_seed_matrix_end", "elba_set_stream", "elba_seed_matrix_send", "elba_seed_matrix_recv", "elba_set_kmer_matrix_device", "elba_export_triples_device",
 ]
 
 _lib = None
@@ -150,6 +161,8 @@ def load_library():
     L.elba_count_kmers.restype = i32; L.elba_count_kmers.argtypes = [vp, C.POINTER(KmerStats)]
     L.elba_create_kmer_matrix.restype = i32; L.elba_create_kmer_matrix.argtypes = [vp, C.POINTER(MatrixStats)]
     L.elba_set_kmer_matrix.restype = i32; L.elba_set_kmer_matrix.argtypes = [vp, i64, i64, i64, vp, vp, vp, C.POINTER(MatrixStats)]
+    L.elba_set_kmer_matrix_device.restype = i32; L.elba_set_kmer_matrix_device.argtypes = [vp, i64, i64, i64, vp, vp, vp, C.POINTER(MatrixStats)]
+    L.elba_export_triples_device.restype = i32; L.elba_export_triples_device.argtypes = [vp, vp, vp, vp]
     L.elba_create_seed_matrix.restype = i32; L.elba_create_seed_matrix.argtypes = [vp, C.POINTER(OverlapStats)]
     L.elba_align_seeds.restype = i32; L.elba_align_seeds.argtypes = [vp, i32, i32, i32, i32, C.POINTER(AlignStats)]
     L.elba_export_overlaps.restype = i32; L.elba_export_overlaps.argtypes = [vp, C.POINTER(Overlaps)]
@@ -271,6 +284,15 @@ class Engine:
         st = MatrixStats()
         self._check(self.L.elba_set_kmer_matrix(self.h, nrows, ncols, len(rows), rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, C.byref(st)))
         return _stats(st)
+
+    def set_kmer_matrix_device(self, nrows, ncols, nnz, d_rows, d_cols, d_vals):
+        """The triples resident in HBM (device pointers: int64 rows, int64 cols, uint32 vals)."""
+        st = MatrixStats()
+        self._check(self.L.elba_set_kmer_matrix_device(self.h, nrows, ncols, nnz, d_rows, d_cols, d_vals, C.byref(st)))
+        return _stats(st)
+
+    def export_triples_device(self, d_rows, d_cols, d_vals):
+        self._check(self.L.elba_export_triples_device(self.h, d_rows, d_cols, d_vals))
 
     def kmer_hash_owner(self, kmers, nprocs):
         """Kmer::GetHash and GetKmerOwner of the reference, computed on the device: kmers = n x W packed words."""

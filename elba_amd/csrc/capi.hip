@@ -218,6 +218,22 @@ int elba_set_kmer_matrix(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nn
     });
 }
 
+int elba_set_kmer_matrix_device(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz, const void *d_rows, const void *d_cols, const void *d_vals, elba_matrix_stats *stats)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        EventTimer t;
+        t.start(c.stream);
+        stage_set_kmer_matrix_device(c, nrows, ncols, nnz, static_cast<const int64_t *>(d_rows), static_cast<const int64_t *>(d_cols), static_cast<const uint32_t *>(d_vals));
+        t.stop(c.stream);
+        if (stats) { stats->nrows = c.M; stats->ncols = c.N; stats->nnz = c.Z; stats->max_row_nnz = c.max_row_nnz; stats->ms_total = t.ms(); }
+    });
+}
+
+int elba_export_triples_device(elba_ctx *ctx, void *d_rows, void *d_cols, void *d_vals)
+{
+    return guarded(ctx, [&](Ctx &c) { stage_export_triples_device(c, static_cast<int64_t *>(d_rows), static_cast<int64_t *>(d_cols), static_cast<uint32_t *>(d_vals)); });
+}
+
 int elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats)
 {
     return guarded(ctx, [&](Ctx &c) {

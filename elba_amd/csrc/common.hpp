@@ -264,6 +264,8 @@ void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
 bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st);   // kmer_msd.hip: false = not applicable (the caller sorts)
 void choose_column_store(Ctx &c, int64_t N, int64_t max_col);     // matrix.hip: padded column store or plain CSC, strides, sequence-number bits
 void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip
+void stage_set_kmer_matrix_device(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *d_rows, const int64_t *d_cols, const uint32_t *d_vals);
+void stage_export_triples_device(Ctx &c, int64_t *d_rows, int64_t *d_cols, uint32_t *d_vals);
 void stage_create_seed_matrix(Ctx &c);                            // spgemm.hip
 void stage_seed_matrix_begin(Ctx &c, int nranks, const uint64_t *bounds_host, uint64_t *send_counts_host);
 void stage_seed_matrix_fill(Ctx &c, void *d_send, const uint64_t *offsets_host);

@@ -332,28 +332,37 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     c.have_B = false;
 }
 
-void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals)
+namespace {
+// device triples -> (key = pos, value = col << 32 | row) pairs of the three-pass sort; out-of-range indices are counted, the largest position kept
+__global__ void k_pack_triples(const int64_t *rows, const int64_t *cols, const uint32_t *vals, int64_t Z, int64_t M, int64_t N, uint64_t *k0, uint64_t *v0, unsigned long long *chk)
 {
-    ELBA_REQUIRE(M >= 0 && N >= 0 && Z >= 0, ELBA_ERR_INVALID_ARG, "negative matrix dimension");
-    ELBA_REQUIRE(M < 0xFFFFFFFFll && N < 0xFFFFFFFFll && Z < 0xFFFFFFFFll, ELBA_ERR_UNSUPPORTED, "matrix dimension beyond 32-bit device indices");
-    ELBA_REQUIRE(Z == 0 || (rows && cols && vals), ELBA_ERR_INVALID_ARG, "null triple array");
+    const int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0, mx = 0;
+    if (z < Z) {
+        const int64_t r = rows[z], cc = cols[z];
+        const uint32_t v = vals[z];
+        if (r < 0 || r >= M || cc < 0 || cc >= N) bad = 1;
+        else { k0[z] = v; v0[z] = ((uint64_t)cc << 32) | (uint64_t)r; mx = v; }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { bad += __shfl_xor(bad, d, 64); const unsigned long long o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0) { if (bad) atomicAdd(&chk[0], bad); if (mx) atomicMax(&chk[1], mx); }
+}
+// A as triples, from the resident matrix (rows: the context's row ids, cols: k-mer ids, vals: positions), in CSR order
+__global__ void k_export_triples(const uint32_t *rowptr, const uint64_t *csr, uint32_t M, uint32_t pos_mask, int64_t *rows, int64_t *cols, uint32_t *vals)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t i = wave; i < M; i += nwaves)
+        for (uint32_t e = rowptr[i] + lane, re = rowptr[i + 1]; e < re; e += 64) { const uint64_t x = csr[e]; rows[e] = i; cols[e] = (int64_t)(x >> 32); vals[e] = (uint32_t)x & pos_mask; }
+}
+}  // namespace
+
+// k0 / v0 (= c.ws_a / c.ws_b) hold (pos, col << 32 | row) of every triple
+static void set_kmer_matrix_from_pairs(Ctx &c, int64_t M, int64_t N, int64_t Z, uint64_t maxpos)
+{
     hipStream_t s = c.stream;
-    std::vector<uint64_t> hk((size_t)Z + 1), hv((size_t)Z + 1);
-    uint32_t maxpos = 0;
-    for (int64_t z = 0; z < Z; ++z) {
-        ELBA_REQUIRE(rows[z] >= 0 && rows[z] < M && cols[z] >= 0 && cols[z] < N, ELBA_ERR_INVALID_ARG, "triple index out of range");
-        hk[(size_t)z] = vals[z];
-        hv[(size_t)z] = ((uint64_t)cols[z] << 32) | (uint64_t)rows[z];
-        if (vals[z] > maxpos) maxpos = vals[z];
-    }
-    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_b.reserve((size_t)(Z + 1) * 8);
-    c.ws_c.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
-    c.ws_e.reserve((size_t)(Z + 1) * 8); c.ws_f.reserve((size_t)(Z + 1) * 8);
     uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
-    if (Z > 0) {
-        ELBA_HIP(hipMemcpyAsync(k0, hk.data(), (size_t)Z * 8, hipMemcpyHostToDevice, s));
-        ELBA_HIP(hipMemcpyAsync(v0, hv.data(), (size_t)Z * 8, hipMemcpyHostToDevice, s));
-    }
     // (1) by pos, (2) by row, (3) by col — LSD, stable: final order (col, row, pos)
     int w = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, bits_for(maxpos), c.ws_sort);
     // swap roles: key := (col<<32|row), value := pos
@@ -372,6 +381,63 @@ void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_
     }
     c.A_has_kmers = false;
     finish_matrix_from_sorted_csc(c, M, N, Z, keys, 32, csc);
+}
+
+void stage_set_kmer_matrix_device(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *d_rows, const int64_t *d_cols, const uint32_t *d_vals)
+{
+    ELBA_REQUIRE(M >= 0 && N >= 0 && Z >= 0, ELBA_ERR_INVALID_ARG, "negative matrix dimension");
+    ELBA_REQUIRE(M < 0xFFFFFFFFll && N < 0xFFFFFFFFll && Z < 0xFFFFFFFFll, ELBA_ERR_UNSUPPORTED, "matrix dimension beyond 32-bit device indices");
+    ELBA_REQUIRE(Z == 0 || (d_rows && d_cols && d_vals), ELBA_ERR_INVALID_ARG, "null triple array");
+    hipStream_t s = c.stream;
+    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_b.reserve((size_t)(Z + 1) * 8);
+    c.ws_c.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
+    c.ws_e.reserve((size_t)(Z + 1) * 8); c.ws_f.reserve((size_t)(Z + 1) * 8);
+    c.ws_scan.reserve(64);
+    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 16, s));
+    if (Z > 0)
+        hipLaunchKernelGGL(k_pack_triples, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, d_rows, d_cols, d_vals, Z, M, N, c.ws_a.as<uint64_t>(), c.ws_b.as<uint64_t>(), c.ws_scan.as<unsigned long long>());
+    unsigned long long chk[2] = {0, 0};
+    ELBA_HIP(hipMemcpyAsync(chk, c.ws_scan.p, 16, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    ELBA_REQUIRE(chk[0] == 0, ELBA_ERR_INVALID_ARG, "triple index out of range");
+    set_kmer_matrix_from_pairs(c, M, N, Z, chk[1]);
+}
+
+void stage_export_triples_device(Ctx &c, int64_t *d_rows, int64_t *d_cols, uint32_t *d_vals)
+{
+    ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "export_triples_device: no k-mer matrix");
+    ELBA_REQUIRE(c.Z == 0 || (d_rows && d_cols && d_vals), ELBA_ERR_INVALID_ARG, "null triple array");
+    if (c.M > 0 && c.Z > 0) {
+        int nb = (int)std::min<int64_t>((c.M + 3) / 4, (int64_t)c.num_cus * 32);
+        hipLaunchKernelGGL(k_export_triples, dim3(nb), dim3(256), 0, c.stream, (const uint32_t *)c.a_rowptr.as<uint32_t>(), (const uint64_t *)c.a_csr.as<uint64_t>(), (uint32_t)c.M,
+                           c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu), d_rows, d_cols, d_vals);
+    }
+    ELBA_HIP(hipStreamSynchronize(c.stream));
+}
+
+void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals)
+{
+    ELBA_REQUIRE(M >= 0 && N >= 0 && Z >= 0, ELBA_ERR_INVALID_ARG, "negative matrix dimension");
+    ELBA_REQUIRE(M < 0xFFFFFFFFll && N < 0xFFFFFFFFll && Z < 0xFFFFFFFFll, ELBA_ERR_UNSUPPORTED, "matrix dimension beyond 32-bit device indices");
+    ELBA_REQUIRE(Z == 0 || (rows && cols && vals), ELBA_ERR_INVALID_ARG, "null triple array");
+    hipStream_t s = c.stream;
+    std::vector<uint64_t> hk((size_t)Z + 1), hv((size_t)Z + 1);
+    uint32_t maxpos = 0;
+    for (int64_t z = 0; z < Z; ++z) {
+        ELBA_REQUIRE(rows[z] >= 0 && rows[z] < M && cols[z] >= 0 && cols[z] < N, ELBA_ERR_INVALID_ARG, "triple index out of range");
+        hk[(size_t)z] = vals[z];
+        hv[(size_t)z] = ((uint64_t)cols[z] << 32) | (uint64_t)rows[z];
+        if (vals[z] > maxpos) maxpos = vals[z];
+    }
+    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_b.reserve((size_t)(Z + 1) * 8);
+    c.ws_c.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
+    c.ws_e.reserve((size_t)(Z + 1) * 8); c.ws_f.reserve((size_t)(Z + 1) * 8);
+    if (Z > 0) {
+        ELBA_HIP(hipMemcpyAsync(c.ws_a.p, hk.data(), (size_t)Z * 8, hipMemcpyHostToDevice, s));
+        ELBA_HIP(hipMemcpyAsync(c.ws_b.p, hv.data(), (size_t)Z * 8, hipMemcpyHostToDevice, s));
+        ELBA_HIP(hipStreamSynchronize(s));      // (the host vectors go out of scope below)
+    }
+    set_kmer_matrix_from_pairs(c, M, N, Z, maxpos);
 }
 
 }  // namespace elba

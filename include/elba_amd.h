@@ -248,6 +248,13 @@ int  elba_create_kmer_matrix(elba_ctx *ctx, elba_matrix_stats *stats);
 int  elba_set_kmer_matrix(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz,
                           const int64_t *rows, const int64_t *cols, const uint32_t *vals, elba_matrix_stats *stats);
 
+/* The same with the three arrays resident in HBM (int64 rows, int64 cols, uint32 vals): what a GPU-resident caller of create_seed_matrix(A, AT)
+ * (include/SharedSeeds.hpp:98-99) hands over.  elba_export_triples_device writes the resident A back as such triples (CSR order) into
+ * caller-allocated device arrays of nnz elements each. */
+int  elba_set_kmer_matrix_device(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz,
+                                 const void *d_rows, const void *d_cols, const void *d_vals, elba_matrix_stats *stats);
+int  elba_export_triples_device(elba_ctx *ctx, void *d_rows, void *d_cols, void *d_vals);
+
 int  elba_create_seed_matrix(elba_ctx *ctx, elba_overlap_stats *stats);
 
 /* PairwiseAlignment (src/PairwiseAlignment.cpp:5-106) on one rank, on the GPU: x-drop seed-and-extend from seeds[0] of every stored

@@ -11,6 +11,8 @@ import shutil
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+from elba_amd.capi import numeric_source_fingerprint      # noqa: E402 — what the counter summaries are valid for (bench.py checks it)
 
 
 def short(n):
@@ -75,13 +77,13 @@ def main():
         steps_r = rn[("k_finalize_wave", "TCC_REQ_sum")] or 1
         req = {c: round(sum(v.get(c, 0) for k, v in ra.items() if k.startswith(NUMERIC)) / steps_r) for c in ("TCC_REQ_sum", "TCP_TCC_READ_REQ_sum", "TCP_TCC_WRITE_REQ_sum", "TCP_TCC_ATOMIC_WITH_RET_REQ_sum")}
         out["L2_requests_per_step"] = req
-        json.dump({"workload": workload, "n_gpus": 1, "source": "%s_summary.json (rocprofv3 --pmc TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum, numeric kernels of one step)" % tag,
+        json.dump({"workload": workload, "n_gpus": 1, "numeric_source_sha16": numeric_source_fingerprint(), "source": "%s_summary.json (rocprofv3 --pmc TCC_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_ATOMIC_WITH_RET_REQ_sum, numeric kernels of one step)" % tag,
                    "tcc_requests_per_step": req["TCC_REQ_sum"], "read_requests_per_step": req["TCP_TCC_READ_REQ_sum"], "write_requests_per_step": req["TCP_TCC_WRITE_REQ_sum"],
                    "returning_atomics_per_step": req["TCP_TCC_ATOMIC_WITH_RET_REQ_sum"],
                    "ceiling_source": "profiles/microbench/gather64.hip (profiles/r02_gather64_microbench.txt): random 64-byte lines read by 4 lanes x 16 B, 350 MB and 12.9 GB arrays",
                    "ceiling_G_requests_per_s": [46.5, 52.5]}, open(os.path.join(HERE, "requests.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(HERE, "%s_summary.json" % tag), "w"), indent=1)
-    json.dump({"workload": out["workload"], "n_gpus": 1, "source": "%s_summary.json" % tag,
+    json.dump({"workload": out["workload"], "n_gpus": 1, "numeric_source_sha16": numeric_source_fingerprint(), "source": "%s_summary.json" % tag,
                "hbm_bytes_per_step_dominant_kernel": out["hbm_bytes_per_step_dominant_kernel"]}, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
