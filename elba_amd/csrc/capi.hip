@@ -506,7 +506,8 @@ int elba_get_device_view(elba_ctx *ctx, elba_device_view *v)
         v->stream = (void *)c.stream;
         if (c.have_A) { v->M = c.M; v->N = c.N; v->Z = c.Z; v->a_rowptr = c.a_rowptr.p; v->a_csr = c.a_csr.p; v->a_colptr = c.a_colptr.p; v->a_csc = c.a_csc.p;
                         v->a_csr_format = c.csr_suffix ? ELBA_CSR_DENSE : (c.csr_hints ? ELBA_CSR_HINTS : ELBA_CSR_PLAIN);
-                        v->a_csr_pos_mask = c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu); }
+                        v->a_csr_pos_mask = c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu);
+                        v->a_kmers = c.A_has_kmers ? c.rel_kmers.p : nullptr; }
         if (c.have_B) { v->Y = c.Y; v->b_rowptr = c.b_rowptr.p; v->b_col = c.b_col.p; v->b_val = c.b_val.p; }
     });
 }

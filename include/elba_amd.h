@@ -213,6 +213,7 @@ typedef struct {
     void *stream;          /* hipStream_t the library launches on */
     uint32_t a_csr_format; /* which of the three encodings of a_csr is active (ELBA_CSR_*) */
     uint32_t a_csr_pos_mask; /* position of an a_csr entry = low word & a_csr_pos_mask, whatever the format */
+    const void *a_kmers;   /* u64[N]: packed canonical k-mer (first word) of every column, ascending; NULL when A came from triples */
 } elba_device_view;
 enum { ELBA_CSR_PLAIN = 0 /* kid<<32 | pos */, ELBA_CSR_HINTS = 1 /* kid<<32 | hint<<30 | pos */, ELBA_CSR_DENSE = 2 /* kid<<32 | L<<23 | idx<<16 | pos */ };
 

@@ -278,6 +278,33 @@ int64_t orc_read_kmers(const uint8_t *mem, uint32_t len, int k, uint64_t *out)
     return n;
 }
 
+/* Test support for checks at sizes where the whole pipeline is too slow on the host: the canonical k-mer instances (k <= 31) of the reads
+ * [r0, r1) whose VALUE CLASS — the right-aligned 2k-bit value modulo 4096 — is set in the 4096-bit bitmap `classes`; the enumeration itself is
+ * orc_read_kmers' (include/KmerOps.hpp:105-137).  vals == NULL: count only.  Returns the number of instances (written: at most cap). */
+int64_t orc_enumerate_classes(const uint8_t *buf, const uint64_t *byte_off, const uint32_t *lens, int64_t r0, int64_t r1, int k, const uint64_t *classes,
+                              uint64_t *vals, uint32_t *reads, uint32_t *pos, int64_t cap)
+{
+    int64_t n = 0;
+    for (int64_t r = r0; r < r1; ++r) {
+        const uint8_t *mem = buf + byte_off[r];
+        const uint32_t len = lens[r];
+        if ((int64_t)len < k) continue;
+        uint64_t w = 0;
+        for (int i = 0; i < k; ++i) w |= (uint64_t)orc_base_at(mem, (size_t)i) << (2 * (31 - i));
+        const int64_t ni = (int64_t)len - k + 1;
+        for (int64_t i = 0; i < ni; ++i) {
+            if (i) w = orc_kmer_extend(w, orc_base_at(mem, (size_t)(i + k - 1)), k);
+            const uint64_t v = orc_kmer_rep(w, k) >> (64 - 2 * k);
+            const uint32_t c = (uint32_t)(v & 4095u);
+            if ((classes[c >> 6] >> (c & 63u)) & 1ull) {
+                if (vals && n < cap) { vals[n] = v; reads[n] = (uint32_t)r; pos[n] = (uint32_t)i; }
+                ++n;
+            }
+        }
+    }
+    return n;
+}
+
 typedef struct { uint64_t kmer, kmer2, kmer3; uint32_t read, pos; } orc_inst_t;      /* kmer2 / kmer3: second / third word when k > 32 / 64, else 0 */
 
 /* stable LSD radix sort of instances by the k-mer value (11-bit digits): the bits of the second word first (k > 32), then the first word's */

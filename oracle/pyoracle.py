@@ -59,6 +59,8 @@ def lib():
         L.orc_kmer2_at.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
         L.orc_read_kmers.restype = C.c_int64
         L.orc_read_kmers.argtypes = [C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]
+        L.orc_enumerate_classes.restype = C.c_int64
+        L.orc_enumerate_classes.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_sr_multiply.restype = Seed
         L.orc_sr_multiply.argtypes = [C.c_uint32, C.c_uint32]
         L.orc_sr_add.restype = Seed
@@ -118,6 +120,30 @@ def pack_reads(seqs):
         b = s if isinstance(s, bytes) else s.encode()
         L.orc_encode_read(b, len(b), buf.ctypes.data + int(off[i]))
     return buf, off, lens
+
+
+def enumerate_classes(buf, off, lens, k, class_ids, nthreads=8):
+    """Every canonical k-mer instance whose value modulo 4096 is one of `class_ids`, over ALL reads, on `nthreads` host threads (ctypes calls
+    release the GIL): arrays (value right-aligned, read, pos), ordered by read then position."""
+    from concurrent.futures import ThreadPoolExecutor
+    L = lib()
+    buf = np.ascontiguousarray(buf, dtype=np.uint8); off = np.ascontiguousarray(off, dtype=np.uint64); lens = np.ascontiguousarray(lens, dtype=np.uint32)
+    bitmap = np.zeros(64, dtype=np.uint64)
+    for c in class_ids:
+        bitmap[int(c) >> 6] |= np.uint64(1) << np.uint64(int(c) & 63)
+    n = len(lens)
+    cuts = np.linspace(0, n, max(1, nthreads * 4) + 1).astype(np.int64)
+
+    def work(a, b):
+        cnt = L.orc_enumerate_classes(buf.ctypes.data, off.ctypes.data, lens.ctypes.data, int(a), int(b), k, bitmap.ctypes.data, None, None, None, 0)
+        v = np.empty(cnt, dtype=np.uint64); r = np.empty(cnt, dtype=np.uint32); p = np.empty(cnt, dtype=np.uint32)
+        got = L.orc_enumerate_classes(buf.ctypes.data, off.ctypes.data, lens.ctypes.data, int(a), int(b), k, bitmap.ctypes.data, v.ctypes.data, r.ctypes.data, p.ctypes.data, cnt)
+        assert got == cnt
+        return v, r, p
+
+    with ThreadPoolExecutor(nthreads) as ex:
+        parts = list(ex.map(lambda ab: work(*ab), zip(cuts[:-1], cuts[1:])))
+    return np.concatenate([x[0] for x in parts]), np.concatenate([x[1] for x in parts]), np.concatenate([x[2] for x in parts])
 
 
 class Oracle:

@@ -84,6 +84,66 @@ def _sampled_rows_equal_oracle(e, B, k, lo, up, nsample, seed=0, d=None):
     return len(rows)
 
 
+def _A_equals_oracle_on_value_classes(e, packed, off, lens, k, lo, up, nclasses=64, nrows=200, seed=0):
+    """A itself at full size (the k-mer stage: 2-4 G instances, the two-level partition, LDS count tables, LDS sorts).  (1) 64 of the 4096
+    value classes (k-mer value modulo 4096): the oracle's enumerator (orc_read_kmers' loop) walks ALL reads on the host cores and keeps the
+    instances of those classes; counting them exactly gives the reliable k-mers of the classes and their (read, pos) lists — the GPU's columns
+    for exactly those k-mers must be the same: the same k-mers (none missing, none of the unreliable ones present), the same entries in the
+    same order.  (2) 200 rows of CSR(A) re-derived from their reads: every position's canonical k-mer looked up among the GPU's reliable
+    k-mers gives the row's (k-mer id, pos) list."""
+    import torch
+    rng = np.random.default_rng(seed)
+    classes = np.sort(rng.choice(4096, size=nclasses, replace=False))
+    vals, rd, ps = po.enumerate_classes(packed, off, lens, k, classes, nthreads=16)
+    order = np.lexsort((ps, rd, vals))
+    vals, rd, ps = vals[order], rd[order], ps[order]
+    head = np.concatenate([[True], vals[1:] != vals[:-1]])
+    starts = np.nonzero(head)[0]
+    counts = np.diff(np.concatenate([starts, [len(vals)]]))
+    rel = (counts >= lo) & (counts <= up)
+    want_kmers = vals[starts[rel]]
+    keep = np.repeat(rel, counts)
+    want_read, want_pos = rd[keep].astype(np.int64), ps[keep].astype(np.int64)
+    want_len = counts[rel]
+    # the GPU's side: the columns of the same classes
+    v = e.device_view()
+    d = _device_tensors(e)
+    dev = d["csc"].device
+    kmers = torch.as_tensor(_DevArray(v["a_kmers"], v["N"], "<i8"), device="cuda")
+    gvals = (kmers >> (64 - 2 * k)) & ((1 << (2 * k)) - 1)
+    cls = torch.zeros(4096, dtype=torch.bool, device=dev); cls[torch.from_numpy(classes).to(dev)] = True
+    kids = torch.nonzero(cls[gvals & 4095]).reshape(-1)
+    got_kmers = gvals[kids].cpu().numpy().astype(np.uint64)
+    assert len(got_kmers) == len(want_kmers) and (got_kmers == want_kmers).all(), (len(got_kmers), len(want_kmers))
+    cp = d["colptr"].to(torch.int64) & 0xFFFFFFFF
+    c0, c1 = cp[kids], cp[kids + 1]
+    glen = (c1 - c0)
+    assert (glen.cpu().numpy() == want_len).all()
+    tot = int(glen.sum().item())
+    st0 = torch.cumsum(glen, 0) - glen
+    which = torch.repeat_interleave(torch.arange(len(kids), device=dev), glen)
+    cent = d["csc"][c0[which] + (torch.arange(tot, device=dev) - st0[which])]
+    assert ((((cent >> 32) & 0xFFFFFFFF).cpu().numpy() == want_read).all() and ((cent & 0xFFFFFFFF).cpu().numpy() == want_pos).all())
+    # rows of CSR(A) from their reads
+    allk = gvals.cpu().numpy().astype(np.uint64)                      # ascending: k-mer id = rank of the value
+    rp = (d["rowptr"].to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+    L = po.lib()
+    pmask = int(v["a_csr_pos_mask"])
+    rows = np.sort(rng.choice(len(lens), size=min(nrows, len(lens)), replace=False))
+    buf = np.zeros(int(lens.max()) + 8, dtype=np.uint64)
+    for r in rows:
+        n = L.orc_read_kmers(packed.ctypes.data + int(off[r]), int(lens[r]), k, buf.ctypes.data)
+        kv = buf[:n] >> np.uint64(64 - 2 * k)
+        at = np.searchsorted(allk, kv)
+        hit = (at < len(allk)) & (allk[np.minimum(at, len(allk) - 1)] == kv)
+        exp_kid, exp_pos = at[hit].astype(np.int64), np.nonzero(hit)[0].astype(np.int64)
+        o2 = np.lexsort((exp_pos, exp_kid))
+        ent = d["csr"][int(rp[r]):int(rp[r + 1])].cpu().numpy()
+        assert len(ent) == len(exp_kid), (r, len(ent), len(exp_kid))
+        assert (((ent >> 32) & 0xFFFFFFFF) == exp_kid[o2]).all() and ((ent & pmask) == exp_pos[o2]).all(), r
+    return len(want_kmers), len(rows)
+
+
 def _properties(e, B, st, ks, packed, off, lens, k, upper):
     assert st["nnz"] == B["Y"] == int(B["rowptr"][-1])
     assert st["nnz"] == st["nnz_diag"] + 2 * st["nnz_upper"]
@@ -119,6 +179,8 @@ def test_baseline_config_properties_and_sampled_rows(name):
     st = e.create_seed_matrix()
     B = e.export_csr()
     _properties(e, B, st, ks, packed, off, lens, k, w["U"])
+    nk, nr = _A_equals_oracle_on_value_classes(e, packed, off, lens, k, w["L"], w["U"])
+    assert nk > 1000 and nr >= 100
     assert _sampled_rows_equal_oracle(e, B, k, w["L"], w["U"], w["nsample"]) >= min(50, w["nsample"])
     # a second call, cold (nothing remembered), returns the identical matrix
     e.set_option("overlap_cold_calls", 1)

@@ -242,3 +242,32 @@ def test_dense_columns_on_shards_and_row_blocks_take_the_dense_path(world, nbloc
         assert len(bad) == 0, (len(bad), B["val"][bad[:4]], oB["val"][bad[:4]])
         assert sum(p[3] for p in parts) == o.stat("Y")
         assert sum(p[1] for p in parts) == o.stat("P")
+
+
+def test_mid_size_sharded_build_equals_the_one_gpu_matrix():
+    """BASELINE config 3 at 1/8 of its genome (25 k reads of 10 kb, 250 M k-mer instances — the one-GPU run takes the two-level partition path,
+    the owners of the sharded run sort) on 4 ranks with the mirror exchange: the stitched rows equal the one-GPU B bit for bit, the ranks'
+    products add up to the one-GPU schedule's and every rank does about a quarter of it."""
+    reads = elba_amd.synth_reads(2, 66_700_000 // 8, 30.0, 10000.0, 1500.0, error_rate=0.15, min_len=1000)
+    packed, off, lens, _ = reads
+    e = elba_amd.Engine(17, 2, 8, options={"kmer_msd": 1}); e.set_reads(packed, off, lens); e.count_kmers(); e.create_kmer_matrix(); st = e.create_seed_matrix()
+    B1 = e.export_csr(); e.close()
+    world = 4
+    bounds = partition_by_bases(lens, world)
+
+    def body(rank, h):
+        a, b = int(bounds[rank]), int(bounds[rank + 1])
+        sp, so, sl = _shard(packed, off, lens, a, b)
+        d = DistributedOverlap(17, 2, 8, device=0, rank=rank, world=world, dist=h, backend=HipBackend(17, 2, 8, 0))
+        d.set_reads(sp, so, sl, a, bounds)
+        d.build_kmer_matrix()
+        s2 = d.create_seed_matrix()
+        out = (d.export_csr(), s2)
+        d.be.e.close()
+        return out
+
+    parts = dist_sim.run_ranks(world, body)
+    B = dist_sim.stitch_rows([p[0] for p in parts])
+    assert B["Y"] == B1["Y"] == st["nnz"] and (B["rowptr"] == B1["rowptr"]).all() and (B["col"] == B1["col"].astype(np.int64)).all() and (B["val"] == B1["val"]).all()
+    prods = [p[1]["products"] for p in parts]
+    assert sum(prods) == st["products"] and max(prods) < 1.35 * min(prods)

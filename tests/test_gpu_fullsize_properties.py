@@ -50,10 +50,10 @@ def test_pattern_and_numshared_are_symmetric_and_rows_sorted(full):
     assert (tkey[order] == key).all()                                         # pattern symmetric (key is sorted)
     assert (B["val"]["numshared"][order] == B["val"]["numshared"]).all()      # numshared(i,j) == numshared(j,i)
     assert (B["val"]["numshared"] >= 2).all()
-    # mirrored entries carry mirrored candidate seeds unless a k-mer occurs twice in one of the reads: compare where they must agree
+    # B(j,i) is B(i,j) with the two positions of each seed exchanged — exactly: the canonical seeds are the minimum / maximum over a cross
+    # product of positions per shared k-mer
     v, vt = B["val"], B["val"][order]
-    same = (v["q0"] == vt["t0"]) & (v["t0"] == vt["q0"])
-    assert same.mean() > 0.99
+    assert (v["q0"] == vt["t0"]).all() and (v["t0"] == vt["q0"]).all() and (v["q1"] == vt["t1"]).all() and (v["t1"] == vt["q1"]).all()
 
 
 def test_sampled_seeds_are_genuine_shared_kmers(full):
