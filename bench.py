@@ -117,6 +117,7 @@ def main():
         from elba_amd.distributed import DistributedOverlap
         runner = DistributedOverlap(k, lo, up, device=local_rank, rank=rank, world=world, dist=dist, timing_stride=args.timing_stride)
         runner.time_phases = True                 # (send, all-to-all, recv) device times of every step, per rank
+        runner.force_exchange = force_dist
         t0 = time.time()
         info = runner.generate_and_set_reads(w, weak=args.weak)
         t_gen = time.time() - t0

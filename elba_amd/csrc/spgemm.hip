@@ -587,11 +587,12 @@ __global__ void k_ingest_remote(StageRec *rem, unsigned long long n, uint32_t *l
 }
 
 // ... and are placed like the local mirror images (k_mirror), once the row pointers are known
-// (slot != 0: rem is nranks slots of `slot` records each, record 0 of a slot its header — the count of records behind it in a.x)
+// (slot != 0: rem is gridDim.y slots of `slot` records each, record 0 of a slot its header — the count of records behind it in a.x;
+//  blockIdx.y = slot, and the blocks of a slot stride over its records only)
 __global__ void k_place_remote(FinParams p, const StageRec *rem, unsigned long long n, unsigned long long slot)
 {
-    for (unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (unsigned long long)gridDim.x * blockDim.x) {
-        if (slot) { const unsigned long long idx = r % slot; if (idx == 0 || idx > rem[r - idx].a.x) continue; }
+    if (slot) { rem += (unsigned long long)blockIdx.y * slot; n = (unsigned long long)rem->a.x + 1; }
+    for (unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + (slot ? 1 : 0); r < n; r += (unsigned long long)gridDim.x * blockDim.x) {
         const uint4 a = rem[r].a, b = rem[r].b;
         if (a.x < p.row_lo || a.x >= p.row_hi) continue;
         const int64_t at = p.b_rowptr[a.x] + (int64_t)b.w;
@@ -633,7 +634,8 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
         int nb = (int)((nrows + 3) / 4);
         if (nb > cus * 32) nb = cus * 32;
         hipLaunchKernelGGL(k_mirror, dim3(nb), dim3(256), 0, s, f);
-        if (nremote > 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((nremote + 255) / 256, (int64_t)cus * 32)), dim3(256), 0, s, f, remote, (unsigned long long)nremote, (unsigned long long)slot);
+        if (nremote > 0 && slot == 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((nremote + 255) / 256, (int64_t)cus * 32)), dim3(256), 0, s, f, remote, (unsigned long long)nremote, 0ull);
+        if (nremote > 0 && slot != 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((slot + 255) / 256, (int64_t)cus * 4), (unsigned)(nremote / slot)), dim3(256), 0, s, f, remote, (unsigned long long)nremote, (unsigned long long)slot);
         hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
         hipLaunchKernelGGL(k_finalize_mid, dim3(nb), dim3(256), 0, s, f);
         skipped_sorts = 0;
@@ -1043,22 +1045,23 @@ __global__ void k_slot_headers(const unsigned long long *cursors, const OvCounte
         send[(unsigned long long)d * slot].b = make_uint4(0u, 0u, 0u, 0u);
     }
 }
-// received slots: every record draws its place in its row's mirror extent; chk = {records for rows outside the window, strict-upper entries, retry flags, slot need}
-__global__ void k_ingest_remote_slots(StageRec *rem, unsigned long long n, unsigned long long slot, uint32_t *low_cnt, uint32_t row_lo, uint32_t row_hi, unsigned long long *chk)
+// received slots: every record draws its place in its row's mirror extent; chk = {records for rows outside the window, strict-upper entries, retry
+// flags, slot need, records merged}.  blockIdx.y = slot; a block beyond the slot's count leaves after one load (slots are sized by a bound).
+__global__ void k_ingest_remote_slots(StageRec *rem, unsigned long long slot, uint32_t *low_cnt, uint32_t row_lo, uint32_t row_hi, unsigned long long *chk)
 {
-    const unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    StageRec *base = rem + (unsigned long long)blockIdx.y * slot;
+    const uint4 h = base->a;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (h.y) atomicOr(&chk[2], 1ull);
+        atomicMax(&chk[3], ((unsigned long long)h.w << 32) | h.z);
+    }
+    const unsigned long long idx = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1;      // record 0 is the header
+    if ((unsigned long long)blockIdx.x * blockDim.x >= h.x) return;
     unsigned long long up = 0, got = 0;
-    if (r < n) {
-        const unsigned long long idx = r % slot;
-        if (idx == 0) {
-            const uint4 h = rem[r].a;
-            if (h.y) atomicOr(&chk[2], 1ull);
-            atomicMax(&chk[3], ((unsigned long long)h.w << 32) | h.z);
-        } else if (idx <= rem[r - idx].a.x) {
-            const uint32_t j = rem[r].a.x;
-            if (j < row_lo || j >= row_hi) atomicAdd(&chk[0], 1ull);
-            else { rem[r].b.w = atomicAdd(&low_cnt[j], 1u); up = rem[r].a.y > j ? 1u : 0u; got = 1; }
-        }
+    if (idx <= h.x) {
+        const uint32_t j = base[idx].a.x;
+        if (j < row_lo || j >= row_hi) atomicAdd(&chk[0], 1ull);
+        else { base[idx].b.w = atomicAdd(&low_cnt[j], 1u); up = base[idx].a.y > j ? 1u : 0u; got = 1; }
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { up += __shfl_xor(up, d, 64); got += __shfl_xor(got, d, 64); }
@@ -1104,7 +1107,7 @@ bool stage_seed_matrix_recv(Ctx &c, void *d_recv, int64_t slot, int64_t *slot_ne
     c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * (mir16 ? 16 : sizeof(StageRec)));
     c.ov_marks.mark(4, s);
     unsigned long long *chk = c.ov_cursors.as<unsigned long long>() + REMOTE_MAX_RANKS;      // (zeroed by send)
-    hipLaunchKernelGGL(k_ingest_remote_slots, dim3((unsigned)((nslotrec + 255) / 256)), dim3(256), 0, s, static_cast<StageRec *>(d_recv), (unsigned long long)nslotrec, (unsigned long long)slot,
+    hipLaunchKernelGGL(k_ingest_remote_slots, dim3((unsigned)((slot + 255) / 256), (unsigned)nranks), dim3(256), 0, s, static_cast<StageRec *>(d_recv), (unsigned long long)slot,
                        c.ov_totcnt.as<uint32_t>(), (uint32_t)row_lo, (uint32_t)row_hi, chk);
     uint32_t skipped_sorts = 0;
     ov_launch_finalize(c, 2u, true, skipped_sorts, static_cast<const StageRec *>(d_recv), nslotrec, slot);

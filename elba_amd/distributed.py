@@ -248,6 +248,7 @@ class DistributedOverlap:
         self.nlocal = 0
         self.bounds = None
         self.row_batches = 1
+        self.force_exchange = False       # world of one: run the step through the exchange machinery all the same (self-test, bench.py under ELBA_FORCE_DIST)
         self.time_phases = False          # record (send, exchange, recv) device times of every step with the fixed-slot exchange (bench.py)
         self.phase_ms = None
         self.panel_records = 0
@@ -424,7 +425,7 @@ class DistributedOverlap:
         _fill / _end): each rank then does 1/world of the one-GPU work instead of computing every cross-rank pair twice.  Without the
         exchange the call has no communication at all."""
         if exchange is None:
-            exchange = self.world > 1 and self.row_batches == 1 and hasattr(self.be, "seed_begin")
+            exchange = (self.world > 1 or self.force_exchange) and self.row_batches == 1 and hasattr(self.be, "seed_begin")
         if not exchange:
             return self.be.create_seed_matrix()
         if exchange != "counted" and hasattr(self.be, "seed_send"):
@@ -448,9 +449,10 @@ class DistributedOverlap:
         if not getattr(self.be, "shares_stream", False):
             self.be.use_current_stream()
         if getattr(self, "_slot", 0) == 0:
-            # a first guess every rank agrees on: nnz(B) of a shard is below nnz(A) / 4 on every read set seen, the cross-rank part of it is spread
-            # over W - 1 peers; all-reduced so that the largest shard decides
-            g = torch.tensor([max(int(self.panel_records) // (4 * max(W - 1, 1)), 1 << 12)], dtype=torch.int64, device=self.be.dev)
+            # a first guess every rank agrees on: the mirror images a rank sends are about nnz(B of the shard) / 2, nnz(B) stays below a quarter of the
+            # panel's entries on every read set seen, and they spread over W - 1 peers (twice that as margin; too small a guess costs one repeated
+            # step, which tells every rank the size that was needed); all-reduced so that the largest shard decides
+            g = torch.tensor([max(int(self.panel_records) // (8 * (W - 1)), 1 << 12) if W > 1 else 1 << 12], dtype=torch.int64, device=self.be.dev)
             if W > 1:
                 self.dist.all_reduce(g, op=self.dist.ReduceOp.MAX)
             self._slot = int(g.item()) + 1
