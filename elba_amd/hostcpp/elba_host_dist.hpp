@@ -173,6 +173,39 @@ public:
         mirror_bytes_ = sum(sc) * 32;
         return st;
     }
+    // The same step with ONE host synchronisation (elba_set_stream / elba_seed_matrix_send / _recv): the library launches on the grid's
+    // stream, the mirror images travel in fixed-size slots — grouped ncclSend / ncclRecv of equal size, nothing about them crosses the host —
+    // and "did everything fit?" is answered once, at the end, by every rank alike (a flag in every slot's header): then the step is repeated
+    // with the slot size that was needed.  `panel_records`: entries of this rank's panel (first slot guess, all-reduced).
+    elba_overlap_stats create_seed_matrix_slots(uint64_t panel_records)
+    {
+        const int W = grid_->size;
+        if (!shares_stream_) { engine_->check(elba_set_stream(engine_->ctx, (void *)grid_->stream)); shares_stream_ = true; }
+        if (slot_ == 0) {
+            uint64_t g = W > 1 ? std::max<uint64_t>(panel_records / (8 * (uint64_t)(W - 1)), 1u << 12) : (1u << 12);
+            for (uint64_t x : all_gather_u64(g)) g = std::max(g, x);
+            slot_ = g + 1;
+        }
+        std::vector<uint64_t> ub(bounds_.begin(), bounds_.end());
+        for (int attempt = 0; attempt < 6; ++attempt) {
+            const uint64_t slot = slot_;
+            send_.reserve((size_t)W * slot * 32); recv_.reserve((size_t)W * slot * 32);
+            engine_->check(elba_seed_matrix_send(engine_->ctx, W, ub.data(), send_.p, (int64_t)slot));
+            ELBA_DIST_NCCL(ncclGroupStart());
+            for (int p = 0; p < W; ++p) {
+                ELBA_DIST_NCCL(ncclSend(send_.as<char>() + (size_t)p * slot * 32, slot * 32, ncclChar, p, grid_->comm, grid_->stream));
+                ELBA_DIST_NCCL(ncclRecv(recv_.as<char>() + (size_t)p * slot * 32, slot * 32, ncclChar, p, grid_->comm, grid_->stream));
+            }
+            ELBA_DIST_NCCL(ncclGroupEnd());
+            elba_overlap_stats st{};
+            int64_t need = 0;
+            const int rc = elba_seed_matrix_recv(engine_->ctx, recv_.p, (int64_t)slot, &st, &need);
+            slot_ = std::max<uint64_t>(slot_, (uint64_t)need);
+            if (rc == ELBA_OK) { mirror_bytes_ = (uint64_t)W * slot * 32; return st; }
+            if (rc != ELBA_ERR_RETRY) engine_->check(rc);
+        }
+        throw std::runtime_error("create_seed_matrix_slots: the mirror exchange did not settle");
+    }
     uint64_t mirror_bytes() const { return mirror_bytes_; }
     uint64_t exchange_bytes() const { return exchange_bytes_; }
 
@@ -242,7 +275,8 @@ private:
     std::vector<int64_t> bounds_;
     detail::DevMem send_, recv_, scratch_;
     int kw_ = 1;
-    uint64_t exchange_bytes_ = 0, mirror_bytes_ = 0;
+    uint64_t exchange_bytes_ = 0, mirror_bytes_ = 0, slot_ = 0;
+    bool shares_stream_ = false;
 };
 
 }  // namespace elba

@@ -50,7 +50,8 @@ int main(int argc, char **argv)
         d.set_reads(mydna, displs);
         elba_kmer_stats ks{}; elba_matrix_stats ms{};
         d.build_kmer_matrix(&ks, &ms);
-        const elba_overlap_stats st = d.create_seed_matrix();
+        // ELBA_DIST_SLOTS=1: the step with one host synchronisation (fixed-size slots on the grid's stream) instead of begin / fill / end
+        const elba_overlap_stats st = std::getenv("ELBA_DIST_SLOTS") ? d.create_seed_matrix_slots((uint64_t)ms.nnz) : d.create_seed_matrix();
         elba_csr_t B;
         d.engine()->check(elba_export_csr(d.engine()->ctx, d.row_lo(), d.row_hi(), &B));
         uint64_t checksum = 0;

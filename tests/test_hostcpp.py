@@ -124,6 +124,10 @@ def test_rccl_host_world_of_one_matches_oracle():
     fa = os.path.join(util.GOLDEN, "small_err.fa")
     p = subprocess.run([DIST_BIN, fa, "17", "2", "8"], capture_output=True, text=True, check=True)
     got = json.loads(p.stdout.strip().splitlines()[-1])
+    # the same through the step with one host synchronisation (elba_set_stream / elba_seed_matrix_send / _recv, equal-size ncclSend / ncclRecv)
+    p2 = subprocess.run([DIST_BIN, fa, "17", "2", "8"], capture_output=True, text=True, check=True, env=dict(os.environ, ELBA_DIST_SLOTS="1"))
+    got2 = json.loads(p2.stdout.strip().splitlines()[-1])
+    assert (got2["nnzB"], got2["products"], got2["checksum"]) == (got["nnzB"], got["products"], got["checksum"])
     packed, off, lens = po.pack_reads(util.read_fasta(fa))
     o = po.Oracle(17, 2, 8); o.count_and_build(packed, off, lens); o.spgemm(1)
     B = o.B(); v = B["val"]
