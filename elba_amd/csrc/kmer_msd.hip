@@ -198,26 +198,22 @@ __global__ __launch_bounds__(MT_MAXBINS) void k_msd_segscan(uint32_t *hist, SegT
 // ---- stable scatter of one tile by one digit --------------------------------------------------------------------------------------
 // ENUM: the tile's keys are enumerated from the reads (tile = 8192 consecutive instances) and the digit is the top b1 value bits, which the word
 // written does not hold any more.  !ENUM: the tile's keys are read from `in` (a bucket-aligned tile) and the digit is (word >> shift) & mask.
-// Ranking as in the radix sort of prims.hip: wave ballots per digit bit, per-wave digit counts in LDS, the tile ordered by digit in LDS and
-// written out by consecutive lanes (a digit's keys of one tile are one contiguous run in the output).
+// The tile is ordered by digit in LDS and written out by consecutive lanes (a digit's keys of one tile are one contiguous run in the output).
 template <bool ENUM>
 __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const BlockInfo *block_read, MsdParams m, const uint64_t *in, SegTiles sg, int shift, int bits,
                                                            const uint32_t *hist_scanned, uint64_t *out)
 {
     constexpr int WAVES = MT_THREADS / 64, DPT = MT_MAXBINS / MT_THREADS;
-    __shared__ uint16_t whist[WAVES][MT_MAXBINS];
-    __shared__ uint32_t lstart[MT_MAXBINS], gbase[MT_MAXBINS], wsum[WAVES];
+    __shared__ uint32_t lcnt[MT_MAXBINS], lstart[MT_MAXBINS], gbase[MT_MAXBINS], wsum[WAVES];
     __shared__ uint64_t lkey[MT_TILE];
     __shared__ unsigned long long hbits[MT_TILE / 64];
     __shared__ uint32_t hpre[MT_TILE / 64], delta[MT_MAXBINS];
-    volatile uint16_t(*vh)[MT_MAXBINS] = whist;
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
     if (!ENUM && blockIdx.x >= sg.tile0[sg.nb1]) return;
-    for (int i = threadIdx.x; i < WAVES * MT_MAXBINS / 2; i += MT_THREADS) reinterpret_cast<uint32_t *>(&whist[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < MT_MAXBINS; i += MT_THREADS) lcnt[i] = 0;
     if (threadIdx.x < MT_TILE / 64) hbits[threadIdx.x] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const uint64_t lt = (1ull << lane) - 1;
     uint64_t key[MT_ITEMS];
     uint32_t dig2[MT_ITEMS / 2];    // the items' digits, two per register (0xFFFF: no key)
     uint32_t count = 0;
@@ -256,39 +252,22 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     uint32_t gb[DPT];
 #pragma unroll
     for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * MT_THREADS; gb[u] = d < nbins ? hist_scanned[(size_t)blockIdx.x * nbins + d] : 0u; }
-    uint32_t rank[MT_ITEMS];
+    // rank of every key among the tile's keys with its digit: ONE returning LDS atomic per key on the workgroup's digit counters.  (Nothing
+    // downstream needs the partition to be stable — the bucket kernels sort every column — so the keys of a digit may land in any order; the
+    // ballot ranking of the radix sort, ~70 instructions per key, bought an order nobody reads.)
+    uint16_t rank[MT_ITEMS];
 #pragma unroll
     for (int it = 0; it < MT_ITEMS; ++it) {
         const uint32_t d = digit(it);
-        const bool valid = d != 0xFFFFu;
-        uint64_t mask = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < MT_MAXBITS; ++b) {
-            if (b < bits) {
-                const uint64_t bal = __ballot((d >> b) & 1u);
-                mask &= ((d >> b) & 1u) ? bal : ~bal;
-            }
-        }
-        const int leader = valid ? (__ffsll((unsigned long long)mask) - 1) : lane;
-        const uint32_t cnt = (uint32_t)__popcll(mask);
-        uint32_t pre = 0;
-        if (valid && lane == leader) { pre = vh[w][d]; vh[w][d] = (uint16_t)(pre + cnt); }
-        pre = __shfl(pre, leader, 64);
-        rank[it] = pre + (uint32_t)__popcll(mask & lt);
+        rank[it] = 0;
+        if (d != 0xFFFFu) rank[it] = (uint16_t)atomicAdd(&lcnt[d], 1u);
     }
     __syncthreads();
     {
+        // exclusive scan of the digit counts: the digits' places in the tile
         uint32_t tot[DPT], both = 0;
 #pragma unroll
-        for (int u = 0; u < DPT; ++u) {
-            const uint32_t d = DPT * threadIdx.x + u;
-            uint32_t t = 0;
-            if (d < nbins) {
-#pragma unroll
-                for (int ww = 0; ww < WAVES; ++ww) { const uint32_t x = whist[ww][d]; whist[ww][d] = (uint16_t)t; t += x; }
-            }
-            tot[u] = t; both += t;
-        }
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = DPT * threadIdx.x + u; tot[u] = d < nbins ? lcnt[d] : 0u; both += tot[u]; }
         uint32_t inc = both;
 #pragma unroll
         for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= s2) inc += o; }
@@ -305,7 +284,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
 #pragma unroll
     for (int it = 0; it < MT_ITEMS; ++it) {
         const uint32_t d = digit(it);
-        if (d != 0xFFFFu) lkey[lstart[d] + whist[w][d] + rank[it]] = key[it];
+        if (d != 0xFFFFu) lkey[lstart[d] + rank[it]] = key[it];
     }
     // The tile now lies ordered by digit in LDS, but an ENUM word does not hold its digit any more.  A place finds its digit's run from a
     // bitmap of the run starts: run number = set bits at or before the place, delta[run] = the run's place in the output - its place in the tile.
