@@ -464,6 +464,13 @@ int elba_export_kmer_matrix(elba_ctx *ctx, elba_kmer_matrix_t *out)
             out->csc_row[z] = (int64_t)(csc[z] >> 32) + c.first_global_id_rows(); out->csc_val[z] = (uint32_t)csc[z];
             out->csr_col[z] = (int64_t)(csr[z] >> 32); out->csr_val[z] = (uint32_t)csr[z] & (c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu));      // (above the position: SpGEMM hints, or column length and place of a dense matrix)
         }
+        if (c.csr_inline) {
+            // rows with inline partners (Ctx::csr_inline) do not name the k-mer of such an entry: the rows are rebuilt from the columns — walked in
+            // k-mer order, every column's entries in (read, pos) order, a row fills up in (k-mer id, pos) order
+            std::vector<size_t> fill(rp.begin(), rp.end() - 1);
+            for (size_t k = 0; k < N; ++k)
+                for (size_t z = cp[k]; z < cp[k + 1]; ++z) { const size_t at = fill[(size_t)(csc[z] >> 32)]++; out->csr_col[at] = (int64_t)k; out->csr_val[at] = (uint32_t)csc[z]; }
+        }
         if (c.A_has_kmers) {
             out->kmers = host_alloc<uint64_t>(N);
             if (N) ELBA_HIP(hipMemcpyAsync(out->kmers, c.rel_kmers.p, N * 8, hipMemcpyDeviceToHost, c.stream));
@@ -505,7 +512,7 @@ int elba_get_device_view(elba_ctx *ctx, elba_device_view *v)
         memset(v, 0, sizeof(*v));
         v->stream = (void *)c.stream;
         if (c.have_A) { v->M = c.M; v->N = c.N; v->Z = c.Z; v->a_rowptr = c.a_rowptr.p; v->a_csr = c.a_csr.p; v->a_colptr = c.a_colptr.p; v->a_csc = c.a_csc.p;
-                        v->a_csr_format = c.csr_suffix ? ELBA_CSR_DENSE : (c.csr_hints ? ELBA_CSR_HINTS : ELBA_CSR_PLAIN);
+                        v->a_csr_format = c.csr_inline ? ELBA_CSR_INLINE : (c.csr_suffix ? ELBA_CSR_DENSE : (c.csr_hints ? ELBA_CSR_HINTS : ELBA_CSR_PLAIN));
                         v->a_csr_pos_mask = c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu);
                         v->a_kmers = c.A_has_kmers ? c.rel_kmers.p : nullptr; }
         if (c.have_B) { v->Y = c.Y; v->b_rowptr = c.b_rowptr.p; v->b_col = c.b_col.p; v->b_val = c.b_val.p; }
@@ -518,7 +525,7 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         ELBA_REQUIRE(name, ELBA_ERR_INVALID_ARG, "set_option: null name");
         struct { const char *n; bool *b; } flags[] = {
             {"overlap_cold_calls", &c.cold_calls}, {"no_symmetry", &c.opt.no_symmetry}, {"no_ell", &c.opt.no_ell}, {"no_pay", &c.opt.no_pay}, {"mir32", &c.opt.mir32},
-            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_suffix", &c.opt.no_suffix}, {"suffix64", &c.opt.suffix64}, {"kmer_pairs", &c.opt.kmer_pairs},
+            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_suffix", &c.opt.no_suffix}, {"no_inline", &c.opt.no_inline}, {"suffix64", &c.opt.suffix64}, {"kmer_pairs", &c.opt.kmer_pairs},
             {"kmer_unfused", &c.opt.kmer_unfused}, {"kmer_no_msd", &c.opt.kmer_no_msd}, {"kmer_msd", &c.opt.kmer_msd}, {"csr_pairs", &c.opt.csr_pairs}, {"emit_plain", &c.opt.emit_plain}, {"trace", &c.opt.trace}};
         for (auto &f : flags) if (!strcmp(name, f.n)) { *f.b = value != 0; return; }
         if (!strcmp(name, "kmer_drop")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: kmer_drop is 0..3"); c.opt.kmer_drop = (int)value; }

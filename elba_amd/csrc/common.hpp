@@ -121,6 +121,7 @@ struct Options {
     bool mir32 = false;         // 32-byte staging / mirror records instead of 16-byte words
     bool no_hints = false;      // no ownership bits in the rows of A
     bool no_sample = false;     // a cold call does not compute a sample of rows first
+    bool no_inline = false;     // no inline partners in the rows of A (the owner's entry of a two-read column carries the other read: no column fetch)
     bool no_suffix = false;     // dense matrices stay on the general kernel
     bool suffix64 = false;      // dense path with 64-bit accumulators
     bool kmer_pairs = false;    // (value, payload) pairs through the k-mer sort instead of one packed word
@@ -166,13 +167,18 @@ struct Ctx {
     DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
     DevBuf csr_words;     // u64[Z] read << (pre_nb + pre_pb) | k-mer id << pre_pb | pos of every entry of a_csc, when pre_words (k_runs_emit -> the CSR build's sort)
-    bool pre_ready = false, pre_consumed = false, pre_words = false, pre_hints = false, pre_hints_done = false, pre_ell_done = false; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
+    bool pre_ready = false, pre_consumed = false, pre_words = false, pre_hints = false, pre_hints_done = false, pre_ell_done = false, pre_inline = false; int pre_rs = 0, pre_pbi = 0; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
     // Ownership hints of the SpGEMM, two bits in every a_csr entry (kid << 32 | hint << 30 | pos; positions below 2^30): bit 30 = under the
     // parity rule of owns_pair (spgemm_direct.hpp) this row accumulates NO pair of the entry's column and appears in it once — the column
     // need not be fetched at all, the entry only counts one diagonal product; bit 31 = the same with every partner outside the row window
     // counted as owned (calls without the mirror exchange between ranks).  They are a property of A, written when A is built (k_runs_emit /
     // k_csc_to_csr_words: every entry sees its whole column there anyway).  csr_hints false: both bits are zero / positions use all 32 bits.
     bool csr_hints = false, ov_hints_used = false, ov_rec16 = false;
+    // Inline partners (whole-matrix windows, positions below 2^16, read ids and positions narrow enough for one sort word): four in five columns of
+    // 15 %-error reads hold TWO reads, and under the parity rule exactly one of the two rows accumulates the pair.  That row's entry then carries the
+    // pair itself — a_csr entry = 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16, the partner's low bit follows from the rule — and the SpGEMM
+    // fetches no column for it (58 % of its gathers on BASELINE config 3).  Such an entry has no k-mer id: exports rebuild CSR from the columns.
+    bool csr_inline = false;
     bool csr_suffix = false;  // dense matrices: a_csr entries are kid << 32 | column length << 23 | own place in the column << 16 | pos, pairs owned by the smaller row (matrix.hip)
     DevBuf ov_sample;         // u32[256]: the rows a cold SpGEMM call computes first (spgemm.hip)
     int64_t A_products = 0;   // sum over the window's row entries of their column's length (what the SpGEMM reports as `products`)

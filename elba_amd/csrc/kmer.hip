@@ -494,7 +494,7 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
         o.csc = c.a_csc.as<uint64_t>(); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); o.nb = nb; o.pb = pb;
         if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
         hipLaunchKernelGGL(k_runs_emit, dim3(nblocks), dim3(RUN_THREADS), 0, s, p, e, (const BlockInfo *)c.ws_b.as<BlockInfo>(), drop, (const uint32_t *)off_rel, (const uint32_t *)off_ent, o);
-        c.pre_ready = true; c.pre_words = words; c.pre_hints = hints; c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos;
+        c.pre_ready = true; c.pre_words = words; c.pre_hints = hints; c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos; c.pre_rs = nb + pb + 2; c.pre_inline = false;
     } else {
     // entry payloads: written straight into a_csc when they are final (pairs: read << 32 | pos), else into scratch and converted
     DevBuf &scratch = c.ws_f;

@@ -30,7 +30,10 @@ namespace {
 
 #include "kmer_enum.hpp"
 
-constexpr int MT_THREADS = 256, MT_ITEMS = 32, MT_TILE = MT_THREADS * MT_ITEMS;      // 8192 instances per tile: a wavefront's share is one block of the instance -> read table
+#ifndef ELBA_MT_THREADS
+#define ELBA_MT_THREADS 256
+#endif
+constexpr int MT_THREADS = ELBA_MT_THREADS, MT_ITEMS = 8192 / MT_THREADS, MT_TILE = MT_THREADS * MT_ITEMS;      // 8192 instances per tile: a wavefront's share is one block of the instance -> read table
 constexpr int MT_MAXBITS = 9, MT_MAXBINS = 1 << MT_MAXBITS;
 constexpr int VBITS = 16;                     // value bits left to the bucket kernel (two halves of 2^15 values)
 constexpr int BK_THREADS = 1024;
@@ -41,7 +44,7 @@ constexpr uint32_t BK_TAB = 16384, BK_ENT = BK_TAB + 2048 + 128 + 2 * (KW + 1); 
 static_assert(BK_ENT % 2 == 0, "staged entries are 8-byte words");
 constexpr size_t BK_LDS_EMIT = (size_t)BK_ENT * 4 + (size_t)(EW + EPAD) * 10;
 constexpr int KPT = 8;                        // instances of a bucket a lane keeps in registers (8192 per workgroup; beyond: re-read from L2)
-static_assert(MT_ITEMS * 64 == (1 << IB_SHIFT), "a wavefront's share of a tile is one block of the instance -> read table");
+static_assert(MT_ITEMS * 64 <= (1 << IB_SHIFT) && MT_TILE == 8192, "a wavefront's share of a tile lies inside one block of the instance -> read table");
 
 struct MsdParams {
     int k2;                 // 2k value bits
@@ -327,8 +330,10 @@ struct BucketOut {
     uint64_t *rel_kmers; uint32_t *rel_counts, *colptr;
     uint64_t *csc, *csr_words, *kid_of_entry, *ell;
     uint32_t ell_stride;      // 0: no padded column store
-    int nb, pb;               // CSR sort key: read << (nb + pb + 2) | kid << (pb + 2) | hint << pb | pos
+    int nb, pb, rs, mb;       // CSR sort key: read << rs | kid << (pb + 2) | hint << pb | pos   (rs >= nb + pb + 2; mb = bits of a read id)
     uint32_t hints;           // write the ownership bits (Ctx::csr_hints)
+    uint32_t inl;             // Ctx::csr_inline (0: off, else pbi = position bits of an inline key): the owning row's key of a two-read column is
+                              // 1 << 63 | read << rs | (partner >> 1) << 2 pbi | posQ << pbi | posT — when both positions fit pbi bits
 };
 
 // ---- buckets: count ------------------------------------------------------------------------------------------------------------------
@@ -561,7 +566,16 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 }
                 const uint32_t z = eb + p, kid = kb + kl;
                 o.csc[z] = (read << 32) | pos;
-                if (o.csr_words) o.csr_words[z] = (read << (o.nb + o.pb + 2)) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
+                uint64_t word = (read << o.rs) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
+                if (o.inl && L == 2u) {
+                    // a column of two reads: the row that accumulates the pair (the smaller read when the ids' sum is even, else the larger:
+                    // owns_pair, spgemm_direct.hpp) carries the other entry in its own — the SpGEMM then fetches no column for it
+                    const uint64_t y = A[p == h0 ? h0 + 1u : h0];
+                    const uint64_t oread = (y & paymask) >> m.pbits, opos = y & posmask;
+                    if (oread != read && ((((read + oread) & 1ull) == 0) == (read < oread)) && ((pos | opos) >> o.inl) == 0)
+                        word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
+                }
+                if (o.csr_words) o.csr_words[z] = word;
                 else o.kid_of_entry[z] = kid;
                 if ((headmask >> u) & 1u) {
                     const uint64_t value = ((uint64_t)b << VBITS) | ((uint32_t)(x >> m.PB) & 0xFFFFu);
@@ -753,7 +767,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                         const uint64_t read = (x & paymask) >> m.pbits, pos = x & posmask, hint = x >> 62;
                         const uint32_t z = eb + wlo + p, kid = kb + klo + entk[p];
                         o.csc[z] = (read << 32) | pos;
-                        if (o.csr_words) o.csr_words[z] = (read << (o.nb + o.pb + 2)) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
+                        if (o.csr_words) o.csr_words[z] = (read << o.rs) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
                         else o.kid_of_entry[z] = kid;
                     }
                     if (o.ell_stride) {
@@ -870,11 +884,24 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     const bool words = mb + nb + pb + 2 <= 64 && !c.opt.csr_pairs;
     const bool hints = pb <= 30 && !c.opt.no_hints;
     o.rel_kmers = c.rel_kmers.as<uint64_t>(); o.rel_counts = c.rel_counts.as<uint32_t>(); o.colptr = c.a_colptr.as<uint32_t>();
-    o.csc = c.a_csc.as<uint64_t>(); o.nb = nb; o.pb = pb; o.hints = hints && words ? 1u : 0u;
-    if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
-    else { c.kid_of_entry.reserve((size_t)(Z + 8) * 8); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); }
     c.max_col_nnz = (int64_t)hs.maxcol;
     choose_column_store(c, (int64_t)N, c.max_col_nnz);
+    // inline partners (Ctx::csr_inline): whole matrix, general (not dense) SpGEMM path with position-carrying accumulators, and a sort word wide
+    // enough for flag | read | partner >> 1 | posQ | posT
+    const bool dense = c.use_ell && maxpos < 65536 && c.max_col_nnz > 16 && !c.opt.no_pay && !c.opt.no_suffix;
+    // The inline key is flag | read << rs | (partner >> 1) << 2 pbi | posQ << pbi | posT with the read as high as it goes (rs = 63 - mb): pbi position
+    // bits are what is left, and an entry is written inline only if both positions fit them (200 100 reads of up to 16.6 kb: 14 bits, all but
+    // the last bases of a handful of reads)
+    int rs = nb + pb + 2, pbi = 0;
+    bool inl = words && hints && c.use_ell && !dense && maxpos < 65536 && !c.opt.no_pay && !c.opt.no_inline && N < (1ull << 31) && mb >= 2;
+    if (inl) {
+        const int rs2 = 63 - mb;
+        pbi = std::min(pb, (rs2 - (mb - 1)) / 2);
+        if (rs2 >= rs && pbi >= 10) rs = rs2; else inl = false;
+    }
+    o.csc = c.a_csc.as<uint64_t>(); o.nb = nb; o.pb = pb; o.rs = rs; o.mb = mb; o.inl = inl ? (uint32_t)pbi : 0u; o.hints = hints && words ? 1u : 0u;
+    if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
+    else { c.kid_of_entry.reserve((size_t)(Z + 8) * 8); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); }
     o.ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; o.ell_stride = c.use_ell ? c.s_stride : 0u;
     if (Z > 0) {
         const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u);
@@ -897,7 +924,7 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     c.t_total.stop(s);
     ELBA_HIP(hipStreamSynchronize(s));
     c.pre_ready = true; c.pre_consumed = false; c.pre_words = words; c.pre_hints = hints; c.pre_hints_done = hints && words; c.pre_ell_done = true;
-    c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos;
+    c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos; c.pre_rs = rs; c.pre_inline = inl; c.pre_pbi = pbi;
     st.instances = (int64_t)I; st.distinct = (int64_t)hs.distinct; st.reliable = (int64_t)N; st.entries = (int64_t)Z;
     st.ms_total = c.t_total.ms(); st.ms_count = c.t_a.ms(); st.ms_sort = c.t_b.ms(); st.ms_lookup = 0;
     c.ndistinct = (int64_t)hs.distinct;

@@ -69,16 +69,21 @@ __global__ void k_add_hints(const uint32_t *colptr, const uint64_t *csc, int64_t
 }
 // sorted keys -> CSR entries, and the row pointers with them: entry z opens the rows (read of z - 1, read of z]; launched with Z + 1 lanes,
 // the last of which closes the rows behind the last entry
-__global__ void k_unpack_csr_words(const uint64_t *words, int64_t Z, int nb, int pb, uint64_t *csr, uint32_t *rowptr, int64_t M)
+__global__ void k_unpack_csr_words(const uint64_t *words, int64_t Z, int nb, int pb, int rs, int mb, int pbi, uint64_t *csr, uint32_t *rowptr, int64_t M)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (z > Z) return;
-    const int rs = nb + pb + 2;
-    const int64_t prev = z == 0 ? -1 : (int64_t)(words[z - 1] >> rs);
+    const uint64_t rmask = (1ull << mb) - 1;
+    const int64_t prev = z == 0 ? -1 : (int64_t)((words[z - 1] >> rs) & rmask);
     const uint64_t w = z < Z ? words[z] : 0;
-    const int64_t cur = z < Z ? (int64_t)(w >> rs) : M;
+    const int64_t cur = z < Z ? (int64_t)((w >> rs) & rmask) : M;
     for (int64_t k = prev + 1; k <= cur; ++k) rowptr[k] = (uint32_t)z;
-    if (z < Z) csr[z] = (((w >> (pb + 2)) & ((1ull << nb) - 1)) << 32) | (((w >> pb) & 3ull) << 30) | (w & ((1ull << pb) - 1));
+    if (z < Z) {
+        if (w >> 63) {      // inline partner (Ctx::csr_inline): flag | partner >> 1 | posQ | posT << 16
+            const uint64_t pm = (1ull << pbi) - 1;
+            csr[z] = (1ull << 63) | (((w >> (2 * pbi)) & ((1ull << (mb - 1)) - 1)) << 32) | ((w >> pbi) & pm) | ((w & pm) << 16);
+        } else csr[z] = (((w >> (pb + 2)) & ((1ull << nb) - 1)) << 32) | (((w >> pb) & 3ull) << 30) | (w & ((1ull << pb) - 1));
+    }
 }
 
 __global__ void k_colrow_to_csc(const uint64_t *colrow, const uint64_t *pos, int64_t Z, uint64_t *csc)
@@ -255,6 +260,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     // its lanes (spgemm_direct.hpp, "suffix" path).  Positions below 2^16, the padded column store.  With a row window (a shard, a row block
     // of a shard: elba_dist_set_panel) the padded columns are stored rotated so that this stays true (k_fill_ell).
     const bool windowed = !(win_lo == 0 && (win_hi < 0 || win_hi == M));
+    c.csr_inline = false;
     const uint8_t *colw0 = nullptr;
     if (!(pre && c.pre_ell_done)) {      // (the two-level partition of kmer_msd.hip writes the padded columns with the columns themselves)
         c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
@@ -286,9 +292,11 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
                                hints, wlo, whi, prod_ctr);
         if (Z > 0 && have_words && hints && !c.pre_hints_done)
             hipLaunchKernelGGL(k_add_hints, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
-        const int where = radix_sort_keys(s, w0, w1, Z, nb + pb + 2, nb + pb + 2 + mb, c.ws_sort);
+        const int rs = have_words ? c.pre_rs : nb + pb + 2;
+        const int where = radix_sort_keys(s, w0, w1, Z, rs, rs + mb, c.ws_sort);
         const uint64_t *sorted = where ? w1 : w0;
-        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
+        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, rs, mb, have_words ? c.pre_pbi : 0, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
+        c.csr_inline = have_words && c.pre_inline;
     } else {
         ELBA_REQUIRE(!pre || !c.pre_words || c.csr_suffix, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
         const bool kid_in_words = pre && c.pre_words;        // (k_runs_emit left sort keys, not column ids: the k-mer id is a field of the word)
@@ -356,6 +364,12 @@ __global__ void k_export_triples(const uint32_t *rowptr, const uint64_t *csr, ui
     for (uint32_t i = wave; i < M; i += nwaves)
         for (uint32_t e = rowptr[i] + lane, re = rowptr[i + 1]; e < re; e += 64) { const uint64_t x = csr[e]; rows[e] = i; cols[e] = (int64_t)(x >> 32); vals[e] = (uint32_t)x & pos_mask; }
 }
+__global__ void k_export_triples_csc(const uint32_t *colptr, const uint64_t *csc, uint64_t N, int64_t *rows, int64_t *cols, uint32_t *vals)
+{
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= N) return;
+    for (uint32_t z = colptr[k], z1 = colptr[k + 1]; z < z1; ++z) { rows[z] = (int64_t)(csc[z] >> 32); cols[z] = (int64_t)k; vals[z] = (uint32_t)csc[z]; }
+}
 }  // namespace
 
 // k0 / v0 (= c.ws_a / c.ws_b) hold (pos, col << 32 | row) of every triple
@@ -407,7 +421,9 @@ void stage_export_triples_device(Ctx &c, int64_t *d_rows, int64_t *d_cols, uint3
 {
     ELBA_REQUIRE(c.have_A, ELBA_ERR_STATE, "export_triples_device: no k-mer matrix");
     ELBA_REQUIRE(c.Z == 0 || (d_rows && d_cols && d_vals), ELBA_ERR_INVALID_ARG, "null triple array");
-    if (c.M > 0 && c.Z > 0) {
+    if (c.csr_inline && c.N > 0 && c.Z > 0) {      // (rows with inline partners do not name every entry's k-mer: the triples come from the columns)
+        hipLaunchKernelGGL(k_export_triples_csc, dim3((unsigned)((c.N + 255) / 256)), dim3(256), 0, c.stream, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), (uint64_t)c.N, d_rows, d_cols, d_vals);
+    } else if (c.M > 0 && c.Z > 0) {
         int nb = (int)std::min<int64_t>((c.M + 3) / 4, (int64_t)c.num_cus * 32);
         hipLaunchKernelGGL(k_export_triples, dim3(nb), dim3(256), 0, c.stream, (const uint32_t *)c.a_rowptr.as<uint32_t>(), (const uint64_t *)c.a_csr.as<uint64_t>(), (uint32_t)c.M,
                            c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu), d_rows, d_cols, d_vals);

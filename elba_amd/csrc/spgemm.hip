@@ -78,6 +78,7 @@ struct OvParams {
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint64_t *a_ell; const uint32_t *a_colptr; const uint64_t *a_csc;
     const uint32_t *a_ellj;         // dense matrices: the partner read of every slot of a_ell (what the dense path gathers: half the bytes per candidate)
     uint32_t hint_mask, pos_mask;   // which hint bit of a row entry lets this call skip its column (0: none) / the position bits (Ctx::csr_hints)
+    uint32_t inl;                   // Ctx::csr_inline: row entries with bit 63 set carry their (only) partner: 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16
     uint32_t suffix;                // dense matrices (Ctx::csr_suffix): row entries carry column length and own place, the smaller row owns a pair
     uint32_t s_stride, lpc_log2, max_col;    // padded column stride in entries (a_ell); lanes per row entry 2^lpc_log2; longest column
     unsigned long long fb_enough;            // row entries behind the in-call partner / entry ratio at which it counts as settled (nobody touches the hot sums any more)
@@ -756,7 +757,10 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     //  ("no_symmetry") and the mirror exchange between ranks (half == 2: the parity rule over all ranks) take the general path, which reads the
     //  same entries through pos_mask)
     p.suffix = c.csr_suffix && p.half == 1u ? 1u : 0u;
-    c.ov_hints_used = p.hint_mask != 0u || p.suffix != 0u;
+    p.inl = c.csr_inline ? 1u : 0u;
+    c.ov_hints_used = c.ov_hints_used || c.csr_inline;
+    ELBA_REQUIRE(!c.csr_inline || (row_lo == 0 && row_hi == M && phase == 0 && c.use_ell), ELBA_ERR_INTERNAL, "inline partners in a matrix with a row window");
+    c.ov_hints_used = p.hint_mask != 0u || p.suffix != 0u || c.csr_inline;      // (entries that fetch no column do not see its length: the product count comes from the build of A)
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);

@@ -334,9 +334,30 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             };
             auto consume = [&]() {                                        // chunk `ea` -> FIFO; the chunk after it moves up, the one after that is requested
                 const bool valid = ca + lane < nnz;
-                const bool need = valid && !(ea.x & hmask);
+                // inline partner (Ctx::csr_inline): the entry of the row that accumulates the pair of a two-read column IS the product — flag |
+                // partner >> 1 | posQ | posT << 16, the partner's low bit from the ownership rule — no column to fetch
+                const bool inl = p.inl != 0u && valid && (ea.y >> 31) != 0u;
+                const bool need = valid && !inl && !(ea.x & hmask);
+                if (p.inl != 0u) {
+                    const uint64_t mi = __ballot(inl);
+                    if (mi) {
+                        const uint32_t jh = ea.y & 0x7FFFFFFFu, ih = i >> 1;
+                        const uint32_t j = jh > ih ? 2u * jh + (i & 1u) : (jh < ih ? 2u * jh + ((i & 1u) ^ 1u) : (i ^ 1u));
+                        const uint32_t seq = ((ca + lane) << fbits) | (j > i ? 1u : 0u);      // the partner's place in its column (two entries, in read order)
+                        if (GLOBAL) { if (inl) tab.insert(j, seq, full); }
+                        else {
+                            const uint32_t at = (tail + (uint32_t)__popcll(mi & lt)) & (RING - 1u);
+                            if (inl) {
+                                qj[at] = j;
+                                if (PAY) qv[at] = ((unsigned long long)seq << 32) | ((ea.x & 0xFFFFu) << 16) | (ea.x >> 16); else qs[at] = seq;
+                            }
+                            tail += (uint32_t)__popcll(mi);
+                            if (tail - head >= 64u) drain(64u);
+                        }
+                    }
+                }
                 const uint64_t mn = __ballot(need);
-                dg += (uint32_t)__popcll(__ballot(valid && !need));       // skipped entries: their one diagonal product
+                dg += (uint32_t)__popcll(__ballot(valid && !need));       // skipped and inline entries: their one diagonal product
                 if (need) {
                     const uint32_t at = ((ft + (uint32_t)__popcll(mn & lt)) & (FQ - 1u)) * 3u;
                     fq[at] = ea.x & pmask; fq[at + 1u] = ea.y; fq[at + 2u] = ca + lane;
@@ -492,6 +513,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             uint32_t nup = 0, mx = 0, nmir = 0;
             auto seed_at = [&](uint32_t a, uint32_t &q, uint32_t &t) {      // sequence number -> the two positions (32-bit accumulators only)
                 const uint2 ce = csr2[rs + (a >> fbits)];
+                if (p.inl != 0u && (ce.y >> 31) != 0u) { q = ce.x & 0xFFFFu; t = ce.x >> 16; return; }      // an inline partner carries both positions
                 q = ce.x & pmask;
                 t = ell ? (uint32_t)p.a_ell[(unsigned long long)ce.y * stride + (a & fmask)] : (uint32_t)p.a_csc[p.a_colptr[ce.y] + (a & fmask)];
             };
@@ -512,7 +534,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                     // B(i,i): first / last product of the fold = the row's first / last entry paired with itself (rows are in (kid, pos)
                     // order, columns in (read, pos) order: the first entry of the row is the first of read i in its column)
                     v.numshared = (int32_t)misc[0];
-                    v.q0 = v.t0 = csr2[rs].x & pmask; v.q1 = v.t1 = csr2[rs + nnz - 1u].x & pmask;
+                    const uint2 e0 = csr2[rs], e1 = csr2[rs + nnz - 1u];
+                    v.q0 = v.t0 = (p.inl != 0u && (e0.y >> 31) != 0u) ? (e0.x & 0xFFFFu) : (e0.x & pmask);
+                    v.q1 = v.t1 = (p.inl != 0u && (e1.y >> 31) != 0u) ? (e1.x & 0xFFFFu) : (e1.x & pmask);
                 }
                 // the partner's row gets the mirrored entry: draw its slot there now; k_mirror places it once the row pointers are known
                 uint32_t tick = 0xFFFFFFFFu;

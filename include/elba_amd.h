@@ -215,7 +215,10 @@ typedef struct {
     uint32_t a_csr_pos_mask; /* position of an a_csr entry = low word & a_csr_pos_mask, whatever the format */
     const void *a_kmers;   /* u64[N]: packed canonical k-mer (first word) of every column, ascending; NULL when A came from triples */
 } elba_device_view;
-enum { ELBA_CSR_PLAIN = 0 /* kid<<32 | pos */, ELBA_CSR_HINTS = 1 /* kid<<32 | hint<<30 | pos */, ELBA_CSR_DENSE = 2 /* kid<<32 | L<<23 | idx<<16 | pos */ };
+enum { ELBA_CSR_PLAIN = 0 /* kid<<32 | pos */, ELBA_CSR_HINTS = 1 /* kid<<32 | hint<<30 | pos */, ELBA_CSR_DENSE = 2 /* kid<<32 | L<<23 | idx<<16 | pos */,
+       ELBA_CSR_INLINE = 3 /* as HINTS, but an entry with bit 63 set carries the one partner of its two-read column instead of the k-mer id:
+                              1<<63 | (partner>>1)<<32 | pos | partner's pos<<16 (positions below 2^16; the partner's low bit follows from the
+                              ownership rule: DESIGN.md §4.1).  elba_export_kmer_matrix and the column side (a_colptr / a_csc / a_kmers) stay canonical */ };
 
 int  elba_abi_version(void);
 const char *elba_strerror(int status);

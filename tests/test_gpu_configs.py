@@ -45,6 +45,54 @@ def _device_tensors(e):
                 colptr=t(v["a_colptr"], v["N"] + 1, "<i4"), csc=t(v["a_csc"], v["Z"], "<i8"))
 
 
+def _rows_from_columns(d, rows):
+    """(k-mer id, pos) of every entry of the given rows, from the COLUMN side of A (a_colptr / a_csc), as {row: (kids, pos)} in (k-mer id, pos)
+    order.  The row side may hold inline partners (ELBA_CSR_INLINE: an entry that carries its column's other read instead of the k-mer id)."""
+    import torch
+    dev = d["csc"].device
+    rt = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(dev)
+    csc = d["csc"]
+    hit = torch.zeros(d["M"], dtype=torch.bool, device=dev); hit[rt] = True
+    z = torch.nonzero(hit[(csc >> 32) & 0xFFFFFFFF]).reshape(-1)
+    cp = (d["colptr"].to(torch.int64) & 0xFFFFFFFF)
+    kid = torch.searchsorted(cp, z, right=True) - 1
+    ent = csc[z]
+    r = ((ent >> 32) & 0xFFFFFFFF).cpu().numpy(); pos = (ent & 0xFFFFFFFF).cpu().numpy(); kid = kid.cpu().numpy()
+    out = {}
+    order = np.lexsort((pos, kid, r))
+    r, pos, kid = r[order], pos[order], kid[order]
+    cuts = np.searchsorted(r, np.asarray(rows))
+    ends = np.searchsorted(r, np.asarray(rows), side="right")
+    for row, a, b in zip(rows, cuts, ends):
+        out[int(row)] = (kid[a:b].astype(np.int64), pos[a:b].astype(np.int64))
+    return out
+
+
+def _check_inline_entries(d, v, row, ent, kids, pos):
+    """An entry with bit 63 set (ELBA_CSR_INLINE) must be the entry of a two-read column whose pair THIS row accumulates (smaller read when the ids'
+    sum is even, else the larger), and carry exactly the column's other entry; every other entry is kid << 32 | hint << 30 | pos."""
+    import torch
+    cp = (d["colptr"].to(torch.int64) & 0xFFFFFFFF)
+    inl = (ent >> 63) & 1
+    hi = (ent >> 32) & 0x7FFFFFFF
+    lo_ = ent & 0xFFFFFFFF
+    plain = inl == 0
+    assert (hi[plain] == kids[plain]).all() and ((lo_[plain] & int(v["a_csr_pos_mask"])) == pos[plain]).all(), row
+    if inl.any():
+        ks = torch.from_numpy(kids[inl == 1]).to(cp.device)
+        c0, c1 = cp[ks], cp[ks + 1]
+        assert bool(((c1 - c0) == 2).all()), row
+        e0 = d["csc"][c0].cpu().numpy(); e1 = d["csc"][c0 + 1].cpu().numpy()
+        r0, p0, r1, p1 = (e0 >> 32) & 0xFFFFFFFF, e0 & 0xFFFFFFFF, (e1 >> 32) & 0xFFFFFFFF, e1 & 0xFFFFFFFF
+        mine0 = r0 == row
+        other_r = np.where(mine0, r1, r0); other_p = np.where(mine0, p1, p0); my_p = np.where(mine0, p0, p1)
+        assert (r0 != r1).all() and ((((row + other_r) & 1) == 0) == (row < other_r)).all(), row
+        jh = hi[inl == 1]
+        j = np.where(jh > (row >> 1), 2 * jh + (row & 1), np.where(jh < (row >> 1), 2 * jh + ((row & 1) ^ 1), row ^ 1))
+        assert (j == other_r).all() and ((lo_[inl == 1] & 0xFFFF) == my_p).all() and ((lo_[inl == 1] >> 16) == other_p).all(), row
+    return int(inl.sum())
+
+
 def _sampled_rows_equal_oracle(e, B, k, lo, up, nsample, seed=0, d=None):
     """See the module docstring.  Returns the number of rows compared."""
     import torch
@@ -57,9 +105,13 @@ def _sampled_rows_equal_oracle(e, B, k, lo, up, nsample, seed=0, d=None):
     cand = np.nonzero(nnz > 0)[0]
     rows = np.sort(rng.choice(cand, size=min(nsample, len(cand)), replace=False))
     rpc = rp.cpu().numpy()
-    idx = np.concatenate([np.arange(rpc[r], rpc[r + 1]) for r in rows])
-    ent = d["csr"][torch.from_numpy(idx).to(dev)]
-    kids = torch.unique((ent >> 32) & 0xFFFFFFFF)                       # every column a sampled row meets, ascending
+    if e.device_view()["a_csr_format"] == 3:                            # inline partners: the columns a row meets are named by the column side
+        rc = _rows_from_columns(d, rows)
+        kids = torch.unique(torch.from_numpy(np.concatenate([rc[int(r)][0] for r in rows])).to(dev))
+    else:
+        idx = np.concatenate([np.arange(rpc[r], rpc[r + 1]) for r in rows])
+        ent = d["csr"][torch.from_numpy(idx).to(dev)]
+        kids = torch.unique((ent >> 32) & 0xFFFFFFFF)                   # every column a sampled row meets, ascending
     cp = d["colptr"].to(torch.int64) & 0xFFFFFFFF
     c0, c1 = cp[kids], cp[kids + 1]
     lens_ = (c1 - c0)
@@ -130,6 +182,7 @@ def _A_equals_oracle_on_value_classes(e, packed, off, lens, k, lo, up, nclasses=
     L = po.lib()
     pmask = int(v["a_csr_pos_mask"])
     rows = np.sort(rng.choice(len(lens), size=min(nrows, len(lens)), replace=False))
+    ninline = 0
     buf = np.zeros(int(lens.max()) + 8, dtype=np.uint64)
     for r in rows:
         n = L.orc_read_kmers(packed.ctypes.data + int(off[r]), int(lens[r]), k, buf.ctypes.data)
@@ -140,7 +193,12 @@ def _A_equals_oracle_on_value_classes(e, packed, off, lens, k, lo, up, nclasses=
         o2 = np.lexsort((exp_pos, exp_kid))
         ent = d["csr"][int(rp[r]):int(rp[r + 1])].cpu().numpy()
         assert len(ent) == len(exp_kid), (r, len(ent), len(exp_kid))
-        assert (((ent >> 32) & 0xFFFFFFFF) == exp_kid[o2]).all() and ((ent & pmask) == exp_pos[o2]).all(), r
+        if v["a_csr_format"] == 3:
+            ninline += _check_inline_entries(d, v, int(r), ent, exp_kid[o2], exp_pos[o2])
+        else:
+            assert (((ent >> 32) & 0xFFFFFFFF) == exp_kid[o2]).all() and ((ent & pmask) == exp_pos[o2]).all(), r
+    if v["a_csr_format"] == 3:
+        assert ninline > 0
     return len(want_kmers), len(rows)
 
 

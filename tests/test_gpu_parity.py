@@ -514,6 +514,8 @@ def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up, cap):
     e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up, options={"kmer_msd": 1, "msd_small_cap": cap})
     o = gu.oracle_run(packed, off, lens, k, lo, up, threads=8)
     assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
+    if up <= 12:
+        assert e.device_view()["a_csr_format"] == 3           # short columns, general SpGEMM path: the rows carry inline partners (ELBA_CSR_INLINE)
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
@@ -521,6 +523,29 @@ def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up, cap):
     st2 = e.create_seed_matrix()
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+
+
+@pytest.mark.parametrize("opts", [{"no_inline": 1}, {"no_symmetry": 1}, {"no_pay": 1}, {"no_ell": 1}, {"mir32": 1}, {"no_sample": 1}])
+def test_inline_partners_against_their_alternatives(opts):
+    """The two-level partition path writes the owning row's entry of every two-read column as an inline partner (no column fetch in the
+    SpGEMM).  Without them ("no_inline"), with both triangles accumulated (the non-owner then fetches the column, the owner still contributes its
+    inline product), with 32-bit accumulators + look-ups / plain CSC columns (which switch the inline format off), wide staging records, no
+    sampled rows: A, B and the statistics equal the oracle's, on a first, a warm and a cold call."""
+    packed, off, lens, info = elba_amd.synth_reads(63, 200000, 16, 3000, 900, error_rate=0.12, min_len=200)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 8)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8, options=dict(opts, kmer_msd=1))
+    fmt = e.device_view()["a_csr_format"]
+    assert fmt == (1 if ("no_inline" in opts or "no_pay" in opts or "no_ell" in opts) else 3)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    st2 = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.set_option("overlap_cold_calls", 1)
+    st3 = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st3, o)
     e.close()
 
 
