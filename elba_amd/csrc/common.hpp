@@ -175,8 +175,8 @@ struct Ctx {
     // k_csc_to_csr_words: every entry sees its whole column there anyway).  csr_hints false: both bits are zero / positions use all 32 bits.
     bool csr_hints = false, ov_hints_used = false, ov_rec16 = false;
     // Inline partners (whole-matrix windows, positions below 2^16, read ids and positions narrow enough for one sort word): four in five columns of
-    // 15 %-error reads hold TWO reads, and under the parity rule exactly one of the two rows accumulates the pair.  That row's entry then carries the
-    // pair itself — a_csr entry = 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16, the partner's low bit follows from the rule — and the SpGEMM
+    // 15 %-error reads hold TWO reads, and under the parity rule exactly one of the two rows accumulates the pair (of longer columns: an entry whose
+    // row accumulates exactly ONE pair of the column).  That row's entry then carries the pair itself — a_csr entry = 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16, the partner's low bit follows from the rule — and the SpGEMM
     // fetches no column for it (58 % of its gathers on BASELINE config 3).  Such an entry has no k-mer id: exports rebuild CSR from the columns.
     bool csr_inline = false;
     bool csr_suffix = false;  // dense matrices: a_csr entries are kid << 32 | column length << 23 | own place in the column << 16 | pos, pairs owned by the smaller row (matrix.hip)

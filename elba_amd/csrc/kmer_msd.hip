@@ -552,29 +552,27 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 const uint64_t x = A[p];
                 const uint32_t kl = slot[u], h0 = H[kl], L = H[kl + 1] - h0;
                 const uint64_t read = (x & paymask) >> m.pbits, pos = x & posmask;
-                uint64_t hint = 0;
+                uint64_t hint = 0, oread = 0, opos = 0;
+                uint32_t nown = 0, mult = 0;
                 if (o.hints && L <= HINT_MAX_COL) {
-                    // Ctx::csr_hints: an entry whose row accumulates no pair of this column under the parity rule (and occurs in it once) is marked
-                    bool own = false; uint32_t mult = 0;
+                    // Ctx::csr_hints: an entry whose row accumulates no pair of this column under the parity rule (and occurs in it once) is marked;
+                    // the entries of the column this row does accumulate a pair with are counted, the last of them remembered
                     const uint32_t i = (uint32_t)read;
                     for (uint32_t t = 0; t < L; ++t) {
-                        const uint32_t j = (uint32_t)((A[h0 + t] & paymask) >> m.pbits);
+                        const uint64_t y = A[h0 + t];
+                        const uint32_t j = (uint32_t)((y & paymask) >> m.pbits);
                         if (j == i) { ++mult; continue; }
-                        own |= ((i ^ j) & 1u) ? j < i : j > i;
+                        if (((i ^ j) & 1u) ? j < i : j > i) { ++nown; oread = j; opos = y & posmask; }
                     }
-                    if (mult < 2 && !own) hint = 3;
+                    if (mult < 2 && nown == 0) hint = 3;
                 }
                 const uint32_t z = eb + p, kid = kb + kl;
                 o.csc[z] = (read << 32) | pos;
                 uint64_t word = (read << o.rs) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
-                if (o.inl && L == 2u) {
-                    // a column of two reads: the row that accumulates the pair (the smaller read when the ids' sum is even, else the larger:
-                    // owns_pair, spgemm_direct.hpp) carries the other entry in its own — the SpGEMM then fetches no column for it
-                    const uint64_t y = A[p == h0 ? h0 + 1u : h0];
-                    const uint64_t oread = (y & paymask) >> m.pbits, opos = y & posmask;
-                    if (oread != read && ((((read + oread) & 1ull) == 0) == (read < oread)) && ((pos | opos) >> o.inl) == 0)
-                        word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
-                }
+                // Ctx::csr_inline: a row that accumulates exactly ONE pair of this column (always so for the owner of a two-read column) carries that
+                // pair in its own entry — the SpGEMM then fetches no column for it
+                if (o.inl && mult == 1u && nown == 1u && ((pos | opos) >> o.inl) == 0)
+                    word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
                 if (o.csr_words) o.csr_words[z] = word;
                 else o.kid_of_entry[z] = kid;
                 if ((headmask >> u) & 1u) {
@@ -893,7 +891,7 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     // bits are what is left, and an entry is written inline only if both positions fit them (200 100 reads of up to 16.6 kb: 14 bits, all but
     // the last bases of a handful of reads)
     int rs = nb + pb + 2, pbi = 0;
-    bool inl = words && hints && c.use_ell && !dense && maxpos < 65536 && !c.opt.no_pay && !c.opt.no_inline && N < (1ull << 31) && mb >= 2;
+    bool inl = words && hints && c.use_ell && !dense && maxpos < 65536 && !c.opt.no_pay && !c.opt.no_inline && !c.opt.no_symmetry && N < (1ull << 31) && mb >= 2;
     if (inl) {
         const int rs2 = 63 - mb;
         pbi = std::min(pb, (rs2 - (mb - 1)) / 2);

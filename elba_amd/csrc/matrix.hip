@@ -354,7 +354,8 @@ __global__ void k_pack_triples(const int64_t *rows, const int64_t *cols, const u
     }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { bad += __shfl_xor(bad, d, 64); const unsigned long long o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
-    if ((threadIdx.x & 63) == 0) { if (bad) atomicAdd(&chk[0], bad); if (mx) atomicMax(&chk[1], mx); }
+    // (one hot word: a wavefront only touches it when it would raise it — 8 M wavefronts each doing an atomic on it took 95 ms)
+    if ((threadIdx.x & 63) == 0) { if (bad) atomicAdd(&chk[0], bad); if (mx > __hip_atomic_load(&chk[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&chk[1], mx); }
 }
 // A as triples, from the resident matrix (rows: the context's row ids, cols: k-mer ids, vals: positions), in CSR order
 __global__ void k_export_triples(const uint32_t *rowptr, const uint64_t *csr, uint32_t M, uint32_t pos_mask, int64_t *rows, int64_t *cols, uint32_t *vals)

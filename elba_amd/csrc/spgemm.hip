@@ -731,7 +731,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     // B is symmetric up to exchanging the two positions of every seed (exactly: the canonical seeds are min / max over a cross product of
     // positions per shared k-mer): a pair of rows of this context's window is accumulated on its smaller row only and the surviving
     // entries are mirrored into the partner's row afterwards (k_mirror) — half the accumulator updates, tables half as full.
-    const bool half = phase >= 1 || !c.opt.no_symmetry;
+    const bool half = phase >= 1 || !c.opt.no_symmetry || c.csr_inline;      // (rows with inline partners hold one triangle's pairs only: "no_symmetry" counts when A is built)
     const int64_t slack = (int64_t)cus * 32 * STAGE_CHUNK + 64;      // one open chunk per resident workgroup
     if (c.ov_tmp_cap == 0) {
         if (c.cfg.workspace_hint_bytes > 0) c.ov_tmp_cap = c.cfg.workspace_hint_bytes / (int64_t)sizeof(StageRec);

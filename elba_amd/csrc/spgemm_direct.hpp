@@ -334,7 +334,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
             };
             auto consume = [&]() {                                        // chunk `ea` -> FIFO; the chunk after it moves up, the one after that is requested
                 const bool valid = ca + lane < nnz;
-                // inline partner (Ctx::csr_inline): the entry of the row that accumulates the pair of a two-read column IS the product — flag |
+                // inline partner (Ctx::csr_inline): an entry whose row accumulates exactly one pair of its column IS that product — flag |
                 // partner >> 1 | posQ | posT << 16, the partner's low bit from the ownership rule — no column to fetch
                 const bool inl = p.inl != 0u && valid && (ea.y >> 31) != 0u;
                 const bool need = valid && !inl && !(ea.x & hmask);
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                     if (mi) {
                         const uint32_t jh = ea.y & 0x7FFFFFFFu, ih = i >> 1;
                         const uint32_t j = jh > ih ? 2u * jh + (i & 1u) : (jh < ih ? 2u * jh + ((i & 1u) ^ 1u) : (i ^ 1u));
-                        const uint32_t seq = ((ca + lane) << fbits) | (j > i ? 1u : 0u);      // the partner's place in its column (two entries, in read order)
+                        const uint32_t seq = (ca + lane) << fbits;      // (the entry's ONLY product with this partner: its place in the column orders nothing)
                         if (GLOBAL) { if (inl) tab.insert(j, seq, full); }
                         else {
                             const uint32_t at = (tail + (uint32_t)__popcll(mi & lt)) & (RING - 1u);

@@ -69,8 +69,8 @@ def _rows_from_columns(d, rows):
 
 
 def _check_inline_entries(d, v, row, ent, kids, pos):
-    """An entry with bit 63 set (ELBA_CSR_INLINE) must be the entry of a two-read column whose pair THIS row accumulates (smaller read when the ids'
-    sum is even, else the larger), and carry exactly the column's other entry; every other entry is kid << 32 | hint << 30 | pos."""
+    """An entry with bit 63 set (ELBA_CSR_INLINE) must be an entry whose row accumulates exactly ONE pair of its column (smaller read when the ids'
+    sum is even, else the larger) and occurs in it once, and carry exactly that partner entry; every other entry is kid << 32 | hint << 30 | pos."""
     import torch
     cp = (d["colptr"].to(torch.int64) & 0xFFFFFFFF)
     inl = (ent >> 63) & 1
@@ -80,16 +80,17 @@ def _check_inline_entries(d, v, row, ent, kids, pos):
     assert (hi[plain] == kids[plain]).all() and ((lo_[plain] & int(v["a_csr_pos_mask"])) == pos[plain]).all(), row
     if inl.any():
         ks = torch.from_numpy(kids[inl == 1]).to(cp.device)
-        c0, c1 = cp[ks], cp[ks + 1]
-        assert bool(((c1 - c0) == 2).all()), row
-        e0 = d["csc"][c0].cpu().numpy(); e1 = d["csc"][c0 + 1].cpu().numpy()
-        r0, p0, r1, p1 = (e0 >> 32) & 0xFFFFFFFF, e0 & 0xFFFFFFFF, (e1 >> 32) & 0xFFFFFFFF, e1 & 0xFFFFFFFF
-        mine0 = r0 == row
-        other_r = np.where(mine0, r1, r0); other_p = np.where(mine0, p1, p0); my_p = np.where(mine0, p0, p1)
-        assert (r0 != r1).all() and ((((row + other_r) & 1) == 0) == (row < other_r)).all(), row
+        c0, c1 = cp[ks].cpu().numpy(), cp[ks + 1].cpu().numpy()
         jh = hi[inl == 1]
         j = np.where(jh > (row >> 1), 2 * jh + (row & 1), np.where(jh < (row >> 1), 2 * jh + ((row & 1) ^ 1), row ^ 1))
-        assert (j == other_r).all() and ((lo_[inl == 1] & 0xFFFF) == my_p).all() and ((lo_[inl == 1] >> 16) == other_p).all(), row
+        posq, post = lo_[inl == 1] & 0xFFFF, lo_[inl == 1] >> 16
+        for a, b, jj, pq, pt in zip(c0, c1, j, posq, post):
+            col = d["csc"][int(a):int(b)].cpu().numpy()
+            r, p_ = (col >> 32) & 0xFFFFFFFF, col & 0xFFFFFFFF
+            mine = r == row
+            owned = (~mine) & np.where(((row ^ r) & 1) == 1, r < row, r > row)      # owns_pair: the larger row when the ids' sum is odd, else the smaller
+            assert mine.sum() == 1 and owned.sum() == 1, (row, r)
+            assert r[owned][0] == jj and p_[owned][0] == pt and p_[mine][0] == pq, (row, r, jj)
     return int(inl.sum())
 
 
