@@ -123,7 +123,6 @@ struct Options {
     bool no_sample = false;     // a cold call does not compute a sample of rows first
     bool no_inline = false;     // no inline partners in the rows of A (the owner's entry of a two-read column carries the other read: no column fetch)
     bool no_suffix = false;     // dense matrices stay on the general kernel
-    bool suffix64 = false;      // dense path with 64-bit accumulators
     bool kmer_pairs = false;    // (value, payload) pairs through the k-mer sort instead of one packed word
     bool kmer_unfused = false;  // per-head column emission (k_runs<true> + k_instance_entries) instead of k_runs_emit
     bool kmer_msd = false;      // force the two-level partition path on inputs below its size threshold (tests)
@@ -133,7 +132,8 @@ struct Options {
     bool trace = false;         // progress lines on stderr
     int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
-    int dense_wgs = 13;         // SpGEMM, dense path: workgroups of the 512-slot tier per CU
+    int dense_up = 0;           // SpGEMM, dense path: the starting tier's table is sized for (estimate << dense_up) partners
+    int dense_wgs = 11;         // SpGEMM, dense path: workgroups of the 512-slot tier per CU
     int dk = 2;                 // SpGEMM: rounds of gather trips in flight (1, 2, 4)
     int64_t aln_tiers = 0;      // x-drop register tiers as decimal digits (1248 = all), 0 = default
     int aln_wide_hint = 6, aln_long_hint = 6000;
@@ -194,7 +194,8 @@ struct Ctx {
     DevBuf a_ell;                              // u64[N * s_stride]: the columns padded to a common stride (entries, then all ones) — the column store the
                                                // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid * s_stride, no pointer
     bool use_ell = false;
-    DevBuf a_ellj;                             // u32[N * s_stride]: the partner read of every slot of a_ell (dense matrices, Ctx::csr_suffix)
+    DevBuf a_ellj;                             // u32[N << j_shift]: the partner reads of every column, right-aligned in an aligned block of 32 or 64 slots (dense matrices, Ctx::csr_suffix)
+    uint32_t j_shift = 5;
     DevBuf col_w0;                             // u8[N]: rotation of every padded column of a dense matrix with a row window (matrix.hip: k_fill_ell)
     uint32_t s_stride = 4, lpc_log2 = 1;       // padded column stride in entries (4, or a multiple of 8: a whole number of 64-byte lines); lanes of the SpGEMM per row entry 2^lpc_log2 >= s_stride / 2
     bool cold_calls = false;                   // every elba_create_seed_matrix call forgets what earlier calls learned (prior, tier usage): elba_set_option

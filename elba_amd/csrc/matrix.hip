@@ -124,13 +124,24 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
 
 // padded column store: slot j of column kid (at kid * stride + j) holds the column's j-th entry, or all ones behind its end; one lane per
 // slot, so the stores of a wavefront are one contiguous 512 bytes (no fill pass before, no column-id array)
-// partner read of every slot of the padded column store (padding stays all ones)
-__global__ void k_ell_partners(const uint64_t *ell, uint64_t nslots, uint32_t *ellj)
+// The dense path's column store (a_ellj): the partner READS of column kid, right-aligned in the aligned block of Sj = 1 << jsh four-byte slots
+// from kid * Sj — its L entries are the block's last L slots, all ones in front of them.  What a row entry owns (the column behind its own
+// place) is then the tail of the block: one aligned 128-byte segment for every entry but the first ones of columns longer than 33.  Copied
+// from the padded 8-byte store (whatever rotation it carries, k_fill_ell), one lane per 16-byte piece of the output.
+__global__ void k_ell_partners(const uint64_t *ell, const uint32_t *colptr, uint64_t N, uint32_t S, uint32_t jsh, uint32_t *ellj)
 {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nslots / 2; t += stride) {
-        const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(ell)[t];
-        reinterpret_cast<uint2 *>(ellj)[t] = make_uint2((uint32_t)(v.x >> 32), (uint32_t)(v.y >> 32));
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, nq = N << (jsh - 2u);
+    const uint32_t Sj = 1u << jsh;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nq; t += stride) {
+        const uint64_t kid = t >> (jsh - 2u);
+        const uint32_t s0 = ((uint32_t)t & ((Sj >> 2) - 1u)) << 2, L = colptr[kid + 1] - colptr[kid];
+        const uint64_t *col = ell + kid * S;
+        uint4 v;
+        v.x = s0 + L >= Sj ? (uint32_t)(col[s0 + L - Sj] >> 32) : 0xFFFFFFFFu;
+        v.y = s0 + 1u + L >= Sj ? (uint32_t)(col[s0 + 1u + L - Sj] >> 32) : 0xFFFFFFFFu;
+        v.z = s0 + 2u + L >= Sj ? (uint32_t)(col[s0 + 2u + L - Sj] >> 32) : 0xFFFFFFFFu;
+        v.w = s0 + 3u + L >= Sj ? (uint32_t)(col[s0 + 3u + L - Sj] >> 32) : 0xFFFFFFFFu;
+        reinterpret_cast<uint4 *>(ellj)[t] = v;
     }
 }
 // colw0 (dense matrices with a row window): column kid is stored ROTATED by colw0[kid] = its entries of reads below the window — the window's
@@ -278,10 +289,11 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     }
     if (c.csr_suffix) {
         hints = false;
-        const uint64_t nslots = (uint64_t)N * c.s_stride;      // (even: the stride is)
+        c.j_shift = c.max_col_nnz <= 32 ? 5u : 6u;      // (use_ell: no column longer than 64)
+        const uint64_t nslots = (uint64_t)N << c.j_shift;
         c.a_ellj.reserve((size_t)nslots * 4 + 64);
-        ELBA_HIP(hipMemsetAsync(c.a_ellj.as<char>() + nslots * 4, 0xFF, 64, s));
-        hipLaunchKernelGGL(k_ell_partners, dim3((unsigned)std::min<uint64_t>((nslots / 2 + 255) / 256, 1ull << 20)), dim3(256), 0, s, (const uint64_t *)c.a_ell.as<uint64_t>(), nslots, c.a_ellj.as<uint32_t>());
+        hipLaunchKernelGGL(k_ell_partners, dim3((unsigned)std::min<uint64_t>((nslots / 4 + 255) / 256, 1ull << 20)), dim3(256), 0, s, (const uint64_t *)c.a_ell.as<uint64_t>(), (const uint32_t *)c.a_colptr.as<uint32_t>(), (uint64_t)N, c.s_stride,
+                           c.j_shift, c.a_ellj.as<uint32_t>());
     }
     if (!c.csr_suffix && mb + nb + pb + 2 <= 64 && !c.opt.csr_pairs) {
         const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;

@@ -76,7 +76,8 @@ struct alignas(32) StageRec { uint4 a, b; };
 struct OvParams {
     // plan-free path (spgemm_direct.hpp): the two orientations of A and nothing else
     const uint32_t *a_rowptr; const uint64_t *a_csr; const uint64_t *a_ell; const uint32_t *a_colptr; const uint64_t *a_csc;
-    const uint32_t *a_ellj;         // dense matrices: the partner read of every slot of a_ell (what the dense path gathers: half the bytes per candidate)
+    const uint32_t *a_ellj;         // dense matrices: the partner reads of every column, right-aligned in an aligned block of 1 << j_shift four-byte slots (what the dense path gathers)
+    uint32_t j_shift, dense_up;
     uint32_t hint_mask, pos_mask;   // which hint bit of a row entry lets this call skip its column (0: none) / the position bits (Ctx::csr_hints)
     uint32_t inl;                   // Ctx::csr_inline: row entries with bit 63 set carry their (only) partner: 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16
     uint32_t suffix;                // dense matrices (Ctx::csr_suffix): row entries carry column length and own place, the smaller row owns a pair
@@ -747,7 +748,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
 
     OvParams p{};
     p.a_rowptr = c.a_rowptr.as<uint32_t>(); p.a_csr = c.a_csr.as<uint64_t>();
-    p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_ellj = c.csr_suffix ? c.a_ellj.as<uint32_t>() : nullptr; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
+    p.a_ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; p.a_ellj = c.csr_suffix ? c.a_ellj.as<uint32_t>() : nullptr; p.j_shift = c.j_shift; p.dense_up = (uint32_t)c.opt.dense_up; p.a_colptr = c.a_colptr.as<uint32_t>(); p.a_csc = c.a_csc.as<uint64_t>();
     p.s_stride = c.s_stride; p.lpc_log2 = c.lpc_log2; p.max_col = (uint32_t)(c.max_col_nnz > 0 ? c.max_col_nnz : 1);
     p.M = (uint32_t)M; p.Mcols = (uint32_t)M; p.row_lo = (uint32_t)row_lo; p.row_hi = (uint32_t)row_hi; p.fbits = c.fbits;
     p.half = phase >= 1 ? 2u : (half ? 1u : 0u);      // 2: a pair is accumulated on ONE of its two rows wherever the other row lives (its rank gets the mirrored entry by exchange)
@@ -781,8 +782,6 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     if (!attr_done) {
         const int lds = 160 * 1024;
 #define ELBA_ATTR(B, P, D) ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<B, false, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, true, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_ATTR(512, true, 1); ELBA_ATTR(512, true, 2); ELBA_ATTR(512, true, 4); ELBA_ATTR(1024, true, 1); ELBA_ATTR(1024, true, 2); ELBA_ATTR(1024, true, 4);
@@ -842,9 +841,8 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         else hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 2>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));                    \
     } while (0)
             const int dk = c.opt.dk;      // rounds of DK trips in flight (tuning knob)
-// (dense path: 32-bit accumulators + seed look-ups for the few survivors — 18.0 vs 19.1 ms on config 5 at 1/25; ELBA_SUFFIX64: the 64-bit ones)
-#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) do { if (!c.opt.suffix64) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3((tier) == 0 ? cus * c.opt.dense_wgs : (grid)), dim3(B), (size_t)18 * (1u << (tb)) + 256 + (size_t)((B) / 64) * 1344, s, p, (tier), (tb), (smp)); \
-                                                          else hipLaunchKernelGGL((k_spgemm_direct<B, false, true, 2, true>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp)); } while (0)
+// (dense path: 32-bit accumulators + seed look-ups for the few survivors; the first tier's grid is a tuning knob: the path waits for memory)
+#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3((tier) == 0 ? cus * c.opt.dense_wgs : (grid)), dim3(B), (size_t)18 * (1u << (tb)) + 256 + (size_t)((B) / 64) * 2368, s, p, (tier), (tb), (smp))
             if (sampling) {
                 if (p.suffix) ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
                 else if (pay) ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);

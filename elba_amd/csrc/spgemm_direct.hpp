@@ -194,9 +194,9 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
         bool full = false;
         uint32_t dg = 0, pr = 0;                 // diagonal products / all products (valid column entries) of the row, as seen by this wavefront (uniform)
         uint32_t head = 0, tail = 0;             // ring positions (uniform)
-        // per wavefront: product ring (128 x 12 or 8 bytes), then the entry FIFO of the padded-column path (128 x 12 bytes); the dense path with
-        // 32-bit accumulators keeps neither: its 336 words of hand-out tables only (more workgroups per CU: the path waits two thirds of its time)
-        uint32_t *qj = misc + 64 + (tid >> 6) * (SUFFIX && !PAY ? 336u : (PAY ? 768u : 640u));
+        // per wavefront: product ring (128 x 12 or 8 bytes), then the entry FIFO of the padded-column path (128 x 12 bytes); the dense path keeps
+        // the ring (for the products its fast look-up misses) and its 336 words of hand-out tables
+        uint32_t *qj = misc + 64 + (tid >> 6) * (SUFFIX ? 592u : (PAY ? 768u : 640u));
         uint32_t *qs = qj + RING;
         unsigned long long *qv = reinterpret_cast<unsigned long long *>(qj + RING);
         auto drain = [&](uint32_t n) {           // n <= 64 products leave the ring, one per lane
@@ -228,48 +228,59 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
         };
         if (SUFFIX) {
             // Dense matrices (matrix.hip: Ctx::csr_suffix).  A row entry carries its column's length L and its own place idx in it; the pairs
-            // it owns (smaller row owns) are exactly the column's entries idx + 1 .. L - 1.  A wavefront takes 64 consecutive row entries,
-            // prefix-sums their numbers of owned candidates and hands the candidates out to its lanes, 64 at a time: a lane finds its entry
-            // by a 6-step search over the prefix sums (LDS), fetches ONE 8-byte candidate and inserts it straight into the table — every lane
-            // a product (but for a read that holds the k-mer twice: the diagonal), no padding, no ownership test, no ring.  The general
-            // path spends ~150 wave-instructions per 28 products here (two padded columns per trip, half of their entries not owned).
-            constexpr uint32_t NWV = (uint32_t)BLOCK / 64u, UN = 4;
+            // it owns (smaller row owns) are exactly the column's entries idx + 1 .. L - 1.  The partner ids of a column sit RIGHT-ALIGNED in
+            // an aligned block of Sj = 32 or 64 four-byte slots (a_ellj: 128 / 256 bytes), so what an entry owns is the tail of that block:
+            // one 128-byte segment for all but the first entries of the longest columns, fetched in 16-byte PIECES (four slots).  The path
+            // is bound by memory requests (profiles/r03_notes.md: 555 M requests at 85 % of the random-line ceiling when it fetched 4 bytes
+            // per lane from columns at a 160-byte stride), and an aligned 128-byte segment costs the memory system what a 64-byte line does
+            // (profiles/microbench/gather128.hip: 41-45 G segments/s against 46-49 G lines/s).
+            // A wavefront takes 64 consecutive row entries, prefix-sums their numbers of pieces and hands the pieces out to its lanes, 64 at
+            // a time: a lane finds its entry through marks the entries leave at their first piece (one LDS round trip + a DPP maximum scan),
+            // fetches ONE 16-byte piece and inserts its four candidates straight into the table — every lane a product but for the slots in
+            // front of the first owned one (first piece of an entry only) and a read that holds the k-mer twice (the diagonal); no padding
+            // to skip, no ownership test, no ring.
+            static_assert(!SUFFIX || !PAY, "dense path: 32-bit accumulators, the seeds of the few survivors are looked up");
+#ifndef ELBA_DENSE_UN
+#define ELBA_DENSE_UN 2
+#endif
+            constexpr uint32_t NWV = (uint32_t)BLOCK / 64u, UN = ELBA_DENSE_UN;      // pieces per lane in flight
             static_assert(UN % 2 == 0, "windows of two batches");
-            uint32_t *skid = PAY ? qj + 384u : qj, *spi = skid + 64, *spre = skid + 128, *sown = skid + 200;      // per wavefront: k-mer id, position | idx << 16, exclusive prefix (65 words), window marks (128)
+            const uint32_t jsh = p.j_shift, Sj = 1u << jsh;
+            const uint4 *ellq = reinterpret_cast<const uint4 *>(p.a_ellj);
+            uint32_t *skid = qj + 2u * RING, *smeta = skid + 64, *spre = skid + 128, *sown = skid + 200;      // per wavefront: k-mer id, first piece | first owned slot << 8 | L << 16, exclusive prefix (65 words), window marks (128)
 #pragma unroll 1
             for (uint32_t cbase = (tid >> 6) * 64u; cbase < nnz; cbase += NWV * 64u) {
                 const bool valid = cbase + lane < nnz;
                 const uint2 en = valid ? csr2[rs + cbase + lane] : make_uint2(0u, 0u);
                 const uint32_t L = (en.x >> 23) & 127u, idx = (en.x >> 16) & 127u;
                 const uint32_t w = valid ? L - idx - 1u : 0u;
-                uint32_t inc = w;
+                const uint32_t fs = Sj - w, p0 = fs >> 2;                      // first owned slot of the block, the piece that holds it
+                const uint32_t np = w ? (Sj >> 2) - p0 : 0u;
+                uint32_t inc = np;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
                 const uint32_t T = __shfl(inc, 63, 64);
                 dg += (uint32_t)__popcll(__ballot(valid));                     // every entry's product with itself
-                __builtin_amdgcn_wave_barrier();                                // (the previous chunk's searches are done)
-                skid[lane] = en.y; spi[lane] = (en.x & 0xFFFFu) | idx << 16; spre[lane] = inc - w;
+                __builtin_amdgcn_wave_barrier();                                // (the previous chunk's look-ups are done)
+                skid[lane] = en.y; smeta[lane] = p0 | fs << 8 | L << 16; spre[lane] = inc - np;
                 if (lane == 63) spre[64] = T;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 if (cbase == (tid >> 6) * 64u) { resolve_early(); } else if (cbase == (tid >> 6) * 64u + NWV * 64u) bounds_early();
 #pragma unroll 1
                 for (uint32_t base = 0; base < T; base += 64u * UN) {
-                    // (32-bit accumulators: the hot loop needs the partner alone — fetched from the 4-byte copy of the padded columns, 16 candidates
-                    //  per 64-byte line.  The path is bound by line requests: 5.2 G candidates of config 5 at 1/25 were 703 M requests at 8 bytes each)
-                    typename std::conditional<PAY, unsigned long long, uint32_t>::type x[UN];
-                    uint32_t pq[UN], sq[UN];
+                    uint4 x[UN];
+                    uint32_t sq[UN], vr[UN];
                     bool ok[UN];
-                    // candidate -> entry, 128 candidates at a time: every entry that starts inside the window (or covers its first place) marks
-                    // its first place with its number, a DPP maximum scan spreads the marks to the right — one LDS round trip where a binary
-                    // search over the prefix sums made six dependent ones
+                    // piece -> entry, 128 pieces at a time: every entry that starts inside the window (or covers its first place) marks
+                    // its first place with its number, a DPP maximum scan spreads the marks to the right
 #pragma unroll
                     for (int hw = 0; hw < (int)UN / 2; ++hw) {
                         const uint32_t B = base + (uint32_t)hw * 128u;
                         sown[lane] = 0; sown[lane + 64u] = 0;
                         __builtin_amdgcn_wave_barrier();
-                        if (w != 0u) {
-                            const uint32_t pre = inc - w;
+                        if (np != 0u) {
+                            const uint32_t pre = inc - np;
                             if (pre >= B && pre - B < 128u) sown[pre - B] = lane + 1u;
                             else if (pre < B && inc > B) sown[0] = lane + 1u;
                         }
@@ -285,22 +296,37 @@ __global__ __launch_bounds__(BLOCK) void k_spgemm_direct(OvParams p, int tier, u
                             const uint32_t c = B + (uint32_t)v2 * 64u + lane;
                             ok[u] = c < T;
                             const uint32_t en1 = v2 ? m1 : m0, lo = ok[u] ? en1 - 1u : 0u;
-                            const uint32_t pi = spi[lo], sl = (pi >> 16) + 1u + (c - spre[lo]);
-                            pq[u] = pi & 0xFFFFu; sq[u] = ((cbase + lo) << fbits) | sl;
-                            if constexpr (PAY) x[u] = ok[u] ? p.a_ell[(unsigned long long)skid[lo] * stride + sl] : ~0ull;
-                            else x[u] = ok[u] ? p.a_ellj[(unsigned long long)skid[lo] * stride + sl] : EMPTY;
+                            const uint32_t mt = smeta[lo], pc = (mt & 63u) + (c - spre[lo]), s0 = pc << 2, f0 = (mt >> 8) & 127u;
+                            vr[u] = f0 > s0 ? f0 - s0 : 0u;                                      // slots of the piece in front of the first owned one
+                            sq[u] = ((cbase + lo) << fbits) + (s0 + (mt >> 16) - Sj);        // sequence number of the piece's first slot: rank of the row entry | place in the column
+                            x[u] = ok[u] ? ellq[((unsigned long long)skid[lo] << (jsh - 2u)) + pc] : make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
 #pragma unroll
                     for (int u = 0; u < (int)UN; ++u) {
-                        uint32_t j, posT = 0;
-                        if constexpr (PAY) { j = (uint32_t)(x[u] >> 32); posT = (uint32_t)x[u]; } else j = x[u];
-                        const bool dgn = ok[u] && j == i;                       // the read holds the k-mer again behind this entry: the pair of entries counts twice on the diagonal
-                        const uint64_t md = __ballot(dgn);
-                        if (md) dg += 2u * (uint32_t)__popcll(md);
-                        if (PAY) { const unsigned long long v = ((unsigned long long)sq[u] << 32) | (pq[u] << 16) | posT; tab.insert_lds64(j, v, v, 1u, ok[u] && !dgn, full); }
-                        else tab.insert_lds(j, sq[u], sq[u], 1u, ok[u] && !dgn, full);
+                        const uint32_t xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+                        uint32_t js[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const bool own = ok[u] && (uint32_t)r >= vr[u];
+                            const bool dgn = own && xs[r] == i;                 // the read holds the k-mer again behind this entry: the pair of entries counts twice on the diagonal
+                            const uint64_t md = __ballot(dgn);
+                            if (md) dg += 2u * (uint32_t)__popcll(md);
+                            js[r] = own && !dgn ? xs[r] : EMPTY;
+                        }
+                        // four look-ups in flight; what they do not settle (a partner not met before or not in its first slot, a new minimum)
+                        // queues for the general insert
+                        const uint32_t miss = full ? 0u : tab.hit4_lds(js, sq[u]);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const uint64_t mm = __ballot((miss >> r) & 1u);
+                            if (mm == 0) continue;
+                            const uint32_t at = (tail + (uint32_t)__popcll(mm & lt)) & (RING - 1u);
+                            if ((miss >> r) & 1u) { qj[at] = js[r]; qs[at] = sq[u] + (uint32_t)r; }
+                            tail += (uint32_t)__popcll(mm);
+                            if (tail - head >= 64u) drain(64u);
+                        }
                     }
                     if (tab.abandoned()) break;
                 }
@@ -618,6 +644,7 @@ __global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
             const uint32_t ub = prod_ub < (unsigned long long)p.Mcols ? (uint32_t)prod_ub : p.Mcols;
             const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
             uint32_t est = (uint32_t)(((unsigned long long)nnz * prior_q16) >> 16);
+            if (p.suffix) est <<= p.dense_up;      // (dense path: a lower load factor means fewer look-ups that miss their first slot)
             if (est < 64) est = 64;
             int tier = 0;
             while (tier < NUM_LDS_TIERS && est > p.tier_limit[tier]) ++tier;

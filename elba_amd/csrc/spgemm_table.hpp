@@ -51,7 +51,7 @@ struct Table {
     __device__ __forceinline__ void insert_lds(uint32_t j, uint32_t s, uint32_t smx, uint32_t cnt, bool valid, bool &full) const
     {
         if (full) return;
-        uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
+        uint32_t slot = lds_slot(j);
         uint32_t claimed = 0, old, addr = 0;
         unsigned long long save, t;
         const uint32_t base = (uint32_t)(uintptr_t)keys;        // LDS byte offset (a local address is the low half of its flat form)
@@ -104,7 +104,7 @@ struct Table {
     __device__ __forceinline__ void insert_lds64(uint32_t j, unsigned long long lo, unsigned long long hi, uint32_t cnt, bool valid, bool &full) const
     {
         if (full) return;
-        uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
+        uint32_t slot = lds_slot(j);
         uint32_t claimed = 0, old, addr = 0;
         unsigned long long save, t;
         const uint32_t base = (uint32_t)(uintptr_t)keys;
@@ -151,6 +151,44 @@ struct Table {
             }
         }
     }
+    // Dense path, the common case of a product: its partner is in the table already and its sequence number is not below the pair's minimum.
+    // Dense matrices meet the same hundred partners tens of thousands of times per row and sequence numbers arrive in ascending order per
+    // wavefront, so after a slot's first visits this is what every product is.  FOUR look-ups (the partner ids of one 16-byte piece of a column;
+    // j == EMPTY: no product in that place) are in flight together, each ONE plain LDS read of key and current minimum (equal addresses are a
+    // broadcast where a compare-and-swap serialises), and a hit costs two atomics — count and maximum — where insert_lds spends four and exposes a
+    // round trip per product.  No loop, no claim: a product that misses (another key or nothing in its first slot, or a new minimum) is
+    // returned in the mask (bit r) and goes through insert_lds (the caller's retry ring).
+    // (profiles/r03_notes.md: the dense path was bound by the LDS pipeline, 63 % of its busy cycles bank conflicts, and by instruction issue.)
+    __device__ __forceinline__ uint32_t hit4_lds(const uint32_t (&j)[4], uint32_t s0) const
+    {
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        const lds_u32 *lk = (const lds_u32 *)keys;
+        const uint32_t T = size(), tb = T * 4;
+        uint32_t slot[4], k[4], m[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot[r] = lds_slot(j[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            k[r] = __hip_atomic_load(&lk[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            m[r] = __hip_atomic_load(&lk[slot[r] + 2u * T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        uint32_t miss = 0;
+        const uint32_t base = (uint32_t)(uintptr_t)keys, one = 1u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t s = s0 + (uint32_t)r;
+            if (k[r] == j[r] && s >= m[r] && j[r] != EMPTY) {
+                uint32_t a;
+                asm volatile("v_lshl_add_u32 %[a], %[slot], 2, %[cb]\n\t"
+                             "ds_add_u32 %[a], %[one]\n\t"
+                             "v_add_u32_e32 %[a], %[tb2], %[a]\n\t"
+                             "ds_max_u32 %[a], %[s]\n"
+                             : [a] "=&v"(a) : [slot] "v"(slot[r]), [cb] "s"(base + tb), [tb2] "s"(2u * tb), [one] "v"(one), [s] "v"(s) : "memory");
+            } else if (j[r] != EMPTY) miss |= 1u << r;
+        }
+        return miss;
+    }
+    __device__ __forceinline__ uint32_t lds_slot(uint32_t j) const { return (j * 0x9E3779B1u) >> (32 - tbits); }      // (a 24-bit multiply, v_mul_u32_u24, was measured: no difference)
     __device__ __forceinline__ uint32_t ldrelaxed(const uint32_t *a) const
     {
         return __hip_atomic_load(a, __ATOMIC_RELAXED, GLOBAL ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -442,11 +442,11 @@ def test_reads_that_hold_a_kmer_twice_and_the_ownership_hints(shape):
         e.close()
 
 
-@pytest.mark.parametrize("knob", [None, "no_suffix", "suffix64"])
+@pytest.mark.parametrize("knob", [None, "no_suffix"])
 def test_dense_columns_take_the_path_of_their_own(knob):
     """Deep, nearly error-free reads with a generous UPPER: columns of ~30 reads, hundreds of products per surviving pair.  Such matrices are
     multiplied by the dense path (pairs owned by the smaller row, the owned candidates of a row entry = its column behind it: DESIGN.md §4.1);
-    the option "no_suffix" keeps them on the general path, "suffix64" runs the dense path with 64-bit accumulators.  A, B and the statistics equal the oracle's either way, on a cold and a warm call, and
+    the option "no_suffix" keeps them on the general path.  A, B and the statistics equal the oracle's either way, on a cold and a warm call, and
     a read that holds a k-mer twice (a repeat family) is among them."""
     packed, off, lens, info = elba_amd.synth_reads(91, 60000, 30, 3000, 600, error_rate=0.01, min_len=500, repeat_families=3, repeat_fraction=0.1, repeat_len=400)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40, options={knob: 1} if knob else None)
