@@ -78,6 +78,11 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # ELBA_DIST_BACKEND=gloo: the N > 1 driver as N processes on ONE GPU, collectives carried over the host (elba_amd.distributed.HostStagedDist) —
+    # a rehearsal of this file's multi-rank path on a one-GPU box (RCCL refuses two ranks on one device); the line then says so in "transport"
+    backend = os.environ.get("ELBA_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     force_dist = bool(os.environ.get("ELBA_FORCE_DIST"))      # exercise the multi-GPU driver with world_size 1 (self-test on a 1-GPU box)
@@ -85,7 +90,12 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            from elba_amd.distributed import HostStagedDist
+            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist = HostStagedDist(dist)
 
     w = WORKLOADS[args.workload]
     k, lo, up = w["k"], w["lower"], w["upper"]
@@ -154,7 +164,8 @@ def main():
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-        tot = torch.tensor([st["nnz"], st["products"], st["algorithmic_bytes"], ks["instances"], ms["nnz"], bases_local], dtype=torch.int64, device="cuda")
+        # (nnz(A): every column is counted by the rank that owns its k-mer — a rank's panel holds whole columns, shared with other ranks' panels)
+        tot = torch.tensor([st["nnz"], st["products"], st["algorithmic_bytes"], ks["instances"], ks.get("entries", ms["nnz"]), bases_local], dtype=torch.int64, device="cuda")
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         Y, P, abytes, I_tot, Z_tot, bases_tot = [int(x) for x in tot.tolist()]
         # every rank's step phases (device time on its stream): queue numeric + group the mirror images | all-to-all | merge + finalize + the one host wait
@@ -341,6 +352,7 @@ def main():
             "value": round(Y / (dt / steps), 1), "unit": "overlap nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak" if (args.weak and world > 1) else "strong", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
+            "transport": ("RCCL (torch.distributed backend nccl)" if backend == "nccl" else "REHEARSAL: %s over host copies, %d processes on %d device(s) — not a scaling measurement" % (backend, world, torch.cuda.device_count())) if dist is not None else None,
             "config": dict({"workload": args.workload, "reads": int(info["total_reads"]) if "total_reads" in info else int(info["nreads"]), "k": k, "lower": lo, "upper": up,
                             "genome": w["genome"] * (world if args.weak else 1), "depth": w["depth"], "error": w["error"], "kmer_instances": I_tot, "nnz_A": Z_tot,
                             "products": P, "overlap_nnz": Y, "algorithmic_bytes": abytes,
@@ -368,7 +380,7 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        (dist.d if backend != "nccl" else dist).destroy_process_group()
 
 
 def run_aux(eng, packed, off, lens, k, lo, up, device):

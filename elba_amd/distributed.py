@@ -238,6 +238,37 @@ class HipBackend:
         self.torch.cuda.synchronize(self.dev)
 
 
+class HostStagedDist:
+    """`torch.distributed` over gloo for DEVICE tensors: every collective goes through host copies.  Not the product transport (that is RCCL,
+    backend "nccl") — a rehearsal transport: RCCL refuses two ranks on one device, so the only way to run the N > 1 driver (`bench.py --gpus N`,
+    the sequence of collectives of src/KmerOps.cpp:117-151,244-274,371-375) as N separate PROCESSES on a one-GPU box is to carry its collectives
+    over the host.  Same call signatures as the torch.distributed functions the driver uses; `.cpu()` waits for the stream, so the ordering the
+    shared stream gives RCCL holds here too."""
+
+    def __init__(self, dist):
+        self.d = dist
+        self.ReduceOp = dist.ReduceOp
+
+    def barrier(self):
+        self.d.barrier()
+
+    def all_reduce(self, t, op=None):
+        c = t.cpu()
+        self.d.all_reduce(c, op=op if op is not None else self.d.ReduceOp.SUM)
+        t.copy_(c)
+
+    def all_gather(self, outs, t):
+        co = [o.cpu() for o in outs]
+        self.d.all_gather(co, t.cpu())
+        for o, c in zip(outs, co):
+            o.copy_(c)
+
+    def all_to_all_single(self, out, inp, output_split_sizes=None, input_split_sizes=None):
+        co = out.cpu()
+        self.d.all_to_all_single(co, inp.cpu(), output_split_sizes=output_split_sizes, input_split_sizes=input_split_sizes)
+        out.copy_(co)
+
+
 class DistributedOverlap:
     MAX_RECORDS_PER_PEER = 1 << 25          # 512 MiB of 16-byte records per peer and all-to-all round
 
