@@ -569,3 +569,30 @@ def test_two_level_partition_windows_of_a_crowded_bucket(nreads):
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
     e.close()
+
+
+@pytest.mark.parametrize("knob", [None, "csr_pairs"])
+def test_device_resident_triples_in_any_order(knob):
+    """INTEGRATION.md Option B hands A over as COO triples that already sit in HBM (elba_set_kmer_matrix_device).  The triples of a GPU-built A,
+    exported on the device and SHUFFLED, rebuild the same matrix — through the one-word sort (k-mer id | read | position in 64 bits) and, with the
+    option "csr_pairs", through the three stable pair sorts — and B equals the oracle's.  An index out of range is refused."""
+    import torch
+    packed, off, lens, info = elba_amd.synth_reads(23, 50000, 25, 3000, 700, error_rate=0.10, min_len=200)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
+    o = gu.oracle_run(packed, off, lens, 17, 2, 8, threads=8)
+    Z, M, N = int(ms["nnz"]), int(ms["nrows"]), int(ms["ncols"])
+    dr = torch.empty(Z, dtype=torch.int64, device="cuda"); dc = torch.empty(Z, dtype=torch.int64, device="cuda"); dv = torch.empty(Z, dtype=torch.int32, device="cuda")
+    e.export_triples_device(dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
+    perm = torch.randperm(Z, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    dr, dc, dv = dr[perm].contiguous(), dc[perm].contiguous(), dv[perm].contiguous()
+    e2 = elba_amd.Engine(17, 2, 8, options={knob: 1} if knob else None)
+    m2 = e2.set_kmer_matrix_device(M, N, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
+    assert int(m2["nnz"]) == Z
+    st2 = e2.create_seed_matrix()
+    gu.assert_A_equal(e2.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e2.export_csr(), o.B())
+    gu.assert_stats_equal(st2, o)
+    dc[Z // 2] = N                                   # a column that does not exist
+    with pytest.raises(Exception):
+        e2.set_kmer_matrix_device(M, N, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
+    e.close(); e2.close()
