@@ -1129,7 +1129,9 @@ bool stage_seed_matrix_recv(Ctx &c, void *d_recv, int64_t slot, int64_t *slot_ne
         c.ov_low_clean = false;
         return false;
     }
-    if (slot_needed) *slot_needed = slot;
+    // (what would have sufficed — the same number on every rank: the largest count any sender put into any slot, + 1/8 — lets the caller SHRINK a
+    //  first guess that was several times too generous: the all-to-all moves whole slots)
+    if (slot_needed) *slot_needed = std::min<int64_t>(slot, (int64_t)hchk[3] + (int64_t)hchk[3] / 8 + 16);
     c.ov_low_clean = true;
     elba_overlap_stats st{};
     st.nrows = row_hi - row_lo;

@@ -475,7 +475,8 @@ class DistributedOverlap:
         """The step with ONE host synchronisation.  The mirror images travel in fixed-size slots (equal splits: no counts cross the host, no
         buffer is sized from a count), the library and the collective run on one stream, and what the counted variant checks in between —
         did everything fit? — is checked once at the end, by every rank alike (a flag in every slot's header).  The slot size starts from
-        an upper-bound guess that all ranks compute from the same numbers and only grows."""
+        an upper-bound guess that all ranks compute from the same numbers; a repeated step grows it, a completed one sets it to what the step
+        needed (+ 1/8: the same figure on every rank, it travels in the headers)."""
         W, torch = self.world, self.be.torch
         if not getattr(self.be, "shares_stream", False):
             self.be.use_current_stream()
@@ -502,10 +503,11 @@ class DistributedOverlap:
             if ev:
                 ev[3].record(); ev[3].synchronize()
                 self.phase_ms = dict(send=ev[0].elapsed_time(ev[1]), exchange=ev[1].elapsed_time(ev[2]), recv=ev[2].elapsed_time(ev[3]))
-            self._slot = max(self._slot, need)
             if st is not None:
+                self._slot = max(need, 2)            # every rank got the same figure: the next step's slots are as large as this one needed (+ 1/8)
                 self.mirror_bytes = W * slot * 32
                 return st
+            self._slot = max(self._slot, need)
         raise RuntimeError("create_seed_matrix: the mirror exchange did not settle")
 
     # ---- the step after the path: x-drop alignment of the candidate pairs, sharded ------------------------------------------

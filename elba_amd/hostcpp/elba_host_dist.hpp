@@ -200,8 +200,8 @@ public:
             elba_overlap_stats st{};
             int64_t need = 0;
             const int rc = elba_seed_matrix_recv(engine_->ctx, recv_.p, (int64_t)slot, &st, &need);
+            if (rc == ELBA_OK) { slot_ = std::max<uint64_t>((uint64_t)need, 2); mirror_bytes_ = (uint64_t)W * slot * 32; return st; }      // (what the step needed + 1/8, the same on every rank)
             slot_ = std::max<uint64_t>(slot_, (uint64_t)need);
-            if (rc == ELBA_OK) { mirror_bytes_ = (uint64_t)W * slot * 32; return st; }
             if (rc != ELBA_ERR_RETRY) engine_->check(rc);
         }
         throw std::runtime_error("create_seed_matrix_slots: the mirror exchange did not settle");

@@ -377,7 +377,9 @@ int  elba_seed_matrix_end(elba_ctx *ctx, const void *d_recv, int64_t nrecords, e
  *   elba_seed_matrix_recv   queues the merge of d_recv's slots (d_recv is scratch: tickets are written into it), row pointers, column sort;
  *                           synchronises once.  ELBA_OK: this rank's rows of B are complete.  ELBA_ERR_RETRY: this rank's staging area or some
  *                           rank's slot was too small — the flag travels in every header, so every rank gets this answer in the same step —
- *                           capacities have grown: repeat send / all-to-all / recv with *slot_records_needed (the same value on every rank). */
+ *                           capacities have grown: repeat send / all-to-all / recv with *slot_records_needed (the same value on every rank).
+ *                           With ELBA_OK *slot_records_needed is the slot size this step would have got by with (+ 1/8; <= slot_records, again
+ *                           the same on every rank): a caller whose first guess was generous uses it for its next step — whole slots travel. */
 int  elba_set_stream(elba_ctx *ctx, void *hip_stream);
 int  elba_seed_matrix_send(elba_ctx *ctx, int nranks, const uint64_t *read_bounds, void *d_send, int64_t slot_records);
 int  elba_seed_matrix_recv(elba_ctx *ctx, void *d_recv, int64_t slot_records, elba_overlap_stats *stats, int64_t *slot_records_needed);
