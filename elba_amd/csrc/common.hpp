@@ -121,6 +121,7 @@ struct Options {
     bool mir32 = false;         // 32-byte staging / mirror records instead of 16-byte words
     bool no_hints = false;      // no ownership bits in the rows of A
     bool no_sample = false;     // a cold call does not compute a sample of rows first
+    bool panel_inline = false;  // inline partners in the rows of a windowed matrix too (a shard's panel): such a matrix is multiplied with the mirror exchange only
     bool no_inline = false;     // no inline partners in the rows of A (the owner's entry of a two-read column carries the other read: no column fetch)
     bool no_suffix = false;     // dense matrices stay on the general kernel
     bool kmer_pairs = false;    // (value, payload) pairs through the k-mer sort instead of one packed word
@@ -179,6 +180,7 @@ struct Ctx {
     // row accumulates exactly ONE pair of the column).  That row's entry then carries the pair itself — a_csr entry = 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16, the partner's low bit follows from the rule — and the SpGEMM
     // fetches no column for it (58 % of its gathers on BASELINE config 3).  Such an entry has no k-mer id: exports rebuild CSR from the columns.
     bool csr_inline = false;
+    bool csr_inline_window = false;      // ... written for a matrix with a row window (option "panel_inline"): valid under the parity rule over all rows only, i.e. for calls with the mirror exchange
     bool csr_suffix = false;  // dense matrices: a_csr entries are kid << 32 | column length << 23 | own place in the column << 16 | pos, pairs owned by the smaller row (matrix.hip)
     DevBuf ov_sample;         // u32[256]: the rows a cold SpGEMM call computes first (spgemm.hip)
     int64_t A_products = 0;   // sum over the window's row entries of their column's length (what the SpGEMM reports as `products`)

@@ -45,7 +45,7 @@ __global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, uint6
 
 // CSR build with ONE word per entry when read, k-mer id, the two hint bits and the position fit 64 bits together:
 // read << (nb + pb + 2) | kid << (pb + 2) | hint << pb | pos, sorted on the read bits only (stable: rows come out in (kid, pos) order)
-__global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, const uint32_t *colptr, const uint64_t *csc, int64_t Z, int nb, int pb, uint64_t *words,
+__global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, const uint32_t *colptr, const uint64_t *csc, int64_t Z, int nb, int pb, int rs, int pbi, uint64_t *words,
                                    bool hints, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,7 +54,26 @@ __global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, cons
     const uint64_t kid = kid_keys[z] >> kid_shift, e = csc[z];
     const uint32_t h = entry_hint(colptr, csc, kid, in ? (uint32_t)(e >> 32) : 0xFFFFFFFFu, hints && in, in ? win_lo : 0u, in ? win_hi : 0u, prod_ctr);
     if (!in) return;
-    words[z] = ((e >> 32) << (nb + pb + 2)) | (kid << (pb + 2)) | ((uint64_t)h << pb) | (e & 0xFFFFFFFFull);
+    uint64_t word = ((e >> 32) << rs) | (kid << (pb + 2)) | ((uint64_t)h << pb) | (e & 0xFFFFFFFFull);
+    if (pbi) {
+        // Ctx::csr_inline, as kmer_msd.hip writes it: a row that accumulates exactly ONE pair of this column under the parity rule over ALL rows
+        // carries that pair in its own entry — flag | read << rs | (partner >> 1) << 2 pbi | posQ << pbi | posT — when both positions fit pbi bits
+        const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0, i = (uint32_t)(e >> 32);
+        if (L <= HINT_MAX_COL) {
+            uint32_t nown = 0, mult = 0;
+            uint64_t other = 0;
+            for (uint32_t t = 0; t < L; ++t) {
+                const uint64_t y = csc[c0 + t];
+                const uint32_t j = (uint32_t)(y >> 32);
+                if (j == i) { ++mult; continue; }
+                if (((i ^ j) & 1u) ? j < i : j > i) { ++nown; other = y; }
+            }
+            const uint64_t pos = e & 0xFFFFFFFFull, opos = other & 0xFFFFFFFFull;
+            if (mult == 1u && nown == 1u && ((pos | opos) >> pbi) == 0)
+                word = (1ull << 63) | ((e >> 32) << rs) | (((other >> 32) >> 1) << (2 * pbi)) | (pos << pbi) | opos;
+        }
+    }
+    words[z] = word;
 }
 // hint bits for sort keys that came without them (k_runs_emit, kmer.hip): the entry's k-mer id is in the word, its column in the CSC
 // (one lane per entry; one lane per COLUMN, its entries in registers, was measured: 7.0 ms against 5.2)
@@ -271,7 +290,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     // its lanes (spgemm_direct.hpp, "suffix" path).  Positions below 2^16, the padded column store.  With a row window (a shard, a row block
     // of a shard: elba_dist_set_panel) the padded columns are stored rotated so that this stays true (k_fill_ell).
     const bool windowed = !(win_lo == 0 && (win_hi < 0 || win_hi == M));
-    c.csr_inline = false;
+    c.csr_inline = false; c.csr_inline_window = false;
     const uint8_t *colw0 = nullptr;
     if (!(pre && c.pre_ell_done)) {      // (the two-level partition of kmer_msd.hip writes the padded columns with the columns themselves)
         c.max_col_nnz = max_segment_len(c, c.a_colptr.as<uint32_t>(), N);
@@ -299,16 +318,26 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;
         uint64_t *w0 = have_words ? c.csr_words.as<uint64_t>() : c.ws_a.as<uint64_t>(), *w1 = c.ws_c.as<uint64_t>();
         ELBA_REQUIRE(!pre || have_words, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
+        int rs = have_words ? c.pre_rs : nb + pb + 2, pbi = have_words ? c.pre_pbi : 0;
+        // inline partners for a matrix that did not come from the k-mer stage of this context (triples, a panel of the sharded build): the keys are
+        // written here.  The rule they follow is the parity rule over ALL rows — what a whole matrix uses, and a shard when the mirror exchange
+        // assigns every pair of the job to one of its two rows (elba_seed_matrix_send / _begin); a windowed matrix gets them only on request
+        // (option "panel_inline") and can then not be multiplied without the exchange.
+        bool inl_here = false;
+        if (!have_words && hints && c.use_ell && c.pos16 && !c.opt.no_pay && !c.opt.no_inline && !c.opt.no_symmetry && (!windowed || c.opt.panel_inline) && N < (1ll << 31) && mb >= 2) {
+            const int rs2 = 63 - mb, pbi2 = std::min(pb, (rs2 - (mb - 1)) / 2);
+            if (rs2 >= nb + pb + 2 && pbi2 >= 10) { rs = rs2; pbi = pbi2; inl_here = true; }
+        }
         if (Z > 0 && !have_words)
-            hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0,
+            hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, rs, inl_here ? pbi : 0, w0,
                                hints, wlo, whi, prod_ctr);
         if (Z > 0 && have_words && hints && !c.pre_hints_done)
             hipLaunchKernelGGL(k_add_hints, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
-        const int rs = have_words ? c.pre_rs : nb + pb + 2;
         const int where = radix_sort_keys(s, w0, w1, Z, rs, rs + mb, c.ws_sort);
         const uint64_t *sorted = where ? w1 : w0;
-        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, rs, mb, have_words ? c.pre_pbi : 0, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
-        c.csr_inline = have_words && c.pre_inline;
+        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, rs, mb, (have_words && c.pre_inline) || inl_here ? pbi : 0, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
+        c.csr_inline = (have_words && c.pre_inline) || inl_here;
+        c.csr_inline_window = inl_here && windowed;
     } else {
         ELBA_REQUIRE(!pre || !c.pre_words || c.csr_suffix, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
         const bool kid_in_words = pre && c.pre_words;        // (k_runs_emit left sort keys, not column ids: the k-mer id is a field of the word)

@@ -760,7 +760,10 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.suffix = c.csr_suffix && p.half == 1u ? 1u : 0u;
     p.inl = c.csr_inline ? 1u : 0u;
     c.ov_hints_used = c.ov_hints_used || c.csr_inline;
-    ELBA_REQUIRE(!c.csr_inline || (row_lo == 0 && row_hi == M && phase == 0 && c.use_ell), ELBA_ERR_INTERNAL, "inline partners in a matrix with a row window");
+    // (inline partners follow the parity rule over ALL rows: a whole matrix in one call, or a shard's rows with the mirror exchange; a windowed matrix
+    //  multiplied alone keeps every partner outside its window — another rule)
+    ELBA_REQUIRE(!c.csr_inline || (c.use_ell && (phase >= 1 || (row_lo == 0 && row_hi == M))), ELBA_ERR_STATE,
+                 "this windowed matrix carries inline partners (option panel_inline): multiply it through elba_seed_matrix_send / _begin, or rebuild it without the option");
     c.ov_hints_used = p.hint_mask != 0u || p.suffix != 0u || c.csr_inline;      // (entries that fetch no column do not see its length: the product count comes from the build of A)
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;

@@ -195,6 +195,9 @@ class HipBackend:
     def create_seed_matrix(self):
         return self.e.create_seed_matrix()
 
+    def set_option(self, name, value):
+        self.e.set_option(name, value)
+
     # sharded call with mirror exchange (elba_seed_matrix_begin / _fill / _end)
     def seed_begin(self, nranks, bounds):
         b = np.ascontiguousarray(bounds, dtype=np.uint64)
@@ -283,6 +286,9 @@ class DistributedOverlap:
         self.time_phases = False          # record (send, exchange, recv) device times of every step with the fixed-slot exchange (bench.py)
         self.phase_ms = None
         self.panel_records = 0
+        self.inline_partners = None       # inline partners in the panel's rows (a third fewer column fetches): None = whenever the step will use the mirror exchange
+        self._panel_inline = False
+        self._cur_block = 0
 
     # ---- inputs -----------------------------------------------------------------------------------------------------
     def set_reads(self, packed, off, lens, first_global_id, bounds):
@@ -441,6 +447,13 @@ class DistributedOverlap:
         panel = self._all_to_all_records(send, pc, prc)
         del send
         m_total = int(self.bounds[-1])
+        # inline partners follow the pair-ownership rule of the mirror exchange (the parity rule over ALL rows): the panel gets them when that is how
+        # it will be multiplied; a call without the exchange on such a panel reloads it without them (create_seed_matrix)
+        want_inl = self.inline_partners if self.inline_partners is not None else ((W > 1 or self.force_exchange) and self.row_batches == 1 and hasattr(self.be, "seed_begin"))
+        if hasattr(self.be, "set_option"):
+            self.be.set_option("panel_inline", 1 if want_inl else 0)
+            self._panel_inline = bool(want_inl)
+        self._cur_block = t
         self.block = self.row_block(self.rank, t) if self.row_batches > 1 else (int(self.bounds[self.rank]), int(self.bounds[self.rank + 1]))
         ms = dict(self.be.set_panel(panel, m_total, self.n_total, self.block[0], self.block[1]))
         ms["panel_records"] = int(prc.sum())
@@ -458,6 +471,9 @@ class DistributedOverlap:
         if exchange is None:
             exchange = (self.world > 1 or self.force_exchange) and self.row_batches == 1 and hasattr(self.be, "seed_begin")
         if not exchange:
+            if self._panel_inline:                  # (every rank takes this branch together: the reload is a collective)
+                self.inline_partners = False
+                self.load_row_block(self._cur_block)
             return self.be.create_seed_matrix()
         if exchange != "counted" and hasattr(self.be, "seed_send"):
             return self._create_seed_matrix_slots()
