@@ -145,6 +145,9 @@ public:
         recv_.reserve(sum(prc) * 16);
         all_to_all(send_, pc, recv_, prc, 16);
         elba_matrix_stats ms{};
+        // (inline partners in the panel's rows follow the pair-ownership rule of the mirror exchange: requested when that is how the panel will be
+        //  multiplied — the default of create_seed_matrix below; a panel built for exchange = false must be built with panel_inline_exchange(false))
+        engine_->check(elba_set_option(engine_->ctx, "panel_inline", panel_inline_ ? 1 : 0));
         engine_->check(elba_dist_set_panel(engine_->ctx, recv_.p, (int64_t)sum(prc), nreads_total(), (int64_t)nall, row_lo(), row_hi(), &ms));
         ks.instances = (int64_t)sum(sc);
         if (kstats) *kstats = ks;
@@ -156,6 +159,7 @@ public:
     // two ranks is accumulated by ONE of them (elba_seed_matrix_begin) and its mirror image travels to the other in one all-to-all of
     // 32-byte records (the only exchange inside the call; the reference's SUMMA stages have no other counterpart), then elba_seed_matrix_end
     // completes the rows.  exchange = false: no communication, both ranks accumulate the pair.
+    void panel_inline_exchange(bool on) { panel_inline_ = on; }      // before create_kmer_matrix: false if the panel will be multiplied with exchange = false
     elba_overlap_stats create_seed_matrix(bool exchange = true)
     {
         elba_overlap_stats st{};
@@ -207,6 +211,7 @@ public:
         throw std::runtime_error("create_seed_matrix_slots: the mirror exchange did not settle");
     }
     uint64_t mirror_bytes() const { return mirror_bytes_; }
+    bool panel_inline_ = true;
     uint64_t exchange_bytes() const { return exchange_bytes_; }
 
 private:
