@@ -134,7 +134,7 @@ struct Options {
     int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
     int dense_up = 0;           // SpGEMM, dense path: the starting tier's table is sized for (estimate << dense_up) partners
-    int dense_wgs = 11;         // SpGEMM, dense path: workgroups of the 512-slot tier per CU
+    int dense_wgs = 8;          // SpGEMM, dense path: workgroups of the 512-slot tier per CU
     int dk = 2;                 // SpGEMM: rounds of gather trips in flight (1, 2, 4)
     int64_t aln_tiers = 0;      // x-drop register tiers as decimal digits (1248 = all), 0 = default
     int aln_wide_hint = 6, aln_long_hint = 6000;

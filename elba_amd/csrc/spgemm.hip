@@ -770,7 +770,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);
     const bool pay = c.pos16 && !c.opt.no_pay;
     // workgroup sizes grow with the table so that the largest tiers still bring enough waves to a CU (one or two workgroups fit its LDS)
-    const uint32_t blk[NUM_LDS_TIERS] = {128u, 256u, 512u, 1024u, 512u};
+    const uint32_t blk[NUM_LDS_TIERS] = {p.suffix ? 256u : 128u, 256u, 512u, 1024u, 512u};      // (dense path: four wavefronts share a 512-slot table — 32 per CU)
     for (int t = 0; t < NUM_LDS_TIERS; ++t) {
         const uint32_t T = 1u << (LDS_TBITS0 + t);
         p.tier_limit[t] = std::min((T >> 2) * 3, T - blk[t]) - 1;      // a lane overshoots by at most one claim (Table::insert_lds)
@@ -858,7 +858,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
                 hipLaunchKernelGGL(k_classify_direct, dim3(nb), dim3(256), 0, s, p, 0);
             }
             if (p.suffix) {      // (dense matrices: the LDS tiers with 64-bit accumulators run the dense path; p.suffix implies pay)
-                ELBA_DTIER(0, ELBA_LAUNCH_S(128, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u, 0u));
+                ELBA_DTIER(0, ELBA_LAUNCH_S(256, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u, 0u));
                 ELBA_DTIER(1, ELBA_LAUNCH_S(256, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u, 0u));
                 ELBA_DTIER(2, ELBA_LAUNCH_S(512, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u, 0u));
                 ELBA_DTIER(3, ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 0u));

@@ -50,9 +50,9 @@ __device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t row_l
 
 // SUFFIX: the dense path (OvParams::suffix) instead of the general one — an instantiation of its own, so that the general kernel does not carry its registers
 // (second launch bound = wavefronts per SIMD the register allocation must leave room for: 4 keeps two 512-thread workgroups on a CU — at 132
-//  VGPRs instead of 128 the kernel loses one of them and runs twice as long (measured) —, 6 is what the dense path's 11 workgroups per CU need)
+//  VGPRs instead of 128 the kernel loses one of them and runs twice as long (measured) —, 8 is what the dense path's 8 workgroups of 4 wavefronts per CU need)
 template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2, bool SUFFIX = false>
-__global__ __launch_bounds__(BLOCK, SUFFIX ? 6 : (DK == 4 ? 1 : 4)) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits, uint32_t sample)
+__global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits, uint32_t sample)
 {
     static_assert(!PAY || !GLOBAL, "payload accumulators: LDS tiers only");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
