@@ -245,13 +245,18 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
 #ifndef ELBA_DENSE_UN
 #define ELBA_DENSE_UN 2
 #endif
-            constexpr uint32_t NWV = (uint32_t)BLOCK / 64u, UN = ELBA_DENSE_UN;      // pieces per lane in flight
+            constexpr uint32_t UN = ELBA_DENSE_UN;      // pieces per lane in flight
             static_assert(UN % 2 == 0, "windows of two batches");
             const uint32_t jsh = p.j_shift, Sj = 1u << jsh;
             const uint4 *ellq = reinterpret_cast<const uint4 *>(p.a_ellj);
             uint32_t *skid = qj + 2u * RING, *smeta = skid + 64, *spre = skid + 128, *sown = skid + 200;      // per wavefront: k-mer id, first piece | first owned slot << 8 | L << 16, exclusive prefix (65 words), window marks (128)
 #pragma unroll 1
-            for (uint32_t cbase = (tid >> 6) * 64u; cbase < nnz; cbase += NWV * 64u) {
+            for (uint32_t cit = 0;; ++cit) {
+                // (chunks of 64 row entries are drawn from a counter of the row, as on the general path: the numbers of candidates per chunk differ)
+                uint32_t cdraw = 0;
+                if (lane == 0) { const uint32_t a14 = (uint32_t)(uintptr_t)&misc[14], step = 64u; asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(cdraw) : "v"(a14), "v"(step) : "memory"); }
+                const uint32_t cbase = sfirst(cdraw);
+                if (cbase >= nnz) break;
                 const bool valid = cbase + lane < nnz;
                 const uint2 en = valid ? csr2[rs + cbase + lane] : make_uint2(0u, 0u);
                 const uint32_t L = (en.x >> 23) & 127u, idx = (en.x >> 16) & 127u;
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 if (lane == 63) spre[64] = T;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                if (cbase == (tid >> 6) * 64u) { resolve_early(); } else if (cbase == (tid >> 6) * 64u + NWV * 64u) bounds_early();
+                if (cit == 0) { resolve_early(); } else if (cit == 1) bounds_early();
 #pragma unroll 1
                 for (uint32_t base = 0; base < T; base += 64u * UN) {
                     uint4 x[UN];
@@ -348,17 +353,20 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             // loop is the number of 64-byte lines a CU has in flight (profiles/r02_gather64_microbench.txt: 46-52 G random lines/s chip-wide).
             const uint4 ones = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
             constexpr int TR = 2 * DK;
-            constexpr uint32_t FQ = 128, NWV = (uint32_t)BLOCK / 64u, NONE = 0xFFFFFFFFu;
+            constexpr uint32_t FQ = 128, NONE = 0xFFFFFFFFu;
             const uint32_t gw = lane >> lb, EW = 64u >> lb;               // this lane's entry within a wave-trip, entries per wave-trip
             uint32_t *fq = qj + (PAY ? 384u : 256u);                      // FIFO: 3 words per entry (position, k-mer id, rank in the row), behind the product ring
             uint32_t fh = 0, ft = 0;                                      // FIFO positions (uniform)
-            uint32_t cnext = (tid >> 6) * 64u;                            // first row entry of the next chunk to request
             uint2 ea, eb;
             uint32_t ca, cb;                                              // the two chunks on their way (first row entry, or NONE)
             auto load_chunk = [&](uint2 &en, uint32_t &cbase) {
+                // chunks are DRAWN, not dealt: a wavefront whose chunks held few products takes more of them (sequence numbers are the entries' ranks
+                // in the row and the accumulators are order-free: who processes a chunk does not matter; misc[14] is zeroed with the row's other words): 7.26 -> 7.13 ms
+                uint32_t c = 0;
+                if (lane == 0) { const uint32_t a14 = (uint32_t)(uintptr_t)&misc[14], step = 64u; asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(c) : "v"(a14), "v"(step) : "memory"); }
+                const uint32_t cnext = sfirst(c);
                 cbase = cnext < nnz ? cnext : NONE;
                 en = cbase != NONE && cbase + lane < nnz ? csr2[rs + cbase + lane] : make_uint2(0u, 0u);
-                if (cbase != NONE) cnext += NWV * 64u;
             };
             auto consume = [&]() {                                        // chunk `ea` -> FIFO; the chunk after it moves up, the one after that is requested
                 const bool valid = ca + lane < nnz;
