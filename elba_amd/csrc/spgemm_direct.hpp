@@ -37,6 +37,19 @@ __device__ __forceinline__ uint32_t wave_max_scan(uint32_t v)
     return (uint32_t)x;
 }
 
+// sum over the wavefront (uniform result): the same six DPP steps with an add — the __shfl_xor butterfly is six LDS-crossbar round trips
+__device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane(x, 63);
+}
+
 // `half`: which of the two rows of a pair {i, j} accumulates it (the other row receives the mirrored entry).  The smaller row when i + j is
 // even, the larger when it is odd: every row then owns about half of its partners whatever its place in the matrix (owned by the smaller
 // row alone, the first rows would own all of theirs and need tables twice the size).  A partner outside this context's row window is
@@ -497,6 +510,29 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
 
         // ---- one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
+        if (!GLOBAL && T == 4u * (uint32_t)BLOCK) {
+            // (the LDS tiers up to 4096 slots: four slots per lane — all eight table words requested at once, the wavefront's survivors take their
+            //  places in the list with ONE returning atomic: three LDS round trips per row where the loop below makes a dozen)
+            uint32_t jj[4], cc[4], pre[4], tot = 0;
+            uint64_t bal[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { jj[u] = tab.keys[(uint32_t)u * BLOCK + tid]; cc[u] = tab.cnt[(uint32_t)u * BLOCK + tid]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t j = jj[u];
+                if (j != EMPTY) yraw += (p.half == 2u || (p.half && j >= p.row_lo && j < p.row_hi)) ? 2u : 1u;
+                bal[u] = __ballot(j != EMPTY && cc[u] >= 2u);
+                pre[u] = tot; tot += (uint32_t)__popcll(bal[u]);
+            }
+            if (tot) {
+                uint32_t at = 0;
+                if (lane == 0) asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(at) : "v"((uint32_t)(uintptr_t)&misc[3]), "v"(tot) : "memory");
+                at = sfirst(at);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if ((bal[u] >> lane) & 1ull) list16[at + pre[u] + (uint32_t)__popcll(bal[u] & lt)] = (uint16_t)((uint32_t)u * BLOCK + tid);
+            }
+        } else
         for (uint32_t b0 = 0; b0 < T; b0 += BLOCK) {                       // wave-uniform trip count: ballots are safe
             const uint32_t s0 = b0 + tid;
             bool keep = false;
@@ -511,8 +547,8 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             at = __shfl(at, 0, 64) + (uint32_t)__popcll(bal & lt);
             if (keep) { if (GLOBAL) list[at] = s0; else list16[at] = (uint16_t)s0; }
         }
-        yraw = wave_sum_u32(yraw);
-        if (lane == 0 && yraw) atomicAdd(&misc[5], yraw);
+        yraw = wave_sum_dpp(yraw);
+        if (lane == 0 && yraw) lds_add32(&misc[5], yraw);
         if (GLOBAL) __syncthreads(); else lds_barrier();
         ELBA_DSTAMP(4);
         if (tid == 0) {
