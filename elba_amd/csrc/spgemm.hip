@@ -343,9 +343,7 @@ __global__ __launch_bounds__(256) void k_finalize_mid(FinParams p)
         __builtin_amdgcn_wave_barrier();
         {   // exclusive scan of the <= 128 bucket counts: 2 per lane
             const uint32_t c0 = bst[w][2 * lane], c1 = bst[w][2 * lane + 1];
-            uint32_t inc = c0 + c1;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if (lane >= d) inc += o; }
+            const uint32_t inc = wave_add_scan(c0 + c1);
             const uint32_t ex = inc - c0 - c1;
             __builtin_amdgcn_wave_barrier();
             bst[w][2 * lane] = ex; bst[w][2 * lane + 1] = ex + c0;
@@ -367,10 +365,16 @@ __global__ __launch_bounds__(256) void k_finalize_mid(FinParams p)
             const uint32_t c = (uint32_t)(k >> 32);
             const uint32_t b = (uint32_t)(((unsigned long long)c * scale) >> 32);
             const uint32_t lo = bst[w][b], hi = lo + bfl[w][b];
-            uint32_t rank = 0;
-            for (uint32_t x = lo; x < hi; ++x) rank += lkeys[w][x] < k ? 1u : 0u;
             uint4 ra, rb;
-            fin_load(p, low, off, dst, (uint32_t)k, ra, rb);
+            fin_load(p, low, off, dst, (uint32_t)k, ra, rb);      // (requested before the ranking: an L2 round trip that overlaps with it)
+            // rank inside the bucket (~8 keys): the first eight requested at once — a loop with a per-lane trip count is a round trip per key
+            uint32_t rank = 0;
+            uint64_t kk[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) kk[q] = lkeys[w][lo + (uint32_t)q < hi ? lo + (uint32_t)q : lo];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rank += (lo + (uint32_t)q < hi && kk[q] < k) ? 1u : 0u;
+            for (uint32_t x = lo + 8u; x < hi; ++x) rank += lkeys[w][x] < k ? 1u : 0u;
             p.b_col[dst + lo + rank] = c;
             p.b_val[dst + lo + rank] = rec_seed(ra, rb);
         }

@@ -50,6 +50,19 @@ __device__ __forceinline__ uint32_t wave_sum_dpp(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readlane(x, 63);
 }
 
+// inclusive prefix sum over the lanes 0 .. own of a wavefront: six DPP steps (a __shfl_up ladder is six LDS-crossbar round trips)
+__device__ __forceinline__ uint32_t wave_add_scan(uint32_t v)
+{
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111 /* row_shr:1 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112 /* row_shr:2 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114 /* row_shr:4 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118 /* row_shr:8 */, 0xf, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142 /* row_bcast:15 */, 0xa, 0xf, false);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143 /* row_bcast:31 */, 0xc, 0xf, false);
+    return (uint32_t)x;
+}
+
 // `half`: which of the two rows of a pair {i, j} accumulates it (the other row receives the mirrored entry).  The smaller row when i + j is
 // even, the larger when it is odd: every row then owns about half of its partners whatever its place in the matrix (owned by the smaller
 // row alone, the first rows would own all of theirs and need tables twice the size).  A partner outside this context's row window is
@@ -276,10 +289,8 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 const uint32_t w = valid ? L - idx - 1u : 0u;
                 const uint32_t fs = Sj - w, p0 = fs >> 2;                      // first owned slot of the block, the piece that holds it
                 const uint32_t np = w ? (Sj >> 2) - p0 : 0u;
-                uint32_t inc = np;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
-                const uint32_t T = __shfl(inc, 63, 64);
+                const uint32_t inc = wave_add_scan(np);
+                const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
                 dg += (uint32_t)__popcll(__ballot(valid));                     // every entry's product with itself
                 __builtin_amdgcn_wave_barrier();                                // (the previous chunk's look-ups are done)
                 skid[lane] = en.y; smeta[lane] = p0 | fs << 8 | L << 16; spre[lane] = inc - np;
