@@ -502,8 +502,14 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
         for (int u = 0; u < ES_KPT; ++u) {
             if ((uint32_t)u * ES_THREADS + tid < Z) {
                 const uint32_t sb = ((uint32_t)(key[u] >> m.PB) & 0xFFFFu) >> sh, lo = sbstart[sb], hi = sbstart[sb + 1];
+                // (the range's first eight words requested at once: a loop with a per-lane trip count is one LDS round trip per word — ~100 per lane and bucket)
                 uint32_t rank = 0;
-                for (uint32_t x = lo; x < hi; ++x) rank += A[x] < key[u] ? 1u : 0u;
+                uint64_t kk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) kk[q] = A[lo + (uint32_t)q < hi ? lo + (uint32_t)q : lo];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rank += (lo + (uint32_t)q < hi && kk[q] < key[u]) ? 1u : 0u;
+                for (uint32_t x = lo + 8u; x < hi; ++x) rank += A[x] < key[u] ? 1u : 0u;
                 slot[u] = lo + rank;
             }
         }

@@ -327,10 +327,11 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                             const uint32_t c = B + (uint32_t)v2 * 64u + lane;
                             ok[u] = c < T;
                             const uint32_t en1 = v2 ? m1 : m0, lo = ok[u] ? en1 - 1u : 0u;
+                            const uint32_t kl = skid[lo];                       // (with the two words below: one LDS round trip, not a second one under the load's predicate)
                             const uint32_t mt = smeta[lo], pc = (mt & 63u) + (c - spre[lo]), s0 = pc << 2, f0 = (mt >> 8) & 127u;
                             vr[u] = f0 > s0 ? f0 - s0 : 0u;                                      // slots of the piece in front of the first owned one
                             sq[u] = ((cbase + lo) << fbits) + (s0 + (mt >> 16) - Sj);        // sequence number of the piece's first slot: rank of the row entry | place in the column
-                            x[u] = ok[u] ? ellq[((unsigned long long)skid[lo] << (jsh - 2u)) + pc] : make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
+                            x[u] = ok[u] ? ellq[((unsigned long long)kl << (jsh - 2u)) + pc] : make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
                         }
                         __builtin_amdgcn_wave_barrier();
                     }
