@@ -114,6 +114,20 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
         }
     };
     if (tid == 0) { const uint32_t r0 = resolve(draw()); misc[D_NEXT] = r0; if (r0 != NOROW) { misc[D_NEXT + 1] = p.a_rowptr[r0]; misc[D_NEXT + 2] = p.a_rowptr[r0 + 1]; } }
+    // LDS tables are initialised ONCE per workgroup: a row hands its table back clean (the sweep resets the slots it does not list, the staging pass
+    // the ones it has read) and zeroes the row's counters while nobody reads them — no init pass and no init barrier per row (4 % of the kernel)
+    auto init_table = [&]() {
+        if (GLOBAL) return;
+        const uint32_t T0 = 1u << lds_tbits;
+        for (uint32_t s2 = tid; s2 < T0; s2 += BLOCK) {
+            smem[s2] = EMPTY; smem[T0 + s2] = 0;
+            if (PAY) { reinterpret_cast<unsigned long long *>(smem + 2 * T0)[s2] = ~0ull; reinterpret_cast<unsigned long long *>(smem + 2 * T0)[T0 + s2] = 0ull; }
+            else { smem[2 * T0 + s2] = 0xFFFFFFFFu; smem[3 * T0 + s2] = 0; }
+        }
+        if (tid < 16) misc[tid] = 0;
+    };
+    init_table();
+    uint32_t dpar = 0;      // which of misc[0] / misc[1] counts this row's diagonal products (the other one is zeroed for the next row meanwhile)
     __syncthreads();
     uint32_t fb_seen = 0;
     bool fb_settled = false;
@@ -149,6 +163,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 if (!early) nrow = qtried < 8u ? resolve(nidx) : NOROW;
                 if (nrow != NOROW && (!early || nre == 0)) { nrs = p.a_rowptr[nrow]; nre = p.a_rowptr[nrow + 1]; }      // (short rows: fetched here, one exposed round trip)
                 misc[D_NEXT] = nrow; misc[D_NEXT + 1] = nrs; misc[D_NEXT + 2] = nre;
+                if (!GLOBAL) misc[3] = 0;      // (the survivor count of the row before: read in its staging pass, needed clean by this row's sweep — behind the hand-off barrier)
             }
         };
 
@@ -206,12 +221,16 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
         }
         const uint32_t T = tab.size();
         ELBA_DSTAMP(0);
-        for (uint32_t s = tid; s < T; s += BLOCK) {
-            tab.keys[s] = EMPTY; tab.cnt[s] = 0;
-            if (PAY) { tab.vmin[s] = ~0ull; tab.vmax[s] = 0ull; } else { tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
+        if (GLOBAL) {
+            for (uint32_t s = tid; s < T; s += BLOCK) { tab.keys[s] = EMPTY; tab.cnt[s] = 0; tab.smin[s] = 0xFFFFFFFFu; tab.smax[s] = 0; }
+            if (tid < 16) misc[tid] = 0;
+            __syncthreads();
         }
-        if (tid < 16) misc[tid] = 0;
-        if (GLOBAL) __syncthreads(); else lds_barrier();
+        auto reset_slot = [&](uint32_t s2) {      // (LDS tables) back to the state init_table leaves
+            tab.keys[s2] = EMPTY; tab.cnt[s2] = 0;
+            if (PAY) { tab.vmin[s2] = ~0ull; tab.vmax[s2] = 0ull; } else { tab.smin[s2] = 0xFFFFFFFFu; tab.smax[s2] = 0; }
+        };
+        const uint32_t DG = GLOBAL ? 0u : dpar;      // the word of this row's diagonal count
 
         // ---- accumulate -----------------------------------------------------------------------------------------------------
         // Products are COMPACTED before they meet the table.  Of the candidate slots a wavefront looks at, one in five holds a product on
@@ -497,7 +516,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             }
         }
         if (!GLOBAL && tail != head) drain(tail - head);
-        if ((pr | dg) != 0 && lane == 0) { lds_add32(&misc[0], dg); lds_add32(&misc[12], pr); }
+        if ((pr | dg) != 0 && lane == 0) { lds_add32(&misc[DG], dg); lds_add32(&misc[12], pr); }
         ELBA_DSTAMP(2);
         publish_next();
         if (GLOBAL) __syncthreads(); else lds_barrier();
@@ -516,6 +535,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                     *w64(W_TOT_C) += fc; *w64(W_TOT_U) += fu; *w64(W_FB_C) = 0; *w64(W_FB_U) = 0; misc[W_FB_N] = 0;
                 }
             }
+            if (!GLOBAL) { __syncthreads(); init_table(); if (tid < 2) misc[tid] = 0; }      // (every wavefront has left the table: an abandoned row leaves it dirty)
             __syncthreads();
             continue;
         }
@@ -534,6 +554,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 const uint32_t j = jj[u];
                 if (j != EMPTY) yraw += (p.half == 2u || (p.half && j >= p.row_lo && j < p.row_hi)) ? 2u : 1u;
                 bal[u] = __ballot(j != EMPTY && cc[u] >= 2u);
+                if (j != EMPTY && cc[u] < 2u) reset_slot((uint32_t)u * BLOCK + tid);      // (not listed: nobody reads this slot again)
                 pre[u] = tot; tot += (uint32_t)__popcll(bal[u]);
             }
             if (tot) {
@@ -550,7 +571,10 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             bool keep = false;
             if (s0 < T) {
                 const uint32_t j = tab.ld(tab.keys, s0);
-                if (j != EMPTY) { yraw += (p.half == 2u || (p.half && j >= p.row_lo && j < p.row_hi)) ? 2u : 1u; keep = tab.ld(tab.cnt, s0) >= 2; }
+                if (j != EMPTY) {
+                    yraw += (p.half == 2u || (p.half && j >= p.row_lo && j < p.row_hi)) ? 2u : 1u; keep = tab.ld(tab.cnt, s0) >= 2;
+                    if (!GLOBAL && !keep) reset_slot(s0);
+                }
             }
             const uint64_t bal = __ballot(keep);
             if (bal == 0) continue;
@@ -564,7 +588,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
         if (GLOBAL) __syncthreads(); else lds_barrier();
         ELBA_DSTAMP(4);
         if (tid == 0) {
-            const uint32_t dcount = misc[0];
+            const uint32_t dcount = misc[DG];
             const uint32_t ytot = misc[3] + (dcount >= 2 ? 1u : 0u);
             unsigned long long off;
             if (ytot <= chunk_left) { off = chunk_off; chunk_off += ytot; chunk_left -= ytot; }
@@ -589,11 +613,13 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
         }
         lds_barrier();          // row_cnt / row_off stores stay in flight
         ELBA_DSTAMP(5);
-        if (misc[8]) {
+        const uint32_t fits_row = misc[8], ysurv_row = misc[3], dcount_row = misc[DG];
+        if (!GLOBAL && tid < 16 && tid != 3u && (tid < 6u ? tid == (DG ^ 1u) || tid == 5u : tid > 8u)) misc[tid] = 0;      // the counters nobody reads any more (and the NEXT row's diagonal word); misc[3] goes with the hand-off
+        if (fits_row) {
             // ---- all survivors (and the diagonal, by the lane after the last of them) write their staging records ----
             const unsigned long long off = ((unsigned long long)misc[7] << 32) | misc[6];
-            const uint32_t ysurv = misc[3];
-            const uint32_t hasd = misc[0] >= 2 ? 1u : 0u;
+            const uint32_t ysurv = ysurv_row;
+            const uint32_t hasd = dcount_row >= 2 ? 1u : 0u;
             uint32_t nup = 0, mx = 0, nmir = 0;
             auto seed_at = [&](uint32_t a, uint32_t &q, uint32_t &t) {      // sequence number -> the two positions (32-bit accumulators only)
                 const uint2 ce = csr2[rs + (a >> fbits)];
@@ -614,10 +640,11 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                         seed_at(tab.ld(tab.smin, s0), v.q0, v.t0);
                         seed_at(tab.ld(tab.smax, s0), v.q1, v.t1);
                     }
+                    if (!GLOBAL) reset_slot(s0);
                 } else {
                     // B(i,i): first / last product of the fold = the row's first / last entry paired with itself (rows are in (kid, pos)
                     // order, columns in (read, pos) order: the first entry of the row is the first of read i in its column)
-                    v.numshared = (int32_t)misc[0];
+                    v.numshared = (int32_t)dcount_row;
                     const uint2 e0 = csr2[rs], e1 = csr2[rs + nnz - 1u];
                     v.q0 = v.t0 = (p.inl != 0u && (e0.y >> 31) != 0u) ? (e0.x & 0xFFFFu) : (e0.x & pmask);
                     v.q1 = v.t1 = (p.inl != 0u && (e1.y >> 31) != 0u) ? (e1.x & 0xFFFFu) : (e1.x & pmask);
@@ -637,8 +664,11 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             if (nup) lds_add64(w64(W_NUP), (unsigned long long)nup);
             if (nmir) lds_add64(w64(W_MIR), (unsigned long long)nmir);
             if (mx) lds_max32(&misc[W_MX], mx);
+        } else if (!GLOBAL) {
+            for (uint32_t t = tid; t < ysurv_row; t += BLOCK) reset_slot((uint32_t)list16[t]);      // (no room in the staging area: the call is repeated, the table goes back clean all the same)
         }
-        if (GLOBAL) __syncthreads(); else lds_barrier();       // table and misc are re-initialised by the next row; staging stores stay in flight
+        dpar ^= 1u;
+        if (GLOBAL) __syncthreads(); else lds_barrier();       // the next row finds table and counters clean; staging stores stay in flight
         ELBA_DSTAMP(6);
     }
 #ifdef ELBA_PHASE_CLOCK
