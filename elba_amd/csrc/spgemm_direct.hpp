@@ -141,12 +141,19 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
 #define ELBA_DSTAMP(k) do { } while (0)
 #endif
 
+    // The row a workgroup works on is published in one of TWO places, alternately: without a barrier at the start of a row a wavefront may still be
+    // about to read its row when the first wavefront — done with a short row — publishes the next one (the hand-off barrier keeps them within one row
+    // of each other).  (Found by tests/test_gpu_fuzz.py: with one place, two wavefronts disagreed about the current row once in ~20 calls on short reads.)
+    uint32_t npar = 0;
     for (;;) {
-        const uint32_t i = sfirst(misc[D_NEXT]);
+        const uint32_t NB = D_NEXT + 4u * npar;      // where this row was published
+        npar ^= 1u;
+        const uint32_t NBN = D_NEXT + 4u * npar;     // where the next one goes
+        const uint32_t i = sfirst(misc[NB]);
         if (i == NOROW) break;
         uint32_t nidx = 0, nrow = UNRESOLVED, nrs = 0, nre = 0;
         if (tid == 0 && qtried < 8u) nidx = draw();      // the row after this one: the round trip hides behind this row
-        const uint32_t rs = sfirst(misc[D_NEXT + 1]), nnz = sfirst(misc[D_NEXT + 2]) - rs;      // (the row's bounds travel with its id: thread 0 fetched them a row ago)
+        const uint32_t rs = sfirst(misc[NB + 1]), nnz = sfirst(misc[NB + 2]) - rs;      // (the row's bounds travel with its id: thread 0 fetched them a row ago)
         // distinct partners of the row <= min(products, reads); products <= nnz * longest column
         const unsigned long long prod_ub = (unsigned long long)nnz * p.max_col;
         const uint32_t ub_i = prod_ub < (unsigned long long)p.Mcols ? (uint32_t)prod_ub : p.Mcols;
@@ -162,7 +169,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 const bool early = nrow != UNRESOLVED;
                 if (!early) nrow = qtried < 8u ? resolve(nidx) : NOROW;
                 if (nrow != NOROW && (!early || nre == 0)) { nrs = p.a_rowptr[nrow]; nre = p.a_rowptr[nrow + 1]; }      // (short rows: fetched here, one exposed round trip)
-                misc[D_NEXT] = nrow; misc[D_NEXT + 1] = nrs; misc[D_NEXT + 2] = nre;
+                misc[NBN] = nrow; misc[NBN + 1] = nrs; misc[NBN + 2] = nre;
                 if (!GLOBAL) misc[3] = 0;      // (the survivor count of the row before: read in its staging pass, needed clean by this row's sweep — behind the hand-off barrier)
             }
         };
