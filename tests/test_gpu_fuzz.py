@@ -97,15 +97,15 @@ def test_short_rows_many_cold_calls_agree_with_the_oracle():
     """Rows of a few hundred entries finish so quickly that a workgroup's wavefronts can drift a whole phase apart wherever no barrier holds them
     together.  (A version of the numeric kernel without a barrier at the start of a row let one wavefront read the NEXT row's id — published by a
     faster one — once in ~20 calls on this input: two wavefronts then filled one table with the products of two rows.  Single calls pass such a
-    bug nine times out of ten; forty cold calls do not.)  Every call: nnz, products and the statistics of the oracle; B itself on three of them."""
+    bug nine times out of ten; 120 cold calls do not.)  Every call: nnz, products and the statistics of the oracle; B itself on three of them."""
     packed, off, lens, _ = elba_amd.synth_reads(114, 300000, 25.0, 400.0, 100.0, error_rate=0.02, min_len=66)
     o = gu.oracle_run(packed, off, lens, 25, 2, 70, threads=8)
     oB = o.B()
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 25, 2, 70)
     e.set_option("overlap_cold_calls", 1)
-    for it in range(40):
+    for it in range(120):
         gu.assert_stats_equal(st, o)
-        if it % 16 == 0:
+        if it % 40 == 0:
             gu.assert_B_equal(e.export_csr(), oB)
         st = e.create_seed_matrix()
     e.close()
