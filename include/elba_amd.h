@@ -211,7 +211,7 @@ typedef struct {
     const void *b_col;     /* u32[Y] */
     const void *b_val;     /* elba_seed_t[Y] */
     void *stream;          /* hipStream_t the library launches on */
-    uint32_t a_csr_format; /* which of the three encodings of a_csr is active (ELBA_CSR_*) */
+    uint32_t a_csr_format; /* which of the four encodings of a_csr is active (ELBA_CSR_*) */
     uint32_t a_csr_pos_mask; /* position of an a_csr entry = low word & a_csr_pos_mask, whatever the format */
     const void *a_kmers;   /* u64[N]: packed canonical k-mer (first word) of every column, ascending; NULL when A came from triples */
 } elba_device_view;
