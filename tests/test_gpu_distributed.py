@@ -271,3 +271,42 @@ def test_mid_size_sharded_build_equals_the_one_gpu_matrix():
     assert B["Y"] == B1["Y"] == st["nnz"] and (B["rowptr"] == B1["rowptr"]).all() and (B["col"] == B1["col"].astype(np.int64)).all() and (B["val"] == B1["val"]).all()
     prods = [p[1]["products"] for p in parts]
     assert sum(prods) == st["products"] and max(prods) < 1.35 * min(prods)
+
+
+def test_a_panel_with_inline_partners_is_multiplied_with_the_exchange_only():
+    """The panel of a shard carries inline partners when the step will use the mirror exchange (option "panel_inline", set by the driver): they follow
+    the parity rule over ALL rows, which is the exchange's ownership rule.  elba_create_seed_matrix on such a windowed matrix would apply another rule
+    (partners outside the window are kept) and is refused; the driver's create_seed_matrix(exchange=False) reloads the panel without them — both
+    give the oracle's rows."""
+    world = 2
+    packed, off, lens, _ = elba_amd.synth_reads(37, 200000, 15, 4000, 900, error_rate=0.10, min_len=200)
+    o = po.Oracle(17, 2, 8); o.count_and_build(packed, off, lens); o.spgemm(4)
+    oB = o.B()
+    bounds = partition_by_bases(lens, world)
+
+    def body(rank, h):
+        a, b = int(bounds[rank]), int(bounds[rank + 1])
+        sp, so, sl = _shard(packed, off, lens, a, b)
+        d = DistributedOverlap(17, 2, 8, device=0, rank=rank, world=world, dist=h, backend=HipBackend(17, 2, 8, 0))
+        d.set_reads(sp, so, sl, a, bounds)
+        d.build_kmer_matrix()
+        assert d._panel_inline
+        refused = False
+        try:
+            d.be.e.create_seed_matrix()                 # straight to the library: no exchange on a windowed matrix with inline partners
+        except elba_amd.ElbaError:
+            refused = True
+        st = d.create_seed_matrix()                     # with the exchange
+        B1 = d.export_csr()
+        st2 = d.create_seed_matrix(exchange=False)      # the driver reloads the panel without inline partners
+        assert not d._panel_inline
+        out = (B1, d.export_csr(), refused, st["nnz"], st2["nnz"])
+        d.be.e.close()
+        return out
+
+    parts = dist_sim.run_ranks(world, body)
+    assert all(p[2] for p in parts)
+    for which in (0, 1):
+        B = dist_sim.stitch_rows([p[which] for p in parts])
+        assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+    assert sum(p[3] for p in parts) == o.stat("Y") == sum(p[4] for p in parts)
