@@ -564,12 +564,18 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                     // Ctx::csr_hints: an entry whose row accumulates no pair of this column under the parity rule (and occurs in it once) is marked;
                     // the entries of the column this row does accumulate a pair with are counted, the last of them remembered
                     const uint32_t i = (uint32_t)read;
-                    for (uint32_t t = 0; t < L; ++t) {
-                        const uint64_t y = A[h0 + t];
+                    auto look = [&](uint64_t y) {
                         const uint32_t j = (uint32_t)((y & paymask) >> m.pbits);
-                        if (j == i) { ++mult; continue; }
+                        if (j == i) { ++mult; return; }
                         if (((i ^ j) & 1u) ? j < i : j > i) { ++nown; oread = j; opos = y & posmask; }
-                    }
+                    };
+                    // (the column's first four entries requested at once — nine columns in ten are no longer —: a loop with a per-lane trip count is an LDS round trip per entry)
+                    uint64_t y4[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y4[q] = A[h0 + ((uint32_t)q < L ? (uint32_t)q : 0u)];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if ((uint32_t)q < L) look(y4[q]);
+                    for (uint32_t t = 4; t < L; ++t) look(A[h0 + t]);
                     if (mult < 2 && nown == 0) hint = 3;
                 }
                 const uint32_t z = eb + p, kid = kb + kl;
