@@ -168,7 +168,7 @@ struct Ctx {
     DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
     DevBuf csr_words;     // u64[Z] read << (pre_nb + pre_pb) | k-mer id << pre_pb | pos of every entry of a_csc, when pre_words (k_runs_emit -> the CSR build's sort)
-    bool pre_ready = false, pre_consumed = false, pre_words = false, pre_hints = false, pre_hints_done = false, pre_ell_done = false, pre_inline = false; int pre_rs = 0, pre_pbi = 0; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
+    bool pre_ready = false, pre_consumed = false, pre_words = false, pre_hints = false, pre_hints_done = false, pre_ell_done = false, pre_inline = false, pre_inline_pending = false /* the sort keys leave room for inline partners: k_add_hints writes them */; int pre_rs = 0, pre_pbi = 0; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
     // Ownership hints of the SpGEMM, two bits in every a_csr entry (kid << 32 | hint << 30 | pos; positions below 2^30): bit 30 = under the
     // parity rule of owns_pair (spgemm_direct.hpp) this row accumulates NO pair of the entry's column and appears in it once — the column
     // need not be fetched at all, the entry only counts one diagonal product; bit 31 = the same with every partner outside the row window

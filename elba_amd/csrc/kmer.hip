@@ -261,7 +261,7 @@ struct EmitOut {
     uint64_t *rel_kmers; uint32_t *rel_counts, *colptr;
     uint64_t *csc, *csr_words, *kid_of_entry;
     unsigned long long *prod_ctr;     // += sum over reliable runs of length^2 (the SpGEMM's product count, Ctx::A_products)
-    int nb, pb;
+    int nb, pb, rs;                   // CSR sort key: read << rs | kid << (pb + 2) | pos  (rs >= nb + pb + 2)
 };
 __global__ __launch_bounds__(RUN_THREADS) __attribute__((amdgpu_waves_per_eu(6))) void k_runs_emit(RunParams p, EnumParams e, const BlockInfo *block_read, int drop, const uint32_t *off_rel, const uint32_t *off_ent, EmitOut o)
 {
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(RUN_THREADS) __attribute__((amdgpu_waves_per_eu(6))
         const uint32_t pos = (uint32_t)(g - off_lo);
         const uint32_t z = at + dist;
         o.csc[z] = ((uint64_t)lo << 32) | pos;
-        if (o.csr_words) o.csr_words[z] = ((uint64_t)lo << (o.nb + o.pb + 2)) | ((uint64_t)kid << (o.pb + 2)) | pos;      // (hint bits: k_add_hints, matrix.hip)
+        if (o.csr_words) o.csr_words[z] = ((uint64_t)lo << o.rs) | ((uint64_t)kid << (o.pb + 2)) | pos;      // (hint bits: k_add_hints, matrix.hip)
         else o.kid_of_entry[z] = kid;
     };
 #pragma unroll
@@ -473,7 +473,7 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
     c.kid_of_entry.reserve((size_t)(Z + 8) * 8);
     // Packed words with UPPER <= 62: one fused pass writes the columns, the entries' (read, pos) and — when read, k-mer id and position fit
     // one word — the sort keys of the CSR build (k_runs_emit).  Otherwise: heads write payloads and column ids, a second kernel converts.
-    c.pre_ready = false; c.pre_consumed = false; c.pre_hints_done = false; c.pre_ell_done = false;
+    c.pre_ready = false; c.pre_consumed = false; c.pre_hints_done = false; c.pre_ell_done = false; c.pre_inline_pending = false;
     const bool fused = ib && p.upper <= 62 && !c.opt.kmer_unfused;
     if (fused && Z > 0) {
         EnumParams e = make_enum(c);
@@ -492,9 +492,20 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
         o.prod_ctr = c.prod_ctr.as<unsigned long long>();
         o.rel_kmers = c.rel_kmers.as<uint64_t>(); o.rel_counts = c.rel_counts.as<uint32_t>(); o.colptr = c.a_colptr.as<uint32_t>();
         o.csc = c.a_csc.as<uint64_t>(); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); o.nb = nb; o.pb = pb;
+        // inline partners (Ctx::csr_inline), as kmer_msd.hip: the keys leave room for them — read as high as it goes, pbi position bits — and
+        // the hint pass that sees every entry's column anyway (k_add_hints, matrix.hip) writes them, if the matrix turns out to qualify
+        // (padded columns, not dense: UPPER <= 16 guarantees the latter here, where no column has been seen yet)
+        int rs = nb + pb + 2, pbi = 0;
+        bool inl = words && hints && maxpos < 65536 && p.upper <= 16 && !c.opt.no_pay && !c.opt.no_inline && !c.opt.no_symmetry && !c.opt.no_ell && N < (1ll << 31) && mb >= 2;
+        if (inl) {
+            const int rs2 = 63 - mb;
+            pbi = std::min(pb, (rs2 - (mb - 1)) / 2);
+            if (rs2 >= rs && pbi >= 10) rs = rs2; else inl = false;
+        }
+        o.rs = rs;
         if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
         hipLaunchKernelGGL(k_runs_emit, dim3(nblocks), dim3(RUN_THREADS), 0, s, p, e, (const BlockInfo *)c.ws_b.as<BlockInfo>(), drop, (const uint32_t *)off_rel, (const uint32_t *)off_ent, o);
-        c.pre_ready = true; c.pre_words = words; c.pre_hints = hints; c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos; c.pre_rs = nb + pb + 2; c.pre_inline = false;
+        c.pre_ready = true; c.pre_words = words; c.pre_hints = hints; c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos; c.pre_rs = rs; c.pre_inline = false; c.pre_inline_pending = inl; c.pre_pbi = inl ? pbi : 0;
     } else {
     // entry payloads: written straight into a_csc when they are final (pairs: read << 32 | pos), else into scratch and converted
     DevBuf &scratch = c.ws_f;

@@ -77,14 +77,32 @@ __global__ void k_csc_to_csr_words(const uint64_t *kid_keys, int kid_shift, cons
 }
 // hint bits for sort keys that came without them (k_runs_emit, kmer.hip): the entry's k-mer id is in the word, its column in the CSC
 // (one lane per entry; one lane per COLUMN, its entries in registers, was measured: 7.0 ms against 5.2)
-__global__ void k_add_hints(const uint32_t *colptr, const uint64_t *csc, int64_t Z, int nb, int pb, uint64_t *words)
+__global__ void k_add_hints(const uint32_t *colptr, const uint64_t *csc, int64_t Z, int nb, int pb, int rs, int pbi, uint64_t *words)
 {
     const int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (z >= Z) return;
     const uint64_t w = words[z];
     const uint64_t kid = (w >> (pb + 2)) & ((1ull << nb) - 1);
     const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0;
-    if (L <= HINT_MAX_COL) words[z] = w | ((uint64_t)column_hint(csc + c0, L, (uint32_t)(csc[z] >> 32), 0u, 0xFFFFFFFFu) << pb);      // (the window is the whole matrix)
+    if (L > HINT_MAX_COL) return;
+    const uint64_t e = csc[z];
+    const uint32_t i = (uint32_t)(e >> 32);
+    if (pbi) {
+        // Ctx::csr_inline (the whole matrix, parity rule over all rows): exactly one pair of this column accumulated by this row -> the entry carries it
+        uint32_t nown = 0, mult = 0;
+        uint64_t other = 0;
+        for (uint32_t t = 0; t < L; ++t) {
+            const uint64_t y = csc[c0 + t];
+            const uint32_t j = (uint32_t)(y >> 32);
+            if (j == i) { ++mult; continue; }
+            if (((i ^ j) & 1u) ? j < i : j > i) { ++nown; other = y; }
+        }
+        const uint64_t pos = e & 0xFFFFFFFFull, opos = other & 0xFFFFFFFFull;
+        if (mult == 1u && nown == 1u && ((pos | opos) >> pbi) == 0) { words[z] = (1ull << 63) | ((e >> 32) << rs) | (((other >> 32) >> 1) << (2 * pbi)) | (pos << pbi) | opos; return; }
+        if (mult < 2u && nown == 0u) words[z] = w | (3ull << pb);      // (the whole matrix: both hint bits agree)
+        return;
+    }
+    words[z] = w | ((uint64_t)column_hint(csc + c0, L, i, 0u, 0xFFFFFFFFu) << pb);      // (the window is the whole matrix)
 }
 // sorted keys -> CSR entries, and the row pointers with them: entry z opens the rows (read of z - 1, read of z]; launched with Z + 1 lanes,
 // the last of which closes the rows behind the last entry
@@ -331,12 +349,14 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         if (Z > 0 && !have_words)
             hipLaunchKernelGGL(k_csc_to_csr_words, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, kid_keys, kid_shift, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, rs, inl_here ? pbi : 0, w0,
                                hints, wlo, whi, prod_ctr);
+        // (sort keys of the k-mer stage's sort path: they left room for inline partners — whether the matrix qualifies is known here)
+        const bool inl_late = have_words && hints && !c.pre_hints_done && c.pre_inline_pending && c.use_ell && !c.csr_suffix && c.pos16 && !windowed;
         if (Z > 0 && have_words && hints && !c.pre_hints_done)
-            hipLaunchKernelGGL(k_add_hints, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, w0);
+            hipLaunchKernelGGL(k_add_hints, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, rs, inl_late ? pbi : 0, w0);
         const int where = radix_sort_keys(s, w0, w1, Z, rs, rs + mb, c.ws_sort);
         const uint64_t *sorted = where ? w1 : w0;
-        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, rs, mb, (have_words && c.pre_inline) || inl_here ? pbi : 0, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
-        c.csr_inline = (have_words && c.pre_inline) || inl_here;
+        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, nb, pb, rs, mb, (have_words && c.pre_inline) || inl_here || inl_late ? pbi : 0, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
+        c.csr_inline = (have_words && c.pre_inline) || inl_here || inl_late;
         c.csr_inline_window = inl_here && windowed;
     } else {
         ELBA_REQUIRE(!pre || !c.pre_words || c.csr_suffix, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
