@@ -596,3 +596,19 @@ def test_device_resident_triples_in_any_order(knob):
     with pytest.raises(Exception):
         e2.set_kmer_matrix_device(M, N, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
     e.close(); e2.close()
+
+
+@pytest.mark.parametrize("dk", [2, 4])
+def test_more_gather_trips_in_flight_give_the_same_matrix(dk):
+    """The option "dk" (rounds of gather trips a wavefront keeps in flight: 1 by default since most row entries carry their product inline) selects
+    other instantiations of the numeric kernel: B and the statistics must not change."""
+    packed, off, lens, info = elba_amd.synth_reads(61, 200000, 16, 3000, 900, error_rate=0.10, min_len=200)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8, options={"dk": dk})
+    o = gu.oracle_run(packed, off, lens, 17, 2, 8)
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.set_option("overlap_cold_calls", 1)
+    st = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    e.close()
