@@ -3,7 +3,7 @@ set, tiny reads, long reads, the table-overflow matrix (escalation, HBM tier), a
 reproduce the first one (statistics every call, a hash of B every tenth).  How the row-id race of round 3 was narrowed down; run after any change
 to the numeric kernel's synchronisation:  python3 profiles/tools/stress_determinism.py"""
 import sys, os, hashlib
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R); sys.path.insert(0, os.path.join(R, "tests"))
 import numpy as np, elba_amd
 def bhash(B):
     h = hashlib.sha1(); h.update(np.ascontiguousarray(B["rowptr"]).tobytes()); h.update(np.ascontiguousarray(B["col"]).tobytes()); h.update(np.ascontiguousarray(B["val"]).tobytes()); return h.hexdigest()[:12]
