@@ -532,7 +532,7 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         else if (!strcmp(name, "dense_up")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: dense_up is 0..3"); c.opt.dense_up = (int)value; }
         else if (!strcmp(name, "dense_wgs")) { ELBA_REQUIRE(value >= 1 && value <= 16, ELBA_ERR_INVALID_ARG, "set_option: dense_wgs is 1..16"); c.opt.dense_wgs = (int)value; }
         else if (!strcmp(name, "msd_small_cap")) c.opt.msd_small_cap = (int)value;
-        else if (!strcmp(name, "dk")) { ELBA_REQUIRE(value == 1 || value == 2 || value == 4, ELBA_ERR_INVALID_ARG, "set_option: dk is 1, 2 or 4"); c.opt.dk = (int)value; }
+        else if (!strcmp(name, "dk")) { ELBA_REQUIRE(value == -1 || value == 0 || value == 1 || value == 2 || value == 4, ELBA_ERR_INVALID_ARG, "set_option: dk is -1 (chosen per matrix), 0, 1, 2 or 4"); c.opt.dk = (int)value; }
         else if (!strcmp(name, "aln_tiers")) { ELBA_REQUIRE(value >= 0, ELBA_ERR_INVALID_ARG, "set_option: aln_tiers is a string of the digits 1, 2, 4, 8"); c.opt.aln_tiers = value; }
         else if (!strcmp(name, "aln_wide_hint")) c.opt.aln_wide_hint = (int)value;
         else if (!strcmp(name, "aln_long_hint")) c.opt.aln_long_hint = (int)value;

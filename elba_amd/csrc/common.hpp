@@ -135,7 +135,7 @@ struct Options {
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
     int dense_up = 0;           // SpGEMM, dense path: the starting tier's table is sized for (estimate << dense_up) partners
     int dense_wgs = 8;          // SpGEMM, dense path: workgroups of the 512-slot tier per CU
-    int dk = 1;                 // SpGEMM: rounds of gather trips in flight (1, 2, 4) — 1 since the inline partners: few entries of a row still gather, two trips per iteration carry them (6.74 -> 6.52 ms on config 3)
+    int dk = -1;                // SpGEMM: gather trips per iteration of the padded-column loop: 0 = one, 1 = two, 2 = four, 4 = eight; -1 = chosen per matrix (spgemm.hip)
     int64_t aln_tiers = 0;      // x-drop register tiers as decimal digits (1248 = all), 0 = default
     int aln_wide_hint = 6, aln_long_hint = 6000;
 };

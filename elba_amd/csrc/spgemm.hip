@@ -791,6 +791,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
 #define ELBA_ATTR(B, P, D) ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<B, false, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ELBA_ATTR(512, true, 0); ELBA_ATTR(1024, true, 0); ELBA_ATTR(256, false, 0); ELBA_ATTR(512, false, 0); ELBA_ATTR(1024, false, 0);
         ELBA_ATTR(512, true, 1); ELBA_ATTR(512, true, 2); ELBA_ATTR(512, true, 4); ELBA_ATTR(1024, true, 1); ELBA_ATTR(1024, true, 2); ELBA_ATTR(1024, true, 4);
         ELBA_ATTR(256, false, 1); ELBA_ATTR(256, false, 2); ELBA_ATTR(256, false, 4);
         ELBA_ATTR(512, false, 1); ELBA_ATTR(512, false, 2); ELBA_ATTR(512, false, 4); ELBA_ATTR(1024, false, 1); ELBA_ATTR(1024, false, 2); ELBA_ATTR(1024, false, 4);
@@ -843,11 +844,15 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
 #define ELBA_DTIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
 #define ELBA_LAUNCH_D(B, G, P, grid, lds, tier, tb, smp)                                                                                  \
     do {                                                                                                                                  \
-        if (dk == 1) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 1>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));            \
+        if (dk == 0) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 0>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));            \
+        else if (dk == 1) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 1>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));       \
         else if (dk == 4) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 4>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));       \
         else hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 2>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));                    \
     } while (0)
-            const int dk = c.opt.dk;      // rounds of DK trips in flight (tuning knob)
+            // gather trips per iteration of the padded-column loop: 1 (DK = 0) where the rows mostly carry their products inline — columns of 2-3
+            // reads, 15 %-error reads: 6.49 -> 6.27 ms on config 3 —, 2 (DK = 1) otherwise (columns of ~7 reads at 5 % error lose 4 % with one trip);
+            // the option "dk" (0, 1, 2, 4) overrides
+            const int dk = c.opt.dk >= 0 ? c.opt.dk : ((c.csr_inline && c.N > 0 && c.Z < 3 * c.N) ? 0 : 1);
 // (dense path: 32-bit accumulators + seed look-ups for the few survivors; the first tier's grid is a tuning knob: the path waits for memory)
 #define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3((tier) == 0 ? cus * c.opt.dense_wgs : (grid)), dim3(B), (size_t)18 * (1u << (tb)) + 256 + (size_t)((B) / 64) * 2368, s, p, (tier), (tb), (smp))
             if (sampling) {

@@ -403,7 +403,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             // (3) requests the next TR trips' column words, (4) updates the accumulator (LDS only) while the requests land.  What bounds the
             // loop is the number of 64-byte lines a CU has in flight (profiles/r02_gather64_microbench.txt: 46-52 G random lines/s chip-wide).
             const uint4 ones = make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
-            constexpr int TR = 2 * DK;
+            constexpr int TR = DK == 0 ? 1 : 2 * DK;      // (DK = 0: ONE trip per iteration — matrices whose rows mostly carry their products inline)
             constexpr uint32_t FQ = 128, NONE = 0xFFFFFFFFu;
             const uint32_t gw = lane >> lb, EW = 64u >> lb;               // this lane's entry within a wave-trip, entries per wave-trip
             uint32_t *fq = qj + (PAY ? 384u : 256u);                      // FIFO: 3 words per entry (position, k-mer id, rank in the row), behind the product ring

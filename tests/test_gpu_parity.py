@@ -598,9 +598,9 @@ def test_device_resident_triples_in_any_order(knob):
     e.close(); e2.close()
 
 
-@pytest.mark.parametrize("dk", [2, 4])
+@pytest.mark.parametrize("dk", [0, 1, 2, 4])
 def test_more_gather_trips_in_flight_give_the_same_matrix(dk):
-    """The option "dk" (rounds of gather trips a wavefront keeps in flight: 1 by default since most row entries carry their product inline) selects
+    """The option "dk" (gather trips per iteration of the padded-column loop: one, two, four or eight; chosen per matrix by default) selects
     other instantiations of the numeric kernel: B and the statistics must not change."""
     packed, off, lens, info = elba_amd.synth_reads(61, 200000, 16, 3000, 900, error_rate=0.10, min_len=200)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8, options={"dk": dk})
