@@ -124,6 +124,7 @@ struct Options {
     bool panel_inline = false;  // inline partners in the rows of a windowed matrix too (a shard's panel): such a matrix is multiplied with the mirror exchange only
     bool no_inline = false;     // no inline partners in the rows of A (the owner's entry of a two-read column carries the other read: no column fetch)
     bool no_suffix = false;     // dense matrices stay on the general kernel
+    bool no_row_order = false;  // dense matrices: partners are named by their row, not by a label that brings reads of one locus together
     bool kmer_pairs = false;    // (value, payload) pairs through the k-mer sort instead of one packed word
     bool kmer_unfused = false;  // per-head column emission (k_runs<true> + k_instance_entries) instead of k_runs_emit
     bool kmer_msd = false;      // force the two-level partition path on inputs below its size threshold (tests)
@@ -133,7 +134,7 @@ struct Options {
     bool trace = false;         // progress lines on stderr
     int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
-    int dense_up = 0;           // SpGEMM, dense path: the starting tier's table is sized for (estimate << dense_up) partners
+    int dense_up = 1;           // SpGEMM, dense path: the tier its rows start on at least (1: eight wavefronts share a 1024-slot table — 32 per CU as with four on 512 slots, half the load)
     int dense_wgs = 8;          // SpGEMM, dense path: workgroups of the 512-slot tier per CU
     int dk = -1;                // SpGEMM: gather trips per iteration of the padded-column loop: 0 = one, 1 = two, 2 = four, 4 = eight; -1 = chosen per matrix (spgemm.hip)
     int64_t aln_tiers = 0;      // x-drop register tiers as decimal digits (1248 = all), 0 = default
@@ -197,6 +198,7 @@ struct Ctx {
                                                // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid * s_stride, no pointer
     bool use_ell = false;
     DevBuf a_ellj;                             // u32[N << j_shift]: the partner reads of every column, right-aligned in an aligned block of 32 or 64 slots (dense matrices, Ctx::csr_suffix)
+    DevBuf row_order, row_label, row_keys; bool have_row_order = false;      // u32[M] each, dense matrices: the rows sorted by their smallest k-mer id (label -> row) and its inverse (row -> label); a_ellj then names partners by label
     uint32_t j_shift = 5;
     DevBuf col_w0;                             // u8[N]: rotation of every padded column of a dense matrix with a row window (matrix.hip: k_fill_ell)
     uint32_t s_stride = 4, lpc_log2 = 1;       // padded column stride in entries (4, or a multiple of 8: a whole number of 64-byte lines); lanes of the SpGEMM per row entry 2^lpc_log2 >= s_stride / 2

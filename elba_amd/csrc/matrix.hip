@@ -165,7 +165,7 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
 // from kid * Sj — its L entries are the block's last L slots, all ones in front of them.  What a row entry owns (the column behind its own
 // place) is then the tail of the block: one aligned 128-byte segment for every entry but the first ones of columns longer than 33.  Copied
 // from the padded 8-byte store (whatever rotation it carries, k_fill_ell), one lane per 16-byte piece of the output.
-__global__ void k_ell_partners(const uint64_t *ell, const uint32_t *colptr, uint64_t N, uint32_t S, uint32_t jsh, uint32_t *ellj)
+__global__ void k_ell_partners(const uint64_t *ell, const uint32_t *colptr, uint64_t N, uint32_t S, uint32_t jsh, uint32_t *ellj, const uint32_t *label)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, nq = N << (jsh - 2u);
     const uint32_t Sj = 1u << jsh;
@@ -178,6 +178,12 @@ __global__ void k_ell_partners(const uint64_t *ell, const uint32_t *colptr, uint
         v.y = s0 + 1u + L >= Sj ? (uint32_t)(col[s0 + 1u + L - Sj] >> 32) : 0xFFFFFFFFu;
         v.z = s0 + 2u + L >= Sj ? (uint32_t)(col[s0 + 2u + L - Sj] >> 32) : 0xFFFFFFFFu;
         v.w = s0 + 3u + L >= Sj ? (uint32_t)(col[s0 + 3u + L - Sj] >> 32) : 0xFFFFFFFFu;
+        if (label) {      // (partners by their LABEL — Ctx::row_label: reads of one locus get neighbouring labels)
+            if (v.x != 0xFFFFFFFFu) v.x = label[v.x];
+            if (v.y != 0xFFFFFFFFu) v.y = label[v.y];
+            if (v.z != 0xFFFFFFFFu) v.z = label[v.z];
+            if (v.w != 0xFFFFFFFFu) v.w = label[v.w];
+        }
         reinterpret_cast<uint4 *>(ellj)[t] = v;
     }
 }
@@ -207,6 +213,21 @@ __global__ void k_fill_ell(const uint32_t *colptr, const uint64_t *csc, uint64_t
         v.y = j + 1u < L ? csc[c0 + (j + 1u + w0 < L ? j + 1u + w0 : j + 1u + w0 - L)] : ~0ull;
         reinterpret_cast<ulonglong2 *>(ell)[t2] = v;
     }
+}
+
+// dense matrices: smallest k-mer id of the row << 32 | row (an empty row: behind all others); the sorted keys give label -> row and row -> label
+__global__ void k_row_minimizer(const uint32_t *rowptr, const uint64_t *csr, uint32_t M, uint64_t *keys)
+{
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const uint32_t rs = rowptr[r], re = rowptr[r + 1];
+    const uint64_t kid = rs < re ? csr[rs] >> 32 : 0xFFFFFFFFull;      // (dense row entries: k-mer id in the upper word)
+    keys[r] = kid << 32 | r;
+}
+__global__ void k_order_and_labels(const uint64_t *keys, uint32_t M, uint32_t *order, uint32_t *label)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) { const uint32_t r = (uint32_t)keys[t]; order[t] = r; label[r] = t; }
 }
 
 int bits_for(uint64_t maxval)
@@ -327,10 +348,6 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     if (c.csr_suffix) {
         hints = false;
         c.j_shift = c.max_col_nnz <= 32 ? 5u : 6u;      // (use_ell: no column longer than 64)
-        const uint64_t nslots = (uint64_t)N << c.j_shift;
-        c.a_ellj.reserve((size_t)nslots * 4 + 64);
-        hipLaunchKernelGGL(k_ell_partners, dim3((unsigned)std::min<uint64_t>((nslots / 4 + 255) / 256, 1ull << 20)), dim3(256), 0, s, (const uint64_t *)c.a_ell.as<uint64_t>(), (const uint32_t *)c.a_colptr.as<uint32_t>(), (uint64_t)N, c.s_stride,
-                           c.j_shift, c.a_ellj.as<uint32_t>());
     }
     if (!c.csr_suffix && mb + nb + pb + 2 <= 64 && !c.opt.csr_pairs) {
         const bool have_words = pre && c.pre_words && c.pre_nb == nb && c.pre_pb == pb;
@@ -396,6 +413,29 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     {
         ELBA_REQUIRE(c.fbits < 31 && (uint64_t)c.max_row_nnz < (1ull << (32 - c.fbits)), ELBA_ERR_UNSUPPORTED,
                      "row nnz x column nnz exceeds the 32-bit product sequence number");
+    }
+    // Dense matrices: a row meets the same ~100 partners tens of thousands of times, and what its accumulator pays for is every look-up that
+    // does not find its partner in the slot its hash names (it queues for the general insert: profiles/r03_notes.md).  Partner ids are random
+    // — reads that overlap stand anywhere in the input — so the keys of a table collide as random keys do.  Reads of one locus share their
+    // MINIMIZER, the smallest k-mer id of the row (its first entry: rows are in column order): ~20 reads of a 40x set share one.  The rows
+    // sorted by minimizer give every read a LABEL (its rank); a row's partners are then a handful of runs of consecutive labels, which the
+    // multiplicative hash keeps apart (config 5 / 25: 10.1 -> 9.7 ms).  The partner store of the dense path (a_ellj) holds labels, the
+    // table is keyed by them, and the kernel turns the few surviving partners back into rows when it writes them.
+    c.have_row_order = false;
+    if (c.csr_suffix && !c.opt.no_row_order && M > 1 && Z > 0) {
+        c.row_order.reserve((size_t)M * 4 + 64); c.row_label.reserve((size_t)M * 4 + 64);
+        c.row_keys.reserve((size_t)(M + 1) * 16);
+        uint64_t *k0 = c.row_keys.as<uint64_t>(), *k1 = k0 + (M + 1);
+        hipLaunchKernelGGL(k_row_minimizer, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_rowptr.as<uint32_t>(), (const uint64_t *)c.a_csr.as<uint64_t>(), (uint32_t)M, k0);
+        const int where = radix_sort_keys(s, k0, k1, M, 32, 64, c.ws_sort);
+        hipLaunchKernelGGL(k_order_and_labels, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const uint64_t *)(where ? k1 : k0), (uint32_t)M, c.row_order.as<uint32_t>(), c.row_label.as<uint32_t>());
+        c.have_row_order = true;
+    }
+    if (c.csr_suffix) {
+        const uint64_t nslots = (uint64_t)N << c.j_shift;
+        c.a_ellj.reserve((size_t)nslots * 4 + 64);
+        hipLaunchKernelGGL(k_ell_partners, dim3((unsigned)std::min<uint64_t>((nslots / 4 + 255) / 256, 1ull << 20)), dim3(256), 0, s, (const uint64_t *)c.a_ell.as<uint64_t>(), (const uint32_t *)c.a_colptr.as<uint32_t>(), (uint64_t)N, c.s_stride,
+                           c.j_shift, c.a_ellj.as<uint32_t>(), c.have_row_order ? (const uint32_t *)c.row_label.as<uint32_t>() : (const uint32_t *)nullptr);
     }
     c.have_A = true;
     c.have_B = false;

@@ -95,6 +95,7 @@ struct OvParams {
     uint32_t *low_cnt;       // [M+1] zero at entry: mirrored entries per row; its returning atomic hands every mirrored entry its slot
     unsigned long long *row_off;   // [M]
     uint32_t *lists;         // [NUM_TIERS][M]
+    const uint32_t *row_order, *row_label;      // dense path with partners named by label (Ctx::row_order: label -> row, Ctx::row_label: row -> label); or null
     uint32_t *sample_list; uint32_t nsample, sstep;      // cold calls: rows row_lo + q * sstep, q < nsample, are the sample (k_classify_direct, mode 1)
     uint32_t *fin_lists;     // [2][M]
     OvCounters *ctr;
@@ -763,6 +764,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     //  same entries through pos_mask)
     p.suffix = c.csr_suffix && p.half == 1u ? 1u : 0u;
     p.inl = c.csr_inline ? 1u : 0u;
+    p.row_order = p.suffix && c.have_row_order ? c.row_order.as<uint32_t>() : nullptr; p.row_label = p.row_order ? c.row_label.as<uint32_t>() : nullptr;
     c.ov_hints_used = c.ov_hints_used || c.csr_inline;
     // (inline partners follow the parity rule over ALL rows: a whole matrix in one call, or a shard's rows with the mirror exchange; a windowed matrix
     //  multiplied alone keeps every partner outside its window — another rule)
@@ -774,7 +776,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);
     const bool pay = c.pos16 && !c.opt.no_pay;
     // workgroup sizes grow with the table so that the largest tiers still bring enough waves to a CU (one or two workgroups fit its LDS)
-    const uint32_t blk[NUM_LDS_TIERS] = {p.suffix ? 256u : 128u, 256u, 512u, 1024u, 512u};      // (dense path: four wavefronts share a 512-slot table — 32 per CU)
+    const uint32_t blk[NUM_LDS_TIERS] = {p.suffix ? 256u : 128u, p.suffix && p.dense_up >= 1u ? 512u : 256u, p.suffix && p.dense_up >= 2u ? 1024u : 512u, 1024u, 512u};      // (dense path: four wavefronts share a 512-slot table — 32 per CU)
     for (int t = 0; t < NUM_LDS_TIERS; ++t) {
         const uint32_t T = 1u << (LDS_TBITS0 + t);
         p.tier_limit[t] = std::min((T >> 2) * 3, T - blk[t]) - 1;      // a lane overshoots by at most one claim (Table::insert_lds)
@@ -791,6 +793,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
 #define ELBA_ATTR(B, P, D) ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<B, false, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<1024, false, false, 2, true, 11>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         ELBA_ATTR(512, true, 0); ELBA_ATTR(1024, true, 0); ELBA_ATTR(256, false, 0); ELBA_ATTR(512, false, 0); ELBA_ATTR(1024, false, 0);
         ELBA_ATTR(512, true, 1); ELBA_ATTR(512, true, 2); ELBA_ATTR(512, true, 4); ELBA_ATTR(1024, true, 1); ELBA_ATTR(1024, true, 2); ELBA_ATTR(1024, true, 4);
         ELBA_ATTR(256, false, 1); ELBA_ATTR(256, false, 2); ELBA_ATTR(256, false, 4);
@@ -854,9 +857,9 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
             // the option "dk" (0, 1, 2, 4) overrides
             const int dk = c.opt.dk >= 0 ? c.opt.dk : ((c.csr_inline && c.N > 0 && c.Z < 3 * c.N) ? 0 : 1);
 // (dense path: 32-bit accumulators + seed look-ups for the few survivors; the first tier's grid is a tuning knob: the path waits for memory)
-#define ELBA_LAUNCH_S(B, grid, lds, tier, tb, smp) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true>), dim3((tier) == 0 ? cus * c.opt.dense_wgs : (grid)), dim3(B), (size_t)18 * (1u << (tb)) + 256 + (size_t)((B) / 64) * 2368, s, p, (tier), (tb), (smp))
+#define ELBA_LAUNCH_S(B, TBC, grid, lds, tier, tb, smp) hipLaunchKernelGGL((k_spgemm_direct<B, false, false, 2, true, TBC>), dim3((tier) == 0 ? cus * c.opt.dense_wgs : (grid)), dim3(B), (size_t)18 * (1u << (tb)) + 256 + (size_t)((B) / 64) * 2368, s, p, (tier), (tb), (smp))
             if (sampling) {
-                if (p.suffix) ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
+                if (p.suffix) ELBA_LAUNCH_S(1024, 0, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
                 else if (pay) ELBA_LAUNCH_D(1024, false, true, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 1u);
                 else ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 4096 + X(1024, false), 3, 12u, 1u);
                 p.use_feedback = 0;      // the ratio is measured: nothing is forwarded on a prediction any more, nobody touches the hot sums
@@ -867,10 +870,12 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
                 hipLaunchKernelGGL(k_classify_direct, dim3(nb), dim3(256), 0, s, p, 0);
             }
             if (p.suffix) {      // (dense matrices: the LDS tiers with 64-bit accumulators run the dense path; p.suffix implies pay)
-                ELBA_DTIER(0, ELBA_LAUNCH_S(256, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u, 0u));
-                ELBA_DTIER(1, ELBA_LAUNCH_S(256, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u, 0u));
-                ELBA_DTIER(2, ELBA_LAUNCH_S(512, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u, 0u));
-                ELBA_DTIER(3, ELBA_LAUNCH_S(1024, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 0u));
+                ELBA_DTIER(0, ELBA_LAUNCH_S(256, 9, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u, 0u));
+                if (p.dense_up >= 1u) ELBA_DTIER(1, ELBA_LAUNCH_S(512, 10, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u, 0u));      // (eight wavefronts share a 1024-slot table: 32 per CU again, half the load)
+                else ELBA_DTIER(1, ELBA_LAUNCH_S(256, 0, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u, 0u));
+                if (p.dense_up >= 2u) ELBA_DTIER(2, ELBA_LAUNCH_S(1024, 11, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u, 0u));
+                else ELBA_DTIER(2, ELBA_LAUNCH_S(512, 0, cus * 2, (size_t)26 * 2048 + X(512, true), 2, 11u, 0u));
+                ELBA_DTIER(3, ELBA_LAUNCH_S(1024, 0, cus, (size_t)26 * 4096 + X(1024, true), 3, 12u, 0u));
             } else if (pay) {
                 ELBA_DTIER(0, ELBA_LAUNCH_D(128, false, true, cus * 9, (size_t)26 * 512 + X(128, true), 0, 9u, 0u));
                 ELBA_DTIER(1, ELBA_LAUNCH_D(256, false, true, cus * 4, (size_t)26 * 1024 + X(256, true), 1, 10u, 0u));

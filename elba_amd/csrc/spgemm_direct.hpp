@@ -77,7 +77,7 @@ __device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t row_l
 // SUFFIX: the dense path (OvParams::suffix) instead of the general one — an instantiation of its own, so that the general kernel does not carry its registers
 // (second launch bound = wavefronts per SIMD the register allocation must leave room for: 4 keeps two 512-thread workgroups on a CU — at 132
 //  VGPRs instead of 128 the kernel loses one of them and runs twice as long (measured) —, 8 is what the dense path's 8 workgroups of 4 wavefronts per CU need)
-template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2, bool SUFFIX = false>
+template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2, bool SUFFIX = false, int TB = 0>
 __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits, uint32_t sample)
 {
     static_assert(!PAY || !GLOBAL, "payload accumulators: LDS tiers only");
@@ -300,8 +300,17 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             constexpr uint32_t UN = ELBA_DENSE_UN;      // pieces per lane in flight
             static_assert(UN % 2 == 0, "windows of two batches");
             const uint32_t jsh = p.j_shift, Sj = 1u << jsh;
+            const uint32_t il = p.row_label ? p.row_label[i] : i;      // (partners are named by label: OvParams::row_label)
             const uint4 *ellq = reinterpret_cast<const uint4 *>(p.a_ellj);
             uint32_t *skid = qj + 2u * RING, *smeta = skid + 64, *spre = skid + 128, *sown = skid + 200;      // per wavefront: k-mer id, first piece | first owned slot << 8 | L << 16, exclusive prefix (65 words), window marks (128)
+            auto retry = [&](bool pred, uint32_t j, uint32_t sq1) {      // the lanes with pred queue a product for the general insert
+                const uint64_t mm = __ballot(pred);
+                if (mm == 0) return;
+                const uint32_t at = (tail + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u))) & (RING - 1u);
+                if (pred) { qj[at] = j; qs[at] = sq1; }
+                tail += (uint32_t)__popcll(mm);
+                if (tail - head >= 64u) drain(64u);
+            };
 #pragma unroll 1
             for (uint32_t cit = 0;; ++cit) {
                 // (chunks of 64 row entries are drawn from a counter of the row, as on the general path: the numbers of candidates per chunk differ)
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                             const uint32_t en1 = v2 ? m1 : m0, lo = ok[u] ? en1 - 1u : 0u;
                             const uint32_t kl = skid[lo];                       // (with the two words below: one LDS round trip, not a second one under the load's predicate)
                             const uint32_t mt = smeta[lo], pc = (mt & 63u) + (c - spre[lo]), s0 = pc << 2, f0 = (mt >> 8) & 127u;
-                            vr[u] = f0 > s0 ? f0 - s0 : 0u;                                      // slots of the piece in front of the first owned one
+                            vr[u] = !ok[u] ? 4u : (f0 > s0 ? f0 - s0 : 0u);                    // slots of the piece in front of the first owned one (a piece not handed out: all four)
                             sq[u] = ((cbase + lo) << fbits) + (s0 + (mt >> 16) - Sj);        // sequence number of the piece's first slot: rank of the row entry | place in the column
                             x[u] = ok[u] ? ellq[((unsigned long long)kl << (jsh - 2u)) + pc] : make_uint4(EMPTY, EMPTY, EMPTY, EMPTY);
                         }
@@ -363,27 +372,27 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                     }
 #pragma unroll
                     for (int u = 0; u < (int)UN; ++u) {
+                        if (u > 0 && base + 64u * (uint32_t)u >= T) break;      // (the chunk's last pieces fill less than the whole batch: ~270 pieces per chunk, handed out 128 at a time)
                         const uint32_t xs[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-                        uint32_t js[4];
+                        // the read holds the k-mer again behind this entry (rare): that pair of entries counts twice on the diagonal, and the
+                        // other candidates of such a piece take the general insert
+                        const bool anyd = (xs[0] == il && vr[u] == 0u) || (xs[1] == il && vr[u] <= 1u) || (xs[2] == il && vr[u] <= 2u) || (xs[3] == il && vr[u] <= 3u);      // (among the OWNED slots: the slot in front of them is the entry itself)
+                        if (__ballot(anyd)) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const bool own = ok[u] && (uint32_t)r >= vr[u];
-                            const bool dgn = own && xs[r] == i;                 // the read holds the k-mer again behind this entry: the pair of entries counts twice on the diagonal
-                            const uint64_t md = __ballot(dgn);
-                            if (md) dg += 2u * (uint32_t)__popcll(md);
-                            js[r] = own && !dgn ? xs[r] : EMPTY;
+                            for (int r = 0; r < 4; ++r) {
+                                const bool own = anyd && (uint32_t)r >= vr[u];
+                                dg += 2u * (uint32_t)__popcll(__ballot(own && xs[r] == il));
+                                if (!full) retry(own && xs[r] != il, xs[r], sq[u] + (uint32_t)r);
+                            }
+                            if (anyd) vr[u] = 4u;
                         }
                         // four look-ups in flight; what they do not settle (a partner not met before or not in its first slot, a new minimum)
                         // queues for the general insert
-                        const uint32_t miss = full ? 0u : tab.hit4_lds(js, sq[u]);
+                        if (!full) {
+                            bool miss[4];
+                            tab.template hit4m_lds<TB>(xs, sq[u], vr[u], miss);
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const uint64_t mm = __ballot((miss >> r) & 1u);
-                            if (mm == 0) continue;
-                            const uint32_t at = (tail + (uint32_t)__popcll(mm & lt)) & (RING - 1u);
-                            if ((miss >> r) & 1u) { qj[at] = js[r]; qs[at] = sq[u] + (uint32_t)r; }
-                            tail += (uint32_t)__popcll(mm);
-                            if (tail - head >= 64u) drain(64u);
+                            for (int r = 0; r < 4; ++r) retry(miss[r], xs[r], sq[u] + (uint32_t)r);
                         }
                     }
                     if (tab.abandoned()) break;
@@ -549,6 +558,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
 
         // ---- one table sweep: nnz before prune + ballot-compacted survivor list ----
         uint32_t yraw = 0;
+        const bool relabel = SUFFIX && p.row_label != nullptr, whole = p.row_lo == 0u && p.row_hi == p.M;
         if (!GLOBAL && T == 4u * (uint32_t)BLOCK) {
             // (the LDS tiers up to 4096 slots: four slots per lane — all eight table words requested at once, the wavefront's survivors take their
             //  places in the list with ONE returning atomic: three LDS round trips per row where the loop below makes a dozen)
@@ -556,6 +566,10 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             uint64_t bal[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) { jj[u] = tab.keys[(uint32_t)u * BLOCK + tid]; cc[u] = tab.cnt[(uint32_t)u * BLOCK + tid]; }
+            if (SUFFIX && relabel && !whole) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (jj[u] != EMPTY) jj[u] = p.row_order[jj[u]];      // (the window test below wants the row)
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t j = jj[u];
@@ -577,8 +591,9 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             const uint32_t s0 = b0 + tid;
             bool keep = false;
             if (s0 < T) {
-                const uint32_t j = tab.ld(tab.keys, s0);
+                uint32_t j = tab.ld(tab.keys, s0);
                 if (j != EMPTY) {
+                    if (SUFFIX && relabel && !whole) j = p.row_order[j];
                     yraw += (p.half == 2u || (p.half && j >= p.row_lo && j < p.row_hi)) ? 2u : 1u; keep = tab.ld(tab.cnt, s0) >= 2;
                     if (!GLOBAL && !keep) reset_slot(s0);
                 }
@@ -640,6 +655,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 if (t < ysurv) {
                     const uint32_t s0 = GLOBAL ? __hip_atomic_load(&list[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (uint32_t)list16[t];
                     j = tab.ld(tab.keys, s0); v.numshared = (int32_t)tab.ld(tab.cnt, s0);
+                    if (SUFFIX && relabel) j = p.row_order[j];      // (the dense path's table is keyed by labels)
                     if (PAY) {
                         const uint32_t va = (uint32_t)tab.vmin[s0], vb = (uint32_t)tab.vmax[s0];
                         v.q0 = va >> 16; v.t0 = va & 0xFFFFu; v.q1 = vb >> 16; v.t1 = vb & 0xFFFFu;
@@ -739,12 +755,12 @@ __global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
             const uint32_t ub = prod_ub < (unsigned long long)p.Mcols ? (uint32_t)prod_ub : p.Mcols;
             const uint32_t gbits = guaranteed_tbits(ub, p.Mcols);
             uint32_t est = (uint32_t)(((unsigned long long)nnz * prior_q16) >> 16);
-            if (p.suffix) est <<= p.dense_up;      // (dense path: a lower load factor means fewer look-ups that miss their first slot)
             if (est < 64) est = 64;
             int tier = 0;
             while (tier < NUM_LDS_TIERS && est > p.tier_limit[tier]) ++tier;
             const int gt = gbits <= LDS_TBITS0 ? 0 : (int)gbits - LDS_TBITS0;      // never start above the tier that is guaranteed to fit
             if (gt < tier) tier = gt;
+            if (p.suffix && tier < (int)p.dense_up) tier = (int)p.dense_up;      // (dense path: a lower load factor means fewer look-ups that miss their first slot)
             if (tier > NUM_LDS_TIERS) tier = NUM_LDS_TIERS;
             mytier = tier;
         }

@@ -188,6 +188,48 @@ struct Table {
         }
         return miss;
     }
+    // The same look-up with its outcome in flags instead of per-lane bits: slot r of the piece takes part when
+    // r >= vr (the piece's slots in front of the first owned one do not; vr = 4: none), miss[r] = product r was not settled (a
+    // divergent flag lives in a scalar register pair: the caller's ballot of it costs nothing).  TB != 0: the table size is known when the kernel is compiled (T = 1 << TB), the four arrays are then immediate offsets
+    // of ONE address per product (keys | counts | minima | maxima, T words apart).
+    template <int TB>
+    __device__ __forceinline__ void hit4m_lds(const uint32_t (&j)[4], uint32_t s0, uint32_t vr, bool (&miss)[4]) const
+    {
+        typedef __attribute__((address_space(3))) uint32_t lds_u32;
+        const lds_u32 *lk = (const lds_u32 *)keys;
+        const uint32_t T = TB ? (1u << TB) : size(), tb = T * 4;
+        uint32_t slot[4], k[4], m[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) slot[r] = TB ? (j[r] * 0x9E3779B1u) >> (32 - (TB ? TB : 1)) : lds_slot(j[r]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            k[r] = __hip_atomic_load(&lk[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            m[r] = __hip_atomic_load(&lk[slot[r] + 2u * T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        const uint32_t base = (uint32_t)(uintptr_t)keys, one = 1u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t s = s0 + (uint32_t)r;
+            const bool v = (uint32_t)r >= vr;
+            const bool h = v && k[r] == j[r] && s >= m[r];
+            if (h) {
+                if (TB) {
+                    const uint32_t a = base + (slot[r] << 2);
+                    asm volatile("ds_add_u32 %[a], %[one] offset:%[o1]\n\t"
+                                 "ds_max_u32 %[a], %[s] offset:%[o3]\n"
+                                 : : [a] "v"(a), [one] "v"(one), [s] "v"(s), [o1] "n"(4 << TB), [o3] "n"(12 << TB) : "memory");
+                } else {
+                    uint32_t a;
+                    asm volatile("v_lshl_add_u32 %[a], %[slot], 2, %[cb]\n\t"
+                                 "ds_add_u32 %[a], %[one]\n\t"
+                                 "v_add_u32_e32 %[a], %[tb2], %[a]\n\t"
+                                 "ds_max_u32 %[a], %[s]\n"
+                                 : [a] "=&v"(a) : [slot] "v"(slot[r]), [cb] "s"(base + tb), [tb2] "s"(2u * tb), [one] "v"(one), [s] "v"(s) : "memory");
+                }
+            }
+            miss[r] = v && !h;
+        }
+    }
     __device__ __forceinline__ uint32_t lds_slot(uint32_t j) const { return (j * 0x9E3779B1u) >> (32 - tbits); }      // (a 24-bit multiply, v_mul_u32_u24, was measured: no difference)
     __device__ __forceinline__ uint32_t ldrelaxed(const uint32_t *a) const
     {
