@@ -745,10 +745,14 @@ __global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
         const unsigned long long u = p.ctr->fb_ub, cl = p.ctr->fb_claims;
         if (u) { const double r = 1.25 * (double)cl / (double)u * 65536.0; prior_q16 = r < 64.0 ? 64u : (r > 4.0e9 ? 4000000000u : (uint32_t)r); }
     }
-    for (uint32_t i0 = p.row_lo + blockIdx.x * blockDim.x; i0 < p.row_hi; i0 += stride) {      // block-uniform trip count
-        const uint32_t i = i0 + threadIdx.x;
+    // (dense path with labels: the rows are queued in label order — reads of one locus are multiplied at the same time and find each other's
+    //  columns in the caches; the order names every row of the matrix, those outside the window pass)
+    const uint32_t qn = p.row_order ? p.M : p.row_hi - p.row_lo;
+    for (uint32_t q0 = blockIdx.x * blockDim.x; q0 < qn; q0 += stride) {      // block-uniform trip count
+        const uint32_t q = q0 + threadIdx.x;
+        const uint32_t i = q >= qn ? p.row_hi : (p.row_order ? p.row_order[q] : p.row_lo + q);
         int mytier = -1;
-        uint32_t nnz = i < p.row_hi ? p.a_rowptr[i + 1] - p.a_rowptr[i] : 0u;
+        uint32_t nnz = i >= p.row_lo && i < p.row_hi ? p.a_rowptr[i + 1] - p.a_rowptr[i] : 0u;
         if (p.nsample && i < p.row_hi && (i - p.row_lo) % p.sstep == 0 && (i - p.row_lo) / p.sstep < p.nsample) nnz = 0;      // a row of the sample: done already
         if (nnz != 0) {
             const unsigned long long prod_ub = (unsigned long long)nnz * p.max_col;
