@@ -442,14 +442,16 @@ def test_reads_that_hold_a_kmer_twice_and_the_ownership_hints(shape):
         e.close()
 
 
-@pytest.mark.parametrize("knob", [None, "no_suffix"])
+@pytest.mark.parametrize("knob", [None, "no_suffix", "no_row_order", ("dense_up", 0), ("dense_up", 2)])
 def test_dense_columns_take_the_path_of_their_own(knob):
     """Deep, nearly error-free reads with a generous UPPER: columns of ~30 reads, hundreds of products per surviving pair.  Such matrices are
     multiplied by the dense path (pairs owned by the smaller row, the owned candidates of a row entry = its column behind it: DESIGN.md §4.1);
-    the option "no_suffix" keeps them on the general path.  A, B and the statistics equal the oracle's either way, on a cold and a warm call, and
-    a read that holds a k-mer twice (a repeat family) is among them."""
+    the option "no_suffix" keeps them on the general path.  The dense path names partners by LABEL (rank of the read among the reads sorted by their
+    smallest k-mer: reads of one locus get neighbouring labels; "no_row_order" names them by row) and starts its rows on the tier "dense_up" says
+    (1: eight wavefronts on a 1024-slot table).  A, B and the statistics equal the oracle's every way, on a cold and a warm call, and a read that
+    holds a k-mer twice (a repeat family) is among them."""
     packed, off, lens, info = elba_amd.synth_reads(91, 60000, 30, 3000, 600, error_rate=0.01, min_len=500, repeat_families=3, repeat_fraction=0.1, repeat_len=400)
-    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40, options={knob: 1} if knob else None)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40, options=({knob[0]: knob[1]} if isinstance(knob, tuple) else {knob: 1}) if knob else None)
     o = gu.oracle_run(packed, off, lens, 17, 2, 40, threads=8)
     assert ms["max_col_nnz"] > 16 if "max_col_nnz" in ms else True
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
@@ -459,6 +461,18 @@ def test_dense_columns_take_the_path_of_their_own(knob):
     st = e.create_seed_matrix()
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
+    if knob is None:
+        # the same dense matrix handed over as device-resident triples (INTEGRATION.md Option B) gets its labels too
+        import torch
+        Z, M, N = int(ms["nnz"]), int(ms["nrows"]), int(ms["ncols"])
+        dr = torch.empty(Z, dtype=torch.int64, device="cuda"); dc = torch.empty(Z, dtype=torch.int64, device="cuda"); dv = torch.empty(Z, dtype=torch.int32, device="cuda")
+        e.export_triples_device(dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
+        e2 = elba_amd.Engine(17, 2, 40)
+        e2.set_kmer_matrix_device(M, N, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
+        st2 = e2.create_seed_matrix()
+        gu.assert_B_equal(e2.export_csr(), o.B())
+        gu.assert_stats_equal(st2, o)
+        e2.close()
     e.close()
 
 
