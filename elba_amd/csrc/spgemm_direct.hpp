@@ -378,11 +378,12 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                         // other candidates of such a piece take the general insert
                         const bool anyd = (xs[0] == il && vr[u] == 0u) || (xs[1] == il && vr[u] <= 1u) || (xs[2] == il && vr[u] <= 2u) || (xs[3] == il && vr[u] <= 3u);      // (among the OWNED slots: the slot in front of them is the entry itself)
                         if (__ballot(anyd)) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const bool own = anyd && (uint32_t)r >= vr[u];
-                                dg += 2u * (uint32_t)__popcll(__ballot(own && xs[r] == il));
-                                if (!full) retry(own && xs[r] != il, xs[r], sq[u] + (uint32_t)r);
+#pragma unroll 1
+                            for (uint32_t r = 0; r < 4u; ++r) {      // (not unrolled: one copy of the ring's drain, not four, beside the hot path)
+                                const uint32_t xr = r == 0u ? xs[0] : (r == 1u ? xs[1] : (r == 2u ? xs[2] : xs[3]));
+                                const bool own = anyd && r >= vr[u];
+                                dg += 2u * (uint32_t)__popcll(__ballot(own && xr == il));
+                                if (!full) retry(own && xr != il, xr, sq[u] + r);
                             }
                             if (anyd) vr[u] = 4u;
                         }
