@@ -301,7 +301,8 @@ int  elba_get_device_view(elba_ctx *ctx, elba_device_view *view);
 
 /* Run-time options by name (unknown name: ELBA_ERR_INVALID_ARG).  Besides the one below: tuning and A/B switches that never change a
  * result (struct Options in elba_amd/csrc/common.hpp lists them: "no_symmetry", "no_ell", "no_pay", "mir32", "no_hints", "no_sample",
- * "no_suffix", "suffix64", "kmer_pairs", "kmer_unfused", "kmer_no_msd", "csr_pairs", "emit_plain", "trace", "kmer_drop", "dk", "aln_tiers", ...).
+ * "no_suffix", "no_row_order", "dense_up", "dense_wgs", "panel_inline", "kmer_pairs", "kmer_unfused", "kmer_no_msd", "csr_pairs", "emit_plain",
+ * "trace", "kmer_drop", "dk", "aln_tiers", ...).
  * Options that shape A must be set before elba_count_kmers / elba_set_kmer_matrix.
  *   "overlap_cold_calls" (0 | 1): 1 = every elba_create_seed_matrix call forgets what earlier calls on the same matrix learned (the
  *       distinct-partner ratio that picks the starting table tiers, which tiers and column sorts received rows): what a caller that
