@@ -216,12 +216,12 @@ __global__ void k_fill_ell(const uint32_t *colptr, const uint64_t *csc, uint64_t
 }
 
 // dense matrices: smallest k-mer id of the row << 32 | row (an empty row: behind all others); the sorted keys give label -> row and row -> label
-__global__ void k_row_minimizer(const uint32_t *rowptr, const uint64_t *csr, uint32_t M, uint64_t *keys)
+__global__ void k_row_minimizer(const uint32_t *rowptr, const uint64_t *csr, uint32_t M, uint64_t N, uint64_t *keys)
 {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= M) return;
     const uint32_t rs = rowptr[r], re = rowptr[r + 1];
-    const uint64_t kid = rs < re ? csr[rs] >> 32 : 0xFFFFFFFFull;      // (dense row entries: k-mer id in the upper word)
+    const uint64_t kid = rs < re ? csr[rs] >> 32 : N;      // (dense row entries: k-mer id in the upper word)
     keys[r] = kid << 32 | r;
 }
 __global__ void k_order_and_labels(const uint64_t *keys, uint32_t M, uint32_t *order, uint32_t *label)
@@ -426,8 +426,8 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         c.row_order.reserve((size_t)M * 4 + 64); c.row_label.reserve((size_t)M * 4 + 64);
         c.row_keys.reserve((size_t)(M + 1) * 16);
         uint64_t *k0 = c.row_keys.as<uint64_t>(), *k1 = k0 + (M + 1);
-        hipLaunchKernelGGL(k_row_minimizer, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_rowptr.as<uint32_t>(), (const uint64_t *)c.a_csr.as<uint64_t>(), (uint32_t)M, k0);
-        const int where = radix_sort_keys(s, k0, k1, M, 32, 64, c.ws_sort);
+        hipLaunchKernelGGL(k_row_minimizer, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_rowptr.as<uint32_t>(), (const uint64_t *)c.a_csr.as<uint64_t>(), (uint32_t)M, (uint64_t)N, k0);
+        const int where = radix_sort_keys(s, k0, k1, M, 32, 32 + bits_for((uint64_t)(N > 0 ? N : 1)), c.ws_sort);
         hipLaunchKernelGGL(k_order_and_labels, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, s, (const uint64_t *)(where ? k1 : k0), (uint32_t)M, c.row_order.as<uint32_t>(), c.row_label.as<uint32_t>());
         c.have_row_order = true;
     }
