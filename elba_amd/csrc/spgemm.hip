@@ -384,6 +384,84 @@ __global__ __launch_bounds__(256) void k_finalize_mid(FinParams p)
     }
 }
 
+// The same rows when a record is ONE 16-byte word (FinParams::rec16 && mir16: positions below 2^16): the lane that fetched a record KEEPS it
+// in registers (up to 16 of them), only the 4-byte columns go through LDS, and the lane itself ranks and writes its records — k_finalize_mid
+// above fetches every record a second time (by the lane that finds it in its bucket: a dependent HBM / L2 round trip per element of the last loop,
+// eight in a row on the 200 k-read set).
+// (162 VGPRs, three workgroups per CU; a budget of 128 or fewer makes it spill: finalize 3.46 -> 3.61 / 4.7 / 5.9 ms at 4 / 5 / 6 wavefronts per SIMD)
+__global__ __launch_bounds__(256) void k_finalize_mid16(FinParams p)
+{
+    constexpr int NU = (int)(FIN_WAVE2_MAX / 64);
+    __shared__ uint32_t lkeys[4][FIN_WAVE2_MAX];
+    __shared__ uint32_t bst[4][128], bfl[4][128];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const uint4 *mir = reinterpret_cast<const uint4 *>(p.mir);
+    for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
+        const int64_t dst = p.b_rowptr[i];
+        const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
+        if (y <= FIN_WAVE_MAX || y > FIN_WAVE2_MAX) continue;
+        if (dst + (int64_t)y > p.b_cap) continue;
+        const uint32_t low = y - p.row_cnt[i];          // (low_cnt itself has been handed back by k_finalize_wave)
+        const unsigned long long off = p.row_off[i];
+        uint32_t nb = y / 8;
+        nb = nb > 128u ? 128u : nb;
+        const unsigned long long scale = ((unsigned long long)nb << 32) / (p.M > 0 ? p.M : 1u);       // bucket(col) = col * nb / M, monotone in col, < nb
+        bst[w][lane] = 0; bst[w][lane + 64] = 0; bfl[w][lane] = 0; bfl[w][lane + 64] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint4 m[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const uint32_t t = (uint32_t)lane + 64u * u;
+            m[u] = t < y ? (t >= low ? p.rec[off + (t - low)] : mir[dst + t]) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+            if ((uint32_t)lane + 64u * u < y) atomicAdd(&bst[w][(uint32_t)(((unsigned long long)m[u].x * scale) >> 32)], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        {   // exclusive scan of the <= 128 bucket counts: 2 per lane
+            const uint32_t c0 = bst[w][2 * lane], c1 = bst[w][2 * lane + 1];
+            const uint32_t inc = wave_add_scan(c0 + c1);
+            const uint32_t ex = inc - c0 - c1;
+            __builtin_amdgcn_wave_barrier();
+            bst[w][2 * lane] = ex; bst[w][2 * lane + 1] = ex + c0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if ((uint32_t)lane + 64u * u < y) {
+                const uint32_t b = (uint32_t)(((unsigned long long)m[u].x * scale) >> 32);
+                lkeys[w][bst[w][b] + atomicAdd(&bfl[w][b], 1u)] = m[u].x;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            if ((uint32_t)lane + 64u * u < y) {
+                const uint32_t c = m[u].x;
+                const uint32_t b = (uint32_t)(((unsigned long long)c * scale) >> 32);
+                const uint32_t lo = bst[w][b], hi = lo + bfl[w][b];
+                // rank inside the bucket (~8 columns, all distinct): the first eight requested at once
+                uint32_t rank = 0, kk[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) kk[q] = lkeys[w][lo + (uint32_t)q < hi ? lo + (uint32_t)q : lo];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rank += (lo + (uint32_t)q < hi && kk[q] < c) ? 1u : 0u;
+                for (uint32_t x = lo + 8u; x < hi; ++x) rank += lkeys[w][x] < c ? 1u : 0u;
+                p.b_col[dst + lo + rank] = c;
+                p.b_val[dst + lo + rank] = rec_seed(make_uint4(c, 0xFFFFFFFFu, m[u].y & 0xFFFFu, m[u].y >> 16), make_uint4(m[u].z & 0xFFFFu, m[u].z >> 16, m[u].w, 0u));
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // bitonic sort of n2 (power of two) u64 keys held in `keys` (LDS or HBM), one workgroup
 template <int BLOCK>
 __device__ __forceinline__ void bitonic_sort(uint64_t *keys, uint32_t n2)
@@ -644,7 +722,8 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
         if (nremote > 0 && slot == 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((nremote + 255) / 256, (int64_t)cus * 32)), dim3(256), 0, s, f, remote, (unsigned long long)nremote, 0ull);
         if (nremote > 0 && slot != 0) hipLaunchKernelGGL(k_place_remote, dim3((unsigned)std::min<int64_t>((slot + 255) / 256, (int64_t)cus * 4), (unsigned)(nremote / slot)), dim3(256), 0, s, f, remote, (unsigned long long)nremote, (unsigned long long)slot);
         hipLaunchKernelGGL(k_finalize_wave, dim3(nb), dim3(256), 0, s, f);
-        hipLaunchKernelGGL(k_finalize_mid, dim3(nb), dim3(256), 0, s, f);
+        if (f.rec16 && f.mir16) hipLaunchKernelGGL(k_finalize_mid16, dim3(nb), dim3(256), 0, s, f);
+        else hipLaunchKernelGGL(k_finalize_mid, dim3(nb), dim3(256), 0, s, f);
         skipped_sorts = 0;
         if (all_sorts || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
         else skipped_sorts |= 1u;
