@@ -219,6 +219,7 @@ def main():
             if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
                 if tj.get("numeric_source_sha16") == fingerprint:
                     traffic = tj.get("hbm_bytes_per_step_dominant_kernel")
+                    traffic_note = tj.get("note")
                 else:
                     traffic_note = "profiles/traffic.json was measured on other kernel sources (%s, now %s): not quoted" % (tj.get("numeric_source_sha16"), fingerprint)
         except Exception:

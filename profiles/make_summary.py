@@ -61,12 +61,26 @@ def main():
         "FETCH_SIZE_KB_per_step": round(fetch_kb, 1), "WRITE_SIZE_KB_per_step": round(write_kb, 1),
         "TCC_HIT_per_step": round(hit), "TCC_MISS_per_step": round(miss),
         "bytes_per_TCC_miss": round(fetch_kb * 1024 / max(1, miss), 1),
-        # MI355X_MICROARCH.md §HBM: FETCH_SIZE = TCC_EA0_RDREQ x 64 B and under-reports 128-B streaming requests by 2x.  This kernel's
-        # reads are 8-byte gathers and 512-byte row segments; FETCH_SIZE / TCC_MISS ~ 64 B says the requests are 64-B ones, for which
-        # the counter is taken at face value; the x2 figure is given as the upper bound.
-        "hbm_bytes_per_step_dominant_kernel": int(fetch_kb * 1024 + write_kb * 1024),
+        # MI355X_MICROARCH.md §HBM: FETCH_SIZE = TCC_EA0_RDREQ x 64 B and under-reports 128-B streaming requests by 2x.  Calibrated on this
+        # kernel's own widths (profiles/microbench/fetchcal.hip, r03_fetchcal.txt): a coalesced stream is fetched in 128-byte requests at 4, 8
+        # and 16 bytes per lane alike, each tallied at 64 bytes.  The kernel's one coalesced stream is the row entries of A (8 bytes each, read
+        # once per step): FETCH_SIZE misses half of it, 4 bytes per entry, which is added back; its gathers are 64-byte column rows, counted
+        # in full.  The face value and the figure with EVERY read doubled are kept beside the corrected one.
+        "hbm_bytes_per_step_face_value": int(fetch_kb * 1024 + write_kb * 1024),
         "hbm_bytes_per_step_upper_bound_if_128B_requests": int(2 * fetch_kb * 1024 + write_kb * 1024),
     }
+    nnz_a = None
+    for cand in (os.path.join(HERE, "%s_bench_line.json" % tag), os.path.join(os.path.dirname(HERE), "gpurun_out", "%s_bench.json" % tag)):
+        if os.path.exists(cand):
+            try:
+                nnz_a = int(json.loads(open(cand).read().strip().splitlines()[-1])["config"]["nnz_A"])
+                break
+            except Exception:
+                pass
+    out["row_entry_stream_correction_bytes"] = 4 * nnz_a if nnz_a else None
+    out["hbm_bytes_per_step_dominant_kernel"] = out["hbm_bytes_per_step_face_value"] + (4 * nnz_a if nnz_a else 0)
+    out["hbm_bytes_note"] = ("FETCH_SIZE + 4 B per row entry of A (the coalesced row-entry stream is fetched in 128-byte requests tallied at 64: r03_fetchcal.txt) + WRITE_SIZE"
+                             if nnz_a else "face value: nnz(A) of the workload not found, the row-entry stream is NOT corrected")
     if sqd:
         sa, sn = pmc(sqd)
         steps_s = sn[("k_finalize_wave", "SQ_WAVES")] or 1
@@ -84,7 +98,8 @@ def main():
                    "ceiling_G_requests_per_s": [46.5, 52.5]}, open(os.path.join(HERE, "requests.json"), "w"), indent=1)
     json.dump(out, open(os.path.join(HERE, "%s_summary.json" % tag), "w"), indent=1)
     json.dump({"workload": out["workload"], "n_gpus": 1, "numeric_source_sha16": numeric_source_fingerprint(), "source": "%s_summary.json" % tag,
-               "hbm_bytes_per_step_dominant_kernel": out["hbm_bytes_per_step_dominant_kernel"]}, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
+               "hbm_bytes_per_step_dominant_kernel": out["hbm_bytes_per_step_dominant_kernel"], "hbm_bytes_per_step_face_value": out["hbm_bytes_per_step_face_value"],
+               "note": out["hbm_bytes_note"]}, open(os.path.join(HERE, "traffic.json"), "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
