@@ -525,18 +525,39 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         ELBA_REQUIRE(name, ELBA_ERR_INVALID_ARG, "set_option: null name");
         struct { const char *n; bool *b; } flags[] = {
             {"overlap_cold_calls", &c.cold_calls}, {"no_symmetry", &c.opt.no_symmetry}, {"no_ell", &c.opt.no_ell}, {"no_pay", &c.opt.no_pay}, {"mir32", &c.opt.mir32},
-            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_suffix", &c.opt.no_suffix}, {"no_row_order", &c.opt.no_row_order}, {"no_inline", &c.opt.no_inline}, {"panel_inline", &c.opt.panel_inline}, {"kmer_pairs", &c.opt.kmer_pairs},
+            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_slab", &c.opt.no_slab}, {"no_suffix", &c.opt.no_suffix}, {"no_row_order", &c.opt.no_row_order}, {"no_inline", &c.opt.no_inline}, {"panel_inline", &c.opt.panel_inline}, {"kmer_pairs", &c.opt.kmer_pairs},
             {"kmer_unfused", &c.opt.kmer_unfused}, {"kmer_no_msd", &c.opt.kmer_no_msd}, {"kmer_msd", &c.opt.kmer_msd}, {"csr_pairs", &c.opt.csr_pairs}, {"emit_plain", &c.opt.emit_plain}, {"trace", &c.opt.trace}};
         for (auto &f : flags) if (!strcmp(name, f.n)) { *f.b = value != 0; return; }
         if (!strcmp(name, "kmer_drop")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: kmer_drop is 0..3"); c.opt.kmer_drop = (int)value; }
         else if (!strcmp(name, "dense_up")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: dense_up is 0..3"); c.opt.dense_up = (int)value; }
         else if (!strcmp(name, "dense_wgs")) { ELBA_REQUIRE(value >= 1 && value <= 16, ELBA_ERR_INVALID_ARG, "set_option: dense_wgs is 1..16"); c.opt.dense_wgs = (int)value; }
         else if (!strcmp(name, "msd_small_cap")) c.opt.msd_small_cap = (int)value;
+        else if (!strcmp(name, "slab_pct")) { ELBA_REQUIRE(value >= 1 && value <= 1000, ELBA_ERR_INVALID_ARG, "set_option: slab_pct is 1..1000"); c.opt.slab_pct = (int)value; }
+        else if (!strcmp(name, "slab_q16")) { ELBA_REQUIRE(value >= 0 && value < (1ll << 31), ELBA_ERR_INVALID_ARG, "set_option: slab_q16 is 0..2^31"); c.opt.slab_q16 = (int)value; }
         else if (!strcmp(name, "dk")) { ELBA_REQUIRE(value == -1 || value == 0 || value == 1 || value == 2 || value == 4, ELBA_ERR_INVALID_ARG, "set_option: dk is -1 (chosen per matrix), 0, 1, 2 or 4"); c.opt.dk = (int)value; }
         else if (!strcmp(name, "aln_tiers")) { ELBA_REQUIRE(value >= 0, ELBA_ERR_INVALID_ARG, "set_option: aln_tiers is a string of the digits 1, 2, 4, 8"); c.opt.aln_tiers = value; }
         else if (!strcmp(name, "aln_wide_hint")) c.opt.aln_wide_hint = (int)value;
         else if (!strcmp(name, "aln_long_hint")) c.opt.aln_long_hint = (int)value;
         else throw Error{ELBA_ERR_INVALID_ARG, std::string("set_option: unknown option ") + name};
+    });
+}
+
+int elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(name && value, ELBA_ERR_INVALID_ARG, "get_stat: null name or value");
+        if (!strcmp(name, "overlap_mirror_placed")) *value = c.ov_mir_placed;
+        else if (!strcmp(name, "overlap_slab_q16")) *value = (int64_t)c.ov_slab_q16_used;
+        else if (!strcmp(name, "resident_bytes_A")) {
+            int64_t b = 0;
+            if (c.have_A) {
+                b = (int64_t)(c.M + 1) * 4 + (int64_t)(c.N + 1) * 4 + 16 * c.Z;
+                if (c.use_ell) b += 8 * c.N * (int64_t)c.s_stride;
+                if (c.csr_suffix) b += (4ll * c.N) << c.j_shift;
+            }
+            *value = b;
+        }
+        else throw Error{ELBA_ERR_INVALID_ARG, std::string("get_stat: unknown counter ") + name};
     });
 }
 

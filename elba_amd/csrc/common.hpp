@@ -121,6 +121,9 @@ struct Options {
     bool mir32 = false;         // 32-byte staging / mirror records instead of 16-byte words
     bool no_hints = false;      // no ownership bits in the rows of A
     bool no_sample = false;     // a cold call does not compute a sample of rows first
+    bool no_slab = false;       // SpGEMM: mirrored entries wait in the staging area for k_mirror instead of going straight to their row's slab (spgemm.hip: "mirror slabs")
+    int slab_pct = 175;         // SpGEMM: a row's slab holds this many percent of the mirrored entries the measured ratio predicts for it (+ SLAB_PAD)
+    int slab_q16 = 0;           // test hook: slab entries per row entry of A in 1/65536 units, instead of the measured ratio (small matrices take no sample)
     bool panel_inline = false;  // inline partners in the rows of a windowed matrix too (a shard's panel): such a matrix is multiplied with the mirror exchange only
     bool no_inline = false;     // no inline partners in the rows of A (the owner's entry of a two-read column carries the other read: no column fetch)
     bool no_suffix = false;     // dense matrices stay on the general kernel
@@ -253,6 +256,12 @@ struct Ctx {
     int64_t b_cap_entries = 0;      // capacity of b_col/b_val the next overlap call may assume (0 = unknown: size it after the numeric pass)
     uint64_t ov_calls = 0;          // steady-state overlap calls so far (phase events are recorded on every cfg.timing_stride-th)
     uint32_t ov_prior_q16 = 0;      // distinct-partner / product ratio measured by the previous overlap call (x 65536), 0 = unknown
+    uint32_t ov_slab_q16 = 0;       // mirrored entries per row entry of A measured by the previous call on the whole matrix (x 65536, without the margin), 0 = unknown
+    DevBuf ov_slab;                 // uint4[ov_slab_cap]: the rows' mirror slabs (spgemm.hip)
+    int64_t ov_slab_cap = 0;
+    bool ov_slab_on = false;        // the running call has slabs (ov_launch_finalize reads them)
+    uint32_t ov_slab_q16_used = 0;  // diagnostic: the ratio the last call's slabs were sized by (margin included), 0 = none
+    int64_t ov_mir_placed = 0;      // diagnostic: mirrored entries of the last call that did NOT go to a slab (placed by k_mirror)
     // sharded call with mirror exchange (spgemm.hip: stage_seed_matrix_begin / _fill / _end)
     int ov_phase = 0;               // 1: begin has run (numeric done, staged records waiting), end not yet
     int ov_pend_passes = 1; bool ov_pend_timed = false; float ov_pend_ms[3] = {0, 0, 0};

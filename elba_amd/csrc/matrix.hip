@@ -408,6 +408,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     // everything fitted (spgemm.hip repeats the call on the synchronising path otherwise)
     c.ov_tiers_known = false; c.ov_sort_used[0] = c.ov_sort_used[1] = true;
     c.ov_prior_q16 = 0;            // a new matrix: forget the partner/product ratio measured on the previous one
+    c.ov_slab_q16 = 0;
     c.ov_phase = 0;                // ... and a sharded call that was begun on the previous one
     c.max_row_nnz = max_segment_len(c, c.a_rowptr.as<uint32_t>(), M);
     {

@@ -57,13 +57,16 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned int tier_count[NUM_TIERS];   // rows queued per tier (grows while lower tiers escalate rows)
     unsigned int tier_done[NUM_TIERS];    // rows completed per tier
     unsigned int fin_count[2];            // rows needing the workgroup bucket sort / the HBM-bitonic sort of their columns
-    unsigned int pad[2];
-    unsigned long long pad2[14];          // keep the feedback sums on a cache line of their own
+    unsigned int slab_q16;                // mirror slabs: slab entries per row entry of A (x 65536) of this call, 0 = no slabs (k_classify_direct writes it: the sample's rows run before it is known)
+    unsigned int pad;
+    unsigned long long mir_placed;        // diagnostic: mirrored entries k_mirror placed (those that found no room in their row's slab, or had none)
+    unsigned long long pad2[13];          // keep the feedback sums on a cache line of their own
     alignas(128) unsigned int sample_next[8][32];          // the same for the sample queue (below)
     unsigned int sample_count;                             // rows of the sample queue: a few hundred rows computed FIRST on a cold call — their distinct-partner ratio then picks the other rows' tiers
     alignas(128) unsigned int tier_next[NUM_TIERS][8][32]; // plan-free kernel: heads ([..][..][0]) of every tier's 8 interleaved sub-queues, a 128-byte line each
     alignas(128)
     unsigned long long fb_claims, fb_ub;  // feedback: distinct partners found / products, summed over rows done so far in this call
+    unsigned long long fb_surv;           // entries the sample's rows staged (what sizes the mirror slabs)
     OvShard shard[NUM_SHARDS];
     unsigned long long phase[12];          // diagnostic (cfg.flags & 16): shader-clock cycles per kernel phase, summed over workgroups
 };
@@ -102,7 +105,26 @@ struct OvParams {
     StageRec *tmp; unsigned long long tmp_cap;
     uint32_t rec16; uint4 *rec; uint32_t *tick;     // rec16: positions fit 16 bits — a staged entry is ONE 16-byte word (partner, q0 | t0 << 16, q1 | t1 << 16, numshared) in `rec` (the staging area itself) + its mirror ticket in `tick` (behind the tmp_cap words)
     uint32_t *gtable; unsigned long long gstride;   // HBM spill tables: per block 4*gstride u32
+    // mirror slabs (below): null = none.  slab_prior_q16: mirrored entries per row entry measured by an earlier call on this matrix (0: take the sample's);
+    // slab_pct: margin in percent
+    uint4 *slab; unsigned long long slab_cap; uint32_t slab_prior_q16, slab_pct;
 };
+
+// ---- mirror slabs ---------------------------------------------------------------------------------------------------------------------
+// The transposed image of a staged entry (i, j) belongs to row j.  Rounds 1-3 left it in the staging area with a ticket (its place among row
+// j's mirrored entries, drawn from low_cnt[j]) and k_mirror placed it once the row pointers of B were known: 49 M random 16-byte stores behind
+// a dependent random read on BASELINE config 3, 1.9 ms = a fifth of the call, at the memory system's rate for such stores.  The numeric kernel
+// itself is bound by latency, not by memory: it now writes the image STRAIGHT into row j's slab — room for the row's mirrored entries reserved
+// before they are counted, sized from what the call already measures on its sample of rows: survivors per row entry of A (x slab_pct / 100, +
+// SLAB_PAD).  The slab of row j starts at floor((a_rowptr[j] - a_rowptr[row_lo]) x ratio) + SLAB_PAD x (j - row_lo): no table, no scan —
+// two adjacent words of a_rowptr that sit in the L2.  An image whose ticket lies beyond its row's slab (or drawn while no ratio was known: the
+// sample's own rows, small matrices) keeps its ticket and takes the old way (k_mirror); the finalize reads a row's mirrored entry t from the slab
+// when t is inside it and from the mirror area otherwise.  Capacity is a performance matter only, never a correctness limit.
+constexpr uint32_t SLAB_PAD = 16;
+__device__ __forceinline__ uint32_t slab_base(uint32_t rp, uint32_t rp0, uint32_t row_rel, uint32_t q16)
+{
+    return (uint32_t)(((unsigned long long)(rp - rp0) * q16) >> 16) + SLAB_PAD * row_rel;
+}
 
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v)
 {
@@ -136,10 +158,27 @@ struct FinParams {
     long long b_cap;         // capacity of b_col / b_val in entries: rows that would not fit are left out (the host regrows and reruns)
     uint32_t mir16;          // positions fit 16 bits: a mirrored entry is ONE 16-byte word (i, q0 | t0 << 16, q1 | t1 << 16, numshared) — one store
                              // request per scattered entry instead of two, half the bytes read back
+    const uint32_t *a_rowptr; uint4 *slab;      // mirror slabs (above; mir16 records): null = none
 };
 
+// this call's slabs: ratio (0 = none) and the first row entry of the window
+struct SlabCall { uint32_t q16, rp0; };
+__device__ __forceinline__ SlabCall slab_call(const FinParams &p)
+{
+    SlabCall s{0u, 0u};
+    if (p.slab) { s.q16 = p.ctr->slab_q16; if (s.q16) s.rp0 = p.a_rowptr[p.row_lo]; }
+    return s;
+}
+// row i's slab: first entry and capacity
+__device__ __forceinline__ uint2 slab_row(const FinParams &p, const SlabCall &s, uint32_t i)
+{
+    if (!s.q16) return make_uint2(0u, 0u);
+    const uint32_t b0 = slab_base(p.a_rowptr[i], s.rp0, i - p.row_lo, s.q16), b1 = slab_base(p.a_rowptr[i + 1], s.rp0, i + 1 - p.row_lo, s.q16);
+    return make_uint2(b0, b1 - b0);
+}
+
 // entry t of a row's extent: mirrored (the first `low`) or staged by the row itself; as the two halves of a staged record
-__device__ __forceinline__ void fin_load(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t, uint4 &a, uint4 &b)
+__device__ __forceinline__ void fin_load(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t, uint4 &a, uint4 &b, uint2 sl = make_uint2(0u, 0u))
 {
     if (t >= low) {
         if (p.rec16) {
@@ -148,14 +187,14 @@ __device__ __forceinline__ void fin_load(const FinParams &p, uint32_t low, unsig
         } else { const StageRec *r = &p.tmp[off + (t - low)]; a = r->a; b = r->b; }
     }
     else if (p.mir16) {
-        const uint4 m = reinterpret_cast<const uint4 *>(p.mir)[dst + t];
+        const uint4 m = t < sl.y ? p.slab[sl.x + t] : reinterpret_cast<const uint4 *>(p.mir)[dst + t];
         a = make_uint4(m.x, 0xFFFFFFFFu, m.y & 0xFFFFu, m.y >> 16); b = make_uint4(m.z & 0xFFFFu, m.z >> 16, m.w, 0u);
     } else { const StageRec *r = &p.mir[dst + t]; a = r->a; b = r->b; }
 }
-__device__ __forceinline__ uint32_t fin_col(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t)
+__device__ __forceinline__ uint32_t fin_col(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t, uint2 sl = make_uint2(0u, 0u))
 {
     if (t >= low) return p.rec16 ? p.rec[off + (t - low)].x : p.tmp[off + (t - low)].a.x;
-    return p.mir16 ? reinterpret_cast<const uint4 *>(p.mir)[dst + t].x : p.mir[dst + t].a.x;
+    return p.mir16 ? (t < sl.y ? p.slab[sl.x + t].x : reinterpret_cast<const uint4 *>(p.mir)[dst + t].x) : p.mir[dst + t].a.x;
 }
 __device__ __forceinline__ elba_seed_t rec_seed(const uint4 a, const uint4 b)
 {
@@ -225,6 +264,8 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const SlabCall sc = slab_call(p);
+    uint32_t placed = 0;
     for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
         const uint32_t own = p.row_cnt[i];
         const unsigned long long off = p.row_off[i];
@@ -240,9 +281,16 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
                 const uint32_t tk = p.tick[off + t];
                 if (tk == 0xFFFFFFFFu) continue;
                 const uint4 r = p.rec[off + t];
+                const uint4 img = make_uint4(i, (r.y >> 16) | (r.y << 16), (r.z >> 16) | (r.z << 16), r.w);
+                ++placed;
+                if (sc.q16 && p.mir16) {      // (a ticket drawn before the ratio was known — the sample's rows — may still lie inside its row's slab)
+                    const uint2 sl = slab_row(p, sc, r.x);
+                    if (tk < sl.y) { p.slab[sl.x + tk] = img; continue; }
+                }
                 const int64_t at = p.b_rowptr[r.x] + (int64_t)tk;
                 if (at >= p.b_cap) continue;
-                reinterpret_cast<uint4 *>(p.mir)[at] = make_uint4(i, (r.y >> 16) | (r.y << 16), (r.z >> 16) | (r.z << 16), r.w);
+                if (p.mir16) reinterpret_cast<uint4 *>(p.mir)[at] = img;
+                else { p.mir[at].a = make_uint4(i, 0xFFFFFFFFu, img.y & 0xFFFFu, img.y >> 16); p.mir[at].b = make_uint4(img.z & 0xFFFFu, img.z >> 16, img.w, 0u); }
             }
             continue;
         }
@@ -259,6 +307,8 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
             }
         }
     }
+    placed = wave_sum_u32(placed);
+    if (lane == 0 && placed) atomicAdd(&p.ctr->mir_placed, (unsigned long long)placed);
 }
 
 // Rows of up to FIN_WAVE_MAX entries: one wavefront per row; the row's columns are staged in LDS and every lane ranks its (up to 4)
@@ -271,6 +321,7 @@ __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     uint32_t *cols = colsm[w];
+    const SlabCall sc = slab_call(p);
     for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
         const int64_t dst = p.b_rowptr[i];
         const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
@@ -279,6 +330,7 @@ __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
         if (y == 0 || y > FIN_WAVE_MAX) continue;
         if (dst + (int64_t)y > p.b_cap) continue;
         const unsigned long long off = p.row_off[i];
+        const uint2 sl = slab_row(p, sc, i);
         uint32_t mine[4];
         uint4 ra[4], rb[4];
 #pragma unroll
@@ -286,7 +338,7 @@ __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
             const uint32_t t = (uint32_t)lane + 64u * u;
             mine[u] = 0xFFFFFFFFu;
             if (t < y) {
-                fin_load(p, low, off, dst, t, ra[u], rb[u]);
+                fin_load(p, low, off, dst, t, ra[u], rb[u], sl);
                 mine[u] = ra[u].x;
                 cols[t] = mine[u];
             }
@@ -318,6 +370,7 @@ __global__ __launch_bounds__(256) void k_finalize_mid(FinParams p)
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+    const SlabCall sc = slab_call(p);
     for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {      // (no queue: 200 k rows drawing slots from one counter cost more than looking at every row's length)
         const int64_t dst = p.b_rowptr[i];
         const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
@@ -325,6 +378,7 @@ __global__ __launch_bounds__(256) void k_finalize_mid(FinParams p)
         if (dst + (int64_t)y > p.b_cap) continue;
         const uint32_t low = y - p.row_cnt[i];          // (low_cnt itself has been handed back by k_finalize_wave)
         const unsigned long long off = p.row_off[i];
+        const uint2 sl = slab_row(p, sc, i);
         uint32_t nb = y / 8;
         nb = nb > 128u ? 128u : nb;
         const unsigned long long scale = ((unsigned long long)nb << 32) / (p.M > 0 ? p.M : 1u);       // bucket(col) = col * nb / M, monotone in col, < nb
@@ -335,7 +389,7 @@ __global__ __launch_bounds__(256) void k_finalize_mid(FinParams p)
 #pragma unroll
         for (int u = 0; u < (int)(FIN_WAVE2_MAX / 64); ++u) {
             const uint32_t t = (uint32_t)lane + 64u * u;
-            col[u] = t < y ? fin_col(p, low, off, dst, t) : 0u;
+            col[u] = t < y ? fin_col(p, low, off, dst, t, sl) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < (int)(FIN_WAVE2_MAX / 64); ++u)
@@ -367,7 +421,7 @@ __global__ __launch_bounds__(256) void k_finalize_mid(FinParams p)
             const uint32_t b = (uint32_t)(((unsigned long long)c * scale) >> 32);
             const uint32_t lo = bst[w][b], hi = lo + bfl[w][b];
             uint4 ra, rb;
-            fin_load(p, low, off, dst, (uint32_t)k, ra, rb);      // (requested before the ranking: an L2 round trip that overlaps with it)
+            fin_load(p, low, off, dst, (uint32_t)k, ra, rb, sl);      // (requested before the ranking: an L2 round trip that overlaps with it)
             // rank inside the bucket (~8 keys): the first eight requested at once — a loop with a per-lane trip count is a round trip per key
             uint32_t rank = 0;
             uint64_t kk[8];
@@ -399,6 +453,7 @@ __global__ __launch_bounds__(256, 3) void k_finalize_mid16(FinParams p)
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
     const uint4 *mir = reinterpret_cast<const uint4 *>(p.mir);
+    const SlabCall sc = slab_call(p);
     for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
         const int64_t dst = p.b_rowptr[i];
         const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
@@ -406,6 +461,8 @@ __global__ __launch_bounds__(256, 3) void k_finalize_mid16(FinParams p)
         if (dst + (int64_t)y > p.b_cap) continue;
         const uint32_t low = y - p.row_cnt[i];          // (low_cnt itself has been handed back by k_finalize_wave)
         const unsigned long long off = p.row_off[i];
+        uint2 sl = slab_row(p, sc, i);
+        sl = make_uint2(sfirst(sl.x), sfirst(sl.y));      // (the row is the wavefront's: scalar registers — the kernel sits two VGPRs below its budget)
         uint32_t nb = y / 8;
         nb = nb > 128u ? 128u : nb;
         const unsigned long long scale = ((unsigned long long)nb << 32) / (p.M > 0 ? p.M : 1u);       // bucket(col) = col * nb / M, monotone in col, < nb
@@ -416,7 +473,7 @@ __global__ __launch_bounds__(256, 3) void k_finalize_mid16(FinParams p)
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const uint32_t t = (uint32_t)lane + 64u * u;
-            m[u] = t < y ? (t >= low ? p.rec[off + (t - low)] : mir[dst + t]) : make_uint4(0u, 0u, 0u, 0u);
+            m[u] = t < y ? (t >= low ? p.rec[off + (t - low)] : (t < sl.y ? p.slab[sl.x + t] : mir[dst + t])) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u)
@@ -521,6 +578,7 @@ __global__ __launch_bounds__(256) void k_finalize_bucket(FinParams p)
         if (dst + (int64_t)y > p.b_cap) continue;
         const uint32_t low = y - p.row_cnt[i];          // (low_cnt itself may already have been handed back by k_finalize_wave)
         const unsigned long long off = p.row_off[i];
+        const uint2 sl = slab_row(p, slab_call(p), i);
         uint32_t nb = y / 8;
         nb = nb < 1 ? 1u : (nb > FIN_BUCKETS ? FIN_BUCKETS : nb);
         // bucket(col) = col * nb / M without a division per element: col * floor(nb * 2^32 / M) >> 32  (monotone in col, < nb)
@@ -529,7 +587,7 @@ __global__ __launch_bounds__(256) void k_finalize_bucket(FinParams p)
         __syncthreads();
         const unsigned long long scale = scale_s;
         for (uint32_t t = tid; t < y; t += 256) {
-            const uint32_t col = fin_col(p, low, off, dst, t);
+            const uint32_t col = fin_col(p, low, off, dst, t, sl);
             atomicAdd(&bstart[(uint32_t)(((unsigned long long)col * scale) >> 32)], 1u);
         }
         __syncthreads();
@@ -546,7 +604,7 @@ __global__ __launch_bounds__(256) void k_finalize_bucket(FinParams p)
         }
         __syncthreads();
         for (uint32_t t = tid; t < y; t += 256) {
-            const uint32_t col = fin_col(p, low, off, dst, t);
+            const uint32_t col = fin_col(p, low, off, dst, t, sl);
             const uint32_t b = (uint32_t)(((unsigned long long)col * scale) >> 32);
             lkeys[bstart[b] + atomicAdd(&bfill[b], 1u)] = ((uint64_t)col << 32) | t;
         }
@@ -559,7 +617,7 @@ __global__ __launch_bounds__(256) void k_finalize_bucket(FinParams p)
             uint32_t rank = 0;
             for (uint32_t x = lo; x < hi; ++x) rank += lkeys[x] < k ? 1u : 0u;
             uint4 ra, rb;
-            fin_load(p, low, off, dst, (uint32_t)k, ra, rb);
+            fin_load(p, low, off, dst, (uint32_t)k, ra, rb, sl);
             p.b_col[dst + lo + rank] = col;
             p.b_val[dst + lo + rank] = rec_seed(ra, rb);
         }
@@ -579,17 +637,18 @@ __global__ __launch_bounds__(256) void k_finalize_huge(FinParams p)
         if (dst + (int64_t)y > p.b_cap) continue;
         const uint32_t low = y - p.row_cnt[i];
         const unsigned long long off = p.row_off[i];
+        const uint2 sl = slab_row(p, slab_call(p), i);
         uint32_t n2 = 1;
         while (n2 < y) n2 <<= 1;
         for (uint32_t t = threadIdx.x; t < n2; t += 256)
-            keys[t] = t < y ? (((uint64_t)fin_col(p, low, off, dst, t) << 32) | t) : ~0ull;
+            keys[t] = t < y ? (((uint64_t)fin_col(p, low, off, dst, t, sl) << 32) | t) : ~0ull;
         __syncthreads();
         bitonic_sort<256>(keys, n2);
         for (uint32_t t = threadIdx.x; t < y; t += 256) {
             const uint64_t k = keys[t];
             p.b_col[dst + t] = (uint32_t)(k >> 32);
             uint4 ra, rb;
-            fin_load(p, low, off, dst, (uint32_t)k, ra, rb);
+            fin_load(p, low, off, dst, (uint32_t)k, ra, rb, sl);
             p.b_val[dst + t] = rec_seed(ra, rb);
         }
         __syncthreads();
@@ -722,6 +781,7 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
     f.b_cap = c.b_cap_entries;
     f.mir16 = mir16 ? 1u : 0u;
     f.rec16 = c.ov_rec16 ? 1u : 0u; f.rec = c.ov_tmp.as<uint4>(); f.tick = reinterpret_cast<const uint32_t *>(c.ov_tmp.as<char>() + (size_t)c.ov_tmp_cap * 16);
+    f.a_rowptr = c.a_rowptr.as<uint32_t>(); f.slab = (half == 1u && mir16 && c.ov_slab_on) ? c.ov_slab.as<uint4>() : nullptr;
     const int gblocks = 32;
     uint64_t sstride = 2;
     while (sstride < (uint64_t)M) sstride <<= 1;
@@ -774,6 +834,12 @@ static void ov_finish_stats(Ctx &c, OvCounters &hc, elba_overlap_stats &st, int 
     for (int t = 0; t < NUM_TIERS; ++t) c.ov_tier_used[t] = hc.tier_count[t] > 0;
     c.ov_tiers_known = true;
     c.ov_sort_used[0] = hc.fin_count[0] > 0; c.ov_sort_used[1] = hc.fin_count[1] > 0;
+    c.ov_mir_placed = (int64_t)hc.mir_placed;
+    c.ov_slab_q16_used = hc.slab_q16;
+    if (c.row_lo == 0 && (c.row_hi < 0 || c.row_hi == M) && Z > 0 && extra_nnz == 0) {      // mirrored entries per row entry of A, for the next call's slabs (a hint, like the ratio below)
+        const double r = 0.5 * (double)((int64_t)hc.nnz - (int64_t)hc.ndiag) / (double)Z * 65536.0;
+        c.ov_slab_q16 = r < 1.0 ? 1u : (r > 4.0e9 ? 4000000000u : (uint32_t)r);
+    }
     if (fbu > 0) {   // the measured distinct-partner / row-entry ratio (+25 %) picks the next call's starting tiers
         double r = 1.25 * (double)fbc / (double)fbu * 65536.0;
         const uint32_t q = r < 64.0 ? 64u : (r > 4.0e9 ? 4000000000u : (uint32_t)r);
@@ -815,7 +881,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     c.have_B = false;
     c.ov_phase = 0;      // (a begun sharded call that was never ended is abandoned here: its staged records are about to be overwritten)
     ELBA_REQUIRE(M < 0xFFFFFF00ll, ELBA_ERR_UNSUPPORTED, "read ids beyond 2^32 - 256 (the top of the id range marks empty slots and idle lanes)");
-    if (c.cold_calls) { c.ov_prior_q16 = 0; c.ov_tiers_known = false; c.ov_sort_used[0] = c.ov_sort_used[1] = true; }
+    if (c.cold_calls) { c.ov_prior_q16 = 0; c.ov_slab_q16 = 0; c.ov_tiers_known = false; c.ov_sort_used[0] = c.ov_sort_used[1] = true; }
 
     c.ov_rowcnt.reserve((size_t)(M + 2) * 4);
     c.ov_rowoff.reserve((size_t)(M + 1) * 8);
@@ -921,6 +987,19 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         c.b_col.reserve((size_t)(c.b_cap_entries + 1) * 4);
         c.b_val.reserve((size_t)(c.b_cap_entries + 1) * sizeof(elba_seed_t));
         if (half) c.ov_mir.reserve((size_t)(c.b_cap_entries + 1) * (mir16 ? 16 : sizeof(StageRec)));
+        // mirror slabs (above): one call on the window, 16-byte records, a ratio to size them by — a sample of this call's rows, an earlier call's
+        // measurement, or the test hook
+        p.use_feedback = c.ov_prior_q16 ? 0u : 1u;      // (a repeated pass starts like the first)
+        const bool sampling = p.use_feedback && nrows >= 8192 && !c.opt.no_sample;
+        p.slab_prior_q16 = c.opt.slab_q16 > 0 ? (uint32_t)c.opt.slab_q16 : c.ov_slab_q16;
+        p.slab_pct = (uint32_t)c.opt.slab_pct;
+        c.ov_slab_on = phase == 0 && half && mir16 && !c.opt.no_slab && nrows > 0 && (sampling || p.slab_prior_q16 != 0u);
+        p.slab = nullptr; p.slab_cap = 0;
+        if (c.ov_slab_on) {
+            c.ov_slab_cap = std::min<int64_t>(c.ov_tmp_cap + (int64_t)SLAB_PAD * nrows, 0xFFFF0000ll);
+            c.ov_slab.reserve((size_t)c.ov_slab_cap * 16);
+            p.slab = c.ov_slab.as<uint4>(); p.slab_cap = (unsigned long long)c.ov_slab_cap;
+        }
 
         if (timed) c.ov_marks.mark(0, s);
         // the ticket counters come back clean from a call that ran to its end (k_finalize_wave); otherwise zero them here
@@ -931,8 +1010,6 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         // A cold call on a matrix of some size computes a SAMPLE of its rows first (every sstep-th row, on the 4096-slot tier): what they find
         // — distinct partners per row entry — picks the starting tier of all the others, instead of a guess that sends most rows of a
         // 15 %-error read set to a tier too small (an abandoned attempt or a forwarding each: 0.9 ms of a 14.7 ms call on the 200 k-read set).
-        p.use_feedback = c.ov_prior_q16 ? 0u : 1u;      // (a repeated pass starts like the first)
-        const bool sampling = p.use_feedback && nrows >= 8192 && !c.opt.no_sample;
         p.nsample = sampling ? 256u : 0u; p.sstep = sampling ? (uint32_t)(nrows / 256) : 1u;
         c.ov_sample.reserve(256 * 4);
         p.sample_list = c.ov_sample.as<uint32_t>();

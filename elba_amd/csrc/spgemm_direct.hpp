@@ -91,6 +91,10 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
     const bool ell = p.a_ell != nullptr;
     const uint32_t hmask = p.hint_mask, pmask = p.pos_mask;      // ownership hints in the row entries (Ctx::csr_hints): skip bit of this call's mode, position bits
     const uint2 *csr2 = reinterpret_cast<const uint2 *>(p.a_csr);      // .x = position in the read, .y = k-mer id
+    // mirror slabs (spgemm.hip): the ratio k_classify_direct settled for this call (0: none — the sample's rows run before it is known) and the
+    // window's first row entry; both scalar
+    const uint32_t slab_q = (p.slab != nullptr && !sample) ? sfirst(p.ctr->slab_q16) : 0u;
+    const uint32_t slab_rp0 = slab_q ? sfirst(p.a_rowptr[p.row_lo]) : 0u;
     unsigned long long chunk_off = 0;
     uint32_t chunk_left = 0;
     auto w64 = [&](uint32_t k) { return reinterpret_cast<unsigned long long *>(&misc[k]); };
@@ -675,7 +679,13 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 }
                 // the partner's row gets the mirrored entry: draw its slot there now; k_mirror places it once the row pointers are known
                 uint32_t tick = 0xFFFFFFFFu;
-                if (p.half && j != i && j >= p.row_lo && j < p.row_hi) { tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir; }
+                if (p.half && j != i && j >= p.row_lo && j < p.row_hi) {
+                    tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir;
+                    if (slab_q) {      // the image goes straight to row j's slab when its ticket lies inside it (else it waits here for k_mirror)
+                        const uint32_t b0 = slab_base(p.a_rowptr[j], slab_rp0, j - p.row_lo, slab_q), b1 = slab_base(p.a_rowptr[j + 1], slab_rp0, j + 1u - p.row_lo, slab_q);
+                        if (tick < b1 - b0) { p.slab[b0 + tick] = make_uint4(i, v.t0 | v.q0 << 16, v.t1 | v.q1 << 16, (uint32_t)v.numshared); tick = 0xFFFFFFFFu; }
+                    }
+                }
                 if (p.rec16) { p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared); p.tick[off + t] = tick; }
                 else {
                     p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
@@ -712,6 +722,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
         if (misc[W_MX]) atomicMax(&sh->maxshared, misc[W_MX]);
         unsigned long long fc = *w64(W_FB_C), fu = *w64(W_FB_U);
         if (p.use_feedback && misc[W_FB_N]) { atomicAdd(&p.ctr->fb_claims, fc); atomicAdd(&p.ctr->fb_ub, fu); }
+        if (sample && *w64(W_ACC_Y)) atomicAdd(&p.ctr->fb_surv, *w64(W_ACC_Y));      // (what sizes the mirror slabs)
         fc += *w64(W_TOT_C); fu += *w64(W_TOT_U);
         if (fu) { atomicAdd(&sh->fb_claims, fc); atomicAdd(&sh->fb_ub, fu); }
         if (misc[W_ACC_DONE]) {
@@ -745,6 +756,22 @@ __global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
     if (p.nsample) {
         const unsigned long long u = p.ctr->fb_ub, cl = p.ctr->fb_claims;
         if (u) { const double r = 1.25 * (double)cl / (double)u * 65536.0; prior_q16 = r < 64.0 ? 64u : (r > 4.0e9 ? 4000000000u : (uint32_t)r); }
+    }
+    if (p.slab != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        // mirror slabs: slab entries per row entry = mirrored entries per row entry (an earlier call's, or what the sample's rows staged — a row
+        // stages about as many entries as it receives) x the margin, cut down to what the slab area holds
+        double r = 0.0;
+        if (p.slab_prior_q16) r = (double)p.slab_prior_q16;
+        else if (p.nsample) { const unsigned long long u = p.ctr->fb_ub; if (u) r = (double)p.ctr->fb_surv / (double)u * 65536.0; }
+        r *= (double)p.slab_pct / 100.0;
+        const unsigned long long nrows = p.row_hi - p.row_lo, zw = p.a_rowptr[p.row_hi] - p.a_rowptr[p.row_lo], padded = (unsigned long long)SLAB_PAD * nrows;
+        uint32_t q = 0;
+        if (r >= 1.0 && zw > 0 && p.slab_cap > padded + 1ull) {
+            const double most = (double)(p.slab_cap - padded - 1ull) * 65536.0 / (double)zw;
+            r = r < most ? r : most;
+            q = r >= 4.0e9 ? 4000000000u : (uint32_t)r;
+        }
+        p.ctr->slab_q16 = q;
     }
     // (dense path with labels: the rows are queued in label order — reads of one locus are multiplied at the same time and find each other's
     //  columns in the caches; the order names every row of the matrix, those outside the window pass)

@@ -309,6 +309,12 @@ int  elba_get_device_view(elba_ctx *ctx, elba_device_view *view);
  *       multiplies every matrix once pays — the reference's create_seed_matrix is called once per A (src/main.cpp:281).  Buffers stay
  *       allocated.  Default 0. */
 int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
+/* Diagnostic counters of the last stage call by name (unknown name: ELBA_ERR_INVALID_ARG); none of them is part of a result.
+ *   "overlap_mirror_placed"  mirrored entries of the last elba_create_seed_matrix call that waited in the staging area for the placement pass
+ *                            instead of going straight to their row's slab ("mirror slabs")
+ *   "overlap_slab_q16"       slab entries reserved per row entry of A in that call, x 65536 (0: the call ran without slabs)
+ *   "resident_bytes_A"       device bytes the resident k-mer matrix occupies (CSR, columns, padded column store, pointers) */
+int  elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value);
 
 /* ---- distributed building blocks (one context per rank/GPU; the collectives are issued by the host driver) ----------------
  * They replace, for a 1D read-row partition over the GPUs of one node, what the reference does with MPI inside the same four

@@ -626,3 +626,47 @@ def test_more_gather_trips_in_flight_give_the_same_matrix(dk):
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
     e.close()
+
+
+@pytest.mark.parametrize("shape", ["forced_ratio", "sampled_cold", "wide_rows"])
+def test_mirror_slabs_of_any_size_give_the_same_matrix(shape):
+    """Mirror slabs (spgemm.hip): the numeric kernel writes a staged entry's transposed image straight into its partner row's slab when its ticket
+    lies inside it; images beyond the slab (or drawn before a ratio was known) wait for k_mirror, and the finalize reads a row's mirrored
+    entries from both places.  Slabs far too small, just right and generous, sized by the test hook, by a cold call's sample of rows and by the
+    previous call's measurement: B never changes."""
+    if shape == "forced_ratio":
+        packed, off, lens, info = elba_amd.synth_reads(71, 300000, 18, 3500, 900, error_rate=0.10, min_len=200)
+        k, lo, up = 17, 2, 8
+    elif shape == "sampled_cold":      # >= 8192 rows: a cold call computes a sample of rows first and sizes the slabs by what they staged
+        packed, off, lens, info = elba_amd.synth_reads(72, 320000, 24, 800, 250, error_rate=0.06, min_len=120)
+        k, lo, up = 17, 2, 12
+        assert len(lens) >= 8192
+    else:                              # rows of B beyond 256 / 1024 / 4096 entries: every finalize kernel reads slabs
+        packed, off, lens, info = elba_amd.synth_reads(6, 200, 2200, 100, 0, error_rate=0.0, min_len=100)
+        k, lo, up = 21, 2, 20000
+    o = gu.oracle_run(packed, off, lens, k, lo, up, threads=8)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up)
+    gu.assert_B_equal(e.export_csr(), o.B())
+    nmir = (o.stat("Y") - o.stat("ndiag")) // 2
+    seen = []
+    for cold, q16, pct in [(1, 0, 175), (1, 1, 100), (1, 400, 100), (1, 3000, 100), (1, 1 << 18, 100), (0, 0, 175), (0, 0, 30), (1, 0, 20), (1, 0, 1000)]:
+        e.set_option("overlap_cold_calls", cold); e.set_option("slab_q16", q16); e.set_option("slab_pct", pct)
+        st = e.create_seed_matrix()
+        gu.assert_B_equal(e.export_csr(), o.B())
+        gu.assert_stats_equal(st, o)
+        seen.append((cold, q16, pct, e.get_stat("overlap_slab_q16"), e.get_stat("overlap_mirror_placed")))
+    by = {(c, q, p): (used, placed) for c, q, p, used, placed in seen}
+    assert by[(1, 1 << 18, 100)] == (1 << 18, 0), seen                 # generous slabs: nothing waits for k_mirror
+    assert by[(1, 1, 100)][0] == 1 and 0 < by[(1, 1, 100)][1] <= nmir, seen       # 16 entries per row: most images take the old way
+    assert by[(0, 0, 175)][0] > 0, seen                                # a warm call sizes its slabs by the previous call's measurement
+    assert by[(0, 0, 30)][1] > by[(0, 0, 175)][1], seen
+    if shape == "sampled_cold":
+        assert by[(1, 0, 175)][0] > 0 and by[(1, 0, 175)][1] < nmir // 10, seen      # sized by the sample: the sample's own rows and a few per cent of the others miss their slab
+        assert by[(1, 0, 1000)][1] < by[(1, 0, 20)][1], seen
+    else:
+        assert by[(1, 0, 175)] == (0, nmir), seen                      # a cold call on a small matrix has no ratio: no slabs
+    e.set_option("no_slab", 1); e.set_option("overlap_cold_calls", 0)
+    st = e.create_seed_matrix()
+    assert e.get_stat("overlap_slab_q16") == 0
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
