@@ -176,6 +176,12 @@ def main():
     else:
         rank_phases = None
         Y, P, abytes, I_tot, Z_tot, bases_tot = st["nnz"], st["products"], st["algorithmic_bytes"], ks["instances"], ms["nnz"], bases_local
+    # mirror slabs: how the last cold step's mirrored entries reached their rows
+    mirror = None
+    if hasattr(eng, "get_stat"):
+        q16 = eng.get_stat("overlap_slab_q16")
+        mirror = {"slab_entries_per_row_entry_q16": q16, "placed_by_k_mirror": eng.get_stat("overlap_mirror_placed"),
+                  "what": "mirrored entries go straight from the numeric kernel to their row's slab (sized by the cold call's sample of rows); the rest waits for k_mirror" if q16 else "no slabs in this step"}
     steps = max(1, args.steps)
     ms_step = dt / steps * 1e3
     for key in acc:
@@ -369,6 +375,7 @@ def main():
             "reference_stage_timers_ms": ref_timers,
             "rank_phases_ms": rank_phases,
             "phases_ms": {key: round(v, 4) for key, v in acc.items()},
+            "mirror": mirror,
             "tiers": {key: int(st_cold[key]) for key in ("rows_lds", "rows_global", "rows_escalated", "nnz_before_prune", "passes") if key in st_cold},
             "aux_stages": aux,
             "gen_s": round(t_gen, 2),

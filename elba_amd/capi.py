@@ -13,13 +13,18 @@ def lib_path():
 
 
 def numeric_source_fingerprint():
-    """sha256 (16 hex digits) of the sources of the SpGEMM's numeric kernel: what a rocprof counter summary under profiles/ is valid for.
-    bench.py quotes `roofline.traffic` from profiles/traffic.json only while this matches the value stored there."""
+    """sha256 (16 hex digits) of the sources that decide what the SpGEMM's numeric kernels do and what they read: the kernels themselves and
+    the files that write the format of A (inline partners, hints, padded-column strides).  A rocprof counter summary under profiles/ is valid
+    for exactly these sources: bench.py quotes `roofline.traffic` from profiles/traffic.json only while this matches the value stored there.
+    None when the sources are not beside the library (an install without csrc/): nothing is quoted then."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("spgemm.hip", "spgemm_direct.hpp", "spgemm_table.hpp"):
-        with open(os.path.join(_HERE, "csrc", name), "rb") as f:
-            h.update(f.read())
+    try:
+        for name in ("spgemm.hip", "spgemm_direct.hpp", "spgemm_table.hpp", "matrix.hip", "kmer_msd.hip", "kmer.hip", "common.hpp"):
+            with open(os.path.join(_HERE, "csrc", name), "rb") as f:
+                h.update(f.read())
+    except OSError:
+        return None
     return h.hexdigest()[:16]
 
 

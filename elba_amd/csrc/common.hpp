@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/elba_amd.h"
@@ -30,6 +31,20 @@ struct Error {
     do {                                                     \
         if (!(cond)) throw ::elba::Error{(code), (text)};    \
     } while (0)
+
+// Work that must run once per DEVICE and process (hipFuncSetAttribute applies to the current device: a host process that drives two GPUs, or
+// ranks that run as threads, must each set it on their own device) — serialised, so that threads never race on the flags.
+struct DeviceOnce {
+    std::mutex m;
+    bool done[64] = {};
+    template <class F> void run(int dev, F &&f)
+    {
+        std::lock_guard<std::mutex> g(m);
+        if (dev >= 0 && dev < 64 && done[dev]) return;
+        f();
+        if (dev >= 0 && dev < 64) done[dev] = true;
+    }
+};
 
 // Growable device buffer (never shrinks; capacity is reused across calls so the steady state allocates nothing).
 struct DevBuf {
@@ -267,6 +282,7 @@ struct Ctx {
     int ov_pend_passes = 1; bool ov_pend_timed = false; float ov_pend_ms[3] = {0, 0, 0};
     std::vector<uint64_t> ov_remote_bounds;
     DevBuf ov_remote;               // mirror images received from other ranks (32-byte records)
+    int64_t ov_send_slot = 0;       // slot size of the step in flight (stage_seed_matrix_send): recv must be given the same
     DevBuf ov_cursors;              // per-destination cursors of the fixed-slot exchange + the receive side's check words (stage_seed_matrix_send / _recv)
     bool own_stream = true;         // c.stream was created by the context (elba_set_stream: the caller's)
 

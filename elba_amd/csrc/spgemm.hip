@@ -121,6 +121,7 @@ struct OvParams {
 // sample's own rows, small matrices) keeps its ticket and takes the old way (k_mirror); the finalize reads a row's mirrored entry t from the slab
 // when t is inside it and from the mirror area otherwise.  Capacity is a performance matter only, never a correctness limit.
 constexpr uint32_t SLAB_PAD = 16;
+struct __attribute__((packed, aligned(4))) RowPair { uint32_t a, b; };      // a_rowptr[j], a_rowptr[j + 1]
 __device__ __forceinline__ uint32_t slab_base(uint32_t rp, uint32_t rp0, uint32_t row_rel, uint32_t q16)
 {
     return (uint32_t)(((unsigned long long)(rp - rp0) * q16) >> 16) + SLAB_PAD * row_rel;
@@ -755,7 +756,7 @@ __global__ void k_ingest_remote(StageRec *rem, unsigned long long n, uint32_t *l
 //  blockIdx.y = slot, and the blocks of a slot stride over its records only)
 __global__ void k_place_remote(FinParams p, const StageRec *rem, unsigned long long n, unsigned long long slot)
 {
-    if (slot) { rem += (unsigned long long)blockIdx.y * slot; n = (unsigned long long)rem->a.x + 1; }
+    if (slot) { rem += (unsigned long long)blockIdx.y * slot; n = (unsigned long long)rem->a.x + 1; if (n > slot) n = slot; }      // (a header that claims more than the slot holds — a failed collective, a slot mismatch — is flagged by k_ingest_remote_slots; never read past the slot)
     for (unsigned long long r = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + (slot ? 1 : 0); r < n; r += (unsigned long long)gridDim.x * blockDim.x) {
         const uint4 a = rem[r].a, b = rem[r].b;
         if (a.x < p.row_lo || a.x >= p.row_hi) continue;
@@ -952,8 +953,8 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.ctr = c.ov_counters.as<OvCounters>();
     p.gtable = c.ov_gtable.as<uint32_t>(); p.gstride = gstride;
 
-    static bool attr_done = false;
-    if (!attr_done) {
+    static DeviceOnce attr_once;
+    attr_once.run(c.device, [&] {
         const int lds = 160 * 1024;
 #define ELBA_ATTR(B, P, D) ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<B, false, P, D>), hipFuncAttributeMaxDynamicSharedMemorySize, lds))
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_spgemm_direct<512, false, false, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -964,8 +965,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         ELBA_ATTR(256, false, 1); ELBA_ATTR(256, false, 2); ELBA_ATTR(256, false, 4);
         ELBA_ATTR(512, false, 1); ELBA_ATTR(512, false, 2); ELBA_ATTR(512, false, 4); ELBA_ATTR(1024, false, 1); ELBA_ATTR(1024, false, 2); ELBA_ATTR(1024, false, 4);
 #undef ELBA_ATTR
-        attr_done = true;
-    }
+    });
 
     c.ov_host.reserve(sizeof(OvCounters));
     OvCounters &hc = *static_cast<OvCounters *>(c.ov_host.p);
@@ -1245,8 +1245,11 @@ __global__ void k_slot_headers(const unsigned long long *cursors, const OvCounte
 __global__ void k_ingest_remote_slots(StageRec *rem, unsigned long long slot, uint32_t *low_cnt, uint32_t row_lo, uint32_t row_hi, unsigned long long *chk)
 {
     StageRec *base = rem + (unsigned long long)blockIdx.y * slot;
-    const uint4 h = base->a;
+    uint4 h = base->a;
+    const bool garbage = (unsigned long long)h.x + 1 > slot;      // more records than the slot holds: not a header this library wrote for this slot size
+    if (garbage) h.x = 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (garbage) atomicAdd(&chk[0], 1ull);
         if (h.y) atomicOr(&chk[2], 1ull);
         atomicMax(&chk[3], ((unsigned long long)h.w << 32) | h.z);
     }
@@ -1273,6 +1276,7 @@ void stage_seed_matrix_send(Ctx &c, int nranks, const uint64_t *bounds_host, voi
     ELBA_REQUIRE(found && (int64_t)bounds_host[nranks] == c.M, ELBA_ERR_INVALID_ARG, "seed_matrix_send: this context's row window is not one of the ranks' row ranges");
     c.ov_remote_bounds.assign(bounds_host, bounds_host + nranks + 1);
     create_seed_matrix_direct(c, 2);
+    c.ov_send_slot = slot;
     hipStream_t s = c.stream;
     c.ov_cursors.reserve(REMOTE_MAX_RANKS * 8 + 64);
     ELBA_HIP(hipMemsetAsync(c.ov_cursors.p, 0, REMOTE_MAX_RANKS * 8 + 64, s));
@@ -1290,6 +1294,7 @@ bool stage_seed_matrix_recv(Ctx &c, void *d_recv, int64_t slot, int64_t *slot_ne
 {
     ELBA_REQUIRE(c.ov_phase == 2, ELBA_ERR_STATE, "seed_matrix_recv: call seed_matrix_send first");
     ELBA_REQUIRE(d_recv && slot >= 2, ELBA_ERR_INVALID_ARG, "seed_matrix_recv: null records");
+    ELBA_REQUIRE(slot == c.ov_send_slot, ELBA_ERR_INVALID_ARG, "seed_matrix_recv: slot_records differs from the value given to seed_matrix_send");
     hipStream_t s = c.stream;
     const int64_t row_lo = c.row_lo, row_hi = c.row_hi < 0 ? c.M : c.row_hi;
     const int nranks = (int)c.ov_remote_bounds.size() - 1;
@@ -1313,7 +1318,7 @@ bool stage_seed_matrix_recv(Ctx &c, void *d_recv, int64_t slot, int64_t *slot_ne
     ELBA_HIP(hipMemcpyAsync(hchk, chk, sizeof(hchk), hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));      // the step's one synchronisation
     c.ov_phase = 0;
-    ELBA_REQUIRE(hchk[0] == 0, ELBA_ERR_INVALID_ARG, "seed_matrix_recv: received records for rows outside this context's window");
+    ELBA_REQUIRE(hchk[0] == 0, ELBA_ERR_INVALID_ARG, "seed_matrix_recv: received records for rows outside this context's window, or a slot header that claims more records than a slot holds");
     if (hc.overflow || hchk[2]) {
         // some rank's staging area or slot was too small: every rank saw the flag (it travels in every header) and repeats the step
         const int64_t slack = (int64_t)c.num_cus * 32 * STAGE_CHUNK + 64;

@@ -682,8 +682,19 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 if (p.half && j != i && j >= p.row_lo && j < p.row_hi) {
                     tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir;
                     if (slab_q) {      // the image goes straight to row j's slab when its ticket lies inside it (else it waits here for k_mirror)
+#if defined(ELBA_SLAB_NOLD)
+                        const uint32_t b0 = j * 431u, b1 = b0 + 431u;
+#elif defined(ELBA_SLAB_LD4)
                         const uint32_t b0 = slab_base(p.a_rowptr[j], slab_rp0, j - p.row_lo, slab_q), b1 = slab_base(p.a_rowptr[j + 1], slab_rp0, j + 1u - p.row_lo, slab_q);
+#else
+                        const RowPair rp = *reinterpret_cast<const RowPair *>(p.a_rowptr + j);      // (two adjacent words, ONE request: a dword-aligned 8-byte load)
+                        const uint32_t b0 = slab_base(rp.a, slab_rp0, j - p.row_lo, slab_q), b1 = slab_base(rp.b, slab_rp0, j + 1u - p.row_lo, slab_q);
+#endif
+#if defined(ELBA_SLAB_NOST)
+                        if (tick < b1 - b0) { tick = 0xFFFFFFFFu; }
+#else
                         if (tick < b1 - b0) { p.slab[b0 + tick] = make_uint4(i, v.t0 | v.q0 << 16, v.t1 | v.q1 << 16, (uint32_t)v.numshared); tick = 0xFFFFFFFFu; }
+#endif
                     }
                 }
                 if (p.rec16) { p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared); p.tick[off + t] = tick; }

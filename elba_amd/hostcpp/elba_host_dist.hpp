@@ -135,7 +135,20 @@ public:
         uint64_t base = 0, nall = 0;
         for (int r = 0; r < W; ++r) { if (r < grid_->rank) base += ns[(size_t)r]; nall += ns[(size_t)r]; }
         engine_->check(elba_dist_set_kmer_id_base(engine_->ctx, (int64_t)base, (int64_t)nall));
-        // exchange #2: column panels to the owners of the reads
+        nall_ = nall;
+        elba_matrix_stats ms = load_panel();
+        ks.instances = (int64_t)sum(sc);
+        if (kstats) *kstats = ks;
+        if (mstats) *mstats = ms;
+        exchange_bytes_ += sum(sc) * rw * 8;
+    }
+
+    // exchange #2: every column, whole, to each rank that owns one of its reads; the panel becomes the context's A.  Collective.  Inline partners
+    // in the panel's rows follow the pair-ownership rule of the mirror exchange: written when that is how the panel will be multiplied
+    // (panel_inline_exchange, default) — create_seed_matrix(false) on such a panel loads it again without them.
+    elba_matrix_stats load_panel()
+    {
+        const int W = grid_->size;
         std::vector<uint64_t> ub(bounds_.begin(), bounds_.end()), pc((size_t)W), prc;
         engine_->check(elba_dist_panel_counts(engine_->ctx, W, ub.data(), pc.data()));
         prc = exchange_counts(pc);
@@ -145,26 +158,28 @@ public:
         recv_.reserve(sum(prc) * 16);
         all_to_all(send_, pc, recv_, prc, 16);
         elba_matrix_stats ms{};
-        // (inline partners in the panel's rows follow the pair-ownership rule of the mirror exchange: requested when that is how the panel will be
-        //  multiplied — the default of create_seed_matrix below; a panel built for exchange = false must be built with panel_inline_exchange(false))
         engine_->check(elba_set_option(engine_->ctx, "panel_inline", panel_inline_ ? 1 : 0));
-        engine_->check(elba_dist_set_panel(engine_->ctx, recv_.p, (int64_t)sum(prc), nreads_total(), (int64_t)nall, row_lo(), row_hi(), &ms));
-        ks.instances = (int64_t)sum(sc);
-        if (kstats) *kstats = ks;
-        if (mstats) *mstats = ms;
-        exchange_bytes_ = sum(sc) * rw * 8 + sum(pc) * 16;
+        engine_->check(elba_dist_set_panel(engine_->ctx, recv_.p, (int64_t)sum(prc), nreads_total(), (int64_t)nall_, row_lo(), row_hi(), &ms));
+        panel_has_inline_ = panel_inline_;
+        exchange_bytes_ += sum(pc) * 16;
+        slot_ = 0;
+        return ms;
     }
 
     // create_seed_matrix (include/SharedSeeds.hpp:98-99) for this rank's rows of B.  With more than one rank every pair of rows that live on
     // two ranks is accumulated by ONE of them (elba_seed_matrix_begin) and its mirror image travels to the other in one all-to-all of
     // 32-byte records (the only exchange inside the call; the reference's SUMMA stages have no other counterpart), then elba_seed_matrix_end
     // completes the rows.  exchange = false: no communication, both ranks accumulate the pair.
-    void panel_inline_exchange(bool on) { panel_inline_ = on; }      // before create_kmer_matrix: false if the panel will be multiplied with exchange = false
+    void panel_inline_exchange(bool on) { panel_inline_ = on; }      // before build_kmer_matrix: false saves the reload if the panel will be multiplied with exchange = false
     elba_overlap_stats create_seed_matrix(bool exchange = true)
     {
         elba_overlap_stats st{};
         const int W = grid_->size;
-        if (!exchange) { engine_->check(elba_create_seed_matrix(engine_->ctx, &st)); return st; }   // (one rank: the same calls with empty messages)
+        if (!exchange) {      // (every rank takes this branch together: the reload is a collective)
+            if (panel_has_inline_) { panel_inline_ = false; (void)load_panel(); }
+            engine_->check(elba_create_seed_matrix(engine_->ctx, &st));
+            return st;
+        }
         std::vector<uint64_t> ub(bounds_.begin(), bounds_.end()), sc((size_t)W), rc;
         engine_->check(elba_seed_matrix_begin(engine_->ctx, W, ub.data(), sc.data()));
         rc = exchange_counts(sc);
@@ -211,7 +226,6 @@ public:
         throw std::runtime_error("create_seed_matrix_slots: the mirror exchange did not settle");
     }
     uint64_t mirror_bytes() const { return mirror_bytes_; }
-    bool panel_inline_ = true;
     uint64_t exchange_bytes() const { return exchange_bytes_; }
 
 private:
@@ -282,6 +296,8 @@ private:
     int kw_ = 1;
     uint64_t exchange_bytes_ = 0, mirror_bytes_ = 0, slot_ = 0;
     bool shares_stream_ = false;
+    bool panel_inline_ = true, panel_has_inline_ = false;
+    uint64_t nall_ = 0;
 };
 
 }  // namespace elba

@@ -48,7 +48,7 @@ enum {
     ELBA_ERR_HIP           = 3,  /* a HIP runtime call failed (elba_last_error has the text) */
     ELBA_ERR_OUT_OF_MEMORY = 4,
     ELBA_ERR_STATE         = 5,  /* stage called before its inputs exist */
-    ELBA_ERR_UNSUPPORTED   = 6,  /* k > 31 (NLONGS > 1), index ranges beyond 32 bit */
+    ELBA_ERR_UNSUPPORTED   = 6,  /* k outside 3..95, index ranges beyond 32 bit, LOWER == 1 */
     ELBA_ERR_INTERNAL      = 7,
     ELBA_ERR_RETRY         = 8   /* elba_seed_matrix_recv: some rank ran out of room; every rank got this answer: repeat the step */
 };
@@ -135,9 +135,9 @@ typedef struct {
     int64_t reliable;      /* N  = k-mers with lower <= count <= upper                */
     int64_t entries;       /* Z  = nnz(A)                                             */
     float   ms_total;      /* device time of the stage (HIP events on the library's stream) */
-    float   ms_count;      /* enumerate + hash-count kernel                           */
-    float   ms_lookup;     /* second enumeration + lookup + compaction                */
-    float   ms_sort;       /* sorts (k-mer ids)                                       */
+    float   ms_count;      /* "collecting distinct k-mers": enumerate + value partition (k <= 31), or enumerate + sort */
+    float   ms_lookup;     /* unused (0): there is no second enumeration — an instance carries its read and position */
+    float   ms_sort;       /* "counting recording k-mer seeds": per-bucket exact count, [lower, upper] filter, columns */
 } elba_kmer_stats;
 
 typedef struct {
@@ -253,8 +253,9 @@ int  elba_set_kmer_matrix(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t n
                           const int64_t *rows, const int64_t *cols, const uint32_t *vals, elba_matrix_stats *stats);
 
 /* The same with the three arrays resident in HBM (int64 rows, int64 cols, uint32 vals): what a GPU-resident caller of create_seed_matrix(A, AT)
- * (include/SharedSeeds.hpp:98-99) hands over.  elba_export_triples_device writes the resident A back as such triples (CSR order) into
- * caller-allocated device arrays of nnz elements each. */
+ * (include/SharedSeeds.hpp:98-99) hands over.  elba_export_triples_device writes the resident A back as such triples into
+ * caller-allocated device arrays of nnz elements each; their ORDER is unspecified (row-major for most matrices, column-major when the rows
+ * carry inline partners, a_csr_format == ELBA_CSR_INLINE: such rows are rebuilt from the columns) — elba_set_kmer_matrix_device takes any order. */
 int  elba_set_kmer_matrix_device(elba_ctx *ctx, int64_t nrows, int64_t ncols, int64_t nnz,
                                  const void *d_rows, const void *d_cols, const void *d_vals, elba_matrix_stats *stats);
 int  elba_export_triples_device(elba_ctx *ctx, void *d_rows, void *d_cols, void *d_vals);
