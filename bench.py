@@ -45,6 +45,45 @@ WORKLOADS = {
 }
 PEAK_GBS = 8000.0          # HBM3E peak, MI355X_MICROARCH.md
 
+# What the one-GPU build of each workload counts (k-mer instances, nnz(A), semiring products, nnz(B)): properties of the generated read set, the
+# same for every number of ranks.  A run on N > 1 GPUs must reproduce them after its all-reduce — the first hardware run of the sharded
+# path validates itself; a mismatch ends the run with a non-zero exit code.  (ELBA_BENCH_EXPECT="I,Z,P,Y" overrides: tests.)
+EXPECTED_COUNTS = {
+    "200k-long-reads": (1996913231, 534826215, 1370686611, 98693580),
+}
+
+
+def host_copy(dev_ptr, count, dtype):
+    """`count` items of `dtype` from a raw device pointer into a fresh numpy array (hipMemcpy through ctypes: plumbing for the checker)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    out = np.empty(int(count), dtype=dtype)
+    if count:
+        rc = hip.hipMemcpy(ctypes.c_void_p(out.ctypes.data), ctypes.c_void_p(int(dev_ptr)), ctypes.c_size_t(out.nbytes), 2)
+        if rc != 0:
+            raise RuntimeError("hipMemcpy D2H failed: %d" % rc)
+    return out
+
+
+def host_memory_available():
+    """bytes this process may still allocate: the smaller of MemAvailable and the cgroup's limit minus its usage"""
+    avail = None
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable:"):
+                avail = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        if lim != "max":
+            used = int(open("/sys/fs/cgroup/memory.current").read().strip())
+            left = int(lim) - used
+            avail = left if avail is None else min(avail, left)
+    except (OSError, ValueError):
+        pass
+    return avail
+
 
 def bytes_kmer_stage(bases, I, N, Z):
     """read the packed reads once, materialise the 16-byte instance stream once (write + read), write CSC(A) with k-mer values."""
@@ -60,7 +99,8 @@ def main():
     ap.add_argument("--steady-steps", type=int, default=10, help="untimed-by-the-contract steps with the hints of earlier calls kept (secondary figure)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-accounting", action="store_true", help="skip spgemm_prep / from_triples (two more contexts)")
-    ap.add_argument("--cpu-sample-div", type=int, default=0, help="CPU baseline sample: the same generator with the genome divided by this (0: chosen for ~10-30 s of CPU work)")
+    ap.add_argument("--cpu-sample-div", type=int, default=0, help="CPU baseline, one-core leg: the same generator with the genome divided by this (0: chosen for ~10-30 s of CPU work)")
+    ap.add_argument("--no-cpu-full", action="store_true", help="skip the all-cores CPU baseline on the WHOLE workload matrix (and the entry-by-entry comparison of B with it)")
     ap.add_argument("--timing-stride", type=int, default=4, help="the library records its phase events (kernel_ms of the roofline) on every N-th step only: "
                     "an event record costs ~5 us of stream time; kernel_ms is the mean over the steps that were measured")
     ap.add_argument("--aux", action="store_true", help="N = 1: also run the stages on either side of the path once (FASTA ingest, x-drop alignment, string graph); "
@@ -182,6 +222,12 @@ def main():
         q16 = eng.get_stat("overlap_slab_q16")
         mirror = {"slab_entries_per_row_entry_q16": q16, "placed_by_k_mirror": eng.get_stat("overlap_mirror_placed"),
                   "what": "mirrored entries go straight from the numeric kernel to their row's slab (sized by the cold call's sample of rows); the rest waits for k_mirror" if q16 else "no slabs in this step"}
+    # the counts every run of this workload must reproduce, on any number of ranks
+    expect = EXPECTED_COUNTS.get(args.workload) if not args.weak else None
+    if os.environ.get("ELBA_BENCH_EXPECT"):
+        expect = tuple(int(x) for x in os.environ["ELBA_BENCH_EXPECT"].split(","))
+    got_counts = (int(I_tot), int(Z_tot), int(P), int(Y))
+    counts_ok = None if expect is None else bool(got_counts == tuple(expect))
     steps = max(1, args.steps)
     ms_step = dt / steps * 1e3
     for key in acc:
@@ -213,7 +259,11 @@ def main():
     # achieved = algorithmic bytes of this rank's rows (16 Z + 8 (2M + N + 3) + 24 Y) / HIP-event duration of those
     # launches on the library's stream, measured live on every timing_stride-th timed step.
     my_bytes = st_cold["algorithmic_bytes"]
-    achieved = my_bytes / (acc["ms_numeric"] * 1e-3) / 1e9 if acc["ms_numeric"] > 0 else 0.0
+    # Headline = the WHOLE region: the formula's bytes (both orientations of A read, all of B written) belong to the whole launch sequence — the numeric
+    # kernels do not write the 24 Y bytes of B, the finalize kernels do — so bytes and time cover the same kernels.  The
+    # numeric kernels alone are reported beside it (`numeric_kernels`): against the same bytes, and against the HBM bytes they were MEASURED to move.
+    achieved = my_bytes / (acc["ms_total"] * 1e-3) / 1e9 if acc["ms_total"] > 0 else 0.0
+    achieved_num = my_bytes / (acc["ms_numeric"] * 1e-3) / 1e9 if acc["ms_numeric"] > 0 else 0.0
     traffic = None
     traffic_note = None
     tj = None
@@ -223,26 +273,30 @@ def main():
         try:
             tj = json.load(open(tpath))
             if tj.get("workload") == args.workload and tj.get("n_gpus", 1) == world:
-                if tj.get("numeric_source_sha16") == fingerprint:
+                if fingerprint is not None and tj.get("numeric_source_sha16") == fingerprint:
                     traffic = tj.get("hbm_bytes_per_step_dominant_kernel")
                     traffic_note = tj.get("note")
                 else:
                     traffic_note = "profiles/traffic.json was measured on other kernel sources (%s, now %s): not quoted" % (tj.get("numeric_source_sha16"), fingerprint)
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_spgemm_direct (plan-free LDS-hash numeric, all tiers)", "achieved": round(achieved, 3), "peak": PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "the launch sequence of one cold call: k_spgemm_direct (plan-free LDS-hash numeric, all tiers; dominant) + classify + row pointers + finalize",
+                "achieved": round(achieved, 3), "peak": PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / PEAK_GBS, 6), "traffic": traffic, "traffic_note": traffic_note,
                 "algorithmic_bytes_per_step": my_bytes, "bytes_per_nnz": round(my_bytes / max(1, st_cold["nnz"]), 2),
                 "kernel_ms": round(acc["ms_numeric"], 4), "kernel_ms_measured_on_steps": ntimed, "region_ms_device": round(acc["ms_total"], 4),
-                "frac_whole_region": round(my_bytes / (acc["ms_total"] * 1e-3) / 1e9 / PEAK_GBS, 6) if acc["ms_total"] > 0 else 0.0,
+                "frac_whole_region": round(achieved / PEAK_GBS, 6),
                 "frac_whole_region_wall": round(abytes / (dt / steps) / 1e9 / PEAK_GBS / world, 6),
+                "numeric_kernels": {"kernel_ms": round(acc["ms_numeric"], 4), "frac_of_algorithmic_bytes": round(achieved_num / PEAK_GBS, 6),
+                                    "frac_of_measured_traffic": round(traffic / (acc["ms_numeric"] * 1e-3) / 1e9 / PEAK_GBS, 6) if (traffic and acc["ms_numeric"] > 0) else None,
+                                    "note": "the dominant kernels alone: the whole step's algorithmic bytes over their time overstates them (they do not write B); the measured figure is what they move"},
                 "expanded_stream_bytes": 8 * st_cold["products"] + 8 * ms["nnz"] + 24 * st_cold["nnz"]}
     # the resource that binds the kernel is the rate of 64-byte line requests (profiles/r02_notes.md): PMC request counts (offline, like `traffic`)
     rpath = os.path.join(ROOT, "profiles", "requests.json")
     if os.path.exists(rpath) and acc["ms_numeric"] > 0:
         try:
             rj = json.load(open(rpath))
-            if rj.get("workload") == args.workload and rj.get("n_gpus", 1) == world and rj.get("numeric_source_sha16") == fingerprint:
+            if rj.get("workload") == args.workload and rj.get("n_gpus", 1) == world and fingerprint is not None and rj.get("numeric_source_sha16") == fingerprint:
                 rate = rj["tcc_requests_per_step"] / (acc["ms_numeric"] * 1e-3) / 1e9
                 roofline["l2_requests"] = {"per_step": rj["tcc_requests_per_step"], "achieved_G_per_s": round(rate, 2), "measured_ceiling_G_per_s": rj["ceiling_G_requests_per_s"],
                                            "frac_of_ceiling": round(rate / max(rj["ceiling_G_requests_per_s"]), 4)}
@@ -330,13 +384,58 @@ def main():
         B = es.export_csr(); oB = o.B()
         parity = bool(B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"]).all() and (B["val"] == oB["val"]).all()
                       and sst["products"] == o.stat("P") and sst["nnz_before_prune"] == o.stat("Yraw"))
-        cpu = {"value": round(o.stat("Y") / t1, 1), "unit": "overlap nnz/s", "cores": 1, "kind": "port",
-               "sample": "the same generator with the genome divided by %d (%d reads, nnz(A) = %d, P = %d products, Y = %d): the SpGEMM region once, "
-                         "oracle/elba_oracle.c orc_spgemm, gcc -O3" % (div, A["M"], A["Z"], o.stat("P"), o.stat("Y")),
-               "seconds": round(t1, 4), "all_cores": {"value": round(o.stat("Y") / tn, 1), "cores": ncores, "seconds": round(tn, 4)},
-               "gpu_on_the_same_sample": {"ms_cold_call": round(sst["ms_total"], 4), "value": round(sst["nnz"] / max(1e-9, sst["ms_total"] * 1e-3), 1)}}
+        one_core = {"value": round(o.stat("Y") / t1, 1), "unit": "overlap nnz/s", "cores": 1,
+                    "sample": "NOT the headline matrix: the same generator with the genome divided by %d (%d reads, nnz(A) = %d, P = %d products, Y = %d): the SpGEMM region once, "
+                              "oracle/elba_oracle.c orc_spgemm, gcc -O3" % (div, A["M"], A["Z"], o.stat("P"), o.stat("Y")),
+                    "seconds": round(t1, 4), "all_cores_on_that_sample": {"value": round(o.stat("Y") / tn, 1), "cores": ncores, "seconds": round(tn, 4)},
+                    "gpu_on_the_same_sample": {"ms_cold_call": round(sst["ms_total"], 4), "value": round(sst["nnz"] / max(1e-9, sst["ms_total"] * 1e-3), 1)}}
+        cpu = dict(one_core, kind="port")
         if es is not eng:
             es.close()
+        del o, A, B, oB, rows
+        # ---- the WHOLE workload matrix on all host cores, and every entry of the GPU's B against it (VERDICT r3 task 7) ----------------------
+        # The timed matrix itself: its columns leave the device as they are (u32 pointers, read << 32 | pos — the reference's AT), the oracle
+        # derives CSR, runs create_seed_matrix's region once on every core this process may use, and compares B entry by entry.
+        full = None
+        if not args.no_cpu_full:
+            need = 40 * int(ms["nnz"]) + 120 * int(st_cold["nnz"]) + (4 << 30)      # host bytes: A twice + the oracle's B twice + the GPU's B
+            avail = host_memory_available()
+            if avail is not None and avail < need:
+                full = {"skipped": "host memory: %d MB available, ~%d MB needed" % (avail >> 20, need >> 20)}
+            else:
+                try:
+                    ncall = len(os.sched_getaffinity(0))
+                except AttributeError:
+                    ncall = os.cpu_count() or 1
+                ncall = max(1, min(ncall, 64))
+                torch.cuda.synchronize()
+                eng.set_option("overlap_cold_calls", 1)
+                stf = eng.create_seed_matrix()                                          # the B that is compared: one more cold call on the timed matrix
+                v = eng.device_view()
+                t0 = time.perf_counter()
+                colptr = host_copy(v["a_colptr"], v["N"] + 1, np.uint32); csc = host_copy(v["a_csc"], v["Z"], np.uint64)
+                of = po.Oracle(k, lo, up)
+                of.set_csc(int(v["M"]), int(v["N"]), colptr, csc, ncall)
+                t_load = time.perf_counter() - t0
+                del colptr, csc
+                t0 = time.perf_counter(); of.spgemm(ncall); t_all = time.perf_counter() - t0
+                t0 = time.perf_counter()
+                g_rowptr = host_copy(v["b_rowptr"], v["M"] + 1, np.int64); g_col = host_copy(v["b_col"], v["Y"], np.uint32)
+                g_val = host_copy(v["b_val"], v["Y"], np.dtype([("q0", "<u4"), ("t0", "<u4"), ("q1", "<u4"), ("t1", "<u4"), ("numshared", "<i4")]))
+                ndiff = of.compare_B(g_rowptr, g_col, g_val, ncall)
+                t_cmp = time.perf_counter() - t0
+                same_counts = bool(stf["nnz"] == of.stat("Y") and stf["products"] == of.stat("P") and stf["nnz_before_prune"] == of.stat("Yraw")
+                                   and stf["nnz_upper"] == of.stat("nupper") and stf["max_numshared"] == of.stat("maxshared"))
+                full = {"value": round(of.stat("Y") / t_all, 1), "unit": "overlap nnz/s", "cores": ncall, "seconds": round(t_all, 3),
+                        "sample": "the WHOLE %s matrix (%d reads, nnz(A) = %d, P = %d products, Y = %d): the SpGEMM region once on %d host threads (OpenMP, dynamic rows), "
+                                  "oracle/elba_oracle.c orc_spgemm, gcc -O3" % (args.workload, v["M"], v["Z"], of.stat("P"), of.stat("Y"), ncall),
+                        "load_seconds": round(t_load, 3), "compare_seconds": round(t_cmp, 3),
+                        "parity_vs_oracle_full": bool(ndiff == 0 and same_counts), "entries_that_differ": int(ndiff)}
+                del of, g_rowptr, g_col, g_val
+        if full is not None and "value" in full:
+            cpu = dict(full, kind="port", one_core_on_a_sample=one_core)
+        elif full is not None:
+            cpu["whole_matrix"] = full
         # the k-mer stage and the whole reads -> B region on the host (reference timers src/main.cpp:191-282): the oracle's count_and_build is a
         # scalar port (1 core), timed on a third of the SpGEMM sample's genome so that it stays within ~10 s
         kp, ko, kl, _ = elba_amd.synth_reads(w["seed"], max(20000, w["genome"] // (div * 3)), w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"],
@@ -359,7 +458,10 @@ def main():
             "value": round(Y / (dt / steps), 1), "unit": "overlap nnz/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak" if (args.weak and world > 1) else "strong", "vs_baseline": None, "dtype": "u32",
             "data": "synthetic",
-            "transport": ("RCCL (torch.distributed backend nccl)" if backend == "nccl" else "REHEARSAL: %s over host copies, %d processes on %d device(s) — not a scaling measurement" % (backend, world, torch.cuda.device_count())) if dist is not None else None,
+            "transport": None if dist is None else {
+                "backend": "RCCL (torch.distributed backend nccl)" if backend == "nccl" else "REHEARSAL: %s over host copies, %d processes on %d device(s) — not a scaling measurement" % (backend, world, torch.cuda.device_count()),
+                "world": world, "rccl_version": ".".join(str(x) for x in torch.cuda.nccl.version()) if backend == "nccl" else None,
+                "per_rank_overlap_nnz": [r["nnz"] for r in rank_phases] if rank_phases else None},
             "config": dict({"workload": args.workload, "reads": int(info["total_reads"]) if "total_reads" in info else int(info["nreads"]), "k": k, "lower": lo, "upper": up,
                             "genome": w["genome"] * (world if args.weak else 1), "depth": w["depth"], "error": w["error"], "kmer_instances": I_tot, "nnz_A": Z_tot,
                             "products": P, "overlap_nnz": Y, "algorithmic_bytes": abytes,
@@ -367,6 +469,9 @@ def main():
             "roofline": roofline,
             "cpu_baseline": cpu,
             "parity_vs_oracle_on_cpu_sample": parity,
+            "parity_vs_oracle_full": (cpu or {}).get("parity_vs_oracle_full"),
+            "counts_match_one_gpu": counts_ok, "counts": dict(zip(("kmer_instances", "nnz_A", "products", "overlap_nnz"), got_counts)),
+            "counts_expected": None if expect is None else list(expect),
             "steady_state": steady,
             "kmer_stage": kmer_stage,
             "end_to_end": end_to_end,
@@ -389,6 +494,11 @@ def main():
     if dist is not None:
         dist.barrier()
         (dist.d if backend != "nccl" else dist).destroy_process_group()
+    if counts_ok is False:
+        # every rank holds the all-reduced counts: all of them leave with the same code
+        if rank == 0:
+            print("bench.py: counts %s differ from the one-GPU build's %s" % (got_counts, tuple(expect)), file=sys.stderr, flush=True)
+        sys.exit(3)
 
 
 def run_aux(eng, packed, off, lens, k, lo, up, device):

@@ -461,6 +461,99 @@ int orc_set_triples(orc_ctx *c, int64_t M, int64_t N, int64_t Z, const int64_t *
 }
 
 /*
+ * The same hand-over for a matrix of BASELINE size (bench.py's cpu_baseline leg on the whole headline matrix: qsort of 5 * 10^8 triples would
+ * take minutes).  Input: the columns of A already in the order of the reference's AT (src/main.cpp:272-273) — colptr[N+1] (u32) and
+ * csc[Z] = read << 32 | pos, entries of a column in (read, pos) order.  CSR is derived here: a stable counting sort by read keeps, for
+ * every row, the columns ascending and the positions ascending within a column, i.e. (kid, pos) order.  Threads own disjoint row ranges
+ * (each scans all columns and takes its rows' entries).  Returns -2 on an index out of range or a column out of order.
+ */
+int orc_set_csc(orc_ctx *c, int64_t M, int64_t N, int64_t Z, const uint32_t *colptr32, const uint64_t *csc, int nthreads)
+{
+    orc_free_A(c); orc_free_B(c);
+    if (nthreads < 1) nthreads = 1;
+    c->M = M; c->N = N; c->Z = Z; c->I = 0; c->ndistinct = 0;
+    c->kmers = NULL; c->kmers_lo = NULL; c->kmers_lo2 = NULL;
+    c->colptr = (int64_t *)calloc((size_t)(N + 2), sizeof(int64_t));
+    c->csc_read = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->csc_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->rowptr = (int64_t *)calloc((size_t)(M + 2), sizeof(int64_t));
+    c->csr_kid = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->csr_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    int bad = 0;
+    if (colptr32[0] != 0 || (int64_t)colptr32[N] != Z) return -2;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(|:bad)
+#endif
+    for (int64_t kcol = 0; kcol < N; ++kcol) {
+        c->colptr[kcol] = colptr32[kcol];
+        if (colptr32[kcol + 1] < colptr32[kcol]) { bad = 1; continue; }
+        for (int64_t f = colptr32[kcol]; f < colptr32[kcol + 1]; ++f) {
+            const uint64_t e = csc[f];
+            if ((int64_t)(e >> 32) >= M) bad = 1;
+            if (f > colptr32[kcol] && csc[f - 1] > e) bad = 1;         /* (read, pos) ascending inside a column */
+            c->csc_read[f] = (uint32_t)(e >> 32); c->csc_pos[f] = (uint32_t)e;
+        }
+    }
+    c->colptr[N] = Z;
+    if (bad) return -2;
+    /* row counts: every thread counts the rows of its own range */
+    int64_t *cnt = (int64_t *)calloc((size_t)(M + 1), sizeof(int64_t));
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int t = 0, T = 1;
+#endif
+        const int64_t r0 = M * t / T, r1 = M * (t + 1) / T;
+        for (int64_t f = 0; f < Z; ++f) { const int64_t r = (int64_t)(csc[f] >> 32); if (r >= r0 && r < r1) cnt[r]++; }
+    }
+    for (int64_t i = 0; i < M; ++i) c->rowptr[i + 1] = c->rowptr[i] + cnt[i];
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+#ifdef _OPENMP
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+#else
+        const int t = 0, T = 1;
+#endif
+        const int64_t r0 = M * t / T, r1 = M * (t + 1) / T;
+        for (int64_t i = r0; i < r1; ++i) cnt[i] = c->rowptr[i];
+        for (int64_t kcol = 0; kcol < N; ++kcol)
+            for (int64_t f = colptr32[kcol]; f < colptr32[kcol + 1]; ++f) {
+                const int64_t r = (int64_t)(csc[f] >> 32);
+                if (r >= r0 && r < r1) { const int64_t d = cnt[r]++; c->csr_kid[d] = (uint32_t)kcol; c->csr_pos[d] = (uint32_t)csc[f]; }
+            }
+    }
+    free(cnt);
+    return 0;
+}
+
+/*
+ * Entry-by-entry comparison of a CSR B handed in (row pointers i64[M+1], columns u32[Y], values 20 bytes each in orc_seed_t's field order)
+ * with this context's B: the number of rows whose extent differs + the number of entries whose column or value differs; -1 if M or Y differ.
+ * (bench.py: the GPU's B of the whole headline matrix against the oracle's, without a Python-side copy of either.)
+ */
+int64_t orc_compare_B(const orc_ctx *c, int64_t M, int64_t Y, const int64_t *rowptr, const uint32_t *col, const orc_seed_t *val, int nthreads)
+{
+    if (!c->b_rowptr || M != c->M || Y != c->Y) return -1;
+    if (nthreads < 1) nthreads = 1;
+    int64_t diff = 0;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static) reduction(+:diff)
+#endif
+    for (int64_t i = 0; i < M; ++i) {
+        if (rowptr[i] != c->b_rowptr[i] || rowptr[i + 1] != c->b_rowptr[i + 1]) { ++diff; continue; }
+        for (int64_t e = rowptr[i]; e < rowptr[i + 1]; ++e)
+            if (col[e] != c->b_col[e] || memcmp(&val[e], &c->b_val[e], sizeof(orc_seed_t)) != 0) ++diff;
+    }
+    return diff;
+}
+
+/*
  * a13: B = A*A^T over SharedSeeds::Semiring, then Prune(numshared <= 1)  (src/SharedSeeds.cpp:4-10).
  * Row-by-row Gustavson with a dense accumulator; for row i the products are visited in ascending
  * (kid, posQ, posT) order and combined by a LEFT fold of Semiring::add (include/SharedSeeds.hpp:41-46), so

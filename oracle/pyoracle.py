@@ -73,6 +73,10 @@ def lib():
         L.orc_count_and_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
         L.orc_set_triples.restype = C.c_int
         L.orc_set_triples.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_set_csc.restype = C.c_int
+        L.orc_set_csc.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int]
+        L.orc_compare_B.restype = C.c_int64
+        L.orc_compare_B.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_spgemm.restype = C.c_int
         L.orc_spgemm.argtypes = [C.c_void_p, C.c_int]
         L.orc_export_dcsc.restype = C.c_int
@@ -181,6 +185,20 @@ class Oracle:
         rc = self.L.orc_set_triples(self.h, M, N, len(rows), rows.ctypes.data, cols.ctypes.data, vals.ctypes.data)
         if rc:
             raise RuntimeError("orc_set_triples failed: %d" % rc)
+
+    def set_csc(self, M, N, colptr_u32, csc_u64, nthreads=1):
+        """A from its columns in the reference's AT order (colptr u32[N+1], entries read << 32 | pos in (read, pos) order); CSR is derived."""
+        colptr_u32 = np.ascontiguousarray(colptr_u32, dtype=np.uint32); csc_u64 = np.ascontiguousarray(csc_u64, dtype=np.uint64)
+        assert len(colptr_u32) == N + 1
+        rc = self.L.orc_set_csc(self.h, M, N, len(csc_u64), colptr_u32.ctypes.data, csc_u64.ctypes.data, int(nthreads))
+        if rc:
+            raise RuntimeError("orc_set_csc failed: %d" % rc)
+
+    def compare_B(self, rowptr_i64, col_u32, val_seed, nthreads=1):
+        """rows + entries in which a CSR B (i64 row pointers, u32 columns, 20-byte values) differs from the oracle's; -1: other shape"""
+        rowptr_i64 = np.ascontiguousarray(rowptr_i64, dtype=np.int64); col_u32 = np.ascontiguousarray(col_u32, dtype=np.uint32)
+        assert val_seed.dtype.itemsize == 20 and val_seed.flags["C_CONTIGUOUS"]
+        return int(self.L.orc_compare_B(self.h, len(rowptr_i64) - 1, len(col_u32), rowptr_i64.ctypes.data, col_u32.ctypes.data, val_seed.ctypes.data, int(nthreads)))
 
     def spgemm(self, nthreads=1):
         rc = self.L.orc_spgemm(self.h, nthreads)

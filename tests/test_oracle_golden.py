@@ -219,6 +219,33 @@ def test_triples_entry_reproduces_B():
     assert (B["rowptr"] == B2["rowptr"]).all() and (B["col"] == B2["col"]).all() and (B["val"] == B2["val"]).all()
 
 
+def test_column_hand_over_and_B_comparison():
+    """The hand-over bench.py uses for the whole headline matrix: A given as its columns (u32 pointers, read << 32 | pos in (read, pos)
+    order), CSR derived by row ranges on several threads; and the entry-by-entry comparison of a foreign B."""
+    m = util.golden_meta()["small_err"][0]
+    buf, off, lens = po.pack_reads(util.read_fasta(os.path.join(G, "small_err.fa")))
+    o = po.Oracle(m["k"], m["lower"], m["upper"])
+    o.count_and_build(buf, off, lens); o.spgemm(1)
+    A, B = o.A(), o.B()
+    csc = (A["csc_read"].astype(np.uint64) << np.uint64(32)) | A["csc_pos"].astype(np.uint64)
+    for threads in (1, 3):
+        o2 = po.Oracle(m["k"], m["lower"], m["upper"])
+        o2.set_csc(A["M"], A["N"], A["colptr"].astype(np.uint32), csc, threads)
+        A2 = o2.A()
+        for key in ("colptr", "csc_read", "csc_pos", "rowptr", "csr_kid", "csr_pos"):
+            assert (A[key] == A2[key]).all(), key
+        o2.spgemm(threads)
+        assert o2.compare_B(B["rowptr"], B["col"], B["val"], threads) == 0
+    v = B["val"].copy(); v["t1"][5] ^= 1
+    c = B["col"].copy(); c[7] += 1
+    assert o.compare_B(B["rowptr"], B["col"], v, 2) == 1 and o.compare_B(B["rowptr"], c, v, 2) == 2
+    assert o.compare_B(B["rowptr"][:-1], B["col"], B["val"]) == -1
+    bad = csc.copy(); bad[[0, 1]] = bad[[1, 0]]
+    if A["colptr"][1] >= 2 and bad[0] != bad[1]:
+        with pytest.raises(RuntimeError):
+            po.Oracle(m["k"], m["lower"], m["upper"]).set_csc(A["M"], A["N"], A["colptr"].astype(np.uint32), bad, 1)
+
+
 @pytest.mark.skipif(po.ref_lib(17) is None, reason="oracle/_ref not built (reference tree absent)")
 def test_live_against_reference_primitives():
     """Random cross-check against the reference's compiled Kmer/DnaSeq/HashFuncs (only where oracle/_ref exists)."""
