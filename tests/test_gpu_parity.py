@@ -357,20 +357,27 @@ def test_alternative_paths_kept_for_ab_runs_give_the_same_matrices(knob):
     e.close()
 
 
-def test_reference_kmer_numbering_through_set_kmer_matrix():
+@pytest.mark.parametrize("which", ["small_err_k17", "reads_ref_default_k31"])
+def test_reference_kmer_numbering_through_set_kmer_matrix(which):
     """A numbered the way a one-rank run of the reference numbers its k-mers (tests/golden/*.order: unordered_map
     iteration order replayed on the reference's compiled code) handed over as triples: the GPU's B equals the oracle's under THAT
-    numbering bit for bit (seeds = min / max product of that numbering), and its pattern and numshared equal the canonical B's."""
-    rd, ref_ids, ps, canon_ids, N, _ = util.libstdcxx_triples("small_err")
-    M = util.golden_meta()["small_err"][0]["M"]
-    e = elba_amd.Engine(17, 2, 8)
+    numbering bit for bit (seeds = min / max product of that numbering), and its pattern and numshared equal the canonical B's.
+    reads_ref_default_k31: the reference's default build (Makefile:1-3: k = 31, L = 15, U = 35) on its bundled reads.fa."""
+    if which == "small_err_k17":
+        k, lo, up = 17, 2, 8
+        rd, ref_ids, ps, canon_ids, N, _ = util.libstdcxx_triples("small_err")
+        M = util.golden_meta()["small_err"][0]["M"]
+    else:
+        k, lo, up = 31, 15, 35
+        M, N, rd, ref_ids, ps, canon_ids, _ = util.reference_default_triples()
+    e = elba_amd.Engine(k, lo, up)
     e.set_kmer_matrix(M, N, rd, ref_ids, ps)
     st = e.create_seed_matrix()
     gB = e.export_csr()
-    o = po.Oracle(17, 2, 8); o.set_triples(M, N, rd, ref_ids, ps); o.spgemm(2)
+    o = po.Oracle(k, lo, up); o.set_triples(M, N, rd, ref_ids, ps); o.spgemm(4)
     gu.assert_B_equal(gB, o.B())
     gu.assert_stats_equal(st, o)
-    oc = po.Oracle(17, 2, 8); oc.set_triples(M, N, rd, canon_ids, ps); oc.spgemm(2)
+    oc = po.Oracle(k, lo, up); oc.set_triples(M, N, rd, canon_ids, ps); oc.spgemm(4)
     Bc = oc.B()
     assert (gB["rowptr"] == Bc["rowptr"]).all() and (gB["col"] == Bc["col"].astype(np.int64)).all() and (gB["val"]["numshared"] == Bc["val"]["numshared"]).all()
     e.close()

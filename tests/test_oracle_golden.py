@@ -344,3 +344,18 @@ def test_reference_kmer_numbering_replay_matches_the_survey_and_leaves_pattern_a
         i, j, v = int(rows[x]), int(Br["col"][x]), Br["val"][x]
         lo, hi = best[(i, j)]
         assert (int(v["q0"]), int(v["t0"]), int(v["q1"]), int(v["t1"])) == (lo[1], lo[2], hi[1], hi[2])
+
+
+def test_reference_default_build_numbering_k31():
+    """The same for the reference's DEFAULT build (Makefile:1-3: k = 31, L = 15, U = 35) on its bundled reads.fa: the replay's N and keys after
+    pass 1 are the survey's figures from the reference's own KmerOps.cpp (105 754 and 146 244), the reliable set is the oracle's,
+    and pattern + numshared + every count do not depend on the numbering (P = 65 606 685, Y = 12 021 as measured there)."""
+    M, N, rd, ref_ids, ps, canon_ids, meta = util.reference_default_triples()
+    assert N == 105754 and int(meta["keys_after_pass1"]) == 146244 and len(rd) == 2579051
+    oc = po.Oracle(31, 15, 35); oc.set_triples(M, N, rd, canon_ids, ps); oc.spgemm(4)
+    orf = po.Oracle(31, 15, 35); orf.set_triples(M, N, rd, ref_ids, ps); orf.spgemm(4)
+    for o in (oc, orf):
+        assert (o.stat("P"), o.stat("Yraw"), o.stat("Y"), o.stat("nupper"), o.stat("maxshared")) == (65606685, 12021, 12021, 5897, 18074)
+    Bc, Br = oc.B(), orf.B()
+    assert (Bc["rowptr"] == Br["rowptr"]).all() and (Bc["col"] == Br["col"]).all() and (Bc["val"]["numshared"] == Br["val"]["numshared"]).all()
+    assert (Bc["val"] != Br["val"]).any()

@@ -57,9 +57,10 @@ def b_triplets(B):
 
 def read_order(path):
     """tests/golden/*.order: (k-mers by reference k-mer id, header fields) — see tests/golden/make_order_golden.py."""
-    head = open(path).readline()
+    op = (lambda: gzip.open(path, "rt")) if path.endswith(".gz") else (lambda: open(path))
+    head = op().readline()
     meta = {kv.split("=")[0]: float(kv.split("=")[1]) for kv in head.split() if "=" in kv}
-    km = np.array([int(line, 16) for line in open(path) if line[0] != "#"], dtype=np.uint64)
+    km = np.array([int(line, 16) for line in op() if line[0] != "#"], dtype=np.uint64)
     return km, meta
 
 
@@ -73,3 +74,20 @@ def libstdcxx_triples(name):
     id_of_value = {int(v): i for i, v in enumerate(order.tolist())}
     ref_ids = np.array([id_of_value[int(v)] for v in gk.tolist()], dtype=np.int64)
     return gr, ref_ids, gp, canon.astype(np.int64), len(uk), meta
+
+
+def reference_default_triples():
+    """The reference's DEFAULT build (Makefile:1-3: k = 31, L = 15, U = 35) on its bundled reads.fa, numbered the way a one-rank run of the
+    reference numbers its k-mers (tests/golden/reads_ref_k31_L15_U35.order.gz): (M, N, reads, reference ids, positions, canonical ids, header).
+    The entries come from the oracle's count (pinned to SURVEY.md App. B's N = 105 754, Z = 2 579 051 for this set)."""
+    from oracle import pyoracle as po
+    buf, off, lens = po.pack_reads(read_fasta(os.path.join(GOLDEN, "reads_ref.fa.gz")))
+    o = po.Oracle(31, 15, 35)
+    o.count_and_build(buf, off, lens)
+    A = o.A()
+    order, meta = read_order(os.path.join(GOLDEN, "reads_ref_k31_L15_U35.order.gz"))
+    assert len(order) == A["N"] and (np.sort(order) == A["kmers"]).all()          # the reference's map holds exactly the reliable k-mers
+    ref_of_canon = np.empty(A["N"], dtype=np.int64)
+    ref_of_canon[np.searchsorted(A["kmers"], order)] = np.arange(A["N"], dtype=np.int64)
+    canon = np.repeat(np.arange(A["N"], dtype=np.int64), np.diff(A["colptr"]))
+    return A["M"], A["N"], A["csc_read"].astype(np.int64), ref_of_canon[canon], A["csc_pos"], canon, meta
