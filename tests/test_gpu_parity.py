@@ -664,7 +664,7 @@ def test_mirror_slabs_of_any_size_give_the_same_matrix(shape):
         seen.append((cold, q16, pct, e.get_stat("overlap_slab_q16"), e.get_stat("overlap_mirror_placed")))
     by = {(c, q, p): (used, placed) for c, q, p, used, placed in seen}
     gen = by[(1, 1 << 18, 100)]                                       # four slab entries per row entry: generous for reads with errors ...
-    assert gen[0] > 3000 and gen[1] < by[(1, 3000, 100)][1] < by[(1, 400, 100)][1] < by[(1, 1, 100)][1], seen
+    assert gen[0] > 3000 and gen[1] <= by[(1, 3000, 100)][1] <= by[(1, 400, 100)][1] <= by[(1, 1, 100)][1] and gen[1] < by[(1, 1, 100)][1], seen
     if shape == "forced_ratio":
         assert gen == (1 << 18, 0), seen                              # ... nothing waits for k_mirror (the other shapes: the sample's own rows do / error-free reads stage a dozen entries per row entry)
     assert by[(1, 1, 100)][0] == 1 and 0 < by[(1, 1, 100)][1] <= nmir, seen       # 16 entries per row: most images take the old way
