@@ -41,6 +41,7 @@ WORKLOADS = {
     # profiling cases (single GPU; not the driver's line): BASELINE configs[3] at half the genome (the whole set — 4.0 G instances — runs too:
     # tests/test_gpu_configs.py) and configs[4] at 1/25 of it
     "hifi-half": dict(genome=50_000_000, depth=40.0, avg_len=15000.0, sd_len=2000.0, min_len=1000, error=0.005, k=17, lower=2, upper=4, seed=3),
+    "dense-repeats-8th": dict(genome=62_500_000, depth=40.0, avg_len=10000.0, sd_len=1000.0, min_len=1000, error=0.01, k=17, lower=2, upper=35, seed=4, repeats=(20, 0.05, 5000)),      # ONE GPU's share of configs[4] at N = 8 (250 000 reads)
     "dense-repeats-25th": dict(genome=20_000_000, depth=40.0, avg_len=10000.0, sd_len=1000.0, min_len=1000, error=0.01, k=17, lower=2, upper=35, seed=4, repeats=(20, 0.05, 5000)),
 }
 PEAK_GBS = 8000.0          # HBM3E peak, MI355X_MICROARCH.md

@@ -10,7 +10,8 @@ At these sizes the oracle cannot rerun the whole pipeline in seconds, so every c
   config 3  200 100 reads x 10 kb, 66.7 Mb genome, 30x, 15 % error, U = 8: as written, whole, on one GPU
   config 4  C. elegans-HiFi-like, 100 Mb genome, 40x, 0.5 % error, U = 4: as written, whole, on one GPU (266 666 reads of 15 kb, 4.0 G k-mer
             instances: just inside one context's 32-bit instance index, two index bits dropped from the sort words and recovered)
-  config 5  20 repeat families, 1 % error, U = 35: 1/25 of the genome (80 k reads, 10.8 G products): the dense / spill stress at a size one GPU holds
+  config 5  20 repeat families, 1 % error, U = 35: 1/25 of the genome (80 k reads, 10.8 G products): the dense / spill stress at a size one GPU holds;
+            and at 1/8 — ONE GPU's share of the 8-GPU run, 250 000 reads — whole and through row-block batching (the last test but three)
 """
 import os
 
@@ -249,6 +250,57 @@ def test_baseline_config_properties_and_sampled_rows(name):
     n2 = int(B2["rowptr"][-1])
     assert (B2["rowptr"] == B["rowptr"][:len(B2["rowptr"])]).all() and (B2["col"] == B["col"][:n2]).all() and (B2["val"] == B["val"][:n2]).all()
     e.close()
+
+
+def test_config5_one_gpus_share_whole_and_through_row_blocks():
+    """BASELINE configs[4] (2 M reads, 20 repeat families, U = 35, 8 GPUs) at ONE GPU's share of it: an eighth of the genome, 250 000 reads,
+    2.5 G k-mer instances, nnz(A) ~ 1.1 G — the size row-block batching and the dense path were built for (VERDICT r3 task 4).
+      (1) whole, in one context: properties, A against the oracle on value classes, sampled rows of B against the oracle;
+      (2) the way a rank of the 8-GPU run walks its rows (elba_amd/distributed.py: build_kmer_matrix(row_batches=b) -> load_row_block(t) ->
+          create_seed_matrix per block; the panel exchange and the owner-side count run with world = 1): the union of the blocks' rows
+          equals the whole matrix bit for bit."""
+    import dist_sim
+    from elba_amd.distributed import DistributedOverlap, HipBackend
+    w = dict(seed=4, genome=62_500_000, depth=40.0, avg=10000.0, sd=1000.0, err=0.01, min_len=1000, k=17, L=2, U=35, rep=(20, 0.05, 5000))
+    packed, off, lens, info = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg"], w["sd"], error_rate=w["err"], min_len=w["min_len"],
+                                                   repeat_families=w["rep"][0], repeat_fraction=w["rep"][1], repeat_len=w["rep"][2])
+    assert 240_000 <= len(lens) <= 260_000
+    k = w["k"]
+    e = elba_amd.Engine(k, w["L"], w["U"])
+    e.set_reads(packed, off, lens)
+    ks = e.count_kmers(); ms = e.create_kmer_matrix()
+    assert ks["instances"] == int(np.maximum(lens.astype(np.int64) - k + 1, 0).sum()) and ms["nnz"] == ks["entries"] and ms["ncols"] == ks["reliable"]
+    assert e.device_view()["a_csr_format"] == 2                       # ELBA_CSR_DENSE: the dense path
+    st = e.create_seed_matrix()
+    B = e.export_csr()
+    _properties(e, B, st, ks, packed, off, lens, k, w["U"])
+    nk, nr = _A_equals_oracle_on_value_classes(e, packed, off, lens, k, w["L"], w["U"], nclasses=16, nrows=100)
+    assert nk > 1000 and nr >= 100
+    assert _sampled_rows_equal_oracle(e, B, k, w["L"], w["U"], 40) >= 40
+    whole = dict(products=st["products"], nnz=st["nnz"])
+    e.close()
+    nblocks = 4
+    bounds = np.array([0, len(lens)], dtype=np.int64)
+
+    def body(rank, h):
+        d = DistributedOverlap(k, w["L"], w["U"], device=0, rank=0, world=1, dist=h, backend=HipBackend(k, w["L"], w["U"], 0))
+        d.set_reads(packed, off, lens, 0, bounds)
+        d.build_kmer_matrix(row_batches=nblocks)
+        rows, fmt, nnz = [], 2, 0
+        for t in range(nblocks):
+            d.load_row_block(t)
+            fmt = min(fmt, d.be.e.device_view()["a_csr_format"])
+            s2 = d.create_seed_matrix()
+            nnz += s2["nnz"]
+            rows.append(d.export_csr())
+        d.be.e.close()
+        return dist_sim.stitch_rows(rows), fmt, nnz
+
+    Bb, fmt, nnz = dist_sim.run_ranks(1, body)[0]
+    assert fmt == 2 and nnz == whole["nnz"]                           # every row block took the dense path
+    assert Bb["Y"] == B["Y"] and (Bb["rowptr"] == B["rowptr"]).all() and (Bb["col"] == B["col"]).all()
+    bad = np.nonzero(Bb["val"] != B["val"])[0]
+    assert len(bad) == 0, (len(bad), Bb["val"][bad[:4]], B["val"][bad[:4]])
 
 
 def test_distributed_driver_over_rccl_world_of_one():
