@@ -314,6 +314,13 @@ class DistributedOverlap:
         info["total_reads"] = total
         return info
 
+    def _release_cached(self):
+        """Exchange buffers are torch tensors of tens of GB (config 5: 40 GB of instances per rank); freed ones stay in torch's caching
+        allocator, where the library's own hipMalloc cannot reach them — hand them back to the device."""
+        t = getattr(self.be, "torch", None)
+        if t is not None and t.cuda.is_available():
+            t.cuda.empty_cache()
+
     # ---- collectives ------------------------------------------------------------------------------------------------
     def _exchange_counts(self, counts, with_max=False):
         """counts[p] = records this rank sends to rank p -> what it receives from every rank.  with_max: every rank also learns the largest
@@ -399,6 +406,7 @@ class DistributedOverlap:
         self.be.fill_send(W, send, np.concatenate([[0], np.cumsum(sc)[:-1]]))
         recv = self._all_to_all_records(send, sc, rc)
         del send
+        self._release_cached()
         ks = self.be.count_records(recv)
         # global k-mer ids: the owners hold ascending value ranges, so id = exclusive scan of the owners' counts + local index
         # (src/KmerOps.cpp:371-375: MPI_Exscan of the local map sizes) — one all-gather of W integers, no k-mer leaves its owner
@@ -409,6 +417,7 @@ class DistributedOverlap:
         n_total = int(sum(ns))
         self.be.set_kmer_id_base(int(sum(ns[:self.rank])), n_total)
         del recv
+        self._release_cached()
         self.n_total = n_total
         ks = dict(ks)
         ks["instances"] = int(sc.sum())          # instances enumerated from THIS rank's reads
@@ -446,6 +455,7 @@ class DistributedOverlap:
             self.be.panel_fill_win(W, self.bounds, wl, wh, send, np.concatenate([[0], np.cumsum(pc)[:-1]]))
         panel = self._all_to_all_records(send, pc, prc)
         del send
+        self._release_cached()
         m_total = int(self.bounds[-1])
         # inline partners follow the pair-ownership rule of the mirror exchange (the parity rule over ALL rows): the panel gets them when that is how
         # it will be multiplied; a call without the exchange on such a panel reloads it without them (create_seed_matrix)
@@ -456,6 +466,8 @@ class DistributedOverlap:
         self._cur_block = t
         self.block = self.row_block(self.rank, t) if self.row_batches > 1 else (int(self.bounds[self.rank]), int(self.bounds[self.rank + 1]))
         ms = dict(self.be.set_panel(panel, m_total, self.n_total, self.block[0], self.block[1]))
+        del panel
+        self._release_cached()
         ms["panel_records"] = int(prc.sum())
         self.panel_records = int(prc.sum())
         self._slot = 0                    # a new panel: the slot size of the mirror exchange is guessed afresh
