@@ -104,7 +104,8 @@ class DeviceView(C.Structure):
     _fields_ = [("M", C.c_int64), ("N", C.c_int64), ("Z", C.c_int64), ("Y", C.c_int64),
                 ("a_rowptr", C.c_void_p), ("a_csr", C.c_void_p), ("a_colptr", C.c_void_p), ("a_csc", C.c_void_p),
                 ("b_rowptr", C.c_void_p), ("b_col", C.c_void_p), ("b_val", C.c_void_p), ("stream", C.c_void_p),
-                ("a_csr_format", C.c_uint32), ("a_csr_pos_mask", C.c_uint32), ("a_kmers", C.c_void_p)]
+                ("a_csr_format", C.c_uint32), ("a_csr_pos_mask", C.c_uint32), ("a_kmers", C.c_void_p),
+                ("a_gather_slots", C.c_int64), ("a_slot_kid", C.c_void_p)]
 
 
 class SynthCfg(C.Structure):

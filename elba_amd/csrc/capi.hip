@@ -514,7 +514,9 @@ int elba_get_device_view(elba_ctx *ctx, elba_device_view *v)
         if (c.have_A) { v->M = c.M; v->N = c.N; v->Z = c.Z; v->a_rowptr = c.a_rowptr.p; v->a_csr = c.a_csr.p; v->a_colptr = c.a_colptr.p; v->a_csc = c.a_csc.p;
                         v->a_csr_format = c.csr_inline ? ELBA_CSR_INLINE : (c.csr_suffix ? ELBA_CSR_DENSE : (c.csr_hints ? ELBA_CSR_HINTS : ELBA_CSR_PLAIN));
                         v->a_csr_pos_mask = c.csr_suffix ? 0xFFFFu : (c.csr_hints ? 0x3FFFFFFFu : 0xFFFFFFFFu);
-                        v->a_kmers = c.A_has_kmers ? c.rel_kmers.p : nullptr; }
+                        v->a_kmers = c.A_has_kmers ? c.rel_kmers.p : nullptr;
+                        v->a_gather_slots = c.use_ell && c.ell_compact ? c.ell_nslots : 0;
+                        v->a_slot_kid = c.use_ell && c.ell_compact ? c.ell_slot_kid.p : nullptr; }
         if (c.have_B) { v->Y = c.Y; v->b_rowptr = c.b_rowptr.p; v->b_col = c.b_col.p; v->b_val = c.b_val.p; }
     });
 }
@@ -525,7 +527,7 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         ELBA_REQUIRE(name, ELBA_ERR_INVALID_ARG, "set_option: null name");
         struct { const char *n; bool *b; } flags[] = {
             {"overlap_cold_calls", &c.cold_calls}, {"no_symmetry", &c.opt.no_symmetry}, {"no_ell", &c.opt.no_ell}, {"no_pay", &c.opt.no_pay}, {"mir32", &c.opt.mir32},
-            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_slab", &c.opt.no_slab}, {"no_suffix", &c.opt.no_suffix}, {"no_row_order", &c.opt.no_row_order}, {"no_inline", &c.opt.no_inline}, {"panel_inline", &c.opt.panel_inline}, {"kmer_pairs", &c.opt.kmer_pairs},
+            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_slab", &c.opt.no_slab}, {"no_ell_compact", &c.opt.no_ell_compact}, {"no_suffix", &c.opt.no_suffix}, {"no_row_order", &c.opt.no_row_order}, {"no_inline", &c.opt.no_inline}, {"panel_inline", &c.opt.panel_inline}, {"kmer_pairs", &c.opt.kmer_pairs},
             {"kmer_unfused", &c.opt.kmer_unfused}, {"kmer_no_msd", &c.opt.kmer_no_msd}, {"kmer_msd", &c.opt.kmer_msd}, {"csr_pairs", &c.opt.csr_pairs}, {"emit_plain", &c.opt.emit_plain}, {"trace", &c.opt.trace}};
         for (auto &f : flags) if (!strcmp(name, f.n)) { *f.b = value != 0; return; }
         if (!strcmp(name, "kmer_drop")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: kmer_drop is 0..3"); c.opt.kmer_drop = (int)value; }
@@ -548,11 +550,12 @@ int elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value)
         ELBA_REQUIRE(name && value, ELBA_ERR_INVALID_ARG, "get_stat: null name or value");
         if (!strcmp(name, "overlap_mirror_placed")) *value = c.ov_mir_placed;
         else if (!strcmp(name, "overlap_slab_q16")) *value = (int64_t)c.ov_slab_q16_used;
+        else if (!strcmp(name, "gather_slots")) *value = c.have_A && c.use_ell ? c.ell_nslots : 0;
         else if (!strcmp(name, "resident_bytes_A")) {
             int64_t b = 0;
             if (c.have_A) {
                 b = (int64_t)(c.M + 1) * 4 + (int64_t)(c.N + 1) * 4 + 16 * c.Z;
-                if (c.use_ell) b += 8 * c.N * (int64_t)c.s_stride;
+                if (c.use_ell) b += 8 * c.ell_nslots * (int64_t)c.s_stride + (c.ell_compact ? 4 * c.ell_nslots : 0);
                 if (c.csr_suffix) b += (4ll * c.N) << c.j_shift;
             }
             *value = b;

@@ -136,6 +136,7 @@ struct Options {
     bool mir32 = false;         // 32-byte staging / mirror records instead of 16-byte words
     bool no_hints = false;      // no ownership bits in the rows of A
     bool no_sample = false;     // a cold call does not compute a sample of rows first
+    bool no_ell_compact = false;// k-mer stage: the padded column store holds every column, row entries name k-mer ids (no gather slots)
     bool no_slab = false;       // SpGEMM: mirrored entries wait in the staging area for k_mirror instead of going straight to their row's slab (spgemm.hip: "mirror slabs")
     int slab_pct = 175;         // SpGEMM: a row's slab holds this many percent of the mirrored entries the measured ratio predicts for it (+ SLAB_PAD)
     int slab_q16 = 0;           // test hook: slab entries per row entry of A in 1/65536 units, instead of the measured ratio (small matrices take no sample)
@@ -215,6 +216,11 @@ struct Ctx {
     DevBuf a_ell;                              // u64[N * s_stride]: the columns padded to a common stride (entries, then all ones) — the column store the
                                                // SpGEMM gathers from when no column is longer than 64 entries: column kid starts at kid * s_stride, no pointer
     bool use_ell = false;
+    // gather slots (kmer_msd.hip, BucketOut): with inline partners the padded store holds only the columns some row entry still fetches; such an entry
+    // names its column's slot in the id field of its a_csr word (the others keep the k-mer id), ell_slot_kid[slot] = k-mer id.  Not compact: slot == k-mer id.
+    bool ell_compact = false;
+    int64_t ell_nslots = 0, ell_cap_cols = 0;  // slots in use (compact: an upper bound, chunks are drawn whole) / columns the store was sized for
+    DevBuf ell_slot_kid;                       // u32[ell_nslots]
     DevBuf a_ellj;                             // u32[N << j_shift]: the partner reads of every column, right-aligned in an aligned block of 32 or 64 slots (dense matrices, Ctx::csr_suffix)
     DevBuf row_order, row_label, row_keys; bool have_row_order = false;      // u32[M] each, dense matrices: the rows sorted by their smallest k-mer id (label -> row) and its inverse (row -> label); a_ellj then names partners by label
     uint32_t j_shift = 5;

@@ -334,7 +334,15 @@ struct BucketOut {
     uint32_t hints;           // write the ownership bits (Ctx::csr_hints)
     uint32_t inl;             // Ctx::csr_inline (0: off, else pbi = position bits of an inline key): the owning row's key of a two-read column is
                               // 1 << 63 | read << rs | (partner >> 1) << 2 pbi | posQ << pbi | posT — when both positions fit pbi bits
+    // Gather slots (Ctx::ell_compact, with inline partners): four columns in five are never fetched by the SpGEMM — every entry of theirs either
+    // carries its product inline or is hinted "no pair owned".  The padded store then holds only the columns some entry still gathers, one after
+    // the other in the order the buckets draw their slots (slot_cursor; a workgroup draws SLOT_CHUNK at a time), and a row entry that gathers
+    // names its column's SLOT where the others name the k-mer id (the SpGEMM multiplies whichever it finds by the stride; a sequence number is
+    // the entry's rank in its row, never the id).  slot_kid[slot] = k-mer id, for exports and tests.  8 N S bytes were written before (14.8 GB on
+    // BASELINE config 3), 8 S per gathered column now.
+    unsigned long long *slot_cursor; uint32_t *slot_kid; uint32_t compact;
 };
+constexpr uint32_t SLOT_CHUNK = 4096;
 
 // ---- buckets: count ------------------------------------------------------------------------------------------------------------------
 // One workgroup per bucket (the instances whose top 2k - 16 value bits agree).  The 16 value bits left index a table of 16-bit counters in LDS
@@ -459,6 +467,10 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
     constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, NH = ES_KPT * 4;      // entries; (u, wavefront) head counts
     __shared__ uint64_t A[ES_CAP];
     __shared__ uint32_t sbcnt[ES_NSB], sbstart[ES_NSB + 1], H[ES_CAP / 2 + 2], hcnt[NH + 1], wsum[4];
+    __shared__ uint16_t GL[ES_CAP / 2 + 2];            // gather slots: the bucket's columns that some entry still fetches, in the order their heads drew a place
+    __shared__ uint32_t gmisc[4];                      // 0: columns that need a slot, 1: the bucket's first slot
+    constexpr uint32_t HPOS = 0x3FFFu, HNEED = 0x80000000u;      // H[column] = head place | local slot << 14 | HNEED
+    unsigned long long slot_next = 0; uint32_t slot_left = 0;    // (thread 0) what is left of the chunk of slots this workgroup drew
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t lt = (1ull << lane) - 1;
     const uint64_t paymask = (1ull << m.PB) - 1, posmask = (1ull << m.pbits) - 1;
@@ -549,14 +561,15 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
             slot[u] = hcnt[u * 4 + wv] + slot[u] - 1u;                      // the column of place u * 256 + tid
             if ((headmask >> u) & 1u) H[slot[u]] = (uint32_t)u * ES_THREADS + tid;
         }
-        if (tid == 0) H[Nb] = Z;
+        if (tid == 0) { H[Nb] = Z; gmisc[0] = 0; }
         lds_sync();
+        uint32_t needmask = 0;      // bit u: the entry at place u * 256 + tid fetches its column (its key waits for the column's slot)
 #pragma unroll
         for (int u = 0; u < ES_KPT; ++u) {
             const uint32_t p = (uint32_t)u * ES_THREADS + tid;
             if (p < Z) {
                 const uint64_t x = A[p];
-                const uint32_t kl = slot[u], h0 = H[kl], L = H[kl + 1] - h0;
+                const uint32_t kl = slot[u], h0 = H[kl] & HPOS, L = (H[kl + 1] & HPOS) - h0;
                 const uint64_t read = (x & paymask) >> m.pbits, pos = x & posmask;
                 uint64_t hint = 0, oread = 0, opos = 0;
                 uint32_t nown = 0, mult = 0;
@@ -583,9 +596,13 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 uint64_t word = (read << o.rs) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
                 // Ctx::csr_inline: a row that accumulates exactly ONE pair of this column (always so for the owner of a two-read column) carries that
                 // pair in its own entry — the SpGEMM then fetches no column for it
-                if (o.inl && mult == 1u && nown == 1u && ((pos | opos) >> o.inl) == 0)
-                    word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
-                if (o.csr_words) o.csr_words[z] = word;
+                const bool isinl = o.inl && mult == 1u && nown == 1u && ((pos | opos) >> o.inl) == 0;
+                if (isinl) word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
+                if (o.compact && !isinl && hint == 0) {      // this entry fetches its column: the column needs a gather slot, the key names it (below)
+                    needmask |= 1u << u;
+                    atomicOr(&H[kl], HNEED);
+                }
+                else if (o.csr_words) o.csr_words[z] = word;
                 else o.kid_of_entry[z] = kid;
                 if ((headmask >> u) & 1u) {
                     const uint64_t value = ((uint64_t)b << VBITS) | ((uint32_t)(x >> m.PB) & 0xFFFFu);
@@ -593,7 +610,46 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 }
             }
         }
-        if (o.ell_stride) {
+        if (o.compact) {
+            lds_sync();                                                  // every entry has flagged its column
+#pragma unroll
+            for (int u = 0; u < ES_KPT; ++u)
+                if (((headmask >> u) & 1u) && (H[slot[u]] & HNEED)) {    // the head of a column that is fetched draws the column's place among the bucket's slots
+                    const uint32_t ls = atomicAdd(&gmisc[0], 1u);
+                    H[slot[u]] |= ls << 14; GL[ls] = (uint16_t)slot[u];
+                }
+            lds_sync();
+            if (tid == 0) {
+                const uint32_t n = gmisc[0];
+                unsigned long long base = slot_next;
+                if (n > slot_left) {                                     // a new chunk (what is left of the old one stays unused: slots need not be dense)
+                    const uint32_t take = n > SLOT_CHUNK ? n : SLOT_CHUNK;
+                    base = atomicAdd(o.slot_cursor, (unsigned long long)take);
+                    slot_next = base; slot_left = take;
+                }
+                slot_next += n; slot_left -= n;
+                gmisc[1] = (uint32_t)base;
+            }
+            lds_sync();
+            const uint32_t gb = gmisc[1], ng = gmisc[0];
+#pragma unroll
+            for (int u = 0; u < ES_KPT; ++u)
+                if ((needmask >> u) & 1u) {
+                    const uint32_t p = (uint32_t)u * ES_THREADS + tid;
+                    const uint64_t x = A[p];
+                    const uint64_t sid = (uint64_t)gb + ((H[slot[u]] >> 14) & 0x1FFFu);
+                    o.csr_words[eb + p] = (((x & paymask) >> m.pbits) << o.rs) | (sid << (o.pb + 2)) | (x & posmask);
+                }
+            const uint32_t S = o.ell_stride, nq = ng * S, sl = (S & (S - 1u)) ? 0u : (uint32_t)__ffs((int)S) - 1u;
+            uint64_t *dst = o.ell + (uint64_t)gb * S;
+            for (uint32_t q = tid; q < nq; q += ES_THREADS) {
+                const uint32_t ls = (S & (S - 1u)) ? q / S : q >> sl, j = q - ls * S, kl = GL[ls], h0 = H[kl] & HPOS;
+                uint64_t v = ~0ull;
+                if (h0 + j < (H[kl + 1] & HPOS)) { const uint64_t x = A[h0 + j]; v = (((x & paymask) >> m.pbits) << 32) | (x & posmask); }
+                dst[q] = v;
+                if (j == 0) o.slot_kid[gb + ls] = kb + kl;
+            }
+        } else if (o.ell_stride) {
             const uint32_t S = o.ell_stride, nq = Nb * S, sl = (S & (S - 1u)) ? 0u : (uint32_t)__ffs((int)S) - 1u;
             uint64_t *dst = o.ell + (uint64_t)kb * S;
             for (uint32_t q = tid; q < nq; q += ES_THREADS) {
@@ -735,6 +791,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                     }
                     __syncthreads();
                     const uint32_t ncolw = misc[1], nentw = misc[2];
+                    if (o.compact && tid == 0) misc[3] = (uint32_t)atomicAdd(o.slot_cursor, (unsigned long long)ncolw);      // gather slots (BucketOut): every column of a crowded bucket's window gets one
                     for_keys([&](uint64_t wd) {
                         const uint32_t idx = (uint32_t)(wd >> m.PB) & 0x7FFFu;
                         if (!((relbits[idx >> 5] >> (idx & 31u)) & 1u)) return;
@@ -774,22 +831,25 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                         }
                     }
                     __syncthreads();
+                    const uint32_t wslot = o.compact ? misc[3] : 0u;
                     for (uint32_t p = headpos[0] + tid; p < nentw; p += BK_THREADS) {      // (the window's first column may start a few places in: the previous window's last column reaches that far)
                         const uint64_t x = ent[p];
                         const uint64_t read = (x & paymask) >> m.pbits, pos = x & posmask, hint = x >> 62;
                         const uint32_t z = eb + wlo + p, kid = kb + klo + entk[p];
+                        const uint32_t id = o.compact && hint == 0 ? wslot + entk[p] : kid;      // (an entry that fetches its column names the column's gather slot)
                         o.csc[z] = (read << 32) | pos;
-                        if (o.csr_words) o.csr_words[z] = (read << o.rs) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
+                        if (o.csr_words) o.csr_words[z] = (read << o.rs) | ((uint64_t)id << (o.pb + 2)) | (hint << o.pb) | pos;
                         else o.kid_of_entry[z] = kid;
                     }
                     if (o.ell_stride) {
                         const uint32_t S = o.ell_stride, nq = ncolw * S;
-                        uint64_t *dst = o.ell + (uint64_t)(kb + klo) * S;
+                        uint64_t *dst = o.ell + (uint64_t)(o.compact ? wslot : kb + klo) * S;
                         for (uint32_t q = tid; q < nq; q += BK_THREADS) {
                             const uint32_t kl = q / S, j = q - kl * S;
                             uint64_t v = ~0ull;
                             if (j < fill[kl]) { const uint64_t x = ent[headpos[kl] + j]; v = (((x & paymask) >> m.pbits) << 32) | (x & posmask); }
                             dst[q] = v;
+                            if (o.compact && j == 0) o.slot_kid[wslot + kl] = kb + klo + kl;
                         }
                     }
                 }
@@ -914,6 +974,15 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
     else { c.kid_of_entry.reserve((size_t)(Z + 8) * 8); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); }
     o.ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; o.ell_stride = c.use_ell ? c.s_stride : 0u;
+    // gather slots: with inline partners the padded store holds the columns that are still fetched, not all of them (BucketOut)
+    const bool compact = inl && words && c.use_ell && !c.opt.no_ell_compact;
+    c.ell_compact = compact; c.ell_nslots = compact ? 0 : (int64_t)N;
+    if (compact) {
+        c.ell_slot_kid.reserve((size_t)(N + 1) * 4);
+        c.ws_scan.reserve(64);
+        ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
+        o.slot_cursor = c.ws_scan.as<unsigned long long>(); o.slot_kid = c.ell_slot_kid.as<uint32_t>(); o.compact = 1u;
+    }
     if (Z > 0) {
         const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u);
         hipLaunchKernelGGL((k_msd_emit_small<16>), dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 12u)), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap16,
@@ -931,9 +1000,17 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     ELBA_HIP(hipMemsetAsync(c.prod_ctr.p, 0, 64 * 128, s));
     const unsigned long long sq = hs.sumsq;
     ELBA_HIP(hipMemcpyAsync(c.prod_ctr.p, &sq, 8, hipMemcpyHostToDevice, s));
+    unsigned long long nslots = 0;
+    if (compact) ELBA_HIP(hipMemcpyAsync(&nslots, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
     c.t_b.stop(s);
     c.t_total.stop(s);
     ELBA_HIP(hipStreamSynchronize(s));
+    if (compact) {
+        // (a workgroup's last chunk of slots is partly unused: the cursor is an upper bound of the slots in use, and never beyond the columns' number
+        //  plus the chunks' slack — the store is sized for all columns)
+        ELBA_REQUIRE(nslots <= (unsigned long long)c.ell_cap_cols, ELBA_ERR_INTERNAL, "count_kmers: gather slots beyond the padded column store");
+        c.ell_nslots = (int64_t)nslots;
+    }
     c.pre_ready = true; c.pre_consumed = false; c.pre_words = words; c.pre_hints = hints; c.pre_hints_done = hints && words; c.pre_ell_done = true; c.pre_inline_pending = false;
     c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos; c.pre_rs = rs; c.pre_inline = inl; c.pre_pbi = pbi;
     st.instances = (int64_t)I; st.distinct = (int64_t)hs.distinct; st.reliable = (int64_t)N; st.entries = (int64_t)Z;

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define ELBA_ABI_VERSION 2
+#define ELBA_ABI_VERSION 3
 
 enum {
     ELBA_OK = 0,
@@ -214,6 +214,9 @@ typedef struct {
     uint32_t a_csr_format; /* which of the four encodings of a_csr is active (ELBA_CSR_*) */
     uint32_t a_csr_pos_mask; /* position of an a_csr entry = low word & a_csr_pos_mask, whatever the format */
     const void *a_kmers;   /* u64[N]: packed canonical k-mer (first word) of every column, ascending; NULL when A came from triples */
+    int64_t a_gather_slots;/* ELBA_CSR_INLINE matrices built by elba_count_kmers: > 0 = an a_csr entry WITHOUT bit 63 and with hint == 0 (an entry that
+                              fetches its column) names its column's gather slot in the id field, not the k-mer id; a_slot_kid maps back.  0: ids are k-mer ids */
+    const void *a_slot_kid;/* u32[a_gather_slots]: k-mer id of every gather slot (slots are drawn in chunks: unused ones hold garbage) */
 } elba_device_view;
 enum { ELBA_CSR_PLAIN = 0 /* kid<<32 | pos */, ELBA_CSR_HINTS = 1 /* kid<<32 | hint<<30 | pos */, ELBA_CSR_DENSE = 2 /* kid<<32 | L<<23 | idx<<16 | pos */,
        ELBA_CSR_INLINE = 3 /* as HINTS, but an entry with bit 63 set carries the one partner of its two-read column instead of the k-mer id:
@@ -314,7 +317,8 @@ int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
  *   "overlap_mirror_placed"  mirrored entries of the last elba_create_seed_matrix call that waited in the staging area for the placement pass
  *                            instead of going straight to their row's slab ("mirror slabs")
  *   "overlap_slab_q16"       slab entries reserved per row entry of A in that call, x 65536 (0: the call ran without slabs)
- *   "resident_bytes_A"       device bytes the resident k-mer matrix occupies (CSR, columns, padded column store, pointers) */
+ *   "resident_bytes_A"       device bytes the resident k-mer matrix occupies (CSR, columns, padded column store in use, pointers)
+ *   "gather_slots"           columns of the padded column store in use (with inline partners: only the columns some row entry still fetches) */
 int  elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value);
 
 /* ---- distributed building blocks (one context per rank/GPU; the collectives are issued by the host driver) ----------------

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert sorted(names) == sorted(capi.EXPORTED_SYMBOLS)
-    assert L.elba_abi_version() == 2
+    assert L.elba_abi_version() == 3
 
 
 def test_struct_layouts_match_header():

@@ -78,7 +78,13 @@ def _check_inline_entries(d, v, row, ent, kids, pos):
     hi = (ent >> 32) & 0x7FFFFFFF
     lo_ = ent & 0xFFFFFFFF
     plain = inl == 0
-    assert (hi[plain] == kids[plain]).all() and ((lo_[plain] & int(v["a_csr_pos_mask"])) == pos[plain]).all(), row
+    ids = hi.copy()
+    if v["a_gather_slots"]:             # gather slots: an entry that fetches its column (no inline partner, hint == 0) names the column's slot; the slot names the k-mer
+        gather = plain & (((lo_ >> 30) & 3) == 0)
+        sk = torch.as_tensor(_DevArray(v["a_slot_kid"], v["a_gather_slots"], "<i4"), device="cuda")
+        assert (hi[gather] < v["a_gather_slots"]).all(), row
+        ids[gather] = (sk[torch.from_numpy(hi[gather].astype(np.int64)).to(sk.device)].to(torch.int64) & 0xFFFFFFFF).cpu().numpy()
+    assert (ids[plain] == kids[plain]).all() and ((lo_[plain] & int(v["a_csr_pos_mask"])) == pos[plain]).all(), row
     if inl.any():
         ks = torch.from_numpy(kids[inl == 1]).to(cp.device)
         c0, c1 = cp[ks].cpu().numpy(), cp[ks + 1].cpu().numpy()
