@@ -138,6 +138,8 @@ struct Options {
     bool no_sample = false;     // a cold call does not compute a sample of rows first
     bool no_ell_compact = false;// k-mer stage: the padded column store holds every column, row entries name k-mer ids (no gather slots)
     bool no_slab = false;       // SpGEMM: mirrored entries wait in the staging area for k_mirror instead of going straight to their row's slab (spgemm.hip: "mirror slabs")
+    bool msd_no_emit8 = false;  // k-mer stage: buckets of up to 2048 entries through the 16-entries-per-lane kernel too (A/B)
+    int ell_slot_cap = 0;       // test hook: the padded column store pretends to hold this many gather slots only (0: its real size)
     int slab_pct = 175;         // SpGEMM: a row's slab holds this many percent of the mirrored entries the measured ratio predicts for it (+ SLAB_PAD)
     int slab_q16 = 0;           // test hook: slab entries per row entry of A in 1/65536 units, instead of the measured ratio (small matrices take no sample)
     bool panel_inline = false;  // inline partners in the rows of a windowed matrix too (a shard's panel): such a matrix is multiplied with the mirror exchange only

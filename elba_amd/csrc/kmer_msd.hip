@@ -289,6 +289,20 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         const uint32_t d = digit(it);
         if (d != 0xFFFFu) lkey[lstart[d] + rank[it]] = key[it];
     }
+    if (!ENUM) {
+        // a word that still holds its digit finds its run by it: delta[digit] = the run's place in the output - its place in the tile; the places of
+        // the tile are walked with a compile-time trip count, so that the LDS reads of all of a lane's places are in flight together (a loop with a
+        // run-time bound exposed three dependent LDS round trips per key: ~4 us of a tile's ~28)
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = DPT * threadIdx.x + u; if (d < nbins) delta[d] = gbase[d] - lstart[d]; }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < MT_ITEMS; ++it) {
+            const uint32_t t = (uint32_t)it * MT_THREADS + threadIdx.x;
+            if (t < count) { const uint64_t kv = lkey[t]; out[delta[(uint32_t)(kv >> shift) & dmask] + t] = kv; }
+        }
+        return;
+    }
     // The tile now lies ordered by digit in LDS, but an ENUM word does not hold its digit any more.  A place finds its digit's run from a
     // bitmap of the run starts: run number = set bits at or before the place, delta[run] = the run's place in the output - its place in the tile.
     {
@@ -316,9 +330,13 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         }
     }
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < count; t += MT_THREADS) {
-        const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & ((2ull << (t & 63u)) - 1ull)) - 1u;
-        out[delta[run] + t] = lkey[t];
+#pragma unroll
+    for (int it = 0; it < MT_ITEMS; ++it) {      // (compile-time trip count: the LDS reads of a lane's places are in flight together)
+        const uint32_t t = (uint32_t)it * MT_THREADS + threadIdx.x;
+        if (t < count) {
+            const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & ((2ull << (t & 63u)) - 1ull)) - 1u;
+            out[delta[run] + t] = lkey[t];
+        }
     }
 }
 
@@ -340,9 +358,9 @@ struct BucketOut {
     // names its column's SLOT where the others name the k-mer id (the SpGEMM multiplies whichever it finds by the stride; a sequence number is
     // the entry's rank in its row, never the id).  slot_kid[slot] = k-mer id, for exports and tests.  8 N S bytes were written before (14.8 GB on
     // BASELINE config 3), 8 S per gathered column now.
-    unsigned long long *slot_cursor; uint32_t *slot_kid; uint32_t compact;
+    unsigned long long *slot_cursor; uint32_t *slot_kid; uint32_t compact, slot_chunk;      // slot_cursor[1] != 0: a draw ran past slot_cap (nothing was written there; the host emits again without slots)
+    unsigned long long slot_cap;
 };
-constexpr uint32_t SLOT_CHUNK = 4096;
 
 // ---- buckets: count ------------------------------------------------------------------------------------------------------------------
 // One workgroup per bucket (the instances whose top 2k - 16 value bits agree).  The 16 value bits left index a table of 16-bit counters in LDS
@@ -623,15 +641,18 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 const uint32_t n = gmisc[0];
                 unsigned long long base = slot_next;
                 if (n > slot_left) {                                     // a new chunk (what is left of the old one stays unused: slots need not be dense)
-                    const uint32_t take = n > SLOT_CHUNK ? n : SLOT_CHUNK;
+                    const uint32_t take = n > o.slot_chunk ? n : o.slot_chunk;
                     base = atomicAdd(o.slot_cursor, (unsigned long long)take);
                     slot_next = base; slot_left = take;
                 }
                 slot_next += n; slot_left -= n;
                 gmisc[1] = (uint32_t)base;
+                gmisc[2] = base + n > o.slot_cap ? 1u : 0u;
+                if (gmisc[2]) atomicOr(&o.slot_cursor[1], 1ull);
             }
             lds_sync();
-            const uint32_t gb = gmisc[1], ng = gmisc[0];
+            const uint32_t gb = gmisc[1], ng = gmisc[2] ? 0u : gmisc[0];      // (past the store: this bucket's slots are not written — the whole emit is repeated)
+            if (gmisc[2]) needmask = 0;
 #pragma unroll
             for (int u = 0; u < ES_KPT; ++u)
                 if ((needmask >> u) & 1u) {
@@ -791,7 +812,11 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                     }
                     __syncthreads();
                     const uint32_t ncolw = misc[1], nentw = misc[2];
-                    if (o.compact && tid == 0) misc[3] = (uint32_t)atomicAdd(o.slot_cursor, (unsigned long long)ncolw);      // gather slots (BucketOut): every column of a crowded bucket's window gets one
+                    if (o.compact && tid == 0) {      // gather slots (BucketOut): every column of a crowded bucket's window gets one
+                        const unsigned long long wb = atomicAdd(o.slot_cursor, (unsigned long long)ncolw);
+                        misc[3] = (uint32_t)wb; misc[4] = wb + ncolw > o.slot_cap ? 1u : 0u;
+                        if (misc[4]) atomicOr(&o.slot_cursor[1], 1ull);
+                    }
                     for_keys([&](uint64_t wd) {
                         const uint32_t idx = (uint32_t)(wd >> m.PB) & 0x7FFFu;
                         if (!((relbits[idx >> 5] >> (idx & 31u)) & 1u)) return;
@@ -832,6 +857,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                     }
                     __syncthreads();
                     const uint32_t wslot = o.compact ? misc[3] : 0u;
+                    const bool past = o.compact && misc[4] != 0u;      // (past the store: nothing slot-addressed is written, the emit is repeated without slots)
                     for (uint32_t p = headpos[0] + tid; p < nentw; p += BK_THREADS) {      // (the window's first column may start a few places in: the previous window's last column reaches that far)
                         const uint64_t x = ent[p];
                         const uint64_t read = (x & paymask) >> m.pbits, pos = x & posmask, hint = x >> 62;
@@ -841,7 +867,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                         if (o.csr_words) o.csr_words[z] = (read << o.rs) | ((uint64_t)id << (o.pb + 2)) | (hint << o.pb) | pos;
                         else o.kid_of_entry[z] = kid;
                     }
-                    if (o.ell_stride) {
+                    if (o.ell_stride && !past) {
                         const uint32_t S = o.ell_stride, nq = ncolw * S;
                         uint64_t *dst = o.ell + (uint64_t)(o.compact ? wslot : kb + klo) * S;
                         for (uint32_t q = tid; q < nq; q += BK_THREADS) {
@@ -977,40 +1003,62 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     // gather slots: with inline partners the padded store holds the columns that are still fetched, not all of them (BucketOut)
     const bool compact = inl && words && c.use_ell && !c.opt.no_ell_compact;
     c.ell_compact = compact; c.ell_nslots = compact ? 0 : (int64_t)N;
+    const uint32_t grid16 = std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 12u), grid32 = std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 4u), grid8 = std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 24u);
     if (compact) {
-        c.ell_slot_kid.reserve((size_t)(N + 1) * 4);
+        // Slots are drawn a chunk at a time per workgroup and a chunk's tail may stay unused (a bucket that needs more than what is left takes a new
+        // chunk, or exactly what it needs when that is more than a chunk): the store is sized for every column + one chunk per workgroup + the
+        // largest single draw a workgroup can leave behind — the slots can never run past it.
+        const uint64_t nwg = (uint64_t)grid8 + grid16 + grid32;
+        const uint32_t chunk = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(4096, N / (4 * nwg)));
+        // (a chunk's tail stays unused when the next bucket needs more than what is left: a quarter more than the columns covers every read set seen —
+        //  ~4 % are wasted on BASELINE config 3 —; a draw past the store is refused on the device and the emit repeated without slots)
+        uint64_t cap_cols = N + N / 4 + nwg * chunk + 4096;
+        c.a_ell.reserve((size_t)cap_cols * c.s_stride * 8 + 64);
+        if (c.opt.ell_slot_cap > 0 && (uint64_t)c.opt.ell_slot_cap < cap_cols) cap_cols = (uint64_t)c.opt.ell_slot_cap;      // (test hook: a store too small for the slots)
+        ELBA_HIP(hipMemsetAsync(c.a_ell.as<char>() + (size_t)cap_cols * c.s_stride * 8, 0xFF, 64, s));
+        c.ell_cap_cols = (int64_t)cap_cols;
+        o.ell = c.a_ell.as<uint64_t>(); o.slot_chunk = chunk; o.slot_cap = cap_cols;
+        c.ell_slot_kid.reserve((size_t)(cap_cols + 1) * 4);
         c.ws_scan.reserve(64);
-        ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
+        ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 16, s));
         o.slot_cursor = c.ws_scan.as<unsigned long long>(); o.slot_kid = c.ell_slot_kid.as<uint32_t>(); o.compact = 1u;
     }
-    if (Z > 0) {
-        const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u);
-        hipLaunchKernelGGL((k_msd_emit_small<16>), dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 12u)), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap16,
+    auto launch_emit = [&]() {
+        if (Z == 0) return;
+        const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u), cap8 = std::min<uint32_t>(cap16, c.opt.msd_no_emit8 ? 0u : 2048u);
+        // (buckets of up to 2048 entries — more than half of them on BASELINE config 3, where a bucket holds 2040 on average — through an instantiation
+        //  with 8 entries per lane: half the predicated-off work of the 16-entry one, 26 KB of LDS instead of 49: six workgroups per CU)
+        if (cap8) hipLaunchKernelGGL((k_msd_emit_small<8>), dim3(grid8), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap8,
+                                     (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+        if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<16>), dim3(grid16), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
                            (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (small_cap > 4096u && hs.nmid)
-            hipLaunchKernelGGL((k_msd_emit_small<32>), dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 4u)), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
+            hipLaunchKernelGGL((k_msd_emit_small<32>), dim3(grid32), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
                                (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (hs.ncrowded)
             hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,
                                (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, (const uint32_t *)crowded, (const BucketStats *)gstat, (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
-    }
+    };
+    launch_emit();
     const uint32_t Zz = (uint32_t)Z;
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
     c.prod_ctr.reserve(64 * 128);
     ELBA_HIP(hipMemsetAsync(c.prod_ctr.p, 0, 64 * 128, s));
     const unsigned long long sq = hs.sumsq;
     ELBA_HIP(hipMemcpyAsync(c.prod_ctr.p, &sq, 8, hipMemcpyHostToDevice, s));
-    unsigned long long nslots = 0;
-    if (compact) ELBA_HIP(hipMemcpyAsync(&nslots, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
+    unsigned long long slots[2] = {0, 0};
+    if (compact) ELBA_HIP(hipMemcpyAsync(slots, c.ws_scan.p, 16, hipMemcpyDeviceToHost, s));
     c.t_b.stop(s);
     c.t_total.stop(s);
     ELBA_HIP(hipStreamSynchronize(s));
-    if (compact) {
-        // (a workgroup's last chunk of slots is partly unused: the cursor is an upper bound of the slots in use, and never beyond the columns' number
-        //  plus the chunks' slack — the store is sized for all columns)
-        ELBA_REQUIRE(nslots <= (unsigned long long)c.ell_cap_cols, ELBA_ERR_INTERNAL, "count_kmers: gather slots beyond the padded column store");
-        c.ell_nslots = (int64_t)nslots;
-    }
+    if (compact && slots[1] != 0) {
+        // more chunk tails were left unused than the store has room for (never seen; a draw past it writes nothing): every column gets the place
+        // of its k-mer id after all — the emit once more, without slots
+        if (c.opt.trace) fprintf(stderr, "[elba] gather slots ran past the padded column store (%llu of %llu): emitting again without them\n", slots[0], (unsigned long long)c.ell_cap_cols);
+        o.compact = 0; c.ell_compact = false; c.ell_nslots = (int64_t)N;
+        launch_emit();
+        ELBA_HIP(hipStreamSynchronize(s));
+    } else if (compact) c.ell_nslots = (int64_t)slots[0];      // (an upper bound of the slots in use: chunks are drawn whole)
     c.pre_ready = true; c.pre_consumed = false; c.pre_words = words; c.pre_hints = hints; c.pre_hints_done = hints && words; c.pre_ell_done = true; c.pre_inline_pending = false;
     c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos; c.pre_rs = rs; c.pre_inline = inl; c.pre_pbi = pbi;
     st.instances = (int64_t)I; st.distinct = (int64_t)hs.distinct; st.reliable = (int64_t)N; st.entries = (int64_t)Z;

@@ -547,7 +547,7 @@ def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up, cap):
     e.close()
 
 
-@pytest.mark.parametrize("opts", [{"no_inline": 1}, {"no_symmetry": 1}, {"no_pay": 1}, {"no_ell": 1}, {"mir32": 1}, {"no_sample": 1}])
+@pytest.mark.parametrize("opts", [{"no_inline": 1}, {"no_symmetry": 1}, {"no_pay": 1}, {"no_ell": 1}, {"mir32": 1}, {"no_sample": 1}, {"no_ell_compact": 1}, {"ell_slot_cap": 100}])
 def test_inline_partners_against_their_alternatives(opts):
     """The two-level partition path writes the owning row's entry of every two-read column as an inline partner (no column fetch in the
     SpGEMM).  Without them ("no_inline"; both triangles accumulated: every row needs every column), with 32-bit accumulators + look-ups / plain CSC columns (which switch the inline format off), wide staging records, no
@@ -557,6 +557,10 @@ def test_inline_partners_against_their_alternatives(opts):
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8, options=dict(opts, kmer_msd=1))
     fmt = e.device_view()["a_csr_format"]
     assert fmt == (1 if ("no_inline" in opts or "no_pay" in opts or "no_ell" in opts or "no_symmetry" in opts) else 3)
+    # gather slots: with inline partners the padded column store holds only the columns some row entry still fetches — unless switched off, or
+    # the store is too small for them (test hook: the emit is then repeated without slots)
+    slots, ncols = e.device_view()["a_gather_slots"], ms["ncols"]
+    assert (slots == 0) if (fmt != 3 or "no_ell_compact" in opts or "ell_slot_cap" in opts) else (0 < slots < ncols), (slots, ncols)
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
