@@ -157,7 +157,9 @@ def main():
         packed, off, lens, info = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"],
                                                        repeat_families=rep[0], repeat_fraction=rep[1], repeat_len=rep[2])
         t_gen = time.time() - t0
-        eng = Engine(k, lo, up, device=local_rank, timing_stride=args.timing_stride)
+        # (A/B runs: ELBA_BENCH_OPTIONS="name=value,name=value" sets library options before A is built — never a result-changing switch)
+        bench_opts = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in os.environ.get("ELBA_BENCH_OPTIONS", "").split(",") if "=" in kv}
+        eng = Engine(k, lo, up, device=local_rank, timing_stride=args.timing_stride, options=bench_opts or None)
         # inputs resident in HBM before anything is timed
         d_packed = torch.from_numpy(packed).cuda(); d_off = torch.from_numpy(off.view(np.int64)).cuda(); d_len = torch.from_numpy(lens.view(np.int32)).cuda()
         eng.set_reads_device(d_packed.data_ptr(), int(packed.size) - 16, d_off.data_ptr(), d_len.data_ptr(), len(lens))

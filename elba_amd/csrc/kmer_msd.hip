@@ -289,6 +289,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         const uint32_t d = digit(it);
         if (d != 0xFFFFu) lkey[lstart[d] + rank[it]] = key[it];
     }
+#ifdef ELBA_SCATTER_MEM_DIRECT
     if (!ENUM) {
         // a word that still holds its digit finds its run by it: delta[digit] = the run's place in the output - its place in the tile; the places of
         // the tile are walked with a compile-time trip count, so that the LDS reads of all of a lane's places are in flight together (a loop with a
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         }
         return;
     }
+#endif
     // The tile now lies ordered by digit in LDS, but an ENUM word does not hold its digit any more.  A place finds its digit's run from a
     // bitmap of the run starts: run number = set bits at or before the place, delta[run] = the run's place in the output - its place in the tile.
     {
@@ -330,6 +332,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         }
     }
     __syncthreads();
+#ifdef ELBA_SCATTER_UNROLL
 #pragma unroll
     for (int it = 0; it < MT_ITEMS; ++it) {      // (compile-time trip count: the LDS reads of a lane's places are in flight together)
         const uint32_t t = (uint32_t)it * MT_THREADS + threadIdx.x;
@@ -338,6 +341,14 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
             out[delta[run] + t] = lkey[t];
         }
     }
+#else
+    // (a compile-time trip count — all of a lane's LDS reads in flight together — was measured: partition 28.0 -> 30.0 ms; the 32 keys it keeps
+    //  in registers beside the tile's cost more than the round trips they hide)
+    for (uint32_t t = threadIdx.x; t < count; t += MT_THREADS) {
+        const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & ((2ull << (t & 63u)) - 1ull)) - 1u;
+        out[delta[run] + t] = lkey[t];
+    }
+#endif
 }
 
 // LDS-only workgroup barrier: the global stores of a bucket (never read back by the workgroup) stay in flight
@@ -560,16 +571,16 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
         }
         lds_sync();
         if (wv == 0) {      // exclusive scan of the NH (u, wave) head counts, in place order: NH / 64 consecutive ones per lane
-            constexpr int PL = NH / 64;
+            constexpr int PL = NH >= 64 ? NH / 64 : 1;      // (NH = 32 with 8 entries per lane: the upper half of the lanes holds nothing)
             uint32_t c[PL], sum = 0;
 #pragma unroll
-            for (int q = 0; q < PL; ++q) { c[q] = hcnt[lane * PL + q]; sum += c[q]; }
+            for (int q = 0; q < PL; ++q) { c[q] = lane * PL + q < NH ? hcnt[lane * PL + q] : 0u; sum += c[q]; }
             uint32_t inc = sum;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
             uint32_t run = inc - sum;
 #pragma unroll
-            for (int q = 0; q < PL; ++q) { hcnt[lane * PL + q] = run; run += c[q]; }
+            for (int q = 0; q < PL; ++q) { if (lane * PL + q < NH) hcnt[lane * PL + q] = run; run += c[q]; }
             if (lane == 63) hcnt[NH] = inc;
         }
         lds_sync();
@@ -1015,6 +1026,8 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
         uint64_t cap_cols = N + N / 4 + nwg * chunk + 4096;
         c.a_ell.reserve((size_t)cap_cols * c.s_stride * 8 + 64);
         if (c.opt.ell_slot_cap > 0 && (uint64_t)c.opt.ell_slot_cap < cap_cols) cap_cols = (uint64_t)c.opt.ell_slot_cap;      // (test hook: a store too small for the slots)
+        const int idbits = std::min(32, rs - pb - 2);      // the id field of a sort key: from the hint bits up to the read
+        if (idbits < 32 && cap_cols > (1ull << idbits)) cap_cols = 1ull << idbits;      // (slots beyond it are refused like slots beyond the store)
         ELBA_HIP(hipMemsetAsync(c.a_ell.as<char>() + (size_t)cap_cols * c.s_stride * 8, 0xFF, 64, s));
         c.ell_cap_cols = (int64_t)cap_cols;
         o.ell = c.a_ell.as<uint64_t>(); o.slot_chunk = chunk; o.slot_cap = cap_cols;
