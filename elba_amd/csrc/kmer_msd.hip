@@ -487,15 +487,18 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
 // leaves from here as coalesced streams.  256 lanes, 44 KB of LDS: three workgroups per CU hide one another's barriers and memory waits.
 // <16>: up to 4096 entries, three workgroups per CU; <32>: up to 8192 (the canonical k-mer is the smaller of two: low values are twice as dense as
 // the average, and the fullest buckets of a large input land here), one workgroup per CU.
-constexpr int ES_THREADS = 256;
 constexpr uint32_t ES_NSB = 512;
-template <int ES_KPT>
+// <32, 256> (8192 entries on 256 lanes: 256 VGPRs, 95 KB of LDS, ONE workgroup of four wavefronts per CU) took 85 ms on BASELINE config 5 at one GPU's
+// share, where the average bucket holds 4400 entries: the widest buckets now run on 512 lanes, 16 entries each (<16, 512>: eight wavefronts per CU)
+template <int ES_KPT, int ES_THREADS = 256>
 __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *wrel, const uint32_t *b2start, const uint32_t *bZ, uint32_t nbuckets, MsdParams m, uint32_t cap_lo, uint32_t cap_hi,
                                                               const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
 {
-    constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, NH = ES_KPT * 4;      // entries; (u, wavefront) head counts
+    constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, NW = ES_THREADS / 64, NH = ES_KPT * NW;      // entries; wavefronts; (u, wavefront) head counts
+    constexpr int PER = (int)(ES_NSB / ES_THREADS);      // value ranges per lane in their scan
+    static_assert(PER >= 1 && ES_NSB % ES_THREADS == 0, "one value range per lane at least");
     __shared__ uint64_t A[ES_CAP];
-    __shared__ uint32_t sbcnt[ES_NSB], sbstart[ES_NSB + 1], H[ES_CAP / 2 + 2], hcnt[NH + 1], wsum[4];
+    __shared__ uint32_t sbcnt[ES_NSB], sbstart[ES_NSB + 1], H[ES_CAP / 2 + 2], hcnt[NH + 1], wsum[NW];
     __shared__ uint16_t GL[ES_CAP / 2 + 2];            // gather slots: the bucket's columns that some entry still fetches, in the order their heads drew a place
     __shared__ uint32_t gmisc[4];                      // 0: columns that need a slot, 1: the bucket's first slot
     constexpr uint32_t HPOS = 0x3FFFu, HNEED = 0x80000000u;      // H[column] = head place | local slot << 14 | HNEED
@@ -513,7 +516,8 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
         // value ranges of the sort: 2^(16 - sh) of them, 4-8 entries each
         uint32_t sh = 7;
         while (sh < 16 && (Z >> (16 - sh)) < 4u) ++sh;
-        sbcnt[tid] = 0; sbcnt[tid + ES_THREADS] = 0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) sbcnt[tid + (uint32_t)q * ES_THREADS] = 0;
         lds_sync();
         uint32_t slot[ES_KPT];
 #pragma unroll
@@ -522,17 +526,20 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
             if ((uint32_t)u * ES_THREADS + tid < Z) slot[u] = atomicAdd(&sbcnt[((uint32_t)(key[u] >> m.PB) & 0xFFFFu) >> sh], 1u);
         }
         lds_sync();
-        {   // exclusive scan of the <= 512 range counts: 2 per lane
-            const uint32_t c0 = sbcnt[2 * tid], c1 = sbcnt[2 * tid + 1];
-            uint32_t inc = c0 + c1;
+        {   // exclusive scan of the <= 512 range counts: PER consecutive ones per lane
+            uint32_t cc[PER], tot = 0;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { cc[q] = sbcnt[PER * tid + q]; tot += cc[q]; }
+            uint32_t inc = tot;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
             if (lane == 63) wsum[wv] = inc;
             lds_sync();
-            uint32_t ex = inc - c0 - c1;
+            uint32_t ex = inc - tot;
             for (uint32_t ww = 0; ww < wv; ++ww) ex += wsum[ww];
-            sbstart[2 * tid] = ex; sbstart[2 * tid + 1] = ex + c0;
-            if (tid == ES_THREADS - 1) sbstart[ES_NSB] = ex + c0 + c1;
+#pragma unroll
+            for (int q = 0; q < PER; ++q) { sbstart[PER * tid + q] = ex; ex += cc[q]; }
+            if (tid == ES_THREADS - 1) sbstart[ES_NSB] = ex;
         }
         lds_sync();
 #pragma unroll
@@ -567,7 +574,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
             const uint64_t bal = __ballot(head);
             if (head) headmask |= 1u << u;
             slot[u] = (uint32_t)__popcll(bal & lt) + (head ? 1u : 0u);      // heads at or before this place within its wavefront's 64 places
-            if (lane == 0) hcnt[u * 4 + wv] = (uint32_t)__popcll(bal);
+            if (lane == 0) hcnt[u * NW + wv] = (uint32_t)__popcll(bal);
         }
         lds_sync();
         if (wv == 0) {      // exclusive scan of the NH (u, wave) head counts, in place order: NH / 64 consecutive ones per lane
@@ -587,7 +594,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
         const uint32_t Nb = hcnt[NH], kb = kidbase[b], eb = entbase[b];
 #pragma unroll
         for (int u = 0; u < ES_KPT; ++u) {
-            slot[u] = hcnt[u * 4 + wv] + slot[u] - 1u;                      // the column of place u * 256 + tid
+            slot[u] = hcnt[u * NW + wv] + slot[u] - 1u;                     // the column of place u * ES_THREADS + tid
             if ((headmask >> u) & 1u) H[slot[u]] = (uint32_t)u * ES_THREADS + tid;
         }
         if (tid == 0) { H[Nb] = Z; gmisc[0] = 0; }
@@ -1041,12 +1048,12 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
         const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u), cap8 = std::min<uint32_t>(cap16, c.opt.msd_no_emit8 ? 0u : 2048u);
         // (buckets of up to 2048 entries — more than half of them on BASELINE config 3, where a bucket holds 2040 on average — through an instantiation
         //  with 8 entries per lane: half the predicated-off work of the 16-entry one, 26 KB of LDS instead of 49: six workgroups per CU)
-        if (cap8) hipLaunchKernelGGL((k_msd_emit_small<8>), dim3(grid8), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap8,
+        if (cap8) hipLaunchKernelGGL((k_msd_emit_small<8>), dim3(grid8), dim3(256), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap8,
                                      (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
-        if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<16>), dim3(grid16), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
+        if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<16>), dim3(grid16), dim3(256), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
                            (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (small_cap > 4096u && hs.nmid)
-            hipLaunchKernelGGL((k_msd_emit_small<32>), dim3(grid32), dim3(ES_THREADS), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
+            hipLaunchKernelGGL((k_msd_emit_small<16, 512>), dim3(grid32), dim3(512), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
                                (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (hs.ncrowded)
             hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,
