@@ -148,23 +148,6 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
     // The row a workgroup works on is published in one of TWO places, alternately: without a barrier at the start of a row a wavefront may still be
     // about to read its row when the first wavefront — done with a short row — publishes the next one (the hand-off barrier keeps them within one row
     // of each other).  (Found by tests/test_gpu_fuzz.py: with one place, two wavefronts disagreed about the current row once in ~20 calls on short reads.)
-    // A mirrored image waits for its ticket (a returning atomic on its partner row's counter) before it can be stored in that row's slab.  The lane
-    // does not wait: the image stays in registers and is stored when the lane next gets here — a row later, with the ticket long returned (it comes
-    // back in order with the next row's first loads) — or behind the last row.  (Waiting cost the staging phase a memory round trip per row: 17 % of
-    // the kernel's time with slabs, profiles/r04_notes.md.)
-    // (not on the dense path: its kernels run under a budget of 64 VGPRs, and a row there stages a handful of survivors for tens of thousands of products)
-    constexpr bool DEFER = !SUFFIX;
-    uint32_t pd_j = EMPTY, pd_tick = 0, pd_w1 = 0, pd_w2 = 0, pd_n = 0, pd_i = 0, pd_r0 = 0, pd_r1 = 0;
-    unsigned long long pd_at = 0;
-    auto flush_pending = [&]() {
-        if (DEFER && pd_j != EMPTY) {
-            const uint32_t b0 = slab_base(pd_r0, slab_rp0, pd_j - p.row_lo, slab_q), b1 = slab_base(pd_r1, slab_rp0, pd_j + 1u - p.row_lo, slab_q);
-            uint32_t tk = pd_tick;
-            if (tk < b1 - b0) { p.slab[b0 + tk] = make_uint4(pd_i, pd_w1, pd_w2, pd_n); tk = 0xFFFFFFFFu; }      // (beyond the slab: the image waits in the staging area for k_mirror)
-            p.tick[pd_at] = tk;
-            pd_j = EMPTY;
-        }
-    };
     uint32_t npar = 0;
     for (;;) {
         const uint32_t NB = D_NEXT + 4u * npar;      // where this row was published
@@ -696,26 +679,23 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 }
                 // the partner's row gets the mirrored entry: draw its slot there now; k_mirror places it once the row pointers are known
                 uint32_t tick = 0xFFFFFFFFu;
-                if (slab_q) {      // (mirror slabs: p.rec16)
-                    flush_pending();      // (the image of this lane's previous survivor: its ticket has long returned)
-                    p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared);
-                    if (j != i && j >= p.row_lo && j < p.row_hi) {
-                        const uint32_t tk0 = atomicAdd(&p.low_cnt[j], 1u); ++nmir;
-                        const RowPair rp = *reinterpret_cast<const RowPair *>(p.a_rowptr + j);      // (two adjacent words, ONE request: a dword-aligned 8-byte load)
-                        if (DEFER) { pd_tick = tk0; pd_r0 = rp.a; pd_r1 = rp.b; pd_j = j; pd_i = i; pd_w1 = v.t0 | v.q0 << 16; pd_w2 = v.t1 | v.q1 << 16; pd_n = (uint32_t)v.numshared; pd_at = off + t; }
-                        else {
-                            const uint32_t b0 = slab_base(rp.a, slab_rp0, j - p.row_lo, slab_q), b1 = slab_base(rp.b, slab_rp0, j + 1u - p.row_lo, slab_q);
-                            uint32_t tk = tk0;
-                            if (tk < b1 - b0) { p.slab[b0 + tk] = make_uint4(i, v.t0 | v.q0 << 16, v.t1 | v.q1 << 16, (uint32_t)v.numshared); tk = 0xFFFFFFFFu; }
-                            p.tick[off + t] = tk;
-                        }
-                    } else p.tick[off + t] = 0xFFFFFFFFu;
-                    if (j != i && ((j >= p.row_lo && j < p.row_hi) || j > i)) ++nup;
-                    mx = (uint32_t)v.numshared > mx ? (uint32_t)v.numshared : mx;
-                    continue;
-                }
                 if (p.half && j != i && j >= p.row_lo && j < p.row_hi) {
                     tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir;
+                    if (slab_q) {      // the image goes straight to row j's slab when its ticket lies inside it (else it waits here for k_mirror)
+#if defined(ELBA_SLAB_NOLD)
+                        const uint32_t b0 = j * 431u, b1 = b0 + 431u;
+#elif defined(ELBA_SLAB_LD4)
+                        const uint32_t b0 = slab_base(p.a_rowptr[j], slab_rp0, j - p.row_lo, slab_q), b1 = slab_base(p.a_rowptr[j + 1], slab_rp0, j + 1u - p.row_lo, slab_q);
+#else
+                        const RowPair rp = *reinterpret_cast<const RowPair *>(p.a_rowptr + j);      // (two adjacent words, ONE request: a dword-aligned 8-byte load)
+                        const uint32_t b0 = slab_base(rp.a, slab_rp0, j - p.row_lo, slab_q), b1 = slab_base(rp.b, slab_rp0, j + 1u - p.row_lo, slab_q);
+#endif
+#if defined(ELBA_SLAB_NOST)
+                        if (tick < b1 - b0) { tick = 0xFFFFFFFFu; }
+#else
+                        if (tick < b1 - b0) { p.slab[b0 + tick] = make_uint4(i, v.t0 | v.q0 << 16, v.t1 | v.q1 << 16, (uint32_t)v.numshared); tick = 0xFFFFFFFFu; }
+#endif
+                    }
                 }
                 if (p.rec16) { p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared); p.tick[off + t] = tick; }
                 else {
@@ -736,7 +716,6 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
         if (GLOBAL) __syncthreads(); else lds_barrier();       // the next row finds table and counters clean; staging stores stay in flight
         ELBA_DSTAMP(6);
     }
-    flush_pending();
 #ifdef ELBA_PHASE_CLOCK
     if (tid == 0) {
 #pragma unroll
