@@ -534,6 +534,7 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         else if (!strcmp(name, "dense_up")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: dense_up is 0..3"); c.opt.dense_up = (int)value; }
         else if (!strcmp(name, "dense_wgs")) { ELBA_REQUIRE(value >= 1 && value <= 16, ELBA_ERR_INVALID_ARG, "set_option: dense_wgs is 1..16"); c.opt.dense_wgs = (int)value; }
         else if (!strcmp(name, "msd_small_cap")) c.opt.msd_small_cap = (int)value;
+        else if (!strcmp(name, "msd_wide_bits")) c.opt.msd_wide_bits = (int)value;
         else if (!strcmp(name, "ell_slot_cap")) c.opt.ell_slot_cap = (int)value;
         else if (!strcmp(name, "slab_pct")) { ELBA_REQUIRE(value >= 1 && value <= 1000, ELBA_ERR_INVALID_ARG, "set_option: slab_pct is 1..1000"); c.opt.slab_pct = (int)value; }
         else if (!strcmp(name, "slab_q16")) { ELBA_REQUIRE(value >= 0 && value < (1ll << 31), ELBA_ERR_INVALID_ARG, "set_option: slab_q16 is 0..2^31"); c.opt.slab_q16 = (int)value; }
@@ -551,6 +552,7 @@ int elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value)
         ELBA_REQUIRE(name && value, ELBA_ERR_INVALID_ARG, "get_stat: null name or value");
         if (!strcmp(name, "overlap_mirror_placed")) *value = c.ov_mir_placed;
         else if (!strcmp(name, "overlap_slab_q16")) *value = (int64_t)c.ov_slab_q16_used;
+        else if (!strcmp(name, "kmer_path")) *value = c.kmer_path;
         else if (!strcmp(name, "gather_slots")) *value = c.have_A && c.use_ell ? c.ell_nslots : 0;
         else if (!strcmp(name, "resident_bytes_A")) {
             int64_t b = 0;

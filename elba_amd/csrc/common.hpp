@@ -153,6 +153,7 @@ struct Options {
     bool csr_pairs = false;     // (read, entry) pairs through the CSR sort instead of one word
     bool emit_plain = false;    // k-mer emit without the fused first histogram
     bool trace = false;         // progress lines on stderr
+    int msd_wide_bits = 0;      // tests: value bits the partition of the 19 <= k <= 31 path takes (0: chosen from the number of instances)
     int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
     int dense_up = 1;           // SpGEMM, dense path: the tier its rows start on at least (1: eight wavefronts share a 1024-slot table — 32 per CU as with four on 512 slots, half the load)
@@ -183,6 +184,7 @@ struct Ctx {
 
     // k-mer stage results (device)
     bool have_counts = false;
+    int kmer_path = 0;    // diagnostic: how the last elba_count_kmers counted — 0 the sort of kmer.hip, 1 two-level partition + LDS count tables (k <= 17), 2 the same on 16-byte records + LDS sort (19 <= k <= 31)
     int64_t I = 0, ndistinct = 0;
     DevBuf inst_off;      // u64[M+1] instance offset of each read
     DevBuf rel_kmers;     // u64[N] reliable k-mers ascending (right-aligned value order == packed order)

@@ -537,6 +537,7 @@ void stage_count_kmers(Ctx &c)
     const int k = c.cfg.k;
     const int64_t M = c.nreads;
     c.have_counts = false; c.have_A = false; c.have_B = false; c.dist_owner = false;
+    c.kmer_path = 0;
     elba_kmer_stats st{};
     st.nreads = M;
 

@@ -58,11 +58,11 @@ struct MsdParams {
 // k-mer is the top 2k bits of a 192-bit window shifted left by one base per step, the twin takes the complement of the entering base at its
 // front (src/Kmer.cpp:149-165 rolls the same way; :167-198 is the twin).  Nothing downstream of the partition needs the instances in (read, pos)
 // order — the bucket kernels sort every column — so the tile may hold them in any order.  f(it, canonical k-mer, read, pos), `it` a constant.
-template <class F>
+template <int ITEMS = MT_ITEMS, class F>
 __device__ __forceinline__ void enum_consecutive(const EnumParams &e, const BlockInfo *block_read, uint64_t wbase, F &&f)
 {
     const uint32_t lane = threadIdx.x & 63;
-    const uint64_t g0 = wbase + (uint64_t)lane * MT_ITEMS;
+    const uint64_t g0 = wbase + (uint64_t)lane * ITEMS;
     const int k = e.k;
     const uint64_t kmask = ~0ull << (64 - 2 * k);
     if (wbase >= e.I) return;
@@ -71,7 +71,7 @@ __device__ __forceinline__ void enum_consecutive(const EnumParams &e, const Bloc
     uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
     uint64_t hi = 0, mid = 0, lo = 0, tw = 0;
 #pragma unroll
-    for (int it = 0; it < MT_ITEMS; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
         const uint64_t g = g0 + (uint64_t)it;
         if (g >= e.I) break;
         uint64_t fwd;
@@ -79,7 +79,7 @@ __device__ __forceinline__ void enum_consecutive(const EnumParams &e, const Bloc
             while (g >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }      // reads shorter than k have empty ranges and are skipped here
             const uint32_t p = (uint32_t)(g - off_lo);
             const uint64_t left = off_hi - g;                     // instances of this read from here on: the window must reach left (<= 32 - it) + k - 1 bases
-            const uint32_t nbases = (uint32_t)(left < (uint64_t)(MT_ITEMS - it) ? left : (uint64_t)(MT_ITEMS - it)) + (uint32_t)k - 1u;
+            const uint32_t nbases = (uint32_t)(left < (uint64_t)(ITEMS - it) ? left : (uint64_t)(ITEMS - it)) + (uint32_t)k - 1u;
             const uint64_t b = boff + (p >> 2), a = b & ~7ull, last = boff + ((p + nbases - 1u) >> 2);
             const uint64_t *w = reinterpret_cast<const uint64_t *>(e.packed + a);
             const uint64_t w0 = __builtin_bswap64(w[0]), w1 = __builtin_bswap64(w[1]), w2 = a + 16 <= last ? __builtin_bswap64(w[2]) : 0ull;      // (16 guard bytes follow the reads: the third word is read only where the read itself reaches it)
@@ -371,6 +371,7 @@ struct BucketOut {
     // BASELINE config 3), 8 S per gathered column now.
     unsigned long long *slot_cursor; uint32_t *slot_kid; uint32_t compact, slot_chunk;      // slot_cursor[1] != 0: a draw ran past slot_cap (nothing was written there; the host emits again without slots)
     unsigned long long slot_cap;
+    const uint64_t *kmer_src;      // k > 17 (k31_count): the bucket's reliable k-mers, left-aligned, at [bucket's first instance + column]; null: the k-mer is bucket << 16 | the entry's 16 value bits
 };
 
 // ---- buckets: count ------------------------------------------------------------------------------------------------------------------
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 else o.kid_of_entry[z] = kid;
                 if ((headmask >> u) & 1u) {
                     const uint64_t value = ((uint64_t)b << VBITS) | ((uint32_t)(x >> m.PB) & 0xFFFFu);
-                    o.rel_kmers[kid] = value << (64 - m.k2); o.rel_counts[kid] = L; o.colptr[kid] = z;
+                    o.rel_kmers[kid] = o.kmer_src ? o.kmer_src[s0 + kl] : value << (64 - m.k2); o.rel_counts[kid] = L; o.colptr[kid] = z;
                 }
             }
         }
@@ -903,6 +904,316 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
     }
 }
 
+// =====================================================================================================================================
+// One-word k-mers beyond k = 17 (19 <= k <= 31: the reference's default build is k = 31, Makefile:1-3).  2k - 16 value bits do not fit a
+// two-level partition any more, and value + read + position do not fit one word (62 + 32 bits), so
+//   * an instance travels as a RECORD of 16 bytes, hi = the canonical k-mer (2k bits, right-aligned), lo = read << pbits | pos;
+//   * the two-level partition takes the top T = b1 + b2 value bits (T chosen so that a bucket holds ~1500 instances; up to 10 bits a level);
+//   * k31_count sorts a bucket's records by (k-mer, read, pos) IN LDS (<= W2_CAP records), finds the runs of equal k-mers, keeps those of
+//     LOWER..UPPER instances and writes their entries — compacted, in order, as the one-word entries the emit kernels of the k <= 17 path
+//     read: (column of the bucket scaled to 16 bits) << PB | read << pbits | pos — and the bucket's reliable k-mers beside them.
+// From there on the path is the k <= 17 one (k_msd_emit_small, the CSR build).  A bucket beyond W2_CAP records (a repeat family, a
+// homopolymer) sends the whole input to the sort of kmer.hip: correct, slower; profiles/r04_notes.md.
+// HBM traffic per instance: 16 B written + 16 read (hist2) + 16 read + 16 written + 16 read = 80 B, against 7 passes x 32 B + 3 x 16 B on the sort path.
+constexpr int W2_THREADS = 256, W2_ITEMS = 16, W2_TILE = W2_THREADS * W2_ITEMS;      // 4096 records of 16 bytes: 64 KB of LDS
+constexpr int W2_MAXBITS = 10, W2_MAXBINS = 1 << W2_MAXBITS;
+constexpr uint32_t W2_CAP = 4096;                // records of a bucket k31_count sorts in LDS
+constexpr int W2C_THREADS = 512, W2C_KPT = (int)(W2_CAP / W2C_THREADS);
+static_assert(W2_ITEMS * 64 <= (1 << IB_SHIFT), "a wavefront's share of a tile lies inside one block of the instance -> read table");
+struct alignas(16) Rec2 { uint64_t hi, lo; };
+
+__global__ __launch_bounds__(W2_THREADS) void k31_hist1(EnumParams e, const BlockInfo *block_read, int b1, uint32_t *hist)
+{
+    __shared__ uint32_t h[W2_MAXBINS];
+    const uint32_t nbins = 1u << b1;
+    for (uint32_t i = threadIdx.x; i < nbins; i += W2_THREADS) h[i] = 0;
+    __syncthreads();
+    const uint64_t base = ((uint64_t)blockIdx.x * (W2_THREADS / 64) + (threadIdx.x >> 6)) * (uint64_t)(W2_ITEMS * 64);
+    enum_consecutive<W2_ITEMS>(e, block_read, base, [&](int, uint64_t km, uint32_t, uint32_t) { atomicAdd(&h[(uint32_t)(km >> (64 - b1))], 1u); });
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nbins; i += W2_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
+}
+
+// tiles of the second pass (none straddles two first-digit buckets): as k_msd_tiles, up to 1024 first digits, tiles of W2_TILE records
+__global__ __launch_bounds__(W2_MAXBINS) void k31_tiles(const uint32_t *hist1_row0, uint32_t nb1, uint64_t I, uint32_t *b1start, uint32_t *tile0)
+{
+    __shared__ uint32_t wsum[W2_MAXBINS / 64];
+    const uint32_t d = threadIdx.x, lane = d & 63, w = d >> 6;
+    const uint32_t st = d < nb1 ? hist1_row0[d] : (uint32_t)I, en = d + 1 < nb1 ? hist1_row0[d + 1] : (uint32_t)I;
+    const uint32_t nt = d < nb1 ? (en - st + W2_TILE - 1) / W2_TILE : 0u;
+    uint32_t inc = nt;
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= (uint32_t)s2) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t run = inc - nt;
+    for (uint32_t ww = 0; ww < w; ++ww) run += wsum[ww];
+    if (d < nb1) { b1start[d] = st; tile0[d] = run; }
+    if (d == nb1 - 1) { b1start[nb1] = (uint32_t)I; tile0[nb1] = run + nt; }
+}
+__device__ __forceinline__ void seg_tile2(const SegTiles &sg, uint32_t t, uint32_t &bucket, uint32_t &start, uint32_t &count)
+{
+    uint32_t lo = 0, hi = sg.nb1;
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sg.tile0[mid] <= t) lo = mid; else hi = mid; }
+    bucket = lo;
+    start = sg.b1start[lo] + (t - sg.tile0[lo]) * (uint32_t)W2_TILE;
+    const uint32_t end = sg.b1start[lo + 1];
+    count = end - start < (uint32_t)W2_TILE ? end - start : (uint32_t)W2_TILE;
+}
+
+__global__ __launch_bounds__(W2_THREADS) void k31_hist2(const Rec2 *recs, SegTiles sg, int shift, int bits, uint32_t *hist)
+{
+    __shared__ uint32_t h[W2_MAXBINS];
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
+    if (blockIdx.x >= sg.tile0[sg.nb1]) return;
+    for (uint32_t i = threadIdx.x; i < nbins; i += W2_THREADS) h[i] = 0;
+    __syncthreads();
+    uint32_t bucket, start, count;
+    seg_tile2(sg, blockIdx.x, bucket, start, count);
+    uint64_t k[W2_ITEMS];
+#pragma unroll
+    for (int r = 0; r < W2_ITEMS; ++r) { const uint32_t q = (uint32_t)r * W2_THREADS + threadIdx.x; k[r] = q < count ? recs[start + q].hi : 0; }
+#pragma unroll
+    for (int r = 0; r < W2_ITEMS; ++r) { const uint32_t q = (uint32_t)r * W2_THREADS + threadIdx.x; if (q < count) atomicAdd(&h[(uint32_t)(k[r] >> shift) & dmask], 1u); }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nbins; i += W2_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
+}
+
+// second-digit places: as k_msd_segscan, up to 1024 second digits
+__global__ __launch_bounds__(W2_MAXBINS) void k31_segscan(uint32_t *hist, SegTiles sg, uint32_t nb2, uint32_t *b2start, uint64_t I)
+{
+    __shared__ uint32_t wsum[W2_MAXBINS / 64];
+    const uint32_t b = blockIdx.x, d = threadIdx.x, lane = d & 63, w = d >> 6;
+    const uint32_t t0 = sg.tile0[b], t1 = sg.tile0[b + 1];
+    uint32_t run = 0;
+    if (d < nb2) {
+        for (uint32_t t = t0; t < t1; ++t) { const uint32_t x = hist[(size_t)t * nb2 + d]; hist[(size_t)t * nb2 + d] = run; run += x; }
+    }
+    uint32_t inc = run;
+#pragma unroll
+    for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= (uint32_t)s2) inc += o; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = sg.b1start[b] + inc - run;
+    for (uint32_t ww = 0; ww < w; ++ww) base += wsum[ww];
+    if (d < nb2) {
+        b2start[(size_t)b * nb2 + d] = base;
+        for (uint32_t t = t0; t < t1; ++t) hist[(size_t)t * nb2 + d] += base;
+    }
+    if (b == gridDim.x - 1 && d == 0) b2start[(size_t)gridDim.x * nb2] = (uint32_t)I;
+}
+
+// scatter of one tile of records by one digit of the k-mer (any order inside a digit: k31_count sorts every bucket).  ENUM: the tile's
+// records are enumerated from the reads (4096 consecutive instances); else read from `in` (a bucket-aligned tile).
+template <bool ENUM>
+__global__ __launch_bounds__(W2_THREADS) void k31_scatter(EnumParams e, const BlockInfo *block_read, int k2, int pbits, const Rec2 *in, SegTiles sg, int shift, int bits,
+                                                         const uint32_t *hist_scanned, Rec2 *out)
+{
+    constexpr int WAVES = W2_THREADS / 64, DPT = W2_MAXBINS / W2_THREADS;
+    __shared__ uint32_t lcnt[W2_MAXBINS], lstart[W2_MAXBINS], delta[W2_MAXBINS], wsum[WAVES];
+    __shared__ Rec2 lrec[W2_TILE];
+    const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
+    if (!ENUM && blockIdx.x >= sg.tile0[sg.nb1]) return;
+    for (int i = threadIdx.x; i < W2_MAXBINS; i += W2_THREADS) lcnt[i] = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint64_t khi[W2_ITEMS], klo[W2_ITEMS];
+    uint32_t count = 0;
+    if (ENUM) {
+        const uint64_t tbase = (uint64_t)blockIdx.x * W2_TILE, base = tbase + (uint64_t)w * (W2_ITEMS * 64);
+        const uint64_t left = e.I - tbase;
+        count = left < (uint64_t)W2_TILE ? (uint32_t)left : (uint32_t)W2_TILE;
+#pragma unroll
+        for (int it = 0; it < W2_ITEMS; ++it) { khi[it] = ~0ull; klo[it] = 0; }
+        enum_consecutive<W2_ITEMS>(e, block_read, base, [&](int it, uint64_t km, uint32_t r, uint32_t p) { khi[it] = km >> (64 - k2); klo[it] = ((uint64_t)r << pbits) | p; });
+    } else {
+        uint32_t bucket, start;
+        seg_tile2(sg, blockIdx.x, bucket, start, count);
+#pragma unroll
+        for (int it = 0; it < W2_ITEMS; ++it) {
+            const uint32_t q = (uint32_t)it * W2_THREADS + threadIdx.x;
+            if (q < count) { const Rec2 r = in[start + q]; khi[it] = r.hi; klo[it] = r.lo; } else { khi[it] = ~0ull; klo[it] = 0; }
+        }
+    }
+    uint32_t gb[DPT];
+#pragma unroll
+    for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * W2_THREADS; gb[u] = d < nbins ? hist_scanned[(size_t)blockIdx.x * nbins + d] : 0u; }
+    uint16_t rank[W2_ITEMS];
+#pragma unroll
+    for (int it = 0; it < W2_ITEMS; ++it) {
+        rank[it] = 0;
+        if (khi[it] != ~0ull) rank[it] = (uint16_t)atomicAdd(&lcnt[(uint32_t)(khi[it] >> shift) & dmask], 1u);      // (a k-mer of 2k <= 62 bits is never all ones)
+    }
+    __syncthreads();
+    {
+        uint32_t tot[DPT], both = 0;
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = DPT * threadIdx.x + u; tot[u] = d < nbins ? lcnt[d] : 0u; both += tot[u]; }
+        uint32_t inc = both;
+#pragma unroll
+        for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= s2) inc += o; }
+        if (lane == 63) wsum[w] = inc;
+        __syncthreads();
+        uint32_t run = inc - both;
+        for (int ww = 0; ww < w; ++ww) run += wsum[ww];
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = DPT * threadIdx.x + u; if (d < nbins) lstart[d] = run; run += tot[u]; }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * W2_THREADS; if (d < nbins) delta[d] = gb[u] - lstart[d]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < W2_ITEMS; ++it)
+        if (khi[it] != ~0ull) lrec[lstart[(uint32_t)(khi[it] >> shift) & dmask] + rank[it]] = Rec2{khi[it], klo[it]};
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < count; t += W2_THREADS) {      // the tile lies ordered by digit: a digit's records are one contiguous run of the output
+        const Rec2 r = lrec[t];
+        out[delta[(uint32_t)(r.hi >> shift) & dmask] + t] = r;
+    }
+}
+
+// One workgroup per bucket: sort, count, filter, compact (see the header of this section).
+__global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const uint32_t *b2start, uint32_t nbuckets, int k2, int T, int PB, uint32_t lower, uint32_t upper,
+                                                        uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint64_t *wrel, uint64_t *ktmp)
+{
+    constexpr uint32_t NW = W2C_THREADS / 64, NH = W2C_KPT * NW, NSB = 512;
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem31[];
+    Rec2 *A = reinterpret_cast<Rec2 *>(smem31);                                  // W2_CAP records
+    uint32_t *sbcnt = smem31 + W2_CAP * 4, *sbstart = sbcnt + NSB, *H = sbstart + NSB + 1, *RE = H + W2_CAP + 2, *hcnt = RE + W2_CAP + 2, *wsum = hcnt + NH + 1, *misc = wsum + 2 * NW;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint64_t lt = (1ull << lane) - 1;
+    const int R = k2 - T;                                  // value bits the partition has not used
+    const uint64_t remmask = (1ull << R) - 1;
+    unsigned long long st_distinct = 0, st_sumsq = 0;
+    uint32_t st_maxcol = 0;
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
+        if (n == 0 || n > W2_CAP) {
+            if (tid == 0) { bN[b] = 0; bZ[b] = 0; if (n > W2_CAP) atomicAdd(&gstat->ncrowded, 1u); }
+            continue;
+        }
+        Rec2 key[W2C_KPT];
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) { const uint32_t i = (uint32_t)u * W2C_THREADS + tid; key[u] = i < n ? recs[s0 + i] : Rec2{~0ull, ~0ull}; }
+        // value ranges of the sort: 2^rbits of them over the R remaining value bits, ~4-8 records each
+        int rbits = R < 9 ? R : 9;
+        while (rbits > 0 && (n >> rbits) < 4u) --rbits;
+        const int rsh = R - rbits;
+        auto range_of = [&](uint64_t hi) -> uint32_t { return (uint32_t)((hi & remmask) >> rsh); };
+        sbcnt[tid] = 0;
+        if (tid == 0) { misc[0] = 0; misc[1] = 0; }
+        lds_sync();
+        uint32_t slot[W2C_KPT];
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) { slot[u] = 0; if ((uint32_t)u * W2C_THREADS + tid < n) slot[u] = atomicAdd(&sbcnt[range_of(key[u].hi)], 1u); }
+        lds_sync();
+        {   // exclusive scan of the 512 range counts: one per lane
+            const uint32_t c0 = sbcnt[tid];
+            uint32_t inc = c0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+            if (lane == 63) wsum[wv] = inc;
+            lds_sync();
+            uint32_t ex = inc - c0;
+            for (uint32_t ww = 0; ww < wv; ++ww) ex += wsum[ww];
+            sbstart[tid] = ex;
+            if (tid == W2C_THREADS - 1) sbstart[NSB] = ex + c0;
+        }
+        lds_sync();
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) if ((uint32_t)u * W2C_THREADS + tid < n) A[sbstart[range_of(key[u].hi)] + slot[u]] = key[u];
+        lds_sync();
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) {
+            if ((uint32_t)u * W2C_THREADS + tid < n) {
+                const uint32_t sb = range_of(key[u].hi), lo = sbstart[sb], hi = sbstart[sb + 1];
+                uint32_t rank = 0;
+                for (uint32_t x = lo; x < hi; ++x) { const Rec2 y = A[x]; rank += (y.hi < key[u].hi || (y.hi == key[u].hi && y.lo < key[u].lo)) ? 1u : 0u; }
+                slot[u] = lo + rank;
+            }
+        }
+        lds_sync();
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) if ((uint32_t)u * W2C_THREADS + tid < n) A[slot[u]] = key[u];
+        lds_sync();
+        // runs of equal k-mers, in place order p = u * 512 + tid; the column of place p = run heads at or before it - 1
+        uint32_t headmask = 0;
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) {
+            const uint32_t p = (uint32_t)u * W2C_THREADS + tid;
+            const bool head = p < n && (p == 0 || A[p - 1].hi != A[p].hi);
+            const uint64_t bal = __ballot(head);
+            if (head) headmask |= 1u << u;
+            slot[u] = (uint32_t)__popcll(bal & lt) + (head ? 1u : 0u);
+            if (lane == 0) hcnt[u * NW + wv] = (uint32_t)__popcll(bal);
+        }
+        lds_sync();
+        if (wv == 0) {      // exclusive scan of the NH = 64 (u, wave) head counts, in place order
+            const uint32_t c0 = hcnt[lane];
+            uint32_t inc = c0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+            hcnt[lane] = inc - c0;
+            if (lane == 63) hcnt[NH] = inc;
+        }
+        lds_sync();
+        const uint32_t ncol = hcnt[NH];
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) {
+            slot[u] = hcnt[u * NW + wv] + slot[u] - 1u;                     // the column of place u * 512 + tid
+            if ((headmask >> u) & 1u) H[slot[u]] = (uint32_t)u * W2C_THREADS + tid;
+        }
+        if (tid == 0) H[ncol] = n;
+        lds_sync();
+        // reliable columns: their number among the reliable ones and the place of their first entry among the kept entries (exclusive scans over the columns)
+        uint32_t carry = 0;      // (rel << 16 | entries) summed over the columns before this chunk: both below 2^13
+        for (uint32_t c0 = 0; c0 < ncol; c0 += W2C_THREADS) {
+            const uint32_t c = c0 + tid;
+            uint32_t L = 0, mine = 0;
+            if (c < ncol) {
+                L = H[c + 1] - H[c];
+                if (L >= lower && L <= upper) { mine = (1u << 16) | L; st_sumsq += (unsigned long long)L * L; st_maxcol = L > st_maxcol ? L : st_maxcol; }
+                ++st_distinct;
+            }
+            uint32_t inc = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+            if (lane == 63) wsum[NW + wv] = inc;
+            lds_sync();
+            uint32_t ex = carry + inc - mine, tot = 0;
+            for (uint32_t ww = 0; ww < NW; ++ww) { const uint32_t x = wsum[NW + ww]; if (ww < wv) ex += x; tot += x; }
+            if (c < ncol) RE[c] = mine ? ex : 0xFFFFFFFFu;      // reliable: (its number << 16) | first kept entry
+            carry += tot;
+            lds_sync();
+        }
+        const uint32_t Nb = carry >> 16, Zb = carry & 0xFFFFu;      // (Zb <= n <= 4096, Nb <= 2048)
+        const uint32_t vscale = Nb > 1u ? 65535u / (Nb - 1u) : 0u;   // columns spread over the 16 value bits the emit kernels sort by (strictly increasing: vscale >= 1)
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) {
+            const uint32_t p = (uint32_t)u * W2C_THREADS + tid;
+            if (p < n) {
+                const uint32_t col = slot[u], re = RE[col];
+                if (re != 0xFFFFFFFFu) {
+                    const uint32_t rc = re >> 16, eo = re & 0xFFFFu;
+                    const Rec2 x = A[p];
+                    wrel[s0 + eo + (p - H[col])] = ((uint64_t)(rc * vscale) << PB) | x.lo;
+                    if ((headmask >> u) & 1u) ktmp[s0 + rc] = x.hi << (64 - k2);
+                }
+            }
+        }
+        if (tid == 0) { bN[b] = Nb; bZ[b] = Zb; }
+        lds_sync();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        st_distinct += __shfl_xor(st_distinct, d, 64); st_sumsq += __shfl_xor(st_sumsq, d, 64);
+        const uint32_t o2 = __shfl_xor(st_maxcol, d, 64); st_maxcol = o2 > st_maxcol ? o2 : st_maxcol;
+    }
+    if (lane == 0) { if (st_distinct) atomicAdd(&gstat->distinct, st_distinct); if (st_sumsq) atomicAdd(&gstat->sumsq, st_sumsq); if (st_maxcol) atomicMax(&gstat->maxcol, st_maxcol); }
+}
+constexpr size_t W2C_LDS = ((size_t)W2_CAP * 4 + 512 + 513 + (W2_CAP + 2) * 2 + (W2C_KPT * (W2C_THREADS / 64) + 1) + 2 * (W2C_THREADS / 64) + 8) * 4;
+
 int bits_needed_u(uint64_t maxval)
 {
     int b = 1;
@@ -916,11 +1227,21 @@ int bits_needed_u(uint64_t maxval)
 // rel_counts, a_colptr, a_csc, the CSR sort keys (csr_words, hint bits included) or kid_of_entry — plus the padded column store.
 bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
 {
-    const int k = c.cfg.k, k2 = 2 * k, T = k2 - VBITS;
+    const int k = c.cfg.k, k2 = 2 * k;
     if (c.opt.kmer_no_msd || c.opt.kmer_pairs || c.opt.kmer_unfused || c.opt.emit_plain || c.opt.kmer_drop) return false;
-    if (T < 2 || T > 2 * MT_MAXBITS || c.cfg.upper > 255 || I == 0) return false;
+    if (k > 31 || c.cfg.upper > 255 || I == 0) return false;
+    // k <= 17: the partition takes all but 16 value bits.  19 <= k <= 31 ("wide", 16-byte records): as many bits as make a bucket of ~1500 instances
+    const bool wide = k2 - VBITS > 2 * MT_MAXBITS;
+    int T = k2 - VBITS;
+    if (wide) {
+        T = 12;
+        while (T < 2 * W2_MAXBITS && (I >> T) > 1536) ++T;
+        if (c.opt.msd_wide_bits > 0) T = std::min(std::max(c.opt.msd_wide_bits, 2), 2 * W2_MAXBITS);      // (tests: other splits)
+        if (T > k2 - 2) return false;
+    }
+    if (T < 2) return false;
     // worth it from ~1024 instances per bucket on (the bucket kernel pays ~2 us per bucket whatever it holds); smaller inputs keep the sort
-    if (!c.opt.kmer_msd && I < ((uint64_t)1024 << T)) return false;
+    if (!c.opt.kmer_msd && (wide ? I < (1ull << 22) : I < ((uint64_t)1024 << T))) return false;
     uint32_t maxlen = 0;
     for (int64_t r = 0; r < c.nreads; ++r) maxlen = c.h_len[(size_t)r] > maxlen ? c.h_len[(size_t)r] : maxlen;
     const uint64_t maxpos = maxlen >= (uint32_t)k ? maxlen - (uint32_t)k : 0;
@@ -929,13 +1250,14 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     m.pbits = bits_needed_u(maxpos);
     const int mb = bits_needed_u((uint64_t)(c.nreads > 0 ? c.nreads - 1 : 0));
     m.PB = mb + m.pbits;
-    if (m.b2 + VBITS + m.PB > 62) return false;      // (the two top bits of a staged entry carry its hint)
+    if ((wide ? 0 : m.b2) + VBITS + m.PB > 62) return false;      // (the two top bits of a staged entry carry its hint)
     hipStream_t s = c.stream;
     const uint32_t nb1 = 1u << m.b1, nb2 = 1u << m.b2, nbuckets = nb1 * nb2;
-    const uint32_t ntiles1 = (uint32_t)((I + MT_TILE - 1) / MT_TILE), ntiles2 = ntiles1 + nb1;
+    const uint32_t tile = wide ? (uint32_t)W2_TILE : (uint32_t)MT_TILE;
+    const uint32_t ntiles1 = (uint32_t)((I + tile - 1) / tile), ntiles2 = ntiles1 + nb1;
 
-    c.ws_a.reserve((size_t)(I + 2) * 8); c.ws_c.reserve((size_t)(I + 2) * 8);
-    c.ws_sort.reserve(((size_t)ntiles2 << MT_MAXBITS) * 4 + 4096);
+    c.ws_a.reserve((size_t)(I + 2) * (wide ? 16 : 8)); c.ws_c.reserve((size_t)(I + 2) * (wide ? 16 : 8));
+    c.ws_sort.reserve(((size_t)ntiles2 << (wide ? W2_MAXBITS : MT_MAXBITS)) * 4 + 4096);
     c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 6 + (size_t)(2 * nb1 + 8) * 4 + 256);
     uint32_t *hist = c.ws_sort.as<uint32_t>();
     BucketStats *gstat = c.ws_e.as<BucketStats>();
@@ -952,10 +1274,19 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     c.ws_b.reserve((size_t)(nib + 1) * sizeof(BlockInfo));
     const BlockInfo *bi = c.ws_b.as<BlockInfo>();
     hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
+    SegTiles sg{b1start, tile0, nb1};
+    BucketOut o{};
+    const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < 8192u ? (uint32_t)c.opt.msd_small_cap : 8192u;
+    static DeviceOnce attr_once;
+    attr_once.run(c.device, [&] {
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_bucket<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k31_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    });
+    if (!wide) {
     // first digit
     hipLaunchKernelGGL(k_msd_hist1, dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, hist);
     radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
-    SegTiles sg{b1start, tile0, nb1};
     hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
     hipLaunchKernelGGL((k_msd_scatter<true>), dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa);
     // second digit, inside every first-digit bucket
@@ -966,19 +1297,30 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     c.t_a.stop(s);
     // buckets: count
     c.t_b.start(s);
-    static DeviceOnce attr_once;
-    attr_once.run(c.device, [&] {
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_bucket<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    });
     ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
     const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus);
     // entries per bucket: up to 4096 -> k_msd_emit_small<16>, up to 8192 -> <32>, beyond -> k_msd_bucket (option "msd_small_cap": tests lower the last bound)
-    const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < 8192u ? (uint32_t)c.opt.msd_small_cap : 8192u;
-    BucketOut o{};
     // (the first pass's words are dead: their buffer takes the entries — the instances of reliable k-mers —, bucket by bucket)
     hipLaunchKernelGGL(k_msd_count, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, small_cap,
                        bN, bZ, gstat, crowded, wa);
+    } else {
+        // 19 <= k <= 31: 16-byte records (the section above k31_hist1)
+        Rec2 *ra = c.ws_a.as<Rec2>(), *rb = c.ws_c.as<Rec2>();
+        hipLaunchKernelGGL(k31_hist1, dim3(ntiles1), dim3(W2_THREADS), 0, s, e, bi, m.b1, hist);
+        radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
+        hipLaunchKernelGGL(k31_tiles, dim3(1), dim3(W2_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
+        hipLaunchKernelGGL((k31_scatter<true>), dim3(ntiles1), dim3(W2_THREADS), 0, s, e, bi, k2, m.pbits, (const Rec2 *)nullptr, sg, k2 - m.b1, m.b1, (const uint32_t *)hist, ra);
+        hipLaunchKernelGGL(k31_hist2, dim3(ntiles2), dim3(W2_THREADS), 0, s, (const Rec2 *)ra, sg, k2 - T, m.b2, hist);
+        hipLaunchKernelGGL(k31_segscan, dim3(nb1), dim3(W2_MAXBINS), 0, s, hist, sg, nb2, b2start, I);
+        hipLaunchKernelGGL((k31_scatter<false>), dim3(ntiles2), dim3(W2_THREADS), 0, s, e, bi, k2, m.pbits, (const Rec2 *)ra, sg, k2 - T, m.b2, (const uint32_t *)hist, rb);
+        c.t_a.stop(s);
+        c.t_b.start(s);
+        ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
+        // (the first pass's records are dead: the front half of their buffer takes the kept entries, one word each, the back half the buckets' reliable k-mers)
+        hipLaunchKernelGGL(k31_count, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus)), dim3(W2C_THREADS), W2C_LDS, s, (const Rec2 *)rb, (const uint32_t *)b2start, nbuckets, k2, T, m.PB,
+                           (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, bN, bZ, gstat, wa, wa + (I + 2));
+        o.kmer_src = wa + (I + 2);
+    }
     ELBA_HIP(hipMemsetAsync(bN + nbuckets, 0, 4, s)); ELBA_HIP(hipMemsetAsync(bZ + nbuckets, 0, 4, s));
     exclusive_scan_u32(s, bN, kidbase, (int64_t)nbuckets + 1, c.ws_scan);
     exclusive_scan_u32(s, bZ, entbase, (int64_t)nbuckets + 1, c.ws_scan);      // Z <= I < 2^32
@@ -989,6 +1331,11 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     ELBA_HIP(hipMemcpyAsync(&hs, gstat, sizeof(hs), hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
     const uint64_t N = h2[0], Z = h2[1];
+    if (wide && hs.ncrowded) {      // a bucket beyond what k31_count sorts in LDS (a repeat family, a homopolymer): the whole input takes the sort of kmer.hip
+        if (c.opt.trace) fprintf(stderr, "[elba] count_kmers: %u buckets of the wide partition hold more than %u instances: sorting instead\n", hs.ncrowded, W2_CAP);
+        c.t_b.stop(s); c.t_total.stop(s);
+        return false;
+    }
     ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
     // buckets: emit
     c.rel_kmers.reserve((size_t)(N + 1) * 8);
@@ -1055,7 +1402,7 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
         if (small_cap > 4096u && hs.nmid)
             hipLaunchKernelGGL((k_msd_emit_small<16, 512>), dim3(grid32), dim3(512), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
                                (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
-        if (hs.ncrowded)
+        if (hs.ncrowded && !wide)
             hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,
                                (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, (const uint32_t *)crowded, (const BucketStats *)gstat, (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
     };
@@ -1085,6 +1432,7 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     st.ms_total = c.t_total.ms(); st.ms_count = c.t_a.ms(); st.ms_sort = c.t_b.ms(); st.ms_lookup = 0;
     c.ndistinct = (int64_t)hs.distinct;
     c.N = (int64_t)N; c.Z = (int64_t)Z;
+    c.kmer_path = wide ? 2 : 1;
     return true;
 }
 

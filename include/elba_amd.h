@@ -318,6 +318,8 @@ int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
  *                            instead of going straight to their row's slab ("mirror slabs")
  *   "overlap_slab_q16"       slab entries reserved per row entry of A in that call, x 65536 (0: the call ran without slabs)
  *   "resident_bytes_A"       device bytes the resident k-mer matrix occupies (CSR, columns, padded column store in use, pointers)
+ *   "kmer_path"              how the last elba_count_kmers counted: 0 = sort, 1 = two-level value partition + LDS count tables (k <= 17),
+ *                            2 = two-level partition of 16-byte records + LDS sort per bucket (19 <= k <= 31)
  *   "gather_slots"           columns of the padded column store in use (with inline partners: only the columns some row entry still fetches) */
 int  elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value);
 

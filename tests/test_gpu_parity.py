@@ -684,3 +684,61 @@ def test_mirror_slabs_of_any_size_give_the_same_matrix(shape):
     assert e.get_stat("overlap_slab_q16") == 0
     gu.assert_B_equal(e.export_csr(), o.B())
     e.close()
+
+
+@pytest.mark.parametrize("k,lo,up,bits", [(31, 2, 8, 0), (31, 3, 40, 0), (19, 2, 8, 0), (21, 2, 12, 14), (25, 2, 8, 4), (31, 2, 8, 20), (27, 2, 30, 9)])
+def test_wide_partition_kmer_path_equals_the_oracle(k, lo, up, bits):
+    """19 <= k <= 31 (the reference's default build is k = 31): value + read + position do not fit one word, the instances travel as 16-byte
+    records through a two-level partition of their leading value bits and every bucket is sorted in LDS (kmer_msd.hip, k31_*).  Forced on a
+    small input ("kmer_msd"; "msd_wide_bits": other splits of the value — few, large buckets; many, empty ones).  Low-complexity reads, reads
+    shorter than k and reads around the word boundaries of the packed stream included: A, B and every statistic equal the oracle's."""
+    reads, _ = synth.make_reads(178 + k, 60000, 14, 2500, 700, error=0.05, min_len=100)
+    rng = np.random.default_rng(k)
+    extra = [b"A" * 300, b"AC" * 200, b"T" * 150 + b"G" * 150, b"ACG" * 120, b"ACGT" * 90] * 3
+    extra += [bytes(rng.choice(list(b"ACGT"), n).tolist()) for n in (k - 1, k, k + 1, k + 2, 31, 32, 33, 63, 64, 65, 3)]
+    seqs = list(reads) + extra
+    np.random.default_rng(5).shuffle(seqs)
+    packed, off, lens = po.pack_reads(seqs)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, k, lo, up, options={"kmer_msd": 1, "msd_wide_bits": bits})
+    assert e.get_stat("kmer_path") == 2
+    o = gu.oracle_run(packed, off, lens, k, lo, up, threads=8)
+    assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    assert (e.kmer_histogram() == o.A()["hist"]).all()
+    e.create_kmer_matrix()                                  # the repeat call rebuilds from the column pointers (the sort keys were consumed)
+    e.create_seed_matrix()
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+
+
+def test_wide_partition_hands_a_crowded_bucket_to_the_sort():
+    """A bucket beyond what the wide path sorts in LDS (4096 instances of ONE k-mer: a homopolymer run) sends the whole input to the sort
+    of kmer.hip: same matrices, another path."""
+    reads, _ = synth.make_reads(7, 40000, 10, 2000, 500, error=0.05, min_len=100)
+    seqs = list(reads) + [b"A" * 700] * 8
+    packed, off, lens = po.pack_reads(seqs)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 31, 2, 8, options={"kmer_msd": 1})
+    assert e.get_stat("kmer_path") == 0
+    o = gu.oracle_run(packed, off, lens, 31, 2, 8, threads=8)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+
+
+def test_reference_default_build_through_the_wide_partition():
+    """The reference's bundled reads.fa at its default build (Makefile:1-3: k = 31, L = 15, U = 35) through the wide partition path: the figures
+    the survey measured from the reference's own code and the oracle's matrices."""
+    m = util.golden_meta()["reads_ref_appB"][1]
+    assert (m["k"], m["lower"], m["upper"]) == (31, 15, 35)
+    packed, off, lens = po.pack_reads(util.read_fasta(os.path.join(G, "reads_ref.fa.gz")))
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 31, 15, 35, options={"kmer_msd": 1})
+    assert e.get_stat("kmer_path") == 2
+    assert (ks["nreads"], ks["instances"], ks["reliable"], ks["entries"]) == (m["M"], m["I"], m["N"], m["Z"])
+    assert (st["products"], st["nnz_before_prune"], st["nnz"], st["nnz_upper"], st["max_numshared"]) == (m["P"], m["Yraw"], m["Y"], m["nupper"], m["maxshared"])
+    o = gu.oracle_run(packed, off, lens, 31, 15, 35)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
