@@ -921,6 +921,15 @@ constexpr uint32_t W2_CAP = 4096;                // records of a bucket k31_coun
 constexpr int W2C_THREADS = 512, W2C_KPT = (int)(W2_CAP / W2C_THREADS);
 static_assert(W2_ITEMS * 64 <= (1 << IB_SHIFT), "a wavefront's share of a tile lies inside one block of the instance -> read table");
 struct alignas(16) Rec2 { uint64_t hi, lo; };
+// The canonical k-mer is the smaller of a k-mer and its reverse complement: as a fraction x of the value range its density is 2 (1 - x) — the lowest
+// buckets of an even split hold twice the average (and run past W2_CAP).  Buckets are therefore cut by the leading bits of G(x) = 2x - x^2, the
+// distribution function of that density, taken on the value's leading 32 bits: monotone in the value (k-mer ids follow the buckets' order),
+// and every bucket receives the same share of a random genome's k-mers.
+__device__ __forceinline__ uint32_t w2_flat(uint32_t x32)
+{
+    const uint64_t g = ((uint64_t)x32 << 1) - (((uint64_t)x32 * x32) >> 32);
+    return g > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)g;
+}
 
 __global__ __launch_bounds__(W2_THREADS) void k31_hist1(EnumParams e, const BlockInfo *block_read, int b1, uint32_t *hist)
 {
@@ -929,7 +938,7 @@ __global__ __launch_bounds__(W2_THREADS) void k31_hist1(EnumParams e, const Bloc
     for (uint32_t i = threadIdx.x; i < nbins; i += W2_THREADS) h[i] = 0;
     __syncthreads();
     const uint64_t base = ((uint64_t)blockIdx.x * (W2_THREADS / 64) + (threadIdx.x >> 6)) * (uint64_t)(W2_ITEMS * 64);
-    enum_consecutive<W2_ITEMS>(e, block_read, base, [&](int, uint64_t km, uint32_t, uint32_t) { atomicAdd(&h[(uint32_t)(km >> (64 - b1))], 1u); });
+    enum_consecutive<W2_ITEMS>(e, block_read, base, [&](int, uint64_t km, uint32_t, uint32_t) { atomicAdd(&h[w2_flat((uint32_t)(km >> 32)) >> (32 - b1)], 1u); });
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nbins; i += W2_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
 }
@@ -961,7 +970,8 @@ __device__ __forceinline__ void seg_tile2(const SegTiles &sg, uint32_t t, uint32
     count = end - start < (uint32_t)W2_TILE ? end - start : (uint32_t)W2_TILE;
 }
 
-__global__ __launch_bounds__(W2_THREADS) void k31_hist2(const Rec2 *recs, SegTiles sg, int shift, int bits, uint32_t *hist)
+// (shift / bits of the digit refer to the flattened leading 32 bits, w2_flat; k2 - 32 = the value bits below them)
+__global__ __launch_bounds__(W2_THREADS) void k31_hist2(const Rec2 *recs, SegTiles sg, int k2, int shift, int bits, uint32_t *hist)
 {
     __shared__ uint32_t h[W2_MAXBINS];
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
@@ -974,7 +984,7 @@ __global__ __launch_bounds__(W2_THREADS) void k31_hist2(const Rec2 *recs, SegTil
 #pragma unroll
     for (int r = 0; r < W2_ITEMS; ++r) { const uint32_t q = (uint32_t)r * W2_THREADS + threadIdx.x; k[r] = q < count ? recs[start + q].hi : 0; }
 #pragma unroll
-    for (int r = 0; r < W2_ITEMS; ++r) { const uint32_t q = (uint32_t)r * W2_THREADS + threadIdx.x; if (q < count) atomicAdd(&h[(uint32_t)(k[r] >> shift) & dmask], 1u); }
+    for (int r = 0; r < W2_ITEMS; ++r) { const uint32_t q = (uint32_t)r * W2_THREADS + threadIdx.x; if (q < count) atomicAdd(&h[(w2_flat((uint32_t)(k[r] >> (k2 - 32))) >> shift) & dmask], 1u); }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nbins; i += W2_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
 }
@@ -1042,7 +1052,7 @@ __global__ __launch_bounds__(W2_THREADS) void k31_scatter(EnumParams e, const Bl
 #pragma unroll
     for (int it = 0; it < W2_ITEMS; ++it) {
         rank[it] = 0;
-        if (khi[it] != ~0ull) rank[it] = (uint16_t)atomicAdd(&lcnt[(uint32_t)(khi[it] >> shift) & dmask], 1u);      // (a k-mer of 2k <= 62 bits is never all ones)
+        if (khi[it] != ~0ull) rank[it] = (uint16_t)atomicAdd(&lcnt[(w2_flat((uint32_t)(khi[it] >> (k2 - 32))) >> shift) & dmask], 1u);      // (a k-mer of 2k <= 62 bits is never all ones)
     }
     __syncthreads();
     {
@@ -1065,11 +1075,11 @@ __global__ __launch_bounds__(W2_THREADS) void k31_scatter(EnumParams e, const Bl
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < W2_ITEMS; ++it)
-        if (khi[it] != ~0ull) lrec[lstart[(uint32_t)(khi[it] >> shift) & dmask] + rank[it]] = Rec2{khi[it], klo[it]};
+        if (khi[it] != ~0ull) lrec[lstart[(w2_flat((uint32_t)(khi[it] >> (k2 - 32))) >> shift) & dmask] + rank[it]] = Rec2{khi[it], klo[it]};
     __syncthreads();
     for (uint32_t t = threadIdx.x; t < count; t += W2_THREADS) {      // the tile lies ordered by digit: a digit's records are one contiguous run of the output
         const Rec2 r = lrec[t];
-        out[delta[(uint32_t)(r.hi >> shift) & dmask] + t] = r;
+        out[delta[(w2_flat((uint32_t)(r.hi >> (k2 - 32))) >> shift) & dmask] + t] = r;
     }
 }
 
@@ -1080,29 +1090,38 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
     constexpr uint32_t NW = W2C_THREADS / 64, NH = W2C_KPT * NW, NSB = 512;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem31[];
     Rec2 *A = reinterpret_cast<Rec2 *>(smem31);                                  // W2_CAP records
-    uint32_t *sbcnt = smem31 + W2_CAP * 4, *sbstart = sbcnt + NSB, *H = sbstart + NSB + 1, *RE = H + W2_CAP + 2, *hcnt = RE + W2_CAP + 2, *wsum = hcnt + NH + 1, *misc = wsum + 2 * NW;
+    uint32_t *sbcnt = smem31 + W2_CAP * 4, *sbstart = sbcnt + NSB, *H = sbstart + NSB + 1, *RE = H + W2_CAP + 2, *hcnt = RE + W2_CAP + 2, *wsum = hcnt + NH + 1;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t lt = (1ull << lane) - 1;
-    const int R = k2 - T;                                  // value bits the partition has not used
-    const uint64_t remmask = (1ull << R) - 1;
+    const int R = 32 - T;                                  // bits of the flattened leading 32 value bits (w2_flat) the partition has not used
     unsigned long long st_distinct = 0, st_sumsq = 0;
     uint32_t st_maxcol = 0;
+    // (the records of the NEXT bucket are requested before this one is processed: one workgroup per CU, nobody else hides the round trip)
+    Rec2 knext[W2C_KPT];
+    uint32_t s0n = 0, nn = 0;
+    auto fetch = [&](uint32_t bb) {
+        s0n = 0; nn = 0;
+        if (bb < nbuckets) { s0n = b2start[bb]; nn = b2start[bb + 1] - s0n; }
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) { const uint32_t i = (uint32_t)u * W2C_THREADS + tid; knext[u] = (nn <= W2_CAP && i < nn) ? recs[s0n + i] : Rec2{~0ull, ~0ull}; }
+    };
+    fetch(blockIdx.x);
     for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-        const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
+        const uint32_t s0 = s0n, n = nn;
+        Rec2 key[W2C_KPT];
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) key[u] = knext[u];
+        fetch(b + gridDim.x);
         if (n == 0 || n > W2_CAP) {
             if (tid == 0) { bN[b] = 0; bZ[b] = 0; if (n > W2_CAP) atomicAdd(&gstat->ncrowded, 1u); }
             continue;
         }
-        Rec2 key[W2C_KPT];
-#pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) { const uint32_t i = (uint32_t)u * W2C_THREADS + tid; key[u] = i < n ? recs[s0 + i] : Rec2{~0ull, ~0ull}; }
         // value ranges of the sort: 2^rbits of them over the R remaining value bits, ~4-8 records each
         int rbits = R < 9 ? R : 9;
         while (rbits > 0 && (n >> rbits) < 4u) --rbits;
         const int rsh = R - rbits;
-        auto range_of = [&](uint64_t hi) -> uint32_t { return (uint32_t)((hi & remmask) >> rsh); };
+        auto range_of = [&](uint64_t hi) -> uint32_t { return (w2_flat((uint32_t)(hi >> (k2 - 32))) >> rsh) & ((1u << rbits) - 1u); };      // (monotone in the k-mer, like the buckets)
         sbcnt[tid] = 0;
-        if (tid == 0) { misc[0] = 0; misc[1] = 0; }
         lds_sync();
         uint32_t slot[W2C_KPT];
 #pragma unroll
@@ -1128,8 +1147,14 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
         for (int u = 0; u < W2C_KPT; ++u) {
             if ((uint32_t)u * W2C_THREADS + tid < n) {
                 const uint32_t sb = range_of(key[u].hi), lo = sbstart[sb], hi = sbstart[sb + 1];
+                // (the range's first eight records requested at once: a loop with a per-lane trip count is one LDS round trip per record)
                 uint32_t rank = 0;
-                for (uint32_t x = lo; x < hi; ++x) { const Rec2 y = A[x]; rank += (y.hi < key[u].hi || (y.hi == key[u].hi && y.lo < key[u].lo)) ? 1u : 0u; }
+                Rec2 yy[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) yy[q] = A[lo + (uint32_t)q < hi ? lo + (uint32_t)q : lo];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rank += (lo + (uint32_t)q < hi && (yy[q].hi < key[u].hi || (yy[q].hi == key[u].hi && yy[q].lo < key[u].lo))) ? 1u : 0u;
+                for (uint32_t x = lo + 8u; x < hi; ++x) { const Rec2 y = A[x]; rank += (y.hi < key[u].hi || (y.hi == key[u].hi && y.lo < key[u].lo)) ? 1u : 0u; }
                 slot[u] = lo + rank;
             }
         }
@@ -1309,10 +1334,10 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
         hipLaunchKernelGGL(k31_hist1, dim3(ntiles1), dim3(W2_THREADS), 0, s, e, bi, m.b1, hist);
         radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
         hipLaunchKernelGGL(k31_tiles, dim3(1), dim3(W2_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
-        hipLaunchKernelGGL((k31_scatter<true>), dim3(ntiles1), dim3(W2_THREADS), 0, s, e, bi, k2, m.pbits, (const Rec2 *)nullptr, sg, k2 - m.b1, m.b1, (const uint32_t *)hist, ra);
-        hipLaunchKernelGGL(k31_hist2, dim3(ntiles2), dim3(W2_THREADS), 0, s, (const Rec2 *)ra, sg, k2 - T, m.b2, hist);
+        hipLaunchKernelGGL((k31_scatter<true>), dim3(ntiles1), dim3(W2_THREADS), 0, s, e, bi, k2, m.pbits, (const Rec2 *)nullptr, sg, 32 - m.b1, m.b1, (const uint32_t *)hist, ra);
+        hipLaunchKernelGGL(k31_hist2, dim3(ntiles2), dim3(W2_THREADS), 0, s, (const Rec2 *)ra, sg, k2, 32 - T, m.b2, hist);
         hipLaunchKernelGGL(k31_segscan, dim3(nb1), dim3(W2_MAXBINS), 0, s, hist, sg, nb2, b2start, I);
-        hipLaunchKernelGGL((k31_scatter<false>), dim3(ntiles2), dim3(W2_THREADS), 0, s, e, bi, k2, m.pbits, (const Rec2 *)ra, sg, k2 - T, m.b2, (const uint32_t *)hist, rb);
+        hipLaunchKernelGGL((k31_scatter<false>), dim3(ntiles2), dim3(W2_THREADS), 0, s, e, bi, k2, m.pbits, (const Rec2 *)ra, sg, 32 - T, m.b2, (const uint32_t *)hist, rb);
         c.t_a.stop(s);
         c.t_b.start(s);
         ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
