@@ -917,7 +917,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
 // HBM traffic per instance: 16 B written + 16 read (hist2) + 16 read + 16 written + 16 read = 80 B, against 7 passes x 32 B + 3 x 16 B on the sort path.
 constexpr int W2_THREADS = 256, W2_ITEMS = 16, W2_TILE = W2_THREADS * W2_ITEMS;      // 4096 records of 16 bytes: 64 KB of LDS
 constexpr int W2_MAXBITS = 10, W2_MAXBINS = 1 << W2_MAXBITS;
-constexpr uint32_t W2_CAP = 4096;                // records of a bucket k31_count sorts in LDS
+constexpr uint32_t W2_CAP = 3072;                // records of a bucket k31_count sorts in LDS (48 KB + 22 KB of tables: two workgroups per CU)
 constexpr int W2C_THREADS = 512, W2C_KPT = (int)(W2_CAP / W2C_THREADS);
 static_assert(W2_ITEMS * 64 <= (1 << IB_SHIFT), "a wavefront's share of a tile lies inside one block of the instance -> read table");
 struct alignas(16) Rec2 { uint64_t hi, lo; };
@@ -1174,12 +1174,13 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             if (lane == 0) hcnt[u * NW + wv] = (uint32_t)__popcll(bal);
         }
         lds_sync();
-        if (wv == 0) {      // exclusive scan of the NH = 64 (u, wave) head counts, in place order
-            const uint32_t c0 = hcnt[lane];
+        if (wv == 0) {      // exclusive scan of the NH <= 64 (u, wave) head counts, in place order
+            static_assert(NH <= 64, "one head count per lane");
+            const uint32_t c0 = lane < NH ? hcnt[lane] : 0u;
             uint32_t inc = c0;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
-            hcnt[lane] = inc - c0;
+            if (lane < NH) hcnt[lane] = inc - c0;
             if (lane == 63) hcnt[NH] = inc;
         }
         lds_sync();
@@ -1212,7 +1213,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             carry += tot;
             lds_sync();
         }
-        const uint32_t Nb = carry >> 16, Zb = carry & 0xFFFFu;      // (Zb <= n <= 4096, Nb <= 2048)
+        const uint32_t Nb = carry >> 16, Zb = carry & 0xFFFFu;      // (Zb <= n <= W2_CAP, Nb <= W2_CAP / 2)
         const uint32_t vscale = Nb > 1u ? 65535u / (Nb - 1u) : 0u;   // columns spread over the 16 value bits the emit kernels sort by (strictly increasing: vscale >= 1)
 #pragma unroll
         for (int u = 0; u < W2C_KPT; ++u) {
@@ -1260,7 +1261,7 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     int T = k2 - VBITS;
     if (wide) {
         T = 12;
-        while (T < 2 * W2_MAXBITS && (I >> T) > 1536) ++T;
+        while (T < 2 * W2_MAXBITS && (I >> T) > 512) ++T;      // (a bucket may hold W2_CAP: six times this average — k-mers are not spread evenly over real genomes)
         if (c.opt.msd_wide_bits > 0) T = std::min(std::max(c.opt.msd_wide_bits, 2), 2 * W2_MAXBITS);      // (tests: other splits)
         if (T > k2 - 2) return false;
     }
