@@ -1083,20 +1083,29 @@ __global__ __launch_bounds__(W2_THREADS) void k31_scatter(EnumParams e, const Bl
     }
 }
 
-// One workgroup per bucket: sort, count, filter, compact (see the header of this section).
+// One workgroup per bucket: count, filter, number, compact (see the header of this section).  The records are NOT sorted: an LDS hash table keyed by
+// the k-mer counts them (HiFi reads at 40x hold every genomic k-mer ~34 times: a sort ranks every record against its whole run, the table takes
+// one compare-and-swap + one add per record), the RELIABLE k-mers alone — a few hundred per bucket — are sorted by value (range + rank), and every
+// record of a reliable k-mer then draws its place in the k-mer's column; the order inside a column is left to the emit kernels, which sort their
+// entries by (column, read, pos) anyway.  (First version: a full sort of the bucket in LDS — 159 ms for 2.0 G instances, profiles/r04_notes.md.)
+constexpr uint32_t W2_SLOTS = 4096, W2_RELMAX = W2_CAP / 2;      // table slots (> W2_CAP distinct k-mers are impossible: a bucket holds at most W2_CAP records); reliable k-mers of a bucket (LOWER >= 2)
+static_assert(W2_CAP < W2_SLOTS && W2C_KPT * W2C_THREADS >= (int)W2_CAP, "the probe loop needs an empty slot; every record has a register");
 __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const uint32_t *b2start, uint32_t nbuckets, int k2, int T, int PB, uint32_t lower, uint32_t upper,
                                                         uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint64_t *wrel, uint64_t *ktmp)
 {
-    constexpr uint32_t NW = W2C_THREADS / 64, NH = W2C_KPT * NW, NSB = 512;
+    constexpr uint32_t NW = W2C_THREADS / 64, NSB = 512, IPT = (W2_RELMAX + W2C_THREADS - 1) / W2C_THREADS, SPT = W2_SLOTS / W2C_THREADS;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem31[];
-    Rec2 *A = reinterpret_cast<Rec2 *>(smem31);                                  // W2_CAP records
-    uint32_t *sbcnt = smem31 + W2_CAP * 4, *sbstart = sbcnt + NSB, *H = sbstart + NSB + 1, *RE = H + W2_CAP + 2, *hcnt = RE + W2_CAP + 2, *wsum = hcnt + NH + 1;
+    unsigned long long *K = reinterpret_cast<unsigned long long *>(smem31);      // W2_SLOTS keys (~0: empty)
+    uint32_t *CNT = smem31 + 2 * W2_SLOTS;                                        // their counts; for reliable k-mers afterwards: the entries placed so far
+    uint32_t *C = CNT + W2_SLOTS;                                                 // [W2_RELMAX + 1] count of the reliable k-mer number rc -> (scan) its first entry
+    uint32_t *sbcnt = C + W2_RELMAX + 1, *sbstart = sbcnt + NSB, *wsum = sbstart + NSB + 1, *misc = wsum + 2 * NW;
+    uint16_t *RC = reinterpret_cast<uint16_t *>(misc + 8);                        // [W2_SLOTS] number of the slot's k-mer among the bucket's reliable ones (0xFFFF: not reliable)
+    uint16_t *RL = RC + W2_SLOTS, *SA = RL + W2_RELMAX;                           // [W2_RELMAX] the reliable slots, as found / ordered by value range
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint64_t lt = (1ull << lane) - 1;
     const int R = 32 - T;                                  // bits of the flattened leading 32 value bits (w2_flat) the partition has not used
     unsigned long long st_distinct = 0, st_sumsq = 0;
     uint32_t st_maxcol = 0;
-    // (the records of the NEXT bucket are requested before this one is processed: one workgroup per CU, nobody else hides the round trip)
+    // (the records of the NEXT bucket are requested before this one is processed)
     Rec2 knext[W2C_KPT];
     uint32_t s0n = 0, nn = 0;
     auto fetch = [&](uint32_t bb) {
@@ -1116,16 +1125,52 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             if (tid == 0) { bN[b] = 0; bZ[b] = 0; if (n > W2_CAP) atomicAdd(&gstat->ncrowded, 1u); }
             continue;
         }
-        // value ranges of the sort: 2^rbits of them over the R remaining value bits, ~4-8 records each
-        int rbits = R < 9 ? R : 9;
-        while (rbits > 0 && (n >> rbits) < 4u) --rbits;
-        const int rsh = R - rbits;
-        auto range_of = [&](uint64_t hi) -> uint32_t { return (w2_flat((uint32_t)(hi >> (k2 - 32))) >> rsh) & ((1u << rbits) - 1u); };      // (monotone in the k-mer, like the buckets)
+#pragma unroll
+        for (int q = 0; q < (int)SPT; ++q) { const uint32_t sl = (uint32_t)q * W2C_THREADS + tid; K[sl] = ~0ull; CNT[sl] = 0; RC[sl] = 0xFFFFu; }
         sbcnt[tid] = 0;
+        if (tid < 8) misc[tid] = 0;
         lds_sync();
+        // count: one compare-and-swap (+ a probe or two) and one add per record
         uint32_t slot[W2C_KPT];
 #pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) { slot[u] = 0; if ((uint32_t)u * W2C_THREADS + tid < n) slot[u] = atomicAdd(&sbcnt[range_of(key[u].hi)], 1u); }
+        for (int u = 0; u < W2C_KPT; ++u) {
+            slot[u] = 0;
+            if ((uint32_t)u * W2C_THREADS + tid < n) {
+                const unsigned long long hk = key[u].hi;
+                uint32_t sl = (((uint32_t)hk ^ (uint32_t)(hk >> 27)) * 0x9E3779B1u) >> 20;      // 12 bits
+                for (;;) {
+                    const unsigned long long old = atomicCAS(&K[sl], ~0ull, hk);
+                    if (old == ~0ull || old == hk) break;
+                    sl = (sl + 1u) & (W2_SLOTS - 1u);
+                }
+                atomicAdd(&CNT[sl], 1u);
+                slot[u] = sl;
+            }
+        }
+        lds_sync();
+        // the reliable k-mers (LOWER <= count <= UPPER), as found
+#pragma unroll
+        for (int q = 0; q < (int)SPT; ++q) {
+            const uint32_t sl = (uint32_t)q * W2C_THREADS + tid, cnt = CNT[sl];
+            if (cnt) {
+                ++st_distinct;
+                if (cnt >= lower && cnt <= upper) { RL[atomicAdd(&misc[0], 1u)] = (uint16_t)sl; st_sumsq += (unsigned long long)cnt * cnt; st_maxcol = cnt > st_maxcol ? cnt : st_maxcol; }
+            }
+        }
+        lds_sync();
+        const uint32_t Nb = misc[0];
+        // ... numbered in value order: value ranges (monotone in the k-mer, like the buckets), count, scan, scatter, rank inside the range
+        int rbits = R < 9 ? R : 9;
+        while (rbits > 0 && (Nb >> rbits) < 4u) --rbits;
+        const int rsh = R - rbits;
+        auto range_of = [&](unsigned long long hi) -> uint32_t { return (w2_flat((uint32_t)(hi >> (k2 - 32))) >> rsh) & ((1u << rbits) - 1u); };
+        uint32_t isl[IPT], ipos[IPT];
+#pragma unroll
+        for (int q = 0; q < (int)IPT; ++q) {
+            const uint32_t i = (uint32_t)q * W2C_THREADS + tid;
+            isl[q] = 0; ipos[q] = 0;
+            if (i < Nb) { isl[q] = RL[i]; ipos[q] = atomicAdd(&sbcnt[range_of(K[isl[q]])], 1u); }
+        }
         lds_sync();
         {   // exclusive scan of the 512 range counts: one per lane
             const uint32_t c0 = sbcnt[tid];
@@ -1141,67 +1186,27 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
         }
         lds_sync();
 #pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) if ((uint32_t)u * W2C_THREADS + tid < n) A[sbstart[range_of(key[u].hi)] + slot[u]] = key[u];
+        for (int q = 0; q < (int)IPT; ++q) if ((uint32_t)q * W2C_THREADS + tid < Nb) SA[sbstart[range_of(K[isl[q]])] + ipos[q]] = (uint16_t)isl[q];
         lds_sync();
 #pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) {
-            if ((uint32_t)u * W2C_THREADS + tid < n) {
-                const uint32_t sb = range_of(key[u].hi), lo = sbstart[sb], hi = sbstart[sb + 1];
-                // (the range's first eight records requested at once: a loop with a per-lane trip count is one LDS round trip per record)
+        for (int q = 0; q < (int)IPT; ++q) {
+            if ((uint32_t)q * W2C_THREADS + tid < Nb) {
+                const unsigned long long mine = K[isl[q]];
+                const uint32_t sb = range_of(mine), lo = sbstart[sb], hi = sbstart[sb + 1];
                 uint32_t rank = 0;
-                Rec2 yy[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) yy[q] = A[lo + (uint32_t)q < hi ? lo + (uint32_t)q : lo];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) rank += (lo + (uint32_t)q < hi && (yy[q].hi < key[u].hi || (yy[q].hi == key[u].hi && yy[q].lo < key[u].lo))) ? 1u : 0u;
-                for (uint32_t x = lo + 8u; x < hi; ++x) { const Rec2 y = A[x]; rank += (y.hi < key[u].hi || (y.hi == key[u].hi && y.lo < key[u].lo)) ? 1u : 0u; }
-                slot[u] = lo + rank;
+                for (uint32_t x = lo; x < hi; ++x) rank += K[SA[x]] < mine ? 1u : 0u;      // (distinct k-mers: a handful per range)
+                const uint32_t rc = lo + rank;
+                RC[isl[q]] = (uint16_t)rc;
+                C[rc] = CNT[isl[q]];
+                CNT[isl[q]] = 0;                                                            // (from here on: the column's entries placed so far)
+                ktmp[s0 + rc] = mine << (64 - k2);
             }
         }
         lds_sync();
-#pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) if ((uint32_t)u * W2C_THREADS + tid < n) A[slot[u]] = key[u];
-        lds_sync();
-        // runs of equal k-mers, in place order p = u * 512 + tid; the column of place p = run heads at or before it - 1
-        uint32_t headmask = 0;
-#pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) {
-            const uint32_t p = (uint32_t)u * W2C_THREADS + tid;
-            const bool head = p < n && (p == 0 || A[p - 1].hi != A[p].hi);
-            const uint64_t bal = __ballot(head);
-            if (head) headmask |= 1u << u;
-            slot[u] = (uint32_t)__popcll(bal & lt) + (head ? 1u : 0u);
-            if (lane == 0) hcnt[u * NW + wv] = (uint32_t)__popcll(bal);
-        }
-        lds_sync();
-        if (wv == 0) {      // exclusive scan of the NH <= 64 (u, wave) head counts, in place order
-            static_assert(NH <= 64, "one head count per lane");
-            const uint32_t c0 = lane < NH ? hcnt[lane] : 0u;
-            uint32_t inc = c0;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
-            if (lane < NH) hcnt[lane] = inc - c0;
-            if (lane == 63) hcnt[NH] = inc;
-        }
-        lds_sync();
-        const uint32_t ncol = hcnt[NH];
-#pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) {
-            slot[u] = hcnt[u * NW + wv] + slot[u] - 1u;                     // the column of place u * 512 + tid
-            if ((headmask >> u) & 1u) H[slot[u]] = (uint32_t)u * W2C_THREADS + tid;
-        }
-        if (tid == 0) H[ncol] = n;
-        lds_sync();
-        // reliable columns: their number among the reliable ones and the place of their first entry among the kept entries (exclusive scans over the columns)
-        uint32_t carry = 0;      // (rel << 16 | entries) summed over the columns before this chunk: both below 2^13
-        for (uint32_t c0 = 0; c0 < ncol; c0 += W2C_THREADS) {
-            const uint32_t c = c0 + tid;
-            uint32_t L = 0, mine = 0;
-            if (c < ncol) {
-                L = H[c + 1] - H[c];
-                if (L >= lower && L <= upper) { mine = (1u << 16) | L; st_sumsq += (unsigned long long)L * L; st_maxcol = L > st_maxcol ? L : st_maxcol; }
-                ++st_distinct;
-            }
+        // first entry of every reliable k-mer: exclusive scan of the counts in value order
+        uint32_t carry = 0;
+        for (uint32_t c0 = 0; c0 < Nb; c0 += W2C_THREADS) {
+            const uint32_t c = c0 + tid, mine = c < Nb ? C[c] : 0u;
             uint32_t inc = mine;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
@@ -1209,23 +1214,17 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             lds_sync();
             uint32_t ex = carry + inc - mine, tot = 0;
             for (uint32_t ww = 0; ww < NW; ++ww) { const uint32_t x = wsum[NW + ww]; if (ww < wv) ex += x; tot += x; }
-            if (c < ncol) RE[c] = mine ? ex : 0xFFFFFFFFu;      // reliable: (its number << 16) | first kept entry
+            if (c < Nb) C[c] = ex;
             carry += tot;
             lds_sync();
         }
-        const uint32_t Nb = carry >> 16, Zb = carry & 0xFFFFu;      // (Zb <= n <= W2_CAP, Nb <= W2_CAP / 2)
+        const uint32_t Zb = carry;
         const uint32_t vscale = Nb > 1u ? 65535u / (Nb - 1u) : 0u;   // columns spread over the 16 value bits the emit kernels sort by (strictly increasing: vscale >= 1)
 #pragma unroll
         for (int u = 0; u < W2C_KPT; ++u) {
-            const uint32_t p = (uint32_t)u * W2C_THREADS + tid;
-            if (p < n) {
-                const uint32_t col = slot[u], re = RE[col];
-                if (re != 0xFFFFFFFFu) {
-                    const uint32_t rc = re >> 16, eo = re & 0xFFFFu;
-                    const Rec2 x = A[p];
-                    wrel[s0 + eo + (p - H[col])] = ((uint64_t)(rc * vscale) << PB) | x.lo;
-                    if ((headmask >> u) & 1u) ktmp[s0 + rc] = x.hi << (64 - k2);
-                }
+            if ((uint32_t)u * W2C_THREADS + tid < n) {
+                const uint32_t rc = RC[slot[u]];
+                if (rc != 0xFFFFu) wrel[s0 + C[rc] + atomicAdd(&CNT[slot[u]], 1u)] = ((uint64_t)(rc * vscale) << PB) | key[u].lo;
             }
         }
         if (tid == 0) { bN[b] = Nb; bZ[b] = Zb; }
@@ -1238,7 +1237,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
     }
     if (lane == 0) { if (st_distinct) atomicAdd(&gstat->distinct, st_distinct); if (st_sumsq) atomicAdd(&gstat->sumsq, st_sumsq); if (st_maxcol) atomicMax(&gstat->maxcol, st_maxcol); }
 }
-constexpr size_t W2C_LDS = ((size_t)W2_CAP * 4 + 512 + 513 + (W2_CAP + 2) * 2 + (W2C_KPT * (W2C_THREADS / 64) + 1) + 2 * (W2C_THREADS / 64) + 8) * 4;
+constexpr size_t W2C_LDS = ((size_t)2 * W2_SLOTS + W2_SLOTS + (W2_RELMAX + 1) + 512 + 513 + 2 * (W2C_THREADS / 64) + 8) * 4 + ((size_t)W2_SLOTS + 2 * W2_RELMAX) * 2 + 64;
 
 int bits_needed_u(uint64_t maxval)
 {
