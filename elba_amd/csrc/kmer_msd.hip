@@ -917,7 +917,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
 // HBM traffic per instance: 16 B written + 16 read (hist2) + 16 read + 16 written + 16 read = 80 B, against 7 passes x 32 B + 3 x 16 B on the sort path.
 constexpr int W2_THREADS = 256, W2_ITEMS = 16, W2_TILE = W2_THREADS * W2_ITEMS;      // 4096 records of 16 bytes: 64 KB of LDS
 constexpr int W2_MAXBITS = 10, W2_MAXBINS = 1 << W2_MAXBITS;
-constexpr uint32_t W2_CAP = 3072;                // records of a bucket k31_count sorts in LDS (48 KB + 22 KB of tables: two workgroups per CU)
+constexpr uint32_t W2_CAP = 4096;                // records of a bucket k31_count takes (eight per lane, in registers)
 constexpr int W2C_THREADS = 512, W2C_KPT = (int)(W2_CAP / W2C_THREADS);
 static_assert(W2_ITEMS * 64 <= (1 << IB_SHIFT), "a wavefront's share of a tile lies inside one block of the instance -> read table");
 struct alignas(16) Rec2 { uint64_t hi, lo; };
@@ -1088,8 +1088,11 @@ __global__ __launch_bounds__(W2_THREADS) void k31_scatter(EnumParams e, const Bl
 // one compare-and-swap + one add per record), the RELIABLE k-mers alone — a few hundred per bucket — are sorted by value (range + rank), and every
 // record of a reliable k-mer then draws its place in the k-mer's column; the order inside a column is left to the emit kernels, which sort their
 // entries by (column, read, pos) anyway.  (First version: a full sort of the bucket in LDS — 159 ms for 2.0 G instances, profiles/r04_notes.md.)
-constexpr uint32_t W2_SLOTS = 4096, W2_RELMAX = W2_CAP / 2;      // table slots (> W2_CAP distinct k-mers are impossible: a bucket holds at most W2_CAP records); reliable k-mers of a bucket (LOWER >= 2)
-static_assert(W2_CAP < W2_SLOTS && W2C_KPT * W2C_THREADS >= (int)W2_CAP, "the probe loop needs an empty slot; every record has a register");
+constexpr uint32_t W2_SLOTS = 4096, W2_RELMAX = W2_CAP / 2;      // table slots; reliable k-mers of a bucket (LOWER >= 2)
+constexpr uint32_t W2_DISTINCT_MAX = W2_SLOTS - 2 * W2C_THREADS;  // distinct k-mers at which a bucket gives up (every lane may claim one more slot: the probe loop always finds an empty one)
+static_assert(W2C_KPT * W2C_THREADS >= (int)W2_CAP, "every record has a register");
+// (a bucket's size fluctuates with coverage x sqrt(distinct genomic k-mers in it): 1900 +- 280 instances on 40x reads of a 50 Mb genome cut into 2^20
+//  buckets — 3300 at five sigma, which 2^20 buckets do reach)
 __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const uint32_t *b2start, uint32_t nbuckets, int k2, int T, int PB, uint32_t lower, uint32_t upper,
                                                         uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint64_t *wrel, uint64_t *ktmp)
 {
@@ -1105,26 +1108,15 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
     const int R = 32 - T;                                  // bits of the flattened leading 32 value bits (w2_flat) the partition has not used
     unsigned long long st_distinct = 0, st_sumsq = 0;
     uint32_t st_maxcol = 0;
-    // (the records of the NEXT bucket are requested before this one is processed)
-    Rec2 knext[W2C_KPT];
-    uint32_t s0n = 0, nn = 0;
-    auto fetch = [&](uint32_t bb) {
-        s0n = 0; nn = 0;
-        if (bb < nbuckets) { s0n = b2start[bb]; nn = b2start[bb + 1] - s0n; }
-#pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) { const uint32_t i = (uint32_t)u * W2C_THREADS + tid; knext[u] = (nn <= W2_CAP && i < nn) ? recs[s0n + i] : Rec2{~0ull, ~0ull}; }
-    };
-    fetch(blockIdx.x);
-    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
-        const uint32_t s0 = s0n, n = nn;
-        Rec2 key[W2C_KPT];
-#pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) key[u] = knext[u];
-        fetch(b + gridDim.x);
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {      // (two workgroups per CU hide one another's round trips: no register prefetch of the next bucket)
+        const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
         if (n == 0 || n > W2_CAP) {
             if (tid == 0) { bN[b] = 0; bZ[b] = 0; if (n > W2_CAP) atomicAdd(&gstat->ncrowded, 1u); }
             continue;
         }
+        Rec2 key[W2C_KPT];
+#pragma unroll
+        for (int u = 0; u < W2C_KPT; ++u) { const uint32_t i = (uint32_t)u * W2C_THREADS + tid; key[u] = i < n ? recs[s0 + i] : Rec2{~0ull, ~0ull}; }
 #pragma unroll
         for (int q = 0; q < (int)SPT; ++q) { const uint32_t sl = (uint32_t)q * W2C_THREADS + tid; K[sl] = ~0ull; CNT[sl] = 0; RC[sl] = 0xFFFFu; }
         sbcnt[tid] = 0;
@@ -1138,16 +1130,25 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             if ((uint32_t)u * W2C_THREADS + tid < n) {
                 const unsigned long long hk = key[u].hi;
                 uint32_t sl = (((uint32_t)hk ^ (uint32_t)(hk >> 27)) * 0x9E3779B1u) >> 20;      // 12 bits
-                for (;;) {
-                    const unsigned long long old = atomicCAS(&K[sl], ~0ull, hk);
-                    if (old == ~0ull || old == hk) break;
-                    sl = (sl + 1u) & (W2_SLOTS - 1u);
+                if (__hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {      // (the table is filling up: the bucket is given up)
+                    for (uint32_t probes = 0; probes < W2_SLOTS; ++probes) {      // (bounded whatever happens: a full table cannot hang the wavefront)
+                        const unsigned long long old = atomicCAS(&K[sl], ~0ull, hk);
+                        if (old == hk) break;
+                        if (old == ~0ull) { if (atomicAdd(&misc[1], 1u) >= W2_DISTINCT_MAX) __hip_atomic_store(&misc[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+                        sl = (sl + 1u) & (W2_SLOTS - 1u);
+                        if (probes + 1u == W2_SLOTS) __hip_atomic_store(&misc[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    atomicAdd(&CNT[sl], 1u);
                 }
-                atomicAdd(&CNT[sl], 1u);
                 slot[u] = sl;
             }
         }
         lds_sync();
+        if (__hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {      // more distinct k-mers than the table takes: a crowded bucket like one beyond W2_CAP records
+            if (tid == 0) { bN[b] = 0; bZ[b] = 0; atomicAdd(&gstat->ncrowded, 1u); }
+            lds_sync();
+            continue;
+        }
         // the reliable k-mers (LOWER <= count <= UPPER), as found
 #pragma unroll
         for (int q = 0; q < (int)SPT; ++q) {
