@@ -108,6 +108,7 @@ struct OvParams {
     // mirror slabs (below): null = none.  slab_prior_q16: mirrored entries per row entry measured by an earlier call on this matrix (0: take the sample's);
     // slab_pct: margin in percent
     uint4 *slab; unsigned long long slab_cap; uint32_t slab_prior_q16, slab_pct;
+    unsigned long long *slab_pos;      // [M] per row: slab end << 32 | next free slab entry (k_classify_direct sets it to end << 32 | start)
 };
 
 // ---- mirror slabs ---------------------------------------------------------------------------------------------------------------------
@@ -116,10 +117,12 @@ struct OvParams {
 // a dependent random read on BASELINE config 3, 1.9 ms = a fifth of the call, at the memory system's rate for such stores.  The numeric kernel
 // itself is bound by latency, not by memory: it now writes the image STRAIGHT into row j's slab — room for the row's mirrored entries reserved
 // before they are counted, sized from what the call already measures on its sample of rows: survivors per row entry of A (x slab_pct / 100, +
-// SLAB_PAD).  The slab of row j starts at floor((a_rowptr[j] - a_rowptr[row_lo]) x ratio) + SLAB_PAD x (j - row_lo): no table, no scan —
-// two adjacent words of a_rowptr that sit in the L2.  An image whose ticket lies beyond its row's slab (or drawn while no ratio was known: the
-// sample's own rows, small matrices) keeps its ticket and takes the old way (k_mirror); the finalize reads a row's mirrored entry t from the slab
-// when t is inside it and from the mirror area otherwise.  Capacity is a performance matter only, never a correctness limit.
+// SLAB_PAD).  The slab of row j starts at floor((a_rowptr[j] - a_rowptr[row_lo]) x ratio) + SLAB_PAD x (j - row_lo), and ONE returning 64-bit atomic
+// on slab_pos[j] = (slab end << 32 | next free entry) — written by the classification pass, which walks every row anyway — hands an image its
+// place and tells it whether the place is still inside the slab.  An image that finds its row's slab full (or is staged while no ratio is known:
+// the sample's own rows, small matrices) draws a ticket from low_cnt[j] and takes the old way (k_mirror, the mirror area); the finalize reads a
+// row's mirrored entries from the slab first (slab_n[j] of them: k_slab_fold), then from the mirror area.  Capacity is a performance matter only,
+// never a correctness limit.
 constexpr uint32_t SLAB_PAD = 16;
 struct __attribute__((packed, aligned(4))) RowPair { uint32_t a, b; };      // a_rowptr[j], a_rowptr[j + 1]
 __device__ __forceinline__ uint32_t slab_base(uint32_t rp, uint32_t rp0, uint32_t row_rel, uint32_t q16)
@@ -160,6 +163,7 @@ struct FinParams {
     uint32_t mir16;          // positions fit 16 bits: a mirrored entry is ONE 16-byte word (i, q0 | t0 << 16, q1 | t1 << 16, numshared) — one store
                              // request per scattered entry instead of two, half the bytes read back
     const uint32_t *a_rowptr; uint4 *slab;      // mirror slabs (above; mir16 records): null = none
+    const unsigned long long *slab_pos; uint32_t *slab_n;      // [M] the slabs' fill words as the numeric kernels left them / entries in every row's slab (k_slab_fold; null with slab)
 };
 
 // this call's slabs: ratio (0 = none) and the first row entry of the window
@@ -170,12 +174,25 @@ __device__ __forceinline__ SlabCall slab_call(const FinParams &p)
     if (p.slab) { s.q16 = p.ctr->slab_q16; if (s.q16) s.rp0 = p.a_rowptr[p.row_lo]; }
     return s;
 }
-// row i's slab: first entry and capacity
+// row i's slab: first entry and entries in it
 __device__ __forceinline__ uint2 slab_row(const FinParams &p, const SlabCall &s, uint32_t i)
 {
     if (!s.q16) return make_uint2(0u, 0u);
-    const uint32_t b0 = slab_base(p.a_rowptr[i], s.rp0, i - p.row_lo, s.q16), b1 = slab_base(p.a_rowptr[i + 1], s.rp0, i + 1 - p.row_lo, s.q16);
-    return make_uint2(b0, b1 - b0);
+    return make_uint2(slab_base(p.a_rowptr[i], s.rp0, i - p.row_lo, s.q16), p.slab_n[i]);
+}
+// entries in every row's slab, from the fill words (a full slab's word has run past its end: one add per image that found no room)
+__global__ void k_slab_fold(FinParams p)
+{
+    const uint32_t i = p.row_lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.row_hi) return;
+    const SlabCall s = slab_call(p);
+    uint32_t n = 0;
+    if (s.q16) {
+        const unsigned long long w = p.slab_pos[i];
+        const uint32_t base = slab_base(p.a_rowptr[i], s.rp0, i - p.row_lo, s.q16), cur = (uint32_t)w, lim = (uint32_t)(w >> 32);
+        n = (cur < lim ? cur : lim) - base;
+    }
+    p.slab_n[i] = n;
 }
 
 // entry t of a row's extent: mirrored (the first `low`) or staged by the row itself; as the two halves of a staged record
@@ -188,14 +205,14 @@ __device__ __forceinline__ void fin_load(const FinParams &p, uint32_t low, unsig
         } else { const StageRec *r = &p.tmp[off + (t - low)]; a = r->a; b = r->b; }
     }
     else if (p.mir16) {
-        const uint4 m = t < sl.y ? p.slab[sl.x + t] : reinterpret_cast<const uint4 *>(p.mir)[dst + t];
+        const uint4 m = t < sl.y ? p.slab[sl.x + t] : reinterpret_cast<const uint4 *>(p.mir)[dst + t - sl.y];
         a = make_uint4(m.x, 0xFFFFFFFFu, m.y & 0xFFFFu, m.y >> 16); b = make_uint4(m.z & 0xFFFFu, m.z >> 16, m.w, 0u);
     } else { const StageRec *r = &p.mir[dst + t]; a = r->a; b = r->b; }
 }
 __device__ __forceinline__ uint32_t fin_col(const FinParams &p, uint32_t low, unsigned long long off, int64_t dst, uint32_t t, uint2 sl = make_uint2(0u, 0u))
 {
     if (t >= low) return p.rec16 ? p.rec[off + (t - low)].x : p.tmp[off + (t - low)].a.x;
-    return p.mir16 ? (t < sl.y ? p.slab[sl.x + t].x : reinterpret_cast<const uint4 *>(p.mir)[dst + t].x) : p.mir[dst + t].a.x;
+    return p.mir16 ? (t < sl.y ? p.slab[sl.x + t].x : reinterpret_cast<const uint4 *>(p.mir)[dst + t - sl.y].x) : p.mir[dst + t].a.x;
 }
 __device__ __forceinline__ elba_seed_t rec_seed(const uint4 a, const uint4 b)
 {
@@ -215,11 +232,12 @@ __global__ __launch_bounds__(256) void k_row_pointers(FinParams p)
     const uint32_t n = p.M + 1, t0 = blockIdx.x * RP_TILE;
     unsigned long long pre = 0;
     {   // t0 is a multiple of 1024: 16-byte loads, 8 in flight per lane
-        const uint4 *ca = reinterpret_cast<const uint4 *>(p.row_cnt), *cb = reinterpret_cast<const uint4 *>(p.low_cnt);
+        const uint4 *ca = reinterpret_cast<const uint4 *>(p.row_cnt), *cb = reinterpret_cast<const uint4 *>(p.low_cnt), *cc = reinterpret_cast<const uint4 *>(p.slab_n);
 #pragma unroll 4
         for (uint32_t q = tid; q < t0 / 4; q += 256) {
             const uint4 x = ca[q], z = cb[q];
             pre += (unsigned long long)x.x + x.y + x.z + x.w + z.x + z.y + z.z + z.w;
+            if (cc) { const uint4 y2 = cc[q]; pre += (unsigned long long)y2.x + y2.y + y2.z + y2.w; }
         }
     }
     uint32_t v[4];
@@ -227,7 +245,7 @@ __global__ __launch_bounds__(256) void k_row_pointers(FinParams p)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const uint32_t e = t0 + tid * 4 + u;
-        v[u] = e < p.M ? p.row_cnt[e] + p.low_cnt[e] : 0u;
+        v[u] = e < p.M ? p.row_cnt[e] + p.low_cnt[e] + (p.slab_n ? p.slab_n[e] : 0u) : 0u;
         mine += v[u];
     }
 #pragma unroll
@@ -253,7 +271,7 @@ __global__ __launch_bounds__(256) void k_row_pointers(FinParams p)
 __global__ void k_sum_counts(FinParams p)
 {
     const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e <= p.M) p.sum_tmp[e] = e < p.M ? p.row_cnt[e] + p.low_cnt[e] : 0u;
+    if (e <= p.M) p.sum_tmp[e] = e < p.M ? p.row_cnt[e] + p.low_cnt[e] + (p.slab_n ? p.slab_n[e] : 0u) : 0u;
 }
 
 // Mirror pass: every staged entry (i,j) whose partner row j is computed here as well is the transpose's entry (j,i) with the two
@@ -265,12 +283,11 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
-    const SlabCall sc = slab_call(p);
     uint32_t placed = 0;
     for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
         const uint32_t own = p.row_cnt[i];
         const unsigned long long off = p.row_off[i];
-        const uint32_t y = own + p.low_cnt[i];
+        const uint32_t y = own + p.low_cnt[i] + (p.slab_n ? p.slab_n[i] : 0u);
         if (lane == 0 && y > FIN_WAVE2_MAX) {
             const int which = y > FIN_LDS_MAX ? 1 : 0;
             const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
@@ -284,10 +301,6 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
                 const uint4 r = p.rec[off + t];
                 const uint4 img = make_uint4(i, (r.y >> 16) | (r.y << 16), (r.z >> 16) | (r.z << 16), r.w);
                 ++placed;
-                if (sc.q16 && p.mir16) {      // (a ticket drawn before the ratio was known — the sample's rows — may still lie inside its row's slab)
-                    const uint2 sl = slab_row(p, sc, r.x);
-                    if (tk < sl.y) { p.slab[sl.x + tk] = img; continue; }
-                }
                 const int64_t at = p.b_rowptr[r.x] + (int64_t)tk;
                 if (at >= p.b_cap) continue;
                 if (p.mir16) reinterpret_cast<uint4 *>(p.mir)[at] = img;
@@ -326,12 +339,13 @@ __global__ __launch_bounds__(256) void k_finalize_wave(FinParams p)
     for (uint32_t i = p.row_lo + wave; i < p.row_hi; i += nwaves) {
         const int64_t dst = p.b_rowptr[i];
         const uint32_t y = (uint32_t)(p.b_rowptr[i + 1] - dst);
-        const uint32_t low = p.low_cnt[i];
-        if (lane == 0 && low) p.low_cnt[i] = 0;          // the ticket counters are handed back clean (k_mirror, the only other reader, has finished)
+        const uint32_t lowt = p.low_cnt[i];
+        if (lane == 0 && lowt) p.low_cnt[i] = 0;          // the ticket counters are handed back clean (k_mirror, the only other reader, has finished)
         if (y == 0 || y > FIN_WAVE_MAX) continue;
         if (dst + (int64_t)y > p.b_cap) continue;
         const unsigned long long off = p.row_off[i];
         const uint2 sl = slab_row(p, sc, i);
+        const uint32_t low = lowt + sl.y;                  // mirrored entries: the slab's, then the ticketed ones
         uint32_t mine[4];
         uint4 ra[4], rb[4];
 #pragma unroll
@@ -474,7 +488,7 @@ __global__ __launch_bounds__(256, 3) void k_finalize_mid16(FinParams p)
 #pragma unroll
         for (int u = 0; u < NU; ++u) {
             const uint32_t t = (uint32_t)lane + 64u * u;
-            m[u] = t < y ? (t >= low ? p.rec[off + (t - low)] : (t < sl.y ? p.slab[sl.x + t] : mir[dst + t])) : make_uint4(0u, 0u, 0u, 0u);
+            m[u] = t < y ? (t >= low ? p.rec[off + (t - low)] : (t < sl.y ? p.slab[sl.x + t] : mir[dst + t - sl.y])) : make_uint4(0u, 0u, 0u, 0u);
         }
 #pragma unroll
         for (int u = 0; u < NU; ++u)
@@ -783,6 +797,8 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
     f.mir16 = mir16 ? 1u : 0u;
     f.rec16 = c.ov_rec16 ? 1u : 0u; f.rec = c.ov_tmp.as<uint4>(); f.tick = reinterpret_cast<const uint32_t *>(c.ov_tmp.as<char>() + (size_t)c.ov_tmp_cap * 16);
     f.a_rowptr = c.a_rowptr.as<uint32_t>(); f.slab = (half == 1u && mir16 && c.ov_slab_on) ? c.ov_slab.as<uint4>() : nullptr;
+    f.slab_pos = f.slab ? c.ov_slabpos.as<unsigned long long>() : nullptr; f.slab_n = f.slab ? c.ov_slabn.as<uint32_t>() : nullptr;
+    if (f.slab && nrows > 0) hipLaunchKernelGGL(k_slab_fold, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, s, f);
     const int gblocks = 32;
     uint64_t sstride = 2;
     while (sstride < (uint64_t)M) sstride <<= 1;
@@ -999,6 +1015,9 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
             c.ov_slab_cap = std::min<int64_t>(c.ov_tmp_cap + (int64_t)SLAB_PAD * nrows, 0xFFFF0000ll);
             c.ov_slab.reserve((size_t)c.ov_slab_cap * 16);
             p.slab = c.ov_slab.as<uint4>(); p.slab_cap = (unsigned long long)c.ov_slab_cap;
+            c.ov_slabpos.reserve((size_t)(M + 4) * 8); c.ov_slabn.reserve((size_t)(M + 8) * 4);
+            p.slab_pos = c.ov_slabpos.as<unsigned long long>();
+            ELBA_HIP(hipMemsetAsync(c.ov_slabn.p, 0, (size_t)(M + 8) * 4, s));      // (rows outside the window hold no slab entries)
         }
 
         if (timed) c.ov_marks.mark(0, s);

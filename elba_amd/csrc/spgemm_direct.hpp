@@ -94,7 +94,6 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
     // mirror slabs (spgemm.hip): the ratio k_classify_direct settled for this call (0: none — the sample's rows run before it is known) and the
     // window's first row entry; both scalar
     const uint32_t slab_q = (p.slab != nullptr && !sample) ? sfirst(p.ctr->slab_q16) : 0u;
-    const uint32_t slab_rp0 = slab_q ? sfirst(p.a_rowptr[p.row_lo]) : 0u;
     unsigned long long chunk_off = 0;
     uint32_t chunk_left = 0;
     auto w64 = [&](uint32_t k) { return reinterpret_cast<unsigned long long *>(&misc[k]); };
@@ -680,22 +679,15 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 // the partner's row gets the mirrored entry: draw its slot there now; k_mirror places it once the row pointers are known
                 uint32_t tick = 0xFFFFFFFFu;
                 if (p.half && j != i && j >= p.row_lo && j < p.row_hi) {
-                    tick = atomicAdd(&p.low_cnt[j], 1u); ++nmir;
-                    if (slab_q) {      // the image goes straight to row j's slab when its ticket lies inside it (else it waits here for k_mirror)
-#if defined(ELBA_SLAB_NOLD)
-                        const uint32_t b0 = j * 431u, b1 = b0 + 431u;
-#elif defined(ELBA_SLAB_LD4)
-                        const uint32_t b0 = slab_base(p.a_rowptr[j], slab_rp0, j - p.row_lo, slab_q), b1 = slab_base(p.a_rowptr[j + 1], slab_rp0, j + 1u - p.row_lo, slab_q);
-#else
-                        const RowPair rp = *reinterpret_cast<const RowPair *>(p.a_rowptr + j);      // (two adjacent words, ONE request: a dword-aligned 8-byte load)
-                        const uint32_t b0 = slab_base(rp.a, slab_rp0, j - p.row_lo, slab_q), b1 = slab_base(rp.b, slab_rp0, j + 1u - p.row_lo, slab_q);
-#endif
-#if defined(ELBA_SLAB_NOST)
-                        if (tick < b1 - b0) { tick = 0xFFFFFFFFu; }
-#else
-                        if (tick < b1 - b0) { p.slab[b0 + tick] = make_uint4(i, v.t0 | v.q0 << 16, v.t1 | v.q1 << 16, (uint32_t)v.numshared); tick = 0xFFFFFFFFu; }
-#endif
-                    }
+                    ++nmir;
+                    if (slab_q) {
+                        // the image goes straight to row j's slab: ONE returning atomic on the row's fill word (slab end << 32 | next free entry) hands it its
+                        // place and says whether that is still inside the slab (else it draws a ticket and waits here for k_mirror)
+                        const unsigned long long w = atomicAdd(&p.slab_pos[j], 1ull);
+                        const uint32_t at = (uint32_t)w;
+                        if (at < (uint32_t)(w >> 32)) p.slab[at] = make_uint4(i, v.t0 | v.q0 << 16, v.t1 | v.q1 << 16, (uint32_t)v.numshared);
+                        else tick = atomicAdd(&p.low_cnt[j], 1u);
+                    } else tick = atomicAdd(&p.low_cnt[j], 1u);
                 }
                 if (p.rec16) { p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared); p.tick[off + t] = tick; }
                 else {
@@ -768,9 +760,11 @@ __global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
         const unsigned long long u = p.ctr->fb_ub, cl = p.ctr->fb_claims;
         if (u) { const double r = 1.25 * (double)cl / (double)u * 65536.0; prior_q16 = r < 64.0 ? 64u : (r > 4.0e9 ? 4000000000u : (uint32_t)r); }
     }
-    if (p.slab != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    uint32_t slab_q = 0, slab_rp0 = 0;
+    if (p.slab != nullptr) {
         // mirror slabs: slab entries per row entry = mirrored entries per row entry (an earlier call's, or what the sample's rows staged — a row
-        // stages about as many entries as it receives) x the margin, cut down to what the slab area holds
+        // stages about as many entries as it receives) x the margin, cut down to what the slab area holds.  (Every lane computes the same figure
+        // from the same words; lane 0 of the first workgroup publishes it for the kernels behind this one.)
         double r = 0.0;
         if (p.slab_prior_q16) r = (double)p.slab_prior_q16;
         else if (p.nsample) { const unsigned long long u = p.ctr->fb_ub; if (u) r = (double)p.ctr->fb_surv / (double)u * 65536.0; }
@@ -782,7 +776,8 @@ __global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
             r = r < most ? r : most;
             q = r >= 4.0e9 ? 4000000000u : (uint32_t)r;
         }
-        p.ctr->slab_q16 = q;
+        slab_q = q; slab_rp0 = p.a_rowptr[p.row_lo];
+        if (blockIdx.x == 0 && threadIdx.x == 0) p.ctr->slab_q16 = q;
     }
     // (dense path with labels: the rows are queued in label order — reads of one locus are multiplied at the same time and find each other's
     //  columns in the caches; the order names every row of the matrix, those outside the window pass)
@@ -791,7 +786,11 @@ __global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
         const uint32_t q = q0 + threadIdx.x;
         const uint32_t i = q >= qn ? p.row_hi : (p.row_order ? p.row_order[q] : p.row_lo + q);
         int mytier = -1;
-        uint32_t nnz = i >= p.row_lo && i < p.row_hi ? p.a_rowptr[i + 1] - p.a_rowptr[i] : 0u;
+        const bool inwin = i >= p.row_lo && i < p.row_hi;
+        const uint32_t rp_a = inwin ? p.a_rowptr[i] : 0u, rp_b = inwin ? p.a_rowptr[i + 1] : 0u;
+        uint32_t nnz = rp_b - rp_a;
+        if (slab_q && inwin)      // the row's slab: end << 32 | first entry (the fill word the numeric kernels add to)
+            p.slab_pos[i] = ((unsigned long long)slab_base(rp_b, slab_rp0, i + 1u - p.row_lo, slab_q) << 32) | slab_base(rp_a, slab_rp0, i - p.row_lo, slab_q);
         if (p.nsample && i < p.row_hi && (i - p.row_lo) % p.sstep == 0 && (i - p.row_lo) / p.sstep < p.nsample) nnz = 0;      // a row of the sample: done already
         if (nnz != 0) {
             const unsigned long long prod_ub = (unsigned long long)nnz * p.max_col;

@@ -9,6 +9,17 @@ enum : uint32_t {
     W_ACC_YRAW = 32 /*u64*/, W_ACC_Y = 34 /*u64*/, W_ACC_DONE = 36, W_ACC_NDIAG = 37, W_FB_N = 38,
     W_FB_C = 40 /*u64*/, W_FB_U = 42 /*u64*/, W_TOT_C = 44 /*u64*/, W_TOT_U = 46 /*u64*/, W_NUP = 48 /*u64*/, W_MIR = 50 /*u64*/, W_MX = 52, W_END = 54
 };
+// (A/B hook: a pre-mix of the key in front of the multiplicative hash — consecutive labels of the dense path land 316 slots apart on a 512-slot
+//  table, i.e. on 8 of the 32 banks; profiles/r03_notes.md)
+#if defined(ELBA_HMIX_SEL) && ELBA_HMIX_SEL == 1
+#define ELBA_HMIX(j) ((j) ^ ((j) >> 5))
+#elif defined(ELBA_HMIX_SEL) && ELBA_HMIX_SEL == 2
+#define ELBA_HMIX(j) (((j) * 0x85EBCA6Bu) ^ ((j) >> 3))
+#elif defined(ELBA_HMIX_SEL) && ELBA_HMIX_SEL == 3
+#define ELBA_HMIX(j) ((j) ^ ((j) << 7))
+#else
+#define ELBA_HMIX(j) (j)
+#endif
 template <bool GLOBAL>
 struct Table {
     uint32_t *keys, *cnt, *smin, *smax, *misc;
@@ -25,7 +36,7 @@ struct Table {
         // so at most 3T/4 + BLOCK slots are ever claimed (BLOCK <= T/8): the probe loop always meets an empty slot.
         if (full) return;
         const uint32_t mask = size() - 1;
-        uint32_t slot = (j * 0x9E3779B1u) >> (32 - tbits);
+        uint32_t slot = (ELBA_HMIX(j) * 0x9E3779B1u) >> (32 - tbits);
         // (A/B measured on MI355X: probing with a plain read before the CAS and guarding min/max with reads is SLOWER —
         //  0.84 vs 0.76 ms per step — the extra dependent LDS round trips cost more than the atomics they save.)
         for (;;) {
@@ -200,7 +211,7 @@ struct Table {
         const uint32_t T = TB ? (1u << TB) : size(), tb = T * 4;
         uint32_t slot[4], k[4], m[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) slot[r] = TB ? (j[r] * 0x9E3779B1u) >> (32 - (TB ? TB : 1)) : lds_slot(j[r]);
+        for (int r = 0; r < 4; ++r) slot[r] = TB ? (ELBA_HMIX(j[r]) * 0x9E3779B1u) >> (32 - (TB ? TB : 1)) : lds_slot(j[r]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             k[r] = __hip_atomic_load(&lk[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -230,7 +241,7 @@ struct Table {
             miss[r] = v && !h;
         }
     }
-    __device__ __forceinline__ uint32_t lds_slot(uint32_t j) const { return (j * 0x9E3779B1u) >> (32 - tbits); }      // (a 24-bit multiply, v_mul_u32_u24, was measured: no difference)
+    __device__ __forceinline__ uint32_t lds_slot(uint32_t j) const { return (ELBA_HMIX(j) * 0x9E3779B1u) >> (32 - tbits); }      // (a 24-bit multiply, v_mul_u32_u24, was measured: no difference)
     __device__ __forceinline__ uint32_t ldrelaxed(const uint32_t *a) const
     {
         return __hip_atomic_load(a, __ATOMIC_RELAXED, GLOBAL ? __HIP_MEMORY_SCOPE_AGENT : __HIP_MEMORY_SCOPE_WORKGROUP);
