@@ -179,6 +179,7 @@ struct Ctx {
     const uint32_t *d_len = nullptr;
     DevBuf own_packed, own_byte_off, own_len;
     bool have_reads = false;
+    uint32_t max_read_len = 0;             // longest read (set by stage_count_kmers)
     std::vector<uint32_t> h_len;           // host copy of lengths (instance offsets are a host-side prefix sum)
     std::vector<uint64_t> h_byte_off;
 

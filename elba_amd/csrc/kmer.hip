@@ -544,8 +544,10 @@ void stage_count_kmers(Ctx &c)
     // instance offsets: a host prefix sum over the read lengths (include/KmerOps.hpp:118-119: reads shorter than k contribute nothing)
     std::vector<uint64_t> off((size_t)M + 1);
     uint64_t I = 0;
-    for (int64_t r = 0; r < M; ++r) { off[(size_t)r] = I; if ((int64_t)c.h_len[(size_t)r] >= k) I += (uint64_t)c.h_len[(size_t)r] - k + 1; }
+    uint32_t maxlen = 0;
+    for (int64_t r = 0; r < M; ++r) { const uint32_t l = c.h_len[(size_t)r]; off[(size_t)r] = I; if ((int64_t)l >= k) I += (uint64_t)l - k + 1; maxlen = l > maxlen ? l : maxlen; }
     off[(size_t)M] = I;
+    c.max_read_len = maxlen;      // (the one host walk over the read lengths of this stage: kmer_msd.hip sizes its position field by it)
     ELBA_REQUIRE(I < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: more than 2^32 k-mer instances on one GPU");
     c.I = (int64_t)I;
     c.inst_off.reserve((size_t)(M + 1) * 8);

@@ -1268,8 +1268,7 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     if (T < 2) return false;
     // worth it from ~1024 instances per bucket on (the bucket kernel pays ~2 us per bucket whatever it holds); smaller inputs keep the sort
     if (!c.opt.kmer_msd && (wide ? I < (1ull << 22) : I < ((uint64_t)1024 << T))) return false;
-    uint32_t maxlen = 0;
-    for (int64_t r = 0; r < c.nreads; ++r) maxlen = c.h_len[(size_t)r] > maxlen ? c.h_len[(size_t)r] : maxlen;
+    const uint32_t maxlen = c.max_read_len;      // (stage_count_kmers' walk over the read lengths)
     const uint64_t maxpos = maxlen >= (uint32_t)k ? maxlen - (uint32_t)k : 0;
     MsdParams m{};
     m.k2 = k2; m.b1 = (T + 1) / 2; m.b2 = T - m.b1; m.I = I;
