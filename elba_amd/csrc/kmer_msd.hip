@@ -1,25 +1,29 @@
-// kmer_msd.hip — k-mer counting for k <= 17 by a two-level value partition and an LDS count table per bucket.
+// kmer_msd.hip — k-mer counting for one-word k-mers (k <= 31) by a two-level value partition and per-bucket counting in LDS.
 //
-// Replaces, for the k every run recipe of the reference uses (README.md:104-109: k = 17), the sort of kmer.hip as the way to compute what
-// get_kmer_count_map_keys / get_kmer_count_map_values compute (src/KmerOps.cpp:18-350): the canonical k-mers with LOWER <= count <= UPPER and
-// the (read, pos) of each of their instances.  The LSD sort of kmer.hip moves every instance four times over HBM
+// Replaces the sort of kmer.hip as the way to compute what get_kmer_count_map_keys / get_kmer_count_map_values compute
+// (src/KmerOps.cpp:18-350): the canonical k-mers with LOWER <= count <= UPPER and the (read, pos) of each of their instances.
+//
+// k <= 17 (every run recipe of the reference's README, README.md:104-109).  The LSD sort of kmer.hip moves every instance four times over HBM
 // (2k = 34 value bits, 9-bit digits) and, because 34 value bits + 31 index bits do not fit one word, has to recompute k-mers afterwards.
 // Here an instance moves twice and is read twice more:
-//
-//   k_msd_hist1     enumerate the k-mers of every tile of 8192 instances, count the tile's FIRST digit (the top b1 value bits)
+//   k_msd_hist1     enumerate the k-mers of every tile of 16384 instances, count the tile's FIRST digit (the top b1 value bits)
 //   k_msd_scatter   <ENUM> enumerate again and write every instance as ONE word straight into its first-digit bucket: the word
 //                   no longer holds the first digit — word = remaining value bits << PB | read << pbits | pos — so read and position travel
 //                   with the instance and nothing is recomputed or looked up afterwards;
 //   k_msd_hist2 / k_msd_segscan / k_msd_scatter<MEM>   the same on the SECOND digit inside every first-digit bucket (tiles never straddle buckets):
 //                   after it the instances sit grouped by their top b1 + b2 = 2k - 16 value bits, 2^(2k-16) buckets;
-//   k_msd_bucket    one workgroup per bucket: the 16 value bits left index a table of 16-bit counters IN LDS (two halves of 2^15 values, 64 KB):
-//                   one LDS atomic per instance gives the exact counts, a scan over the table numbers the reliable k-mers in value order
-//                   (k-mer id = rank of the value) and places their columns; <false> counts per bucket (N, Z), <true> — after the
-//                   scan over the buckets — writes the k-mers, the column pointers, the columns sorted by (read, pos), the padded column store
-//                   the SpGEMM gathers from, and the CSR build's sort keys with their ownership hints: everything k_runs / k_runs_emit /
-//                   k_add_hints / k_fill_ell of the sort path produce, from the bucket while it sits in LDS.
-//
+//   k_msd_count     one workgroup per bucket: the 16 value bits left index a table of 16-bit counters IN LDS (128 KB): one LDS atomic per
+//                   instance gives the exact counts; the instances of reliable k-mers — the entries of A — are compacted to the front of the bucket;
+//   k_msd_emit_small<8 | 16 | 16, 512>   (buckets of up to 2048 / 4096 / 8192 entries) sort the bucket's entries in LDS by (value, read, pos): columns
+//                   in value order (k-mer id = rank of the value), each ordered by (read, pos); the k-mers, the column pointers,
+//                   the columns, the padded column store the SpGEMM gathers from — for the columns some row entry still fetches only: "gather
+//                   slots", BucketOut —, and the CSR build's sort keys with their ownership hints and inline partners leave from LDS: everything
+//                   k_runs / k_runs_emit / k_add_hints / k_fill_ell of the sort path produce.  k_msd_bucket<true>: buckets beyond that.
 // HBM traffic per instance: 8 B written + 8 B read (hist2) + 8 B read + 8 B written + 2 x 8 B read = 48 B, against ~112 B on the sort path.
+//
+// 19 <= k <= 31 (the reference's default build is k = 31, Makefile:1-3; round 4): the section above k31_hist1 — 16-byte records, the same two-level
+// partition on as many leading value bits as make buckets of ~500-2000 instances (cut by the flattened density of canonical k-mers), an LDS
+// hash table per bucket for the counts; from the compacted entries on, the k <= 17 kernels.
 #include "common.hpp"
 #include "matrix.hpp"
 #include <algorithm>
@@ -31,9 +35,12 @@ namespace {
 #include "kmer_enum.hpp"
 
 #ifndef ELBA_MT_THREADS
-#define ELBA_MT_THREADS 256
+#define ELBA_MT_THREADS 512
 #endif
-constexpr int MT_THREADS = ELBA_MT_THREADS, MT_ITEMS = 8192 / MT_THREADS, MT_TILE = MT_THREADS * MT_ITEMS;      // 8192 instances per tile: a wavefront's share is one block of the instance -> read table
+#ifndef ELBA_MT_ITEMS
+#define ELBA_MT_ITEMS 32
+#endif
+constexpr int MT_THREADS = ELBA_MT_THREADS, MT_ITEMS = ELBA_MT_ITEMS, MT_TILE = MT_THREADS * MT_ITEMS;      // instances per tile; a wavefront's share is at most one block of the instance -> read table
 constexpr int MT_MAXBITS = 9, MT_MAXBINS = 1 << MT_MAXBITS;
 constexpr int VBITS = 16;                     // value bits left to the bucket kernel (two halves of 2^15 values)
 constexpr int BK_THREADS = 1024;
@@ -44,7 +51,7 @@ constexpr uint32_t BK_TAB = 16384, BK_ENT = BK_TAB + 2048 + 128 + 2 * (KW + 1); 
 static_assert(BK_ENT % 2 == 0, "staged entries are 8-byte words");
 constexpr size_t BK_LDS_EMIT = (size_t)BK_ENT * 4 + (size_t)(EW + EPAD) * 10;
 constexpr int KPT = 8;                        // instances of a bucket a lane keeps in registers (8192 per workgroup; beyond: re-read from L2)
-static_assert(MT_ITEMS * 64 <= (1 << IB_SHIFT) && MT_TILE == 8192, "a wavefront's share of a tile lies inside one block of the instance -> read table");
+static_assert(MT_ITEMS * 64 <= (1 << IB_SHIFT) && MT_TILE % 4096 == 0 && MT_TILE <= 65536, "a wavefront's share of a tile lies inside one block of the instance -> read table; run-start bitmap words per lane; 16-bit ranks");
 
 struct MsdParams {
     int k2;                 // 2k value bits
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
     if (!ENUM && blockIdx.x >= sg.tile0[sg.nb1]) return;
     for (int i = threadIdx.x; i < MT_MAXBINS; i += MT_THREADS) lcnt[i] = 0;
-    if (threadIdx.x < MT_TILE / 64) hbits[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < MT_TILE / 64; i += MT_THREADS) hbits[i] = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint64_t key[MT_ITEMS];
@@ -316,11 +323,16 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     }
     __syncthreads();
     if (w == 0) {
-        const uint32_t c0 = (uint32_t)__popcll(hbits[2 * lane]), c1 = (uint32_t)__popcll(hbits[2 * lane + 1]);
-        uint32_t inc = c0 + c1;
+        constexpr int HPL = MT_TILE / 64 / 64;      // bitmap words per lane
+        uint32_t cw[HPL], tot = 0;
+#pragma unroll
+        for (int q = 0; q < HPL; ++q) { cw[q] = (uint32_t)__popcll(hbits[HPL * lane + q]); tot += cw[q]; }
+        uint32_t inc = tot;
 #pragma unroll
         for (int s2 = 1; s2 < 64; s2 <<= 1) { const uint32_t o = __shfl_up(inc, s2, 64); if (lane >= s2) inc += o; }
-        hpre[2 * lane] = inc - c0 - c1; hpre[2 * lane + 1] = inc - c1;
+        uint32_t run = inc - tot;
+#pragma unroll
+        for (int q = 0; q < HPL; ++q) { hpre[HPL * lane + q] = run; run += cw[q]; }
     }
     __syncthreads();
 #pragma unroll
@@ -915,7 +927,10 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
 // From there on the path is the k <= 17 one (k_msd_emit_small, the CSR build).  A bucket beyond W2_CAP records (a repeat family, a
 // homopolymer) sends the whole input to the sort of kmer.hip: correct, slower; profiles/r04_notes.md.
 // HBM traffic per instance: 16 B written + 16 read (hist2) + 16 read + 16 written + 16 read = 80 B, against 7 passes x 32 B + 3 x 16 B on the sort path.
-constexpr int W2_THREADS = 256, W2_ITEMS = 16, W2_TILE = W2_THREADS * W2_ITEMS;      // 4096 records of 16 bytes: 64 KB of LDS
+#ifndef ELBA_W2_THREADS
+#define ELBA_W2_THREADS 512
+#endif
+constexpr int W2_THREADS = ELBA_W2_THREADS, W2_ITEMS = 16, W2_TILE = W2_THREADS * W2_ITEMS;      // 8192 records of 16 bytes: 128 KB of LDS (runs of 8 records per digit and tile; 4096-record tiles: partition 78 -> 58 ms on 2.0 G instances)
 constexpr int W2_MAXBITS = 10, W2_MAXBINS = 1 << W2_MAXBITS;
 constexpr uint32_t W2_CAP = 4096;                // records of a bucket k31_count takes (eight per lane, in registers)
 constexpr int W2C_THREADS = 512, W2C_KPT = (int)(W2_CAP / W2C_THREADS);

@@ -144,6 +144,9 @@ __global__ void k_reduce_max(const uint64_t *p, int64_t n, unsigned long long *o
 #ifndef ELBA_RS_SCATTER_THREADS
 #define ELBA_RS_SCATTER_THREADS 256
 #endif
+#ifndef ELBA_RS_PAIR_ITEMS
+#define ELBA_RS_PAIR_ITEMS 16
+#endif
 #ifndef ELBA_RS_KEY_ITEMS
 #define ELBA_RS_KEY_ITEMS 32
 #endif
@@ -406,7 +409,7 @@ static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *
 {
     if (n <= 1 || bit_hi <= bit_lo) return 0;
     ELBA_REQUIRE(n < (int64_t)0xFFFFFFFFLL, ELBA_ERR_UNSUPPORTED, "radix sort of >= 2^32 items");
-    constexpr int ITEMS = HAS_VAL ? 8 : ELBA_RS_KEY_ITEMS, TILE = RS_THREADS * ITEMS;
+    constexpr int ITEMS = HAS_VAL ? ELBA_RS_PAIR_ITEMS : ELBA_RS_KEY_ITEMS, TILE = RS_THREADS * ITEMS;
     constexpr int STHREADS = HAS_VAL ? RS_THREADS : ELBA_RS_SCATTER_THREADS;      // the scatter's workgroup (512 threads on the same 8192-key tile were measured: 14.1-14.9 ms per pass against 10.8-13.7)
     int shifts[64], widths[64];
     const int npass = radix_digits(bit_lo, bit_hi, shifts, widths);
