@@ -924,8 +924,8 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
 //   * k31_count sorts a bucket's records by (k-mer, read, pos) IN LDS (<= W2_CAP records), finds the runs of equal k-mers, keeps those of
 //     LOWER..UPPER instances and writes their entries — compacted, in order, as the one-word entries the emit kernels of the k <= 17 path
 //     read: (column of the bucket scaled to 16 bits) << PB | read << pbits | pos — and the bucket's reliable k-mers beside them.
-// From there on the path is the k <= 17 one (k_msd_emit_small, the CSR build).  A bucket beyond W2_CAP records (a repeat family, a
-// homopolymer) sends the whole input to the sort of kmer.hip: correct, slower; profiles/r04_notes.md.
+// From there on the path is the k <= 17 one (k_msd_emit_small, the CSR build).  A bucket of more DISTINCT k-mers than the count table takes, or of
+// more kept entries than the emit kernels sort, sends the whole input to the sort of kmer.hip: correct, slower; profiles/r04_notes.md.
 // HBM traffic per instance: 16 B written + 16 read (hist2) + 16 read + 16 written + 16 read = 80 B, against 7 passes x 32 B + 3 x 16 B on the sort path.
 #ifndef ELBA_W2_THREADS
 #define ELBA_W2_THREADS 512
@@ -1125,13 +1125,17 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
     uint32_t st_maxcol = 0;
     for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {      // (two workgroups per CU hide one another's round trips: no register prefetch of the next bucket)
         const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
-        if (n == 0 || n > W2_CAP) {
-            if (tid == 0) { bN[b] = 0; bZ[b] = 0; if (n > W2_CAP) atomicAdd(&gstat->ncrowded, 1u); }
-            continue;
-        }
+        if (n == 0) { if (tid == 0) { bN[b] = 0; bZ[b] = 0; } continue; }
+        // A bucket of more than W2_CAP records (a homopolymer, a satellite: FEW k-mers, each far beyond UPPER) is walked in chunks of W2_CAP — the table
+        // only holds the distinct k-mers — and read a second time for its kept entries; what gives a bucket up is more distinct k-mers than the
+        // table takes, or more kept entries than the emit kernels sort.
+        const uint32_t nch = (n + W2_CAP - 1u) / W2_CAP;
         Rec2 key[W2C_KPT];
+        auto load_chunk = [&](uint32_t ch) {
 #pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) { const uint32_t i = (uint32_t)u * W2C_THREADS + tid; key[u] = i < n ? recs[s0 + i] : Rec2{~0ull, ~0ull}; }
+            for (int u = 0; u < W2C_KPT; ++u) { const uint32_t i = ch * W2_CAP + (uint32_t)u * W2C_THREADS + tid; key[u] = i < n ? recs[s0 + i] : Rec2{~0ull, ~0ull}; }
+        };
+        load_chunk(0);
 #pragma unroll
         for (int q = 0; q < (int)SPT; ++q) { const uint32_t sl = (uint32_t)q * W2C_THREADS + tid; K[sl] = ~0ull; CNT[sl] = 0; RC[sl] = 0xFFFFu; }
         sbcnt[tid] = 0;
@@ -1139,10 +1143,13 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
         lds_sync();
         // count: one compare-and-swap (+ a probe or two) and one add per record
         uint32_t slot[W2C_KPT];
+#pragma unroll 1
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+        if (ch) load_chunk(ch);
 #pragma unroll
         for (int u = 0; u < W2C_KPT; ++u) {
             slot[u] = 0;
-            if ((uint32_t)u * W2C_THREADS + tid < n) {
+            if (key[u].hi != ~0ull) {
                 const unsigned long long hk = key[u].hi;
                 uint32_t sl = (((uint32_t)hk ^ (uint32_t)(hk >> 27)) * 0x9E3779B1u) >> 20;      // 12 bits
                 if (__hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {      // (the table is filling up: the bucket is given up)
@@ -1157,6 +1164,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
                 }
                 slot[u] = sl;
             }
+        }
         }
         lds_sync();
         if (__hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {      // more distinct k-mers than the table takes: a crowded bucket like one beyond W2_CAP records
@@ -1235,15 +1243,35 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             lds_sync();
         }
         const uint32_t Zb = carry;
+        if (Zb > 8192u) {      // (more kept entries than the emit kernels sort in LDS: given up like a bucket of too many distinct k-mers)
+            if (tid == 0) { bN[b] = 0; bZ[b] = 0; atomicAdd(&gstat->ncrowded, 1u); }
+            lds_sync();
+            continue;
+        }
         const uint32_t vscale = Nb > 1u ? 65535u / (Nb - 1u) : 0u;   // columns spread over the 16 value bits the emit kernels sort by (strictly increasing: vscale >= 1)
+#pragma unroll 1
+        for (uint32_t ch = 0; ch < nch; ++ch) {
+            if (nch > 1u) {      // (the records again; their slots are found, not claimed: every k-mer of the bucket is in the table)
+                load_chunk(ch);
 #pragma unroll
-        for (int u = 0; u < W2C_KPT; ++u) {
-            if ((uint32_t)u * W2C_THREADS + tid < n) {
-                const uint32_t rc = RC[slot[u]];
-                if (rc != 0xFFFFu) wrel[s0 + C[rc] + atomicAdd(&CNT[slot[u]], 1u)] = ((uint64_t)(rc * vscale) << PB) | key[u].lo;
+                for (int u = 0; u < W2C_KPT; ++u) {
+                    if (key[u].hi != ~0ull) {
+                        const unsigned long long hk = key[u].hi;
+                        uint32_t sl = (((uint32_t)hk ^ (uint32_t)(hk >> 27)) * 0x9E3779B1u) >> 20;
+                        for (uint32_t probes = 0; probes < W2_SLOTS && K[sl] != hk; ++probes) sl = (sl + 1u) & (W2_SLOTS - 1u);
+                        slot[u] = sl;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < W2C_KPT; ++u) {
+                if (key[u].hi != ~0ull) {
+                    const uint32_t rc = RC[slot[u]];
+                    if (rc != 0xFFFFu) wrel[s0 + C[rc] + atomicAdd(&CNT[slot[u]], 1u)] = ((uint64_t)(rc * vscale) << PB) | key[u].lo;
+                }
             }
         }
-        if (tid == 0) { bN[b] = Nb; bZ[b] = Zb; }
+        if (tid == 0) { bN[b] = Nb; bZ[b] = Zb; if (Zb > 4096u) atomicAdd(&gstat->nmid, 1u); }
         lds_sync();
     }
 #pragma unroll

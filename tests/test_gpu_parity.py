@@ -727,15 +727,16 @@ def test_wide_partition_gives_up_a_bucket_of_too_many_distinct_kmers():
     e.close()
 
 
-def test_wide_partition_hands_a_crowded_bucket_to_the_sort():
-    """A bucket beyond what the wide path sorts in LDS (4096 instances of ONE k-mer: a homopolymer run) sends the whole input to the sort
-    of kmer.hip: same matrices, another path."""
+def test_wide_partition_walks_a_homopolymer_bucket_in_chunks():
+    """A bucket far beyond what a workgroup holds in registers (tens of thousands of instances of ONE k-mer: homopolymer runs) is walked in chunks
+    — the count table only holds the distinct k-mers — and stays on the wide path: same matrices."""
     reads, _ = synth.make_reads(7, 40000, 10, 2000, 500, error=0.05, min_len=100)
-    seqs = list(reads) + [b"A" * 700] * 8
+    seqs = list(reads) + [b"A" * 700] * 40 + [b"AC" * 400] * 20
     packed, off, lens = po.pack_reads(seqs)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 31, 2, 8, options={"kmer_msd": 1})
-    assert e.get_stat("kmer_path") == 0
+    assert e.get_stat("kmer_path") == 2
     o = gu.oracle_run(packed, off, lens, 31, 2, 8, threads=8)
+    assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
     e.close()
