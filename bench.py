@@ -54,6 +54,11 @@ PEAK_GBS = 8000.0          # HBM3E peak, MI355X_MICROARCH.md
 # path validates itself; a mismatch ends the run with a non-zero exit code.  (ELBA_BENCH_EXPECT="I,Z,P,Y" overrides: tests.)
 EXPECTED_COUNTS = {
     "200k-long-reads": (1996913231, 534826215, 1370686611, 98693580),
+    "ecsample30x-like": (138894522, 14180071, 42458349, 1359357),
+    "hifi-half": (1996504200, 10175381, 20959215, 1316021),
+    "dense-repeats-25th": (798652841, 366045468, 10848555572, 8388812),
+    "dense-repeats-8th": (2496166557, 1153437658, 33856055912, 41427794),
+    "hifi-k31": (1994637538, 903534856, 27911412714, 10219284),
 }
 
 
