@@ -118,6 +118,7 @@ constexpr uint32_t HINT_MAX_COL = 12;     // longer columns are not examined: a 
 int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
 // The same for bare 64-bit words (whatever rides in the bits outside [bit_lo, bit_hi) moves with them): returns 0 if the result is in k0, 1 if in k1.
 int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done = false);
+int radix_sort_where(int64_t n, int bit_lo, int bit_hi);
 void radix_column_scan(hipStream_t s, uint32_t *rows, int64_t nrows, uint32_t nbins, DevBuf &tmp);      // (prims.hip)
 uint32_t *radix_first_histogram(int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, int *shift, int *bits, int *tile);      // (prims.hip)
 void fill_u32(hipStream_t s, uint32_t *p, uint32_t v, int64_t n);
@@ -138,6 +139,8 @@ struct Options {
     bool no_sample = false;     // a cold call does not compute a sample of rows first
     bool no_ell_compact = false;// k-mer stage: the padded column store holds every column, row entries name k-mer ids (no gather slots)
     bool no_slab = false;       // SpGEMM: mirrored entries wait in the staging area for k_mirror instead of going straight to their row's slab (spgemm.hip: "mirror slabs")
+    bool csr_pairs_late = false; // dense matrices from the two-level partition: the CSR build's sort pairs written by the CSR build, not by the bucket kernels (A/B)
+    bool msd_no_rank = false;   // k-mer stage: entries without their column's rank — the emit kernels sort by ranges of the 16 value bits (A/B; what runs when the payload leaves no room)
     bool msd_no_emit8 = false;  // k-mer stage: buckets of up to 2048 entries through the 16-entries-per-lane kernel too (A/B)
     int ell_slot_cap = 0;       // test hook: the padded column store pretends to hold this many gather slots only (0: its real size)
     int slab_pct = 175;         // SpGEMM: a row's slab holds this many percent of the mirrored entries the measured ratio predicts for it (+ SLAB_PAD)
@@ -193,6 +196,7 @@ struct Ctx {
     DevBuf rel_kmers_lo2; // u64[N] their third word when k > 64
     DevBuf rel_counts;    // u32[N]
     DevBuf csr_words;     // u64[Z] read << (pre_nb + pre_pb) | k-mer id << pre_pb | pos of every entry of a_csc, when pre_words (k_runs_emit -> the CSR build's sort)
+    bool pre_pairs = false;      // dense matrix from kmer_msd.hip: the (read, kid | L | place | pos) pairs of the CSR sort are written (keys in ws_b; values where a sort of Z pairs on the read bits that ENDS in a_csr starts: a_csr or ws_d)
     bool pre_ready = false, pre_consumed = false, pre_words = false, pre_hints = false, pre_hints_done = false, pre_ell_done = false, pre_inline = false, pre_inline_pending = false /* the sort keys leave room for inline partners: k_add_hints writes them */; int pre_rs = 0, pre_pbi = 0; int pre_nb = 0, pre_pb = 0; uint64_t pre_maxpos = 0;
     // Ownership hints of the SpGEMM, two bits in every a_csr entry (kid << 32 | hint << 30 | pos; positions below 2^30): bit 30 = under the
     // parity rule of owns_pair (spgemm_direct.hpp) this row accumulates NO pair of the entry's column and appears in it once — the column

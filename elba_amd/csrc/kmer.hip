@@ -473,7 +473,7 @@ static void runs_to_columns(Ctx &c, const uint64_t *skeys, const uint64_t *svals
     c.kid_of_entry.reserve((size_t)(Z + 8) * 8);
     // Packed words with UPPER <= 62: one fused pass writes the columns, the entries' (read, pos) and — when read, k-mer id and position fit
     // one word — the sort keys of the CSR build (k_runs_emit).  Otherwise: heads write payloads and column ids, a second kernel converts.
-    c.pre_ready = false; c.pre_consumed = false; c.pre_hints_done = false; c.pre_ell_done = false; c.pre_inline_pending = false;
+    c.pre_ready = false; c.pre_consumed = false; c.pre_hints_done = false; c.pre_ell_done = false; c.pre_inline_pending = false; c.pre_pairs = false;
     const bool fused = ib && p.upper <= 62 && !c.opt.kmer_unfused;
     if (fused && Z > 0) {
         EnumParams e = make_enum(c);

@@ -58,6 +58,7 @@ struct MsdParams {
     int b1, b2;             // digit widths: b1 + b2 + VBITS == k2
     int pbits, PB;          // payload = read << pbits | pos, PB = bits of the payload
     uint64_t I;
+    int rk;                 // entries carry their column's rank inside the bucket from this bit up (the count kernels write it, the emit kernels sort by it); 0: they do not
 };
 
 // Enumeration for the partition kernels: a lane takes 32 CONSECUTIVE instances (g = wbase + 32 * lane + it) and rolls its k-mer window along
@@ -383,6 +384,7 @@ struct BucketOut {
     // BASELINE config 3), 8 S per gathered column now.
     unsigned long long *slot_cursor; uint32_t *slot_kid; uint32_t compact, slot_chunk;      // slot_cursor[1] != 0: a draw ran past slot_cap (nothing was written there; the host emits again without slots)
     unsigned long long slot_cap;
+    uint64_t *pair_key, *pair_val; // dense matrices (Ctx::csr_suffix): the pairs the CSR build sorts by read — read; k-mer id << 32 | column length << 23 | place in the column << 16 | pos — instead of sort words
     const uint64_t *kmer_src;      // k > 17 (k31_count): the bucket's reliable k-mers, left-aligned, at [bucket's first instance + column]; null: the k-mer is bucket << 16 | the entry's 16 value bits
 };
 
@@ -394,17 +396,18 @@ struct BucketOut {
 // those alone (a quarter of the instances on 15 %-error reads).  Out: reliable k-mers and entries per bucket (the scan over the buckets gives the
 // k-mer ids and column pointers), buckets too crowded for the small emit kernel.
 constexpr uint32_t CT_TAB = 32768, CT_BITS = 2048;      // words
-constexpr size_t CT_LDS = (size_t)(CT_TAB + 2 * CT_BITS + 64) * 4;
+constexpr size_t CT_LDS = (size_t)(CT_TAB + 3 * CT_BITS + 64) * 4;
 __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words, const uint32_t *b2start, uint32_t nbuckets, MsdParams m, uint32_t lower, uint32_t upper, uint32_t small_cap,
                                                          uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint32_t *crowded, uint64_t *wrel)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t *tab = smem;
     const uint16_t *tab16 = reinterpret_cast<const uint16_t *>(smem);
-    uint32_t *relbits = smem + CT_TAB, *seenbits = relbits + CT_BITS, *misc = seenbits + CT_BITS;
+    uint32_t *relbits = smem + CT_TAB, *seenbits = relbits + CT_BITS, *misc = seenbits + CT_BITS, *pre = misc + 64;      // pre[w]: reliable values below word w of the bitmap
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     unsigned long long st_distinct = 0, st_sumsq = 0;
     uint32_t st_maxcol = 0;
+    const uint64_t lowmask = m.rk ? (1ull << m.rk) - 1 : ~0ull;
     // the instances of the NEXT bucket are requested before this one is processed (one workgroup per CU: nobody else hides the round trip)
     uint32_t b = blockIdx.x, s0 = 0, n = 0;
     uint64_t kreg[KPT];
@@ -432,7 +435,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
             uint4 *t4 = reinterpret_cast<uint4 *>(smem);
 #pragma unroll
             for (int u = 0; u < 9; ++u) t4[(uint32_t)u * BK_THREADS + tid] = make_uint4(0u, 0u, 0u, 0u);
-            if (tid < 16) misc[tid] = 0;
+            if (tid < 32) misc[tid] = 0;
         }
         lds_sync();
         const bool guard = n > 65535u;          // a value's count could run over its 16 bits: stop counting beyond 2^15 (UPPER <= 255: unreliable anyway)
@@ -450,16 +453,15 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
         for_keys([&](uint64_t wd) {
             const uint32_t v = (uint32_t)(wd >> m.PB) & 0xFFFFu, cnt = tab16[v];
             atomicOr(&seenbits[v >> 5], 1u << (v & 31u));
-            if (cnt >= lower && cnt <= upper) {
-                atomicOr(&relbits[v >> 5], 1u << (v & 31u));
-                wrel[s0 + atomicAdd(&misc[0], 1u)] = wd;
-            }
+            if (cnt >= lower && cnt <= upper) atomicOr(&relbits[v >> 5], 1u << (v & 31u));
         });
         lds_sync();
-        uint32_t nrel = 0;
+        // the reliable values in value order: lane t owns words 2t, 2t + 1 of the bitmap; a scan over the lanes numbers them (the column's rank in the bucket)
+        uint32_t nrel = 0, c0 = 0;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const uint32_t wi = (uint32_t)q * BK_THREADS + tid, mybits = relbits[wi];
+            const uint32_t wi = 2u * tid + (uint32_t)q, mybits = relbits[wi];
+            if (q == 0) c0 = (uint32_t)__popc(mybits);
             nrel += (uint32_t)__popc(mybits);
             st_distinct += (unsigned long long)__popc(seenbits[wi]);
             for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
@@ -467,9 +469,25 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
                 st_sumsq += (unsigned long long)cnt * cnt; st_maxcol = cnt > st_maxcol ? cnt : st_maxcol;
             }
         }
+        {
+            uint32_t inc = nrel;
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) nrel += __shfl_xor(nrel, d, 64);
-        if (lane == 0 && nrel) atomicAdd(&misc[1], nrel);
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += x; }
+            if (lane == 63) misc[16 + (tid >> 6)] = inc;
+            lds_sync();
+            uint32_t ex = inc - nrel;
+            for (uint32_t ww = 0; ww < (tid >> 6); ++ww) ex += misc[16 + ww];
+            pre[2u * tid] = ex; pre[2u * tid + 1u] = ex + c0;
+            if (tid == BK_THREADS - 1) misc[1] = ex + nrel;
+        }
+        lds_sync();
+        for_keys([&](uint64_t wd) {
+            const uint32_t v = (uint32_t)(wd >> m.PB) & 0xFFFFu, bits = relbits[v >> 5];
+            if ((bits >> (v & 31u)) & 1u) {
+                const uint64_t rc = pre[v >> 5] + (uint32_t)__popc(bits & ((1u << (v & 31u)) - 1u));
+                wrel[s0 + atomicAdd(&misc[0], 1u)] = m.rk ? (wd & lowmask) | (rc << m.rk) : wd;
+            }
+        });
         lds_sync();
         if (tid == 0) {
             const uint32_t Zb = misc[0], Nb = misc[1];
@@ -500,7 +518,6 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
 // leaves from here as coalesced streams.  256 lanes, 44 KB of LDS: three workgroups per CU hide one another's barriers and memory waits.
 // <16>: up to 4096 entries, three workgroups per CU; <32>: up to 8192 (the canonical k-mer is the smaller of two: low values are twice as dense as
 // the average, and the fullest buckets of a large input land here), one workgroup per CU.
-constexpr uint32_t ES_NSB = 512;
 // <32, 256> (8192 entries on 256 lanes: 256 VGPRs, 95 KB of LDS, ONE workgroup of four wavefronts per CU) took 85 ms on BASELINE config 5 at one GPU's
 // share, where the average bucket holds 4400 entries: the widest buckets now run on 512 lanes, 16 entries each (<16, 512>: eight wavefronts per CU)
 template <int ES_KPT, int ES_THREADS = 256>
@@ -508,7 +525,9 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                                                               const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
 {
     constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, NW = ES_THREADS / 64, NH = ES_KPT * NW;      // entries; wavefronts; (u, wavefront) head counts
-    constexpr int PER = (int)(ES_NSB / ES_THREADS);      // value ranges per lane in their scan
+    constexpr uint32_t ES_NSB = ES_CAP >= 8192 ? 1024 : 512;      // ranges of the sort
+    constexpr int NSB_BITS = ES_CAP >= 8192 ? 10 : 9;
+    constexpr int PER = (int)(ES_NSB / ES_THREADS);      // ranges per lane in their scan
     static_assert(PER >= 1 && ES_NSB % ES_THREADS == 0, "one value range per lane at least");
     __shared__ uint64_t A[ES_CAP];
     __shared__ uint32_t sbcnt[ES_NSB], sbstart[ES_NSB + 1], H[ES_CAP / 2 + 2], hcnt[NH + 1], wsum[NW];
@@ -526,9 +545,26 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
         uint64_t key[ES_KPT];
 #pragma unroll
         for (int u = 0; u < ES_KPT; ++u) { const uint32_t i = (uint32_t)u * ES_THREADS + tid; key[u] = i < Z ? wrel[s0 + i] : ~0ull; }
-        // value ranges of the sort: 2^(16 - sh) of them, 4-8 entries each
+        // Ranges of the sort, monotone in the word.  Without column ranks: 2^(16 - sh) ranges of the 16 value bits, 4-8 entries each while the
+        // values are spread evenly — but a column of 30 entries (deep coverage, BASELINE config 5) is ONE value: every entry then ranks itself among 30.
+        // With ranks (MsdParams::rk): the range is (column rank, leading bits of the read) cut to NSB_BITS bits — each column has its own ranges, and
+        // a long column is split by read.
         uint32_t sh = 7;
         while (sh < 16 && (Z >> (16 - sh)) < 4u) ++sh;
+        int rs_s = 0, rs_t = 0;
+        if (m.rk) {
+            const uint32_t ncol = kidbase[b + 1] - kidbase[b];
+            int cb = 0;
+            while (cb < 16 && (ncol >> cb)) ++cb;                     // bits of a column rank
+            int want = 2;
+            while (want < NSB_BITS && (Z >> (want + 2)) != 0u) ++want;      // ~4 entries per range
+            if (cb >= want) rs_t = cb - want;
+            else { rs_s = want - cb; const int mbits = m.PB - m.pbits; if (rs_s > mbits) rs_s = mbits; }
+        }
+        auto range_of = [&](uint64_t x) -> uint32_t {
+            return m.rk ? (uint32_t)((((x >> m.rk) << rs_s) | ((x & paymask) >> (m.PB - rs_s))) >> rs_t) : ((uint32_t)(x >> m.PB) & 0xFFFFu) >> sh;
+        };
+        auto col_of = [&](uint64_t x) -> uint32_t { return m.rk ? (uint32_t)(x >> m.rk) : (uint32_t)(x >> m.PB) & 0xFFFFu; };
 #pragma unroll
         for (int q = 0; q < PER; ++q) sbcnt[tid + (uint32_t)q * ES_THREADS] = 0;
         lds_sync();
@@ -536,7 +572,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
 #pragma unroll
         for (int u = 0; u < ES_KPT; ++u) {
             slot[u] = 0;
-            if ((uint32_t)u * ES_THREADS + tid < Z) slot[u] = atomicAdd(&sbcnt[((uint32_t)(key[u] >> m.PB) & 0xFFFFu) >> sh], 1u);
+            if ((uint32_t)u * ES_THREADS + tid < Z) slot[u] = atomicAdd(&sbcnt[range_of(key[u])], 1u);
         }
         lds_sync();
         {   // exclusive scan of the <= 512 range counts: PER consecutive ones per lane
@@ -557,12 +593,12 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
         lds_sync();
 #pragma unroll
         for (int u = 0; u < ES_KPT; ++u)
-            if ((uint32_t)u * ES_THREADS + tid < Z) A[sbstart[((uint32_t)(key[u] >> m.PB) & 0xFFFFu) >> sh] + slot[u]] = key[u];
+            if ((uint32_t)u * ES_THREADS + tid < Z) A[sbstart[range_of(key[u])] + slot[u]] = key[u];
         lds_sync();
 #pragma unroll
         for (int u = 0; u < ES_KPT; ++u) {
             if ((uint32_t)u * ES_THREADS + tid < Z) {
-                const uint32_t sb = ((uint32_t)(key[u] >> m.PB) & 0xFFFFu) >> sh, lo = sbstart[sb], hi = sbstart[sb + 1];
+                const uint32_t sb = range_of(key[u]), lo = sbstart[sb], hi = sbstart[sb + 1];
                 // (the range's first eight words requested at once: a loop with a per-lane trip count is one LDS round trip per word — ~100 per lane and bucket)
                 uint32_t rank = 0;
                 uint64_t kk[8];
@@ -583,7 +619,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
 #pragma unroll
         for (int u = 0; u < ES_KPT; ++u) {
             const uint32_t p = (uint32_t)u * ES_THREADS + tid;
-            const bool head = p < Z && (p == 0 || ((uint32_t)(A[p - 1] >> m.PB) & 0xFFFFu) != ((uint32_t)(A[p] >> m.PB) & 0xFFFFu));
+            const bool head = p < Z && (p == 0 || col_of(A[p - 1]) != col_of(A[p]));
             const uint64_t bal = __ballot(head);
             if (head) headmask |= 1u << u;
             slot[u] = (uint32_t)__popcll(bal & lt) + (head ? 1u : 0u);      // heads at or before this place within its wavefront's 64 places
@@ -647,7 +683,8 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 // pair in its own entry — the SpGEMM then fetches no column for it
                 const bool isinl = o.inl && mult == 1u && nown == 1u && ((pos | opos) >> o.inl) == 0;
                 if (isinl) word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
-                if (o.compact && !isinl && hint == 0) {      // this entry fetches its column: the column needs a gather slot, the key names it (below)
+                if (o.pair_val) { o.pair_key[z] = read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)L << 23) | ((uint64_t)(p - h0) << 16) | pos; }
+                else if (o.compact && !isinl && hint == 0) {      // this entry fetches its column: the column needs a gather slot, the key names it (below)
                     needmask |= 1u << u;
                     atomicOr(&H[kl], HNEED);
                 }
@@ -895,7 +932,8 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                         const uint32_t z = eb + wlo + p, kid = kb + klo + entk[p];
                         const uint32_t id = o.compact && hint == 0 ? wslot + entk[p] : kid;      // (an entry that fetches its column names the column's gather slot)
                         o.csc[z] = (read << 32) | pos;
-                        if (o.csr_words) o.csr_words[z] = (read << o.rs) | ((uint64_t)id << (o.pb + 2)) | (hint << o.pb) | pos;
+                        if (o.pair_val) { const uint32_t kl = entk[p]; o.pair_key[z] = read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)fill[kl] << 23) | ((uint64_t)(p - headpos[kl]) << 16) | pos; }
+                        else if (o.csr_words) o.csr_words[z] = (read << o.rs) | ((uint64_t)id << (o.pb + 2)) | (hint << o.pb) | pos;
                         else o.kid_of_entry[z] = kid;
                     }
                     if (o.ell_stride && !past) {
@@ -1108,7 +1146,7 @@ constexpr uint32_t W2_DISTINCT_MAX = W2_SLOTS - 2 * W2C_THREADS;  // distinct k-
 static_assert(W2C_KPT * W2C_THREADS >= (int)W2_CAP, "every record has a register");
 // (a bucket's size fluctuates with coverage x sqrt(distinct genomic k-mers in it): 1900 +- 280 instances on 40x reads of a 50 Mb genome cut into 2^20
 //  buckets — 3300 at five sigma, which 2^20 buckets do reach)
-__global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const uint32_t *b2start, uint32_t nbuckets, int k2, int T, int PB, uint32_t lower, uint32_t upper,
+__global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const uint32_t *b2start, uint32_t nbuckets, int k2, int T, int PB, int rk, uint32_t lower, uint32_t upper,
                                                         uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint64_t *wrel, uint64_t *ktmp)
 {
     constexpr uint32_t NW = W2C_THREADS / 64, NSB = 512, IPT = (W2_RELMAX + W2C_THREADS - 1) / W2C_THREADS, SPT = W2_SLOTS / W2C_THREADS;
@@ -1267,7 +1305,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             for (int u = 0; u < W2C_KPT; ++u) {
                 if (key[u].hi != ~0ull) {
                     const uint32_t rc = RC[slot[u]];
-                    if (rc != 0xFFFFu) wrel[s0 + C[rc] + atomicAdd(&CNT[slot[u]], 1u)] = ((uint64_t)(rc * vscale) << PB) | key[u].lo;
+                    if (rc != 0xFFFFu) wrel[s0 + C[rc] + atomicAdd(&CNT[slot[u]], 1u)] = (rk ? (uint64_t)rc << rk : (uint64_t)(rc * vscale) << PB) | key[u].lo;
                 }
             }
         }
@@ -1319,6 +1357,8 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     const int mb = bits_needed_u((uint64_t)(c.nreads > 0 ? c.nreads - 1 : 0));
     m.PB = mb + m.pbits;
     if ((wide ? 0 : m.b2) + VBITS + m.PB > 62) return false;      // (the two top bits of a staged entry carry its hint)
+    // an entry's column rank inside its bucket (< 8192: the emit kernels take no more entries) above the 16 value bits, where there is room for it
+    m.rk = (m.PB + VBITS + 13 <= 64 && !c.opt.msd_no_rank) ? m.PB + VBITS : 0;
     hipStream_t s = c.stream;
     const uint32_t nb1 = 1u << m.b1, nb2 = 1u << m.b2, nbuckets = nb1 * nb2;
     const uint32_t tile = wide ? (uint32_t)W2_TILE : (uint32_t)MT_TILE;
@@ -1385,7 +1425,7 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
         c.t_b.start(s);
         ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
         // (the first pass's records are dead: the front half of their buffer takes the kept entries, one word each, the back half the buckets' reliable k-mers)
-        hipLaunchKernelGGL(k31_count, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus)), dim3(W2C_THREADS), W2C_LDS, s, (const Rec2 *)rb, (const uint32_t *)b2start, nbuckets, k2, T, m.PB,
+        hipLaunchKernelGGL(k31_count, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus)), dim3(W2C_THREADS), W2C_LDS, s, (const Rec2 *)rb, (const uint32_t *)b2start, nbuckets, k2, T, m.PB, m.rk,
                            (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, bN, bZ, gstat, wa, wa + (I + 2));
         o.kmer_src = wa + (I + 2);
     }
@@ -1429,8 +1469,17 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
         pbi = std::min(pb, (rs2 - (mb - 1)) / 2);
         if (rs2 >= rs && pbi >= 10) rs = rs2; else inl = false;
     }
-    o.csc = c.a_csc.as<uint64_t>(); o.nb = nb; o.pb = pb; o.rs = rs; o.mb = mb; o.inl = inl ? (uint32_t)pbi : 0u; o.hints = hints && words ? 1u : 0u;
-    if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
+    o.csc = c.a_csc.as<uint64_t>(); o.nb = nb; o.pb = pb; o.rs = rs; o.mb = mb; o.inl = inl ? (uint32_t)pbi : 0u; o.hints = hints && words && !dense ? 1u : 0u;
+    // a dense matrix's CSR build sorts (read, entry) pairs (matrix.hip, csr_suffix: the entry carries its column's length and its place in it — known
+    // here, where the column lies sorted in LDS): they are written instead of sort words, the values where a sort that ends in a_csr starts
+    const bool pairs = dense && N < (1ull << 32) && c.max_col_nnz < 128 && !c.opt.csr_pairs_late;
+    c.pre_pairs = pairs;
+    if (pairs) {
+        c.ws_b.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8); c.a_csr.reserve((size_t)(Z + 1) * 8);      // (ws_b: the enumeration's block table is dead)
+        o.pair_key = c.ws_b.as<uint64_t>();
+        o.pair_val = radix_sort_where((int64_t)Z, 0, mb) == 0 ? c.a_csr.as<uint64_t>() : c.ws_d.as<uint64_t>();
+    }
+    else if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }
     else { c.kid_of_entry.reserve((size_t)(Z + 8) * 8); o.kid_of_entry = c.kid_of_entry.as<uint64_t>(); }
     o.ell = c.use_ell ? c.a_ell.as<uint64_t>() : nullptr; o.ell_stride = c.use_ell ? c.s_stride : 0u;
     // gather slots: with inline partners the padded store holds the columns that are still fetched, not all of them (BucketOut)

@@ -380,23 +380,28 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         c.csr_inline = (have_words && c.pre_inline) || inl_here || inl_late;
         c.csr_inline_window = inl_here && windowed;
     } else {
-        ELBA_REQUIRE(!pre || !c.pre_words || c.csr_suffix, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
-        const bool kid_in_words = pre && c.pre_words;        // (k_runs_emit left sort keys, not column ids: the k-mer id is a field of the word)
-        const uint64_t *kk = kid_in_words ? c.csr_words.as<uint64_t>() : kid_keys;
-        const int ks = kid_in_words ? c.pre_pb + 2 : kid_shift;
-        const uint64_t km = kid_in_words ? (1ull << c.pre_nb) - 1 : ~0ull;
+        const bool pre_pairs = pre && c.pre_pairs;           // (kmer_msd.hip has written the pairs of a dense matrix: keys in ws_b, values where the sort must start to end in a_csr)
+        ELBA_REQUIRE(!pre || !c.pre_words || c.csr_suffix || pre_pairs, ELBA_ERR_INTERNAL, "create_kmer_matrix: the sort keys of the k-mer stage do not match the matrix");
+        ELBA_REQUIRE(!pre_pairs || c.csr_suffix, ELBA_ERR_INTERNAL, "create_kmer_matrix: the k-mer stage wrote the pairs of a dense matrix, the matrix is not one");
+        const bool kid_in_words = pre && c.pre_words && !pre_pairs;        // (k_runs_emit left sort keys, not column ids: the k-mer id is a field of the word)
+        // the sorted values are the rows of A: the sort's buffers are handed over so that it ENDS in a_csr (no copy behind it)
         c.ws_b.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
-        uint64_t *k0 = c.ws_a.as<uint64_t>(), *v0 = c.ws_b.as<uint64_t>(), *k1 = c.ws_c.as<uint64_t>(), *v1 = c.ws_d.as<uint64_t>();
-        if (Z > 0) {
+        const bool ends_in_second = radix_sort_where(Z, 0, mb) != 0;
+        uint64_t *k0 = pre_pairs ? c.ws_b.as<uint64_t>() : c.ws_a.as<uint64_t>(), *k1 = pre_pairs ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>();
+        uint64_t *spare = pre_pairs ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
+        uint64_t *v0 = ends_in_second ? spare : c.a_csr.as<uint64_t>(), *v1 = ends_in_second ? c.a_csr.as<uint64_t>() : spare;
+        const uint64_t *kk = pre_pairs ? v0 : kid_in_words ? c.csr_words.as<uint64_t>() : kid_keys;      // (pairs that must be written again — a row window rotates the columns —: the k-mer id is the value's upper half)
+        const int ks = pre_pairs ? 32 : kid_in_words ? c.pre_pb + 2 : kid_shift;
+        const uint64_t km = pre_pairs ? 0xFFFFFFFFull : kid_in_words ? (1ull << c.pre_nb) - 1 : ~0ull;
+        if (Z > 0 && !(pre_pairs && !windowed)) {
             int64_t nbk = (Z + 255) / 256;
             if (pre) ELBA_HIP(hipMemsetAsync(prod_ctr, 0, 64 * 128, s));
             hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kk, ks, km, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, k0, v0,
                                hints, c.csr_suffix, wlo, whi, prod_ctr, colw0);
         }
-        int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, mb, c.ws_sort);
-        const uint64_t *rk = where ? k1 : k0, *rv = where ? v1 : v0;
-        group_offsets_u32(s, rk, 0, Z, c.a_rowptr.as<uint32_t>(), M);
-        if (Z > 0) ELBA_HIP(hipMemcpyAsync(c.a_csr.p, rv, (size_t)Z * 8, hipMemcpyDeviceToDevice, s));
+        const int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, mb, c.ws_sort);
+        ELBA_REQUIRE((where != 0) == ends_in_second, ELBA_ERR_INTERNAL, "create_kmer_matrix: the CSR sort ended in the other buffer");
+        group_offsets_u32(s, where ? k1 : k0, 0, Z, c.a_rowptr.as<uint32_t>(), M);
     }
     c.csr_hints = hints;
     {

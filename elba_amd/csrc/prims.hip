@@ -459,6 +459,14 @@ uint32_t *radix_first_histogram(int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, 
     return tmp.as<uint32_t>();
 }
 
+// which of its two buffers a sort of n items on the bits [bit_lo, bit_hi) ends in (what radix_sort_pairs / _keys return): a caller that wants the
+// result in a buffer of its own hands that buffer over as the one the sort ends in
+int radix_sort_where(int64_t n, int bit_lo, int bit_hi)
+{
+    int shifts[64], widths[64];
+    return (n <= 1 || bit_hi <= bit_lo) ? 0 : (radix_digits(bit_lo, bit_hi, shifts, widths) & 1);
+}
+
 int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
 {
     return radix_sort_impl<true>(s, k0, v0, k1, v1, n, bit_lo, bit_hi, tmp, false);

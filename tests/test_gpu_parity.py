@@ -449,16 +449,22 @@ def test_reads_that_hold_a_kmer_twice_and_the_ownership_hints(shape):
         e.close()
 
 
-@pytest.mark.parametrize("knob", [None, "no_suffix", "no_row_order", ("dense_up", 0), ("dense_up", 2)])
+@pytest.mark.parametrize("knob", [None, "no_suffix", "no_row_order", ("dense_up", 0), ("dense_up", 2), {"kmer_msd": 1}, {"kmer_msd": 1, "csr_pairs_late": 1}, {"kmer_msd": 1, "msd_no_rank": 1},
+                                  {"kmer_msd": 1, "msd_small_cap": 64}])
 def test_dense_columns_take_the_path_of_their_own(knob):
     """Deep, nearly error-free reads with a generous UPPER: columns of ~30 reads, hundreds of products per surviving pair.  Such matrices are
     multiplied by the dense path (pairs owned by the smaller row, the owned candidates of a row entry = its column behind it: DESIGN.md §4.1);
     the option "no_suffix" keeps them on the general path.  The dense path names partners by LABEL (rank of the read among the reads sorted by their
     smallest k-mer: reads of one locus get neighbouring labels; "no_row_order" names them by row) and starts its rows on the tier "dense_up" says
     (1: eight wavefronts on a 1024-slot table).  A, B and the statistics equal the oracle's every way, on a cold and a warm call, and a read that
-    holds a k-mer twice (a repeat family) is among them."""
+    holds a k-mer twice (a repeat family) is among them.  Through the two-level partition ("kmer_msd" forces it on an input this small) the
+    bucket kernels write the CSR build's (read, entry) pairs themselves — the entry carries its column's length and its own place in it, which is
+    known where the column lies sorted — ("csr_pairs_late": the CSR build does), and sort a bucket by (column rank, read) ranges
+    ("msd_no_rank": by ranges of the value bits, where a long column is one range); "msd_small_cap": the crowded-bucket kernel writes them."""
     packed, off, lens, info = elba_amd.synth_reads(91, 60000, 30, 3000, 600, error_rate=0.01, min_len=500, repeat_families=3, repeat_fraction=0.1, repeat_len=400)
-    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40, options=({knob[0]: knob[1]} if isinstance(knob, tuple) else {knob: 1}) if knob else None)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 40, options=(dict(knob) if isinstance(knob, dict) else {knob[0]: knob[1]} if isinstance(knob, tuple) else {knob: 1}) if knob else None)
+    if isinstance(knob, dict):
+        assert e.get_stat("kmer_path") == 1
     o = gu.oracle_run(packed, off, lens, 17, 2, 40, threads=8)
     assert ms["max_col_nnz"] > 16 if "max_col_nnz" in ms else True
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
@@ -480,6 +486,11 @@ def test_dense_columns_take_the_path_of_their_own(knob):
         gu.assert_B_equal(e2.export_csr(), o.B())
         gu.assert_stats_equal(st2, o)
         e2.close()
+    if isinstance(knob, dict):
+        e.create_kmer_matrix()                              # (the pairs were consumed: rebuilt from the column pointers)
+        e.create_seed_matrix()
+        gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+        gu.assert_B_equal(e.export_csr(), o.B())
     e.close()
 
 
