@@ -361,6 +361,7 @@ def main():
         t0 = time.perf_counter(); s3 = e3.create_seed_matrix(); torch.cuda.synchronize(); t_call = time.perf_counter() - t0
         from_triples = {"set_kmer_matrix_device_ms": round(t_set * 1e3, 3), "first_cold_call_ms": round(t_call * 1e3, 3), "ms": round((t_set + t_call) * 1e3, 3),
                         "overlap_nnz_per_s": round(s3["nnz"] / (t_set + t_call), 1), "same_nnz_and_products": bool(s3["nnz"] == st_cold["nnz"] and s3["products"] == st_cold["products"]),
+                        "path": "bucket kernels of the k-mer stage" if e3.get_stat("triples_path") == 1 else "radix sorts of the whole matrix",
                         "what": "device-resident COO triples of A (int64, int64, uint32) -> CSR + k-mer columns + hints + padded columns, then one cold elba_create_seed_matrix"}
         e3.close()
         del d_rows, d_cols, d_vals

@@ -553,6 +553,7 @@ int elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value)
         if (!strcmp(name, "overlap_mirror_placed")) *value = c.ov_mir_placed;
         else if (!strcmp(name, "overlap_slab_q16")) *value = (int64_t)c.ov_slab_q16_used;
         else if (!strcmp(name, "kmer_path")) *value = c.kmer_path;
+        else if (!strcmp(name, "triples_path")) *value = c.triples_path;
         else if (!strcmp(name, "gather_slots")) *value = c.have_A && c.use_ell ? c.ell_nslots : 0;
         else if (!strcmp(name, "resident_bytes_A")) {
             int64_t b = 0;

@@ -188,6 +188,7 @@ struct Ctx {
 
     // k-mer stage results (device)
     bool have_counts = false;
+    int triples_path = 0; // diagnostic: how the last elba_set_kmer_matrix_device built the matrix — 0 radix sorts of the whole matrix (matrix.hip), 1 the k-mer stage's bucket kernels (kmer_msd.hip)
     int kmer_path = 0;    // diagnostic: how the last elba_count_kmers counted — 0 the sort of kmer.hip, 1 two-level partition + LDS count tables (k <= 17), 2 the same on 16-byte records + LDS sort (19 <= k <= 31)
     int64_t I = 0, ndistinct = 0;
     DevBuf inst_off;      // u64[M+1] instance offset of each read
@@ -313,6 +314,7 @@ void stage_set_reads_fasta(Ctx &c, const char *chunk, int64_t chunk_bytes, uint6
                            int64_t first_global_id, elba_ingest_stats *stats);      // ingest.hip
 void stage_count_kmers(Ctx &c);                                   // kmer.hip
 void stage_create_kmer_matrix(Ctx &c);                            // kmer.hip
+bool msd_matrix_from_triples(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *d_rows, const int64_t *d_cols, const uint32_t *d_vals);   // kmer_msd.hip: false = matrix.hip sorts
 bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st);   // kmer_msd.hip: false = not applicable (the caller sorts)
 void choose_column_store(Ctx &c, int64_t N, int64_t max_col);     // matrix.hip: padded column store or plain CSC, strides, sequence-number bits
 void stage_set_kmer_matrix(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *rows, const int64_t *cols, const uint32_t *vals);  // matrix.hip

@@ -59,6 +59,7 @@ struct MsdParams {
     int pbits, PB;          // payload = read << pbits | pos, PB = bits of the payload
     uint64_t I;
     int rk;                 // entries carry their column's rank inside the bucket from this bit up (the count kernels write it, the emit kernels sort by it); 0: they do not
+    uint32_t rkmask;        // ... in these bits (triples: the rank is the column id's low bits, the rest of the id sits above them)
 };
 
 // Enumeration for the partition kernels: a lane takes 32 CONSECUTIVE instances (g = wbase + 32 * lane + it) and rolls its k-mer window along
@@ -562,9 +563,9 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
             else { rs_s = want - cb; const int mbits = m.PB - m.pbits; if (rs_s > mbits) rs_s = mbits; }
         }
         auto range_of = [&](uint64_t x) -> uint32_t {
-            return m.rk ? (uint32_t)((((x >> m.rk) << rs_s) | ((x & paymask) >> (m.PB - rs_s))) >> rs_t) : ((uint32_t)(x >> m.PB) & 0xFFFFu) >> sh;
+            return m.rk ? (uint32_t)(((((x >> m.rk) & m.rkmask) << rs_s) | ((x & paymask) >> (m.PB - rs_s))) >> rs_t) : ((uint32_t)(x >> m.PB) & 0xFFFFu) >> sh;
         };
-        auto col_of = [&](uint64_t x) -> uint32_t { return m.rk ? (uint32_t)(x >> m.rk) : (uint32_t)(x >> m.PB) & 0xFFFFu; };
+        auto col_of = [&](uint64_t x) -> uint32_t { return m.rk ? (uint32_t)(x >> m.rk) & m.rkmask : (uint32_t)(x >> m.PB) & 0xFFFFu; };
 #pragma unroll
         for (int q = 0; q < PER; ++q) sbcnt[tid + (uint32_t)q * ES_THREADS] = 0;
         lds_sync();
@@ -692,7 +693,8 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 else o.kid_of_entry[z] = kid;
                 if ((headmask >> u) & 1u) {
                     const uint64_t value = ((uint64_t)b << VBITS) | ((uint32_t)(x >> m.PB) & 0xFFFFu);
-                    o.rel_kmers[kid] = o.kmer_src ? o.kmer_src[s0 + kl] : value << (64 - m.k2); o.rel_counts[kid] = L; o.colptr[kid] = z;
+                    if (o.rel_kmers) o.rel_kmers[kid] = o.kmer_src ? o.kmer_src[s0 + kl] : value << (64 - m.k2);
+                    o.rel_counts[kid] = L; o.colptr[kid] = z;
                 }
             }
         }
@@ -1330,35 +1332,120 @@ int bits_needed_u(uint64_t maxval)
 
 }  // namespace
 
+// largest position among the triples (what the layout of a partition word depends on)
+__global__ void k_tri_maxpos(const uint32_t *vals, uint64_t Z, unsigned long long *out)
+{
+    uint32_t mx = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < Z; i += (uint64_t)gridDim.x * blockDim.x) { const uint32_t v = vals[i]; mx = v > mx ? v : mx; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o2 = __shfl_xor(mx, d, 64); mx = o2 > mx ? o2 : mx; }
+    if ((threadIdx.x & 63) == 0 && mx > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, (unsigned long long)mx);
+}
+// device triples -> one partition word each: col << PB | row << pbits | pos (msd_matrix_from_triples); indices out of range are counted
+__global__ void k_pack_triple_msd(const int64_t *rows, const int64_t *cols, const uint32_t *vals, uint64_t Z, int64_t M, int64_t N, int pbits, int PB, uint64_t *w, unsigned long long *bad)
+{
+    const uint64_t z = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool b = false;
+    if (z < Z) {
+        const int64_t r = rows[z], cc = cols[z];
+        b = r < 0 || r >= M || cc < 0 || cc >= N;
+        w[z] = b ? 0ull : ((uint64_t)cc << PB) | ((uint64_t)r << pbits) | (uint64_t)vals[z];
+    }
+    const uint64_t bal = __ballot(b);
+    if (bal && (threadIdx.x & 63) == 0) atomicAdd(bad, (unsigned long long)__popcll(bal));
+}
+// triples: entries and columns of every bucket (2^vb consecutive columns, the rank of a column = the low bits of its id), the longest column,
+// the sum of the squared column lengths (= the products of A x A^T).  Nothing is rewritten: the emit kernels take the partitioned words.
+__global__ __launch_bounds__(256) void k_tri_stats(const uint64_t *words, const uint32_t *b2start, uint32_t nbuckets, int PB, uint32_t vmask, uint32_t small_cap,
+                                                  uint32_t *bN, uint32_t *bZ, BucketStats *gstat)
+{
+    __shared__ uint32_t cnt[8192], red[4];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    unsigned long long st_distinct = 0, st_sumsq = 0;
+    uint32_t st_maxcol = 0;
+    for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
+        const uint32_t s0 = b2start[b], n = b2start[b + 1] - s0;
+        if (n == 0 || n > small_cap) {
+            if (tid == 0) { bN[b] = 0; bZ[b] = n; if (n) atomicAdd(&gstat->ncrowded, 1u); }
+            continue;
+        }
+        for (uint32_t v = tid; v <= vmask; v += 256) cnt[v] = 0;
+        __syncthreads();
+        for (uint32_t i = tid; i < n; i += 256) atomicAdd(&cnt[(uint32_t)(words[s0 + i] >> PB) & vmask], 1u);
+        __syncthreads();
+        uint32_t nb = 0;
+        for (uint32_t v = tid; v <= vmask; v += 256) {
+            const uint32_t cc = cnt[v];
+            if (cc) { ++nb; st_sumsq += (unsigned long long)cc * cc; st_maxcol = cc > st_maxcol ? cc : st_maxcol; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nb += __shfl_xor(nb, d, 64);
+        if (lane == 0) red[tid >> 6] = nb;
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t Nb = red[0] + red[1] + red[2] + red[3];
+            bN[b] = Nb; bZ[b] = n; st_distinct += Nb;
+            if (n > 4096u) atomicAdd(&gstat->nmid, 1u);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        st_distinct += __shfl_xor(st_distinct, d, 64); st_sumsq += __shfl_xor(st_sumsq, d, 64);
+        const uint32_t o2 = __shfl_xor(st_maxcol, d, 64); st_maxcol = o2 > st_maxcol ? o2 : st_maxcol;
+    }
+    if (lane == 0) { if (st_distinct) atomicAdd(&gstat->distinct, st_distinct); if (st_sumsq) atomicAdd(&gstat->sumsq, st_sumsq); if (st_maxcol) atomicMax(&gstat->maxcol, st_maxcol); }
+}
+
+// A matrix handed over as device triples (elba_set_kmer_matrix_device, INTEGRATION.md option B) through the same bucket kernels: the "value" is the
+// column id, a bucket 2^vb consecutive columns.  Every column counts as reliable; a matrix with an EMPTY column (the bucket kernels number the
+// columns they find), or with a bucket beyond what the LDS sort takes, keeps the sort of matrix.hip.
+struct MsdTriples { int64_t M, N; uint64_t maxpos; const int64_t *rows, *cols; const uint32_t *vals; unsigned long long bad; };
+
 // The k-mer stage of one GPU for 9 <= k <= 17 (see the file header).  Leaves behind exactly what runs_to_columns (kmer.hip) leaves: rel_kmers,
 // rel_counts, a_colptr, a_csc, the CSR sort keys (csr_words, hint bits included) or kid_of_entry — plus the padded column store.
-bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
+static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
 {
-    const int k = c.cfg.k, k2 = 2 * k;
+    const int k = tri ? 17 : c.cfg.k, k2 = 2 * k;
     if (c.opt.kmer_no_msd || c.opt.kmer_pairs || c.opt.kmer_unfused || c.opt.emit_plain || c.opt.kmer_drop) return false;
-    if (k > 31 || c.cfg.upper > 255 || I == 0) return false;
+    if (k > 31 || (!tri && c.cfg.upper > 255) || I == 0) return false;
     // k <= 17: the partition takes all but 16 value bits.  19 <= k <= 31 ("wide", 16-byte records): as many bits as make a bucket of ~1500 instances
-    const bool wide = k2 - VBITS > 2 * MT_MAXBITS;
-    int T = k2 - VBITS;
+    const bool wide = !tri && k2 - VBITS > 2 * MT_MAXBITS;
+    int T = k2 - VBITS, vb = VBITS;      // partitioned bits; value bits below them
     if (wide) {
         T = 12;
         while (T < 2 * W2_MAXBITS && (I >> T) > 512) ++T;      // (a bucket may hold W2_CAP: six times this average — k-mers are not spread evenly over real genomes)
         if (c.opt.msd_wide_bits > 0) T = std::min(std::max(c.opt.msd_wide_bits, 2), 2 * W2_MAXBITS);      // (tests: other splits)
         if (T > k2 - 2) return false;
     }
+    if (tri) {
+        // buckets of ~2048 entries: 2^vb columns of Z / N entries each; at most 2 x 9 partitioned bits
+        if (tri->N < 8 || c.opt.csr_pairs) return false;
+        const int nbc = bits_needed_u((uint64_t)tri->N - 1);
+        const uint64_t avg = (I + (uint64_t)tri->N - 1) / (uint64_t)tri->N;
+        vb = 1;
+        while (vb < 13 && (avg << (vb + 1)) <= 2048) ++vb;
+        if (nbc - vb > 2 * MT_MAXBITS) vb = nbc - 2 * MT_MAXBITS;
+        if (vb > 13 || (avg << vb) > 4096) return false;
+        T = nbc - vb;
+    }
     if (T < 2) return false;
     // worth it from ~1024 instances per bucket on (the bucket kernel pays ~2 us per bucket whatever it holds); smaller inputs keep the sort
     if (!c.opt.kmer_msd && (wide ? I < (1ull << 22) : I < ((uint64_t)1024 << T))) return false;
     const uint32_t maxlen = c.max_read_len;      // (stage_count_kmers' walk over the read lengths)
-    const uint64_t maxpos = maxlen >= (uint32_t)k ? maxlen - (uint32_t)k : 0;
+    const uint64_t maxpos = tri ? tri->maxpos : maxlen >= (uint32_t)k ? maxlen - (uint32_t)k : 0;
+    const int64_t nrows = tri ? tri->M : c.nreads;
+    const uint32_t lower = tri ? 1u : (uint32_t)c.cfg.lower, upper = tri ? 0xFFFFu : (uint32_t)c.cfg.upper;
     MsdParams m{};
     m.k2 = k2; m.b1 = (T + 1) / 2; m.b2 = T - m.b1; m.I = I;
     m.pbits = bits_needed_u(maxpos);
-    const int mb = bits_needed_u((uint64_t)(c.nreads > 0 ? c.nreads - 1 : 0));
+    const int mb = bits_needed_u((uint64_t)(nrows > 0 ? nrows - 1 : 0));
     m.PB = mb + m.pbits;
-    if ((wide ? 0 : m.b2) + VBITS + m.PB > 62) return false;      // (the two top bits of a staged entry carry its hint)
+    if ((wide ? VBITS : tri ? T + vb : m.b2 + VBITS) + m.PB > 62) return false;      // (the two top bits of a staged entry carry its hint)
     // an entry's column rank inside its bucket (< 8192: the emit kernels take no more entries) above the 16 value bits, where there is room for it
     m.rk = (m.PB + VBITS + 13 <= 64 && !c.opt.msd_no_rank) ? m.PB + VBITS : 0;
+    m.rkmask = 0xFFFFFFFFu;
+    if (tri) { m.rk = m.PB; m.rkmask = (1u << vb) - 1u; }      // (the rank of a column inside its bucket = the low bits of its id: every column holds entries, or the matrix is refused below)
     hipStream_t s = c.stream;
     const uint32_t nb1 = 1u << m.b1, nb2 = 1u << m.b2, nbuckets = nb1 * nb2;
     const uint32_t tile = wide ? (uint32_t)W2_TILE : (uint32_t)MT_TILE;
@@ -1366,11 +1453,12 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
 
     c.ws_a.reserve((size_t)(I + 2) * (wide ? 16 : 8)); c.ws_c.reserve((size_t)(I + 2) * (wide ? 16 : 8));
     c.ws_sort.reserve(((size_t)ntiles2 << (wide ? W2_MAXBITS : MT_MAXBITS)) * 4 + 4096);
-    c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 6 + (size_t)(2 * nb1 + 8) * 4 + 256);
+    c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 6 + (size_t)(2 * nb1 + 8) * 4 + 256 + 64);
     uint32_t *hist = c.ws_sort.as<uint32_t>();
     BucketStats *gstat = c.ws_e.as<BucketStats>();
     uint32_t *b2start = c.ws_e.as<uint32_t>() + 16, *bN = b2start + (nbuckets + 2), *bZ = bN + (nbuckets + 2), *kidbase = bZ + (nbuckets + 2), *entbase = kidbase + (nbuckets + 2);
     uint32_t *crowded = entbase + (nbuckets + 2), *b1start = crowded + (nbuckets + 2), *tile0 = b1start + (nb1 + 2);
+    uint32_t *one_seg = tile0 + (nb1 + 2);      // (triples: the whole input as ONE segment of tiles, for the first digit's pass)
     uint64_t *wa = c.ws_a.as<uint64_t>(), *wb = c.ws_c.as<uint64_t>();
 
     c.t_total.start(s);
@@ -1379,9 +1467,9 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     e.packed = c.d_packed; e.byte_off = c.d_byte_off; e.len = c.d_len; e.inst_off = c.inst_off.as<uint64_t>();
     e.nreads = (uint32_t)c.nreads; e.I = I; e.k = k;
     const uint64_t nib = (I >> IB_SHIFT) + 1;
-    c.ws_b.reserve((size_t)(nib + 1) * sizeof(BlockInfo));
+    if (!tri) c.ws_b.reserve((size_t)(nib + 1) * sizeof(BlockInfo));
     const BlockInfo *bi = c.ws_b.as<BlockInfo>();
-    hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
+    if (!tri) hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
     SegTiles sg{b1start, tile0, nb1};
     BucketOut o{};
     const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < 8192u ? (uint32_t)c.opt.msd_small_cap : 8192u;
@@ -1392,13 +1480,27 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k31_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
     if (!wide) {
+    const int shift2 = m.PB + vb;
+    if (tri) {
+        // first digit, from the packed triples: one segment of ntiles1 tiles
+        const uint32_t seg[4] = {0u, (uint32_t)I, 0u, ntiles1};
+        ELBA_HIP(hipMemcpyAsync(one_seg, seg, sizeof(seg), hipMemcpyHostToDevice, s));
+        SegTiles sg1{one_seg, one_seg + 2, 1u};
+        unsigned long long *badctr = reinterpret_cast<unsigned long long *>(one_seg + 4);
+        ELBA_HIP(hipMemsetAsync(badctr, 0, 8, s));
+        hipLaunchKernelGGL(k_pack_triple_msd, dim3((unsigned)((I + 255) / 256)), dim3(256), 0, s, tri->rows, tri->cols, tri->vals, I, tri->M, tri->N, m.pbits, m.PB, wb, badctr);
+        hipLaunchKernelGGL(k_msd_hist2, dim3(ntiles1), dim3(MT_THREADS), 0, s, (const uint64_t *)wb, sg1, shift2 + m.b2, m.b1, hist);
+        radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
+        hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
+        hipLaunchKernelGGL((k_msd_scatter<false>), dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wb, sg1, shift2 + m.b2, m.b1, (const uint32_t *)hist, wa);
+    } else {
     // first digit
     hipLaunchKernelGGL(k_msd_hist1, dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, hist);
     radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
     hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
     hipLaunchKernelGGL((k_msd_scatter<true>), dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa);
+    }
     // second digit, inside every first-digit bucket
-    const int shift2 = m.PB + VBITS;
     hipLaunchKernelGGL(k_msd_hist2, dim3(ntiles2), dim3(MT_THREADS), 0, s, (const uint64_t *)wa, sg, shift2, m.b2, hist);
     hipLaunchKernelGGL(k_msd_segscan, dim3(nb1), dim3(MT_MAXBINS), 0, s, hist, sg, nb2, b2start, I);
     hipLaunchKernelGGL((k_msd_scatter<false>), dim3(ntiles2), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sg, shift2, m.b2, (const uint32_t *)hist, wb);
@@ -1407,9 +1509,12 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     c.t_b.start(s);
     ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
     const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus);
+    if (tri)
+        hipLaunchKernelGGL(k_tri_stats, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 8u)), dim3(256), 0, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m.PB, m.rkmask, small_cap, bN, bZ, gstat);
+    else
     // entries per bucket: up to 4096 -> k_msd_emit_small<16>, up to 8192 -> <32>, beyond -> k_msd_bucket (option "msd_small_cap": tests lower the last bound)
     // (the first pass's words are dead: their buffer takes the entries — the instances of reliable k-mers —, bucket by bucket)
-    hipLaunchKernelGGL(k_msd_count, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, small_cap,
+    hipLaunchKernelGGL(k_msd_count, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap,
                        bN, bZ, gstat, crowded, wa);
     } else {
         // 19 <= k <= 31: 16-byte records (the section above k31_hist1)
@@ -1437,23 +1542,30 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     ELBA_HIP(hipMemcpyAsync(&h2[0], kidbase + nbuckets, 4, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipMemcpyAsync(&h2[1], entbase + nbuckets, 4, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipMemcpyAsync(&hs, gstat, sizeof(hs), hipMemcpyDeviceToHost, s));
+    unsigned long long nbad = 0;
+    if (tri) ELBA_HIP(hipMemcpyAsync(&nbad, one_seg + 4, 8, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
+    ELBA_REQUIRE(nbad == 0, ELBA_ERR_INVALID_ARG, "triple index out of range");
     const uint64_t N = h2[0], Z = h2[1];
     if (wide && hs.ncrowded) {      // a bucket beyond what k31_count sorts in LDS (a repeat family, a homopolymer): the whole input takes the sort of kmer.hip
         if (c.opt.trace) fprintf(stderr, "[elba] count_kmers: %u buckets of the wide partition hold more than %u instances: sorting instead\n", hs.ncrowded, W2_CAP);
         c.t_b.stop(s); c.t_total.stop(s);
         return false;
     }
+    if (tri && (hs.ncrowded || (int64_t)N != tri->N || Z != I)) {      // an empty column (the buckets number the columns they find), a bucket beyond the LDS sort: matrix.hip sorts
+        if (c.opt.trace) fprintf(stderr, "[elba] set_kmer_matrix_device: %llu of %lld columns hold entries, %u crowded buckets: sorting instead\n", (unsigned long long)N, (long long)tri->N, hs.ncrowded);
+        return false;
+    }
     ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
     // buckets: emit
-    c.rel_kmers.reserve((size_t)(N + 1) * 8);
+    if (!tri) c.rel_kmers.reserve((size_t)(N + 1) * 8);
     c.rel_counts.reserve((size_t)(N + 2) * 4);
     c.a_colptr.reserve((size_t)(N + 2) * 4);
     c.a_csc.reserve((size_t)(Z + 8) * 8);
     const int nb = bits_needed_u((uint64_t)(N > 0 ? N - 1 : 0)), pb = m.pbits;
     const bool words = mb + nb + pb + 2 <= 64 && !c.opt.csr_pairs;
     const bool hints = pb <= 30 && !c.opt.no_hints;
-    o.rel_kmers = c.rel_kmers.as<uint64_t>(); o.rel_counts = c.rel_counts.as<uint32_t>(); o.colptr = c.a_colptr.as<uint32_t>();
+    o.rel_kmers = tri ? nullptr : c.rel_kmers.as<uint64_t>(); o.rel_counts = c.rel_counts.as<uint32_t>(); o.colptr = c.a_colptr.as<uint32_t>();
     c.max_col_nnz = (int64_t)hs.maxcol;
     choose_column_store(c, (int64_t)N, c.max_col_nnz);
     // inline partners (Ctx::csr_inline): whole matrix, general (not dense) SpGEMM path with position-carrying accumulators, and a sort word wide
@@ -1507,17 +1619,18 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
         ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 16, s));
         o.slot_cursor = c.ws_scan.as<unsigned long long>(); o.slot_kid = c.ell_slot_kid.as<uint32_t>(); o.compact = 1u;
     }
+    const uint64_t *wrel = tri ? wb : wa;      // (triples: the partitioned words are the entries)
     auto launch_emit = [&]() {
         if (Z == 0) return;
         const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u), cap8 = std::min<uint32_t>(cap16, c.opt.msd_no_emit8 ? 0u : 2048u);
         // (buckets of up to 2048 entries — more than half of them on BASELINE config 3, where a bucket holds 2040 on average — through an instantiation
         //  with 8 entries per lane: half the predicated-off work of the 16-entry one, 26 KB of LDS instead of 49: six workgroups per CU)
-        if (cap8) hipLaunchKernelGGL((k_msd_emit_small<8>), dim3(grid8), dim3(256), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap8,
+        if (cap8) hipLaunchKernelGGL((k_msd_emit_small<8>), dim3(grid8), dim3(256), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap8,
                                      (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
-        if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<16>), dim3(grid16), dim3(256), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
+        if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<16>), dim3(grid16), dim3(256), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
                            (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (small_cap > 4096u && hs.nmid)
-            hipLaunchKernelGGL((k_msd_emit_small<16, 512>), dim3(grid32), dim3(512), 0, s, (const uint64_t *)wa, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
+            hipLaunchKernelGGL((k_msd_emit_small<16, 512>), dim3(grid32), dim3(512), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
                                (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (hs.ncrowded && !wide)
             hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,
@@ -1545,12 +1658,32 @@ bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st)
     } else if (compact) c.ell_nslots = (int64_t)slots[0];      // (an upper bound of the slots in use: chunks are drawn whole)
     c.pre_ready = true; c.pre_consumed = false; c.pre_words = words; c.pre_hints = hints; c.pre_hints_done = hints && words; c.pre_ell_done = true; c.pre_inline_pending = false;
     c.pre_nb = nb; c.pre_pb = pb; c.pre_maxpos = maxpos; c.pre_rs = rs; c.pre_inline = inl; c.pre_pbi = pbi;
+    if (tri) return true;
+    elba_kmer_stats &st = *stp;
     st.instances = (int64_t)I; st.distinct = (int64_t)hs.distinct; st.reliable = (int64_t)N; st.entries = (int64_t)Z;
     st.ms_total = c.t_total.ms(); st.ms_count = c.t_a.ms(); st.ms_sort = c.t_b.ms(); st.ms_lookup = 0;
     c.ndistinct = (int64_t)hs.distinct;
     c.N = (int64_t)N; c.Z = (int64_t)Z;
     c.kmer_path = wide ? 2 : 1;
     return true;
+}
+
+bool msd_count_kmers(Ctx &c, uint64_t I, elba_kmer_stats &st) { return msd_run(c, I, &st, nullptr); }
+
+// (matrix.hip, stage_set_kmer_matrix_device: the triples were checked — indices in range, maxpos = the largest position)
+bool msd_matrix_from_triples(Ctx &c, int64_t M, int64_t N, int64_t Z, const int64_t *d_rows, const int64_t *d_cols, const uint32_t *d_vals)
+{
+    if (M <= 0 || N < 8 || Z <= 0 || c.opt.kmer_no_msd || c.opt.csr_pairs || (!c.opt.kmer_msd && Z < (1ll << 20))) return false;
+    // the largest position decides the layout of a partition word; the indices are checked by the pass that packs them
+    hipStream_t s = c.stream;
+    c.ws_scan.reserve(64);
+    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 8, s));
+    hipLaunchKernelGGL(k_tri_maxpos, dim3((unsigned)std::min<int64_t>((Z + 1023) / 1024, (int64_t)c.num_cus * 16)), dim3(256), 0, s, d_vals, (uint64_t)Z, c.ws_scan.as<unsigned long long>());
+    unsigned long long maxpos = 0;
+    ELBA_HIP(hipMemcpyAsync(&maxpos, c.ws_scan.p, 8, hipMemcpyDeviceToHost, s));
+    ELBA_HIP(hipStreamSynchronize(s));
+    MsdTriples t{M, N, maxpos, d_rows, d_cols, d_vals, 0ull};
+    return msd_run(c, (uint64_t)Z, nullptr, &t);
 }
 
 }  // namespace elba

@@ -543,17 +543,29 @@ void stage_set_kmer_matrix_device(Ctx &c, int64_t M, int64_t N, int64_t Z, const
     ELBA_REQUIRE(M < 0xFFFFFFFFll && N < 0xFFFFFFFFll && Z < 0xFFFFFFFFll, ELBA_ERR_UNSUPPORTED, "matrix dimension beyond 32-bit device indices");
     ELBA_REQUIRE(Z == 0 || (d_rows && d_cols && d_vals), ELBA_ERR_INVALID_ARG, "null triple array");
     hipStream_t s = c.stream;
-    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_b.reserve((size_t)(Z + 1) * 8);
-    c.ws_c.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
-    c.ws_e.reserve((size_t)(Z + 1) * 8); c.ws_f.reserve((size_t)(Z + 1) * 8);
     c.ws_scan.reserve(64);
-    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 16, s));
     const unsigned nbz = (unsigned)((Z + 255) / 256);
+    // Matrices of some size whose columns all hold entries (the reference's A: a reliable k-mer occurs LOWER times at least) go through the k-mer stage's
+    // bucket kernels — two-level partition by column, every bucket of ~256 columns sorted in LDS, columns, hints, inline partners, gather slots and the
+    // CSR build's sort keys written from there (kmer_msd.hip; it checks the indices as it packs them) — instead of seven radix passes over the whole
+    // matrix and a pass per by-product
+    c.triples_path = 0;
+    if (msd_matrix_from_triples(c, M, N, Z, d_rows, d_cols, d_vals)) {
+        c.triples_path = 1;
+        c.A_has_kmers = false;
+        finish_matrix_from_sorted_csc(c, M, N, Z, nullptr, 0, c.a_csc.as<uint64_t>(), 0, -1, true);
+        c.pre_ready = false; c.pre_consumed = true;
+        return;
+    }
+    ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 16, s));
     if (Z > 0) hipLaunchKernelGGL(k_check_triples, dim3(nbz), dim3(256), 0, s, d_rows, d_cols, d_vals, Z, M, N, c.ws_scan.as<unsigned long long>());
     unsigned long long chk[2] = {0, 0};
     ELBA_HIP(hipMemcpyAsync(chk, c.ws_scan.p, 16, hipMemcpyDeviceToHost, s));
     ELBA_HIP(hipStreamSynchronize(s));
     ELBA_REQUIRE(chk[0] == 0, ELBA_ERR_INVALID_ARG, "triple index out of range");
+    c.ws_a.reserve((size_t)(Z + 1) * 8); c.ws_b.reserve((size_t)(Z + 1) * 8);
+    c.ws_c.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
+    c.ws_e.reserve((size_t)(Z + 1) * 8); c.ws_f.reserve((size_t)(Z + 1) * 8);
     // k-mer id, read and position in ONE 64-bit word when they fit (28 + 18 + 14 bits on the 200 k-read set): one sort of 8-byte keys over
     // all their bits instead of three stable sorts of 16-byte (key, value) pairs — 7 passes of ~3 ms instead of 8 of ~7 ms there
     const int mb = bits_for((uint64_t)(M > 0 ? M - 1 : 0)), nb = bits_for((uint64_t)(N > 0 ? N - 1 : 0)), pb = bits_for(chk[1]);

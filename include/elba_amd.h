@@ -320,6 +320,8 @@ int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
  *   "resident_bytes_A"       device bytes the resident k-mer matrix occupies (CSR, columns, padded column store in use, pointers)
  *   "kmer_path"              how the last elba_count_kmers counted: 0 = sort, 1 = two-level value partition + LDS count tables (k <= 17),
  *                            2 = two-level partition of 16-byte records + LDS sort per bucket (19 <= k <= 31)
+ *   "triples_path"           how the last elba_set_kmer_matrix_device built the matrix: 1 = two-level partition by column + the k-mer stage's
+ *                            bucket kernels (matrices of some size whose columns all hold entries), 0 = radix sorts of the whole matrix
  *   "gather_slots"           columns of the padded column store in use (with inline partners: only the columns some row entry still fetches) */
 int  elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value);
 

@@ -480,12 +480,14 @@ def test_dense_columns_take_the_path_of_their_own(knob):
         Z, M, N = int(ms["nnz"]), int(ms["nrows"]), int(ms["ncols"])
         dr = torch.empty(Z, dtype=torch.int64, device="cuda"); dc = torch.empty(Z, dtype=torch.int64, device="cuda"); dv = torch.empty(Z, dtype=torch.int32, device="cuda")
         e.export_triples_device(dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
-        e2 = elba_amd.Engine(17, 2, 40)
-        e2.set_kmer_matrix_device(M, N, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
-        st2 = e2.create_seed_matrix()
-        gu.assert_B_equal(e2.export_csr(), o.B())
-        gu.assert_stats_equal(st2, o)
-        e2.close()
+        for opts in ({"kmer_no_msd": 1}, {"kmer_msd": 1}):            # (through the sorts of matrix.hip / through the k-mer stage's bucket kernels)
+            e2 = elba_amd.Engine(17, 2, 40, options=opts)
+            e2.set_kmer_matrix_device(M, N, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
+            assert e2.get_stat("triples_path") == (1 if "kmer_msd" in opts else 0)
+            st2 = e2.create_seed_matrix()
+            gu.assert_B_equal(e2.export_csr(), o.B())
+            gu.assert_stats_equal(st2, o)
+            e2.close()
     if isinstance(knob, dict):
         e.create_kmer_matrix()                              # (the pairs were consumed: rebuilt from the column pointers)
         e.create_seed_matrix()
@@ -607,11 +609,13 @@ def test_two_level_partition_windows_of_a_crowded_bucket(nreads):
     e.close()
 
 
-@pytest.mark.parametrize("knob", [None, "csr_pairs"])
+@pytest.mark.parametrize("knob", [None, "csr_pairs", "kmer_msd"])
 def test_device_resident_triples_in_any_order(knob):
     """INTEGRATION.md Option B hands A over as COO triples that already sit in HBM (elba_set_kmer_matrix_device).  The triples of a GPU-built A,
-    exported on the device and SHUFFLED, rebuild the same matrix — through the one-word sort (k-mer id | read | position in 64 bits) and, with the
-    option "csr_pairs", through the three stable pair sorts — and B equals the oracle's.  An index out of range is refused."""
+    exported on the device and SHUFFLED, rebuild the same matrix — through the one-word sort (k-mer id | read | position in 64 bits), with the
+    option "csr_pairs" through the three stable pair sorts, and through the k-mer stage's bucket kernels (two-level partition by column: what a
+    matrix of some size takes; "kmer_msd" forces it on this one) — and B equals the oracle's.  An index out of range is refused; a matrix with an
+    empty column keeps the sort (the bucket kernels number the columns they find)."""
     import torch
     packed, off, lens, info = elba_amd.synth_reads(23, 50000, 25, 3000, 700, error_rate=0.10, min_len=200)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
@@ -621,13 +625,27 @@ def test_device_resident_triples_in_any_order(knob):
     e.export_triples_device(dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
     perm = torch.randperm(Z, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
     dr, dc, dv = dr[perm].contiguous(), dc[perm].contiguous(), dv[perm].contiguous()
-    e2 = elba_amd.Engine(17, 2, 8, options={knob: 1} if knob else None)
+    e2 = elba_amd.Engine(17, 2, 8, options={knob: 1} if knob else {"kmer_no_msd": 1})
     m2 = e2.set_kmer_matrix_device(M, N, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
     assert int(m2["nnz"]) == Z
+    assert e2.get_stat("triples_path") == (1 if knob == "kmer_msd" else 0)
     st2 = e2.create_seed_matrix()
     gu.assert_A_equal(e2.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e2.export_csr(), o.B())
     gu.assert_stats_equal(st2, o)
+    if knob == "kmer_msd":
+        assert e2.device_view()["a_csr_format"] == 3      # inline partners, as from the reads
+        # the same triples without the entries of one column: N stays, the column is empty — the sort path builds it, like an engine without the option
+        keep = dc != int(dc[0])
+        r3, c3, v3 = dr[keep].contiguous(), dc[keep].contiguous(), dv[keep].contiguous()
+        e3 = elba_amd.Engine(17, 2, 8, options={"kmer_no_msd": 1})
+        for eng in (e2, e3):
+            eng.set_kmer_matrix_device(M, N, int(r3.numel()), r3.data_ptr(), c3.data_ptr(), v3.data_ptr())
+            eng.create_seed_matrix()
+        assert e2.get_stat("triples_path") == 0
+        gu.assert_A_equal(e2.export_kmer_matrix(), e3.export_kmer_matrix())
+        gu.assert_B_equal(e2.export_csr(), e3.export_csr())
+        e3.close()
     dc[Z // 2] = N                                   # a column that does not exist
     with pytest.raises(Exception):
         e2.set_kmer_matrix_device(M, N, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
