@@ -527,7 +527,7 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         ELBA_REQUIRE(name, ELBA_ERR_INVALID_ARG, "set_option: null name");
         struct { const char *n; bool *b; } flags[] = {
             {"overlap_cold_calls", &c.cold_calls}, {"no_symmetry", &c.opt.no_symmetry}, {"no_ell", &c.opt.no_ell}, {"no_pay", &c.opt.no_pay}, {"mir32", &c.opt.mir32},
-            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_slab", &c.opt.no_slab}, {"no_ell_compact", &c.opt.no_ell_compact}, {"msd_no_emit8", &c.opt.msd_no_emit8}, {"msd_no_rank", &c.opt.msd_no_rank}, {"csr_pairs_late", &c.opt.csr_pairs_late}, {"no_suffix", &c.opt.no_suffix}, {"no_row_order", &c.opt.no_row_order}, {"no_inline", &c.opt.no_inline}, {"panel_inline", &c.opt.panel_inline}, {"kmer_pairs", &c.opt.kmer_pairs},
+            {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_slab", &c.opt.no_slab}, {"no_ell_compact", &c.opt.no_ell_compact}, {"msd_no_emit8", &c.opt.msd_no_emit8}, {"msd_no_rank", &c.opt.msd_no_rank}, {"msd_rank", &c.opt.msd_rank}, {"csr_pairs_late", &c.opt.csr_pairs_late}, {"no_suffix", &c.opt.no_suffix}, {"no_row_order", &c.opt.no_row_order}, {"no_inline", &c.opt.no_inline}, {"panel_inline", &c.opt.panel_inline}, {"kmer_pairs", &c.opt.kmer_pairs},
             {"kmer_unfused", &c.opt.kmer_unfused}, {"kmer_no_msd", &c.opt.kmer_no_msd}, {"kmer_msd", &c.opt.kmer_msd}, {"csr_pairs", &c.opt.csr_pairs}, {"emit_plain", &c.opt.emit_plain}, {"trace", &c.opt.trace}};
         for (auto &f : flags) if (!strcmp(name, f.n)) { *f.b = value != 0; return; }
         if (!strcmp(name, "kmer_drop")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: kmer_drop is 0..3"); c.opt.kmer_drop = (int)value; }

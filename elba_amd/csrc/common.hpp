@@ -140,6 +140,7 @@ struct Options {
     bool no_ell_compact = false;// k-mer stage: the padded column store holds every column, row entries name k-mer ids (no gather slots)
     bool no_slab = false;       // SpGEMM: mirrored entries wait in the staging area for k_mirror instead of going straight to their row's slab (spgemm.hip: "mirror slabs")
     bool csr_pairs_late = false; // dense matrices from the two-level partition: the CSR build's sort pairs written by the CSR build, not by the bucket kernels (A/B)
+    bool msd_rank = false;      // k-mer stage: column ranks whatever UPPER is (tests)
     bool msd_no_rank = false;   // k-mer stage: entries without their column's rank — the emit kernels sort by ranges of the 16 value bits (A/B; what runs when the payload leaves no room)
     bool msd_no_emit8 = false;  // k-mer stage: buckets of up to 2048 entries through the 16-entries-per-lane kernel too (A/B)
     int ell_slot_cap = 0;       // test hook: the padded column store pretends to hold this many gather slots only (0: its real size)

@@ -398,6 +398,7 @@ struct BucketOut {
 // k-mer ids and column pointers), buckets too crowded for the small emit kernel.
 constexpr uint32_t CT_TAB = 32768, CT_BITS = 2048;      // words
 constexpr size_t CT_LDS = (size_t)(CT_TAB + 3 * CT_BITS + 64) * 4;
+template <bool RANK>      // RANK: the entries leave with their column's rank in the bucket (MsdParams::rk) — one more pass over the bucket's instances, which only long columns repay
 __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words, const uint32_t *b2start, uint32_t nbuckets, MsdParams m, uint32_t lower, uint32_t upper, uint32_t small_cap,
                                                          uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint32_t *crowded, uint64_t *wrel)
 {
@@ -451,6 +452,32 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
             atomicAdd(&tab[v >> 1], 1u << ((v & 1u) * 16u));
         });
         lds_sync();
+        if (!RANK) {
+        for_keys([&](uint64_t wd) {
+            const uint32_t v = (uint32_t)(wd >> m.PB) & 0xFFFFu, cnt = tab16[v];
+            atomicOr(&seenbits[v >> 5], 1u << (v & 31u));
+            if (cnt >= lower && cnt <= upper) {
+                atomicOr(&relbits[v >> 5], 1u << (v & 31u));
+                wrel[s0 + atomicAdd(&misc[0], 1u)] = wd;
+            }
+        });
+        lds_sync();
+        uint32_t nrel = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const uint32_t wi = (uint32_t)q * BK_THREADS + tid, mybits = relbits[wi];
+            nrel += (uint32_t)__popc(mybits);
+            st_distinct += (unsigned long long)__popc(seenbits[wi]);
+            for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
+                const uint32_t cnt = tab16[wi * 32u + (uint32_t)__ffs((int)bits) - 1u];
+                st_sumsq += (unsigned long long)cnt * cnt; st_maxcol = cnt > st_maxcol ? cnt : st_maxcol;
+            }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) nrel += __shfl_xor(nrel, d, 64);
+        if (lane == 0 && nrel) atomicAdd(&misc[1], nrel);
+        lds_sync();
+        } else {
         for_keys([&](uint64_t wd) {
             const uint32_t v = (uint32_t)(wd >> m.PB) & 0xFFFFu, cnt = tab16[v];
             atomicOr(&seenbits[v >> 5], 1u << (v & 31u));
@@ -490,6 +517,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
             }
         });
         lds_sync();
+        }
         if (tid == 0) {
             const uint32_t Zb = misc[0], Nb = misc[1];
             bN[b] = Nb; bZ[b] = Zb;
@@ -1443,7 +1471,8 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     m.PB = mb + m.pbits;
     if ((wide ? VBITS : tri ? T + vb : m.b2 + VBITS) + m.PB > 62) return false;      // (the two top bits of a staged entry carry its hint)
     // an entry's column rank inside its bucket (< 8192: the emit kernels take no more entries) above the 16 value bits, where there is room for it
-    m.rk = (m.PB + VBITS + 13 <= 64 && !c.opt.msd_no_rank) ? m.PB + VBITS : 0;
+    // ... and where columns grow long enough for one value to fill a sort range of the emit kernels (UPPER beyond HINT_MAX_COL; the wide path ranks its columns anyway)
+    m.rk = (m.PB + VBITS + 13 <= 64 && !c.opt.msd_no_rank && (wide || tri || upper > HINT_MAX_COL || c.opt.msd_rank)) ? m.PB + VBITS : 0;
     m.rkmask = 0xFFFFFFFFu;
     if (tri) { m.rk = m.PB; m.rkmask = (1u << vb) - 1u; }      // (the rank of a column inside its bucket = the low bits of its id: every column holds entries, or the matrix is refused below)
     hipStream_t s = c.stream;
@@ -1475,7 +1504,8 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < 8192u ? (uint32_t)c.opt.msd_small_cap : 8192u;
     static DeviceOnce attr_once;
     attr_once.run(c.device, [&] {
-        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_count<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_bucket<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k31_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
@@ -1509,13 +1539,15 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     c.t_b.start(s);
     ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
     const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus);
+    // (columns of up to HINT_MAX_COL entries: the value bits spread a bucket's entries evenly over the emit kernels' sort ranges already)
+    const bool rank_pass = m.rk != 0;
     if (tri)
         hipLaunchKernelGGL(k_tri_stats, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 8u)), dim3(256), 0, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m.PB, m.rkmask, small_cap, bN, bZ, gstat);
     else
     // entries per bucket: up to 4096 -> k_msd_emit_small<16>, up to 8192 -> <32>, beyond -> k_msd_bucket (option "msd_small_cap": tests lower the last bound)
     // (the first pass's words are dead: their buffer takes the entries — the instances of reliable k-mers —, bucket by bucket)
-    hipLaunchKernelGGL(k_msd_count, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap,
-                       bN, bZ, gstat, crowded, wa);
+    if (rank_pass) hipLaunchKernelGGL(k_msd_count<true>, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap, bN, bZ, gstat, crowded, wa);
+    else hipLaunchKernelGGL(k_msd_count<false>, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap, bN, bZ, gstat, crowded, wa);
     } else {
         // 19 <= k <= 31: 16-byte records (the section above k31_hist1)
         Rec2 *ra = c.ws_a.as<Rec2>(), *rb = c.ws_c.as<Rec2>();

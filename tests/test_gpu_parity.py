@@ -560,11 +560,12 @@ def test_two_level_partition_kmer_path_equals_the_oracle(k, lo, up, cap):
     e.close()
 
 
-@pytest.mark.parametrize("opts", [{"no_inline": 1}, {"no_symmetry": 1}, {"no_pay": 1}, {"no_ell": 1}, {"mir32": 1}, {"no_sample": 1}, {"no_ell_compact": 1}, {"ell_slot_cap": 100}])
+@pytest.mark.parametrize("opts", [{"no_inline": 1}, {"no_symmetry": 1}, {"no_pay": 1}, {"no_ell": 1}, {"mir32": 1}, {"no_sample": 1}, {"no_ell_compact": 1}, {"ell_slot_cap": 100}, {"msd_rank": 1}])
 def test_inline_partners_against_their_alternatives(opts):
     """The two-level partition path writes the owning row's entry of every two-read column as an inline partner (no column fetch in the
     SpGEMM).  Without them ("no_inline"; both triangles accumulated: every row needs every column), with 32-bit accumulators + look-ups / plain CSC columns (which switch the inline format off), wide staging records, no
-    sampled rows: A, B and the statistics equal the oracle's, on a first, a warm and a cold call."""
+    sampled rows, buckets sorted by (column rank, read) ranges as they are when UPPER allows long columns ("msd_rank"): A, B and the statistics
+    equal the oracle's, on a first, a warm and a cold call."""
     packed, off, lens, info = elba_amd.synth_reads(63, 200000, 16, 3000, 900, error_rate=0.12, min_len=200)
     o = gu.oracle_run(packed, off, lens, 17, 2, 8)
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8, options=dict(opts, kmer_msd=1))
