@@ -14,7 +14,8 @@
 //                   after it the instances sit grouped by their top b1 + b2 = 2k - 16 value bits, 2^(2k-16) buckets;
 //   k_msd_count     one workgroup per bucket: the 16 value bits left index a table of 16-bit counters IN LDS (128 KB): one LDS atomic per
 //                   instance gives the exact counts; the instances of reliable k-mers — the entries of A — are compacted to the front of the bucket;
-//   k_msd_emit_small<8 | 16 | 16, 512>   (buckets of up to 2048 / 4096 / 8192 entries) sort the bucket's entries in LDS by (value, read, pos): columns
+//   k_msd_emit_small<8, 256 | 512 | 1024>   (buckets of up to 2048 / 4096 / 8192 entries: eight per lane) sort the bucket's entries in LDS by (value, read, pos) —
+//                   by ranges of the value bits, or of (the column's rank in the bucket, the read) where UPPER allows long columns (MsdParams::rk) —: columns
 //                   in value order (k-mer id = rank of the value), each ordered by (read, pos); the k-mers, the column pointers,
 //                   the columns, the padded column store the SpGEMM gathers from — for the columns some row entry still fetches only: "gather
 //                   slots", BucketOut —, and the CSR build's sort keys with their ownership hints and inline partners leave from LDS: everything
@@ -1544,7 +1545,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     if (tri)
         hipLaunchKernelGGL(k_tri_stats, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 8u)), dim3(256), 0, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m.PB, m.rkmask, small_cap, bN, bZ, gstat);
     else
-    // entries per bucket: up to 4096 -> k_msd_emit_small<16>, up to 8192 -> <32>, beyond -> k_msd_bucket (option "msd_small_cap": tests lower the last bound)
+    // entries per bucket: up to 2048 / 4096 / 8192 -> k_msd_emit_small on 256 / 512 / 1024 lanes, beyond -> k_msd_bucket (option "msd_small_cap": tests lower the last bound)
     // (the first pass's words are dead: their buffer takes the entries — the instances of reliable k-mers —, bucket by bucket)
     if (rank_pass) hipLaunchKernelGGL(k_msd_count<true>, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap, bN, bZ, gstat, crowded, wa);
     else hipLaunchKernelGGL(k_msd_count<false>, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap, bN, bZ, gstat, crowded, wa);
@@ -1657,12 +1658,16 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u), cap8 = std::min<uint32_t>(cap16, c.opt.msd_no_emit8 ? 0u : 2048u);
         // (buckets of up to 2048 entries — more than half of them on BASELINE config 3, where a bucket holds 2040 on average — through an instantiation
         //  with 8 entries per lane: half the predicated-off work of the 16-entry one, 26 KB of LDS instead of 49: six workgroups per CU)
+        // (512 lanes x 4 for them was measured too: 17.6 against 17.5 ms on config 3, 48.4 against 47.6 ms on the k = 31 workload)
         if (cap8) hipLaunchKernelGGL((k_msd_emit_small<8>), dim3(grid8), dim3(256), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap8,
                                      (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
-        if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<16>), dim3(grid16), dim3(256), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
+        // 2049..4096 entries: 512 lanes x 8 (three workgroups of eight wavefronts per CU, not of four: 19.0 -> 17.5 ms for the bucket kernels on config 3)
+        if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<8, 512>), dim3(grid16), dim3(512), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
                            (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (small_cap > 4096u && hs.nmid)
-            hipLaunchKernelGGL((k_msd_emit_small<16, 512>), dim3(grid32), dim3(512), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
+            // (8192 entries on 1024 lanes x 8: the 99 KB of LDS allow ONE workgroup per CU — sixteen wavefronts hide the barriers better than eight:
+            //  39.7 against 46.8 ms for the bucket kernels on BASELINE config 5 at one GPU's share)
+            hipLaunchKernelGGL((k_msd_emit_small<8, 1024>), dim3(grid32), dim3(1024), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
                                (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (hs.ncrowded && !wide)
             hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,

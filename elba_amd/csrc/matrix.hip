@@ -165,14 +165,15 @@ __global__ void k_max_low32(const uint64_t *v, int64_t n, unsigned long long *ou
 // from kid * Sj — its L entries are the block's last L slots, all ones in front of them.  What a row entry owns (the column behind its own
 // place) is then the tail of the block: one aligned 128-byte segment for every entry but the first ones of columns longer than 33.  Copied
 // from the padded 8-byte store (whatever rotation it carries, k_fill_ell), one lane per 16-byte piece of the output.
-__global__ void k_ell_partners(const uint64_t *ell, const uint32_t *colptr, uint64_t N, uint32_t S, uint32_t jsh, uint32_t *ellj, const uint32_t *label)
+// (ell == null: no rotation — the whole matrix —: the columns themselves, csc, are read instead of the padded store — 8 bytes per entry, not per slot)
+__global__ void k_ell_partners(const uint64_t *ell, const uint64_t *csc, const uint32_t *colptr, uint64_t N, uint32_t S, uint32_t jsh, uint32_t *ellj, const uint32_t *label)
 {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x, nq = N << (jsh - 2u);
     const uint32_t Sj = 1u << jsh;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nq; t += stride) {
         const uint64_t kid = t >> (jsh - 2u);
-        const uint32_t s0 = ((uint32_t)t & ((Sj >> 2) - 1u)) << 2, L = colptr[kid + 1] - colptr[kid];
-        const uint64_t *col = ell + kid * S;
+        const uint32_t c0 = colptr[kid], s0 = ((uint32_t)t & ((Sj >> 2) - 1u)) << 2, L = colptr[kid + 1] - c0;
+        const uint64_t *col = ell ? ell + kid * S : csc + c0;
         uint4 v;
         v.x = s0 + L >= Sj ? (uint32_t)(col[s0 + L - Sj] >> 32) : 0xFFFFFFFFu;
         v.y = s0 + 1u + L >= Sj ? (uint32_t)(col[s0 + 1u + L - Sj] >> 32) : 0xFFFFFFFFu;
@@ -444,7 +445,7 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
     if (c.csr_suffix) {
         const uint64_t nslots = (uint64_t)N << c.j_shift;
         c.a_ellj.reserve((size_t)nslots * 4 + 64);
-        hipLaunchKernelGGL(k_ell_partners, dim3((unsigned)std::min<uint64_t>((nslots / 4 + 255) / 256, 1ull << 20)), dim3(256), 0, s, (const uint64_t *)c.a_ell.as<uint64_t>(), (const uint32_t *)c.a_colptr.as<uint32_t>(), (uint64_t)N, c.s_stride,
+        hipLaunchKernelGGL(k_ell_partners, dim3((unsigned)std::min<uint64_t>((nslots / 4 + 255) / 256, 1ull << 20)), dim3(256), 0, s, windowed ? (const uint64_t *)c.a_ell.as<uint64_t>() : (const uint64_t *)nullptr, (const uint64_t *)c.a_csc.as<uint64_t>(), (const uint32_t *)c.a_colptr.as<uint32_t>(), (uint64_t)N, c.s_stride,
                            c.j_shift, c.a_ellj.as<uint32_t>(), c.have_row_order ? (const uint32_t *)c.row_label.as<uint32_t>() : (const uint32_t *)nullptr);
     }
     c.have_A = true;
