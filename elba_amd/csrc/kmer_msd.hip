@@ -35,11 +35,13 @@ namespace {
 
 #include "kmer_enum.hpp"
 
+// (16384-key tiles, 139 KB of LDS, one workgroup per CU: on 1024 lanes x 16 keys — sixteen wavefronts to hide the barriers — the partition of
+//  config 3 takes 26.4 ms, on 512 x 32 27.6 ms)
 #ifndef ELBA_MT_THREADS
-#define ELBA_MT_THREADS 512
+#define ELBA_MT_THREADS 1024
 #endif
 #ifndef ELBA_MT_ITEMS
-#define ELBA_MT_ITEMS 32
+#define ELBA_MT_ITEMS 16
 #endif
 constexpr int MT_THREADS = ELBA_MT_THREADS, MT_ITEMS = ELBA_MT_ITEMS, MT_TILE = MT_THREADS * MT_ITEMS;      // instances per tile; a wavefront's share is at most one block of the instance -> read table
 constexpr int MT_MAXBITS = 9, MT_MAXBINS = 1 << MT_MAXBITS;
@@ -216,7 +218,7 @@ template <bool ENUM>
 __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const BlockInfo *block_read, MsdParams m, const uint64_t *in, SegTiles sg, int shift, int bits,
                                                            const uint32_t *hist_scanned, uint64_t *out)
 {
-    constexpr int WAVES = MT_THREADS / 64, DPT = MT_MAXBINS / MT_THREADS;
+    constexpr int WAVES = MT_THREADS / 64, DPT = MT_MAXBINS / MT_THREADS > 0 ? MT_MAXBINS / MT_THREADS : 1;
     __shared__ uint32_t lcnt[MT_MAXBINS], lstart[MT_MAXBINS], gbase[MT_MAXBINS], wsum[WAVES];
     __shared__ uint64_t lkey[MT_TILE];
     __shared__ unsigned long long hbits[MT_TILE / 64];
@@ -999,7 +1001,10 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
 #ifndef ELBA_W2_THREADS
 #define ELBA_W2_THREADS 512
 #endif
-constexpr int W2_THREADS = ELBA_W2_THREADS, W2_ITEMS = 16, W2_TILE = W2_THREADS * W2_ITEMS;      // 8192 records of 16 bytes: 128 KB of LDS (runs of 8 records per digit and tile; 4096-record tiles: partition 78 -> 58 ms on 2.0 G instances)
+#ifndef ELBA_W2_ITEMS
+#define ELBA_W2_ITEMS 16
+#endif
+constexpr int W2_THREADS = ELBA_W2_THREADS, W2_ITEMS = ELBA_W2_ITEMS, W2_TILE = W2_THREADS * W2_ITEMS;      // 8192 records of 16 bytes: 128 KB of LDS (runs of 8 records per digit and tile; 4096-record tiles: partition 78 -> 58 ms on 2.0 G instances)
 constexpr int W2_MAXBITS = 10, W2_MAXBINS = 1 << W2_MAXBITS;
 constexpr uint32_t W2_CAP = 4096;                // records of a bucket k31_count takes (eight per lane, in registers)
 constexpr int W2C_THREADS = 512, W2C_KPT = (int)(W2_CAP / W2C_THREADS);
