@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
                 const unsigned long long hk = key[u].hi;
                 uint32_t sl = (((uint32_t)hk ^ (uint32_t)(hk >> 27)) * 0x9E3779B1u) >> 20;      // 12 bits
                 if (__hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u) {      // (the table is filling up: the bucket is given up)
-                    for (uint32_t probes = 0; probes < W2_SLOTS; ++probes) {      // (bounded whatever happens: a full table cannot hang the wavefront)
+                    for (uint32_t probes = 0; probes < W2_SLOTS; ++probes) {      // (bounded whatever happens: a full table cannot hang the wavefront; a plain read in front of the compare-and-swap — most records find their k-mer there — was measured: 44.3 against 42.7 ms for the bucket kernels)
                         const unsigned long long old = atomicCAS(&K[sl], ~0ull, hk);
                         if (old == hk) break;
                         if (old == ~0ull) { if (atomicAdd(&misc[1], 1u) >= W2_DISTINCT_MAX) __hip_atomic_store(&misc[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
@@ -1257,6 +1257,30 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
         }
         lds_sync();
         const uint32_t Nb = misc[0];
+        const bool few = Nb <= W2C_THREADS;
+        uint32_t Zb = 0;
+        if (few) {
+            // ... numbered in value order.  The usual bucket holds a few dozen of them (a HiFi read set: ~1900 records of ~56 genomic k-mers): every lane
+            // sums, over the bucket's reliable k-mers, those below its own and their counts — broadcast reads; no ranges, no scans, five barriers less (bucket kernels of the k = 31 workload: 47.6 -> 42.7 ms).
+            // (The columns' fill counters are then sbcnt[column], zero since the bucket began.)
+            if (tid < Nb) {
+                const uint32_t sl = RL[tid];
+                const unsigned long long mine = K[sl];
+                uint32_t rc = 0, first = 0, tot = 0;
+#pragma unroll 4
+                for (uint32_t x = 0; x < Nb; ++x) {
+                    const uint32_t sx = RL[x], cx = CNT[sx];
+                    const bool below = K[sx] < mine;
+                    rc += below ? 1u : 0u; first += below ? cx : 0u; tot += cx;
+                }
+                RC[sl] = (uint16_t)rc;
+                C[rc] = first;
+                ktmp[s0 + rc] = mine << (64 - k2);
+                if (tid == 0) misc[3] = tot;
+            }
+            lds_sync();
+            Zb = Nb ? misc[3] : 0u;
+        } else {
         // ... numbered in value order: value ranges (monotone in the k-mer, like the buckets), count, scan, scatter, rank inside the range
         int rbits = R < 9 ? R : 9;
         while (rbits > 0 && (Nb >> rbits) < 4u) --rbits;
@@ -1316,7 +1340,8 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             carry += tot;
             lds_sync();
         }
-        const uint32_t Zb = carry;
+        Zb = carry;
+        }
         if (Zb > 8192u) {      // (more kept entries than the emit kernels sort in LDS: given up like a bucket of too many distinct k-mers)
             if (tid == 0) { bN[b] = 0; bZ[b] = 0; atomicAdd(&gstat->ncrowded, 1u); }
             lds_sync();
@@ -1341,7 +1366,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             for (int u = 0; u < W2C_KPT; ++u) {
                 if (key[u].hi != ~0ull) {
                     const uint32_t rc = RC[slot[u]];
-                    if (rc != 0xFFFFu) wrel[s0 + C[rc] + atomicAdd(&CNT[slot[u]], 1u)] = (rk ? (uint64_t)rc << rk : (uint64_t)(rc * vscale) << PB) | key[u].lo;
+                    if (rc != 0xFFFFu) wrel[s0 + C[rc] + atomicAdd(few ? &sbcnt[rc] : &CNT[slot[u]], 1u)] = (rk ? (uint64_t)rc << rk : (uint64_t)(rc * vscale) << PB) | key[u].lo;
                 }
             }
         }
