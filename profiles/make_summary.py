@@ -27,7 +27,7 @@ def main():
     sqd = sys.argv[5] if len(sys.argv) > 5 and sys.argv[5] != "-" else None
     rqd = sys.argv[6] if len(sys.argv) > 6 and sys.argv[6] != "-" else None
     workload = sys.argv[7] if len(sys.argv) > 7 else "200k-long-reads"
-    ks = glob.glob(os.path.join(ktd, "*", "*kernel_stats.csv"))[0]
+    ks = max(glob.glob(os.path.join(ktd, "*", "*kernel_stats.csv")), key=os.path.getmtime)      # (gpurun_out/ keeps earlier runs of the same tag: the newest)
     shutil.copy(ks, os.path.join(HERE, "%s_kernel_stats.csv" % tag))
     rows = list(csv.DictReader(open(ks)))
     stats = {short(r["Name"]): dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3, total_ms=float(r["TotalDurationNs"]) / 1e6) for r in rows}
@@ -38,7 +38,7 @@ def main():
     def pmc(d):
         agg = collections.defaultdict(lambda: collections.defaultdict(float))
         n = collections.Counter()
-        f = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0]
+        f = max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime)
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
