@@ -351,6 +351,7 @@ def main():
         prep = {"spgemm_prep_ms": round(prep_ms, 3), "what": "padded column store + ownership hint bits: k-mer stage with them (%.3f ms) minus without (%.3f ms)" % (t_kmer_wall * 1e3, t_plain * 1e3),
                 "frac_incl_prep": round(my_bytes / ((acc["ms_numeric"] + prep_ms) * 1e-3) / 1e9 / PEAK_GBS, 6) if acc["ms_numeric"] > 0 else None,
                 "frac_whole_region_incl_prep": round(my_bytes / ((acc["ms_total"] + prep_ms) * 1e-3) / 1e9 / PEAK_GBS, 6) if acc["ms_total"] > 0 else None}
+        eng.release_workspace()      # (the timed context's sort / partition scratch — 64 GB on config 3: the second context below decides by the free memory whether its padded column store fits)
         Zt = int(ms["nnz"])
         d_rows = torch.empty(Zt, dtype=torch.int64, device="cuda"); d_cols = torch.empty(Zt, dtype=torch.int64, device="cuda"); d_vals = torch.empty(Zt, dtype=torch.int32, device="cuda")
         eng.export_triples_device(d_rows.data_ptr(), d_cols.data_ptr(), d_vals.data_ptr())
@@ -362,6 +363,7 @@ def main():
         from_triples = {"set_kmer_matrix_device_ms": round(t_set * 1e3, 3), "first_cold_call_ms": round(t_call * 1e3, 3), "ms": round((t_set + t_call) * 1e3, 3),
                         "overlap_nnz_per_s": round(s3["nnz"] / (t_set + t_call), 1), "same_nnz_and_products": bool(s3["nnz"] == st_cold["nnz"] and s3["products"] == st_cold["products"]),
                         "path": "bucket kernels of the k-mer stage" if e3.get_stat("triples_path") == 1 else "radix sorts of the whole matrix",
+                        "padded_columns": bool(e3.get_stat("padded_columns")),
                         "what": "device-resident COO triples of A (int64, int64, uint32) -> CSR + k-mer columns + hints + padded columns, then one cold elba_create_seed_matrix"}
         e3.close()
         del d_rows, d_cols, d_vals

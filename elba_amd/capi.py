@@ -127,7 +127,7 @@ EXPORTED_SYMBOLS = [
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
     "elba_kmer_hash_owner", "elba_dist_value_histogram", "elba_dist_set_owner_ranges", "elba_dist_set_kmer_id_base", "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
     "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_panel_counts_win", "elba_dist_panel_fill_win", "elba_dist_set_panel",
-    "elba_seed_matrix_begin", "elba_seed_matrix_fill", "elba_seed_matrix_end", "elba_set_stream", "elba_seed_matrix_send", "elba_seed_matrix_recv", "elba_set_kmer_matrix_device", "elba_export_triples_device", "elba_get_stat",
+    "elba_seed_matrix_begin", "elba_seed_matrix_fill", "elba_seed_matrix_end", "elba_set_stream", "elba_seed_matrix_send", "elba_seed_matrix_recv", "elba_set_kmer_matrix_device", "elba_export_triples_device", "elba_get_stat", "elba_release_workspace",
 ]
 
 _lib = None
@@ -187,6 +187,7 @@ def load_library():
     L.elba_get_device_view.restype = i32; L.elba_get_device_view.argtypes = [vp, C.POINTER(DeviceView)]
     L.elba_set_option.restype = i32; L.elba_set_option.argtypes = [vp, C.c_char_p, i64]
     L.elba_get_stat.restype = i32; L.elba_get_stat.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.elba_release_workspace.restype = i32; L.elba_release_workspace.argtypes = [vp]
     L.elba_kmer_hash_owner.restype = i32; L.elba_kmer_hash_owner.argtypes = [vp, vp, i64, i32, vp, vp]
     L.elba_synth_num_reads.restype = i64; L.elba_synth_num_reads.argtypes = [C.POINTER(SynthCfg)]
     L.elba_synth_generate.restype = i32; L.elba_synth_generate.argtypes = [C.POINTER(SynthCfg), C.POINTER(SynthReads)]
@@ -318,6 +319,10 @@ class Engine:
         v = C.c_int64(0)
         self._check(self.L.elba_get_stat(self.h, name.encode(), C.byref(v)))
         return int(v.value)
+
+    def release_workspace(self):
+        """the stage calls' scratch memory back to the device; matrices, reads and the multiplication's buffers stay (elba_release_workspace)"""
+        self._check(self.L.elba_release_workspace(self.h))
 
     # --- stages ---
     def count_kmers(self):

@@ -546,6 +546,17 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
     });
 }
 
+int elba_release_workspace(elba_ctx *ctx)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(!c.dist_owner && c.ov_phase == 0, ELBA_ERR_STATE, "release_workspace: the context holds exchanged records or is inside a sharded multiplication");
+        ELBA_HIP(hipStreamSynchronize(c.stream));
+        c.ws_a.release(); c.ws_b.release(); c.ws_c.release(); c.ws_d.release(); c.ws_e.release(); c.ws_f.release(); c.ws_sort.release();
+        c.csr_words.release(); c.kid_of_entry.release();
+        if (c.have_counts) { c.pre_ready = false; c.pre_consumed = true; }    // (the CSR sort keys / column ids of the entries are gone: create_kmer_matrix rebuilds them from the column pointers)
+    });
+}
+
 int elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value)
 {
     return guarded(ctx, [&](Ctx &c) {
@@ -554,6 +565,7 @@ int elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value)
         else if (!strcmp(name, "overlap_slab_q16")) *value = (int64_t)c.ov_slab_q16_used;
         else if (!strcmp(name, "kmer_path")) *value = c.kmer_path;
         else if (!strcmp(name, "triples_path")) *value = c.triples_path;
+        else if (!strcmp(name, "padded_columns")) *value = c.have_A && c.use_ell ? 1 : 0;
         else if (!strcmp(name, "gather_slots")) *value = c.have_A && c.use_ell ? c.ell_nslots : 0;
         else if (!strcmp(name, "resident_bytes_A")) {
             int64_t b = 0;

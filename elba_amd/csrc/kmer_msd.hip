@@ -1485,7 +1485,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         vb = 1;
         while (vb < 13 && (avg << (vb + 1)) <= 2048) ++vb;
         if (nbc - vb > 2 * MT_MAXBITS) vb = nbc - 2 * MT_MAXBITS;
-        if (vb > 13 || (avg << vb) > 4096) return false;
+        if (vb > 13 || (avg << vb) > 6144) return false;      // (a bucket beyond 8192 entries sends the whole matrix to the sort: the average must stay clear of it)
         T = nbc - vb;
     }
     if (T < 2) return false;

@@ -269,6 +269,8 @@ void choose_column_store(Ctx &c, int64_t N, int64_t max_col)
     ELBA_HIP(hipMemGetInfo(&free_b, &total_b));
     const size_t ell_bytes = (size_t)N * stride * 8;
     c.use_ell = mc <= 64 && N > 0 && !c.opt.no_ell && ell_bytes <= (free_b + c.a_ell.cap) / 3 && (uint64_t)N * stride < (1ull << 40);
+    if (!c.use_ell && mc <= 64 && N > 0 && !c.opt.no_ell && c.opt.trace)
+        fprintf(stderr, "[elba] the padded column store (%zu bytes) does not fit a third of the free device memory (%zu bytes): columns are gathered from CSC\n", ell_bytes, free_b + c.a_ell.cap);
     c.ell_compact = false; c.ell_nslots = c.use_ell ? N : 0; c.ell_cap_cols = c.use_ell ? N : 0;      // (kmer_msd.hip may compact the store: gather slots)
     if (c.use_ell) {
         uint32_t lb = 1, fb = 2;

@@ -322,8 +322,19 @@ int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
  *                            2 = two-level partition of 16-byte records + LDS sort per bucket (19 <= k <= 31)
  *   "triples_path"           how the last elba_set_kmer_matrix_device built the matrix: 1 = two-level partition by column + the k-mer stage's
  *                            bucket kernels (matrices of some size whose columns all hold entries), 0 = radix sorts of the whole matrix
+ *   "padded_columns"         1: the resident matrix has its padded column store (what the fast SpGEMM paths gather from); 0: columns longer than 64
+ *                            entries, or the store did not fit a third of the free device memory when the matrix was built
+ *                            (elba_release_workspace on other contexts of the device, then build again)
  *   "gather_slots"           columns of the padded column store in use (with inline partners: only the columns some row entry still fetches) */
 int  elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value);
+
+/* Gives the stage calls' scratch memory back to the device (the sort / partition buffers of elba_count_kmers, elba_create_kmer_matrix and
+ * elba_set_kmer_matrix_device: ~32 bytes per k-mer instance, 64 GB on BASELINE config 3), keeping the resident matrices, the reads and the
+ * buffers of elba_create_seed_matrix.  A caller that builds A once and multiplies many times (or runs a second context beside this one)
+ * calls it after elba_create_kmer_matrix; the next stage call allocates again.  The sort keys elba_count_kmers left for
+ * elba_create_kmer_matrix go with the scratch: a later elba_create_kmer_matrix rebuilds them from the columns.
+ * ELBA_ERR_STATE on a context that counted exchanged records (elba_dist_count_records) or inside a sharded multiplication. */
+int  elba_release_workspace(elba_ctx *ctx);
 
 /* ---- distributed building blocks (one context per rank/GPU; the collectives are issued by the host driver) ----------------
  * They replace, for a 1D read-row partition over the GPUs of one node, what the reference does with MPI inside the same four

@@ -515,11 +515,12 @@ def test_dropped_index_bits_are_recovered_from_the_reads(drop):
     e.close()
 
 
-def test_create_kmer_matrix_twice_after_one_count_gives_the_same_matrices():
+@pytest.mark.parametrize("opts", [None, {"kmer_msd": 1}, {"kmer_unfused": 1}])
+def test_create_kmer_matrix_twice_after_one_count_gives_the_same_matrices(opts):
     """elba_create_kmer_matrix consumes the CSR sort keys the fused column pass left behind (hint bits are ORed into them, the sort
     ping-pongs over them); a second call after ONE elba_count_kmers must rebuild what it needs and give the same A and B."""
     packed, off, lens, info = elba_amd.synth_reads(62, 150000, 14, 3000, 900, error_rate=0.10, min_len=200)
-    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8, options=opts)
     o = gu.oracle_run(packed, off, lens, 17, 2, 8)
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
@@ -528,6 +529,17 @@ def test_create_kmer_matrix_twice_after_one_count_gives_the_same_matrices():
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st2, o)
+    # elba_release_workspace gives the stages' scratch back: the resident matrices multiply as before, and a count whose sort keys went with the
+    # scratch still builds its matrix
+    e.release_workspace()
+    st3 = e.create_seed_matrix()
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st3, o)
+    e.count_kmers(); e.release_workspace(); e.create_kmer_matrix()
+    st4 = e.create_seed_matrix()
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st4, o)
     e.close()
 
 
