@@ -119,6 +119,8 @@ int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, ui
 // The same for bare 64-bit words (whatever rides in the bits outside [bit_lo, bit_hi) moves with them): returns 0 if the result is in k0, 1 if in k1.
 int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done = false);
 int radix_sort_where(int64_t n, int bit_lo, int bit_hi);
+int radix_sort_pairs_k32(hipStream_t s, uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
+void group_offsets_k32(hipStream_t s, const uint32_t *sorted_keys, int64_t n, uint32_t *ptr, int64_t nkeys);
 void radix_column_scan(hipStream_t s, uint32_t *rows, int64_t nrows, uint32_t nbins, DevBuf &tmp);      // (prims.hip)
 uint32_t *radix_first_histogram(int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, int *shift, int *bits, int *tile);      // (prims.hip)
 void fill_u32(hipStream_t s, uint32_t *p, uint32_t v, int64_t n);

@@ -388,7 +388,7 @@ struct BucketOut {
     // BASELINE config 3), 8 S per gathered column now.
     unsigned long long *slot_cursor; uint32_t *slot_kid; uint32_t compact, slot_chunk;      // slot_cursor[1] != 0: a draw ran past slot_cap (nothing was written there; the host emits again without slots)
     unsigned long long slot_cap;
-    uint64_t *pair_key, *pair_val; // dense matrices (Ctx::csr_suffix): the pairs the CSR build sorts by read — read; k-mer id << 32 | column length << 23 | place in the column << 16 | pos — instead of sort words
+    uint32_t *pair_key; uint64_t *pair_val; // dense matrices (Ctx::csr_suffix): the pairs the CSR build sorts by read — read; k-mer id << 32 | column length << 23 | place in the column << 16 | pos — instead of sort words
     const uint64_t *kmer_src;      // k > 17 (k31_count): the bucket's reliable k-mers, left-aligned, at [bucket's first instance + column]; null: the k-mer is bucket << 16 | the entry's 16 value bits
 };
 
@@ -715,7 +715,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 // pair in its own entry — the SpGEMM then fetches no column for it
                 const bool isinl = o.inl && mult == 1u && nown == 1u && ((pos | opos) >> o.inl) == 0;
                 if (isinl) word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
-                if (o.pair_val) { o.pair_key[z] = read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)L << 23) | ((uint64_t)(p - h0) << 16) | pos; }
+                if (o.pair_val) { o.pair_key[z] = (uint32_t)read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)L << 23) | ((uint64_t)(p - h0) << 16) | pos; }
                 else if (o.compact && !isinl && hint == 0) {      // this entry fetches its column: the column needs a gather slot, the key names it (below)
                     needmask |= 1u << u;
                     atomicOr(&H[kl], HNEED);
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                         const uint32_t z = eb + wlo + p, kid = kb + klo + entk[p];
                         const uint32_t id = o.compact && hint == 0 ? wslot + entk[p] : kid;      // (an entry that fetches its column names the column's gather slot)
                         o.csc[z] = (read << 32) | pos;
-                        if (o.pair_val) { const uint32_t kl = entk[p]; o.pair_key[z] = read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)fill[kl] << 23) | ((uint64_t)(p - headpos[kl]) << 16) | pos; }
+                        if (o.pair_val) { const uint32_t kl = entk[p]; o.pair_key[z] = (uint32_t)read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)fill[kl] << 23) | ((uint64_t)(p - headpos[kl]) << 16) | pos; }
                         else if (o.csr_words) o.csr_words[z] = (read << o.rs) | ((uint64_t)id << (o.pb + 2)) | (hint << o.pb) | pos;
                         else o.kid_of_entry[z] = kid;
                     }
@@ -1651,7 +1651,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     c.pre_pairs = pairs;
     if (pairs) {
         c.ws_b.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8); c.a_csr.reserve((size_t)(Z + 1) * 8);      // (ws_b: the enumeration's block table is dead)
-        o.pair_key = c.ws_b.as<uint64_t>();
+        o.pair_key = c.ws_b.as<uint32_t>();
         o.pair_val = radix_sort_where((int64_t)Z, 0, mb) == 0 ? c.a_csr.as<uint64_t>() : c.ws_d.as<uint64_t>();
     }
     else if (words) { c.csr_words.reserve((size_t)(Z + 8) * 8); o.csr_words = c.csr_words.as<uint64_t>(); }

@@ -24,7 +24,7 @@ __device__ __forceinline__ uint32_t entry_hint(const uint32_t *colptr, const uin
     return hints && L <= HINT_MAX_COL ? column_hint(csc + c0, L, i, win_lo, win_hi) : 0u;
 }
 
-__global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, uint64_t kid_mask, const uint32_t *colptr, const uint64_t *csc, int64_t Z, uint64_t *row_keys, uint64_t *csr_vals,
+__global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, uint64_t kid_mask, const uint32_t *colptr, const uint64_t *csc, int64_t Z, uint32_t *row_keys, uint64_t *csr_vals,
                                   bool hints, bool suffix, uint32_t win_lo, uint32_t win_hi, unsigned long long *prod_ctr, const uint8_t *colw0)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -34,7 +34,7 @@ __global__ void k_csc_to_csr_keys(const uint64_t *kid_keys, int kid_shift, uint6
     uint64_t e = csc[z];
     const uint32_t h = entry_hint(colptr, csc, kid, in ? (uint32_t)(e >> 32) : 0xFFFFFFFFu, hints && in, in ? win_lo : 0u, in ? win_hi : 0u, prod_ctr);
     if (!in) return;
-    row_keys[z] = e >> 32;                                   // read
+    row_keys[z] = (uint32_t)(e >> 32);                       // read
     if (suffix) {      // dense matrices (Ctx::csr_suffix): the entry knows its column's length and its own place in it — kid | L << 23 | idx << 16 | pos (16 bits)
         const uint32_t c0 = colptr[kid], L = colptr[kid + 1] - c0;
         uint32_t idx = (uint32_t)z - c0;
@@ -390,7 +390,8 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         // the sorted values are the rows of A: the sort's buffers are handed over so that it ENDS in a_csr (no copy behind it)
         c.ws_b.reserve((size_t)(Z + 1) * 8); c.ws_d.reserve((size_t)(Z + 1) * 8);
         const bool ends_in_second = radix_sort_where(Z, 0, mb) != 0;
-        uint64_t *k0 = pre_pairs ? c.ws_b.as<uint64_t>() : c.ws_a.as<uint64_t>(), *k1 = pre_pairs ? c.ws_a.as<uint64_t>() : c.ws_c.as<uint64_t>();
+        // (row ids as 32-bit keys: 12 bytes per pair and pass)
+        uint32_t *k0 = pre_pairs ? c.ws_b.as<uint32_t>() : c.ws_a.as<uint32_t>(), *k1 = pre_pairs ? c.ws_a.as<uint32_t>() : c.ws_c.as<uint32_t>();
         uint64_t *spare = pre_pairs ? c.ws_d.as<uint64_t>() : c.ws_b.as<uint64_t>();
         uint64_t *v0 = ends_in_second ? spare : c.a_csr.as<uint64_t>(), *v1 = ends_in_second ? c.a_csr.as<uint64_t>() : spare;
         const uint64_t *kk = pre_pairs ? v0 : kid_in_words ? c.csr_words.as<uint64_t>() : kid_keys;      // (pairs that must be written again — a row window rotates the columns —: the k-mer id is the value's upper half)
@@ -402,9 +403,9 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
             hipLaunchKernelGGL(k_csc_to_csr_keys, dim3((unsigned)nbk), dim3(256), 0, s, kk, ks, km, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, k0, v0,
                                hints, c.csr_suffix, wlo, whi, prod_ctr, colw0);
         }
-        const int where = radix_sort_pairs(s, k0, v0, k1, v1, Z, 0, mb, c.ws_sort);
+        const int where = radix_sort_pairs_k32(s, k0, v0, k1, v1, Z, 0, mb, c.ws_sort);
         ELBA_REQUIRE((where != 0) == ends_in_second, ELBA_ERR_INTERNAL, "create_kmer_matrix: the CSR sort ended in the other buffer");
-        group_offsets_u32(s, where ? k1 : k0, 0, Z, c.a_rowptr.as<uint32_t>(), M);
+        group_offsets_k32(s, where ? k1 : k0, Z, c.a_rowptr.as<uint32_t>(), M);
     }
     c.csr_hints = hints;
     {

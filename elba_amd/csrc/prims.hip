@@ -107,7 +107,8 @@ __global__ void k_fill(T *p, T v, int64_t n)
     for (; i < n; i += stride) p[i] = v;
 }
 
-__global__ void k_group_offsets(const uint64_t *keys, int shift, int64_t n, uint32_t *ptr, int64_t nkeys)
+template <class K>
+__global__ void k_group_offsets(const K *keys, int shift, int64_t n, uint32_t *ptr, int64_t nkeys)
 {
     int64_t z = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (z > n) return;
@@ -155,15 +156,15 @@ constexpr int RS_MAXBITS = 9;
 constexpr int RS_MAXBINS = 1 << RS_MAXBITS;
 constexpr int CS_ROWS = 128;           // rows of the histogram one workgroup of the column scan folds
 
-template <int ITEMS>
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const uint64_t *keys, int64_t n, int shift, int bits, uint32_t *hist)
+template <int ITEMS, class K = uint64_t>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const K *keys, int64_t n, int shift, int bits, uint32_t *hist)
 {
     __shared__ uint32_t h[RS_MAXBINS];
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
     for (uint32_t i = threadIdx.x; i < nbins; i += RS_THREADS) h[i] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * (RS_THREADS * ITEMS);
-    uint64_t k[ITEMS];
+    K k[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
         const int64_t idx = base + r * RS_THREADS + threadIdx.x;
@@ -241,15 +242,16 @@ size_t column_scan_tmp_elems(int64_t nrows, uint32_t nbins)
     return tot + 64;
 }
 
-template <bool HAS_VAL, int THREADS, int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint64_t *keys_in, const uint64_t *vals_in, uint64_t *keys_out, uint64_t *vals_out,
+template <bool HAS_VAL, int THREADS, int ITEMS, class K = uint64_t>
+__global__ __launch_bounds__(THREADS) void k_rs_scatter(const K *keys_in, const uint64_t *vals_in, K *keys_out, uint64_t *vals_out,
                                                         int64_t n, int shift, int bits, const uint32_t *hist_scanned)
 {
     constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DPT = RS_MAXBINS / THREADS;      // digits per thread in the per-digit step
     static_assert(DPT >= 1 && ITEMS * 64 < 65536, "one thread per digit at least; a wave's count of a digit fits 16 bits");
     __shared__ uint16_t whist[WAVES][RS_MAXBINS];
     __shared__ uint32_t lstart[RS_MAXBINS], gbase[RS_MAXBINS], wsum[WAVES];
-    __shared__ uint64_t lkey[TILE], lval[HAS_VAL ? TILE : 1];
+    __shared__ K lkey[TILE];
+    __shared__ uint64_t lval[HAS_VAL ? TILE : 1];
     volatile uint16_t(*vh)[RS_MAXBINS] = whist;
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
     for (int i = threadIdx.x; i < WAVES * RS_MAXBINS / 2; i += THREADS) reinterpret_cast<uint32_t *>(&whist[0][0])[i] = 0;
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint64_t *keys_in,
     // a wave owns ITEMS*64 CONSECUTIVE items of the tile so that tile order == (wave, round, lane) order: stability
     const int64_t tbase = (int64_t)blockIdx.x * TILE;
     const int64_t wbase = tbase + (int64_t)w * (ITEMS * 64);
-    uint64_t key[ITEMS];
+    K key[ITEMS];
     uint32_t rank[ITEMS];
 #pragma unroll
     for (int r = 0; r < ITEMS; ++r) {
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter(const uint64_t *keys_in,
     const int64_t left = n - tbase;
     const uint32_t nvalid = left < (int64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
     for (uint32_t t = threadIdx.x; t < nvalid; t += THREADS) {
-        const uint64_t k = lkey[t];
+        const K k = lkey[t];
         const uint32_t d = (uint32_t)(k >> shift) & dmask;
         const uint32_t dst = gbase[d] + (t - lstart[d]);
         keys_out[dst] = k;
@@ -375,7 +377,13 @@ void fill_u64(hipStream_t s, uint64_t *p, uint64_t v, int64_t n)
 void group_offsets_u32(hipStream_t s, const uint64_t *sorted_keys, int key_shift, int64_t n, uint32_t *ptr, int64_t nkeys)
 {
     int64_t nb = (n + 1 + 255) / 256;
-    hipLaunchKernelGGL(k_group_offsets, dim3((unsigned)nb), dim3(256), 0, s, sorted_keys, key_shift, n, ptr, nkeys);
+    hipLaunchKernelGGL(k_group_offsets<uint64_t>, dim3((unsigned)nb), dim3(256), 0, s, sorted_keys, key_shift, n, ptr, nkeys);
+}
+
+void group_offsets_k32(hipStream_t s, const uint32_t *sorted_keys, int64_t n, uint32_t *ptr, int64_t nkeys)
+{
+    int64_t nb = (n + 1 + 255) / 256;
+    hipLaunchKernelGGL(k_group_offsets<uint32_t>, dim3((unsigned)nb), dim3(256), 0, s, sorted_keys, 0, n, ptr, nkeys);
 }
 
 uint64_t reduce_max_u64(hipStream_t s, const uint64_t *p, int64_t n, DevBuf &tmp)
@@ -404,8 +412,8 @@ static int radix_digits(int bit_lo, int bit_hi, int *shift, int *bits)
     return npass;
 }
 
-template <bool HAS_VAL>
-static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done)
+template <bool HAS_VAL, class K = uint64_t>
+static int radix_sort_impl(hipStream_t s, K *k0, uint64_t *v0, K *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done)
 {
     if (n <= 1 || bit_hi <= bit_lo) return 0;
     ELBA_REQUIRE(n < (int64_t)0xFFFFFFFFLL, ELBA_ERR_UNSUPPORTED, "radix sort of >= 2^32 items");
@@ -418,17 +426,17 @@ static int radix_sort_impl(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *
     tmp.reserve((hist_elems + column_scan_tmp_elems((int64_t)nblocks, RS_MAXBINS)) * sizeof(uint32_t));      // (never reallocates behind radix_first_histogram: same size)
     uint32_t *hist = tmp.as<uint32_t>(), *scan_tmp = hist + hist_elems;
     int cur = 0;
-    uint64_t *ki = k0, *vi = v0, *ko = k1, *vo = v1;
+    K *ki = k0, *ko = k1;
+    uint64_t *vi = v0, *vo = v1;
     for (int q = 0; q < npass; ++q) {
         const int shift = shifts[q], bits = widths[q];
         const uint32_t nbins = 1u << bits;
         if (q > 0 || !first_hist_done)
-            hipLaunchKernelGGL((k_rs_hist<ITEMS>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const uint64_t *)ki, n, shift, bits, hist);
+            hipLaunchKernelGGL((k_rs_hist<ITEMS, K>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const K *)ki, n, shift, bits, hist);
         column_scan(s, hist, (int64_t)nblocks, nbins, scan_tmp);
-        hipLaunchKernelGGL((k_rs_scatter<HAS_VAL, STHREADS, TILE / STHREADS>), dim3(nblocks), dim3(STHREADS), 0, s, (const uint64_t *)ki, (const uint64_t *)vi, ko, vo, n, shift, bits, (const uint32_t *)hist);
-        uint64_t *t;
-        t = ki; ki = ko; ko = t;
-        t = vi; vi = vo; vo = t;
+        hipLaunchKernelGGL((k_rs_scatter<HAS_VAL, STHREADS, TILE / STHREADS, K>), dim3(nblocks), dim3(STHREADS), 0, s, (const K *)ki, (const uint64_t *)vi, ko, vo, n, shift, bits, (const uint32_t *)hist);
+        { K *t = ki; ki = ko; ko = t; }
+        { uint64_t *t = vi; vi = vo; vo = t; }
         cur ^= 1;
     }
     return cur;
@@ -470,6 +478,12 @@ int radix_sort_where(int64_t n, int bit_lo, int bit_hi)
 int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
 {
     return radix_sort_impl<true>(s, k0, v0, k1, v1, n, bit_lo, bit_hi, tmp, false);
+}
+
+// (32-bit keys — row ids — with 64-bit values: 12 bytes per pair and pass instead of 16: the dense matrices' CSR build)
+int radix_sort_pairs_k32(hipStream_t s, uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp)
+{
+    return radix_sort_impl<true, uint32_t>(s, k0, v0, k1, v1, n, bit_lo, bit_hi, tmp, false);
 }
 
 int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done)
