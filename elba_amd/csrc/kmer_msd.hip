@@ -1489,8 +1489,9 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         T = nbc - vb;
     }
     if (T < 2) return false;
-    // worth it from ~1024 instances per bucket on (the bucket kernel pays ~2 us per bucket whatever it holds); smaller inputs keep the sort
-    if (!c.opt.kmer_msd && (wide ? I < (1ull << 22) : I < ((uint64_t)1024 << T))) return false;
+    // worth it from ~512 instances per bucket on (the bucket kernels pay a few us per bucket whatever it holds: BASELINE config 2 — 530 per bucket — 6.9 ms
+    // here, 7.1 ms through the sort); smaller inputs keep the sort
+    if (!c.opt.kmer_msd && (wide ? I < (1ull << 22) : I < ((uint64_t)512 << T))) return false;
     const uint32_t maxlen = c.max_read_len;      // (stage_count_kmers' walk over the read lengths)
     const uint64_t maxpos = tri ? tri->maxpos : maxlen >= (uint32_t)k ? maxlen - (uint32_t)k : 0;
     const int64_t nrows = tri ? tri->M : c.nreads;
