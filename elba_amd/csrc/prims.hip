@@ -146,7 +146,7 @@ __global__ void k_reduce_max(const uint64_t *p, int64_t n, unsigned long long *o
 #define ELBA_RS_SCATTER_THREADS 256
 #endif
 #ifndef ELBA_RS_PAIR_ITEMS
-#define ELBA_RS_PAIR_ITEMS 16
+#define ELBA_RS_PAIR_ITEMS 32
 #endif
 #ifndef ELBA_RS_KEY_ITEMS
 #define ELBA_RS_KEY_ITEMS 32
@@ -246,8 +246,8 @@ template <bool HAS_VAL, int THREADS, int ITEMS, class K = uint64_t>
 __global__ __launch_bounds__(THREADS) void k_rs_scatter(const K *keys_in, const uint64_t *vals_in, K *keys_out, uint64_t *vals_out,
                                                         int64_t n, int shift, int bits, const uint32_t *hist_scanned)
 {
-    constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DPT = RS_MAXBINS / THREADS;      // digits per thread in the per-digit step
-    static_assert(DPT >= 1 && ITEMS * 64 < 65536, "one thread per digit at least; a wave's count of a digit fits 16 bits");
+    constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DPT = RS_MAXBINS / THREADS > 0 ? RS_MAXBINS / THREADS : 1;      // digits per thread in the per-digit step (more threads than digits: the others idle there)
+    static_assert(ITEMS * 64 < 65536, "a wave's count of a digit fits 16 bits");
     __shared__ uint16_t whist[WAVES][RS_MAXBINS];
     __shared__ uint32_t lstart[RS_MAXBINS], gbase[RS_MAXBINS], wsum[WAVES];
     __shared__ K lkey[TILE];
@@ -418,7 +418,12 @@ static int radix_sort_impl(hipStream_t s, K *k0, uint64_t *v0, K *k1, uint64_t *
     if (n <= 1 || bit_hi <= bit_lo) return 0;
     ELBA_REQUIRE(n < (int64_t)0xFFFFFFFFLL, ELBA_ERR_UNSUPPORTED, "radix sort of >= 2^32 items");
     constexpr int ITEMS = HAS_VAL ? ELBA_RS_PAIR_ITEMS : ELBA_RS_KEY_ITEMS, TILE = RS_THREADS * ITEMS;
-    constexpr int STHREADS = HAS_VAL ? RS_THREADS : ELBA_RS_SCATTER_THREADS;      // the scatter's workgroup (512 threads on the same 8192-key tile were measured: 14.1-14.9 ms per pass against 10.8-13.7)
+    // (pairs: 8192-pair tiles on 1024 lanes x 8 — the CSR build of the k = 31 workload 34.1 -> 27.0 ms against 4096-pair tiles on 256 x 16; keys alone
+    //  stay on 256 x 32: 10.0 against 10.6 ms on 1024 x 8)
+#ifndef ELBA_RS_PAIR_THREADS
+#define ELBA_RS_PAIR_THREADS 1024
+#endif
+    constexpr int STHREADS = HAS_VAL ? ELBA_RS_PAIR_THREADS : ELBA_RS_SCATTER_THREADS;      // the scatter's workgroup (512 threads on the same 8192-key tile were measured: 14.1-14.9 ms per pass against 10.8-13.7)
     int shifts[64], widths[64];
     const int npass = radix_digits(bit_lo, bit_hi, shifts, widths);
     const uint32_t nblocks = (uint32_t)((n + TILE - 1) / TILE);
