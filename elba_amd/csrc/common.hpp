@@ -144,7 +144,7 @@ struct Options {
     bool csr_pairs_late = false; // dense matrices from the two-level partition: the CSR build's sort pairs written by the CSR build, not by the bucket kernels (A/B)
     bool msd_rank = false;      // k-mer stage: column ranks whatever UPPER is (tests)
     bool msd_no_rank = false;   // k-mer stage: entries without their column's rank — the emit kernels sort by ranges of the 16 value bits (A/B; what runs when the payload leaves no room)
-    bool msd_no_emit8 = false;  // k-mer stage: buckets of up to 2048 entries through the 16-entries-per-lane kernel too (A/B)
+    bool msd_no_emit8 = false;  // k-mer stage: buckets of up to 2048 entries through the 512-lane emit kernel too (A/B)
     int ell_slot_cap = 0;       // test hook: the padded column store pretends to hold this many gather slots only (0: its real size)
     int slab_pct = 175;         // SpGEMM: a row's slab holds this many percent of the mirrored entries the measured ratio predicts for it (+ SLAB_PAD)
     int slab_q16 = 0;           // test hook: slab entries per row entry of A in 1/65536 units, instead of the measured ratio (small matrices take no sample)

@@ -547,11 +547,11 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
 // sort (the 16 value bits are spread evenly over a bucket: ~Z/8 equal value ranges, count, scan, scatter, then every entry ranks itself among
 // the handful that share its range).  A run of equal values is a column: its number (k-mer id = rank of the value) is the
 // number of run heads before it, its pointer the head's place.  Everything the sort path's k_runs_emit / k_add_hints / k_fill_ell produce
-// leaves from here as coalesced streams.  256 lanes, 44 KB of LDS: three workgroups per CU hide one another's barriers and memory waits.
-// <16>: up to 4096 entries, three workgroups per CU; <32>: up to 8192 (the canonical k-mer is the smaller of two: low values are twice as dense as
-// the average, and the fullest buckets of a large input land here), one workgroup per CU.
-// <32, 256> (8192 entries on 256 lanes: 256 VGPRs, 95 KB of LDS, ONE workgroup of four wavefronts per CU) took 85 ms on BASELINE config 5 at one GPU's
-// share, where the average bucket holds 4400 entries: the widest buckets now run on 512 lanes, 16 entries each (<16, 512>: eight wavefronts per CU)
+// leaves from here as coalesced streams.  Eight entries per lane; instantiated on 256 lanes (buckets of up to 2048 entries: 27 KB of LDS, five
+// workgroups per CU), 512 (up to 4096: 50 KB, three) and 1024 (up to 8192 — the canonical k-mer is the smaller of two: low values are twice as
+// dense as the average, and the fullest buckets of a large input, or most buckets of deep low-error coverage, land here —: 99 KB, one workgroup of
+// sixteen wavefronts).  History of the widest class on BASELINE config 5 at one GPU's share (average bucket 4400 entries): 256 lanes x 32 entries
+// (256 VGPRs, four wavefronts per CU) 85 ms; 512 x 16 44 ms; with ranges by column rank 20 ms; 1024 x 8 13 ms.
 template <int ES_KPT, int ES_THREADS = 256>
 __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *wrel, const uint32_t *b2start, const uint32_t *bZ, uint32_t nbuckets, MsdParams m, uint32_t cap_lo, uint32_t cap_hi,
                                                               const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)

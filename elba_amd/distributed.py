@@ -303,13 +303,14 @@ class DistributedOverlap:
         """Synthetic shard: rank r generates reads [bounds[r], bounds[r+1]) of one read set drawn from a genome that grows with the
         world size (weak scaling: per-GPU reads fixed)."""
         genome = w["genome"] * (self.world if weak else 1)
-        cfg = capi.SynthCfg(w["seed"], genome, w["depth"], w["avg_len"], w["sd_len"], w["min_len"], w["error"], 0, 0.0, 0, 0, -1)
+        rep = w.get("repeats", (0, 0.0, 0))      # (families, fraction of the genome, length: the dense workloads — the same read set as the one-GPU run's)
+        cfg = capi.SynthCfg(w["seed"], genome, w["depth"], w["avg_len"], w["sd_len"], w["min_len"], w["error"], rep[0], rep[1], rep[2], 0, -1)
         total = int(capi.load_library().elba_synth_num_reads(C.byref(cfg)))
         per = (total + self.world - 1) // self.world
         bounds = np.minimum(np.arange(self.world + 1, dtype=np.int64) * per, total)
         lo, hi = int(bounds[self.rank]), int(bounds[self.rank + 1])
         packed, off, lens, info = capi.synth_reads(w["seed"], genome, w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"],
-                                                   first_read=lo, num_reads=hi - lo)
+                                                   repeat_families=rep[0], repeat_fraction=rep[1], repeat_len=rep[2], first_read=lo, num_reads=hi - lo)
         self.set_reads(packed, off, lens, lo, bounds)
         info["total_reads"] = total
         return info

@@ -603,7 +603,7 @@ def test_inline_partners_against_their_alternatives(opts):
 def test_two_level_partition_windows_of_a_crowded_bucket(nreads):
     """A genome of few distinct k-mers at high depth: single buckets of the two-level partition hold thousands of reliable columns and, with
     1500 reads, tens of thousands of entries — more than one staging window per bucket half (kmer_msd.hip: EW), instances beyond what a
-    workgroup keeps in registers (k_msd_bucket); with 500 reads 4-8 thousand entries: the wide instantiation of the LDS sort (k_msd_emit_small<32>)."""
+    workgroup keeps in registers (k_msd_bucket); with 500 reads 4-8 thousand entries: the widest instantiation of the LDS sort (k_msd_emit_small on 1024 lanes)."""
     rng = np.random.default_rng(11)
     unit = bytes(rng.choice(list(b"ACGT"), 24).tolist())
     seqs = []
