@@ -222,3 +222,31 @@ def test_multi_word_kmers_through_the_exchange(k):
     assert o.stat("Y") > 50
     assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
     assert sum(p[1]["reliable"] for p in parts) == o.stat("N") and sum(p[1]["entries"] for p in parts) == o.stat("Z")
+
+
+def test_the_ranks_generate_shares_of_the_one_process_read_set_repeat_families_included():
+    """bench.py --gpus N: rank r generates reads [bounds[r], bounds[r+1]) of the workload's read set (DistributedOverlap.generate_and_set_reads).
+    The shares, concatenated, are the read set the one-GPU run generates — with the repeat families of the dense workloads (round 4: they
+    were dropped, the N > 1 run of a dense workload built another read set and its self-validating counts said so)."""
+    w = dict(seed=4, genome=60000, depth=12.0, avg_len=2000.0, sd_len=300.0, min_len=500, error=0.01, repeats=(3, 0.1, 400))
+    packed, off, lens, _ = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"],
+                                                repeat_families=3, repeat_fraction=0.1, repeat_len=400)
+    plain = elba_amd.synth_reads(w["seed"], w["genome"], w["depth"], w["avg_len"], w["sd_len"], error_rate=w["error"], min_len=w["min_len"])
+    assert not (len(plain[0]) == len(packed) and (plain[0] == packed).all())          # (the families change the reads)
+
+    class Capture:
+        """a backend that only keeps what set_reads hands it"""
+        def set_reads(self, p, o, l, first):
+            self.got = (np.array(p), np.array(o), np.array(l), first)
+
+    seqs = []
+    for rank in range(3):
+        d = DistributedOverlap(K, LO, UP, rank=rank, world=3, dist=None, backend=Capture())
+        info = d.generate_and_set_reads(w, weak=False)
+        assert info["total_reads"] == len(lens)
+        p, o, l, first = d.be.got
+        assert first == int(d.bounds[rank])
+        for i in range(len(l)):
+            seqs.append(bytes(p[int(o[i]):int(o[i]) + (int(l[i]) + 3) // 4]))
+    whole = [bytes(packed[int(off[i]):int(off[i]) + (int(lens[i]) + 3) // 4]) for i in range(len(lens))]
+    assert seqs == whole
