@@ -316,7 +316,9 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             };
 #pragma unroll 1
             for (uint32_t cit = 0;; ++cit) {
-                // (chunks of 64 row entries are drawn from a counter of the row, as on the general path: the numbers of candidates per chunk differ)
+                // (chunks of 64 row entries are drawn from a counter of the row, as on the general path: the numbers of candidates per chunk differ.
+                //  Drawing and requesting the NEXT chunk before this one is walked was measured on config 5 at 1/25: 9.50 against 9.51 ms, two more
+                //  spilled registers — the path is bound by its LDS accesses, profiles/r04_notes.md)
                 uint32_t cdraw = 0;
                 if (lane == 0) { const uint32_t a14 = (uint32_t)(uintptr_t)&misc[14], step = 64u; asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(cdraw) : "v"(a14), "v"(step) : "memory"); }
                 const uint32_t cbase = sfirst(cdraw);
@@ -423,6 +425,11 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             uint32_t fh = 0, ft = 0;                                      // FIFO positions (uniform)
             uint2 ea, eb;
             uint32_t ca, cb;                                              // the two chunks on their way (first row entry, or NONE)
+#ifndef ELBA_CHUNKS
+#define ELBA_CHUNKS 3
+#endif
+            constexpr int XC = ELBA_CHUNKS - 2;                           // further chunks requested ahead: THREE in flight in all (numeric 6.75 -> 6.65 ms against two; four and six: no better)
+            uint2 ex[XC > 0 ? XC : 1]; uint32_t cx[XC > 0 ? XC : 1];
             auto load_chunk = [&](uint2 &en, uint32_t &cbase) {
                 // chunks are DRAWN, not dealt: a wavefront whose chunks held few products takes more of them (sequence numbers are the entries' ranks
                 // in the row and the accumulators are order-free: who processes a chunk does not matter; misc[14] is zeroed with the row's other words): 7.26 -> 7.13 ms
@@ -464,7 +471,12 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 }
                 ft += (uint32_t)__popcll(mn);
                 ea = eb; ca = cb;
-                load_chunk(eb, cb);
+                if (XC > 0) {
+                    eb = ex[0]; cb = cx[0];
+#pragma unroll
+                    for (int q = 0; q + 1 < XC; ++q) { ex[q] = ex[q + 1]; cx[q] = cx[q + 1]; }
+                    load_chunk(ex[XC > 0 ? XC - 1 : 0], cx[XC > 0 ? XC - 1 : 0]);
+                } else load_chunk(eb, cb);
             };
             auto issue = [&](uint4 *x, uint32_t *pq, uint32_t *rk) {      // the next TR trips leave the FIFO: their column words are requested
 #pragma unroll
@@ -481,6 +493,8 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 fh += n < (uint32_t)TR * EW ? n : (uint32_t)TR * EW;
             };
             load_chunk(ea, ca); load_chunk(eb, cb);
+#pragma unroll
+            for (int q = 0; q < XC; ++q) load_chunk(ex[q], cx[q]);
             if (ca != NONE) consume();
             if (ca != NONE && ft - fh <= 64u) consume();
             uint4 x_cur[TR];
