@@ -109,3 +109,44 @@ def test_short_rows_many_cold_calls_agree_with_the_oracle():
             gu.assert_B_equal(e.export_csr(), oB)
         st = e.create_seed_matrix()
     e.close()
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_random_device_triples_through_the_bucket_kernels(case):
+    """elba_set_kmer_matrix_device, both ways: the k-mer stage's bucket kernels (two-level partition by column; "kmer_msd" forces them on a
+    matrix this small) against the radix sorts of the whole matrix ("kmer_no_msd") and the oracle.  Shuffled triples; columns of 1 .. 40 entries
+    (short ones: hints + inline partners; long ones: the dense path's pairs); reads that hold a k-mer twice; positions up to 14, 16 and 18 bits;
+    column counts that are no multiple of a bucket; every column holds an entry (else the bucket path hands over to the sorts: the other test)."""
+    import torch
+    rng = np.random.default_rng(7000 + case)
+    M = int(rng.choice([64, 300, 3000, 40000]))
+    ncol = int(rng.choice([37, 500, 4097, 30011, 100003]))
+    maxlen = int(rng.choice([2, 3, 8, 12, 20, 40]))
+    maxpos = int(rng.choice([5000, 16383, 65535, 200000]))
+    hot = rng.choice(M, min(M, int(rng.choice([3, 40, 500, 4000]))), replace=False)
+    lens = rng.integers(1, maxlen + 1, ncol)
+    cols = np.repeat(np.arange(ncol, dtype=np.int64), lens)
+    rows = hot[rng.integers(0, len(hot), len(cols))].astype(np.int64)
+    vals = rng.integers(0, maxpos + 1, len(cols)).astype(np.uint32)
+    key = np.unique(np.stack([cols, rows, vals.astype(np.int64)], axis=1), axis=0)      # (a read holds a k-mer at a position once)
+    cols, rows, vals = key[:, 0].copy(), key[:, 1].copy(), key[:, 2].astype(np.uint32)
+    assert len(np.unique(cols)) == ncol
+    Z = len(cols)
+    up = max(2, maxlen)
+    o = po.Oracle(17, 2, up)
+    o.set_triples(M, ncol, rows, cols, vals)
+    o.spgemm(8)
+    perm = rng.permutation(Z)
+    dr = torch.from_numpy(rows[perm]).cuda(); dc = torch.from_numpy(cols[perm]).cuda(); dv = torch.from_numpy(vals[perm].view(np.int32)).cuda()
+    out = {}
+    for name, opts in (("buckets", {"kmer_msd": 1}), ("sorts", {"kmer_no_msd": 1})):
+        e = elba_amd.Engine(17, 2, up, options=opts)
+        e.set_kmer_matrix_device(M, ncol, Z, dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
+        took_buckets = e.get_stat("triples_path") == 1
+        assert took_buckets == (name == "buckets") or (name == "buckets" and Z < 16384), (name, took_buckets, Z)      # (a matrix that fits a bucket or two: nothing to partition)
+        st = e.create_seed_matrix()
+        gu.assert_B_equal(e.export_csr(), o.B())
+        gu.assert_stats_equal(st, o)
+        out[name] = e.export_kmer_matrix()
+        e.close()
+    gu.assert_A_equal(out["buckets"], out["sorts"])
