@@ -371,7 +371,8 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
 // LDS-only workgroup barrier: the global stores of a bucket (never read back by the workgroup) stay in flight
 __device__ __forceinline__ void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct BucketStats { unsigned long long distinct, sumsq; unsigned int maxcol, ncrowded, nmid, pad; };
+struct BucketStats { unsigned long long distinct, sumsq; unsigned int maxcol, ncrowded, nmid, nbig; };      // nmid / nbig: buckets of 4097..8192 / 8193..ES_CAP_MAX entries
+constexpr uint32_t ES_CAP_MAX = 12288;      // entries of a bucket the widest emit kernel sorts in LDS
 struct BucketOut {
     uint64_t *rel_kmers; uint32_t *rel_counts, *colptr;
     uint64_t *csc, *csr_words, *kid_of_entry, *ell;
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
             const uint32_t Zb = misc[0], Nb = misc[1];
             bN[b] = Nb; bZ[b] = Zb;
             if (Zb > small_cap) crowded[atomicAdd(&gstat->ncrowded, 1u)] = b;
+            else if (Zb > 8192u) atomicAdd(&gstat->nbig, 1u);
             else if (Zb > 4096u) atomicAdd(&gstat->nmid, 1u);
         }
         lds_sync();                               // (misc is zeroed for the next bucket)
@@ -1342,7 +1344,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
         }
         Zb = carry;
         }
-        if (Zb > 8192u) {      // (more kept entries than the emit kernels sort in LDS: given up like a bucket of too many distinct k-mers)
+        if (Zb > ES_CAP_MAX) {      // (more kept entries than the emit kernels sort in LDS: given up like a bucket of too many distinct k-mers)
             if (tid == 0) { bN[b] = 0; bZ[b] = 0; atomicAdd(&gstat->ncrowded, 1u); }
             lds_sync();
             continue;
@@ -1370,7 +1372,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
                 }
             }
         }
-        if (tid == 0) { bN[b] = Nb; bZ[b] = Zb; if (Zb > 4096u) atomicAdd(&gstat->nmid, 1u); }
+        if (tid == 0) { bN[b] = Nb; bZ[b] = Zb; if (Zb > 8192u) atomicAdd(&gstat->nbig, 1u); else if (Zb > 4096u) atomicAdd(&gstat->nmid, 1u); }
         lds_sync();
     }
 #pragma unroll
@@ -1418,7 +1420,7 @@ __global__ void k_pack_triple_msd(const int64_t *rows, const int64_t *cols, cons
 __global__ __launch_bounds__(256) void k_tri_stats(const uint64_t *words, const uint32_t *b2start, uint32_t nbuckets, int PB, uint32_t vmask, uint32_t small_cap,
                                                   uint32_t *bN, uint32_t *bZ, BucketStats *gstat)
 {
-    __shared__ uint32_t cnt[8192], red[4];
+    __shared__ uint32_t cnt[8192], red[4];      // (counters per column of a bucket: 2^vb <= 8192)
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     unsigned long long st_distinct = 0, st_sumsq = 0;
     uint32_t st_maxcol = 0;
@@ -1444,7 +1446,7 @@ __global__ __launch_bounds__(256) void k_tri_stats(const uint64_t *words, const 
         if (tid == 0) {
             const uint32_t Nb = red[0] + red[1] + red[2] + red[3];
             bN[b] = Nb; bZ[b] = n; st_distinct += Nb;
-            if (n > 4096u) atomicAdd(&gstat->nmid, 1u);
+            if (n > 8192u) atomicAdd(&gstat->nbig, 1u); else if (n > 4096u) atomicAdd(&gstat->nmid, 1u);
         }
         __syncthreads();
     }
@@ -1533,7 +1535,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     if (!tri) hipLaunchKernelGGL(k_block_reads, dim3((unsigned)((nib + 255) / 256)), dim3(256), 0, s, e.inst_off, e.byte_off, e.nreads, nib, c.ws_b.as<BlockInfo>());
     SegTiles sg{b1start, tile0, nb1};
     BucketOut o{};
-    const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < 8192u ? (uint32_t)c.opt.msd_small_cap : 8192u;
+    const uint32_t small_cap = c.opt.msd_small_cap > 0 && (uint32_t)c.opt.msd_small_cap < ES_CAP_MAX ? (uint32_t)c.opt.msd_small_cap : ES_CAP_MAX;
     static DeviceOnce attr_once;
     attr_once.run(c.device, [&] {
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_count<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1698,7 +1700,12 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         if (small_cap > 4096u && hs.nmid)
             // (8192 entries on 1024 lanes x 8: the 99 KB of LDS allow ONE workgroup per CU — sixteen wavefronts hide the barriers better than eight:
             //  39.7 against 46.8 ms for the bucket kernels on BASELINE config 5 at one GPU's share)
-            hipLaunchKernelGGL((k_msd_emit_small<8, 1024>), dim3(grid32), dim3(1024), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, small_cap,
+            hipLaunchKernelGGL((k_msd_emit_small<8, 1024>), dim3(grid32), dim3(1024), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 4096u, std::min(small_cap, 8192u),
+                               (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+        // 8193..12288 entries (the lowest values of a deep read set: the canonical k-mer is the smaller of two, the first buckets hold twice the average):
+        // twelve entries per lane, 144 KB of LDS — one kernel launch over a few percent of the buckets instead of the windowed kernel's ~45 us per bucket
+        if (small_cap > 8192u && hs.nbig)
+            hipLaunchKernelGGL((k_msd_emit_small<12, 1024>), dim3(grid32), dim3(1024), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 8192u, small_cap,
                                (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (hs.ncrowded && !wide)
             hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,
