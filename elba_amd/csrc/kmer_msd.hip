@@ -402,6 +402,9 @@ struct BucketOut {
 // k-mer ids and column pointers), buckets too crowded for the small emit kernel.
 constexpr uint32_t CT_TAB = 32768, CT_BITS = 2048;      // words
 constexpr size_t CT_LDS = (size_t)(CT_TAB + 3 * CT_BITS + 64) * 4;
+// (the count kernel keeps TWELVE instances per lane: a bucket of BASELINE config 3 holds 7600 on average, more than 8192 often enough — those were
+//  read three times — bucket kernels 17.6 -> 17.1 ms; sixteen spill)
+constexpr int CT_KPT = 12;
 template <bool RANK>      // RANK: the entries leave with their column's rank in the bucket (MsdParams::rk) — one more pass over the bucket's instances, which only long columns repay
 __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words, const uint32_t *b2start, uint32_t nbuckets, MsdParams m, uint32_t lower, uint32_t upper, uint32_t small_cap,
                                                          uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint32_t *crowded, uint64_t *wrel)
@@ -416,24 +419,24 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
     const uint64_t lowmask = m.rk ? (1ull << m.rk) - 1 : ~0ull;
     // the instances of the NEXT bucket are requested before this one is processed (one workgroup per CU: nobody else hides the round trip)
     uint32_t b = blockIdx.x, s0 = 0, n = 0;
-    uint64_t kreg[KPT];
+    uint64_t kreg[CT_KPT];
 #pragma unroll
-    for (int u = 0; u < KPT; ++u) kreg[u] = 0;
+    for (int u = 0; u < CT_KPT; ++u) kreg[u] = 0;
     if (b < nbuckets) {
         s0 = b2start[b]; n = b2start[b + 1] - s0;
 #pragma unroll
-        for (int u = 0; u < KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; if (i < n) kreg[u] = words[s0 + i]; }
+        for (int u = 0; u < CT_KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; if (i < n) kreg[u] = words[s0 + i]; }
     }
     for (; b < nbuckets;) {
         const uint32_t bnext = b + gridDim.x;
         uint32_t s0n = 0, nn = 0;
-        uint64_t knext[KPT];
+        uint64_t knext[CT_KPT];
 #pragma unroll
-        for (int u = 0; u < KPT; ++u) knext[u] = 0;
+        for (int u = 0; u < CT_KPT; ++u) knext[u] = 0;
         if (bnext < nbuckets) {
             s0n = b2start[bnext]; nn = b2start[bnext + 1] - s0n;
 #pragma unroll
-            for (int u = 0; u < KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; if (i < nn) knext[u] = words[s0n + i]; }
+            for (int u = 0; u < CT_KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; if (i < nn) knext[u] = words[s0n + i]; }
         }
         if (n == 0) { if (tid == 0) { bN[b] = 0; bZ[b] = 0; } }
         else {
@@ -447,8 +450,8 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
         const bool guard = n > 65535u;          // a value's count could run over its 16 bits: stop counting beyond 2^15 (UPPER <= 255: unreliable anyway)
         auto for_keys = [&](auto &&f) {
 #pragma unroll
-            for (int u = 0; u < KPT; ++u) if ((uint32_t)u * BK_THREADS + tid < n) f(kreg[u]);
-            for (uint32_t i = (uint32_t)KPT * BK_THREADS + tid; i < n; i += BK_THREADS) f(words[s0 + i]);
+            for (int u = 0; u < CT_KPT; ++u) if ((uint32_t)u * BK_THREADS + tid < n) f(kreg[u]);
+            for (uint32_t i = (uint32_t)CT_KPT * BK_THREADS + tid; i < n; i += BK_THREADS) f(words[s0 + i]);
         };
         for_keys([&](uint64_t wd) {
             const uint32_t v = (uint32_t)(wd >> m.PB) & 0xFFFFu;
@@ -532,7 +535,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
         lds_sync();                               // (misc is zeroed for the next bucket)
         }
 #pragma unroll
-        for (int u = 0; u < KPT; ++u) kreg[u] = knext[u];
+        for (int u = 0; u < CT_KPT; ++u) kreg[u] = knext[u];
         b = bnext; s0 = s0n; n = nn;
     }
 #pragma unroll
