@@ -1490,7 +1490,10 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         vb = 1;
         while (vb < 13 && (avg << (vb + 1)) <= 2048) ++vb;
         if (nbc - vb > 2 * MT_MAXBITS) vb = nbc - 2 * MT_MAXBITS;
-        if (vb > 13 || (avg << vb) > 6144) return false;      // (a bucket beyond 8192 entries sends the whole matrix to the sort: the average must stay clear of it)
+        // (a bucket holds at most 1024 columns: the emit kernels keep a column table of half their capacity + 1 — enough for k-mers, which come with LOWER >= 2
+        //  entries each, and for 1024 one-entry columns in the smallest class; a bucket beyond the largest class sends the whole matrix to the sort: the
+        //  average must stay clear of it)
+        if (vb > 10 || (avg << vb) > 6144) return false;
         T = nbc - vb;
     }
     if (T < 2) return false;

@@ -111,7 +111,7 @@ def test_short_rows_many_cold_calls_agree_with_the_oracle():
     e.close()
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", range(20))
 def test_random_device_triples_through_the_bucket_kernels(case):
     """elba_set_kmer_matrix_device, both ways: the k-mer stage's bucket kernels (two-level partition by column; "kmer_msd" forces them on a
     matrix this small) against the radix sorts of the whole matrix ("kmer_no_msd") and the oracle.  Shuffled triples; columns of 1 .. 40 entries
@@ -121,7 +121,7 @@ def test_random_device_triples_through_the_bucket_kernels(case):
     rng = np.random.default_rng(7000 + case)
     M = int(rng.choice([64, 300, 3000, 40000]))
     ncol = int(rng.choice([37, 500, 4097, 30011, 100003]))
-    maxlen = int(rng.choice([2, 3, 8, 12, 20, 40]))
+    maxlen = int(rng.choice([1, 2, 3, 8, 12, 20, 40]))      # (1: every column a single entry — 1024 columns in a bucket of 1024 entries)
     maxpos = int(rng.choice([5000, 16383, 65535, 200000]))
     hot = rng.choice(M, min(M, int(rng.choice([3, 40, 500, 4000]))), replace=False)
     lens = rng.integers(1, maxlen + 1, ncol)
