@@ -63,6 +63,7 @@ struct MsdParams {
     uint64_t I;
     int rk;                 // entries carry their column's rank inside the bucket from this bit up (the count kernels write it, the emit kernels sort by it); 0: they do not
     uint32_t rkmask;        // ... in these bits (triples: the rank is the column id's low bits, the rest of the id sits above them)
+    uint32_t dup;           // the bucket's words need not be distinct (triples: duplicates are kept, include/elba_amd.h) — equal words are ranked by where the first scatter put them
 };
 
 // Enumeration for the partition kernels: a lane takes 32 CONSECUTIVE instances (g = wbase + 32 * lane + it) and rolls its k-mer window along
@@ -641,9 +642,16 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 uint64_t kk[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) kk[q] = A[lo + (uint32_t)q < hi ? lo + (uint32_t)q : lo];
+                if (m.dup) {      // (equal words — an entry handed over twice — keep the order of their places in the range: every word gets a place of its own)
+                    const uint32_t mine = lo + slot[u];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) rank += (lo + (uint32_t)q < hi && (kk[q] < key[u] || (kk[q] == key[u] && lo + (uint32_t)q < mine))) ? 1u : 0u;
+                    for (uint32_t x = lo + 8u; x < hi; ++x) { const uint64_t a = A[x]; rank += (a < key[u] || (a == key[u] && x < mine)) ? 1u : 0u; }
+                } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) rank += (lo + (uint32_t)q < hi && kk[q] < key[u]) ? 1u : 0u;
                 for (uint32_t x = lo + 8u; x < hi; ++x) rank += A[x] < key[u] ? 1u : 0u;
+                }
                 slot[u] = lo + rank;
             }
         }
@@ -1514,7 +1522,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     // ... and where columns grow long enough for one value to fill a sort range of the emit kernels (UPPER beyond HINT_MAX_COL; the wide path ranks its columns anyway)
     m.rk = (m.PB + VBITS + 13 <= 64 && !c.opt.msd_no_rank && (wide || tri || upper > HINT_MAX_COL || c.opt.msd_rank)) ? m.PB + VBITS : 0;
     m.rkmask = 0xFFFFFFFFu;
-    if (tri) { m.rk = m.PB; m.rkmask = (1u << vb) - 1u; }      // (the rank of a column inside its bucket = the low bits of its id: every column holds entries, or the matrix is refused below)
+    if (tri) { m.rk = m.PB; m.rkmask = (1u << vb) - 1u; m.dup = 1u; }      // (the rank of a column inside its bucket = the low bits of its id: every column holds entries, or the matrix is refused below)
     hipStream_t s = c.stream;
     const uint32_t nb1 = 1u << m.b1, nb2 = 1u << m.b2, nbuckets = nb1 * nb2;
     const uint32_t tile = wide ? (uint32_t)W2_TILE : (uint32_t)MT_TILE;
@@ -1626,6 +1634,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     }
     if (tri && (hs.ncrowded || (int64_t)N != tri->N || Z != I)) {      // an empty column (the buckets number the columns they find), a bucket beyond the LDS sort: matrix.hip sorts
         if (c.opt.trace) fprintf(stderr, "[elba] set_kmer_matrix_device: %llu of %lld columns hold entries, %u crowded buckets: sorting instead\n", (unsigned long long)N, (long long)tri->N, hs.ncrowded);
+        c.t_b.stop(s); c.t_total.stop(s);
         return false;
     }
     ELBA_REQUIRE(Z < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: nnz(A) beyond 32-bit device offsets");
@@ -1733,7 +1742,9 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         // more chunk tails were left unused than the store has room for (never seen; a draw past it writes nothing): every column gets the place
         // of its k-mer id after all — the emit once more, without slots
         if (c.opt.trace) fprintf(stderr, "[elba] gather slots ran past the padded column store (%llu of %llu): emitting again without them\n", slots[0], (unsigned long long)c.ell_cap_cols);
-        o.compact = 0; c.ell_compact = false; c.ell_nslots = (int64_t)N;
+        o.compact = 0; c.ell_compact = false; c.ell_nslots = (int64_t)N; c.ell_cap_cols = (int64_t)N;
+        // (the guard words behind column N: choose_column_store's were lost when the store was sized for the slots, and the re-emit writes right up to them)
+        ELBA_HIP(hipMemsetAsync(c.a_ell.as<char>() + (size_t)N * c.s_stride * 8, 0xFF, 64, s));
         launch_emit();
         ELBA_HIP(hipStreamSynchronize(s));
     } else if (compact) c.ell_nslots = (int64_t)slots[0];      // (an upper bound of the slots in use: chunks are drawn whole)

@@ -1013,6 +1013,12 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         p.slab = nullptr; p.slab_cap = 0;
         if (c.ov_slab_on) {
             c.ov_slab_cap = std::min<int64_t>(c.ov_tmp_cap + (int64_t)SLAB_PAD * nrows, 0xFFFF0000ll);
+            // (the fill word of a row is slab end << 32 | next free entry, bumped once per image — also by those that find the slab full: a row receives
+            //  at most M images, so the low half cannot carry into the end as long as the slab area + M stays below 2^32)
+            if (c.ov_slab_cap + M >= 0xFFFFFFFFll) c.ov_slab_cap = std::max<int64_t>(0xFFFFFFFFll - M - 1, 0);
+            if (c.ov_slab_cap <= (int64_t)SLAB_PAD * nrows + 1) c.ov_slab_on = false;      // (no room left for slabs under that bound: tickets + k_mirror)
+        }
+        if (c.ov_slab_on) {
             c.ov_slab.reserve((size_t)c.ov_slab_cap * 16);
             p.slab = c.ov_slab.as<uint4>(); p.slab_cap = (unsigned long long)c.ov_slab_cap;
             c.ov_slabpos.reserve((size_t)(M + 4) * 8); c.ov_slabn.reserve((size_t)(M + 8) * 4);

@@ -96,6 +96,7 @@ public:
     void build_kmer_matrix(elba_kmer_stats *kstats = nullptr, elba_matrix_stats *mstats = nullptr)
     {
         const int W = grid_->size;
+        exchange_bytes_ = 0;      // (per build: the panel reload of create_seed_matrix(false) adds to THIS build's figure)
         // owners by value range, balanced on the all-reduced histogram of the instances
         if (W > 1) {
             std::vector<uint64_t> hist(ELBA_OWNER_BINS);

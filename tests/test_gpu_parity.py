@@ -665,6 +665,40 @@ def test_device_resident_triples_in_any_order(knob):
     e.close(); e2.close()
 
 
+def test_duplicate_triples_are_kept_by_the_bucket_kernels():
+    """include/elba_amd.h (elba_set_kmer_matrix): duplicates are kept (SumDuplicates = false, src/KmerOps.cpp:400).  Two triples with the same
+    (row, column, position) pack to the same word in the bucket kernels' LDS sort; equal words must still get places of their own (they are
+    ranked by where the first scatter put them).  Exact duplicates — single ones, runs of four, a whole column doubled — through the bucket
+    kernels ("kmer_msd") equal the radix sorts of matrix.hip ("kmer_no_msd") entry for entry, A and B."""
+    import torch
+    packed, off, lens, info = elba_amd.synth_reads(29, 40000, 25, 3000, 700, error_rate=0.10, min_len=200)
+    e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, 2, 8)
+    Z, M, N = int(ms["nnz"]), int(ms["nrows"]), int(ms["ncols"])
+    dr = torch.empty(Z, dtype=torch.int64, device="cuda"); dc = torch.empty(Z, dtype=torch.int64, device="cuda"); dv = torch.empty(Z, dtype=torch.int32, device="cuda")
+    e.export_triples_device(dr.data_ptr(), dc.data_ptr(), dv.data_ptr())
+    g = torch.Generator(device="cuda").manual_seed(11)
+    once = torch.randperm(Z, device="cuda", generator=g)[: Z // 50]                 # 2 % of the entries twice
+    four = torch.randperm(Z, device="cuda", generator=g)[: Z // 400].repeat(3)      # some of them four times
+    col = (dc == int(dc[Z // 3])).nonzero().flatten()                              # one column doubled whole
+    idx = torch.cat([torch.arange(Z, device="cuda"), once, four, col])
+    idx = idx[torch.randperm(idx.numel(), device="cuda", generator=g)]
+    r2, c2, v2 = dr[idx].contiguous(), dc[idx].contiguous(), dv[idx].contiguous()
+    Z2 = int(idx.numel())
+    out = []
+    for knob in ("kmer_msd", "kmer_no_msd"):
+        eng = elba_amd.Engine(17, 2, 8, options={knob: 1})
+        m2 = eng.set_kmer_matrix_device(M, N, Z2, r2.data_ptr(), c2.data_ptr(), v2.data_ptr())
+        assert int(m2["nnz"]) == Z2
+        assert eng.get_stat("triples_path") == (1 if knob == "kmer_msd" else 0)
+        st2 = eng.create_seed_matrix()
+        out.append((eng.export_kmer_matrix(), eng.export_csr(), st2))
+        eng.close()
+    gu.assert_A_equal(out[0][0], out[1][0])
+    gu.assert_B_equal(out[0][1], out[1][1])
+    assert out[0][2]["nnz"] == out[1][2]["nnz"] and out[0][2]["products"] == out[1][2]["products"]
+    e.close()
+
+
 @pytest.mark.parametrize("dk", [0, 1, 2, 4])
 def test_more_gather_trips_in_flight_give_the_same_matrix(dk):
     """The option "dk" (gather trips per iteration of the padded-column loop: one, two, four or eight; chosen per matrix by default) selects
