@@ -533,6 +533,7 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         if (!strcmp(name, "kmer_drop")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: kmer_drop is 0..3"); c.opt.kmer_drop = (int)value; }
         else if (!strcmp(name, "dense_up")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: dense_up is 0..3"); c.opt.dense_up = (int)value; }
         else if (!strcmp(name, "dense_wgs")) { ELBA_REQUIRE(value >= 1 && value <= 16, ELBA_ERR_INVALID_ARG, "set_option: dense_wgs is 1..16"); c.opt.dense_wgs = (int)value; }
+        else if (!strncmp(name, "tune", 4) && name[4] >= '0' && name[4] <= '7' && name[5] == 0) c.opt.tune[name[4] - '0'] = value;
         else if (!strcmp(name, "msd_small_cap")) c.opt.msd_small_cap = (int)value;
         else if (!strcmp(name, "msd_wide_bits")) c.opt.msd_wide_bits = (int)value;
         else if (!strcmp(name, "ell_slot_cap")) c.opt.ell_slot_cap = (int)value;

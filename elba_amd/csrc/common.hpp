@@ -119,6 +119,11 @@ int radix_sort_pairs(hipStream_t s, uint64_t *k0, uint64_t *v0, uint64_t *k1, ui
 // The same for bare 64-bit words (whatever rides in the bits outside [bit_lo, bit_hi) moves with them): returns 0 if the result is in k0, 1 if in k1.
 int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done = false);
 int radix_sort_where(int64_t n, int bit_lo, int bit_hi);
+// The CSR build's sort of one-word keys (read << rs | id << (pb + 2) | hint << pb | pos, or an inline partner: bit 63, matrix.hip) on the read bits
+// [rs, rs + mb), with the LAST pass writing the rows of A themselves: csr[z] = the unpacked entry (k_unpack_csr_words' format) and rowptr[0 .. M]
+// (the first entry of every read, empty rows included) — no pass over the sorted keys behind the sort.  The keys in k0 are consumed.
+struct CsrFin { int idbits, pb, rs, mb, pbi; uint64_t *csr; uint32_t *rowptr; int64_t M; };
+void radix_sort_keys_to_csr(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, const CsrFin &f, DevBuf &tmp);
 int radix_sort_pairs_k32(hipStream_t s, uint32_t *k0, uint64_t *v0, uint32_t *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp);
 void group_offsets_k32(hipStream_t s, const uint32_t *sorted_keys, int64_t n, uint32_t *ptr, int64_t nkeys);
 void radix_column_scan(hipStream_t s, uint32_t *rows, int64_t nrows, uint32_t nbins, DevBuf &tmp);      // (prims.hip)
@@ -159,6 +164,7 @@ struct Options {
     bool csr_pairs = false;     // (read, entry) pairs through the CSR sort instead of one word
     bool emit_plain = false;    // k-mer emit without the fused first histogram
     bool trace = false;         // progress lines on stderr
+    int64_t tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // A/B switches of the round in progress ("tune0" .. "tune7"): what each means is said where it is read
     int msd_wide_bits = 0;      // tests: value bits the partition of the 19 <= k <= 31 path takes (0: chosen from the number of instances)
     int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)

@@ -71,6 +71,55 @@ struct MsdParams {
 // k-mer is the top 2k bits of a 192-bit window shifted left by one base per step, the twin takes the complement of the entering base at its
 // front (src/Kmer.cpp:149-165 rolls the same way; :167-198 is the twin).  Nothing downstream of the partition needs the instances in (read, pos)
 // order — the bucket kernels sort every column — so the tile may hold them in any order.  f(it, canonical k-mer, read, pos), `it` a constant.
+// Where a lane's ITEMS consecutive k-mers fit ONE 64-bit window (ITEMS + k - 1 <= 32 bases: k <= 17 with sixteen instances per lane) nothing is
+// rolled at all: W = the 32 bases from the lane's first position, RC = the reverse complement of all of W, and the j-th k-mer and its twin
+// are two shifts and two masks — (W << 2j) & kmask, (RC << 2 (32 - k - j)) & kmask (the twin of bases j .. j+k-1 starts at comp(base j+k-1),
+// which sits 31 - (j+k-1) places from the top of RC).  Two aligned 8-byte loads and ~25 operations per lane, then ~9 per instance where the
+// rolling window of three words below spends ~22 (the partition's first scatter issued 82 vector instructions per instance: profiles/r04_kmer_pmc.txt).
+template <int ITEMS, class F>
+__device__ __forceinline__ void enum_consecutive_one_window(const EnumParams &e, const BlockInfo *block_read, uint64_t wbase, F &&f)
+{
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t g0 = wbase + (uint64_t)lane * ITEMS;
+    const int k = e.k;
+    const uint64_t kmask = ~0ull << (64 - 2 * k);
+    if (g0 >= e.I) return;
+    const uint64_t leftI = e.I - g0;
+    const uint32_t nvalid = leftI < (uint64_t)ITEMS ? (uint32_t)leftI : (uint32_t)ITEMS;
+    const ReadCursor rc = cursor_at(e, block_read, wbase);
+    uint32_t r = rc.lo;
+    uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
+    while (g0 >= off_hi) { ++r; off_lo = off_hi; off_hi = e.inst_off[r + 1]; boff = e.byte_off[r]; }      // (g0 < I: ends inside the reads; reads shorter than k have empty ranges)
+    uint32_t p = (uint32_t)(g0 - off_lo), j = 0;
+    uint32_t rem = off_hi - g0 < (uint64_t)ITEMS ? (uint32_t)(off_hi - g0) : (uint32_t)ITEMS;      // instances of this read from here on (all a lane can use)
+    uint64_t W = 0, RC = 0;
+    auto load = [&]() {
+        const uint64_t b = boff + (p >> 2), a = b & ~7ull;
+        const uint64_t *w = reinterpret_cast<const uint64_t *>(e.packed + a);
+        const uint64_t w0 = __builtin_bswap64(w[0]), w1 = __builtin_bswap64(w[1]);      // (16 guard bytes follow the reads)
+        const uint32_t sh = (uint32_t)(b - a) * 8 + 2 * (p & 3);                       // 0..62
+        W = sh ? (w0 << sh) | (w1 >> (64 - sh)) : w0;
+        RC = rev2bit64(~W);
+    };
+    load();
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        if ((uint32_t)it < nvalid) {
+            if (rem == 0) {      // the next read that holds instances
+                off_lo = off_hi;
+                while (off_hi == off_lo) { ++r; off_hi = e.inst_off[r + 1]; }
+                boff = e.byte_off[r];
+                p = 0; j = 0;
+                rem = off_hi - off_lo < (uint64_t)ITEMS ? (uint32_t)(off_hi - off_lo) : (uint32_t)ITEMS;
+                load();
+            }
+            const uint64_t fwd = (W << (2u * j)) & kmask, tw = (RC << (2u * (32u - (uint32_t)k - j))) & kmask;
+            f(it, tw < fwd ? tw : fwd, r, p);
+            ++p; ++j; --rem;
+        }
+    }
+}
+
 template <int ITEMS = MT_ITEMS, class F>
 __device__ __forceinline__ void enum_consecutive(const EnumParams &e, const BlockInfo *block_read, uint64_t wbase, F &&f)
 {
@@ -79,6 +128,9 @@ __device__ __forceinline__ void enum_consecutive(const EnumParams &e, const Bloc
     const int k = e.k;
     const uint64_t kmask = ~0ull << (64 - 2 * k);
     if (wbase >= e.I) return;
+#ifndef ELBA_ENUM_ROLL
+    if (ITEMS + k - 1 <= 32) { enum_consecutive_one_window<ITEMS>(e, block_read, wbase, f); return; }
+#endif
     const ReadCursor rc = cursor_at(e, block_read, wbase);
     uint32_t r = rc.lo;
     uint64_t off_lo = rc.off_lo, off_hi = rc.off_hi, boff = rc.boff;
@@ -211,13 +263,16 @@ __global__ __launch_bounds__(MT_MAXBINS) void k_msd_segscan(uint32_t *hist, SegT
     if (b == gridDim.x - 1 && d == 0) b2start[(size_t)gridDim.x * nb2] = (uint32_t)I;
 }
 
+__device__ __forceinline__ void lds_sync_fwd() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // LDS-only workgroup barrier (lds_sync below)
 // ---- stable scatter of one tile by one digit --------------------------------------------------------------------------------------
 // ENUM: the tile's keys are enumerated from the reads (tile = 8192 consecutive instances) and the digit is the top b1 value bits, which the word
 // written does not hold any more.  !ENUM: the tile's keys are read from `in` (a bucket-aligned tile) and the digit is (word >> shift) & mask.
 // The tile is ordered by digit in LDS and written out by consecutive lanes (a digit's keys of one tile are one contiguous run in the output).
+// The grid is PERSISTENT (ntiles tiles dealt round-robin to the workgroups, one workgroup per CU: the tile fills its LDS): a workgroup per tile paid the
+// dispatch of sixteen wavefronts and 139 KB of LDS every ~20 us.
 template <bool ENUM>
 __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const BlockInfo *block_read, MsdParams m, const uint64_t *in, SegTiles sg, int shift, int bits,
-                                                           const uint32_t *hist_scanned, uint64_t *out)
+                                                           const uint32_t *hist_scanned, uint64_t *out, uint32_t ntiles)
 {
     constexpr int WAVES = MT_THREADS / 64, DPT = MT_MAXBINS / MT_THREADS > 0 ? MT_MAXBINS / MT_THREADS : 1;
     __shared__ uint32_t lcnt[MT_MAXBINS], lstart[MT_MAXBINS], gbase[MT_MAXBINS], wsum[WAVES];
@@ -225,18 +280,20 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     __shared__ unsigned long long hbits[MT_TILE / 64];
     __shared__ uint32_t hpre[MT_TILE / 64], delta[MT_MAXBINS];
     const uint32_t nbins = 1u << bits, dmask = nbins - 1u;
-    if (!ENUM && blockIdx.x >= sg.tile0[sg.nb1]) return;
+    if (!ENUM) ntiles = sg.tile0[sg.nb1];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long lane_le = (2ull << lane) - 1ull;      // (a place t = it * MT_THREADS + tid of the write-out has t & 63 == lane)
+    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     for (int i = threadIdx.x; i < MT_MAXBINS; i += MT_THREADS) lcnt[i] = 0;
     for (int i = threadIdx.x; i < MT_TILE / 64; i += MT_THREADS) hbits[i] = 0;
     __syncthreads();
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     uint64_t key[MT_ITEMS];
     uint32_t dig2[MT_ITEMS / 2];    // the items' digits, two per register (0xFFFF: no key)
     uint32_t count = 0;
     auto digit = [&](int it) -> uint32_t { return (dig2[it >> 1] >> ((it & 1) * 16)) & 0xFFFFu; };
     auto set_digit = [&](int it, uint32_t d) { if (it & 1) dig2[it >> 1] |= d << 16; else dig2[it >> 1] = d; };
     if (ENUM) {
-        const uint64_t tbase = (uint64_t)blockIdx.x * MT_TILE, base = tbase + (uint64_t)w * (MT_ITEMS * 64);
+        const uint64_t tbase = (uint64_t)tile * MT_TILE, base = tbase + (uint64_t)w * (MT_ITEMS * 64);
         const uint64_t left = e.I - tbase;
         count = left < (uint64_t)MT_TILE ? (uint32_t)left : (uint32_t)MT_TILE;
         const uint64_t vmask = (1ull << (m.k2 - m.b1)) - 1;
@@ -251,7 +308,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         });
     } else {
         uint32_t bucket, start;
-        seg_tile(sg, blockIdx.x, bucket, start, count);
+        seg_tile(sg, tile, bucket, start, count);
         const uint32_t wb = (uint32_t)w * (MT_ITEMS * 64);
 #pragma unroll
         for (int it = 0; it < MT_ITEMS; ++it) {
@@ -267,7 +324,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     // (the tile's row of output places: one coalesced load, in flight while the ranks are computed)
     uint32_t gb[DPT];
 #pragma unroll
-    for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * MT_THREADS; gb[u] = d < nbins ? hist_scanned[(size_t)blockIdx.x * nbins + d] : 0u; }
+    for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * MT_THREADS; gb[u] = d < nbins ? hist_scanned[(size_t)tile * nbins + d] : 0u; }
     // rank of every key among the tile's keys with its digit: ONE returning LDS atomic per key on the workgroup's digit counters.  (Nothing
     // downstream needs the partition to be stable — the bucket kernels sort every column — so the keys of a digit may land in any order; the
     // ballot ranking of the radix sort, ~70 instructions per key, bought an order nobody reads.)
@@ -315,7 +372,8 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
             const uint32_t t = (uint32_t)it * MT_THREADS + threadIdx.x;
             if (t < count) { const uint64_t kv = lkey[t]; out[delta[(uint32_t)(kv >> shift) & dmask] + t] = kv; }
         }
-        return;
+        __syncthreads();
+        continue;
     }
 #endif
     // The tile now lies ordered by digit in LDS, but an ENUM word does not hold its digit any more.  A place finds its digit's run from a
@@ -362,11 +420,22 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
 #else
     // (a compile-time trip count — all of a lane's LDS reads in flight together — was measured: partition 28.0 -> 30.0 ms; the 32 keys it keeps
     //  in registers beside the tile's cost more than the round trips they hide)
+#if defined(ELBA_X_SCATTER) && ELBA_X_SCATTER == 1      // timing experiment (wrong results): the tile leaves as ONE contiguous run
+    for (uint32_t t = threadIdx.x; t < count; t += MT_THREADS) out[(size_t)tile * MT_TILE + t] = lkey[t];
+#elif defined(ELBA_X_SCATTER) && ELBA_X_SCATTER == 2    // timing experiment (wrong results): nothing leaves
     for (uint32_t t = threadIdx.x; t < count; t += MT_THREADS) {
-        const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & ((2ull << (t & 63u)) - 1ull)) - 1u;
+        const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & lane_le) - 1u;
+        if (delta[run] == 0xFFFFFFFEu) out[t] = lkey[t];
+    }
+#else
+    for (uint32_t t = threadIdx.x; t < count; t += MT_THREADS) {
+        const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & lane_le) - 1u;
         out[delta[run] + t] = lkey[t];
     }
 #endif
+#endif
+    lds_sync_fwd();      // (the tile's LDS is reused by the workgroup's next tile; its global stores stay in flight)
+    }
 }
 
 // LDS-only workgroup barrier: the global stores of a bucket (never read back by the workgroup) stay in flight
@@ -563,7 +632,8 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                                                               const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
 {
     constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, NW = ES_THREADS / 64, NH = ES_KPT * NW;      // entries; wavefronts; (u, wavefront) head counts
-    constexpr uint32_t ES_NSB = ES_CAP >= 8192 ? 1024 : 512;      // ranges of the sort
+    // (ranges of the sort; a quarter of the capacity — 1024 / 2048 ranges for the larger classes, ~4 entries each instead of ~8 — was measured in round 5: no difference)
+    constexpr uint32_t ES_NSB = ES_CAP >= 8192 ? 1024 : 512;
     constexpr int NSB_BITS = ES_CAP >= 8192 ? 10 : 9;
     constexpr int PER = (int)(ES_NSB / ES_THREADS);      // ranges per lane in their scan
     static_assert(PER >= 1 && ES_NSB % ES_THREADS == 0, "one value range per lane at least");
@@ -576,6 +646,11 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t lt = (1ull << lane) - 1;
     const uint64_t paymask = (1ull << m.PB) - 1, posmask = (1ull << m.pbits) - 1;
+#ifdef ELBA_X_EMIT
+    const bool xst = o.nb == 12345;      // timing experiment (wrong results): nothing leaves the kernel
+#else
+    constexpr bool xst = true;
+#endif
     for (uint32_t b = blockIdx.x; b < nbuckets; b += gridDim.x) {
         const uint32_t Z = bZ[b];
         if (Z <= cap_lo || Z > cap_hi) continue;      // (other sizes: the other instantiation, or k_msd_bucket)
@@ -587,7 +662,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
         // values are spread evenly — but a column of 30 entries (deep coverage, BASELINE config 5) is ONE value: every entry then ranks itself among 30.
         // With ranks (MsdParams::rk): the range is (column rank, leading bits of the read) cut to NSB_BITS bits — each column has its own ranges, and
         // a long column is split by read.
-        uint32_t sh = 7;
+        uint32_t sh = 16 - NSB_BITS;
         while (sh < 16 && (Z >> (16 - sh)) < 4u) ++sh;
         int rs_s = 0, rs_t = 0;
         if (m.rk) {
@@ -722,20 +797,20 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                     if (mult < 2 && nown == 0) hint = 3;
                 }
                 const uint32_t z = eb + p, kid = kb + kl;
-                o.csc[z] = (read << 32) | pos;
+                if (xst) o.csc[z] = (read << 32) | pos;
                 uint64_t word = (read << o.rs) | ((uint64_t)kid << (o.pb + 2)) | (hint << o.pb) | pos;
                 // Ctx::csr_inline: a row that accumulates exactly ONE pair of this column (always so for the owner of a two-read column) carries that
                 // pair in its own entry — the SpGEMM then fetches no column for it
                 const bool isinl = o.inl && mult == 1u && nown == 1u && ((pos | opos) >> o.inl) == 0;
                 if (isinl) word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
-                if (o.pair_val) { o.pair_key[z] = (uint32_t)read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)L << 23) | ((uint64_t)(p - h0) << 16) | pos; }
+                if (!xst) {} else if (o.pair_val) { o.pair_key[z] = (uint32_t)read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)L << 23) | ((uint64_t)(p - h0) << 16) | pos; }
                 else if (o.compact && !isinl && hint == 0) {      // this entry fetches its column: the column needs a gather slot, the key names it (below)
                     needmask |= 1u << u;
                     atomicOr(&H[kl], HNEED);
                 }
                 else if (o.csr_words) o.csr_words[z] = word;
                 else o.kid_of_entry[z] = kid;
-                if ((headmask >> u) & 1u) {
+                if (xst && ((headmask >> u) & 1u)) {
                     const uint64_t value = ((uint64_t)b << VBITS) | ((uint32_t)(x >> m.PB) & 0xFFFFu);
                     if (o.rel_kmers) o.rel_kmers[kid] = o.kmer_src ? o.kmer_src[s0 + kl] : value << (64 - m.k2);
                     o.rel_counts[kid] = L; o.colptr[kid] = z;
@@ -773,7 +848,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                     const uint32_t p = (uint32_t)u * ES_THREADS + tid;
                     const uint64_t x = A[p];
                     const uint64_t sid = (uint64_t)gb + ((H[slot[u]] >> 14) & 0x1FFFu);
-                    o.csr_words[eb + p] = (((x & paymask) >> m.pbits) << o.rs) | (sid << (o.pb + 2)) | (x & posmask);
+                    if (xst) o.csr_words[eb + p] = (((x & paymask) >> m.pbits) << o.rs) | (sid << (o.pb + 2)) | (x & posmask);
                 }
             const uint32_t S = o.ell_stride, nq = ng * S, sl = (S & (S - 1u)) ? 0u : (uint32_t)__ffs((int)S) - 1u;
             uint64_t *dst = o.ell + (uint64_t)gb * S;
@@ -781,8 +856,8 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 const uint32_t ls = (S & (S - 1u)) ? q / S : q >> sl, j = q - ls * S, kl = GL[ls], h0 = H[kl] & HPOS;
                 uint64_t v = ~0ull;
                 if (h0 + j < (H[kl + 1] & HPOS)) { const uint64_t x = A[h0 + j]; v = (((x & paymask) >> m.pbits) << 32) | (x & posmask); }
-                dst[q] = v;
-                if (j == 0) o.slot_kid[gb + ls] = kb + kl;
+                if (xst) dst[q] = v;
+                if (xst && j == 0) o.slot_kid[gb + ls] = kb + kl;
             }
         } else if (o.ell_stride) {
             const uint32_t S = o.ell_stride, nq = Nb * S, sl = (S & (S - 1u)) ? 0u : (uint32_t)__ffs((int)S) - 1u;
@@ -793,7 +868,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 //  the bucket kernels: the stores are fire-and-forget, the test is not)
                 uint64_t v = ~0ull;
                 if (h0 + j < H[kl + 1]) { const uint64_t x = A[h0 + j]; v = (((x & paymask) >> m.pbits) << 32) | (x & posmask); }
-                dst[q] = v;
+                if (xst) dst[q] = v;
             }
         }
         lds_sync();                               // A, H and the counters are reused by the next bucket
@@ -1559,6 +1634,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     });
     if (!wide) {
     const int shift2 = m.PB + vb;
+    const uint32_t sgrid = c.opt.tune[0] == 1 ? 0xFFFFFFFFu : (uint32_t)c.num_cus * (MT_TILE <= 8192 ? 2u : 1u);      // (tune0 = 1: a workgroup per tile, as before round 5 — A/B)
     if (tri) {
         // first digit, from the packed triples: one segment of ntiles1 tiles
         const uint32_t seg[4] = {0u, (uint32_t)I, 0u, ntiles1};
@@ -1570,18 +1646,18 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         hipLaunchKernelGGL(k_msd_hist2, dim3(ntiles1), dim3(MT_THREADS), 0, s, (const uint64_t *)wb, sg1, shift2 + m.b2, m.b1, hist);
         radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
         hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
-        hipLaunchKernelGGL((k_msd_scatter<false>), dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wb, sg1, shift2 + m.b2, m.b1, (const uint32_t *)hist, wa);
+        hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wb, sg1, shift2 + m.b2, m.b1, (const uint32_t *)hist, wa, ntiles1);
     } else {
     // first digit
     hipLaunchKernelGGL(k_msd_hist1, dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, hist);
     radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
     hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
-    hipLaunchKernelGGL((k_msd_scatter<true>), dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa);
+    hipLaunchKernelGGL((k_msd_scatter<true>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa, ntiles1);
     }
     // second digit, inside every first-digit bucket
     hipLaunchKernelGGL(k_msd_hist2, dim3(ntiles2), dim3(MT_THREADS), 0, s, (const uint64_t *)wa, sg, shift2, m.b2, hist);
     hipLaunchKernelGGL(k_msd_segscan, dim3(nb1), dim3(MT_MAXBINS), 0, s, hist, sg, nb2, b2start, I);
-    hipLaunchKernelGGL((k_msd_scatter<false>), dim3(ntiles2), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sg, shift2, m.b2, (const uint32_t *)hist, wb);
+    hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(ntiles2, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sg, shift2, m.b2, (const uint32_t *)hist, wb, ntiles2);
     c.t_a.stop(s);
     // buckets: count
     c.t_b.start(s);

@@ -374,12 +374,20 @@ void finish_matrix_from_sorted_csc(Ctx &c, int64_t M, int64_t N, int64_t Z, cons
         const bool inl_late = have_words && hints && !c.pre_hints_done && c.pre_inline_pending && c.use_ell && !c.csr_suffix && c.pos16 && !windowed;
         if (Z > 0 && have_words && hints && !c.pre_hints_done)
             hipLaunchKernelGGL(k_add_hints, dim3((unsigned)((Z + 255) / 256)), dim3(256), 0, s, (const uint32_t *)c.a_colptr.as<uint32_t>(), (const uint64_t *)c.a_csc.as<uint64_t>(), Z, nb, pb, rs, inl_late ? pbi : 0, w0);
-        const int where = radix_sort_keys(s, w0, w1, Z, rs, rs + mb, c.ws_sort);
-        const uint64_t *sorted = where ? w1 : w0;
         // (gather slots, kmer_msd.hip: the id field of a key may hold a slot beyond the last k-mer id — slots are drawn in chunks — and is as wide as
         //  the key leaves room below the read)
         const int idbits = have_words && c.ell_compact ? std::min(32, rs - pb - 2) : nb;
-        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, idbits, pb, rs, mb, (have_words && c.pre_inline) || inl_here || inl_late ? pbi : 0, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
+        const int pbi_used = (have_words && c.pre_inline) || inl_here || inl_late ? pbi : 0;
+        if (Z > 0 && M > 0 && c.opt.tune[1] != 1) {
+            // the sort's last pass writes the rows themselves and their pointers (prims.hip: k_rs_scatter<FIN>): no pass over the sorted keys behind it
+            // (round 4: k_unpack_csr_words read and wrote all of them once more — 1.9 ms of the 10 ms CSR build of BASELINE config 3)
+            const CsrFin fin{idbits, pb, rs, mb, pbi_used, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M};
+            radix_sort_keys_to_csr(s, w0, w1, Z, fin, c.ws_sort);
+        } else {
+        const int where = radix_sort_keys(s, w0, w1, Z, rs, rs + mb, c.ws_sort);
+        const uint64_t *sorted = where ? w1 : w0;
+        hipLaunchKernelGGL(k_unpack_csr_words, dim3((unsigned)((Z + 1 + 255) / 256)), dim3(256), 0, s, sorted, Z, idbits, pb, rs, mb, pbi_used, c.a_csr.as<uint64_t>(), c.a_rowptr.as<uint32_t>(), M);
+        }
         c.csr_inline = (have_words && c.pre_inline) || inl_here || inl_late;
         c.csr_inline_window = inl_here && windowed;
     } else {

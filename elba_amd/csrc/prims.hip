@@ -242,9 +242,14 @@ size_t column_scan_tmp_elems(int64_t nrows, uint32_t nbins)
     return tot + 64;
 }
 
-template <bool HAS_VAL, int THREADS, int ITEMS, class K = uint64_t>
+// FIN (the last pass of the CSR build's sort, radix_sort_keys_to_csr): the keys leave UNPACKED — the rows of A — and the row pointers with them.  The
+// tile lies ordered by this pass's digit (the read's high bits) in LDS, and inside a digit by the earlier passes' (its low bits): the keys of one read
+// are contiguous there.  A key whose left neighbour in the digit's run belongs to another read is the FIRST entry of its read in the whole
+// output (an earlier tile holds smaller low bits only) and writes the row pointer; the first key of a run cannot know — the run may continue a
+// read of the tile before — and takes the minimum with what is there (rowptr starts as all ones; empty rows are closed by k_rowptr_close_*).
+template <bool HAS_VAL, int THREADS, int ITEMS, class K = uint64_t, bool FIN = false>
 __global__ __launch_bounds__(THREADS) void k_rs_scatter(const K *keys_in, const uint64_t *vals_in, K *keys_out, uint64_t *vals_out,
-                                                        int64_t n, int shift, int bits, const uint32_t *hist_scanned)
+                                                        int64_t n, int shift, int bits, const uint32_t *hist_scanned, CsrFin fin = CsrFin{})
 {
     constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DPT = RS_MAXBINS / THREADS > 0 ? RS_MAXBINS / THREADS : 1;      // digits per thread in the per-digit step (more threads than digits: the others idle there)
     static_assert(ITEMS * 64 < 65536, "a wave's count of a digit fits 16 bits");
@@ -339,9 +344,89 @@ __global__ __launch_bounds__(THREADS) void k_rs_scatter(const K *keys_in, const 
         const K k = lkey[t];
         const uint32_t d = (uint32_t)(k >> shift) & dmask;
         const uint32_t dst = gbase[d] + (t - lstart[d]);
+        if (FIN) {
+            const uint64_t w = (uint64_t)k, rmask = (1ull << fin.mb) - 1;
+            const uint32_t read = (uint32_t)((w >> fin.rs) & rmask);
+            if (t == lstart[d]) atomicMin(&fin.rowptr[read], dst);
+            else if ((uint32_t)(((uint64_t)lkey[t - 1] >> fin.rs) & rmask) != read) fin.rowptr[read] = dst;
+            uint64_t e;
+            if (w >> 63) {      // inline partner (Ctx::csr_inline): flag | partner >> 1 | posQ | posT << 16
+                const uint64_t pm = (1ull << fin.pbi) - 1;
+                e = (1ull << 63) | (((w >> (2 * fin.pbi)) & ((1ull << (fin.mb - 1)) - 1)) << 32) | ((w >> fin.pbi) & pm) | ((w & pm) << 16);
+            } else e = (((w >> (fin.pb + 2)) & ((1ull << fin.idbits) - 1)) << 32) | (((w >> fin.pb) & 3ull) << 30) | (w & ((1ull << fin.pb) - 1));
+            fin.csr[dst] = e;
+        } else {
         keys_out[dst] = k;
         if (HAS_VAL) vals_out[dst] = lval[t];
+        }
     }
+}
+
+// rowptr[r] = all ones for a read without entries: closed to the next read's first entry (rowptr[M] = n), i.e. a suffix minimum.  Three small
+// kernels: per block of 1024 rows the block's minimum, a suffix minimum over the blocks (one workgroup), the rows themselves.
+__global__ __launch_bounds__(256) void k_rowptr_close_a(const uint32_t *rowptr, int64_t M1, uint32_t *bmin)
+{
+    __shared__ uint32_t ws[4];
+    const int64_t r0 = (int64_t)blockIdx.x * 1024;
+    uint32_t m = 0xFFFFFFFFu;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int64_t r = r0 + u * 256 + threadIdx.x; if (r < M1) { const uint32_t x = rowptr[r]; m = x < m ? x : m; } }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const uint32_t o = __shfl_xor(m, d, 64); m = o < m ? o : m; }
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) { for (int q = 1; q < 4; ++q) m = ws[q] < m ? ws[q] : m; bmin[blockIdx.x] = m; }
+}
+__global__ __launch_bounds__(1024) void k_rowptr_close_b(uint32_t *bmin, int64_t nb)      // bmin[b] becomes the minimum over the blocks BEHIND b
+{
+    __shared__ uint32_t ws[16];
+    __shared__ uint32_t carry_s;
+    if (threadIdx.x == 0) carry_s = 0xFFFFFFFFu;
+    __syncthreads();
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t hi = nb; hi > 0; hi -= 1024) {      // chunks of 1024 blocks, from the last to the first
+        const int64_t b = hi - 1 - (int64_t)threadIdx.x;      // thread 0 takes the chunk's last block
+        const uint32_t mine = b >= 0 ? bmin[b] : 0xFFFFFFFFu;
+        uint32_t inc = mine;      // inclusive minimum over the threads 0 .. own (the blocks from the chunk's end down to this one)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d && o < inc) inc = o; }
+        if (lane == 63) ws[w] = inc;
+        __syncthreads();
+        uint32_t before = carry_s;      // everything behind this thread's wavefront
+        for (uint32_t q = 0; q < w; ++q) before = ws[q] < before ? ws[q] : before;
+        const uint32_t excl_in_wave = __shfl_up(inc, 1, 64);
+        uint32_t behind = before;
+        if (lane > 0 && excl_in_wave < behind) behind = excl_in_wave;
+        if (b >= 0) bmin[b] = behind;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry_s = inc < before ? inc : before;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_rowptr_close_c(uint32_t *rowptr, int64_t M1, const uint32_t *bmin)
+{
+    // one wavefront per 256 rows would do; kept simple: thread t of the block walks 4 consecutive rows from the back, a suffix minimum over the threads between
+    __shared__ uint32_t ws[4];
+    const int64_t r0 = (int64_t)blockIdx.x * 1024 + (int64_t)(255 - threadIdx.x) * 4;      // thread 0 holds the block's LAST four rows
+    uint32_t x[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) x[u] = r0 + u < M1 ? rowptr[r0 + u] : 0xFFFFFFFFu;
+    uint32_t m = x[3];
+    m = x[2] < m ? x[2] : m; m = x[1] < m ? x[1] : m; m = x[0] < m ? x[0] : m;
+    const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    uint32_t inc = m;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(inc, d, 64); if ((int)lane >= d && o < inc) inc = o; }
+    if (lane == 63) ws[w] = inc;
+    __syncthreads();
+    uint32_t behind = bmin[blockIdx.x];
+    for (uint32_t q = 0; q < w; ++q) behind = ws[q] < behind ? ws[q] : behind;
+    const uint32_t ex = __shfl_up(inc, 1, 64);
+    if (lane > 0 && ex < behind) behind = ex;
+    // rows r0+3 .. r0: each takes the minimum of itself and everything behind it
+    uint32_t run = behind;
+#pragma unroll
+    for (int u = 3; u >= 0; --u) { run = x[u] < run ? x[u] : run; if (r0 + u < M1) rowptr[r0 + u] = run; }
 }
 
 }  // namespace
@@ -413,9 +498,9 @@ static int radix_digits(int bit_lo, int bit_hi, int *shift, int *bits)
 }
 
 template <bool HAS_VAL, class K = uint64_t>
-static int radix_sort_impl(hipStream_t s, K *k0, uint64_t *v0, K *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done)
+static int radix_sort_impl(hipStream_t s, K *k0, uint64_t *v0, K *k1, uint64_t *v1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done, const CsrFin *fin = nullptr)
 {
-    if (n <= 1 || bit_hi <= bit_lo) return 0;
+    if (!fin && (n <= 1 || bit_hi <= bit_lo)) return 0;
     ELBA_REQUIRE(n < (int64_t)0xFFFFFFFFLL, ELBA_ERR_UNSUPPORTED, "radix sort of >= 2^32 items");
     constexpr int ITEMS = HAS_VAL ? ELBA_RS_PAIR_ITEMS : ELBA_RS_KEY_ITEMS, TILE = RS_THREADS * ITEMS;
     // (pairs: 8192-pair tiles on 1024 lanes x 8 — the CSR build of the k = 31 workload 34.1 -> 27.0 ms against 4096-pair tiles on 256 x 16; keys alone
@@ -439,7 +524,10 @@ static int radix_sort_impl(hipStream_t s, K *k0, uint64_t *v0, K *k1, uint64_t *
         if (q > 0 || !first_hist_done)
             hipLaunchKernelGGL((k_rs_hist<ITEMS, K>), dim3(nblocks), dim3(RS_THREADS), 0, s, (const K *)ki, n, shift, bits, hist);
         column_scan(s, hist, (int64_t)nblocks, nbins, scan_tmp);
-        hipLaunchKernelGGL((k_rs_scatter<HAS_VAL, STHREADS, TILE / STHREADS, K>), dim3(nblocks), dim3(STHREADS), 0, s, (const K *)ki, (const uint64_t *)vi, ko, vo, n, shift, bits, (const uint32_t *)hist);
+        if (!HAS_VAL && sizeof(K) == 8 && fin && q == npass - 1)
+            hipLaunchKernelGGL((k_rs_scatter<false, STHREADS, TILE / STHREADS, uint64_t, true>), dim3(nblocks), dim3(STHREADS), 0, s, (const uint64_t *)ki, (const uint64_t *)nullptr, (uint64_t *)nullptr, (uint64_t *)nullptr, n, shift, bits, (const uint32_t *)hist, *fin);
+        else
+        hipLaunchKernelGGL((k_rs_scatter<HAS_VAL, STHREADS, TILE / STHREADS, K>), dim3(nblocks), dim3(STHREADS), 0, s, (const K *)ki, (const uint64_t *)vi, ko, vo, n, shift, bits, (const uint32_t *)hist, CsrFin{});
         { K *t = ki; ki = ko; ko = t; }
         { uint64_t *t = vi; vi = vo; vo = t; }
         cur ^= 1;
@@ -494,6 +582,23 @@ int radix_sort_pairs_k32(hipStream_t s, uint32_t *k0, uint64_t *v0, uint32_t *k1
 int radix_sort_keys(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, int bit_lo, int bit_hi, DevBuf &tmp, bool first_hist_done)
 {
     return radix_sort_impl<false>(s, k0, nullptr, k1, nullptr, n, bit_lo, bit_hi, tmp, first_hist_done);
+}
+
+void radix_sort_keys_to_csr(hipStream_t s, uint64_t *k0, uint64_t *k1, int64_t n, const CsrFin &f, DevBuf &tmp)
+{
+    ELBA_REQUIRE(f.mb >= 1 && n >= 1 && f.M >= 1, ELBA_ERR_INTERNAL, "radix_sort_keys_to_csr: empty matrix");
+    const int64_t M1 = f.M + 1;
+    ELBA_HIP(hipMemsetAsync(f.rowptr, 0xFF, (size_t)M1 * 4, s));
+    const uint32_t nn = (uint32_t)n;
+    ELBA_HIP(hipMemcpyAsync(f.rowptr + f.M, &nn, 4, hipMemcpyHostToDevice, s));
+    radix_sort_impl<false>(s, k0, nullptr, k1, nullptr, n, f.rs, f.rs + f.mb, tmp, false, &f);
+    // (the sort's workspace is free again: the block minima of the row pointers go there)
+    const int64_t nb = (M1 + 1023) / 1024;
+    tmp.reserve((size_t)(nb + 1) * 4);
+    uint32_t *bmin = tmp.as<uint32_t>();
+    hipLaunchKernelGGL(k_rowptr_close_a, dim3((unsigned)nb), dim3(256), 0, s, (const uint32_t *)f.rowptr, M1, bmin);
+    hipLaunchKernelGGL(k_rowptr_close_b, dim3(1), dim3(1024), 0, s, bmin, nb);
+    hipLaunchKernelGGL(k_rowptr_close_c, dim3((unsigned)nb), dim3(256), 0, s, f.rowptr, M1, (const uint32_t *)bmin);
 }
 
 }  // namespace elba
