@@ -86,6 +86,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
     const uint32_t tid = threadIdx.x, lane = tid & 63;
     const uint64_t lt = (1ull << lane) - 1;
     const uint32_t nrows = sample ? p.ctr->sample_count : p.ctr->tier_count[tier];      // complete: every lower tier has finished (same stream); sample: the rows computed before all others on a cold call
+    if (nrows == 0) return;      // (a tier nobody queued on — most tiers of a small matrix: its workgroups leave before they initialise a table; rows only ever move to HIGHER tiers, which start later)
     const uint32_t lb = p.lpc_log2, sub = tid & ((1u << lb) - 1u), grp = tid >> lb, EPT = (uint32_t)BLOCK >> lb;
     const uint32_t fbits = p.fbits, fmask = (1u << fbits) - 1u, stride = p.s_stride;
     const bool ell = p.a_ell != nullptr;

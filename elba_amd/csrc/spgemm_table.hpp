@@ -210,12 +210,18 @@ struct Table {
         const lds_u32 *lk = (const lds_u32 *)keys;
         const uint32_t T = TB ? (1u << TB) : size(), tb = T * 4;
         uint32_t slot[4], k[4], m[4];
+#ifndef ELBA_DENSE_NO_CMAX
+        uint32_t mx[4];
+#endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) slot[r] = TB ? (ELBA_HMIX(j[r]) * 0x9E3779B1u) >> (32 - (TB ? TB : 1)) : lds_slot(j[r]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             k[r] = __hip_atomic_load(&lk[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             m[r] = __hip_atomic_load(&lk[slot[r] + 2u * T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#ifndef ELBA_DENSE_NO_CMAX
+            mx[r] = __hip_atomic_load(&lk[slot[r] + 3u * T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         }
         const uint32_t base = (uint32_t)(uintptr_t)keys, one = 1u;
 #pragma unroll
@@ -224,6 +230,16 @@ struct Table {
             const bool v = (uint32_t)r >= vr;
             const bool h = v && k[r] == j[r] && s >= m[r];
             if (h) {
+#ifndef ELBA_DENSE_NO_CMAX
+                // The largest sequence number is only raised by a product that exceeds what the slot was READ to hold: eight wavefronts share a table and walk the
+                // row's chunks in order — the one furthest ahead raises it, the others read a value above theirs (equal addresses of a read broadcast, those of
+                // an atomic serialise).  Config 5 at 1/25: numeric 9.50 -> 8.95 ms (round 4 measured 7.3 ms with no ds_max at all: profiles/r04_notes.md).
+                if (TB) {
+                    const uint32_t a = base + (slot[r] << 2);
+                    asm volatile("ds_add_u32 %[a], %[one] offset:%[o1]\n" : : [a] "v"(a), [one] "v"(one), [o1] "n"(4 << TB) : "memory");
+                    if (s > mx[r]) asm volatile("ds_max_u32 %[a], %[s] offset:%[o3]\n" : : [a] "v"(a), [s] "v"(s), [o3] "n"(12 << TB) : "memory");
+                } else
+#endif
                 if (TB) {
                     const uint32_t a = base + (slot[r] << 2);
                     asm volatile("ds_add_u32 %[a], %[one] offset:%[o1]\n\t"
