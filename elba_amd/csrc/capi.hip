@@ -528,7 +528,7 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         struct { const char *n; bool *b; } flags[] = {
             {"overlap_cold_calls", &c.cold_calls}, {"no_symmetry", &c.opt.no_symmetry}, {"no_ell", &c.opt.no_ell}, {"no_pay", &c.opt.no_pay}, {"mir32", &c.opt.mir32},
             {"no_hints", &c.opt.no_hints}, {"no_sample", &c.opt.no_sample}, {"no_slab", &c.opt.no_slab}, {"no_ell_compact", &c.opt.no_ell_compact}, {"msd_no_emit8", &c.opt.msd_no_emit8}, {"msd_no_rank", &c.opt.msd_no_rank}, {"msd_rank", &c.opt.msd_rank}, {"csr_pairs_late", &c.opt.csr_pairs_late}, {"no_suffix", &c.opt.no_suffix}, {"no_row_order", &c.opt.no_row_order}, {"no_inline", &c.opt.no_inline}, {"panel_inline", &c.opt.panel_inline}, {"kmer_pairs", &c.opt.kmer_pairs},
-            {"kmer_unfused", &c.opt.kmer_unfused}, {"kmer_no_msd", &c.opt.kmer_no_msd}, {"kmer_msd", &c.opt.kmer_msd}, {"csr_pairs", &c.opt.csr_pairs}, {"emit_plain", &c.opt.emit_plain}, {"trace", &c.opt.trace}};
+            {"kmer_unfused", &c.opt.kmer_unfused}, {"kmer_no_msd", &c.opt.kmer_no_msd}, {"kmer_msd", &c.opt.kmer_msd}, {"csr_pairs", &c.opt.csr_pairs}, {"emit_plain", &c.opt.emit_plain}, {"trace", &c.opt.trace}, {"measure_prep", &c.opt.measure_prep}};
         for (auto &f : flags) if (!strcmp(name, f.n)) { *f.b = value != 0; return; }
         if (!strcmp(name, "kmer_drop")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: kmer_drop is 0..3"); c.opt.kmer_drop = (int)value; }
         else if (!strcmp(name, "dense_up")) { ELBA_REQUIRE(value >= 0 && value <= 3, ELBA_ERR_INVALID_ARG, "set_option: dense_up is 0..3"); c.opt.dense_up = (int)value; }
@@ -552,7 +552,7 @@ int elba_release_workspace(elba_ctx *ctx)
     return guarded(ctx, [&](Ctx &c) {
         ELBA_REQUIRE(!c.dist_owner && c.ov_phase == 0, ELBA_ERR_STATE, "release_workspace: the context holds exchanged records or is inside a sharded multiplication");
         ELBA_HIP(hipStreamSynchronize(c.stream));
-        c.ws_a.release(); c.ws_b.release(); c.ws_c.release(); c.ws_d.release(); c.ws_e.release(); c.ws_f.release(); c.ws_sort.release();
+        c.ws_a.release(); c.ws_b.release(); c.ws_c.release(); c.ws_d.release(); c.ws_e.release(); c.ws_f.release(); c.ws_g.release(); c.ws_h.release(); c.ws_sort.release();
         c.csr_words.release(); c.kid_of_entry.release();
         if (c.have_counts) { c.pre_ready = false; c.pre_consumed = true; }    // (the CSR sort keys / column ids of the entries are gone: create_kmer_matrix rebuilds them from the column pointers)
     });
@@ -565,6 +565,8 @@ int elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value)
         if (!strcmp(name, "overlap_mirror_placed")) *value = c.ov_mir_placed;
         else if (!strcmp(name, "overlap_slab_q16")) *value = (int64_t)c.ov_slab_q16_used;
         else if (!strcmp(name, "kmer_path")) *value = c.kmer_path;
+        else if (!strcmp(name, "spgemm_prep_us")) *value = c.prep_us;      // (option "measure_prep"; -1: not measured — the option was off, or the path taken has no emit kernels of its own)
+        else if (!strcmp(name, "emit_us")) *value = c.emit_us;
         else if (!strcmp(name, "triples_path")) *value = c.triples_path;
         else if (!strcmp(name, "padded_columns")) *value = c.have_A && c.use_ell ? 1 : 0;
         else if (!strcmp(name, "gather_slots")) *value = c.have_A && c.use_ell ? c.ell_nslots : 0;

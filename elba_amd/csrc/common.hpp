@@ -164,6 +164,8 @@ struct Options {
     bool csr_pairs = false;     // (read, entry) pairs through the CSR sort instead of one word
     bool emit_plain = false;    // k-mer emit without the fused first histogram
     bool trace = false;         // progress lines on stderr
+    bool measure_prep = false;  // diagnostic (bench.py, "spgemm_prep"): elba_count_kmers runs its emit kernels a second time WITHOUT what they write for the SpGEMM's sake alone (hint bits,
+                                // inline partners, gather slots + padded columns), both runs bracketed by events: elba_get_stat("spgemm_prep_us") = the difference (kmer_msd.hip)
     int64_t tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // A/B switches of the round in progress ("tune0" .. "tune7"): what each means is said where it is read
     int msd_wide_bits = 0;      // tests: value bits the partition of the 19 <= k <= 31 path takes (0: chosen from the number of instances)
     int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
@@ -287,6 +289,7 @@ struct Ctx {
 
     // workspaces
     DevBuf ws_scan, ws_sort, ws_a, ws_b, ws_c, ws_d, ws_e, ws_f;
+    DevBuf ws_g, ws_h;      // crowded buckets of the wide k-mer partition (kmer_msd.hip: k31_gather_crowded ...): their records / the pseudo-buckets' arrays
     DevBuf ov_totcnt, ov_mir, ov_tmp, ov_sum_tmp;  // u32[M+1] mirrored entries per row (ticket counters); mirrored entries laid out like B (32-byte records); staging area (32-byte records)
     bool ov_low_clean = false;                 // the ticket counters are all zero (handed back clean by the previous call)
     DevBuf ov_rowub, ov_rowcnt, ov_rowoff, ov_lists, ov_counters, ov_gtable, ov_sortkeys;
@@ -313,6 +316,7 @@ struct Ctx {
     bool own_stream = true;         // c.stream was created by the context (elba_set_stream: the caller's)
 
     EventTimer t_total, t_a, t_b, t_c;
+    EventTimer t_emit, t_emit_plain; int64_t prep_us = -1, emit_us = -1;      // Options::measure_prep
     struct PinnedHost { void *p = nullptr; size_t cap = 0; void reserve(size_t n) { if (n <= cap) return; if (p) (void)hipHostFree(p); p = nullptr; cap = 0; ELBA_HIP(hipHostMalloc(&p, n, hipHostMallocDefault)); cap = n; } ~PinnedHost() { if (p) (void)hipHostFree(p); } };
     PinnedHost ov_host;            // pinned landing area of the per-call counter read-back (a pageable target makes the copy a staged, blocking one)
     PhaseMarks<5> ov_marks;        // overlap SpGEMM: 0 call start, 1 numeric start, 2 numeric end, 3 call end, 4 finalize start when the host synchronised before it

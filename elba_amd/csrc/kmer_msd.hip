@@ -461,6 +461,8 @@ struct BucketOut {
     unsigned long long slot_cap;
     uint32_t *pair_key; uint64_t *pair_val; // dense matrices (Ctx::csr_suffix): the pairs the CSR build sorts by read — read; k-mer id << 32 | column length << 23 | place in the column << 16 | pos — instead of sort words
     const uint64_t *kmer_src;      // k > 17 (k31_count): the bucket's reliable k-mers, left-aligned, at [bucket's first instance + column]; null: the k-mer is bucket << 16 | the entry's 16 value bits
+    const uint32_t *ncols;         // columns per bucket where consecutive buckets' k-mer id bases do not follow one another (pseudo-buckets); null: kidbase[b + 1] - kidbase[b]
+    const uint64_t *kmer_dist; const uint32_t *dist_base;      // pseudo-buckets of a crowded wide bucket (k31_crowded_*): the entry's 16 value bits are the k-mer's rank among the pseudo-bucket's DISTINCT k-mers — the k-mer is kmer_dist[dist_base[bucket] + those bits]
 };
 
 // ---- buckets: count ------------------------------------------------------------------------------------------------------------------
@@ -666,7 +668,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
         while (sh < 16 && (Z >> (16 - sh)) < 4u) ++sh;
         int rs_s = 0, rs_t = 0;
         if (m.rk) {
-            const uint32_t ncol = kidbase[b + 1] - kidbase[b];
+            const uint32_t ncol = o.ncols ? o.ncols[b] : kidbase[b + 1] - kidbase[b];
             int cb = 0;
             while (cb < 16 && (ncol >> cb)) ++cb;                     // bits of a column rank
             int want = 2;
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *w
                 else o.kid_of_entry[z] = kid;
                 if (xst && ((headmask >> u) & 1u)) {
                     const uint64_t value = ((uint64_t)b << VBITS) | ((uint32_t)(x >> m.PB) & 0xFFFFu);
-                    if (o.rel_kmers) o.rel_kmers[kid] = o.kmer_src ? o.kmer_src[s0 + kl] : value << (64 - m.k2);
+                    if (o.rel_kmers) o.rel_kmers[kid] = o.kmer_dist ? o.kmer_dist[o.dist_base[b] + ((uint32_t)(x >> m.PB) & 0xFFFFu)] : (o.kmer_src ? o.kmer_src[s0 + kl] : value << (64 - m.k2));
                     o.rel_counts[kid] = L; o.colptr[kid] = z;
                 }
             }
@@ -963,7 +965,8 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_bucket(const uint64_t *words
                     for (uint32_t bits = mybits; bits; bits &= bits - 1u) {
                         const uint32_t idx = tid * 32u + (uint32_t)__ffs((int)bits) - 1u, cnt = tab16[idx];
                         const uint64_t value = ((uint64_t)b << VBITS) | (h << 15) | idx;
-                        o.rel_kmers[kb + r2] = value << (64 - m.k2); o.rel_counts[kb + r2] = cnt; o.colptr[kb + r2] = eb + e2;
+                        if (o.rel_kmers) o.rel_kmers[kb + r2] = o.kmer_dist ? o.kmer_dist[o.dist_base[b] + ((h << 15) | idx)] : value << (64 - m.k2);
+                        o.rel_counts[kb + r2] = cnt; o.colptr[kb + r2] = eb + e2;
                         ++r2; e2 += cnt;
                     }
                 }
@@ -1271,7 +1274,7 @@ static_assert(W2C_KPT * W2C_THREADS >= (int)W2_CAP, "every record has a register
 // (a bucket's size fluctuates with coverage x sqrt(distinct genomic k-mers in it): 1900 +- 280 instances on 40x reads of a 50 Mb genome cut into 2^20
 //  buckets — 3300 at five sigma, which 2^20 buckets do reach)
 __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const uint32_t *b2start, uint32_t nbuckets, int k2, int T, int PB, int rk, uint32_t lower, uint32_t upper,
-                                                        uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint64_t *wrel, uint64_t *ktmp)
+                                                        uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint64_t *wrel, uint64_t *ktmp, uint32_t *crowded)
 {
     constexpr uint32_t NW = W2C_THREADS / 64, NSB = 512, IPT = (W2_RELMAX + W2C_THREADS - 1) / W2C_THREADS, SPT = W2_SLOTS / W2C_THREADS;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem31[];
@@ -1330,7 +1333,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
         }
         lds_sync();
         if (__hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {      // more distinct k-mers than the table takes: a crowded bucket like one beyond W2_CAP records
-            if (tid == 0) { bN[b] = 0; bZ[b] = 0; atomicAdd(&gstat->ncrowded, 1u); }
+            if (tid == 0) { bN[b] = 0; bZ[b] = 0; crowded[atomicAdd(&gstat->ncrowded, 1u)] = b; }
             lds_sync();
             continue;
         }
@@ -1431,7 +1434,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
         Zb = carry;
         }
         if (Zb > ES_CAP_MAX) {      // (more kept entries than the emit kernels sort in LDS: given up like a bucket of too many distinct k-mers)
-            if (tid == 0) { bN[b] = 0; bZ[b] = 0; atomicAdd(&gstat->ncrowded, 1u); }
+            if (tid == 0) { bN[b] = 0; bZ[b] = 0; crowded[atomicAdd(&gstat->ncrowded, 1u)] = b; }
             lds_sync();
             continue;
         }
@@ -1469,6 +1472,63 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
     if (lane == 0) { if (st_distinct) atomicAdd(&gstat->distinct, st_distinct); if (st_sumsq) atomicAdd(&gstat->sumsq, st_sumsq); if (st_maxcol) atomicMax(&gstat->maxcol, st_maxcol); }
 }
 constexpr size_t W2C_LDS = ((size_t)2 * W2_SLOTS + W2_SLOTS + (W2_RELMAX + 1) + 512 + 513 + 2 * (W2C_THREADS / 64) + 8) * 4 + ((size_t)W2_SLOTS + 2 * W2_RELMAX) * 2 + 64;
+
+// ---- crowded buckets of the wide partition (round 5) -------------------------------------------------------------------------------------
+// A bucket k31_count gives up — more DISTINCT k-mers than its LDS table takes (a satellite array: 10^5 k-mers that share their leading bits), or more
+// kept entries than the emit kernels sort in LDS — used to send the WHOLE input to the sort of kmer.hip.  Now such buckets alone are taken out:
+//   k31_gather_crowded   their records, contiguous, as (k-mer, payload) pairs;
+//   radix_sort_pairs     sorted by the k-mer (prims.hip; buckets are value ranges: the sort keeps them together and in order);
+//   k31_crowded_heads / k31_crowded_words   every record gets its k-mer's RANK among the DISTINCT k-mers of its bucket, and a bucket is cut into PSEUDO-BUCKETS
+//                        of 2^16 distinct k-mers: a record becomes the one-word instance of the k <= 17 path, rank's low 16 bits << PB | payload;
+//   k_msd_count, k_msd_emit_small, k_msd_bucket   the k <= 17 kernels, unchanged, on the pseudo-buckets (any number of entries per pseudo-bucket: the windowed kernel);
+// their counts are folded into their bucket's before the scan over the buckets (k31_fold_pseudo), their k-mer id / entry bases follow from the bucket's
+// (k31_pseudo_bases).  A homopolymer (ONE k-mer, millions of records) never comes here: k31_count walks it in chunks.
+__global__ __launch_bounds__(256) void k31_gather_crowded(const Rec2 *recs, const uint32_t *b2start, const uint32_t *clist, const uint64_t *coff, uint32_t nc, uint64_t *keys, uint64_t *vals)
+{
+    for (uint32_t p = blockIdx.y; p < nc; p += gridDim.y) {
+        const uint32_t b = clist[p], s0 = b2start[b], n = b2start[b + 1] - s0;
+        const uint64_t at = coff[p];
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) { const Rec2 r = recs[s0 + i]; keys[at + i] = r.hi; vals[at + i] = r.lo; }
+    }
+}
+__global__ __launch_bounds__(256) void k31_crowded_heads(const uint64_t *keys, uint64_t n, uint32_t *head)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
+}
+// dpos[i] = heads in front of record i (exclusive scan of head); coff[p] = first record of crowded bucket p (a head); pbase[p] = its first pseudo-bucket
+__global__ __launch_bounds__(256) void k31_crowded_words(const uint64_t *keys, const uint64_t *vals, uint64_t n, const uint32_t *head, const uint32_t *dpos, const uint64_t *coff, const uint32_t *pbase,
+                                                        uint32_t nc, int k2, int PB, uint64_t *words, uint64_t *cdist, uint32_t *b2s, uint32_t *parent_of, uint32_t *dist_base)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t lo = 0, hi = nc;      // last p with coff[p] <= i
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= i) lo = mid; else hi = mid; }
+    const uint32_t h = head[i], d = dpos[i] + h - 1u, rank = d - dpos[coff[lo]];      // (the first record of a bucket is a head: its distinct index is dpos there)
+    words[i] = ((uint64_t)(rank & 0xFFFFu) << PB) | vals[i];
+    if (h) {
+        cdist[d] = keys[i] << (64 - k2);
+        if ((rank & 0xFFFFu) == 0u) { const uint32_t j = pbase[lo] + (rank >> 16); b2s[j] = (uint32_t)i; parent_of[j] = lo; dist_base[j] = d; }
+    }
+}
+__global__ void k_gather_u32_at(const uint32_t *src, const uint64_t *at, uint32_t n, uint32_t *dst)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[at[i]];
+}
+__global__ void k31_fold_pseudo(const uint32_t *bN2, const uint32_t *bZ2, const uint32_t *parent_of, const uint32_t *clist, uint32_t np, uint32_t *bN, uint32_t *bZ)
+{
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < np) { const uint32_t b = clist[parent_of[j]]; atomicAdd(&bN[b], bN2[j]); atomicAdd(&bZ[b], bZ2[j]); }
+}
+__global__ void k31_pseudo_bases(const uint32_t *kidbase, const uint32_t *entbase, const uint32_t *clist, const uint32_t *pbase, uint32_t nc, const uint32_t *bN2, const uint32_t *bZ2, uint32_t *kidbase2, uint32_t *entbase2)
+{
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nc) return;
+    const uint32_t b = clist[p];
+    uint32_t kn = kidbase[b], en = entbase[b];
+    for (uint32_t j = pbase[p]; j < pbase[p + 1]; ++j) { kidbase2[j] = kn; entbase2[j] = en; kn += bN2[j]; en += bZ2[j]; }
+}
 
 int bits_needed_u(uint64_t maxval)
 {
@@ -1632,6 +1692,9 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_msd_bucket<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ELBA_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k31_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     });
+    // pseudo-buckets of the wide partition's crowded buckets (the section above k31_gather_crowded)
+    struct { bool on = false; uint32_t nc = 0, np = 0; const uint64_t *words = nullptr; uint64_t *wrel = nullptr; uint32_t *b2s = nullptr, *bN = nullptr, *bZ = nullptr, *kidbase = nullptr, *entbase = nullptr, *crowded = nullptr;
+             BucketStats *gstat = nullptr; const uint32_t *clist = nullptr, *pbase = nullptr; const uint64_t *cdist = nullptr; const uint32_t *dist_base = nullptr; BucketStats hs{}; } ps;
     if (!wide) {
     const int shift2 = m.PB + vb;
     const uint32_t sgrid = c.opt.tune[0] == 1 ? 0xFFFFFFFFu : (uint32_t)c.num_cus * (MT_TILE <= 8192 ? 2u : 1u);      // (tune0 = 1: a workgroup per tile, as before round 5 — A/B)
@@ -1687,8 +1750,71 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
         // (the first pass's records are dead: the front half of their buffer takes the kept entries, one word each, the back half the buckets' reliable k-mers)
         hipLaunchKernelGGL(k31_count, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus)), dim3(W2C_THREADS), W2C_LDS, s, (const Rec2 *)rb, (const uint32_t *)b2start, nbuckets, k2, T, m.PB, m.rk,
-                           (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, bN, bZ, gstat, wa, wa + (I + 2));
+                           (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, bN, bZ, gstat, wa, wa + (I + 2), crowded);
         o.kmer_src = wa + (I + 2);
+        // buckets k31_count gave up (the section above k31_gather_crowded): taken out, sorted by k-mer, cut into pseudo-buckets of 2^16 distinct k-mers and
+        // counted by the k <= 17 kernel — their counts join their bucket's before the scan over the buckets
+        BucketStats hs0{};
+        ELBA_HIP(hipMemcpyAsync(&hs0, gstat, sizeof(hs0), hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        if (hs0.ncrowded) {
+            const uint32_t nc = hs0.ncrowded;
+            std::vector<uint32_t> clist(nc), hb2((size_t)nbuckets + 1);
+            ELBA_HIP(hipMemcpyAsync(clist.data(), crowded, (size_t)nc * 4, hipMemcpyDeviceToHost, s));
+            ELBA_HIP(hipMemcpyAsync(hb2.data(), b2start, ((size_t)nbuckets + 1) * 4, hipMemcpyDeviceToHost, s));
+            ELBA_HIP(hipStreamSynchronize(s));
+            std::sort(clist.begin(), clist.end());      // (bucket order = value order: what the sorted records follow)
+            std::vector<uint64_t> coff((size_t)nc + 1);
+            uint64_t Rc = 0;
+            for (uint32_t q = 0; q < nc; ++q) { coff[q] = Rc; Rc += hb2[clist[q] + 1] - hb2[clist[q]]; }
+            coff[nc] = Rc;
+            if (c.opt.trace) fprintf(stderr, "[elba] count_kmers: %u crowded buckets of the wide partition (%llu records) take the pseudo-bucket path\n", nc, (unsigned long long)Rc);
+            // workspace: two (key, value) buffer pairs for the sort, head flags + their scan, the distinct k-mers, the small per-bucket arrays
+            const size_t R8 = ((size_t)Rc + 8) * 8;
+            c.ws_g.reserve(4 * R8 + 2 * (((size_t)Rc + 8) * 4) + R8 + ((size_t)nc + 2) * 24 + 4096);
+            char *g0 = c.ws_g.as<char>();
+            uint64_t *ck0 = reinterpret_cast<uint64_t *>(g0), *cv0 = reinterpret_cast<uint64_t *>(g0 + R8), *ck1 = reinterpret_cast<uint64_t *>(g0 + 2 * R8), *cv1 = reinterpret_cast<uint64_t *>(g0 + 3 * R8);
+            uint32_t *head = reinterpret_cast<uint32_t *>(g0 + 4 * R8), *dpos = head + (Rc + 8);
+            uint64_t *cdist = reinterpret_cast<uint64_t *>(g0 + 4 * R8 + 2 * (((size_t)Rc + 8) * 4));
+            uint64_t *coff_d = reinterpret_cast<uint64_t *>(reinterpret_cast<char *>(cdist) + R8);
+            uint32_t *clist_d = reinterpret_cast<uint32_t *>(coff_d + (nc + 2)), *pbase_d = clist_d + (nc + 2), *dfirst_d = pbase_d + (nc + 2);
+            ELBA_HIP(hipMemcpyAsync(coff_d, coff.data(), ((size_t)nc + 1) * 8, hipMemcpyHostToDevice, s));
+            ELBA_HIP(hipMemcpyAsync(clist_d, clist.data(), (size_t)nc * 4, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k31_gather_crowded, dim3(64, (unsigned)std::min<uint32_t>(nc, 1024u)), dim3(256), 0, s, (const Rec2 *)rb, (const uint32_t *)b2start, (const uint32_t *)clist_d, (const uint64_t *)coff_d, nc, ck0, cv0);
+            const int where = radix_sort_pairs(s, ck0, cv0, ck1, cv1, (int64_t)Rc, 0, k2, c.ws_sort);      // (stable; the order inside a k-mer is the emit kernels' business)
+            uint64_t *sk = where ? ck1 : ck0, *sv = where ? cv1 : cv0, *words2 = where ? ck0 : ck1, *wrel2 = where ? cv0 : cv1;
+            hipLaunchKernelGGL(k31_crowded_heads, dim3((unsigned)((Rc + 255) / 256)), dim3(256), 0, s, (const uint64_t *)sk, Rc, head);
+            exclusive_scan_u32(s, head, dpos, (int64_t)Rc, c.ws_scan);
+            hipLaunchKernelGGL(k_gather_u32_at, dim3((nc + 255) / 256), dim3(256), 0, s, (const uint32_t *)dpos, (const uint64_t *)coff_d, nc, dfirst_d);
+            std::vector<uint32_t> dfirst((size_t)nc + 1);
+            uint32_t lasth = 0, lastd = 0;
+            ELBA_HIP(hipMemcpyAsync(dfirst.data(), dfirst_d, (size_t)nc * 4, hipMemcpyDeviceToHost, s));
+            ELBA_HIP(hipMemcpyAsync(&lasth, head + (Rc - 1), 4, hipMemcpyDeviceToHost, s));
+            ELBA_HIP(hipMemcpyAsync(&lastd, dpos + (Rc - 1), 4, hipMemcpyDeviceToHost, s));
+            ELBA_HIP(hipStreamSynchronize(s));
+            dfirst[nc] = lastd + lasth;      // distinct k-mers of all crowded buckets
+            std::vector<uint32_t> pbase((size_t)nc + 1);
+            uint32_t np = 0;
+            for (uint32_t q = 0; q < nc; ++q) { pbase[q] = np; np += (dfirst[q + 1] - dfirst[q] + 65535u) >> 16; }
+            pbase[nc] = np;
+            ELBA_HIP(hipMemcpyAsync(pbase_d, pbase.data(), ((size_t)nc + 1) * 4, hipMemcpyHostToDevice, s));
+            c.ws_h.reserve(((size_t)np + 4) * 4 * 9 + sizeof(BucketStats) + 256);
+            uint32_t *b2s = c.ws_h.as<uint32_t>() + 64, *parent_of = b2s + (np + 4), *dist_base = parent_of + (np + 4), *bN2 = dist_base + (np + 4), *bZ2 = bN2 + (np + 4),
+                     *kidbase2 = bZ2 + (np + 4), *entbase2 = kidbase2 + (np + 4), *crowded2 = entbase2 + (np + 4);
+            BucketStats *gstat2 = c.ws_h.as<BucketStats>();
+            static_assert(sizeof(BucketStats) <= 256, "the pseudo-buckets' statistics sit in front of their arrays");
+            hipLaunchKernelGGL(k31_crowded_words, dim3((unsigned)((Rc + 255) / 256)), dim3(256), 0, s, (const uint64_t *)sk, (const uint64_t *)sv, Rc, (const uint32_t *)head, (const uint32_t *)dpos, (const uint64_t *)coff_d,
+                               (const uint32_t *)pbase_d, nc, k2, m.PB, words2, cdist, b2s, parent_of, dist_base);
+            const uint32_t rc32 = (uint32_t)Rc;
+            ELBA_HIP(hipMemcpyAsync(b2s + np, &rc32, 4, hipMemcpyHostToDevice, s));
+            ELBA_HIP(hipMemsetAsync(gstat2, 0, sizeof(BucketStats), s));
+            const unsigned pgrid = (unsigned)std::min<uint32_t>(np, (uint32_t)c.num_cus);
+            if (m.rk) hipLaunchKernelGGL(k_msd_count<true>, dim3(pgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)words2, (const uint32_t *)b2s, np, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, small_cap, bN2, bZ2, gstat2, crowded2, wrel2);
+            else hipLaunchKernelGGL(k_msd_count<false>, dim3(pgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)words2, (const uint32_t *)b2s, np, m, (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, small_cap, bN2, bZ2, gstat2, crowded2, wrel2);
+            hipLaunchKernelGGL(k31_fold_pseudo, dim3((np + 255) / 256), dim3(256), 0, s, (const uint32_t *)bN2, (const uint32_t *)bZ2, (const uint32_t *)parent_of, (const uint32_t *)clist_d, np, bN, bZ);
+            ps.on = true; ps.nc = nc; ps.np = np; ps.words = words2; ps.wrel = wrel2; ps.b2s = b2s; ps.bN = bN2; ps.bZ = bZ2; ps.kidbase = kidbase2; ps.entbase = entbase2; ps.crowded = crowded2;
+            ps.gstat = gstat2; ps.clist = clist_d; ps.pbase = pbase_d; ps.cdist = cdist; ps.dist_base = dist_base;
+        }
     }
     ELBA_HIP(hipMemsetAsync(bN + nbuckets, 0, 4, s)); ELBA_HIP(hipMemsetAsync(bZ + nbuckets, 0, 4, s));
     exclusive_scan_u32(s, bN, kidbase, (int64_t)nbuckets + 1, c.ws_scan);
@@ -1700,14 +1826,14 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     ELBA_HIP(hipMemcpyAsync(&hs, gstat, sizeof(hs), hipMemcpyDeviceToHost, s));
     unsigned long long nbad = 0;
     if (tri) ELBA_HIP(hipMemcpyAsync(&nbad, one_seg + 4, 8, hipMemcpyDeviceToHost, s));
+    if (ps.on) {
+        ELBA_HIP(hipMemcpyAsync(&ps.hs, ps.gstat, sizeof(BucketStats), hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k31_pseudo_bases, dim3((ps.nc + 255) / 256), dim3(256), 0, s, (const uint32_t *)kidbase, (const uint32_t *)entbase, ps.clist, ps.pbase, ps.nc, (const uint32_t *)ps.bN, (const uint32_t *)ps.bZ, ps.kidbase, ps.entbase);
+    }
     ELBA_HIP(hipStreamSynchronize(s));
+    if (ps.on) { hs.distinct += ps.hs.distinct; hs.sumsq += ps.hs.sumsq; hs.maxcol = std::max(hs.maxcol, ps.hs.maxcol); }
     ELBA_REQUIRE(nbad == 0, ELBA_ERR_INVALID_ARG, "triple index out of range");
     const uint64_t N = h2[0], Z = h2[1];
-    if (wide && hs.ncrowded) {      // a bucket beyond what k31_count sorts in LDS (a repeat family, a homopolymer): the whole input takes the sort of kmer.hip
-        if (c.opt.trace) fprintf(stderr, "[elba] count_kmers: %u buckets of the wide partition hold more than %u instances: sorting instead\n", hs.ncrowded, W2_CAP);
-        c.t_b.stop(s); c.t_total.stop(s);
-        return false;
-    }
     if (tri && (hs.ncrowded || (int64_t)N != tri->N || Z != I)) {      // an empty column (the buckets number the columns they find), a bucket beyond the LDS sort: matrix.hip sorts
         if (c.opt.trace) fprintf(stderr, "[elba] set_kmer_matrix_device: %llu of %lld columns hold entries, %u crowded buckets: sorting instead\n", (unsigned long long)N, (long long)tri->N, hs.ncrowded);
         c.t_b.stop(s); c.t_total.stop(s);
@@ -1759,7 +1885,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         // Slots are drawn a chunk at a time per workgroup and a chunk's tail may stay unused (a bucket that needs more than what is left takes a new
         // chunk, or exactly what it needs when that is more than a chunk): the store is sized for every column + one chunk per workgroup + the
         // largest single draw a workgroup can leave behind — the slots can never run past it.
-        const uint64_t nwg = (uint64_t)grid8 + grid16 + grid32;
+        const uint64_t nwg = (uint64_t)grid8 + grid16 + grid32 + (ps.on ? 3ull * std::min<uint32_t>(ps.np, (uint32_t)c.num_cus * 24u) : 0ull);
         const uint32_t chunk = (uint32_t)std::max<uint64_t>(64, std::min<uint64_t>(4096, N / (4 * nwg)));
         // (a chunk's tail stays unused when the next bucket needs more than what is left: a quarter more than the columns covers every read set seen —
         //  ~4 % are wasted on BASELINE config 3 —; a draw past the store is refused on the device and the emit repeated without slots)
@@ -1801,8 +1927,37 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         if (hs.ncrowded && !wide)
             hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m,
                                (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, (const uint32_t *)crowded, (const BucketStats *)gstat, (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+        if (ps.on) {
+            // the pseudo-buckets of the wide partition's crowded buckets: the same kernels on their own bucket table; the k-mer of a column is looked up by its rank among the distinct ones
+            BucketOut o2 = o;
+            o2.kmer_src = nullptr; o2.kmer_dist = ps.cdist; o2.dist_base = ps.dist_base; o2.ncols = ps.bN;
+            const uint32_t np = ps.np, g8 = std::min<uint32_t>(np, (uint32_t)c.num_cus * 24u), g16 = std::min<uint32_t>(np, (uint32_t)c.num_cus * 12u), g32 = std::min<uint32_t>(np, (uint32_t)c.num_cus * 4u);
+            if (cap8) hipLaunchKernelGGL((k_msd_emit_small<8>), dim3(g8), dim3(256), 0, s, (const uint64_t *)ps.wrel, (const uint32_t *)ps.b2s, (const uint32_t *)ps.bZ, np, m, 0u, cap8, (const uint32_t *)ps.kidbase, (const uint32_t *)ps.entbase, o2);
+            if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<8, 512>), dim3(g16), dim3(512), 0, s, (const uint64_t *)ps.wrel, (const uint32_t *)ps.b2s, (const uint32_t *)ps.bZ, np, m, cap8, cap16, (const uint32_t *)ps.kidbase, (const uint32_t *)ps.entbase, o2);
+            if (small_cap > 4096u && ps.hs.nmid)
+                hipLaunchKernelGGL((k_msd_emit_small<8, 1024>), dim3(g32), dim3(1024), 0, s, (const uint64_t *)ps.wrel, (const uint32_t *)ps.b2s, (const uint32_t *)ps.bZ, np, m, 4096u, std::min(small_cap, 8192u), (const uint32_t *)ps.kidbase, (const uint32_t *)ps.entbase, o2);
+            if (small_cap > 8192u && ps.hs.nbig)
+                hipLaunchKernelGGL((k_msd_emit_small<12, 1024>), dim3(g32), dim3(1024), 0, s, (const uint64_t *)ps.wrel, (const uint32_t *)ps.b2s, (const uint32_t *)ps.bZ, np, m, 8192u, small_cap, (const uint32_t *)ps.kidbase, (const uint32_t *)ps.entbase, o2);
+            if (ps.hs.ncrowded)
+                hipLaunchKernelGGL((k_msd_bucket<true>), dim3((unsigned)std::min<uint32_t>(ps.hs.ncrowded, (uint32_t)c.num_cus)), dim3(BK_THREADS), BK_LDS_EMIT, s, ps.words, (const uint32_t *)ps.b2s, np, m,
+                                   (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, (const uint32_t *)ps.crowded, (const BucketStats *)ps.gstat, (const uint32_t *)ps.kidbase, (const uint32_t *)ps.entbase, o2);
+        }
     };
+    const bool mprep = c.opt.measure_prep && !pairs && words && !(hs.ncrowded && !wide);      // (the crowded-bucket kernel still reads the partition's buffer)
+    c.prep_us = -1; c.emit_us = -1;
+    if (mprep) c.t_emit.start(s);
     launch_emit();
+    if (mprep) {
+        // (diagnostic) the same kernels once more, without what they write for the SpGEMM's sake alone: no hint bits, no inline partners, no padded column
+        // store / gather slots — the columns, k-mers and counts are rewritten with what they hold, the sort keys go to the partition's dead buffer
+        c.t_emit.stop(s);
+        const BucketOut keep = o;
+        o.hints = 0; o.inl = 0; o.ell = nullptr; o.ell_stride = 0; o.compact = 0; o.csr_words = tri ? wa : wb;
+        c.t_emit_plain.start(s);
+        launch_emit();
+        c.t_emit_plain.stop(s);
+        o = keep;
+    }
     const uint32_t Zz = (uint32_t)Z;
     ELBA_HIP(hipMemcpyAsync(c.a_colptr.as<uint32_t>() + N, &Zz, 4, hipMemcpyHostToDevice, s));
     c.prod_ctr.reserve(64 * 128);
@@ -1814,6 +1969,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     c.t_b.stop(s);
     c.t_total.stop(s);
     ELBA_HIP(hipStreamSynchronize(s));
+    if (mprep) { const float a = c.t_emit.ms(), b = c.t_emit_plain.ms(); c.emit_us = (int64_t)(a * 1000.0f); c.prep_us = (int64_t)((a - b) * 1000.0f); }
     if (compact && slots[1] != 0) {
         // more chunk tails were left unused than the store has room for (never seen; a draw past it writes nothing): every column gets the place
         // of its k-mer id after all — the emit once more, without slots

@@ -420,6 +420,184 @@ int orc_count_and_build(orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off
 }
 
 /*
+ * The same on `nthreads` host threads (bench.py's all-cores CPU figure for the k-mer stage; the one-thread function above stays the plain statement
+ * and tests/test_oracle_golden.py holds the two against each other).  Same algorithm, cut by k-mer VALUE: reads are split into contiguous ranges
+ * (one per thread, balanced on instances); every thread counts, then writes, its instances into 256 buckets by the leading 8 value bits — thread t's
+ * share of a bucket lies behind thread t-1's, so a bucket holds its instances in (read, pos) order as the one-thread pass does; buckets are sorted
+ * (the same stable LSD sort), run-length counted and emitted independently; k-mer ids and column pointers come from a prefix over the buckets.  CSR: the
+ * same stable counting transpose, columns split over the threads with per-thread row counts.
+ */
+int orc_count_and_build_mt(orc_ctx *c, const uint8_t *buf, const uint64_t *byte_off, const uint32_t *lens, int64_t nreads, int nthreads)
+{
+    if (nthreads <= 1) return orc_count_and_build(c, buf, byte_off, lens, nreads);
+    orc_free_A(c); orc_free_B(c);
+    const int k = c->k, T = nthreads;
+    enum { NBK = 256 };
+    c->M = nreads;
+    int64_t I = 0;
+    uint32_t maxlen = 0;
+    for (int64_t r = 0; r < nreads; ++r) { if ((int64_t)lens[r] >= k) I += (int64_t)lens[r] - k + 1; if (lens[r] > maxlen) maxlen = lens[r]; }
+    c->I = I;
+    orc_inst_t *a = (orc_inst_t *)malloc((size_t)(I > 0 ? I : 1) * sizeof(orc_inst_t));
+    orc_inst_t *b = (orc_inst_t *)malloc((size_t)(I > 0 ? I : 1) * sizeof(orc_inst_t));
+    int64_t *rbound = (int64_t *)malloc((size_t)(T + 1) * sizeof(int64_t));          /* read ranges of the threads */
+    int64_t *cnt = (int64_t *)calloc((size_t)T * NBK, sizeof(int64_t));              /* [thread][bucket] */
+    int64_t *bstart = (int64_t *)calloc(NBK + 1, sizeof(int64_t));
+    if (!a || !b || !rbound || !cnt || !bstart) { free(a); free(b); free(rbound); free(cnt); free(bstart); return -1; }
+    {
+        int64_t acc = 0; int t = 0;
+        rbound[0] = 0;
+        for (int64_t r = 0; r < nreads; ++r) {
+            if ((int64_t)lens[r] >= k) acc += (int64_t)lens[r] - k + 1;
+            while (t + 1 < T && acc >= (I * (t + 1)) / T && r + 1 <= nreads) rbound[++t] = r + 1;
+        }
+        while (t < T) rbound[++t] = nreads;
+    }
+#define ORC_BK(w0) ((int)((w0) >> 56))
+    int fail = 0;
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        uint64_t *scratch = (uint64_t *)malloc((size_t)(maxlen + 1) * sizeof(uint64_t));
+        if (!scratch) {
+#pragma omp atomic write
+            fail = 1;
+        }
+#pragma omp barrier
+        if (!fail) {
+            int64_t *mycnt = cnt + (size_t)t * NBK;
+            for (int64_t r = rbound[t]; r < rbound[t + 1]; ++r) {
+                if (k > 32) {
+                    const int64_t n = (int64_t)lens[r] >= k ? (int64_t)lens[r] - k + 1 : 0;
+                    for (int64_t p = 0; p < n; ++p) { uint64_t w[3]; orc_kmerN_at(buf + byte_off[r], (size_t)p, k, w); mycnt[ORC_BK(w[0])]++; }
+                } else {
+                    const int64_t n = orc_read_kmers(buf + byte_off[r], lens[r], k, scratch);
+                    for (int64_t p = 0; p < n; ++p) mycnt[ORC_BK(scratch[p])]++;
+                }
+            }
+        }
+#pragma omp barrier
+#pragma omp single
+        {
+            int64_t run = 0;
+            for (int bk = 0; bk < NBK; ++bk) {
+                bstart[bk] = run;
+                for (int tt = 0; tt < T; ++tt) { const int64_t x = cnt[(size_t)tt * NBK + bk]; cnt[(size_t)tt * NBK + bk] = run; run += x; }      /* cnt becomes the write cursor */
+            }
+            bstart[NBK] = run;
+        }
+        if (!fail) {
+            int64_t *cur = cnt + (size_t)t * NBK;
+            for (int64_t r = rbound[t]; r < rbound[t + 1]; ++r) {
+                if (k > 32) {
+                    const int64_t n = (int64_t)lens[r] >= k ? (int64_t)lens[r] - k + 1 : 0;
+                    for (int64_t p = 0; p < n; ++p) {
+                        uint64_t w[3]; orc_kmerN_at(buf + byte_off[r], (size_t)p, k, w);
+                        orc_inst_t *d = &a[cur[ORC_BK(w[0])]++];
+                        d->kmer = w[0]; d->kmer2 = w[1]; d->kmer3 = w[2]; d->read = (uint32_t)r; d->pos = (uint32_t)p;
+                    }
+                } else {
+                    const int64_t n = orc_read_kmers(buf + byte_off[r], lens[r], k, scratch);
+                    for (int64_t p = 0; p < n; ++p) {
+                        orc_inst_t *d = &a[cur[ORC_BK(scratch[p])]++];
+                        d->kmer = scratch[p]; d->kmer2 = 0; d->kmer3 = 0; d->read = (uint32_t)r; d->pos = (uint32_t)p;
+                    }
+                }
+            }
+        }
+        free(scratch);
+    }
+    if (fail) { free(a); free(b); free(rbound); free(cnt); free(bstart); return -1; }
+    /* every bucket on its own: sort (the number of passes does not depend on the bucket: all of them end in the same buffer), count */
+    int64_t bN[NBK + 1], bZ[NBK + 1], bD[NBK];
+    int64_t *hists = (int64_t *)calloc((size_t)NBK * ((size_t)c->upper + 2), sizeof(int64_t));
+    orc_inst_t *sorted_in = NULL;
+#pragma omp parallel for num_threads(T) schedule(dynamic, 1)
+    for (int bk = 0; bk < NBK; ++bk) {
+        const int64_t n = bstart[bk + 1] - bstart[bk];
+        orc_inst_t *s = orc_sort_instances(a + bstart[bk], b + bstart[bk], n, k);
+        if (bk == 0) sorted_in = (s == a + bstart[bk]) ? a : b;
+        int64_t N = 0, Z = 0, nd = 0;
+        for (int64_t i = 0; i < n; ) {
+            int64_t j = i + 1;
+            while (j < n && s[j].kmer == s[i].kmer && s[j].kmer2 == s[i].kmer2 && s[j].kmer3 == s[i].kmer3) ++j;
+            const int64_t cn = j - i;
+            ++nd;
+            if (cn >= c->lower && cn <= c->upper) { ++N; Z += cn; hists[(size_t)bk * ((size_t)c->upper + 2) + (size_t)cn]++; }
+            i = j;
+        }
+        bN[bk] = N; bZ[bk] = Z; bD[bk] = nd;
+    }
+    int64_t N = 0, Z = 0, nd = 0;
+    for (int bk = 0; bk < NBK; ++bk) { const int64_t x = bN[bk], y = bZ[bk]; bN[bk] = N; bZ[bk] = Z; N += x; Z += y; nd += bD[bk]; }
+    bN[NBK] = N; bZ[NBK] = Z;
+    c->N = N; c->Z = Z; c->ndistinct = nd;
+    c->hist = (int64_t *)calloc((size_t)c->upper + 2, sizeof(int64_t));
+    for (int bk = 0; bk < NBK; ++bk) for (int64_t q = 0; q < (int64_t)c->upper + 2; ++q) c->hist[q] += hists[(size_t)bk * ((size_t)c->upper + 2) + (size_t)q];
+    free(hists);
+    c->kmers = (uint64_t *)malloc((size_t)(N + 1) * sizeof(uint64_t));
+    c->kmers_lo = k > 32 ? (uint64_t *)malloc((size_t)(N + 1) * sizeof(uint64_t)) : NULL;
+    c->kmers_lo2 = k > 64 ? (uint64_t *)malloc((size_t)(N + 1) * sizeof(uint64_t)) : NULL;
+    c->colptr = (int64_t *)malloc((size_t)(N + 1) * sizeof(int64_t));
+    c->csc_read = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->csc_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->rowptr = (int64_t *)calloc((size_t)(nreads + 2), sizeof(int64_t));
+    c->csr_kid = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    c->csr_pos = (uint32_t *)malloc((size_t)(Z + 1) * sizeof(uint32_t));
+    const orc_inst_t *sall = sorted_in ? sorted_in : a;
+#pragma omp parallel for num_threads(T) schedule(dynamic, 1)
+    for (int bk = 0; bk < NBK; ++bk) {
+        const int64_t n = bstart[bk + 1] - bstart[bk];
+        const orc_inst_t *s = sall + bstart[bk];
+        int64_t kid = bN[bk], e = bZ[bk];
+        for (int64_t i = 0; i < n; ) {
+            int64_t j = i + 1;
+            while (j < n && s[j].kmer == s[i].kmer && s[j].kmer2 == s[i].kmer2 && s[j].kmer3 == s[i].kmer3) ++j;
+            const int64_t cn = j - i;
+            if (cn >= c->lower && cn <= c->upper) {
+                c->kmers[kid] = s[i].kmer;
+                if (c->kmers_lo) c->kmers_lo[kid] = s[i].kmer2;
+                if (c->kmers_lo2) c->kmers_lo2[kid] = s[i].kmer3;
+                c->colptr[kid] = e;
+                for (int64_t t2 = i; t2 < j; ++t2) { c->csc_read[e] = s[t2].read; c->csc_pos[e] = s[t2].pos; ++e; }
+                ++kid;
+            }
+            i = j;
+        }
+    }
+    c->colptr[N] = Z;
+    free(a); free(b); free(rbound); free(cnt); free(bstart);
+    /* CSR: stable counting transpose, columns split over the threads (thread t's entries of a row lie behind those of the threads before it) */
+    int64_t *rc = (int64_t *)calloc((size_t)T * (size_t)(nreads + 1), sizeof(int64_t));
+    if (!rc) return -1;
+#pragma omp parallel num_threads(T)
+    {
+        const int t = omp_get_thread_num();
+        const int64_t k0 = N * t / T, k1 = N * (t + 1) / T;
+        int64_t *mine = rc + (size_t)t * (size_t)(nreads + 1);
+        for (int64_t e = c->colptr[k0]; e < c->colptr[k1]; ++e) mine[c->csc_read[e]]++;
+#pragma omp barrier
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < nreads; ++r) { int64_t tot = 0; for (int tt = 0; tt < T; ++tt) tot += rc[(size_t)tt * (size_t)(nreads + 1) + (size_t)r]; c->rowptr[r + 1] = tot; }
+#pragma omp single
+        { for (int64_t r = 0; r < nreads; ++r) c->rowptr[r + 1] += c->rowptr[r]; }
+#pragma omp for schedule(static)
+        for (int64_t r = 0; r < nreads; ++r) {
+            int64_t run = c->rowptr[r];
+            for (int tt = 0; tt < T; ++tt) { int64_t *x = &rc[(size_t)tt * (size_t)(nreads + 1) + (size_t)r]; const int64_t v = *x; *x = run; run += v; }
+        }
+        for (int64_t kk = k0; kk < k1; ++kk)
+            for (int64_t e = c->colptr[kk]; e < c->colptr[kk + 1]; ++e) {
+                const int64_t d = mine[c->csc_read[e]]++;
+                c->csr_kid[d] = (uint32_t)kk; c->csr_pos[d] = c->csc_pos[e];
+            }
+    }
+    free(rc);
+    return 0;
+}
+#undef ORC_BK
+
+/*
  * Alternative entry for a13 alone: take A as triples (row, col, val) — what create_seed_matrix's caller holds
  * (src/KmerOps.cpp:380-400 emits exactly such triples) — and build CSC/CSR with the canonical entry order:
  * within a column by (row,val), within a row by (col,val).  Duplicates kept.

@@ -71,6 +71,8 @@ def lib():
         L.orc_destroy.argtypes = [C.c_void_p]
         L.orc_count_and_build.restype = C.c_int
         L.orc_count_and_build.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+        L.orc_count_and_build_mt.restype = C.c_int
+        L.orc_count_and_build_mt.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
         L.orc_set_triples.restype = C.c_int
         L.orc_set_triples.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_set_csc.restype = C.c_int
@@ -170,11 +172,15 @@ class Oracle:
     def stat(self, name):
         return int(self.L.orc_get_i64(self.h, self.STAT[name]))
 
-    def count_and_build(self, buf, off, lens):
+    def count_and_build(self, buf, off, lens, nthreads=1):
+        """reads -> A (both orientations); nthreads > 1: the same result on that many host threads (orc_count_and_build_mt)"""
         buf = np.ascontiguousarray(buf, dtype=np.uint8)
         off = np.ascontiguousarray(off, dtype=np.uint64)
         lens = np.ascontiguousarray(lens, dtype=np.uint32)
-        rc = self.L.orc_count_and_build(self.h, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens))
+        if nthreads > 1:
+            rc = self.L.orc_count_and_build_mt(self.h, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens), int(nthreads))
+        else:
+            rc = self.L.orc_count_and_build(self.h, buf.ctypes.data, off.ctypes.data, lens.ctypes.data, len(lens))
         if rc:
             raise RuntimeError("orc_count_and_build failed: %d" % rc)
 

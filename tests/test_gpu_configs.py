@@ -20,6 +20,7 @@ import pytest
 
 import elba_amd
 from oracle import pyoracle as po
+import gpu_util as gu
 
 pytestmark = pytest.mark.gpu
 
@@ -248,6 +249,9 @@ def test_baseline_config_properties_and_sampled_rows(name):
     nk, nr = _A_equals_oracle_on_value_classes(e, packed, off, lens, k, w["L"], w["U"])
     assert nk > 1000 and nr >= 100
     assert _sampled_rows_equal_oracle(e, B, k, w["L"], w["U"], w["nsample"]) >= min(50, w["nsample"])
+    # ... and EVERY entry of B against the oracle's product of the same A (round 5: what bench.py does for the headline matrix — 98.7 M entries on
+    # config 3, 10.8 G products on config 5 at 1/25 — as a test; the oracle's left fold on every host core the box gives this process)
+    assert gu.assert_whole_B_equals_oracle(e, k, w["L"], w["U"], st) == B["Y"]
     # a second call, cold (nothing remembered), returns the identical matrix
     e.set_option("overlap_cold_calls", 1)
     st2 = e.create_seed_matrix()

@@ -1,6 +1,6 @@
 """-m gpu: BASELINE.json configs[1] at FULL size (the bench workload: 16 893 reads, 138.9 M k-mer instances) checked through
-size-independent properties of the domain — the oracle would need ~30 s of CPU for the k-mer stage at this size, so here it only
-judges sampled seeds:
+size-independent properties of the domain (the oracle's k-mer stage would need ~30 s of one core at this size) AND, since round 5, every entry of B
+against the oracle's product of the GPU-built A (test_every_entry_of_B_equals_the_oracle):
   * pattern symmetry and numshared symmetry (B = A·Aᵀ),  Y = diag + 2·strict-upper,  columns strictly ascending in every row;
   * every stored seed names the same k-mer in both reads, forward or reverse complement (the reference's test.py:57-65);
   * seeds[0] <= seeds[1] in the canonical order when both lie on one k-mer id is not observable, but seeds[0] == seeds[1] iff ... numshared >= 2 always;
@@ -36,6 +36,13 @@ def test_counts_are_consistent(full):
     h = full["e"].kmer_histogram()
     assert h[:2].sum() == 0 and h.sum() == ks["reliable"] and int((h * np.arange(len(h))).sum()) == ks["entries"]
     assert st["products"] == int((h * np.arange(len(h)) ** 2).sum())          # P = sum_k c_k^2
+
+
+def test_every_entry_of_B_equals_the_oracle(full):
+    """BASELINE configs[1] WHOLE, entry by entry (round 5): the oracle multiplies the very matrix the GPU built (its columns, copied off the device) on the
+    host's cores — 42 M products — and every row pointer, column and seed field of the GPU's B is compared with it."""
+    import gpu_util as gu
+    assert gu.assert_whole_B_equals_oracle(full["e"], 17, 2, 8, full["st"]) == full["B"]["Y"]
 
 
 def test_pattern_and_numshared_are_symmetric_and_rows_sorted(full):

@@ -791,15 +791,61 @@ def test_wide_partition_kmer_path_equals_the_oracle(k, lo, up, bits):
 
 
 def test_wide_partition_gives_up_a_bucket_of_too_many_distinct_kmers():
-    """Few buckets ("msd_wide_bits" = 2: four of them) on noisy reads: a bucket of at most 4096 instances can still hold more distinct k-mers than
-    the count table takes — the bucket is given up like a crowded one (the whole input takes the sort), nothing hangs, same matrices."""
+    """Random reads cut into FOUR buckets (msd_wide_bits = 2): every bucket holds more distinct k-mers than k31_count's LDS table takes.  Round 4 sent the
+    whole input to the sort of kmer.hip; since round 5 such buckets ALONE are taken out, sorted by k-mer and cut into pseudo-buckets of 2^16 distinct
+    k-mers that the k <= 17 bucket kernels count and emit (kmer_msd.hip: k31_gather_crowded ...): the input stays on the partition path, same matrices."""
     reads, _ = synth.make_reads(9, 3700, 5, 600, 100, error=0.10, min_len=100)
     packed, off, lens = po.pack_reads(list(reads))
     e, ks, ms, st = gu.gpu_full(packed, off, lens, 31, 2, 8, options={"kmer_msd": 1, "msd_wide_bits": 2})
     o = gu.oracle_run(packed, off, lens, 31, 2, 8, threads=8)
-    assert 3300 * 4 < ks["instances"] < 4000 * 4 and ks["distinct"] > 3200 * 4 and e.get_stat("kmer_path") == 0      # (buckets of < 4096 instances, > 3072 of them distinct)
+    assert 3300 * 4 < ks["instances"] < 4000 * 4 and ks["distinct"] > 3200 * 4 and e.get_stat("kmer_path") == 2      # (buckets of < 4096 instances, > 3072 of them distinct)
+    assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
+    e.close()
+
+
+@pytest.mark.parametrize("lo,up", [(2, 8), (2, 40)])
+def test_wide_partition_keeps_a_satellite_bucket_and_a_homopolymer_on_the_partition_path(lo, up):
+    """What a real genome brings (task 3): a SATELLITE — 10^5 distinct 31-mers that share their ten leading bases, three (or more) copies of each: one
+    bucket of 3.6 * 10^5 records, 10^5 of them distinct, two pseudo-buckets — plus a HOMOPOLYMER (one k-mer, 24 000 records: walked in chunks by k31_count),
+    on top of ordinary reads.  The input stays on the wide partition path (kmer_path == 2), equals the oracle entry for entry — also with UPPER = 40, where
+    the matrix is dense and the satellite's columns are kept — and the stage takes at most 1.3 x what it takes without the two."""
+    rng = np.random.default_rng(77)
+    reads, _ = synth.make_reads(17, 400000, 12, 2500, 600, error=0.04, min_len=100)
+    base = list(reads)
+    bases = np.frombuffer(b"ACGT", dtype=np.uint8)
+    tails = bases[rng.integers(0, 4, size=(100000, 21))]
+    sat = [b"A" * 10 + t.tobytes() for t in tails]                  # canonical = forward (it starts with ten A): all of them in the lowest bucket
+    copies = [sat[i] for i in rng.integers(0, len(sat), size=60000)]
+    extra = sat * 3 + copies + [b"C" * 630] * 40                     # every satellite k-mer 3-6 times; 40 x 600 instances of CCC...C
+    k = 31
+
+    def run(seqs):
+        packed, off, lens = po.pack_reads(seqs)
+        e = elba_amd.Engine(k, lo, up, options={"kmer_msd": 1})
+        e.set_reads(packed, off, lens)
+        e.count_kmers(); e.create_kmer_matrix()                      # allocations
+        best = None
+        for _ in range(3):
+            ks = e.count_kmers()
+            best = ks["ms_total"] if best is None else min(best, ks["ms_total"])
+        e.create_kmer_matrix()
+        return e, ks, best, (packed, off, lens)
+
+    e0, ks0, t_clean, _ = run(base)
+    assert e0.get_stat("kmer_path") == 2
+    e0.close()
+    e, ks, t_sat, (packed, off, lens) = run(base + extra)
+    assert e.get_stat("kmer_path") == 2
+    st = e.create_seed_matrix()
+    o = gu.oracle_run(packed, off, lens, k, lo, up, threads=8)
+    assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
+    assert ks["reliable"] >= ks0["reliable"] + 100000                # the satellite's k-mers are kept (3-6 copies each)
+    gu.assert_A_equal(e.export_kmer_matrix(), o.A())
+    gu.assert_B_equal(e.export_csr(), o.B())
+    gu.assert_stats_equal(st, o)
+    assert t_sat <= 1.3 * t_clean + 0.5, (t_sat, t_clean)            # (ms; half a millisecond for the three host round trips of the pseudo-bucket path on this small input)
     e.close()
 
 

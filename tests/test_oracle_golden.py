@@ -359,3 +359,27 @@ def test_reference_default_build_numbering_k31():
     Bc, Br = oc.B(), orf.B()
     assert (Bc["rowptr"] == Br["rowptr"]).all() and (Bc["col"] == Br["col"]).all() and (Bc["val"]["numshared"] == Br["val"]["numshared"]).all()
     assert (Bc["val"] != Br["val"]).any()
+
+
+@pytest.mark.parametrize("k,lo,up,threads", [(17, 2, 8, 2), (17, 2, 8, 7), (31, 3, 30, 4), (33, 2, 8, 3), (65, 2, 8, 5), (9, 2, 60, 8)])
+def test_the_oracles_kmer_stage_on_several_threads_equals_the_one_thread_statement(k, lo, up, threads):
+    """orc_count_and_build_mt (bench.py's all-cores CPU figure for the k-mer stage: reads split over the threads, 256 value buckets sorted and counted
+    independently) against the plain one-thread restatement of a7-a10: every array of A, the count histogram and the counters — including reads
+    shorter than k, empty reads and more threads than reads would fill."""
+    import elba_amd
+    packed, off, lens, info = elba_amd.synth_reads(100 + k, 120000, 15, 1500, 900, error_rate=0.07, min_len=5)
+    o1 = po.Oracle(k, lo, up); o1.count_and_build(packed, off, lens)
+    o2 = po.Oracle(k, lo, up); o2.count_and_build(packed, off, lens, threads)
+    A1, A2 = o1.A(), o2.A()
+    for key in A1:
+        if isinstance(A1[key], np.ndarray):
+            assert np.array_equal(A1[key], A2[key]), key
+        else:
+            assert A1[key] == A2[key], key
+    assert all(o1.stat(s) == o2.stat(s) for s in ("I", "N", "Z", "ndistinct", "M"))
+    o1.spgemm(2); o2.spgemm(2)
+    assert o1.stat("Y") == o2.stat("Y") and o1.stat("P") == o2.stat("P")
+    # a handful of reads on many threads (most threads hold no read)
+    o3 = po.Oracle(k, lo, up); o3.count_and_build(packed, off[:5], lens[:5], 16)
+    o4 = po.Oracle(k, lo, up); o4.count_and_build(packed, off[:5], lens[:5])
+    assert o3.stat("N") == o4.stat("N") and o3.stat("Z") == o4.stat("Z") and np.array_equal(o3.A()["csr_kid"], o4.A()["csr_kid"])
