@@ -1479,7 +1479,7 @@ constexpr size_t W2C_LDS = ((size_t)2 * W2_SLOTS + W2_SLOTS + (W2_RELMAX + 1) + 
 //   k31_gather_crowded   their records, contiguous, as (k-mer, payload) pairs;
 //   radix_sort_pairs     sorted by the k-mer (prims.hip; buckets are value ranges: the sort keeps them together and in order);
 //   k31_crowded_heads / k31_crowded_words   every record gets its k-mer's RANK among the DISTINCT k-mers of its bucket, and a bucket is cut into PSEUDO-BUCKETS
-//                        of 2^16 distinct k-mers: a record becomes the one-word instance of the k <= 17 path, rank's low 16 bits << PB | payload;
+//                        of up to 2^16 distinct k-mers (as many as make ~4096 records): a record becomes the one-word instance of the k <= 17 path, rank's low 16 bits << PB | payload;
 //   k_msd_count, k_msd_emit_small, k_msd_bucket   the k <= 17 kernels, unchanged, on the pseudo-buckets (any number of entries per pseudo-bucket: the windowed kernel);
 // their counts are folded into their bucket's before the scan over the buckets (k31_fold_pseudo), their k-mer id / entry bases follow from the bucket's
 // (k31_pseudo_bases).  A homopolymer (ONE k-mer, millions of records) never comes here: k31_count walks it in chunks.
@@ -1498,17 +1498,18 @@ __global__ __launch_bounds__(256) void k31_crowded_heads(const uint64_t *keys, u
 }
 // dpos[i] = heads in front of record i (exclusive scan of head); coff[p] = first record of crowded bucket p (a head); pbase[p] = its first pseudo-bucket
 __global__ __launch_bounds__(256) void k31_crowded_words(const uint64_t *keys, const uint64_t *vals, uint64_t n, const uint32_t *head, const uint32_t *dpos, const uint64_t *coff, const uint32_t *pbase,
-                                                        uint32_t nc, int k2, int PB, uint64_t *words, uint64_t *cdist, uint32_t *b2s, uint32_t *parent_of, uint32_t *dist_base)
+                                                        uint32_t nc, int k2, int PB, uint32_t pshift, uint64_t *words, uint64_t *cdist, uint32_t *b2s, uint32_t *parent_of, uint32_t *dist_base)
 {
+    const uint32_t pmask = (1u << pshift) - 1u;      // a pseudo-bucket holds 2^pshift distinct k-mers (<= 2^16: the value field of the k <= 17 kernels)
     const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     uint32_t lo = 0, hi = nc;      // last p with coff[p] <= i
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (coff[mid] <= i) lo = mid; else hi = mid; }
     const uint32_t h = head[i], d = dpos[i] + h - 1u, rank = d - dpos[coff[lo]];      // (the first record of a bucket is a head: its distinct index is dpos there)
-    words[i] = ((uint64_t)(rank & 0xFFFFu) << PB) | vals[i];
+    words[i] = ((uint64_t)(rank & pmask) << PB) | vals[i];
     if (h) {
         cdist[d] = keys[i] << (64 - k2);
-        if ((rank & 0xFFFFu) == 0u) { const uint32_t j = pbase[lo] + (rank >> 16); b2s[j] = (uint32_t)i; parent_of[j] = lo; dist_base[j] = d; }
+        if ((rank & pmask) == 0u) { const uint32_t j = pbase[lo] + (rank >> pshift); b2s[j] = (uint32_t)i; parent_of[j] = lo; dist_base[j] = d; }
     }
 }
 __global__ void k_gather_u32_at(const uint32_t *src, const uint64_t *at, uint32_t n, uint32_t *dst)
@@ -1793,9 +1794,13 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
             ELBA_HIP(hipMemcpyAsync(&lastd, dpos + (Rc - 1), 4, hipMemcpyDeviceToHost, s));
             ELBA_HIP(hipStreamSynchronize(s));
             dfirst[nc] = lastd + lasth;      // distinct k-mers of all crowded buckets
+            // a pseudo-bucket holds 2^pshift distinct k-mers: as many as make ~4096 records at the crowded buckets' average multiplicity (a satellite at 3-6
+            // copies: 1024 k-mers; HiFi coverage, every genomic k-mer ~34 times: 64) — one workgroup counts a pseudo-bucket, the emit kernels sort <= 12288 entries in LDS
+            uint32_t pshift = 16;
+            { const uint64_t D = std::max<uint32_t>(dfirst[nc], 1u); while (pshift > 4 && ((Rc << pshift) / D) > 4096) --pshift; }
             std::vector<uint32_t> pbase((size_t)nc + 1);
             uint32_t np = 0;
-            for (uint32_t q = 0; q < nc; ++q) { pbase[q] = np; np += (dfirst[q + 1] - dfirst[q] + 65535u) >> 16; }
+            for (uint32_t q = 0; q < nc; ++q) { pbase[q] = np; np += (uint32_t)(((uint64_t)(dfirst[q + 1] - dfirst[q]) + (1u << pshift) - 1u) >> pshift); }
             pbase[nc] = np;
             ELBA_HIP(hipMemcpyAsync(pbase_d, pbase.data(), ((size_t)nc + 1) * 4, hipMemcpyHostToDevice, s));
             c.ws_h.reserve(((size_t)np + 4) * 4 * 9 + sizeof(BucketStats) + 256);
@@ -1804,7 +1809,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
             BucketStats *gstat2 = c.ws_h.as<BucketStats>();
             static_assert(sizeof(BucketStats) <= 256, "the pseudo-buckets' statistics sit in front of their arrays");
             hipLaunchKernelGGL(k31_crowded_words, dim3((unsigned)((Rc + 255) / 256)), dim3(256), 0, s, (const uint64_t *)sk, (const uint64_t *)sv, Rc, (const uint32_t *)head, (const uint32_t *)dpos, (const uint64_t *)coff_d,
-                               (const uint32_t *)pbase_d, nc, k2, m.PB, words2, cdist, b2s, parent_of, dist_base);
+                               (const uint32_t *)pbase_d, nc, k2, m.PB, pshift, words2, cdist, b2s, parent_of, dist_base);
             const uint32_t rc32 = (uint32_t)Rc;
             ELBA_HIP(hipMemcpyAsync(b2s + np, &rc32, 4, hipMemcpyHostToDevice, s));
             ELBA_HIP(hipMemsetAsync(gstat2, 0, sizeof(BucketStats), s));

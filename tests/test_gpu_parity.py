@@ -812,8 +812,7 @@ def test_wide_partition_keeps_a_satellite_bucket_and_a_homopolymer_on_the_partit
     on top of ordinary reads.  The input stays on the wide partition path (kmer_path == 2), equals the oracle entry for entry — also with UPPER = 40, where
     the matrix is dense and the satellite's columns are kept — and the stage takes at most 1.3 x what it takes without the two."""
     rng = np.random.default_rng(77)
-    reads, _ = synth.make_reads(17, 400000, 12, 2500, 600, error=0.04, min_len=100)
-    base = list(reads)
+    bp, bo, bl, _ = elba_amd.synth_reads(17, 5_000_000, 12, 2500, 600, error_rate=0.04, min_len=100)      # 60 M instances: the stage takes a few ms
     bases = np.frombuffer(b"ACGT", dtype=np.uint8)
     tails = bases[rng.integers(0, 4, size=(100000, 21))]
     sat = [b"A" * 10 + t.tobytes() for t in tails]                  # canonical = forward (it starts with ten A): all of them in the lowest bucket
@@ -822,7 +821,12 @@ def test_wide_partition_keeps_a_satellite_bucket_and_a_homopolymer_on_the_partit
     k = 31
 
     def run(seqs):
-        packed, off, lens = po.pack_reads(seqs)
+        nb = int(bo[-1]) + (int(bl[-1]) + 3) // 4                   # bytes of the base reads (DnaBuffer layout: a read starts on a byte)
+        if seqs:
+            xp, xo, xl = po.pack_reads(seqs)
+            packed, off, lens = np.concatenate([bp[:nb], xp]), np.concatenate([bo, xo + np.uint64(nb)]), np.concatenate([bl, xl])
+        else:
+            packed, off, lens = np.concatenate([bp[:nb], np.zeros(8, dtype=np.uint8)]), bo, bl
         e = elba_amd.Engine(k, lo, up, options={"kmer_msd": 1})
         e.set_reads(packed, off, lens)
         e.count_kmers(); e.create_kmer_matrix()                      # allocations
@@ -833,19 +837,19 @@ def test_wide_partition_keeps_a_satellite_bucket_and_a_homopolymer_on_the_partit
         e.create_kmer_matrix()
         return e, ks, best, (packed, off, lens)
 
-    e0, ks0, t_clean, _ = run(base)
+    e0, ks0, t_clean, _ = run([])
     assert e0.get_stat("kmer_path") == 2
     e0.close()
-    e, ks, t_sat, (packed, off, lens) = run(base + extra)
+    e, ks, t_sat, (packed, off, lens) = run(extra)
     assert e.get_stat("kmer_path") == 2
     st = e.create_seed_matrix()
     o = gu.oracle_run(packed, off, lens, k, lo, up, threads=8)
     assert (ks["instances"], ks["distinct"], ks["reliable"], ks["entries"]) == (o.stat("I"), o.stat("ndistinct"), o.stat("N"), o.stat("Z"))
-    assert ks["reliable"] >= ks0["reliable"] + 100000                # the satellite's k-mers are kept (3-6 copies each)
+    assert ks["reliable"] >= ks0["reliable"] + 99000                 # the satellite's k-mers are kept (3-6 copies each; a handful of the random tails coincide)
     gu.assert_A_equal(e.export_kmer_matrix(), o.A())
     gu.assert_B_equal(e.export_csr(), o.B())
     gu.assert_stats_equal(st, o)
-    assert t_sat <= 1.3 * t_clean + 0.5, (t_sat, t_clean)            # (ms; half a millisecond for the three host round trips of the pseudo-bucket path on this small input)
+    assert t_sat <= 1.3 * t_clean, (t_sat, t_clean)
     e.close()
 
 
