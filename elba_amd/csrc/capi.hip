@@ -535,6 +535,7 @@ int elba_set_option(elba_ctx *ctx, const char *name, int64_t value)
         else if (!strcmp(name, "dense_wgs")) { ELBA_REQUIRE(value >= 1 && value <= 16, ELBA_ERR_INVALID_ARG, "set_option: dense_wgs is 1..16"); c.opt.dense_wgs = (int)value; }
         else if (!strncmp(name, "tune", 4) && name[4] >= '0' && name[4] <= '7' && name[5] == 0) c.opt.tune[name[4] - '0'] = value;
         else if (!strcmp(name, "msd_small_cap")) c.opt.msd_small_cap = (int)value;
+        else if (!strcmp(name, "kmer_batch_instances")) { ELBA_REQUIRE(value >= 0, ELBA_ERR_INVALID_ARG, "set_option: kmer_batch_instances is >= 0"); c.opt.kmer_batch_instances = value; }
         else if (!strcmp(name, "msd_wide_bits")) c.opt.msd_wide_bits = (int)value;
         else if (!strcmp(name, "ell_slot_cap")) c.opt.ell_slot_cap = (int)value;
         else if (!strcmp(name, "slab_pct")) { ELBA_REQUIRE(value >= 1 && value <= 1000, ELBA_ERR_INVALID_ARG, "set_option: slab_pct is 1..1000"); c.opt.slab_pct = (int)value; }
@@ -565,6 +566,7 @@ int elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value)
         if (!strcmp(name, "overlap_mirror_placed")) *value = c.ov_mir_placed;
         else if (!strcmp(name, "overlap_slab_q16")) *value = (int64_t)c.ov_slab_q16_used;
         else if (!strcmp(name, "kmer_path")) *value = c.kmer_path;
+        else if (!strcmp(name, "kmer_passes")) *value = c.kmer_passes;      // value-range passes the last elba_count_kmers took (1: the whole input at once)
         else if (!strcmp(name, "spgemm_prep_us")) *value = c.prep_us;      // (option "measure_prep"; -1: not measured — the option was off, or the path taken has no emit kernels of its own)
         else if (!strcmp(name, "emit_us")) *value = c.emit_us;
         else if (!strcmp(name, "triples_path")) *value = c.triples_path;
@@ -616,6 +618,30 @@ int elba_dist_fill_send(elba_ctx *ctx, int nranks, void *d_send, const uint64_t 
     return guarded(ctx, [&](Ctx &c) {
         ELBA_REQUIRE(offsets && (d_send || c.I == 0), ELBA_ERR_INVALID_ARG, "dist_fill_send: null argument");
         stage_dist_fill_send(c, nranks, d_send, offsets);
+    });
+}
+
+int elba_dist_packed_format(elba_ctx *ctx, int nranks, const int64_t *read_bounds, const uint32_t *all_lens, int *fits, int *value_bits, int *index_bits)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(fits, ELBA_ERR_INVALID_ARG, "dist_packed_format: null output");
+        *fits = stage_dist_packed_format(c, nranks, read_bounds, all_lens, value_bits, index_bits) ? 1 : 0;
+    });
+}
+
+int elba_dist_fill_send_packed(elba_ctx *ctx, int nranks, void *d_send, const uint64_t *offsets)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(offsets && (d_send || c.I == 0), ELBA_ERR_INVALID_ARG, "dist_fill_send_packed: null argument");
+        stage_dist_fill_send_packed(c, nranks, d_send, offsets);
+    });
+}
+
+int elba_dist_unpack_records(elba_ctx *ctx, int nranks, int rank, const void *d_packed, const uint64_t *recv_counts, void *d_records)
+{
+    return guarded(ctx, [&](Ctx &c) {
+        ELBA_REQUIRE(recv_counts, ELBA_ERR_INVALID_ARG, "dist_unpack_records: null counts");
+        stage_dist_unpack_records(c, nranks, rank, d_packed, recv_counts, d_records);
     });
 }
 

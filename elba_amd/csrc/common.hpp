@@ -168,6 +168,7 @@ struct Options {
                                 // inline partners, gather slots + padded columns), both runs bracketed by events: elba_get_stat("spgemm_prep_us") = the difference (kmer_msd.hip)
     int64_t tune[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // A/B switches of the round in progress ("tune0" .. "tune7"): what each means is said where it is read
     int msd_wide_bits = 0;      // tests: value bits the partition of the 19 <= k <= 31 path takes (0: chosen from the number of instances)
+    int64_t kmer_batch_instances = 0;      // k-mer stage (k <= 17, reads): more instances than this are counted in passes over value ranges (0: 0xE0000000 — what a 32-bit place holds); tests force passes on small sets
     int msd_small_cap = 0;      // tests: buckets with more entries than this go to the crowded-bucket kernel (0 = its real capacity)
     int kmer_drop = 0;          // test hook: force that many dropped index bits on a small input (1..3)
     int dense_up = 1;           // SpGEMM, dense path: the tier its rows start on at least (1: eight wavefronts share a 1024-slot table — 32 per CU as with four on 512 slots, half the load)
@@ -200,6 +201,7 @@ struct Ctx {
     // k-mer stage results (device)
     bool have_counts = false;
     int triples_path = 0; // diagnostic: how the last elba_set_kmer_matrix_device built the matrix — 0 radix sorts of the whole matrix (matrix.hip), 1 the k-mer stage's bucket kernels (kmer_msd.hip)
+    int kmer_passes = 1;  // diagnostic: value-range passes of the last elba_count_kmers (kmer_msd.hip)
     int kmer_path = 0;    // diagnostic: how the last elba_count_kmers counted — 0 the sort of kmer.hip, 1 two-level partition + LDS count tables (k <= 17), 2 the same on 16-byte records + LDS sort (19 <= k <= 31)
     int64_t I = 0, ndistinct = 0;
     DevBuf inst_off;      // u64[M+1] instance offset of each read
@@ -259,6 +261,7 @@ struct Ctx {
     bool dist_owner = false;
     DevBuf dist_gid;          // u32[N_local] global k-mer id of each local column
     int64_t dist_nall = -1;
+    DevBuf dist_all_off; std::vector<int64_t> dist_bounds; int dist_pack_vb = 0, dist_pack_ib = 0;      // exchange #1 with 8-byte records (kmer.hip, stage_dist_packed_format): every rank's instance offsets (rank r's at bounds[r] + r), the read bounds, the format
     std::vector<uint32_t> owner_upper;   // value-range owners: rank r owns the value bins [owner_upper[r-1], owner_upper[r]) (kmer.hip)
     int64_t N_global = -1;    // a panel context: k-mers of the whole run (its own columns are renumbered locally)
     DevBuf own_colptr, own_csc;   // the columns this rank OWNS (u32[own_N + 1], u64[own_Z]): kept apart from the context's A, which the panels overwrite —
@@ -289,6 +292,7 @@ struct Ctx {
 
     // workspaces
     DevBuf ws_scan, ws_sort, ws_a, ws_b, ws_c, ws_d, ws_e, ws_f;
+    DevBuf ws_cursor;       // the gather-slot cursor of the k-mer stage's emit kernels (kmer_msd.hip)
     DevBuf ws_g, ws_h;      // crowded buckets of the wide k-mer partition (kmer_msd.hip: k31_gather_crowded ...): their records / the pseudo-buckets' arrays
     DevBuf ov_totcnt, ov_mir, ov_tmp, ov_sum_tmp;  // u32[M+1] mirrored entries per row (ticket counters); mirrored entries laid out like B (32-byte records); staging area (32-byte records)
     bool ov_low_clean = false;                 // the ticket counters are all zero (handed back clean by the previous call)
@@ -349,6 +353,9 @@ void stage_ref_hash_owner(Ctx &c, const uint64_t *kmers_host, int64_t n, int npr
 void stage_dist_set_owner_ranges(Ctx &c, int nranks, const uint32_t *upper_bins);
 void stage_dist_set_kmer_id_base(Ctx &c, int64_t base, int64_t nall);
 void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);
+bool stage_dist_packed_format(Ctx &c, int nranks, const int64_t *bounds, const uint32_t *all_lens, int *value_bits, int *index_bits);
+void stage_dist_fill_send_packed(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host);
+void stage_dist_unpack_records(Ctx &c, int nranks, int rank, const void *d_packed, const uint64_t *recv_counts_host, void *d_out);
 void stage_dist_count_records(Ctx &c, const void *d_rec, int64_t nrec);
 void stage_dist_copy_reliable_kmers(Ctx &c, void *d_dst);       // N k-mers of 1 + (k > 32) + (k > 64) words each, interleaved
 void stage_dist_set_global_kmers(Ctx &c, const void *d_all, int64_t nall);

@@ -548,8 +548,9 @@ void stage_count_kmers(Ctx &c)
     for (int64_t r = 0; r < M; ++r) { const uint32_t l = c.h_len[(size_t)r]; off[(size_t)r] = I; if ((int64_t)l >= k) I += (uint64_t)l - k + 1; maxlen = l > maxlen ? l : maxlen; }
     off[(size_t)M] = I;
     c.max_read_len = maxlen;      // (the one host walk over the read lengths of this stage: kmer_msd.hip sizes its position field by it)
-    ELBA_REQUIRE(I < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: more than 2^32 k-mer instances on one GPU");
-    c.I = (int64_t)I;
+    // (more than 2^32 instances: the two-level partition of kmer_msd.hip counts them in passes over value ranges — k <= 17; every other path holds 32-bit places)
+    ELBA_REQUIRE(I < 0xFFFFFFF0ull || (k <= 17 && k >= 9 && !c.opt.kmer_no_msd), ELBA_ERR_UNSUPPORTED, "count_kmers: more than 2^32 k-mer instances on one GPU (k <= 17 only)");
+    c.I = (int64_t)I; c.kmer_passes = 1;
     c.inst_off.reserve((size_t)(M + 1) * 8);
     ELBA_HIP(hipMemcpyAsync(c.inst_off.p, off.data(), (size_t)(M + 1) * 8, hipMemcpyHostToDevice, s));
 
@@ -606,6 +607,7 @@ void stage_count_kmers(Ctx &c)
         c.have_counts = true;
         return;
     }
+    ELBA_REQUIRE(I < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: more than 2^32 k-mer instances on one GPU and the two-level partition does not take this input");
     {
         // ---- one-word k-mers: see the header of this file ----
         c.t_total.start(s);
@@ -784,6 +786,45 @@ __global__ __launch_bounds__(EN_THREADS) void k_dist_fill_send(EnumParams e, Own
         if constexpr (W >= 3) rec[2] = c2;
         rec[W] = ((first_global_id + r) << 32) | p;
     });
+}
+
+// ---- exchange #1 with 8-byte records (one-word k-mers; round 5) -------------------------------------------------------------------------
+// A record of exchange #1 was (k-mer, global read << 32 | pos): 16 bytes per instance, 2 * 10^9 instances on BASELINE config 3 — at 8 GPUs ~3.5 GB per
+// rank over xGMI against a ~7 ms local k-mer stage.  Packed: (value - first value of the OWNER's range) << IB | instance index in the SENDER's reads —
+// the owner's range is 1/nranks of the value space and an index needs bits(instances per rank): 31 + 28 bits at eight ranks, 33 + 30 at two.  The source
+// rank is known from the segment of the receive buffer a record arrives in; every rank holds every rank's read lengths (one all-gather of 4 bytes per
+// read), so the owner turns (source, index) back into (global read, pos) by a search in the source's instance offsets — neighbouring records name
+// neighbouring instances: the searches of a wavefront walk the same few cache lines — and hands elba_dist_count_records the 16-byte records it always took.
+struct PackFmt { int vb, ib, k2; uint32_t nranks; uint64_t lo[MAX_RANKS]; };      // lo[r] = first value (right-aligned) of owner r's range
+__global__ __launch_bounds__(EN_THREADS) void k_dist_fill_send_packed(EnumParams e, OwnerMap om, PackFmt f, uint64_t *send, unsigned long long *cursors)
+{
+    __shared__ uint32_t hist[MAX_RANKS];
+    __shared__ unsigned long long base[MAX_RANKS];
+    if (threadIdx.x < MAX_RANKS) hist[threadIdx.x] = 0;
+    __syncthreads();
+    for_each_instance(e, [&](uint64_t, uint32_t, uint32_t, uint64_t km) { atomicAdd(&hist[owner_of(km, om)], 1u); });
+    __syncthreads();
+    if (threadIdx.x < om.nranks) {
+        base[threadIdx.x] = hist[threadIdx.x] ? atomicAdd(&cursors[threadIdx.x], (unsigned long long)hist[threadIdx.x]) : 0ull;
+        hist[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    for_each_instance(e, [&](uint64_t g, uint32_t, uint32_t, uint64_t km) {
+        const uint32_t o = owner_of(km, om);
+        const unsigned long long at = base[o] + atomicAdd(&hist[o], 1u);
+        send[at] = (((km >> (64 - f.k2)) - f.lo[o]) << f.ib) | g;
+    });
+}
+// segment `src` of the receive buffer: n packed records of rank src -> 16-byte records; off = the instance offsets of src's reads (nr + 1 of them), gid0 = its first global read
+__global__ __launch_bounds__(256) void k_dist_unpack(const uint64_t *packed, uint64_t n, const uint64_t *off, uint32_t nr, uint64_t gid0, uint64_t lo_self, int ib, int k2, uint64_t *out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t w = packed[i], g = w & ((1ull << ib) - 1ull), value = (w >> ib) + lo_self;
+    uint32_t a = 0, b = nr;      // last read with off[read] <= g (reads shorter than k have empty ranges: the LAST of equal offsets is the one that holds g)
+    while (b - a > 1) { const uint32_t mid = (a + b) >> 1; if (off[mid] <= g) a = mid; else b = mid; }
+    out[2 * i] = value << (64 - k2);
+    out[2 * i + 1] = ((gid0 + a) << 32) | (g - off[a]);
 }
 
 // records of W + 1 words -> W word arrays + the payload
@@ -1080,6 +1121,84 @@ void stage_dist_fill_send(Ctx &c, int nranks, void *d_send, const uint64_t *offs
         if (W == 1) hipLaunchKernelGGL(k_dist_fill_send<1>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, (uint64_t)c.first_global_id, snd, cur);
         else if (W == 2) hipLaunchKernelGGL(k_dist_fill_send<2>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, (uint64_t)c.first_global_id, snd, cur);
         else hipLaunchKernelGGL(k_dist_fill_send<3>, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, om, (uint64_t)c.first_global_id, snd, cur);
+    }
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
+// ---- exchange #1 with 8-byte records: format, fill, unpack (the kernels above k_split_records) ---------------------------------------------------
+static PackFmt pack_format(Ctx &c, int nranks)
+{
+    PackFmt f{};
+    f.k2 = 2 * c.cfg.k; f.nranks = (uint32_t)nranks; f.vb = c.dist_pack_vb; f.ib = c.dist_pack_ib;
+    const OwnerMap om = owner_map(c, nranks);
+    for (int r = 0; r < nranks; ++r) f.lo[r] = r == 0 ? 0ull : ((uint64_t)om.upper[r - 1] << (f.k2 - OWNER_BITS));
+    return f;
+}
+// Every rank's read lengths (bounds[r] .. bounds[r + 1] = the reads of rank r): decides the packed format — the same on every rank, a pure function of
+// the lengths, k and the owner ranges — and uploads every rank's instance offsets.  Returns false where an instance does not fit 64 bits.
+bool stage_dist_packed_format(Ctx &c, int nranks, const int64_t *bounds, const uint32_t *all_lens, int *value_bits, int *index_bits)
+{
+    ELBA_REQUIRE(nranks >= 1 && nranks <= MAX_RANKS && bounds && (all_lens || bounds[nranks] == 0), ELBA_ERR_INVALID_ARG, "dist_packed_format: 1..64 ranks, bounds and lengths");
+    const int k = c.cfg.k, k2 = 2 * k;
+    c.dist_pack_vb = c.dist_pack_ib = 0;
+    if (kmer_words(k) != 1 || k2 < OWNER_BITS) return false;
+    const int64_t Mt = bounds[nranks];
+    std::vector<uint64_t> off((size_t)Mt + (size_t)nranks + 1);      // rank r's offsets (reads of r + 1 entries) start at bounds[r] + r
+    uint64_t maxI = 0;
+    for (int r = 0; r < nranks; ++r) {
+        ELBA_REQUIRE(bounds[r] <= bounds[r + 1], ELBA_ERR_INVALID_ARG, "dist_packed_format: bounds must ascend");
+        uint64_t I = 0;
+        uint64_t *o = off.data() + bounds[r] + r;
+        for (int64_t q = bounds[r]; q < bounds[r + 1]; ++q) { o[q - bounds[r]] = I; if ((int64_t)all_lens[q] >= k) I += (uint64_t)all_lens[q] - k + 1; }
+        o[bounds[r + 1] - bounds[r]] = I;
+        maxI = std::max(maxI, I);
+    }
+    const OwnerMap om = owner_map(c, nranks);
+    uint64_t maxw = 0;
+    for (int r = 0; r < nranks; ++r) maxw = std::max<uint64_t>(maxw, (uint64_t)(om.upper[r] - (r ? om.upper[r - 1] : 0u)) << (k2 - OWNER_BITS));
+    const int ib = bits_needed(maxI > 0 ? maxI - 1 : 0), vb = bits_needed(maxw > 0 ? maxw - 1 : 0);
+    if (value_bits) *value_bits = vb;
+    if (index_bits) *index_bits = ib;
+    if (vb + ib > 64 || c.opt.tune[2] == 1) return false;      // (tune2 = 1: 16-byte records — A/B, tests)
+    c.dist_all_off.reserve(off.size() * 8);
+    ELBA_HIP(hipMemcpyAsync(c.dist_all_off.p, off.data(), off.size() * 8, hipMemcpyHostToDevice, c.stream));
+    ELBA_HIP(hipStreamSynchronize(c.stream));
+    c.dist_bounds.assign(bounds, bounds + nranks + 1);
+    c.dist_pack_vb = vb; c.dist_pack_ib = ib;
+    return true;
+}
+
+void stage_dist_fill_send_packed(Ctx &c, int nranks, void *d_send, const uint64_t *offsets_host)
+{
+    ELBA_REQUIRE(c.have_reads && c.inst_off.p, ELBA_ERR_STATE, "dist_fill_send_packed: call dist_count_owners first");
+    ELBA_REQUIRE(c.dist_pack_ib > 0 && (int)c.dist_bounds.size() == nranks + 1, ELBA_ERR_STATE, "dist_fill_send_packed: call dist_packed_format first (it must have returned 1)");
+    hipStream_t s = c.stream;
+    c.ws_scan.reserve(MAX_RANKS * 8);
+    ELBA_HIP(hipMemcpyAsync(c.ws_scan.p, offsets_host, (size_t)nranks * 8, hipMemcpyHostToDevice, s));
+    EnumParams e = make_enum(c);
+    const uint64_t nblocks = ((uint64_t)c.I + EN_PER_BLOCK - 1) / EN_PER_BLOCK;
+    if (c.I > 0)
+        hipLaunchKernelGGL(k_dist_fill_send_packed, dim3((unsigned)nblocks), dim3(EN_THREADS), 0, s, e, owner_map(c, nranks), pack_format(c, nranks), static_cast<uint64_t *>(d_send), c.ws_scan.as<unsigned long long>());
+    ELBA_HIP(hipStreamSynchronize(s));
+}
+
+// recv_counts[p] packed records of rank p, segment after segment in d_packed -> 2 words per record in d_out (what elba_dist_count_records takes); `rank` = this owner
+void stage_dist_unpack_records(Ctx &c, int nranks, int rank, const void *d_packed, const uint64_t *recv_counts_host, void *d_out)
+{
+    ELBA_REQUIRE(c.dist_pack_ib > 0 && (int)c.dist_bounds.size() == nranks + 1 && rank >= 0 && rank < nranks, ELBA_ERR_STATE, "dist_unpack_records: call dist_packed_format first (it must have returned 1)");
+    hipStream_t s = c.stream;
+    const PackFmt f = pack_format(c, nranks);
+    uint64_t at = 0;
+    for (int p = 0; p < nranks; ++p) {
+        const uint64_t n = recv_counts_host[p];
+        if (n) {
+            ELBA_REQUIRE(d_packed && d_out, ELBA_ERR_INVALID_ARG, "dist_unpack_records: null buffers");
+            const uint32_t nr = (uint32_t)(c.dist_bounds[(size_t)p + 1] - c.dist_bounds[(size_t)p]);
+            hipLaunchKernelGGL(k_dist_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, static_cast<const uint64_t *>(d_packed) + at, n,
+                               (const uint64_t *)(c.dist_all_off.as<uint64_t>() + c.dist_bounds[(size_t)p] + p), nr, (uint64_t)c.dist_bounds[(size_t)p], f.lo[rank], f.ib, f.k2,
+                               static_cast<uint64_t *>(d_out) + 2 * at);
+        }
+        at += n;
     }
     ELBA_HIP(hipStreamSynchronize(s));
 }

@@ -28,6 +28,7 @@
 #include "common.hpp"
 #include "matrix.hpp"
 #include <algorithm>
+#include <functional>
 
 namespace elba {
 
@@ -165,16 +166,31 @@ __device__ __forceinline__ void enum_consecutive(const EnumParams &e, const Bloc
 }
 
 // ---- first digit: count ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(MT_THREADS) void k_msd_hist1(EnumParams e, const BlockInfo *block_read, MsdParams m, uint32_t *hist)
+// (dlo, dhi: the first digits of this PASS — value-range batching, msd_run: instances of other first digits are not counted; one pass: 0, all of them)
+__global__ __launch_bounds__(MT_THREADS) void k_msd_hist1(EnumParams e, const BlockInfo *block_read, MsdParams m, uint32_t *hist, uint32_t dlo, uint32_t dhi)
 {
     __shared__ uint32_t h[MT_MAXBINS];
     const uint32_t nbins = 1u << m.b1;
     for (uint32_t i = threadIdx.x; i < nbins; i += MT_THREADS) h[i] = 0;
     __syncthreads();
     const uint64_t base = ((uint64_t)blockIdx.x * (MT_THREADS / 64) + (threadIdx.x >> 6)) * (uint64_t)(MT_ITEMS * 64);
-    enum_consecutive(e, block_read, base, [&](int, uint64_t km, uint32_t, uint32_t) { atomicAdd(&h[(uint32_t)(km >> (64 - m.b1))], 1u); });
+    enum_consecutive(e, block_read, base, [&](int, uint64_t km, uint32_t, uint32_t) { const uint32_t d = (uint32_t)(km >> (64 - m.b1)); if (d >= dlo && d < dhi) atomicAdd(&h[d], 1u); });
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nbins; i += MT_THREADS) hist[(size_t)blockIdx.x * nbins + i] = h[i];
+}
+
+// per-digit totals of a tile-major histogram in 64 bits (value-range batching: more than 2^32 instances in all); blockDim.x = nbins
+__global__ void k_msd_digit_totals(const uint32_t *hist, uint64_t ntiles, uint32_t nbins, unsigned long long *tot)
+{
+    const uint32_t d = threadIdx.x;
+    unsigned long long sum = 0;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256u; t < ntiles && t < (uint64_t)(blockIdx.x + 1) * 256u; ++t) sum += hist[t * nbins + d];
+    if (sum) atomicAdd(&tot[d], sum);
+}
+__global__ void k_add_u32(uint32_t *a, uint32_t n, uint32_t v)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += v;
 }
 
 // ---- tiles of the second pass: none of them straddles two first-digit buckets ------------------------------------------------------------
@@ -272,8 +288,9 @@ __device__ __forceinline__ void lds_sync_fwd() { asm volatile("s_waitcnt lgkmcnt
 // dispatch of sixteen wavefronts and 139 KB of LDS every ~20 us.
 template <bool ENUM>
 __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const BlockInfo *block_read, MsdParams m, const uint64_t *in, SegTiles sg, int shift, int bits,
-                                                           const uint32_t *hist_scanned, uint64_t *out, uint32_t ntiles)
+                                                           const uint32_t *hist_scanned, uint64_t *out, uint32_t ntiles, uint32_t dlo, uint32_t dhi)
 {
+    __shared__ uint32_t kept_s;      // keys of the tile that belong to this pass (value-range batching: k_msd_hist1)
     constexpr int WAVES = MT_THREADS / 64, DPT = MT_MAXBINS / MT_THREADS > 0 ? MT_MAXBINS / MT_THREADS : 1;
     __shared__ uint32_t lcnt[MT_MAXBINS], lstart[MT_MAXBINS], gbase[MT_MAXBINS], wsum[WAVES];
     __shared__ uint64_t lkey[MT_TILE];
@@ -302,8 +319,9 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
 #pragma unroll
         for (int q = 0; q < MT_ITEMS / 2; ++q) dig2[q] = 0xFFFFFFFFu;
         enum_consecutive(e, block_read, base, [&](int it, uint64_t km, uint32_t r, uint32_t p) {
-            key[it] = (((km >> (64 - m.k2)) & vmask) << m.PB) | ((uint64_t)r << m.pbits) | p;
             const uint32_t dg = (uint32_t)(km >> (64 - m.b1));
+            if (dg < dlo || dg >= dhi) return;      // (another pass's instance: no key)
+            key[it] = (((km >> (64 - m.k2)) & vmask) << m.PB) | ((uint64_t)r << m.pbits) | p;
             dig2[it >> 1] = (it & 1) ? (dig2[it >> 1] & 0xFFFFu) | (dg << 16) : (dig2[it >> 1] & 0xFFFF0000u) | dg;
         });
     } else {
@@ -350,10 +368,12 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         for (int ww = 0; ww < w; ++ww) run += wsum[ww];
 #pragma unroll
         for (int u = 0; u < DPT; ++u) { const uint32_t d = DPT * threadIdx.x + u; if (d < nbins) lstart[d] = run; run += tot[u]; }
+        if (threadIdx.x == MT_THREADS - 1) kept_s = run;      // (the inclusive sum at the last thread: every key of the tile that has a digit)
 #pragma unroll
         for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * MT_THREADS; if (d < nbins) gbase[d] = gb[u]; }
     }
     __syncthreads();
+    if (ENUM) count = kept_s;
 #pragma unroll
     for (int it = 0; it < MT_ITEMS; ++it) {
         const uint32_t d = digit(it);
@@ -1662,9 +1682,15 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     hipStream_t s = c.stream;
     const uint32_t nb1 = 1u << m.b1, nb2 = 1u << m.b2, nbuckets = nb1 * nb2;
     const uint32_t tile = wide ? (uint32_t)W2_TILE : (uint32_t)MT_TILE;
+    // more instances than a 32-bit place holds (or than "kmer_batch_instances": tests): passes over value ranges (reads, k <= 17 only)
+    const uint64_t batch_cap = c.opt.kmer_batch_instances > 0 ? (uint64_t)c.opt.kmer_batch_instances : 0xE0000000ull;
+    const bool batched = !wide && !tri && I > batch_cap;
+    if (!batched && I >= 0xFFFFFFF0ull) return false;      // (the caller refuses: the sort, the wide partition and the triples hold 32-bit places)
+    ELBA_REQUIRE((I + tile - 1) / tile < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: more than 2^45 k-mer instances");
+    const uint64_t Ibuf = batched ? std::min<uint64_t>(I, batch_cap + (I >> (m.b1 - 1)) + (1u << 20)) : I;      // (a pass: the cap, or one digit beyond it — a digit holds ~2 I / 2^b1 at most on canonical k-mers; checked per pass below)
     const uint32_t ntiles1 = (uint32_t)((I + tile - 1) / tile), ntiles2 = ntiles1 + nb1;
 
-    c.ws_a.reserve((size_t)(I + 2) * (wide ? 16 : 8)); c.ws_c.reserve((size_t)(I + 2) * (wide ? 16 : 8));
+    c.ws_a.reserve((size_t)(Ibuf + 2) * (wide ? 16 : 8)); c.ws_c.reserve((size_t)(Ibuf + 2) * (wide ? 16 : 8));
     c.ws_sort.reserve(((size_t)ntiles2 << (wide ? W2_MAXBITS : MT_MAXBITS)) * 4 + 4096);
     c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 6 + (size_t)(2 * nb1 + 8) * 4 + 256 + 64);
     uint32_t *hist = c.ws_sort.as<uint32_t>();
@@ -1696,6 +1722,23 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     // pseudo-buckets of the wide partition's crowded buckets (the section above k31_gather_crowded)
     struct { bool on = false; uint32_t nc = 0, np = 0; const uint64_t *words = nullptr; uint64_t *wrel = nullptr; uint32_t *b2s = nullptr, *bN = nullptr, *bZ = nullptr, *kidbase = nullptr, *entbase = nullptr, *crowded = nullptr;
              BucketStats *gstat = nullptr; const uint32_t *clist = nullptr, *pbase = nullptr; const uint64_t *cdist = nullptr; const uint32_t *dist_base = nullptr; BucketStats hs{}; } ps;
+    // value-range batching (the section "VALUE-RANGE BATCHING" below): the passes, and what phase A learnt of each
+    struct Pass { uint32_t dlo = 0, dhi = 0; uint64_t I = 0, N = 0, Z = 0; BucketStats hs{}; };
+    std::vector<Pass> passes;
+    std::function<void(uint32_t, uint32_t, uint64_t, bool)> partition_count;
+    // k-mers and entries in front of every bucket (+ the totals), the count kernels' statistics: one host round trip
+    auto scan_buckets = [&](BucketStats *hs_out, uint64_t *N_out, uint64_t *Z_out) {
+        ELBA_HIP(hipMemsetAsync(bN + nbuckets, 0, 4, s)); ELBA_HIP(hipMemsetAsync(bZ + nbuckets, 0, 4, s));
+        exclusive_scan_u32(s, bN, kidbase, (int64_t)nbuckets + 1, c.ws_scan);
+        exclusive_scan_u32(s, bZ, entbase, (int64_t)nbuckets + 1, c.ws_scan);      // (a pass holds fewer than 2^32 instances)
+        if (!hs_out) return;
+        uint32_t h2[2] = {0, 0};
+        ELBA_HIP(hipMemcpyAsync(&h2[0], kidbase + nbuckets, 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipMemcpyAsync(&h2[1], entbase + nbuckets, 4, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipMemcpyAsync(hs_out, gstat, sizeof(BucketStats), hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        *N_out = h2[0]; *Z_out = h2[1];
+    };
     if (!wide) {
     const int shift2 = m.PB + vb;
     const uint32_t sgrid = c.opt.tune[0] == 1 ? 0xFFFFFFFFu : (uint32_t)c.num_cus * (MT_TILE <= 8192 ? 2u : 1u);      // (tune0 = 1: a workgroup per tile, as before round 5 — A/B)
@@ -1710,32 +1753,67 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         hipLaunchKernelGGL(k_msd_hist2, dim3(ntiles1), dim3(MT_THREADS), 0, s, (const uint64_t *)wb, sg1, shift2 + m.b2, m.b1, hist);
         radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
         hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
-        hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wb, sg1, shift2 + m.b2, m.b1, (const uint32_t *)hist, wa, ntiles1);
-    } else {
-    // first digit
-    hipLaunchKernelGGL(k_msd_hist1, dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, hist);
-    radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
-    hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, I, b1start, tile0);
-    hipLaunchKernelGGL((k_msd_scatter<true>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa, ntiles1);
-    }
+        hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wb, sg1, shift2 + m.b2, m.b1, (const uint32_t *)hist, wa, ntiles1, 0u, nb1);
     // second digit, inside every first-digit bucket
     hipLaunchKernelGGL(k_msd_hist2, dim3(ntiles2), dim3(MT_THREADS), 0, s, (const uint64_t *)wa, sg, shift2, m.b2, hist);
     hipLaunchKernelGGL(k_msd_segscan, dim3(nb1), dim3(MT_MAXBINS), 0, s, hist, sg, nb2, b2start, I);
-    hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(ntiles2, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sg, shift2, m.b2, (const uint32_t *)hist, wb, ntiles2);
+    hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(ntiles2, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sg, shift2, m.b2, (const uint32_t *)hist, wb, ntiles2, 0u, nb1);
     c.t_a.stop(s);
-    // buckets: count
     c.t_b.start(s);
     ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
-    const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus);
-    // (columns of up to HINT_MAX_COL entries: the value bits spread a bucket's entries evenly over the emit kernels' sort ranges already)
-    const bool rank_pass = m.rk != 0;
-    if (tri)
-        hipLaunchKernelGGL(k_tri_stats, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 8u)), dim3(256), 0, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m.PB, m.rkmask, small_cap, bN, bZ, gstat);
-    else
-    // entries per bucket: up to 2048 / 4096 / 8192 -> k_msd_emit_small on 256 / 512 / 1024 lanes, beyond -> k_msd_bucket (option "msd_small_cap": tests lower the last bound)
-    // (the first pass's words are dead: their buffer takes the entries — the instances of reliable k-mers —, bucket by bucket)
-    if (rank_pass) hipLaunchKernelGGL(k_msd_count<true>, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap, bN, bZ, gstat, crowded, wa);
-    else hipLaunchKernelGGL(k_msd_count<false>, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap, bN, bZ, gstat, crowded, wa);
+    hipLaunchKernelGGL(k_tri_stats, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * 8u)), dim3(256), 0, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m.PB, m.rkmask, small_cap, bN, bZ, gstat);
+    } else {
+    // The reads' instances whose FIRST digit lies in [dlo, dhi) — Iv of them; one pass: every instance —: two-level partition, then one workgroup per bucket
+    // counts.  hist1 and the first scatter enumerate ALL reads (tiles of the whole instance range) and keep their pass's instances.
+    partition_count = [&, shift2, sgrid](uint32_t dlo, uint32_t dhi, uint64_t Iv, bool timed) {
+        const uint32_t nt2 = (uint32_t)((Iv + tile - 1) / tile) + nb1;
+        if (timed) c.t_a.start(s);
+        hipLaunchKernelGGL(k_msd_hist1, dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, hist, dlo, dhi);
+        radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
+        hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, Iv, b1start, tile0);
+        hipLaunchKernelGGL((k_msd_scatter<true>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa, ntiles1, dlo, dhi);
+        // second digit, inside every first-digit bucket
+        hipLaunchKernelGGL(k_msd_hist2, dim3(nt2), dim3(MT_THREADS), 0, s, (const uint64_t *)wa, sg, shift2, m.b2, hist);
+        hipLaunchKernelGGL(k_msd_segscan, dim3(nb1), dim3(MT_MAXBINS), 0, s, hist, sg, nb2, b2start, Iv);
+        hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(nt2, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sg, shift2, m.b2, (const uint32_t *)hist, wb, nt2, 0u, nb1);
+        if (timed) { c.t_a.stop(s); c.t_b.start(s); }
+        // buckets: count
+        ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
+        const unsigned bgrid = (unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus);
+        // (columns of up to HINT_MAX_COL entries: the value bits spread a bucket's entries evenly over the emit kernels' sort ranges already)
+        // entries per bucket: up to 2048 / 4096 / 8192 -> k_msd_emit_small on 256 / 512 / 1024 lanes, beyond -> k_msd_bucket (option "msd_small_cap": tests lower the last bound)
+        // (the first pass's words are dead: their buffer takes the entries — the instances of reliable k-mers —, bucket by bucket)
+        if (m.rk != 0) hipLaunchKernelGGL(k_msd_count<true>, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap, bN, bZ, gstat, crowded, wa);
+        else hipLaunchKernelGGL(k_msd_count<false>, dim3(bgrid), dim3(BK_THREADS), CT_LDS, s, (const uint64_t *)wb, (const uint32_t *)b2start, nbuckets, m, lower, upper, small_cap, bN, bZ, gstat, crowded, wa);
+    };
+    if (batched) {
+        // VALUE-RANGE BATCHING (round 5; include/elba_amd.h, "limits"): more instances than a 32-bit place holds (or than the option "kmer_batch_instances"
+        // allows) are counted in passes over RANGES OF FIRST DIGITS — the reference batches its exchange so that size is no limit (include/KmerOps.hpp:33-56)
+        // —: the buckets are value ranges, so pass after pass yields consecutive k-mer ids and consecutive stretches of the columns.  Planning: the
+        // per-digit totals of one unfiltered histogram; phase A (here): partition + count of every pass for N, Z and the longest column — what the layout
+        // of A depends on —; phase B (below): partition + count again, then the emit with the pass's id / entry bases.
+        hipLaunchKernelGGL(k_msd_hist1, dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, hist, 0u, nb1);
+        c.ws_scan.reserve((size_t)nb1 * 8 + 64);
+        ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, (size_t)nb1 * 8, s));
+        hipLaunchKernelGGL(k_msd_digit_totals, dim3((unsigned)((ntiles1 + 255) / 256)), dim3(nb1), 0, s, (const uint32_t *)hist, (uint64_t)ntiles1, nb1, c.ws_scan.as<unsigned long long>());
+        std::vector<unsigned long long> dt(nb1);
+        ELBA_HIP(hipMemcpyAsync(dt.data(), c.ws_scan.p, (size_t)nb1 * 8, hipMemcpyDeviceToHost, s));
+        ELBA_HIP(hipStreamSynchronize(s));
+        for (uint32_t d = 0; d < nb1;) {
+            Pass ps1{}; ps1.dlo = d;
+            do { ps1.I += dt[d]; ++d; } while (d < nb1 && ps1.I + dt[d] <= batch_cap);
+            ps1.dhi = d;
+            ELBA_REQUIRE(ps1.I < 0xFFFFFFF0ull, ELBA_ERR_UNSUPPORTED, "count_kmers: one first-digit bucket alone holds more than 2^32 k-mer instances");
+            if (ps1.I) passes.push_back(ps1);
+        }
+        if (c.opt.trace) fprintf(stderr, "[elba] count_kmers: %llu instances in %zu value-range passes\n", (unsigned long long)I, passes.size());
+        for (Pass &ps1 : passes) {
+            partition_count(ps1.dlo, ps1.dhi, ps1.I, false);
+            scan_buckets(&ps1.hs, &ps1.N, &ps1.Z);
+        }
+        c.t_a.stop(s); c.t_b.start(s);      // (the stage's two labels: phase A | phase B)
+    } else partition_count(0u, nb1, I, true);
+    }
     } else {
         // 19 <= k <= 31: 16-byte records (the section above k31_hist1)
         Rec2 *ra = c.ws_a.as<Rec2>(), *rb = c.ws_c.as<Rec2>();
@@ -1821,24 +1899,23 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
             ps.gstat = gstat2; ps.clist = clist_d; ps.pbase = pbase_d; ps.cdist = cdist; ps.dist_base = dist_base;
         }
     }
-    ELBA_HIP(hipMemsetAsync(bN + nbuckets, 0, 4, s)); ELBA_HIP(hipMemsetAsync(bZ + nbuckets, 0, 4, s));
-    exclusive_scan_u32(s, bN, kidbase, (int64_t)nbuckets + 1, c.ws_scan);
-    exclusive_scan_u32(s, bZ, entbase, (int64_t)nbuckets + 1, c.ws_scan);      // Z <= I < 2^32
-    uint32_t h2[2] = {0, 0};
     BucketStats hs{};
-    ELBA_HIP(hipMemcpyAsync(&h2[0], kidbase + nbuckets, 4, hipMemcpyDeviceToHost, s));
-    ELBA_HIP(hipMemcpyAsync(&h2[1], entbase + nbuckets, 4, hipMemcpyDeviceToHost, s));
-    ELBA_HIP(hipMemcpyAsync(&hs, gstat, sizeof(hs), hipMemcpyDeviceToHost, s));
+    uint64_t N = 0, Z = 0;
     unsigned long long nbad = 0;
-    if (tri) ELBA_HIP(hipMemcpyAsync(&nbad, one_seg + 4, 8, hipMemcpyDeviceToHost, s));
-    if (ps.on) {
-        ELBA_HIP(hipMemcpyAsync(&ps.hs, ps.gstat, sizeof(BucketStats), hipMemcpyDeviceToHost, s));
-        hipLaunchKernelGGL(k31_pseudo_bases, dim3((ps.nc + 255) / 256), dim3(256), 0, s, (const uint32_t *)kidbase, (const uint32_t *)entbase, ps.clist, ps.pbase, ps.nc, (const uint32_t *)ps.bN, (const uint32_t *)ps.bZ, ps.kidbase, ps.entbase);
+    if (batched) {      // (phase A has scanned every pass: the totals, and what the layout of A depends on)
+        for (const Pass &ps1 : passes) { N += ps1.N; Z += ps1.Z; hs.distinct += ps1.hs.distinct; hs.sumsq += ps1.hs.sumsq; hs.maxcol = std::max(hs.maxcol, ps1.hs.maxcol); }
+    } else {
+        if (tri) ELBA_HIP(hipMemcpyAsync(&nbad, one_seg + 4, 8, hipMemcpyDeviceToHost, s));
+        if (ps.on) ELBA_HIP(hipMemcpyAsync(&ps.hs, ps.gstat, sizeof(BucketStats), hipMemcpyDeviceToHost, s));
+        scan_buckets(&hs, &N, &Z);
+        if (ps.on) {
+            hipLaunchKernelGGL(k31_pseudo_bases, dim3((ps.nc + 255) / 256), dim3(256), 0, s, (const uint32_t *)kidbase, (const uint32_t *)entbase, ps.clist, ps.pbase, ps.nc, (const uint32_t *)ps.bN, (const uint32_t *)ps.bZ, ps.kidbase, ps.entbase);
+            hs.distinct += ps.hs.distinct; hs.sumsq += ps.hs.sumsq; hs.maxcol = std::max(hs.maxcol, ps.hs.maxcol);
+        }
+        Pass whole{}; whole.dlo = 0; whole.dhi = nb1; whole.I = I; whole.N = N; whole.Z = Z; whole.hs = hs;
+        passes.assign(1, whole);
     }
-    ELBA_HIP(hipStreamSynchronize(s));
-    if (ps.on) { hs.distinct += ps.hs.distinct; hs.sumsq += ps.hs.sumsq; hs.maxcol = std::max(hs.maxcol, ps.hs.maxcol); }
     ELBA_REQUIRE(nbad == 0, ELBA_ERR_INVALID_ARG, "triple index out of range");
-    const uint64_t N = h2[0], Z = h2[1];
     if (tri && (hs.ncrowded || (int64_t)N != tri->N || Z != I)) {      // an empty column (the buckets number the columns they find), a bucket beyond the LDS sort: matrix.hip sorts
         if (c.opt.trace) fprintf(stderr, "[elba] set_kmer_matrix_device: %llu of %lld columns hold entries, %u crowded buckets: sorting instead\n", (unsigned long long)N, (long long)tri->N, hs.ncrowded);
         c.t_b.stop(s); c.t_total.stop(s);
@@ -1903,12 +1980,12 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         c.ell_cap_cols = (int64_t)cap_cols;
         o.ell = c.a_ell.as<uint64_t>(); o.slot_chunk = chunk; o.slot_cap = cap_cols;
         c.ell_slot_kid.reserve((size_t)(cap_cols + 1) * 4);
-        c.ws_scan.reserve(64);
-        ELBA_HIP(hipMemsetAsync(c.ws_scan.p, 0, 16, s));
-        o.slot_cursor = c.ws_scan.as<unsigned long long>(); o.slot_kid = c.ell_slot_kid.as<uint32_t>(); o.compact = 1u;
+        c.ws_cursor.reserve(64);      // (a buffer of its own: the scans of the later value-range passes use ws_scan)
+        ELBA_HIP(hipMemsetAsync(c.ws_cursor.p, 0, 16, s));
+        o.slot_cursor = c.ws_cursor.as<unsigned long long>(); o.slot_kid = c.ell_slot_kid.as<uint32_t>(); o.compact = 1u;
     }
     const uint64_t *wrel = tri ? wb : wa;      // (triples: the partitioned words are the entries)
-    auto launch_emit = [&]() {
+    auto launch_emit = [&](const BucketStats &hs) {      // (hs: the statistics of the pass whose buckets are emitted — which classes hold buckets)
         if (Z == 0) return;
         const uint32_t cap16 = std::min<uint32_t>(small_cap, 4096u), cap8 = std::min<uint32_t>(cap16, c.opt.msd_no_emit8 ? 0u : 2048u);
         // (buckets of up to 2048 entries — more than half of them on BASELINE config 3, where a bucket holds 2040 on average — through an instantiation
@@ -1948,10 +2025,25 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
                                    (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, (const uint32_t *)ps.crowded, (const BucketStats *)ps.gstat, (const uint32_t *)ps.kidbase, (const uint32_t *)ps.entbase, o2);
         }
     };
-    const bool mprep = c.opt.measure_prep && !pairs && words && !(hs.ncrowded && !wide);      // (the crowded-bucket kernel still reads the partition's buffer)
+    const bool mprep = c.opt.measure_prep && !pairs && words && !batched && !(hs.ncrowded && !wide);      // (the crowded-bucket kernel still reads the partition's buffer)
     c.prep_us = -1; c.emit_us = -1;
     if (mprep) c.t_emit.start(s);
-    launch_emit();
+    auto emit_passes = [&]() {
+        // one pass: the buckets are counted, emit them.  Value-range batching, phase B: every pass is partitioned and counted again (phase A kept its
+        // figures only), its k-mer ids and entries start behind those of the passes before it
+        uint64_t Nprev = 0, Zprev = 0;
+        for (const Pass &pp : passes) {
+            if (batched) {
+                partition_count(pp.dlo, pp.dhi, pp.I, false);
+                scan_buckets(nullptr, nullptr, nullptr);
+                if (Nprev) hipLaunchKernelGGL(k_add_u32, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, s, kidbase, nbuckets + 1, (uint32_t)Nprev);
+                if (Zprev) hipLaunchKernelGGL(k_add_u32, dim3((nbuckets + 1 + 255) / 256), dim3(256), 0, s, entbase, nbuckets + 1, (uint32_t)Zprev);
+            }
+            launch_emit(pp.hs);
+            Nprev += pp.N; Zprev += pp.Z;
+        }
+    };
+    emit_passes();
     if (mprep) {
         // (diagnostic) the same kernels once more, without what they write for the SpGEMM's sake alone: no hint bits, no inline partners, no padded column
         // store / gather slots — the columns, k-mers and counts are rewritten with what they hold, the sort keys go to the partition's dead buffer
@@ -1959,7 +2051,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         const BucketOut keep = o;
         o.hints = 0; o.inl = 0; o.ell = nullptr; o.ell_stride = 0; o.compact = 0; o.csr_words = tri ? wa : wb;
         c.t_emit_plain.start(s);
-        launch_emit();
+        launch_emit(passes[0].hs);
         c.t_emit_plain.stop(s);
         o = keep;
     }
@@ -1970,7 +2062,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     const unsigned long long sq = hs.sumsq;
     ELBA_HIP(hipMemcpyAsync(c.prod_ctr.p, &sq, 8, hipMemcpyHostToDevice, s));
     unsigned long long slots[2] = {0, 0};
-    if (compact) ELBA_HIP(hipMemcpyAsync(slots, c.ws_scan.p, 16, hipMemcpyDeviceToHost, s));
+    if (compact) ELBA_HIP(hipMemcpyAsync(slots, c.ws_cursor.p, 16, hipMemcpyDeviceToHost, s));
     c.t_b.stop(s);
     c.t_total.stop(s);
     ELBA_HIP(hipStreamSynchronize(s));
@@ -1982,7 +2074,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         o.compact = 0; c.ell_compact = false; c.ell_nslots = (int64_t)N; c.ell_cap_cols = (int64_t)N;
         // (the guard words behind column N: choose_column_store's were lost when the store was sized for the slots, and the re-emit writes right up to them)
         ELBA_HIP(hipMemsetAsync(c.a_ell.as<char>() + (size_t)N * c.s_stride * 8, 0xFF, 64, s));
-        launch_emit();
+        emit_passes();
         ELBA_HIP(hipStreamSynchronize(s));
     } else if (compact) c.ell_nslots = (int64_t)slots[0];      // (an upper bound of the slots in use: chunks are drawn whole)
     c.pre_ready = true; c.pre_consumed = false; c.pre_words = words; c.pre_hints = hints; c.pre_hints_done = hints && words; c.pre_ell_done = true; c.pre_inline_pending = false;
@@ -1994,6 +2086,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     c.ndistinct = (int64_t)hs.distinct;
     c.N = (int64_t)N; c.Z = (int64_t)Z;
     c.kmer_path = wide ? 2 : 1;
+    c.kmer_passes = (int)passes.size();
     return true;
 }
 

@@ -75,6 +75,9 @@ class HipBackend:
         L.elba_dist_count_owners.restype = i32; L.elba_dist_count_owners.argtypes = [vp, i32, vp]
         L.elba_dist_fill_send.restype = i32; L.elba_dist_fill_send.argtypes = [vp, i32, vp, vp]
         L.elba_dist_count_records.restype = i32; L.elba_dist_count_records.argtypes = [vp, vp, i64, C.POINTER(capi.KmerStats)]
+        L.elba_dist_packed_format.restype = i32; L.elba_dist_packed_format.argtypes = [vp, i32, vp, vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+        L.elba_dist_fill_send_packed.restype = i32; L.elba_dist_fill_send_packed.argtypes = [vp, i32, vp, vp]
+        L.elba_dist_unpack_records.restype = i32; L.elba_dist_unpack_records.argtypes = [vp, i32, i32, vp, vp, vp]
         L.elba_dist_get_reliable_kmers.restype = i32; L.elba_dist_get_reliable_kmers.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
         L.elba_dist_copy_reliable_kmers.restype = i32; L.elba_dist_copy_reliable_kmers.argtypes = [vp, vp, i64]
         L.elba_dist_set_global_kmers.restype = i32; L.elba_dist_set_global_kmers.argtypes = [vp, vp, i64]
@@ -147,6 +150,23 @@ class HipBackend:
     def fill_send(self, nranks, send, offsets):
         off = np.ascontiguousarray(offsets, dtype=np.uint64)
         self.e._check(self.L.elba_dist_fill_send(self.h, nranks, send.data_ptr() if send.numel() else None, off.ctypes.data))
+
+    def packed_format(self, nranks, bounds, all_lens):
+        """exchange #1 with 8-byte records (elba_dist_packed_format): (value bits, index bits) if an instance fits 64 bits, else None — the same on every rank"""
+        b = np.ascontiguousarray(bounds, dtype=np.int64); l = np.ascontiguousarray(all_lens, dtype=np.uint32)
+        fits, vb, ib = C.c_int(0), C.c_int(0), C.c_int(0)
+        self.e._check(self.L.elba_dist_packed_format(self.h, nranks, b.ctypes.data, l.ctypes.data if len(l) else None, C.byref(fits), C.byref(vb), C.byref(ib)))
+        return (int(vb.value), int(ib.value)) if fits.value else None
+
+    def fill_send_packed(self, nranks, send, offsets):
+        off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        self.e._check(self.L.elba_dist_fill_send_packed(self.h, nranks, send.data_ptr() if send.numel() else None, off.ctypes.data))
+
+    def unpack_records(self, nranks, rank, packed, recv_counts):
+        rc = np.ascontiguousarray(recv_counts, dtype=np.uint64)
+        out = self.empty_records(int(rc.sum()), 2)
+        self.e._check(self.L.elba_dist_unpack_records(self.h, nranks, rank, packed.data_ptr() if packed.numel() else None, rc.ctypes.data, out.data_ptr() if out.numel() else None))
+        return out
 
     def count_records(self, rec):
         self._rec = rec                                   # borrowed by the library until set_global_kmers
@@ -289,6 +309,8 @@ class DistributedOverlap:
         self.inline_partners = None       # inline partners in the panel's rows (a third fewer column fetches): None = whenever the step will use the mirror exchange
         self._panel_inline = False
         self._cur_block = 0
+        self.packed_exchange = True       # exchange #1 in 8-byte records where they fit (False: always (k-mer, read << 32 | pos) — A/B, tests)
+        self.exchange_format = None
 
     # ---- inputs -----------------------------------------------------------------------------------------------------
     def set_reads(self, packed, off, lens, first_global_id, bounds):
@@ -314,6 +336,21 @@ class DistributedOverlap:
         self.set_reads(packed, off, lens, lo, bounds)
         info["total_reads"] = total
         return info
+
+    def _all_read_lengths(self):
+        """the lengths of ALL reads, in global read order (one all-gather of the shards' u32 lengths, padded to the longest shard)"""
+        lens = np.asarray(self._reads[2], dtype=np.uint32)
+        if self.world == 1:
+            return lens
+        torch = self.be.torch
+        per = np.diff(self.bounds).astype(np.int64)
+        mx = int(max(per.max(initial=0), 1))
+        pad = torch.zeros(mx, dtype=torch.int32, device=self.be.dev)
+        if len(lens):
+            pad[:len(lens)] = torch.from_numpy(lens.view(np.int32).copy()).to(self.be.dev)
+        outs = [torch.zeros(mx, dtype=torch.int32, device=self.be.dev) for _ in range(self.world)]
+        self.dist.all_gather(outs, pad)
+        return np.concatenate([o[:int(n)].cpu().numpy().view(np.uint32) for o, n in zip(outs, per)]) if int(per.sum()) else np.zeros(0, np.uint32)
 
     def _release_cached(self):
         """Exchange buffers are torch tensors of tens of GB (config 5: 40 GB of instances per rank); freed ones stay in torch's caching
@@ -403,10 +440,25 @@ class DistributedOverlap:
         sc = self.be.count_owners(W)
         rc = self._exchange_counts(sc)
         kw = kmer_words(self.k)
-        send = self.be.empty_records(int(sc.sum()), kw + 1)
-        self.be.fill_send(W, send, np.concatenate([[0], np.cumsum(sc)[:-1]]))
-        recv = self._all_to_all_records(send, sc, rc)
-        del send
+        # one-word k-mers travel as 8-byte records where (value inside the owner's range, instance index in the sender's reads) fit 64 bits (round 5;
+        # include/elba_amd.h: elba_dist_packed_format) — every rank needs every rank's read lengths for that: one all-gather of 4 bytes per read
+        fmt = None
+        if kw == 1 and self.packed_exchange and hasattr(self.be, "packed_format"):
+            fmt = self.be.packed_format(W, self.bounds, self._all_read_lengths())
+        self.exchange_format = "8-byte records (%d value bits + %d index bits)" % fmt if fmt else "%d-byte records" % (8 * (kw + 1))
+        if fmt:
+            send = self.be.empty_records(int(sc.sum()), 1)
+            self.be.fill_send_packed(W, send, np.concatenate([[0], np.cumsum(sc)[:-1]]))
+            got = self._all_to_all_records(send, sc, rc)
+            del send
+            self._release_cached()
+            recv = self.be.unpack_records(W, self.rank, got, rc)
+            del got
+        else:
+            send = self.be.empty_records(int(sc.sum()), kw + 1)
+            self.be.fill_send(W, send, np.concatenate([[0], np.cumsum(sc)[:-1]]))
+            recv = self._all_to_all_records(send, sc, rc)
+            del send
         self._release_cached()
         ks = self.be.count_records(recv)
         # global k-mer ids: the owners hold ascending value ranges, so id = exclusive scan of the owners' counts + local index
@@ -423,7 +475,7 @@ class DistributedOverlap:
         ks = dict(ks)
         ks["instances"] = int(sc.sum())          # instances enumerated from THIS rank's reads
         ks["nreads"] = self.nlocal
-        self.exchange_bytes = dict(instances=int(sc.sum()) * 8 * (kw + 1), panels=0)
+        self.exchange_bytes = dict(instances=int(sc.sum()) * (8 if fmt else 8 * (kw + 1)), panels=0, instance_format=self.exchange_format)
         if row_batches > 1:
             self.row_batches = row_batches
             return ks, None                      # the caller walks the row blocks: load_row_block(t), create_seed_matrix(), export_csr()

@@ -89,8 +89,11 @@ public:
     {
         if ((int)readdispls.size() != grid_->size + 1) throw Error(ELBA_ERR_INVALID_ARG, "set_reads: partition needs size + 1 bounds");
         bounds_ = readdispls;
+        my_lens_.assign(mine.lengths(), mine.lengths() + mine.size());
         engine_->check(elba_set_reads(engine_->ctx, mine.data(), mine.offsets(), mine.lengths(), (int64_t)mine.size(), row_lo()));
     }
+    void packed_exchange(bool on) { packed_exchange_ = on; }      // exchange #1 in 8-byte records where an instance fits them (default on; elba_dist_packed_format)
+    bool exchange_was_packed() const { return was_packed_; }
 
     // get_kmer_count_map_keys + _values + create_kmer_matrix + Transpose, distributed (src/main.cpp:192-273)
     void build_kmer_matrix(elba_kmer_stats *kstats = nullptr, elba_matrix_stats *mstats = nullptr)
@@ -123,13 +126,29 @@ public:
         std::vector<uint64_t> sc((size_t)W), rc;
         engine_->check(elba_dist_count_owners(engine_->ctx, W, sc.data()));
         rc = exchange_counts(sc);
-        const size_t rw = (size_t)kw_ + 1;                        // words per record
+        // one-word k-mers travel as 8-byte records where (value inside the owner's range, instance index in the sender's reads) fit 64 bits: every rank then
+        // needs every rank's read lengths — one all-gather of 4 bytes per read (include/elba_amd.h: elba_dist_packed_format)
+        int fits = 0;
+        if (kw_ == 1 && packed_exchange_) {
+            const std::vector<uint32_t> all = all_gather_lengths();
+            int vb = 0, ib = 0;
+            engine_->check(elba_dist_packed_format(engine_->ctx, W, bounds_.data(), all.data(), &fits, &vb, &ib));
+        }
+        was_packed_ = fits != 0;
+        const size_t rw = fits ? 1 : (size_t)kw_ + 1;             // words per record
         send_.reserve(sum(sc) * rw * 8);
         const std::vector<uint64_t> soff = offsets(sc);
-        engine_->check(elba_dist_fill_send(engine_->ctx, W, send_.p, soff.data()));
+        if (fits) engine_->check(elba_dist_fill_send_packed(engine_->ctx, W, send_.p, soff.data()));
+        else engine_->check(elba_dist_fill_send(engine_->ctx, W, send_.p, soff.data()));
         recv_.reserve(sum(rc) * rw * 8);
         all_to_all(send_, sc, recv_, rc, rw * 8);
         elba_kmer_stats ks{};
+        if (fits) {      // (the owner's side: 16-byte records again, in the send buffer — it is free — or a buffer of their own when that is too small)
+            detail::DevMem &exp = send_.cap >= sum(rc) * 16 ? send_ : unpacked_;
+            exp.reserve(sum(rc) * 16);
+            engine_->check(elba_dist_unpack_records(engine_->ctx, W, grid_->rank, recv_.p, rc.data(), exp.p));
+            engine_->check(elba_dist_count_records(engine_->ctx, exp.p, (int64_t)sum(rc), &ks));
+        } else
         engine_->check(elba_dist_count_records(engine_->ctx, recv_.p, (int64_t)sum(rc), &ks));
         // global k-mer ids: exclusive scan of the owners' counts (src/KmerOps.cpp:371-375)
         std::vector<uint64_t> ns = all_gather_u64((uint64_t)ks.reliable);
@@ -250,6 +269,25 @@ private:
         ELBA_DIST_HIP(hipStreamSynchronize(grid_->stream));
         return out;
     }
+    // the lengths of ALL reads in global order: an all-gather of the shards' lengths, padded to the longest shard
+    std::vector<uint32_t> all_gather_lengths()
+    {
+        const int W = grid_->size;
+        size_t mx = 1;
+        for (int r = 0; r < W; ++r) mx = std::max<size_t>(mx, (size_t)(bounds_[(size_t)r + 1] - bounds_[(size_t)r]));
+        scratch_.reserve((size_t)(W + 1) * mx * 4);
+        uint32_t *d = scratch_.as<uint32_t>();
+        std::vector<uint32_t> pad(mx, 0u);
+        std::copy(my_lens_.begin(), my_lens_.end(), pad.begin());
+        ELBA_DIST_HIP(hipMemcpyAsync(d + (size_t)W * mx, pad.data(), mx * 4, hipMemcpyHostToDevice, grid_->stream));
+        ELBA_DIST_NCCL(ncclAllGather(d + (size_t)W * mx, d, mx, ncclUint32, grid_->comm, grid_->stream));
+        std::vector<uint32_t> got((size_t)W * mx), out;
+        ELBA_DIST_HIP(hipMemcpyAsync(got.data(), d, (size_t)W * mx * 4, hipMemcpyDeviceToHost, grid_->stream));
+        ELBA_DIST_HIP(hipStreamSynchronize(grid_->stream));
+        out.reserve((size_t)bounds_.back());
+        for (int r = 0; r < W; ++r) out.insert(out.end(), got.begin() + (size_t)r * mx, got.begin() + (size_t)r * mx + (size_t)(bounds_[(size_t)r + 1] - bounds_[(size_t)r]));
+        return out;
+    }
     // recv_counts[p] = what rank p sends to this rank: an all-gather of every rank's send counts (W x W words), this rank's column of it
     std::vector<uint64_t> exchange_counts(const std::vector<uint64_t> &sendcnt)
     {
@@ -293,7 +331,9 @@ private:
     std::shared_ptr<DistGrid> grid_;
     std::shared_ptr<detail::Engine> engine_;
     std::vector<int64_t> bounds_;
-    detail::DevMem send_, recv_, scratch_;
+    detail::DevMem send_, recv_, scratch_, unpacked_;
+    std::vector<uint32_t> my_lens_;
+    bool packed_exchange_ = true, was_packed_ = false;
     int kw_ = 1;
     uint64_t exchange_bytes_ = 0, mirror_bytes_ = 0, slot_ = 0;
     bool shares_stream_ = false;

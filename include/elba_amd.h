@@ -364,6 +364,18 @@ int  elba_dist_set_kmer_id_base(elba_ctx *ctx, int64_t base, int64_t nall);
 int  elba_dist_count_owners(elba_ctx *ctx, int nranks, uint64_t *counts);
 /* write this rank's records into d_send (device, 8 (W + 1) bytes per record) grouped by owner; offsets[r] = first record index of owner r */
 int  elba_dist_fill_send(elba_ctx *ctx, int nranks, void *d_send, const uint64_t *offsets);
+/* Exchange #1 with 8-byte records (one-word k-mers, k <= 31; round 5).  The reference ships (k-mer, read, pos) per instance
+ * (src/KmerOps.cpp:105-151: a k-mer of NBYTES + the 8-byte seed, batched); here an instance travels as
+ * (value - first value of the owner's range) << index_bits | instance index in the SENDER's reads — the source rank is the segment of the
+ * receive buffer a record arrives in — where value_bits + index_bits <= 64 (k = 17 at two or more ranks of BASELINE config 3; never k = 31).
+ * elba_dist_packed_format: read_bounds[nranks + 1] = first global read of every rank, all_lens = the lengths of ALL reads (one all-gather of
+ * 4 bytes per read); decides the format — the same on every rank — and stores every rank's instance offsets on the device; *fits = 0: keep
+ * elba_dist_fill_send's 16-byte records.  Call after elba_dist_set_owner_ranges.  elba_dist_fill_send_packed: as elba_dist_fill_send, 8 bytes
+ * per record.  elba_dist_unpack_records: the owner side — recv_counts[p] packed records of rank p, segment after segment in d_packed, become
+ * 16-byte records (k-mer, global read << 32 | pos) in d_records, what elba_dist_count_records takes; `rank` = this owner. */
+int  elba_dist_packed_format(elba_ctx *ctx, int nranks, const int64_t *read_bounds, const uint32_t *all_lens, int *fits, int *value_bits, int *index_bits);
+int  elba_dist_fill_send_packed(elba_ctx *ctx, int nranks, void *d_send, const uint64_t *offsets);
+int  elba_dist_unpack_records(elba_ctx *ctx, int nranks, int rank, const void *d_packed, const uint64_t *recv_counts, void *d_records);
 /* owner side: exact count + [lower, upper] filter of the received records; builds the owner's columns (device; records are
  * borrowed until elba_dist_set_global_kmers returns) */
 int  elba_dist_count_records(elba_ctx *ctx, const void *d_records, int64_t nrecords, elba_kmer_stats *stats);

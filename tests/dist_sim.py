@@ -178,6 +178,48 @@ class NumpyBackend:
         rec = np.concatenate([km, self.rp[order][:, None]], axis=1).view(np.int64)
         send.copy_(torch.from_numpy(rec.copy()))
 
+    # exchange #1 with 8-byte records (include/elba_amd.h: elba_dist_packed_format): the same format, restated in numpy
+    def packed_format(self, W, bounds, all_lens):
+        if self.kw != 1 or getattr(self, "no_packed", False):
+            return None
+        k2 = 2 * self.k
+        self._pb = np.asarray(bounds, dtype=np.int64)
+        n = np.maximum(np.asarray(all_lens, dtype=np.int64) - self.k + 1, 0)
+        self._poff = [np.concatenate([[0], np.cumsum(n[self._pb[r]:self._pb[r + 1]])]).astype(np.uint64) for r in range(W)]
+        maxI = max(int(o[-1]) for o in self._poff)
+        up = np.asarray(self.range_upper, dtype=np.int64) if W > 1 else np.array([4096], dtype=np.int64)
+        lo_bins = np.concatenate([[0], up[:-1]])
+        self._plo = (lo_bins.astype(np.uint64) << np.uint64(k2 - 12))
+        maxw = int(((up - lo_bins).max()) << (k2 - 12))
+        bits = lambda x: max(1, int(x).bit_length())
+        vb, ib = bits(max(maxw - 1, 0)), bits(max(maxI - 1, 0))
+        if vb + ib > 64:
+            return None
+        self._pib = ib
+        return vb, ib
+
+    def fill_send_packed(self, W, send, offsets):
+        order = np.argsort(self.own, kind="stable")
+        val = (self.km >> np.uint64(64 - 2 * self.k))[order]
+        g = np.arange(len(self.km), dtype=np.uint64)[order]          # set_reads enumerated the instances in (read, pos) order: the index is the place
+        rec = ((val - self._plo[self.own[order]]) << np.uint64(self._pib)) | g
+        send.copy_(torch.from_numpy(rec.view(np.int64).copy()).reshape(-1, 1))
+
+    def unpack_records(self, W, rank, packed, recv_counts):
+        a = packed.numpy().reshape(-1).view(np.uint64)
+        out = np.zeros((len(a), 2), dtype=np.uint64)
+        at = 0
+        for p in range(W):
+            n = int(recv_counts[p])
+            w = a[at:at + n]
+            g = w & np.uint64((1 << self._pib) - 1)
+            val = (w >> np.uint64(self._pib)) + self._plo[rank]
+            r = np.searchsorted(self._poff[p], g, side="right") - 1
+            out[at:at + n, 0] = val << np.uint64(64 - 2 * self.k)
+            out[at:at + n, 1] = ((np.uint64(self._pb[p]) + r.astype(np.uint64)) << np.uint64(32)) | (g - self._poff[p][r])
+            at += n
+        return torch.from_numpy(out.view(np.int64).copy())
+
     def count_records(self, rec):
         a = rec.numpy().view(np.uint64)
         if self.kw > 1:

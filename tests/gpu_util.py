@@ -57,6 +57,7 @@ def gpu_full(packed, off, lens, k, lo, up, **kw):
 def host_copy(dev_ptr, count, dtype):
     """`count` items of `dtype` from a raw device pointer into a fresh numpy array (hipMemcpy through ctypes: plumbing for the checker)."""
     import ctypes
+    import torch  # noqa: F401  (the process's HIP runtime: the system libamdhip64.so resolves against the ROCr torch has loaded)
     hip = ctypes.CDLL("libamdhip64.so")
     out = np.empty(int(count), dtype=dtype)
     if count:

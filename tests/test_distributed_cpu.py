@@ -250,3 +250,36 @@ def test_the_ranks_generate_shares_of_the_one_process_read_set_repeat_families_i
             seqs.append(bytes(p[int(o[i]):int(o[i]) + (int(l[i]) + 3) // 4]))
     whole = [bytes(packed[int(off[i]):int(off[i]) + (int(lens[i]) + 3) // 4]) for i in range(len(lens))]
     assert seqs == whole
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_exchange_one_in_8_byte_records_equals_the_16_byte_exchange(world):
+    """Exchange #1 (round 5): an instance travels as (value inside its owner's range) << index bits | instance index in the sender's reads — 8 bytes,
+    the source rank known from the receive segment, every rank's read lengths all-gathered — and the owner turns it back into the 16-byte record
+    (k-mer, global read << 32 | pos).  The driver with the packed exchange equals the driver without it and the one-process oracle, rows, counters and
+    all; the bytes a rank sends are halved; with EIGHT ranks (the target machine: value ranges, panel windows and the ownership rule with eight
+    participants) as with two and three."""
+    o = _expected()
+
+    def run(r, h, packed):
+        rp, ro, rl, _ = _reads()
+        bounds = partition_by_bases(rl, world)
+        lo, hi = int(bounds[r]), int(bounds[r + 1])
+        sp, so, sl = _shard(rp, ro, rl, lo, hi)
+        d = DistributedOverlap(K, LO, UP, rank=r, world=world, dist=h, backend=dist_sim.NumpyBackend(K, LO, UP))
+        d.packed_exchange = packed
+        d.set_reads(sp, so, sl, lo, bounds)
+        ks, ms = d.build_kmer_matrix()
+        d.create_seed_matrix()
+        return d.export_csr(), ks, dict(d.exchange_bytes)
+
+    a = dist_sim.run_ranks(world, lambda r, h: run(r, h, True))
+    b = dist_sim.run_ranks(world, lambda r, h: run(r, h, False))
+    Ba, Bb, oB = dist_sim.stitch_rows([p[0] for p in a]), dist_sim.stitch_rows([p[0] for p in b]), o.B()
+    for B in (Ba, Bb):
+        assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
+    for pa, pb in zip(a, b):
+        assert all(pa[1][f] == pb[1][f] for f in ("reliable", "entries", "instances", "distinct"))
+        assert pa[2]["instance_format"].startswith("8-byte") and pb[2]["instance_format"].startswith("16-byte")
+        assert 2 * pa[2]["instances"] == pb[2]["instances"] and pa[2]["panels"] == pb[2]["panels"]
+    assert sum(p[1]["reliable"] for p in a) == o.stat("N") and sum(p[1]["entries"] for p in a) == o.stat("Z")

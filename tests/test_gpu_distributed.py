@@ -310,3 +310,38 @@ def test_a_panel_with_inline_partners_is_multiplied_with_the_exchange_only():
         B = dist_sim.stitch_rows([p[which] for p in parts])
         assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
     assert sum(p[3] for p in parts) == o.stat("Y") == sum(p[4] for p in parts)
+
+
+def test_eight_ranks_with_8_byte_exchange_records_equal_the_one_gpu_matrix():
+    """The target machine has EIGHT GPUs: eight ranks as threads on the one GPU of the test box — value-range owners, panel windows,
+    the pair-ownership rule and the mirror exchange with eight participants — on BASELINE config 3 at 1/16 of its genome.  Exchange #1 travels as 8-byte
+    records (round 5: value inside the owner's range | instance index in the sender's reads; elba_dist_packed_format) — half the bytes of the
+    (k-mer, read << 32 | pos) records, which the same driver with packed_exchange = False still sends: both equal the one-GPU B bit for bit."""
+    reads = elba_amd.synth_reads(2, 66_700_000 // 16, 30.0, 10000.0, 1500.0, error_rate=0.15, min_len=1000)
+    packed, off, lens, _ = reads
+    e = elba_amd.Engine(17, 2, 8, options={"kmer_msd": 1}); e.set_reads(packed, off, lens); ks1 = e.count_kmers(); e.create_kmer_matrix(); st = e.create_seed_matrix()
+    B1 = e.export_csr(); e.close()
+    world = 8
+    bounds = partition_by_bases(lens, world)
+
+    def body(rank, h, packed_records):
+        a, b = int(bounds[rank]), int(bounds[rank + 1])
+        sp, so, sl = _shard(packed, off, lens, a, b)
+        d = DistributedOverlap(17, 2, 8, device=0, rank=rank, world=world, dist=h, backend=HipBackend(17, 2, 8, 0))
+        d.packed_exchange = packed_records
+        d.set_reads(sp, so, sl, a, bounds)
+        ks, ms = d.build_kmer_matrix()
+        s2 = d.create_seed_matrix()
+        out = (d.export_csr(), s2, ks, dict(d.exchange_bytes))
+        d.be.e.close()
+        return out
+
+    for packed_records in (True, False):
+        parts = dist_sim.run_ranks(world, lambda r, h: body(r, h, packed_records))
+        B = dist_sim.stitch_rows([p[0] for p in parts])
+        assert B["Y"] == B1["Y"] == st["nnz"] and (B["rowptr"] == B1["rowptr"]).all() and (B["col"] == B1["col"].astype(np.int64)).all() and (B["val"] == B1["val"]).all()
+        assert sum(p[1]["products"] for p in parts) == st["products"]
+        assert sum(p[2]["instances"] for p in parts) == ks1["instances"] and sum(p[2]["entries"] for p in parts) == ks1["entries"] and sum(p[2]["reliable"] for p in parts) == ks1["reliable"]
+        for p in parts:
+            assert p[3]["instance_format"].startswith("8-byte" if packed_records else "16-byte")
+            assert p[3]["instances"] == p[2]["instances"] * (8 if packed_records else 16)

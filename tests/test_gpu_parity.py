@@ -699,6 +699,29 @@ def test_duplicate_triples_are_kept_by_the_bucket_kernels():
     e.close()
 
 
+@pytest.mark.parametrize("lo,up,opts", [(2, 8, {}), (2, 40, {}), (2, 8, {"msd_small_cap": 300}), (3, 12, {"no_inline": 1})])
+def test_value_range_batches_of_the_kmer_stage_equal_the_unbatched_matrix(lo, up, opts):
+    """More k-mer instances than a 32-bit place holds are counted in PASSES over ranges of first digits (kmer_msd.hip, "VALUE-RANGE BATCHING": the
+    reference batches its exchange so that size is no limit, include/KmerOps.hpp:33-56).  The option "kmer_batch_instances" forces passes on a small
+    set: three passes, and one pass per first digit, give the k-mers, both orientations of A and B of the unbatched run bit for bit — general and
+    dense matrices, crowded buckets (the windowed kernel), a build without inline partners."""
+    packed, off, lens, info = elba_amd.synth_reads(83, 900000, 14, 3000, 800, error_rate=0.06, min_len=100)
+    base = dict(opts, kmer_msd=1)
+    e0, ks0, ms0, st0 = gu.gpu_full(packed, off, lens, 17, lo, up, options=base)
+    assert e0.get_stat("kmer_path") == 1
+    A0, B0 = e0.export_kmer_matrix(), e0.export_csr()
+    e0.close()
+    I = int(ks0["instances"])
+    for cap in (I // 3 + 1, 1):                                      # three passes; a pass per first digit (a digit is never split)
+        e, ks, ms, st = gu.gpu_full(packed, off, lens, 17, lo, up, options=dict(base, kmer_batch_instances=cap))
+        assert e.get_stat("kmer_path") == 1 and e.get_stat("kmer_passes") >= (3 if cap > 1 else 100)
+        assert all(ks[f] == ks0[f] for f in ("instances", "distinct", "reliable", "entries"))
+        gu.assert_A_equal(e.export_kmer_matrix(), A0)
+        gu.assert_B_equal(e.export_csr(), B0)
+        assert all(st[f] == st0[f] for f in ("nnz", "products", "nnz_before_prune", "nnz_diag", "nnz_upper", "max_numshared"))
+        e.close()
+
+
 @pytest.mark.parametrize("dk", [0, 1, 2, 4])
 def test_more_gather_trips_in_flight_give_the_same_matrix(dk):
     """The option "dk" (gather trips per iteration of the padded-column loop: one, two, four or eight; chosen per matrix by default) selects
