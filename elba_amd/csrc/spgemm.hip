@@ -83,6 +83,8 @@ struct OvParams {
     uint32_t j_shift, dense_up;
     uint32_t hint_mask, pos_mask;   // which hint bit of a row entry lets this call skip its column (0: none) / the position bits (Ctx::csr_hints)
     uint32_t inl;                   // Ctx::csr_inline: row entries with bit 63 set carry their (only) partner: 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16
+    uint32_t pay16;                 // the LDS tiers' 32-bit accumulators carry posT (sequence number << 16 | posT) and the FIFO entries are 8 bytes: positions and every row's
+                                    // sequence numbers fit 16 bits (spgemm_direct.hpp) — 18 bytes per table slot and 2 KB of rings per wavefront: three rows per CU on the 2048-slot tier
     uint32_t suffix;                // dense matrices (Ctx::csr_suffix): row entries carry column length and own place, the smaller row owns a pair
     uint32_t s_stride, lpc_log2, max_col;    // padded column stride in entries (a_ell); lanes per row entry 2^lpc_log2; longest column
     unsigned long long fb_enough;            // row entries behind the in-call partner / entry ratio at which it counts as settled (nobody touches the hot sums any more)
@@ -956,7 +958,14 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.prior_q16 = c.ov_prior_q16 ? c.ov_prior_q16 : 16384u;      // distinct partners per row entry: 1/4 until measured
     p.use_feedback = c.ov_prior_q16 ? 0u : 1u;
     p.fb_enough = (unsigned long long)std::min<int64_t>(std::max<int64_t>(Z / 32, 1 << 16), 1 << 23);
-    const bool pay = c.pos16 && !c.opt.no_pay;
+    bool pay = c.pos16 && !c.opt.no_pay;
+    // Round 5: where the positions AND every row's product sequence numbers (rank in the row << fbits | place in the column) fit 16 bits — every read set of
+    // ~10 kb reads — the extremes live in 32-bit words that carry posT (posQ is looked up in the row entry the sequence number names): the 2048-slot tier
+    // then needs 37 KB of table + 16 KB of rings per 512-lane workgroup instead of 53 + 24.5: THREE rows per CU in flight instead of two (the kernel waits for
+    // memory 69 % of its time: profiles/r04_summary.json), at the same 72-78 VGPRs.  Option "tune3" = 1 keeps the 64-bit accumulators (A/B).
+    const bool pay16 = pay && c.use_ell && !c.csr_suffix && c.opt.tune[3] != 1 && ((uint64_t)c.max_row_nnz << c.fbits) <= 65536ull;
+    p.pay16 = pay16 ? 1u : 0u;
+    if (pay16) pay = false;
     // workgroup sizes grow with the table so that the largest tiers still bring enough waves to a CU (one or two workgroups fit its LDS)
     const uint32_t blk[NUM_LDS_TIERS] = {p.suffix ? 256u : 128u, p.suffix && p.dense_up >= 1u ? 512u : 256u, p.suffix && p.dense_up >= 2u ? 1024u : 512u, 1024u, 512u};      // (dense path: four wavefronts share a 512-slot table — 32 per CU)
     for (int t = 0; t < NUM_LDS_TIERS; ++t) {
@@ -1042,7 +1051,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         if (timed) c.ov_marks.mark(1, s);
         if (nrows > 0) {
             // bytes behind the table: misc words + per wavefront one product ring (128 entries of 12 / 8 bytes) and one row-entry FIFO (128 x 12 bytes)
-            auto X = [&](int B, bool P) { return (size_t)256 + (size_t)(B / 64) * (P ? 3072 : 2560); };
+            auto X = [&](int B, bool P) { return (size_t)256 + (size_t)(B / 64) * (P ? 3072 : (pay16 ? 2048 : 2560)); };
             const bool all_tiers = !c.ov_tiers_known || phase == 2;
             skipped_tiers = 0;
 #define ELBA_DTIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
@@ -1089,7 +1098,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
                 ELBA_DTIER(3, ELBA_LAUNCH_D(1024, false, false, cus, (size_t)18 * 4096 + X(1024, false), 3, 12u, 0u));
             }
             ELBA_DTIER(4, ELBA_LAUNCH_D(256, false, false, cus, (size_t)18 * 8192 + X(256, false), 4, 13u, 0u));      // (4 wavefronts: 8192 slots + their rings fill the 160 KB)
-            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, X(256, false), NUM_LDS_TIERS, 0u, 0u));
+            ELBA_DTIER(5, ELBA_LAUNCH_D(256, true, false, spill_blocks, (size_t)256 + 4 * 2560, NUM_LDS_TIERS, 0u, 0u));      // (the HBM tier never packs its FIFO entries: 2560 bytes of rings per wavefront)
 #undef ELBA_LAUNCH_S
 #undef ELBA_LAUNCH_D
 #undef ELBA_DTIER

@@ -254,7 +254,10 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
         uint32_t head = 0, tail = 0;             // ring positions (uniform)
         // per wavefront: product ring (128 x 12 or 8 bytes), then the entry FIFO of the padded-column path (128 x 12 bytes); the dense path keeps
         // the ring (for the products its fast look-up misses) and its 336 words of hand-out tables
-        uint32_t *qj = misc + 64 + (tid >> 6) * (SUFFIX ? 592u : (PAY ? 768u : 640u));
+        // (pay16, OvParams: 32-bit accumulators that CARRY posT — sequence number << 16 | posT — and 8-byte FIFO entries: 512 words per wavefront, 18 bytes per slot:
+        //  three 512-lane workgroups per CU where the 64-bit accumulators admit two)
+        const bool pay16 = !PAY && !SUFFIX && !GLOBAL && p.pay16 != 0u;
+        uint32_t *qj = misc + 64 + (tid >> 6) * (SUFFIX ? 592u : (PAY ? 768u : (pay16 ? 512u : 640u)));
         uint32_t *qs = qj + RING;
         unsigned long long *qv = reinterpret_cast<unsigned long long *>(qj + RING);
         auto drain = [&](uint32_t n) {           // n <= 64 products leave the ring, one per lane
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             const uint32_t at = (tail + (uint32_t)__popcll(mi & lt)) & (RING - 1u);
             if (ins) {
                 qj[at] = j;
-                if (PAY) qv[at] = ((unsigned long long)seq << 32) | (posQ << 16) | posT; else qs[at] = seq;
+                if (PAY) qv[at] = ((unsigned long long)seq << 32) | (posQ << 16) | posT; else qs[at] = pay16 ? (seq << 16) | posT : seq;
             }
             tail += (uint32_t)__popcll(mi);
             if (tail - head >= 64u) drain(64u);
@@ -457,7 +460,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                             const uint32_t at = (tail + (uint32_t)__popcll(mi & lt)) & (RING - 1u);
                             if (inl) {
                                 qj[at] = j;
-                                if (PAY) qv[at] = ((unsigned long long)seq << 32) | ((ea.x & 0xFFFFu) << 16) | (ea.x >> 16); else qs[at] = seq;
+                                if (PAY) qv[at] = ((unsigned long long)seq << 32) | ((ea.x & 0xFFFFu) << 16) | (ea.x >> 16); else qs[at] = pay16 ? (seq << 16) | (ea.x >> 16) : seq;
                             }
                             tail += (uint32_t)__popcll(mi);
                             if (tail - head >= 64u) drain(64u);
@@ -467,8 +470,9 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 const uint64_t mn = __ballot(need);
                 dg += (uint32_t)__popcll(__ballot(valid && !need));       // skipped and inline entries: their one diagonal product
                 if (need) {
-                    const uint32_t at = ((ft + (uint32_t)__popcll(mn & lt)) & (FQ - 1u)) * 3u;
-                    fq[at] = ea.x & pmask; fq[at + 1u] = ea.y; fq[at + 2u] = ca + lane;
+                    const uint32_t at = ((ft + (uint32_t)__popcll(mn & lt)) & (FQ - 1u)) * (pay16 ? 2u : 3u);
+                    if (pay16) { fq[at] = (ea.x & 0xFFFFu) | ((ca + lane) << 16); fq[at + 1u] = ea.y; }      // (positions and the rank in the row fit 16 bits each: the condition of pay16)
+                    else { fq[at] = ea.x & pmask; fq[at + 1u] = ea.y; fq[at + 2u] = ca + lane; }
                 }
                 ft += (uint32_t)__popcll(mn);
                 ea = eb; ca = cb;
@@ -485,8 +489,9 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                     const uint32_t k = (uint32_t)u * EW + gw;
                     x[u] = ones; pq[u] = 0; rk[u] = 0;
                     if (k < ft - fh && 2u * sub < stride) {      // (a stride that is no power of two leaves the group's last lanes without a word)
-                        const uint32_t at = ((fh + k) & (FQ - 1u)) * 3u;
-                        pq[u] = fq[at]; rk[u] = fq[at + 2u];
+                        const uint32_t at = ((fh + k) & (FQ - 1u)) * (pay16 ? 2u : 3u);
+                        if (pay16) { const uint32_t w0 = fq[at]; pq[u] = w0 & 0xFFFFu; rk[u] = w0 >> 16; }
+                        else { pq[u] = fq[at]; rk[u] = fq[at + 2u]; }
                         x[u] = *reinterpret_cast<const uint4 *>(p.a_ell + ((unsigned long long)fq[at + 1u] * stride + 2u * sub));
                     }
                 }
@@ -678,6 +683,12 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                     if (PAY) {
                         const uint32_t va = (uint32_t)tab.vmin[s0], vb = (uint32_t)tab.vmax[s0];
                         v.q0 = va >> 16; v.t0 = va & 0xFFFFu; v.q1 = vb >> 16; v.t1 = vb & 0xFFFFu;
+                    } else if (pay16) {
+                        // the accumulators hold sequence number << 16 | posT; posQ is the row entry's own position — the entry is named by the sequence number
+                        const uint32_t va = tab.ld(tab.smin, s0), vb = tab.ld(tab.smax, s0);
+                        const uint2 ca2 = csr2[rs + ((va >> 16) >> fbits)], cb2 = csr2[rs + ((vb >> 16) >> fbits)];
+                        v.q0 = (p.inl != 0u && (ca2.y >> 31) != 0u) ? (ca2.x & 0xFFFFu) : (ca2.x & pmask); v.t0 = va & 0xFFFFu;
+                        v.q1 = (p.inl != 0u && (cb2.y >> 31) != 0u) ? (cb2.x & 0xFFFFu) : (cb2.x & pmask); v.t1 = vb & 0xFFFFu;
                     } else {
                         seed_at(tab.ld(tab.smin, s0), v.q0, v.t0);
                         seed_at(tab.ld(tab.smax, s0), v.q1, v.t1);
