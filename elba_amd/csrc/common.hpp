@@ -306,6 +306,7 @@ struct Ctx {
     uint32_t ov_slab_q16 = 0;       // mirrored entries per row entry of A measured by the previous call on the whole matrix (x 65536, without the margin), 0 = unknown
     DevBuf ov_slab;                 // uint4[ov_slab_cap]: the rows' mirror slabs (spgemm.hip)
     int64_t ov_slab_cap = 0;
+    DevBuf ov_tickrows;             // u32[M / 32 + 1]: rows that staged an entry whose image took a ticket (spgemm.hip: OvParams::tick_rows)
     DevBuf ov_slabpos, ov_slabn;    // u64[M] slab end << 32 | next free entry; u32[M] entries in every row's slab (spgemm.hip)
     bool ov_slab_on = false;        // the running call has slabs (ov_launch_finalize reads them)
     uint32_t ov_slab_q16_used = 0;  // diagnostic: the ratio the last call's slabs were sized by (margin included), 0 = none

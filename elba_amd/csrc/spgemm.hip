@@ -83,6 +83,8 @@ struct OvParams {
     uint32_t j_shift, dense_up;
     uint32_t hint_mask, pos_mask;   // which hint bit of a row entry lets this call skip its column (0: none) / the position bits (Ctx::csr_hints)
     uint32_t inl;                   // Ctx::csr_inline: row entries with bit 63 set carry their (only) partner: 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16
+    uint32_t *tick_rows;            // bit i: row i staged at least one entry whose image took a TICKET (k_mirror places those; rows without one are not walked)
+    uint32_t min_tier;              // rows start on this tier at least (k_classify_direct)
     uint32_t pay16;                 // the LDS tiers' 32-bit accumulators carry posT (sequence number << 16 | posT) and the FIFO entries are 8 bytes: positions and every row's
                                     // sequence numbers fit 16 bits (spgemm_direct.hpp) — 18 bytes per table slot and 2 KB of rings per wavefront: three rows per CU on the 2048-slot tier
     uint32_t suffix;                // dense matrices (Ctx::csr_suffix): row entries carry column length and own place, the smaller row owns a pair
@@ -164,6 +166,7 @@ struct FinParams {
     long long b_cap;         // capacity of b_col / b_val in entries: rows that would not fit are left out (the host regrows and reruns)
     uint32_t mir16;          // positions fit 16 bits: a mirrored entry is ONE 16-byte word (i, q0 | t0 << 16, q1 | t1 << 16, numshared) — one store
                              // request per scattered entry instead of two, half the bytes read back
+    const uint32_t *tick_rows;      // OvParams::tick_rows
     const uint32_t *a_rowptr; uint4 *slab;      // mirror slabs (above; mir16 records): null = none
     const unsigned long long *slab_pos; uint32_t *slab_n;      // [M] the slabs' fill words as the numeric kernels left them / entries in every row's slab (k_slab_fold; null with slab)
 };
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
             p.fin_lists[(size_t)which * p.M + at] = i;
         }
         if (!p.half) continue;
+        if (p.tick_rows && !((p.tick_rows[i >> 5] >> (i & 31u)) & 1u)) continue;      // (none of the row's images took a ticket: nothing to place — round 5: the pass read every staged entry's ticket, 200 MB on config 3, to find 63 k of them)
         if (p.rec16) {           // one 16-byte word in, one out: the two positions of each seed change places
             for (uint32_t t = lane; t < own; t += 64) {
                 const uint32_t tk = p.tick[off + t];
@@ -797,6 +801,7 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
     f.M = (uint32_t)M; f.row_lo = (uint32_t)row_lo; f.row_hi = (uint32_t)row_hi; f.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1); f.ctr = c.ov_counters.as<OvCounters>();
     f.b_cap = c.b_cap_entries;
     f.mir16 = mir16 ? 1u : 0u;
+    f.tick_rows = c.ov_tickrows.as<uint32_t>();
     f.rec16 = c.ov_rec16 ? 1u : 0u; f.rec = c.ov_tmp.as<uint4>(); f.tick = reinterpret_cast<const uint32_t *>(c.ov_tmp.as<char>() + (size_t)c.ov_tmp_cap * 16);
     f.a_rowptr = c.a_rowptr.as<uint32_t>(); f.slab = (half == 1u && mir16 && c.ov_slab_on) ? c.ov_slab.as<uint4>() : nullptr;
     f.slab_pos = f.slab ? c.ov_slabpos.as<unsigned long long>() : nullptr; f.slab_n = f.slab ? c.ov_slabn.as<uint32_t>() : nullptr;
@@ -972,6 +977,11 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         const uint32_t T = 1u << (LDS_TBITS0 + t);
         p.tier_limit[t] = std::min((T >> 2) * 3, T - blk[t]) - 1;      // a lane overshoots by at most one claim (Table::insert_lds)
     }
+    c.ov_tickrows.reserve((size_t)(M / 32 + 2) * 4);
+    p.tick_rows = c.ov_tickrows.as<uint32_t>();
+    // a large matrix's rows start on the 2048-slot tier at least (three rows per CU with pay16): the two smaller tiers would receive a percent of the rows and cost a
+    // ~60 us launch each — 6.48 -> 6.3x ms on config 3; small matrices keep them (their rows ARE small); option "tune4" = 1: every tier (A/B)
+    p.min_tier = (pay16 && nrows >= 65536 && Z / nrows >= 1024 && c.opt.tune[4] != 1) ? 2u : 0u;      // (long rows only: a 512-lane workgroup on a row of 75 entries would idle)
     p.row_cnt = c.ov_rowcnt.as<uint32_t>(); p.low_cnt = c.ov_totcnt.as<uint32_t>();
     p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
     p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
@@ -1041,6 +1051,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         c.ov_low_clean = false;
         ELBA_HIP(hipMemsetAsync(c.ov_counters.p, 0, sizeof(OvCounters), s));
         ELBA_HIP(hipMemsetAsync(c.ov_rowcnt.p, 0, (size_t)(M + 2) * 4, s));
+        ELBA_HIP(hipMemsetAsync(c.ov_tickrows.p, 0, (size_t)(M / 32 + 2) * 4, s));
         // A cold call on a matrix of some size computes a SAMPLE of its rows first (every sstep-th row, on the 4096-slot tier): what they find
         // — distinct partners per row entry — picks the starting tier of all the others, instead of a guess that sends most rows of a
         // 15 %-error read set to a tier too small (an abandoned attempt or a forwarding each: 0.9 ms of a 14.7 ms call on the 200 k-read set).

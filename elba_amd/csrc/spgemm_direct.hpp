@@ -667,6 +667,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
             const uint32_t ysurv = ysurv_row;
             const uint32_t hasd = dcount_row >= 2 ? 1u : 0u;
             uint32_t nup = 0, mx = 0, nmir = 0;
+            bool drew = false;      // an image of this row took a ticket (no slab yet, or a full one): k_mirror has to walk the row's staged entries (OvParams::tick_rows)
             auto seed_at = [&](uint32_t a, uint32_t &q, uint32_t &t) {      // sequence number -> the two positions (32-bit accumulators only)
                 const uint2 ce = csr2[rs + (a >> fbits)];
                 if (p.inl != 0u && (ce.y >> 31) != 0u) { q = ce.x & 0xFFFFu; t = ce.x >> 16; return; }      // an inline partner carries both positions
@@ -715,6 +716,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                         else tick = atomicAdd(&p.low_cnt[j], 1u);
                     } else tick = atomicAdd(&p.low_cnt[j], 1u);
                 }
+                drew |= tick != 0xFFFFFFFFu;
                 if (p.rec16) { p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared); p.tick[off + t] = tick; }
                 else {
                     p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
@@ -724,6 +726,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                 if (j != i && ((p.half && j >= p.row_lo && j < p.row_hi) || j > i)) ++nup;
                 mx = (uint32_t)v.numshared > mx ? (uint32_t)v.numshared : mx;
             }
+            if (__ballot(drew) != 0 && lane == 0) atomicOr(&p.tick_rows[i >> 5], 1u << (i & 31u));
             if (nup) lds_add64(w64(W_NUP), (unsigned long long)nup);
             if (nmir) lds_add64(w64(W_MIR), (unsigned long long)nmir);
             if (mx) lds_max32(&misc[W_MX], mx);
@@ -828,6 +831,7 @@ __global__ __launch_bounds__(256) void k_classify_direct(OvParams p, int mode)
             while (tier < NUM_LDS_TIERS && est > p.tier_limit[tier]) ++tier;
             const int gt = gbits <= LDS_TBITS0 ? 0 : (int)gbits - LDS_TBITS0;      // never start above the tier that is guaranteed to fit
             if (gt < tier) tier = gt;
+            if (tier < (int)p.min_tier) tier = (int)p.min_tier;      // (a large matrix skips the small-table tiers: their handful of rows costs a launch of ~60 us each)
             if (p.suffix && tier < (int)p.dense_up) tier = (int)p.dense_up;      // (dense path: a lower load factor means fewer look-ups that miss their first slot)
             if (tier > NUM_LDS_TIERS) tier = NUM_LDS_TIERS;
             mytier = tier;
