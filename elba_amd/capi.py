@@ -125,7 +125,7 @@ EXPORTED_SYMBOLS = [
     "elba_export_csr", "elba_free_csr", "elba_export_kmer_matrix", "elba_free_kmer_matrix", "elba_kmer_histogram", "elba_get_device_view", "elba_set_option",
     "elba_align_seeds", "elba_export_overlaps", "elba_free_overlaps", "elba_set_overlaps", "elba_transitive_reduction", "elba_export_string_graph", "elba_export_read_flags", "elba_set_reads_fasta", "elba_export_reads", "elba_dist_set_all_reads",
     "elba_synth_num_reads", "elba_synth_generate", "elba_synth_free",
-    "elba_kmer_hash_owner", "elba_dist_value_histogram", "elba_dist_set_owner_ranges", "elba_dist_set_kmer_id_base", "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
+    "elba_kmer_hash_owner", "elba_dist_value_histogram", "elba_dist_set_owner_ranges", "elba_dist_set_kmer_id_base", "elba_dist_count_owners", "elba_dist_fill_send", "elba_dist_packed_format", "elba_dist_fill_send_packed", "elba_dist_unpack_records", "elba_dist_count_records", "elba_dist_get_reliable_kmers", "elba_dist_copy_reliable_kmers",
     "elba_dist_set_global_kmers", "elba_dist_panel_counts", "elba_dist_panel_fill", "elba_dist_panel_counts_win", "elba_dist_panel_fill_win", "elba_dist_set_panel",
     "elba_seed_matrix_begin", "elba_seed_matrix_fill", "elba_seed_matrix_end", "elba_set_stream", "elba_seed_matrix_send", "elba_seed_matrix_recv", "elba_set_kmer_matrix_device", "elba_export_triples_device", "elba_get_stat", "elba_release_workspace",
 ]

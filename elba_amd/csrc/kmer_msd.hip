@@ -286,7 +286,7 @@ __device__ __forceinline__ void lds_sync_fwd() { asm volatile("s_waitcnt lgkmcnt
 // The tile is ordered by digit in LDS and written out by consecutive lanes (a digit's keys of one tile are one contiguous run in the output).
 // The grid is PERSISTENT (ntiles tiles dealt round-robin to the workgroups, one workgroup per CU: the tile fills its LDS): a workgroup per tile paid the
 // dispatch of sixteen wavefronts and 139 KB of LDS every ~20 us.
-template <bool ENUM>
+template <bool ENUM, bool FILTER = false>      // FILTER: value-range batching — only the instances whose first digit lies in [dlo, dhi) (an instantiation of its own: the test costs the one-pass kernel 7 %)
 __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const BlockInfo *block_read, MsdParams m, const uint64_t *in, SegTiles sg, int shift, int bits,
                                                            const uint32_t *hist_scanned, uint64_t *out, uint32_t ntiles, uint32_t dlo, uint32_t dhi)
 {
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         for (int q = 0; q < MT_ITEMS / 2; ++q) dig2[q] = 0xFFFFFFFFu;
         enum_consecutive(e, block_read, base, [&](int it, uint64_t km, uint32_t r, uint32_t p) {
             const uint32_t dg = (uint32_t)(km >> (64 - m.b1));
-            if (dg < dlo || dg >= dhi) return;      // (another pass's instance: no key)
+            if (FILTER && (dg < dlo || dg >= dhi)) return;      // (another pass's instance: no key)
             key[it] = (((km >> (64 - m.k2)) & vmask) << m.PB) | ((uint64_t)r << m.pbits) | p;
             dig2[it >> 1] = (it & 1) ? (dig2[it >> 1] & 0xFFFFu) | (dg << 16) : (dig2[it >> 1] & 0xFFFF0000u) | dg;
         });
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * MT_THREADS; if (d < nbins) gbase[d] = gb[u]; }
     }
     __syncthreads();
-    if (ENUM) count = kept_s;
+    if (ENUM && FILTER) count = kept_s;
 #pragma unroll
     for (int it = 0; it < MT_ITEMS; ++it) {
         const uint32_t d = digit(it);
@@ -1771,7 +1771,8 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         hipLaunchKernelGGL(k_msd_hist1, dim3(ntiles1), dim3(MT_THREADS), 0, s, e, bi, m, hist, dlo, dhi);
         radix_column_scan(s, hist, (int64_t)ntiles1, nb1, c.ws_scan);
         hipLaunchKernelGGL(k_msd_tiles, dim3(1), dim3(MT_MAXBINS), 0, s, (const uint32_t *)hist, nb1, Iv, b1start, tile0);
-        hipLaunchKernelGGL((k_msd_scatter<true>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa, ntiles1, dlo, dhi);
+        if (batched) hipLaunchKernelGGL((k_msd_scatter<true, true>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa, ntiles1, dlo, dhi);
+        else hipLaunchKernelGGL((k_msd_scatter<true, false>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa, ntiles1, dlo, dhi);
         // second digit, inside every first-digit bucket
         hipLaunchKernelGGL(k_msd_hist2, dim3(nt2), dim3(MT_THREADS), 0, s, (const uint64_t *)wa, sg, shift2, m.b2, hist);
         hipLaunchKernelGGL(k_msd_segscan, dim3(nb1), dim3(MT_MAXBINS), 0, s, hist, sg, nb2, b2start, Iv);

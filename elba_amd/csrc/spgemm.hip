@@ -58,7 +58,7 @@ struct OvCounters {              // device-side counters, zeroed per call
     unsigned int tier_done[NUM_TIERS];    // rows completed per tier
     unsigned int fin_count[2];            // rows needing the workgroup bucket sort / the HBM-bitonic sort of their columns
     unsigned int slab_q16;                // mirror slabs: slab entries per row entry of A (x 65536) of this call, 0 = no slabs (k_classify_direct writes it: the sample's rows run before it is known)
-    unsigned int pad;
+    unsigned int ntick;                   // staged entries whose image took a ticket: the list k_mirror walks (OvParams::tick, 16-byte records)
     unsigned long long mir_placed;        // diagnostic: mirrored entries k_mirror placed (those that found no room in their row's slab, or had none)
     unsigned long long pad2[13];          // keep the feedback sums on a cache line of their own
     alignas(128) unsigned int sample_next[8][32];          // the same for the sample queue (below)
@@ -298,22 +298,8 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
             const uint32_t at = atomicAdd(&p.ctr->fin_count[which], 1u);
             p.fin_lists[(size_t)which * p.M + at] = i;
         }
-        if (!p.half) continue;
-        if (p.tick_rows && !((p.tick_rows[i >> 5] >> (i & 31u)) & 1u)) continue;      // (none of the row's images took a ticket: nothing to place — round 5: the pass read every staged entry's ticket, 200 MB on config 3, to find 63 k of them)
-        if (p.rec16) {           // one 16-byte word in, one out: the two positions of each seed change places
-            for (uint32_t t = lane; t < own; t += 64) {
-                const uint32_t tk = p.tick[off + t];
-                if (tk == 0xFFFFFFFFu) continue;
-                const uint4 r = p.rec[off + t];
-                const uint4 img = make_uint4(i, (r.y >> 16) | (r.y << 16), (r.z >> 16) | (r.z << 16), r.w);
-                ++placed;
-                const int64_t at = p.b_rowptr[r.x] + (int64_t)tk;
-                if (at >= p.b_cap) continue;
-                if (p.mir16) reinterpret_cast<uint4 *>(p.mir)[at] = img;
-                else { p.mir[at].a = make_uint4(i, 0xFFFFFFFFu, img.y & 0xFFFFu, img.y >> 16); p.mir[at].b = make_uint4(img.z & 0xFFFFu, img.z >> 16, img.w, 0u); }
-            }
-            continue;
-        }
+        if (!p.half || p.rec16) continue;      // (16-byte records: the ticketed entries are a list, below)
+        if (p.tick_rows && !((p.tick_rows[i >> 5] >> (i & 31u)) & 1u)) continue;      // (none of the row's images took a ticket: nothing to place)
         for (uint32_t t = lane; t < own; t += 64) {
             const uint4 a = p.tmp[off + t].a;
             if (a.y == 0xFFFFFFFFu) continue;
@@ -325,6 +311,20 @@ __global__ __launch_bounds__(256) void k_mirror(FinParams p)
                 p.mir[at].a = make_uint4(i, 0xFFFFFFFFu, a.w, a.z);
                 p.mir[at].b = make_uint4(b.y, b.x, b.z, 0u);
             }
+        }
+    }
+    if (p.half && p.rec16) {
+        // 16-byte records: one lane per listed entry (row, place among the row's staged entries, ticket) — one word in, one out, the two positions of each seed change places
+        const uint32_t n = p.ctr->ntick, stride = gridDim.x * blockDim.x;
+        for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += stride) {
+            const uint32_t i = p.tick[3ull * e], t = p.tick[3ull * e + 1u], tk = p.tick[3ull * e + 2u];
+            const uint4 r = p.rec[p.row_off[i] + t];
+            const uint4 img = make_uint4(i, (r.y >> 16) | (r.y << 16), (r.z >> 16) | (r.z << 16), r.w);
+            ++placed;
+            const int64_t at = p.b_rowptr[r.x] + (int64_t)tk;
+            if (at >= p.b_cap) continue;
+            if (p.mir16) reinterpret_cast<uint4 *>(p.mir)[at] = img;
+            else { p.mir[at].a = make_uint4(i, 0xFFFFFFFFu, img.y & 0xFFFFu, img.y >> 16); p.mir[at].b = make_uint4(img.z & 0xFFFFu, img.z >> 16, img.w, 0u); }
         }
     }
     placed = wave_sum_u32(placed);

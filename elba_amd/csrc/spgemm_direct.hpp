@@ -717,7 +717,12 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
                     } else tick = atomicAdd(&p.low_cnt[j], 1u);
                 }
                 drew |= tick != 0xFFFFFFFFu;
-                if (p.rec16) { p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared); p.tick[off + t] = tick; }
+                if (p.rec16) {
+                    p.rec[off + t] = make_uint4(j, v.q0 | v.t0 << 16, v.q1 | v.t1 << 16, (uint32_t)v.numshared);
+                    // (round 5: an entry whose image took a ticket — rare: the sample's rows, a full slab — joins a LIST for k_mirror; every staged entry used to
+                    //  store its ticket, 49 M four-byte store requests of a kernel that is bound by its request rate)
+                    if (tick != 0xFFFFFFFFu) { const uint32_t at = atomicAdd(&p.ctr->ntick, 1u); p.tick[3ull * at] = i; p.tick[3ull * at + 1u] = t; p.tick[3ull * at + 2u] = tick; }
+                }
                 else {
                     p.tmp[off + t].a = make_uint4(j, tick, v.q0, v.t0);
                     p.tmp[off + t].b = make_uint4(v.q1, v.t1, (uint32_t)v.numshared, 0u);

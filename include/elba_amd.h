@@ -311,7 +311,17 @@ int  elba_get_device_view(elba_ctx *ctx, elba_device_view *view);
  *   "overlap_cold_calls" (0 | 1): 1 = every elba_create_seed_matrix call forgets what earlier calls on the same matrix learned (the
  *       distinct-partner ratio that picks the starting table tiers, which tiers and column sorts received rows): what a caller that
  *       multiplies every matrix once pays — the reference's create_seed_matrix is called once per A (src/main.cpp:281).  Buffers stay
- *       allocated.  Default 0. */
+ *       allocated.  Default 0.
+ *   "kmer_batch_instances" (>= 0): LIMITS.  The reference batches its k-mer exchange so that the input's size is no limit
+ *       (include/KmerOps.hpp:10-12,33-56).  Here a context counts any number of k-mer instances for 9 <= k <= 17 — more than this option allows at
+ *       once (0, the default: 0xE0000000, what a 32-bit place holds) are counted in PASSES over ranges of the k-mer value (consecutive first
+ *       digits of the value partition: the passes yield consecutive k-mer ids and consecutive stretches of the columns; every pass enumerates the
+ *       reads again and the whole input is counted twice — once for the sizes A's layout depends on, once to write it) — bounded by device memory
+ *       (16 bytes per instance of the largest pass) and by nnz(A) < 2^32 per context (32-bit row / column pointers).  Tests set a small value to
+ *       force passes; the result does not depend on it.  Every other k-mer path (k > 17, the sort) holds 32-bit places: < 2^32 instances.
+ *   "measure_prep" (0 | 1): diagnostic — elba_count_kmers runs its emit kernels a second time without what they write for the SpGEMM's sake alone and
+ *       brackets both runs with events (elba_get_stat "spgemm_prep_us").
+ *   "tune0" .. "tune7": A/B switches of the round in progress (what each means is said where the library reads it); never a result-changing switch. */
 int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
 /* Diagnostic counters of the last stage call by name (unknown name: ELBA_ERR_INVALID_ARG); none of them is part of a result.
  *   "overlap_mirror_placed"  mirrored entries of the last elba_create_seed_matrix call that waited in the staging area for the placement pass
@@ -325,7 +335,11 @@ int  elba_set_option(elba_ctx *ctx, const char *name, int64_t value);
  *   "padded_columns"         1: the resident matrix has its padded column store (what the fast SpGEMM paths gather from); 0: columns longer than 64
  *                            entries, or the store did not fit a third of the free device memory when the matrix was built
  *                            (elba_release_workspace on other contexts of the device, then build again)
- *   "gather_slots"           columns of the padded column store in use (with inline partners: only the columns some row entry still fetches) */
+ *   "gather_slots"           columns of the padded column store in use (with inline partners: only the columns some row entry still fetches)
+ *   "kmer_passes"            value-range passes the last elba_count_kmers took (1: the whole input at once; option "kmer_batch_instances")
+ *   "spgemm_prep_us"         option "measure_prep": device microseconds the emit kernels of the last elba_count_kmers spent on hint bits, inline partners,
+ *                            gather slots and padded columns (the kernels as built minus the same kernels without them; -1: not measured)
+ *   "emit_us"                ... and the emit kernels as built */
 int  elba_get_stat(elba_ctx *ctx, const char *name, int64_t *value);
 
 /* Gives the stage calls' scratch memory back to the device (the sort / partition buffers of elba_count_kmers, elba_create_kmer_matrix and
