@@ -115,6 +115,15 @@ struct OvParams {
     unsigned long long *slab_pos;      // [M] per row: slab end << 32 | next free slab entry (k_classify_direct sets it to end << 32 | start)
 };
 
+// several small buffers zeroed by one launch (the counters of a call)
+struct ZeroList { uint32_t *p[6]; size_t words[6]; int n; };
+__global__ __launch_bounds__(256) void k_zero_regions(ZeroList z)
+{
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (int q = 0; q < z.n; ++q)
+        for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < z.words[q]; i += stride) z.p[q][i] = 0u;
+}
+
 // ---- mirror slabs ---------------------------------------------------------------------------------------------------------------------
 // The transposed image of a staged entry (i, j) belongs to row j.  Rounds 1-3 left it in the staging area with a ticket (its place among row
 // j's mirrored entries, drawn from low_cnt[j]) and k_mirror placed it once the row pointers of B were known: 49 M random 16-byte stores behind
@@ -1028,6 +1037,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
         const bool sampling = p.use_feedback && nrows >= 8192 && !c.opt.no_sample;
         p.slab_prior_q16 = c.opt.slab_q16 > 0 ? (uint32_t)c.opt.slab_q16 : c.ov_slab_q16;
         p.slab_pct = (uint32_t)c.opt.slab_pct;
+        bool zero_slabn = false;
         c.ov_slab_on = phase == 0 && half && mir16 && !c.opt.no_slab && nrows > 0 && (sampling || p.slab_prior_q16 != 0u);
         p.slab = nullptr; p.slab_cap = 0;
         if (c.ov_slab_on) {
@@ -1042,16 +1052,24 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
             p.slab = c.ov_slab.as<uint4>(); p.slab_cap = (unsigned long long)c.ov_slab_cap;
             c.ov_slabpos.reserve((size_t)(M + 4) * 8); c.ov_slabn.reserve((size_t)(M + 8) * 4);
             p.slab_pos = c.ov_slabpos.as<unsigned long long>();
-            ELBA_HIP(hipMemsetAsync(c.ov_slabn.p, 0, (size_t)(M + 8) * 4, s));      // (rows outside the window hold no slab entries)
+            zero_slabn = true;      // (rows outside the window hold no slab entries; zeroed with the call's other counters, below)
         }
 
         if (timed) c.ov_marks.mark(0, s);
         // the ticket counters come back clean from a call that ran to its end (k_finalize_wave); otherwise zero them here
-        if (!c.ov_low_clean) ELBA_HIP(hipMemsetAsync(c.ov_totcnt.p, 0, (size_t)(M + 2) * 4, s));
+        {   // the call's counters, in ONE launch (five memsets were five ~8 us gaps in front of a 6 ms call)
+            ZeroList z{};
+            auto add = [&](void *ptr, size_t bytes) { z.p[z.n] = static_cast<uint32_t *>(ptr); z.words[z.n] = (bytes + 3) / 4; ++z.n; };
+            if (!c.ov_low_clean) add(c.ov_totcnt.p, (size_t)(M + 2) * 4);
+            add(c.ov_counters.p, sizeof(OvCounters));
+            add(c.ov_rowcnt.p, (size_t)(M + 2) * 4);
+            add(c.ov_tickrows.p, (size_t)(M / 32 + 2) * 4);
+            if (zero_slabn) add(c.ov_slabn.p, (size_t)(M + 8) * 4);
+            size_t most = 0;
+            for (int q = 0; q < z.n; ++q) most = std::max(most, z.words[q]);
+            hipLaunchKernelGGL(k_zero_regions, dim3((unsigned)std::min<size_t>((most + 255) / 256, (size_t)cus * 8)), dim3(256), 0, s, z);
+        }
         c.ov_low_clean = false;
-        ELBA_HIP(hipMemsetAsync(c.ov_counters.p, 0, sizeof(OvCounters), s));
-        ELBA_HIP(hipMemsetAsync(c.ov_rowcnt.p, 0, (size_t)(M + 2) * 4, s));
-        ELBA_HIP(hipMemsetAsync(c.ov_tickrows.p, 0, (size_t)(M / 32 + 2) * 4, s));
         // A cold call on a matrix of some size computes a SAMPLE of its rows first (every sstep-th row, on the 4096-slot tier): what they find
         // — distinct partners per row entry — picks the starting tier of all the others, instead of a guess that sends most rows of a
         // 15 %-error read set to a tier too small (an abandoned attempt or a forwarding each: 0.9 ms of a 14.7 ms call on the 200 k-read set).
