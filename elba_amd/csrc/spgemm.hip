@@ -85,6 +85,7 @@ struct OvParams {
     uint32_t inl;                   // Ctx::csr_inline: row entries with bit 63 set carry their (only) partner: 1 << 63 | (partner >> 1) << 32 | posQ | posT << 16
     uint32_t *tick_rows;            // bit i: row i staged at least one entry whose image took a TICKET (k_mirror places those; rows without one are not walked)
     uint32_t min_tier;              // rows start on this tier at least (k_classify_direct)
+    uint32_t qblk_log2;             // the tier queues' sub-queues take blocks of this many (log2) consecutive places (spgemm_direct.hpp: qplace)
     uint32_t pay16;                 // the LDS tiers' 32-bit accumulators carry posT (sequence number << 16 | posT) and the FIFO entries are 8 bytes: positions and every row's
                                     // sequence numbers fit 16 bits (spgemm_direct.hpp) — 18 bytes per table slot and 2 KB of rings per wavefront: three rows per CU on the 2048-slot tier
     uint32_t suffix;                // dense matrices (Ctx::csr_suffix): row entries carry column length and own place, the smaller row owns a pair
@@ -990,6 +991,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     p.tick_rows = c.ov_tickrows.as<uint32_t>();
     // a large matrix's rows start on the 2048-slot tier at least (three rows per CU with pay16): the two smaller tiers would receive a percent of the rows and cost a
     // ~60 us launch each — 6.48 -> 6.3x ms on config 3; small matrices keep them (their rows ARE small); option "tune4" = 1: every tier (A/B)
+    p.qblk_log2 = c.opt.tune[5] > 0 ? (uint32_t)std::min<int64_t>(c.opt.tune[5] - 1, 12) : 0u;      // ("tune5" = log2 + 1.  Measured on config 5 at 1/25 — label-ordered queue, blocks of 32 / 128 / 512 places per XCD: 8.66-8.74 against 8.74-8.77 ms: nothing; single places stay)
     p.min_tier = (pay16 && nrows >= 65536 && Z / nrows >= 1024 && c.opt.tune[4] != 1) ? 2u : 0u;      // (long rows only: a 512-lane workgroup on a row of 75 entries would idle)
     p.row_cnt = c.ov_rowcnt.as<uint32_t>(); p.low_cnt = c.ov_totcnt.as<uint32_t>();
     p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();

@@ -78,7 +78,10 @@ __device__ __forceinline__ bool owns_pair(uint32_t i, uint32_t j, uint32_t row_l
 // (second launch bound = wavefronts per SIMD the register allocation must leave room for: 4 keeps two 512-thread workgroups on a CU — at 132
 //  VGPRs instead of 128 the kernel loses one of them and runs twice as long (measured) —, 8 is what the dense path's 8 workgroups of 4 wavefronts per CU need)
 template <int BLOCK, bool GLOBAL, bool PAY, int DK = 2, bool SUFFIX = false, int TB = 0>
-__global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits, uint32_t sample)
+#ifndef ELBA_DENSE_OCC
+#define ELBA_DENSE_OCC 8
+#endif
+__global__ __launch_bounds__(BLOCK, SUFFIX ? ELBA_DENSE_OCC : (DK == 4 ? 1 : 4)) void k_spgemm_direct(OvParams p, int tier, uint32_t lds_tbits, uint32_t sample)
 {
     static_assert(!PAY || !GLOBAL, "payload accumulators: LDS tiers only");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -107,10 +110,15 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
     uint32_t qshard = blockIdx.x & 7u, qtried = 0;
     // (thread 0 only) draw: one atomic, nothing waits for it; resolve: where the draw is first needed — a draw beyond the end of the
     // sub-queue moves on to the next one (then, and only then, the claim is a synchronous round trip)
+    // place of a sub-queue's k-th draw in the queue: the sub-queues take BLOCKS of 2^qb consecutive places in turn (qb = 0, the default: single places).  (A/B
+    // hook of round 5: the dense path queues its rows in label order and a sub-queue belongs to an XCD — blocks of 128 places put the rows of one locus on ONE
+    // XCD at the same time; it bought nothing, profiles/r05_notes.md)
+    const uint32_t qb = p.qblk_log2;
+    auto qplace = [&](uint32_t k) -> unsigned long long { return ((((unsigned long long)(k >> qb) * 8u + qshard) << qb) | (k & ((1u << qb) - 1u))); };
     auto draw = [&]() -> uint32_t { return atomicAdd(sample ? &p.ctr->sample_next[qshard][0] : &p.ctr->tier_next[tier][qshard][0], 1u); };
     auto resolve = [&](uint32_t k) -> uint32_t {
         for (;;) {
-            const unsigned long long idx = (unsigned long long)k * 8u + qshard;
+            const unsigned long long idx = qplace(k);
             if (idx < nrows) return queue[idx];
             if (++qtried >= 8u) return NOROW;
             qshard = (qshard + 1u) & 7u;
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(BLOCK, SUFFIX ? 8 : (DK == 4 ? 1 : 4)) void k_spgem
         // the draw has returned by the time the first round's column words have (loads and returning atomics come back in order): its queue
         // entry is requested there and arrives with the second round's words — the hand-off below then waits for nothing
         auto resolve_early = [&]() {
-            if (tid == 0 && qtried < 8u) { const unsigned long long idx = (unsigned long long)nidx * 8u + qshard; if (idx < nrows) nrow = queue[idx]; }
+            if (tid == 0 && qtried < 8u) { const unsigned long long idx = qplace(nidx); if (idx < nrows) nrow = queue[idx]; }
         };
         // ... and the next row's bounds with the second round's (they depend on the queue entry)
         auto bounds_early = [&]() { if (tid == 0 && nrow != UNRESOLVED && nrow != NOROW) { nrs = p.a_rowptr[nrow]; nre = p.a_rowptr[nrow + 1]; } };

@@ -215,17 +215,36 @@ struct Table {
 #endif
 #pragma unroll
         for (int r = 0; r < 4; ++r) slot[r] = TB ? (ELBA_HMIX(j[r]) * 0x9E3779B1u) >> (32 - (TB ? TB : 1)) : lds_slot(j[r]);
+        const uint32_t base = (uint32_t)(uintptr_t)keys, one = 1u;
+#ifndef ELBA_DENSE_QUADS      // two look-ups in flight at a time (four: twelve more live registers in a kernel that is held to 64 — 36 bytes of scratch against 16; config 5 at 1/25: 8.89 vs 8.70 ms)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r0 = 0; r0 < 4; r0 += 2) {
+#else
+        {
+        constexpr int r0 = 0;
+#endif
+#pragma unroll
+        for (int r = r0; r < (
+#ifndef ELBA_DENSE_QUADS
+                              r0 + 2
+#else
+                              4
+#endif
+                              ); ++r) {
             k[r] = __hip_atomic_load(&lk[slot[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             m[r] = __hip_atomic_load(&lk[slot[r] + 2u * T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #ifndef ELBA_DENSE_NO_CMAX
             mx[r] = __hip_atomic_load(&lk[slot[r] + 3u * T], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #endif
         }
-        const uint32_t base = (uint32_t)(uintptr_t)keys, one = 1u;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
+        for (int r = r0; r < (
+#ifndef ELBA_DENSE_QUADS
+                              r0 + 2
+#else
+                              4
+#endif
+                              ); ++r) {
             const uint32_t s = s0 + (uint32_t)r;
             const bool v = (uint32_t)r >= vr;
             const bool h = v && k[r] == j[r] && s >= m[r];
@@ -255,6 +274,7 @@ struct Table {
                 }
             }
             miss[r] = v && !h;
+        }
         }
     }
     __device__ __forceinline__ uint32_t lds_slot(uint32_t j) const { return (ELBA_HMIX(j) * 0x9E3779B1u) >> (32 - tbits); }      // (a 24-bit multiply, v_mul_u32_u24, was measured: no difference)
