@@ -300,7 +300,12 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     if (!ENUM) ntiles = sg.tile0[sg.nb1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long lane_le = (2ull << lane) - 1ull;      // (a place t = it * MT_THREADS + tid of the write-out has t & 63 == lane)
+#ifndef ELBA_SCATTER_ONE_TILE      // (the persistent grid costs the ENUM kernel 50 registers — 228 bytes of scratch — and is still 0.4 ms ahead of a workgroup per tile: 25.1 vs 25.5 ms for the partition)
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+#else
+    const uint32_t tile = blockIdx.x;
+    if (tile < ntiles) {
+#endif
     for (int i = threadIdx.x; i < MT_MAXBINS; i += MT_THREADS) lcnt[i] = 0;
     for (int i = threadIdx.x; i < MT_TILE / 64; i += MT_THREADS) hbits[i] = 0;
     __syncthreads();
@@ -393,7 +398,11 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
             if (t < count) { const uint64_t kv = lkey[t]; out[delta[(uint32_t)(kv >> shift) & dmask] + t] = kv; }
         }
         __syncthreads();
+#ifndef ELBA_SCATTER_ONE_TILE
         continue;
+#else
+        return;
+#endif
     }
 #endif
     // The tile now lies ordered by digit in LDS, but an ENUM word does not hold its digit any more.  A place finds its digit's run from a
@@ -1741,7 +1750,11 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
     };
     if (!wide) {
     const int shift2 = m.PB + vb;
-    const uint32_t sgrid = c.opt.tune[0] == 1 ? 0xFFFFFFFFu : (uint32_t)c.num_cus * (MT_TILE <= 8192 ? 2u : 1u);      // (tune0 = 1: a workgroup per tile, as before round 5 — A/B)
+#ifndef ELBA_SCATTER_ONE_TILE
+    const uint32_t sgrid = c.opt.tune[0] == 1 ? 0xFFFFFFFFu : (uint32_t)c.num_cus * (MT_TILE <= 8192 ? 2u : 1u);      // (tune0 = 1: a workgroup per tile — A/B)
+#else
+    const uint32_t sgrid = 0xFFFFFFFFu;      // a workgroup per tile
+#endif
     if (tri) {
         // first digit, from the packed triples: one segment of ntiles1 tiles
         const uint32_t seg[4] = {0u, (uint32_t)I, 0u, ntiles1};
