@@ -659,7 +659,14 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
 // sixteen wavefronts).  History of the widest class on BASELINE config 5 at one GPU's share (average bucket 4400 entries): 256 lanes x 32 entries
 // (256 VGPRs, four wavefronts per CU) 85 ms; 512 x 16 44 ms; with ranges by column rank 20 ms; 1024 x 8 13 ms.
 template <int ES_KPT, int ES_THREADS = 256>
-__global__ __launch_bounds__(ES_THREADS) void k_msd_emit_small(const uint64_t *wrel, const uint32_t *b2start, const uint32_t *bZ, uint32_t nbuckets, MsdParams m, uint32_t cap_lo, uint32_t cap_hi,
+#ifndef ELBA_ES_OCC256
+#define ELBA_ES_OCC256 5      // (92 VGPRs instead of 100: five workgroups per CU instead of four)
+#endif
+#ifndef ELBA_ES_OCC512
+#define ELBA_ES_OCC512 6      // (80 VGPRs + 32 bytes of scratch instead of 99: THREE workgroups per CU — what the 49 KB of LDS allow — instead of two: bucket kernels of config 3 17.6 -> 16.1 ms)
+#endif
+// (second launch bound = wavefronts per SIMD the register allocation leaves room for; 0: whatever the kernel needs)
+__global__ __launch_bounds__(ES_THREADS, (ES_THREADS == 256 ? ELBA_ES_OCC256 : (ES_THREADS == 512 ? ELBA_ES_OCC512 : 0))) void k_msd_emit_small(const uint64_t *wrel, const uint32_t *b2start, const uint32_t *bZ, uint32_t nbuckets, MsdParams m, uint32_t cap_lo, uint32_t cap_hi,
                                                               const uint32_t *kidbase, const uint32_t *entbase, BucketOut o)
 {
     constexpr uint32_t ES_CAP = ES_THREADS * ES_KPT, NW = ES_THREADS / 64, NH = ES_KPT * NW;      // entries; wavefronts; (u, wavefront) head counts

@@ -143,7 +143,7 @@ __global__ void k_reduce_max(const uint64_t *p, int64_t n, unsigned long long *o
 // (A one-sweep variant — one kernel per pass, decoupled look-back over per-tile status words — was measured here and was 1.7x slower per
 // pass: with ~770 tiles in flight the look-back reads dozens of predecessors' status rows, each an agent-scope 8-byte access.)
 #ifndef ELBA_RS_SCATTER_THREADS
-#define ELBA_RS_SCATTER_THREADS 256
+#define ELBA_RS_SCATTER_THREADS 512      // (round 5: 512 lanes x 16 keys held to 128 VGPRs — two workgroups of eight wavefronts per CU; 256 x 32 needs 247 VGPRs: eight wavefronts per CU.  Round 4 measured 512 x 16 without the bound — 130 VGPRs, ONE workgroup per CU — and found it slower)
 #endif
 #ifndef ELBA_RS_PAIR_ITEMS
 #define ELBA_RS_PAIR_ITEMS 32
@@ -248,7 +248,7 @@ size_t column_scan_tmp_elems(int64_t nrows, uint32_t nbins)
 // output (an earlier tile holds smaller low bits only) and writes the row pointer; the first key of a run cannot know — the run may continue a
 // read of the tile before — and takes the minimum with what is there (rowptr starts as all ones; empty rows are closed by k_rowptr_close_*).
 template <bool HAS_VAL, int THREADS, int ITEMS, class K = uint64_t, bool FIN = false>
-__global__ __launch_bounds__(THREADS) void k_rs_scatter(const K *keys_in, const uint64_t *vals_in, K *keys_out, uint64_t *vals_out,
+__global__ __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 0)) void k_rs_scatter(const K *keys_in, const uint64_t *vals_in, K *keys_out, uint64_t *vals_out,
                                                         int64_t n, int shift, int bits, const uint32_t *hist_scanned, CsrFin fin = CsrFin{})
 {
     constexpr int TILE = THREADS * ITEMS, WAVES = THREADS / 64, DPT = RS_MAXBINS / THREADS > 0 ? RS_MAXBINS / THREADS : 1;      // digits per thread in the per-digit step (more threads than digits: the others idle there)
