@@ -300,6 +300,54 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     if (!ENUM) ntiles = sg.tile0[sg.nb1];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const unsigned long long lane_le = (2ull << lane) - 1ull;      // (a place t = it * MT_THREADS + tid of the write-out has t & 63 == lane)
+    // The keys of a tile live in registers from where they are fetched — enumerated from the reads, or loaded from the first pass's output — to where they
+    // are placed in LDS.  Round 5 (ELBA_SCATTER_NO_PIPE: off): the NEXT tile is fetched in the shadow of this tile's write-out — the key registers are dead by
+    // then — so that the loads' latency (MEM) hides behind the write-out, and, ENUM, half the wavefronts enumerate (vector ALU) while the other half
+    // write out (LDS reads + global stores) instead of all sixteen doing the one and then the other: partition of config 3 26.4 -> 24.1 ms.
+    uint64_t key[MT_ITEMS];
+    uint32_t dig2[MT_ITEMS / 2];    // the items' digits, two per register (0xFFFF: no key)
+    uint32_t count = 0, ncount = 0; (void)ncount;
+    auto digit = [&](int it) -> uint32_t { return (dig2[it >> 1] >> ((it & 1) * 16)) & 0xFFFFu; };
+    auto set_digit = [&](int it, uint32_t d) { if (it & 1) dig2[it >> 1] |= d << 16; else dig2[it >> 1] = d; };
+    auto fetch = [&](uint32_t t, uint32_t &cnt) {
+        if (ENUM) {
+            const uint64_t tbase = (uint64_t)t * MT_TILE, base = tbase + (uint64_t)w * (MT_ITEMS * 64);
+            const uint64_t left = e.I - tbase;
+            cnt = left < (uint64_t)MT_TILE ? (uint32_t)left : (uint32_t)MT_TILE;
+            const uint64_t vmask = (1ull << (m.k2 - m.b1)) - 1;
+#pragma unroll
+            for (int it = 0; it < MT_ITEMS; ++it) key[it] = 0;
+#pragma unroll
+            for (int q = 0; q < MT_ITEMS / 2; ++q) dig2[q] = 0xFFFFFFFFu;
+            enum_consecutive(e, block_read, base, [&](int it, uint64_t km, uint32_t r, uint32_t p) {
+                const uint32_t dg = (uint32_t)(km >> (64 - m.b1));
+                if (FILTER && (dg < dlo || dg >= dhi)) return;      // (another pass's instance: no key)
+                key[it] = (((km >> (64 - m.k2)) & vmask) << m.PB) | ((uint64_t)r << m.pbits) | p;
+                dig2[it >> 1] = (it & 1) ? (dig2[it >> 1] & 0xFFFFu) | (dg << 16) : (dig2[it >> 1] & 0xFFFF0000u) | dg;
+            });
+        } else {
+            uint32_t bucket, start;
+            seg_tile(sg, t, bucket, start, cnt);
+            const uint32_t wb = (uint32_t)w * (MT_ITEMS * 64);
+#pragma unroll
+            for (int it = 0; it < MT_ITEMS; ++it) {
+                const uint32_t q = wb + (uint32_t)it * 64 + lane;
+                key[it] = q < cnt ? in[start + q] : 0;
+            }
+        }
+    };
+    auto digits_of_loaded = [&](uint32_t cnt) {      // (MEM: the digits follow from the words once they have arrived)
+        if (ENUM) return;
+        const uint32_t wb = (uint32_t)w * (MT_ITEMS * 64);
+#pragma unroll
+        for (int it = 0; it < MT_ITEMS; ++it) {
+            const uint32_t q = wb + (uint32_t)it * 64 + lane;
+            set_digit(it, q < cnt ? (uint32_t)(key[it] >> shift) & dmask : 0xFFFFu);
+        }
+    };
+#ifndef ELBA_SCATTER_NO_PIPE
+    if (blockIdx.x < ntiles) fetch(blockIdx.x, count);
+#endif
 #ifndef ELBA_SCATTER_ONE_TILE      // (the persistent grid costs the ENUM kernel 50 registers — 228 bytes of scratch — and is still 0.4 ms ahead of a workgroup per tile: 25.1 vs 25.5 ms for the partition)
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
 #else
@@ -309,41 +357,10 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     for (int i = threadIdx.x; i < MT_MAXBINS; i += MT_THREADS) lcnt[i] = 0;
     for (int i = threadIdx.x; i < MT_TILE / 64; i += MT_THREADS) hbits[i] = 0;
     __syncthreads();
-    uint64_t key[MT_ITEMS];
-    uint32_t dig2[MT_ITEMS / 2];    // the items' digits, two per register (0xFFFF: no key)
-    uint32_t count = 0;
-    auto digit = [&](int it) -> uint32_t { return (dig2[it >> 1] >> ((it & 1) * 16)) & 0xFFFFu; };
-    auto set_digit = [&](int it, uint32_t d) { if (it & 1) dig2[it >> 1] |= d << 16; else dig2[it >> 1] = d; };
-    if (ENUM) {
-        const uint64_t tbase = (uint64_t)tile * MT_TILE, base = tbase + (uint64_t)w * (MT_ITEMS * 64);
-        const uint64_t left = e.I - tbase;
-        count = left < (uint64_t)MT_TILE ? (uint32_t)left : (uint32_t)MT_TILE;
-        const uint64_t vmask = (1ull << (m.k2 - m.b1)) - 1;
-#pragma unroll
-        for (int it = 0; it < MT_ITEMS; ++it) key[it] = 0;
-#pragma unroll
-        for (int q = 0; q < MT_ITEMS / 2; ++q) dig2[q] = 0xFFFFFFFFu;
-        enum_consecutive(e, block_read, base, [&](int it, uint64_t km, uint32_t r, uint32_t p) {
-            const uint32_t dg = (uint32_t)(km >> (64 - m.b1));
-            if (FILTER && (dg < dlo || dg >= dhi)) return;      // (another pass's instance: no key)
-            key[it] = (((km >> (64 - m.k2)) & vmask) << m.PB) | ((uint64_t)r << m.pbits) | p;
-            dig2[it >> 1] = (it & 1) ? (dig2[it >> 1] & 0xFFFFu) | (dg << 16) : (dig2[it >> 1] & 0xFFFF0000u) | dg;
-        });
-    } else {
-        uint32_t bucket, start;
-        seg_tile(sg, tile, bucket, start, count);
-        const uint32_t wb = (uint32_t)w * (MT_ITEMS * 64);
-#pragma unroll
-        for (int it = 0; it < MT_ITEMS; ++it) {
-            const uint32_t q = wb + (uint32_t)it * 64 + lane;
-            key[it] = q < count ? in[start + q] : 0;
-        }
-#pragma unroll
-        for (int it = 0; it < MT_ITEMS; ++it) {
-            const uint32_t q = wb + (uint32_t)it * 64 + lane;
-            set_digit(it, q < count ? (uint32_t)(key[it] >> shift) & dmask : 0xFFFFu);
-        }
-    }
+#ifdef ELBA_SCATTER_NO_PIPE
+    fetch(tile, count);
+#endif
+    digits_of_loaded(count);
     // (the tile's row of output places: one coalesced load, in flight while the ranks are computed)
     uint32_t gb[DPT];
 #pragma unroll
@@ -437,6 +454,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         }
     }
     __syncthreads();
+    auto writeout = [&]() {
 #ifdef ELBA_SCATTER_UNROLL
 #pragma unroll
     for (int it = 0; it < MT_ITEMS; ++it) {      // (compile-time trip count: the LDS reads of a lane's places are in flight together)
@@ -463,7 +481,21 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     }
 #endif
 #endif
+    };
+#if !defined(ELBA_SCATTER_NO_PIPE) && !defined(ELBA_SCATTER_ONE_TILE)
+    {
+        const uint32_t nxt = tile + gridDim.x;
+        const bool has = nxt < ntiles;
+        if (ENUM && (w & 1)) { writeout(); if (has) fetch(nxt, ncount); }
+        else { if (has) fetch(nxt, ncount); writeout(); }
+    }
+#else
+    writeout();
+#endif
     lds_sync_fwd();      // (the tile's LDS is reused by the workgroup's next tile; its global stores stay in flight)
+#ifndef ELBA_SCATTER_NO_PIPE
+    count = ncount;
+#endif
     }
 }
 
