@@ -345,8 +345,12 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
             set_digit(it, q < cnt ? (uint32_t)(key[it] >> shift) & dmask : 0xFFFFu);
         }
     };
+#ifndef ELBA_SCATTER_ENUM_MODE
+#define ELBA_SCATTER_ENUM_MODE 2      // ENUM: 0 = the tile is enumerated at the top of its own turn, 1 = every wavefront enumerates the next tile before it writes this one out, 2 = half of them before, half after
+#endif
+    constexpr bool PIPE = !ENUM || ELBA_SCATTER_ENUM_MODE != 0;
 #ifndef ELBA_SCATTER_NO_PIPE
-    if (blockIdx.x < ntiles) fetch(blockIdx.x, count);
+    if (PIPE && blockIdx.x < ntiles) fetch(blockIdx.x, count);
 #endif
 #ifndef ELBA_SCATTER_ONE_TILE      // (the persistent grid costs the ENUM kernel 50 registers — 228 bytes of scratch — and is still 0.4 ms ahead of a workgroup per tile: 25.1 vs 25.5 ms for the partition)
     for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -359,6 +363,8 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     __syncthreads();
 #ifdef ELBA_SCATTER_NO_PIPE
     fetch(tile, count);
+#else
+    if (!PIPE) fetch(tile, count);
 #endif
     digits_of_loaded(count);
     // (the tile's row of output places: one coalesced load, in flight while the ranks are computed)
@@ -486,7 +492,8 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     {
         const uint32_t nxt = tile + gridDim.x;
         const bool has = nxt < ntiles;
-        if (ENUM && (w & 1)) { writeout(); if (has) fetch(nxt, ncount); }
+        if (!PIPE) writeout();
+        else if (ENUM && ELBA_SCATTER_ENUM_MODE == 2 && (w & 1)) { writeout(); if (has) fetch(nxt, ncount); }
         else { if (has) fetch(nxt, ncount); writeout(); }
     }
 #else
@@ -494,7 +501,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
 #endif
     lds_sync_fwd();      // (the tile's LDS is reused by the workgroup's next tile; its global stores stay in flight)
 #ifndef ELBA_SCATTER_NO_PIPE
-    count = ncount;
+    if (PIPE) count = ncount;
 #endif
     }
 }
