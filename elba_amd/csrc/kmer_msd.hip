@@ -559,13 +559,20 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
     const uint64_t lowmask = m.rk ? (1ull << m.rk) - 1 : ~0ull;
     // the instances of the NEXT bucket are requested before this one is processed (one workgroup per CU: nobody else hides the round trip)
     uint32_t b = blockIdx.x, s0 = 0, n = 0;
+    // (a lane holds PAIRS of neighbouring instances: 16-byte requests)
+    struct __attribute__((aligned(8))) Two { uint64_t a, c; };
+    auto ld2 = [&](const uint64_t *src, uint32_t cnt, uint32_t u, uint64_t &a, uint64_t &c) {
+        const uint32_t i = ((u >> 1) * BK_THREADS + tid) * 2u;
+        if (i + 1u < cnt) { const Two t = *reinterpret_cast<const Two *>(src + i); a = t.a; c = t.c; }
+        else if (i < cnt) a = src[i];
+    };
     uint64_t kreg[CT_KPT];
 #pragma unroll
     for (int u = 0; u < CT_KPT; ++u) kreg[u] = 0;
     if (b < nbuckets) {
         s0 = b2start[b]; n = b2start[b + 1] - s0;
 #pragma unroll
-        for (int u = 0; u < CT_KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; if (i < n) kreg[u] = words[s0 + i]; }
+        for (int u = 0; u < CT_KPT; u += 2) ld2(words + s0, n, (uint32_t)u, kreg[u], kreg[u + 1]);
     }
     for (; b < nbuckets;) {
         const uint32_t bnext = b + gridDim.x;
@@ -576,7 +583,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
         if (bnext < nbuckets) {
             s0n = b2start[bnext]; nn = b2start[bnext + 1] - s0n;
 #pragma unroll
-            for (int u = 0; u < CT_KPT; ++u) { const uint32_t i = (uint32_t)u * BK_THREADS + tid; if (i < nn) knext[u] = words[s0n + i]; }
+            for (int u = 0; u < CT_KPT; u += 2) ld2(words + s0n, nn, (uint32_t)u, knext[u], knext[u + 1]);
         }
         if (n == 0) { if (tid == 0) { bN[b] = 0; bZ[b] = 0; } }
         else {
@@ -590,7 +597,7 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
         const bool guard = n > 65535u;          // a value's count could run over its 16 bits: stop counting beyond 2^15 (UPPER <= 255: unreliable anyway)
         auto for_keys = [&](auto &&f) {
 #pragma unroll
-            for (int u = 0; u < CT_KPT; ++u) if ((uint32_t)u * BK_THREADS + tid < n) f(kreg[u]);
+            for (int u = 0; u < CT_KPT; ++u) if (((uint32_t)(u >> 1) * BK_THREADS + tid) * 2u + (uint32_t)(u & 1) < n) f(kreg[u]);
             for (uint32_t i = (uint32_t)CT_KPT * BK_THREADS + tid; i < n; i += BK_THREADS) f(words[s0 + i]);
         };
         for_keys([&](uint64_t wd) {
