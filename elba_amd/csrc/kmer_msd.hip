@@ -1355,7 +1355,7 @@ constexpr uint32_t W2_DISTINCT_MAX = W2_SLOTS - 2 * W2C_THREADS;  // distinct k-
 static_assert(W2C_KPT * W2C_THREADS >= (int)W2_CAP, "every record has a register");
 // (a bucket's size fluctuates with coverage x sqrt(distinct genomic k-mers in it): 1900 +- 280 instances on 40x reads of a 50 Mb genome cut into 2^20
 //  buckets — 3300 at five sigma, which 2^20 buckets do reach)
-__global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const uint32_t *b2start, uint32_t nbuckets, int k2, int T, int PB, int rk, uint32_t lower, uint32_t upper,
+__global__ __launch_bounds__(W2C_THREADS, 4) void k31_count(const Rec2 *recs, const uint32_t *b2start, uint32_t nbuckets, int k2, int T, int PB, int rk, uint32_t lower, uint32_t upper,
                                                         uint32_t *bN, uint32_t *bZ, BucketStats *gstat, uint64_t *wrel, uint64_t *ktmp, uint32_t *crowded)
 {
     constexpr uint32_t NW = W2C_THREADS / 64, NSB = 512, IPT = (W2_RELMAX + W2C_THREADS - 1) / W2C_THREADS, SPT = W2_SLOTS / W2C_THREADS;
@@ -1393,6 +1393,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
 #pragma unroll 1
         for (uint32_t ch = 0; ch < nch; ++ch) {
         if (ch) load_chunk(ch);
+#ifdef ELBA_K31_SERIAL_CAS
 #pragma unroll
         for (int u = 0; u < W2C_KPT; ++u) {
             slot[u] = 0;
@@ -1412,6 +1413,42 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
                 slot[u] = sl;
             }
         }
+#else
+        {   // (a lane's eight first attempts are in flight together — nine records in ten find their k-mer, or an empty slot, where their hash points —, then the rest probes on: the
+            //  loop below used to be eight dependent LDS round trips per lane)
+            const bool live = __hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u;      // (the table is filling up: the bucket is given up)
+            unsigned long long old[W2C_KPT];
+#pragma unroll
+            for (int u = 0; u < W2C_KPT; ++u) {
+                slot[u] = 0; old[u] = 0;
+                if (key[u].hi != ~0ull) {
+                    const unsigned long long hk = key[u].hi;
+                    slot[u] = (((uint32_t)hk ^ (uint32_t)(hk >> 27)) * 0x9E3779B1u) >> 20;      // 12 bits
+                    if (live) old[u] = atomicCAS(&K[slot[u]], ~0ull, hk);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < W2C_KPT; ++u) {
+                if (live && key[u].hi != ~0ull) {
+                    const unsigned long long hk = key[u].hi;
+                    uint32_t sl = slot[u];
+                    if (old[u] == ~0ull) { if (atomicAdd(&misc[1], 1u) >= W2_DISTINCT_MAX) __hip_atomic_store(&misc[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                    else if (old[u] != hk) {
+                        for (uint32_t probes = 1; probes < W2_SLOTS; ++probes) {      // (bounded whatever happens: a full table cannot hang the wavefront)
+                            if (__hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) break;      // (given up meanwhile: a table that fills up is not probed to its end)
+                            sl = (sl + 1u) & (W2_SLOTS - 1u);
+                            const unsigned long long o = atomicCAS(&K[sl], ~0ull, hk);
+                            if (o == hk) break;
+                            if (o == ~0ull) { if (atomicAdd(&misc[1], 1u) >= W2_DISTINCT_MAX) __hip_atomic_store(&misc[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; }
+                            if (probes + 1u == W2_SLOTS) __hip_atomic_store(&misc[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        slot[u] = sl;
+                    }
+                    atomicAdd(&CNT[sl], 1u);
+                }
+            }
+        }
+#endif
         }
         lds_sync();
         if (__hip_atomic_load(&misc[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) {      // more distinct k-mers than the table takes: a crowded bucket like one beyond W2_CAP records
@@ -1436,6 +1473,7 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
             // ... numbered in value order.  The usual bucket holds a few dozen of them (a HiFi read set: ~1900 records of ~56 genomic k-mers): every lane
             // sums, over the bucket's reliable k-mers, those below its own and their counts — broadcast reads; no ranges, no scans, five barriers less (bucket kernels of the k = 31 workload: 47.6 -> 42.7 ms).
             // (The columns' fill counters are then sbcnt[column], zero since the bucket began.)
+#ifdef ELBA_K31_FEW_ONE_LANE
             if (tid < Nb) {
                 const uint32_t sl = RL[tid];
                 const unsigned long long mine = K[sl];
@@ -1451,6 +1489,35 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
                 ktmp[s0 + rc] = mine << (64 - k2);
                 if (tid == 0) misc[3] = tot;
             }
+#else
+            {   // (G lanes per reliable k-mer share the walk — as many as the workgroup has for Nb of them, 8 for the usual 56 — and add their parts up with shuffles:
+                //  one wavefront used to walk all Nb alone while the other seven waited)
+                uint32_t lg = 0;
+                while (lg < 6u && ((Nb << (lg + 1u)) <= (uint32_t)W2C_THREADS)) ++lg;
+                const uint32_t G = 1u << lg, i = tid >> lg, g = tid & (G - 1u);
+                uint32_t sl = 0, rc = 0, first = 0, tot = 0;
+                unsigned long long mine = 0;
+                if (i < Nb) {
+                    sl = RL[i]; mine = K[sl];
+                    for (uint32_t x = g; x < Nb; x += G) {
+                        const uint32_t sx = RL[x], cx = CNT[sx];
+                        const bool below = K[sx] < mine;
+                        rc += below ? 1u : 0u; first += below ? cx : 0u; tot += cx;
+                    }
+                }
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const uint32_t a = __shfl_xor(rc, d, 64), c2 = __shfl_xor(first, d, 64), e2 = __shfl_xor(tot, d, 64);
+                    if ((uint32_t)d < G) { rc += a; first += c2; tot += e2; }
+                }
+                if (i < Nb && g == 0u) {
+                    RC[sl] = (uint16_t)rc;
+                    C[rc] = first;
+                    ktmp[s0 + rc] = mine << (64 - k2);
+                    if (i == 0u) misc[3] = tot;
+                }
+            }
+#endif
             lds_sync();
             Zb = Nb ? misc[3] : 0u;
         } else {
@@ -1535,13 +1602,14 @@ __global__ __launch_bounds__(W2C_THREADS) void k31_count(const Rec2 *recs, const
                     }
                 }
             }
+            uint32_t rcv[W2C_KPT], at[W2C_KPT];      // (in three steps, so that a lane's look-ups of one kind are in flight together)
 #pragma unroll
-            for (int u = 0; u < W2C_KPT; ++u) {
-                if (key[u].hi != ~0ull) {
-                    const uint32_t rc = RC[slot[u]];
-                    if (rc != 0xFFFFu) wrel[s0 + C[rc] + atomicAdd(few ? &sbcnt[rc] : &CNT[slot[u]], 1u)] = (rk ? (uint64_t)rc << rk : (uint64_t)(rc * vscale) << PB) | key[u].lo;
-                }
-            }
+            for (int u = 0; u < W2C_KPT; ++u) rcv[u] = key[u].hi != ~0ull ? (uint32_t)RC[slot[u]] : 0xFFFFu;
+#pragma unroll
+            for (int u = 0; u < W2C_KPT; ++u) { at[u] = 0; if (rcv[u] != 0xFFFFu) at[u] = C[rcv[u]] + atomicAdd(few ? &sbcnt[rcv[u]] : &CNT[slot[u]], 1u); }
+#pragma unroll
+            for (int u = 0; u < W2C_KPT; ++u)
+                if (rcv[u] != 0xFFFFu) wrel[s0 + at[u]] = (rk ? (uint64_t)rcv[u] << rk : (uint64_t)(rcv[u] * vscale) << PB) | key[u].lo;
         }
         if (tid == 0) { bN[b] = Nb; bZ[b] = Zb; if (Zb > 8192u) atomicAdd(&gstat->nbig, 1u); else if (Zb > 4096u) atomicAdd(&gstat->nmid, 1u); }
         lds_sync();
