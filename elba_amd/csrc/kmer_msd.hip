@@ -1364,7 +1364,8 @@ __global__ __launch_bounds__(W2C_THREADS, 4) void k31_count(const Rec2 *recs, co
     uint32_t *CNT = smem31 + 2 * W2_SLOTS;                                        // their counts; for reliable k-mers afterwards: the entries placed so far
     uint32_t *C = CNT + W2_SLOTS;                                                 // [W2_RELMAX + 1] count of the reliable k-mer number rc -> (scan) its first entry
     uint32_t *sbcnt = C + W2_RELMAX + 1, *sbstart = sbcnt + NSB, *wsum = sbstart + NSB + 1, *misc = wsum + 2 * NW;
-    uint16_t *RC = reinterpret_cast<uint16_t *>(misc + 8);                        // [W2_SLOTS] number of the slot's k-mer among the bucket's reliable ones (0xFFFF: not reliable)
+    constexpr uint32_t RC_OFF = (2 * W2_SLOTS + W2_SLOTS + (W2_RELMAX + 1) + NSB + (NSB + 1) + 2 * NW + 8 + 3u) & ~3u;      // (16-byte aligned: the table is initialised with 16-byte stores; W2C_LDS has the slack)
+    uint16_t *RC = reinterpret_cast<uint16_t *>(smem31 + RC_OFF);                        // [W2_SLOTS] number of the slot's k-mer among the bucket's reliable ones (0xFFFF: not reliable)
     uint16_t *RL = RC + W2_SLOTS, *SA = RL + W2_RELMAX;                           // [W2_RELMAX] the reliable slots, as found / ordered by value range
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int R = 32 - T;                                  // bits of the flattened leading 32 value bits (w2_flat) the partition has not used
@@ -1383,8 +1384,15 @@ __global__ __launch_bounds__(W2C_THREADS, 4) void k31_count(const Rec2 *recs, co
             for (int u = 0; u < W2C_KPT; ++u) { const uint32_t i = ch * W2_CAP + (uint32_t)u * W2C_THREADS + tid; key[u] = i < n ? recs[s0 + i] : Rec2{~0ull, ~0ull}; }
         };
         load_chunk(0);
+        {   // empty table: keys all ones, counts zero, no slot reliable — 16-byte stores (7 per lane instead of 24)
+            static_assert(W2_SLOTS == 8 * W2C_THREADS, "the stores below cover the table exactly");
+            uint4 *k4 = reinterpret_cast<uint4 *>(K), *c4 = reinterpret_cast<uint4 *>(CNT), *r4 = reinterpret_cast<uint4 *>(RC);
 #pragma unroll
-        for (int q = 0; q < (int)SPT; ++q) { const uint32_t sl = (uint32_t)q * W2C_THREADS + tid; K[sl] = ~0ull; CNT[sl] = 0; RC[sl] = 0xFFFFu; }
+            for (int q = 0; q < 4; ++q) k4[(uint32_t)q * W2C_THREADS + tid] = make_uint4(~0u, ~0u, ~0u, ~0u);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) c4[(uint32_t)q * W2C_THREADS + tid] = make_uint4(0u, 0u, 0u, 0u);
+            r4[tid] = make_uint4(~0u, ~0u, ~0u, ~0u);
+        }
         sbcnt[tid] = 0;
         if (tid < 8) misc[tid] = 0;
         lds_sync();
@@ -1458,11 +1466,17 @@ __global__ __launch_bounds__(W2C_THREADS, 4) void k31_count(const Rec2 *recs, co
         }
         // the reliable k-mers (LOWER <= count <= UPPER), as found
 #pragma unroll
-        for (int q = 0; q < (int)SPT; ++q) {
-            const uint32_t sl = (uint32_t)q * W2C_THREADS + tid, cnt = CNT[sl];
-            if (cnt) {
-                ++st_distinct;
-                if (cnt >= lower && cnt <= upper) { RL[atomicAdd(&misc[0], 1u)] = (uint16_t)sl; st_sumsq += (unsigned long long)cnt * cnt; st_maxcol = cnt > st_maxcol ? cnt : st_maxcol; }
+        for (int q = 0; q < (int)SPT / 4; ++q) {
+            const uint32_t s4 = (uint32_t)q * W2C_THREADS + tid;
+            const uint4 c4 = reinterpret_cast<const uint4 *>(CNT)[s4];
+            const uint32_t cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t cnt = cc[j];
+                if (cnt) {
+                    ++st_distinct;
+                    if (cnt >= lower && cnt <= upper) { RL[atomicAdd(&misc[0], 1u)] = (uint16_t)(4u * s4 + (uint32_t)j); st_sumsq += (unsigned long long)cnt * cnt; st_maxcol = cnt > st_maxcol ? cnt : st_maxcol; }
+                }
             }
         }
         lds_sync();
