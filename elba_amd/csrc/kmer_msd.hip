@@ -1977,7 +1977,7 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         c.t_b.start(s);
         ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
         // (the first pass's records are dead: the front half of their buffer takes the kept entries, one word each, the back half the buckets' reliable k-mers)
-        hipLaunchKernelGGL(k31_count, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus)), dim3(W2C_THREADS), W2C_LDS, s, (const Rec2 *)rb, (const uint32_t *)b2start, nbuckets, k2, T, m.PB, m.rk,
+        hipLaunchKernelGGL(k31_count, dim3((unsigned)std::min<uint32_t>(nbuckets, (uint32_t)c.num_cus * (c.opt.tune[6] == 1 ? 1u : 2u))), dim3(W2C_THREADS), W2C_LDS, s, (const Rec2 *)rb, (const uint32_t *)b2start, nbuckets, k2, T, m.PB, m.rk,
                            (uint32_t)c.cfg.lower, (uint32_t)c.cfg.upper, bN, bZ, gstat, wa, wa + (I + 2), crowded);
         o.kmer_src = wa + (I + 2);
         // buckets k31_count gave up (the section above k31_gather_crowded): taken out, sorted by k-mer, cut into pseudo-buckets of 2^16 distinct k-mers and

@@ -835,7 +835,7 @@ def test_wide_partition_keeps_a_satellite_bucket_and_a_homopolymer_on_the_partit
     on top of ordinary reads.  The input stays on the wide partition path (kmer_path == 2), equals the oracle entry for entry — also with UPPER = 40, where
     the matrix is dense and the satellite's columns are kept — and the stage takes at most 1.3 x what it takes without the two."""
     rng = np.random.default_rng(77)
-    bp, bo, bl, _ = elba_amd.synth_reads(17, 5_000_000, 12, 2500, 600, error_rate=0.04, min_len=100)      # 60 M instances: the stage takes a few ms
+    bp, bo, bl, _ = elba_amd.synth_reads(17, 5_000_000, 24, 2500, 600, error_rate=0.04, min_len=100)      # 120 M instances: the stage takes ~7 ms (the crowded bucket's own kernels ~1.2 ms, whatever the input's size)
     bases = np.frombuffer(b"ACGT", dtype=np.uint8)
     tails = bases[rng.integers(0, 4, size=(100000, 21))]
     sat = [b"A" * 10 + t.tobytes() for t in tails]                  # canonical = forward (it starts with ten A): all of them in the lowest bucket
