@@ -212,16 +212,27 @@ __global__ __launch_bounds__(MT_MAXBINS) void k_msd_tiles(const uint32_t *hist1_
     if (d == nb1 - 1) { b1start[nb1] = (uint32_t)I; tile0[nb1] = run + nt; }
 }
 
-struct SegTiles { const uint32_t *b1start, *tile0; uint32_t nb1; };
+struct SegTiles { const uint32_t *b1start, *tile0; uint32_t nb1; const uint2 *tinfo; };      // tinfo (or null): every tile's (first key, keys), written once by k_msd_tile_info
 // tile t of the second pass: its bucket (last b with tile0[b] <= t: empty buckets share their successor's first tile), first key, keys
 __device__ __forceinline__ void seg_tile(const SegTiles &sg, uint32_t t, uint32_t &bucket, uint32_t &start, uint32_t &count)
 {
+    if (sg.tinfo) { const uint2 ti = sg.tinfo[t]; bucket = 0; start = ti.x; count = ti.y; return; }      // (ONE load: the search below is nine dependent ones, in front of every tile of a persistent workgroup)
     uint32_t lo = 0, hi = sg.nb1;
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (sg.tile0[mid] <= t) lo = mid; else hi = mid; }
     bucket = lo;
     start = sg.b1start[lo] + (t - sg.tile0[lo]) * (uint32_t)MT_TILE;
     const uint32_t end = sg.b1start[lo + 1];
     count = end - start < (uint32_t)MT_TILE ? end - start : (uint32_t)MT_TILE;
+}
+
+__global__ __launch_bounds__(256) void k_msd_tile_info(SegTiles sg, uint2 *tinfo)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= sg.tile0[sg.nb1]) return;
+    SegTiles plain = sg; plain.tinfo = nullptr;
+    uint32_t bucket, start, count;
+    seg_tile(plain, t, bucket, start, count);
+    tinfo[t] = make_uint2(start, count);
 }
 
 __global__ __launch_bounds__(MT_THREADS) void k_msd_hist2(const uint64_t *words, SegTiles sg, int shift, int bits, uint32_t *hist)
@@ -279,6 +290,12 @@ __global__ __launch_bounds__(MT_MAXBINS) void k_msd_segscan(uint32_t *hist, SegT
     if (b == gridDim.x - 1 && d == 0) b2start[(size_t)gridDim.x * nb2] = (uint32_t)I;
 }
 
+#ifdef ELBA_SCATTER_CLOCK      // diagnostic build only: shader-clock cycles of wavefront 0 (and 1) per phase of k_msd_scatter, summed over workgroups and tiles
+__device__ unsigned long long g_sc_phase[2][2][12];
+#define ELBA_SSTAMP(k) do { if (lane == 0 && w < 2) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); sph[k] += tn - stp; stp = tn; } } while (0)
+#else
+#define ELBA_SSTAMP(k) do { } while (0)
+#endif
 __device__ __forceinline__ void lds_sync_fwd() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }      // LDS-only workgroup barrier (lds_sync below)
 // ---- stable scatter of one tile by one digit --------------------------------------------------------------------------------------
 // ENUM: the tile's keys are enumerated from the reads (tile = 8192 consecutive instances) and the digit is the top b1 value bits, which the word
@@ -304,6 +321,9 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
     // are placed in LDS.  Round 5 (ELBA_SCATTER_NO_PIPE: off): the NEXT tile is fetched in the shadow of this tile's write-out — the key registers are dead by
     // then — so that the loads' latency (MEM) hides behind the write-out, and, ENUM, half the wavefronts enumerate (vector ALU) while the other half
     // write out (LDS reads + global stores) instead of all sixteen doing the one and then the other: partition of config 3 26.4 -> 24.1 ms.
+#ifdef ELBA_SCATTER_CLOCK
+    unsigned long long sph[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, stp = __builtin_amdgcn_s_memtime();
+#endif
     uint64_t key[MT_ITEMS];
     uint32_t dig2[MT_ITEMS / 2];    // the items' digits, two per register (0xFFFF: no key)
     uint32_t count = 0, ncount = 0; (void)ncount;
@@ -349,18 +369,29 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
 #define ELBA_SCATTER_ENUM_MODE 2      // ENUM: 0 = the tile is enumerated at the top of its own turn, 1 = every wavefront enumerates the next tile before it writes this one out, 2 = half of them before, half after
 #endif
     constexpr bool PIPE = !ENUM || ELBA_SCATTER_ENUM_MODE != 0;
+    // Which tiles a workgroup takes.  A digit's runs of CONSECUTIVE tiles lie one behind the other in the output, 256 bytes each at any 8-byte alignment: the
+    // 64-byte lines at their seams are written half by one tile and half by the next.  Workgroups go to the XCDs round-robin (blockIdx mod 8), each XCD
+    // has its own L2: dealt round-robin, neighbouring tiles never share an L2 and every seam line leaves two L2s as a partial line.  Each XCD therefore takes a
+    // BLOCK of consecutive tiles per round (its 32 workgroups walk 32 neighbouring tiles at the same time): the seams inside the block merge in its L2.
+#ifndef ELBA_SCATTER_RR
+    const uint32_t first_tile = (gridDim.x & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#else
+    const uint32_t first_tile = blockIdx.x;
+#endif
 #ifndef ELBA_SCATTER_NO_PIPE
-    if (PIPE && blockIdx.x < ntiles) fetch(blockIdx.x, count);
+    if (PIPE && first_tile < ntiles) fetch(first_tile, count);
 #endif
 #ifndef ELBA_SCATTER_ONE_TILE      // (the persistent grid costs the ENUM kernel 50 registers — 228 bytes of scratch — and is still 0.4 ms ahead of a workgroup per tile: 25.1 vs 25.5 ms for the partition)
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (uint32_t tile = first_tile; tile < ntiles; tile += gridDim.x) {
 #else
     const uint32_t tile = blockIdx.x;
     if (tile < ntiles) {
 #endif
+    ELBA_SSTAMP(0);
     for (int i = threadIdx.x; i < MT_MAXBINS; i += MT_THREADS) lcnt[i] = 0;
     for (int i = threadIdx.x; i < MT_TILE / 64; i += MT_THREADS) hbits[i] = 0;
     __syncthreads();
+    ELBA_SSTAMP(1);
 #ifdef ELBA_SCATTER_NO_PIPE
     fetch(tile, count);
 #else
@@ -381,7 +412,9 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         rank[it] = 0;
         if (d != 0xFFFFu) rank[it] = (uint16_t)atomicAdd(&lcnt[d], 1u);
     }
+    ELBA_SSTAMP(2);
     __syncthreads();
+    ELBA_SSTAMP(3);
     {
         // exclusive scan of the digit counts: the digits' places in the tile
         uint32_t tot[DPT], both = 0;
@@ -401,12 +434,14 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         for (int u = 0; u < DPT; ++u) { const uint32_t d = threadIdx.x + u * MT_THREADS; if (d < nbins) gbase[d] = gb[u]; }
     }
     __syncthreads();
+    ELBA_SSTAMP(4);
     if (ENUM && FILTER) count = kept_s;
 #pragma unroll
     for (int it = 0; it < MT_ITEMS; ++it) {
         const uint32_t d = digit(it);
         if (d != 0xFFFFu) lkey[lstart[d] + rank[it]] = key[it];
     }
+    ELBA_SSTAMP(5);
 #ifdef ELBA_SCATTER_MEM_DIRECT
     if (!ENUM) {
         // a word that still holds its digit finds its run by it: delta[digit] = the run's place in the output - its place in the tile; the places of
@@ -460,6 +495,7 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         }
     }
     __syncthreads();
+    ELBA_SSTAMP(6);
     auto writeout = [&]() {
 #ifdef ELBA_SCATTER_UNROLL
 #pragma unroll
@@ -493,17 +529,21 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         const uint32_t nxt = tile + gridDim.x;
         const bool has = nxt < ntiles;
         if (!PIPE) writeout();
-        else if (ENUM && ELBA_SCATTER_ENUM_MODE == 2 && (w & 1)) { writeout(); if (has) fetch(nxt, ncount); }
-        else { if (has) fetch(nxt, ncount); writeout(); }
+        else if (ENUM && ELBA_SCATTER_ENUM_MODE == 2 && (w & 1)) { writeout(); ELBA_SSTAMP(7); if (has) fetch(nxt, ncount); ELBA_SSTAMP(8); }
+        else { if (has) fetch(nxt, ncount); ELBA_SSTAMP(8); writeout(); ELBA_SSTAMP(7); }
     }
 #else
     writeout();
 #endif
     lds_sync_fwd();      // (the tile's LDS is reused by the workgroup's next tile; its global stores stay in flight)
+    ELBA_SSTAMP(9);
 #ifndef ELBA_SCATTER_NO_PIPE
     if (PIPE) count = ncount;
 #endif
     }
+#ifdef ELBA_SCATTER_CLOCK
+    if (lane == 0 && w < 2) for (int q = 0; q < 12; ++q) atomicAdd(&g_sc_phase[ENUM ? 1 : 0][w][q], sph[q]);
+#endif
 }
 
 // LDS-only workgroup barrier: the global stores of a bucket (never read back by the workgroup) stay in flight
@@ -1836,12 +1876,13 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
 
     c.ws_a.reserve((size_t)(Ibuf + 2) * (wide ? 16 : 8)); c.ws_c.reserve((size_t)(Ibuf + 2) * (wide ? 16 : 8));
     c.ws_sort.reserve(((size_t)ntiles2 << (wide ? W2_MAXBITS : MT_MAXBITS)) * 4 + 4096);
-    c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 6 + (size_t)(2 * nb1 + 8) * 4 + 256 + 64);
+    c.ws_e.reserve((size_t)(nbuckets + 2) * 4 * 6 + (size_t)(2 * nb1 + 8) * 4 + 256 + 64 + (size_t)(ntiles2 + 4) * 8);
     uint32_t *hist = c.ws_sort.as<uint32_t>();
     BucketStats *gstat = c.ws_e.as<BucketStats>();
     uint32_t *b2start = c.ws_e.as<uint32_t>() + 16, *bN = b2start + (nbuckets + 2), *bZ = bN + (nbuckets + 2), *kidbase = bZ + (nbuckets + 2), *entbase = kidbase + (nbuckets + 2);
     uint32_t *crowded = entbase + (nbuckets + 2), *b1start = crowded + (nbuckets + 2), *tile0 = b1start + (nb1 + 2);
     uint32_t *one_seg = tile0 + (nb1 + 2);      // (triples: the whole input as ONE segment of tiles, for the first digit's pass)
+    uint2 *tinfo = reinterpret_cast<uint2 *>(c.ws_e.as<char>() + (((size_t)((char *)(one_seg + 16) - c.ws_e.as<char>()) + 15) & ~(size_t)15));      // (k <= 17: the second pass's tiles)
     uint64_t *wa = c.ws_a.as<uint64_t>(), *wb = c.ws_c.as<uint64_t>();
 
     c.t_total.start(s);
@@ -1922,9 +1963,27 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         if (batched) hipLaunchKernelGGL((k_msd_scatter<true, true>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa, ntiles1, dlo, dhi);
         else hipLaunchKernelGGL((k_msd_scatter<true, false>), dim3(std::min<uint32_t>(ntiles1, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)nullptr, sg, 0, m.b1, (const uint32_t *)hist, wa, ntiles1, dlo, dhi);
         // second digit, inside every first-digit bucket
-        hipLaunchKernelGGL(k_msd_hist2, dim3(nt2), dim3(MT_THREADS), 0, s, (const uint64_t *)wa, sg, shift2, m.b2, hist);
+        SegTiles sgi = sg; sgi.tinfo = tinfo;
+        hipLaunchKernelGGL(k_msd_tile_info, dim3((nt2 + 255u) / 256u), dim3(256), 0, s, sg, tinfo);
+        hipLaunchKernelGGL(k_msd_hist2, dim3(nt2), dim3(MT_THREADS), 0, s, (const uint64_t *)wa, sgi, shift2, m.b2, hist);
         hipLaunchKernelGGL(k_msd_segscan, dim3(nb1), dim3(MT_MAXBINS), 0, s, hist, sg, nb2, b2start, Iv);
-        hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(nt2, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sg, shift2, m.b2, (const uint32_t *)hist, wb, nt2, 0u, nb1);
+        hipLaunchKernelGGL((k_msd_scatter<false>), dim3(std::min<uint32_t>(nt2, sgrid)), dim3(MT_THREADS), 0, s, e, bi, m, (const uint64_t *)wa, sgi, shift2, m.b2, (const uint32_t *)hist, wb, nt2, 0u, nb1);
+#ifdef ELBA_SCATTER_CLOCK
+        {
+            ELBA_HIP(hipStreamSynchronize(s));
+            unsigned long long h[2][2][12];
+            ELBA_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sc_phase), sizeof(h)));
+            static const char *nm[12] = {"top", "zero+bar", "rank", "bar", "scan+bar", "place", "bitmap+delta", "writeout", "fetch next", "end bar", "", ""};
+            for (int en = 1; en >= 0; --en) for (int wv = 0; wv < 2; ++wv) {
+                unsigned long long tot = 0; for (int q = 0; q < 12; ++q) tot += h[en][wv][q];
+                fprintf(stderr, "k_msd_scatter<%s> wavefront %d:", en ? "ENUM" : "MEM", wv);
+                for (int q = 0; q < 10; ++q) fprintf(stderr, " %s %.1f%%", nm[q], tot ? 100.0 * (double)h[en][wv][q] / (double)tot : 0.0);
+                fprintf(stderr, "  (total %.0f cycles of the 100 MHz clock per workgroup)\n", (double)tot / 256.0);
+            }
+            unsigned long long z[2][2][12] = {};
+            ELBA_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_sc_phase), z, sizeof(z)));
+        }
+#endif
         if (timed) { c.t_a.stop(s); c.t_b.start(s); }
         // buckets: count
         ELBA_HIP(hipMemsetAsync(gstat, 0, sizeof(BucketStats), s));
