@@ -14,4 +14,4 @@ bash profiles/run_profiles.sh $TAG all > gpurun_out/${TAG}_top.txt 2>&1
 BENCH_ARGS="--workload dense-repeats-8th" bash profiles/run_profiles.sh ${TAG}_dense8th kt > gpurun_out/${TAG}_dense8th_top.txt 2>&1
 BENCH_ARGS="--workload hifi-k31" bash profiles/run_profiles.sh ${TAG}_k31 kt > gpurun_out/${TAG}_k31_top.txt 2>&1
 BENCH_ARGS="--workload dense-repeats-25th" bash profiles/run_profiles.sh ${TAG}_dense25th kt > gpurun_out/${TAG}_dense25th_top.txt 2>&1
-bash profiles/tools/final_lines.sh
+bash profiles/tools/final_lines.sh $TAG
