@@ -337,6 +337,21 @@ def main():
     #     Their cost = this k-mer stage minus the same stage built without them ("no_ell", "no_hints"), on a context of its own.
     # (b) what a replacement of create_seed_matrix(A, AT) alone pays (option B): A arrives as device-resident triples,
     #     elba_set_kmer_matrix_device rebuilds CSR + columns + hints, then ONE cold call.
+    # what the HBM-table tier costs when every row is FORCED onto it: two cold calls with "tune7" = 6 (k_classify_direct queues every row on the
+    # spill tier: tables in HBM instead of LDS), the second one timed; same B by count
+    hbm_forced = None
+    if single and rank == 0 and not args.no_accounting:
+        eng.set_option("tune7", 6); eng.set_option("overlap_cold_calls", 1)
+        try:
+            eng.create_seed_matrix(); torch.cuda.synchronize()
+            t0 = time.perf_counter(); sf = eng.create_seed_matrix(); torch.cuda.synchronize(); tf = time.perf_counter() - t0
+            hbm_forced = {"ms_cold_call": round(tf * 1e3, 3), "rows_global": int(sf.get("rows_global", -1)), "rows_lds": int(sf.get("rows_lds", -1)),
+                          "same_nnz_and_products": bool(sf["nnz"] == st_cold["nnz"] and sf["products"] == st_cold["products"]),
+                          "vs_lds_tiers": round(tf * 1e3 / max(1e-9, ms_step), 2), "what": "option tune7 = 6: every row starts on the HBM-table tier (the sample's rows excepted)"}
+        except elba_amd.capi.ElbaError as ex:
+            hbm_forced = {"failed": str(ex)}
+        eng.set_option("tune7", 0); eng.set_option("overlap_cold_calls", 0)
+        eng.create_seed_matrix(); torch.cuda.synchronize()      # (the context holds the LDS-tier result again: exports and the CPU comparison below read it)
     prep = None
     from_triples = None
     if single and rank == 0 and not args.no_accounting and args.workload.startswith("dense-repeats-8"):
@@ -547,6 +562,7 @@ def main():
             "rank_phases_ms": rank_phases,
             "phases_ms": {key: round(v, 4) for key, v in acc.items()},
             "mirror": mirror,
+            "hbm_tier_forced": hbm_forced,
             "tiers": {key: int(st_cold[key]) for key in ("rows_lds", "rows_global", "rows_escalated", "nnz_before_prune", "passes") if key in st_cold},
             "aux_stages": aux,
             "gen_s": round(t_gen, 2),

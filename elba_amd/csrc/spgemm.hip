@@ -839,9 +839,12 @@ static void ov_launch_finalize(Ctx &c, uint32_t half, bool all_sorts, uint32_t &
         if (f.rec16 && f.mir16) hipLaunchKernelGGL(k_finalize_mid16, dim3(nb), dim3(256), 0, s, f);
         else hipLaunchKernelGGL(k_finalize_mid, dim3(nb), dim3(256), 0, s, f);
         skipped_sorts = 0;
-        if (all_sorts || c.ov_sort_used[0]) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
+        bool narrow = false;
+        // (a row of B holds at most min(longest row of A x longest column, reads) entries: the sorts for wider rows are not launched for a matrix that cannot have them)
+        if (c.opt.tune[4] != 2 && std::min<uint64_t>((uint64_t)std::max<int64_t>(c.max_row_nnz, 1) * (uint64_t)std::max<int64_t>(c.max_col_nnz, 1), (uint64_t)M) <= (uint64_t)FIN_WAVE2_MAX && nremote == 0) narrow = true;
+        if (!narrow && (all_sorts || c.ov_sort_used[0])) hipLaunchKernelGGL(k_finalize_bucket, dim3((unsigned)(nrows < (int64_t)cus * 4 ? nrows : (int64_t)cus * 4)), dim3(256), 0, s, f);
         else skipped_sorts |= 1u;
-        if (all_sorts || c.ov_sort_used[1]) hipLaunchKernelGGL(k_finalize_huge, dim3(gblocks), dim3(256), 0, s, f);
+        if (!narrow && (all_sorts || c.ov_sort_used[1])) hipLaunchKernelGGL(k_finalize_huge, dim3(gblocks), dim3(256), 0, s, f);
         else skipped_sorts |= 2u;
     }
 }
@@ -993,6 +996,7 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
     // ~60 us launch each — 6.48 -> 6.3x ms on config 3; small matrices keep them (their rows ARE small); option "tune4" = 1: every tier (A/B)
     p.qblk_log2 = c.opt.tune[5] > 0 ? (uint32_t)std::min<int64_t>(c.opt.tune[5] - 1, 12) : 0u;      // ("tune5" = log2 + 1.  Measured on config 5 at 1/25 — label-ordered queue, blocks of 32 / 128 / 512 places per XCD: 8.66-8.74 against 8.74-8.77 ms: nothing; single places stay)
     p.min_tier = (pay16 && nrows >= 65536 && Z / nrows >= 1024 && c.opt.tune[4] != 1) ? 2u : 0u;      // (long rows only: a 512-lane workgroup on a row of 75 entries would idle)
+    if (c.opt.tune[7] >= 1 && c.opt.tune[7] <= NUM_TIERS) p.min_tier = (uint32_t)(c.opt.tune[7] - 1);      // ("tune7" = tier + 1: every row starts there at least; 6 = the HBM-table tier for all of them — what the spill tier costs when forced, bench.py)
     p.row_cnt = c.ov_rowcnt.as<uint32_t>(); p.low_cnt = c.ov_totcnt.as<uint32_t>();
     p.row_off = c.ov_rowoff.as<unsigned long long>(); p.lists = c.ov_lists.as<uint32_t>();
     p.fin_lists = c.ov_lists.as<uint32_t>() + (size_t)NUM_TIERS * (size_t)(M + 1);
@@ -1085,7 +1089,18 @@ static void create_seed_matrix_direct(Ctx &c, int phase)
             auto X = [&](int B, bool P) { return (size_t)256 + (size_t)(B / 64) * (P ? 3072 : (pay16 ? 2048 : 2560)); };
             const bool all_tiers = !c.ov_tiers_known || phase == 2;
             skipped_tiers = 0;
-#define ELBA_DTIER(t, stmt) do { if (all_tiers || c.ov_tier_used[t]) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
+            // the highest tier ANY row of this matrix can reach: a row's distinct partners <= min(its entries x the longest column, reads), the tier that holds
+            // twice that is guaranteed to fit it and k_classify_direct never starts a row above it.  A cold call on a small matrix launched five tiers
+            // nobody could queue on (~5 us each, dependent: hifi-half 0.59 -> 0.53 ms with the finalize's counterpart).  (Still under the `missed` check below.)
+            int tmax = NUM_TIERS;
+            if (c.opt.tune[4] != 2) {
+                const uint64_t ubm = std::min<uint64_t>((uint64_t)std::max<int64_t>(c.max_row_nnz, 1) * (uint64_t)p.max_col, (uint64_t)p.Mcols);
+                const int gmax = ubm <= 1 ? 1 : 64 - __builtin_clzll(2 * ubm - 1);
+                tmax = gmax <= LDS_TBITS0 ? 0 : gmax - LDS_TBITS0;
+                tmax = std::max(tmax, (int)p.min_tier);
+                if (p.suffix) tmax = std::max(tmax, (int)p.dense_up);
+            }
+#define ELBA_DTIER(t, stmt) do { if ((all_tiers || c.ov_tier_used[t]) && (t) <= tmax) { stmt; } else skipped_tiers |= 1u << (t); } while (0)
 #define ELBA_LAUNCH_D(B, G, P, grid, lds, tier, tb, smp)                                                                                  \
     do {                                                                                                                                  \
         if (dk == 0) hipLaunchKernelGGL((k_spgemm_direct<B, G, P, 0>), dim3(grid), dim3(B), (lds), s, p, (tier), (tb), (smp));            \
