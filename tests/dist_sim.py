@@ -205,8 +205,9 @@ class NumpyBackend:
         rec = ((val - self._plo[self.own[order]]) << np.uint64(self._pib)) | g
         send.copy_(torch.from_numpy(rec.view(np.int64).copy()).reshape(-1, 1))
 
-    def unpack_records(self, W, rank, packed, recv_counts):
+    def unpack_records(self, W, rank, packed, recv_counts, out=None):
         a = packed.numpy().reshape(-1).view(np.uint64)
+        dest = out
         out = np.zeros((len(a), 2), dtype=np.uint64)
         at = 0
         for p in range(W):
@@ -218,7 +219,11 @@ class NumpyBackend:
             out[at:at + n, 0] = val << np.uint64(64 - 2 * self.k)
             out[at:at + n, 1] = ((np.uint64(self._pb[p]) + r.astype(np.uint64)) << np.uint64(32)) | (g - self._poff[p][r])
             at += n
-        return torch.from_numpy(out.view(np.int64).copy())
+        res = torch.from_numpy(out.view(np.int64).copy())
+        if dest is not None:
+            dest.copy_(res)
+            return dest
+        return res
 
     def count_records(self, rec):
         a = rec.numpy().view(np.uint64)

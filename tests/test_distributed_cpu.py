@@ -43,8 +43,10 @@ def _run_rank(rank, world, dist, backend, align=False):
     lo, hi = int(bounds[rank]), int(bounds[rank + 1])
     sp, so, sl = _shard(packed, off, lens, lo, hi)
     d = DistributedOverlap(K, LO, UP, rank=rank, world=world, dist=dist, backend=backend)
+    d.exchange_chunks = 2            # (exchange #1 in two rounds: under torch.distributed the second one is posted with async_op before the first is unpacked)
     d.set_reads(sp, so, sl, lo, bounds)
     ks, ms = d.build_kmer_matrix()
+    assert d.exchange_rounds >= 2    # (more where a test lowers MAX_RECORDS_PER_PEER)
     st = d.create_seed_matrix()
     if align:
         d.align_seeds()
@@ -261,22 +263,27 @@ def test_exchange_one_in_8_byte_records_equals_the_16_byte_exchange(world):
     participants) as with two and three."""
     o = _expected()
 
-    def run(r, h, packed):
+    def run(r, h, packed, chunks=1):
         rp, ro, rl, _ = _reads()
         bounds = partition_by_bases(rl, world)
         lo, hi = int(bounds[r]), int(bounds[r + 1])
         sp, so, sl = _shard(rp, ro, rl, lo, hi)
         d = DistributedOverlap(K, LO, UP, rank=r, world=world, dist=h, backend=dist_sim.NumpyBackend(K, LO, UP))
         d.packed_exchange = packed
+        d.exchange_chunks = chunks
         d.set_reads(sp, so, sl, lo, bounds)
         ks, ms = d.build_kmer_matrix()
         d.create_seed_matrix()
+        assert d.exchange_rounds == (chunks if packed else 1)
         return d.export_csr(), ks, dict(d.exchange_bytes)
 
     a = dist_sim.run_ranks(world, lambda r, h: run(r, h, True))
     b = dist_sim.run_ranks(world, lambda r, h: run(r, h, False))
-    Ba, Bb, oB = dist_sim.stitch_rows([p[0] for p in a]), dist_sim.stitch_rows([p[0] for p in b]), o.B()
-    for B in (Ba, Bb):
+    c = dist_sim.run_ranks(world, lambda r, h: run(r, h, True, chunks=3))      # the packed exchange in three rounds, each unpacked while the next one travels
+    Ba, Bb, Bc, oB = dist_sim.stitch_rows([p[0] for p in a]), dist_sim.stitch_rows([p[0] for p in b]), dist_sim.stitch_rows([p[0] for p in c]), o.B()
+    for pa, pc in zip(a, c):
+        assert all(pa[1][f] == pc[1][f] for f in ("reliable", "entries", "instances", "distinct")) and pa[2] == pc[2]
+    for B in (Ba, Bb, Bc):
         assert B["Y"] == oB["Y"] and (B["rowptr"] == oB["rowptr"]).all() and (B["col"] == oB["col"].astype(np.int64)).all() and (B["val"] == oB["val"]).all()
     for pa, pb in zip(a, b):
         assert all(pa[1][f] == pb[1][f] for f in ("reliable", "entries", "instances", "distinct"))

@@ -326,8 +326,10 @@ def test_distributed_driver_over_rccl_world_of_one():
         reads = elba_amd.synth_reads(33, 400000, 15, 4000, 900, error_rate=0.10, min_len=200)
         packed, off, lens, _ = reads
         d = DistributedOverlap(17, 2, 8, device=0, rank=0, world=1, dist=dist)
+        d.exchange_chunks = 3            # (exchange #1 in three rounds over RCCL itself: each round's all-to-all is posted with async_op before the round before it is unpacked)
         d.set_reads(packed, off, lens, 0, np.array([0, len(lens)], dtype=np.int64))
         ks, ms = d.build_kmer_matrix()
+        assert d.exchange_rounds == 3 and d.exchange_format.startswith("8-byte")
         st = d.create_seed_matrix()
         B = d.export_csr()
         o = po.Oracle(17, 2, 8); o.count_and_build(packed, off, lens); o.spgemm(4)

@@ -329,8 +329,10 @@ def test_eight_ranks_with_8_byte_exchange_records_equal_the_one_gpu_matrix():
         sp, so, sl = _shard(packed, off, lens, a, b)
         d = DistributedOverlap(17, 2, 8, device=0, rank=rank, world=world, dist=h, backend=HipBackend(17, 2, 8, 0))
         d.packed_exchange = packed_records
+        d.exchange_chunks = 3            # (the packed exchange in three rounds, each unpacked into its place in the record buffer while the next one travels)
         d.set_reads(sp, so, sl, a, bounds)
         ks, ms = d.build_kmer_matrix()
+        assert d.exchange_rounds == (3 if packed_records else 1)
         s2 = d.create_seed_matrix()
         out = (d.export_csr(), s2, ks, dict(d.exchange_bytes))
         d.be.e.close()
