@@ -34,7 +34,7 @@ def body(rank, h):
     t0 = time.perf_counter(); ks2, ms2 = d.build_kmer_matrix(); t_build = time.perf_counter() - t0
     t0 = time.perf_counter(); s2 = d.create_seed_matrix(); t_step = time.perf_counter() - t0
     out = dict(instances=int(ks2["instances"]), entries=int(ks2["entries"]), products=int(s2["products"]), nnz=int(s2["nnz"]), exchange=dict(d.exchange_bytes),
-               panel_records=int(d.panel_records), build_s=round(t_build, 3), step_s=round(t_step, 3))
+               panel_records=int(d.panel_records), build_s=round(t_build, 3), step_s=round(t_step, 3), exchange_rounds=int(d.exchange_rounds))
     d.be.e.close()
     return out
 
