@@ -744,7 +744,10 @@ __global__ __launch_bounds__(BK_THREADS) void k_msd_count(const uint64_t *words,
 // dense as the average, and the fullest buckets of a large input, or most buckets of deep low-error coverage, land here —: 99 KB, one workgroup of
 // sixteen wavefronts).  History of the widest class on BASELINE config 5 at one GPU's share (average bucket 4400 entries): 256 lanes x 32 entries
 // (256 VGPRs, four wavefronts per CU) 85 ms; 512 x 16 44 ms; with ranges by column rank 20 ms; 1024 x 8 13 ms.
-template <int ES_KPT, int ES_THREADS = 256>
+// SPEC: the instantiation for what the reads path of k <= 17 always builds — no column ranks, distinct words, gather slots, hints, inline partners, one-word CSR sort
+// keys, k-mers from the bucket number — with those switches compiled in: the general kernel keeps ~75 kernel-argument scalars alive and spilled them to vector lanes
+// (472 v_readlane of 4000 vector instructions per bucket and lane: the emit kernels are bound by instruction issue, profiles/r05_notes.md)
+template <int ES_KPT, int ES_THREADS = 256, bool SPEC = false>
 #ifndef ELBA_ES_OCC256
 #define ELBA_ES_OCC256 5      // (92 VGPRs instead of 100: five workgroups per CU instead of four)
 #endif
@@ -770,6 +773,15 @@ __global__ __launch_bounds__(ES_THREADS, (ES_THREADS == 256 ? ELBA_ES_OCC256 : (
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint64_t lt = (1ull << lane) - 1;
     const uint64_t paymask = (1ull << m.PB) - 1, posmask = (1ull << m.pbits) - 1;
+    const int m_rk = SPEC ? 0 : m.rk;
+    const bool m_dup = SPEC ? false : m.dup != 0u;
+    const bool o_hints = SPEC ? true : o.hints != 0u, o_compact = SPEC ? true : o.compact != 0u;
+    uint64_t *const o_pair_val = SPEC ? nullptr : o.pair_val;
+    uint64_t *const o_csr_words = o.csr_words;
+    const bool has_words = SPEC ? true : o.csr_words != nullptr;
+    const uint64_t *const o_kmer_src = SPEC ? nullptr : o.kmer_src, *const o_kmer_dist = SPEC ? nullptr : o.kmer_dist;
+    const uint32_t *const o_ncols = SPEC ? nullptr : o.ncols;
+    const bool has_relk = SPEC ? true : o.rel_kmers != nullptr;
 #ifdef ELBA_X_EMIT
     const bool xst = o.nb == 12345;      // timing experiment (wrong results): nothing leaves the kernel
 #else
@@ -789,8 +801,8 @@ __global__ __launch_bounds__(ES_THREADS, (ES_THREADS == 256 ? ELBA_ES_OCC256 : (
         uint32_t sh = 16 - NSB_BITS;
         while (sh < 16 && (Z >> (16 - sh)) < 4u) ++sh;
         int rs_s = 0, rs_t = 0;
-        if (m.rk) {
-            const uint32_t ncol = o.ncols ? o.ncols[b] : kidbase[b + 1] - kidbase[b];
+        if (m_rk) {
+            const uint32_t ncol = o_ncols ? o_ncols[b] : kidbase[b + 1] - kidbase[b];
             int cb = 0;
             while (cb < 16 && (ncol >> cb)) ++cb;                     // bits of a column rank
             int want = 2;
@@ -799,9 +811,9 @@ __global__ __launch_bounds__(ES_THREADS, (ES_THREADS == 256 ? ELBA_ES_OCC256 : (
             else { rs_s = want - cb; const int mbits = m.PB - m.pbits; if (rs_s > mbits) rs_s = mbits; }
         }
         auto range_of = [&](uint64_t x) -> uint32_t {
-            return m.rk ? (uint32_t)(((((x >> m.rk) & m.rkmask) << rs_s) | ((x & paymask) >> (m.PB - rs_s))) >> rs_t) : ((uint32_t)(x >> m.PB) & 0xFFFFu) >> sh;
+            return m_rk ? (uint32_t)(((((x >> m_rk) & m.rkmask) << rs_s) | ((x & paymask) >> (m.PB - rs_s))) >> rs_t) : ((uint32_t)(x >> m.PB) & 0xFFFFu) >> sh;
         };
-        auto col_of = [&](uint64_t x) -> uint32_t { return m.rk ? (uint32_t)(x >> m.rk) & m.rkmask : (uint32_t)(x >> m.PB) & 0xFFFFu; };
+        auto col_of = [&](uint64_t x) -> uint32_t { return m_rk ? (uint32_t)(x >> m_rk) & m.rkmask : (uint32_t)(x >> m.PB) & 0xFFFFu; };
 #pragma unroll
         for (int q = 0; q < PER; ++q) sbcnt[tid + (uint32_t)q * ES_THREADS] = 0;
         lds_sync();
@@ -841,7 +853,7 @@ __global__ __launch_bounds__(ES_THREADS, (ES_THREADS == 256 ? ELBA_ES_OCC256 : (
                 uint64_t kk[8];
 #pragma unroll
                 for (int q = 0; q < 8; ++q) kk[q] = A[lo + (uint32_t)q < hi ? lo + (uint32_t)q : lo];
-                if (m.dup) {      // (equal words — an entry handed over twice — keep the order of their places in the range: every word gets a place of its own)
+                if (m_dup) {      // (equal words — an entry handed over twice — keep the order of their places in the range: every word gets a place of its own)
                     const uint32_t mine = lo + slot[u];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) rank += (lo + (uint32_t)q < hi && (kk[q] < key[u] || (kk[q] == key[u] && lo + (uint32_t)q < mine))) ? 1u : 0u;
@@ -902,7 +914,7 @@ __global__ __launch_bounds__(ES_THREADS, (ES_THREADS == 256 ? ELBA_ES_OCC256 : (
                 const uint64_t read = (x & paymask) >> m.pbits, pos = x & posmask;
                 uint64_t hint = 0, oread = 0, opos = 0;
                 uint32_t nown = 0, mult = 0;
-                if (o.hints && L <= HINT_MAX_COL) {
+                if (o_hints && L <= HINT_MAX_COL) {
                     // Ctx::csr_hints: an entry whose row accumulates no pair of this column under the parity rule (and occurs in it once) is marked;
                     // the entries of the column this row does accumulate a pair with are counted, the last of them remembered
                     const uint32_t i = (uint32_t)read;
@@ -927,21 +939,21 @@ __global__ __launch_bounds__(ES_THREADS, (ES_THREADS == 256 ? ELBA_ES_OCC256 : (
                 // pair in its own entry — the SpGEMM then fetches no column for it
                 const bool isinl = o.inl && mult == 1u && nown == 1u && ((pos | opos) >> o.inl) == 0;
                 if (isinl) word = (1ull << 63) | (read << o.rs) | ((oread >> 1) << (2 * o.inl)) | (pos << o.inl) | opos;
-                if (!xst) {} else if (o.pair_val) { o.pair_key[z] = (uint32_t)read; o.pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)L << 23) | ((uint64_t)(p - h0) << 16) | pos; }
-                else if (o.compact && !isinl && hint == 0) {      // this entry fetches its column: the column needs a gather slot, the key names it (below)
+                if (!xst) {} else if (o_pair_val) { o.pair_key[z] = (uint32_t)read; o_pair_val[z] = ((uint64_t)kid << 32) | ((uint64_t)L << 23) | ((uint64_t)(p - h0) << 16) | pos; }
+                else if (o_compact && !isinl && hint == 0) {      // this entry fetches its column: the column needs a gather slot, the key names it (below)
                     needmask |= 1u << u;
                     atomicOr(&H[kl], HNEED);
                 }
-                else if (o.csr_words) o.csr_words[z] = word;
+                else if (has_words) o_csr_words[z] = word;
                 else o.kid_of_entry[z] = kid;
                 if (xst && ((headmask >> u) & 1u)) {
                     const uint64_t value = ((uint64_t)b << VBITS) | ((uint32_t)(x >> m.PB) & 0xFFFFu);
-                    if (o.rel_kmers) o.rel_kmers[kid] = o.kmer_dist ? o.kmer_dist[o.dist_base[b] + ((uint32_t)(x >> m.PB) & 0xFFFFu)] : (o.kmer_src ? o.kmer_src[s0 + kl] : value << (64 - m.k2));
+                    if (has_relk) o.rel_kmers[kid] = o_kmer_dist ? o_kmer_dist[o.dist_base[b] + ((uint32_t)(x >> m.PB) & 0xFFFFu)] : (o_kmer_src ? o_kmer_src[s0 + kl] : value << (64 - m.k2));
                     o.rel_counts[kid] = L; o.colptr[kid] = z;
                 }
             }
         }
-        if (o.compact) {
+        if (o_compact) {
             lds_sync();                                                  // every entry has flagged its column
 #pragma unroll
             for (int u = 0; u < ES_KPT; ++u)
@@ -972,7 +984,7 @@ __global__ __launch_bounds__(ES_THREADS, (ES_THREADS == 256 ? ELBA_ES_OCC256 : (
                     const uint32_t p = (uint32_t)u * ES_THREADS + tid;
                     const uint64_t x = A[p];
                     const uint64_t sid = (uint64_t)gb + ((H[slot[u]] >> 14) & 0x1FFFu);
-                    if (xst) o.csr_words[eb + p] = (((x & paymask) >> m.pbits) << o.rs) | (sid << (o.pb + 2)) | (x & posmask);
+                    if (xst) o_csr_words[eb + p] = (((x & paymask) >> m.pbits) << o.rs) | (sid << (o.pb + 2)) | (x & posmask);
                 }
             const uint32_t S = o.ell_stride, nq = ng * S, sl = (S & (S - 1u)) ? 0u : (uint32_t)__ffs((int)S) - 1u;
             uint64_t *dst = o.ell + (uint64_t)gb * S;
@@ -2199,9 +2211,16 @@ static bool msd_run(Ctx &c, uint64_t I, elba_kmer_stats *stp, MsdTriples *tri)
         // (buckets of up to 2048 entries — more than half of them on BASELINE config 3, where a bucket holds 2040 on average — through an instantiation
         //  with 8 entries per lane: half the predicated-off work of the 16-entry one, 26 KB of LDS instead of 49: six workgroups per CU)
         // (512 lanes x 4 for them was measured too: 17.6 against 17.5 ms on config 3, 48.4 against 47.6 ms on the k = 31 workload)
+        const bool spec = m.rk == 0 && m.dup == 0u && o.compact && o.hints && o.csr_words && !o.pair_val && !o.kmer_src && !o.kmer_dist && !o.ncols && o.rel_kmers && c.opt.tune[6] != 3;      // ("tune6" = 3: the general instantiation — A/B)
+        if (cap8 && spec) hipLaunchKernelGGL((k_msd_emit_small<8, 256, true>), dim3(grid8), dim3(256), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap8,
+                                     (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+        else
         if (cap8) hipLaunchKernelGGL((k_msd_emit_small<8>), dim3(grid8), dim3(256), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, 0u, cap8,
                                      (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         // 2049..4096 entries: 512 lanes x 8 (three workgroups of eight wavefronts per CU, not of four: 19.0 -> 17.5 ms for the bucket kernels on config 3)
+        if (cap16 > cap8 && spec) hipLaunchKernelGGL((k_msd_emit_small<8, 512, true>), dim3(grid16), dim3(512), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
+                           (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
+        else
         if (cap16 > cap8) hipLaunchKernelGGL((k_msd_emit_small<8, 512>), dim3(grid16), dim3(512), 0, s, wrel, (const uint32_t *)b2start, (const uint32_t *)bZ, nbuckets, m, cap8, cap16,
                            (const uint32_t *)kidbase, (const uint32_t *)entbase, o);
         if (small_cap > 4096u && hs.nmid)
