@@ -517,6 +517,15 @@ __global__ __launch_bounds__(MT_THREADS) void k_msd_scatter(EnumParams e, const 
         if (delta[run] == 0xFFFFFFFEu) out[t] = lkey[t];
     }
 #else
+    // (a place's run costs two dependent LDS round trips — bitmap word, then the run's delta — in a loop with a run-time trip count: two places per trip keep two chains in
+    //  flight: ENUM 10.25 -> 9.87 ms; MEM 8.54 -> 8.76: its trips stay single; four: no better)
+    if (ENUM) {
+#pragma unroll 2
+        for (uint32_t t = threadIdx.x; t < count; t += MT_THREADS) {
+            const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & lane_le) - 1u;
+            out[delta[run] + t] = lkey[t];
+        }
+    } else
     for (uint32_t t = threadIdx.x; t < count; t += MT_THREADS) {
         const uint32_t run = hpre[t >> 6] + (uint32_t)__popcll(hbits[t >> 6] & lane_le) - 1u;
         out[delta[run] + t] = lkey[t];

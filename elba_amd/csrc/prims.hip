@@ -340,6 +340,7 @@ __global__ __launch_bounds__(THREADS, (THREADS == 512 ? 4 : 0)) void k_rs_scatte
     __syncthreads();
     const int64_t left = n - tbase;
     const uint32_t nvalid = left < (int64_t)TILE ? (uint32_t)left : (uint32_t)TILE;
+#pragma unroll 2      // (two places per trip: their LDS chains — key, then the digit's two offsets — overlap: a plain pass of the CSR sort 3.04 -> 2.92 ms)
     for (uint32_t t = threadIdx.x; t < nvalid; t += THREADS) {
         const K k = lkey[t];
         const uint32_t d = (uint32_t)(k >> shift) & dmask;
